@@ -1,0 +1,243 @@
+/*
+ * arroy_hip.h — C ABI of libarroy_hip.so: the MI355X (gfx950) implementation of arroy's
+ * distance-kernel hot path.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * arroy (Rust, /root/reference) has no FFI of its own: the boundary of the hot path is
+ * the crate-internal `Distance` trait (src/distance/mod.rs:40-124) driven by three
+ * batched loops.  Per-pair FFI is useless for a GPU, so every entry point below replaces
+ * one *loop* (or one storage-to-memory staging step) of the reference; the citation after
+ * each declaration names the reference code it stands in for.  INTEGRATION.md shows the
+ * `extern "C"` block and the call-site patches a maintainer would add to arroy.
+ *
+ * Conventions
+ *   - every function returns an `ah_status` (0 = ok); no C++ exception crosses the ABI
+ *     (the reference catches worker panics at src/writer.rs:799-827);
+ *   - `ah_last_error()` returns the thread's last error text (-> Error::Panic(String),
+ *     src/error.rs:84-85);
+ *   - the library never keeps a host pointer past the call that received it (LMDB pages
+ *     move after writes, src/writer.rs:512-513); output buffers are caller-allocated;
+ *   - a finalized dataset is immutable and may be used by any number of host threads
+ *     concurrently (Reader is Sync); `ah_build_forest` is single-caller per dataset;
+ *   - results never depend on thread / stream / workgroup scheduling.
+ *
+ * Numerics contract: every f32 result is bit-identical to arroy's x86-64 AVX+FMA tier
+ * (src/spaces/simple_avx.rs) for dims >= 32, its SSE tier for 16 <= dims < 32
+ * (src/spaces/simple_sse.rs) and its scalar tier below (src/spaces/simple.rs:49-51,81-83).
+ */
+#ifndef ARROY_HIP_H
+#define ARROY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AH_ABI_VERSION 1
+
+/* arroy::distances (src/lib.rs:145-150).  The value is also the tag used in files/tests. */
+typedef enum ah_metric {
+    AH_EUCLIDEAN = 0,              /* src/distance/euclidean.rs                 header {bias:f32}           */
+    AH_MANHATTAN = 1,              /* src/distance/manhattan.rs                 header {bias:f32}           */
+    AH_COSINE = 2,                 /* src/distance/cosine.rs                    header {norm:f32}           */
+    AH_DOT_PRODUCT = 3,            /* src/distance/dot_product.rs               header {extra_dim,norm:f32} */
+    AH_BQ_EUCLIDEAN = 4,           /* src/distance/binary_quantized_euclidean.rs header {bias:f32}          */
+    AH_BQ_MANHATTAN = 5,           /* src/distance/binary_quantized_manhattan.rs header {bias:f32}          */
+    AH_BQ_COSINE = 6               /* src/distance/binary_quantized_cosine.rs    header {norm:f32}          */
+} ah_metric;
+
+/* Mapping onto arroy::Error (src/error.rs:6-85). */
+typedef enum ah_status {
+    AH_OK = 0,
+    AH_ERR_INVALID_DIMENSION = 1,  /* Error::InvalidVecDimension  (error.rs:17-23)              */
+    AH_ERR_CANCELLED = 2,          /* Error::BuildCancelled       (error.rs:54-55)              */
+    AH_ERR_DEVICE = 3,             /* HIP runtime failure      -> Error::Panic(ah_last_error()) */
+    AH_ERR_OUT_OF_MEMORY = 4,      /* host or HBM allocation   -> Error::Panic                  */
+    AH_ERR_INVALID_ARGUMENT = 5,   /* contract violation       -> Error::Panic                  */
+    AH_ERR_MISSING_ITEM = 6,       /* Error::MissingKey           (error.rs:38-46)              */
+    AH_ERR_NOT_FINALIZED = 7,      /* dataset used before ah_dataset_finalize -> Error::Panic   */
+    AH_ERR_NEED_PREPROCESS = 8     /* DotProduct dataset searched/built before ah_preprocess_dot */
+} ah_status;
+
+typedef struct ah_dataset ah_dataset;   /* opaque: the HBM-resident image of ImmutableLeafs */
+typedef struct ah_forest ah_forest;     /* opaque: host-side result of one forest build     */
+
+/* Size in bytes of D::Header for the metric (4, or 8 for DotProduct). src/distance/<metric>.rs `Header`. */
+size_t ah_header_size(int metric);
+/* Size in bytes of one stored vector: 4*dims for f32 codecs (src/unaligned_vector/f32.rs),
+ * ceil(dims/64)*8 for the 1-bit codec (src/unaligned_vector/binary_quantized.rs:80-91). */
+size_t ah_vector_size(int metric, uint32_t dimensions);
+
+int ah_abi_version(void);
+int ah_device_count(int *out_count);
+/* Text of the calling thread's last failure ("" if none).  Never NULL. */
+const char *ah_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dataset = what `ImmutableLeafs::new` builds (src/parallel.rs:271-293): instead of a map
+ * id -> pointer into an LMDB page, the records are split into three arrays in HBM (ids,
+ * headers, 128-byte-aligned vector rows) in ascending item-id order.
+ * ---------------------------------------------------------------------------------------- */
+
+/* `capacity` = number of items that will be uploaded (exact or an upper bound). */
+int ah_dataset_create(int metric, uint32_t dimensions, uint64_t capacity, int device, ah_dataset **out);
+
+/* Stage `n` stored item records `[0u8][header][vector]` (src/node.rs:224-228,252-258) straight
+ * from LMDB pages.  record_ptrs[i] may be arbitrarily (mis)aligned; every record is
+ * `record_len` bytes (ImmutableLeafs asserts a constant length, src/parallel.rs:286).
+ * Ids must be strictly ascending within and across calls (RoaringBitmap iteration order,
+ * src/parallel.rs:283).  Records are copied into pinned staging buffers and sent with
+ * hipMemcpyAsync, double-buffered; the pointers are not used after return. */
+int ah_dataset_upload_records(ah_dataset *ds, const uint32_t *item_ids, const uint8_t *const *record_ptrs,
+                              size_t record_len, size_t n);
+
+/* `Writer::add_item` for a batch (src/writer.rs:380-394): f32 vectors, row-major n x dims; the
+ * library applies the codec (`UnalignedVector::from_slice`) and `D::new_header` on device. */
+int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, const float *vectors, size_t n);
+
+/* Benchmark harness only: materialise `n_items` synthetic items (ids 0..n-1) directly in HBM with
+ * the generator of arroy_hip_policy.h, then codec + new_header as in ah_dataset_upload_vectors. */
+int ah_dataset_fill_synthetic(ah_dataset *ds, uint64_t seed, int distribution, uint64_t n_items);
+
+/* Freeze the dataset (build the id -> row index).  Required before any query/build call. */
+int ah_dataset_finalize(ah_dataset *ds);
+int ah_dataset_len(const ah_dataset *ds, uint64_t *out_n_items);
+/* `Reader::item_vector` (src/reader.rs:266-276): decoded f32 vector (dims floats; +-1.0 for BQ). */
+int ah_dataset_item_vector(ah_dataset *ds, uint32_t item_id, float *out_vector);
+/* Copy stored headers of rows [first_row, first_row+n) to the host (header_size bytes each): what the
+ * host needs to rewrite LMDB after `ah_preprocess_dot`. */
+int ah_dataset_read_headers(ah_dataset *ds, uint64_t first_row, uint64_t n, void *out_headers);
+int ah_dataset_destroy(ah_dataset *ds);
+
+/* `DotProduct::preprocess` (src/distance/dot_product.rs:119-165): max norm over all items, then
+ * header.norm = max^2, header.extra_dim = sqrt(max^2 - |v|^2) for every item, on device. */
+int ah_preprocess_dot(ah_dataset *ds, float *out_max_norm);
+
+/* ------------------------------------------------------------------------------------------
+ * Search side (src/reader.rs:376-400, 607-640)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Raw batched `D::built_distance(query, item)` (non-normalized), `QueryBuilder::by_vector`
+ * semantics for the query (src/reader.rs:64-75: codec + `D::new_header`).  `item_ids == NULL`
+ * scans rows 0..n-1 of the dataset in id order; otherwise one distance per listed id. */
+int ah_distances_by_vector(ah_dataset *ds, const float *query, const uint32_t *item_ids, size_t n, float *out);
+/* Same with the query taken from a stored item (`by_item`, src/reader.rs:46-51). */
+int ah_distances_by_item(ah_dataset *ds, uint32_t query_item, const uint32_t *item_ids, size_t n, float *out);
+
+/* The re-rank loop + `median_based_top_k` + `D::normalized_distance` (src/reader.rs:381-399):
+ * `sorted_ids` ascending and unique (src/reader.rs:378-379) or NULL for "all items".  Writes
+ * min(k, n) pairs ordered by (OrderedFloat(distance), id) ascending. */
+int ah_rerank_by_vector(ah_dataset *ds, const float *query, const uint32_t *sorted_ids, size_t n, size_t k,
+                        uint32_t *out_ids, float *out_distances, size_t *out_n);
+int ah_rerank_by_item(ah_dataset *ds, uint32_t query_item, const uint32_t *sorted_ids, size_t n, size_t k,
+                      uint32_t *out_ids, float *out_distances, size_t *out_n);
+/* Many queries in one submission (candidate lists concatenated; list q is
+ * ids[offsets[q] .. offsets[q+1])).  Outputs are n_queries x k, short lists padded with id
+ * 0xFFFFFFFF / distance NaN; out_counts[q] = min(k, len_q). */
+int ah_rerank_batch(ah_dataset *ds, const float *queries, size_t n_queries, const uint32_t *ids,
+                    const uint64_t *offsets, size_t k, uint32_t *out_ids, float *out_distances,
+                    uint32_t *out_counts);
+
+/* ------------------------------------------------------------------------------------------
+ * Build side (src/writer.rs:1193-1233, 1398-1531; src/distance/mod.rs:126-223)
+ * ---------------------------------------------------------------------------------------- */
+
+#define AH_SPLIT_SAMPLES 12   /* choose_two + 10 x choose (src/distance/mod.rs:139,149-152) */
+
+/* The margin loop (src/writer.rs:1201-1207,1424-1431,1494-1501): `D::side(normal, item)` for every
+ * listed item.  `normal_vector` is in the metric's codec (ah_vector_size bytes), `normal_header`
+ * is D::Header.  Bit i (LSB first) of side_bits = 1 when item i goes Right
+ * (`margin.is_sign_positive()`, src/distance/mod.rs:103-110); (n+7)/8 bytes. Optionally also
+ * returns the margins themselves (out_margins may be NULL). */
+int ah_split_sides(ah_dataset *ds, const void *normal_vector, const void *normal_header,
+                   const uint32_t *sorted_ids, size_t n, uint8_t *side_bits, uint64_t *out_n_left,
+                   float *out_margins);
+
+/* `D::create_split` (src/distance/{euclidean.rs:55-77,cosine.rs:73-85,dot_product.rs:98-113,...}) with the
+ * randomness supplied by the host: sample_ids[0..1] = choose_two, [2..11] = the ten `choose` draws
+ * (the RNG policy stays in the caller, as with `R: Rng`). */
+int ah_create_split(ah_dataset *ds, const uint32_t sample_ids[AH_SPLIT_SAMPLES], void *out_normal_vector,
+                    void *out_normal_header);
+
+typedef void (*ah_progress_fn)(void *user, uint32_t level, uint64_t nodes_done, uint64_t items_routed);
+
+typedef struct ah_build_options {
+    uint32_t n_trees;              /* trees built by THIS call (the caller shards trees over GPUs)   */
+    uint32_t split_after;          /* 0 = dimensions (src/writer.rs:474-477)                         */
+    const uint64_t *tree_seeds;    /* n_trees seeds (src/writer.rs:575: one RNG per root task)       */
+    const volatile int *cancel;    /* polled between kernel batches; non-zero -> AH_ERR_CANCELLED     */
+    ah_progress_fn progress;       /* may be NULL (src/writer.rs:53-69 SubStep)                      */
+    void *progress_user;
+    uint32_t max_trees_in_flight;  /* 0 = as many as HBM allows                                      */
+} ah_build_options;
+
+/* Whole-forest build: `make_tree_in_file` for every tree (src/writer.rs:556-591,1167-1261) with the
+ * randomness policy of arroy_hip_policy.h.  Level-synchronous on device; nothing is visible to the
+ * caller until the whole forest exists (src/writer.rs:597-607). */
+int ah_build_forest(ah_dataset *ds, const ah_build_options *options, ah_forest **out);
+
+enum { AH_NODE_DESCENDANTS = 1, AH_NODE_SPLIT = 2 };   /* node tags, src/node.rs:216-241 */
+
+typedef struct ah_node {
+    uint8_t kind;           /* AH_NODE_DESCENDANTS | AH_NODE_SPLIT                                   */
+    uint8_t has_normal;     /* 0 = `normal: None` (random split fallback, src/writer.rs:1220-1227)   */
+    uint16_t tree;          /* tree index inside this forest                                        */
+    uint32_t left, right;   /* forest-local node indices (SPLIT)                                    */
+    uint64_t offset;        /* SPLIT: byte offset into the normals blob; DESCENDANTS: first id index */
+    uint32_t count;         /* DESCENDANTS: number of item ids; SPLIT: items under the node         */
+    uint32_t depth;
+} ah_node;
+
+typedef struct ah_forest_view {
+    uint32_t n_trees;
+    uint64_t n_nodes;
+    const uint32_t *roots;        /* n_trees forest-local node indices                               */
+    const ah_node *nodes;         /* n_nodes                                                         */
+    const uint8_t *normals;       /* per split node with a normal: [D::Header][vector codec bytes]   */
+    uint64_t normals_len;
+    uint64_t normal_stride;       /* ah_header_size + ah_vector_size                                 */
+    const uint32_t *descendants;  /* item ids, ascending inside each Descendants node                */
+    uint64_t descendants_len;
+} ah_forest_view;
+
+typedef struct ah_build_stats {
+    double seconds_total;         /* wall time of ah_build_forest                                    */
+    double seconds_device;        /* HIP-event time of all kernels                                   */
+    double seconds_margin;        /* HIP-event time of the margin/side kernel only                   */
+    uint64_t margin_evaluations;  /* number of (item, node-visit) units incl. retries                */
+    uint64_t margin_launches;
+    uint64_t split_nodes, descendant_nodes, dummy_normals, retries;
+    uint32_t levels;
+} ah_build_stats;
+
+int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out);
+int ah_forest_stats(const ah_forest *forest, ah_build_stats *out);
+/* Node sink in the shape `TmpNodes::put` expects (src/parallel.rs:130-147): children first, parent
+ * last (post-order), per tree. `payload`: SPLIT -> [header][vector] or NULL; DESCENDANTS -> u32 ids. */
+typedef int (*ah_node_sink_fn)(void *user, uint32_t tree, uint32_t node, uint8_t kind, uint32_t left,
+                               uint32_t right, const void *payload, size_t payload_len);
+int ah_forest_visit(const ah_forest *forest, ah_node_sink_fn sink, void *user);
+int ah_forest_destroy(ah_forest *forest);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement helpers (bench.py).  They time with hipEvents recorded on the same stream the
+ * kernels run on and never touch the host data path.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Launch the Q=1 distance scan `iterations` times back to back over the first `n` rows and report
+ * the total kernel time in milliseconds (HIP events on the launch stream).  The query is
+ * item `query_item`.  Distances of the last iteration are left in an internal device buffer; if
+ * `out` is non-NULL they are copied to it (n floats) after the timed region. */
+int ah_bench_scan(ah_dataset *ds, uint32_t query_item, uint64_t n, uint32_t iterations, float *out,
+                  double *out_ms_total);
+/* Device-to-device copy of `bytes` bytes, `iterations` times: the measured streaming ceiling. */
+int ah_bench_memcpy(int device, uint64_t bytes, uint32_t iterations, double *out_ms_total);
+/* Name of the device (hipDeviceProp_t.name / gcnArchName) into buf. */
+int ah_device_name(int device, char *buf, size_t buf_len);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* ARROY_HIP_H */

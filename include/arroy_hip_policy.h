@@ -1,0 +1,112 @@
+/*
+ * arroy_hip_policy.h — the two *policies* that are part of the public contract of
+ * libarroy_hip.so and that both the device code and any host (the Rust shim, the
+ * CPU oracle under oracle/, the benchmark harness) must be able to evaluate
+ * bit-identically:
+ *
+ *   1. the counter-based randomness policy that replaces arroy's `R: Rng` inside the
+ *      tree build (reference call sites: src/parallel.rs:342-367 `choose_two`/`choose`,
+ *      src/writer.rs:1310-1326 `randomly_split_children`, src/lib.rs:135 `Side::random`);
+ *   2. the counter-based synthetic vector generator of the benchmark harness
+ *      (keyed (seed, item, dim) so host and device materialise the
+ *      same data without a 30 GB transfer).
+ *
+ * Why a *policy* and not rand 0.8: the reference consumes one sequential ChaCha12
+ * stream per task in DFS order (src/writer.rs:1235-1254).  A level-synchronous GPU
+ * build visits nodes in BFS order, so any sequential generator would hand different
+ * numbers to the same node.  Here every draw is a pure function of
+ * (tree_seed, node path, attempt, draw index): the DFS CPU oracle and the BFS GPU
+ * build therefore sample the *same* items for the *same* node and must produce the
+ * same forest bit for bit.  The host stays in charge of `tree_seeds` (the reference
+ * seeds each task with `StdRng::from_seed(rng.gen())`, src/writer.rs:575,795).
+ *
+ * Plain C99, no dependencies; usable from C, C++ and HIP device code.
+ */
+#ifndef ARROY_HIP_POLICY_H
+#define ARROY_HIP_POLICY_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define AH_HD __host__ __device__ static inline
+#else
+#define AH_HD static inline
+#endif
+
+/* splitmix64 finaliser (Steele/Lea/Flood 2014; public domain constants). */
+AH_HD uint64_t ah_mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+/* Key of the root node of the tree seeded with `tree_seed`. */
+AH_HD uint64_t ah_node_key_root(uint64_t tree_seed) { return ah_mix64(tree_seed ^ 0xA5A5A5A55A5A5A5Aull); }
+
+/* Key of a child: side 0 = left, 1 = right.  A hash chain, not a heap index, because a
+ * 95/5 split policy (src/writer.rs:1209) allows depths far beyond 64. */
+AH_HD uint64_t ah_node_key_child(uint64_t parent_key, uint32_t side) {
+    return ah_mix64(parent_key * 0xD6E8FEB86659FD93ull + 2u * (uint64_t)side + 1u);
+}
+
+/* One 64-bit draw.  `attempt` is the split attempt (0..3, src/writer.rs:1193-1216);
+ * `draw` is the index of the draw inside one `create_split`:
+ *   0,1   -> choose_two            (src/parallel.rs:342-355)
+ *   2..11 -> the ten `choose` calls of two_means (src/distance/mod.rs:151-152) */
+AH_HD uint64_t ah_draw(uint64_t node_key, uint32_t attempt, uint32_t draw) {
+    return ah_mix64(ah_mix64(node_key + 0x632BE59BD9B4E019ull * (uint64_t)(attempt + 1u)) ^ (uint64_t)draw);
+}
+
+/* Unbiased-enough map of a 64-bit draw to [0, n): high half of the 128-bit product
+ * (bias <= n / 2^64). */
+AH_HD uint64_t ah_bounded(uint64_t r, uint64_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(r, n);
+#else
+    return (uint64_t)(((unsigned __int128)r * (unsigned __int128)n) >> 64);
+#endif
+}
+
+/* choose_two: two distinct ranks in [0, len), len >= 2. */
+AH_HD void ah_choose_two(uint64_t node_key, uint32_t attempt, uint64_t len, uint64_t *first, uint64_t *second) {
+    uint64_t a = ah_bounded(ah_draw(node_key, attempt, 0u), len);
+    uint64_t b = ah_bounded(ah_draw(node_key, attempt, 1u), len - 1u);
+    if (b >= a) b += 1u;
+    *first = a;
+    *second = b;
+}
+
+/* choose: rank in [0, len) for two-means iteration `iter` (0..9). */
+AH_HD uint64_t ah_choose(uint64_t node_key, uint32_t attempt, uint32_t iter, uint64_t len) {
+    return ah_bounded(ah_draw(node_key, attempt, 2u + iter), len);
+}
+
+/* randomly_split_children: the coin of the item of rank `rank` inside the node
+ * (ascending item id order, src/writer.rs:1320-1325).  1 = Left (the reference maps
+ * `true` to `Side::Left`, src/lib.rs:135-141). */
+AH_HD uint32_t ah_random_side_is_left(uint64_t node_key, uint64_t rank) {
+    return (uint32_t)(ah_mix64(ah_mix64(node_key ^ 0x1F83D9ABFB41BD6Bull) + rank) >> 63);
+}
+
+/* ---- synthetic vectors ------------------------------------------------------------ */
+
+enum ah_synth_distribution {
+    AH_SYNTH_UNIFORM_01 = 0,    /* i.i.d. uniform [0,1): what the reference's tests use
+                                   (src/tests/writer.rs:302 `rng.gen()`)                     */
+    AH_SYNTH_UNIFORM_PM1 = 1    /* i.i.d. uniform [-1,1): sign-balanced margins for cosine   */
+};
+
+/* value of component `dim` of item `item` (item = row index, ids are 0..N-1). Exact in f32:
+ * a 24-bit integer scaled by a power of two, so host and device agree bit for bit. */
+AH_HD float ah_synth_value(uint64_t seed, uint64_t item, uint32_t dim, uint32_t dims, int distribution) {
+    uint64_t h = ah_mix64(ah_mix64(seed) + item * (uint64_t)dims + (uint64_t)dim);
+    uint32_t m = (uint32_t)(h >> 40);                 /* 24 random bits */
+    float u = (float)m * (1.0f / 16777216.0f);       /* [0,1) exactly */
+    if (distribution == AH_SYNTH_UNIFORM_PM1) {
+        return u * 2.0f - 1.0f;                       /* exact: 25-bit grid in [-1,1) */
+    }
+    return u;
+}
+
+#endif /* ARROY_HIP_POLICY_H */

@@ -1,0 +1,319 @@
+"""ctypes binding of the CPU oracle (oracle/libarroy_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+``cpu_baseline`` leg.  The product package ``arroy_amd`` never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libarroy_oracle.so")
+
+EUCLIDEAN, MANHATTAN, COSINE, DOT_PRODUCT, BQ_EUCLIDEAN, BQ_MANHATTAN, BQ_COSINE = range(7)
+METRIC_NAMES = {
+    EUCLIDEAN: "euclidean", MANHATTAN: "manhattan", COSINE: "cosine", DOT_PRODUCT: "dot-product",
+    BQ_EUCLIDEAN: "binary quantized euclidean", BQ_MANHATTAN: "binary quantized manhattan",
+    BQ_COSINE: "binary quantized cosine",
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with the committed recipe (oracle/Makefile)."""
+    src = os.path.join(HERE, "arroy_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-s"])
+    return LIB_PATH
+
+
+class AhNode(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("has_normal", C.c_uint8), ("tree", C.c_uint16), ("left", C.c_uint32),
+                ("right", C.c_uint32), ("offset", C.c_uint64), ("count", C.c_uint32), ("depth", C.c_uint32)]
+
+
+class AhForestView(C.Structure):
+    _fields_ = [("n_trees", C.c_uint32), ("n_nodes", C.c_uint64), ("roots", C.POINTER(C.c_uint32)),
+                ("nodes", C.POINTER(AhNode)), ("normals", C.POINTER(C.c_uint8)), ("normals_len", C.c_uint64),
+                ("normal_stride", C.c_uint64), ("descendants", C.POINTER(C.c_uint32)),
+                ("descendants_len", C.c_uint64)]
+
+
+class AoData(C.Structure):
+    _fields_ = [("metric", C.c_int), ("dims", C.c_uint32), ("n", C.c_uint64), ("vectors", C.c_void_p),
+                ("headers", C.c_void_p), ("ids", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        f32p, u32p, u8p = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+        for name in ("ao_dot", "ao_euclid", "ao_dot_scalar", "ao_euclid_scalar", "ao_dot_sse", "ao_euclid_sse",
+                     "ao_dot_avx_emul", "ao_euclid_avx_emul", "ao_dot_avx_real", "ao_euclid_avx_real"):
+            fn = getattr(L, name)
+            fn.restype = C.c_float
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ao_set_tier.argtypes = [C.c_int]
+        L.ao_set_use_intrinsics.argtypes = [C.c_int]
+        L.ao_bq_bytes.restype = C.c_size_t
+        L.ao_bq_bytes.argtypes = [C.c_size_t]
+        L.ao_bq_quantize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.ao_bq_dequantize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.ao_bq_dot_i32.restype = C.c_int32
+        L.ao_bq_dot_i32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ao_bq_hamming.restype = C.c_uint32
+        L.ao_bq_hamming.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ao_header_floats.restype = C.c_size_t
+        L.ao_header_floats.argtypes = [C.c_int]
+        L.ao_vector_bytes.restype = C.c_size_t
+        L.ao_vector_bytes.argtypes = [C.c_int, C.c_size_t]
+        L.ao_norm_no_header.restype = C.c_float
+        L.ao_norm_no_header.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+        L.ao_new_header.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.ao_norm.restype = C.c_float
+        L.ao_norm.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        for name in ("ao_built_distance", "ao_non_built_distance", "ao_margin"):
+            fn = getattr(L, name)
+            fn.restype = C.c_float
+            fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ao_normalized_distance.restype = C.c_float
+        L.ao_normalized_distance.argtypes = [C.c_int, C.c_float, C.c_size_t]
+        L.ao_side_of_margin.restype = C.c_int
+        L.ao_side_of_margin.argtypes = [C.c_float]
+        L.ao_pq_distance.restype = C.c_float
+        L.ao_pq_distance.argtypes = [C.c_float, C.c_float, C.c_int]
+        L.ao_distances.argtypes = [C.POINTER(AoData), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        for name in ("ao_top_k", "ao_top_k_spec"):
+            fn = getattr(L, name)
+            fn.restype = C.c_size_t
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.ao_rerank.restype = C.c_size_t
+        L.ao_rerank.argtypes = [C.POINTER(AoData), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t,
+                                C.c_void_p, C.c_void_p]
+        L.ao_split_sides.argtypes = [C.POINTER(AoData), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                     C.POINTER(C.c_uint64), C.c_void_p]
+        L.ao_preprocess_dot.argtypes = [C.POINTER(AoData), C.POINTER(C.c_float)]
+        L.ao_two_means.restype = C.c_size_t
+        L.ao_two_means.argtypes = [C.POINTER(AoData), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ao_create_split.argtypes = [C.POINTER(AoData), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ao_split_imbalance.restype = C.c_double
+        L.ao_split_imbalance.argtypes = [C.c_uint64, C.c_uint64]
+        L.ao_build_tree.restype = C.c_void_p
+        L.ao_build_tree.argtypes = [C.POINTER(AoData), C.c_uint32, C.c_uint64]
+        L.ao_tree_view.argtypes = [C.c_void_p, C.POINTER(AhForestView), C.POINTER(C.c_uint32)]
+        L.ao_tree_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_uint64)]
+        L.ao_tree_free.argtypes = [C.c_void_p]
+        L.ao_build_forest_count.restype = C.c_uint64
+        L.ao_build_forest_count.argtypes = [C.POINTER(AoData), C.c_uint32, C.c_void_p, C.c_uint32]
+        L.ao_synth_fill.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
+        L.ao_num_threads.restype = C.c_int
+        L.ao_set_num_threads.argtypes = [C.c_int]
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def is_bq(metric: int) -> bool:
+    return metric >= BQ_EUCLIDEAN
+
+
+def header_floats(metric: int) -> int:
+    return 2 if metric == DOT_PRODUCT else 1
+
+
+def vector_bytes(metric: int, dims: int) -> int:
+    return ((dims + 63) // 64) * 8 if is_bq(metric) else 4 * dims
+
+
+# ---- spaces -------------------------------------------------------------------------------
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def dot(u, v, tier="auto"):
+    u, v = _f32(u), _f32(v)
+    name = {"auto": "ao_dot", "scalar": "ao_dot_scalar", "sse": "ao_dot_sse", "avx_emul": "ao_dot_avx_emul",
+            "avx_real": "ao_dot_avx_real"}[tier]
+    return np.float32(getattr(lib(), name)(_p(u), _p(v), u.size))
+
+
+def euclid(u, v, tier="auto"):
+    u, v = _f32(u), _f32(v)
+    name = {"auto": "ao_euclid", "scalar": "ao_euclid_scalar", "sse": "ao_euclid_sse",
+            "avx_emul": "ao_euclid_avx_emul", "avx_real": "ao_euclid_avx_real"}[tier]
+    return np.float32(getattr(lib(), name)(_p(u), _p(v), u.size))
+
+
+def bq_quantize(x) -> np.ndarray:
+    x = _f32(x)
+    out = np.zeros(lib().ao_bq_bytes(x.size), dtype=np.uint8)
+    lib().ao_bq_quantize(_p(x), x.size, _p(out))
+    return out
+
+
+def bq_dequantize(b) -> np.ndarray:
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    out = np.zeros(b.size * 8, dtype=np.float32)
+    lib().ao_bq_dequantize(_p(b), b.size, _p(out))
+    return out
+
+
+# ---- a data set in the oracle's layout ------------------------------------------------------
+
+class Data:
+    """Items in the stored layout: codec bytes + headers, ascending ids (id == row unless ids given)."""
+
+    def __init__(self, metric: int, vectors_f32: np.ndarray, ids=None, headers=None, codec_bytes=None):
+        L = lib()
+        self.metric = metric
+        v = _f32(vectors_f32)
+        self.n, self.dims = v.shape if v.ndim == 2 else (0, 0)
+        if codec_bytes is not None:
+            self.codec = np.ascontiguousarray(codec_bytes, dtype=np.uint8)
+        elif is_bq(metric):
+            self.codec = np.stack([bq_quantize(r) for r in v]) if self.n else np.zeros((0, 0), np.uint8)
+        else:
+            self.codec = v.view(np.uint8).reshape(self.n, 4 * self.dims).copy()
+        hf = header_floats(metric)
+        if headers is not None:
+            self.headers = _f32(headers).reshape(self.n, hf).copy()
+        else:
+            self.headers = np.zeros((self.n, hf), dtype=np.float32)
+            for r in range(self.n):  # D::new_header at add_item time
+                L.ao_new_header(metric, _p(self.codec[r]), self.dims, _p(self.headers[r]))
+        self.ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
+        self._c = AoData(metric, self.dims, self.n, self.codec.ctypes.data, self.headers.ctypes.data,
+                         None if self.ids is None else self.ids.ctypes.data)
+
+    def c(self):
+        return C.byref(self._c)
+
+    def id_of(self, row):
+        return int(row) if self.ids is None else int(self.ids[row])
+
+    # Reader::by_vector query leaf: codec + new_header (src/reader.rs:64-75)
+    def query_leaf(self, vector):
+        vector = _f32(vector)
+        q = bq_quantize(vector) if is_bq(self.metric) else vector.view(np.uint8).copy()
+        h = np.zeros(2, dtype=np.float32)
+        lib().ao_new_header(self.metric, _p(q), self.dims, _p(h))
+        return q, h
+
+    def item_leaf(self, row):
+        h = np.zeros(2, dtype=np.float32)
+        h[: self.headers.shape[1]] = self.headers[row]
+        return self.codec[row].copy(), h
+
+    def distances(self, q, qh, rows=None):
+        n = self.n if rows is None else len(rows)
+        out = np.zeros(n, dtype=np.float32)
+        r = None if rows is None else np.ascontiguousarray(rows, dtype=np.uint32)
+        lib().ao_distances(self.c(), _p(q), _p(qh), None if r is None else _p(r), n, _p(out))
+        return out
+
+    def rerank(self, q, qh, rows, k):
+        n = self.n if rows is None else len(rows)
+        r = None if rows is None else np.ascontiguousarray(rows, dtype=np.uint32)
+        oi = np.zeros(max(k, 1), dtype=np.uint32)
+        od = np.zeros(max(k, 1), dtype=np.float32)
+        m = lib().ao_rerank(self.c(), _p(q), _p(qh), None if r is None else _p(r), n, k, _p(oi), _p(od))
+        return oi[:m].copy(), od[:m].copy()
+
+    def split_sides(self, nv, nh, rows=None):
+        n = self.n if rows is None else len(rows)
+        r = None if rows is None else np.ascontiguousarray(rows, dtype=np.uint32)
+        sides = np.zeros(n, dtype=np.uint8)
+        margins = np.zeros(n, dtype=np.float32)
+        nl = C.c_uint64(0)
+        nh2 = np.zeros(2, dtype=np.float32)
+        nh2[: len(nh)] = nh
+        lib().ao_split_sides(self.c(), _p(np.ascontiguousarray(nv)), _p(nh2), None if r is None else _p(r), n,
+                             _p(sides), C.byref(nl), _p(margins))
+        return sides, int(nl.value), margins
+
+    def create_split(self, sample_rows):
+        s = np.ascontiguousarray(sample_rows, dtype=np.uint32)
+        assert s.size == 12
+        nv = np.zeros(vector_bytes(self.metric, self.dims), dtype=np.uint8)
+        nh = np.zeros(2, dtype=np.float32)
+        lib().ao_create_split(self.c(), _p(s), _p(nv), _p(nh))
+        return nv, nh[: header_floats(self.metric)].copy()
+
+    def two_means(self, sample_rows):
+        s = np.ascontiguousarray(sample_rows, dtype=np.uint32)
+        fd = vector_bytes(self.metric, self.dims) * 8 if is_bq(self.metric) else self.dims
+        p = np.zeros(fd, np.float32); q = np.zeros(fd, np.float32)
+        ph = np.zeros(2, np.float32); qh = np.zeros(2, np.float32)
+        lib().ao_two_means(self.c(), _p(s), _p(p), _p(ph), _p(q), _p(qh))
+        return p, ph, q, qh
+
+    def preprocess_dot(self):
+        m = C.c_float(0)
+        lib().ao_preprocess_dot(self.c(), C.byref(m))
+        return np.float32(m.value)
+
+    def build_tree(self, split_after: int, seed: int):
+        return Tree(self, split_after, seed)
+
+
+def top_k(dists, ids, k, spec=False):
+    d = _f32(dists)
+    i = np.ascontiguousarray(ids, dtype=np.uint32)
+    oi = np.zeros(max(k, 1), dtype=np.uint32)
+    od = np.zeros(max(k, 1), dtype=np.float32)
+    fn = lib().ao_top_k_spec if spec else lib().ao_top_k
+    m = fn(_p(d), _p(i), d.size, k, _p(oi), _p(od))
+    return oi[:m].copy(), od[:m].copy()
+
+
+class Tree:
+    """One tree built by the oracle's depth-first restatement of make_tree_in_file."""
+
+    def __init__(self, data: Data, split_after: int, seed: int):
+        L = lib()
+        h = L.ao_build_tree(data.c(), split_after, seed)
+        view = AhForestView()
+        root = C.c_uint32(0)
+        L.ao_tree_view(h, C.byref(view), C.byref(root))
+        n = view.n_nodes
+        self.root = int(root.value)
+        self.nodes = [(nd.kind, nd.has_normal, nd.left, nd.right, nd.offset, nd.count, nd.depth)
+                      for nd in (view.nodes[i] for i in range(n))]
+        self.normals = bytes(C.string_at(view.normals, view.normals_len)) if view.normals_len else b""
+        self.descendants = np.ctypeslib.as_array(view.descendants, shape=(view.descendants_len,)).copy() \
+            if view.descendants_len else np.zeros(0, np.uint32)
+        me, rt, dm = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        L.ao_tree_counters(h, C.byref(me), C.byref(rt), C.byref(dm))
+        self.margin_evals, self.retries, self.dummy_normals = int(me.value), int(rt.value), int(dm.value)
+        self.stride = 4 * header_floats(data.metric) + vector_bytes(data.metric, data.dims)
+        L.ao_tree_free(h)
+
+    def canonical(self, node=None):
+        """Structure independent of node numbering: nested tuples."""
+        import sys
+        sys.setrecursionlimit(100000)
+        node = self.root if node is None else node
+        kind, has_normal, left, right, offset, count, depth = self.nodes[node]
+        if kind == 1:
+            return ("D", tuple(int(x) for x in self.descendants[offset:offset + count]))
+        nb = self.normals[offset:offset + self.stride] if has_normal else None
+        return ("S", nb, self.canonical(left), self.canonical(right))
+
+
+def synth(seed: int, distribution: int, n: int, dims: int, first_item: int = 0) -> np.ndarray:
+    out = np.zeros((n, dims), dtype=np.float32)
+    lib().ao_synth_fill(seed, distribution, first_item, n, dims, _p(out))
+    return out
