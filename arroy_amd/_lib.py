@@ -1,0 +1,153 @@
+"""ctypes binding of libarroy_hip.so (the C ABI declared in include/arroy_hip.h).
+
+There is deliberately NO fallback: if the shared object is missing or a call fails, an exception is
+raised.  The product never imports anything from ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libarroy_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+# ah_status (include/arroy_hip.h) -> arroy::Error (src/error.rs:6-85)
+AH_OK = 0
+STATUS_NAMES = {
+    1: "InvalidVecDimension", 2: "BuildCancelled", 3: "Panic(device)", 4: "Panic(out of memory)",
+    5: "Panic(invalid argument)", 6: "MissingKey", 7: "Panic(not finalized)", 8: "Panic(need preprocess)",
+}
+AH_SPLIT_SAMPLES = 12
+
+
+class ArroyHipError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+        self.message = message
+
+
+class InvalidVecDimension(ArroyHipError):
+    """arroy::Error::InvalidVecDimension (src/error.rs:17-23)."""
+
+
+class BuildCancelled(ArroyHipError):
+    """arroy::Error::BuildCancelled (src/error.rs:54-55)."""
+
+
+class MissingKey(ArroyHipError):
+    """arroy::Error::MissingKey (src/error.rs:38-46)."""
+
+
+class AhNode(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("has_normal", C.c_uint8), ("tree", C.c_uint16), ("left", C.c_uint32),
+                ("right", C.c_uint32), ("offset", C.c_uint64), ("count", C.c_uint32), ("depth", C.c_uint32)]
+
+
+class AhForestView(C.Structure):
+    _fields_ = [("n_trees", C.c_uint32), ("n_nodes", C.c_uint64), ("roots", C.POINTER(C.c_uint32)),
+                ("nodes", C.POINTER(AhNode)), ("normals", C.POINTER(C.c_uint8)), ("normals_len", C.c_uint64),
+                ("normal_stride", C.c_uint64), ("descendants", C.POINTER(C.c_uint32)),
+                ("descendants_len", C.c_uint64)]
+
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64)
+
+
+class AhBuildOptions(C.Structure):
+    _fields_ = [("n_trees", C.c_uint32), ("split_after", C.c_uint32), ("tree_seeds", C.POINTER(C.c_uint64)),
+                ("cancel", C.POINTER(C.c_int)), ("progress", PROGRESS_FN), ("progress_user", C.c_void_p),
+                ("max_trees_in_flight", C.c_uint32)]
+
+
+class AhBuildStats(C.Structure):
+    _fields_ = [("seconds_total", C.c_double), ("seconds_device", C.c_double), ("seconds_margin", C.c_double),
+                ("margin_evaluations", C.c_uint64), ("margin_launches", C.c_uint64), ("split_nodes", C.c_uint64),
+                ("descendant_nodes", C.c_uint64), ("dummy_normals", C.c_uint64), ("retries", C.c_uint64),
+                ("levels", C.c_uint32)]
+
+
+# name -> (restype, argtypes): exactly the declarations of include/arroy_hip.h
+_VP, _U32P, _F32P, _U64P = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+SIGNATURES = {
+    "ah_header_size": (C.c_size_t, [C.c_int]),
+    "ah_vector_size": (C.c_size_t, [C.c_int, C.c_uint32]),
+    "ah_abi_version": (C.c_int, []),
+    "ah_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "ah_last_error": (C.c_char_p, []),
+    "ah_dataset_create": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
+    "ah_dataset_upload_records": (C.c_int, [_VP, _U32P, _VP, C.c_size_t, C.c_size_t]),
+    "ah_dataset_upload_vectors": (C.c_int, [_VP, _U32P, _F32P, C.c_size_t]),
+    "ah_dataset_fill_synthetic": (C.c_int, [_VP, C.c_uint64, C.c_int, C.c_uint64]),
+    "ah_dataset_finalize": (C.c_int, [_VP]),
+    "ah_dataset_len": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
+    "ah_dataset_item_vector": (C.c_int, [_VP, C.c_uint32, _F32P]),
+    "ah_dataset_read_headers": (C.c_int, [_VP, C.c_uint64, C.c_uint64, _VP]),
+    "ah_dataset_destroy": (C.c_int, [_VP]),
+    "ah_preprocess_dot": (C.c_int, [_VP, C.POINTER(C.c_float)]),
+    "ah_distances_by_vector": (C.c_int, [_VP, _F32P, _U32P, C.c_size_t, _F32P]),
+    "ah_distances_by_item": (C.c_int, [_VP, C.c_uint32, _U32P, C.c_size_t, _F32P]),
+    "ah_rerank_by_vector": (C.c_int, [_VP, _F32P, _U32P, C.c_size_t, C.c_size_t, _U32P, _F32P,
+                                      C.POINTER(C.c_size_t)]),
+    "ah_rerank_by_item": (C.c_int, [_VP, C.c_uint32, _U32P, C.c_size_t, C.c_size_t, _U32P, _F32P,
+                                    C.POINTER(C.c_size_t)]),
+    "ah_rerank_batch": (C.c_int, [_VP, _F32P, C.c_size_t, _U32P, _U64P, C.c_size_t, _U32P, _F32P, _U32P]),
+    "ah_split_sides": (C.c_int, [_VP, _VP, _VP, _U32P, C.c_size_t, _VP, C.POINTER(C.c_uint64), _F32P]),
+    "ah_create_split": (C.c_int, [_VP, _U32P, _VP, _VP]),
+    "ah_build_forest": (C.c_int, [_VP, C.POINTER(AhBuildOptions), C.POINTER(C.c_void_p)]),
+    "ah_forest_view_get": (C.c_int, [_VP, C.POINTER(AhForestView)]),
+    "ah_forest_stats": (C.c_int, [_VP, C.POINTER(AhBuildStats)]),
+    "ah_forest_visit": (C.c_int, [_VP, _VP, _VP]),
+    "ah_forest_destroy": (C.c_int, [_VP]),
+    "ah_bench_scan": (C.c_int, [_VP, C.c_uint32, C.c_uint64, C.c_uint32, _F32P, C.POINTER(C.c_double)]),
+    "ah_bench_memcpy": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
+    "ah_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile libarroy_hip.so for gfx950 with the in-tree Makefile (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean", "-s"])
+    subprocess.check_call(["make", "-C", CSRC, "-j4", "-s"])
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(arroy_amd has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status: int) -> None:
+    if status == AH_OK:
+        return
+    msg = lib().ah_last_error().decode("utf-8", "replace")
+    cls = {1: InvalidVecDimension, 2: BuildCancelled, 6: MissingKey}.get(status, ArroyHipError)
+    raise cls(status, msg)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(lib().ah_device_count(C.byref(n)))
+    return n.value
+
+
+def device_name(device: int = 0) -> str:
+    buf = C.create_string_buffer(256)
+    check(lib().ah_device_name(device, buf, 256))
+    return buf.value.decode()

@@ -1,0 +1,807 @@
+// api.hip — the C ABI (include/arroy_hip.h): dataset staging, search-side and split-side entry points.
+// The forest build lives in forest.hip.  Host code only orchestrates: every arithmetic result comes from
+// a HIP kernel; there is no CPU fallback.
+#include <algorithm>
+#include <cmath>
+#include <new>
+
+#include "common.h"
+
+namespace ah {
+
+static thread_local std::string g_error;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+}
+const char *last_error() { return g_error.c_str(); }
+
+int Context::ensure_device(size_t bytes) {
+    if (bytes <= d_cap) return AH_OK;
+    size_t cap = std::max(bytes, d_cap * 2);
+    cap = (cap + 4095) & ~(size_t)4095;
+    if (d_scratch) AH_HIP(hipFree(d_scratch));
+    d_scratch = nullptr;
+    d_cap = 0;
+    AH_HIP(hipMalloc(&d_scratch, cap));
+    d_cap = cap;
+    return AH_OK;
+}
+int Context::ensure_pinned(size_t bytes) {
+    if (bytes <= h_cap) return AH_OK;
+    size_t cap = std::max(bytes, h_cap * 2);
+    cap = (cap + 4095) & ~(size_t)4095;
+    if (h_pinned) AH_HIP(hipHostFree(h_pinned));
+    h_pinned = nullptr;
+    h_cap = 0;
+    AH_HIP(hipHostMalloc(&h_pinned, cap, hipHostMallocDefault));
+    h_cap = cap;
+    return AH_OK;
+}
+void Context::destroy() {
+    if (d_scratch) (void)hipFree(d_scratch);
+    if (h_pinned) (void)hipHostFree(h_pinned);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+    d_scratch = h_pinned = nullptr;
+    stream = nullptr;
+}
+
+// carve `bytes` (256-byte aligned) out of a linear scratch region
+struct Carver {
+    uint8_t *base;
+    size_t off = 0;
+    explicit Carver(void *b) : base(reinterpret_cast<uint8_t *>(b)) {}
+    template <typename T>
+    T *take(size_t count) {
+        T *p = reinterpret_cast<T *>(base + off);
+        off += (count * sizeof(T) + 255) & ~(size_t)255;
+        return p;
+    }
+};
+static inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace ah
+
+using namespace ah;
+
+ah::DataView ah_dataset::view() const {
+    DataView v;
+    v.metric = metric;
+    v.dims = dims;
+    v.pitch = pitch;
+    v.words = words;
+    v.n = n;
+    v.rows_f32 = d_rows_f32;
+    v.rows_bq = d_rows_bq;
+    v.headers = d_headers;
+    v.ids = d_ids;
+    v.lut = d_lut;
+    v.lut_len = lut_len;
+    v.identity_ids = identity_ids ? 1 : 0;
+    return v;
+}
+
+ah::Context *ah_dataset::acquire() {
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!pool.empty()) {
+            Context *c = pool.back();
+            pool.pop_back();
+            return c;
+        }
+    }
+    Context *c = new (std::nothrow) Context();
+    if (!c) return nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        c->destroy();
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+void ah_dataset::release(ah::Context *c) {
+    std::lock_guard<std::mutex> lk(mu);
+    pool.push_back(c);
+}
+
+#define AH_LEASE(ds, name)                                                             \
+    AH_HIP(hipSetDevice((ds)->device));                                                \
+    ContextLease name##_lease(ds);                                                     \
+    AH_REQUIRE(name##_lease.c != nullptr, AH_ERR_DEVICE, "cannot create a HIP stream"); \
+    Context *name = name##_lease.c
+
+extern "C" {
+
+size_t ah_header_size(int metric) { return metric_valid(metric) ? 4 * header_floats(metric) : 0; }
+size_t ah_vector_size(int metric, uint32_t dimensions) {
+    if (!metric_valid(metric)) return 0;
+    return metric_is_bq(metric) ? (size_t)bq_words(dimensions) * 8 : (size_t)dimensions * 4;
+}
+int ah_abi_version(void) { return AH_ABI_VERSION; }
+const char *ah_last_error(void) { return ah::last_error(); }
+
+int ah_device_count(int *out_count) {
+    AH_REQUIRE(out_count, AH_ERR_INVALID_ARGUMENT, "out_count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *out_count = n;
+    return AH_OK;
+}
+
+int ah_device_name(int device, char *buf, size_t buf_len) {
+    AH_REQUIRE(buf && buf_len, AH_ERR_INVALID_ARGUMENT, "buf is NULL");
+    hipDeviceProp_t p;
+    AH_HIP(hipGetDeviceProperties(&p, device));
+    snprintf(buf, buf_len, "%s (%s, %d CUs, %.1f GiB)", p.name, p.gcnArchName, p.multiProcessorCount,
+             (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+    return AH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dataset
+// ---------------------------------------------------------------------------------------------
+int ah_dataset_create(int metric, uint32_t dimensions, uint64_t capacity, int device, ah_dataset **out) {
+    AH_REQUIRE(out, AH_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    AH_REQUIRE(metric_valid(metric), AH_ERR_INVALID_ARGUMENT, "unknown metric %d", metric);
+    AH_REQUIRE(dimensions > 0, AH_ERR_INVALID_DIMENSION, "dimensions must be > 0");
+    AH_REQUIRE(capacity < 0xFFFFFFFFull, AH_ERR_INVALID_ARGUMENT, "capacity exceeds the u32 item-id space");
+    int n_dev = 0;
+    AH_HIP(hipGetDeviceCount(&n_dev));
+    AH_REQUIRE(device >= 0 && device < n_dev, AH_ERR_DEVICE, "device %d not present (%d visible)", device, n_dev);
+    AH_HIP(hipSetDevice(device));
+    ah_dataset *ds = new (std::nothrow) ah_dataset();
+    AH_REQUIRE(ds, AH_ERR_OUT_OF_MEMORY, "host allocation failed");
+    ds->metric = metric;
+    ds->dims = dimensions;
+    ds->device = device;
+    ds->capacity = capacity;
+    const uint64_t cap = capacity ? capacity : 1;
+    int st = AH_OK;
+    do {
+        hipError_t e;
+        if (metric_is_bq(metric)) {
+            ds->words = bq_words(dimensions);
+            ds->pitch = (ds->words + 1u) & ~1u;  // 16-byte rows
+            e = hipMalloc((void **)&ds->d_rows_bq, cap * ds->pitch * 8);
+        } else {
+            ds->pitch = (dimensions + 31u) & ~31u;  // 128-byte rows
+            e = hipMalloc((void **)&ds->d_rows_f32, cap * (uint64_t)ds->pitch * 4);
+        }
+        if (e == hipSuccess) e = hipMalloc((void **)&ds->d_headers, cap * header_floats(metric) * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&ds->d_ids, cap * 4);
+        if (e != hipSuccess) {
+            set_error("hipMalloc of %llu items x %u dims failed: %s", (unsigned long long)cap, dimensions,
+                      hipGetErrorString(e));
+            st = e == hipErrorOutOfMemory ? AH_ERR_OUT_OF_MEMORY : AH_ERR_DEVICE;
+        }
+    } while (0);
+    if (st != AH_OK) {
+        ah_dataset_destroy(ds);
+        return st;
+    }
+    *out = ds;
+    return AH_OK;
+}
+
+int ah_dataset_destroy(ah_dataset *ds) {
+    if (!ds) return AH_OK;
+    (void)hipSetDevice(ds->device);
+    (void)hipDeviceSynchronize();
+    for (Context *c : ds->pool) {
+        c->destroy();
+        delete c;
+    }
+    ds->pool.clear();
+    if (ds->d_rows_f32) (void)hipFree(ds->d_rows_f32);
+    if (ds->d_rows_bq) (void)hipFree(ds->d_rows_bq);
+    if (ds->d_headers) (void)hipFree(ds->d_headers);
+    if (ds->d_ids) (void)hipFree(ds->d_ids);
+    if (ds->d_lut) (void)hipFree(ds->d_lut);
+    delete ds;
+    return AH_OK;
+}
+
+static int check_append(ah_dataset *ds, const uint32_t *item_ids, size_t n) {
+    AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
+    AH_REQUIRE(!ds->finalized, AH_ERR_INVALID_ARGUMENT, "dataset already finalized");
+    AH_REQUIRE(ds->n + n <= ds->capacity, AH_ERR_INVALID_ARGUMENT, "upload of %zu items exceeds capacity %llu", n,
+               (unsigned long long)ds->capacity);
+    for (size_t i = 0; i < n; i++) {
+        const bool first = ds->n == 0 && i == 0;
+        const uint32_t prev = i == 0 ? ds->last_id : item_ids[i - 1];
+        AH_REQUIRE(first || item_ids[i] > prev, AH_ERR_INVALID_ARGUMENT,
+                   "item ids must be strictly ascending (id %u after %u)", item_ids[i], prev);
+    }
+    return AH_OK;
+}
+
+static void note_ids(ah_dataset *ds, const uint32_t *item_ids, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        if (item_ids[i] != (uint32_t)(ds->n + i)) ds->identity_ids = false;
+        ds->h_ids.push_back(item_ids[i]);
+    }
+    if (n) ds->last_id = item_ids[n - 1];
+    ds->n += n;
+}
+
+// LMDB pages -> pinned staging (header and vector split apart, rows re-pitched to 128-byte lines) ->
+// hipMemcpyAsync, double-buffered so the host-side gather of chunk c+1 overlaps the DMA of chunk c.
+int ah_dataset_upload_records(ah_dataset *ds, const uint32_t *item_ids, const uint8_t *const *record_ptrs,
+                              size_t record_len, size_t n) {
+    AH_TRY(check_append(ds, item_ids, n));
+    if (n == 0) return AH_OK;
+    AH_REQUIRE(item_ids && record_ptrs, AH_ERR_INVALID_ARGUMENT, "NULL input");
+    const size_t hs = ah_header_size(ds->metric), vs = ah_vector_size(ds->metric, ds->dims);
+    // src/node.rs:252-258: [LEAF_TAG=0][header][vector]; a length mismatch is what UnalignedVector::from_bytes
+    // / the dimension check reports as InvalidVecDimension
+    AH_REQUIRE(record_len == 1 + hs + vs, AH_ERR_INVALID_DIMENSION,
+               "record length %zu does not match 1 + %zu + %zu for %u dimensions", record_len, hs, vs, ds->dims);
+    AH_LEASE(ds, ctx);
+    const size_t rb = ds->row_bytes();
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (8u << 20) / (rb + hs + 4)));
+    const size_t buf_bytes = pad256(chunk * rb) + pad256(chunk * hs) + pad256(chunk * 4);
+    AH_TRY(ctx->ensure_pinned(2 * buf_bytes));
+    hipEvent_t ev[2] = {ctx->ev0, ctx->ev1};
+    bool used[2] = {false, false};
+    size_t done = 0;
+    int b = 0;
+    while (done < n) {
+        const size_t c = std::min(chunk, n - done);
+        uint8_t *base = reinterpret_cast<uint8_t *>(ctx->h_pinned) + (size_t)b * buf_bytes;
+        if (used[b]) AH_HIP(hipEventSynchronize(ev[b]));
+        uint8_t *h_rows = base, *h_hdr = base + pad256(chunk * rb), *h_ids = h_hdr + pad256(chunk * hs);
+        for (size_t i = 0; i < c; i++) {
+            const uint8_t *rec = record_ptrs[done + i];
+            AH_REQUIRE(rec && rec[0] == 0, AH_ERR_INVALID_ARGUMENT, "record %zu is not a leaf (tag %d)", done + i,
+                       rec ? rec[0] : -1);
+            memcpy(h_hdr + i * hs, rec + 1, hs);
+            memcpy(h_rows + i * rb, rec + 1 + hs, vs);
+            if (rb > vs) memset(h_rows + i * rb + vs, 0, rb - vs);
+        }
+        memcpy(h_ids, item_ids + done, c * 4);
+        const uint64_t row0 = ds->n + done;
+        uint8_t *d_rows = ds->d_rows_f32 ? reinterpret_cast<uint8_t *>(ds->d_rows_f32)
+                                         : reinterpret_cast<uint8_t *>(ds->d_rows_bq);
+        AH_HIP(hipMemcpyAsync(d_rows + row0 * rb, h_rows, c * rb, hipMemcpyHostToDevice, ctx->stream));
+        AH_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t *>(ds->d_headers) + row0 * hs, h_hdr, c * hs,
+                              hipMemcpyHostToDevice, ctx->stream));
+        AH_HIP(hipMemcpyAsync(ds->d_ids + row0, h_ids, c * 4, hipMemcpyHostToDevice, ctx->stream));
+        AH_HIP(hipEventRecord(ev[b], ctx->stream));
+        used[b] = true;
+        b ^= 1;
+        done += c;
+    }
+    AH_HIP(hipStreamSynchronize(ctx->stream));
+    note_ids(ds, item_ids, n);
+    if (ds->metric == AH_DOT_PRODUCT) ds->dot_preprocessed = true;  // stored headers already carry norm/extra_dim
+    return AH_OK;
+}
+
+// Writer::add_item for a batch: stage f32 rows, then codec + new_header on device.
+int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, const float *vectors, size_t n) {
+    AH_TRY(check_append(ds, item_ids, n));
+    if (n == 0) return AH_OK;
+    AH_REQUIRE(item_ids && vectors, AH_ERR_INVALID_ARGUMENT, "NULL input");
+    AH_LEASE(ds, ctx);
+    const bool bq = metric_is_bq(ds->metric);
+    const uint32_t fpitch = bq ? ((ds->dims + 3u) & ~3u) : ds->pitch;  // staging pitch in floats
+    const size_t frb = (size_t)fpitch * 4;
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (8u << 20) / (frb + 4)));
+    const size_t buf_bytes = pad256(chunk * frb) + pad256(chunk * 4);
+    AH_TRY(ctx->ensure_pinned(2 * buf_bytes));
+    if (bq) AH_TRY(ctx->ensure_device(2 * pad256(chunk * frb)));
+    hipEvent_t ev[2] = {ctx->ev0, ctx->ev1};
+    bool used[2] = {false, false};
+    size_t done = 0;
+    int b = 0;
+    DataView dv = ds->view();
+    while (done < n) {
+        const size_t c = std::min(chunk, n - done);
+        uint8_t *base = reinterpret_cast<uint8_t *>(ctx->h_pinned) + (size_t)b * buf_bytes;
+        if (used[b]) AH_HIP(hipEventSynchronize(ev[b]));
+        float *h_rows = reinterpret_cast<float *>(base);
+        uint8_t *h_ids = base + pad256(chunk * frb);
+        for (size_t i = 0; i < c; i++) {
+            memcpy(h_rows + i * fpitch, vectors + (done + i) * (size_t)ds->dims, (size_t)ds->dims * 4);
+            for (uint32_t e = ds->dims; e < fpitch; e++) h_rows[i * fpitch + e] = 0.0f;
+        }
+        memcpy(h_ids, item_ids + done, c * 4);
+        const uint64_t row0 = ds->n + done;
+        if (!bq) {
+            AH_HIP(hipMemcpyAsync(ds->d_rows_f32 + row0 * ds->pitch, h_rows, c * frb, hipMemcpyHostToDevice,
+                                  ctx->stream));
+        } else {
+            float *d_tmp = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(ctx->d_scratch) +
+                                                     (size_t)b * pad256(chunk * frb));
+            AH_HIP(hipMemcpyAsync(d_tmp, h_rows, c * frb, hipMemcpyHostToDevice, ctx->stream));
+            AH_TRY(launch_quantize_rows(d_tmp, fpitch, ds->dims, ds->d_rows_bq + row0 * ds->pitch, ds->pitch, ds->words,
+                                        c, ctx->stream));
+        }
+        AH_HIP(hipMemcpyAsync(ds->d_ids + row0, h_ids, c * 4, hipMemcpyHostToDevice, ctx->stream));
+        AH_TRY(launch_headers_from_vectors(dv, row0, c, ctx->stream));
+        AH_HIP(hipEventRecord(ev[b], ctx->stream));
+        used[b] = true;
+        b ^= 1;
+        done += c;
+    }
+    AH_HIP(hipStreamSynchronize(ctx->stream));
+    note_ids(ds, item_ids, n);
+    return AH_OK;
+}
+
+int ah_dataset_fill_synthetic(ah_dataset *ds, uint64_t seed, int distribution, uint64_t n_items) {
+    AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
+    AH_REQUIRE(!ds->finalized && ds->n == 0, AH_ERR_INVALID_ARGUMENT, "synthetic fill needs an empty dataset");
+    AH_REQUIRE(n_items <= ds->capacity, AH_ERR_INVALID_ARGUMENT, "n_items exceeds capacity");
+    AH_REQUIRE(distribution == AH_SYNTH_UNIFORM_01 || distribution == AH_SYNTH_UNIFORM_PM1, AH_ERR_INVALID_ARGUMENT,
+               "unknown distribution %d", distribution);
+    AH_LEASE(ds, ctx);
+    DataView dv = ds->view();
+    if (!metric_is_bq(ds->metric)) {
+        AH_TRY(launch_synth_fill(ds->d_rows_f32, ds->pitch, ds->dims, 0, n_items, seed, distribution, ctx->stream));
+    } else {
+        const uint32_t fpitch = (ds->dims + 3u) & ~3u;
+        const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n_items, (256ull << 20) / ((uint64_t)fpitch * 4)));
+        AH_TRY(ctx->ensure_device(chunk * fpitch * 4));
+        for (uint64_t done = 0; done < n_items; done += chunk) {
+            const uint64_t c = std::min(chunk, n_items - done);
+            float *d_tmp = reinterpret_cast<float *>(ctx->d_scratch);
+            AH_TRY(launch_synth_fill(d_tmp, fpitch, ds->dims, done, c, seed, distribution, ctx->stream));
+            AH_TRY(launch_quantize_rows(d_tmp, fpitch, ds->dims, ds->d_rows_bq + done * ds->pitch, ds->pitch, ds->words, c,
+                                        ctx->stream));
+        }
+    }
+    AH_TRY(launch_headers_from_vectors(dv, 0, n_items, ctx->stream));
+    AH_HIP(hipStreamSynchronize(ctx->stream));
+    ds->n = n_items;
+    ds->identity_ids = true;
+    ds->last_id = n_items ? (uint32_t)(n_items - 1) : 0;
+    ds->h_ids.clear();  // identity: no host mirror needed
+    return AH_OK;
+}
+
+int ah_dataset_finalize(ah_dataset *ds) {
+    AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
+    if (ds->finalized) return AH_OK;
+    AH_LEASE(ds, ctx);
+    if (ds->identity_ids) {
+        // ids 0..n-1: no table needed; the id array is still materialised for uniform kernels
+        if (ds->h_ids.empty() && ds->n) {
+            std::vector<uint32_t> ids(ds->n);
+            for (uint64_t i = 0; i < ds->n; i++) ids[i] = (uint32_t)i;
+            AH_HIP(hipMemcpy(ds->d_ids, ids.data(), ds->n * 4, hipMemcpyHostToDevice));
+        }
+    } else {
+        const uint64_t span = (uint64_t)ds->last_id + 1;
+        if (span <= 8 * ds->n + (1u << 20)) {  // dense table; otherwise kernels binary-search the id array
+            AH_HIP(hipMalloc((void **)&ds->d_lut, span * 4));
+            ds->lut_len = (uint32_t)span;
+            AH_TRY(launch_build_lut(ds->d_ids, ds->n, ds->d_lut, ds->lut_len, ctx->stream));
+            AH_HIP(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    ds->finalized = true;
+    return AH_OK;
+}
+
+int ah_dataset_len(const ah_dataset *ds, uint64_t *out_n_items) {
+    AH_REQUIRE(ds && out_n_items, AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out_n_items = ds->n;
+    return AH_OK;
+}
+
+// host-side id -> row (the host mirror is only used to validate single ids; lists are resolved on device)
+static int host_row_of_id(const ah_dataset *ds, uint32_t id, uint32_t *row) {
+    if (ds->identity_ids) {
+        AH_REQUIRE(id < ds->n, AH_ERR_MISSING_ITEM, "item %u does not exist", id);
+        *row = id;
+        return AH_OK;
+    }
+    auto it = std::lower_bound(ds->h_ids.begin(), ds->h_ids.end(), id);
+    AH_REQUIRE(it != ds->h_ids.end() && *it == id, AH_ERR_MISSING_ITEM, "item %u does not exist", id);
+    *row = (uint32_t)(it - ds->h_ids.begin());
+    return AH_OK;
+}
+
+#define AH_NEED_FINALIZED(ds)                                                                       \
+    AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");                                     \
+    AH_REQUIRE((ds)->finalized, AH_ERR_NOT_FINALIZED, "dataset not finalized (call ah_dataset_finalize)")
+
+int ah_dataset_item_vector(ah_dataset *ds, uint32_t item_id, float *out_vector) {
+    AH_NEED_FINALIZED(ds);
+    AH_REQUIRE(out_vector, AH_ERR_INVALID_ARGUMENT, "out_vector is NULL");
+    uint32_t row;
+    AH_TRY(host_row_of_id(ds, item_id, &row));
+    AH_LEASE(ds, ctx);
+    AH_TRY(ctx->ensure_device(pad256((size_t)ds->dims * 4)));
+    AH_TRY(ctx->ensure_pinned((size_t)ds->dims * 4));
+    AH_TRY(launch_decode_item(ds->view(), row, reinterpret_cast<float *>(ctx->d_scratch), ctx->stream));
+    AH_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_scratch, (size_t)ds->dims * 4, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out_vector, ctx->h_pinned, (size_t)ds->dims * 4);
+    return AH_OK;
+}
+
+int ah_dataset_read_headers(ah_dataset *ds, uint64_t first_row, uint64_t n, void *out_headers) {
+    AH_REQUIRE(ds && out_headers, AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    AH_REQUIRE(first_row + n <= ds->n, AH_ERR_INVALID_ARGUMENT, "row range out of bounds");
+    AH_HIP(hipSetDevice(ds->device));
+    const size_t hs = ah_header_size(ds->metric);
+    AH_HIP(hipMemcpy(out_headers, reinterpret_cast<uint8_t *>(ds->d_headers) + first_row * hs, n * hs,
+                     hipMemcpyDeviceToHost));
+    return AH_OK;
+}
+
+int ah_preprocess_dot(ah_dataset *ds, float *out_max_norm) {
+    AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
+    AH_REQUIRE(ds->metric == AH_DOT_PRODUCT, AH_ERR_INVALID_ARGUMENT, "preprocess is only defined for DotProduct");
+    AH_LEASE(ds, ctx);
+    AH_TRY(ctx->ensure_device(256));
+    AH_TRY(launch_preprocess_dot(ds->view(), reinterpret_cast<float *>(ctx->d_scratch), ctx->stream));
+    float m = 0.0f;
+    AH_HIP(hipMemcpyAsync(&m, ctx->d_scratch, 4, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipStreamSynchronize(ctx->stream));
+    ds->dot_preprocessed = true;
+    if (out_max_norm) *out_max_norm = m;
+    return AH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// search side
+// ---------------------------------------------------------------------------------------------
+struct QueryBufs {
+    void *d_qvec;
+    float *d_qhdr;
+    float *d_qf32;
+    uint32_t *d_err;
+};
+
+// Device scratch layout for one query call.  Returns the carver positioned after the query block.
+static int stage_query(ah_dataset *ds, Context *ctx, const float *query, const uint32_t *query_item, size_t extra_dev,
+                       size_t extra_pinned, QueryBufs *qb, Carver *dev_out, Carver *pin_out) {
+    const size_t qbytes = pad256(ds->row_bytes()) + pad256(8) + pad256((size_t)ds->dims * 4) + pad256(4);
+    AH_TRY(ctx->ensure_device(qbytes + extra_dev));
+    AH_TRY(ctx->ensure_pinned(pad256((size_t)ds->dims * 4) + extra_pinned));
+    Carver dev(ctx->d_scratch), pin(ctx->h_pinned);
+    qb->d_qvec = dev.take<uint8_t>(ds->row_bytes());
+    qb->d_qhdr = dev.take<float>(2);
+    qb->d_qf32 = dev.take<float>(ds->dims);
+    qb->d_err = dev.take<uint32_t>(1);
+    float *h_q = pin.take<float>(ds->dims);
+    AH_HIP(hipMemsetAsync(qb->d_err, 0, 4, ctx->stream));
+    DataView dv = ds->view();
+    if (query) {
+        memcpy(h_q, query, (size_t)ds->dims * 4);
+        AH_HIP(hipMemcpyAsync(qb->d_qf32, h_q, (size_t)ds->dims * 4, hipMemcpyHostToDevice, ctx->stream));
+        AH_TRY(launch_prepare_query(dv, qb->d_qf32, qb->d_qvec, qb->d_qhdr, ctx->stream));
+    } else {
+        uint32_t row;
+        AH_TRY(host_row_of_id(ds, *query_item, &row));
+        AH_TRY(launch_load_item_as_query(dv, row, qb->d_qvec, qb->d_qhdr, ctx->stream));
+    }
+    *dev_out = dev;
+    *pin_out = pin;
+    return AH_OK;
+}
+
+static int check_err_flags(uint32_t flags, bool need_sorted) {
+    AH_REQUIRE((flags & 1u) == 0, AH_ERR_MISSING_ITEM, "a listed item id does not exist in the dataset");
+    AH_REQUIRE(!need_sorted || (flags & 2u) == 0, AH_ERR_INVALID_ARGUMENT,
+               "candidate ids must be ascending and unique (src/reader.rs:378-379)");
+    return AH_OK;
+}
+
+static int distances_impl(ah_dataset *ds, const float *query, const uint32_t *query_item, const uint32_t *item_ids,
+                          size_t n, float *out) {
+    AH_NEED_FINALIZED(ds);
+    AH_REQUIRE(out || n == 0, AH_ERR_INVALID_ARGUMENT, "out is NULL");
+    AH_REQUIRE(item_ids || n <= ds->n, AH_ERR_INVALID_ARGUMENT, "n exceeds the number of items");
+    if (n == 0) return AH_OK;
+    AH_LEASE(ds, ctx);
+    QueryBufs qb;
+    Carver dev(nullptr), pin(nullptr);
+    const size_t extra_dev = pad256(n * 4) * 2;
+    const size_t extra_pin = pad256(n * 4) * 2 + 256;
+    AH_TRY(stage_query(ds, ctx, query, query_item, extra_dev, extra_pin, &qb, &dev, &pin));
+    uint32_t *d_ids = nullptr;
+    if (item_ids) {
+        d_ids = dev.take<uint32_t>(n);
+        uint32_t *h_ids = pin.take<uint32_t>(n);
+        memcpy(h_ids, item_ids, n * 4);
+        AH_HIP(hipMemcpyAsync(d_ids, h_ids, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    float *d_out = dev.take<float>(n);
+    float *h_out = pin.take<float>(n);
+    uint32_t *h_err = pin.take<uint32_t>(1);
+    AH_TRY(launch_distances(ds->view(), qb.d_qvec, qb.d_qhdr, d_ids, n, d_out, qb.d_err, ctx->stream));
+    AH_HIP(hipMemcpyAsync(h_out, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipMemcpyAsync(h_err, qb.d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipStreamSynchronize(ctx->stream));
+    AH_TRY(check_err_flags(*h_err, false));
+    memcpy(out, h_out, n * 4);
+    return AH_OK;
+}
+
+int ah_distances_by_vector(ah_dataset *ds, const float *query, const uint32_t *item_ids, size_t n, float *out) {
+    AH_REQUIRE(query, AH_ERR_INVALID_ARGUMENT, "query is NULL");
+    return distances_impl(ds, query, nullptr, item_ids, n, out);
+}
+int ah_distances_by_item(ah_dataset *ds, uint32_t query_item, const uint32_t *item_ids, size_t n, float *out) {
+    return distances_impl(ds, nullptr, &query_item, item_ids, n, out);
+}
+
+static int rerank_impl(ah_dataset *ds, const float *query, const uint32_t *query_item, const uint32_t *sorted_ids,
+                       size_t n, size_t k, uint32_t *out_ids, float *out_distances, size_t *out_n) {
+    AH_NEED_FINALIZED(ds);
+    AH_REQUIRE(out_n, AH_ERR_INVALID_ARGUMENT, "out_n is NULL");
+    *out_n = 0;
+    if (!sorted_ids) n = ds->n;  // "all items"
+    const size_t kk = std::min(k, n);  // src/reader.rs:394
+    if (kk == 0) return AH_OK;
+    AH_REQUIRE(out_ids && out_distances, AH_ERR_INVALID_ARGUMENT, "output buffers are NULL");
+    AH_LEASE(ds, ctx);
+    QueryBufs qb;
+    Carver dev(nullptr), pin(nullptr);
+    const size_t extra_dev = pad256(n * 4) * 2 + pad256(kk * 4) * 2 + pad256(topk_scratch_bytes(n, kk));
+    const size_t extra_pin = pad256(n * 4) + pad256(kk * 4) * 2 + 256;
+    AH_TRY(stage_query(ds, ctx, query, query_item, extra_dev, extra_pin, &qb, &dev, &pin));
+    uint32_t *d_ids = nullptr;
+    if (sorted_ids) {
+        d_ids = dev.take<uint32_t>(n);
+        uint32_t *h_ids = pin.take<uint32_t>(n);
+        memcpy(h_ids, sorted_ids, n * 4);
+        AH_HIP(hipMemcpyAsync(d_ids, h_ids, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    float *d_dist = dev.take<float>(n);
+    uint32_t *d_oi = dev.take<uint32_t>(kk);
+    float *d_od = dev.take<float>(kk);
+    void *d_tk = dev.take<uint8_t>(topk_scratch_bytes(n, kk));
+    uint32_t *h_oi = pin.take<uint32_t>(kk);
+    float *h_od = pin.take<float>(kk);
+    uint32_t *h_err = pin.take<uint32_t>(1);
+    DataView dv = ds->view();
+    AH_TRY(launch_distances(dv, qb.d_qvec, qb.d_qhdr, d_ids, n, d_dist, qb.d_err, ctx->stream));
+    AH_TRY(launch_topk(dv, d_dist, d_ids, n, kk, d_tk, d_oi, d_od, ctx->stream));
+    AH_HIP(hipMemcpyAsync(h_oi, d_oi, kk * 4, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipMemcpyAsync(h_od, d_od, kk * 4, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipMemcpyAsync(h_err, qb.d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipStreamSynchronize(ctx->stream));
+    AH_TRY(check_err_flags(*h_err, true));
+    memcpy(out_ids, h_oi, kk * 4);
+    memcpy(out_distances, h_od, kk * 4);
+    *out_n = kk;
+    return AH_OK;
+}
+
+int ah_rerank_by_vector(ah_dataset *ds, const float *query, const uint32_t *sorted_ids, size_t n, size_t k,
+                        uint32_t *out_ids, float *out_distances, size_t *out_n) {
+    AH_REQUIRE(query, AH_ERR_INVALID_ARGUMENT, "query is NULL");
+    return rerank_impl(ds, query, nullptr, sorted_ids, n, k, out_ids, out_distances, out_n);
+}
+int ah_rerank_by_item(ah_dataset *ds, uint32_t query_item, const uint32_t *sorted_ids, size_t n, size_t k,
+                      uint32_t *out_ids, float *out_distances, size_t *out_n) {
+    return rerank_impl(ds, nullptr, &query_item, sorted_ids, n, k, out_ids, out_distances, out_n);
+}
+
+// Many queries in one submission: all inputs staged once, kernels of all queries queued back to back on
+// one stream, a single synchronisation at the end.
+int ah_rerank_batch(ah_dataset *ds, const float *queries, size_t n_queries, const uint32_t *ids,
+                    const uint64_t *offsets, size_t k, uint32_t *out_ids, float *out_distances, uint32_t *out_counts) {
+    AH_NEED_FINALIZED(ds);
+    AH_REQUIRE(queries && ids && offsets && out_ids && out_distances && out_counts, AH_ERR_INVALID_ARGUMENT,
+               "NULL argument");
+    if (n_queries == 0) return AH_OK;
+    AH_REQUIRE(k > 0, AH_ERR_INVALID_ARGUMENT, "k must be > 0");
+    const uint64_t total = offsets[n_queries];
+    size_t max_n = 0;
+    for (size_t q = 0; q < n_queries; q++) {
+        AH_REQUIRE(offsets[q + 1] >= offsets[q], AH_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+        max_n = std::max<size_t>(max_n, offsets[q + 1] - offsets[q]);
+    }
+    AH_LEASE(ds, ctx);
+    const size_t qrow = pad256(ds->row_bytes());
+    const size_t tk_bytes = pad256(topk_scratch_bytes(std::max<size_t>(max_n, 1), std::min(k, std::max<size_t>(max_n, 1))));
+    const size_t dev_bytes = pad256(n_queries * (size_t)ds->dims * 4) + n_queries * (qrow + 256) + pad256(total * 4) * 2 +
+                             pad256(n_queries * k * 4) * 2 + tk_bytes + 1024;
+    const size_t pin_bytes = pad256(n_queries * (size_t)ds->dims * 4) + pad256(total * 4) + pad256(n_queries * k * 4) * 2 + 1024;
+    AH_TRY(ctx->ensure_device(dev_bytes));
+    AH_TRY(ctx->ensure_pinned(pin_bytes));
+    Carver dev(ctx->d_scratch), pin(ctx->h_pinned);
+    float *d_qf32 = dev.take<float>(n_queries * (size_t)ds->dims);
+    uint8_t *d_qvecs = dev.take<uint8_t>(n_queries * qrow);
+    float *d_qhdrs = dev.take<float>(n_queries * 64);
+    uint32_t *d_ids = dev.take<uint32_t>(total);
+    float *d_dist = dev.take<float>(total);
+    uint32_t *d_oi = dev.take<uint32_t>(n_queries * k);
+    float *d_od = dev.take<float>(n_queries * k);
+    uint32_t *d_err = dev.take<uint32_t>(1);
+    void *d_tk = dev.take<uint8_t>(tk_bytes);
+    float *h_q = pin.take<float>(n_queries * (size_t)ds->dims);
+    uint32_t *h_ids = pin.take<uint32_t>(total);
+    uint32_t *h_oi = pin.take<uint32_t>(n_queries * k);
+    float *h_od = pin.take<float>(n_queries * k);
+    uint32_t *h_err = pin.take<uint32_t>(1);
+    memcpy(h_q, queries, n_queries * (size_t)ds->dims * 4);
+    memcpy(h_ids, ids, total * 4);
+    AH_HIP(hipMemcpyAsync(d_qf32, h_q, n_queries * (size_t)ds->dims * 4, hipMemcpyHostToDevice, ctx->stream));
+    AH_HIP(hipMemcpyAsync(d_ids, h_ids, total * 4, hipMemcpyHostToDevice, ctx->stream));
+    AH_HIP(hipMemsetAsync(d_err, 0, 4, ctx->stream));
+    AH_HIP(hipMemsetAsync(d_oi, 0xFF, n_queries * k * 4, ctx->stream));  // id 0xFFFFFFFF / NaN padding
+    AH_HIP(hipMemsetAsync(d_od, 0xFF, n_queries * k * 4, ctx->stream));
+    DataView dv = ds->view();
+    for (size_t q = 0; q < n_queries; q++) {
+        const size_t nq = offsets[q + 1] - offsets[q];
+        const size_t kk = std::min(k, nq);
+        out_counts[q] = (uint32_t)kk;
+        if (kk == 0) continue;
+        void *qv = d_qvecs + q * qrow;
+        float *qh = d_qhdrs + q * 64;
+        AH_TRY(launch_prepare_query(dv, d_qf32 + q * (size_t)ds->dims, qv, qh, ctx->stream));
+        AH_TRY(launch_distances(dv, qv, qh, d_ids + offsets[q], nq, d_dist + offsets[q], d_err, ctx->stream));
+        AH_TRY(launch_topk(dv, d_dist + offsets[q], d_ids + offsets[q], nq, kk, d_tk, d_oi + q * k, d_od + q * k,
+                           ctx->stream));
+    }
+    AH_HIP(hipMemcpyAsync(h_oi, d_oi, n_queries * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipMemcpyAsync(h_od, d_od, n_queries * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipStreamSynchronize(ctx->stream));
+    AH_TRY(check_err_flags(*h_err, true));
+    memcpy(out_ids, h_oi, n_queries * k * 4);
+    memcpy(out_distances, h_od, n_queries * k * 4);
+    return AH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// build side: single-node entry points (the incremental paths of arroy call these per node)
+// ---------------------------------------------------------------------------------------------
+int ah_split_sides(ah_dataset *ds, const void *normal_vector, const void *normal_header, const uint32_t *sorted_ids,
+                   size_t n, uint8_t *side_bits, uint64_t *out_n_left, float *out_margins) {
+    AH_NEED_FINALIZED(ds);
+    AH_REQUIRE(normal_vector && normal_header && side_bits && out_n_left, AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!sorted_ids) n = ds->n;
+    *out_n_left = 0;
+    if (n == 0) return AH_OK;
+    AH_LEASE(ds, ctx);
+    const size_t vs = ah_vector_size(ds->metric, ds->dims), hs = ah_header_size(ds->metric);
+    const size_t nbytes = (n + 7) / 8;
+    const size_t nwords = (n + 31) / 32;
+    AH_TRY(ctx->ensure_device(pad256(ds->row_bytes()) + 256 + pad256(n * 4) * 2 + pad256(nwords * 4) + 1024));
+    AH_TRY(ctx->ensure_pinned(pad256(ds->row_bytes()) + 256 + pad256(n * 4) * 2 + pad256(nwords * 4) + 1024));
+    Carver dev(ctx->d_scratch), pin(ctx->h_pinned);
+    uint8_t *d_nv = dev.take<uint8_t>(ds->row_bytes());
+    float *d_nh = dev.take<float>(2);
+    unsigned long long *d_left = dev.take<unsigned long long>(1);
+    uint32_t *d_err = dev.take<uint32_t>(1);
+    uint32_t *d_ids = sorted_ids ? dev.take<uint32_t>(n) : nullptr;
+    uint8_t *d_bits = dev.take<uint8_t>(nwords * 4);
+    float *d_marg = out_margins ? dev.take<float>(n) : nullptr;
+    uint8_t *h_nv = pin.take<uint8_t>(ds->row_bytes());
+    float *h_nh = pin.take<float>(2);
+    uint32_t *h_ids = sorted_ids ? pin.take<uint32_t>(n) : nullptr;
+    uint8_t *h_bits = pin.take<uint8_t>(nwords * 4);
+    float *h_marg = out_margins ? pin.take<float>(n) : nullptr;
+    unsigned long long *h_left = pin.take<unsigned long long>(1);
+    uint32_t *h_err = pin.take<uint32_t>(1);
+    memset(h_nv, 0, ds->row_bytes());
+    memcpy(h_nv, normal_vector, vs);
+    h_nh[0] = h_nh[1] = 0.0f;
+    memcpy(h_nh, normal_header, hs);
+    AH_HIP(hipMemcpyAsync(d_nv, h_nv, ds->row_bytes(), hipMemcpyHostToDevice, ctx->stream));
+    AH_HIP(hipMemcpyAsync(d_nh, h_nh, 8, hipMemcpyHostToDevice, ctx->stream));
+    if (sorted_ids) {
+        memcpy(h_ids, sorted_ids, n * 4);
+        AH_HIP(hipMemcpyAsync(d_ids, h_ids, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    AH_HIP(hipMemsetAsync(d_left, 0, 8, ctx->stream));
+    AH_HIP(hipMemsetAsync(d_err, 0, 4, ctx->stream));
+    AH_HIP(hipMemsetAsync(d_bits, 0, nwords * 4, ctx->stream));
+    AH_TRY(launch_split_sides(ds->view(), d_nv, d_nh, d_ids, n, d_bits, d_left, d_marg, d_err, ctx->stream));
+    AH_HIP(hipMemcpyAsync(h_bits, d_bits, nwords * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_margins) AH_HIP(hipMemcpyAsync(h_marg, d_marg, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipMemcpyAsync(h_left, d_left, 8, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipStreamSynchronize(ctx->stream));
+    AH_TRY(check_err_flags(*h_err, false));
+    memcpy(side_bits, h_bits, nbytes);
+    if (out_margins) memcpy(out_margins, h_marg, n * 4);
+    *out_n_left = *h_left;
+    return AH_OK;
+}
+
+int ah_create_split(ah_dataset *ds, const uint32_t sample_ids[AH_SPLIT_SAMPLES], void *out_normal_vector,
+                    void *out_normal_header) {
+    AH_NEED_FINALIZED(ds);
+    AH_REQUIRE(sample_ids && out_normal_vector && out_normal_header, AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    AH_REQUIRE(ds->metric != AH_DOT_PRODUCT || ds->dot_preprocessed, AH_ERR_NEED_PREPROCESS,
+               "DotProduct needs ah_preprocess_dot before splits");
+    uint32_t rows[AH_SPLIT_SAMPLES];
+    for (int i = 0; i < AH_SPLIT_SAMPLES; i++) AH_TRY(host_row_of_id(ds, sample_ids[i], &rows[i]));
+    AH_LEASE(ds, ctx);
+    const size_t vs = ah_vector_size(ds->metric, ds->dims), hs = ah_header_size(ds->metric);
+    AH_TRY(ctx->ensure_device(pad256(ds->row_bytes()) + 1024));
+    AH_TRY(ctx->ensure_pinned(pad256(ds->row_bytes()) + 1024));
+    Carver dev(ctx->d_scratch), pin(ctx->h_pinned);
+    uint32_t *d_rows = dev.take<uint32_t>(AH_SPLIT_SAMPLES);
+    uint8_t *d_nv = dev.take<uint8_t>(ds->row_bytes());
+    float *d_nh = dev.take<float>(2);
+    uint32_t *h_rows = pin.take<uint32_t>(AH_SPLIT_SAMPLES);
+    uint8_t *h_nv = pin.take<uint8_t>(ds->row_bytes());
+    float *h_nh = pin.take<float>(2);
+    memcpy(h_rows, rows, sizeof rows);
+    AH_HIP(hipMemcpyAsync(d_rows, h_rows, sizeof rows, hipMemcpyHostToDevice, ctx->stream));
+    AH_TRY(launch_create_split(ds->view(), d_rows, d_nv, d_nh, ctx->stream));
+    AH_HIP(hipMemcpyAsync(h_nv, d_nv, ds->row_bytes(), hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipMemcpyAsync(h_nh, d_nh, 8, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out_normal_vector, h_nv, vs);
+    memcpy(out_normal_header, h_nh, hs);
+    return AH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// measurement helpers
+// ---------------------------------------------------------------------------------------------
+int ah_bench_scan(ah_dataset *ds, uint32_t query_item, uint64_t n, uint32_t iterations, float *out,
+                  double *out_ms_total) {
+    AH_NEED_FINALIZED(ds);
+    AH_REQUIRE(out_ms_total && iterations > 0 && n > 0 && n <= ds->n, AH_ERR_INVALID_ARGUMENT, "bad arguments");
+    AH_LEASE(ds, ctx);
+    QueryBufs qb;
+    Carver dev(nullptr), pin(nullptr);
+    AH_TRY(stage_query(ds, ctx, nullptr, &query_item, pad256(n * 4), 256, &qb, &dev, &pin));
+    float *d_out = dev.take<float>(n);
+    DataView dv = ds->view();
+    AH_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (uint32_t it = 0; it < iterations; it++)
+        AH_TRY(launch_distances(dv, qb.d_qvec, qb.d_qhdr, nullptr, n, d_out, qb.d_err, ctx->stream));
+    AH_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    AH_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0.0f;
+    AH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *out_ms_total = ms;
+    if (out) AH_HIP(hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost));
+    return AH_OK;
+}
+
+int ah_bench_memcpy(int device, uint64_t bytes, uint32_t iterations, double *out_ms_total) {
+    AH_REQUIRE(out_ms_total && iterations > 0 && bytes > 0, AH_ERR_INVALID_ARGUMENT, "bad arguments");
+    AH_HIP(hipSetDevice(device));
+    void *a = nullptr, *b = nullptr;
+    hipStream_t s;
+    hipEvent_t e0, e1;
+    AH_HIP(hipMalloc(&a, bytes));
+    AH_HIP(hipMalloc(&b, bytes));
+    AH_HIP(hipStreamCreate(&s));
+    AH_HIP(hipEventCreate(&e0));
+    AH_HIP(hipEventCreate(&e1));
+    AH_HIP(hipMemsetAsync(a, 1, bytes, s));
+    AH_HIP(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, s));
+    AH_HIP(hipEventRecord(e0, s));
+    for (uint32_t i = 0; i < iterations; i++) AH_HIP(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, s));
+    AH_HIP(hipEventRecord(e1, s));
+    AH_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    AH_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *out_ms_total = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(s);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    return AH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,159 @@
+// common.h — internal declarations shared by the translation units of libarroy_hip.so.
+// gfx950 (MI355X) only: wave = 64 lanes, hard-coded.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/arroy_hip.h"
+#include "../../include/arroy_hip_policy.h"
+
+namespace ah {
+
+// ---------------------------------------------------------------------------------------------
+// errors: thread-local text, integer codes across the ABI
+// ---------------------------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+const char *last_error();
+
+#define AH_HIP(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            ::ah::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return (_e == hipErrorOutOfMemory) ? AH_ERR_OUT_OF_MEMORY : AH_ERR_DEVICE;             \
+        }                                                                                          \
+    } while (0)
+
+#define AH_TRY(expr)                  \
+    do {                              \
+        int _s = (expr);              \
+        if (_s != AH_OK) return _s;   \
+    } while (0)
+
+#define AH_REQUIRE(cond, code, ...)       \
+    do {                                  \
+        if (!(cond)) {                    \
+            ::ah::set_error(__VA_ARGS__); \
+            return (code);                \
+        }                                 \
+    } while (0)
+
+inline bool metric_is_bq(int m) { return m >= AH_BQ_EUCLIDEAN && m <= AH_BQ_COSINE; }
+inline bool metric_valid(int m) { return m >= AH_EUCLIDEAN && m <= AH_BQ_COSINE; }
+inline uint32_t header_floats(int m) { return m == AH_DOT_PRODUCT ? 2u : 1u; }
+inline uint32_t bq_words(uint32_t dims) { return (dims + 63u) / 64u; }
+
+// ---------------------------------------------------------------------------------------------
+// Device-side view of a dataset (passed by value to kernels).
+//
+// HBM layout ("SoA of the LMDB record"): the stored record [tag][header][vector] is split into
+//   ids[n]            u32, ascending
+//   headers[n*hf]     f32, hf = 1 (bias | norm) or 2 (extra_dim, norm)
+//   rows              f32 metrics: n rows of `pitch` floats, pitch = round_up(dims, 32) so every row
+//                     starts on a 128-byte line and is read as whole lines by 8-lane groups;
+//                     BQ metrics: n rows of `pitch` 64-bit words (pitch = round_up(words, 2): 16-B rows)
+// plus an optional id -> row table.
+// ---------------------------------------------------------------------------------------------
+struct DataView {
+    int metric;
+    uint32_t dims;
+    uint32_t pitch;        // floats (f32 metrics) or u64 words (BQ)
+    uint32_t words;        // BQ: ceil(dims/64); else 0
+    uint64_t n;
+    const float *rows_f32;
+    const uint64_t *rows_bq;
+    float *headers;
+    const uint32_t *ids;
+    const uint32_t *lut;   // dense id -> row (0xFFFFFFFF = absent) or nullptr
+    uint32_t lut_len;
+    int identity_ids;      // ids are exactly 0..n-1
+};
+
+// One per concurrently calling host thread: a stream plus growable device / pinned scratch.
+struct Context {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void *d_scratch = nullptr;
+    size_t d_cap = 0;
+    void *h_pinned = nullptr;
+    size_t h_cap = 0;
+    int ensure_device(size_t bytes);
+    int ensure_pinned(size_t bytes);
+    void destroy();
+};
+
+}  // namespace ah
+
+struct ah_dataset {
+    int metric = 0;
+    uint32_t dims = 0;
+    uint32_t pitch = 0;
+    uint32_t words = 0;
+    uint64_t n = 0, capacity = 0;
+    int device = 0;
+    bool finalized = false;
+    bool dot_preprocessed = false;
+    float *d_rows_f32 = nullptr;
+    uint64_t *d_rows_bq = nullptr;
+    float *d_headers = nullptr;
+    uint32_t *d_ids = nullptr;
+    uint32_t *d_lut = nullptr;
+    uint32_t lut_len = 0;
+    bool identity_ids = true;
+    uint32_t last_id = 0;
+    std::vector<uint32_t> h_ids;     // host mirror of ids (ascending) for id validation / lookups
+    std::mutex mu;
+    std::vector<ah::Context *> pool;
+
+    ah::DataView view() const;
+    size_t row_bytes() const { return ah::metric_is_bq(metric) ? (size_t)pitch * 8 : (size_t)pitch * 4; }
+    ah::Context *acquire();
+    void release(ah::Context *c);
+};
+
+namespace ah {
+
+struct ContextLease {
+    ah_dataset *ds;
+    Context *c;
+    explicit ContextLease(ah_dataset *d) : ds(d), c(d->acquire()) {}
+    ~ContextLease() {
+        if (c) ds->release(c);
+    }
+};
+
+// ---- launchers implemented in the kernel translation units ------------------------------------
+// distance.hip
+int launch_prepare_query(const DataView &dv, const float *d_query_f32, void *d_qvec, float *d_qhdr, hipStream_t s);
+int launch_load_item_as_query(const DataView &dv, uint32_t row, void *d_qvec, float *d_qhdr, hipStream_t s);
+// distances of `n` rows: rows given by d_ids (item ids, may be nullptr = rows 0..n-1). d_err: u32 flags.
+int launch_distances(const DataView &dv, const void *d_qvec, const float *d_qhdr, const uint32_t *d_ids, uint64_t n,
+                     float *d_out, uint32_t *d_err, hipStream_t s);
+size_t topk_scratch_bytes(uint64_t n, size_t k);
+int launch_topk(const DataView &dv, const float *d_dist, const uint32_t *d_ids, uint64_t n, size_t k, void *d_scratch,
+                uint32_t *d_out_ids, float *d_out_dist, hipStream_t s);
+int launch_headers_from_vectors(const DataView &dv, uint64_t first_row, uint64_t n, hipStream_t s);
+int launch_quantize_rows(const float *d_src, uint32_t src_pitch, uint32_t dims, uint64_t *d_dst, uint32_t dst_pitch,
+                         uint32_t words, uint64_t n, hipStream_t s);
+int launch_synth_fill(float *d_rows, uint32_t pitch, uint32_t dims, uint64_t first_item, uint64_t n, uint64_t seed,
+                      int distribution, hipStream_t s);
+int launch_build_lut(const uint32_t *d_ids, uint64_t n, uint32_t *d_lut, uint32_t lut_len, hipStream_t s);
+int launch_preprocess_dot(const DataView &dv, float *d_max_norm_bits, hipStream_t s);
+int launch_decode_item(const DataView &dv, uint32_t row, float *d_out, hipStream_t s);
+
+// split.hip
+int launch_split_sides(const DataView &dv, const void *d_nvec, const float *d_nhdr, const uint32_t *d_ids, uint64_t n,
+                       uint8_t *d_side_bits, unsigned long long *d_n_left, float *d_margins, uint32_t *d_err,
+                       hipStream_t s);
+int launch_create_split(const DataView &dv, const uint32_t *d_sample_rows, void *d_out_vec, float *d_out_hdr,
+                        hipStream_t s);
+
+}  // namespace ah

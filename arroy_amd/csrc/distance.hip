@@ -1,0 +1,589 @@
+// distance.hip — batched distance kernels, query preparation, top-k and dataset helper kernels.
+//
+// Replaces the re-rank loop of arroy's search (src/reader.rs:381-399) and the per-pair SIMD kernels it
+// calls (src/spaces/simple_avx.rs, simple_sse.rs, simple.rs).  All kernels are HBM-bound vector
+// contractions (0.5 flop/byte): no MFMA.  See device_math.h for the lane mapping that makes every f32
+// result bit-identical to the reference's AVX+FMA tier.
+#include "common.h"
+#include "device_math.h"
+
+namespace ah {
+
+static constexpr int kBlock = 256;       // 4 waves = 32 octets
+static constexpr int kMaxBlocks = 2048;  // 256 CUs x 8 blocks: grid-stride beyond that
+
+static inline unsigned grid_for(uint64_t work_items, int items_per_block) {
+    uint64_t b = (work_items + items_per_block - 1) / items_per_block;
+    if (b < 1) b = 1;
+    if (b > (uint64_t)kMaxBlocks) b = kMaxBlocks;
+    return (unsigned)b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Query preparation: `QueryBuilder::by_vector` (src/reader.rs:64-75) = codec + D::new_header.
+// One 64-thread block.  qvec gets `pitch` elements (zero padded).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_prepare_query(DataView dv, const float *__restrict__ q_f32, void *qvec, float *qhdr) {
+    const uint32_t t = threadIdx.x;
+    if (!metric_is_bq_dev(dv.metric)) {
+        float *dst = reinterpret_cast<float *>(qvec);
+        for (uint32_t i = t; i < dv.pitch; i += blockDim.x) dst[i] = i < dv.dims ? q_f32[i] : 0.0f;
+        __syncthreads();
+        if (t < 8) {
+            float hdr0 = 0.0f;
+            if (dv.metric == AH_COSINE) {  // cosine.rs:39-41: norm = sqrt(dot(v,v))
+                float d = octet_reduce_any<OP_DOT>(dst, dst, dv.dims, t);
+                hdr0 = f_sqrt(d);
+            }
+            if (t == 0) {
+                qhdr[0] = hdr0;
+                qhdr[1] = 0.0f;
+            }
+        }
+    } else {
+        uint64_t *dst = reinterpret_cast<uint64_t *>(qvec);
+        for (uint32_t w = t; w < dv.pitch; w += blockDim.x) {
+            uint64_t word = 0;
+            if (w < dv.words) {  // binary_quantized.rs:80-91: bit i = is_sign_positive(x[64w+i])
+                for (uint32_t i = 0; i < 64; i++) {
+                    uint32_t e = 64 * w + i;
+                    if (e < dv.dims) word |= (uint64_t)((__float_as_uint(q_f32[e]) >> 31) == 0u) << i;
+                }
+            }
+            dst[w] = word;
+        }
+        if (t == 0) {
+            // bq_cosine.rs:45-47: norm = sqrt(bqdot(v,v)) = sqrt(64*words); others: bias 0
+            qhdr[0] = dv.metric == AH_BQ_COSINE ? f_sqrt((float)(int32_t)(64u * dv.words)) : 0.0f;
+            qhdr[1] = 0.0f;
+        }
+    }
+}
+
+__global__ void k_load_item_as_query(DataView dv, uint32_t row, void *qvec, float *qhdr) {
+    const uint32_t t = threadIdx.x;
+    if (!metric_is_bq_dev(dv.metric)) {
+        float *dst = reinterpret_cast<float *>(qvec);
+        const float *src = dv.rows_f32 + (uint64_t)row * dv.pitch;
+        for (uint32_t i = t; i < dv.pitch; i += blockDim.x) dst[i] = src[i];
+    } else {
+        uint64_t *dst = reinterpret_cast<uint64_t *>(qvec);
+        const uint64_t *src = dv.rows_bq + (uint64_t)row * dv.pitch;
+        for (uint32_t i = t; i < dv.pitch; i += blockDim.x) dst[i] = src[i];
+    }
+    if (t == 0) {
+        const uint32_t hf = dv.metric == AH_DOT_PRODUCT ? 2u : 1u;
+        qhdr[0] = dv.headers[(uint64_t)row * hf];
+        qhdr[1] = hf == 2 ? dv.headers[(uint64_t)row * hf + 1] : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32 distance scan / gather, dims >= 32.  One octet per row, grid-stride over rows.
+//   METRIC in {EUCLIDEAN, MANHATTAN, COSINE, DOT_PRODUCT};  GATHER: rows addressed through item ids.
+// Algorithmic traffic per distance: 4*dims (+4 header for cosine) read + 4 written (+4 id if GATHER).
+// ------------------------------------------------------------------------------------------------
+template <int METRIC>
+__device__ __forceinline__ float f32_epilogue(float r, const float *qhdr, const DataView &dv, uint64_t row) {
+    if (METRIC == AH_COSINE) return cosine_from_dot(r, qhdr[0], dv.headers[row]);
+    if (METRIC == AH_DOT_PRODUCT) return -r;  // dot_product.rs:52-56
+    return r;                                 // euclidean.rs:45-47 / manhattan.rs:44-46
+}
+
+template <int METRIC, bool GATHER>
+__global__ __launch_bounds__(kBlock) void k_distances_f32(DataView dv, const float *__restrict__ qvec,
+                                                          const float *__restrict__ qhdr,
+                                                          const uint32_t *__restrict__ ids, uint64_t n,
+                                                          float *__restrict__ out, uint32_t *err) {
+    constexpr int OP = METRIC == AH_EUCLIDEAN ? OP_EUCLID : OP_DOT;
+    extern __shared__ float4 s_q4[];
+    const uint32_t nq4 = dv.pitch >> 2;
+    for (uint32_t i = threadIdx.x; i < nq4; i += blockDim.x) s_q4[i] = reinterpret_cast<const float4 *>(qvec)[i];
+    __shared__ float s_hdr[2];
+    if (threadIdx.x < 2) s_hdr[threadIdx.x] = qhdr[threadIdx.x];
+    __syncthreads();
+    const float *s_q = reinterpret_cast<const float *>(s_q4);
+
+    const uint32_t j = threadIdx.x & 7u;
+    const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+    const uint32_t blocks = dv.dims >> 5;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < n; i += n_octets) {
+        uint64_t row = i;
+        if (GATHER) {
+            row = row_of_id(dv, ids[i]);
+            if (row == ~0ull) {  // Error::MissingKey (src/reader.rs:383-384)
+                if (j == 0) {
+                    atomicOr(err, 1u);
+                    out[i] = __uint_as_float(0x7FC00000u);
+                }
+                continue;
+            }
+            if (i > 0 && ids[i] <= ids[i - 1] && j == 0) atomicOr(err, 2u);  // contract: ascending, unique
+        }
+        const float *rp = dv.rows_f32 + row * dv.pitch;
+        float r;
+        if (METRIC == AH_MANHATTAN) {
+            r = octet_manhattan(s_q, rp, dv.dims, j);
+        } else {
+            const float4 *r4 = reinterpret_cast<const float4 *>(rp) + j;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint32_t k = 0;
+            // 8 line-loads in flight per lane (128 B/lane, 8 KiB/wave) before the first use
+            for (; k + 8 <= blocks; k += 8) {
+                float4 x[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) x[u] = ld_stream(r4 + (k + u) * 8);
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    fma_step<OP>(acc, s_q4[(k + u) * 8 + j], x[u]);
+            }
+            for (; k < blocks; k++)
+                fma_step<OP>(acc, s_q4[k * 8 + j], r4[k * 8]);
+            r = octet_finish(acc);
+            r = scalar_tail<OP>(r, s_q, rp, blocks << 5, dv.dims);
+        }
+        if (j == 0) out[i] = f32_epilogue<METRIC>(r, s_hdr, dv, row);
+    }
+}
+
+// dims < 32: SSE / scalar tiers, one thread per row (test-sized inputs; not a performance path).
+template <int METRIC, bool GATHER>
+__global__ __launch_bounds__(kBlock) void k_distances_f32_small(DataView dv, const float *__restrict__ qvec,
+                                                                const float *__restrict__ qhdr,
+                                                                const uint32_t *__restrict__ ids, uint64_t n,
+                                                                float *__restrict__ out, uint32_t *err) {
+    constexpr int OP = METRIC == AH_EUCLIDEAN ? OP_EUCLID : OP_DOT;
+    __shared__ float s_q[32];
+    __shared__ float s_hdr[2];
+    if (threadIdx.x < 32) s_q[threadIdx.x] = threadIdx.x < dv.dims ? qvec[threadIdx.x] : 0.0f;
+    if (threadIdx.x < 2) s_hdr[threadIdx.x] = qhdr[threadIdx.x];
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t row = i;
+        if (GATHER) {
+            row = row_of_id(dv, ids[i]);
+            if (row == ~0ull) {
+                atomicOr(err, 1u);
+                out[i] = __uint_as_float(0x7FC00000u);
+                continue;
+            }
+            if (i > 0 && ids[i] <= ids[i - 1]) atomicOr(err, 2u);
+        }
+        const float *rp = dv.rows_f32 + row * dv.pitch;
+        float r;
+        if (METRIC == AH_MANHATTAN) {
+            r = 0.0f;
+            for (uint32_t e = 0; e < dv.dims; e++) r = f_add(r, fabsf(f_sub(s_q[e], rp[e])));
+        } else {
+            r = thread_reduce_small<OP>(s_q, rp, dv.dims);
+        }
+        out[i] = f32_epilogue<METRIC>(r, s_hdr, dv, row);
+    }
+}
+
+// 1-bit metrics: one thread per row, 16-byte loads (rows are 16-byte multiples).
+// Algorithmic traffic per distance: 8*words (+4 header for BQ-cosine) read + 4 written.
+template <bool GATHER>
+__global__ __launch_bounds__(kBlock) void k_distances_bq(DataView dv, const uint64_t *__restrict__ qvec,
+                                                         const float *__restrict__ qhdr,
+                                                         const uint32_t *__restrict__ ids, uint64_t n,
+                                                         float *__restrict__ out, uint32_t *err) {
+    extern __shared__ uint64_t s_qw[];
+    for (uint32_t i = threadIdx.x; i < dv.pitch; i += blockDim.x) s_qw[i] = qvec[i];
+    __shared__ float s_hdr[2];
+    if (threadIdx.x < 2) s_hdr[threadIdx.x] = qhdr[threadIdx.x];
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t pairs = dv.pitch >> 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t row = i;
+        if (GATHER) {
+            row = row_of_id(dv, ids[i]);
+            if (row == ~0ull) {
+                atomicOr(err, 1u);
+                out[i] = __uint_as_float(0x7FC00000u);
+                continue;
+            }
+            if (i > 0 && ids[i] <= ids[i - 1]) atomicOr(err, 2u);
+        }
+        const ulonglong2 *rp = reinterpret_cast<const ulonglong2 *>(dv.rows_bq + row * dv.pitch);
+        uint32_t ham = 0;
+        for (uint32_t p = 0; p < pairs; p++) {
+            ulonglong2 v = rp[p];
+            ham += (uint32_t)__popcll(v.x ^ s_qw[2 * p]) + (uint32_t)__popcll(v.y ^ s_qw[2 * p + 1]);
+        }
+        float d;
+        if (dv.metric == AH_BQ_EUCLIDEAN) d = (float)(ham * 4u);       // bq_euclidean.rs:117-124
+        else if (dv.metric == AH_BQ_MANHATTAN) d = (float)(ham * 2u);  // bq_manhattan.rs:113-120
+        else d = bq_cosine_from_dot((float)bq_dot_from_hamming(ham, dv.words), s_hdr[0], dv.headers[row]);
+        out[i] = d;
+    }
+}
+
+template <bool GATHER>
+static int launch_distances_t(const DataView &dv, const void *qvec, const float *qhdr, const uint32_t *ids, uint64_t n,
+                              float *out, uint32_t *err, hipStream_t s) {
+    if (n == 0) return AH_OK;
+    if (metric_is_bq(dv.metric)) {
+        hipLaunchKernelGGL((k_distances_bq<GATHER>), dim3(grid_for(n, kBlock)), dim3(kBlock), dv.pitch * 8, s, dv,
+                           (const uint64_t *)qvec, qhdr, ids, n, out, err);
+    } else if (dv.dims >= 32) {
+        const unsigned g = grid_for(n, kBlock / 8);
+        const size_t sh = (size_t)dv.pitch * 4;
+#define AH_LAUNCH_F32(M)                                                                                          \
+    hipLaunchKernelGGL((k_distances_f32<M, GATHER>), dim3(g), dim3(kBlock), sh, s, dv, (const float *)qvec, qhdr, \
+                       ids, n, out, err)
+        switch (dv.metric) {
+        case AH_EUCLIDEAN: AH_LAUNCH_F32(AH_EUCLIDEAN); break;
+        case AH_MANHATTAN: AH_LAUNCH_F32(AH_MANHATTAN); break;
+        case AH_COSINE: AH_LAUNCH_F32(AH_COSINE); break;
+        default: AH_LAUNCH_F32(AH_DOT_PRODUCT); break;
+        }
+#undef AH_LAUNCH_F32
+    } else {
+        const unsigned g = grid_for(n, kBlock);
+#define AH_LAUNCH_SMALL(M)                                                                                      \
+    hipLaunchKernelGGL((k_distances_f32_small<M, GATHER>), dim3(g), dim3(kBlock), 0, s, dv, (const float *)qvec, \
+                       qhdr, ids, n, out, err)
+        switch (dv.metric) {
+        case AH_EUCLIDEAN: AH_LAUNCH_SMALL(AH_EUCLIDEAN); break;
+        case AH_MANHATTAN: AH_LAUNCH_SMALL(AH_MANHATTAN); break;
+        case AH_COSINE: AH_LAUNCH_SMALL(AH_COSINE); break;
+        default: AH_LAUNCH_SMALL(AH_DOT_PRODUCT); break;
+        }
+#undef AH_LAUNCH_SMALL
+    }
+    AH_HIP(hipGetLastError());
+    return AH_OK;
+}
+
+int launch_distances(const DataView &dv, const void *d_qvec, const float *d_qhdr, const uint32_t *d_ids, uint64_t n,
+                     float *d_out, uint32_t *d_err, hipStream_t s) {
+    return d_ids ? launch_distances_t<true>(dv, d_qvec, d_qhdr, d_ids, n, d_out, d_err, s)
+                 : launch_distances_t<false>(dv, d_qvec, d_qhdr, nullptr, n, d_out, d_err, s);
+}
+
+int launch_prepare_query(const DataView &dv, const float *d_query_f32, void *d_qvec, float *d_qhdr, hipStream_t s) {
+    hipLaunchKernelGGL(k_prepare_query, dim3(1), dim3(64), 0, s, dv, d_query_f32, d_qvec, d_qhdr);
+    AH_HIP(hipGetLastError());
+    return AH_OK;
+}
+int launch_load_item_as_query(const DataView &dv, uint32_t row, void *d_qvec, float *d_qhdr, hipStream_t s) {
+    hipLaunchKernelGGL(k_load_item_as_query, dim3(1), dim3(64), 0, s, dv, row, d_qvec, d_qhdr);
+    AH_HIP(hipGetLastError());
+    return AH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-k: `median_based_top_k` (src/reader.rs:607-640) = the k smallest (OrderedFloat(dist), id) tuples
+// in ascending order.  Candidates arrive in ascending id order, so the POSITION in the candidate list
+// is used as the tie-break word: same order as the id, and it recovers the original distance and id.
+// Key = orderable(dist) << 32 | position.  A tournament of LDS bitonic sorts: every block sorts a chunk
+// of kChunk keys and keeps its `keep` smallest; rounds repeat until one block is left.
+// Faithful quirk: the reference skips items >= (f32::MAX, u32::MAX) once its 2k prefill buffer is full
+// (reader.rs:611,619-621); such items at positions >= 2k get the sentinel key and are never selected.
+// ------------------------------------------------------------------------------------------------
+static constexpr uint32_t kChunk = 4096;
+static constexpr uint64_t kSentinel = ~0ull;
+
+__device__ __forceinline__ uint64_t make_key(float d, uint64_t pos, uint32_t id, uint64_t two_k) {
+    uint32_t ok = orderable_key(d);
+    if (pos >= two_k) {
+        // item >= threshold (OrderedFloat(f32::MAX), u32::MAX)
+        const uint32_t max_key = 0xFF7FFFFFu;  // orderable_key(f32::MAX)
+        if (ok > max_key || (ok == max_key && id == 0xFFFFFFFFu)) return kSentinel;
+    }
+    return ((uint64_t)ok << 32) | (uint64_t)(uint32_t)pos;
+}
+
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t *s, uint32_t n_pow2) {
+    for (uint32_t size = 2; size <= n_pow2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < (n_pow2 >> 1); t += blockDim.x) {
+                uint32_t lo = 2 * t - (t & (stride - 1));
+                uint32_t hi = lo + stride;
+                bool up = (lo & size) == 0;
+                uint64_t a = s[lo], b = s[hi];
+                if ((a > b) == up) {
+                    s[lo] = b;
+                    s[hi] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// FIRST round reads distances and builds keys; later rounds read keys.
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock) void k_topk_round(const float *__restrict__ dist, const uint32_t *__restrict__ ids,
+                                                       const uint32_t *__restrict__ row_ids, int have_ids,
+                                                       const uint64_t *__restrict__ keys_in, uint64_t n_in,
+                                                       uint64_t two_k, uint32_t keep, uint64_t *__restrict__ keys_out) {
+    __shared__ uint64_t s[kChunk];
+    const uint64_t base = (uint64_t)blockIdx.x * kChunk;
+    for (uint32_t t = threadIdx.x; t < kChunk; t += blockDim.x) {
+        uint64_t g = base + t;
+        uint64_t key = kSentinel;
+        if (g < n_in) {
+            if (FIRST) {
+                uint32_t id = have_ids ? ids[g] : (row_ids ? row_ids[g] : (uint32_t)g);
+                key = make_key(dist[g], g, id, two_k);
+            } else {
+                key = keys_in[g];
+            }
+        }
+        s[t] = key;
+    }
+    bitonic_sort_lds(s, kChunk);
+    for (uint32_t t = threadIdx.x; t < keep; t += blockDim.x) keys_out[(uint64_t)blockIdx.x * keep + t] = s[t];
+}
+
+// Global-memory bitonic step for k > kChunk/2 (rare: `count` in the thousands).
+__global__ void k_bitonic_global(uint64_t *keys, uint64_t n_pow2, uint64_t size, uint64_t stride) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (n_pow2 >> 1)) return;
+    uint64_t lo = 2 * t - (t & (stride - 1));
+    uint64_t hi = lo + stride;
+    bool up = (lo & size) == 0;
+    uint64_t a = keys[lo], b = keys[hi];
+    if ((a > b) == up) {
+        keys[lo] = b;
+        keys[hi] = a;
+    }
+}
+__global__ void k_make_keys(const float *dist, const uint32_t *ids, const uint32_t *row_ids, int have_ids, uint64_t n,
+                            uint64_t n_pow2, uint64_t two_k, uint64_t *keys) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_pow2) return;
+    uint64_t key = kSentinel;
+    if (g < n) {
+        uint32_t id = have_ids ? ids[g] : (row_ids ? row_ids[g] : (uint32_t)g);
+        key = make_key(dist[g], g, id, two_k);
+    }
+    keys[g] = key;
+}
+
+// Final: sorted keys -> (id, normalized distance).  src/reader.rs:396-399.
+__global__ void k_topk_emit(DataView dv, const uint64_t *__restrict__ keys, const float *__restrict__ dist,
+                            const uint32_t *__restrict__ ids, size_t k, uint32_t *out_ids, float *out_dist) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= k) return;
+    uint64_t key = keys[t];
+    uint32_t pos = (uint32_t)key;
+    uint32_t id = ids ? ids[pos] : (dv.identity_ids ? pos : dv.ids[pos]);
+    out_ids[t] = id;
+    out_dist[t] = normalized_distance(dv.metric, dist[pos], dv.dims);
+}
+
+static uint64_t next_pow2(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+size_t topk_scratch_bytes(uint64_t n, size_t k) {
+    if (k > kChunk / 2) return next_pow2(n) * 8 + 64;
+    uint64_t blocks = (n + kChunk - 1) / kChunk;
+    return (size_t)(blocks * (uint64_t)kChunk * 8 * 2 + 64);  // two ping-pong key buffers (upper bound)
+}
+
+// k = min(count, n) already; d_ids == nullptr means "positions are rows" (ids from the dataset).
+int launch_topk(const DataView &dv, const float *d_dist, const uint32_t *d_ids, uint64_t n, size_t k, void *d_scratch,
+                uint32_t *d_out_ids, float *d_out_dist, hipStream_t s) {
+    if (k == 0 || n == 0) return AH_OK;
+    const uint64_t two_k = 2 * (uint64_t)k;
+    const uint32_t *row_ids = (d_ids == nullptr && !dv.identity_ids) ? dv.ids : nullptr;
+    uint64_t *bufA = reinterpret_cast<uint64_t *>(d_scratch);
+    const uint64_t *sorted = nullptr;
+    if (k > kChunk / 2) {
+        const uint64_t np = next_pow2(n);
+        hipLaunchKernelGGL(k_make_keys, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, d_dist, d_ids, row_ids,
+                           d_ids != nullptr, n, np, two_k, bufA);
+        for (uint64_t size = 2; size <= np; size <<= 1)
+            for (uint64_t stride = size >> 1; stride > 0; stride >>= 1)
+                hipLaunchKernelGGL(k_bitonic_global, dim3((unsigned)(((np >> 1) + 255) / 256)), dim3(256), 0, s, bufA,
+                                   np, size, stride);
+        sorted = bufA;
+    } else {
+        uint64_t blocks = (n + kChunk - 1) / kChunk;
+        uint64_t *bufB = bufA + blocks * kChunk;
+        const uint32_t keep = (uint32_t)(blocks == 1 ? k : (k < kChunk / 2 ? k : kChunk / 2));
+        hipLaunchKernelGGL((k_topk_round<true>), dim3((unsigned)blocks), dim3(kBlock), 0, s, d_dist, d_ids, row_ids,
+                           d_ids != nullptr, (const uint64_t *)nullptr, n, two_k, keep, bufA);
+        uint64_t n_cur = blocks * keep;
+        uint64_t *cur = bufA, *nxt = bufB;
+        while (blocks > 1) {
+            blocks = (n_cur + kChunk - 1) / kChunk;
+            hipLaunchKernelGGL((k_topk_round<false>), dim3((unsigned)blocks), dim3(kBlock), 0, s, (const float *)nullptr,
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0, (const uint64_t *)cur, n_cur,
+                               two_k, keep, nxt);
+            n_cur = blocks * keep;
+            uint64_t *tmp = cur;
+            cur = nxt;
+            nxt = tmp;
+        }
+        sorted = cur;
+    }
+    hipLaunchKernelGGL(k_topk_emit, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, s, dv, sorted, d_dist, d_ids, k,
+                       d_out_ids, d_out_dist);
+    AH_HIP(hipGetLastError());
+    return AH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dataset helper kernels
+// ------------------------------------------------------------------------------------------------
+
+// D::new_header for freshly uploaded rows (src/writer.rs:380-394 -> cosine.rs:39-41, bq_cosine.rs:45-47).
+__global__ __launch_bounds__(kBlock) void k_headers_from_vectors(DataView dv, uint64_t first_row, uint64_t n) {
+    const uint32_t hf = dv.metric == AH_DOT_PRODUCT ? 2u : 1u;
+    if (dv.metric == AH_COSINE) {
+        const uint32_t j = threadIdx.x & 7u;
+        const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+        for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < n; i += n_octets) {
+            const float *rp = dv.rows_f32 + (first_row + i) * dv.pitch;
+            float d = octet_reduce_any<OP_DOT>(rp, rp, dv.dims, j);
+            if (j == 0) dv.headers[first_row + i] = f_sqrt(d);
+        }
+    } else {
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            float h0 = 0.0f;
+            if (dv.metric == AH_BQ_COSINE) h0 = f_sqrt((float)(int32_t)(64u * dv.words));
+            dv.headers[(first_row + i) * hf] = h0;
+            if (hf == 2) dv.headers[(first_row + i) * hf + 1] = 0.0f;
+        }
+    }
+}
+int launch_headers_from_vectors(const DataView &dv, uint64_t first_row, uint64_t n, hipStream_t s) {
+    if (n == 0) return AH_OK;
+    hipLaunchKernelGGL(k_headers_from_vectors, dim3(grid_for(n, kBlock / 8)), dim3(kBlock), 0, s, dv, first_row, n);
+    AH_HIP(hipGetLastError());
+    return AH_OK;
+}
+
+// UnalignedVector::<BinaryQuantized>::from_slice for n rows (binary_quantized.rs:80-91): one thread per word.
+__global__ void k_quantize_rows(const float *__restrict__ src, uint32_t src_pitch, uint32_t dims,
+                                uint64_t *__restrict__ dst, uint32_t dst_pitch, uint32_t words, uint64_t n) {
+    const uint64_t total = n * dst_pitch;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const uint64_t row = g / dst_pitch;
+        const uint32_t w = (uint32_t)(g % dst_pitch);
+        uint64_t word = 0;
+        if (w < words) {
+            const float *rp = src + row * src_pitch;
+            for (uint32_t i = 0; i < 64; i++) {
+                uint32_t e = 64 * w + i;
+                if (e < dims) word |= (uint64_t)((__float_as_uint(rp[e]) >> 31) == 0u) << i;
+            }
+        }
+        dst[g] = word;
+    }
+}
+int launch_quantize_rows(const float *d_src, uint32_t src_pitch, uint32_t dims, uint64_t *d_dst, uint32_t dst_pitch,
+                         uint32_t words, uint64_t n, hipStream_t s) {
+    if (n == 0) return AH_OK;
+    hipLaunchKernelGGL(k_quantize_rows, dim3(grid_for(n * dst_pitch, 256)), dim3(256), 0, s, d_src, src_pitch, dims,
+                       d_dst, dst_pitch, words, n);
+    AH_HIP(hipGetLastError());
+    return AH_OK;
+}
+
+// Synthetic rows (include/arroy_hip_policy.h): one thread per float4 of the padded row.
+__global__ void k_synth_fill(float *__restrict__ rows, uint32_t pitch, uint32_t dims, uint64_t first_item, uint64_t n,
+                             uint64_t seed, int distribution) {
+    const uint64_t per_row = pitch >> 2;
+    const uint64_t total = n * per_row;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const uint64_t row = g / per_row;
+        const uint32_t c = (uint32_t)(g % per_row) * 4;
+        float4 v;
+        v.x = c + 0 < dims ? ah_synth_value(seed, first_item + row, c + 0, dims, distribution) : 0.0f;
+        v.y = c + 1 < dims ? ah_synth_value(seed, first_item + row, c + 1, dims, distribution) : 0.0f;
+        v.z = c + 2 < dims ? ah_synth_value(seed, first_item + row, c + 2, dims, distribution) : 0.0f;
+        v.w = c + 3 < dims ? ah_synth_value(seed, first_item + row, c + 3, dims, distribution) : 0.0f;
+        reinterpret_cast<float4 *>(rows)[g] = v;
+    }
+}
+int launch_synth_fill(float *d_rows, uint32_t pitch, uint32_t dims, uint64_t first_item, uint64_t n, uint64_t seed,
+                      int distribution, hipStream_t s) {
+    if (n == 0) return AH_OK;
+    hipLaunchKernelGGL(k_synth_fill, dim3(grid_for(n * (pitch >> 2), 256)), dim3(256), 0, s, d_rows, pitch, dims,
+                       first_item, n, seed, distribution);
+    AH_HIP(hipGetLastError());
+    return AH_OK;
+}
+
+__global__ void k_build_lut(const uint32_t *__restrict__ ids, uint64_t n, uint32_t *__restrict__ lut) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += stride) lut[ids[g]] = (uint32_t)g;
+}
+int launch_build_lut(const uint32_t *d_ids, uint64_t n, uint32_t *d_lut, uint32_t lut_len, hipStream_t s) {
+    AH_HIP(hipMemsetAsync(d_lut, 0xFF, (size_t)lut_len * 4, s));
+    if (n) hipLaunchKernelGGL(k_build_lut, dim3(grid_for(n, 256)), dim3(256), 0, s, d_ids, n, d_lut);
+    AH_HIP(hipGetLastError());
+    return AH_OK;
+}
+
+// DotProduct::preprocess (src/distance/dot_product.rs:119-165).  Pass 1: max over items of
+// sqrt(dot(v,v)) (f32::max ignores NaN; norms are >= 0 so the u32 bit pattern orders like the float).
+// Pass 2: norm = max*max, extra_dim = sqrt(max*max - |v|*|v|).
+__global__ __launch_bounds__(kBlock) void k_dot_max_norm(DataView dv, unsigned int *max_bits) {
+    const uint32_t j = threadIdx.x & 7u;
+    const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < dv.n; i += n_octets) {
+        const float *rp = dv.rows_f32 + i * dv.pitch;
+        float nrm = f_sqrt(octet_reduce_any<OP_DOT>(rp, rp, dv.dims, j));
+        if (j == 0 && nrm == nrm) atomicMax(max_bits, __float_as_uint(fmaxf(nrm, 0.0f)));
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_dot_write_headers(DataView dv, const unsigned int *max_bits) {
+    const float max_norm = __uint_as_float(*max_bits);
+    const float m2 = f_mul(max_norm, max_norm);
+    const uint32_t j = threadIdx.x & 7u;
+    const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < dv.n; i += n_octets) {
+        const float *rp = dv.rows_f32 + i * dv.pitch;
+        float nrm = f_sqrt(octet_reduce_any<OP_DOT>(rp, rp, dv.dims, j));
+        if (j == 0) {
+            float diff = f_sub(m2, f_mul(nrm, nrm));
+            dv.headers[2 * i + 0] = f_sqrt(diff);  // extra_dim
+            dv.headers[2 * i + 1] = m2;            // norm
+        }
+    }
+}
+int launch_preprocess_dot(const DataView &dv, float *d_max_norm_bits, hipStream_t s) {
+    AH_HIP(hipMemsetAsync(d_max_norm_bits, 0, 4, s));
+    if (dv.n) {
+        const unsigned g = grid_for(dv.n, kBlock / 8);
+        hipLaunchKernelGGL(k_dot_max_norm, dim3(g), dim3(kBlock), 0, s, dv, (unsigned int *)d_max_norm_bits);
+        hipLaunchKernelGGL(k_dot_write_headers, dim3(g), dim3(kBlock), 0, s, dv, (const unsigned int *)d_max_norm_bits);
+    }
+    AH_HIP(hipGetLastError());
+    return AH_OK;
+}
+
+// Reader::item_vector (src/reader.rs:266-276): f32 codec = the floats; BQ codec = +-1.0 per bit
+// (binary_quantized.rs:261-290), truncated to `dims`.
+__global__ void k_decode_item(DataView dv, uint32_t row, float *out) {
+    for (uint32_t i = threadIdx.x; i < dv.dims; i += blockDim.x) {
+        if (!metric_is_bq_dev(dv.metric)) {
+            out[i] = dv.rows_f32[(uint64_t)row * dv.pitch + i];
+        } else {
+            uint64_t w = dv.rows_bq[(uint64_t)row * dv.pitch + (i >> 6)];
+            out[i] = f_sub(f_mul((float)((w >> (i & 63)) & 1ull), 2.0f), 1.0f);
+        }
+    }
+}
+int launch_decode_item(const DataView &dv, uint32_t row, float *d_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_decode_item, dim3(1), dim3(256), 0, s, dv, row, d_out);
+    AH_HIP(hipGetLastError());
+    return AH_OK;
+}
+
+}  // namespace ah

@@ -1,0 +1,714 @@
+// forest.hip — whole-forest build on one GPU: `make_tree_in_file` (src/writer.rs:1167-1261) for every tree
+// of the batch, level-synchronously.
+//
+// The reference recurses depth-first per tree under rayon (src/writer.rs:568-591,798-828); every node of
+// every tree at the same depth is independent, so here ONE set of launches handles one level of ALL trees:
+//
+//   per level   create_split (one wave per node)  ->  margins + sides over node-major tiles (the HBM-bound
+//               pass: 4*dims bytes per (item, node visit))  ->  accept / retry (<= 4 attempts,
+//               src/writer.rs:1193-1216)  ->  random fallback (:1220-1227)  ->  stable partition of every
+//               node's id list into its two children (ascending ids preserved, :1230-1231).
+//
+// Item lists live in HBM as one permutation of row indices per tree: a node owns perm[start, start+count),
+// its children subdivide that range, so positions never move between nodes.  Randomness is the
+// counter-based policy of include/arroy_hip_policy.h: a pure function of (tree_seed, node path, attempt,
+// draw), so this breadth-first build and the depth-first CPU oracle produce the same forest bit for bit.
+// No atomics on floats, no dependence on workgroup scheduling: results are deterministic.
+#include <algorithm>
+#include <chrono>
+#include <new>
+
+#include "common.h"
+#include "split_device.h"
+
+namespace ah {
+
+static constexpr uint32_t kTile = 2048;  // items per tile = 32 octets x 64 items
+static constexpr int kBlock = 256;
+static constexpr int kMaxBlocks = 4096;
+
+enum { ST_PENDING = 0, ST_ACCEPTED = 1, ST_RANDOM = 2 };
+
+struct FNode {
+    uint64_t key;      // ah_node_key_* of this node
+    uint64_t start;    // first position inside the tree's permutation
+    uint32_t tree;     // tree index inside the batch
+    uint32_t count;    // items under the node
+    uint32_t n_left;   // accumulated by the margin kernel (integer atomics)
+    uint32_t attempt;  // current / final split attempt (0..3)
+    uint32_t state;    // ST_*
+    uint32_t tile_begin, n_tiles;
+    uint32_t rec;      // host record index
+};
+struct FTile {
+    uint32_t node;
+    uint32_t first;  // offset of the tile inside its node
+};
+
+__global__ void k_init_perm(uint32_t *perm, uint64_t n, uint32_t n_trees) {
+    const uint64_t total = n * n_trees;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride)
+        perm[g] = (uint32_t)(g % n);
+}
+
+// One wave per pending node: sample 2+10 items with the policy RNG, run create_split.
+__global__ __launch_bounds__(64) void k_forest_create_split(DataView dv, FNode *nodes, const uint32_t *__restrict__ perm,
+                                                            uint64_t n_items, uint8_t *normals, uint64_t nstride,
+                                                            float *nhdrs) {
+    FNode &nd = nodes[blockIdx.x];
+    if (nd.state != ST_PENDING) return;
+    extern __shared__ float4 s_buf4[];
+    float *s_buf = reinterpret_cast<float *>(s_buf4);
+    __shared__ uint32_t s_rows[AH_SPLIT_SAMPLES];
+    const uint32_t fpitch = f32_space_pitch(dv.metric, dv.dims);
+    const uint32_t *pp = perm + (uint64_t)nd.tree * n_items + nd.start;
+    if (threadIdx.x == 0) {
+        uint64_t a, b;
+        ah_choose_two(nd.key, nd.attempt, nd.count, &a, &b);  // src/parallel.rs:342-355
+        s_rows[0] = pp[a];
+        s_rows[1] = pp[b];
+        nd.n_left = 0;
+    } else if (threadIdx.x >= 2 && threadIdx.x < AH_SPLIT_SAMPLES) {
+        s_rows[threadIdx.x] = pp[ah_choose(nd.key, nd.attempt, threadIdx.x - 2, nd.count)];  // :358-367
+    }
+    __syncthreads();
+    wave_create_split_any(dv, s_rows, s_buf, s_buf + fpitch, s_buf + 2 * fpitch, normals + blockIdx.x * nstride,
+                          nhdrs + 2 * (uint64_t)blockIdx.x, threadIdx.x);
+}
+
+// The margin loop (src/writer.rs:1201-1207) for all pending nodes of the level, tile by tile.
+// Output per tile: 32 side masks (bit i of mask o = side of item o + 32 i of the tile; 1 = Right) and the
+// number of Left items; per node: n_left.
+// Algorithmic traffic: 4*dims bytes per item (+4 B of permutation, +1 bit out).
+template <int METRIC>
+__global__ __launch_bounds__(kBlock) void k_forest_margin_f32(DataView dv, FNode *nodes, const FTile *__restrict__ tiles,
+                                                              uint32_t n_tiles, const uint32_t *__restrict__ perm,
+                                                              uint64_t n_items, const uint8_t *__restrict__ normals,
+                                                              uint64_t nstride, const float *__restrict__ nhdrs,
+                                                              uint64_t *__restrict__ masks,
+                                                              uint32_t *__restrict__ tile_left) {
+    extern __shared__ float4 s_n4[];
+    __shared__ uint32_t s_left;
+    const float *s_n = reinterpret_cast<const float *>(s_n4);
+    const uint32_t o = threadIdx.x >> 3, j = threadIdx.x & 7u;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const FTile tl = tiles[tile];
+        const FNode *nd = nodes + tl.node;
+        if (nd->state != ST_PENDING) continue;  // block-uniform
+        __syncthreads();
+        const float4 *g_n4 = reinterpret_cast<const float4 *>(normals + tl.node * nstride);
+        for (uint32_t i = threadIdx.x; i < (dv.pitch >> 2); i += blockDim.x) s_n4[i] = g_n4[i];
+        if (threadIdx.x == 0) s_left = 0;
+        __syncthreads();
+        const LeafHdr nh = {nhdrs[2 * (uint64_t)tl.node], nhdrs[2 * (uint64_t)tl.node + 1]};
+        const uint32_t in_tile = min(kTile, nd->count - tl.first);
+        const uint32_t *pp = perm + (uint64_t)nd->tree * n_items + nd->start + tl.first;
+        uint64_t mask = 0;
+        uint32_t lefts = 0;
+        for (uint32_t i = 0; i < 64; i++) {
+            const uint32_t p = o + 32 * i;
+            if (p >= in_tile) break;
+            const uint64_t row = pp[p];
+            const float m = margin_f32<METRIC>(dv, s_n, nh, row, j);
+            const uint32_t side = side_of_margin(m);
+            mask |= (uint64_t)side << i;
+            lefts += side ^ 1u;
+        }
+        if (j == 0) {
+            masks[(uint64_t)tile * 32 + o] = mask;
+            if (lefts) atomicAdd(&s_left, lefts);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            tile_left[tile] = s_left;
+            if (s_left) atomicAdd(&nodes[tl.node].n_left, s_left);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_forest_margin_bq(DataView dv, FNode *nodes, const FTile *__restrict__ tiles,
+                                                             uint32_t n_tiles, const uint32_t *__restrict__ perm,
+                                                             uint64_t n_items, const uint8_t *__restrict__ normals,
+                                                             uint64_t nstride, const float *__restrict__ nhdrs,
+                                                             uint64_t *__restrict__ masks,
+                                                             uint32_t *__restrict__ tile_left) {
+    extern __shared__ uint64_t s_nw[];
+    __shared__ uint32_t s_left;
+    __shared__ uint8_t s_side[kTile];
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const FTile tl = tiles[tile];
+        const FNode *nd = nodes + tl.node;
+        if (nd->state != ST_PENDING) continue;
+        __syncthreads();
+        const uint64_t *g_n = reinterpret_cast<const uint64_t *>(normals + tl.node * nstride);
+        for (uint32_t i = threadIdx.x; i < dv.pitch; i += blockDim.x) s_nw[i] = g_n[i];
+        if (threadIdx.x == 0) s_left = 0;
+        __syncthreads();
+        const LeafHdr nh = {nhdrs[2 * (uint64_t)tl.node], nhdrs[2 * (uint64_t)tl.node + 1]};
+        const uint32_t in_tile = min(kTile, nd->count - tl.first);
+        const uint32_t *pp = perm + (uint64_t)nd->tree * n_items + nd->start + tl.first;
+        for (uint32_t p = threadIdx.x; p < in_tile; p += blockDim.x)
+            s_side[p] = (uint8_t)side_of_margin(margin_bq(dv, s_nw, nh, pp[p]));
+        __syncthreads();
+        if (threadIdx.x < 32) {  // pack into the same mask layout as the f32 kernel
+            uint64_t mask = 0;
+            uint32_t lefts = 0;
+            for (uint32_t i = 0; i < 64; i++) {
+                const uint32_t p = threadIdx.x + 32 * i;
+                if (p >= in_tile) break;
+                mask |= (uint64_t)s_side[p] << i;
+                lefts += s_side[p] ^ 1u;
+            }
+            masks[(uint64_t)tile * 32 + threadIdx.x] = mask;
+            if (lefts) atomicAdd(&s_left, lefts);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            tile_left[tile] = s_left;
+            if (s_left) atomicAdd(&nodes[tl.node].n_left, s_left);
+        }
+    }
+}
+
+// split_imbalance (src/writer.rs:1348-1353, f64) and the accept / retry / random decision (:1209-1227).
+__global__ void k_forest_decide(FNode *nodes, uint32_t n_nodes) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    FNode &nd = nodes[i];
+    if (nd.state != ST_PENDING) return;
+    const double ls = (double)nd.n_left, rs = (double)(nd.count - nd.n_left);
+    const double f = ls / (ls + rs + 2.220446049250313e-16);
+    const double g = 1.0 - f;
+    const double imb = f > g ? f : g;
+    if (imb < 0.95 || nd.attempt == 3) {
+        if (imb > 0.99) {
+            nd.state = ST_RANDOM;
+            nd.n_left = 0;
+        } else {
+            nd.state = ST_ACCEPTED;
+        }
+    } else {
+        nd.attempt += 1;  // remaining_attempts -= 1; n_left is reset by the next create_split
+    }
+}
+
+// randomly_split_children (src/writer.rs:1310-1326) with the policy coin, same mask layout.
+__global__ __launch_bounds__(64) void k_forest_random_sides(FNode *nodes, const FTile *__restrict__ tiles,
+                                                            uint32_t n_tiles, uint64_t *__restrict__ masks,
+                                                            uint32_t *__restrict__ tile_left) {
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const FTile tl = tiles[tile];
+        const FNode *nd = nodes + tl.node;
+        if (nd->state != ST_RANDOM) continue;
+        const uint32_t in_tile = min(kTile, nd->count - tl.first);
+        uint32_t lefts = 0;
+        if (threadIdx.x < 32) {
+            uint64_t mask = 0;
+            for (uint32_t i = 0; i < 64; i++) {
+                const uint32_t p = threadIdx.x + 32 * i;
+                if (p >= in_tile) break;
+                const uint32_t left = ah_random_side_is_left(nd->key, (uint64_t)tl.first + p);
+                mask |= (uint64_t)(left ^ 1u) << i;
+                lefts += left;
+            }
+            masks[(uint64_t)tile * 32 + threadIdx.x] = mask;
+        }
+        for (int off = 32; off > 0; off >>= 1) lefts += __shfl_down(lefts, off);
+        if (threadIdx.x == 0) {
+            tile_left[tile] = lefts;
+            if (lefts) atomicAdd(&nodes[tl.node].n_left, lefts);
+        }
+    }
+}
+
+// Exclusive scan of the per-tile left counts inside every node: one wave per node.
+__global__ __launch_bounds__(64) void k_forest_tile_offsets(const FNode *__restrict__ nodes, uint32_t n_nodes,
+                                                            const uint32_t *__restrict__ tile_left,
+                                                            uint32_t *__restrict__ tile_left_off) {
+    for (uint32_t node = blockIdx.x; node < n_nodes; node += gridDim.x) {
+        const FNode nd = nodes[node];
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < nd.n_tiles; base += 64) {
+            const uint32_t t = base + threadIdx.x;
+            const uint32_t v = t < nd.n_tiles ? tile_left[nd.tile_begin + t] : 0u;
+            uint32_t incl = v;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off);
+                if ((int)threadIdx.x >= off) incl += up;
+            }
+            if (t < nd.n_tiles) tile_left_off[nd.tile_begin + t] = carry + incl - v;
+            carry += __shfl(incl, 63);
+        }
+    }
+}
+
+// Stable partition of every split node into its children (ascending order kept inside each child =
+// RoaringBitmap::from_sorted_iter, src/writer.rs:1230-1231).  A child that fits in a Descendants node
+// (count <= split_after, :474-477) is written to `final_perm`, the others to the next level's permutation.
+__global__ __launch_bounds__(kBlock) void k_forest_scatter(const FNode *__restrict__ nodes,
+                                                           const FTile *__restrict__ tiles, uint32_t n_tiles,
+                                                           const uint32_t *__restrict__ perm_cur,
+                                                           uint32_t *__restrict__ perm_next,
+                                                           uint32_t *__restrict__ final_perm, uint64_t n_items,
+                                                           const uint64_t *__restrict__ masks,
+                                                           const uint32_t *__restrict__ tile_left_off,
+                                                           uint32_t split_after) {
+    __shared__ uint64_t s_masks[32];
+    __shared__ uint32_t s_wave[kBlock / 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const FTile tl = tiles[tile];
+        const FNode nd = nodes[tl.node];
+        __syncthreads();
+        if (threadIdx.x < 32) s_masks[threadIdx.x] = masks[(uint64_t)tile * 32 + threadIdx.x];
+        __syncthreads();
+        const uint32_t in_tile = min(kTile, nd.count - tl.first);
+        const uint32_t p0 = threadIdx.x * 8;
+        const uint32_t i = p0 >> 5;
+        const uint32_t nvalid = p0 < in_tile ? min(8u, in_tile - p0) : 0u;
+        uint32_t sidebits = 0;
+        for (uint32_t e = 0; e < nvalid; e++) sidebits |= (uint32_t)((s_masks[(p0 + e) & 31u] >> i) & 1ull) << e;
+        const uint32_t my_left = nvalid - (uint32_t)__popc(sidebits);
+        // block-wide exclusive scan of my_left
+        uint32_t incl = my_left;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wave_base = 0;
+        for (uint32_t w = 0; w < wave; w++) wave_base += s_wave[w];
+        uint32_t left_before = tile_left_off[tile] + wave_base + incl - my_left;  // lefts before p0, inside the node
+        uint32_t right_before = (tl.first + p0) - left_before;
+        const uint64_t base = (uint64_t)nd.tree * n_items + nd.start;
+        const uint32_t n_right = nd.count - nd.n_left;
+        uint32_t *dst_l = (nd.n_left <= split_after ? final_perm : perm_next) + base;
+        uint32_t *dst_r = (n_right <= split_after ? final_perm : perm_next) + base + nd.n_left;
+        const uint32_t *src = perm_cur + base + tl.first + p0;
+        for (uint32_t e = 0; e < nvalid; e++) {
+            const uint32_t row = src[e];
+            if ((sidebits >> e) & 1u) dst_r[right_before++] = row;
+            else dst_l[left_before++] = row;
+        }
+    }
+}
+
+__global__ void k_rows_to_ids(uint32_t *perm, uint64_t total, const uint32_t *__restrict__ ids) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) perm[g] = ids[perm[g]];
+}
+
+}  // namespace ah
+
+using namespace ah;
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+struct ah_forest {
+    std::vector<uint32_t> roots;
+    std::vector<ah_node> nodes;
+    std::vector<uint8_t> normals;
+    std::vector<uint32_t> descendants;
+    uint64_t normal_stride = 0;
+    ah_build_stats stats{};
+};
+
+namespace {
+
+struct HostRec {  // one tree node, in creation (breadth-first) order
+    uint8_t kind, has_normal;
+    uint32_t tree;
+    uint32_t left = 0, right = 0;  // HostRec indices
+    uint64_t start;
+    uint32_t count;
+    uint32_t depth;
+    uint64_t normal_off = 0;  // into the batch normal blob
+};
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return AH_OK;
+        if (p) AH_HIP(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(n, (size_t)1024);
+        AH_HIP(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+        return AH_OK;
+    }
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t first_tree, uint32_t n_trees,
+                       uint32_t split_after, ah_forest *forest, Context *ctx) {
+    const uint64_t N = ds->n;
+    const DataView dv = ds->view();
+    hipStream_t s = ctx->stream;
+    const bool bq = metric_is_bq(ds->metric);
+    const uint64_t nstride = ds->row_bytes();
+    const size_t hs = ah_header_size(ds->metric), vs = ah_vector_size(ds->metric, ds->dims);
+
+    DevBuf<uint32_t> perm_a, perm_b, final_perm, tile_left, tile_left_off;
+    DevBuf<FNode> d_nodes;
+    DevBuf<FTile> d_tiles;
+    DevBuf<uint64_t> masks;
+    DevBuf<uint8_t> d_normals;
+    DevBuf<float> d_nhdrs;
+    AH_TRY(perm_a.ensure(N * n_trees));
+    AH_TRY(perm_b.ensure(N * n_trees));
+    AH_TRY(final_perm.ensure(N * n_trees));
+    hipLaunchKernelGGL(k_init_perm, dim3(2048), dim3(256), 0, s, perm_a.p, N, n_trees);
+    AH_HIP(hipGetLastError());
+
+    std::vector<HostRec> recs;
+    std::vector<uint8_t> normal_blob;  // [header][vector] per split node with a normal
+    std::vector<FNode> level;          // active (to be split) nodes of the current level
+    std::vector<uint32_t> tree_root(n_trees);
+    for (uint32_t t = 0; t < n_trees; t++) {
+        HostRec r{};
+        r.kind = AH_NODE_SPLIT;
+        r.tree = t;
+        r.start = 0;
+        r.count = (uint32_t)N;
+        r.depth = 0;
+        tree_root[t] = (uint32_t)recs.size();
+        FNode nd{};
+        nd.key = ah_node_key_root(opt->tree_seeds[first_tree + t]);
+        nd.start = 0;
+        nd.tree = t;
+        nd.count = (uint32_t)N;
+        nd.rec = (uint32_t)recs.size();
+        recs.push_back(r);
+        level.push_back(nd);
+    }
+
+    uint32_t *cur = perm_a.p, *nxt = perm_b.p;
+    std::vector<FTile> tiles;
+    std::vector<FNode> level_out;
+    std::vector<uint8_t> h_normals;
+    std::vector<float> h_nhdrs;
+    std::vector<EventPair> margin_events;
+    hipEvent_t ev_begin, ev_end;
+    AH_HIP(hipEventCreate(&ev_begin));
+    AH_HIP(hipEventCreate(&ev_end));
+    AH_HIP(hipEventRecord(ev_begin, s));
+    const size_t cs_shared = (size_t)f32_space_pitch(ds->metric, ds->dims) * 4 * 3;
+    AH_REQUIRE(cs_shared <= 150 * 1024, AH_ERR_INVALID_DIMENSION, "dimensions %u too large for the LDS-resident two-means",
+               ds->dims);
+    if (cs_shared > 48 * 1024)
+        AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_create_split),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_shared));
+    uint32_t depth = 0;
+    uint64_t items_routed = 0;
+    while (!level.empty()) {
+        if (opt->cancel && *opt->cancel) {
+            set_error("build cancelled");
+            return AH_ERR_CANCELLED;  // Error::BuildCancelled, polled per level (src/writer.rs:1178,1196)
+        }
+        AH_REQUIRE(depth < 100000, AH_ERR_DEVICE, "forest build: depth %u exceeded (internal error)", depth);
+        const uint32_t n_nodes = (uint32_t)level.size();
+        tiles.clear();
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            FNode &nd = level[i];
+            nd.tile_begin = (uint32_t)tiles.size();
+            nd.n_tiles = (nd.count + kTile - 1) / kTile;
+            for (uint32_t t = 0; t < nd.n_tiles; t++) tiles.push_back(FTile{i, t * kTile});
+        }
+        const uint32_t n_tiles = (uint32_t)tiles.size();
+        AH_TRY(d_nodes.ensure(n_nodes));
+        AH_TRY(d_tiles.ensure(n_tiles));
+        AH_TRY(masks.ensure((size_t)n_tiles * 32));
+        AH_TRY(tile_left.ensure(n_tiles));
+        AH_TRY(tile_left_off.ensure(n_tiles));
+        AH_TRY(d_normals.ensure((size_t)n_nodes * nstride));
+        AH_TRY(d_nhdrs.ensure((size_t)n_nodes * 2));
+        AH_HIP(hipMemcpyAsync(d_nodes.p, level.data(), n_nodes * sizeof(FNode), hipMemcpyHostToDevice, s));
+        AH_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), n_tiles * sizeof(FTile), hipMemcpyHostToDevice, s));
+        const unsigned tile_grid = std::min<uint32_t>(n_tiles, kMaxBlocks);
+        for (int attempt = 0; attempt < 4; attempt++) {
+            hipLaunchKernelGGL(k_forest_create_split, dim3(n_nodes), dim3(64), cs_shared, s, dv, d_nodes.p, cur, N,
+                               d_normals.p, nstride, d_nhdrs.p);
+            EventPair ep;
+            AH_HIP(hipEventCreate(&ep.a));
+            AH_HIP(hipEventCreate(&ep.b));
+            AH_HIP(hipEventRecord(ep.a, s));
+            if (bq) {
+                hipLaunchKernelGGL(k_forest_margin_bq, dim3(tile_grid), dim3(kBlock), dv.pitch * 8, s, dv, d_nodes.p,
+                                   d_tiles.p, n_tiles, cur, N, d_normals.p, nstride, d_nhdrs.p, masks.p, tile_left.p);
+            } else {
+                const size_t sh = (size_t)dv.pitch * 4;
+#define AH_LAUNCH(M)                                                                                              \
+    hipLaunchKernelGGL((k_forest_margin_f32<M>), dim3(tile_grid), dim3(kBlock), sh, s, dv, d_nodes.p, d_tiles.p,   \
+                       n_tiles, cur, N, d_normals.p, nstride, d_nhdrs.p, masks.p, tile_left.p)
+                switch (ds->metric) {
+                case AH_EUCLIDEAN: AH_LAUNCH(AH_EUCLIDEAN); break;
+                case AH_MANHATTAN: AH_LAUNCH(AH_MANHATTAN); break;
+                case AH_COSINE: AH_LAUNCH(AH_COSINE); break;
+                default: AH_LAUNCH(AH_DOT_PRODUCT); break;
+                }
+#undef AH_LAUNCH
+            }
+            AH_HIP(hipEventRecord(ep.b, s));
+            margin_events.push_back(ep);
+            hipLaunchKernelGGL(k_forest_decide, dim3((n_nodes + 255) / 256), dim3(256), 0, s, d_nodes.p, n_nodes);
+        }
+        hipLaunchKernelGGL(k_forest_random_sides, dim3(std::min<uint32_t>(n_tiles, kMaxBlocks)), dim3(64), 0, s,
+                           d_nodes.p, d_tiles.p, n_tiles, masks.p, tile_left.p);
+        hipLaunchKernelGGL(k_forest_tile_offsets, dim3(std::min<uint32_t>(n_nodes, kMaxBlocks)), dim3(64), 0, s,
+                           d_nodes.p, n_nodes, tile_left.p, tile_left_off.p);
+        hipLaunchKernelGGL(k_forest_scatter, dim3(tile_grid), dim3(kBlock), 0, s, d_nodes.p, d_tiles.p, n_tiles, cur, nxt,
+                           final_perm.p, N, masks.p, tile_left_off.p, split_after);
+        AH_HIP(hipGetLastError());
+        level_out.resize(n_nodes);
+        h_normals.resize((size_t)n_nodes * nstride);
+        h_nhdrs.resize((size_t)n_nodes * 2);
+        AH_HIP(hipMemcpyAsync(level_out.data(), d_nodes.p, n_nodes * sizeof(FNode), hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_normals.data(), d_normals.p, (size_t)n_nodes * nstride, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_nhdrs.data(), d_nhdrs.p, (size_t)n_nodes * 8, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipStreamSynchronize(s));
+
+        // host: materialise the split records and the next level (children lists subdivide the parent range)
+        level.clear();
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            const FNode &nd = level_out[i];
+            AH_REQUIRE(nd.state != ST_PENDING && nd.n_left <= nd.count, AH_ERR_DEVICE,
+                       "forest build: node %u left pending (internal error)", i);
+            forest->stats.margin_evaluations += (uint64_t)(nd.attempt + 1) * nd.count;
+            forest->stats.retries += nd.attempt;
+            items_routed += nd.count;
+            const uint32_t rec_idx = nd.rec;
+            recs[rec_idx].has_normal = nd.state == ST_ACCEPTED;
+            if (nd.state == ST_ACCEPTED) {
+                recs[rec_idx].normal_off = normal_blob.size();
+                const uint8_t *h = reinterpret_cast<const uint8_t *>(&h_nhdrs[2 * (size_t)i]);
+                normal_blob.insert(normal_blob.end(), h, h + hs);
+                const uint8_t *v = &h_normals[(size_t)i * nstride];
+                normal_blob.insert(normal_blob.end(), v, v + vs);
+            } else {
+                forest->stats.dummy_normals++;
+            }
+            const uint32_t child_cnt[2] = {nd.n_left, nd.count - nd.n_left};
+            const uint64_t child_start[2] = {nd.start, nd.start + nd.n_left};
+            for (uint32_t side = 0; side < 2; side++) {
+                HostRec c{};
+                c.tree = nd.tree;
+                c.start = child_start[side];
+                c.count = child_cnt[side];
+                c.depth = depth + 1;
+                const uint32_t cidx = (uint32_t)recs.size();
+                if (c.count <= split_after) {
+                    c.kind = AH_NODE_DESCENDANTS;
+                } else {
+                    c.kind = AH_NODE_SPLIT;
+                    FNode cn{};
+                    cn.key = ah_node_key_child(nd.key, side);
+                    cn.start = c.start;
+                    cn.tree = nd.tree;
+                    cn.count = c.count;
+                    cn.rec = cidx;
+                    level.push_back(cn);
+                }
+                recs.push_back(c);
+                if (side == 0) recs[rec_idx].left = cidx;
+                else recs[rec_idx].right = cidx;
+            }
+        }
+        std::swap(cur, nxt);
+        depth++;
+        forest->stats.levels = std::max(forest->stats.levels, depth);
+        if (opt->progress) opt->progress(opt->progress_user, depth, recs.size(), items_routed);
+    }
+    AH_HIP(hipEventRecord(ev_end, s));
+    // Descendants: rows -> item ids on device, then one D2H of the final permutations
+    if (!ds->identity_ids)
+        hipLaunchKernelGGL(k_rows_to_ids, dim3(2048), dim3(256), 0, s, final_perm.p, N * n_trees, ds->d_ids);
+    std::vector<uint32_t> h_final(N * n_trees);
+    AH_HIP(hipMemcpyAsync(h_final.data(), final_perm.p, N * n_trees * 4, hipMemcpyDeviceToHost, s));
+    AH_HIP(hipStreamSynchronize(s));
+    float ms = 0.0f;
+    AH_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
+    forest->stats.seconds_device += ms * 1e-3;
+    for (EventPair &ep : margin_events) {
+        float m = 0.0f;
+        if (hipEventElapsedTime(&m, ep.a, ep.b) == hipSuccess) forest->stats.seconds_margin += m * 1e-3;
+        (void)hipEventDestroy(ep.a);
+        (void)hipEventDestroy(ep.b);
+    }
+    forest->stats.margin_launches += margin_events.size();
+    (void)hipEventDestroy(ev_begin);
+    (void)hipEventDestroy(ev_end);
+
+    // Emit per tree in post-order (children before parents: the order TmpNodes::put receives them,
+    // src/writer.rs:1235-1258), with forest-local indices.
+    std::vector<uint32_t> new_index(recs.size(), 0xFFFFFFFFu);
+    std::vector<std::pair<uint32_t, int>> stack;
+    for (uint32_t t = 0; t < n_trees; t++) {
+        stack.clear();
+        stack.push_back({tree_root[t], 0});
+        while (!stack.empty()) {
+            auto &top = stack.back();
+            const HostRec &r = recs[top.first];
+            if (r.kind == AH_NODE_SPLIT && top.second == 0) {
+                top.second = 1;
+                const uint32_t l = r.left, rr = r.right;
+                stack.push_back({rr, 0});
+                stack.push_back({l, 0});
+                continue;
+            }
+            ah_node nd{};
+            nd.kind = r.kind;
+            nd.has_normal = r.has_normal;
+            nd.tree = (uint16_t)(first_tree + t);
+            nd.count = r.count;
+            nd.depth = r.depth;
+            if (r.kind == AH_NODE_SPLIT) {
+                nd.left = new_index[r.left];
+                nd.right = new_index[r.right];
+                nd.offset = forest->normals.size();
+                if (r.has_normal) {
+                    forest->normals.insert(forest->normals.end(), normal_blob.begin() + r.normal_off,
+                                           normal_blob.begin() + r.normal_off + hs + vs);
+                }
+                forest->stats.split_nodes++;
+            } else {
+                nd.offset = forest->descendants.size();
+                const uint32_t *src = h_final.data() + (uint64_t)t * N + r.start;
+                forest->descendants.insert(forest->descendants.end(), src, src + r.count);
+                forest->stats.descendant_nodes++;
+            }
+            new_index[top.first] = (uint32_t)forest->nodes.size();
+            forest->nodes.push_back(nd);
+            stack.pop_back();
+        }
+        forest->roots.push_back(new_index[tree_root[t]]);
+    }
+    return AH_OK;
+}
+
+extern "C" {
+
+int ah_build_forest(ah_dataset *ds, const ah_build_options *options, ah_forest **out) {
+    AH_REQUIRE(out, AH_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    AH_REQUIRE(ds && options, AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    AH_REQUIRE(ds->finalized, AH_ERR_NOT_FINALIZED, "dataset not finalized (call ah_dataset_finalize)");
+    AH_REQUIRE(options->n_trees == 0 || options->tree_seeds, AH_ERR_INVALID_ARGUMENT, "tree_seeds is NULL");
+    AH_REQUIRE(options->n_trees <= 0xFFFF, AH_ERR_INVALID_ARGUMENT, "at most 65535 trees per call");
+    AH_REQUIRE(ds->metric != AH_DOT_PRODUCT || ds->dot_preprocessed, AH_ERR_NEED_PREPROCESS,
+               "DotProduct needs ah_preprocess_dot before the build (src/writer.rs:964-976)");
+    AH_HIP(hipSetDevice(ds->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t split_after = options->split_after ? options->split_after : ds->dims;  // src/writer.rs:474-477
+    ah_forest *forest = new (std::nothrow) ah_forest();
+    AH_REQUIRE(forest, AH_ERR_OUT_OF_MEMORY, "host allocation failed");
+    forest->normal_stride = ah_header_size(ds->metric) + ah_vector_size(ds->metric, ds->dims);
+    int st = AH_OK;
+    if (ds->n <= split_after) {
+        // fit_in_descendant at the root (src/writer.rs:1183-1188): every tree is one Descendants node
+        std::vector<uint32_t> ids(ds->n);
+        for (uint64_t i = 0; i < ds->n; i++) ids[i] = ds->identity_ids ? (uint32_t)i : ds->h_ids[i];
+        for (uint32_t t = 0; t < options->n_trees; t++) {
+            ah_node nd{};
+            nd.kind = AH_NODE_DESCENDANTS;
+            nd.tree = (uint16_t)t;
+            nd.count = (uint32_t)ds->n;
+            nd.offset = forest->descendants.size();
+            forest->descendants.insert(forest->descendants.end(), ids.begin(), ids.end());
+            forest->roots.push_back((uint32_t)forest->nodes.size());
+            forest->nodes.push_back(nd);
+            forest->stats.descendant_nodes++;
+        }
+    } else if (options->n_trees) {
+        ContextLease lease(ds);
+        if (!lease.c) {
+            set_error("cannot create a HIP stream");
+            st = AH_ERR_DEVICE;
+        } else {
+            // Trees in flight: bounded by HBM (13 bytes per item per tree + normals) or by the caller.
+            size_t free_b = 0, total_b = 0;
+            (void)hipMemGetInfo(&free_b, &total_b);
+            const uint64_t per_tree = ds->n * 13 + ((ds->n / std::max<uint32_t>(split_after, 1)) + 2) * (ds->row_bytes() + 64);
+            uint64_t fit = per_tree ? (uint64_t)(free_b * 0.8) / per_tree : options->n_trees;
+            if (fit < 1) fit = 1;
+            uint32_t batch = (uint32_t)std::min<uint64_t>(fit, options->n_trees);
+            if (options->max_trees_in_flight) batch = std::min(batch, options->max_trees_in_flight);
+            try {
+                for (uint32_t first = 0; first < options->n_trees && st == AH_OK; first += batch)
+                    st = build_batch(ds, options, first, std::min(batch, options->n_trees - first), split_after, forest,
+                                     lease.c);
+            } catch (const std::bad_alloc &) {
+                set_error("host allocation failed during the forest build");
+                st = AH_ERR_OUT_OF_MEMORY;
+            }
+        }
+    }
+    if (st != AH_OK) {
+        delete forest;
+        return st;
+    }
+    forest->stats.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *out = forest;
+    return AH_OK;
+}
+
+int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out) {
+    AH_REQUIRE(forest && out, AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    out->n_trees = (uint32_t)forest->roots.size();
+    out->n_nodes = forest->nodes.size();
+    out->roots = forest->roots.data();
+    out->nodes = forest->nodes.data();
+    out->normals = forest->normals.data();
+    out->normals_len = forest->normals.size();
+    out->normal_stride = forest->normal_stride;
+    out->descendants = forest->descendants.data();
+    out->descendants_len = forest->descendants.size();
+    return AH_OK;
+}
+
+int ah_forest_stats(const ah_forest *forest, ah_build_stats *out) {
+    AH_REQUIRE(forest && out, AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = forest->stats;
+    return AH_OK;
+}
+
+int ah_forest_visit(const ah_forest *forest, ah_node_sink_fn sink, void *user) {
+    AH_REQUIRE(forest && sink, AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    for (size_t i = 0; i < forest->nodes.size(); i++) {
+        const ah_node &nd = forest->nodes[i];
+        const void *payload = nullptr;
+        size_t len = 0;
+        if (nd.kind == AH_NODE_SPLIT) {
+            if (nd.has_normal) {
+                payload = forest->normals.data() + nd.offset;
+                len = forest->normal_stride;
+            }
+        } else {
+            payload = forest->descendants.data() + nd.offset;
+            len = (size_t)nd.count * 4;
+        }
+        const int rc = sink(user, nd.tree, (uint32_t)i, nd.kind, nd.left, nd.right, payload, len);
+        AH_REQUIRE(rc == 0, AH_ERR_CANCELLED, "node sink asked to stop (code %d)", rc);
+    }
+    return AH_OK;
+}
+
+int ah_forest_destroy(ah_forest *forest) {
+    delete forest;
+    return AH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,287 @@
+"""`Dataset` / `Forest`: numpy-facing wrappers of the C ABI handles (ah_dataset / ah_forest).
+
+`Dataset` is the HBM-resident image of what arroy calls `ImmutableLeafs` (src/parallel.rs:262-312);
+every method is one C-ABI call, all arithmetic happens in HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .distances import BY_METRIC, Distance
+
+
+def _u32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Dataset:
+    def __init__(self, distance: type[Distance], dimensions: int, capacity: int, device: int = 0):
+        self.distance = distance
+        self.metric = distance.metric
+        self.dimensions = int(dimensions)
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().ah_dataset_create(self.metric, self.dimensions, int(capacity), device, C.byref(self._h)))
+        self.finalized = False
+
+    # -- staging ---------------------------------------------------------------------------------
+    def upload_vectors(self, item_ids: Sequence[int], vectors) -> None:
+        """`Writer::add_item` for a batch (src/writer.rs:380-394)."""
+        ids = _u32(item_ids)
+        v = _f32(vectors)
+        if v.ndim != 2 or v.shape[1] != self.dimensions:
+            got = v.shape[1] if v.ndim == 2 else v.size
+            raise _lib.InvalidVecDimension(1, f"invalid vector dimensions, provided {got} but expected "
+                                              f"{self.dimensions}")  # src/error.rs:17-23
+        if v.shape[0] != ids.size:
+            raise ValueError("ids and vectors disagree on the number of items")
+        _lib.check(_lib.lib().ah_dataset_upload_vectors(self._h, _ptr(ids), _ptr(v), ids.size))
+
+    def upload_records(self, item_ids: Sequence[int], records: Sequence[bytes]) -> None:
+        """Stored item records `[0u8][header][vector]` as they sit in LMDB pages (src/node.rs:224-228)."""
+        ids = _u32(item_ids)
+        n = ids.size
+        if n == 0:
+            return
+        rec_len = len(records[0])
+        # deliberately misaligned copies: LMDB hands out pointers at page+16+... (SURVEY.md §7 hard part 4)
+        keep = [C.create_string_buffer(b"\0" + bytes(r), rec_len + 1) for r in records]
+        ptrs = (C.c_void_p * n)(*[C.addressof(b) + 1 for b in keep])
+        _lib.check(_lib.lib().ah_dataset_upload_records(self._h, _ptr(ids), ptrs, rec_len, n))
+
+    def fill_synthetic(self, seed: int, distribution: int, n_items: int) -> None:
+        _lib.check(_lib.lib().ah_dataset_fill_synthetic(self._h, seed, distribution, n_items))
+
+    def finalize(self) -> "Dataset":
+        _lib.check(_lib.lib().ah_dataset_finalize(self._h))
+        self.finalized = True
+        return self
+
+    def __len__(self) -> int:
+        n = C.c_uint64(0)
+        _lib.check(_lib.lib().ah_dataset_len(self._h, C.byref(n)))
+        return int(n.value)
+
+    def item_vector(self, item_id: int) -> np.ndarray:
+        out = np.zeros(self.dimensions, dtype=np.float32)
+        _lib.check(_lib.lib().ah_dataset_item_vector(self._h, item_id, _ptr(out)))
+        return out
+
+    def read_headers(self, first_row: int = 0, n: Optional[int] = None) -> np.ndarray:
+        n = len(self) - first_row if n is None else n
+        hf = self.distance.header_size() // 4
+        out = np.zeros((n, hf), dtype=np.float32)
+        _lib.check(_lib.lib().ah_dataset_read_headers(self._h, first_row, n, _ptr(out)))
+        return out
+
+    def preprocess_dot(self) -> np.float32:
+        m = C.c_float(0)
+        _lib.check(_lib.lib().ah_preprocess_dot(self._h, C.byref(m)))
+        return np.float32(m.value)
+
+    # -- search side -------------------------------------------------------------------------------
+    def distances(self, query=None, item: Optional[int] = None, ids=None, n: Optional[int] = None) -> np.ndarray:
+        ids_a = None if ids is None else _u32(ids)
+        n = (len(self) if n is None else n) if ids_a is None else ids_a.size
+        out = np.zeros(n, dtype=np.float32)
+        if query is not None:
+            q = self._check_query(query)
+            _lib.check(_lib.lib().ah_distances_by_vector(self._h, _ptr(q), _ptr(ids_a), n, _ptr(out)))
+        else:
+            _lib.check(_lib.lib().ah_distances_by_item(self._h, int(item), _ptr(ids_a), n, _ptr(out)))
+        return out
+
+    def rerank(self, k: int, query=None, item: Optional[int] = None, sorted_ids=None):
+        ids_a = None if sorted_ids is None else _u32(sorted_ids)
+        n = len(self) if ids_a is None else ids_a.size
+        kk = max(1, min(int(k), n)) if n else 1
+        oi = np.zeros(kk, dtype=np.uint32)
+        od = np.zeros(kk, dtype=np.float32)
+        on = C.c_size_t(0)
+        if query is not None:
+            q = self._check_query(query)
+            _lib.check(_lib.lib().ah_rerank_by_vector(self._h, _ptr(q), _ptr(ids_a), n, int(k), _ptr(oi), _ptr(od),
+                                                      C.byref(on)))
+        else:
+            _lib.check(_lib.lib().ah_rerank_by_item(self._h, int(item), _ptr(ids_a), n, int(k), _ptr(oi), _ptr(od),
+                                                    C.byref(on)))
+        return oi[: on.value].copy(), od[: on.value].copy()
+
+    def rerank_batch(self, queries, id_lists: Sequence[Sequence[int]], k: int):
+        q = _f32(queries)
+        if q.ndim != 2 or q.shape[1] != self.dimensions:
+            raise _lib.InvalidVecDimension(1, "invalid query dimensions")
+        nq = q.shape[0]
+        offsets = np.zeros(nq + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum([len(l) for l in id_lists])
+        ids = _u32(np.concatenate([_u32(l) for l in id_lists])) if nq else np.zeros(0, np.uint32)
+        oi = np.zeros((nq, k), dtype=np.uint32)
+        od = np.zeros((nq, k), dtype=np.float32)
+        oc = np.zeros(nq, dtype=np.uint32)
+        _lib.check(_lib.lib().ah_rerank_batch(self._h, _ptr(q), nq, _ptr(ids), _ptr(offsets), k, _ptr(oi), _ptr(od),
+                                              _ptr(oc)))
+        return oi, od, oc
+
+    # -- build side --------------------------------------------------------------------------------
+    def split_sides(self, normal_vector: np.ndarray, normal_header, sorted_ids=None, want_margins: bool = True):
+        """The margin loop (src/writer.rs:1201-1207). Returns (sides u8 per item, n_left, margins)."""
+        ids_a = None if sorted_ids is None else _u32(sorted_ids)
+        n = len(self) if ids_a is None else ids_a.size
+        nv = np.ascontiguousarray(normal_vector).view(np.uint8)
+        assert nv.size == self.distance.vector_size(self.dimensions)
+        nh = np.zeros(2, dtype=np.float32)
+        h = _f32(normal_header).ravel()
+        nh[: h.size] = h
+        bits = np.zeros((n + 7) // 8, dtype=np.uint8)
+        margins = np.zeros(n, dtype=np.float32) if want_margins else None
+        nl = C.c_uint64(0)
+        _lib.check(_lib.lib().ah_split_sides(self._h, _ptr(nv), _ptr(nh), _ptr(ids_a), n, _ptr(bits), C.byref(nl),
+                                             _ptr(margins)))
+        sides = np.unpackbits(bits, bitorder="little")[:n]
+        return sides, int(nl.value), margins
+
+    def create_split(self, sample_ids: Sequence[int]):
+        """`D::create_split` with host-supplied samples (choose_two + 10 x choose)."""
+        s = _u32(sample_ids)
+        assert s.size == _lib.AH_SPLIT_SAMPLES
+        nv = np.zeros(self.distance.vector_size(self.dimensions), dtype=np.uint8)
+        nh = np.zeros(2, dtype=np.float32)
+        _lib.check(_lib.lib().ah_create_split(self._h, _ptr(s), _ptr(nv), _ptr(nh)))
+        return nv, nh[: self.distance.header_size() // 4].copy()
+
+    def build_forest(self, tree_seeds: Sequence[int], split_after: int = 0, cancel=None, progress=None,
+                     max_trees_in_flight: int = 0) -> "Forest":
+        seeds = np.ascontiguousarray(tree_seeds, dtype=np.uint64)
+        opt = _lib.AhBuildOptions()
+        opt.n_trees = seeds.size
+        opt.split_after = int(split_after)
+        opt.tree_seeds = seeds.ctypes.data_as(C.POINTER(C.c_uint64))
+        cflag = C.c_int(0)
+        opt.cancel = C.pointer(cflag)
+        keep = None
+        if cancel is not None or progress is not None:
+            def _cb(_user, level, nodes_done, items_routed):
+                if progress is not None:
+                    progress(level, nodes_done, items_routed)
+                if cancel is not None and cancel():
+                    cflag.value = 1
+            keep = _lib.PROGRESS_FN(_cb)
+            opt.progress = keep
+            if cancel is not None and cancel():  # polled before the first level too (src/writer.rs:1178)
+                cflag.value = 1
+        opt.max_trees_in_flight = int(max_trees_in_flight)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ah_build_forest(self._h, C.byref(opt), C.byref(h)))
+        return Forest(h, self.distance, self.dimensions)
+
+    # -- measurement -------------------------------------------------------------------------------
+    def bench_scan(self, query_item: int, n: int, iterations: int, want_out: bool = False):
+        out = np.zeros(n, dtype=np.float32) if want_out else None
+        ms = C.c_double(0)
+        _lib.check(_lib.lib().ah_bench_scan(self._h, query_item, n, iterations, _ptr(out), C.byref(ms)))
+        return ms.value, out
+
+    # -- plumbing ----------------------------------------------------------------------------------
+    def _check_query(self, query) -> np.ndarray:
+        q = _f32(query).ravel()
+        if q.size != self.dimensions:  # src/reader.rs:64-69
+            raise _lib.InvalidVecDimension(1, f"invalid vector dimensions, provided {q.size} but expected "
+                                              f"{self.dimensions}")
+        return q
+
+    def close(self) -> None:
+        if self._h:
+            _lib.lib().ah_dataset_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Forest:
+    """Host-side result of one forest build (ah_forest): flat nodes, normals blob, descendant ids."""
+
+    def __init__(self, handle: C.c_void_p, distance: type[Distance], dimensions: int):
+        self._h = handle
+        self.distance = distance
+        self.dimensions = dimensions
+        v = _lib.AhForestView()
+        _lib.check(_lib.lib().ah_forest_view_get(self._h, C.byref(v)))
+        self.n_trees = int(v.n_trees)
+        n = int(v.n_nodes)
+        self.roots = np.ctypeslib.as_array(v.roots, shape=(self.n_trees,)).copy() if self.n_trees else np.zeros(0, np.uint32)
+        node_dt = np.dtype([("kind", "u1"), ("has_normal", "u1"), ("tree", "<u2"), ("left", "<u4"), ("right", "<u4"),
+                            ("offset", "<u8"), ("count", "<u4"), ("depth", "<u4")])
+        assert node_dt.itemsize == C.sizeof(_lib.AhNode)
+        self.nodes = np.frombuffer(C.string_at(v.nodes, n * node_dt.itemsize), dtype=node_dt).copy() if n else \
+            np.zeros(0, node_dt)
+        self.normal_stride = int(v.normal_stride)
+        self.normals = np.frombuffer(C.string_at(v.normals, v.normals_len), dtype=np.uint8).copy() \
+            if v.normals_len else np.zeros(0, np.uint8)
+        self.descendants = np.ctypeslib.as_array(v.descendants, shape=(int(v.descendants_len),)).copy() \
+            if v.descendants_len else np.zeros(0, np.uint32)
+        st = _lib.AhBuildStats()
+        _lib.check(_lib.lib().ah_forest_stats(self._h, C.byref(st)))
+        self.stats = {f: getattr(st, f) for f, _ in _lib.AhBuildStats._fields_}
+        _lib.lib().ah_forest_destroy(self._h)
+        self._h = None
+
+    def normal_of(self, node: int):
+        """(header f32[], vector codec bytes) of a split node, or None for `normal: None`."""
+        nd = self.nodes[node]
+        if nd["kind"] != 2 or not nd["has_normal"]:
+            return None
+        hs = self.distance.header_size()
+        raw = self.normals[int(nd["offset"]): int(nd["offset"]) + self.normal_stride]
+        return raw[:hs].view(np.float32).copy(), raw[hs:].copy()
+
+    def descendants_of(self, node: int) -> np.ndarray:
+        nd = self.nodes[node]
+        return self.descendants[int(nd["offset"]): int(nd["offset"]) + int(nd["count"])]
+
+    def canonical(self, tree: int):
+        """Numbering-independent nested tuples; comparable with oracle.Tree.canonical()."""
+        import sys
+        sys.setrecursionlimit(100000)
+
+        def rec(i):
+            nd = self.nodes[i]
+            if nd["kind"] == 1:
+                return ("D", tuple(int(x) for x in self.descendants_of(i)))
+            nb = None
+            if nd["has_normal"]:
+                nb = bytes(self.normals[int(nd["offset"]): int(nd["offset"]) + self.normal_stride])
+            return ("S", nb, rec(int(nd["left"])), rec(int(nd["right"])))
+
+        return rec(int(self.roots[tree]))
+
+    def tree_stats(self, tree: int):
+        """`Reader::stats` per tree (src/reader.rs:210-252): depth, split nodes, dummy normals, descendants."""
+        depth = splits = dummies = descs = 0
+        stack = [(int(self.roots[tree]), 1)]
+        while stack:
+            i, d = stack.pop()
+            nd = self.nodes[i]
+            depth = max(depth, d)
+            if nd["kind"] == 1:
+                descs += 1
+            else:
+                splits += 1
+                dummies += 0 if nd["has_normal"] else 1
+                stack.append((int(nd["left"]), d + 1))
+                stack.append((int(nd["right"]), d + 1))
+        return {"depth": depth, "split_nodes": splits, "dummy_normals": dummies, "descendants": descs}

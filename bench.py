@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — the headline measurement of arroy's distance-kernel hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): 1M x 768-dim cosine, synthetic i.i.d. uniform[-1,1) vectors generated
+in HBM by the counter-based generator of include/arroy_hip_policy.h (seed 42), ids 0..N-1.
+  * A "step" = one Q=1 batched cosine-distance scan over all 1M resident items (one kernel launch):
+    `D::built_distance(query, item)` for every item, src/reader.rs:381-391 -> src/distance/cosine.rs:43-59.
+    Inputs are resident in HBM when the timed region starts; outputs stay in HBM.
+  * value = total distances/s over all ranks (every rank scans its own replica: weak scaling).
+  * roofline: algorithmic bytes per launch = 1M x (4*768 + 4 header + 4 out) = 3080 B/distance
+     / the average kernel time measured with HIP events on the launch stream.
+  * build: the n_trees=50 forest of the same config, trees sharded round-robin over ranks, no collective.
+  * cpu_baseline (rank 0, N=1 only): the C oracle (a restatement of arroy's AVX2+FMA path, NOT arroy) on a
+    bounded sample of the same workload, all host cores.
+One JSON line on stdout (rank 0).  `--dry-run` exercises the multi-process control path on CPU (gloo).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_ITEMS = 1_000_000
+DIMS = 768
+N_TREES = 50
+SEED = 42
+BYTES_PER_DISTANCE = 4 * DIMS + 4 + 4  # vector + stored norm + written distance
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--items", type=int, default=N_ITEMS)
+    ap.add_argument("--trees", type=int, default=N_TREES)
+    ap.add_argument("--no-build", action="store_true", help="skip the forest-build measurement")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: test the N>1 control path (gloo)")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, n_items):
+    """Oracle timed on the host cores: bounded sample of the same workload (scan + a slice of the build)."""
+    import numpy as np
+
+    from oracle import oracle as O
+    L = O.lib()
+    cores = L.ao_num_threads()
+    n = min(n_items, 200_000)
+    vecs = O.synth(SEED, 1, n, DIMS)
+    big = O.Data(O.COSINE, vecs)  # headers = exact norms, computed by the oracle itself (parallel)
+    import ctypes as C
+    q, qh = big.item_leaf(0)
+    out = np.zeros(n, dtype=np.float32)
+    # warm-up + timed repetitions for ~cpu_seconds/2
+    big.distances(q, qh)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        L.ao_distances(big.c(), q.ctypes.data_as(C.c_void_p), qh.ctypes.data_as(C.c_void_p), None, n,
+                       out.ctypes.data_as(C.c_void_p))
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > args.cpu_seconds * 0.5 or reps >= 200:
+            break
+    scan_rate = reps * n / el
+    res = {"value": scan_rate, "unit": "distances/s", "cores": int(cores), "kind": "port",
+           "sample": f"Q=1 cosine scan over {n}x{DIMS} resident rows x {reps} reps, OpenMP on {cores} threads; "
+                     "C restatement of arroy's AVX2+FMA path (not arroy), data in RAM",
+           "scan_gb_per_s": scan_rate * BYTES_PER_DISTANCE / 1e9}
+    if not args.no_build:
+        nb = min(n, 100_000)
+        small = O.Data(O.COSINE, vecs[:nb], headers=big.headers[:nb])
+        seeds = np.arange(1, cores + 1, dtype=np.uint64)
+        t0 = time.perf_counter()
+        evals = L.ao_build_forest_count(small.c(), 0, seeds.ctypes.data_as(C.c_void_p), len(seeds))
+        el = time.perf_counter() - t0
+        res["build_margins_per_s"] = evals / el
+        res["build_sample"] = f"{len(seeds)} trees over {nb}x{DIMS} (one tree per thread), {el:.2f}s"
+    return res
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if args.dry_run else "nccl", rank=rank, world_size=world)
+
+    import torch
+
+    def barrier_sync():
+        if dist is not None:
+            if args.dry_run:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
+        if not args.dry_run:
+            torch.cuda.synchronize()
+
+    def max_over_ranks(x: float) -> float:
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if args.dry_run else f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    from arroy_amd import shard
+    my_trees = shard.trees_for_rank(args.trees, rank, world)
+    my_seeds = shard.tree_seeds(SEED, my_trees)
+
+    n = args.items
+    result = {}
+    if args.dry_run:
+        # control-path test: no device work, fixed fake durations
+        barrier_sync()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        barrier_sync()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        scan_ms = elapsed * 1e3 / max(args.steps, 1)
+        build = {"trees": args.trees, "trees_this_rank": len(my_trees), "seconds": max_over_ranks(0.001 * len(my_trees))}
+        kernel_ms = scan_ms
+        dev_name = "dry-run (cpu, gloo)"
+        cpu = None
+    else:
+        torch.cuda.set_device(local_rank)
+        import arroy_amd
+        from arroy_amd import Dataset, distances
+        dev_name = arroy_amd.device_name(local_rank)
+        ds = Dataset(distances.Cosine, DIMS, n, device=local_rank)
+        ds.fill_synthetic(SEED, 1, n)
+        ds.finalize()
+        query_item = 12345 % n
+        if args.warmup > 0:
+            ds.bench_scan(query_item, n, args.warmup)
+        barrier_sync()
+        t0 = time.perf_counter()
+        kernel_ms_total, _ = ds.bench_scan(query_item, n, args.steps)  # K launches, HIP events on the launch stream
+        barrier_sync()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        kernel_ms = max_over_ranks(kernel_ms_total / args.steps)
+        build = None
+        if not args.no_build and args.trees > 0:
+            barrier_sync()
+            t0 = time.perf_counter()
+            forest = ds.build_forest(my_seeds) if my_seeds else None
+            barrier_sync()
+            b_elapsed = max_over_ranks(time.perf_counter() - t0)
+            st = forest.stats if forest is not None else {}
+            margin_s = st.get("seconds_margin", 0.0)
+            evals = st.get("margin_evaluations", 0)
+            build = {
+                "workload": f"{n}x{DIMS} cosine, n_trees={args.trees} (split_after={DIMS}), trees t=rank mod {world}",
+                "trees": args.trees, "trees_this_rank": len(my_trees), "seconds": b_elapsed,
+                "seconds_device_rank0": st.get("seconds_device"), "seconds_margin_kernel_rank0": margin_s,
+                "margin_evaluations_rank0": evals, "levels": st.get("levels"),
+                "margins_per_s_rank0": evals / margin_s if margin_s else None,
+                "margin_algorithmic_gb_per_s_rank0": evals * 4 * DIMS / margin_s / 1e9 if margin_s else None,
+                "margin_frac_of_hbm_peak_rank0": evals * 4 * DIMS / margin_s / 1e9 / HBM_PEAK_GBS if margin_s else None,
+                "split_nodes_rank0": st.get("split_nodes"), "retries_rank0": st.get("retries"),
+                "dummy_normals_rank0": st.get("dummy_normals"), "scaling": "strong",
+            }
+        cpu = None
+        if rank == 0 and world == 1 and not args.no_cpu:
+            cpu = cpu_baseline(args, n)
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = world * n * args.steps / elapsed
+        achieved = n * BYTES_PER_DISTANCE / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "distances/sec, Q=1 batched 768-dim cosine scan (GB/s vs HBM roofline in `roofline`)",
+            "value": value, "unit": "distances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic uniform[-1,1) (counter-based generator, seed 42), generated in HBM",
+            "config": {"workload": f"{n}x{DIMS} cosine Q=1 distance scan, one replica per GPU (BASELINE configs[1])",
+                       "items": n, "dims": DIMS, "metric": "cosine", "device": dev_name},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": args.traffic_bytes,
+                         "kernel": "ah::k_distances_f32<COSINE,false>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": n * BYTES_PER_DISTANCE},
+            "cpu_baseline": cpu,
+            "build": build,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

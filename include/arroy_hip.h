@@ -36,6 +36,13 @@ extern "C" {
 
 #define AH_ABI_VERSION 1
 
+/* every entry point is exported from the shared object (it is built with -fvisibility=hidden) */
+#if defined(__GNUC__)
+#define AH_API __attribute__((visibility("default")))
+#else
+#define AH_API
+#endif
+
 /* arroy::distances (src/lib.rs:145-150).  The value is also the tag used in files/tests. */
 typedef enum ah_metric {
     AH_EUCLIDEAN = 0,              /* src/distance/euclidean.rs                 header {bias:f32}           */
@@ -64,15 +71,15 @@ typedef struct ah_dataset ah_dataset;   /* opaque: the HBM-resident image of Imm
 typedef struct ah_forest ah_forest;     /* opaque: host-side result of one forest build     */
 
 /* Size in bytes of D::Header for the metric (4, or 8 for DotProduct). src/distance/<metric>.rs `Header`. */
-size_t ah_header_size(int metric);
+AH_API size_t ah_header_size(int metric);
 /* Size in bytes of one stored vector: 4*dims for f32 codecs (src/unaligned_vector/f32.rs),
  * ceil(dims/64)*8 for the 1-bit codec (src/unaligned_vector/binary_quantized.rs:80-91). */
-size_t ah_vector_size(int metric, uint32_t dimensions);
+AH_API size_t ah_vector_size(int metric, uint32_t dimensions);
 
-int ah_abi_version(void);
-int ah_device_count(int *out_count);
+AH_API int ah_abi_version(void);
+AH_API int ah_device_count(int *out_count);
 /* Text of the calling thread's last failure ("" if none).  Never NULL. */
-const char *ah_last_error(void);
+AH_API const char *ah_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
  * Dataset = what `ImmutableLeafs::new` builds (src/parallel.rs:271-293): instead of a map
@@ -81,7 +88,7 @@ const char *ah_last_error(void);
  * ---------------------------------------------------------------------------------------- */
 
 /* `capacity` = number of items that will be uploaded (exact or an upper bound). */
-int ah_dataset_create(int metric, uint32_t dimensions, uint64_t capacity, int device, ah_dataset **out);
+AH_API int ah_dataset_create(int metric, uint32_t dimensions, uint64_t capacity, int device, ah_dataset **out);
 
 /* Stage `n` stored item records `[0u8][header][vector]` (src/node.rs:224-228,252-258) straight
  * from LMDB pages.  record_ptrs[i] may be arbitrarily (mis)aligned; every record is
@@ -89,30 +96,30 @@ int ah_dataset_create(int metric, uint32_t dimensions, uint64_t capacity, int de
  * Ids must be strictly ascending within and across calls (RoaringBitmap iteration order,
  * src/parallel.rs:283).  Records are copied into pinned staging buffers and sent with
  * hipMemcpyAsync, double-buffered; the pointers are not used after return. */
-int ah_dataset_upload_records(ah_dataset *ds, const uint32_t *item_ids, const uint8_t *const *record_ptrs,
+AH_API int ah_dataset_upload_records(ah_dataset *ds, const uint32_t *item_ids, const uint8_t *const *record_ptrs,
                               size_t record_len, size_t n);
 
 /* `Writer::add_item` for a batch (src/writer.rs:380-394): f32 vectors, row-major n x dims; the
  * library applies the codec (`UnalignedVector::from_slice`) and `D::new_header` on device. */
-int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, const float *vectors, size_t n);
+AH_API int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, const float *vectors, size_t n);
 
 /* Benchmark harness only: materialise `n_items` synthetic items (ids 0..n-1) directly in HBM with
  * the generator of arroy_hip_policy.h, then codec + new_header as in ah_dataset_upload_vectors. */
-int ah_dataset_fill_synthetic(ah_dataset *ds, uint64_t seed, int distribution, uint64_t n_items);
+AH_API int ah_dataset_fill_synthetic(ah_dataset *ds, uint64_t seed, int distribution, uint64_t n_items);
 
 /* Freeze the dataset (build the id -> row index).  Required before any query/build call. */
-int ah_dataset_finalize(ah_dataset *ds);
-int ah_dataset_len(const ah_dataset *ds, uint64_t *out_n_items);
+AH_API int ah_dataset_finalize(ah_dataset *ds);
+AH_API int ah_dataset_len(const ah_dataset *ds, uint64_t *out_n_items);
 /* `Reader::item_vector` (src/reader.rs:266-276): decoded f32 vector (dims floats; +-1.0 for BQ). */
-int ah_dataset_item_vector(ah_dataset *ds, uint32_t item_id, float *out_vector);
+AH_API int ah_dataset_item_vector(ah_dataset *ds, uint32_t item_id, float *out_vector);
 /* Copy stored headers of rows [first_row, first_row+n) to the host (header_size bytes each): what the
  * host needs to rewrite LMDB after `ah_preprocess_dot`. */
-int ah_dataset_read_headers(ah_dataset *ds, uint64_t first_row, uint64_t n, void *out_headers);
-int ah_dataset_destroy(ah_dataset *ds);
+AH_API int ah_dataset_read_headers(ah_dataset *ds, uint64_t first_row, uint64_t n, void *out_headers);
+AH_API int ah_dataset_destroy(ah_dataset *ds);
 
 /* `DotProduct::preprocess` (src/distance/dot_product.rs:119-165): max norm over all items, then
  * header.norm = max^2, header.extra_dim = sqrt(max^2 - |v|^2) for every item, on device. */
-int ah_preprocess_dot(ah_dataset *ds, float *out_max_norm);
+AH_API int ah_preprocess_dot(ah_dataset *ds, float *out_max_norm);
 
 /* ------------------------------------------------------------------------------------------
  * Search side (src/reader.rs:376-400, 607-640)
@@ -121,21 +128,21 @@ int ah_preprocess_dot(ah_dataset *ds, float *out_max_norm);
 /* Raw batched `D::built_distance(query, item)` (non-normalized), `QueryBuilder::by_vector`
  * semantics for the query (src/reader.rs:64-75: codec + `D::new_header`).  `item_ids == NULL`
  * scans rows 0..n-1 of the dataset in id order; otherwise one distance per listed id. */
-int ah_distances_by_vector(ah_dataset *ds, const float *query, const uint32_t *item_ids, size_t n, float *out);
+AH_API int ah_distances_by_vector(ah_dataset *ds, const float *query, const uint32_t *item_ids, size_t n, float *out);
 /* Same with the query taken from a stored item (`by_item`, src/reader.rs:46-51). */
-int ah_distances_by_item(ah_dataset *ds, uint32_t query_item, const uint32_t *item_ids, size_t n, float *out);
+AH_API int ah_distances_by_item(ah_dataset *ds, uint32_t query_item, const uint32_t *item_ids, size_t n, float *out);
 
 /* The re-rank loop + `median_based_top_k` + `D::normalized_distance` (src/reader.rs:381-399):
  * `sorted_ids` ascending and unique (src/reader.rs:378-379) or NULL for "all items".  Writes
  * min(k, n) pairs ordered by (OrderedFloat(distance), id) ascending. */
-int ah_rerank_by_vector(ah_dataset *ds, const float *query, const uint32_t *sorted_ids, size_t n, size_t k,
+AH_API int ah_rerank_by_vector(ah_dataset *ds, const float *query, const uint32_t *sorted_ids, size_t n, size_t k,
                         uint32_t *out_ids, float *out_distances, size_t *out_n);
-int ah_rerank_by_item(ah_dataset *ds, uint32_t query_item, const uint32_t *sorted_ids, size_t n, size_t k,
+AH_API int ah_rerank_by_item(ah_dataset *ds, uint32_t query_item, const uint32_t *sorted_ids, size_t n, size_t k,
                       uint32_t *out_ids, float *out_distances, size_t *out_n);
 /* Many queries in one submission (candidate lists concatenated; list q is
  * ids[offsets[q] .. offsets[q+1])).  Outputs are n_queries x k, short lists padded with id
  * 0xFFFFFFFF / distance NaN; out_counts[q] = min(k, len_q). */
-int ah_rerank_batch(ah_dataset *ds, const float *queries, size_t n_queries, const uint32_t *ids,
+AH_API int ah_rerank_batch(ah_dataset *ds, const float *queries, size_t n_queries, const uint32_t *ids,
                     const uint64_t *offsets, size_t k, uint32_t *out_ids, float *out_distances,
                     uint32_t *out_counts);
 
@@ -150,14 +157,14 @@ int ah_rerank_batch(ah_dataset *ds, const float *queries, size_t n_queries, cons
  * is D::Header.  Bit i (LSB first) of side_bits = 1 when item i goes Right
  * (`margin.is_sign_positive()`, src/distance/mod.rs:103-110); (n+7)/8 bytes. Optionally also
  * returns the margins themselves (out_margins may be NULL). */
-int ah_split_sides(ah_dataset *ds, const void *normal_vector, const void *normal_header,
+AH_API int ah_split_sides(ah_dataset *ds, const void *normal_vector, const void *normal_header,
                    const uint32_t *sorted_ids, size_t n, uint8_t *side_bits, uint64_t *out_n_left,
                    float *out_margins);
 
 /* `D::create_split` (src/distance/{euclidean.rs:55-77,cosine.rs:73-85,dot_product.rs:98-113,...}) with the
  * randomness supplied by the host: sample_ids[0..1] = choose_two, [2..11] = the ten `choose` draws
  * (the RNG policy stays in the caller, as with `R: Rng`). */
-int ah_create_split(ah_dataset *ds, const uint32_t sample_ids[AH_SPLIT_SAMPLES], void *out_normal_vector,
+AH_API int ah_create_split(ah_dataset *ds, const uint32_t sample_ids[AH_SPLIT_SAMPLES], void *out_normal_vector,
                     void *out_normal_header);
 
 typedef void (*ah_progress_fn)(void *user, uint32_t level, uint64_t nodes_done, uint64_t items_routed);
@@ -175,7 +182,7 @@ typedef struct ah_build_options {
 /* Whole-forest build: `make_tree_in_file` for every tree (src/writer.rs:556-591,1167-1261) with the
  * randomness policy of arroy_hip_policy.h.  Level-synchronous on device; nothing is visible to the
  * caller until the whole forest exists (src/writer.rs:597-607). */
-int ah_build_forest(ah_dataset *ds, const ah_build_options *options, ah_forest **out);
+AH_API int ah_build_forest(ah_dataset *ds, const ah_build_options *options, ah_forest **out);
 
 enum { AH_NODE_DESCENDANTS = 1, AH_NODE_SPLIT = 2 };   /* node tags, src/node.rs:216-241 */
 
@@ -211,14 +218,14 @@ typedef struct ah_build_stats {
     uint32_t levels;
 } ah_build_stats;
 
-int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out);
-int ah_forest_stats(const ah_forest *forest, ah_build_stats *out);
+AH_API int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out);
+AH_API int ah_forest_stats(const ah_forest *forest, ah_build_stats *out);
 /* Node sink in the shape `TmpNodes::put` expects (src/parallel.rs:130-147): children first, parent
  * last (post-order), per tree. `payload`: SPLIT -> [header][vector] or NULL; DESCENDANTS -> u32 ids. */
 typedef int (*ah_node_sink_fn)(void *user, uint32_t tree, uint32_t node, uint8_t kind, uint32_t left,
                                uint32_t right, const void *payload, size_t payload_len);
-int ah_forest_visit(const ah_forest *forest, ah_node_sink_fn sink, void *user);
-int ah_forest_destroy(ah_forest *forest);
+AH_API int ah_forest_visit(const ah_forest *forest, ah_node_sink_fn sink, void *user);
+AH_API int ah_forest_destroy(ah_forest *forest);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py).  They time with hipEvents recorded on the same stream the
@@ -229,12 +236,12 @@ int ah_forest_destroy(ah_forest *forest);
  * the total kernel time in milliseconds (HIP events on the launch stream).  The query is
  * item `query_item`.  Distances of the last iteration are left in an internal device buffer; if
  * `out` is non-NULL they are copied to it (n floats) after the timed region. */
-int ah_bench_scan(ah_dataset *ds, uint32_t query_item, uint64_t n, uint32_t iterations, float *out,
+AH_API int ah_bench_scan(ah_dataset *ds, uint32_t query_item, uint64_t n, uint32_t iterations, float *out,
                   double *out_ms_total);
 /* Device-to-device copy of `bytes` bytes, `iterations` times: the measured streaming ceiling. */
-int ah_bench_memcpy(int device, uint64_t bytes, uint32_t iterations, double *out_ms_total);
+AH_API int ah_bench_memcpy(int device, uint64_t bytes, uint32_t iterations, double *out_ms_total);
 /* Name of the device (hipDeviceProp_t.name / gcnArchName) into buf. */
-int ah_device_name(int device, char *buf, size_t buf_len);
+AH_API int ah_device_name(int device, char *buf, size_t buf_len);
 
 #ifdef __cplusplus
 }

@@ -439,6 +439,13 @@ static const void *row_vec(const ao_data *d, uint64_t row) {
 }
 static const float *row_hdr(const ao_data *d, uint64_t row) { return d->headers + row * ao_header_floats(d->metric); }
 
+/* D::new_header for every row (Writer::add_item, src/writer.rs:380-394), parallel over rows. */
+AO_API void ao_new_headers(ao_data *d) {
+    size_t hf = ao_header_floats(d->metric);
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < (int64_t)d->n; r++) ao_new_header(d->metric, row_vec(d, (uint64_t)r), d->dims, d->headers + (size_t)r * hf);
+}
+
 /* The re-rank loop, src/reader.rs:381-391 (rows == NULL: rows 0..n-1). OpenMP over rows = the
  * rayon-style CPU baseline. */
 AO_API void ao_distances(const ao_data *d, const void *qv, const float *qh, const uint32_t *rows, uint64_t n,

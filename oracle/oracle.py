@@ -90,6 +90,7 @@ def lib() -> C.CDLL:
         L.ao_side_of_margin.argtypes = [C.c_float]
         L.ao_pq_distance.restype = C.c_float
         L.ao_pq_distance.argtypes = [C.c_float, C.c_float, C.c_int]
+        L.ao_new_headers.argtypes = [C.POINTER(AoData)]
         L.ao_distances.argtypes = [C.POINTER(AoData), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         for name in ("ao_top_k", "ao_top_k_spec"):
             fn = getattr(L, name)
@@ -186,17 +187,16 @@ class Data:
         elif is_bq(metric):
             self.codec = np.stack([bq_quantize(r) for r in v]) if self.n else np.zeros((0, 0), np.uint8)
         else:
-            self.codec = v.view(np.uint8).reshape(self.n, 4 * self.dims).copy()
+            self.codec = v.view(np.uint8).reshape(self.n, 4 * self.dims)  # no copy: rows may be GBs
         hf = header_floats(metric)
-        if headers is not None:
-            self.headers = _f32(headers).reshape(self.n, hf).copy()
-        else:
-            self.headers = np.zeros((self.n, hf), dtype=np.float32)
-            for r in range(self.n):  # D::new_header at add_item time
-                L.ao_new_header(metric, _p(self.codec[r]), self.dims, _p(self.headers[r]))
+        self.headers = np.zeros((self.n, hf), dtype=np.float32) if headers is None else \
+            _f32(headers).reshape(self.n, hf).copy()
         self.ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
+        self._keep = v
         self._c = AoData(metric, self.dims, self.n, self.codec.ctypes.data, self.headers.ctypes.data,
                          None if self.ids is None else self.ids.ctypes.data)
+        if headers is None and self.n:
+            L.ao_new_headers(C.byref(self._c))  # D::new_header at add_item time
 
     def c(self):
         return C.byref(self._c)

@@ -1,0 +1,63 @@
+"""CPU-side checks of the drop-in boundary: the shared object loads and exports exactly the symbols that
+include/arroy_hip.h declares.  No compute calls (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "arroy_hip.h")).read()
+    return sorted(set(re.findall(r"^AH_API [^;(]*?\b(ah_[a-z_0-9]+)\s*\(", src, re.M)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from arroy_amd import _lib
+    _lib.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 28
+    for name in names:
+        assert hasattr(L, name), f"{name} declared in include/arroy_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
+
+
+def test_abi_scalars_without_a_gpu():
+    from arroy_amd import _lib
+    L = _lib.lib()
+    assert L.ah_abi_version() == 1
+    assert [L.ah_header_size(m) for m in range(7)] == [4, 4, 4, 8, 4, 4, 4]
+    assert L.ah_vector_size(2, 768) == 3072
+    assert L.ah_vector_size(6, 768) == 96
+    assert L.ah_vector_size(6, 65) == 16  # rounds up to whole 64-bit words (binary_quantized.rs:67-69)
+    assert L.ah_header_size(99) == 0
+    assert _lib.device_count() >= 0
+    assert L.ah_last_error() is not None
+
+
+def test_errors_are_codes_not_exceptions_across_the_abi():
+    import pytest
+
+    from arroy_amd import _lib
+    h = ctypes.c_void_p()
+    # unknown metric -> AH_ERR_INVALID_ARGUMENT with a message; nothing thrown through C
+    st = _lib.lib().ah_dataset_create(42, 8, 10, 0, ctypes.byref(h))
+    assert st == 5 and b"metric" in _lib.lib().ah_last_error()
+    st = _lib.lib().ah_dataset_create(0, 0, 10, 0, ctypes.byref(h))
+    assert st == 1  # InvalidVecDimension
+    with pytest.raises(_lib.ArroyHipError):
+        _lib.check(st)
+    assert _lib.lib().ah_dataset_destroy(None) == 0
+
+
+def test_policy_header_matches_between_host_compilers():
+    """The RNG / synthetic-data policy is plain C shared by host and device code; pin a few values so an
+    accidental edit is caught on CPU (the GPU tests compare device output with these functions)."""
+    from oracle import oracle as O
+    x = O.synth(42, 0, 4, 8)
+    assert x.shape == (4, 8) and x.min() >= 0.0 and x.max() < 1.0
+    y = O.synth(42, 1, 4, 8)
+    assert y.min() >= -1.0 and y.max() < 1.0
+    assert (y == x * 2 - 1).all()
+    assert not (O.synth(43, 0, 4, 8) == x).all()

@@ -1,0 +1,365 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bit-exact for everything: integer / index work by nature, f32 because the kernels reproduce the
+reference's AVX+FMA (dims >= 32), SSE (16..31) and scalar (< 16) summation order.  The tolerance the
+north star allows for f32 distances (1e-5 relative) is therefore asserted as *zero* ulps here.
+Run with:  gpurun -- python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+from conftest import hex_f32
+
+pytestmark = pytest.mark.gpu
+
+D = None  # arroy_amd.distances, imported lazily so collection works without the .so
+O = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _imports():
+    global D, O
+    import arroy_amd
+    from arroy_amd import distances
+    from oracle import oracle
+    assert arroy_amd.device_count() >= 1, "no GPU visible: these tests must run on an MI355X"
+    D, O = distances, oracle
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bit_equal(a, b, what=""):
+    a, b = np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    bad = np.nonzero(bits(a) != bits(b))[0]
+    assert bad.size == 0, f"{what}: {bad.size} of {a.size} differ, first at {bad[:5]}: {a[bad[:5]]} vs {b[bad[:5]]}"
+
+
+def make_data(metric_cls, n, dims, seed, ids=None, scale=1.0):
+    from arroy_amd import Dataset
+    rng = np.random.default_rng(seed)
+    vecs = (rng.standard_normal((n, dims)) * scale).astype(np.float32)
+    # a few exact duplicates and zeros: ties and degenerate norms
+    if n > 10:
+        vecs[3] = vecs[1]
+        vecs[n // 2] = vecs[1]
+        vecs[5] = 0.0
+    ids = np.arange(n, dtype=np.uint32) if ids is None else np.asarray(ids, dtype=np.uint32)
+    ds = Dataset(metric_cls, dims, n)
+    half = n // 2
+    ds.upload_vectors(ids[:half], vecs[:half])  # two calls: chunked append
+    ds.upload_vectors(ids[half:], vecs[half:])
+    oracle = O.Data(metric_cls.metric, vecs, ids=None if np.array_equal(ids, np.arange(n)) else ids)
+    if metric_cls.metric == 3:  # DotProduct: preprocess on both sides
+        m_gpu = ds.preprocess_dot()
+        m_cpu = oracle.preprocess_dot()
+        assert bits(m_gpu) == bits(m_cpu)
+    ds.finalize()
+    return ds, oracle, vecs, ids
+
+
+ALL_METRICS = [0, 1, 2, 3, 4, 5, 6]
+DIMS = [3, 17, 30, 32, 70, 96, 128, 768]
+
+
+# ---- golden vectors of the reference, through the GPU (src/tests/upgrade.rs:58-67,116-128) ------------
+
+@pytest.mark.parametrize("name", ["large_v0_6", "smol_v0_6"])
+def test_reference_golden_nns_on_gpu(golden, name):
+    from arroy_amd import Dataset
+    g = golden[name]
+    vecs = np.stack([hex_f32(h) for h in g["vectors_hex"]])
+    hdrs = [bytes.fromhex(h) for h in g["headers_hex"]]
+    # the stored LMDB record layout [tag][header][vector] (src/node.rs:224-228), pointers misaligned
+    records = [b"\x00" + hdrs[i] + vecs[i].tobytes() for i in range(len(hdrs))]
+    ds = Dataset(D.Euclidean, g["dims"], len(records))
+    ds.upload_records(g["ids"], records)
+    ds.finalize()
+    ids, dists = ds.rerank(g["count"], query=np.array(g["query"], dtype=np.float32))
+    from test_oracle_golden import rust_display_f32
+    assert [[int(i), rust_display_f32(d)] for i, d in zip(ids, dists)] == g["expected"]
+    assert_bit_equal(ds.item_vector(g["ids"][0]), vecs[0])
+
+
+# ---- batched distances (src/reader.rs:381-391) ----------------------------------------------------------
+
+@pytest.mark.parametrize("metric", ALL_METRICS)
+@pytest.mark.parametrize("dims", DIMS)
+def test_distances_bit_exact(metric, dims):
+    cls = D.BY_METRIC[metric]
+    n = 700
+    ds, oracle, vecs, ids = make_data(cls, n, dims, seed=100 + metric * 31 + dims)
+    rng = np.random.default_rng(dims)
+    q = rng.standard_normal(dims).astype(np.float32)
+    qv, qh = oracle.query_leaf(q)
+    assert_bit_equal(ds.distances(query=q), oracle.distances(qv, qh), f"scan by_vector m={metric} d={dims}")
+    qv, qh = oracle.item_leaf(7)
+    assert_bit_equal(ds.distances(item=7), oracle.distances(qv, qh), "scan by_item")
+    sub = np.sort(rng.choice(n, 123, replace=False)).astype(np.uint32)
+    assert_bit_equal(ds.distances(item=7, ids=sub), oracle.distances(qv, qh, rows=sub), "gather")
+    d_self = ds.distances(item=9, ids=[9])
+    if metric in (0, 1, 4, 5):
+        assert d_self[0] == 0.0
+
+
+@pytest.mark.parametrize("metric", ALL_METRICS)
+def test_sparse_item_ids_and_lut(metric):
+    cls = D.BY_METRIC[metric]
+    n, dims = 300, 40
+    ids = np.sort(np.random.default_rng(1).choice(5000, n, replace=False)).astype(np.uint32)
+    ds, oracle, vecs, _ = make_data(cls, n, dims, seed=5, ids=ids)
+    qv, qh = oracle.item_leaf(11)
+    rows = np.arange(0, n, 3, dtype=np.uint32)
+    got = ds.distances(item=int(ids[11]), ids=ids[rows])
+    assert_bit_equal(got, oracle.distances(qv, qh, rows=rows))
+    oi, od = ds.rerank(10, item=int(ids[11]))
+    ei, ed = oracle.rerank(qv, qh, None, 10)
+    assert list(oi) == list(ei)
+    assert_bit_equal(od, ed)
+    from arroy_amd import MissingKey
+    with pytest.raises(MissingKey):
+        missing = int(np.setdiff1d(np.arange(5000), ids)[0])
+        ds.distances(item=int(ids[0]), ids=[missing])
+
+
+def test_very_sparse_ids_use_binary_search():
+    n, dims = 64, 32
+    ids = (np.arange(n, dtype=np.uint64) * 50_000_000 + 7).astype(np.uint32)
+    ds, oracle, vecs, _ = make_data(D.Euclidean, n, dims, seed=9, ids=ids)
+    qv, qh = oracle.item_leaf(3)
+    assert_bit_equal(ds.distances(item=int(ids[3]), ids=ids[::2]), oracle.distances(qv, qh, rows=np.arange(0, n, 2)))
+
+
+# ---- re-rank + top-k (src/reader.rs:376-400, 607-640) ---------------------------------------------------
+
+@pytest.mark.parametrize("metric", ALL_METRICS)
+@pytest.mark.parametrize("n,k", [(50, 10), (5000, 1), (5000, 100), (9000, 2048), (9000, 3000), (300, 1000)])
+def test_rerank_matches_reference_top_k(metric, n, k):
+    cls = D.BY_METRIC[metric]
+    dims = 64
+    ds, oracle, vecs, ids = make_data(cls, n, dims, seed=n + k + metric, scale=1.0 if metric < 4 else 1.0)
+    rng = np.random.default_rng(k)
+    q = rng.standard_normal(dims).astype(np.float32)
+    qv, qh = oracle.query_leaf(q)
+    cand = np.sort(rng.choice(n, max(1, (2 * n) // 3), replace=False)).astype(np.uint32)
+    for rows in (None, cand):
+        oi, od = ds.rerank(k, query=q, sorted_ids=rows)
+        ei, ed = oracle.rerank(qv, qh, rows, k)
+        assert list(oi) == list(ei), f"ids differ m={metric} n={n} k={k}"
+        assert_bit_equal(od, ed)
+
+
+def test_rerank_ties_break_by_item_id():
+    """BQ distances are small integers: massive ties, the order must be (distance, id)."""
+    n, dims = 4000, 64
+    ds, oracle, vecs, ids = make_data(D.BinaryQuantizedEuclidean, n, dims, seed=77)
+    q = np.random.default_rng(2).standard_normal(dims).astype(np.float32)
+    qv, qh = oracle.query_leaf(q)
+    oi, od = ds.rerank(500, query=q)
+    ei, ed = oracle.rerank(qv, qh, None, 500)
+    assert list(oi) == list(ei)
+    assert_bit_equal(od, ed)
+    assert len(set(od.tolist())) < 40  # really tie-heavy
+
+
+def test_rerank_rejects_unsorted_candidates_and_bad_dimensions():
+    from arroy_amd import ArroyHipError, InvalidVecDimension
+    ds, oracle, vecs, ids = make_data(D.Euclidean, 100, 32, seed=1)
+    with pytest.raises(ArroyHipError):
+        ds.rerank(5, item=0, sorted_ids=[5, 3, 9])
+    with pytest.raises(InvalidVecDimension):
+        ds.rerank(5, query=np.zeros(31, dtype=np.float32))
+    with pytest.raises(InvalidVecDimension):
+        ds2 = __import__("arroy_amd").Dataset(D.Euclidean, 32, 4)
+        ds2.upload_records([0], [b"\x00" + b"\x00" * 4 + b"\x00" * 4 * 31])  # 31-dim record in a 32-dim index
+
+
+def test_rerank_batch_equals_single_queries():
+    n, dims, k = 3000, 96, 20
+    ds, oracle, vecs, ids = make_data(D.Cosine, n, dims, seed=4)
+    rng = np.random.default_rng(8)
+    qs = rng.standard_normal((5, dims)).astype(np.float32)
+    lists = [np.sort(rng.choice(n, m, replace=False)).astype(np.uint32) for m in (900, 15, 2500, 1, 0)]
+    oi, od, oc = ds.rerank_batch(qs, lists, k)
+    for i in range(5):
+        if len(lists[i]) == 0:
+            assert oc[i] == 0
+            continue
+        ei, ed = ds.rerank(k, query=qs[i], sorted_ids=lists[i])
+        assert oc[i] == len(ei)
+        assert list(oi[i, : oc[i]]) == list(ei)
+        assert_bit_equal(od[i, : oc[i]], ed)
+
+
+# ---- build side: margins / sides / create_split ------------------------------------------------------------
+
+@pytest.mark.parametrize("metric", ALL_METRICS)
+@pytest.mark.parametrize("dims", [3, 30, 64, 100, 768])
+def test_create_split_and_sides_bit_exact(metric, dims):
+    cls = D.BY_METRIC[metric]
+    n = 400
+    ds, oracle, vecs, ids = make_data(cls, n, dims, seed=dims * 7 + metric)
+    rng = np.random.default_rng(metric)
+    for trial in range(3):
+        sample = rng.choice(n, 12, replace=trial == 2).astype(np.uint32)
+        if sample[0] == sample[1]:
+            sample[1] = (sample[0] + 1) % n
+        nv, nh = ds.create_split(sample)
+        env, enh = oracle.create_split(sample)
+        assert nv.tobytes() == env.tobytes(), f"normal differs m={metric} d={dims} trial={trial}"
+        assert_bit_equal(nh, enh, "normal header")
+        sides, n_left, margins = ds.split_sides(nv, nh)
+        es, enl, em = oracle.split_sides(env, enh)
+        assert_bit_equal(margins, em, "margins")
+        assert np.array_equal(sides, es) and n_left == enl
+        sub = np.sort(rng.choice(n, 77, replace=False)).astype(np.uint32)
+        sides, n_left, margins = ds.split_sides(nv, nh, sorted_ids=sub)
+        es, enl, em = oracle.split_sides(env, enh, rows=sub)
+        assert_bit_equal(margins, em)
+        assert np.array_equal(sides, es) and n_left == enl
+
+
+def test_side_of_signed_zero():
+    """`is_sign_positive` (src/distance/mod.rs:103-110): +0.0 -> Right, -0.0 -> Left."""
+    from arroy_amd import Dataset
+    vecs = np.zeros((4, 32), dtype=np.float32)
+    vecs[1, 0] = 1.0
+    vecs[2, 0] = -1.0
+    ds = Dataset(D.Euclidean, 32, 4)
+    ds.upload_vectors(np.arange(4), vecs)
+    ds.finalize()
+    normal = np.zeros(32, dtype=np.float32)
+    normal[0] = 1.0
+    sides, n_left, margins = ds.split_sides(normal, [0.0])
+    assert list(sides) == [1, 1, 0, 1] and n_left == 1
+    sides, n_left, margins = ds.split_sides(normal, [-0.0])  # bias -0.0: -0.0 + +0.0 = +0.0
+    assert list(sides) == [1, 1, 0, 1]
+    normal[:] = 0.0
+    normal[0] = -0.0
+    sides, n_left, margins = ds.split_sides(normal, [-0.0])
+    o = O.Data(0, vecs)
+    es, enl, em = o.split_sides(normal, np.array([-0.0], dtype=np.float32))
+    assert np.array_equal(sides, es)
+    assert_bit_equal(margins, em)
+
+
+# ---- whole forest: GPU level-synchronous build == CPU depth-first oracle ------------------------------------
+
+def check_forest_valid(forest, n_items, ids=None):
+    """`Reader::assert_validity` (src/reader.rs:509-589): every tree reaches every item exactly once."""
+    expect = np.arange(n_items, dtype=np.uint32) if ids is None else np.sort(ids)
+    for t in range(forest.n_trees):
+        got = []
+        stack = [int(forest.roots[t])]
+        seen = set()
+        while stack:
+            i = stack.pop()
+            assert i not in seen
+            seen.add(i)
+            nd = forest.nodes[i]
+            if nd["kind"] == 1:
+                d = forest.descendants_of(i)
+                assert np.all(np.diff(d.astype(np.int64)) > 0)  # ascending ids inside a Descendants node
+                got.append(d)
+            else:
+                stack += [int(nd["left"]), int(nd["right"])]
+        got = np.sort(np.concatenate(got)) if got else np.zeros(0, np.uint32)
+        assert np.array_equal(got, expect), f"tree {t} does not cover every item exactly once"
+
+
+@pytest.mark.parametrize("metric", ALL_METRICS)
+@pytest.mark.parametrize("n,dims,split_after", [(3000, 32, 32), (2500, 40, 100), (700, 8, 8), (6000, 96, 0)])
+def test_forest_equals_oracle(metric, n, dims, split_after):
+    cls = D.BY_METRIC[metric]
+    ds, oracle, vecs, ids = make_data(cls, n, dims, seed=n + dims + metric)
+    seeds = [42, 7, 2**63 + 5]
+    forest = ds.build_forest(seeds, split_after=split_after)
+    assert forest.n_trees == 3
+    check_forest_valid(forest, n)
+    for t, seed in enumerate(seeds):
+        ref = oracle.build_tree(split_after, seed)
+        assert forest.canonical(t) == ref.canonical(), f"tree {t} differs from the oracle (m={metric})"
+    total = sum(oracle.build_tree(split_after, s).margin_evals for s in seeds)
+    assert forest.stats["margin_evaluations"] == total
+
+
+def test_forest_degenerate_inputs():
+    from arroy_amd import Dataset
+    # all items identical: every split fails 4 times, then the random fallback halves the node
+    n, dims = 600, 32
+    vecs = np.ones((n, dims), dtype=np.float32)
+    ds = Dataset(D.Euclidean, dims, n)
+    ds.upload_vectors(np.arange(n), vecs)
+    ds.finalize()
+    forest = ds.build_forest([1, 2], split_after=16)
+    check_forest_valid(forest, n)
+    assert forest.stats["dummy_normals"] > 0
+    o = O.Data(0, vecs)
+    for t, seed in enumerate([1, 2]):
+        assert forest.canonical(t) == o.build_tree(16, seed).canonical()
+    # fewer items than split_after: one Descendants root per tree (src/writer.rs:499-501)
+    forest = ds.build_forest([5], split_after=1000)
+    assert forest.nodes.size == 1 and forest.nodes[0]["kind"] == 1
+    assert list(forest.descendants_of(0)) == list(range(n))
+    # zero trees
+    assert ds.build_forest([], split_after=16).n_trees == 0
+
+
+def test_forest_with_sparse_ids_and_batches():
+    n, dims = 2000, 32
+    ids = np.sort(np.random.default_rng(3).choice(100000, n, replace=False)).astype(np.uint32)
+    ds, oracle, vecs, _ = make_data(D.Cosine, n, dims, seed=12, ids=ids)
+    seeds = list(range(10, 15))
+    a = ds.build_forest(seeds, split_after=50)
+    b = ds.build_forest(seeds, split_after=50, max_trees_in_flight=2)  # batching must not change anything
+    check_forest_valid(a, n, ids)
+    for t, seed in enumerate(seeds):
+        assert a.canonical(t) == b.canonical(t) == oracle.build_tree(50, seed).canonical()
+
+
+def test_build_can_be_cancelled():
+    from arroy_amd import BuildCancelled
+    ds, oracle, vecs, ids = make_data(D.Euclidean, 5000, 32, seed=1)
+    with pytest.raises(BuildCancelled):
+        ds.build_forest([1, 2, 3], split_after=8, cancel=lambda: True)
+
+
+# ---- full-size properties (BASELINE config 2 shape: 1M x 768 cosine) ----------------------------------------
+
+def test_full_size_properties_1m_x_768_cosine():
+    from arroy_amd import Dataset
+    n, dims = 1_000_000, 768
+    ds = Dataset(D.Cosine, dims, n)
+    ds.fill_synthetic(42, 1, n)
+    ds.finalize()
+    # (1) sampled rows are exactly the policy generator's rows; their headers the exact norms
+    rows = np.array([0, 1, 12345, 999_999], dtype=np.uint32)
+    for r in rows:
+        assert_bit_equal(ds.item_vector(int(r)), O.synth(42, 1, 1, dims, first_item=int(r))[0])
+    sample = np.sort(np.random.default_rng(0).choice(n, 1500, replace=False)).astype(np.uint32)
+    vec_s = np.concatenate([O.synth(42, 1, 1, dims, first_item=int(r)) for r in sample])
+    od = O.Data(2, vec_s)
+    # (2) distances of the sampled rows are bit-exact against the oracle on the same rows
+    q = O.synth(7, 1, 1, dims)[0]
+    qv, qh = od.query_leaf(q)
+    assert_bit_equal(ds.distances(query=q, ids=sample), od.distances(qv, qh))
+    # (3) the top-k of the full scan is the sorted head of the full distance array under (distance, id)
+    full = ds.distances(query=q)
+    assert_bit_equal(full[sample], od.distances(qv, qh))
+    oi, odist = ds.rerank(100, query=q)
+    order = np.lexsort((np.arange(n), full))[:100]
+    assert list(oi) == list(order)
+    assert_bit_equal(odist, full[order])
+    # (4) a split partitions: sides follow the margins' sign bit, counts add up
+    nv, nh = ds.create_split(sample[:12])
+    sides, n_left, margins = ds.split_sides(nv, nh)
+    assert n_left == int((sides == 0).sum()) and np.array_equal(sides, (~np.signbit(margins)).astype(np.uint8))
+    assert 0.05 * n < n_left < 0.95 * n
+    # (5) a 2-tree forest over all items is structurally valid and deterministic
+    f1 = ds.build_forest([1, 2])
+    check_forest_valid(f1, n)
+    f2 = ds.build_forest([1, 2])
+    assert f1.normals.tobytes() == f2.normals.tobytes() and np.array_equal(f1.descendants, f2.descendants)
+    assert all(f1.tree_stats(t)["descendants"] > n // 768 for t in range(2))
