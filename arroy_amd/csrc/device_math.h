@@ -19,13 +19,16 @@
 
 namespace ah {
 
-// IEEE single ops that the compiler must not fuse/reassociate (the TU is also built with
-// -ffp-contract=off; these make the intent local and explicit).
-__device__ __forceinline__ float f_add(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ float f_sub(float a, float b) { return __fsub_rn(a, b); }
-__device__ __forceinline__ float f_mul(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float f_div(float a, float b) { return __fdiv_rn(a, b); }
-__device__ __forceinline__ float f_sqrt(float a) { return __fsqrt_rn(a); }
+// IEEE single ops.  The TU is built with -ffp-contract=off (Rust never fuses a*b+c) and
+// -fhip-fp32-correctly-rounded-divide-sqrt ('/' and sqrtf lower to the correctly rounded sequences).
+// NOTE: HIP's __fsqrt_rn / __fdiv_rn are NOT used: without OCML_BASIC_ROUNDED_OPERATIONS __fsqrt_rn is
+// __ocml_native_sqrt_f32 (1 ulp), which breaks bit parity with the reference's f32::sqrt.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float f_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float f_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float f_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float f_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float f_sqrt(float a) { return sqrtf(a); }
 
 enum { OP_DOT = 0, OP_EUCLID = 1 };
 

@@ -16,6 +16,7 @@
 // No atomics on floats, no dependence on workgroup scheduling: results are deterministic.
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <new>
 
 #include "common.h"
@@ -53,9 +54,11 @@ __global__ void k_init_perm(uint32_t *perm, uint64_t n, uint32_t n_trees) {
 }
 
 // One wave per pending node: sample 2+10 items with the policy RNG, run create_split.
+//
+// Normal records (device layout == the layout handed to the caller): [vector, row_bytes][header, 16-byte slot].
 __global__ __launch_bounds__(64) void k_forest_create_split(DataView dv, FNode *nodes, const uint32_t *__restrict__ perm,
                                                             uint64_t n_items, uint8_t *normals, uint64_t nstride,
-                                                            float *nhdrs) {
+                                                            uint64_t hdr_off) {
     FNode &nd = nodes[blockIdx.x];
     if (nd.state != ST_PENDING) return;
     extern __shared__ float4 s_buf4[];
@@ -73,8 +76,10 @@ __global__ __launch_bounds__(64) void k_forest_create_split(DataView dv, FNode *
         s_rows[threadIdx.x] = pp[ah_choose(nd.key, nd.attempt, threadIdx.x - 2, nd.count)];  // :358-367
     }
     __syncthreads();
-    wave_create_split_any(dv, s_rows, s_buf, s_buf + fpitch, s_buf + 2 * fpitch, normals + blockIdx.x * nstride,
-                          nhdrs + 2 * (uint64_t)blockIdx.x, threadIdx.x);
+    uint8_t *rec = normals + blockIdx.x * nstride;
+    float *hdr = reinterpret_cast<float *>(rec + hdr_off);
+    wave_create_split_any(dv, s_rows, s_buf, s_buf + fpitch, s_buf + 2 * fpitch, rec, hdr, threadIdx.x);
+    if (threadIdx.x == 0) hdr[2] = hdr[3] = 0.0f;  // deterministic padding
 }
 
 // The margin loop (src/writer.rs:1201-1207) for all pending nodes of the level, tile by tile.
@@ -85,7 +90,7 @@ template <int METRIC>
 __global__ __launch_bounds__(kBlock) void k_forest_margin_f32(DataView dv, FNode *nodes, const FTile *__restrict__ tiles,
                                                               uint32_t n_tiles, const uint32_t *__restrict__ perm,
                                                               uint64_t n_items, const uint8_t *__restrict__ normals,
-                                                              uint64_t nstride, const float *__restrict__ nhdrs,
+                                                              uint64_t nstride, uint64_t hdr_off,
                                                               uint64_t *__restrict__ masks,
                                                               uint32_t *__restrict__ tile_left) {
     extern __shared__ float4 s_n4[];
@@ -101,7 +106,8 @@ __global__ __launch_bounds__(kBlock) void k_forest_margin_f32(DataView dv, FNode
         for (uint32_t i = threadIdx.x; i < (dv.pitch >> 2); i += blockDim.x) s_n4[i] = g_n4[i];
         if (threadIdx.x == 0) s_left = 0;
         __syncthreads();
-        const LeafHdr nh = {nhdrs[2 * (uint64_t)tl.node], nhdrs[2 * (uint64_t)tl.node + 1]};
+        const float *g_h = reinterpret_cast<const float *>(normals + tl.node * nstride + hdr_off);
+        const LeafHdr nh = {g_h[0], g_h[1]};
         const uint32_t in_tile = min(kTile, nd->count - tl.first);
         const uint32_t *pp = perm + (uint64_t)nd->tree * n_items + nd->start + tl.first;
         uint64_t mask = 0;
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void k_forest_margin_f32(DataView dv, FNode
 __global__ __launch_bounds__(kBlock) void k_forest_margin_bq(DataView dv, FNode *nodes, const FTile *__restrict__ tiles,
                                                              uint32_t n_tiles, const uint32_t *__restrict__ perm,
                                                              uint64_t n_items, const uint8_t *__restrict__ normals,
-                                                             uint64_t nstride, const float *__restrict__ nhdrs,
+                                                             uint64_t nstride, uint64_t hdr_off,
                                                              uint64_t *__restrict__ masks,
                                                              uint32_t *__restrict__ tile_left) {
     extern __shared__ uint64_t s_nw[];
@@ -145,7 +151,8 @@ __global__ __launch_bounds__(kBlock) void k_forest_margin_bq(DataView dv, FNode 
         for (uint32_t i = threadIdx.x; i < dv.pitch; i += blockDim.x) s_nw[i] = g_n[i];
         if (threadIdx.x == 0) s_left = 0;
         __syncthreads();
-        const LeafHdr nh = {nhdrs[2 * (uint64_t)tl.node], nhdrs[2 * (uint64_t)tl.node + 1]};
+        const float *g_h = reinterpret_cast<const float *>(normals + tl.node * nstride + hdr_off);
+        const LeafHdr nh = {g_h[0], g_h[1]};
         const uint32_t in_tile = min(kTile, nd->count - tl.first);
         const uint32_t *pp = perm + (uint64_t)nd->tree * n_items + nd->start + tl.first;
         for (uint32_t p = threadIdx.x; p < in_tile; p += blockDim.x)
@@ -310,10 +317,16 @@ using namespace ah;
 struct ah_forest {
     std::vector<uint32_t> roots;
     std::vector<ah_node> nodes;
-    std::vector<uint8_t> normals;
-    std::vector<uint32_t> descendants;
-    uint64_t normal_stride = 0;
+    uint8_t *normals = nullptr;  // raw (uninitialised) buffers: filled by D2H copies only, never repacked
+    uint64_t normals_len = 0;
+    uint32_t *descendants = nullptr;
+    uint64_t descendants_len = 0;
+    uint64_t normal_stride = 0, normal_vector_offset = 0, normal_header_offset = 0;
     ah_build_stats stats{};
+    ~ah_forest() {
+        free(normals);
+        free(descendants);
+    }
 };
 
 namespace {
@@ -325,7 +338,7 @@ struct HostRec {  // one tree node, in creation (breadth-first) order
     uint64_t start;
     uint32_t count;
     uint32_t depth;
-    uint64_t normal_off = 0;  // into the batch normal blob
+    uint64_t normal_off = 0;  // byte offset of the normal record inside the forest's normals buffer
 };
 
 template <typename T>
@@ -347,8 +360,41 @@ struct DevBuf {
     }
 };
 
+struct LevelChunk {  // the normal records of one level stay in HBM until the end of the batch
+    uint8_t *d = nullptr;
+    uint64_t bytes = 0;
+    uint64_t host_off = 0;
+};
+
 struct EventPair {
     hipEvent_t a, b;
+};
+
+// AH_DEBUG=1: synchronise after every launch and say which kernel finished (debugging aid only)
+bool g_debug = getenv("AH_DEBUG") != nullptr;
+#define AH_DBG(s, what)                                                       \
+    do {                                                                      \
+        if (g_debug) {                                                        \
+            hipError_t _e = hipStreamSynchronize(s);                          \
+            fprintf(stderr, "[ah] %s: %s\n", what, hipGetErrorString(_e));    \
+            fflush(stderr);                                                   \
+        }                                                                     \
+    } while (0)
+
+struct BatchCleanup {
+    std::vector<LevelChunk> chunks;
+    std::vector<EventPair> events;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    ~BatchCleanup() {
+        for (LevelChunk &c : chunks)
+            if (c.d) (void)hipFree(c.d);
+        for (EventPair &e : events) {
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+        if (ev_begin) (void)hipEventDestroy(ev_begin);
+        if (ev_end) (void)hipEventDestroy(ev_end);
+    }
 };
 
 }  // namespace
@@ -359,25 +405,36 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     const DataView dv = ds->view();
     hipStream_t s = ctx->stream;
     const bool bq = metric_is_bq(ds->metric);
-    const uint64_t nstride = ds->row_bytes();
-    const size_t hs = ah_header_size(ds->metric), vs = ah_vector_size(ds->metric, ds->dims);
+    const uint64_t hdr_off = ds->row_bytes();
+    const uint64_t nstride = hdr_off + 16;
 
+    // Upper bounds known up front (every split node owns > split_after items), so nothing is reallocated
+    // between levels: nodes per level <= n_trees * N / (split_after + 1), tiles <= items / kTile + nodes.
+    const uint64_t max_nodes = (uint64_t)n_trees * (N / ((uint64_t)split_after + 1)) + n_trees;
+    const uint64_t max_tiles = (uint64_t)n_trees * (N / kTile + 1) + max_nodes;
     DevBuf<uint32_t> perm_a, perm_b, final_perm, tile_left, tile_left_off;
     DevBuf<FNode> d_nodes;
     DevBuf<FTile> d_tiles;
     DevBuf<uint64_t> masks;
-    DevBuf<uint8_t> d_normals;
-    DevBuf<float> d_nhdrs;
     AH_TRY(perm_a.ensure(N * n_trees));
     AH_TRY(perm_b.ensure(N * n_trees));
     AH_TRY(final_perm.ensure(N * n_trees));
+    AH_TRY(d_nodes.ensure(max_nodes));
+    AH_TRY(d_tiles.ensure(max_tiles));
+    AH_TRY(masks.ensure(max_tiles * 32));
+    AH_TRY(tile_left.ensure(max_tiles));
+    AH_TRY(tile_left_off.ensure(max_tiles));
+    AH_TRY(ctx->ensure_pinned(max_nodes * sizeof(FNode) + max_tiles * sizeof(FTile) + 4096));
+    FNode *h_nodes = reinterpret_cast<FNode *>(ctx->h_pinned);
+    FTile *h_tiles = reinterpret_cast<FTile *>(h_nodes + max_nodes);
     hipLaunchKernelGGL(k_init_perm, dim3(2048), dim3(256), 0, s, perm_a.p, N, n_trees);
     AH_HIP(hipGetLastError());
 
+    BatchCleanup bc;
     std::vector<HostRec> recs;
-    std::vector<uint8_t> normal_blob;  // [header][vector] per split node with a normal
-    std::vector<FNode> level;          // active (to be split) nodes of the current level
+    std::vector<FNode> level;  // active (to be split) nodes of the current level
     std::vector<uint32_t> tree_root(n_trees);
+    recs.reserve(4 * max_nodes / 3 + 16);
     for (uint32_t t = 0; t < n_trees; t++) {
         HostRec r{};
         r.kind = AH_NODE_SPLIT;
@@ -397,21 +454,17 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     }
 
     uint32_t *cur = perm_a.p, *nxt = perm_b.p;
-    std::vector<FTile> tiles;
-    std::vector<FNode> level_out;
-    std::vector<uint8_t> h_normals;
-    std::vector<float> h_nhdrs;
-    std::vector<EventPair> margin_events;
-    hipEvent_t ev_begin, ev_end;
-    AH_HIP(hipEventCreate(&ev_begin));
-    AH_HIP(hipEventCreate(&ev_end));
-    AH_HIP(hipEventRecord(ev_begin, s));
+    AH_HIP(hipEventCreate(&bc.ev_begin));
+    AH_HIP(hipEventCreate(&bc.ev_end));
+    AH_HIP(hipEventRecord(bc.ev_begin, s));
     const size_t cs_shared = (size_t)f32_space_pitch(ds->metric, ds->dims) * 4 * 3;
     AH_REQUIRE(cs_shared <= 150 * 1024, AH_ERR_INVALID_DIMENSION, "dimensions %u too large for the LDS-resident two-means",
                ds->dims);
     if (cs_shared > 48 * 1024)
         AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_create_split),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_shared));
+    const uint64_t normals_base = forest->normals_len;  // this batch appends its levels after earlier batches
+    uint64_t normals_bytes = 0;
     uint32_t depth = 0;
     uint64_t items_routed = 0;
     while (!level.empty()) {
@@ -421,39 +474,42 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         }
         AH_REQUIRE(depth < 100000, AH_ERR_DEVICE, "forest build: depth %u exceeded (internal error)", depth);
         const uint32_t n_nodes = (uint32_t)level.size();
-        tiles.clear();
+        AH_REQUIRE(n_nodes <= max_nodes, AH_ERR_DEVICE, "forest build: node bound exceeded (internal error)");
+        uint32_t n_tiles = 0;
         for (uint32_t i = 0; i < n_nodes; i++) {
             FNode &nd = level[i];
-            nd.tile_begin = (uint32_t)tiles.size();
+            nd.tile_begin = n_tiles;
             nd.n_tiles = (nd.count + kTile - 1) / kTile;
-            for (uint32_t t = 0; t < nd.n_tiles; t++) tiles.push_back(FTile{i, t * kTile});
+            AH_REQUIRE((uint64_t)n_tiles + nd.n_tiles <= max_tiles, AH_ERR_DEVICE, "forest build: tile bound exceeded");
+            for (uint32_t t = 0; t < nd.n_tiles; t++) h_tiles[n_tiles++] = FTile{i, t * kTile};
+            h_nodes[i] = nd;
         }
-        const uint32_t n_tiles = (uint32_t)tiles.size();
-        AH_TRY(d_nodes.ensure(n_nodes));
-        AH_TRY(d_tiles.ensure(n_tiles));
-        AH_TRY(masks.ensure((size_t)n_tiles * 32));
-        AH_TRY(tile_left.ensure(n_tiles));
-        AH_TRY(tile_left_off.ensure(n_tiles));
-        AH_TRY(d_normals.ensure((size_t)n_nodes * nstride));
-        AH_TRY(d_nhdrs.ensure((size_t)n_nodes * 2));
-        AH_HIP(hipMemcpyAsync(d_nodes.p, level.data(), n_nodes * sizeof(FNode), hipMemcpyHostToDevice, s));
-        AH_HIP(hipMemcpyAsync(d_tiles.p, tiles.data(), n_tiles * sizeof(FTile), hipMemcpyHostToDevice, s));
+        LevelChunk chunk;
+        chunk.bytes = (uint64_t)n_nodes * nstride;
+        chunk.host_off = normals_base + normals_bytes;
+        AH_HIP(hipMalloc((void **)&chunk.d, chunk.bytes));
+        bc.chunks.push_back(chunk);
+        normals_bytes += chunk.bytes;
+        AH_HIP(hipMemcpyAsync(d_nodes.p, h_nodes, n_nodes * sizeof(FNode), hipMemcpyHostToDevice, s));
+        AH_HIP(hipMemcpyAsync(d_tiles.p, h_tiles, n_tiles * sizeof(FTile), hipMemcpyHostToDevice, s));
         const unsigned tile_grid = std::min<uint32_t>(n_tiles, kMaxBlocks);
         for (int attempt = 0; attempt < 4; attempt++) {
             hipLaunchKernelGGL(k_forest_create_split, dim3(n_nodes), dim3(64), cs_shared, s, dv, d_nodes.p, cur, N,
-                               d_normals.p, nstride, d_nhdrs.p);
+                               chunk.d, nstride, hdr_off);
+            AH_DBG(s, "create_split");
             EventPair ep;
             AH_HIP(hipEventCreate(&ep.a));
             AH_HIP(hipEventCreate(&ep.b));
+            bc.events.push_back(ep);
             AH_HIP(hipEventRecord(ep.a, s));
             if (bq) {
                 hipLaunchKernelGGL(k_forest_margin_bq, dim3(tile_grid), dim3(kBlock), dv.pitch * 8, s, dv, d_nodes.p,
-                                   d_tiles.p, n_tiles, cur, N, d_normals.p, nstride, d_nhdrs.p, masks.p, tile_left.p);
+                                   d_tiles.p, n_tiles, cur, N, chunk.d, nstride, hdr_off, masks.p, tile_left.p);
             } else {
                 const size_t sh = (size_t)dv.pitch * 4;
-#define AH_LAUNCH(M)                                                                                              \
-    hipLaunchKernelGGL((k_forest_margin_f32<M>), dim3(tile_grid), dim3(kBlock), sh, s, dv, d_nodes.p, d_tiles.p,   \
-                       n_tiles, cur, N, d_normals.p, nstride, d_nhdrs.p, masks.p, tile_left.p)
+#define AH_LAUNCH(M)                                                                                            \
+    hipLaunchKernelGGL((k_forest_margin_f32<M>), dim3(tile_grid), dim3(kBlock), sh, s, dv, d_nodes.p, d_tiles.p, \
+                       n_tiles, cur, N, chunk.d, nstride, hdr_off, masks.p, tile_left.p)
                 switch (ds->metric) {
                 case AH_EUCLIDEAN: AH_LAUNCH(AH_EUCLIDEAN); break;
                 case AH_MANHATTAN: AH_LAUNCH(AH_MANHATTAN); break;
@@ -463,28 +519,27 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
 #undef AH_LAUNCH
             }
             AH_HIP(hipEventRecord(ep.b, s));
-            margin_events.push_back(ep);
+            AH_DBG(s, "margin");
             hipLaunchKernelGGL(k_forest_decide, dim3((n_nodes + 255) / 256), dim3(256), 0, s, d_nodes.p, n_nodes);
+            AH_DBG(s, "decide");
         }
         hipLaunchKernelGGL(k_forest_random_sides, dim3(std::min<uint32_t>(n_tiles, kMaxBlocks)), dim3(64), 0, s,
                            d_nodes.p, d_tiles.p, n_tiles, masks.p, tile_left.p);
+        AH_DBG(s, "random_sides");
         hipLaunchKernelGGL(k_forest_tile_offsets, dim3(std::min<uint32_t>(n_nodes, kMaxBlocks)), dim3(64), 0, s,
                            d_nodes.p, n_nodes, tile_left.p, tile_left_off.p);
+        AH_DBG(s, "tile_offsets");
         hipLaunchKernelGGL(k_forest_scatter, dim3(tile_grid), dim3(kBlock), 0, s, d_nodes.p, d_tiles.p, n_tiles, cur, nxt,
                            final_perm.p, N, masks.p, tile_left_off.p, split_after);
+        AH_DBG(s, "scatter");
         AH_HIP(hipGetLastError());
-        level_out.resize(n_nodes);
-        h_normals.resize((size_t)n_nodes * nstride);
-        h_nhdrs.resize((size_t)n_nodes * 2);
-        AH_HIP(hipMemcpyAsync(level_out.data(), d_nodes.p, n_nodes * sizeof(FNode), hipMemcpyDeviceToHost, s));
-        AH_HIP(hipMemcpyAsync(h_normals.data(), d_normals.p, (size_t)n_nodes * nstride, hipMemcpyDeviceToHost, s));
-        AH_HIP(hipMemcpyAsync(h_nhdrs.data(), d_nhdrs.p, (size_t)n_nodes * 8, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_nodes, d_nodes.p, n_nodes * sizeof(FNode), hipMemcpyDeviceToHost, s));
         AH_HIP(hipStreamSynchronize(s));
 
         // host: materialise the split records and the next level (children lists subdivide the parent range)
         level.clear();
         for (uint32_t i = 0; i < n_nodes; i++) {
-            const FNode &nd = level_out[i];
+            const FNode nd = h_nodes[i];
             AH_REQUIRE(nd.state != ST_PENDING && nd.n_left <= nd.count, AH_ERR_DEVICE,
                        "forest build: node %u left pending (internal error)", i);
             forest->stats.margin_evaluations += (uint64_t)(nd.attempt + 1) * nd.count;
@@ -492,15 +547,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             items_routed += nd.count;
             const uint32_t rec_idx = nd.rec;
             recs[rec_idx].has_normal = nd.state == ST_ACCEPTED;
-            if (nd.state == ST_ACCEPTED) {
-                recs[rec_idx].normal_off = normal_blob.size();
-                const uint8_t *h = reinterpret_cast<const uint8_t *>(&h_nhdrs[2 * (size_t)i]);
-                normal_blob.insert(normal_blob.end(), h, h + hs);
-                const uint8_t *v = &h_normals[(size_t)i * nstride];
-                normal_blob.insert(normal_blob.end(), v, v + vs);
-            } else {
-                forest->stats.dummy_normals++;
-            }
+            recs[rec_idx].normal_off = chunk.host_off + (uint64_t)i * nstride;
+            if (nd.state != ST_ACCEPTED) forest->stats.dummy_normals++;
             const uint32_t child_cnt[2] = {nd.n_left, nd.count - nd.n_left};
             const uint64_t child_start[2] = {nd.start, nd.start + nd.n_left};
             for (uint32_t side = 0; side < 2; side++) {
@@ -532,38 +580,53 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         forest->stats.levels = std::max(forest->stats.levels, depth);
         if (opt->progress) opt->progress(opt->progress_user, depth, recs.size(), items_routed);
     }
-    AH_HIP(hipEventRecord(ev_end, s));
-    // Descendants: rows -> item ids on device, then one D2H of the final permutations
-    if (!ds->identity_ids)
-        hipLaunchKernelGGL(k_rows_to_ids, dim3(2048), dim3(256), 0, s, final_perm.p, N * n_trees, ds->d_ids);
-    std::vector<uint32_t> h_final(N * n_trees);
-    AH_HIP(hipMemcpyAsync(h_final.data(), final_perm.p, N * n_trees * 4, hipMemcpyDeviceToHost, s));
+    AH_HIP(hipEventRecord(bc.ev_end, s));
+
+    // Results come back with plain D2H copies straight into their final place — no host-side repacking:
+    //   normals      one copy per level chunk (device record layout == caller-visible layout)
+    //   descendants  the final permutations themselves (rows -> item ids on device first)
+    {
+        uint8_t *grown = (uint8_t *)realloc(forest->normals, normals_base + normals_bytes + 16);
+        AH_REQUIRE(grown, AH_ERR_OUT_OF_MEMORY, "host allocation of %llu bytes of normals failed",
+                   (unsigned long long)(normals_base + normals_bytes));
+        forest->normals = grown;
+        forest->normals_len = normals_base + normals_bytes;
+        for (const LevelChunk &c : bc.chunks)
+            AH_HIP(hipMemcpyAsync(forest->normals + c.host_off, c.d, c.bytes, hipMemcpyDeviceToHost, s));
+    }
+    const uint64_t desc_base = forest->descendants_len;
+    {
+        uint32_t *grown = (uint32_t *)realloc(forest->descendants, (desc_base + N * n_trees) * 4 + 16);
+        AH_REQUIRE(grown, AH_ERR_OUT_OF_MEMORY, "host allocation of the descendants failed");
+        forest->descendants = grown;
+        forest->descendants_len = desc_base + N * n_trees;
+        if (!ds->identity_ids)
+            hipLaunchKernelGGL(k_rows_to_ids, dim3(2048), dim3(256), 0, s, final_perm.p, N * n_trees, ds->d_ids);
+        AH_HIP(hipMemcpyAsync(forest->descendants + desc_base, final_perm.p, N * n_trees * 4, hipMemcpyDeviceToHost, s));
+    }
     AH_HIP(hipStreamSynchronize(s));
     float ms = 0.0f;
-    AH_HIP(hipEventElapsedTime(&ms, ev_begin, ev_end));
+    AH_HIP(hipEventElapsedTime(&ms, bc.ev_begin, bc.ev_end));
     forest->stats.seconds_device += ms * 1e-3;
-    for (EventPair &ep : margin_events) {
+    for (EventPair &ep : bc.events) {
         float m = 0.0f;
         if (hipEventElapsedTime(&m, ep.a, ep.b) == hipSuccess) forest->stats.seconds_margin += m * 1e-3;
-        (void)hipEventDestroy(ep.a);
-        (void)hipEventDestroy(ep.b);
     }
-    forest->stats.margin_launches += margin_events.size();
-    (void)hipEventDestroy(ev_begin);
-    (void)hipEventDestroy(ev_end);
+    forest->stats.margin_launches += bc.events.size();
 
     // Emit per tree in post-order (children before parents: the order TmpNodes::put receives them,
     // src/writer.rs:1235-1258), with forest-local indices.
     std::vector<uint32_t> new_index(recs.size(), 0xFFFFFFFFu);
     std::vector<std::pair<uint32_t, int>> stack;
+    forest->nodes.reserve(forest->nodes.size() + recs.size());
     for (uint32_t t = 0; t < n_trees; t++) {
         stack.clear();
         stack.push_back({tree_root[t], 0});
         while (!stack.empty()) {
-            auto &top = stack.back();
-            const HostRec &r = recs[top.first];
-            if (r.kind == AH_NODE_SPLIT && top.second == 0) {
-                top.second = 1;
+            const uint32_t ri = stack.back().first;
+            const HostRec &r = recs[ri];
+            if (r.kind == AH_NODE_SPLIT && stack.back().second == 0) {
+                stack.back().second = 1;
                 const uint32_t l = r.left, rr = r.right;
                 stack.push_back({rr, 0});
                 stack.push_back({l, 0});
@@ -578,19 +641,13 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             if (r.kind == AH_NODE_SPLIT) {
                 nd.left = new_index[r.left];
                 nd.right = new_index[r.right];
-                nd.offset = forest->normals.size();
-                if (r.has_normal) {
-                    forest->normals.insert(forest->normals.end(), normal_blob.begin() + r.normal_off,
-                                           normal_blob.begin() + r.normal_off + hs + vs);
-                }
+                nd.offset = r.normal_off;
                 forest->stats.split_nodes++;
             } else {
-                nd.offset = forest->descendants.size();
-                const uint32_t *src = h_final.data() + (uint64_t)t * N + r.start;
-                forest->descendants.insert(forest->descendants.end(), src, src + r.count);
+                nd.offset = desc_base + (uint64_t)t * N + r.start;
                 forest->stats.descendant_nodes++;
             }
-            new_index[top.first] = (uint32_t)forest->nodes.size();
+            new_index[ri] = (uint32_t)forest->nodes.size();
             forest->nodes.push_back(nd);
             stack.pop_back();
         }
@@ -615,19 +672,28 @@ int ah_build_forest(ah_dataset *ds, const ah_build_options *options, ah_forest *
     const uint32_t split_after = options->split_after ? options->split_after : ds->dims;  // src/writer.rs:474-477
     ah_forest *forest = new (std::nothrow) ah_forest();
     AH_REQUIRE(forest, AH_ERR_OUT_OF_MEMORY, "host allocation failed");
-    forest->normal_stride = ah_header_size(ds->metric) + ah_vector_size(ds->metric, ds->dims);
+    forest->normal_vector_offset = 0;
+    forest->normal_header_offset = ds->row_bytes();
+    forest->normal_stride = ds->row_bytes() + 16;
     int st = AH_OK;
     if (ds->n <= split_after) {
         // fit_in_descendant at the root (src/writer.rs:1183-1188): every tree is one Descendants node
-        std::vector<uint32_t> ids(ds->n);
-        for (uint64_t i = 0; i < ds->n; i++) ids[i] = ds->identity_ids ? (uint32_t)i : ds->h_ids[i];
+        const uint64_t total = ds->n * options->n_trees;
+        forest->descendants = (uint32_t *)malloc(total * 4 + 16);
+        if (!forest->descendants) {
+            delete forest;
+            set_error("host allocation failed");
+            return AH_ERR_OUT_OF_MEMORY;
+        }
+        forest->descendants_len = total;
         for (uint32_t t = 0; t < options->n_trees; t++) {
+            for (uint64_t i = 0; i < ds->n; i++)
+                forest->descendants[t * ds->n + i] = ds->identity_ids ? (uint32_t)i : ds->h_ids[i];
             ah_node nd{};
             nd.kind = AH_NODE_DESCENDANTS;
             nd.tree = (uint16_t)t;
             nd.count = (uint32_t)ds->n;
-            nd.offset = forest->descendants.size();
-            forest->descendants.insert(forest->descendants.end(), ids.begin(), ids.end());
+            nd.offset = t * ds->n;
             forest->roots.push_back((uint32_t)forest->nodes.size());
             forest->nodes.push_back(nd);
             forest->stats.descendant_nodes++;
@@ -638,11 +704,12 @@ int ah_build_forest(ah_dataset *ds, const ah_build_options *options, ah_forest *
             set_error("cannot create a HIP stream");
             st = AH_ERR_DEVICE;
         } else {
-            // Trees in flight: bounded by HBM (13 bytes per item per tree + normals) or by the caller.
+            // Trees in flight: bounded by HBM (13 bytes per item per tree + masks + normals) or by the caller.
             size_t free_b = 0, total_b = 0;
             (void)hipMemGetInfo(&free_b, &total_b);
-            const uint64_t per_tree = ds->n * 13 + ((ds->n / std::max<uint32_t>(split_after, 1)) + 2) * (ds->row_bytes() + 64);
-            uint64_t fit = per_tree ? (uint64_t)(free_b * 0.8) / per_tree : options->n_trees;
+            const uint64_t per_tree =
+                ds->n * 14 + ((ds->n / ((uint64_t)split_after + 1)) + 2) * 2 * (ds->row_bytes() + 128) + (1u << 20);
+            uint64_t fit = (uint64_t)(free_b * 0.8) / per_tree;
             if (fit < 1) fit = 1;
             uint32_t batch = (uint32_t)std::min<uint64_t>(fit, options->n_trees);
             if (options->max_trees_in_flight) batch = std::min(batch, options->max_trees_in_flight);
@@ -671,11 +738,13 @@ int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out) {
     out->n_nodes = forest->nodes.size();
     out->roots = forest->roots.data();
     out->nodes = forest->nodes.data();
-    out->normals = forest->normals.data();
-    out->normals_len = forest->normals.size();
+    out->normals = forest->normals;
+    out->normals_len = forest->normals_len;
     out->normal_stride = forest->normal_stride;
-    out->descendants = forest->descendants.data();
-    out->descendants_len = forest->descendants.size();
+    out->normal_vector_offset = forest->normal_vector_offset;
+    out->normal_header_offset = forest->normal_header_offset;
+    out->descendants = forest->descendants;
+    out->descendants_len = forest->descendants_len;
     return AH_OK;
 }
 
@@ -685,6 +754,8 @@ int ah_forest_stats(const ah_forest *forest, ah_build_stats *out) {
     return AH_OK;
 }
 
+// payload: SPLIT -> the normal record (vector at normal_vector_offset, header at normal_header_offset) or
+// NULL for `normal: None`; DESCENDANTS -> u32 item ids.
 int ah_forest_visit(const ah_forest *forest, ah_node_sink_fn sink, void *user) {
     AH_REQUIRE(forest && sink, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     for (size_t i = 0; i < forest->nodes.size(); i++) {
@@ -693,11 +764,11 @@ int ah_forest_visit(const ah_forest *forest, ah_node_sink_fn sink, void *user) {
         size_t len = 0;
         if (nd.kind == AH_NODE_SPLIT) {
             if (nd.has_normal) {
-                payload = forest->normals.data() + nd.offset;
+                payload = forest->normals + nd.offset;
                 len = forest->normal_stride;
             }
         } else {
-            payload = forest->descendants.data() + nd.offset;
+            payload = forest->descendants + nd.offset;
             len = (size_t)nd.count * 4;
         }
         const int rc = sink(user, nd.tree, (uint32_t)i, nd.kind, nd.left, nd.right, payload, len);

@@ -225,11 +225,12 @@ class Forest:
         n = int(v.n_nodes)
         self.roots = np.ctypeslib.as_array(v.roots, shape=(self.n_trees,)).copy() if self.n_trees else np.zeros(0, np.uint32)
         node_dt = np.dtype([("kind", "u1"), ("has_normal", "u1"), ("tree", "<u2"), ("left", "<u4"), ("right", "<u4"),
-                            ("offset", "<u8"), ("count", "<u4"), ("depth", "<u4")])
+                            ("offset", "<u8"), ("count", "<u4"), ("depth", "<u4")], align=True)
         assert node_dt.itemsize == C.sizeof(_lib.AhNode)
         self.nodes = np.frombuffer(C.string_at(v.nodes, n * node_dt.itemsize), dtype=node_dt).copy() if n else \
             np.zeros(0, node_dt)
         self.normal_stride = int(v.normal_stride)
+        self._vec_off, self._hdr_off = int(v.normal_vector_offset), int(v.normal_header_offset)
         self.normals = np.frombuffer(C.string_at(v.normals, v.normals_len), dtype=np.uint8).copy() \
             if v.normals_len else np.zeros(0, np.uint8)
         self.descendants = np.ctypeslib.as_array(v.descendants, shape=(int(v.descendants_len),)).copy() \
@@ -245,9 +246,10 @@ class Forest:
         nd = self.nodes[node]
         if nd["kind"] != 2 or not nd["has_normal"]:
             return None
-        hs = self.distance.header_size()
+        hs, vs = self.distance.header_size(), self.distance.vector_size(self.dimensions)
         raw = self.normals[int(nd["offset"]): int(nd["offset"]) + self.normal_stride]
-        return raw[:hs].view(np.float32).copy(), raw[hs:].copy()
+        return (raw[self._hdr_off: self._hdr_off + hs].view(np.float32).copy(),
+                raw[self._vec_off: self._vec_off + vs].copy())
 
     def descendants_of(self, node: int) -> np.ndarray:
         nd = self.nodes[node]
@@ -264,7 +266,8 @@ class Forest:
                 return ("D", tuple(int(x) for x in self.descendants_of(i)))
             nb = None
             if nd["has_normal"]:
-                nb = bytes(self.normals[int(nd["offset"]): int(nd["offset"]) + self.normal_stride])
+                h, v = self.normal_of(i)  # canonical form = [header][vector], the oracle's record layout
+                nb = h.tobytes() + v.tobytes()
             return ("S", nb, rec(int(nd["left"])), rec(int(nd["right"])))
 
         return rec(int(self.roots[tree]))

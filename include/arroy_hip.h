@@ -200,10 +200,17 @@ typedef struct ah_forest_view {
     uint32_t n_trees;
     uint64_t n_nodes;
     const uint32_t *roots;        /* n_trees forest-local node indices                               */
-    const ah_node *nodes;         /* n_nodes                                                         */
-    const uint8_t *normals;       /* per split node with a normal: [D::Header][vector codec bytes]   */
+    const ah_node *nodes;         /* n_nodes, children before parents (post-order) inside each tree  */
+    /* Normals: one fixed-size record per split node at byte `ah_node.offset` of `normals`.  Inside a record
+     * the vector (metric codec, ah_vector_size bytes) sits at `normal_vector_offset` and D::Header
+     * (ah_header_size bytes) at `normal_header_offset`.  (The records are the device layout copied back
+     * verbatim, so nothing is repacked on the host; the Rust side copies both parts into the LMDB value
+     * `[2u8][left][right][header][vector]` anyway, src/node.rs:229-237.) */
+    const uint8_t *normals;
     uint64_t normals_len;
-    uint64_t normal_stride;       /* ah_header_size + ah_vector_size                                 */
+    uint64_t normal_stride;
+    uint64_t normal_vector_offset;
+    uint64_t normal_header_offset;
     const uint32_t *descendants;  /* item ids, ascending inside each Descendants node                */
     uint64_t descendants_len;
 } ah_forest_view;
@@ -221,7 +228,8 @@ typedef struct ah_build_stats {
 AH_API int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out);
 AH_API int ah_forest_stats(const ah_forest *forest, ah_build_stats *out);
 /* Node sink in the shape `TmpNodes::put` expects (src/parallel.rs:130-147): children first, parent
- * last (post-order), per tree. `payload`: SPLIT -> [header][vector] or NULL; DESCENDANTS -> u32 ids. */
+ * last (post-order), per tree. `payload`: SPLIT -> the normal record of ah_forest_view (vector at
+ * normal_vector_offset, header at normal_header_offset) or NULL for `normal: None`; DESCENDANTS -> u32 ids. */
 typedef int (*ah_node_sink_fn)(void *user, uint32_t tree, uint32_t node, uint8_t kind, uint32_t left,
                                uint32_t right, const void *payload, size_t payload_len);
 AH_API int ah_forest_visit(const ah_forest *forest, ah_node_sink_fn sink, void *user);

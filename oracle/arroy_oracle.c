@@ -35,6 +35,9 @@
 #include "../include/arroy_hip_policy.h"
 
 #define AO_API __attribute__((visibility("default")))
+/* Loops shorter than this run serially: a fork/join over 128+ host threads per tiny tree node costs more
+ * than the node (and was observed to stall for minutes on a 256-thread GPU host). */
+#define AO_PAR_MIN 4096
 
 /* ---------------------------------------------------------------------------------------
  * Tier selection: which of the reference's runtime-dispatched code paths is "the reference"
@@ -442,7 +445,7 @@ static const float *row_hdr(const ao_data *d, uint64_t row) { return d->headers 
 /* D::new_header for every row (Writer::add_item, src/writer.rs:380-394), parallel over rows. */
 AO_API void ao_new_headers(ao_data *d) {
     size_t hf = ao_header_floats(d->metric);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (d->n >= AO_PAR_MIN)
     for (int64_t r = 0; r < (int64_t)d->n; r++) ao_new_header(d->metric, row_vec(d, (uint64_t)r), d->dims, d->headers + (size_t)r * hf);
 }
 
@@ -450,7 +453,7 @@ AO_API void ao_new_headers(ao_data *d) {
  * rayon-style CPU baseline. */
 AO_API void ao_distances(const ao_data *d, const void *qv, const float *qh, const uint32_t *rows, uint64_t n,
                          float *out) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= AO_PAR_MIN)
     for (int64_t i = 0; i < (int64_t)n; i++) {
         uint64_t r = rows ? rows[i] : (uint64_t)i;
         out[i] = ao_built_distance(d->metric, qv, qh, row_vec(d, r), row_hdr(d, r), d->dims);
@@ -551,7 +554,7 @@ AO_API size_t ao_rerank(const ao_data *d, const void *qv, const float *qh, const
 AO_API void ao_split_sides(const ao_data *d, const void *nv, const float *nh, const uint32_t *rows, uint64_t n,
                            uint8_t *sides, uint64_t *n_left, float *margins) {
     uint64_t left = 0;
-#pragma omp parallel for schedule(static) reduction(+ : left)
+#pragma omp parallel for schedule(static) reduction(+ : left) if (n >= AO_PAR_MIN)
     for (int64_t i = 0; i < (int64_t)n; i++) {
         uint64_t r = rows ? rows[i] : (uint64_t)i;
         float m = ao_margin(d->metric, nv, nh, row_vec(d, r), row_hdr(d, r), d->dims);
@@ -869,7 +872,7 @@ AO_API void ao_tree_view(const ao_tree *t, ah_forest_view *v, uint32_t *root_out
     v->n_nodes = t->n_nodes;
     v->nodes = t->nodes;
     v->normals = t->normals;
-    v->normals_len = t->normals_len;
+    v->normals_len = t->normals_len; /* oracle records are [header][vector]; offsets are filled in by the caller */
     v->descendants = t->desc;
     v->descendants_len = t->desc_len;
     *root_out = t->root;

@@ -38,7 +38,8 @@ class AhNode(C.Structure):
 class AhForestView(C.Structure):
     _fields_ = [("n_trees", C.c_uint32), ("n_nodes", C.c_uint64), ("roots", C.POINTER(C.c_uint32)),
                 ("nodes", C.POINTER(AhNode)), ("normals", C.POINTER(C.c_uint8)), ("normals_len", C.c_uint64),
-                ("normal_stride", C.c_uint64), ("descendants", C.POINTER(C.c_uint32)),
+                ("normal_stride", C.c_uint64), ("normal_vector_offset", C.c_uint64), ("normal_header_offset", C.c_uint64),
+                ("descendants", C.POINTER(C.c_uint32)),
                 ("descendants_len", C.c_uint64)]
 
 
