@@ -96,6 +96,7 @@ SIGNATURES = {
                                     C.POINTER(C.c_size_t)]),
     "ah_rerank_batch": (C.c_int, [_VP, _F32P, C.c_size_t, _U32P, _U64P, C.c_size_t, _U32P, _F32P, _U32P]),
     "ah_split_sides": (C.c_int, [_VP, _VP, _VP, _U32P, C.c_size_t, _VP, C.POINTER(C.c_uint64), _F32P]),
+    "ah_margins": (C.c_int, [_VP, _VP, _VP, _U32P, C.c_size_t, _F32P]),
     "ah_create_split": (C.c_int, [_VP, _U32P, _VP, _VP]),
     "ah_build_forest": (C.c_int, [_VP, C.POINTER(AhBuildOptions), C.POINTER(C.c_void_p)]),
     "ah_forest_view_get": (C.c_int, [_VP, C.POINTER(AhForestView)]),

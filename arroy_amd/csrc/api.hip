@@ -721,6 +721,50 @@ int ah_split_sides(ah_dataset *ds, const void *normal_vector, const void *normal
     return AH_OK;
 }
 
+// `D::margin(&normal, query_leaf)` for many stored normals at once: the dataset's ROWS are split-plane normals
+// (header = the normal's header), the broadcast operand is the query leaf.  src/reader.rs:366-369.
+int ah_margins(ah_dataset *normals, const void *leaf_vector, const void *leaf_header, const uint32_t *item_ids,
+               size_t n, float *out_margins) {
+    ah_dataset *ds = normals;
+    AH_NEED_FINALIZED(ds);
+    AH_REQUIRE(leaf_vector && leaf_header && (out_margins || n == 0), AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!item_ids) n = ds->n;
+    if (n == 0) return AH_OK;
+    AH_LEASE(ds, ctx);
+    const size_t vs = ah_vector_size(ds->metric, ds->dims), hs = ah_header_size(ds->metric);
+    AH_TRY(ctx->ensure_device(pad256(ds->row_bytes()) + 1024 + pad256(n * 4) * 2));
+    AH_TRY(ctx->ensure_pinned(pad256(ds->row_bytes()) + 1024 + pad256(n * 4) * 2));
+    Carver dev(ctx->d_scratch), pin(ctx->h_pinned);
+    uint8_t *d_v = dev.take<uint8_t>(ds->row_bytes());
+    float *d_h = dev.take<float>(2);
+    uint32_t *d_err = dev.take<uint32_t>(1);
+    uint32_t *d_ids = item_ids ? dev.take<uint32_t>(n) : nullptr;
+    float *d_m = dev.take<float>(n);
+    uint8_t *h_v = pin.take<uint8_t>(ds->row_bytes());
+    float *h_h = pin.take<float>(2);
+    uint32_t *h_ids = item_ids ? pin.take<uint32_t>(n) : nullptr;
+    float *h_m = pin.take<float>(n);
+    uint32_t *h_err = pin.take<uint32_t>(1);
+    memset(h_v, 0, ds->row_bytes());
+    memcpy(h_v, leaf_vector, vs);
+    h_h[0] = h_h[1] = 0.0f;
+    memcpy(h_h, leaf_header, hs);
+    AH_HIP(hipMemcpyAsync(d_v, h_v, ds->row_bytes(), hipMemcpyHostToDevice, ctx->stream));
+    AH_HIP(hipMemcpyAsync(d_h, h_h, 8, hipMemcpyHostToDevice, ctx->stream));
+    if (item_ids) {
+        memcpy(h_ids, item_ids, n * 4);
+        AH_HIP(hipMemcpyAsync(d_ids, h_ids, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    AH_HIP(hipMemsetAsync(d_err, 0, 4, ctx->stream));
+    AH_TRY(launch_split_sides(ds->view(), d_v, d_h, d_ids, n, nullptr, nullptr, d_m, d_err, ctx->stream, 1));
+    AH_HIP(hipMemcpyAsync(h_m, d_m, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(hipStreamSynchronize(ctx->stream));
+    AH_TRY(check_err_flags(*h_err, false));
+    memcpy(out_margins, h_m, n * 4);
+    return AH_OK;
+}
+
 int ah_create_split(ah_dataset *ds, const uint32_t sample_ids[AH_SPLIT_SAMPLES], void *out_normal_vector,
                     void *out_normal_header) {
     AH_NEED_FINALIZED(ds);

@@ -152,7 +152,7 @@ int launch_decode_item(const DataView &dv, uint32_t row, float *d_out, hipStream
 // split.hip
 int launch_split_sides(const DataView &dv, const void *d_nvec, const float *d_nhdr, const uint32_t *d_ids, uint64_t n,
                        uint8_t *d_side_bits, unsigned long long *d_n_left, float *d_margins, uint32_t *d_err,
-                       hipStream_t s);
+                       hipStream_t s, int row_is_normal = 0);
 int launch_create_split(const DataView &dv, const uint32_t *d_sample_rows, void *d_out_vec, float *d_out_hdr,
                         hipStream_t s);
 

@@ -182,13 +182,79 @@ __global__ __launch_bounds__(kBlock) void k_distances_f32_small(DataView dv, con
     }
 }
 
-// 1-bit metrics: one thread per row, 16-byte loads (rows are 16-byte multiples).
+// 1-bit metrics, cooperative version (the fast path).  A 768-d row is only 96 bytes, so one-thread-per-row
+// loads would touch 64 different lines per wave instruction.  Instead a wave takes 64 consecutive rows and
+// reads them as `C` fully coalesced 1 KiB instructions (C = 16-byte chunks per row): lane L of load c owns
+// chunk g = 64c + L -> (row g / C, part g % C), xor-popcounts it against the matching 16 bytes of the query
+// (LDS), and parks the partial count in LDS; lane r then adds the C partials of row r (integer adds: exact in
+// any order) and writes 64 contiguous distances.
 // Algorithmic traffic per distance: 8*words (+4 header for BQ-cosine) read + 4 written.
+static constexpr uint32_t kBqMaxChunks = 32;  // rows up to 512 bytes (dims <= 4096); larger rows use the fallback
+
 template <bool GATHER>
 __global__ __launch_bounds__(kBlock) void k_distances_bq(DataView dv, const uint64_t *__restrict__ qvec,
                                                          const float *__restrict__ qhdr,
                                                          const uint32_t *__restrict__ ids, uint64_t n,
                                                          float *__restrict__ out, uint32_t *err) {
+    extern __shared__ uint64_t s_qw[];  // [pitch] query words, then 4 x [64 * C] u32 partial counts
+    const uint32_t C = dv.pitch >> 1;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *s_part = reinterpret_cast<uint32_t *>(s_qw + dv.pitch) + wave * 64 * C;
+    for (uint32_t i = threadIdx.x; i < dv.pitch; i += blockDim.x) s_qw[i] = qvec[i];
+    __shared__ float s_hdr[2];
+    if (threadIdx.x < 2) s_hdr[threadIdx.x] = qhdr[threadIdx.x];
+    __syncthreads();
+    const uint64_t n_tiles = (n + 63) >> 6;
+    const uint64_t tiles_per_pass = (uint64_t)gridDim.x * (kBlock / 64);
+    for (uint64_t tile0 = (uint64_t)blockIdx.x * (kBlock / 64); tile0 < n_tiles; tile0 += tiles_per_pass) {
+        const uint64_t tile = tile0 + wave;  // block-uniform trip count: the barriers below are safe
+        const uint64_t base = tile << 6;
+        const uint32_t rows_here = tile < n_tiles ? (uint32_t)min((uint64_t)64, n - base) : 0u;
+        for (uint32_t c = 0; c < C; c++) {
+            const uint32_t g = c * 64 + lane;
+            const uint32_t r = g / C, part = g - r * C;
+            uint32_t pc = 0;
+            if (r < rows_here) {
+                uint64_t row = base + r;
+                if (GATHER) row = row_of_id(dv, ids[base + r]);
+                if (row != ~0ull) {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(dv.rows_bq + row * dv.pitch + 2 * part);
+                    pc = (uint32_t)__popcll(v.x ^ s_qw[2 * part]) + (uint32_t)__popcll(v.y ^ s_qw[2 * part + 1]);
+                }
+            }
+            s_part[g] = pc;
+        }
+        __syncthreads();
+        if (lane < rows_here) {
+            const uint64_t i = base + lane;
+            uint64_t row = i;
+            if (GATHER) {
+                row = row_of_id(dv, ids[i]);
+                if (i > 0 && ids[i] <= ids[i - 1]) atomicOr(err, 2u);
+            }
+            if (row == ~0ull) {
+                atomicOr(err, 1u);
+                out[i] = __uint_as_float(0x7FC00000u);
+            } else {
+                uint32_t ham = 0;
+                for (uint32_t p = 0; p < C; p++) ham += s_part[lane * C + p];
+                float d;
+                if (dv.metric == AH_BQ_EUCLIDEAN) d = (float)(ham * 4u);       // bq_euclidean.rs:117-124
+                else if (dv.metric == AH_BQ_MANHATTAN) d = (float)(ham * 2u);  // bq_manhattan.rs:113-120
+                else d = bq_cosine_from_dot((float)bq_dot_from_hamming(ham, dv.words), s_hdr[0], dv.headers[row]);
+                out[i] = d;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Fallback for very wide rows (> 512 bytes): one thread per row.
+template <bool GATHER>
+__global__ __launch_bounds__(kBlock) void k_distances_bq_wide(DataView dv, const uint64_t *__restrict__ qvec,
+                                                              const float *__restrict__ qhdr,
+                                                              const uint32_t *__restrict__ ids, uint64_t n,
+                                                              float *__restrict__ out, uint32_t *err) {
     extern __shared__ uint64_t s_qw[];
     for (uint32_t i = threadIdx.x; i < dv.pitch; i += blockDim.x) s_qw[i] = qvec[i];
     __shared__ float s_hdr[2];
@@ -214,8 +280,8 @@ __global__ __launch_bounds__(kBlock) void k_distances_bq(DataView dv, const uint
             ham += (uint32_t)__popcll(v.x ^ s_qw[2 * p]) + (uint32_t)__popcll(v.y ^ s_qw[2 * p + 1]);
         }
         float d;
-        if (dv.metric == AH_BQ_EUCLIDEAN) d = (float)(ham * 4u);       // bq_euclidean.rs:117-124
-        else if (dv.metric == AH_BQ_MANHATTAN) d = (float)(ham * 2u);  // bq_manhattan.rs:113-120
+        if (dv.metric == AH_BQ_EUCLIDEAN) d = (float)(ham * 4u);
+        else if (dv.metric == AH_BQ_MANHATTAN) d = (float)(ham * 2u);
         else d = bq_cosine_from_dot((float)bq_dot_from_hamming(ham, dv.words), s_hdr[0], dv.headers[row]);
         out[i] = d;
     }
@@ -226,8 +292,15 @@ static int launch_distances_t(const DataView &dv, const void *qvec, const float 
                               float *out, uint32_t *err, hipStream_t s) {
     if (n == 0) return AH_OK;
     if (metric_is_bq(dv.metric)) {
-        hipLaunchKernelGGL((k_distances_bq<GATHER>), dim3(grid_for(n, kBlock)), dim3(kBlock), dv.pitch * 8, s, dv,
-                           (const uint64_t *)qvec, qhdr, ids, n, out, err);
+        const uint32_t C = dv.pitch >> 1;
+        if (C <= kBqMaxChunks) {
+            const size_t sh = (size_t)dv.pitch * 8 + (size_t)(kBlock / 64) * 64 * C * 4;
+            hipLaunchKernelGGL((k_distances_bq<GATHER>), dim3(grid_for(n, kBlock)), dim3(kBlock), sh, s, dv,
+                               (const uint64_t *)qvec, qhdr, ids, n, out, err);
+        } else {
+            hipLaunchKernelGGL((k_distances_bq_wide<GATHER>), dim3(grid_for(n, kBlock)), dim3(kBlock), dv.pitch * 8, s,
+                               dv, (const uint64_t *)qvec, qhdr, ids, n, out, err);
+        }
     } else if (dv.dims >= 32) {
         const unsigned g = grid_for(n, kBlock / 8);
         const size_t sh = (size_t)dv.pitch * 4;

@@ -16,7 +16,8 @@ __global__ __launch_bounds__(kBlock) void k_split_sides_f32(DataView dv, const f
                                                             const float *__restrict__ nhdr,
                                                             const uint32_t *__restrict__ ids, uint64_t n,
                                                             uint32_t *__restrict__ bits, unsigned long long *n_left,
-                                                            float *__restrict__ margins, uint32_t *err) {
+                                                            float *__restrict__ margins, uint32_t *err,
+                                                            int row_is_normal) {
     extern __shared__ float4 s_n4[];
     for (uint32_t i = threadIdx.x; i < (dv.pitch >> 2); i += blockDim.x)
         s_n4[i] = reinterpret_cast<const float4 *>(nvec)[i];
@@ -35,24 +36,31 @@ __global__ __launch_bounds__(kBlock) void k_split_sides_f32(DataView dv, const f
                 continue;
             }
         }
-        const float m = margin_f32<METRIC>(dv, s_n, nh, row, j);
+        // row_is_normal: the dataset rows are split-plane normals and the broadcast vector is the query leaf
+        // (`D::margin(&normal, query_leaf)`, src/reader.rs:366-369): the bias then comes from the ROW's header.
+        LeafHdr h = nh;
+        if (row_is_normal && (METRIC == AH_EUCLIDEAN || METRIC == AH_MANHATTAN)) h.h0 = dv.headers[row];
+        const float m = margin_f32<METRIC>(dv, s_n, h, row, j);
         if (j == 0) {
             const uint32_t side = side_of_margin(m);
-            if (side) atomicOr(&bits[i >> 5], 1u << (i & 31));
-            else my_left++;
+            if (bits) {
+                if (side) atomicOr(&bits[i >> 5], 1u << (i & 31));
+                else my_left++;
+            }
             if (margins) margins[i] = m;
         }
     }
     // wave reduction of the per-lane left counts, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) my_left += __shfl_down(my_left, off);
-    if ((threadIdx.x & 63u) == 0 && my_left) atomicAdd(n_left, (unsigned long long)my_left);
+    if ((threadIdx.x & 63u) == 0 && my_left && n_left) atomicAdd(n_left, (unsigned long long)my_left);
 }
 
 __global__ __launch_bounds__(kBlock) void k_split_sides_bq(DataView dv, const uint64_t *__restrict__ nvec,
                                                            const float *__restrict__ nhdr,
                                                            const uint32_t *__restrict__ ids, uint64_t n,
                                                            uint32_t *__restrict__ bits, unsigned long long *n_left,
-                                                           float *__restrict__ margins, uint32_t *err) {
+                                                           float *__restrict__ margins, uint32_t *err,
+                                                           int row_is_normal) {
     extern __shared__ uint64_t s_nw[];
     for (uint32_t i = threadIdx.x; i < dv.pitch; i += blockDim.x) s_nw[i] = nvec[i];
     __syncthreads();
@@ -68,33 +76,37 @@ __global__ __launch_bounds__(kBlock) void k_split_sides_bq(DataView dv, const ui
                 continue;
             }
         }
-        const float m = margin_bq(dv, s_nw, nh, row);
+        LeafHdr h = nh;
+        if (row_is_normal) h.h0 = dv.headers[row];
+        const float m = margin_bq(dv, s_nw, h, row);
         const uint32_t side = side_of_margin(m);
-        if (side) atomicOr(&bits[i >> 5], 1u << (i & 31));
-        else my_left++;
+        if (bits) {
+            if (side) atomicOr(&bits[i >> 5], 1u << (i & 31));
+            else my_left++;
+        }
         if (margins) margins[i] = m;
     }
     for (int off = 32; off > 0; off >>= 1) my_left += __shfl_down(my_left, off);
-    if ((threadIdx.x & 63u) == 0 && my_left) atomicAdd(n_left, (unsigned long long)my_left);
+    if ((threadIdx.x & 63u) == 0 && my_left && n_left) atomicAdd(n_left, (unsigned long long)my_left);
 }
 
 int launch_split_sides(const DataView &dv, const void *d_nvec, const float *d_nhdr, const uint32_t *d_ids, uint64_t n,
                        uint8_t *d_side_bits, unsigned long long *d_n_left, float *d_margins, uint32_t *d_err,
-                       hipStream_t s) {
+                       hipStream_t s, int row_is_normal) {
     if (n == 0) return AH_OK;
     uint32_t *bits = reinterpret_cast<uint32_t *>(d_side_bits);
     if (metric_is_bq(dv.metric)) {
         uint64_t b = (n + kBlock - 1) / kBlock;
         if (b > kMaxBlocks) b = kMaxBlocks;
         hipLaunchKernelGGL(k_split_sides_bq, dim3((unsigned)b), dim3(kBlock), dv.pitch * 8, s, dv,
-                           (const uint64_t *)d_nvec, d_nhdr, d_ids, n, bits, d_n_left, d_margins, d_err);
+                           (const uint64_t *)d_nvec, d_nhdr, d_ids, n, bits, d_n_left, d_margins, d_err, row_is_normal);
     } else {
         uint64_t b = (n + (kBlock / 8) - 1) / (kBlock / 8);
         if (b > kMaxBlocks) b = kMaxBlocks;
         const size_t sh = (size_t)dv.pitch * 4;
 #define AH_LAUNCH(M)                                                                                               \
     hipLaunchKernelGGL((k_split_sides_f32<M>), dim3((unsigned)b), dim3(kBlock), sh, s, dv, (const float *)d_nvec, \
-                       d_nhdr, d_ids, n, bits, d_n_left, d_margins, d_err)
+                       d_nhdr, d_ids, n, bits, d_n_left, d_margins, d_err, row_is_normal)
         switch (dv.metric) {
         case AH_EUCLIDEAN: AH_LAUNCH(AH_EUCLIDEAN); break;
         case AH_MANHATTAN: AH_LAUNCH(AH_MANHATTAN); break;

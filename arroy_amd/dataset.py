@@ -223,23 +223,39 @@ class Forest:
         _lib.check(_lib.lib().ah_forest_view_get(self._h, C.byref(v)))
         self.n_trees = int(v.n_trees)
         n = int(v.n_nodes)
-        self.roots = np.ctypeslib.as_array(v.roots, shape=(self.n_trees,)).copy() if self.n_trees else np.zeros(0, np.uint32)
         node_dt = np.dtype([("kind", "u1"), ("has_normal", "u1"), ("tree", "<u2"), ("left", "<u4"), ("right", "<u4"),
                             ("offset", "<u8"), ("count", "<u4"), ("depth", "<u4")], align=True)
         assert node_dt.itemsize == C.sizeof(_lib.AhNode)
-        self.nodes = np.frombuffer(C.string_at(v.nodes, n * node_dt.itemsize), dtype=node_dt).copy() if n else \
-            np.zeros(0, node_dt)
+
+        def view(ptr, count, dtype):
+            # zero-copy numpy view of a buffer owned by the ah_forest handle (kept alive by self)
+            if not count:
+                return np.zeros(0, dtype)
+            nbytes = count * np.dtype(dtype).itemsize
+            buf = (C.c_uint8 * nbytes).from_address(C.cast(ptr, C.c_void_p).value)
+            return np.frombuffer(buf, dtype=dtype, count=count)
+
+        self.roots = view(v.roots, self.n_trees, np.uint32)
+        self.nodes = view(v.nodes, n, node_dt)
         self.normal_stride = int(v.normal_stride)
         self._vec_off, self._hdr_off = int(v.normal_vector_offset), int(v.normal_header_offset)
-        self.normals = np.frombuffer(C.string_at(v.normals, v.normals_len), dtype=np.uint8).copy() \
-            if v.normals_len else np.zeros(0, np.uint8)
-        self.descendants = np.ctypeslib.as_array(v.descendants, shape=(int(v.descendants_len),)).copy() \
-            if v.descendants_len else np.zeros(0, np.uint32)
+        self.normals = view(v.normals, int(v.normals_len), np.uint8)
+        self.descendants = view(v.descendants, int(v.descendants_len), np.uint32)
         st = _lib.AhBuildStats()
         _lib.check(_lib.lib().ah_forest_stats(self._h, C.byref(st)))
         self.stats = {f: getattr(st, f) for f, _ in _lib.AhBuildStats._fields_}
-        _lib.lib().ah_forest_destroy(self._h)
-        self._h = None
+
+    def close(self) -> None:
+        if self._h:
+            self.roots = self.nodes = self.normals = self.descendants = None
+            _lib.lib().ah_forest_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def normal_of(self, node: int):
         """(header f32[], vector codec bytes) of a split node, or None for `normal: None`."""

@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: test the N>1 control path (gloo)")
+    ap.add_argument("--extra", default="", help="comma list of extra measurements: c3 (10M build), c4 (re-rank), "
+                                               "c5 (1-bit scan); reported under the `extra` key")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
     return ap.parse_args()
@@ -87,6 +89,101 @@ def cpu_baseline(args, n_items):
         res["build_margins_per_s"] = evals / el
         res["build_sample"] = f"{len(seeds)} trees over {nb}x{DIMS} (one tree per thread), {el:.2f}s"
     return res
+
+
+def measured_traffic(n_items):
+    """HBM bytes per scan launch from the committed rocprofv3 --pmc passes (profiles/rNN_pmc_*_size.csv; separate
+    FETCH_SIZE / WRITE_SIZE runs).  gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE counts half of a
+    16 B/lane coalesced read stream, so reads = FETCH_SIZE x 1024 x 2; writes = WRITE_SIZE x 1024."""
+    import csv
+    import glob
+    if n_items != N_ITEMS:
+        return None, None
+    fetch = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size.csv")))
+    write = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_write_size.csv")))
+    if not fetch or not write:
+        return None, None
+
+    def mean(path, counter):
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+                if "k_distances_f32<2, false>" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        return sum(vals) / len(vals) if vals else None
+
+    f, w = mean(fetch[-1], "FETCH_SIZE"), mean(write[-1], "WRITE_SIZE")
+    if f is None or w is None:
+        return None, None
+    return f * 1024 * 2 + w * 1024, f"{os.path.basename(fetch[-1])} + {os.path.basename(write[-1])}"
+
+
+def extra_c5(device):
+    """BASELINE configs[4]: 5M x 768 binary-quantized vectors, Q=1 popcount scan (src/spaces/simple.rs:119-131)."""
+    from arroy_amd import Dataset, distances
+    out = {}
+    n, iters = 5_000_000, 50
+    for dist in (distances.BinaryQuantizedCosine, distances.BinaryQuantizedEuclidean, distances.BinaryQuantizedManhattan):
+        ds = Dataset(dist, DIMS, n, device=device)
+        ds.fill_synthetic(SEED, 1, n)
+        ds.finalize()
+        ds.bench_scan(7, n, 3)
+        ms, _ = ds.bench_scan(7, n, iters)
+        per = 96 + 4 + (4 if dist is distances.BinaryQuantizedCosine else 0)  # 12 words + out (+ stored norm)
+        rate = n * iters / (ms * 1e-3)
+        out[dist.name] = {"distances_per_s": rate, "bytes_per_distance": per, "gb_per_s": rate * per / 1e9,
+                          "frac_of_hbm_peak": rate * per / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms / iters}
+        ds.close()
+    return {"workload": "5M x 768 1-bit vectors, Q=1 scan", "metrics": out}
+
+
+def extra_c4(device):
+    """BASELINE configs[3]: 1M x 1536 dot product, search_k=10000 candidate re-rank + top-100, 1000 queries
+    (src/reader.rs:376-400).  Candidate lists are 10 000..11 535 sorted random ids (search_k <= |nns| < search_k + K)."""
+    import numpy as np
+
+    from arroy_amd import Dataset, distances
+    n, dims, nq, k = 1_000_000, 1536, 1000, 100
+    ds = Dataset(distances.DotProduct, dims, n, device=device)
+    ds.fill_synthetic(SEED, 1, n)
+    ds.preprocess_dot()
+    ds.finalize()
+    rng = np.random.default_rng(SEED)
+    queries = np.stack([ds.item_vector(int(i)) for i in rng.choice(n, 64, replace=False)])
+    queries = np.tile(queries, (nq // 64 + 1, 1))[:nq]
+    lists = [np.sort(rng.choice(n, int(rng.integers(10_000, 11_536)), replace=False)).astype(np.uint32) for _ in range(nq)]
+    total = sum(len(l) for l in lists)
+    ds.rerank_batch(queries[:50], lists[:50], k)  # warm-up
+    t0 = time.perf_counter()
+    for b in range(0, nq, 250):
+        ds.rerank_batch(queries[b:b + 250], lists[b:b + 250], k)
+    el = time.perf_counter() - t0
+    per = 4 * dims + 4 + 4  # vector + id + written distance
+    ds.close()
+    return {"workload": f"{n}x{dims} dot product, {nq} queries x ~10.8k candidates, top-{k} (host in/out included)",
+            "queries_per_s": nq / el, "candidates_per_s": total / el, "bytes_per_candidate": per,
+            "gb_per_s": total / el * per / 1e9, "frac_of_hbm_peak": total / el * per / 1e9 / HBM_PEAK_GBS,
+            "seconds": el}
+
+
+def extra_c3(device, my_seeds_fn):
+    """BASELINE configs[2]: 10M x 768 cosine, n_trees=100; this rank's share of the trees (all 100 at N=1)."""
+    from arroy_amd import Dataset, distances
+    n = 10_000_000
+    ds = Dataset(distances.Cosine, DIMS, n, device=device)
+    ds.fill_synthetic(SEED, 1, n)
+    ds.finalize()
+    seeds = my_seeds_fn(100)
+    t0 = time.perf_counter()
+    forest = ds.build_forest(seeds)
+    el = time.perf_counter() - t0
+    st = forest.stats
+    out = {"workload": f"{n}x{DIMS} cosine, n_trees=100, trees on this rank: {len(seeds)}", "seconds": el,
+           "seconds_library": st["seconds_total"], "seconds_device": st["seconds_device"],
+           "seconds_margin_kernel": st["seconds_margin"], "margin_evaluations": st["margin_evaluations"],
+           "levels": st["levels"], "split_nodes": st["split_nodes"],
+           "margin_algorithmic_gb_per_s": st["margin_evaluations"] * 4 * DIMS / st["seconds_margin"] / 1e9,
+           "margin_frac_of_hbm_peak": st["margin_evaluations"] * 4 * DIMS / st["seconds_margin"] / 1e9 / HBM_PEAK_GBS}
+    forest.close()
+    ds.close()
+    return out
 
 
 def main():
@@ -166,6 +263,7 @@ def main():
             build = {
                 "workload": f"{n}x{DIMS} cosine, n_trees={args.trees} (split_after={DIMS}), trees t=rank mod {world}",
                 "trees": args.trees, "trees_this_rank": len(my_trees), "seconds": b_elapsed,
+                "seconds_library_rank0": st.get("seconds_total"),
                 "seconds_device_rank0": st.get("seconds_device"), "seconds_margin_kernel_rank0": margin_s,
                 "margin_evaluations_rank0": evals, "levels": st.get("levels"),
                 "margins_per_s_rank0": evals / margin_s if margin_s else None,
@@ -177,11 +275,28 @@ def main():
         cpu = None
         if rank == 0 and world == 1 and not args.no_cpu:
             cpu = cpu_baseline(args, n)
+        extra = {}
+        wanted = [x for x in args.extra.split(",") if x]
+        if wanted:
+            ds.close()
+        if "c5" in wanted and rank == 0:
+            extra["c5"] = extra_c5(local_rank)
+        if "c4" in wanted and rank == 0:
+            extra["c4"] = extra_c4(local_rank)
+        if "c3" in wanted:
+            barrier_sync()
+            t0 = time.perf_counter()
+            c3 = extra_c3(local_rank, lambda t: shard.tree_seeds(SEED, shard.trees_for_rank(t, rank, world)))
+            barrier_sync()
+            c3["seconds_max_over_ranks"] = max_over_ranks(time.perf_counter() - t0)
+            extra["c3"] = c3
+        result["extra"] = extra
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * n * args.steps / elapsed
         achieved = n * BYTES_PER_DISTANCE / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = (args.traffic_bytes, "--traffic-bytes") if args.traffic_bytes else measured_traffic(n)
         line = {
             "metric": "distances/sec, Q=1 batched 768-dim cosine scan (GB/s vs HBM roofline in `roofline`)",
             "value": value, "unit": "distances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -190,12 +305,14 @@ def main():
             "config": {"workload": f"{n}x{DIMS} cosine Q=1 distance scan, one replica per GPU (BASELINE configs[1])",
                        "items": n, "dims": DIMS, "metric": "cosine", "device": dev_name},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": args.traffic_bytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "ah::k_distances_f32<COSINE,false>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": n * BYTES_PER_DISTANCE},
             "cpu_baseline": cpu,
             "build": build,
         }
+        if result.get("extra"):
+            line["extra"] = result["extra"]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -161,6 +161,13 @@ AH_API int ah_split_sides(ah_dataset *ds, const void *normal_vector, const void 
                    const uint32_t *sorted_ids, size_t n, uint8_t *side_bits, uint64_t *out_n_left,
                    float *out_margins);
 
+/* The margins of the tree descent (src/reader.rs:366-369): `D::margin(&normal_i, query_leaf)` for many split-plane
+ * normals at once.  `normals` is a dataset whose ITEMS are normals (stage them with ah_dataset_upload_records:
+ * header = the normal's header); `leaf_vector` / `leaf_header` is the query leaf in the metric's codec
+ * (by_vector: codec + D::new_header; by_item: the stored item).  item_ids NULL = every normal in row order. */
+AH_API int ah_margins(ah_dataset *normals, const void *leaf_vector, const void *leaf_header, const uint32_t *item_ids,
+                      size_t n, float *out_margins);
+
 /* `D::create_split` (src/distance/{euclidean.rs:55-77,cosine.rs:73-85,dot_product.rs:98-113,...}) with the
  * randomness supplied by the host: sample_ids[0..1] = choose_two, [2..11] = the ten `choose` draws
  * (the RNG policy stays in the caller, as with `R: Rng`). */

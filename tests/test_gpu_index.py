@@ -1,0 +1,178 @@
+"""The reference's own reader/writer tests replayed through the arroy-surface mirror (arroy_amd/index.py) on the
+GPU.  Only RNG-independent expectations are mirrored (the reference's tree *shape* snapshots depend on rand 0.8's
+ChaCha12 stream)."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    import arroy_amd
+    from arroy_amd import distances as D
+    from arroy_amd import index as I
+    assert arroy_amd.device_count() >= 1
+    return D, I
+
+
+def rng():
+    return random.Random(42)  # the reference seeds StdRng with [42; 32] (src/tests/mod.rs:105-107)
+
+
+def fmt(res):
+    """NnsRes Display (src/tests/reader.rs:14-29): `id(n): distance(d)` per line."""
+    def f(d):
+        return str(int(d)) if float(d).is_integer() else repr(float(np.float32(d)))
+    return [f"id({i}): distance({f(d)})" for i, d in res]
+
+
+def test_open_db_with_wrong_dimension(api):
+    """src/tests/reader.rs:45-60."""
+    D, I = api
+    db = I.Database(D.Euclidean)
+    w = I.Writer(db, 0, 2)
+    w.add_item(0, [0.0, 0.0])
+    w.builder(rng()).n_trees(1).build()
+    reader = I.Reader.open(db, 0)
+    with pytest.raises(I.InvalidVecDimension) as e:
+        reader.nns(5).by_vector([1.0, 2.0, 3.0])
+    assert str(e.value) == "Invalid vector dimensions. Got 3 but expected 2"
+
+
+def test_search_in_db_with_a_single_vector(api):
+    """src/tests/reader.rs:81-99 (meilisearch#4296): cosine of an item with itself is 0."""
+    D, I = api
+    db = I.Database(D.Cosine)
+    w = I.Writer(db, 0, 3)
+    w.add_item(0, [0.00397, 0.553, 0.0])
+    w.builder(rng()).build()
+    reader = I.Reader.open(db, 0)
+    assert fmt(reader.nns(1).by_item(0)) == ["id(0): distance(0)"]
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_two_dimension_on_a_line_and_on_a_column(api, axis):
+    """src/tests/reader.rs:101-171: exhaustive searches are independent of the tree shapes."""
+    D, I = api
+    db = I.Database(D.Euclidean)
+    w = I.Writer(db, 0, 2)
+    for i in range(100):
+        v = [0.0, 0.0]
+        v[axis] = float(i)
+        w.add_item(i, v)
+    w.builder(rng()).n_trees(50).build()
+    reader = I.Reader.open(db, 0)
+    want = [f"id({i}): distance({i})" for i in range(5)]
+    assert fmt(reader.nns(5).search_k(2**63).by_item(0)) == want
+    assert fmt(reader.nns(5).by_item(0)) == want          # default search_k = count * n_trees = 250 >= 100 items
+    # "if we can't look into enough nodes we find some random points": at least the item itself, sorted output
+    res = reader.nns(5).search_k(1).by_item(1)
+    assert res[0] == (1, 0.0) and [d for _, d in res] == sorted(d for _, d in res)
+    assert reader.n_trees() == 50 and reader.n_items() == 100 and reader.dimensions() == 2
+    stats = reader.stats()
+    assert stats["leaf"] == 100 and len(stats["tree_stats"]) == 50
+    assert all(t["descendants"] == t["split_nodes"] + 1 for t in stats["tree_stats"])
+
+
+def test_get_item_ids(api):
+    """src/tests/reader.rs:173-191."""
+    D, I = api
+    db = I.Database(D.Euclidean)
+    w = I.Writer(db, 0, 2)
+    for i in range(10):
+        w.add_item(i, [0.0, float(i)])
+    w.builder(rng()).n_trees(50).build()
+    assert I.Reader.open(db, 0).item_ids() == list(range(10))
+
+
+def test_filtering(api):
+    """src/tests/reader.rs:194-227."""
+    D, I = api
+    db = I.Database(D.Euclidean)
+    w = I.Writer(db, 0, 2)
+    for i in range(100):
+        w.add_item(i, [0.0, float(i)])
+    w.builder(rng()).n_trees(50).build()
+    reader = I.Reader.open(db, 0)
+    assert fmt(reader.nns(5).candidates(range(0, 2)).by_item(0)) == ["id(0): distance(0)", "id(1): distance(1)"]
+    assert fmt(reader.nns(5).candidates(range(98, 1000)).by_item(0)) == ["id(98): distance(98)", "id(99): distance(99)"]
+
+
+def test_search_in_empty_database(api):
+    """src/tests/reader.rs:229-243 (arroy#75)."""
+    D, I = api
+    db = I.Database(D.Euclidean)
+    I.Writer(db, 0, 2).builder(rng()).build()
+    assert I.Reader.open(db, 0).nns(10).by_vector([0.0, 0.0]) == []
+
+
+def test_try_reading_in_a_non_built_database(api):
+    """src/tests/reader.rs:245-281 (arroy#74)."""
+    D, I = api
+    db = I.Database(D.Euclidean)
+    w = I.Writer(db, 0, 2)
+    w.add_item(0, [0.0, 0.0])
+    with pytest.raises(I.MissingMetadata):
+        I.Reader.open(db, 0)
+    w.builder(rng()).build()
+    I.Writer(db, 0, 2).del_item(0)
+    with pytest.raises(I.NeedBuild):
+        I.Reader.open(db, 0)
+
+
+def test_binary_quantized_item_vector(api):
+    """src/tests/binary_quantized.rs:7-55: item_vector returns the +-1 representation, 0.0 -> +1, -0.1 -> -1."""
+    D, I = api
+    for dist in (D.BinaryQuantizedCosine, D.BinaryQuantizedEuclidean, D.BinaryQuantizedManhattan):
+        db = I.Database(dist)
+        w = I.Writer(db, 0, 16)
+        vec = [-2.0, -1.0, 0.0, -0.1, 2.0, 2.0, -12.4, 21.2, -2.0, -1.0, 0.0, 1.0, 2.0, 2.0, -12.4, 21.2]
+        w.add_item(0, vec)
+        w.builder(rng()).build()
+        got = I.Reader.open(db, 0).item_vector(0)
+        want = [-1.0 if np.signbit(np.float32(x)) else 1.0 for x in vec]
+        assert list(got) == want
+
+
+def test_cancel_build(api):
+    """src/tests/writer.rs:1346-1375: the cancel closure aborts the build with BuildCancelled."""
+    D, I = api
+    from arroy_amd import BuildCancelled
+    db = I.Database(D.Euclidean)
+    w = I.Writer(db, 0, 2)
+    for i in range(100):
+        w.add_item(i, [float(i), 0.0])
+    with pytest.raises(BuildCancelled):
+        w.builder(rng()).cancel(lambda: True).build()
+
+
+@pytest.mark.parametrize("dist_name", ["Euclidean", "Manhattan", "Cosine", "DotProduct", "BinaryQuantizedCosine",
+                                       "BinaryQuantizedEuclidean", "BinaryQuantizedManhattan"])
+def test_search_recall_against_exhaustive_search(api, dist_name):
+    """Quality check in the spirit of examples/compare_with_hnsw.rs: with a generous search_k the forest
+    search returns (almost) the exhaustive top-k, and an exhaustive search_k returns it exactly."""
+    D, I = api
+    dist = getattr(D, dist_name)
+    n, dims, k = 3000, 64, 10
+    vecs = np.random.default_rng(5).standard_normal((n, dims)).astype(np.float32)
+    db = I.Database(dist)
+    w = I.Writer(db, 0, dims)
+    for i in range(n):
+        w.add_item(i, vecs[i])
+    w.builder(rng()).n_trees(10).build()
+    reader = I.Reader.open(db, 0)
+    st = reader._st
+    hits = total = 0
+    for q in range(0, 40):
+        exact_ids, exact_d = st.dataset.rerank(k, item=q)
+        full = reader.nns(k).search_k(2**62).by_item(q)
+        assert [i for i, _ in full] == list(exact_ids)
+        got = reader.nns(k).search_k(1500).by_item(q)
+        hits += len(set(i for i, _ in got) & set(int(i) for i in exact_ids))
+        total += k
+        qv = reader.nns(k).search_k(2**62).by_vector(vecs[q])
+        assert [i for i, _ in qv] == list(exact_ids)
+    assert hits / total > (0.6 if dist.binary_quantized else 0.85)

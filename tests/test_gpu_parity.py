@@ -363,3 +363,17 @@ def test_full_size_properties_1m_x_768_cosine():
     f2 = ds.build_forest([1, 2])
     assert f1.normals.tobytes() == f2.normals.tobytes() and np.array_equal(f1.descendants, f2.descendants)
     assert all(f1.tree_stats(t)["descendants"] > n // 768 for t in range(2))
+
+
+@pytest.mark.parametrize("metric", [4, 5, 6])
+@pytest.mark.parametrize("dims", [64, 1000, 4096, 5000])
+def test_bq_scan_wide_and_narrow_rows(metric, dims):
+    """1-bit rows from 8 bytes to > 512 bytes (cooperative kernel and the wide-row fallback)."""
+    cls = D.BY_METRIC[metric]
+    n = 333
+    ds, oracle, vecs, ids = make_data(cls, n, dims, seed=dims + metric)
+    q = np.random.default_rng(dims).standard_normal(dims).astype(np.float32)
+    qv, qh = oracle.query_leaf(q)
+    assert_bit_equal(ds.distances(query=q), oracle.distances(qv, qh))
+    sub = np.arange(5, n, 7, dtype=np.uint32)
+    assert_bit_equal(ds.distances(query=q, ids=sub), oracle.distances(qv, qh, rows=sub))
