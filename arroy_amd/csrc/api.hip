@@ -596,8 +596,86 @@ int ah_rerank_by_item(ah_dataset *ds, uint32_t query_item, const uint32_t *sorte
     return rerank_impl(ds, nullptr, &query_item, sorted_ids, n, k, out_ids, out_distances, out_n);
 }
 
-// Many queries in one submission: all inputs staged once, kernels of all queries queued back to back on
-// one stream, a single synchronisation at the end.
+// Many queries in one submission.  Fast path (k <= 2048): five launches for the whole batch (batch.hip).
+// Fallback (huge k): the single-query kernels queued back to back on one stream.
+struct HostSeg {
+    uint64_t off;
+    uint32_t n, k;
+};
+struct HostTile {
+    uint32_t query, first;
+};
+
+static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries, size_t nq, const uint32_t *ids,
+                              const uint64_t *offsets, size_t k, uint32_t *out_ids, float *out_distances,
+                              uint32_t *out_counts) {
+    const uint64_t base = offsets[0];
+    const uint64_t total = offsets[nq] - base;
+    uint32_t max_n = 0, max_rounds = 0;
+    std::vector<HostSeg> segs(nq);
+    std::vector<HostTile> tiles;
+    const uint32_t tc = batch_tile_candidates();
+    for (size_t q = 0; q < nq; q++) {
+        const uint64_t nq_items = offsets[q + 1] - offsets[q];
+        AH_REQUIRE(nq_items < 0xFFFFFFFFull, AH_ERR_INVALID_ARGUMENT, "candidate list too long");
+        segs[q] = HostSeg{offsets[q] - base, (uint32_t)nq_items, (uint32_t)std::min<uint64_t>(k, nq_items)};
+        out_counts[q] = segs[q].k;
+        max_n = std::max(max_n, segs[q].n);
+        max_rounds = std::max(max_rounds, batch_rounds(segs[q].n, segs[q].k));
+        for (uint32_t f = 0; f < segs[q].n; f += tc) tiles.push_back(HostTile{(uint32_t)q, f});
+    }
+    const size_t qstride = pad256(ds->row_bytes());
+    const size_t kstride = batch_key_stride(std::max<uint32_t>(max_n, 1));
+    const size_t dev_bytes = pad256(nq * (size_t)ds->dims * 4) + nq * qstride + pad256(nq * 8) + pad256(nq * sizeof(HostSeg)) +
+                             pad256(tiles.size() * sizeof(HostTile)) + pad256(total * 4) * 2 + 2 * pad256(nq * kstride * 8) +
+                             pad256(nq * k * 4) * 2 + 4096;
+    const size_t pin_bytes = pad256(nq * (size_t)ds->dims * 4) + pad256(nq * sizeof(HostSeg)) +
+                             pad256(tiles.size() * sizeof(HostTile)) + pad256(total * 4) + pad256(nq * k * 4) * 2 + 4096;
+    AH_TRY(ctx->ensure_device(dev_bytes));
+    AH_TRY(ctx->ensure_pinned(pin_bytes));
+    Carver dev(ctx->d_scratch), pin(ctx->h_pinned);
+    float *d_qf32 = dev.take<float>(nq * (size_t)ds->dims);
+    uint8_t *d_qvecs = dev.take<uint8_t>(nq * qstride);
+    float *d_qhdrs = dev.take<float>(nq * 2);
+    HostSeg *d_segs = dev.take<HostSeg>(nq);
+    HostTile *d_tiles = dev.take<HostTile>(tiles.size());
+    uint32_t *d_ids = dev.take<uint32_t>(total);
+    float *d_dist = dev.take<float>(total);
+    uint64_t *d_ka = dev.take<uint64_t>(nq * kstride);
+    uint64_t *d_kb = dev.take<uint64_t>(nq * kstride);
+    uint32_t *d_oi = dev.take<uint32_t>(nq * k);
+    float *d_od = dev.take<float>(nq * k);
+    uint32_t *d_err = dev.take<uint32_t>(1);
+    float *h_q = pin.take<float>(nq * (size_t)ds->dims);
+    HostSeg *h_segs = pin.take<HostSeg>(nq);
+    HostTile *h_tiles = pin.take<HostTile>(tiles.size());
+    uint32_t *h_ids = pin.take<uint32_t>(total);
+    uint32_t *h_oi = pin.take<uint32_t>(nq * k);
+    float *h_od = pin.take<float>(nq * k);
+    uint32_t *h_err = pin.take<uint32_t>(1);
+    memcpy(h_q, queries, nq * (size_t)ds->dims * 4);
+    memcpy(h_segs, segs.data(), nq * sizeof(HostSeg));
+    if (!tiles.empty()) memcpy(h_tiles, tiles.data(), tiles.size() * sizeof(HostTile));
+    if (total) memcpy(h_ids, ids + base, total * 4);
+    hipStream_t s = ctx->stream;
+    AH_HIP(hipMemcpyAsync(d_qf32, h_q, nq * (size_t)ds->dims * 4, hipMemcpyHostToDevice, s));
+    AH_HIP(hipMemcpyAsync(d_segs, h_segs, nq * sizeof(HostSeg), hipMemcpyHostToDevice, s));
+    if (!tiles.empty()) AH_HIP(hipMemcpyAsync(d_tiles, h_tiles, tiles.size() * sizeof(HostTile), hipMemcpyHostToDevice, s));
+    if (total) AH_HIP(hipMemcpyAsync(d_ids, h_ids, total * 4, hipMemcpyHostToDevice, s));
+    AH_HIP(hipMemsetAsync(d_err, 0, 4, s));
+    AH_TRY(launch_rerank_batch(ds->view(), d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles,
+                               (uint32_t)tiles.size(), d_ids, d_dist, d_ka, d_kb, kstride, max_n, (uint32_t)k, max_rounds,
+                               d_oi, d_od, d_err, s));
+    AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
+    AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
+    AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
+    AH_HIP(hipStreamSynchronize(s));
+    AH_TRY(check_err_flags(*h_err, true));
+    memcpy(out_ids, h_oi, nq * k * 4);
+    memcpy(out_distances, h_od, nq * k * 4);
+    return AH_OK;
+}
+
 int ah_rerank_batch(ah_dataset *ds, const float *queries, size_t n_queries, const uint32_t *ids,
                     const uint64_t *offsets, size_t k, uint32_t *out_ids, float *out_distances, uint32_t *out_counts) {
     AH_NEED_FINALIZED(ds);
@@ -605,62 +683,36 @@ int ah_rerank_batch(ah_dataset *ds, const float *queries, size_t n_queries, cons
                "NULL argument");
     if (n_queries == 0) return AH_OK;
     AH_REQUIRE(k > 0, AH_ERR_INVALID_ARGUMENT, "k must be > 0");
-    const uint64_t total = offsets[n_queries];
-    size_t max_n = 0;
-    for (size_t q = 0; q < n_queries; q++) {
+    for (size_t q = 0; q < n_queries; q++)
         AH_REQUIRE(offsets[q + 1] >= offsets[q], AH_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
-        max_n = std::max<size_t>(max_n, offsets[q + 1] - offsets[q]);
+    if (!batch_supported((uint32_t)std::min<size_t>(k, 0xFFFFFFFFu))) {
+        // rare: count in the thousands.  One query at a time through the single-query path.
+        for (size_t q = 0; q < n_queries; q++) {
+            for (size_t t = 0; t < k; t++) {
+                out_ids[q * k + t] = 0xFFFFFFFFu;
+                uint32_t nan_bits = 0xFFFFFFFFu;
+                memcpy(&out_distances[q * k + t], &nan_bits, 4);
+            }
+            size_t got = 0;
+            const size_t nq_items = offsets[q + 1] - offsets[q];
+            out_counts[q] = 0;
+            if (nq_items == 0) continue;
+            AH_TRY(ah_rerank_by_vector(ds, queries + q * (size_t)ds->dims, ids + offsets[q], nq_items, k, out_ids + q * k,
+                                       out_distances + q * k, &got));
+            out_counts[q] = (uint32_t)got;
+        }
+        return AH_OK;
     }
     AH_LEASE(ds, ctx);
-    const size_t qrow = pad256(ds->row_bytes());
-    const size_t tk_bytes = pad256(topk_scratch_bytes(std::max<size_t>(max_n, 1), std::min(k, std::max<size_t>(max_n, 1))));
-    const size_t dev_bytes = pad256(n_queries * (size_t)ds->dims * 4) + n_queries * (qrow + 256) + pad256(total * 4) * 2 +
-                             pad256(n_queries * k * 4) * 2 + tk_bytes + 1024;
-    const size_t pin_bytes = pad256(n_queries * (size_t)ds->dims * 4) + pad256(total * 4) + pad256(n_queries * k * 4) * 2 + 1024;
-    AH_TRY(ctx->ensure_device(dev_bytes));
-    AH_TRY(ctx->ensure_pinned(pin_bytes));
-    Carver dev(ctx->d_scratch), pin(ctx->h_pinned);
-    float *d_qf32 = dev.take<float>(n_queries * (size_t)ds->dims);
-    uint8_t *d_qvecs = dev.take<uint8_t>(n_queries * qrow);
-    float *d_qhdrs = dev.take<float>(n_queries * 64);
-    uint32_t *d_ids = dev.take<uint32_t>(total);
-    float *d_dist = dev.take<float>(total);
-    uint32_t *d_oi = dev.take<uint32_t>(n_queries * k);
-    float *d_od = dev.take<float>(n_queries * k);
-    uint32_t *d_err = dev.take<uint32_t>(1);
-    void *d_tk = dev.take<uint8_t>(tk_bytes);
-    float *h_q = pin.take<float>(n_queries * (size_t)ds->dims);
-    uint32_t *h_ids = pin.take<uint32_t>(total);
-    uint32_t *h_oi = pin.take<uint32_t>(n_queries * k);
-    float *h_od = pin.take<float>(n_queries * k);
-    uint32_t *h_err = pin.take<uint32_t>(1);
-    memcpy(h_q, queries, n_queries * (size_t)ds->dims * 4);
-    memcpy(h_ids, ids, total * 4);
-    AH_HIP(hipMemcpyAsync(d_qf32, h_q, n_queries * (size_t)ds->dims * 4, hipMemcpyHostToDevice, ctx->stream));
-    AH_HIP(hipMemcpyAsync(d_ids, h_ids, total * 4, hipMemcpyHostToDevice, ctx->stream));
-    AH_HIP(hipMemsetAsync(d_err, 0, 4, ctx->stream));
-    AH_HIP(hipMemsetAsync(d_oi, 0xFF, n_queries * k * 4, ctx->stream));  // id 0xFFFFFFFF / NaN padding
-    AH_HIP(hipMemsetAsync(d_od, 0xFF, n_queries * k * 4, ctx->stream));
-    DataView dv = ds->view();
-    for (size_t q = 0; q < n_queries; q++) {
-        const size_t nq = offsets[q + 1] - offsets[q];
-        const size_t kk = std::min(k, nq);
-        out_counts[q] = (uint32_t)kk;
-        if (kk == 0) continue;
-        void *qv = d_qvecs + q * qrow;
-        float *qh = d_qhdrs + q * 64;
-        AH_TRY(launch_prepare_query(dv, d_qf32 + q * (size_t)ds->dims, qv, qh, ctx->stream));
-        AH_TRY(launch_distances(dv, qv, qh, d_ids + offsets[q], nq, d_dist + offsets[q], d_err, ctx->stream));
-        AH_TRY(launch_topk(dv, d_dist + offsets[q], d_ids + offsets[q], nq, kk, d_tk, d_oi + q * k, d_od + q * k,
-                           ctx->stream));
+    // bound the scratch: sub-batches of queries whose candidate lists total <= 64M ids and <= 1024 queries
+    size_t q0 = 0;
+    while (q0 < n_queries) {
+        size_t q1 = q0 + 1;
+        while (q1 < n_queries && q1 - q0 < 1024 && offsets[q1 + 1] - offsets[q0] <= (64ull << 20)) q1++;
+        AH_TRY(rerank_batch_chunk(ds, ctx, queries + q0 * (size_t)ds->dims, q1 - q0, ids, offsets + q0, k, out_ids + q0 * k,
+                                  out_distances + q0 * k, out_counts + q0));
+        q0 = q1;
     }
-    AH_HIP(hipMemcpyAsync(h_oi, d_oi, n_queries * k * 4, hipMemcpyDeviceToHost, ctx->stream));
-    AH_HIP(hipMemcpyAsync(h_od, d_od, n_queries * k * 4, hipMemcpyDeviceToHost, ctx->stream));
-    AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
-    AH_HIP(hipStreamSynchronize(ctx->stream));
-    AH_TRY(check_err_flags(*h_err, true));
-    memcpy(out_ids, h_oi, n_queries * k * 4);
-    memcpy(out_distances, h_od, n_queries * k * 4);
     return AH_OK;
 }
 

@@ -1,0 +1,322 @@
+// batch.hip — many re-ranks in five launches (src/reader.rs:376-400 for a whole batch of queries).
+//
+// A single query touches ~10k candidate rows (tens of MB): far too little to fill 256 CUs, and three launches
+// per query make the host the bottleneck.  Here all queries of a submission share the launches:
+//   1. k_prepare_queries      codec + D::new_header for every query            (grid = queries)
+//   2. k_batch_distances_*    one block per (query, tile of 1024 candidates)   (grid = tiles)
+//   3. k_batch_topk_round     tournament of LDS bitonic sorts, grid (chunk, query); repeated until every
+//                             query is down to one chunk (2 rounds for search_k ~ 10k, k <= 2048)
+//   4. k_batch_topk_emit      (id, normalized distance) pairs, padded with 0xFFFFFFFF / NaN
+// Same arithmetic and the same (OrderedFloat(distance), position) keys as the single-query path.
+#include "common.h"
+#include "device_math.h"
+
+namespace ah {
+
+static constexpr int kBlock = 256;
+static constexpr uint32_t kChunk = 4096;   // keys per LDS sort (32 KiB)
+static constexpr uint32_t kTileCand = 1024;
+static constexpr uint64_t kSentinel = ~0ull;
+
+struct Seg {          // one query's slice of the concatenated candidate list
+    uint64_t off;     // first candidate
+    uint32_t n;       // candidates
+    uint32_t k;       // min(count, n)
+};
+struct BTile {
+    uint32_t query;
+    uint32_t first;   // offset inside the query's candidate list
+};
+
+// `QueryBuilder::by_vector` for every query of the batch (src/reader.rs:64-75).
+__global__ void k_prepare_queries(DataView dv, const float *__restrict__ q_f32, uint8_t *qvecs, uint64_t qstride,
+                                  float *qhdrs) {
+    const uint32_t q = blockIdx.x, t = threadIdx.x;
+    const float *src = q_f32 + (uint64_t)q * dv.dims;
+    if (!metric_is_bq_dev(dv.metric)) {
+        float *dst = reinterpret_cast<float *>(qvecs + q * qstride);
+        for (uint32_t i = t; i < dv.pitch; i += blockDim.x) dst[i] = i < dv.dims ? src[i] : 0.0f;
+        __syncthreads();
+        float hdr0 = 0.0f;
+        if (dv.metric == AH_COSINE && t < 8) hdr0 = f_sqrt(octet_reduce_any<OP_DOT>(dst, dst, dv.dims, t));
+        if (t == 0) {
+            qhdrs[2 * q] = hdr0;
+            qhdrs[2 * q + 1] = 0.0f;
+        }
+    } else {
+        uint64_t *dst = reinterpret_cast<uint64_t *>(qvecs + q * qstride);
+        for (uint32_t w = t; w < dv.pitch; w += blockDim.x) {
+            uint64_t word = 0;
+            if (w < dv.words)
+                for (uint32_t i = 0; i < 64; i++) {
+                    const uint32_t e = 64 * w + i;
+                    if (e < dv.dims) word |= (uint64_t)((__float_as_uint(src[e]) >> 31) == 0u) << i;
+                }
+            dst[w] = word;
+        }
+        if (t == 0) {
+            qhdrs[2 * q] = dv.metric == AH_BQ_COSINE ? f_sqrt((float)(int32_t)(64u * dv.words)) : 0.0f;
+            qhdrs[2 * q + 1] = 0.0f;
+        }
+    }
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(kBlock) void k_batch_distances_f32(DataView dv, const uint8_t *__restrict__ qvecs,
+                                                                uint64_t qstride, const float *__restrict__ qhdrs,
+                                                                const Seg *__restrict__ segs,
+                                                                const BTile *__restrict__ tiles, uint32_t n_tiles,
+                                                                const uint32_t *__restrict__ ids,
+                                                                float *__restrict__ out, uint32_t *err) {
+    constexpr int OP = METRIC == AH_EUCLIDEAN ? OP_EUCLID : OP_DOT;
+    extern __shared__ float4 s_q4[];
+    __shared__ float s_hdr[2];
+    const float *s_q = reinterpret_cast<const float *>(s_q4);
+    const uint32_t o = threadIdx.x >> 3, j = threadIdx.x & 7u;
+    uint32_t loaded_query = 0xFFFFFFFFu;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const BTile tl = tiles[tile];
+        const Seg sg = segs[tl.query];
+        if (tl.query != loaded_query) {  // block-uniform
+            __syncthreads();
+            const float4 *g = reinterpret_cast<const float4 *>(qvecs + tl.query * qstride);
+            for (uint32_t i = threadIdx.x; i < (dv.pitch >> 2); i += blockDim.x) s_q4[i] = g[i];
+            if (threadIdx.x < 2) s_hdr[threadIdx.x] = qhdrs[2 * tl.query + threadIdx.x];
+            loaded_query = tl.query;
+            __syncthreads();
+        }
+        const uint32_t in_tile = min(kTileCand, sg.n - tl.first);
+        const uint64_t base = sg.off + tl.first;
+        for (uint32_t p = o; p < in_tile; p += kBlock / 8) {
+            const uint64_t i = base + p;
+            const uint32_t id = ids[i];
+            const uint64_t row = row_of_id(dv, id);
+            if (row == ~0ull) {
+                if (j == 0) {
+                    atomicOr(err, 1u);
+                    out[i] = __uint_as_float(0x7FC00000u);
+                }
+                continue;
+            }
+            if ((tl.first + p) > 0 && id <= ids[i - 1] && j == 0) atomicOr(err, 2u);
+            const float *rp = dv.rows_f32 + row * dv.pitch;
+            float r;
+            if (dv.dims >= 32) {
+                if (METRIC == AH_MANHATTAN) r = octet_manhattan(s_q, rp, dv.dims, j);
+                else r = octet_reduce_stream<OP>(s_q4, rp, dv.dims, j);
+            } else if (METRIC == AH_MANHATTAN) {
+                r = 0.0f;
+                for (uint32_t e = 0; e < dv.dims; e++) r = f_add(r, fabsf(f_sub(s_q[e], rp[e])));
+            } else {
+                r = thread_reduce_small<OP>(s_q, rp, dv.dims);
+            }
+            if (j == 0) {
+                float d = r;
+                if (METRIC == AH_COSINE) d = cosine_from_dot(r, s_hdr[0], dv.headers[row]);
+                if (METRIC == AH_DOT_PRODUCT) d = -r;
+                out[i] = d;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_batch_distances_bq(DataView dv, const uint8_t *__restrict__ qvecs,
+                                                               uint64_t qstride, const float *__restrict__ qhdrs,
+                                                               const Seg *__restrict__ segs,
+                                                               const BTile *__restrict__ tiles, uint32_t n_tiles,
+                                                               const uint32_t *__restrict__ ids,
+                                                               float *__restrict__ out, uint32_t *err) {
+    extern __shared__ uint64_t s_qw[];
+    __shared__ float s_hdr[2];
+    uint32_t loaded_query = 0xFFFFFFFFu;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const BTile tl = tiles[tile];
+        const Seg sg = segs[tl.query];
+        if (tl.query != loaded_query) {
+            __syncthreads();
+            const uint64_t *g = reinterpret_cast<const uint64_t *>(qvecs + tl.query * qstride);
+            for (uint32_t i = threadIdx.x; i < dv.pitch; i += blockDim.x) s_qw[i] = g[i];
+            if (threadIdx.x < 2) s_hdr[threadIdx.x] = qhdrs[2 * tl.query + threadIdx.x];
+            loaded_query = tl.query;
+            __syncthreads();
+        }
+        const uint32_t in_tile = min(kTileCand, sg.n - tl.first);
+        const uint64_t base = sg.off + tl.first;
+        for (uint32_t p = threadIdx.x; p < in_tile; p += blockDim.x) {
+            const uint64_t i = base + p;
+            const uint32_t id = ids[i];
+            const uint64_t row = row_of_id(dv, id);
+            if (row == ~0ull) {
+                atomicOr(err, 1u);
+                out[i] = __uint_as_float(0x7FC00000u);
+                continue;
+            }
+            if ((tl.first + p) > 0 && id <= ids[i - 1]) atomicOr(err, 2u);
+            const uint64_t *rp = dv.rows_bq + row * dv.pitch;
+            uint32_t ham = 0;
+            for (uint32_t w = 0; w < dv.pitch; w++) ham += (uint32_t)__popcll(rp[w] ^ s_qw[w]);
+            float d;
+            if (dv.metric == AH_BQ_EUCLIDEAN) d = (float)(ham * 4u);
+            else if (dv.metric == AH_BQ_MANHATTAN) d = (float)(ham * 2u);
+            else d = bq_cosine_from_dot((float)bq_dot_from_hamming(ham, dv.words), s_hdr[0], dv.headers[row]);
+            out[i] = d;
+        }
+    }
+}
+
+// ---- batched top-k ----------------------------------------------------------------------------------
+// State of one query's tournament after `rounds` rounds: keys in flight and the number of blocks that wrote
+// them.  Pure function of (n, k), evaluated identically by every kernel and by the host.
+struct Tournament {
+    uint32_t n_in;    // keys entering the next round
+    uint32_t blocks;  // blocks of the last executed round (0 before round 0)
+    uint32_t keep;    // keys each of those blocks kept
+};
+__host__ __device__ inline uint32_t tour_keep(uint32_t blocks, uint32_t k) { return blocks == 1 ? k : min(k, kChunk / 2); }
+__host__ __device__ inline Tournament tour_after(uint32_t n, uint32_t k, uint32_t rounds) {
+    Tournament t{n, 0u, 0u};
+    for (uint32_t r = 0; r < rounds; r++) {
+        if (t.blocks == 1) break;  // finished: further rounds are no-ops
+        t.blocks = (t.n_in + kChunk - 1) / kChunk;
+        t.keep = tour_keep(t.blocks, k);
+        t.n_in = t.blocks * t.keep;
+    }
+    return t;
+}
+__host__ __device__ inline uint32_t tour_rounds(uint32_t n, uint32_t k) {
+    uint32_t r = 0;
+    Tournament t{n, 0u, 0u};
+    while (t.blocks != 1) {
+        t.blocks = (t.n_in + kChunk - 1) / kChunk;
+        t.keep = tour_keep(t.blocks, k);
+        t.n_in = t.blocks * t.keep;
+        r++;
+    }
+    return r;
+}
+
+__device__ __forceinline__ uint64_t batch_make_key(float d, uint32_t pos, uint32_t id, uint64_t two_k) {
+    const uint32_t ok = orderable_key(d);
+    if (pos >= two_k) {  // reader.rs:611,619-621: items >= (f32::MAX, u32::MAX) are skipped once 2k are buffered
+        const uint32_t max_key = 0xFF7FFFFFu;
+        if (ok > max_key || (ok == max_key && id == 0xFFFFFFFFu)) return kSentinel;
+    }
+    return ((uint64_t)ok << 32) | (uint64_t)pos;
+}
+
+__device__ __forceinline__ void batch_bitonic_sort(uint64_t *s) {
+    for (uint32_t size = 2; size <= kChunk; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < (kChunk >> 1); t += blockDim.x) {
+                const uint32_t lo = 2 * t - (t & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t a = s[lo], b = s[hi];
+                if ((a > b) == up) {
+                    s[lo] = b;
+                    s[hi] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// round r reads buffer (r odd ? B : A) ... round 0 reads the distances; it writes buffer (r even ? A : B).
+__global__ __launch_bounds__(kBlock) void k_batch_topk_round(const Seg *__restrict__ segs, uint32_t round,
+                                                             const float *__restrict__ dist,
+                                                             const uint32_t *__restrict__ ids, uint64_t *keys_a,
+                                                             uint64_t *keys_b, uint64_t kstride) {
+    __shared__ uint64_t s[kChunk];
+    const uint32_t q = blockIdx.y, c = blockIdx.x;
+    const Seg sg = segs[q];
+    if (sg.k == 0) return;
+    const Tournament before = tour_after(sg.n, sg.k, round);
+    if (before.blocks == 1) return;  // this query finished in an earlier round
+    const uint32_t blocks = (before.n_in + kChunk - 1) / kChunk;
+    if (c >= blocks) return;
+    const uint32_t keep = tour_keep(blocks, sg.k);
+    const uint64_t *src = (round & 1u) ? keys_a + q * kstride : keys_b + q * kstride;  // written by round-1
+    uint64_t *dst = (round & 1u) ? keys_b + q * kstride : keys_a + q * kstride;
+    const uint64_t two_k = 2ull * sg.k;
+    for (uint32_t t = threadIdx.x; t < kChunk; t += blockDim.x) {
+        const uint32_t g = c * kChunk + t;
+        uint64_t key = kSentinel;
+        if (g < before.n_in) key = round == 0 ? batch_make_key(dist[sg.off + g], g, ids[sg.off + g], two_k) : src[g];
+        s[t] = key;
+    }
+    batch_bitonic_sort(s);
+    for (uint32_t t = threadIdx.x; t < keep; t += blockDim.x) dst[(uint64_t)c * keep + t] = s[t];
+}
+
+__global__ void k_batch_topk_emit(DataView dv, const Seg *__restrict__ segs, const float *__restrict__ dist,
+                                  const uint32_t *__restrict__ ids, const uint64_t *keys_a, const uint64_t *keys_b,
+                                  uint64_t kstride, uint32_t k_out, uint32_t *out_ids, float *out_dist) {
+    const uint32_t q = blockIdx.y;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= k_out) return;
+    const Seg sg = segs[q];
+    uint32_t id = 0xFFFFFFFFu;
+    float d = __uint_as_float(0xFFFFFFFFu);  // NaN padding
+    if (t < sg.k) {
+        const uint32_t rounds = tour_rounds(sg.n, sg.k);  // the last round r = rounds-1 wrote (r even ? A : B)
+        const uint64_t *keys = ((rounds - 1) & 1u) ? keys_b + q * kstride : keys_a + q * kstride;
+        const uint32_t pos = (uint32_t)keys[t];
+        id = ids[sg.off + pos];
+        d = normalized_distance(dv.metric, dist[sg.off + pos], dv.dims);
+    }
+    out_ids[(uint64_t)q * k_out + t] = id;
+    out_dist[(uint64_t)q * k_out + t] = d;
+}
+
+// ---- host driver --------------------------------------------------------------------------------------
+// All device pointers are caller-carved scratch.  `h_segs` / `h_tiles` are host arrays already filled.
+size_t batch_key_stride(uint32_t max_n) { return (size_t)((max_n + kChunk - 1) / kChunk) * kChunk; }
+uint32_t batch_tile_candidates() { return kTileCand; }
+bool batch_supported(uint32_t k) { return k <= kChunk / 2; }
+
+int launch_rerank_batch(const DataView &dv, const float *d_q_f32, uint32_t n_queries, uint8_t *d_qvecs, uint64_t qstride,
+                        float *d_qhdrs, const void *d_segs_v, const void *d_tiles_v, uint32_t n_tiles,
+                        const uint32_t *d_ids, float *d_dist, uint64_t *d_keys_a, uint64_t *d_keys_b, uint64_t kstride,
+                        uint32_t max_n, uint32_t k_out, uint32_t max_rounds, uint32_t *d_out_ids, float *d_out_dist,
+                        uint32_t *d_err, hipStream_t s) {
+    const Seg *d_segs = reinterpret_cast<const Seg *>(d_segs_v);
+    const BTile *d_tiles = reinterpret_cast<const BTile *>(d_tiles_v);
+    hipLaunchKernelGGL(k_prepare_queries, dim3(n_queries), dim3(64), 0, s, dv, d_q_f32, d_qvecs, qstride, d_qhdrs);
+    if (n_tiles) {
+        const unsigned grid = n_tiles < 4096u ? n_tiles : 4096u;
+        if (metric_is_bq(dv.metric)) {
+            hipLaunchKernelGGL(k_batch_distances_bq, dim3(grid), dim3(kBlock), dv.pitch * 8, s, dv, d_qvecs, qstride,
+                               d_qhdrs, d_segs, d_tiles, n_tiles, d_ids, d_dist, d_err);
+        } else {
+            const size_t sh = (size_t)dv.pitch * 4;
+#define AH_LAUNCH(M)                                                                                          \
+    hipLaunchKernelGGL((k_batch_distances_f32<M>), dim3(grid), dim3(kBlock), sh, s, dv, d_qvecs, qstride,      \
+                       d_qhdrs, d_segs, d_tiles, n_tiles, d_ids, d_dist, d_err)
+            switch (dv.metric) {
+            case AH_EUCLIDEAN: AH_LAUNCH(AH_EUCLIDEAN); break;
+            case AH_MANHATTAN: AH_LAUNCH(AH_MANHATTAN); break;
+            case AH_COSINE: AH_LAUNCH(AH_COSINE); break;
+            default: AH_LAUNCH(AH_DOT_PRODUCT); break;
+            }
+#undef AH_LAUNCH
+        }
+        const uint32_t max_blocks = (max_n + kChunk - 1) / kChunk;
+        uint32_t blocks_bound = max_blocks;
+        for (uint32_t r = 0; r < max_rounds; r++) {
+            hipLaunchKernelGGL(k_batch_topk_round, dim3(blocks_bound, n_queries), dim3(kBlock), 0, s, d_segs, r, d_dist,
+                               d_ids, d_keys_a, d_keys_b, kstride);
+            blocks_bound = (blocks_bound * (kChunk / 2) + kChunk - 1) / kChunk;  // every round at least halves
+            if (blocks_bound < 1) blocks_bound = 1;
+        }
+    }
+    hipLaunchKernelGGL(k_batch_topk_emit, dim3((k_out + 255) / 256, n_queries), dim3(256), 0, s, dv, d_segs, d_dist,
+                       d_ids, d_keys_a, d_keys_b, kstride, k_out, d_out_ids, d_out_dist);
+    AH_HIP(hipGetLastError());
+    return AH_OK;
+}
+
+uint32_t batch_rounds(uint32_t n, uint32_t k) { return (n == 0 || k == 0) ? 0u : tour_rounds(n, k); }
+
+}  // namespace ah

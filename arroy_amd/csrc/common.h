@@ -149,6 +149,17 @@ int launch_build_lut(const uint32_t *d_ids, uint64_t n, uint32_t *d_lut, uint32_
 int launch_preprocess_dot(const DataView &dv, float *d_max_norm_bits, hipStream_t s);
 int launch_decode_item(const DataView &dv, uint32_t row, float *d_out, hipStream_t s);
 
+// batch.hip
+size_t batch_key_stride(uint32_t max_n);
+uint32_t batch_tile_candidates();
+bool batch_supported(uint32_t k);
+uint32_t batch_rounds(uint32_t n, uint32_t k);
+int launch_rerank_batch(const DataView &dv, const float *d_q_f32, uint32_t n_queries, uint8_t *d_qvecs, uint64_t qstride,
+                        float *d_qhdrs, const void *d_segs, const void *d_tiles, uint32_t n_tiles, const uint32_t *d_ids,
+                        float *d_dist, uint64_t *d_keys_a, uint64_t *d_keys_b, uint64_t kstride, uint32_t max_n,
+                        uint32_t k_out, uint32_t max_rounds, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err,
+                        hipStream_t s);
+
 // split.hip
 int launch_split_sides(const DataView &dv, const void *d_nvec, const float *d_nhdr, const uint32_t *d_ids, uint64_t n,
                        uint8_t *d_side_bits, unsigned long long *d_n_left, float *d_margins, uint32_t *d_err,

@@ -101,6 +101,28 @@ __device__ __forceinline__ float octet_reduce(const float *a, const float *b, ui
     return scalar_tail<OP>(r, a, b, blocks << 5, dims);
 }
 
+// Same reduction with the streamed operand `row` in global memory (read once, non-temporal) and the broadcast
+// operand `s_b4` (query / normal) in LDS: 8 line-loads (128 B per lane, 8 KiB per wave) are issued before the
+// first use so HBM latency is covered by loads in flight rather than by occupancy alone.  dims >= 32.
+template <int OP>
+__device__ __forceinline__ float octet_reduce_stream(const float4 *s_b4, const float *row, uint32_t dims, uint32_t j) {
+    const uint32_t blocks = dims >> 5;
+    const float4 *r4 = reinterpret_cast<const float4 *>(row) + j;
+    const float4 *b4 = s_b4 + j;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t k = 0;
+    for (; k + 8 <= blocks; k += 8) {
+        float4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = ld_stream(r4 + (k + u) * 8);
+#pragma unroll
+        for (int u = 0; u < 8; u++) fma_step<OP>(acc, b4[(k + u) * 8], x[u]);
+    }
+    for (; k < blocks; k++) fma_step<OP>(acc, b4[k * 8], r4[k * 8]);
+    float r = octet_finish(acc);
+    return scalar_tail<OP>(r, reinterpret_cast<const float *>(s_b4), row, blocks << 5, dims);
+}
+
 // SSE tier (16 <= dims < 32, simple_sse.rs) and scalar tier (dims < 16, simple.rs:49-51,81-83),
 // executed by ONE thread.  16 chains, multiply THEN add (never fused); hsum128 = (x0+x2)+(x1+x3).
 template <int OP>

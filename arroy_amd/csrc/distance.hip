@@ -106,7 +106,6 @@ __global__ __launch_bounds__(kBlock) void k_distances_f32(DataView dv, const flo
 
     const uint32_t j = threadIdx.x & 7u;
     const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
-    const uint32_t blocks = dv.dims >> 5;
     for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < n; i += n_octets) {
         uint64_t row = i;
         if (GATHER) {
@@ -125,22 +124,7 @@ __global__ __launch_bounds__(kBlock) void k_distances_f32(DataView dv, const flo
         if (METRIC == AH_MANHATTAN) {
             r = octet_manhattan(s_q, rp, dv.dims, j);
         } else {
-            const float4 *r4 = reinterpret_cast<const float4 *>(rp) + j;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            uint32_t k = 0;
-            // 8 line-loads in flight per lane (128 B/lane, 8 KiB/wave) before the first use
-            for (; k + 8 <= blocks; k += 8) {
-                float4 x[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) x[u] = ld_stream(r4 + (k + u) * 8);
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    fma_step<OP>(acc, s_q4[(k + u) * 8 + j], x[u]);
-            }
-            for (; k < blocks; k++)
-                fma_step<OP>(acc, s_q4[k * 8 + j], r4[k * 8]);
-            r = octet_finish(acc);
-            r = scalar_tail<OP>(r, s_q, rp, blocks << 5, dv.dims);
+            r = octet_reduce_stream<OP>(s_q4, rp, dv.dims, j);
         }
         if (j == 0) out[i] = f32_epilogue<METRIC>(r, s_hdr, dv, row);
     }

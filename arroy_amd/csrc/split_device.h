@@ -44,21 +44,7 @@ __device__ __forceinline__ float margin_f32(const DataView &dv, const float *s_n
     const float *rp = dv.rows_f32 + row * dv.pitch;
     float d;
     if (dv.dims >= 32) {
-        const float4 *r4 = reinterpret_cast<const float4 *>(rp) + j;
-        const float4 *n4 = reinterpret_cast<const float4 *>(s_n) + j;
-        const uint32_t blocks = dv.dims >> 5;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint32_t k = 0;
-        for (; k + 8 <= blocks; k += 8) {
-            float4 x[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) x[u] = ld_stream(r4 + (k + u) * 8);
-#pragma unroll
-            for (int u = 0; u < 8; u++) fma_step<OP_DOT>(acc, n4[(k + u) * 8], x[u]);
-        }
-        for (; k < blocks; k++) fma_step<OP_DOT>(acc, n4[k * 8], r4[k * 8]);
-        d = octet_finish(acc);
-        d = scalar_tail<OP_DOT>(d, s_n, rp, blocks << 5, dv.dims);
+        d = octet_reduce_stream<OP_DOT>(reinterpret_cast<const float4 *>(s_n), rp, dv.dims, j);
     } else {
         d = thread_reduce_small<OP_DOT>(s_n, rp, dv.dims);
     }
