@@ -921,3 +921,249 @@ AO_API void ao_synth_fill(uint64_t seed, int distribution, uint64_t first_item, 
 
 AO_API int ao_num_threads(void) { return omp_get_max_threads(); }
 AO_API void ao_set_num_threads(int n) { omp_set_num_threads(n); }
+
+/* =======================================================================================
+ * "Reference-order" build: the SAME make_tree_in_file, but with a restatement of the reference's
+ * own randomness — `StdRng` of rand 0.8.5 (= ChaCha12 of rand_chacha 0.3.1) consumed in the
+ * reference's depth-first order — so that the insta snapshots of src/tests/writer.rs can be
+ * replayed.  rand / rand_chacha are UN-VENDORED dependencies (Cargo.toml:16-32, no Cargo.lock):
+ * the algorithms below are restated from their published sources:
+ *   - ChaCha (D. J. Bernstein), 12 rounds, 64-bit block counter in words 12-13, stream id 0;
+ *     rand_chacha refills 4 consecutive blocks (64 words) at a time, words consumed in order;
+ *   - `Standard` u8  = low byte of next_u32;  [u8; 32] = 32 such draws (rand/src/distributions/other.rs);
+ *   - `Standard` bool = top bit of next_u32;
+ *   - `gen_range(lo..=hi)` for u32 = UniformInt::sample_single_inclusive: widening multiply with the
+ *     rejection zone `(range << range.leading_zeros()) - 1` (rand/src/distributions/uniform.rs);
+ *   - `seq::index::sample(rng, len, 2)` = Floyd's algorithm, fully shuffled variant for amount < 50
+ *     (rand/src/seq/index.rs).
+ * Pinned by tests/test_oracle_reference_order.py against snapshots in src/tests/writer.rs.
+ * Scope: one tree per build (n_trees(1)): with several trees the reference iterates a hashbrown
+ * `IntMap` and a rayon scope whose orders are not restated here.
+ * ===================================================================================== */
+typedef struct ao_chacha {
+    uint32_t key[8];
+    uint64_t counter;
+    uint32_t buf[64];
+    int index;
+} ao_chacha;
+
+static uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+#define AO_QR(a, b, c, d) \
+    a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); \
+    a += b; d ^= a; d = rotl32(d, 8);  c += d; b ^= c; b = rotl32(b, 7);
+
+static void chacha12_block(const uint32_t key[8], uint64_t counter, uint32_t out[16]) {
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                      key[4],      key[5],      key[6],      key[7],      (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+    uint32_t x[16];
+    memcpy(x, s, sizeof x);
+    for (int r = 0; r < 6; r++) { /* 12 rounds = 6 double rounds */
+        AO_QR(x[0], x[4], x[8], x[12]) AO_QR(x[1], x[5], x[9], x[13]) AO_QR(x[2], x[6], x[10], x[14]) AO_QR(x[3], x[7], x[11], x[15])
+        AO_QR(x[0], x[5], x[10], x[15]) AO_QR(x[1], x[6], x[11], x[12]) AO_QR(x[2], x[7], x[8], x[13]) AO_QR(x[3], x[4], x[9], x[14])
+    }
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
+AO_API void ao_rng_from_seed(ao_chacha *r, const uint8_t seed[32]) {
+    for (int i = 0; i < 8; i++) memcpy(&r->key[i], seed + 4 * i, 4); /* little-endian words */
+    r->counter = 0;
+    r->index = 64;
+}
+AO_API uint32_t ao_rng_next_u32(ao_chacha *r) {
+    if (r->index >= 64) {
+        for (int b = 0; b < 4; b++) chacha12_block(r->key, r->counter + (uint64_t)b, r->buf + 16 * b);
+        r->counter += 4;
+        r->index = 0;
+    }
+    return r->buf[r->index++];
+}
+AO_API void ao_rng_gen_seed(ao_chacha *r, uint8_t out[32]) {
+    for (int i = 0; i < 32; i++) out[i] = (uint8_t)ao_rng_next_u32(r);
+}
+AO_API int ao_rng_gen_bool(ao_chacha *r) { return (int32_t)ao_rng_next_u32(r) < 0; }
+AO_API uint32_t ao_rng_gen_range_inclusive_u32(ao_chacha *r, uint32_t low, uint32_t high) {
+    uint32_t range = high - low + 1u;
+    if (range == 0) return ao_rng_next_u32(r);
+    uint32_t zone = (range << __builtin_clz(range)) - 1u;
+    for (;;) {
+        uint32_t v = ao_rng_next_u32(r);
+        uint64_t m = (uint64_t)v * (uint64_t)range;
+        uint32_t hi = (uint32_t)(m >> 32), lo = (uint32_t)m;
+        if (lo <= zone) return low + hi;
+    }
+}
+/* seq::index::sample(rng, length, 2) -> (index(0), index(1)) */
+AO_API void ao_rng_index_sample2(ao_chacha *r, uint32_t length, uint32_t out[2]) {
+    uint32_t idx[2];
+    int n = 0;
+    for (uint32_t j = length - 2; j < length; j++) {
+        uint32_t t = ao_rng_gen_range_inclusive_u32(r, 0, j);
+        int pos = -1;
+        for (int i = 0; i < n; i++)
+            if (idx[i] == t) { pos = i; break; }
+        if (pos >= 0) { /* indices.insert(pos, j) */
+            for (int i = n; i > pos; i--) idx[i] = idx[i - 1];
+            idx[pos] = j;
+            n++;
+            continue;
+        }
+        idx[n++] = t;
+    }
+    out[0] = idx[0];
+    out[1] = idx[1];
+}
+
+typedef struct ao_ref_node {
+    uint32_t id;          /* the reference's tree-node id (ConcurrentNodeIds) */
+    uint8_t kind, has_normal;
+    uint32_t left, right; /* node ids */
+    uint64_t offset;      /* normals blob / descendants blob */
+    uint32_t count;
+} ao_ref_node;
+typedef struct ao_ref_tree {
+    ao_ref_node *nodes;
+    size_t n_nodes, cap_nodes;
+    uint8_t *normals;
+    size_t normals_len, cap_normals;
+    uint32_t *desc;
+    size_t desc_len, cap_desc;
+    uint32_t next_id;
+} ao_ref_tree;
+
+static void ref_push(ao_ref_tree *t, ao_ref_node nd) {
+    if (t->n_nodes == t->cap_nodes) {
+        t->cap_nodes = t->cap_nodes ? 2 * t->cap_nodes : 64;
+        t->nodes = (ao_ref_node *)realloc(t->nodes, t->cap_nodes * sizeof(ao_ref_node));
+    }
+    t->nodes[t->n_nodes++] = nd;
+}
+
+/* make_tree_in_file, src/writer.rs:1167-1261, with `next_id` exactly as the reference threads it. */
+static uint32_t ref_build_rec(const ao_data *d, ao_ref_tree *t, uint32_t split_after, uint32_t *rows, uint64_t n,
+                              ao_chacha *rng, int has_next_id, uint32_t next_id, uint32_t *scratch) {
+    ao_ref_node nd;
+    memset(&nd, 0, sizeof nd);
+    if (n <= split_after) {
+        nd.id = has_next_id ? next_id : t->next_id++;
+        nd.kind = AH_NODE_DESCENDANTS;
+        nd.offset = t->desc_len;
+        nd.count = (uint32_t)n;
+        if (t->desc_len + n > t->cap_desc) {
+            t->cap_desc = (t->desc_len + n) * 2 + 64;
+            t->desc = (uint32_t *)realloc(t->desc, t->cap_desc * sizeof(uint32_t));
+        }
+        for (uint64_t i = 0; i < n; i++) t->desc[t->desc_len + i] = d->ids ? d->ids[rows[i]] : rows[i];
+        t->desc_len += n;
+        ref_push(t, nd);
+        return nd.id;
+    }
+    size_t hs = ao_header_floats(d->metric) * 4, vs = ao_vector_bytes(d->metric, d->dims);
+    uint8_t *normal = (uint8_t *)malloc(hs + vs);
+    uint8_t *sides = (uint8_t *)malloc(n);
+    uint64_t n_left = 0;
+    int remaining = 3;
+    for (;;) {
+        uint32_t sample[AH_SPLIT_SAMPLES], two[2];
+        ao_rng_index_sample2(rng, (uint32_t)n, two); /* choose_two, src/parallel.rs:342-355 */
+        sample[0] = rows[two[0]];
+        sample[1] = rows[two[1]];
+        for (int it = 0; it < 10; it++) /* choose, :358-367: gen_range(0..=len-1), one per two-means iteration */
+            sample[2 + it] = rows[ao_rng_gen_range_inclusive_u32(rng, 0, (uint32_t)n - 1u)];
+        float nh[2] = {0, 0};
+        ao_create_split(d, sample, normal + hs, nh);
+        memcpy(normal, nh, hs);
+        ao_split_sides(d, normal + hs, nh, rows, n, sides, &n_left, NULL);
+        if (ao_split_imbalance(n_left, n - n_left) < 0.95 || remaining == 0) break;
+        remaining--;
+    }
+    int has_normal = 1;
+    if (ao_split_imbalance(n_left, n - n_left) > 0.99) {
+        has_normal = 0;
+        n_left = 0;
+        for (uint64_t i = 0; i < n; i++) { /* Side::random: true -> Left (src/lib.rs:135-141) */
+            int left = ao_rng_gen_bool(rng);
+            sides[i] = (uint8_t)(1 - left);
+            n_left += (uint64_t)left;
+        }
+    }
+    uint64_t li = 0, ri = n_left;
+    for (uint64_t i = 0; i < n; i++) {
+        if (sides[i]) scratch[ri++] = rows[i];
+        else scratch[li++] = rows[i];
+    }
+    memcpy(rows, scratch, n * sizeof(uint32_t));
+    free(sides);
+    uint32_t left = ref_build_rec(d, t, split_after, rows, n_left, rng, 0, 0, scratch);
+    uint32_t right = ref_build_rec(d, t, split_after, rows + n_left, n - n_left, rng, 0, 0, scratch + n_left);
+    nd.id = has_next_id ? next_id : t->next_id++; /* allocated AFTER the children (src/writer.rs:1257) */
+    nd.kind = AH_NODE_SPLIT;
+    nd.has_normal = (uint8_t)has_normal;
+    nd.left = left;
+    nd.right = right;
+    nd.count = (uint32_t)n;
+    nd.offset = t->normals_len;
+    if (t->normals_len + hs + vs > t->cap_normals) {
+        t->cap_normals = (t->normals_len + hs + vs) * 2;
+        t->normals = (uint8_t *)realloc(t->normals, t->cap_normals);
+    }
+    memcpy(t->normals + t->normals_len, normal, hs + vs);
+    t->normals_len += hs + vs;
+    free(normal);
+    ref_push(t, nd);
+    return nd.id;
+}
+
+/* Writer::build for a FRESH index on ONE rayon thread (src/tests/mod.rs:94), src/writer.rs:487-629:
+ *   - the caller's rng may already have been used (`skip_u32` draws, e.g. to generate the test vectors);
+ *   - roots take node ids 0..n_trees-1 (:556-561), remaining ids are handed out in allocation order;
+ *   - the task that walks `descendants` gets `StdRng::from_seed(rng.gen())` (:575); it visits the roots in
+ *     ascending id order (IntMap = hashbrown with the identity hash: bucket = key) and gives every root its
+ *     own `StdRng::from_seed(rng.gen())` (:795) in THAT order;
+ *   - the spawned tasks then run last-in-first-out on the single worker (rayon's local deque), i.e. the
+ *     highest root first: that is what fixes which tree gets which node ids.
+ * Each task = make_tree_in_file on all items (fit_in_memory with unlimited memory consumes no randomness).
+ * The order facts in the last two bullets are not in arroy's sources (hashbrown / rayon internals); they are
+ * confirmed by the 10-tree snapshot arroy__tests__writer__write_and_update_lot_of_random_points.snap. */
+AO_API ao_ref_tree *ao_build_forest_reference_order(const ao_data *d, uint32_t split_after, uint32_t n_trees,
+                                                    const uint8_t seed[32], uint64_t skip_u32) {
+    ao_ref_tree *t = (ao_ref_tree *)calloc(1, sizeof(ao_ref_tree));
+    if (split_after == 0) split_after = d->dims;
+    ao_chacha rng0, rng1;
+    uint8_t s[32];
+    ao_rng_from_seed(&rng0, seed);
+    for (uint64_t i = 0; i < skip_u32; i++) (void)ao_rng_next_u32(&rng0);
+    t->next_id = n_trees;
+    ao_rng_gen_seed(&rng0, s);
+    ao_rng_from_seed(&rng1, s);
+    uint8_t *task_seeds = (uint8_t *)malloc(32 * (size_t)(n_trees ? n_trees : 1));
+    for (uint32_t r = 0; r < n_trees; r++) ao_rng_gen_seed(&rng1, task_seeds + 32 * (size_t)r);
+    uint32_t *rows = (uint32_t *)malloc(sizeof(uint32_t) * (d->n ? d->n : 1));
+    uint32_t *scratch = (uint32_t *)malloc(sizeof(uint32_t) * (d->n ? d->n : 1));
+    for (uint32_t k = 0; k < n_trees; k++) {
+        uint32_t r = n_trees - 1 - k; /* LIFO */
+        ao_chacha rng2;
+        ao_rng_from_seed(&rng2, task_seeds + 32 * (size_t)r);
+        for (uint64_t i = 0; i < d->n; i++) rows[i] = (uint32_t)i;
+        ref_build_rec(d, t, split_after, rows, d->n, &rng2, 1, r, scratch);
+    }
+    free(task_seeds);
+    free(rows);
+    free(scratch);
+    return t;
+}
+AO_API ao_ref_tree *ao_build_tree_reference_order(const ao_data *d, uint32_t split_after, const uint8_t seed[32]) {
+    return ao_build_forest_reference_order(d, split_after, 1, seed, 0);
+}
+AO_API size_t ao_ref_tree_nodes(const ao_ref_tree *t, const ao_ref_node **nodes, const uint8_t **normals,
+                                const uint32_t **desc) {
+    *nodes = t->nodes;
+    *normals = t->normals;
+    *desc = t->desc;
+    return t->n_nodes;
+}
+AO_API void ao_ref_tree_free(ao_ref_tree *t) {
+    if (!t) return;
+    free(t->nodes);
+    free(t->normals);
+    free(t->desc);
+    free(t);
+}

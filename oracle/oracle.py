@@ -43,6 +43,11 @@ class AhForestView(C.Structure):
                 ("descendants_len", C.c_uint64)]
 
 
+class AoRefNode(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("kind", C.c_uint8), ("has_normal", C.c_uint8), ("left", C.c_uint32),
+                ("right", C.c_uint32), ("offset", C.c_uint64), ("count", C.c_uint32)]
+
+
 class AoData(C.Structure):
     _fields_ = [("metric", C.c_int), ("dims", C.c_uint32), ("n", C.c_uint64), ("vectors", C.c_void_p),
                 ("headers", C.c_void_p), ("ids", C.c_void_p)]
@@ -117,6 +122,23 @@ def lib() -> C.CDLL:
         L.ao_build_forest_count.restype = C.c_uint64
         L.ao_build_forest_count.argtypes = [C.POINTER(AoData), C.c_uint32, C.c_void_p, C.c_uint32]
         L.ao_synth_fill.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
+        L.ao_build_tree_reference_order.restype = C.c_void_p
+        L.ao_build_tree_reference_order.argtypes = [C.POINTER(AoData), C.c_uint32, C.c_void_p]
+        L.ao_build_forest_reference_order.restype = C.c_void_p
+        L.ao_build_forest_reference_order.argtypes = [C.POINTER(AoData), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64]
+        L.ao_ref_tree_nodes.restype = C.c_size_t
+        L.ao_ref_tree_nodes.argtypes = [C.c_void_p, C.POINTER(C.POINTER(AoRefNode)), C.POINTER(C.POINTER(C.c_uint8)),
+                                        C.POINTER(C.POINTER(C.c_uint32))]
+        L.ao_ref_tree_free.argtypes = [C.c_void_p]
+        L.ao_rng_from_seed.argtypes = [C.c_void_p, C.c_void_p]
+        L.ao_rng_next_u32.restype = C.c_uint32
+        L.ao_rng_next_u32.argtypes = [C.c_void_p]
+        L.ao_rng_gen_seed.argtypes = [C.c_void_p, C.c_void_p]
+        L.ao_rng_gen_bool.restype = C.c_int
+        L.ao_rng_gen_bool.argtypes = [C.c_void_p]
+        L.ao_rng_gen_range_inclusive_u32.restype = C.c_uint32
+        L.ao_rng_gen_range_inclusive_u32.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.ao_rng_index_sample2.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.ao_num_threads.restype = C.c_int
         L.ao_set_num_threads.argtypes = [C.c_int]
         _lib = L
@@ -317,4 +339,59 @@ class Tree:
 def synth(seed: int, distribution: int, n: int, dims: int, first_item: int = 0) -> np.ndarray:
     out = np.zeros((n, dims), dtype=np.float32)
     lib().ao_synth_fill(seed, distribution, first_item, n, dims, _p(out))
+    return out
+
+
+class ChaCha12:
+    """`StdRng` of rand 0.8 (restated in arroy_oracle.c): only what the tests need."""
+
+    def __init__(self, seed: bytes):
+        self._st = C.create_string_buffer(8 * 4 + 8 + 64 * 4 + 8)
+        lib().ao_rng_from_seed(self._st, C.c_char_p(bytes(seed)))
+
+    def next_u32(self) -> int:
+        return int(lib().ao_rng_next_u32(self._st))
+
+    def gen_f32(self) -> np.float32:
+        """`rng.gen::<f32>()`: 24 random bits scaled into [0, 1)."""
+        return np.float32((self.next_u32() >> 8) * (1.0 / (1 << 24)))
+
+    def gen_seed(self) -> bytes:
+        """`rng.gen::<[u8; 32]>()` (the argument of `StdRng::from_seed(rng.gen())`, src/writer.rs:575,795)."""
+        out = C.create_string_buffer(32)
+        lib().ao_rng_gen_seed(self._st, out)
+        return out.raw
+
+    def gen_bool(self) -> bool:
+        return bool(lib().ao_rng_gen_bool(self._st))
+
+    def gen_range_inclusive(self, low: int, high: int) -> int:
+        return int(lib().ao_rng_gen_range_inclusive_u32(self._st, low, high))
+
+    def index_sample2(self, length: int):
+        out = (C.c_uint32 * 2)()
+        lib().ao_rng_index_sample2(self._st, length, out)
+        return int(out[0]), int(out[1])
+
+
+def build_tree_reference_order(data: "Data", split_after: int, seed: bytes = bytes([42] * 32), n_trees: int = 1,
+                               skip_u32: int = 0):
+    """`Writer::build` of a fresh index with the reference's own randomness (StdRng seeded like the reference's
+    tests), depth-first, one rayon thread.  Returns {node_id: node} with node = ("D", [ids]) or
+    ("S", left_id, right_id, header f32[], vector bytes or None)."""
+    L = lib()
+    h = L.ao_build_forest_reference_order(data.c(), split_after, n_trees, C.c_char_p(bytes(seed)), skip_u32)
+    nodes_p, normals_p, desc_p = C.POINTER(AoRefNode)(), C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint32)()
+    n = L.ao_ref_tree_nodes(h, C.byref(nodes_p), C.byref(normals_p), C.byref(desc_p))
+    hs, vs = 4 * header_floats(data.metric), vector_bytes(data.metric, data.dims)
+    out = {}
+    for i in range(n):
+        nd = nodes_p[i]
+        if nd.kind == 1:
+            out[int(nd.id)] = ("D", [int(desc_p[nd.offset + j]) for j in range(nd.count)])
+        else:
+            raw = bytes(C.string_at(C.addressof(normals_p.contents) + nd.offset, hs + vs))
+            hdr = np.frombuffer(raw[:hs], dtype=np.float32).copy()
+            out[int(nd.id)] = ("S", int(nd.left), int(nd.right), hdr, raw[hs:] if nd.has_normal else None)
+    L.ao_ref_tree_free(h)
     return out

@@ -377,3 +377,73 @@ def test_bq_scan_wide_and_narrow_rows(metric, dims):
     assert_bit_equal(ds.distances(query=q), oracle.distances(qv, qh))
     sub = np.arange(5, n, 7, dtype=np.uint32)
     assert_bit_equal(ds.distances(query=q, ids=sub), oracle.distances(qv, qh, rows=sub))
+
+
+# ---- the reference's own insta snapshot, through the GPU ---------------------------------------------------
+
+def _reference_order_build_on_gpu(ds, n_items, split_after, n_trees, seed, skip_u32):
+    """`Writer::build` in the reference's order (depth-first, rand 0.8 StdRng, one rayon thread) where every
+    create_split / margin loop is a C-ABI call into the HIP library: the "host RNG" mode of the integration
+    (ah_create_split takes the sampled ids from the caller, exactly like `R: Rng` stays on the Rust side)."""
+    rng0 = O.ChaCha12(seed)
+    for _ in range(skip_u32):
+        rng0.next_u32()
+    rng1 = O.ChaCha12(rng0.gen_seed())
+    task_seeds = [rng1.gen_seed() for _ in range(n_trees)]
+    nodes, next_id = {}, [n_trees]
+
+    def alloc():
+        next_id[0] += 1
+        return next_id[0] - 1
+
+    def rec(ids, rng, node_id):
+        if len(ids) <= split_after:
+            node_id = alloc() if node_id is None else node_id
+            nodes[node_id] = ("D", [int(i) for i in ids])
+            return node_id
+        remaining = 3
+        while True:
+            a, b = rng.index_sample2(len(ids))
+            sample = [ids[a], ids[b]] + [ids[rng.gen_range_inclusive(0, len(ids) - 1)] for _ in range(10)]
+            nv, nh = ds.create_split(sample)
+            sides, n_left, _ = ds.split_sides(nv, nh, sorted_ids=ids, want_margins=False)
+            imb = O.lib().ao_split_imbalance(n_left, len(ids) - n_left)
+            if imb < 0.95 or remaining == 0:
+                break
+            remaining -= 1
+        if imb > 0.99:
+            sides = np.array([0 if rng.gen_bool() else 1 for _ in ids], dtype=np.uint8)
+            nv = None
+        left = rec(ids[sides == 0], rng, None)
+        right = rec(ids[sides == 1], rng, None)
+        node_id = alloc() if node_id is None else node_id
+        nodes[node_id] = ("S", left, right, "%.4f" % nh[0],
+                          None if nv is None else ["%.4f" % x for x in nv.view(np.float32)])
+        return node_id
+
+    for root in reversed(range(n_trees)):  # tasks run last-in-first-out on the single rayon worker
+        rec(np.arange(n_items, dtype=np.uint32), O.ChaCha12(task_seeds[root]), root)
+    return nodes
+
+
+def test_reference_insta_snapshot_through_the_gpu(golden):
+    """src/tests/writer.rs:296-308: the 10-tree, 92-node snapshot of arroy's own test-suite, with every split
+    computed by the HIP kernels (ids, children, bias, normal prefix and descendants of every node)."""
+    from arroy_amd import Dataset
+    g = golden["random_points_10_trees"]
+    seed = bytes([42] * 32)
+    rng = O.ChaCha12(seed)
+    vecs = np.array([[rng.gen_f32() for _ in range(g["dims"])] for _ in range(g["n_items"])], dtype=np.float32)
+    ds = Dataset(D.Euclidean, g["dims"], g["n_items"])
+    ds.upload_vectors(np.arange(g["n_items"], dtype=np.uint32), vecs)
+    ds.finalize()
+    nodes = _reference_order_build_on_gpu(ds, g["n_items"], g["dims"], g["n_trees"], seed,
+                                          skip_u32=g["n_items"] * g["dims"])
+    assert sorted(nodes) == sorted(int(k) for k in g["trees"])
+    for k, want in g["trees"].items():
+        got = nodes[int(k)]
+        if want["kind"] == "D":
+            assert got == ("D", want["descendants"]), f"tree node {k}"
+        else:
+            assert (got[0], got[1], got[2], got[3]) == ("S", want["left"], want["right"], want["bias"]), f"node {k}"
+            assert got[4][:10] == want["vector10"], f"normal of tree node {k}"
