@@ -9,7 +9,7 @@ Layout
 """
 from . import distances
 from ._lib import ArroyHipError, BuildCancelled, InvalidVecDimension, MissingKey, device_count, device_name
-from .dataset import Dataset, Forest
+from .dataset import Dataset, Forest, Index
 
-__all__ = ["distances", "Dataset", "Forest", "ArroyHipError", "BuildCancelled", "InvalidVecDimension", "MissingKey",
+__all__ = ["distances", "Dataset", "Forest", "Index", "ArroyHipError", "BuildCancelled", "InvalidVecDimension", "MissingKey",
            "device_count", "device_name"]

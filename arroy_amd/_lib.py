@@ -103,6 +103,10 @@ SIGNATURES = {
     "ah_forest_stats": (C.c_int, [_VP, C.POINTER(AhBuildStats)]),
     "ah_forest_visit": (C.c_int, [_VP, _VP, _VP]),
     "ah_forest_destroy": (C.c_int, [_VP]),
+    "ah_index_create": (C.c_int, [_VP, _VP, C.POINTER(C.c_void_p)]),
+    "ah_index_destroy": (C.c_int, [_VP]),
+    "ah_search_batch": (C.c_int, [_VP, _F32P, _U32P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _U32P, C.c_size_t,
+                                  C.c_int, _U32P, _F32P, _U32P]),
     "ah_bench_scan": (C.c_int, [_VP, C.c_uint32, C.c_uint64, C.c_uint32, _F32P, C.POINTER(C.c_double)]),
     "ah_bench_memcpy": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     "ah_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),

@@ -276,14 +276,22 @@ size_t batch_key_stride(uint32_t max_n) { return (size_t)((max_n + kChunk - 1) /
 uint32_t batch_tile_candidates() { return kTileCand; }
 bool batch_supported(uint32_t k) { return k <= kChunk / 2; }
 
-int launch_rerank_batch(const DataView &dv, const float *d_q_f32, uint32_t n_queries, uint8_t *d_qvecs, uint64_t qstride,
-                        float *d_qhdrs, const void *d_segs_v, const void *d_tiles_v, uint32_t n_tiles,
-                        const uint32_t *d_ids, float *d_dist, uint64_t *d_keys_a, uint64_t *d_keys_b, uint64_t kstride,
-                        uint32_t max_n, uint32_t k_out, uint32_t max_rounds, uint32_t *d_out_ids, float *d_out_dist,
-                        uint32_t *d_err, hipStream_t s) {
+int launch_prepare_queries_only(const DataView &dv, const float *d_q_f32, uint32_t n_queries, uint8_t *d_qvecs,
+                                uint64_t qstride, float *d_qhdrs, hipStream_t s) {
+    if (n_queries)
+        hipLaunchKernelGGL(k_prepare_queries, dim3(n_queries), dim3(64), 0, s, dv, d_q_f32, d_qvecs, qstride, d_qhdrs);
+    AH_HIP(hipGetLastError());
+    return AH_OK;
+}
+
+// distances + tournament top-k + emit for queries whose leaves (qvecs / qhdrs) are already on the device
+int launch_rerank_batch_prepared(const DataView &dv, uint32_t n_queries, const uint8_t *d_qvecs, uint64_t qstride,
+                                 const float *d_qhdrs, const void *d_segs_v, const void *d_tiles_v, uint32_t n_tiles,
+                                 const uint32_t *d_ids, float *d_dist, uint64_t *d_keys_a, uint64_t *d_keys_b,
+                                 uint64_t kstride, uint32_t max_n, uint32_t k_out, uint32_t max_rounds,
+                                 uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s) {
     const Seg *d_segs = reinterpret_cast<const Seg *>(d_segs_v);
     const BTile *d_tiles = reinterpret_cast<const BTile *>(d_tiles_v);
-    hipLaunchKernelGGL(k_prepare_queries, dim3(n_queries), dim3(64), 0, s, dv, d_q_f32, d_qvecs, qstride, d_qhdrs);
     if (n_tiles) {
         const unsigned grid = n_tiles < 4096u ? n_tiles : 4096u;
         if (metric_is_bq(dv.metric)) {
@@ -315,6 +323,17 @@ int launch_rerank_batch(const DataView &dv, const float *d_q_f32, uint32_t n_que
                        d_ids, d_keys_a, d_keys_b, kstride, k_out, d_out_ids, d_out_dist);
     AH_HIP(hipGetLastError());
     return AH_OK;
+}
+
+int launch_rerank_batch(const DataView &dv, const float *d_q_f32, uint32_t n_queries, uint8_t *d_qvecs, uint64_t qstride,
+                        float *d_qhdrs, const void *d_segs_v, const void *d_tiles_v, uint32_t n_tiles,
+                        const uint32_t *d_ids, float *d_dist, uint64_t *d_keys_a, uint64_t *d_keys_b, uint64_t kstride,
+                        uint32_t max_n, uint32_t k_out, uint32_t max_rounds, uint32_t *d_out_ids, float *d_out_dist,
+                        uint32_t *d_err, hipStream_t s) {
+    AH_TRY(launch_prepare_queries_only(dv, d_q_f32, n_queries, d_qvecs, qstride, d_qhdrs, s));
+    return launch_rerank_batch_prepared(dv, n_queries, d_qvecs, qstride, d_qhdrs, d_segs_v, d_tiles_v, n_tiles, d_ids,
+                                        d_dist, d_keys_a, d_keys_b, kstride, max_n, k_out, max_rounds, d_out_ids,
+                                        d_out_dist, d_err, s);
 }
 
 uint32_t batch_rounds(uint32_t n, uint32_t k) { return (n == 0 || k == 0) ? 0u : tour_rounds(n, k); }

@@ -1,0 +1,707 @@
+// search.hip — `Reader::nns_by_leaf` (src/reader.rs:317-401) entirely on device, for a batch of queries:
+// best-first tree descent -> candidate collection -> sort + dedup -> re-rank -> top-k.
+//
+// The forest built by ah_build_forest is mirrored in HBM as flat arrays: nodes
+// {kind, left/right or descendants range, normal row}, the split-plane normals as a second row matrix
+// (same layout and the same exact-order margin code as the item rows) and the descendants blob.
+//
+// Descent: ONE OCTET PER QUERY (8 queries per wave).  Lane 0 of the octet owns the priority queue — a binary
+// max-heap of 64-bit keys `orderable(distance) << 32 | node` in LDS, which is exactly the reference's
+// BinaryHeap<(OrderedFloat<f32>, NodeId)> order, ties included; all 8 lanes compute the margin of a popped
+// split node with the AVX-order dot product (both operands stream from L2/HBM) and copy descendants.
+// The pop sequence is inherently sequential per query (best-first), so throughput comes from running
+// thousands of queries concurrently; a query whose queue outgrows its LDS slot is re-run by a second kernel
+// with the queue in global memory (capacity = number of nodes, a hard bound: every node is pushed at most
+// once).
+#include <algorithm>
+#include <new>
+
+#include "common.h"
+#include "split_device.h"
+
+namespace ah {
+
+static constexpr uint32_t kHeapLds = 1024;   // queue entries per query in LDS (8 KiB)
+static constexpr uint32_t kSortLds = 16384;  // candidate ids sorted in LDS per query (64 KiB)
+
+struct DNode {
+    uint32_t kind;  // AH_NODE_*; bit 8 = has_normal
+    uint32_t a;     // SPLIT: left            DESCENDANTS: first id (index into the blob)
+    uint32_t b;     // SPLIT: right           DESCENDANTS: count
+    uint32_t c;     // SPLIT: normal row      DESCENDANTS: unused
+};
+
+struct SearchParams {
+    const DNode *nodes;
+    const uint32_t *roots;
+    uint32_t n_trees;
+    const uint32_t *desc;
+    const uint32_t *filter_bits;  // bitmap over item ids or nullptr
+    uint32_t filter_len_bits;
+    uint32_t search_k;            // already multiplied by the oversampling, clamped to the blob size
+    uint32_t nns_stride;          // capacity of one query's candidate buffer
+};
+
+__device__ __forceinline__ float key_to_dist(uint32_t k) {
+    if (k == 0xFFFFFFFFu) return __uint_as_float(0x7FC00000u);
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+__device__ __forceinline__ void heap_push(uint64_t *h, uint32_t &n, uint64_t key) {
+    uint32_t i = n++;
+    while (i > 0) {
+        const uint32_t p = (i - 1) >> 1;
+        if (h[p] >= key) break;
+        h[i] = h[p];
+        i = p;
+    }
+    h[i] = key;
+}
+__device__ __forceinline__ uint64_t heap_pop(uint64_t *h, uint32_t &n) {
+    const uint64_t top = h[0];
+    const uint64_t last = h[--n];
+    uint32_t i = 0;
+    for (;;) {
+        const uint32_t l = 2 * i + 1;
+        if (l >= n) break;
+        const uint32_t r = l + 1;
+        const uint32_t m = (r < n && h[r] > h[l]) ? r : l;
+        if (h[m] <= last) break;
+        h[i] = h[m];
+        i = m;
+    }
+    if (n) h[i] = last;
+    return top;
+}
+// Rust f32::min: the non-NaN operand if one is NaN.
+__device__ __forceinline__ float rust_min(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    return a < b ? a : b;
+}
+
+// `D::margin(&normal, query_leaf)` with the normal a ROW of the normals matrix `nv` and the query leaf in
+// global memory (qvec / qh).  All 8 lanes of the octet participate; every lane gets the result.
+__device__ __forceinline__ float descent_margin(const DataView &nv, uint32_t nrow, const void *qvec, LeafHdr qh,
+                                                uint32_t j) {
+    if (metric_is_bq_dev(nv.metric)) {
+        const uint64_t *np = nv.rows_bq + (uint64_t)nrow * nv.pitch;
+        const uint64_t *qp = reinterpret_cast<const uint64_t *>(qvec);
+        uint32_t ham = 0;
+        for (uint32_t w = 0; w < nv.pitch; w++) ham += (uint32_t)__popcll(np[w] ^ qp[w]);
+        const float d = (float)bq_dot_from_hamming(ham, nv.words);
+        return nv.metric == AH_BQ_COSINE ? d : f_add(nv.headers[nrow], d);
+    }
+    const float *np = nv.rows_f32 + (uint64_t)nrow * nv.pitch;
+    const float *qp = reinterpret_cast<const float *>(qvec);
+    const float d = octet_reduce_any<OP_DOT>(np, qp, nv.dims, j);
+    if (nv.metric == AH_EUCLIDEAN || nv.metric == AH_MANHATTAN) return f_add(nv.headers[nrow], d);
+    if (nv.metric == AH_DOT_PRODUCT) return f_add(d, f_mul(nv.headers[2 * (uint64_t)nrow], qh.h0));
+    return d;
+}
+
+// One octet per query.  HEAP_GLOBAL = false: queue in LDS (kHeapLds entries), overflow reported;
+// true: queue in global memory with `heap_cap` entries per query (re-run of the overflowed queries).
+template <bool HEAP_GLOBAL>
+__global__ __launch_bounds__(64) void k_descend(DataView nv, SearchParams sp, const uint32_t *__restrict__ query_list,
+                                                uint32_t n_list, const uint8_t *__restrict__ qvecs, uint64_t qstride,
+                                                const float *__restrict__ qhdrs, uint32_t *__restrict__ nns,
+                                                uint32_t *__restrict__ nns_count, uint32_t *__restrict__ overflow,
+                                                uint64_t *heap_global, uint32_t heap_cap) {
+    extern __shared__ uint64_t s_heap[];  // 8 x kHeapLds entries when the queue lives in LDS
+    const uint32_t o = threadIdx.x >> 3, j = threadIdx.x & 7u;
+    const uint32_t slot = blockIdx.x * 8 + o;
+    const bool live = slot < n_list;
+    const uint32_t q = live ? (query_list ? query_list[slot] : slot) : 0u;
+    uint64_t *heap = HEAP_GLOBAL ? heap_global + (uint64_t)slot * heap_cap : s_heap + o * kHeapLds;
+    const uint32_t cap = HEAP_GLOBAL ? heap_cap : kHeapLds;
+    const void *qvec = qvecs + (uint64_t)q * qstride;
+    const LeafHdr qh = {qhdrs[2 * (uint64_t)q], qhdrs[2 * (uint64_t)q + 1]};
+    uint32_t *my_nns = nns + (uint64_t)q * sp.nns_stride;
+    uint32_t hn = 0, nn = 0;
+    bool failed = false;
+    if (live && j == 0) {  // queue.extend(repeat(+inf).zip(roots)), src/reader.rs:338
+        for (uint32_t t = 0; t < sp.n_trees && !failed; t++) {
+            if (hn == cap) failed = true;
+            else heap_push(heap, hn, ((uint64_t)0xFF800000u << 32) | sp.roots[t]);
+        }
+    }
+    bool active = live;
+    while (__any(active)) {
+        // lane 0 pops; the decision is broadcast to the octet
+        uint32_t action = 0, node = 0;
+        float dist = 0.0f;
+        if (active && j == 0) {
+            if (failed || nn >= sp.search_k || hn == 0) {
+                action = 0;
+            } else {
+                const uint64_t key = heap_pop(heap, hn);
+                node = (uint32_t)key;
+                dist = key_to_dist((uint32_t)(key >> 32));
+                action = sp.nodes[node].kind & 0xFFu;
+            }
+        }
+        action = __shfl(action, 0, 8);
+        node = __shfl(node, 0, 8);
+        dist = __shfl(dist, 0, 8);
+        if (!active || action == 0) {
+            active = false;
+            continue;
+        }
+        const DNode nd = sp.nodes[node];
+        if (action == AH_NODE_DESCENDANTS) {  // src/reader.rs:354-360
+            const uint32_t *ids = sp.desc + nd.a;
+            if (!sp.filter_bits) {
+                for (uint32_t i = j; i < nd.b; i += 8) my_nns[nn + i] = ids[i];
+                nn += nd.b;
+            } else {  // descendants & candidates: order inside nns is irrelevant (sorted afterwards)
+                for (uint32_t base = 0; base < nd.b; base += 8) {
+                    const uint32_t i = base + j;
+                    uint32_t keep = 0, id = 0;
+                    if (i < nd.b) {
+                        id = ids[i];
+                        keep = id < sp.filter_len_bits && ((sp.filter_bits[id >> 5] >> (id & 31)) & 1u);
+                    }
+                    // prefix inside the octet
+                    uint32_t before = 0, total = 0;
+                    for (uint32_t l = 0; l < 8; l++) {
+                        const uint32_t kl = __shfl(keep, l, 8);
+                        if (l < j) before += kl;
+                        total += kl;
+                    }
+                    if (keep) my_nns[nn + before] = id;
+                    nn += total;
+                }
+            }
+        } else {  // SplitPlaneNormal, src/reader.rs:361-372
+            float margin = 0.0f;
+            if (nd.kind & 0x100u) margin = descent_margin(nv, nd.c, qvec, qh, j);
+            if (j == 0) {
+                if (hn + 2 > cap) {
+                    failed = true;
+                } else {  // D::pq_distance, src/distance/mod.rs:63-68
+                    const float pl = rust_min(-margin, dist), pr = rust_min(margin, dist);
+                    heap_push(heap, hn, ((uint64_t)orderable_key(pl) << 32) | nd.a);
+                    heap_push(heap, hn, ((uint64_t)orderable_key(pr) << 32) | nd.b);
+                }
+            }
+        }
+    }
+    if (live && j == 0) {
+        nns_count[q] = failed ? 0u : nn;
+        overflow[q] = failed ? 1u : 0u;
+    }
+}
+
+// nns.sort_unstable(); nns.dedup()  (src/reader.rs:378-379): one block per query, LDS bitonic sort.
+__global__ __launch_bounds__(256) void k_sort_dedup_lds(uint32_t *__restrict__ nns, uint32_t stride,
+                                                        uint32_t *__restrict__ counts) {
+    extern __shared__ uint32_t s_ids[];
+    __shared__ uint32_t s_scan[256];
+    const uint32_t q = blockIdx.x;
+    const uint32_t n = counts[q];
+    uint32_t *ids = nns + (uint64_t)q * stride;
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    if (np2 < 2) np2 = 2;
+    for (uint32_t t = threadIdx.x; t < np2; t += blockDim.x) s_ids[t] = t < n ? ids[t] : 0xFFFFFFFFu;
+    for (uint32_t size = 2; size <= np2; size <<= 1) {
+        for (uint32_t str = size >> 1; str > 0; str >>= 1) {
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < (np2 >> 1); t += blockDim.x) {
+                const uint32_t lo = 2 * t - (t & (str - 1)), hi = lo + str;
+                const bool up = (lo & size) == 0;
+                const uint32_t a = s_ids[lo], b = s_ids[hi];
+                if ((a > b) == up) {
+                    s_ids[lo] = b;
+                    s_ids[hi] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // dedup: thread t owns the contiguous slice [t*per, (t+1)*per)
+    const uint32_t per = (n + blockDim.x - 1) / blockDim.x;
+    const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    uint32_t mine = 0;
+    for (uint32_t i = lo; i < hi; i++) mine += (i == 0 || s_ids[i] != s_ids[i - 1]) ? 1u : 0u;
+    s_scan[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t t = 0; t < blockDim.x; t++) {
+            const uint32_t v = s_scan[t];
+            s_scan[t] = run;
+            run += v;
+        }
+        counts[q] = run;
+    }
+    __syncthreads();
+    uint32_t w = s_scan[threadIdx.x];
+    for (uint32_t i = lo; i < hi; i++)
+        if (i == 0 || s_ids[i] != s_ids[i - 1]) ids[w++] = s_ids[i];
+}
+
+// Larger candidate sets: bitonic steps in global memory, all queries of the batch per launch.
+__global__ void k_pad_ids(uint32_t *nns, uint32_t stride, const uint32_t *counts, uint32_t np2) {
+    const uint32_t q = blockIdx.y;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < np2 && t >= counts[q]) nns[(uint64_t)q * stride + t] = 0xFFFFFFFFu;
+}
+__global__ void k_bitonic_ids(uint32_t *nns, uint32_t stride, uint32_t np2, uint32_t size, uint32_t str) {
+    const uint32_t q = blockIdx.y;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (np2 >> 1)) return;
+    uint32_t *ids = nns + (uint64_t)q * stride;
+    const uint32_t lo = 2 * t - (t & (str - 1)), hi = lo + str;
+    const bool up = (lo & size) == 0;
+    const uint32_t a = ids[lo], b = ids[hi];
+    if ((a > b) == up) {
+        ids[lo] = b;
+        ids[hi] = a;
+    }
+}
+// in-place dedup of a sorted list by one block per query (serial over chunks of 256, stable)
+__global__ __launch_bounds__(256) void k_dedup_sorted(uint32_t *nns, uint32_t stride, uint32_t *counts) {
+    __shared__ uint32_t s_flag[256];
+    __shared__ uint32_t s_base;
+    const uint32_t q = blockIdx.x;
+    const uint32_t n = counts[q];
+    uint32_t *ids = nns + (uint64_t)q * stride;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (uint32_t c = 0; c < n; c += 256) {
+        const uint32_t i = c + threadIdx.x;
+        uint32_t v = 0, keep = 0;
+        if (i < n) {
+            v = ids[i];
+            keep = (i == 0 || ids[i - 1] != v) ? 1u : 0u;
+        }
+        __syncthreads();  // every read of this chunk (and of ids[c-1]) happens before any write below
+        s_flag[threadIdx.x] = keep;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t t = 0; t < threadIdx.x; t++) before += s_flag[t];
+        const uint32_t base = s_base;
+        // writes go to positions <= i, and ids[c-1 .. c+255] were already read by this chunk's threads
+        if (keep) ids[base + before] = v;
+        __syncthreads();
+        if (threadIdx.x == 255) s_base = base + before + keep;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[q] = s_base;
+}
+
+__global__ void k_load_items_as_queries(DataView dv, const uint32_t *__restrict__ rows, uint8_t *qvecs, uint64_t qstride,
+                                        float *qhdrs) {
+    const uint32_t q = blockIdx.x;
+    const uint64_t row = rows[q];
+    const size_t words32 = metric_is_bq_dev(dv.metric) ? (size_t)dv.pitch * 2 : dv.pitch;
+    const uint32_t *src = metric_is_bq_dev(dv.metric) ? reinterpret_cast<const uint32_t *>(dv.rows_bq + row * dv.pitch)
+                                                      : reinterpret_cast<const uint32_t *>(dv.rows_f32 + row * dv.pitch);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(qvecs + q * qstride);
+    for (uint32_t i = threadIdx.x; i < words32; i += blockDim.x) dst[i] = src[i];
+    if (threadIdx.x == 0) {
+        const uint32_t hf = dv.metric == AH_DOT_PRODUCT ? 2u : 1u;
+        qhdrs[2 * q] = dv.headers[row * hf];
+        qhdrs[2 * q + 1] = hf == 2 ? dv.headers[row * hf + 1] : 0.0f;
+    }
+}
+
+__global__ void k_filter_bitmap(const uint32_t *__restrict__ ids, uint64_t n, uint32_t *bits) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += stride)
+        atomicOr(&bits[ids[g] >> 5], 1u << (ids[g] & 31));
+}
+
+// normal records [vector (row_bytes)][header (16)] -> row matrix + header array of the normals view
+__global__ void k_unpack_normals(const uint8_t *__restrict__ recs, const uint64_t *__restrict__ offsets, uint32_t n,
+                                 uint64_t vec_off, uint64_t hdr_off, uint32_t row_words32, uint32_t hf,
+                                 uint32_t *__restrict__ rows, float *__restrict__ headers) {
+    const uint32_t r = blockIdx.x;
+    if (r >= n) return;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(recs + offsets[r] + vec_off);
+    for (uint32_t i = threadIdx.x; i < row_words32; i += blockDim.x) rows[(uint64_t)r * row_words32 + i] = src[i];
+    if (threadIdx.x < hf)
+        headers[(uint64_t)r * hf + threadIdx.x] = reinterpret_cast<const float *>(recs + offsets[r] + hdr_off)[threadIdx.x];
+}
+
+}  // namespace ah
+
+using namespace ah;
+
+struct ah_index {
+    ah_dataset *ds = nullptr;
+    DataView nv{};  // the normals as a row matrix
+    DNode *d_nodes = nullptr;
+    uint32_t *d_roots = nullptr, *d_desc = nullptr;
+    void *d_nrows = nullptr;
+    float *d_nhdrs = nullptr;
+    uint32_t n_trees = 0, n_nodes = 0, n_normals = 0, max_desc = 0;
+    uint64_t desc_len = 0;
+};
+
+extern "C" {
+
+int ah_index_destroy(ah_index *ix) {
+    if (!ix) return AH_OK;
+    if (ix->ds) (void)hipSetDevice(ix->ds->device);
+    (void)hipDeviceSynchronize();
+    if (ix->d_nodes) (void)hipFree(ix->d_nodes);
+    if (ix->d_roots) (void)hipFree(ix->d_roots);
+    if (ix->d_desc) (void)hipFree(ix->d_desc);
+    if (ix->d_nrows) (void)hipFree(ix->d_nrows);
+    if (ix->d_nhdrs) (void)hipFree(ix->d_nhdrs);
+    delete ix;
+    return AH_OK;
+}
+
+// Mirror a forest in HBM next to its dataset.  The forest handle may be destroyed afterwards.
+int ah_index_create(ah_dataset *ds, const ah_forest *forest, ah_index **out) {
+    AH_REQUIRE(out, AH_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    AH_REQUIRE(ds && forest, AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    AH_REQUIRE(ds->finalized, AH_ERR_NOT_FINALIZED, "dataset not finalized");
+    ah_forest_view v;
+    AH_TRY(ah_forest_view_get(forest, &v));
+    AH_REQUIRE(v.descendants_len < 0xFFFFFFFFull && v.n_nodes < 0xFFFFFFFFull, AH_ERR_INVALID_ARGUMENT,
+               "forest too large for 32-bit node / descendant offsets");
+    AH_HIP(hipSetDevice(ds->device));
+    ah_index *ix = new (std::nothrow) ah_index();
+    AH_REQUIRE(ix, AH_ERR_OUT_OF_MEMORY, "host allocation failed");
+    ix->ds = ds;
+    ix->n_trees = v.n_trees;
+    ix->n_nodes = (uint32_t)v.n_nodes;
+    ix->desc_len = v.descendants_len;
+    std::vector<DNode> nodes(v.n_nodes);
+    std::vector<uint64_t> offsets;
+    for (uint64_t i = 0; i < v.n_nodes; i++) {
+        const ah_node &nd = v.nodes[i];
+        DNode d{};
+        d.kind = nd.kind;
+        if (nd.kind == AH_NODE_SPLIT) {
+            d.a = nd.left;
+            d.b = nd.right;
+            if (nd.has_normal) {
+                d.kind |= 0x100u;
+                d.c = (uint32_t)offsets.size();
+                offsets.push_back(nd.offset);
+            }
+        } else {
+            d.a = (uint32_t)nd.offset;
+            d.b = nd.count;
+            ix->max_desc = std::max(ix->max_desc, nd.count);
+        }
+        nodes[i] = d;
+    }
+    ix->n_normals = (uint32_t)offsets.size();
+    const bool bq = metric_is_bq(ds->metric);
+    const uint32_t hf = header_floats(ds->metric);
+    const size_t row_bytes = ds->row_bytes();
+    int st = AH_OK;
+    auto fail = [&](int code) {
+        ah_index_destroy(ix);
+        return code;
+    };
+#define AH_IX(expr)                                                                        \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            set_error("%s failed: %s", #expr, hipGetErrorString(_e));                      \
+            return fail(_e == hipErrorOutOfMemory ? AH_ERR_OUT_OF_MEMORY : AH_ERR_DEVICE); \
+        }                                                                                  \
+    } while (0)
+    AH_IX(hipMalloc((void **)&ix->d_nodes, std::max<size_t>(1, nodes.size()) * sizeof(DNode)));
+    AH_IX(hipMalloc((void **)&ix->d_roots, std::max<size_t>(1, v.n_trees) * 4));
+    AH_IX(hipMalloc((void **)&ix->d_desc, std::max<uint64_t>(1, v.descendants_len) * 4));
+    AH_IX(hipMalloc(&ix->d_nrows, std::max<size_t>(1, ix->n_normals) * row_bytes));
+    AH_IX(hipMalloc((void **)&ix->d_nhdrs, std::max<size_t>(1, ix->n_normals) * hf * 4));
+    if (!nodes.empty()) AH_IX(hipMemcpy(ix->d_nodes, nodes.data(), nodes.size() * sizeof(DNode), hipMemcpyHostToDevice));
+    if (v.n_trees) AH_IX(hipMemcpy(ix->d_roots, v.roots, v.n_trees * 4, hipMemcpyHostToDevice));
+    if (v.descendants_len)
+        AH_IX(hipMemcpy(ix->d_desc, v.descendants, v.descendants_len * 4, hipMemcpyHostToDevice));
+    if (ix->n_normals) {
+        uint8_t *d_recs = nullptr;
+        uint64_t *d_offs = nullptr;
+        AH_IX(hipMalloc((void **)&d_recs, v.normals_len));
+        AH_IX(hipMalloc((void **)&d_offs, offsets.size() * 8));
+        AH_IX(hipMemcpy(d_recs, v.normals, v.normals_len, hipMemcpyHostToDevice));
+        AH_IX(hipMemcpy(d_offs, offsets.data(), offsets.size() * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_unpack_normals, dim3(ix->n_normals), dim3(256), 0, 0, d_recs, d_offs, ix->n_normals,
+                           v.normal_vector_offset, v.normal_header_offset, (uint32_t)(row_bytes / 4), hf,
+                           reinterpret_cast<uint32_t *>(ix->d_nrows), ix->d_nhdrs);
+        AH_IX(hipDeviceSynchronize());
+        (void)hipFree(d_recs);
+        (void)hipFree(d_offs);
+    }
+#undef AH_IX
+    (void)st;
+    ix->nv.metric = ds->metric;
+    ix->nv.dims = ds->dims;
+    ix->nv.pitch = ds->pitch;
+    ix->nv.words = ds->words;
+    ix->nv.n = ix->n_normals;
+    ix->nv.rows_f32 = bq ? nullptr : reinterpret_cast<const float *>(ix->d_nrows);
+    ix->nv.rows_bq = bq ? reinterpret_cast<const uint64_t *>(ix->d_nrows) : nullptr;
+    ix->nv.headers = ix->d_nhdrs;
+    ix->nv.ids = nullptr;
+    ix->nv.lut = nullptr;
+    ix->nv.lut_len = 0;
+    ix->nv.identity_ids = 1;
+    *out = ix;
+    return AH_OK;
+}
+
+struct HostSeg2 {
+    uint64_t off;
+    uint32_t n, k;
+};
+struct HostTile2 {
+    uint32_t query, first;
+};
+
+static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const uint32_t *query_rows, size_t nq,
+                        size_t count, uint32_t search_k, uint32_t nns_stride, const uint32_t *d_filter_bits,
+                        uint32_t filter_len_bits, uint32_t *out_ids, float *out_dists, uint32_t *out_counts) {
+    ah_dataset *ds = ix->ds;
+    hipStream_t s = ctx->stream;
+    const size_t qstride = (ds->row_bytes() + 255) & ~(size_t)255;
+    const size_t k = count;
+    // device scratch (one carve for the whole chunk)
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const uint32_t max_tiles_bound = (uint32_t)(nq * ((size_t)nns_stride / batch_tile_candidates() + 1));
+    const size_t kstride = batch_key_stride(nns_stride);
+    const uint32_t heap_cap = ix->n_nodes + ix->n_trees + 2;
+    size_t dev_bytes = pad(nq * (size_t)ds->dims * 4) + pad(nq * 4) + nq * qstride + pad(nq * 8) + pad(nq * (size_t)nns_stride * 4) * 2 +
+                       pad(nq * 4) * 3 + pad(nq * sizeof(HostSeg2)) + pad((size_t)max_tiles_bound * sizeof(HostTile2)) +
+                       2 * pad(nq * kstride * 8) + pad(nq * k * 4) * 2 + 4096;
+    AH_TRY(ctx->ensure_device(dev_bytes));
+    const size_t pin_bytes = pad(nq * (size_t)ds->dims * 4) + pad(nq * 4) * 4 + pad(nq * sizeof(HostSeg2)) +
+                             pad((size_t)max_tiles_bound * sizeof(HostTile2)) + pad(nq * k * 4) * 2 + 4096;
+    AH_TRY(ctx->ensure_pinned(pin_bytes));
+    uint8_t *dbase = reinterpret_cast<uint8_t *>(ctx->d_scratch);
+    size_t doff = 0;
+    auto dtake = [&](size_t bytes) {
+        void *p = dbase + doff;
+        doff += pad(bytes);
+        return p;
+    };
+    uint8_t *pbase = reinterpret_cast<uint8_t *>(ctx->h_pinned);
+    size_t poff = 0;
+    auto ptake = [&](size_t bytes) {
+        void *p = pbase + poff;
+        poff += pad(bytes);
+        return p;
+    };
+    float *d_qf32 = (float *)dtake(nq * (size_t)ds->dims * 4);
+    uint32_t *d_qrows = (uint32_t *)dtake(nq * 4);
+    uint8_t *d_qvecs = (uint8_t *)dtake(nq * qstride);
+    float *d_qhdrs = (float *)dtake(nq * 8);
+    uint32_t *d_nns = (uint32_t *)dtake(nq * (size_t)nns_stride * 4);
+    float *d_dist = (float *)dtake(nq * (size_t)nns_stride * 4);
+    uint32_t *d_counts = (uint32_t *)dtake(nq * 4);
+    uint32_t *d_overflow = (uint32_t *)dtake(nq * 4);
+    uint32_t *d_list = (uint32_t *)dtake(nq * 4);
+    HostSeg2 *d_segs = (HostSeg2 *)dtake(nq * sizeof(HostSeg2));
+    HostTile2 *d_tiles = (HostTile2 *)dtake((size_t)max_tiles_bound * sizeof(HostTile2));
+    uint64_t *d_ka = (uint64_t *)dtake(nq * kstride * 8);
+    uint64_t *d_kb = (uint64_t *)dtake(nq * kstride * 8);
+    uint32_t *d_oi = (uint32_t *)dtake(nq * k * 4);
+    float *d_od = (float *)dtake(nq * k * 4);
+    uint32_t *d_err = (uint32_t *)dtake(4);
+    float *h_q = (float *)ptake(nq * (size_t)ds->dims * 4);
+    uint32_t *h_qrows = (uint32_t *)ptake(nq * 4);
+    uint32_t *h_counts = (uint32_t *)ptake(nq * 4);
+    uint32_t *h_overflow = (uint32_t *)ptake(nq * 4);
+    uint32_t *h_list = (uint32_t *)ptake(nq * 4);
+    HostSeg2 *h_segs = (HostSeg2 *)ptake(nq * sizeof(HostSeg2));
+    HostTile2 *h_tiles = (HostTile2 *)ptake((size_t)max_tiles_bound * sizeof(HostTile2));
+    uint32_t *h_oi = (uint32_t *)ptake(nq * k * 4);
+    float *h_od = (float *)ptake(nq * k * 4);
+    uint32_t *h_err = (uint32_t *)ptake(4);
+
+    const DataView dv = ds->view();
+    // 1. query leaves (src/reader.rs:46-51 by_item, :64-75 by_vector)
+    if (queries) {
+        memcpy(h_q, queries, nq * (size_t)ds->dims * 4);
+        AH_HIP(hipMemcpyAsync(d_qf32, h_q, nq * (size_t)ds->dims * 4, hipMemcpyHostToDevice, s));
+    } else {
+        memcpy(h_qrows, query_rows, nq * 4);
+        AH_HIP(hipMemcpyAsync(d_qrows, h_qrows, nq * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_load_items_as_queries, dim3((unsigned)nq), dim3(64), 0, s, dv, d_qrows, d_qvecs, qstride, d_qhdrs);
+    }
+    AH_HIP(hipMemsetAsync(d_err, 0, 4, s));
+    // (by_vector leaves are prepared by the batch launcher below; the descent needs them first)
+    SearchParams sp{};
+    sp.nodes = ix->d_nodes;
+    sp.roots = ix->d_roots;
+    sp.n_trees = ix->n_trees;
+    sp.desc = ix->d_desc;
+    sp.filter_bits = d_filter_bits;
+    sp.filter_len_bits = filter_len_bits;
+    sp.search_k = search_k;
+    sp.nns_stride = nns_stride;
+    if (queries) AH_TRY(launch_prepare_queries_only(dv, d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
+    // 2. descent, queue in LDS
+    const size_t heap_lds = (size_t)8 * kHeapLds * 8;
+    AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_descend<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)heap_lds));
+    hipLaunchKernelGGL((k_descend<false>), dim3((unsigned)((nq + 7) / 8)), dim3(64), heap_lds, s, ix->nv, sp,
+                       (const uint32_t *)nullptr, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow,
+                       (uint64_t *)nullptr, 0u);
+    AH_HIP(hipMemcpyAsync(h_overflow, d_overflow, nq * 4, hipMemcpyDeviceToHost, s));
+    AH_HIP(hipStreamSynchronize(s));
+    uint32_t n_over = 0;
+    for (size_t q = 0; q < nq; q++)
+        if (h_overflow[q]) h_list[n_over++] = (uint32_t)q;
+    if (n_over) {  // 2b. the rare big queues: re-run with the queue in global memory (hard capacity bound)
+        uint64_t *d_heap = nullptr;
+        AH_HIP(hipMalloc((void **)&d_heap, (size_t)n_over * heap_cap * 8));
+        AH_HIP(hipMemcpyAsync(d_list, h_list, n_over * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL((k_descend<true>), dim3((n_over + 7) / 8), dim3(64), 0, s, ix->nv, sp, (const uint32_t *)d_list,
+                           n_over, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, d_heap, heap_cap);
+        hipError_t e = hipStreamSynchronize(s);
+        (void)hipFree(d_heap);
+        AH_HIP(e);
+    }
+    // 3. sort + dedup
+    AH_HIP(hipMemcpyAsync(h_counts, d_counts, nq * 4, hipMemcpyDeviceToHost, s));
+    AH_HIP(hipStreamSynchronize(s));
+    uint32_t max_nn = 0;
+    for (size_t q = 0; q < nq; q++) max_nn = std::max(max_nn, h_counts[q]);
+    if (max_nn <= kSortLds) {
+        uint32_t np2 = 2;
+        while (np2 < max_nn) np2 <<= 1;
+        const size_t sh = (size_t)np2 * 4;
+        if (sh > 48 * 1024)
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sort_dedup_lds),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL(k_sort_dedup_lds, dim3((unsigned)nq), dim3(256), sh, s, d_nns, nns_stride, d_counts);
+    } else {
+        uint32_t np2 = 2;
+        while (np2 < max_nn) np2 <<= 1;
+        // the stride was sized to the next power of two by the caller when this path is possible
+        AH_REQUIRE(np2 <= nns_stride, AH_ERR_DEVICE, "internal: candidate stride %u < %u", nns_stride, np2);
+        hipLaunchKernelGGL(k_pad_ids, dim3((np2 + 255) / 256, (unsigned)nq), dim3(256), 0, s, d_nns, nns_stride, d_counts, np2);
+        for (uint32_t size = 2; size <= np2; size <<= 1)
+            for (uint32_t str = size >> 1; str > 0; str >>= 1)
+                hipLaunchKernelGGL(k_bitonic_ids, dim3(((np2 >> 1) + 255) / 256, (unsigned)nq), dim3(256), 0, s, d_nns,
+                                   nns_stride, np2, size, str);
+        hipLaunchKernelGGL(k_dedup_sorted, dim3((unsigned)nq), dim3(256), 0, s, d_nns, nns_stride, d_counts);
+    }
+    AH_HIP(hipMemcpyAsync(h_counts, d_counts, nq * 4, hipMemcpyDeviceToHost, s));
+    AH_HIP(hipStreamSynchronize(s));
+    // 4. re-rank + top-k + normalized distances (batch.hip), candidates already resident
+    uint32_t n_tiles = 0, max_n = 0, max_rounds = 0;
+    const uint32_t tc = batch_tile_candidates();
+    for (size_t q = 0; q < nq; q++) {
+        const uint32_t n = h_counts[q];
+        h_segs[q] = HostSeg2{(uint64_t)q * nns_stride, n, (uint32_t)std::min<size_t>(k, n)};
+        out_counts[q] = h_segs[q].k;
+        max_n = std::max(max_n, n);
+        max_rounds = std::max(max_rounds, batch_rounds(n, h_segs[q].k));
+        for (uint32_t f = 0; f < n; f += tc) h_tiles[n_tiles++] = HostTile2{(uint32_t)q, f};
+    }
+    AH_HIP(hipMemcpyAsync(d_segs, h_segs, nq * sizeof(HostSeg2), hipMemcpyHostToDevice, s));
+    if (n_tiles) AH_HIP(hipMemcpyAsync(d_tiles, h_tiles, (size_t)n_tiles * sizeof(HostTile2), hipMemcpyHostToDevice, s));
+    AH_TRY(launch_rerank_batch_prepared(dv, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, n_tiles, d_nns, d_dist,
+                                        d_ka, d_kb, kstride, max_n, (uint32_t)k, max_rounds, d_oi, d_od, d_err, s));
+    AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
+    AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
+    AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
+    AH_HIP(hipStreamSynchronize(s));
+    AH_REQUIRE((*h_err & 1u) == 0, AH_ERR_MISSING_ITEM, "a descendant id does not exist in the dataset");
+    memcpy(out_ids, h_oi, nq * k * 4);
+    memcpy(out_dists, h_od, nq * k * 4);
+    return AH_OK;
+}
+
+// `QueryBuilder::{by_vector, by_item}` for a batch (src/reader.rs:46-75, 317-401).
+//   queries      nq x dims f32 (by_vector), or NULL with query_items = nq item ids (by_item)
+//   search_k     0 = count * n_trees (reader.rs:330); oversampling 0 = D::DEFAULT_OVERSAMPLING (1, or 3 for 1-bit)
+//   filter       optional ascending candidate ids (`QueryBuilder::candidates`)
+// Outputs are nq x count, short lists padded with id 0xFFFFFFFF / NaN; out_counts[q] = results of query q.
+int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_items, size_t nq, size_t count,
+                    size_t search_k, size_t oversampling, const uint32_t *filter_sorted, size_t n_filter, int have_filter,
+                    uint32_t *out_ids, float *out_distances, uint32_t *out_counts) {
+    AH_REQUIRE(ix && ix->ds, AH_ERR_INVALID_ARGUMENT, "index is NULL");
+    ah_dataset *ds = ix->ds;
+    AH_REQUIRE((queries != nullptr) != (query_items != nullptr), AH_ERR_INVALID_ARGUMENT,
+               "exactly one of queries / query_items must be given");
+    AH_REQUIRE(out_ids && out_distances && out_counts, AH_ERR_INVALID_ARGUMENT, "NULL output");
+    if (nq == 0) return AH_OK;
+    AH_REQUIRE(count > 0 && batch_supported((uint32_t)std::min<size_t>(count, 0xFFFFFFFFu)), AH_ERR_INVALID_ARGUMENT,
+               "count must be in 1..=2048 for the batched search");
+    AH_HIP(hipSetDevice(ds->device));
+    for (size_t i = 0; i < nq * count; i++) {
+        out_ids[i] = 0xFFFFFFFFu;
+        const uint32_t nan_bits = 0xFFFFFFFFu;
+        memcpy(&out_distances[i], &nan_bits, 4);
+    }
+    for (size_t q = 0; q < nq; q++) out_counts[q] = 0;
+    if (ds->n == 0 || ix->n_trees == 0) return AH_OK;  // reader.rs:323-325
+    // search_k: reader.rs:330-335; nns can never exceed the blob (every Descendants node is popped at most once)
+    unsigned __int128 sk = search_k ? (unsigned __int128)search_k : (unsigned __int128)count * ix->n_trees;
+    sk *= oversampling ? oversampling : (metric_is_bq(ds->metric) ? 3u : 1u);
+    const uint64_t sk_eff = (uint64_t)std::min<unsigned __int128>(sk, (unsigned __int128)ix->desc_len);
+    uint64_t stride = std::min<uint64_t>(sk_eff + ix->max_desc, ix->desc_len);
+    if (stride > kSortLds) {  // the global sort path pads to a power of two
+        uint64_t p = 2;
+        while (p < stride) p <<= 1;
+        stride = p;
+    }
+    AH_REQUIRE(stride < 0x7FFFFFFFull, AH_ERR_INVALID_ARGUMENT, "search_k too large");
+    std::vector<uint32_t> rows;
+    if (query_items) {
+        rows.resize(nq);
+        for (size_t q = 0; q < nq; q++) {
+            if (ds->identity_ids) {
+                AH_REQUIRE(query_items[q] < ds->n, AH_ERR_MISSING_ITEM, "item %u does not exist", query_items[q]);
+                rows[q] = query_items[q];
+            } else {
+                auto it = std::lower_bound(ds->h_ids.begin(), ds->h_ids.end(), query_items[q]);
+                AH_REQUIRE(it != ds->h_ids.end() && *it == query_items[q], AH_ERR_MISSING_ITEM, "item %u does not exist",
+                           query_items[q]);
+                rows[q] = (uint32_t)(it - ds->h_ids.begin());
+            }
+        }
+    }
+    ContextLease lease(ds);
+    AH_REQUIRE(lease.c, AH_ERR_DEVICE, "cannot create a HIP stream");
+    Context *ctx = lease.c;
+    // candidate filter -> bitmap over item ids
+    uint32_t *d_bits = nullptr;
+    uint32_t bits_len = 0;
+    if (have_filter) {
+        const uint32_t max_id = ds->identity_ids ? (uint32_t)(ds->n - 1) : ds->last_id;
+        bits_len = max_id + 1;
+        const size_t words = ((size_t)bits_len + 31) / 32;
+        AH_HIP(hipMalloc((void **)&d_bits, words * 4));
+        AH_HIP(hipMemsetAsync(d_bits, 0, words * 4, ctx->stream));
+        std::vector<uint32_t> keep;
+        for (size_t i = 0; i < n_filter; i++)
+            if (filter_sorted[i] <= max_id) keep.push_back(filter_sorted[i]);
+        if (!keep.empty()) {
+            uint32_t *d_f = nullptr;
+            AH_HIP(hipMalloc((void **)&d_f, keep.size() * 4));
+            AH_HIP(hipMemcpyAsync(d_f, keep.data(), keep.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_filter_bitmap, dim3(256), dim3(256), 0, ctx->stream, d_f, (uint64_t)keep.size(), d_bits);
+            AH_HIP(hipStreamSynchronize(ctx->stream));
+            (void)hipFree(d_f);
+        }
+    }
+    // sub-batches bounded by scratch (~1.5 GiB of candidate buffers)
+    const size_t per_query = (size_t)stride * 8 + 2 * batch_key_stride((uint32_t)stride) * 8 + ds->row_bytes() + 4096;
+    size_t chunk = std::max<size_t>(1, std::min<size_t>(nq, (1536ull << 20) / per_query));
+    chunk = std::min<size_t>(chunk, 4096);
+    int st = AH_OK;
+    for (size_t q0 = 0; q0 < nq && st == AH_OK; q0 += chunk) {
+        const size_t c = std::min(chunk, nq - q0);
+        st = search_chunk(ix, ctx, queries ? queries + q0 * (size_t)ds->dims : nullptr, query_items ? rows.data() + q0 : nullptr,
+                          c, count, (uint32_t)sk_eff, (uint32_t)stride, d_bits, bits_len, out_ids + q0 * count,
+                          out_distances + q0 * count, out_counts + q0);
+    }
+    if (d_bits) (void)hipFree(d_bits);
+    return st;
+}
+
+}  // extern "C"

@@ -185,6 +185,10 @@ class Dataset:
         _lib.check(_lib.lib().ah_build_forest(self._h, C.byref(opt), C.byref(h)))
         return Forest(h, self.distance, self.dimensions)
 
+    def create_index(self, forest: "Forest") -> "Index":
+        """Mirror `forest` in HBM next to this dataset (ah_index_create)."""
+        return Index(self, forest)
+
     # -- measurement -------------------------------------------------------------------------------
     def bench_scan(self, query_item: int, n: int, iterations: int, want_out: bool = False):
         out = np.zeros(n, dtype=np.float32) if want_out else None
@@ -203,6 +207,50 @@ class Dataset:
     def close(self) -> None:
         if self._h:
             _lib.lib().ah_dataset_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Index:
+    """Dataset + forest resident in HBM: the whole `Reader::nns_by_leaf` runs on device (ah_search_batch)."""
+
+    def __init__(self, dataset: Dataset, forest: "Forest"):
+        self.dataset = dataset
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().ah_index_create(dataset._h, forest._h, C.byref(self._h)))
+
+    def search(self, count: int, queries=None, items=None, search_k: int = 0, oversampling: int = 0, candidates=None):
+        """Batch of `QueryBuilder::by_vector` (queries: nq x dims) or `by_item` (items: nq ids).
+        Returns a list (one entry per query) of [(id, distance), ...]."""
+        ds = self.dataset
+        if queries is not None:
+            q = _f32(queries)
+            if q.ndim == 1:
+                q = q[None, :]
+            if q.shape[1] != ds.dimensions:
+                raise _lib.InvalidVecDimension(1, f"Invalid vector dimensions. Got {q.shape[1]} but expected "
+                                                  f"{ds.dimensions}")
+            nq, it = q.shape[0], None
+        else:
+            it = _u32(items).ravel()
+            nq, q = it.size, None
+        filt = None if candidates is None else _u32(sorted(set(int(c) for c in candidates)))
+        oi = np.zeros((nq, count), dtype=np.uint32)
+        od = np.zeros((nq, count), dtype=np.float32)
+        oc = np.zeros(nq, dtype=np.uint32)
+        _lib.check(_lib.lib().ah_search_batch(self._h, _ptr(q), _ptr(it), nq, int(count), int(min(search_k, 2**62)),
+                                              int(oversampling), _ptr(filt), 0 if filt is None else filt.size,
+                                              0 if filt is None else 1, _ptr(oi), _ptr(od), _ptr(oc)))
+        return [[(int(oi[i, j]), float(od[i, j])) for j in range(int(oc[i]))] for i in range(nq)]
+
+    def close(self) -> None:
+        if self._h:
+            _lib.lib().ah_index_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -243,6 +243,28 @@ AH_API int ah_forest_visit(const ah_forest *forest, ah_node_sink_fn sink, void *
 AH_API int ah_forest_destroy(ah_forest *forest);
 
 /* ------------------------------------------------------------------------------------------
+ * Whole search on device (src/reader.rs:317-401): the forest mirrored in HBM next to its dataset, best-first
+ * descent + candidate collection + sort/dedup + re-rank + top-k for a batch of queries in one call.
+ * Node identity (the tie-break of the reference's BinaryHeap<(OrderedFloat<f32>, NodeId)>) is the forest-local
+ * node index; a host that hands out global node ids in that same order (children before parents, as
+ * INTEGRATION.md does) preserves every tie-break.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ah_index ah_index;
+
+/* Upload the forest (nodes, split-plane normals, descendants) to the dataset's device.  The ah_forest may be
+ * destroyed afterwards; the dataset must outlive the index. */
+AH_API int ah_index_create(ah_dataset *ds, const ah_forest *forest, ah_index **out);
+AH_API int ah_index_destroy(ah_index *index);
+
+/* `QueryBuilder::by_vector` (queries = nq x dims f32, query_items = NULL) or `by_item` (queries = NULL,
+ * query_items = nq ids) with `search_k` (0 = count * n_trees, src/reader.rs:330), `oversampling`
+ * (0 = D::DEFAULT_OVERSAMPLING) and optional `candidates` (have_filter != 0: ascending ids).
+ * count <= 2048.  Outputs nq x count, padded with id 0xFFFFFFFF / NaN; out_counts[q] = results of query q. */
+AH_API int ah_search_batch(ah_index *index, const float *queries, const uint32_t *query_items, size_t nq, size_t count,
+                           size_t search_k, size_t oversampling, const uint32_t *filter_sorted, size_t n_filter,
+                           int have_filter, uint32_t *out_ids, float *out_distances, uint32_t *out_counts);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py).  They time with hipEvents recorded on the same stream the
  * kernels run on and never touch the host data path.
  * ---------------------------------------------------------------------------------------- */

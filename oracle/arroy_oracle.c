@@ -872,7 +872,9 @@ AO_API void ao_tree_view(const ao_tree *t, ah_forest_view *v, uint32_t *root_out
     v->n_nodes = t->n_nodes;
     v->nodes = t->nodes;
     v->normals = t->normals;
-    v->normals_len = t->normals_len; /* oracle records are [header][vector]; offsets are filled in by the caller */
+    v->normals_len = t->normals_len; /* oracle records are [header][vector] */
+    v->normal_header_offset = 0;
+    v->normal_vector_offset = 0; /* set by ao_tree_view_for(metric) below when the metric is known */
     v->descendants = t->desc;
     v->descendants_len = t->desc_len;
     *root_out = t->root;
@@ -1166,4 +1168,125 @@ AO_API void ao_ref_tree_free(ao_ref_tree *t) {
     free(t->normals);
     free(t->desc);
     free(t);
+}
+
+/* =======================================================================================
+ * Reader::nns_by_leaf, src/reader.rs:317-401, over a forest given as an ah_forest_view: the best-first
+ * descent (BinaryHeap of (OrderedFloat(distance), NodeId), all roots at +inf), candidate collection,
+ * sort + dedup, re-rank, top-k, normalized_distance.  Node identity = index in `view->nodes` (the
+ * reference's NodeId::tree(id); ties in the queue are broken by it exactly as the derived Ord does).
+ * ===================================================================================== */
+typedef struct heap_ent {
+    float d;
+    uint32_t node;
+} heap_ent;
+static int heap_less(heap_ent a, heap_ent b) { /* a < b in (OrderedFloat, NodeId) order */
+    int c = of_cmp(a.d, b.d);
+    if (c) return c < 0;
+    return a.node < b.node;
+}
+static void heap_push(heap_ent **h, size_t *n, size_t *cap, heap_ent e) {
+    if (*n == *cap) {
+        *cap = *cap ? 2 * *cap : 64;
+        *h = (heap_ent *)realloc(*h, *cap * sizeof(heap_ent));
+    }
+    size_t i = (*n)++;
+    (*h)[i] = e;
+    while (i > 0) {
+        size_t p = (i - 1) / 2;
+        if (!heap_less((*h)[p], (*h)[i])) break;
+        heap_ent t = (*h)[p]; (*h)[p] = (*h)[i]; (*h)[i] = t;
+        i = p;
+    }
+}
+static heap_ent heap_pop(heap_ent *h, size_t *n) {
+    heap_ent top = h[0];
+    h[0] = h[--(*n)];
+    size_t i = 0;
+    for (;;) {
+        size_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < *n && heap_less(h[m], h[l])) m = l;
+        if (r < *n && heap_less(h[m], h[r])) m = r;
+        if (m == i) break;
+        heap_ent t = h[m]; h[m] = h[i]; h[i] = t;
+        i = m;
+    }
+    return top;
+}
+static int u32_cmp(const void *a, const void *b) {
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return (x > y) - (x < y);
+}
+static int sorted_contains(const uint32_t *a, size_t n, uint32_t x) {
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        size_t mid = (lo + hi) / 2;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo < n && a[lo] == x;
+}
+
+/* Returns the number of results; if out_cand != NULL also returns the sorted, de-duplicated candidate ids
+ * (at most cand_cap of them) and their count in *out_n_cand. */
+AO_API size_t ao_search(const ao_data *d, const ah_forest_view *f, const void *qv, const float *qh, size_t count,
+                        size_t search_k, size_t oversampling, const uint32_t *filter_sorted, size_t n_filter,
+                        int have_filter, uint32_t *out_ids, float *out_dists, uint32_t *out_cand, size_t cand_cap,
+                        size_t *out_n_cand) {
+    if (out_n_cand) *out_n_cand = 0;
+    if (d->n == 0) return 0; /* reader.rs:323-325 */
+    size_t sk = search_k ? search_k : count * (size_t)f->n_trees; /* :330 */
+    size_t os = oversampling ? oversampling : (is_bq(d->metric) ? 3 : 1); /* DEFAULT_OVERSAMPLING, :331-335 */
+    sk = sk * os;
+    heap_ent *heap = NULL;
+    size_t hn = 0, hcap = 0;
+    for (uint32_t t = 0; t < f->n_trees; t++) heap_push(&heap, &hn, &hcap, (heap_ent){INFINITY, f->roots[t]});
+    uint32_t *nns = NULL;
+    size_t nn = 0, ncap = 0;
+    size_t hs = ao_header_floats(d->metric) * 4;
+    while (nn < sk && hn > 0) { /* :341-374 */
+        heap_ent top = heap_pop(heap, &hn);
+        const ah_node *nd = &f->nodes[top.node];
+        if (nd->kind == AH_NODE_DESCENDANTS) {
+            const uint32_t *ids = f->descendants + nd->offset;
+            if (nn + nd->count > ncap) {
+                ncap = (nn + nd->count) * 2 + 64;
+                nns = (uint32_t *)realloc(nns, ncap * sizeof(uint32_t));
+            }
+            for (uint32_t i = 0; i < nd->count; i++)
+                if (!have_filter || sorted_contains(filter_sorted, n_filter, ids[i])) nns[nn++] = ids[i];
+        } else {
+            float margin = 0.0f; /* `None => 0.0`, :366-369 */
+            if (nd->has_normal) {
+                const uint8_t *rec = f->normals + nd->offset;
+                float nh[2] = {0, 0};
+                memcpy(nh, rec + f->normal_header_offset, hs);
+                margin = ao_margin(d->metric, rec + f->normal_vector_offset, nh, qv, qh, d->dims);
+            }
+            heap_push(&heap, &hn, &hcap, (heap_ent){ao_pq_distance(top.d, margin, 0), nd->left});
+            heap_push(&heap, &hn, &hcap, (heap_ent){ao_pq_distance(top.d, margin, 1), nd->right});
+        }
+    }
+    free(heap);
+    qsort(nns, nn, sizeof(uint32_t), u32_cmp); /* sort_unstable + dedup, :378-379 */
+    size_t u = 0;
+    for (size_t i = 0; i < nn; i++)
+        if (u == 0 || nns[i] != nns[u - 1]) nns[u++] = nns[i];
+    if (out_cand) {
+        for (size_t i = 0; i < u && i < cand_cap; i++) out_cand[i] = nns[i];
+        if (out_n_cand) *out_n_cand = u;
+    }
+    /* ids -> rows */
+    uint32_t *rows = (uint32_t *)malloc(sizeof(uint32_t) * (u ? u : 1));
+    for (size_t i = 0; i < u; i++) {
+        if (!d->ids) rows[i] = nns[i];
+        else {
+            size_t lo = 0, hi = d->n;
+            while (lo < hi) { size_t mid = (lo + hi) / 2; if (d->ids[mid] < nns[i]) lo = mid + 1; else hi = mid; }
+            rows[i] = (uint32_t)lo;
+        }
+    }
+    size_t m = u ? ao_rerank(d, qv, qh, rows, u, count, out_ids, out_dists) : 0;
+    free(rows);
+    free(nns);
+    return m;
 }

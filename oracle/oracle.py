@@ -139,6 +139,10 @@ def lib() -> C.CDLL:
         L.ao_rng_gen_range_inclusive_u32.restype = C.c_uint32
         L.ao_rng_gen_range_inclusive_u32.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.ao_rng_index_sample2.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.ao_search.restype = C.c_size_t
+        L.ao_search.argtypes = [C.POINTER(AoData), C.POINTER(AhForestView), C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                C.POINTER(C.c_size_t)]
         L.ao_num_threads.restype = C.c_int
         L.ao_set_num_threads.argtypes = [C.c_int]
         _lib = L
@@ -324,6 +328,20 @@ class Tree:
         self.stride = 4 * header_floats(data.metric) + vector_bytes(data.metric, data.dims)
         L.ao_tree_free(h)
 
+    def as_forest(self, data: "Data"):
+        """The tree as a one-tree forest object with the attributes `search()` / `forest_view()` expect."""
+        node_dt = np.dtype([("kind", "u1"), ("has_normal", "u1"), ("tree", "<u2"), ("left", "<u4"), ("right", "<u4"),
+                            ("offset", "<u8"), ("count", "<u4"), ("depth", "<u4")], align=True)
+        f = type("OracleForest", (), {})()
+        f.n_trees = 1
+        f.roots = np.array([self.root], dtype=np.uint32)
+        f.nodes = np.array([(k, hn, 0, l, r, off, cnt, dep) for (k, hn, l, r, off, cnt, dep) in self.nodes], dtype=node_dt)
+        f.normals = np.frombuffer(self.normals, dtype=np.uint8).copy() if self.normals else np.zeros(0, np.uint8)
+        f.normal_stride = self.stride
+        f._hdr_off, f._vec_off = 0, 4 * header_floats(data.metric)
+        f.descendants = np.ascontiguousarray(self.descendants, dtype=np.uint32)
+        return f
+
     def canonical(self, node=None):
         """Structure independent of node numbering: nested tuples."""
         import sys
@@ -395,3 +413,37 @@ def build_tree_reference_order(data: "Data", split_after: int, seed: bytes = byt
             out[int(nd.id)] = ("S", int(nd.left), int(nd.right), hdr, raw[hs:] if nd.has_normal else None)
     L.ao_ref_tree_free(h)
     return out
+
+
+def forest_view(forest) -> "AhForestView":
+    """An ah_forest_view over the numpy arrays of an arroy_amd.Forest (the arrays must stay alive)."""
+    v = AhForestView()
+    v.n_trees = forest.n_trees
+    v.n_nodes = len(forest.nodes)
+    v.roots = forest.roots.ctypes.data_as(C.POINTER(C.c_uint32))
+    v.nodes = C.cast(forest.nodes.ctypes.data, C.POINTER(AhNode))
+    v.normals = forest.normals.ctypes.data_as(C.POINTER(C.c_uint8)) if forest.normals.size else None
+    v.normals_len = forest.normals.size
+    v.normal_stride = forest.normal_stride
+    v.normal_vector_offset = forest._vec_off
+    v.normal_header_offset = forest._hdr_off
+    v.descendants = forest.descendants.ctypes.data_as(C.POINTER(C.c_uint32)) if forest.descendants.size else None
+    v.descendants_len = forest.descendants.size
+    return v
+
+
+def search(data: "Data", forest, qv, qh, count: int, search_k: int = 0, oversampling: int = 0, candidates=None):
+    """`Reader::nns_by_leaf` (src/reader.rs:317-401) over `forest`; returns ([(id, dist)...], candidate ids)."""
+    view = forest_view(forest)
+    filt = None if candidates is None else np.ascontiguousarray(sorted(set(int(c) for c in candidates)), dtype=np.uint32)
+    oi = np.zeros(max(count, 1), dtype=np.uint32)
+    od = np.zeros(max(count, 1), dtype=np.float32)
+    cap = int(forest.descendants.size) + 1
+    cand = np.zeros(cap, dtype=np.uint32)
+    nc = C.c_size_t(0)
+    qh2 = np.zeros(2, dtype=np.float32)
+    qh2[: len(qh)] = qh
+    m = lib().ao_search(data.c(), C.byref(view), _p(np.ascontiguousarray(qv)), _p(qh2), count, min(search_k, 2**62),
+                        oversampling, None if filt is None else _p(filt), 0 if filt is None else filt.size,
+                        0 if filt is None else 1, _p(oi), _p(od), _p(cand), cap, C.byref(nc))
+    return [(int(oi[i]), float(od[i])) for i in range(m)], cand[: nc.value].copy()

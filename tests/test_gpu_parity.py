@@ -447,3 +447,50 @@ def test_reference_insta_snapshot_through_the_gpu(golden):
         else:
             assert (got[0], got[1], got[2], got[3]) == ("S", want["left"], want["right"], want["bias"]), f"node {k}"
             assert got[4][:10] == want["vector10"], f"normal of tree node {k}"
+
+
+# ---- the whole search on device (src/reader.rs:317-401) vs the oracle's restatement --------------------------
+
+@pytest.mark.parametrize("metric", ALL_METRICS)
+def test_device_search_equals_oracle(metric):
+    cls = D.BY_METRIC[metric]
+    n, dims = 4000, 48
+    ds, oracle, vecs, ids = make_data(cls, n, dims, seed=900 + metric)
+    forest = ds.build_forest([11, 12, 13, 14, 15], split_after=40)
+    index = ds.create_index(forest)
+    rng = np.random.default_rng(metric)
+    queries = rng.standard_normal((24, dims)).astype(np.float32)
+    items = rng.choice(n, 24, replace=False).astype(np.uint32)
+    for count, search_k, over, cand in [(10, 0, 0, None), (5, 300, 0, None), (20, 2500, 2, None), (7, 1, 0, None),
+                                        (10, 2**62, 0, None), (10, 800, 0, range(0, n, 3)), (3, 50, 0, [])]:
+        got_v = index.search(count, queries=queries, search_k=search_k, oversampling=over, candidates=cand)
+        got_i = index.search(count, items=items, search_k=search_k, oversampling=over, candidates=cand)
+        for qi in range(len(queries)):
+            qv, qh = oracle.query_leaf(queries[qi])
+            want, _ = O.search(oracle, forest, qv, qh, count, search_k, over, cand)
+            assert [i for i, _ in got_v[qi]] == [i for i, _ in want], f"by_vector q={qi} {count},{search_k},{over}"
+            assert_bit_equal([d for _, d in got_v[qi]], [d for _, d in want])
+            qv, qh = oracle.item_leaf(int(items[qi]))
+            want, _ = O.search(oracle, forest, qv, qh, count, search_k, over, cand)
+            assert [i for i, _ in got_i[qi]] == [i for i, _ in want], f"by_item q={qi} {count},{search_k},{over}"
+            assert_bit_equal([d for _, d in got_i[qi]], [d for _, d in want])
+
+
+def test_device_search_big_queue_and_big_candidate_sets():
+    """Tiny leaves (split_after=2) and a huge search_k: the queue overflows its LDS slot (re-run with the queue in
+    global memory) and the candidate set exceeds the LDS sort (global bitonic + dedup path)."""
+    n, dims = 30000, 32
+    ds, oracle, vecs, ids = make_data(D.Euclidean, n, dims, seed=31)
+    forest = ds.build_forest([1, 2, 3], split_after=2)
+    index = ds.create_index(forest)
+    queries = np.random.default_rng(1).standard_normal((3, dims)).astype(np.float32)
+    for search_k in (4000, 40000, 2**62):
+        got = index.search(15, queries=queries, search_k=search_k)
+        for qi in range(3):
+            qv, qh = oracle.query_leaf(queries[qi])
+            want, cand = O.search(oracle, forest, qv, qh, 15, search_k)
+            assert [i for i, _ in got[qi]] == [i for i, _ in want]
+            assert_bit_equal([d for _, d in got[qi]], [d for _, d in want])
+    # exhaustive search_k == exact top-k
+    exact_ids, exact_d = ds.rerank(15, query=queries[0])
+    assert [i for i, _ in index.search(15, queries=queries[:1], search_k=2**62)[0]] == list(exact_ids)

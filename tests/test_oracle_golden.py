@@ -227,3 +227,24 @@ def test_target_split_imbalance_formula():
     assert L.ao_split_imbalance(0, 0) == 1.0  # 0/eps = 0 -> max(0, 1)
     assert L.ao_split_imbalance(95, 5) == pytest.approx(0.95)
     assert L.ao_split_imbalance(96, 4) > 0.95
+
+
+# --- Reader::nns_by_leaf restated (src/reader.rs:317-401), on oracle-built trees ---------------------------------
+
+def test_oracle_search_exhaustive_equals_full_rerank_and_respects_search_k():
+    rng = np.random.default_rng(0)
+    for metric in (O.EUCLIDEAN, O.COSINE, O.BQ_COSINE):
+        vecs = rng.standard_normal((600, 24)).astype(np.float32)
+        data = O.Data(metric, vecs)
+        forest = data.build_tree(10, 5).as_forest(data)
+        qv, qh = data.query_leaf(rng.standard_normal(24).astype(np.float32))
+        full, cand = O.search(data, forest, qv, qh, 7, search_k=2**62)
+        ids, d = data.rerank(qv, qh, None, 7)
+        assert [i for i, _ in full] == list(ids) and len(cand) == 600
+        few, cand = O.search(data, forest, qv, qh, 7, search_k=1)   # one leaf: at most split_after candidates
+        assert 0 < len(cand) <= 10 and len(few) == min(7, len(cand))
+        assert [x for x, _ in few] == [int(i) for i in data.rerank(qv, qh, cand, 7)[0]]
+        none, cand = O.search(data, forest, qv, qh, 7, search_k=50, candidates=[])
+        assert none == [] and len(cand) == 0
+        some, cand = O.search(data, forest, qv, qh, 7, search_k=2**62, candidates=range(0, 600, 5))
+        assert set(cand) == set(range(0, 600, 5))
