@@ -99,6 +99,7 @@ SIGNATURES = {
     "ah_margins": (C.c_int, [_VP, _VP, _VP, _U32P, C.c_size_t, _F32P]),
     "ah_create_split": (C.c_int, [_VP, _U32P, _VP, _VP]),
     "ah_build_forest": (C.c_int, [_VP, C.POINTER(AhBuildOptions), C.POINTER(C.c_void_p)]),
+    "ah_build_subtrees": (C.c_int, [_VP, C.POINTER(AhBuildOptions), _U32P, _U64P, C.POINTER(C.c_void_p)]),
     "ah_forest_view_get": (C.c_int, [_VP, C.POINTER(AhForestView)]),
     "ah_forest_stats": (C.c_int, [_VP, C.POINTER(AhBuildStats)]),
     "ah_forest_visit": (C.c_int, [_VP, _VP, _VP]),
@@ -107,6 +108,7 @@ SIGNATURES = {
     "ah_index_destroy": (C.c_int, [_VP]),
     "ah_search_batch": (C.c_int, [_VP, _F32P, _U32P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _U32P, C.c_size_t,
                                   C.c_int, _U32P, _F32P, _U32P]),
+    "ah_route_items": (C.c_int, [_VP, _U32P, C.c_size_t, _U64P, _U32P]),
     "ah_bench_scan": (C.c_int, [_VP, C.c_uint32, C.c_uint64, C.c_uint32, _F32P, C.POINTER(C.c_double)]),
     "ah_bench_memcpy": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     "ah_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),

@@ -32,7 +32,7 @@ enum { ST_PENDING = 0, ST_ACCEPTED = 1, ST_RANDOM = 2 };
 
 struct FNode {
     uint64_t key;      // ah_node_key_* of this node
-    uint64_t start;    // first position inside the tree's permutation
+    uint64_t start;    // first position inside the batch permutation (absolute: tree base + offset)
     uint32_t tree;     // tree index inside the batch
     uint32_t count;    // items under the node
     uint32_t n_left;   // accumulated by the margin kernel (integer atomics)
@@ -52,6 +52,15 @@ __global__ void k_init_perm(uint32_t *perm, uint64_t n, uint32_t n_trees) {
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride)
         perm[g] = (uint32_t)(g % n);
 }
+// item ids -> rows, in place (sub-tree builds start from caller-given id lists)
+__global__ void k_ids_to_rows(DataView dv, uint32_t *perm, uint64_t total, uint32_t *err) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const uint64_t row = row_of_id(dv, perm[g]);
+        if (row == ~0ull) atomicOr(err, 1u);
+        perm[g] = (uint32_t)row;
+    }
+}
 
 // One wave per pending node: sample 2+10 items with the policy RNG, run create_split.
 //
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(64) void k_forest_create_split(DataView dv, FNode *
     float *s_buf = reinterpret_cast<float *>(s_buf4);
     __shared__ uint32_t s_rows[AH_SPLIT_SAMPLES];
     const uint32_t fpitch = f32_space_pitch(dv.metric, dv.dims);
-    const uint32_t *pp = perm + (uint64_t)nd.tree * n_items + nd.start;
+    const uint32_t *pp = perm + nd.start;  // starts are absolute positions in the batch permutation
     if (threadIdx.x == 0) {
         uint64_t a, b;
         ah_choose_two(nd.key, nd.attempt, nd.count, &a, &b);  // src/parallel.rs:342-355
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void k_forest_margin_f32(DataView dv, FNode
         const float *g_h = reinterpret_cast<const float *>(normals + tl.node * nstride + hdr_off);
         const LeafHdr nh = {g_h[0], g_h[1]};
         const uint32_t in_tile = min(kTile, nd->count - tl.first);
-        const uint32_t *pp = perm + (uint64_t)nd->tree * n_items + nd->start + tl.first;
+        const uint32_t *pp = perm + nd->start + tl.first;
         uint64_t mask = 0;
         uint32_t lefts = 0;
         for (uint32_t i = 0; i < 64; i++) {
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void k_forest_margin_bq(DataView dv, FNode 
         const float *g_h = reinterpret_cast<const float *>(normals + tl.node * nstride + hdr_off);
         const LeafHdr nh = {g_h[0], g_h[1]};
         const uint32_t in_tile = min(kTile, nd->count - tl.first);
-        const uint32_t *pp = perm + (uint64_t)nd->tree * n_items + nd->start + tl.first;
+        const uint32_t *pp = perm + nd->start + tl.first;
         for (uint32_t p = threadIdx.x; p < in_tile; p += blockDim.x)
             s_side[p] = (uint8_t)side_of_margin(margin_bq(dv, s_nw, nh, pp[p]));
         __syncthreads();
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(kBlock) void k_forest_scatter(const FNode *__restri
         for (uint32_t w = 0; w < wave; w++) wave_base += s_wave[w];
         uint32_t left_before = tile_left_off[tile] + wave_base + incl - my_left;  // lefts before p0, inside the node
         uint32_t right_before = (tl.first + p0) - left_before;
-        const uint64_t base = (uint64_t)nd.tree * n_items + nd.start;
+        const uint64_t base = nd.start;
         const uint32_t n_right = nd.count - nd.n_left;
         uint32_t *dst_l = (nd.n_left <= split_after ? final_perm : perm_next) + base;
         uint32_t *dst_r = (n_right <= split_after ? final_perm : perm_next) + base + nd.n_left;
@@ -399,9 +408,17 @@ struct BatchCleanup {
 
 }  // namespace
 
+// `subset_ids` == nullptr: every tree covers all items (Writer::build with missing trees).  Otherwise tree t covers
+// the ascending id list subset_ids[subset_offsets[first_tree + t] .. subset_offsets[first_tree + t + 1]) — the
+// "descendants that became too large" of an incremental build (src/writer.rs:660-739).
 static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t first_tree, uint32_t n_trees,
-                       uint32_t split_after, ah_forest *forest, Context *ctx) {
+                       uint32_t split_after, ah_forest *forest, Context *ctx, const uint32_t *subset_ids,
+                       const uint64_t *subset_offsets) {
     const uint64_t N = ds->n;
+    std::vector<uint64_t> tree_base(n_trees + 1, 0);
+    for (uint32_t t = 0; t < n_trees; t++)
+        tree_base[t + 1] = tree_base[t] + (subset_ids ? subset_offsets[first_tree + t + 1] - subset_offsets[first_tree + t] : N);
+    const uint64_t M = tree_base[n_trees];  // entries of the batch permutation
     const DataView dv = ds->view();
     hipStream_t s = ctx->stream;
     const bool bq = metric_is_bq(ds->metric);
@@ -410,15 +427,15 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
 
     // Upper bounds known up front (every split node owns > split_after items), so nothing is reallocated
     // between levels: nodes per level <= n_trees * N / (split_after + 1), tiles <= items / kTile + nodes.
-    const uint64_t max_nodes = (uint64_t)n_trees * (N / ((uint64_t)split_after + 1)) + n_trees;
-    const uint64_t max_tiles = (uint64_t)n_trees * (N / kTile + 1) + max_nodes;
+    const uint64_t max_nodes = M / ((uint64_t)split_after + 1) + n_trees;
+    const uint64_t max_tiles = M / kTile + n_trees + max_nodes;
     DevBuf<uint32_t> perm_a, perm_b, final_perm, tile_left, tile_left_off;
     DevBuf<FNode> d_nodes;
     DevBuf<FTile> d_tiles;
     DevBuf<uint64_t> masks;
-    AH_TRY(perm_a.ensure(N * n_trees));
-    AH_TRY(perm_b.ensure(N * n_trees));
-    AH_TRY(final_perm.ensure(N * n_trees));
+    AH_TRY(perm_a.ensure(M));
+    AH_TRY(perm_b.ensure(M));
+    AH_TRY(final_perm.ensure(M));
     AH_TRY(d_nodes.ensure(max_nodes));
     AH_TRY(d_tiles.ensure(max_tiles));
     AH_TRY(masks.ensure(max_tiles * 32));
@@ -427,7 +444,20 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     AH_TRY(ctx->ensure_pinned(max_nodes * sizeof(FNode) + max_tiles * sizeof(FTile) + 4096));
     FNode *h_nodes = reinterpret_cast<FNode *>(ctx->h_pinned);
     FTile *h_tiles = reinterpret_cast<FTile *>(h_nodes + max_nodes);
-    hipLaunchKernelGGL(k_init_perm, dim3(2048), dim3(256), 0, s, perm_a.p, N, n_trees);
+    if (!subset_ids) {
+        hipLaunchKernelGGL(k_init_perm, dim3(2048), dim3(256), 0, s, perm_a.p, N, n_trees);
+    } else if (M) {
+        const uint32_t *src = subset_ids + subset_offsets[first_tree];
+        AH_HIP(hipMemcpyAsync(perm_a.p, src, M * 4, hipMemcpyHostToDevice, s));
+        DevBuf<uint32_t> d_err;
+        AH_TRY(d_err.ensure(1));
+        AH_HIP(hipMemsetAsync(d_err.p, 0, 4, s));
+        hipLaunchKernelGGL(k_ids_to_rows, dim3(2048), dim3(256), 0, s, dv, perm_a.p, M, d_err.p);
+        uint32_t e = 0;
+        AH_HIP(hipMemcpyAsync(&e, d_err.p, 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipStreamSynchronize(s));
+        AH_REQUIRE(e == 0, AH_ERR_MISSING_ITEM, "a sub-tree item id does not exist in the dataset");
+    }
     AH_HIP(hipGetLastError());
 
     BatchCleanup bc;
@@ -436,18 +466,24 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     std::vector<uint32_t> tree_root(n_trees);
     recs.reserve(4 * max_nodes / 3 + 16);
     for (uint32_t t = 0; t < n_trees; t++) {
+        const uint32_t cnt = (uint32_t)(tree_base[t + 1] - tree_base[t]);
         HostRec r{};
-        r.kind = AH_NODE_SPLIT;
         r.tree = t;
-        r.start = 0;
-        r.count = (uint32_t)N;
+        r.start = tree_base[t];
+        r.count = cnt;
         r.depth = 0;
         tree_root[t] = (uint32_t)recs.size();
+        if (cnt <= split_after) {  // fit_in_descendant at the root: the tree is one Descendants node
+            r.kind = AH_NODE_DESCENDANTS;
+            recs.push_back(r);
+            continue;
+        }
+        r.kind = AH_NODE_SPLIT;
         FNode nd{};
         nd.key = ah_node_key_root(opt->tree_seeds[first_tree + t]);
-        nd.start = 0;
+        nd.start = tree_base[t];
         nd.tree = t;
-        nd.count = (uint32_t)N;
+        nd.count = cnt;
         nd.rec = (uint32_t)recs.size();
         recs.push_back(r);
         level.push_back(nd);
@@ -596,13 +632,18 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     }
     const uint64_t desc_base = forest->descendants_len;
     {
-        uint32_t *grown = (uint32_t *)realloc(forest->descendants, (desc_base + N * n_trees) * 4 + 16);
+        uint32_t *grown = (uint32_t *)realloc(forest->descendants, (desc_base + M) * 4 + 16);
         AH_REQUIRE(grown, AH_ERR_OUT_OF_MEMORY, "host allocation of the descendants failed");
         forest->descendants = grown;
-        forest->descendants_len = desc_base + N * n_trees;
-        if (!ds->identity_ids)
-            hipLaunchKernelGGL(k_rows_to_ids, dim3(2048), dim3(256), 0, s, final_perm.p, N * n_trees, ds->d_ids);
-        AH_HIP(hipMemcpyAsync(forest->descendants + desc_base, final_perm.p, N * n_trees * 4, hipMemcpyDeviceToHost, s));
+        forest->descendants_len = desc_base + M;
+        // trees that are a single Descendants node never went through a scatter: their list is the input itself
+        for (uint32_t t = 0; t < n_trees; t++)
+            if (recs[tree_root[t]].kind == AH_NODE_DESCENDANTS && tree_base[t + 1] > tree_base[t])
+                AH_HIP(hipMemcpyAsync(final_perm.p + tree_base[t], perm_a.p + tree_base[t],
+                                      (tree_base[t + 1] - tree_base[t]) * 4, hipMemcpyDeviceToDevice, s));
+        if (!ds->identity_ids && M)
+            hipLaunchKernelGGL(k_rows_to_ids, dim3(2048), dim3(256), 0, s, final_perm.p, M, ds->d_ids);
+        if (M) AH_HIP(hipMemcpyAsync(forest->descendants + desc_base, final_perm.p, M * 4, hipMemcpyDeviceToHost, s));
     }
     AH_HIP(hipStreamSynchronize(s));
     float ms = 0.0f;
@@ -644,7 +685,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                 nd.offset = r.normal_off;
                 forest->stats.split_nodes++;
             } else {
-                nd.offset = desc_base + (uint64_t)t * N + r.start;
+                nd.offset = desc_base + r.start;
                 forest->stats.descendant_nodes++;
             }
             new_index[ri] = (uint32_t)forest->nodes.size();
@@ -658,13 +699,14 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
 
 extern "C" {
 
-int ah_build_forest(ah_dataset *ds, const ah_build_options *options, ah_forest **out) {
+static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, const uint32_t *subset_ids,
+                             const uint64_t *subset_offsets, ah_forest **out) {
     AH_REQUIRE(out, AH_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     AH_REQUIRE(ds && options, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     AH_REQUIRE(ds->finalized, AH_ERR_NOT_FINALIZED, "dataset not finalized (call ah_dataset_finalize)");
     AH_REQUIRE(options->n_trees == 0 || options->tree_seeds, AH_ERR_INVALID_ARGUMENT, "tree_seeds is NULL");
-    AH_REQUIRE(options->n_trees <= 0xFFFF, AH_ERR_INVALID_ARGUMENT, "at most 65535 trees per call");
+    AH_REQUIRE(options->n_trees <= 0xFFFF || subset_ids, AH_ERR_INVALID_ARGUMENT, "at most 65535 trees per call");
     AH_REQUIRE(ds->metric != AH_DOT_PRODUCT || ds->dot_preprocessed, AH_ERR_NEED_PREPROCESS,
                "DotProduct needs ah_preprocess_dot before the build (src/writer.rs:964-976)");
     AH_HIP(hipSetDevice(ds->device));
@@ -676,7 +718,7 @@ int ah_build_forest(ah_dataset *ds, const ah_build_options *options, ah_forest *
     forest->normal_header_offset = ds->row_bytes();
     forest->normal_stride = ds->row_bytes() + 16;
     int st = AH_OK;
-    if (ds->n <= split_after) {
+    if (!subset_ids && ds->n <= split_after) {
         // fit_in_descendant at the root (src/writer.rs:1183-1188): every tree is one Descendants node
         const uint64_t total = ds->n * options->n_trees;
         forest->descendants = (uint32_t *)malloc(total * 4 + 16);
@@ -707,16 +749,19 @@ int ah_build_forest(ah_dataset *ds, const ah_build_options *options, ah_forest *
             // Trees in flight: bounded by HBM (13 bytes per item per tree + masks + normals) or by the caller.
             size_t free_b = 0, total_b = 0;
             (void)hipMemGetInfo(&free_b, &total_b);
-            const uint64_t per_tree =
-                ds->n * 14 + ((ds->n / ((uint64_t)split_after + 1)) + 2) * 2 * (ds->row_bytes() + 128) + (1u << 20);
-            uint64_t fit = (uint64_t)(free_b * 0.8) / per_tree;
-            if (fit < 1) fit = 1;
-            uint32_t batch = (uint32_t)std::min<uint64_t>(fit, options->n_trees);
+            uint32_t batch = options->n_trees;
+            if (!subset_ids) {
+                const uint64_t per_tree =
+                    ds->n * 14 + ((ds->n / ((uint64_t)split_after + 1)) + 2) * 2 * (ds->row_bytes() + 128) + (1u << 20);
+                uint64_t fit = (uint64_t)(free_b * 0.8) / per_tree;
+                if (fit < 1) fit = 1;
+                batch = (uint32_t)std::min<uint64_t>(fit, options->n_trees);
+            }
             if (options->max_trees_in_flight) batch = std::min(batch, options->max_trees_in_flight);
             try {
                 for (uint32_t first = 0; first < options->n_trees && st == AH_OK; first += batch)
                     st = build_batch(ds, options, first, std::min(batch, options->n_trees - first), split_after, forest,
-                                     lease.c);
+                                     lease.c, subset_ids, subset_offsets);
             } catch (const std::bad_alloc &) {
                 set_error("host allocation failed during the forest build");
                 st = AH_ERR_OUT_OF_MEMORY;
@@ -730,6 +775,26 @@ int ah_build_forest(ah_dataset *ds, const ah_build_options *options, ah_forest *
     forest->stats.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     *out = forest;
     return AH_OK;
+}
+
+int ah_build_forest(ah_dataset *ds, const ah_build_options *options, ah_forest **out) {
+    return build_forest_impl(ds, options, nullptr, nullptr, out);
+}
+
+// `incremental_index_large_descendant` (src/writer.rs:660-739) for many descendants at once: tree t of the result is
+// `make_tree_in_file` over the ascending id list item_ids[offsets[t] .. offsets[t+1]).
+int ah_build_subtrees(ah_dataset *ds, const ah_build_options *options, const uint32_t *item_ids, const uint64_t *offsets,
+                      ah_forest **out) {
+    AH_REQUIRE(options, AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    AH_REQUIRE((item_ids && offsets) || options->n_trees == 0, AH_ERR_INVALID_ARGUMENT, "NULL id lists");
+    for (uint32_t t = 0; t < options->n_trees; t++) {
+        AH_REQUIRE(offsets[t + 1] >= offsets[t], AH_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+        for (uint64_t i = offsets[t] + 1; i < offsets[t + 1]; i++)
+            AH_REQUIRE(item_ids[i] > item_ids[i - 1], AH_ERR_INVALID_ARGUMENT,
+                       "sub-tree id lists must be strictly ascending (RoaringBitmap order)");
+    }
+    static const uint32_t dummy = 0;
+    return build_forest_impl(ds, options, item_ids ? item_ids : &dummy, offsets, out);
 }
 
 int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out) {

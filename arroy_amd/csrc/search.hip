@@ -307,6 +307,50 @@ __global__ void k_load_items_as_queries(DataView dv, const uint32_t *__restrict_
     }
 }
 
+// insert_items_in_descendants_from_frozen_reader (src/writer.rs:1398-1459) for every (tree, new item) pair at once:
+// each pair walks from the root to the Descendants node the item lands in.  One octet per pair.
+__global__ __launch_bounds__(256) void k_route_items(DataView dv, DataView nv, const DNode *__restrict__ nodes,
+                                                     const uint32_t *__restrict__ roots, uint32_t n_trees,
+                                                     const uint32_t *__restrict__ ids, uint64_t n,
+                                                     const uint64_t *__restrict__ seeds, uint32_t *__restrict__ out_leaf,
+                                                     uint32_t *err) {
+    const uint32_t j = threadIdx.x & 7u;
+    const uint64_t pair = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const bool live = pair < n * n_trees;
+    const uint32_t t = live ? (uint32_t)(pair / n) : 0u;
+    const uint64_t i = live ? pair % n : 0;
+    const uint32_t id = live ? ids[i] : 0u;
+    const uint64_t row = live ? row_of_id(dv, id) : ~0ull;
+    bool active = live && row != ~0ull;
+    if (live && row == ~0ull && j == 0) {
+        atomicOr(err, 1u);
+        out_leaf[pair] = 0xFFFFFFFFu;
+    }
+    const bool bq = metric_is_bq_dev(dv.metric);
+    const void *leaf_vec = nullptr;
+    LeafHdr lh = {0.0f, 0.0f};
+    if (active) {
+        leaf_vec = bq ? static_cast<const void *>(dv.rows_bq + row * dv.pitch)
+                      : static_cast<const void *>(dv.rows_f32 + row * dv.pitch);
+        const uint32_t hf = dv.metric == AH_DOT_PRODUCT ? 2u : 1u;
+        lh.h0 = dv.headers[row * hf];
+    }
+    uint32_t node = live ? roots[t] : 0u;
+    while (__any(active)) {
+        if (!active) continue;
+        const DNode nd = nodes[node];
+        if ((nd.kind & 0xFFu) == AH_NODE_DESCENDANTS) {
+            if (j == 0) out_leaf[pair] = node;
+            active = false;
+            continue;
+        }
+        uint32_t right;
+        if (nd.kind & 0x100u) right = side_of_margin(descent_margin(nv, nd.c, leaf_vec, lh, j));  // D::side
+        else right = ah_route_side_is_left(seeds[t], node, id) ^ 1u;                               // Side::random
+        node = right ? nd.b : nd.a;
+    }
+}
+
 __global__ void k_filter_bitmap(const uint32_t *__restrict__ ids, uint64_t n, uint32_t *bits) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += stride)
@@ -612,6 +656,48 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     AH_REQUIRE((*h_err & 1u) == 0, AH_ERR_MISSING_ITEM, "a descendant id does not exist in the dataset");
     memcpy(out_ids, h_oi, nq * k * 4);
     memcpy(out_dists, h_od, nq * k * 4);
+    return AH_OK;
+}
+
+// Route `n` items (already present in the index's dataset) down every tree of the index.
+// out_leaf[t * n + i] = forest-local index of the Descendants node item i reaches in tree t.
+int ah_route_items(ah_index *ix, const uint32_t *item_ids, size_t n, const uint64_t *tree_seeds, uint32_t *out_leaf) {
+    AH_REQUIRE(ix && ix->ds, AH_ERR_INVALID_ARGUMENT, "index is NULL");
+    AH_REQUIRE((item_ids && out_leaf && tree_seeds) || n == 0, AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n == 0 || ix->n_trees == 0) return AH_OK;
+    ah_dataset *ds = ix->ds;
+    AH_HIP(hipSetDevice(ds->device));
+    ContextLease lease(ds);
+    AH_REQUIRE(lease.c, AH_ERR_DEVICE, "cannot create a HIP stream");
+    Context *ctx = lease.c;
+    const size_t pairs = n * (size_t)ix->n_trees;
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    AH_TRY(ctx->ensure_device(pad(n * 4) + pad(ix->n_trees * 8) + pad(pairs * 4) + 1024));
+    AH_TRY(ctx->ensure_pinned(pad(n * 4) + pad(ix->n_trees * 8) + pad(pairs * 4) + 1024));
+    uint8_t *d = reinterpret_cast<uint8_t *>(ctx->d_scratch), *h = reinterpret_cast<uint8_t *>(ctx->h_pinned);
+    uint32_t *d_ids = reinterpret_cast<uint32_t *>(d);
+    uint64_t *d_seeds = reinterpret_cast<uint64_t *>(d + pad(n * 4));
+    uint32_t *d_leaf = reinterpret_cast<uint32_t *>(d + pad(n * 4) + pad(ix->n_trees * 8));
+    uint32_t *d_err = reinterpret_cast<uint32_t *>(d + pad(n * 4) + pad(ix->n_trees * 8) + pad(pairs * 4));
+    uint32_t *h_ids = reinterpret_cast<uint32_t *>(h);
+    uint64_t *h_seeds = reinterpret_cast<uint64_t *>(h + pad(n * 4));
+    uint32_t *h_leaf = reinterpret_cast<uint32_t *>(h + pad(n * 4) + pad(ix->n_trees * 8));
+    uint32_t *h_err = reinterpret_cast<uint32_t *>(h + pad(n * 4) + pad(ix->n_trees * 8) + pad(pairs * 4));
+    memcpy(h_ids, item_ids, n * 4);
+    memcpy(h_seeds, tree_seeds, (size_t)ix->n_trees * 8);
+    hipStream_t s = ctx->stream;
+    AH_HIP(hipMemcpyAsync(d_ids, h_ids, n * 4, hipMemcpyHostToDevice, s));
+    AH_HIP(hipMemcpyAsync(d_seeds, h_seeds, (size_t)ix->n_trees * 8, hipMemcpyHostToDevice, s));
+    AH_HIP(hipMemsetAsync(d_err, 0, 4, s));
+    const unsigned grid = (unsigned)((pairs * 8 + 255) / 256);
+    hipLaunchKernelGGL(k_route_items, dim3(grid), dim3(256), 0, s, ds->view(), ix->nv, ix->d_nodes, ix->d_roots, ix->n_trees,
+                       d_ids, (uint64_t)n, d_seeds, d_leaf, d_err);
+    AH_HIP(hipGetLastError());
+    AH_HIP(hipMemcpyAsync(h_leaf, d_leaf, pairs * 4, hipMemcpyDeviceToHost, s));
+    AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
+    AH_HIP(hipStreamSynchronize(s));
+    AH_REQUIRE((*h_err & 1u) == 0, AH_ERR_MISSING_ITEM, "an item to route does not exist in the dataset");
+    memcpy(out_leaf, h_leaf, pairs * 4);
     return AH_OK;
 }
 

@@ -185,6 +185,21 @@ class Dataset:
         _lib.check(_lib.lib().ah_build_forest(self._h, C.byref(opt), C.byref(h)))
         return Forest(h, self.distance, self.dimensions)
 
+    def build_subtrees(self, id_lists: Sequence[Sequence[int]], tree_seeds: Sequence[int], split_after: int = 0) -> "Forest":
+        """`incremental_index_large_descendant` for many item subsets at once (ah_build_subtrees)."""
+        seeds = np.ascontiguousarray(tree_seeds, dtype=np.uint64)
+        assert seeds.size == len(id_lists)
+        offsets = np.zeros(len(id_lists) + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum([len(l) for l in id_lists])
+        ids = _u32(np.concatenate([_u32(l) for l in id_lists])) if len(id_lists) else np.zeros(1, np.uint32)
+        opt = _lib.AhBuildOptions()
+        opt.n_trees = seeds.size
+        opt.split_after = int(split_after)
+        opt.tree_seeds = seeds.ctypes.data_as(C.POINTER(C.c_uint64))
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ah_build_subtrees(self._h, C.byref(opt), _ptr(ids), _ptr(offsets), C.byref(h)))
+        return Forest(h, self.distance, self.dimensions)
+
     def create_index(self, forest: "Forest") -> "Index":
         """Mirror `forest` in HBM next to this dataset (ah_index_create)."""
         return Index(self, forest)
@@ -247,6 +262,14 @@ class Index:
                                               int(oversampling), _ptr(filt), 0 if filt is None else filt.size,
                                               0 if filt is None else 1, _ptr(oi), _ptr(od), _ptr(oc)))
         return [[(int(oi[i, j]), float(od[i, j])) for j in range(int(oc[i]))] for i in range(nq)]
+
+    def route_items(self, item_ids: Sequence[int], tree_seeds: Sequence[int]) -> np.ndarray:
+        """Incremental routing (src/writer.rs:1398-1459): [n_trees, n] forest-local Descendants node per item."""
+        ids = _u32(item_ids)
+        seeds = np.ascontiguousarray(tree_seeds, dtype=np.uint64)
+        out = np.zeros((seeds.size, ids.size), dtype=np.uint32)
+        _lib.check(_lib.lib().ah_route_items(self._h, _ptr(ids), ids.size, _ptr(seeds), _ptr(out)))
+        return out
 
     def close(self) -> None:
         if self._h:

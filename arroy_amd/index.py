@@ -10,10 +10,8 @@ exactly the split of work of the Rust integration.
 """
 from __future__ import annotations
 
-import heapq
 import math
 import random
-import struct
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -78,8 +76,7 @@ class _IndexState:
         self.metadata: Optional[dict] = None
         self.dataset: Optional[Dataset] = None
         self.forest: Optional[Forest] = None
-        self.normals: Optional[Dataset] = None
-        self.normal_row: Dict[int, int] = {}
+        self.index = None  # arroy_amd.Index: dataset + forest resident in HBM
 
 
 class Database:
@@ -168,7 +165,7 @@ class ArroyBuilder:
         dist = w.database.distance
         ids = np.array(sorted(st.items), dtype=np.uint32)
         n = ids.size
-        st.dataset = st.forest = st.normals = None
+        st.dataset = st.forest = st.index = None
         if n:
             vecs = np.stack([st.items[int(i)] for i in ids])
             ds = Dataset(dist, w.dimensions, n)
@@ -181,18 +178,7 @@ class ArroyBuilder:
             forest = ds.build_forest(seeds, split_after=self._split_after or 0, cancel=self._cancel,
                                      progress=self._progress)
             st.dataset, st.forest = ds, forest
-            # split-plane normals as a second dataset, so the descent's margins come from one batched call
-            split = [i for i in range(len(forest.nodes)) if forest.nodes[i]["kind"] == 2 and forest.nodes[i]["has_normal"]]
-            st.normal_row = {node: r for r, node in enumerate(split)}
-            if split:
-                nds = Dataset(dist, w.dimensions, len(split))
-                recs = []
-                for node in split:
-                    h, v = forest.normal_of(node)
-                    recs.append(b"\x00" + h.tobytes() + v.tobytes())  # [tag][header][vector], src/node.rs:224-228
-                nds.upload_records(np.arange(len(split), dtype=np.uint32), recs)
-                nds.finalize()
-                st.normals = nds
+            st.index = ds.create_index(forest)  # forest mirrored in HBM for the on-device search
             roots = [int(r) for r in forest.roots]
         else:
             roots = []
@@ -248,25 +234,6 @@ class Reader:
         return QueryBuilder(self, int(count))
 
 
-def _ord_key(f: float) -> int:
-    """OrderedFloat<f32> as an integer: NaN greatest, -0 == +0 (ordered-float 4.6)."""
-    if f != f:
-        return 0xFFFFFFFF
-    if f == 0.0:
-        return 0x80000000
-    b = struct.unpack("<I", struct.pack("<f", f))[0]
-    return (~b & 0xFFFFFFFF) if (b & 0x80000000) else (b | 0x80000000)
-
-
-def _f32_min(a: float, b: float) -> float:
-    """Rust `f32::min`: returns the non-NaN operand."""
-    if a != a:
-        return b
-    if b != b:
-        return a
-    return a if a < b else b
-
-
 class QueryBuilder:
     """`QueryBuilder` (src/reader.rs:26-124)."""
 
@@ -299,61 +266,14 @@ class QueryBuilder:
             raise InvalidVecDimension(self._r.dimensions(), v.size)
         return self._nns(vector=v)
 
-    # nns_by_leaf, src/reader.rs:317-401
+    # nns_by_leaf, src/reader.rs:317-401 — the whole thing runs on device (ah_search_batch)
     def _nns(self, vector: Optional[np.ndarray] = None, item: Optional[int] = None):
         r, st = self._r, self._r._st
         if r.is_empty():
             return []
-        dist = r.distance
-        forest = st.forest
-        roots = st.metadata["roots"]
-        search_k = self._search_k if self._search_k is not None else self._count * len(roots)
-        search_k *= self._oversampling if self._oversampling is not None else dist.DEFAULT_OVERSAMPLING
-        margins = self._margins(vector, item)
-        # BinaryHeap<(OrderedFloat<f32>, NodeId)>: max-heap on the tuple; all ids here are tree nodes
-        heap = [(-_ord_key(math.inf), -int(root), math.inf, int(root)) for root in roots]
-        heapq.heapify(heap)
-        nns: List[int] = []
-        while len(nns) < search_k and heap:
-            _, _, d, node = heapq.heappop(heap)
-            nd = forest.nodes[node]
-            if nd["kind"] == 1:
-                desc = forest.descendants_of(node)
-                if self._candidates is not None:
-                    nns.extend(int(i) for i in desc if int(i) in self._candidates)
-                else:
-                    nns.extend(int(i) for i in desc)
-            else:
-                margin = float(margins[st.normal_row[node]]) if nd["has_normal"] else 0.0
-                for side, child in ((0, int(nd["left"])), (1, int(nd["right"]))):
-                    pq = _f32_min(-margin if side == 0 else margin, d)  # D::pq_distance, src/distance/mod.rs:63-68
-                    heapq.heappush(heap, (-_ord_key(pq), -child, pq, child))
-        cand = np.unique(np.asarray(nns, dtype=np.uint32))  # sort_unstable + dedup, src/reader.rs:378-379
-        if cand.size == 0:
-            return []
-        ids, dists = st.dataset.rerank(self._count, query=vector, item=item, sorted_ids=cand)
-        return [(int(i), float(d)) for i, d in zip(ids, dists)]
-
-    def _margins(self, vector, item) -> np.ndarray:
-        st, dist = self._r._st, self._r.distance
-        if st.normals is None:
-            return np.zeros(0, dtype=np.float32)
-        dims = self._r.dimensions()
-        if vector is None:
-            vector = st.dataset.item_vector(item)  # +-1.0 for the 1-bit codec: re-quantises to the stored bits
-        if dist.binary_quantized:  # UnalignedVector::<BinaryQuantized>::from_slice: sign bits, LSB first
-            bits = np.zeros(((dims + 63) // 64) * 64, dtype=np.uint8)
-            bits[:dims] = ~np.signbit(vector)
-            leaf_vec = np.packbits(bits, bitorder="little")
-        else:
-            leaf_vec = np.ascontiguousarray(vector, dtype=np.float32).view(np.uint8)
-        leaf_hdr = np.zeros(2, dtype=np.float32)
-        if dist.metric == 3 and item is not None:  # DotProduct margin uses the item's extra_dim
-            row = st.metadata["items"].index(item)
-            leaf_hdr[:] = st.dataset.read_headers(row, 1)[0]
-        n = len(st.normal_row)
-        out = np.zeros(n, dtype=np.float32)
-        import ctypes as C
-        _lib.check(_lib.lib().ah_margins(st.normals._h, leaf_vec.ctypes.data_as(C.c_void_p),
-                                         leaf_hdr.ctypes.data_as(C.c_void_p), None, n, out.ctypes.data_as(C.c_void_p)))
-        return out
+        res = st.index.search(self._count, queries=None if vector is None else vector[None, :],
+                              items=None if item is None else [item],
+                              search_k=0 if self._search_k is None else self._search_k,
+                              oversampling=0 if self._oversampling is None else self._oversampling,
+                              candidates=self._candidates)
+        return res[0]

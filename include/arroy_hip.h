@@ -191,6 +191,13 @@ typedef struct ah_build_options {
  * caller until the whole forest exists (src/writer.rs:597-607). */
 AH_API int ah_build_forest(ah_dataset *ds, const ah_build_options *options, ah_forest **out);
 
+/* The same build over caller-given item subsets: `incremental_index_large_descendant` (src/writer.rs:660-739), i.e.
+ * `make_tree_in_file` for every Descendants node that grew beyond split_after during an incremental insert.  Tree t
+ * of the result covers the ascending id list item_ids[offsets[t] .. offsets[t+1]) and uses options->tree_seeds[t];
+ * options->n_trees = number of subsets.  A subset that fits in one Descendants node yields a one-node tree. */
+AH_API int ah_build_subtrees(ah_dataset *ds, const ah_build_options *options, const uint32_t *item_ids,
+                             const uint64_t *offsets, ah_forest **out);
+
 enum { AH_NODE_DESCENDANTS = 1, AH_NODE_SPLIT = 2 };   /* node tags, src/node.rs:216-241 */
 
 typedef struct ah_node {
@@ -263,6 +270,16 @@ AH_API int ah_index_destroy(ah_index *index);
 AH_API int ah_search_batch(ah_index *index, const float *queries, const uint32_t *query_items, size_t nq, size_t count,
                            size_t search_k, size_t oversampling, const uint32_t *filter_sorted, size_t n_filter,
                            int have_filter, uint32_t *out_ids, float *out_distances, uint32_t *out_counts);
+
+/* Incremental insert routing, `insert_items_in_descendants_from_frozen_reader` (src/writer.rs:1398-1459), for
+ * every tree of the index at once: each of the `n` items (they must already be rows of the index's dataset — the
+ * reference also re-creates `ImmutableLeafs` over all current items for every build, src/writer.rs:530) walks from
+ * each root to the Descendants node it lands in, by `D::side` at split planes and by the coin of
+ * arroy_hip_policy.h (`ah_route_side_is_left`, keyed by tree_seeds[t]) at `normal: None` nodes.
+ * out_leaf[t * n + i] = forest-local node index reached by item i in tree t.  The host merges the items into those
+ * Descendants nodes and re-splits the ones that grew beyond split_after (src/writer.rs:1411-1414, 546-561). */
+AH_API int ah_route_items(ah_index *index, const uint32_t *item_ids, size_t n, const uint64_t *tree_seeds,
+                          uint32_t *out_leaf);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py).  They time with hipEvents recorded on the same stream the

@@ -89,6 +89,14 @@ AH_HD uint32_t ah_random_side_is_left(uint64_t node_key, uint64_t rank) {
     return (uint32_t)(ah_mix64(ah_mix64(node_key ^ 0x1F83D9ABFB41BD6Bull) + rank) >> 63);
 }
 
+/* Incremental routing (src/writer.rs:1398-1459): the coin of a new item at a split node whose normal is
+ * `None` (`randomly_split_children`, :1421-1423).  The reference consumes a per-tree sequential RNG
+ * (`R::seed_from_u64(seed + root)`, :1133) in bitmap order; here the coin is a pure function of
+ * (tree seed, node, item id) so every item can be routed independently.  1 = Left. */
+AH_HD uint32_t ah_route_side_is_left(uint64_t tree_seed, uint32_t node, uint32_t item_id) {
+    return (uint32_t)(ah_mix64(ah_mix64(tree_seed ^ 0x3C6EF372FE94F82Bull) + ((uint64_t)node << 32 | item_id)) >> 63);
+}
+
 /* ---- synthetic vectors ------------------------------------------------------------ */
 
 enum ah_synth_distribution {

@@ -866,6 +866,18 @@ AO_API ao_tree *ao_build_tree(const ao_data *d, uint32_t split_after, uint64_t t
     free(scratch);
     return t;
 }
+/* make_tree_in_file over a caller-given ascending row subset (incremental_index_large_descendant, src/writer.rs:660-739) */
+AO_API ao_tree *ao_build_tree_on(const ao_data *d, uint32_t split_after, uint64_t tree_seed, const uint32_t *subset, uint64_t n) {
+    ao_tree *t = (ao_tree *)calloc(1, sizeof(ao_tree));
+    if (split_after == 0) split_after = d->dims;
+    uint32_t *rows = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint32_t *scratch = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    memcpy(rows, subset, n * sizeof(uint32_t));
+    t->root = build_rec(d, t, split_after, rows, n, ah_node_key_root(tree_seed), 0, scratch);
+    free(rows);
+    free(scratch);
+    return t;
+}
 AO_API void ao_tree_view(const ao_tree *t, ah_forest_view *v, uint32_t *root_out) {
     memset(v, 0, sizeof *v);
     v->n_trees = 1;
@@ -1289,4 +1301,32 @@ AO_API size_t ao_search(const ao_data *d, const ah_forest_view *f, const void *q
     free(rows);
     free(nns);
     return m;
+}
+
+/* insert_items_in_descendants_from_frozen_reader, src/writer.rs:1398-1459: every item walks independently from
+ * each root to a Descendants node; `normal: None` nodes use the policy coin.  out_leaf[t * n + i]. */
+AO_API void ao_route_items(const ao_data *d, const ah_forest_view *f, const uint32_t *rows, size_t n,
+                           const uint64_t *tree_seeds, uint32_t *out_leaf) {
+    size_t hs = ao_header_floats(d->metric) * 4;
+    for (uint32_t t = 0; t < f->n_trees; t++)
+        for (size_t i = 0; i < n; i++) {
+            uint32_t node = f->roots[t];
+            uint32_t id = d->ids ? d->ids[rows[i]] : rows[i];
+            for (;;) {
+                const ah_node *nd = &f->nodes[node];
+                if (nd->kind == AH_NODE_DESCENDANTS) break;
+                int right;
+                if (nd->has_normal) {
+                    const uint8_t *rec = f->normals + nd->offset;
+                    float nh[2] = {0, 0};
+                    memcpy(nh, rec + f->normal_header_offset, hs);
+                    float m = ao_margin(d->metric, rec + f->normal_vector_offset, nh, row_vec(d, rows[i]), row_hdr(d, rows[i]), d->dims);
+                    right = ao_side_of_margin(m);
+                } else {
+                    right = (int)(ah_route_side_is_left(tree_seeds[t], node, id) ^ 1u);
+                }
+                node = right ? nd->right : nd->left;
+            }
+            out_leaf[(size_t)t * n + i] = node;
+        }
 }

@@ -115,6 +115,8 @@ def lib() -> C.CDLL:
         L.ao_split_imbalance.argtypes = [C.c_uint64, C.c_uint64]
         L.ao_build_tree.restype = C.c_void_p
         L.ao_build_tree.argtypes = [C.POINTER(AoData), C.c_uint32, C.c_uint64]
+        L.ao_build_tree_on.restype = C.c_void_p
+        L.ao_build_tree_on.argtypes = [C.POINTER(AoData), C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint64]
         L.ao_tree_view.argtypes = [C.c_void_p, C.POINTER(AhForestView), C.POINTER(C.c_uint32)]
         L.ao_tree_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_uint64)]
@@ -143,6 +145,7 @@ def lib() -> C.CDLL:
         L.ao_search.argtypes = [C.POINTER(AoData), C.POINTER(AhForestView), C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                 C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                 C.POINTER(C.c_size_t)]
+        L.ao_route_items.argtypes = [C.POINTER(AoData), C.POINTER(AhForestView), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.ao_num_threads.restype = C.c_int
         L.ao_set_num_threads.argtypes = [C.c_int]
         _lib = L
@@ -292,8 +295,8 @@ class Data:
         lib().ao_preprocess_dot(self.c(), C.byref(m))
         return np.float32(m.value)
 
-    def build_tree(self, split_after: int, seed: int):
-        return Tree(self, split_after, seed)
+    def build_tree(self, split_after: int, seed: int, rows=None):
+        return Tree(self, split_after, seed, rows)
 
 
 def top_k(dists, ids, k, spec=False):
@@ -309,9 +312,13 @@ def top_k(dists, ids, k, spec=False):
 class Tree:
     """One tree built by the oracle's depth-first restatement of make_tree_in_file."""
 
-    def __init__(self, data: Data, split_after: int, seed: int):
+    def __init__(self, data: Data, split_after: int, seed: int, rows=None):
         L = lib()
-        h = L.ao_build_tree(data.c(), split_after, seed)
+        if rows is None:
+            h = L.ao_build_tree(data.c(), split_after, seed)
+        else:
+            r = np.ascontiguousarray(rows, dtype=np.uint32)
+            h = L.ao_build_tree_on(data.c(), split_after, seed, _p(r), r.size)
         view = AhForestView()
         root = C.c_uint32(0)
         L.ao_tree_view(h, C.byref(view), C.byref(root))
@@ -447,3 +454,13 @@ def search(data: "Data", forest, qv, qh, count: int, search_k: int = 0, oversamp
                         oversampling, None if filt is None else _p(filt), 0 if filt is None else filt.size,
                         0 if filt is None else 1, _p(oi), _p(od), _p(cand), cap, C.byref(nc))
     return [(int(oi[i]), float(od[i])) for i in range(m)], cand[: nc.value].copy()
+
+
+def route_items(data: "Data", forest, rows, tree_seeds) -> np.ndarray:
+    """Incremental routing (src/writer.rs:1398-1459): [n_trees, n] node index reached by every item."""
+    view = forest_view(forest)
+    r = np.ascontiguousarray(rows, dtype=np.uint32)
+    seeds = np.ascontiguousarray(tree_seeds, dtype=np.uint64)
+    out = np.zeros((forest.n_trees, r.size), dtype=np.uint32)
+    lib().ao_route_items(data.c(), C.byref(view), _p(r), r.size, _p(seeds), _p(out))
+    return out

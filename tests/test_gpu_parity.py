@@ -494,3 +494,60 @@ def test_device_search_big_queue_and_big_candidate_sets():
     # exhaustive search_k == exact top-k
     exact_ids, exact_d = ds.rerank(15, query=queries[0])
     assert [i for i, _ in index.search(15, queries=queries[:1], search_k=2**62)[0]] == list(exact_ids)
+
+
+# ---- incremental paths: routing through existing trees + sub-tree builds (src/writer.rs:660-739, 1398-1459) ----
+
+@pytest.mark.parametrize("metric", ALL_METRICS)
+def test_route_items_equals_oracle_and_finds_the_items_own_leaf(metric):
+    cls = D.BY_METRIC[metric]
+    n, dims = 3000, 40
+    ds, oracle, vecs, ids = make_data(cls, n, dims, seed=50 + metric)
+    seeds = [3, 4, 5]
+    forest = ds.build_forest(seeds, split_after=64)
+    index = ds.create_index(forest)
+    rows = np.sort(np.random.default_rng(metric).choice(n, 500, replace=False)).astype(np.uint32)
+    got = index.route_items(rows, seeds)
+    want = O.route_items(oracle, forest, rows, seeds)
+    assert np.array_equal(got, want)
+    # every reached node is a Descendants node; without dummy normals an item already in the tree reaches the
+    # leaf that holds it (the same side() decisions as during the build)
+    for t in range(3):
+        for i, r in enumerate(rows):
+            nd = forest.nodes[int(got[t, i])]
+            assert nd["kind"] == 1
+            if forest.stats["dummy_normals"] == 0:
+                assert int(r) in set(int(x) for x in forest.descendants_of(int(got[t, i])))
+
+
+def test_route_items_through_dummy_normals():
+    """`normal: None` nodes route by the policy coin (degenerate data: all splits fail)."""
+    from arroy_amd import Dataset
+    n, dims = 800, 32
+    vecs = np.ones((n, dims), dtype=np.float32)
+    ds = Dataset(D.Euclidean, dims, n)
+    ds.upload_vectors(np.arange(n), vecs)
+    ds.finalize()
+    forest = ds.build_forest([9], split_after=16)
+    assert forest.stats["dummy_normals"] > 0
+    index = ds.create_index(forest)
+    o = O.Data(0, vecs)
+    rows = np.arange(0, n, 3, dtype=np.uint32)
+    assert np.array_equal(index.route_items(rows, [77]), O.route_items(o, forest, rows, [77]))
+
+
+@pytest.mark.parametrize("metric", [0, 2, 3, 6])
+def test_build_subtrees_equals_oracle(metric):
+    cls = D.BY_METRIC[metric]
+    n, dims = 5000, 32
+    ds, oracle, vecs, ids = make_data(cls, n, dims, seed=70 + metric)
+    rng = np.random.default_rng(metric)
+    subsets = [np.sort(rng.choice(n, m, replace=False)).astype(np.uint32) for m in (1200, 40, 333, 2, 0, 2500)]
+    seeds = [100 + i for i in range(len(subsets))]
+    forest = ds.build_subtrees(subsets, seeds, split_after=48)
+    assert forest.n_trees == len(subsets)
+    for t, (sub, seed) in enumerate(zip(subsets, seeds)):
+        ref = oracle.build_tree(48, seed, rows=sub)
+        assert forest.canonical(t) == ref.canonical(), f"sub-tree {t} ({len(sub)} items) differs from the oracle"
+    with pytest.raises(__import__("arroy_amd").ArroyHipError):
+        ds.build_subtrees([[5, 3, 9]], [1], split_after=1)  # not ascending
