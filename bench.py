@@ -163,6 +163,37 @@ def extra_c4(device):
             "seconds": el}
 
 
+def extra_search(device):
+    """End-to-end on-device search on the configs[3] shape: 1M x 1536 dot product, 20 trees, 1000 by-vector queries,
+    count=100, search_k=10000: descent + candidate collection + sort/dedup + re-rank + top-k (src/reader.rs:317-401)."""
+    import numpy as np
+
+    from arroy_amd import Dataset, distances, shard
+    n, dims, nq, k, n_trees = 1_000_000, 1536, 1000, 100, 20
+    ds = Dataset(distances.DotProduct, dims, n, device=device)
+    ds.fill_synthetic(SEED, 1, n)
+    ds.preprocess_dot()
+    ds.finalize()
+    t0 = time.perf_counter()
+    forest = ds.build_forest(shard.tree_seeds(SEED, range(n_trees)))
+    build_s = time.perf_counter() - t0
+    index = ds.create_index(forest)
+    rng = np.random.default_rng(SEED)
+    queries = np.stack([ds.item_vector(int(i)) for i in rng.choice(n, 64, replace=False)])
+    queries = (np.tile(queries, (nq // 64 + 1, 1))[:nq] + rng.standard_normal((nq, dims)).astype(np.float32) * 0.05).astype(np.float32)
+    index.search(k, queries=queries[:64], search_k=10_000)  # warm-up
+    t0 = time.perf_counter()
+    res = index.search(k, queries=queries, search_k=10_000)
+    el = time.perf_counter() - t0
+    out = {"workload": f"{n}x{dims} dot product, {n_trees} trees, {nq} queries, count={k}, search_k=10000 (host in/out included)",
+           "queries_per_s": nq / el, "seconds": el, "forest_build_seconds": build_s,
+           "results_per_query": float(np.mean([len(r) for r in res]))}
+    index.close()
+    forest.close()
+    ds.close()
+    return out
+
+
 def extra_c3(device, my_seeds_fn):
     """BASELINE configs[2]: 10M x 768 cosine, n_trees=100; this rank's share of the trees (all 100 at N=1)."""
     from arroy_amd import Dataset, distances
@@ -283,6 +314,8 @@ def main():
             extra["c5"] = extra_c5(local_rank)
         if "c4" in wanted and rank == 0:
             extra["c4"] = extra_c4(local_rank)
+        if "search" in wanted and rank == 0:
+            extra["search"] = extra_search(local_rank)
         if "c3" in wanted:
             barrier_sync()
             t0 = time.perf_counter()
