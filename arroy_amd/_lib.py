@@ -105,6 +105,7 @@ SIGNATURES = {
     "ah_forest_visit": (C.c_int, [_VP, _VP, _VP]),
     "ah_forest_destroy": (C.c_int, [_VP]),
     "ah_index_create": (C.c_int, [_VP, _VP, C.POINTER(C.c_void_p)]),
+    "ah_index_create_from_view": (C.c_int, [_VP, C.POINTER(AhForestView), C.POINTER(C.c_void_p)]),
     "ah_index_destroy": (C.c_int, [_VP]),
     "ah_search_batch": (C.c_int, [_VP, _F32P, _U32P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _U32P, C.c_size_t,
                                   C.c_int, _U32P, _F32P, _U32P]),

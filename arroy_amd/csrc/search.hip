@@ -386,6 +386,8 @@ struct ah_index {
 
 extern "C" {
 
+int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_index **out);
+
 int ah_index_destroy(ah_index *ix) {
     if (!ix) return AH_OK;
     if (ix->ds) (void)hipSetDevice(ix->ds->device);
@@ -403,10 +405,33 @@ int ah_index_destroy(ah_index *ix) {
 int ah_index_create(ah_dataset *ds, const ah_forest *forest, ah_index **out) {
     AH_REQUIRE(out, AH_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
-    AH_REQUIRE(ds && forest, AH_ERR_INVALID_ARGUMENT, "NULL argument");
-    AH_REQUIRE(ds->finalized, AH_ERR_NOT_FINALIZED, "dataset not finalized");
+    AH_REQUIRE(forest, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     ah_forest_view v;
     AH_TRY(ah_forest_view_get(forest, &v));
+    return ah_index_create_from_view(ds, &v, out);
+}
+
+// Same from caller-owned arrays (e.g. tree nodes decoded from LMDB by `Reader::open`); nothing is retained.
+int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_index **out) {
+    AH_REQUIRE(out, AH_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    AH_REQUIRE(ds && view, AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    AH_REQUIRE(ds->finalized, AH_ERR_NOT_FINALIZED, "dataset not finalized");
+    const ah_forest_view v = *view;
+    for (uint64_t i = 0; i < v.n_nodes; i++) {
+        const ah_node &nd = v.nodes[i];
+        if (nd.kind == AH_NODE_SPLIT) {
+            AH_REQUIRE(nd.left < v.n_nodes && nd.right < v.n_nodes, AH_ERR_INVALID_ARGUMENT, "node %llu: child out of range",
+                       (unsigned long long)i);
+            AH_REQUIRE(!nd.has_normal || nd.offset + v.normal_stride <= v.normals_len, AH_ERR_INVALID_ARGUMENT,
+                       "node %llu: normal record out of range", (unsigned long long)i);
+        } else {
+            AH_REQUIRE(nd.kind == AH_NODE_DESCENDANTS && nd.offset + nd.count <= v.descendants_len, AH_ERR_INVALID_ARGUMENT,
+                       "node %llu: bad kind or descendants out of range", (unsigned long long)i);
+        }
+    }
+    for (uint32_t t = 0; t < v.n_trees; t++)
+        AH_REQUIRE(v.roots[t] < v.n_nodes, AH_ERR_INVALID_ARGUMENT, "root %u out of range", t);
     AH_REQUIRE(v.descendants_len < 0xFFFFFFFFull && v.n_nodes < 0xFFFFFFFFull, AH_ERR_INVALID_ARGUMENT,
                "forest too large for 32-bit node / descendant offsets");
     AH_HIP(hipSetDevice(ds->device));

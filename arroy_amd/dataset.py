@@ -234,10 +234,14 @@ class Dataset:
 class Index:
     """Dataset + forest resident in HBM: the whole `Reader::nns_by_leaf` runs on device (ah_search_batch)."""
 
-    def __init__(self, dataset: Dataset, forest: "Forest"):
+    def __init__(self, dataset: Dataset, forest: Optional["Forest"], view=None):
         self.dataset = dataset
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().ah_index_create(dataset._h, forest._h, C.byref(self._h)))
+        if view is not None:  # caller-owned arrays in the ah_forest_view shape (ah_index_create_from_view)
+            _lib.check(_lib.lib().ah_index_create_from_view(dataset._h, C.cast(C.byref(view), C.POINTER(_lib.AhForestView)),
+                                                            C.byref(self._h)))
+        else:
+            _lib.check(_lib.lib().ah_index_create(dataset._h, forest._h, C.byref(self._h)))
 
     def search(self, count: int, queries=None, items=None, search_k: int = 0, oversampling: int = 0, candidates=None):
         """Batch of `QueryBuilder::by_vector` (queries: nq x dims) or `by_item` (items: nq ids).

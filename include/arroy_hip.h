@@ -261,6 +261,9 @@ typedef struct ah_index ah_index;
 /* Upload the forest (nodes, split-plane normals, descendants) to the dataset's device.  The ah_forest may be
  * destroyed afterwards; the dataset must outlive the index. */
 AH_API int ah_index_create(ah_dataset *ds, const ah_forest *forest, ah_index **out);
+/* Same from caller-owned arrays in the ah_forest_view shape (e.g. tree nodes decoded from LMDB by `Reader::open`):
+ * validated, copied to the device, not retained. */
+AH_API int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_index **out);
 AH_API int ah_index_destroy(ah_index *index);
 
 /* `QueryBuilder::by_vector` (queries = nq x dims f32, query_items = NULL) or `by_item` (queries = NULL,

@@ -551,3 +551,23 @@ def test_build_subtrees_equals_oracle(metric):
         assert forest.canonical(t) == ref.canonical(), f"sub-tree {t} ({len(sub)} items) differs from the oracle"
     with pytest.raises(__import__("arroy_amd").ArroyHipError):
         ds.build_subtrees([[5, 3, 9]], [1], split_after=1)  # not ascending
+
+
+def test_index_from_caller_owned_arrays():
+    """`ah_index_create_from_view`: tree nodes that never were an ah_forest (here: built by the CPU oracle, records in
+    the oracle's [header][vector] layout) are searchable on device; garbage views are rejected, not dereferenced."""
+    from arroy_amd import ArroyHipError, Index
+    n, dims = 2500, 40
+    ds, oracle, vecs, ids = make_data(D.Euclidean, n, dims, seed=8)
+    tree = oracle.build_tree(50, 99).as_forest(oracle)
+    view = O.forest_view(tree)
+    index = Index(ds, None, view=view)
+    queries = np.random.default_rng(3).standard_normal((10, dims)).astype(np.float32)
+    got = index.search(10, queries=queries, search_k=400)
+    for qi in range(10):
+        qv, qh = oracle.query_leaf(queries[qi])
+        want, _ = O.search(oracle, tree, qv, qh, 10, 400)
+        assert [i for i, _ in got[qi]] == [i for i, _ in want]
+    tree.nodes["left"][int(tree.roots[0])] = 10**6  # child index out of range
+    with pytest.raises(ArroyHipError):
+        Index(ds, None, view=O.forest_view(tree))
