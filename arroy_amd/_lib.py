@@ -65,7 +65,7 @@ class AhBuildOptions(C.Structure):
 
 class AhBuildStats(C.Structure):
     _fields_ = [("seconds_total", C.c_double), ("seconds_device", C.c_double), ("seconds_margin", C.c_double),
-                ("margin_evaluations", C.c_uint64), ("margin_launches", C.c_uint64), ("split_nodes", C.c_uint64),
+                ("margin_evaluations", C.c_uint64), ("margin_launches", C.c_uint64), ("margin_row_passes", C.c_uint64), ("split_nodes", C.c_uint64),
                 ("descendant_nodes", C.c_uint64), ("dummy_normals", C.c_uint64), ("retries", C.c_uint64),
                 ("levels", C.c_uint32)]
 

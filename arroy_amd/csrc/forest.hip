@@ -187,6 +187,132 @@ __global__ __launch_bounds__(kBlock) void k_forest_margin_bq(DataView dv, FNode 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-major margin pass (first attempt of a level, full-dataset trees, f32 metrics).
+//
+// Node-major tiles read every item row once PER TREE: T x N x 4*dims bytes of HBM per level.  But at a given
+// level every tree partitions the same N rows, so one pass over the rows can serve several trees at once: an
+// octet streams row r ONCE and, for each of up to TC trees, looks up the node that owns r in that tree
+// (`node_of[t][r]`) and accumulates the dot with that node's normal.  The normals of one level
+// (trees x nodes x 4*dims bytes) are small and re-used by thousands of rows, i.e. they come from L2 / the
+// Infinity Cache, while HBM traffic drops to ceil(T / TC) x N x 4*dims bytes.  The arithmetic per (row, normal)
+// pair is unchanged — the same 32-chain FMA order, the same reduction tree — so the sides are bit-identical to
+// the node-major kernel; the host picks whichever mode moves fewer bytes for the level (deep levels, where few
+// rows are still active and the normals no longer fit in cache, stay node-major).
+// Output: one side byte per (tree, row); k_forest_masks_from_bytes turns them into the tile masks / counts the
+// rest of the pipeline consumes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_forest_assign_node_of(const FNode *__restrict__ nodes,
+                                                                  const FTile *__restrict__ tiles, uint32_t n_tiles,
+                                                                  const uint32_t *__restrict__ perm, uint64_t n_items,
+                                                                  uint32_t *__restrict__ node_of) {
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const FTile tl = tiles[tile];
+        const FNode *nd = nodes + tl.node;
+        const uint32_t in_tile = min(kTile, nd->count - tl.first);
+        const uint32_t *pp = perm + nd->start + tl.first;
+        uint32_t *dst = node_of + (uint64_t)nd->tree * n_items;
+        for (uint32_t p = threadIdx.x; p < in_tile; p += blockDim.x) dst[pp[p]] = tl.node;
+    }
+}
+
+template <int METRIC, int TC>
+__global__ __launch_bounds__(kBlock) void k_forest_margin_rows(DataView dv, const uint32_t *__restrict__ node_of,
+                                                               uint32_t tree0, uint32_t n_pass,
+                                                               const uint8_t *__restrict__ normals, uint64_t nstride,
+                                                               uint64_t hdr_off, uint8_t *__restrict__ side_bytes) {
+    const uint32_t j = threadIdx.x & 7u;
+    const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+    const uint32_t blocks = dv.dims >> 5;
+    for (uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; row < dv.n; row += n_octets) {
+        const float *rp = dv.rows_f32 + row * dv.pitch;
+        const float4 *r4 = reinterpret_cast<const float4 *>(rp) + j;
+        const float4 *n4[TC];
+        bool on[TC];
+        float4 acc[TC];
+#pragma unroll
+        for (int t = 0; t < TC; t++) {
+            uint32_t node = 0xFFFFFFFFu;
+            if ((uint32_t)t < n_pass) node = node_of[(uint64_t)(tree0 + t) * dv.n + row];
+            on[t] = node != 0xFFFFFFFFu;
+            n4[t] = reinterpret_cast<const float4 *>(normals + (on[t] ? (uint64_t)node : 0ull) * nstride) + j;
+            acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        uint32_t k = 0;
+        for (; k + 8 <= blocks; k += 8) {
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = ld_stream(r4 + (k + u) * 8);
+#pragma unroll
+            for (int t = 0; t < TC; t++) {
+                if (on[t]) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) fma_step<OP_DOT>(acc[t], n4[t][(k + u) * 8], x[u]);
+                }
+            }
+        }
+        for (; k < blocks; k++) {
+            const float4 x = r4[k * 8];
+#pragma unroll
+            for (int t = 0; t < TC; t++)
+                if (on[t]) fma_step<OP_DOT>(acc[t], n4[t][k * 8], x);
+        }
+#pragma unroll
+        for (int t = 0; t < TC; t++) {
+            if (on[t]) {
+                const float *np = reinterpret_cast<const float *>(n4[t] - j);
+                float d = octet_finish(acc[t]);
+                d = scalar_tail<OP_DOT>(d, np, rp, blocks << 5, dv.dims);
+                const float *nh = reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(np) + hdr_off);
+                float m = d;
+                if (METRIC == AH_EUCLIDEAN || METRIC == AH_MANHATTAN) m = f_add(nh[0], d);
+                if (METRIC == AH_DOT_PRODUCT) m = f_add(d, f_mul(nh[0], dv.headers[2 * row]));
+                if (j == 0) side_bytes[(uint64_t)(tree0 + t) * dv.n + row] = (uint8_t)side_of_margin(m);
+            }
+        }
+    }
+}
+
+// side bytes (by row) -> the per-tile masks / left counts of the node-major pipeline
+__global__ __launch_bounds__(kBlock) void k_forest_masks_from_bytes(FNode *nodes, const FTile *__restrict__ tiles,
+                                                                    uint32_t n_tiles, const uint32_t *__restrict__ perm,
+                                                                    uint64_t n_items,
+                                                                    const uint8_t *__restrict__ side_bytes,
+                                                                    uint64_t *__restrict__ masks,
+                                                                    uint32_t *__restrict__ tile_left) {
+    __shared__ uint32_t s_left;
+    __shared__ uint8_t s_side[kTile];
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const FTile tl = tiles[tile];
+        const FNode *nd = nodes + tl.node;
+        if (nd->state != ST_PENDING) continue;
+        __syncthreads();
+        if (threadIdx.x == 0) s_left = 0;
+        const uint32_t in_tile = min(kTile, nd->count - tl.first);
+        const uint32_t *pp = perm + nd->start + tl.first;
+        const uint8_t *sb = side_bytes + (uint64_t)nd->tree * n_items;
+        for (uint32_t p = threadIdx.x; p < in_tile; p += blockDim.x) s_side[p] = sb[pp[p]];
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            uint64_t mask = 0;
+            uint32_t lefts = 0;
+            for (uint32_t i = 0; i < 64; i++) {
+                const uint32_t p = threadIdx.x + 32 * i;
+                if (p >= in_tile) break;
+                mask |= (uint64_t)s_side[p] << i;
+                lefts += s_side[p] ^ 1u;
+            }
+            masks[(uint64_t)tile * 32 + threadIdx.x] = mask;
+            if (lefts) atomicAdd(&s_left, lefts);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            tile_left[tile] = s_left;
+            if (s_left) atomicAdd(&nodes[tl.node].n_left, s_left);
+        }
+    }
+}
+
 // split_imbalance (src/writer.rs:1348-1353, f64) and the accept / retry / random decision (:1209-1227).
 __global__ void k_forest_decide(FNode *nodes, uint32_t n_nodes) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -381,6 +507,10 @@ struct EventPair {
 
 // AH_DEBUG=1: synchronise after every launch and say which kernel finished (debugging aid only)
 bool g_debug = getenv("AH_DEBUG") != nullptr;
+// AH_ROWMAJOR=0 disables the row-major margin pass, =1 forces it whenever it is legal (A/B measurements);
+// AH_ROWMAJOR_CACHE_MB = budget for one group's normals (default 4 MiB ~ one XCD's L2).
+int g_rows_force = getenv("AH_ROWMAJOR") ? atoi(getenv("AH_ROWMAJOR")) : -1;
+uint64_t g_rows_cache_bytes = (uint64_t)(getenv("AH_ROWMAJOR_CACHE_MB") ? atof(getenv("AH_ROWMAJOR_CACHE_MB")) : 4.0) * (1u << 20);
 #define AH_DBG(s, what)                                                       \
     do {                                                                      \
         if (g_debug) {                                                        \
@@ -442,6 +572,14 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     AH_TRY(tile_left.ensure(max_tiles));
     AH_TRY(tile_left_off.ensure(max_tiles));
     AH_TRY(ctx->ensure_pinned(max_nodes * sizeof(FNode) + max_tiles * sizeof(FTile) + 4096));
+    // row-major margin mode (full-dataset trees, f32 metrics): node index and side byte per (tree, row)
+    const bool rows_allowed = !subset_ids && !bq && ds->dims >= 32 && n_trees >= 2 && g_rows_force != 0;
+    DevBuf<uint32_t> node_of;
+    DevBuf<uint8_t> side_bytes;
+    if (rows_allowed) {
+        AH_TRY(node_of.ensure((size_t)n_trees * N));
+        AH_TRY(side_bytes.ensure((size_t)n_trees * N));
+    }
     FNode *h_nodes = reinterpret_cast<FNode *>(ctx->h_pinned);
     FTile *h_tiles = reinterpret_cast<FTile *>(h_nodes + max_nodes);
     if (!subset_ids) {
@@ -529,6 +667,20 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_HIP(hipMemcpyAsync(d_nodes.p, h_nodes, n_nodes * sizeof(FNode), hipMemcpyHostToDevice, s));
         AH_HIP(hipMemcpyAsync(d_tiles.p, h_tiles, n_tiles * sizeof(FTile), hipMemcpyHostToDevice, s));
         const unsigned tile_grid = std::min<uint32_t>(n_tiles, kMaxBlocks);
+        // Row-major or node-major for the first attempt of this level?  Row-major streams all N rows once per group of
+        // row_tc trees; node-major reads only the still-active items, once per tree.  The group is sized so that the
+        // level's normals of one group stay cache-resident.
+        uint32_t row_tc = 0;
+        if (rows_allowed) {
+            uint64_t pairs = 0;
+            for (uint32_t i = 0; i < n_nodes; i++) pairs += level[i].count;
+            const uint64_t nodes_per_tree = (n_nodes + n_trees - 1) / n_trees;
+            uint32_t tc = 16;
+            while (tc > 1 && (uint64_t)tc * nodes_per_tree * nstride > g_rows_cache_bytes) tc >>= 1;
+            while (tc > 2 && tc / 2 >= n_trees) tc >>= 1;  // do not instantiate more slots than trees
+            const uint64_t passes = (n_trees + tc - 1) / tc;
+            if (tc >= 2 && (g_rows_force == 1 || (double)pairs >= 1.25 * (double)(passes * N))) row_tc = tc;
+        }
         for (int attempt = 0; attempt < 4; attempt++) {
             hipLaunchKernelGGL(k_forest_create_split, dim3(n_nodes), dim3(64), cs_shared, s, dv, d_nodes.p, cur, N,
                                chunk.d, nstride, hdr_off);
@@ -538,7 +690,37 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             AH_HIP(hipEventCreate(&ep.b));
             bc.events.push_back(ep);
             AH_HIP(hipEventRecord(ep.a, s));
-            if (bq) {
+            if (attempt == 0 && row_tc >= 2) {
+                // one pass over the rows serves up to row_tc trees (see k_forest_margin_rows)
+                AH_HIP(hipMemsetAsync(node_of.p, 0xFF, (size_t)n_trees * N * 4, s));
+                hipLaunchKernelGGL(k_forest_assign_node_of, dim3(tile_grid), dim3(kBlock), 0, s, d_nodes.p, d_tiles.p, n_tiles,
+                                   cur, N, node_of.p);
+                const unsigned row_grid = (unsigned)std::min<uint64_t>((N + 31) / 32, kMaxBlocks);
+                for (uint32_t t0 = 0; t0 < n_trees; t0 += row_tc) {
+                    const uint32_t np = std::min<uint32_t>(row_tc, n_trees - t0);
+#define AH_ROWS(M, TCV)                                                                                          \
+    hipLaunchKernelGGL((k_forest_margin_rows<M, TCV>), dim3(row_grid), dim3(kBlock), 0, s, dv, node_of.p, t0, np, \
+                       chunk.d, nstride, hdr_off, side_bytes.p)
+#define AH_ROWS_TC(M)                       \
+    switch (row_tc) {                       \
+    case 16: AH_ROWS(M, 16); break;         \
+    case 8: AH_ROWS(M, 8); break;           \
+    case 4: AH_ROWS(M, 4); break;           \
+    default: AH_ROWS(M, 2); break;          \
+    }
+                    switch (ds->metric) {
+                    case AH_EUCLIDEAN: AH_ROWS_TC(AH_EUCLIDEAN); break;
+                    case AH_MANHATTAN: AH_ROWS_TC(AH_MANHATTAN); break;
+                    case AH_COSINE: AH_ROWS_TC(AH_COSINE); break;
+                    default: AH_ROWS_TC(AH_DOT_PRODUCT); break;
+                    }
+#undef AH_ROWS_TC
+#undef AH_ROWS
+                }
+                hipLaunchKernelGGL(k_forest_masks_from_bytes, dim3(tile_grid), dim3(kBlock), 0, s, d_nodes.p, d_tiles.p, n_tiles,
+                                   cur, N, side_bytes.p, masks.p, tile_left.p);
+                forest->stats.margin_row_passes += (n_trees + row_tc - 1) / row_tc;
+            } else if (bq) {
                 hipLaunchKernelGGL(k_forest_margin_bq, dim3(tile_grid), dim3(kBlock), dv.pitch * 8, s, dv, d_nodes.p,
                                    d_tiles.p, n_tiles, cur, N, chunk.d, nstride, hdr_off, masks.p, tile_left.p);
             } else {

@@ -235,6 +235,7 @@ typedef struct ah_build_stats {
     double seconds_margin;        /* HIP-event time of the margin/side kernel only                   */
     uint64_t margin_evaluations;  /* number of (item, node-visit) units incl. retries                */
     uint64_t margin_launches;
+    uint64_t margin_row_passes;   /* row-major passes (each streams all rows once and serves several trees)  */
     uint64_t split_nodes, descendant_nodes, dummy_normals, retries;
     uint32_t levels;
 } ah_build_stats;
