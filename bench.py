@@ -210,8 +210,8 @@ def extra_c3(device, my_seeds_fn):
            "seconds_library": st["seconds_total"], "seconds_device": st["seconds_device"],
            "seconds_margin_kernel": st["seconds_margin"], "margin_evaluations": st["margin_evaluations"],
            "levels": st["levels"], "split_nodes": st["split_nodes"],
-           "margin_algorithmic_gb_per_s": st["margin_evaluations"] * 4 * DIMS / st["seconds_margin"] / 1e9,
-           "margin_frac_of_hbm_peak": st["margin_evaluations"] * 4 * DIMS / st["seconds_margin"] / 1e9 / HBM_PEAK_GBS}
+           "margin_effective_gb_per_s": st["margin_evaluations"] * 4 * DIMS / st["seconds_margin"] / 1e9,
+           "margin_row_major_passes": st["margin_row_passes"]}
     forest.close()
     ds.close()
     return out
@@ -298,8 +298,10 @@ def main():
                 "seconds_device_rank0": st.get("seconds_device"), "seconds_margin_kernel_rank0": margin_s,
                 "margin_evaluations_rank0": evals, "levels": st.get("levels"),
                 "margins_per_s_rank0": evals / margin_s if margin_s else None,
-                "margin_algorithmic_gb_per_s_rank0": evals * 4 * DIMS / margin_s / 1e9 if margin_s else None,
-                "margin_frac_of_hbm_peak_rank0": evals * 4 * DIMS / margin_s / 1e9 / HBM_PEAK_GBS if margin_s else None,
+                # algorithmic = 4*dims bytes per (item, node visit).  With row-major passes one HBM read of a row serves
+                # several trees, so this is an EFFECTIVE rate (it may exceed the HBM peak), not a roofline fraction.
+                "margin_effective_gb_per_s_rank0": evals * 4 * DIMS / margin_s / 1e9 if margin_s else None,
+                "margin_row_major_passes_rank0": st.get("margin_row_passes"),
                 "split_nodes_rank0": st.get("split_nodes"), "retries_rank0": st.get("retries"),
                 "dummy_normals_rank0": st.get("dummy_normals"), "scaling": "strong",
             }
