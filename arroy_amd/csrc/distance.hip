@@ -4,6 +4,8 @@
 // calls (src/spaces/simple_avx.rs, simple_sse.rs, simple.rs).  All kernels are HBM-bound vector
 // contractions (0.5 flop/byte): no MFMA.  See device_math.h for the lane mapping that makes every f32
 // result bit-identical to the reference's AVX+FMA tier.
+#include <cstdlib>
+
 #include "common.h"
 #include "device_math.h"
 
@@ -11,11 +13,13 @@ namespace ah {
 
 static constexpr int kBlock = 256;       // 4 waves = 32 octets
 static constexpr int kMaxBlocks = 2048;  // 256 CUs x 8 blocks: grid-stride beyond that
+// AH_SCAN_BLOCKS overrides the grid cap of the grid-stride kernels (tuning experiments only)
+static const int g_max_blocks = getenv("AH_SCAN_BLOCKS") ? atoi(getenv("AH_SCAN_BLOCKS")) : kMaxBlocks;
 
 static inline unsigned grid_for(uint64_t work_items, int items_per_block) {
     uint64_t b = (work_items + items_per_block - 1) / items_per_block;
     if (b < 1) b = 1;
-    if (b > (uint64_t)kMaxBlocks) b = kMaxBlocks;
+    if (b > (uint64_t)g_max_blocks) b = g_max_blocks;
     return (unsigned)b;
 }
 
@@ -188,12 +192,14 @@ __global__ __launch_bounds__(kBlock) void k_distances_bq(DataView dv, const uint
     __shared__ float s_hdr[2];
     if (threadIdx.x < 2) s_hdr[threadIdx.x] = qhdr[threadIdx.x];
     __syncthreads();
+    // Each wave owns a private slice of LDS and works on its own tiles: producer and consumer of s_part are lanes
+    // of the SAME wave and LDS operations of one wave complete in issue order, so no workgroup barrier is needed —
+    // only a compiler fence so the reads are not hoisted above the writes.
     const uint64_t n_tiles = (n + 63) >> 6;
-    const uint64_t tiles_per_pass = (uint64_t)gridDim.x * (kBlock / 64);
-    for (uint64_t tile0 = (uint64_t)blockIdx.x * (kBlock / 64); tile0 < n_tiles; tile0 += tiles_per_pass) {
-        const uint64_t tile = tile0 + wave;  // block-uniform trip count: the barriers below are safe
+    const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / 64);
+    for (uint64_t tile = (uint64_t)blockIdx.x * (kBlock / 64) + wave; tile < n_tiles; tile += n_waves) {
         const uint64_t base = tile << 6;
-        const uint32_t rows_here = tile < n_tiles ? (uint32_t)min((uint64_t)64, n - base) : 0u;
+        const uint32_t rows_here = (uint32_t)min((uint64_t)64, n - base);
         for (uint32_t c = 0; c < C; c++) {
             const uint32_t g = c * 64 + lane;
             const uint32_t r = g / C, part = g - r * C;
@@ -208,7 +214,9 @@ __global__ __launch_bounds__(kBlock) void k_distances_bq(DataView dv, const uint
             }
             s_part[g] = pc;
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane < rows_here) {
             const uint64_t i = base + lane;
             uint64_t row = i;
@@ -229,7 +237,9 @@ __global__ __launch_bounds__(kBlock) void k_distances_bq(DataView dv, const uint
                 out[i] = d;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 

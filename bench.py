@@ -163,6 +163,25 @@ def extra_c4(device):
             "seconds": el}
 
 
+def extra_staging(device):
+    """PCIe-inclusive staging: 250k x 768 f32 vectors from pageable host memory through the pinned
+    double buffer into HBM (`ah_dataset_upload_vectors`: rows re-pitched, norms computed on device)."""
+    import numpy as np
+
+    from arroy_amd import Dataset, distances
+    from oracle import oracle as O
+    n = 250_000
+    vecs = O.synth(SEED, 1, n, DIMS)
+    ids = np.arange(n, dtype=np.uint32)
+    ds = Dataset(distances.Cosine, DIMS, n, device=device)
+    t0 = time.perf_counter()
+    ds.upload_vectors(ids, vecs)
+    ds.finalize()
+    el = time.perf_counter() - t0
+    ds.close()
+    return {"workload": f"{n}x{DIMS} f32 from pageable host memory", "seconds": el, "gb_per_s": n * DIMS * 4 / el / 1e9}
+
+
 def extra_search(device):
     """End-to-end on-device search on the configs[3] shape: 1M x 1536 dot product, 20 trees, 1000 by-vector queries,
     count=100, search_k=10000: descent + candidate collection + sort/dedup + re-rank + top-k (src/reader.rs:317-401)."""
@@ -316,6 +335,8 @@ def main():
             extra["c5"] = extra_c5(local_rank)
         if "c4" in wanted and rank == 0:
             extra["c4"] = extra_c4(local_rank)
+        if "staging" in wanted and rank == 0:
+            extra["staging"] = extra_staging(local_rank)
         if "search" in wanted and rank == 0:
             extra["search"] = extra_search(local_rank)
         if "c3" in wanted:

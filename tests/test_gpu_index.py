@@ -176,3 +176,42 @@ def test_search_recall_against_exhaustive_search(api, dist_name):
         qv = reader.nns(k).search_k(2**62).by_vector(vecs[q])
         assert [i for i, _ in qv] == list(exact_ids)
     assert hits / total > (0.5 if dist.binary_quantized else 0.7)
+
+
+def test_write_one_vector_and_until_there_is_a_descendants(api):
+    """src/tests/writer.rs:181-264: up to `dimensions` items the whole tree is one Descendants node per root."""
+    D, I = api
+    db = I.Database(D.Euclidean)
+    w = I.Writer(db, 0, 3)
+    w.add_item(0, [0, 1, 2])
+    w.builder(rng()).n_trees(1).build()
+    st = I.Reader.open(db, 0)._st
+    assert len(st.forest.nodes) == 1 and list(st.forest.descendants_of(0)) == [0]
+    for i in range(1, 3):
+        w.add_item(i, [i, i, i])
+    w.builder(rng()).n_trees(1).build()
+    st = I.Reader.open(db, 0)._st
+    assert len(st.forest.nodes) == 1 and list(st.forest.descendants_of(0)) == [0, 1, 2]
+    # one more item than dimensions: the first split appears (src/tests/writer.rs:266-293)
+    w.add_item(3, [3, 3, 3])
+    w.builder(rng()).n_trees(1).build()
+    st = I.Reader.open(db, 0)._st
+    root = st.forest.nodes[int(st.forest.roots[0])]
+    assert root["kind"] == 2 and root["has_normal"] == 1
+    hdr, vec = st.forest.normal_of(int(st.forest.roots[0]))
+    assert ["%.4f" % abs(x) for x in vec.view(np.float32)] == ["0.5774"] * 3
+    got = sorted(sorted(int(x) for x in st.forest.descendants_of(c)) for c in (int(root["left"]), int(root["right"])))
+    assert sum(len(g) for g in got) == 4 and sorted(sum(got, [])) == [0, 1, 2, 3]
+
+
+def test_write_multiple_indexes(api):
+    """src/tests/writer.rs:323-366: indexes of one database are independent."""
+    D, I = api
+    db = I.Database(D.Euclidean)
+    for index in range(5):
+        w = I.Writer(db, index, 3)
+        w.add_item(0, [0, 1, 2])
+        w.builder(rng()).n_trees(1).build()
+    for index in range(5):
+        r = I.Reader.open(db, index)
+        assert r.item_ids() == [0] and fmt(r.nns(1).by_item(0)) == ["id(0): distance(0)"]

@@ -571,3 +571,54 @@ def test_index_from_caller_owned_arrays():
     tree.nodes["left"][int(tree.roots[0])] = 10**6  # child index out of range
     with pytest.raises(ArroyHipError):
         Index(ds, None, view=O.forest_view(tree))
+
+
+# ---- staging, concurrency -----------------------------------------------------------------------------------
+
+def test_staging_many_chunks_records_and_vectors_agree():
+    """10k x 768 cosine: several 8 MiB staging chunks through both upload paths (LMDB-style records with the stored
+    header vs raw vectors with the header computed on device) give the same dataset."""
+    from arroy_amd import Dataset
+    n, dims = 10_000, 768
+    vecs = O.synth(3, 1, n, dims)
+    od = O.Data(O.COSINE, vecs)
+    a = Dataset(D.Cosine, dims, n)
+    a.upload_vectors(np.arange(n, dtype=np.uint32), vecs)
+    a.finalize()
+    assert_bit_equal(a.read_headers().ravel(), od.headers.ravel(), "norms computed on device == oracle new_header")
+    records = [b"\x00" + od.headers[i].tobytes() + vecs[i].tobytes() for i in range(n)]
+    b = Dataset(D.Cosine, dims, n)
+    b.upload_records(np.arange(n, dtype=np.uint32), records)
+    b.finalize()
+    q = O.synth(9, 1, 1, dims)[0]
+    assert_bit_equal(a.distances(query=q), b.distances(query=q))
+    assert_bit_equal(b.item_vector(n - 1), vecs[n - 1])
+    qv, qh = od.query_leaf(q)
+    assert_bit_equal(a.distances(query=q), od.distances(qv, qh))
+
+
+def test_concurrent_queries_from_many_threads():
+    """`Reader` is Sync: many host threads share one finalized dataset (each call leases its own stream + scratch)."""
+    import threading
+    n, dims = 20_000, 96
+    ds, oracle, vecs, ids = make_data(D.Cosine, n, dims, seed=4)
+    queries = np.random.default_rng(0).standard_normal((16, dims)).astype(np.float32)
+    expect = [ds.rerank(25, query=q) for q in queries]
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(30):
+                qi = (tid * 7 + rep) % len(queries)
+                i, d = ds.rerank(25, query=queries[qi])
+                if not (np.array_equal(i, expect[qi][0]) and d.tobytes() == expect[qi][1].tobytes()):
+                    errors.append((tid, rep))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
