@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <new>
+#include <thread>
 
 #include "common.h"
 
@@ -66,6 +67,26 @@ struct Carver {
     }
 };
 static inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// The host side of staging is a gather of records out of (unaligned) storage pages into pinned memory; one core
+// cannot keep a PCIe Gen5 link busy, so large chunks are split over a few threads.
+template <typename F>
+static void parallel_rows(size_t n, F &&fn) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t n_threads = std::min<size_t>(std::min<unsigned>(hw, 8u), n / 256);
+    if (n_threads <= 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = (n + n_threads - 1) / n_threads;
+    for (size_t t = 0; t < n_threads; t++) {
+        const size_t lo = t * per, hi = std::min(n, lo + per);
+        if (lo >= hi) break;
+        pool.emplace_back([&fn, lo, hi] { fn(lo, hi); });
+    }
+    for (auto &th : pool) th.join();
+}
 
 }  // namespace ah
 
@@ -251,7 +272,7 @@ int ah_dataset_upload_records(ah_dataset *ds, const uint32_t *item_ids, const ui
                "record length %zu does not match 1 + %zu + %zu for %u dimensions", record_len, hs, vs, ds->dims);
     AH_LEASE(ds, ctx);
     const size_t rb = ds->row_bytes();
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (8u << 20) / (rb + hs + 4)));
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (32u << 20) / (rb + hs + 4)));
     const size_t buf_bytes = pad256(chunk * rb) + pad256(chunk * hs) + pad256(chunk * 4);
     AH_TRY(ctx->ensure_pinned(2 * buf_bytes));
     hipEvent_t ev[2] = {ctx->ev0, ctx->ev1};
@@ -267,10 +288,15 @@ int ah_dataset_upload_records(ah_dataset *ds, const uint32_t *item_ids, const ui
             const uint8_t *rec = record_ptrs[done + i];
             AH_REQUIRE(rec && rec[0] == 0, AH_ERR_INVALID_ARGUMENT, "record %zu is not a leaf (tag %d)", done + i,
                        rec ? rec[0] : -1);
-            memcpy(h_hdr + i * hs, rec + 1, hs);
-            memcpy(h_rows + i * rb, rec + 1 + hs, vs);
-            if (rb > vs) memset(h_rows + i * rb + vs, 0, rb - vs);
         }
+        parallel_rows(c, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                const uint8_t *rec = record_ptrs[done + i];
+                memcpy(h_hdr + i * hs, rec + 1, hs);
+                memcpy(h_rows + i * rb, rec + 1 + hs, vs);
+                if (rb > vs) memset(h_rows + i * rb + vs, 0, rb - vs);
+            }
+        });
         memcpy(h_ids, item_ids + done, c * 4);
         const uint64_t row0 = ds->n + done;
         uint8_t *d_rows = ds->d_rows_f32 ? reinterpret_cast<uint8_t *>(ds->d_rows_f32)
@@ -299,7 +325,7 @@ int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, const fl
     const bool bq = metric_is_bq(ds->metric);
     const uint32_t fpitch = bq ? ((ds->dims + 3u) & ~3u) : ds->pitch;  // staging pitch in floats
     const size_t frb = (size_t)fpitch * 4;
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (8u << 20) / (frb + 4)));
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (32u << 20) / (frb + 4)));
     const size_t buf_bytes = pad256(chunk * frb) + pad256(chunk * 4);
     AH_TRY(ctx->ensure_pinned(2 * buf_bytes));
     if (bq) AH_TRY(ctx->ensure_device(2 * pad256(chunk * frb)));
@@ -314,10 +340,12 @@ int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, const fl
         if (used[b]) AH_HIP(hipEventSynchronize(ev[b]));
         float *h_rows = reinterpret_cast<float *>(base);
         uint8_t *h_ids = base + pad256(chunk * frb);
-        for (size_t i = 0; i < c; i++) {
-            memcpy(h_rows + i * fpitch, vectors + (done + i) * (size_t)ds->dims, (size_t)ds->dims * 4);
-            for (uint32_t e = ds->dims; e < fpitch; e++) h_rows[i * fpitch + e] = 0.0f;
-        }
+        parallel_rows(c, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                memcpy(h_rows + i * fpitch, vectors + (done + i) * (size_t)ds->dims, (size_t)ds->dims * 4);
+                for (uint32_t e = ds->dims; e < fpitch; e++) h_rows[i * fpitch + e] = 0.0f;
+            }
+        });
         memcpy(h_ids, item_ids + done, c * 4);
         const uint64_t row0 = ds->n + done;
         if (!bq) {
@@ -875,28 +903,26 @@ int ah_bench_scan(ah_dataset *ds, uint32_t query_item, uint64_t n, uint32_t iter
 int ah_bench_memcpy(int device, uint64_t bytes, uint32_t iterations, double *out_ms_total) {
     AH_REQUIRE(out_ms_total && iterations > 0 && bytes > 0, AH_ERR_INVALID_ARGUMENT, "bad arguments");
     AH_HIP(hipSetDevice(device));
-    void *a = nullptr, *b = nullptr;
-    hipStream_t s;
-    hipEvent_t e0, e1;
-    AH_HIP(hipMalloc(&a, bytes));
-    AH_HIP(hipMalloc(&b, bytes));
-    AH_HIP(hipStreamCreate(&s));
-    AH_HIP(hipEventCreate(&e0));
-    AH_HIP(hipEventCreate(&e1));
-    AH_HIP(hipMemsetAsync(a, 1, bytes, s));
-    AH_HIP(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, s));
-    AH_HIP(hipEventRecord(e0, s));
-    for (uint32_t i = 0; i < iterations; i++) AH_HIP(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, s));
-    AH_HIP(hipEventRecord(e1, s));
-    AH_HIP(hipEventSynchronize(e1));
+    DevMem a, b;
+    Context c;  // stream + two events, destroyed on every path
+    struct Guard {
+        Context &c;
+        ~Guard() { c.destroy(); }
+    } guard{c};
+    AH_HIP(hipMalloc(&a.p, bytes));
+    AH_HIP(hipMalloc(&b.p, bytes));
+    AH_HIP(hipStreamCreate(&c.stream));
+    AH_HIP(hipEventCreate(&c.ev0));
+    AH_HIP(hipEventCreate(&c.ev1));
+    AH_HIP(hipMemsetAsync(a.p, 1, bytes, c.stream));
+    AH_HIP(hipMemcpyAsync(b.p, a.p, bytes, hipMemcpyDeviceToDevice, c.stream));
+    AH_HIP(hipEventRecord(c.ev0, c.stream));
+    for (uint32_t i = 0; i < iterations; i++) AH_HIP(hipMemcpyAsync(b.p, a.p, bytes, hipMemcpyDeviceToDevice, c.stream));
+    AH_HIP(hipEventRecord(c.ev1, c.stream));
+    AH_HIP(hipEventSynchronize(c.ev1));
     float ms = 0.0f;
-    AH_HIP(hipEventElapsedTime(&ms, e0, e1));
+    AH_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
     *out_ms_total = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipStreamDestroy(s);
-    (void)hipFree(a);
-    (void)hipFree(b);
     return AH_OK;
 }
 

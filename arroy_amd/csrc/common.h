@@ -121,6 +121,21 @@ struct ah_dataset {
 
 namespace ah {
 
+// owning device pointer for short-lived buffers on paths with early error returns
+struct DevMem {
+    void *p = nullptr;
+    DevMem() = default;
+    DevMem(const DevMem &) = delete;
+    DevMem &operator=(const DevMem &) = delete;
+    ~DevMem() {
+        if (p) (void)hipFree(p);
+    }
+    template <typename T>
+    T *as() const {
+        return reinterpret_cast<T *>(p);
+    }
+};
+
 struct ContextLease {
     ah_dataset *ds;
     Context *c;

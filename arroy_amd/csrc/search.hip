@@ -489,18 +489,15 @@ int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_ind
     if (v.descendants_len)
         AH_IX(hipMemcpy(ix->d_desc, v.descendants, v.descendants_len * 4, hipMemcpyHostToDevice));
     if (ix->n_normals) {
-        uint8_t *d_recs = nullptr;
-        uint64_t *d_offs = nullptr;
-        AH_IX(hipMalloc((void **)&d_recs, v.normals_len));
-        AH_IX(hipMalloc((void **)&d_offs, offsets.size() * 8));
-        AH_IX(hipMemcpy(d_recs, v.normals, v.normals_len, hipMemcpyHostToDevice));
-        AH_IX(hipMemcpy(d_offs, offsets.data(), offsets.size() * 8, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_unpack_normals, dim3(ix->n_normals), dim3(256), 0, 0, d_recs, d_offs, ix->n_normals,
-                           v.normal_vector_offset, v.normal_header_offset, (uint32_t)(row_bytes / 4), hf,
+        DevMem recs, offs;
+        AH_IX(hipMalloc(&recs.p, v.normals_len));
+        AH_IX(hipMalloc(&offs.p, offsets.size() * 8));
+        AH_IX(hipMemcpy(recs.p, v.normals, v.normals_len, hipMemcpyHostToDevice));
+        AH_IX(hipMemcpy(offs.p, offsets.data(), offsets.size() * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_unpack_normals, dim3(ix->n_normals), dim3(256), 0, 0, recs.as<uint8_t>(), offs.as<uint64_t>(),
+                           ix->n_normals, v.normal_vector_offset, v.normal_header_offset, (uint32_t)(row_bytes / 4), hf,
                            reinterpret_cast<uint32_t *>(ix->d_nrows), ix->d_nhdrs);
         AH_IX(hipDeviceSynchronize());
-        (void)hipFree(d_recs);
-        (void)hipFree(d_offs);
     }
 #undef AH_IX
     (void)st;
@@ -623,14 +620,12 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     for (size_t q = 0; q < nq; q++)
         if (h_overflow[q]) h_list[n_over++] = (uint32_t)q;
     if (n_over) {  // 2b. the rare big queues: re-run with the queue in global memory (hard capacity bound)
-        uint64_t *d_heap = nullptr;
-        AH_HIP(hipMalloc((void **)&d_heap, (size_t)n_over * heap_cap * 8));
+        DevMem heap;
+        AH_HIP(hipMalloc(&heap.p, (size_t)n_over * heap_cap * 8));
         AH_HIP(hipMemcpyAsync(d_list, h_list, n_over * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL((k_descend<true>), dim3((n_over + 7) / 8), dim3(64), 0, s, ix->nv, sp, (const uint32_t *)d_list,
-                           n_over, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, d_heap, heap_cap);
-        hipError_t e = hipStreamSynchronize(s);
-        (void)hipFree(d_heap);
-        AH_HIP(e);
+                           n_over, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, heap.as<uint64_t>(), heap_cap);
+        AH_HIP(hipStreamSynchronize(s));
     }
     // 3. sort + dedup
     AH_HIP(hipMemcpyAsync(h_counts, d_counts, nq * 4, hipMemcpyDeviceToHost, s));
@@ -780,24 +775,26 @@ int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_it
     AH_REQUIRE(lease.c, AH_ERR_DEVICE, "cannot create a HIP stream");
     Context *ctx = lease.c;
     // candidate filter -> bitmap over item ids
+    DevMem bits_mem;
     uint32_t *d_bits = nullptr;
     uint32_t bits_len = 0;
     if (have_filter) {
         const uint32_t max_id = ds->identity_ids ? (uint32_t)(ds->n - 1) : ds->last_id;
         bits_len = max_id + 1;
         const size_t words = ((size_t)bits_len + 31) / 32;
-        AH_HIP(hipMalloc((void **)&d_bits, words * 4));
+        AH_HIP(hipMalloc(&bits_mem.p, words * 4));
+        d_bits = bits_mem.as<uint32_t>();
         AH_HIP(hipMemsetAsync(d_bits, 0, words * 4, ctx->stream));
         std::vector<uint32_t> keep;
         for (size_t i = 0; i < n_filter; i++)
             if (filter_sorted[i] <= max_id) keep.push_back(filter_sorted[i]);
         if (!keep.empty()) {
-            uint32_t *d_f = nullptr;
-            AH_HIP(hipMalloc((void **)&d_f, keep.size() * 4));
-            AH_HIP(hipMemcpyAsync(d_f, keep.data(), keep.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(k_filter_bitmap, dim3(256), dim3(256), 0, ctx->stream, d_f, (uint64_t)keep.size(), d_bits);
+            DevMem f;
+            AH_HIP(hipMalloc(&f.p, keep.size() * 4));
+            AH_HIP(hipMemcpyAsync(f.p, keep.data(), keep.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_filter_bitmap, dim3(256), dim3(256), 0, ctx->stream, f.as<uint32_t>(), (uint64_t)keep.size(),
+                               d_bits);
             AH_HIP(hipStreamSynchronize(ctx->stream));
-            (void)hipFree(d_f);
         }
     }
     // sub-batches bounded by scratch (~1.5 GiB of candidate buffers)
@@ -811,7 +808,6 @@ int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_it
                           c, count, (uint32_t)sk_eff, (uint32_t)stride, d_bits, bits_len, out_ids + q0 * count,
                           out_distances + q0 * count, out_counts + q0);
     }
-    if (d_bits) (void)hipFree(d_bits);
     return st;
 }
 
