@@ -160,3 +160,10 @@ def device_name(device: int = 0) -> str:
     buf = C.create_string_buffer(256)
     check(lib().ah_device_name(device, buf, 256))
     return buf.value.decode()
+
+
+def bench_memcpy(device: int, nbytes: int, iterations: int) -> float:
+    """Device-to-device copy of `nbytes` x `iterations`; returns total milliseconds (HIP events)."""
+    ms = C.c_double(0)
+    check(lib().ah_bench_memcpy(device, nbytes, iterations, C.byref(ms)))
+    return ms.value

@@ -281,6 +281,7 @@ def main():
         scan_ms = elapsed * 1e3 / max(args.steps, 1)
         build = {"trees": args.trees, "trees_this_rank": len(my_trees), "seconds": max_over_ranks(0.001 * len(my_trees))}
         kernel_ms = scan_ms
+        copy_gbs = None
         dev_name = "dry-run (cpu, gloo)"
         cpu = None
     else:
@@ -300,6 +301,11 @@ def main():
         barrier_sync()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         kernel_ms = max_over_ranks(kernel_ms_total / args.steps)
+        # measured streaming ceiling of this device, next to the spec peak: a 2 GiB device-to-device copy
+        from arroy_amd import _lib as ahlib
+        cp_bytes, cp_iters = 2 << 30, 10
+        cp_ms = ahlib.bench_memcpy(local_rank, cp_bytes, cp_iters)
+        copy_gbs = 2 * cp_bytes * cp_iters / (cp_ms * 1e-3) / 1e9  # read + write
         build = None
         if not args.no_build and args.trees > 0:
             barrier_sync()
@@ -363,6 +369,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "ah::k_distances_f32<COSINE,false>", "kernel_ms": kernel_ms,
+                         "measured_d2d_copy_gb_per_s": copy_gbs,
                          "algorithmic_bytes_per_launch": n * BYTES_PER_DISTANCE},
             "cpu_baseline": cpu,
             "build": build,
