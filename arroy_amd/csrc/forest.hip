@@ -511,6 +511,7 @@ bool g_debug = getenv("AH_DEBUG") != nullptr;
 // AH_ROWMAJOR_CACHE_MB = budget for one group's normals (default 16 MiB: measured optimum on MI355X, the
 // normals of a group are shared by all XCDs through the Infinity Cache).
 int g_rows_force = getenv("AH_ROWMAJOR") ? atoi(getenv("AH_ROWMAJOR")) : -1;
+uint32_t g_rows_max_tc = getenv("AH_ROWMAJOR_MAX_TC") ? (uint32_t)atoi(getenv("AH_ROWMAJOR_MAX_TC")) : 16u;
 uint64_t g_rows_cache_bytes = (uint64_t)(getenv("AH_ROWMAJOR_CACHE_MB") ? atof(getenv("AH_ROWMAJOR_CACHE_MB")) : 16.0) * (1u << 20);
 #define AH_DBG(s, what)                                                       \
     do {                                                                      \
@@ -676,7 +677,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             uint64_t pairs = 0;
             for (uint32_t i = 0; i < n_nodes; i++) pairs += level[i].count;
             const uint64_t nodes_per_tree = (n_nodes + n_trees - 1) / n_trees;
-            uint32_t tc = 16;
+            uint32_t tc = g_rows_max_tc;
             while (tc > 1 && (uint64_t)tc * nodes_per_tree * nstride > g_rows_cache_bytes) tc >>= 1;
             while (tc > 2 && tc / 2 >= n_trees) tc >>= 1;  // do not instantiate more slots than trees
             const uint64_t passes = (n_trees + tc - 1) / tc;
