@@ -188,7 +188,7 @@ def extra_search(device):
     import numpy as np
 
     from arroy_amd import Dataset, distances, shard
-    n, dims, nq, k, n_trees = 1_000_000, 1536, 1000, 100, 20
+    n, dims, nq, k, n_trees = 1_000_000, 1536, int(os.environ.get("AH_BENCH_SEARCH_QUERIES", "1000")), 100, 20
     ds = Dataset(distances.DotProduct, dims, n, device=device)
     ds.fill_synthetic(SEED, 1, n)
     ds.preprocess_dot()

@@ -622,3 +622,46 @@ def test_concurrent_queries_from_many_threads():
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+# ---- numeric corner cases ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("metric", [0, 1, 2, 3])
+@pytest.mark.parametrize("scale", [1e-22, 1e-12, 1e12, 3e18])
+def test_subnormal_and_huge_magnitudes_stay_bit_exact(metric, scale):
+    """Products in the subnormal range (scale^2 ~ 1e-44) and sums that overflow to +inf must match the reference's
+    IEEE behaviour: no flush-to-zero, correctly rounded sqrt / div, inf handled like the CPU.  (NaN *payloads* are
+    outside the contract: x86 generates 0xFFC00000, the GPU 0x7FC00000; inputs here never produce NaN.)"""
+    cls = D.BY_METRIC[metric]
+    n, dims = 500, 96
+    ds, oracle, vecs, ids = make_data(cls, n, dims, seed=17 + metric, scale=scale)
+    q = (np.abs(np.random.default_rng(5).standard_normal(dims)) * scale).astype(np.float32)
+    qv, qh = oracle.query_leaf(q)
+    with np.errstate(all="ignore"):
+        want = oracle.distances(qv, qh)
+    got = ds.distances(query=q)
+    finite_or_inf = ~np.isnan(want)
+    assert finite_or_inf.sum() > n // 2
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert_bit_equal(got[finite_or_inf], want[finite_or_inf], f"scale={scale}")
+    oi, od = ds.rerank(20, query=q)
+    ei, ed = oracle.rerank(qv, qh, None, 20)
+    assert list(oi) == list(ei)
+
+
+@pytest.mark.parametrize("metric", [3, 4, 6])
+def test_upload_records_with_stored_headers_for_dot_and_bq(metric):
+    """`ImmutableLeafs` staging for the metrics whose stored header / codec is not trivial: DotProduct records carry
+    {extra_dim, norm} written by `preprocess` (src/distance/dot_product.rs:119-165), 1-bit records carry packed words."""
+    from arroy_amd import Dataset
+    cls = D.BY_METRIC[metric]
+    n, dims = 900, 70
+    ds_a, oracle, vecs, ids = make_data(cls, n, dims, seed=33 + metric)  # upload_vectors (+ preprocess for dot)
+    records = [b"\x00" + oracle.headers[i].tobytes() + oracle.codec[i].tobytes() for i in range(n)]
+    ds_b = Dataset(cls, dims, n)
+    ds_b.upload_records(np.arange(n, dtype=np.uint32), records)
+    ds_b.finalize()
+    assert_bit_equal(ds_a.read_headers().ravel(), ds_b.read_headers().ravel())
+    assert_bit_equal(ds_a.distances(item=3), ds_b.distances(item=3))
+    fa, fb = ds_a.build_forest([5], split_after=30), ds_b.build_forest([5], split_after=30)
+    assert fa.canonical(0) == fb.canonical(0) == oracle.build_tree(30, 5).canonical()
