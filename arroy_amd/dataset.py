@@ -243,9 +243,11 @@ class Index:
         else:
             _lib.check(_lib.lib().ah_index_create(dataset._h, forest._h, C.byref(self._h)))
 
-    def search(self, count: int, queries=None, items=None, search_k: int = 0, oversampling: int = 0, candidates=None):
+    def search(self, count: int, queries=None, items=None, search_k: int = 0, oversampling: int = 0, candidates=None,
+               raw: bool = False):
         """Batch of `QueryBuilder::by_vector` (queries: nq x dims) or `by_item` (items: nq ids).
-        Returns a list (one entry per query) of [(id, distance), ...]."""
+        Returns a list (one entry per query) of [(id, distance), ...]; with raw=True the (ids, distances, counts)
+        arrays of the C ABI (no per-result Python objects)."""
         ds = self.dataset
         if queries is not None:
             q = _f32(queries)
@@ -265,6 +267,8 @@ class Index:
         _lib.check(_lib.lib().ah_search_batch(self._h, _ptr(q), _ptr(it), nq, int(count), int(min(search_k, 2**62)),
                                               int(oversampling), _ptr(filt), 0 if filt is None else filt.size,
                                               0 if filt is None else 1, _ptr(oi), _ptr(od), _ptr(oc)))
+        if raw:
+            return oi, od, oc
         return [[(int(oi[i, j]), float(od[i, j])) for j in range(int(oc[i]))] for i in range(nq)]
 
     def route_items(self, item_ids: Sequence[int], tree_seeds: Sequence[int]) -> np.ndarray:
