@@ -64,7 +64,11 @@ AH_HD uint64_t ah_bounded(uint64_t r, uint64_t n) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __umul64hi(r, n);
 #else
-    return (uint64_t)(((unsigned __int128)r * (unsigned __int128)n) >> 64);
+    /* portable C99: high 64 bits of the 128-bit product from four 32x32 partial products */
+    const uint64_t a_lo = r & 0xFFFFFFFFu, a_hi = r >> 32, b_lo = n & 0xFFFFFFFFu, b_hi = n >> 32;
+    const uint64_t p0 = a_lo * b_lo, p1 = a_lo * b_hi, p2 = a_hi * b_lo, p3 = a_hi * b_hi;
+    const uint64_t mid = (p0 >> 32) + (p1 & 0xFFFFFFFFu) + (p2 & 0xFFFFFFFFu);
+    return p3 + (p1 >> 32) + (p2 >> 32) + (mid >> 32);
 #endif
 }
 

@@ -61,3 +61,27 @@ def test_policy_header_matches_between_host_compilers():
     assert y.min() >= -1.0 and y.max() < 1.0
     assert (y == x * 2 - 1).all()
     assert not (O.synth(43, 0, 4, 8) == x).all()
+
+
+def test_public_headers_are_plain_c99(tmp_path):
+    """The boundary is a C ABI: both public headers must compile as strict C99 with gcc (no C++/HIP needed), and a C
+    program using them must link against the shared object."""
+    import subprocess
+    src = tmp_path / "use.c"
+    src.write_text(
+        '#include "arroy_hip.h"\n#include "arroy_hip_policy.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        "  ah_build_options o; ah_forest_view v; ah_build_stats s; (void)o; (void)v; (void)s;\n"
+        "  uint64_t a, b; ah_choose_two(ah_node_key_root(42), 0, 10, &a, &b);\n"
+        "  if (a == b || a >= 10 || b >= 10) return 2;\n"
+        "  if (ah_abi_version() != AH_ABI_VERSION) return 3;\n"
+        "  if (ah_header_size(AH_DOT_PRODUCT) != 8 || ah_vector_size(AH_BQ_COSINE, 768) != 96) return 4;\n"
+        '  printf("%s%d\\n", ah_last_error(), (int)sizeof(ah_node));\n  return 0;\n}\n')
+    exe = tmp_path / "use"
+    lib_dir = os.path.join(ROOT, "arroy_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", lib_dir, "-larroy_hip", f"-Wl,-rpath,{lib_dir}",
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stderr)
+    assert out.stdout.strip() == "32"
