@@ -2,9 +2,10 @@
 `QueryBuilder` (src/writer.rs:37-485, src/reader.rs:26-298) over an in-memory item store instead of LMDB.
 
 Scope: this mirror exists so that the parity tests read like the reference's own tests and so that the
-C ABI is exercised the way arroy's Rust host code would drive it.  It implements the *full rebuild* path
-(`Writer::build` with every tree missing) and the search; LMDB, the incremental insert/delete machinery,
-upgrades and `available_memory` batching are out of scope.  All distance / margin / split
+C ABI is exercised the way arroy's Rust host code would drive it.  It implements `Writer::build` — the full
+build, and the incremental one (updated items leave the trees, new ones are routed by `ah_route_items`,
+overgrown descendants are re-split by `ah_build_subtrees`, trees are added / dropped per `target_n_trees`) —
+and the search; LMDB, upgrades and `available_memory` batching are out of scope.  All distance / margin / split
 arithmetic is done by libarroy_hip.so; the host only keeps dictionaries, a priority queue and id lists —
 exactly the split of work of the Rust integration.
 """
@@ -69,14 +70,115 @@ def target_n_trees(n_trees: Optional[int], dimensions: int, n_items: int, n_root
     return nb_trees
 
 
+class TreeStore:
+    """Host-side tree nodes — what arroy keeps in LMDB under `Key::tree` (src/node.rs:216-241):
+    id -> ("D", ascending ids) | ("S", left, right, header f32[], vector bytes or None)."""
+
+    def __init__(self):
+        self.nodes: Dict[int, tuple] = {}
+        self.roots: List[int] = []
+        self._next = 0
+
+    def next_id(self) -> int:  # ConcurrentNodeIds::next (src/parallel.rs:239-254) without id reuse
+        self._next += 1
+        return self._next - 1
+
+    def import_tree(self, forest: Forest, tree: int, root_id: Optional[int] = None) -> int:
+        """Copy tree `tree` of a freshly built ah_forest; children get fresh ids before their parent (the order
+        `make_tree_in_file` allocates them, src/writer.rs:1235-1258), the root takes `root_id` when given
+        (`Some(descendant_id)`, src/writer.rs:693-702)."""
+        order, stack = [], [int(forest.roots[tree])]
+        while stack:  # reverse post-order, then reversed: children before parents
+            i = stack.pop()
+            order.append(i)
+            nd = forest.nodes[i]
+            if nd["kind"] == 2:
+                stack += [int(nd["left"]), int(nd["right"])]
+        ids: Dict[int, int] = {}
+        for i in reversed(order):
+            nd = forest.nodes[i]
+            is_root = i == int(forest.roots[tree])
+            ids[i] = root_id if (is_root and root_id is not None) else self.next_id()
+            if nd["kind"] == 1:
+                self.nodes[ids[i]] = ("D", forest.descendants_of(i).copy())
+            else:
+                normal = forest.normal_of(i)
+                hdr, vec = normal if normal is not None else (np.zeros(forest.distance.header_size() // 4, np.float32), None)
+                self.nodes[ids[i]] = ("S", ids[int(nd["left"])], ids[int(nd["right"])], hdr,
+                                      None if vec is None else vec.tobytes())
+        return ids[int(forest.roots[tree])]
+
+    def subtree_ids(self, root: int) -> List[int]:
+        out, stack = [], [root]
+        while stack:
+            i = stack.pop()
+            out.append(i)
+            nd = self.nodes[i]
+            if nd[0] == "S":
+                stack += [nd[1], nd[2]]
+        return out
+
+    def to_view(self, distance: type[Distance], dimensions: int):
+        """Dense arrays in the ah_forest_view shape (records [header][vector]); returns (view, keepalive)."""
+        import ctypes as C
+        order = sorted(self.nodes)
+        dense = {nid: i for i, nid in enumerate(order)}
+        hs, vs = distance.header_size(), distance.vector_size(dimensions)
+        node_dt = np.dtype([("kind", "u1"), ("has_normal", "u1"), ("tree", "<u2"), ("left", "<u4"), ("right", "<u4"),
+                            ("offset", "<u8"), ("count", "<u4"), ("depth", "<u4")], align=True)
+        nodes = np.zeros(len(order), dtype=node_dt)
+        normals, desc = bytearray(), []
+        n_desc = 0
+        for nid in order:
+            nd, i = self.nodes[nid], dense[nid]
+            if nd[0] == "D":
+                nodes[i] = (1, 0, 0, 0, 0, n_desc, len(nd[1]), 0)
+                desc.append(np.asarray(nd[1], dtype=np.uint32))
+                n_desc += len(nd[1])
+            else:
+                has = nd[4] is not None
+                nodes[i] = (2, 1 if has else 0, 0, dense[nd[1]], dense[nd[2]], len(normals), 0, 0)
+                if has:
+                    normals += np.asarray(nd[3], dtype=np.float32).tobytes().ljust(hs, b"\0")[:hs] + nd[4]
+        normals_a = np.frombuffer(bytes(normals), dtype=np.uint8).copy() if normals else np.zeros(1, np.uint8)
+        desc_a = np.concatenate(desc).astype(np.uint32) if desc and n_desc else np.zeros(1, np.uint32)
+        roots_a = np.array([dense[r] for r in self.roots], dtype=np.uint32) if self.roots else np.zeros(1, np.uint32)
+        v = _lib.AhForestView()
+        v.n_trees, v.n_nodes = len(self.roots), len(order)
+        v.roots = roots_a.ctypes.data_as(C.POINTER(C.c_uint32))
+        v.nodes = C.cast(nodes.ctypes.data, C.POINTER(_lib.AhNode))
+        v.normals = normals_a.ctypes.data_as(C.POINTER(C.c_uint8))
+        v.normals_len = len(normals)
+        v.normal_stride, v.normal_vector_offset, v.normal_header_offset = hs + vs, hs, 0
+        v.descendants = desc_a.ctypes.data_as(C.POINTER(C.c_uint32))
+        v.descendants_len = n_desc
+        return v, (nodes, normals_a, desc_a, roots_a, dense)
+
+    def stats(self, root: int) -> dict:  # `Reader::stats` per tree (src/reader.rs:210-252)
+        depth = splits = dummies = descs = 0
+        stack = [(root, 1)]
+        while stack:
+            i, d = stack.pop()
+            depth = max(depth, d)
+            nd = self.nodes[i]
+            if nd[0] == "D":
+                descs += 1
+            else:
+                splits += 1
+                dummies += 0 if nd[4] is not None else 1
+                stack += [(nd[1], d + 1), (nd[2], d + 1)]
+        return {"depth": depth, "split_nodes": splits, "dummy_normals": dummies, "descendants": descs}
+
+
 class _IndexState:
     def __init__(self):
         self.items: Dict[ItemId, np.ndarray] = {}
         self.updated: set = set()          # the `Updated` key set (src/writer.rs:391)
         self.metadata: Optional[dict] = None
         self.dataset: Optional[Dataset] = None
-        self.forest: Optional[Forest] = None
-        self.index = None  # arroy_amd.Index: dataset + forest resident in HBM
+        self.trees: Optional[TreeStore] = None
+        self.index = None    # arroy_amd.Index: dataset + tree nodes resident in HBM
+        self._keep = None    # arrays the index view was built from
 
 
 class Database:
@@ -158,14 +260,20 @@ class ArroyBuilder:
         self._progress = fn
         return self
 
-    def build(self) -> None:  # Writer::build, src/writer.rs:487-629 (full rebuild)
+    def build(self) -> None:
+        """`Writer::build` (src/writer.rs:487-629): a full build when the index has no trees yet, otherwise the
+        incremental path — remove updated items from the trees (:525), route the new / changed ones through the
+        existing planes (:541-542, `ah_route_items`), re-split the descendants that outgrew `split_after` (:660-739,
+        `ah_build_subtrees`), then add or drop whole trees to reach `target_n_trees` (:521-524, 556-561)."""
         w, st = self._w, self._w._st
         if self._cancel is not None and self._cancel():
             raise _lib.BuildCancelled(2, "build cancelled")
         dist = w.database.distance
         ids = np.array(sorted(st.items), dtype=np.uint32)
         n = ids.size
-        st.dataset = st.forest = st.index = None
+        split_after = self._split_after or w.dimensions
+        st.index = None
+        ds = None
         if n:
             vecs = np.stack([st.items[int(i)] for i in ids])
             ds = Dataset(dist, w.dimensions, n)
@@ -173,18 +281,78 @@ class ArroyBuilder:
             if dist.metric == 3:
                 ds.preprocess_dot()  # pre_process_items, src/writer.rs:964-976
             ds.finalize()
+        st.dataset = ds
+        if n <= split_after:
+            # clear_db_and_create_a_single_leaf (src/writer.rs:916-962): ONE Descendants root, whatever n_trees says
+            st.trees = TreeStore()
+            if n:
+                root = st.trees.next_id()
+                st.trees.nodes[root] = ("D", ids.copy())
+                st.trees.roots = [root]
+        elif st.trees is None or not st.trees.roots or st.metadata is None:
+            st.trees = TreeStore()
             n_trees = target_n_trees(self._n_trees, w.dimensions, n, 0)
-            seeds = [self._rng.getrandbits(64) for _ in range(n_trees)]  # one RNG per root task (:575)
-            forest = ds.build_forest(seeds, split_after=self._split_after or 0, cancel=self._cancel,
-                                     progress=self._progress)
-            st.dataset, st.forest = ds, forest
-            st.index = ds.create_index(forest)  # forest mirrored in HBM for the on-device search
-            roots = [int(r) for r in forest.roots]
+            self._add_trees(ds, st.trees, n_trees, split_after)
         else:
-            roots = []
-        st.metadata = {"dimensions": w.dimensions, "items": [int(i) for i in ids], "roots": roots,
+            self._incremental(ds, st, ids, split_after)
+        if n:
+            view, keep = st.trees.to_view(dist, w.dimensions)
+            from .dataset import Index
+            st.index, st._keep = Index(ds, None, view=view), keep
+        st.metadata = {"dimensions": w.dimensions, "items": [int(i) for i in ids], "roots": list(st.trees.roots),
                        "distance": dist.name}  # src/writer.rs:611-626
         st.updated.clear()
+
+    def _seeds(self, count: int) -> List[int]:
+        return [self._rng.getrandbits(64) for _ in range(count)]  # one RNG per task (src/writer.rs:575,795)
+
+    def _add_trees(self, ds: Dataset, trees: TreeStore, count: int, split_after: int) -> None:
+        if count <= 0:
+            return
+        forest = ds.build_forest(self._seeds(count), split_after=split_after, cancel=self._cancel, progress=self._progress)
+        for t in range(forest.n_trees):
+            root = trees.next_id()  # roots are allocated before their subtree (src/writer.rs:556-561)
+            trees.import_tree(forest, t, root_id=root)
+            trees.roots.append(root)
+
+    def _incremental(self, ds: Dataset, st: "_IndexState", ids: np.ndarray, split_after: int) -> None:
+        from .dataset import Index
+        w, trees, dist = self._w, st.trees, self._w.database.distance
+        present = set(int(i) for i in ids)
+        to_delete = np.array(sorted(st.updated), dtype=np.uint32)                 # :504
+        to_insert = np.array(sorted(i for i in st.updated if i in present), dtype=np.uint32)  # :505
+        # target_n_trees / delete_extra_trees (:521-522)
+        want = target_n_trees(self._n_trees, w.dimensions, len(ids), len(trees.roots))
+        while len(trees.roots) > want:
+            for nid in trees.subtree_ids(trees.roots.pop()):
+                del trees.nodes[nid]
+        # delete_items_from_trees (:525): updated ids leave every Descendants node (structure kept)
+        if to_delete.size:
+            for nid, nd in trees.nodes.items():
+                if nd[0] == "D" and len(nd[1]):
+                    trees.nodes[nid] = ("D", np.setdiff1d(nd[1], to_delete, assume_unique=True).astype(np.uint32))
+        # insert_items_in_current_trees (:541-542): one ah_route_items call for all trees
+        if to_insert.size and trees.roots:
+            view, keep = trees.to_view(dist, w.dimensions)
+            dense = keep[4]
+            back = {i: nid for nid, i in dense.items()}
+            old = Index(ds, None, view=view)
+            leaf_of = old.route_items(to_insert, self._seeds(len(trees.roots)))
+            old.close()
+            grown: Dict[int, List[int]] = {}
+            for t in range(leaf_of.shape[0]):
+                for i, leaf in enumerate(leaf_of[t]):
+                    grown.setdefault(back[int(leaf)], []).append(int(to_insert[i]))
+            for nid, extra in grown.items():
+                trees.nodes[nid] = ("D", np.union1d(trees.nodes[nid][1], np.array(extra, dtype=np.uint32)).astype(np.uint32))
+        # descendants that no longer fit (`fit_in_descendant`, :474-477) -> incremental_index_large_descendant
+        large = [nid for nid, nd in trees.nodes.items() if nd[0] == "D" and len(nd[1]) > split_after]
+        if large:
+            forest = ds.build_subtrees([trees.nodes[nid][1] for nid in large], self._seeds(len(large)), split_after)
+            for t, nid in enumerate(large):
+                trees.import_tree(forest, t, root_id=nid)  # the sub-tree's root keeps the descendant's id (:693-702)
+        # missing trees (:556-561)
+        self._add_trees(ds, trees, want - len(trees.roots), split_after)
 
 
 class Reader:
@@ -227,8 +395,8 @@ class Reader:
         return self._st.dataset.item_vector(int(item))
 
     def stats(self) -> dict:  # src/reader.rs:210-252
-        f = self._st.forest
-        return {"leaf": self.n_items(), "tree_stats": [f.tree_stats(t) for t in range(f.n_trees)] if f else []}
+        tr = self._st.trees
+        return {"leaf": self.n_items(), "tree_stats": [tr.stats(r) for r in tr.roots] if tr else []}
 
     def nns(self, count: int) -> "QueryBuilder":  # src/reader.rs:296-298
         return QueryBuilder(self, int(count))

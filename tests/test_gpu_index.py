@@ -186,21 +186,21 @@ def test_write_one_vector_and_until_there_is_a_descendants(api):
     w.add_item(0, [0, 1, 2])
     w.builder(rng()).n_trees(1).build()
     st = I.Reader.open(db, 0)._st
-    assert len(st.forest.nodes) == 1 and list(st.forest.descendants_of(0)) == [0]
+    assert st.trees.roots == [0] and len(st.trees.nodes) == 1 and list(st.trees.nodes[0][1]) == [0]
     for i in range(1, 3):
         w.add_item(i, [i, i, i])
     w.builder(rng()).n_trees(1).build()
     st = I.Reader.open(db, 0)._st
-    assert len(st.forest.nodes) == 1 and list(st.forest.descendants_of(0)) == [0, 1, 2]
+    assert st.trees.roots == [0] and len(st.trees.nodes) == 1 and list(st.trees.nodes[0][1]) == [0, 1, 2]
     # one more item than dimensions: the first split appears (src/tests/writer.rs:266-293)
     w.add_item(3, [3, 3, 3])
     w.builder(rng()).n_trees(1).build()
     st = I.Reader.open(db, 0)._st
-    root = st.forest.nodes[int(st.forest.roots[0])]
-    assert root["kind"] == 2 and root["has_normal"] == 1
-    hdr, vec = st.forest.normal_of(int(st.forest.roots[0]))
-    assert ["%.4f" % abs(x) for x in vec.view(np.float32)] == ["0.5774"] * 3
-    got = sorted(sorted(int(x) for x in st.forest.descendants_of(c)) for c in (int(root["left"]), int(root["right"])))
+    assert st.trees.roots == [0]  # the sub-tree's root keeps the descendant's id (src/writer.rs:693-702)
+    root = st.trees.nodes[0]
+    assert root[0] == "S" and root[4] is not None
+    assert ["%.4f" % abs(x) for x in np.frombuffer(root[4], np.float32)] == ["0.5774"] * 3
+    got = sorted(sorted(int(x) for x in st.trees.nodes[c][1]) for c in (root[1], root[2]))
     assert sum(len(g) for g in got) == 4 and sorted(sum(got, [])) == [0, 1, 2, 3]
 
 
@@ -215,3 +215,128 @@ def test_write_multiple_indexes(api):
     for index in range(5):
         r = I.Reader.open(db, index)
         assert r.item_ids() == [0] and fmt(r.nns(1).by_item(0)) == ["id(0): distance(0)"]
+
+
+def check_trees(st, split_after=None):
+    """Every tree partitions the item set; leaves respect split_after; ids of the store are unique per node."""
+    items = set(st.items)
+    for r in st.trees.roots:
+        seen = []
+        for nid in st.trees.subtree_ids(r):
+            nd = st.trees.nodes[nid]
+            if nd[0] == "D":
+                assert list(nd[1]) == sorted(set(int(x) for x in nd[1]))
+                if split_after is not None:
+                    assert len(nd[1]) <= split_after
+                seen += [int(x) for x in nd[1]]
+        assert sorted(seen) == sorted(items), "tree %d does not partition the items" % r
+    owned = sum((st.trees.subtree_ids(r) for r in st.trees.roots), [])
+    assert len(owned) == len(set(owned)) == len(st.trees.nodes)
+
+
+def check_exhaustive_search(reader, st, k=10, probes=8):
+    ids = reader.item_ids()
+    for q in ids[:: max(1, len(ids) // probes)]:
+        exact_ids, exact_d = st.dataset.rerank(min(k, len(ids)), item=q)
+        got = reader.nns(k).search_k(2**62).by_item(q)
+        assert [i for i, _ in got] == [int(i) for i in exact_ids]
+        assert np.array_equal(np.array([d for _, d in got], np.float32), exact_d)
+
+
+@pytest.mark.parametrize("dist_name", ["Euclidean", "Cosine", "DotProduct", "BinaryQuantizedCosine"])
+def test_incremental_add_and_delete(api, dist_name):
+    """src/tests/writer.rs:368-1040 (add_one_item_incrementally*, delete_one_item*, delete_one_leaf_in_a_split,
+    delete_document_in_an_empty_index...): after every incremental build each tree still partitions the item
+    set, overgrown descendants were re-split, and an exhaustive search equals the brute-force ranking."""
+    D, I = api
+    dist = getattr(D, dist_name)
+    dims, n0 = 24, 900
+    g = np.random.default_rng(5)
+    vecs = g.standard_normal((n0 + 400, dims)).astype(np.float32)
+    db = I.Database(dist)
+    w = I.Writer(db, 0, dims)
+    for i in range(n0):
+        w.add_item(i, vecs[i])
+    w.builder(rng()).n_trees(5).build()
+    st = I.Reader.open(db, 0)._st
+    check_trees(st, dims)
+    before = {nid: nd for nid, nd in st.trees.nodes.items() if nd[0] == "S"}
+    # add 300 new items, overwrite 50, delete 100
+    for i in range(n0, n0 + 300):
+        w.add_item(i, vecs[i])
+    for i in range(0, 50):
+        w.add_item(i, vecs[n0 + 300 + i])
+    for i in range(100, 200):
+        assert w.del_item(i)
+    assert w.need_build()
+    w.builder(rng()).n_trees(5).build()
+    reader = I.Reader.open(db, 0)
+    st = reader._st
+    assert reader.n_items() == n0 + 300 - 100 and reader.n_trees() == 5
+    check_trees(st, dims)
+    # incremental, not a rebuild: the old split planes are all still there, byte for byte
+    for nid, nd in before.items():
+        now = st.trees.nodes[nid]
+        assert now[0] == "S" and now[4] == nd[4] and np.array_equal(now[3], nd[3])
+    check_exhaustive_search(reader, st)
+    # delete everything but a handful: back to ONE Descendants root (src/writer.rs:916-962)
+    for i in list(st.items)[dims - 2:]:
+        w.del_item(i)
+    w.builder(rng()).n_trees(5).build()
+    reader = I.Reader.open(db, 0)
+    st = reader._st
+    assert st.trees.roots == [0] and len(st.trees.nodes) == 1 and reader.n_trees() == 1
+    check_exhaustive_search(reader, st, k=5)
+    # and grow again from the single leaf
+    for i in range(n0, n0 + 200):
+        w.add_item(i, vecs[i])
+    w.builder(rng()).build()
+    reader = I.Reader.open(db, 0)
+    check_trees(reader._st, dims)
+    check_exhaustive_search(reader, reader._st)
+
+
+def test_add_and_remove_trees(api):
+    """src/tests/writer.rs:1042-1170 (delete_extraneous_tree, create_root_split_node_with_empty_child...):
+    an explicit n_trees shrinks or grows the forest without touching the surviving trees."""
+    D, I = api
+    dims = 16
+    g = np.random.default_rng(6)
+    vecs = g.random((500, dims)).astype(np.float32)
+    db = I.Database(D.Manhattan)
+    w = I.Writer(db, 0, dims)
+    for i in range(500):
+        w.add_item(i, vecs[i])
+    w.builder(rng()).n_trees(6).build()
+    st = I.Reader.open(db, 0)._st
+    roots6 = list(st.trees.roots)
+    keep = {r: sorted(st.trees.subtree_ids(r)) for r in roots6}
+    w.add_item(0, vecs[0])  # mark one item updated so a build is needed
+    w.builder(rng()).n_trees(2).build()
+    st = I.Reader.open(db, 0)._st
+    assert st.trees.roots == roots6[:2]
+    check_trees(st, dims)
+    w.add_item(1, vecs[1])
+    w.builder(rng()).n_trees(4).build()
+    reader = I.Reader.open(db, 0)
+    st = reader._st
+    assert st.trees.roots[:2] == roots6[:2] and len(st.trees.roots) == 4
+    check_trees(st, dims)
+    check_exhaustive_search(reader, st)
+
+
+def test_delete_item_not_in_trees_then_search(api):
+    """src/tests/writer.rs:560-640 (delete_one_item_in_a_descendant / delete_one_leaf_in_a_split): a deleted item
+    never comes back from a search, and an emptied leaf is tolerated by the descent."""
+    D, I = api
+    db = I.Database(D.Euclidean)
+    w = I.Writer(db, 0, 2)
+    for i in range(6):
+        w.add_item(i, [i, 0])
+    w.builder(rng()).n_trees(1).build()
+    for victim in (3, 0, 5):
+        w.del_item(victim)
+        w.builder(rng()).n_trees(1).build()
+        reader = I.Reader.open(db, 0)
+        got = reader.nns(10).search_k(2**62).by_vector([0, 0])
+        assert victim not in [i for i, _ in got] and sorted(i for i, _ in got) == reader.item_ids()
