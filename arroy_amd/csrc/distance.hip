@@ -12,7 +12,7 @@
 namespace ah {
 
 static constexpr int kBlock = 256;       // 4 waves = 32 octets
-static constexpr int kMaxBlocks = 2048;  // 256 CUs x 8 blocks: grid-stride beyond that
+static constexpr int kMaxBlocks = 32768;  // one tile per wave up to ~1M f32 rows / 8M 1-bit rows (measured: 1-bit scan 90 -> 80 us vs a 2048-block persistent grid), grid-stride beyond that
 // AH_SCAN_BLOCKS overrides the grid cap of the grid-stride kernels (tuning experiments only)
 static const int g_max_blocks = getenv("AH_SCAN_BLOCKS") ? atoi(getenv("AH_SCAN_BLOCKS")) : kMaxBlocks;
 
@@ -178,6 +178,16 @@ __global__ __launch_bounds__(kBlock) void k_distances_f32_small(DataView dv, con
 // any order) and writes 64 contiguous distances.
 // Algorithmic traffic per distance: 8*words (+4 header for BQ-cosine) read + 4 written.
 static constexpr uint32_t kBqMaxChunks = 32;  // rows up to 512 bytes (dims <= 4096); larger rows use the fallback
+static constexpr uint32_t kBqUnroll = 8;      // chunk loads in flight per lane
+
+typedef unsigned long long bq_chunk_raw __attribute__((ext_vector_type(2)));
+struct bq_chunk {
+    unsigned long long x, y;
+};
+__device__ __forceinline__ bq_chunk ld_stream_bq(const uint64_t *p) {
+    const bq_chunk_raw t = __builtin_nontemporal_load(reinterpret_cast<const bq_chunk_raw *>(p));
+    return bq_chunk{t.x, t.y};
+}
 
 template <bool GATHER>
 __global__ __launch_bounds__(kBlock) void k_distances_bq(DataView dv, const uint64_t *__restrict__ qvec,
@@ -197,22 +207,45 @@ __global__ __launch_bounds__(kBlock) void k_distances_bq(DataView dv, const uint
     // only a compiler fence so the reads are not hoisted above the writes.
     const uint64_t n_tiles = (n + 63) >> 6;
     const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / 64);
+    // chunk g = 64c + lane of a tile belongs to part g % C of row g / C; both advance by a constant per c
+    const uint32_t step_r = 64u / C, step_p = 64u - step_r * C;
     for (uint64_t tile = (uint64_t)blockIdx.x * (kBlock / 64) + wave; tile < n_tiles; tile += n_waves) {
         const uint64_t base = tile << 6;
         const uint32_t rows_here = (uint32_t)min((uint64_t)64, n - base);
-        for (uint32_t c = 0; c < C; c++) {
-            const uint32_t g = c * 64 + lane;
-            const uint32_t r = g / C, part = g - r * C;
-            uint32_t pc = 0;
-            if (r < rows_here) {
-                uint64_t row = base + r;
-                if (GATHER) row = row_of_id(dv, ids[base + r]);
-                if (row != ~0ull) {
-                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(dv.rows_bq + row * dv.pitch + 2 * part);
-                    pc = (uint32_t)__popcll(v.x ^ s_qw[2 * part]) + (uint32_t)__popcll(v.y ^ s_qw[2 * part + 1]);
+        uint32_t r = lane / C, part = lane - r * C;
+        // the loads of kBqUnroll chunks are issued back to back (kBqUnroll KiB in flight per wave) before the
+        // first popcount waits on them
+        for (uint32_t c0 = 0; c0 < C; c0 += kBqUnroll) {
+            bq_chunk v[kBqUnroll];
+            uint32_t parts[kBqUnroll];
+            bool ok[kBqUnroll];
+#pragma unroll
+            for (uint32_t u = 0; u < kBqUnroll; u++) {
+                parts[u] = part;
+                ok[u] = (c0 + u < C) && (r < rows_here);
+                v[u] = bq_chunk{0ull, 0ull};
+                if (ok[u]) {
+                    uint64_t row = base + r;
+                    if (GATHER) row = row_of_id(dv, ids[base + r]);
+                    ok[u] = row != ~0ull;
+                    if (ok[u]) v[u] = ld_stream_bq(dv.rows_bq + row * dv.pitch + 2 * part);
+                }
+                r += step_r;
+                part += step_p;
+                if (part >= C) {
+                    part -= C;
+                    r += 1;
                 }
             }
-            s_part[g] = pc;
+#pragma unroll
+            for (uint32_t u = 0; u < kBqUnroll; u++) {
+                if (c0 + u < C) {
+                    const uint32_t pc = ok[u] ? (uint32_t)__popcll(v[u].x ^ s_qw[2 * parts[u]]) +
+                                                    (uint32_t)__popcll(v[u].y ^ s_qw[2 * parts[u] + 1])
+                                              : 0u;
+                    s_part[(c0 + u) * 64 + lane] = pc;
+                }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -532,23 +565,34 @@ int launch_headers_from_vectors(const DataView &dv, uint64_t first_row, uint64_t
     return AH_OK;
 }
 
-// UnalignedVector::<BinaryQuantized>::from_slice for n rows (binary_quantized.rs:80-91): one thread per word.
-__global__ void k_quantize_rows(const float *__restrict__ src, uint32_t src_pitch, uint32_t dims,
-                                uint64_t *__restrict__ dst, uint32_t dst_pitch, uint32_t words, uint64_t n) {
+// UnalignedVector::<BinaryQuantized>::from_slice for n rows (binary_quantized.rs:80-91).  One wave per run of 64
+// consecutive output words: for each word the 64 lanes read its 64 source floats as one coalesced 256-byte
+// load and the ballot of "sign bit clear" IS the packed word (bit i = is_sign_positive(x[64w + i]), :84-87;
+// elements past `dims` and the pitch padding words stay 0).  Lane j keeps word j; one coalesced store per run.
+__global__ __launch_bounds__(256) void k_quantize_rows(const float *__restrict__ src, uint32_t src_pitch, uint32_t dims,
+                                                       uint64_t *__restrict__ dst, uint32_t dst_pitch, uint32_t words,
+                                                       uint64_t n) {
     const uint64_t total = n * dst_pitch;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-        const uint64_t row = g / dst_pitch;
-        const uint32_t w = (uint32_t)(g % dst_pitch);
-        uint64_t word = 0;
-        if (w < words) {
-            const float *rp = src + row * src_pitch;
-            for (uint32_t i = 0; i < 64; i++) {
-                uint32_t e = 64 * w + i;
-                if (e < dims) word |= (uint64_t)((__float_as_uint(rp[e]) >> 31) == 0u) << i;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4u;
+    for (uint64_t g0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) << 6; g0 < total; g0 += n_waves << 6) {
+        uint64_t row = g0 / dst_pitch;
+        uint32_t w = (uint32_t)(g0 - row * dst_pitch);
+        uint64_t mine = 0;
+#pragma unroll 8
+        for (uint32_t j = 0; j < 64; j++) {
+            bool positive = false;
+            const uint32_t e = 64u * w + lane;
+            if (g0 + j < total && w < words && e < dims)
+                positive = (__float_as_uint(__builtin_nontemporal_load(src + row * src_pitch + e)) >> 31) == 0u;
+            const uint64_t word = __ballot(positive);
+            if (lane == j) mine = word;
+            if (++w == dst_pitch) {
+                w = 0;
+                row++;
             }
         }
-        dst[g] = word;
+        if (g0 + lane < total) dst[g0 + lane] = mine;
     }
 }
 int launch_quantize_rows(const float *d_src, uint32_t src_pitch, uint32_t dims, uint64_t *d_dst, uint32_t dst_pitch,
