@@ -134,6 +134,17 @@ def extra_c5(device):
     return {"workload": "5M x 768 1-bit vectors, Q=1 scan", "metrics": out}
 
 
+def _timed_callers(fn, batches, threads):
+    """Seconds to push `batches` through `fn` from `threads` concurrent callers (one untimed pass first so every
+    caller's stream, pinned staging and scratch exist at their final size)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(fn, batches))
+        t0 = time.perf_counter()
+        list(pool.map(fn, batches))
+        return time.perf_counter() - t0
+
+
 def extra_c4(device):
     """BASELINE configs[3]: 1M x 1536 dot product, search_k=10000 candidate re-rank + top-100, 1000 queries
     (src/reader.rs:376-400).  Candidate lists are 10 000..11 535 sorted random ids (search_k <= |nns| < search_k + K)."""
@@ -150,17 +161,19 @@ def extra_c4(device):
     queries = np.tile(queries, (nq // 64 + 1, 1))[:nq]
     lists = [np.sort(rng.choice(n, int(rng.integers(10_000, 11_536)), replace=False)).astype(np.uint32) for _ in range(nq)]
     total = sum(len(l) for l in lists)
-    ds.rerank_batch(queries[:50], lists[:50], k)  # warm-up
-    t0 = time.perf_counter()
-    for b in range(0, nq, 250):
-        ds.rerank_batch(queries[b:b + 250], lists[b:b + 250], k)
-    el = time.perf_counter() - t0
     per = 4 * dims + 4 + 4  # vector + id + written distance
+    out = {"workload": f"{n}x{dims} dot product, {nq} queries x ~10.8k candidates, top-{k} (host in/out included)",
+           "bytes_per_candidate": per}
+    # the reference's readers are concurrent (`Reader: Sync`, one RoTxn per thread): 1 caller, then 4 callers, each
+    # with its own stream + scratch inside the library (ctypes drops the GIL during the call)
+    batches = [(queries[b:b + 125], lists[b:b + 125]) for b in range(0, nq, 125)]
+    for threads in (1, 4):
+        el = _timed_callers(lambda a: ds.rerank_batch(a[0], a[1], k), batches, threads)
+        out[f"callers_{threads}"] = {"queries_per_s": nq / el, "candidates_per_s": total / el,
+                                     "gb_per_s": total / el * per / 1e9,
+                                     "frac_of_hbm_peak": total / el * per / 1e9 / HBM_PEAK_GBS, "seconds": el}
     ds.close()
-    return {"workload": f"{n}x{dims} dot product, {nq} queries x ~10.8k candidates, top-{k} (host in/out included)",
-            "queries_per_s": nq / el, "candidates_per_s": total / el, "bytes_per_candidate": per,
-            "gb_per_s": total / el * per / 1e9, "frac_of_hbm_peak": total / el * per / 1e9 / HBM_PEAK_GBS,
-            "seconds": el}
+    return out
 
 
 def extra_staging(device):
@@ -200,13 +213,13 @@ def extra_search(device):
     rng = np.random.default_rng(SEED)
     queries = np.stack([ds.item_vector(int(i)) for i in rng.choice(n, 64, replace=False)])
     queries = (np.tile(queries, (nq // 64 + 1, 1))[:nq] + rng.standard_normal((nq, dims)).astype(np.float32) * 0.05).astype(np.float32)
-    index.search(k, queries=queries[:64], search_k=10_000)  # warm-up
-    t0 = time.perf_counter()
-    _ids, _d, counts = index.search(k, queries=queries, search_k=10_000, raw=True)
-    el = time.perf_counter() - t0
+    _ids, _d, counts = index.search(k, queries=queries[:64], search_k=10_000, raw=True)
     out = {"workload": f"{n}x{dims} dot product, {n_trees} trees, {nq} queries, count={k}, search_k=10000 (host in/out included)",
-           "queries_per_s": nq / el, "seconds": el, "forest_build_seconds": build_s,
-           "results_per_query": float(counts.mean())}
+           "forest_build_seconds": build_s, "results_per_query": float(counts.mean())}
+    # best-first descent is sequential per query, so a call wants many queries: every caller submits all `nq`
+    for threads in (1, 4):
+        el = _timed_callers(lambda q: index.search(k, queries=q, search_k=10_000, raw=True), [queries] * threads, threads)
+        out[f"callers_{threads}"] = {"queries_per_s": threads * nq / el, "queries": threads * nq, "seconds": el}
     index.close()
     forest.close()
     ds.close()
