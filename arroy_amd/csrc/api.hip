@@ -24,7 +24,7 @@ const char *last_error() { return g_error.c_str(); }
 
 int Context::ensure_device(size_t bytes) {
     if (bytes <= d_cap) return AH_OK;
-    size_t cap = std::max(bytes, d_cap * 2);
+    size_t cap = std::max(bytes + bytes / 4, d_cap * 2);  // headroom: similar-sized submissions must not regrow
     cap = (cap + 4095) & ~(size_t)4095;
     if (d_scratch) AH_HIP(hipFree(d_scratch));
     d_scratch = nullptr;
@@ -35,7 +35,7 @@ int Context::ensure_device(size_t bytes) {
 }
 int Context::ensure_pinned(size_t bytes) {
     if (bytes <= h_cap) return AH_OK;
-    size_t cap = std::max(bytes, h_cap * 2);
+    size_t cap = std::max(bytes + bytes / 4, h_cap * 2);
     cap = (cap + 4095) & ~(size_t)4095;
     if (h_pinned) AH_HIP(hipHostFree(h_pinned));
     h_pinned = nullptr;
@@ -70,10 +70,11 @@ static inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // The host side of staging is a gather of records out of (unaligned) storage pages into pinned memory; one core
 // cannot keep a PCIe Gen5 link busy, so large chunks are split over a few threads.
+static constexpr size_t kParallelGrain = 256;  // items (rows, or ids of a candidate list) worth a thread
 template <typename F>
 static void parallel_rows(size_t n, F &&fn) {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const size_t n_threads = std::min<size_t>(std::min<unsigned>(hw, 8u), n / 256);
+    const size_t n_threads = std::min<size_t>(std::min<unsigned>(hw, 8u), n / kParallelGrain);
     if (n_threads <= 1) {
         fn((size_t)0, n);
         return;
@@ -654,9 +655,10 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     }
     const size_t qstride = pad256(ds->row_bytes());
     const size_t kstride = batch_key_stride(std::max<uint32_t>(max_n, 1));
+    const size_t inv_bytes = batch_invert_wanted(ds->view(), total) ? batch_invert_counter_bytes(ds->n) : 0;
     const size_t dev_bytes = pad256(nq * (size_t)ds->dims * 4) + nq * qstride + pad256(nq * 8) + pad256(nq * sizeof(HostSeg)) +
                              pad256(tiles.size() * sizeof(HostTile)) + pad256(total * 4) * 2 + 2 * pad256(nq * kstride * 8) +
-                             pad256(nq * k * 4) * 2 + 4096;
+                             pad256(nq * k * 4) * 2 + pad256(inv_bytes) + 4096;
     const size_t pin_bytes = pad256(nq * (size_t)ds->dims * 4) + pad256(nq * sizeof(HostSeg)) +
                              pad256(tiles.size() * sizeof(HostTile)) + pad256(total * 4) + pad256(nq * k * 4) * 2 + 4096;
     AH_TRY(ctx->ensure_device(dev_bytes));
@@ -674,6 +676,7 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     uint32_t *d_oi = dev.take<uint32_t>(nq * k);
     float *d_od = dev.take<float>(nq * k);
     uint32_t *d_err = dev.take<uint32_t>(1);
+    uint32_t *d_inv = inv_bytes ? dev.take<uint32_t>(inv_bytes / 4) : nullptr;
     float *h_q = pin.take<float>(nq * (size_t)ds->dims);
     HostSeg *h_segs = pin.take<HostSeg>(nq);
     HostTile *h_tiles = pin.take<HostTile>(tiles.size());
@@ -684,7 +687,8 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     memcpy(h_q, queries, nq * (size_t)ds->dims * 4);
     memcpy(h_segs, segs.data(), nq * sizeof(HostSeg));
     if (!tiles.empty()) memcpy(h_tiles, tiles.data(), tiles.size() * sizeof(HostTile));
-    if (total) memcpy(h_ids, ids + base, total * 4);
+    if (total)  // tens of MB for a big submission: several cores, like the staging gather
+        parallel_rows(total, [&](size_t lo, size_t hi) { memcpy(h_ids + lo, ids + base + lo, (hi - lo) * 4); });
     hipStream_t s = ctx->stream;
     AH_HIP(hipMemcpyAsync(d_qf32, h_q, nq * (size_t)ds->dims * 4, hipMemcpyHostToDevice, s));
     AH_HIP(hipMemcpyAsync(d_segs, h_segs, nq * sizeof(HostSeg), hipMemcpyHostToDevice, s));
@@ -693,7 +697,7 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     AH_HIP(hipMemsetAsync(d_err, 0, 4, s));
     AH_TRY(launch_rerank_batch(ds->view(), d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles,
                                (uint32_t)tiles.size(), d_ids, d_dist, d_ka, d_kb, kstride, max_n, (uint32_t)k, max_rounds,
-                               d_oi, d_od, d_err, s));
+                               d_oi, d_od, d_err, s, total, d_inv));
     AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
     AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
     AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));

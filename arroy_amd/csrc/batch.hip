@@ -164,6 +164,236 @@ __global__ __launch_bounds__(kBlock) void k_batch_distances_bq(DataView dv, cons
     }
 }
 
+// ---- row-major ("inverted") distances -------------------------------------------------------------------
+// A big submission re-reads the same rows many times: 1000 queries x ~10.8k candidates over 1M items touch every
+// row ~11 times, and the query-major kernel above pays one HBM read of the row (4*dims bytes) per candidate.
+// Here the (query, candidate) pairs are counting-sorted by row first, so that one octet handles kPairGroup
+// consecutive pairs that mostly share a row: the row is streamed from HBM once (kept in registers across the pairs
+// of a group, and in L2 for the neighbouring groups) while the queries — a few MB in total — come from L2 /
+// Infinity Cache.  HBM traffic drops from `pairs x 4*dims` to about `distinct rows x 4*dims`.  The arithmetic per
+// pair is the same octet reduction, so the distances are bit-identical to the query-major kernel; only the order
+// in which pairs are processed changes, and every pair writes its own output slot.
+static constexpr int kPairGroup = 4;   // pairs per octet (measured on 10M pairs x 1536 dims: 2: 5.4 ms, 4: 5.6 ms, 8: 6.1 ms)
+static constexpr uint32_t kScanItems = 2048;  // counters per scan block (256 threads x 8)
+
+// pass 1: validate the candidates exactly like the query-major kernel and histogram them by row
+__global__ __launch_bounds__(kBlock) void k_inv_count(DataView dv, const Seg *__restrict__ segs,
+                                                      const BTile *__restrict__ tiles, uint32_t n_tiles,
+                                                      const uint32_t *__restrict__ ids, uint32_t *__restrict__ count,
+                                                      float *__restrict__ out, uint32_t *err) {
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const BTile tl = tiles[tile];
+        const Seg sg = segs[tl.query];
+        const uint32_t in_tile = min(kTileCand, sg.n - tl.first);
+        const uint64_t base = sg.off + tl.first;
+        for (uint32_t p = threadIdx.x; p < in_tile; p += blockDim.x) {
+            const uint64_t i = base + p;
+            const uint32_t id = ids[i];
+            const uint64_t row = row_of_id(dv, id);
+            if (row == ~0ull) {
+                atomicOr(err, 1u);
+                out[i] = __uint_as_float(0x7FC00000u);
+                continue;
+            }
+            if ((tl.first + p) > 0 && id <= ids[i - 1]) atomicOr(err, 2u);
+            atomicAdd(&count[row], 1u);
+        }
+    }
+}
+
+// exclusive scan of `count` in place: per-block scan + block totals, scan of the totals (one block), add back
+__global__ __launch_bounds__(256) void k_scan_block(uint32_t *__restrict__ data, uint64_t n, uint32_t *__restrict__ sums) {
+    __shared__ uint32_t s_wave[4];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanItems + (uint64_t)threadIdx.x * 8;
+    uint32_t v[8], local = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        v[e] = base + e < n ? data[base + e] : 0u;
+        local += v[e];
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if ((int)lane >= d) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - local;
+    for (uint32_t w = 0; w < wave; w++) before += s_wave[w];
+    if (threadIdx.x == 255) sums[blockIdx.x] = before + local;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        if (base + e < n) data[base + e] = before;
+        before += v[e];
+    }
+}
+__global__ __launch_bounds__(256) void k_scan_sums(uint32_t *__restrict__ sums, uint32_t n_sums, uint32_t *__restrict__ total) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t b0 = 0; b0 < n_sums; b0 += 256) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t v = i < n_sums ? sums[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = s_carry + incl - v;
+        for (uint32_t w = 0; w < wave; w++) before += s_wave[w];
+        if (i < n_sums) sums[i] = before;
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = before + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+__global__ __launch_bounds__(256) void k_scan_add(uint32_t *__restrict__ data, uint64_t n, const uint32_t *__restrict__ sums) {
+    const uint32_t add = sums[blockIdx.x];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanItems;
+    for (uint32_t e = threadIdx.x; e < kScanItems; e += 256)
+        if (base + e < n) data[base + e] += add;
+}
+
+// pass 2: scatter (row, query, position) into row order; `start` holds the exclusive scan and is advanced
+__global__ __launch_bounds__(kBlock) void k_inv_scatter(DataView dv, const Seg *__restrict__ segs,
+                                                        const BTile *__restrict__ tiles, uint32_t n_tiles,
+                                                        const uint32_t *__restrict__ ids, uint32_t *__restrict__ start,
+                                                        uint64_t *__restrict__ pair_rq, uint32_t *__restrict__ pair_pos) {
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const BTile tl = tiles[tile];
+        const Seg sg = segs[tl.query];
+        const uint32_t in_tile = min(kTileCand, sg.n - tl.first);
+        const uint64_t base = sg.off + tl.first;
+        for (uint32_t p = threadIdx.x; p < in_tile; p += blockDim.x) {
+            const uint64_t i = base + p;
+            const uint64_t row = row_of_id(dv, ids[i]);
+            if (row == ~0ull) continue;
+            const uint32_t slot = atomicAdd(&start[row], 1u);
+            pair_rq[slot] = (row << 32) | (uint64_t)tl.query;
+            pair_pos[slot] = (uint32_t)i;
+        }
+    }
+}
+
+// pass 3: one octet per G consecutive pairs of the row-sorted list.  Both operands come through L1: the row chunk
+// (non-temporal; the first pair of a row pulls it from HBM, its neighbours hit L1/L2) and the query chunk (L2).
+// (Splitting the queries into per-XCD classes so that each L2 only sees 1/8 of them was measured and does not
+// help: the kernel is bound by the L1 request rate, ~21-24 TB/s of operand traffic, not by L2 capacity.)
+template <int METRIC, int G>
+__global__ __launch_bounds__(kBlock) void k_pairs_distances(DataView dv, const uint8_t *__restrict__ qvecs,
+                                                            uint64_t qstride, const float *__restrict__ qhdrs,
+                                                            const uint64_t *__restrict__ pair_rq,
+                                                            const uint32_t *__restrict__ pair_pos,
+                                                            const uint32_t *__restrict__ n_pairs_p,
+                                                            float *__restrict__ out) {
+    constexpr int OP = METRIC == AH_EUCLIDEAN ? OP_EUCLID : OP_DOT;
+    const uint32_t j = threadIdx.x & 7u;
+    const uint64_t hi = *n_pairs_p;
+    const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+    const uint32_t blocks = dv.dims >> 5;
+    for (uint64_t g0 = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3) * G; g0 < hi; g0 += n_octets * G) {
+        // branch-free inner loop: a short last group repeats its final pair (only the store is guarded), and every
+        // pair loads its row chunk itself — pairs of one row sit next to each other, so the repeats are L1 hits
+        const float4 *r4[G];
+        const float4 *q4[G];
+        bool on[G];
+        float4 acc[G];
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            on[t] = g0 + t < hi;
+            const uint64_t rq = pair_rq[on[t] ? g0 + t : hi - 1];
+            r4[t] = reinterpret_cast<const float4 *>(dv.rows_f32 + (rq >> 32) * dv.pitch) + j;
+            q4[t] = reinterpret_cast<const float4 *>(qvecs + (uint64_t)(uint32_t)rq * qstride) + j;
+            acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (uint32_t k = 0; k < blocks; k++) {
+            float4 x[G], q[G];
+#pragma unroll
+            for (int t = 0; t < G; t++) {
+                x[t] = ld_stream(r4[t] + k * 8);
+                q[t] = q4[t][k * 8];
+            }
+#pragma unroll
+            for (int t = 0; t < G; t++) fma_step<OP>(acc[t], q[t], x[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            if (on[t]) {
+                const float *rp = reinterpret_cast<const float *>(r4[t] - j);
+                const float *qp = reinterpret_cast<const float *>(q4[t] - j);
+                float r = octet_finish(acc[t]);
+                r = scalar_tail<OP>(r, qp, rp, blocks << 5, dv.dims);
+                if (j == 0) {
+                    const uint64_t rq = pair_rq[g0 + t];
+                    float d = r;
+                    if (METRIC == AH_COSINE) d = cosine_from_dot(r, qhdrs[2 * (uint32_t)rq], dv.headers[rq >> 32]);
+                    if (METRIC == AH_DOT_PRODUCT) d = -r;
+                    out[pair_pos[g0 + t]] = d;
+                }
+            }
+        }
+    }
+}
+
+// AH_RERANK_INVERT=0 never uses the row-major path, =1 uses it whenever it is legal (A/B measurements)
+static const int g_invert_force = getenv("AH_RERANK_INVERT") ? atoi(getenv("AH_RERANK_INVERT")) : -1;
+static const int g_pair_group = getenv("AH_PAIR_GROUP") ? atoi(getenv("AH_PAIR_GROUP")) : 0;
+
+// counters: one per stored row + the scan's block totals + the grand total
+size_t batch_invert_counter_bytes(uint64_t n_rows) { return (size_t)((n_rows + (n_rows + kScanItems - 1) / kScanItems + 64) * 4); }
+static bool invert_legal(const DataView &dv, uint64_t n_pairs) {
+    return !metric_is_bq(dv.metric) && dv.metric != AH_MANHATTAN && dv.dims >= 32 && n_pairs > 0 && n_pairs < 0xFFFFFFFFull &&
+           dv.n < 0xFFFFFFFFull;
+}
+// policy: row-major when the submission re-reads rows (>= 2 candidates per stored row on average)
+bool batch_invert_wanted(const DataView &dv, uint64_t n_candidates) {
+    if (!invert_legal(dv, n_candidates) || g_invert_force == 0) return false;
+    return g_invert_force == 1 || n_candidates >= 2 * dv.n;
+}
+
+// The pair lists live in the tournament buffers, which are idle until the distances exist:
+// keys_a: pair_rq (8 B x pairs); keys_b: pair_pos (4 B x pairs).  The counters are caller-provided scratch.
+template <int METRIC>
+static void launch_inverted(const DataView &dv, uint32_t /*n_queries*/, const uint8_t *d_qvecs, uint64_t qstride,
+                            const float *d_qhdrs, const Seg *d_segs, const BTile *d_tiles, uint32_t n_tiles,
+                            const uint32_t *d_ids, uint64_t n_pairs, float *d_dist, uint64_t *d_keys_a, uint64_t *d_keys_b,
+                            uint32_t *d_counters, uint32_t *d_err, hipStream_t s) {
+    uint64_t *pair_rq = d_keys_a;
+    uint32_t *pair_pos = reinterpret_cast<uint32_t *>(d_keys_b);
+    uint32_t *count = d_counters;
+    const uint32_t n_sums = (uint32_t)((dv.n + kScanItems - 1) / kScanItems);
+    uint32_t *sums = count + dv.n;
+    uint32_t *total = sums + n_sums;  // valid pairs, known to the device only
+    const unsigned grid = n_tiles < 4096u ? n_tiles : 4096u;
+    (void)hipMemsetAsync(count, 0, (size_t)dv.n * 4, s);
+    hipLaunchKernelGGL(k_inv_count, dim3(grid), dim3(kBlock), 0, s, dv, d_segs, d_tiles, n_tiles, d_ids, count, d_dist, d_err);
+    hipLaunchKernelGGL(k_scan_block, dim3(n_sums), dim3(256), 0, s, count, dv.n, sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, s, sums, n_sums, total);
+    hipLaunchKernelGGL(k_scan_add, dim3(n_sums), dim3(256), 0, s, count, dv.n, sums);
+    hipLaunchKernelGGL(k_inv_scatter, dim3(grid), dim3(kBlock), 0, s, dv, d_segs, d_tiles, n_tiles, d_ids, count, pair_rq,
+                       pair_pos);
+    const int group = g_pair_group == 8 ? 8 : (g_pair_group == 2 ? 2 : kPairGroup);
+    const uint64_t octets = (n_pairs + group - 1) / group;
+    const unsigned pgrid = (unsigned)std::min<uint64_t>((octets + kBlock / 8 - 1) / (kBlock / 8), 32768);
+    if (group == 8)
+        hipLaunchKernelGGL((k_pairs_distances<METRIC, 8>), dim3(pgrid), dim3(kBlock), 0, s, dv, d_qvecs, qstride, d_qhdrs,
+                           pair_rq, pair_pos, total, d_dist);
+    else if (group == 2)
+        hipLaunchKernelGGL((k_pairs_distances<METRIC, 2>), dim3(pgrid), dim3(kBlock), 0, s, dv, d_qvecs, qstride, d_qhdrs,
+                           pair_rq, pair_pos, total, d_dist);
+    else
+        hipLaunchKernelGGL((k_pairs_distances<METRIC, kPairGroup>), dim3(pgrid), dim3(kBlock), 0, s, dv, d_qvecs, qstride,
+                           d_qhdrs, pair_rq, pair_pos, total, d_dist);
+}
+
 // ---- batched top-k ----------------------------------------------------------------------------------
 // State of one query's tournament after `rounds` rounds: keys in flight and the number of blocks that wrote
 // them.  Pure function of (n, k), evaluated identically by every kernel and by the host.
@@ -289,12 +519,29 @@ int launch_rerank_batch_prepared(const DataView &dv, uint32_t n_queries, const u
                                  const float *d_qhdrs, const void *d_segs_v, const void *d_tiles_v, uint32_t n_tiles,
                                  const uint32_t *d_ids, float *d_dist, uint64_t *d_keys_a, uint64_t *d_keys_b,
                                  uint64_t kstride, uint32_t max_n, uint32_t k_out, uint32_t max_rounds,
-                                 uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s) {
+                                 uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s,
+                                 uint64_t n_candidates, uint32_t *d_inv_counters) {
     const Seg *d_segs = reinterpret_cast<const Seg *>(d_segs_v);
     const BTile *d_tiles = reinterpret_cast<const BTile *>(d_tiles_v);
     if (n_tiles) {
         const unsigned grid = n_tiles < 4096u ? n_tiles : 4096u;
-        if (metric_is_bq(dv.metric)) {
+        const bool invert = d_inv_counters != nullptr && batch_invert_wanted(dv, n_candidates);
+        if (invert) {
+            switch (dv.metric) {
+            case AH_EUCLIDEAN:
+                launch_inverted<AH_EUCLIDEAN>(dv, n_queries, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, n_tiles, d_ids,
+                                              n_candidates, d_dist, d_keys_a, d_keys_b, d_inv_counters, d_err, s);
+                break;
+            case AH_COSINE:
+                launch_inverted<AH_COSINE>(dv, n_queries, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, n_tiles, d_ids,
+                                           n_candidates, d_dist, d_keys_a, d_keys_b, d_inv_counters, d_err, s);
+                break;
+            default:
+                launch_inverted<AH_DOT_PRODUCT>(dv, n_queries, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, n_tiles, d_ids,
+                                                n_candidates, d_dist, d_keys_a, d_keys_b, d_inv_counters, d_err, s);
+                break;
+            }
+        } else if (metric_is_bq(dv.metric)) {
             hipLaunchKernelGGL(k_batch_distances_bq, dim3(grid), dim3(kBlock), dv.pitch * 8, s, dv, d_qvecs, qstride,
                                d_qhdrs, d_segs, d_tiles, n_tiles, d_ids, d_dist, d_err);
         } else {
@@ -329,11 +576,11 @@ int launch_rerank_batch(const DataView &dv, const float *d_q_f32, uint32_t n_que
                         float *d_qhdrs, const void *d_segs_v, const void *d_tiles_v, uint32_t n_tiles,
                         const uint32_t *d_ids, float *d_dist, uint64_t *d_keys_a, uint64_t *d_keys_b, uint64_t kstride,
                         uint32_t max_n, uint32_t k_out, uint32_t max_rounds, uint32_t *d_out_ids, float *d_out_dist,
-                        uint32_t *d_err, hipStream_t s) {
+                        uint32_t *d_err, hipStream_t s, uint64_t n_candidates, uint32_t *d_inv_counters) {
     AH_TRY(launch_prepare_queries_only(dv, d_q_f32, n_queries, d_qvecs, qstride, d_qhdrs, s));
     return launch_rerank_batch_prepared(dv, n_queries, d_qvecs, qstride, d_qhdrs, d_segs_v, d_tiles_v, n_tiles, d_ids,
                                         d_dist, d_keys_a, d_keys_b, kstride, max_n, k_out, max_rounds, d_out_ids,
-                                        d_out_dist, d_err, s);
+                                        d_out_dist, d_err, s, n_candidates, d_inv_counters);
 }
 
 uint32_t batch_rounds(uint32_t n, uint32_t k) { return (n == 0 || k == 0) ? 0u : tour_rounds(n, k); }

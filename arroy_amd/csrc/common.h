@@ -173,7 +173,7 @@ int launch_rerank_batch(const DataView &dv, const float *d_q_f32, uint32_t n_que
                         float *d_qhdrs, const void *d_segs, const void *d_tiles, uint32_t n_tiles, const uint32_t *d_ids,
                         float *d_dist, uint64_t *d_keys_a, uint64_t *d_keys_b, uint64_t kstride, uint32_t max_n,
                         uint32_t k_out, uint32_t max_rounds, uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err,
-                        hipStream_t s);
+                        hipStream_t s, uint64_t n_candidates, uint32_t *d_inv_counters);
 
 int launch_prepare_queries_only(const DataView &dv, const float *d_q_f32, uint32_t n_queries, uint8_t *d_qvecs,
                                 uint64_t qstride, float *d_qhdrs, hipStream_t s);
@@ -181,7 +181,11 @@ int launch_rerank_batch_prepared(const DataView &dv, uint32_t n_queries, const u
                                  const float *d_qhdrs, const void *d_segs, const void *d_tiles, uint32_t n_tiles,
                                  const uint32_t *d_ids, float *d_dist, uint64_t *d_keys_a, uint64_t *d_keys_b,
                                  uint64_t kstride, uint32_t max_n, uint32_t k_out, uint32_t max_rounds,
-                                 uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s);
+                                 uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s,
+                                 uint64_t n_candidates, uint32_t *d_inv_counters);
+// row-major ("inverted") re-rank of big submissions: policy + the counter scratch it needs (see batch.hip)
+bool batch_invert_wanted(const DataView &dv, uint64_t n_candidates);
+size_t batch_invert_counter_bytes(uint64_t n_rows);
 
 // split.hip
 int launch_split_sides(const DataView &dv, const void *d_nvec, const float *d_nhdr, const uint32_t *d_ids, uint64_t n,

@@ -540,6 +540,9 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     size_t dev_bytes = pad(nq * (size_t)ds->dims * 4) + pad(nq * 4) + nq * qstride + pad(nq * 8) + pad(nq * (size_t)nns_stride * 4) * 2 +
                        pad(nq * 4) * 3 + pad(nq * sizeof(HostSeg2)) + pad((size_t)max_tiles_bound * sizeof(HostTile2)) +
                        2 * pad(nq * kstride * 8) + pad(nq * k * 4) * 2 + 4096;
+    // counters of the row-major re-rank, reserved when the candidate lists could be long enough for it
+    const size_t inv_bytes = batch_invert_wanted(ds->view(), (uint64_t)nq * nns_stride) ? batch_invert_counter_bytes(ds->n) : 0;
+    dev_bytes += pad(inv_bytes);
     AH_TRY(ctx->ensure_device(dev_bytes));
     const size_t pin_bytes = pad(nq * (size_t)ds->dims * 4) + pad(nq * 4) * 4 + pad(nq * sizeof(HostSeg2)) +
                              pad((size_t)max_tiles_bound * sizeof(HostTile2)) + pad(nq * k * 4) * 2 + 4096;
@@ -574,6 +577,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     uint32_t *d_oi = (uint32_t *)dtake(nq * k * 4);
     float *d_od = (float *)dtake(nq * k * 4);
     uint32_t *d_err = (uint32_t *)dtake(4);
+    uint32_t *d_inv = inv_bytes ? (uint32_t *)dtake(inv_bytes) : nullptr;
     float *h_q = (float *)ptake(nq * (size_t)ds->dims * 4);
     uint32_t *h_qrows = (uint32_t *)ptake(nq * 4);
     uint32_t *h_counts = (uint32_t *)ptake(nq * 4);
@@ -656,9 +660,11 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     AH_HIP(hipStreamSynchronize(s));
     // 4. re-rank + top-k + normalized distances (batch.hip), candidates already resident
     uint32_t n_tiles = 0, max_n = 0, max_rounds = 0;
+    uint64_t n_candidates = 0;
     const uint32_t tc = batch_tile_candidates();
     for (size_t q = 0; q < nq; q++) {
         const uint32_t n = h_counts[q];
+        n_candidates += n;
         h_segs[q] = HostSeg2{(uint64_t)q * nns_stride, n, (uint32_t)std::min<size_t>(k, n)};
         out_counts[q] = h_segs[q].k;
         max_n = std::max(max_n, n);
@@ -668,7 +674,8 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     AH_HIP(hipMemcpyAsync(d_segs, h_segs, nq * sizeof(HostSeg2), hipMemcpyHostToDevice, s));
     if (n_tiles) AH_HIP(hipMemcpyAsync(d_tiles, h_tiles, (size_t)n_tiles * sizeof(HostTile2), hipMemcpyHostToDevice, s));
     AH_TRY(launch_rerank_batch_prepared(dv, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, n_tiles, d_nns, d_dist,
-                                        d_ka, d_kb, kstride, max_n, (uint32_t)k, max_rounds, d_oi, d_od, d_err, s));
+                                        d_ka, d_kb, kstride, max_n, (uint32_t)k, max_rounds, d_oi, d_od, d_err, s, n_candidates,
+                                        d_inv));
     AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
     AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
     AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));

@@ -118,14 +118,20 @@ class Dataset:
                                                     C.byref(on)))
         return oi[: on.value].copy(), od[: on.value].copy()
 
-    def rerank_batch(self, queries, id_lists: Sequence[Sequence[int]], k: int):
+    def rerank_batch(self, queries, id_lists, k: int):
+        """`id_lists`: one ascending id list per query, or the C ABI's own shape `(ids, offsets)` (concatenated
+        u32 ids + nq+1 u64 offsets) when the caller already holds it."""
         q = _f32(queries)
         if q.ndim != 2 or q.shape[1] != self.dimensions:
             raise _lib.InvalidVecDimension(1, "invalid query dimensions")
         nq = q.shape[0]
-        offsets = np.zeros(nq + 1, dtype=np.uint64)
-        offsets[1:] = np.cumsum([len(l) for l in id_lists])
-        ids = _u32(np.concatenate([_u32(l) for l in id_lists])) if nq else np.zeros(0, np.uint32)
+        if isinstance(id_lists, tuple):
+            ids, offsets = _u32(id_lists[0]), np.ascontiguousarray(id_lists[1], dtype=np.uint64)
+            assert offsets.size == nq + 1 and int(offsets[-1]) == ids.size
+        else:
+            offsets = np.zeros(nq + 1, dtype=np.uint64)
+            offsets[1:] = np.cumsum([len(l) for l in id_lists])
+            ids = _u32(np.concatenate([_u32(l) for l in id_lists])) if nq else np.zeros(0, np.uint32)
         oi = np.zeros((nq, k), dtype=np.uint32)
         od = np.zeros((nq, k), dtype=np.float32)
         oc = np.zeros(nq, dtype=np.uint32)
