@@ -193,6 +193,41 @@ def test_rerank_batch_equals_single_queries():
         assert_bit_equal(od[i, : oc[i]], ed)
 
 
+@pytest.mark.parametrize("metric,dims,sparse_ids", [(0, 70, False), (2, 96, True), (3, 128, False), (2, 33, False)])
+def test_rerank_batch_row_major_path(metric, dims, sparse_ids):
+    """A submission with >= 2 candidates per stored row is re-ranked row-major (pairs counting-sorted by row,
+    batch.hip); same distances bit for bit as the query-major kernel, the single-query path and the oracle."""
+    cls = D.BY_METRIC[metric]
+    n, nq, k = 1500, 48, 25
+    ids = np.sort(np.random.default_rng(3).choice(40_000, n, replace=False)).astype(np.uint32) if sparse_ids else None
+    ds, oracle, vecs, ids = make_data(cls, n, dims, seed=17 + metric, ids=ids)
+    rng = np.random.default_rng(9)
+    qs = rng.standard_normal((nq, dims)).astype(np.float32)
+    sizes = [int(x) for x in rng.integers(1, n, nq)]
+    sizes[0], sizes[1] = n, 0  # every row, and an empty list
+    lists = [np.sort(rng.choice(ids, m, replace=False)).astype(np.uint32) for m in sizes]
+    assert sum(sizes) >= 2 * n  # the library's policy threshold for the row-major path
+    oi, od, oc = ds.rerank_batch(qs, lists, k)
+    for i in range(nq):
+        if sizes[i] == 0:
+            assert oc[i] == 0
+            continue
+        ei, ed = ds.rerank(k, query=qs[i], sorted_ids=lists[i])
+        assert oc[i] == len(ei) and list(oi[i, : oc[i]]) == list(ei)
+        assert_bit_equal(od[i, : oc[i]], ed)
+    for i in (0, 2, nq - 1):  # and against the CPU restatement
+        q, qh = oracle.query_leaf(qs[i])
+        rows = np.searchsorted(ids, lists[i]).astype(np.uint32)  # the oracle addresses rows, the C ABI item ids
+        ci, cd = oracle.rerank(q, qh, rows, k)
+        assert list(oi[i, : oc[i]]) == list(ci)
+        assert_bit_equal(od[i, : oc[i]], cd)
+    # a missing id is still reported through the row-major path
+    bad = [l.copy() for l in lists]
+    bad[5] = np.sort(np.append(bad[5][:-1], np.uint32(0xFFFFFFF0))).astype(np.uint32)
+    with pytest.raises(Exception):
+        ds.rerank_batch(qs, bad, k)
+
+
 # ---- build side: margins / sides / create_split ------------------------------------------------------------
 
 @pytest.mark.parametrize("metric", ALL_METRICS)
