@@ -16,6 +16,9 @@
 // No atomics on floats, no dependence on workgroup scheduling: results are deterministic.
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <thread>
 #include <cstdlib>
 #include <new>
 
@@ -543,10 +546,131 @@ struct BatchCleanup {
 // `subset_ids` == nullptr: every tree covers all items (Writer::build with missing trees).  Otherwise tree t covers
 // the ascending id list subset_ids[subset_offsets[first_tree + t] .. subset_offsets[first_tree + t + 1]) — the
 // "descendants that became too large" of an incremental build (src/writer.rs:660-739).
+// Device -> pageable host copies off the build's critical path.  hipMemcpy into pageable memory is staged by the
+// runtime on one thread and pays the first-touch page faults of the fresh destination there (measured: 4 GB of item
+// ids in 0.60 s = 6.7 GB/s, whatever the number of concurrent calls).  Instead a worker thread owns a pinned double
+// buffer: the DMA engine fills one half while a few threads copy the other half to its final place, and the level
+// loop never waits for it — each level's normals travel while the next levels are computed.
+struct Readback {
+    struct Job {
+        void *dst;
+        const void *src;
+        size_t bytes;
+    };
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job> q;
+    size_t pending = 0;
+    bool stop = false, started = false;
+    hipError_t err = hipSuccess;
+    int device = 0;
+    uint8_t *pin = nullptr;  // 2 x half bytes of pinned memory (owned by the build's Context)
+    size_t half = 0;
+
+    void start(int dev, void *pinned, size_t pinned_bytes) {
+        device = dev;
+        pin = reinterpret_cast<uint8_t *>(pinned);
+        half = pinned_bytes / 2;
+        started = true;
+        th = std::thread([this] { run(); });
+    }
+    static void spread(uint8_t *dst, const uint8_t *src, size_t bytes) {  // memcpy on up to 8 cores
+        const size_t n_threads = std::min<size_t>(8, bytes >> 20);
+        if (n_threads <= 1) {
+            memcpy(dst, src, bytes);
+            return;
+        }
+        std::vector<std::thread> pool;
+        const size_t per = ((bytes + n_threads - 1) / n_threads + 4095) & ~(size_t)4095;
+        for (size_t lo = 0; lo < bytes; lo += per) {
+            const size_t len = std::min(per, bytes - lo);
+            pool.emplace_back([=] { memcpy(dst + lo, src + lo, len); });
+        }
+        for (auto &t : pool) t.join();
+    }
+    hipError_t copy(const Job &job, hipStream_t cs, hipEvent_t *ev) {
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(job.src);
+        uint8_t *dst = reinterpret_cast<uint8_t *>(job.dst);
+        size_t issued = 0, landed = 0, prev_len = 0;
+        int b = 0;
+        hipError_t e = hipSuccess;
+        while (landed < job.bytes && e == hipSuccess) {
+            size_t len = 0;
+            if (issued < job.bytes) {
+                len = std::min(half, job.bytes - issued);
+                e = hipMemcpyAsync(pin + (size_t)b * half, src + issued, len, hipMemcpyDeviceToHost, cs);
+                if (e == hipSuccess) e = hipEventRecord(ev[b], cs);
+                issued += len;
+            }
+            if (prev_len && e == hipSuccess) {  // the other half is in flight while this one is spread out
+                e = hipEventSynchronize(ev[b ^ 1]);
+                if (e == hipSuccess) spread(dst + landed, pin + (size_t)(b ^ 1) * half, prev_len);
+                landed += prev_len;
+            }
+            prev_len = len;
+            b ^= 1;
+        }
+        return e;
+    }
+    void run() {
+        hipStream_t cs = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+        for (;;) {
+            Job job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [this] { return stop || !q.empty(); });
+                if (q.empty()) break;
+                job = q.front();
+                q.pop_front();
+            }
+            if (e == hipSuccess) e = copy(job, cs, ev);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (e != hipSuccess && err == hipSuccess) err = e;
+                pending--;
+            }
+            cv.notify_all();
+        }
+        if (ev[0]) (void)hipEventDestroy(ev[0]);
+        if (ev[1]) (void)hipEventDestroy(ev[1]);
+        if (cs) (void)hipStreamDestroy(cs);
+    }
+    void push(void *dst, const void *src, size_t bytes) {
+        if (!bytes) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            q.push_back(Job{dst, src, bytes});
+            pending++;
+        }
+        cv.notify_all();
+    }
+    hipError_t drain() {  // every pushed copy has landed
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return pending == 0; });
+        return err;
+    }
+    ~Readback() {
+        if (!started) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        th.join();
+    }
+};
+
 static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t first_tree, uint32_t n_trees,
                        uint32_t split_after, ah_forest *forest, Context *ctx, const uint32_t *subset_ids,
                        const uint64_t *subset_offsets) {
     const uint64_t N = ds->n;
+    const auto t_batch = std::chrono::steady_clock::now();
     std::vector<uint64_t> tree_base(n_trees + 1, 0);
     for (uint32_t t = 0; t < n_trees; t++)
         tree_base[t + 1] = tree_base[t] + (subset_ids ? subset_offsets[first_tree + t + 1] - subset_offsets[first_tree + t] : N);
@@ -573,7 +697,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     AH_TRY(masks.ensure(max_tiles * 32));
     AH_TRY(tile_left.ensure(max_tiles));
     AH_TRY(tile_left_off.ensure(max_tiles));
-    AH_TRY(ctx->ensure_pinned(max_nodes * sizeof(FNode) + max_tiles * sizeof(FTile) + 4096));
+    const size_t kBounce = 64ull << 20;  // pinned double buffer of the read-back worker
+    const size_t pin_tables = (max_nodes * sizeof(FNode) + max_tiles * sizeof(FTile) + 4096 + 4095) & ~(size_t)4095;
+    AH_TRY(ctx->ensure_pinned(pin_tables + kBounce));
     // row-major margin mode (full-dataset trees, f32 metrics): node index and side byte per (tree, row)
     const bool rows_allowed = !subset_ids && !bq && ds->dims >= 32 && n_trees >= 2 && g_rows_force != 0;
     DevBuf<uint32_t> node_of;
@@ -600,7 +726,39 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     }
     AH_HIP(hipGetLastError());
 
+    // The item-id lists come back in one piece at the very end; their size is known now, so the host memory is
+    // allocated up front and its pages are touched in the background while the GPU works (first-touch faults of
+    // fresh memory, not the copy, bound a read-back of several GB).
+    const uint64_t desc_base = forest->descendants_len;
+    {
+        uint32_t *grown = (uint32_t *)realloc(forest->descendants, (desc_base + M) * 4 + 16);
+        AH_REQUIRE(grown, AH_ERR_OUT_OF_MEMORY, "host allocation of the descendants failed");
+        forest->descendants = grown;
+    }
+    struct Joiner {
+        std::thread th;
+        void join() {
+            if (th.joinable()) th.join();
+        }
+        ~Joiner() { join(); }
+    } prefault;
+    if (M * 4 >= (8u << 20)) {
+        uint8_t *lo = reinterpret_cast<uint8_t *>(forest->descendants + desc_base);
+        const size_t bytes = M * 4;
+        prefault.th = std::thread([lo, bytes] {
+            const size_t parts = std::min<size_t>(4, std::max<size_t>(1, bytes >> 26));
+            std::vector<std::thread> pool;
+            for (size_t p = 0; p < parts; p++)
+                pool.emplace_back([=] {
+                    const size_t a = bytes * p / parts, b = bytes * (p + 1) / parts;
+                    for (size_t off = a; off < b; off += 4096) reinterpret_cast<volatile uint8_t *>(lo)[off] = 0;
+                });
+            for (auto &t : pool) t.join();
+        });
+    }
     BatchCleanup bc;
+    Readback rb;  // declared after `bc`: joined before the level chunks it reads are freed
+    rb.start(ds->device, reinterpret_cast<uint8_t *>(ctx->h_pinned) + pin_tables, kBounce);
     std::vector<HostRec> recs;
     std::vector<FNode> level;  // active (to be split) nodes of the current level
     std::vector<uint32_t> tree_root(n_trees);
@@ -641,6 +799,23 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_shared));
     const uint64_t normals_base = forest->normals_len;  // this batch appends its levels after earlier batches
     uint64_t normals_bytes = 0;
+    // The host blob gets lazily committed head-room (splits in total ~1.3-1.6 x items / split_after) so that finished
+    // levels can land in their final place while the build continues; it only moves when no copy is in flight.
+    uint64_t normals_cap = forest->normals_len;
+    auto reserve_normals = [&](uint64_t need) -> int {
+        if (need <= normals_cap) return AH_OK;
+        AH_REQUIRE(rb.drain() == hipSuccess, AH_ERR_DEVICE, "device -> host copy of the normals failed");
+        uint64_t want = std::max<uint64_t>(need + need / 2, normals_base + 2 * max_nodes * nstride);
+        uint8_t *grown = (uint8_t *)realloc(forest->normals, want + 16);
+        if (!grown) {
+            want = need;
+            grown = (uint8_t *)realloc(forest->normals, want + 16);
+        }
+        AH_REQUIRE(grown, AH_ERR_OUT_OF_MEMORY, "host allocation of %llu bytes of normals failed", (unsigned long long)want);
+        forest->normals = grown;
+        normals_cap = want;
+        return AH_OK;
+    };
     uint32_t depth = 0;
     uint64_t items_routed = 0;
     while (!level.empty()) {
@@ -755,6 +930,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_HIP(hipGetLastError());
         AH_HIP(hipMemcpyAsync(h_nodes, d_nodes.p, n_nodes * sizeof(FNode), hipMemcpyDeviceToHost, s));
         AH_HIP(hipStreamSynchronize(s));
+        // this level's normals are final: the worker copies them while the next level runs
+        AH_TRY(reserve_normals(chunk.host_off + chunk.bytes));
+        rb.push(forest->normals + chunk.host_off, chunk.d, chunk.bytes);
 
         // host: materialise the split records and the next level (children lists subdivide the parent range)
         level.clear();
@@ -801,24 +979,13 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         if (opt->progress) opt->progress(opt->progress_user, depth, recs.size(), items_routed);
     }
     AH_HIP(hipEventRecord(bc.ev_end, s));
+    const auto t_levels = std::chrono::steady_clock::now();
 
     // Results come back with plain D2H copies straight into their final place — no host-side repacking:
-    //   normals      one copy per level chunk (device record layout == caller-visible layout)
+    //   normals      one copy per level chunk (device record layout == caller-visible layout), already under way
     //   descendants  the final permutations themselves (rows -> item ids on device first)
     {
-        uint8_t *grown = (uint8_t *)realloc(forest->normals, normals_base + normals_bytes + 16);
-        AH_REQUIRE(grown, AH_ERR_OUT_OF_MEMORY, "host allocation of %llu bytes of normals failed",
-                   (unsigned long long)(normals_base + normals_bytes));
-        forest->normals = grown;
-        forest->normals_len = normals_base + normals_bytes;
-        for (const LevelChunk &c : bc.chunks)
-            AH_HIP(hipMemcpyAsync(forest->normals + c.host_off, c.d, c.bytes, hipMemcpyDeviceToHost, s));
-    }
-    const uint64_t desc_base = forest->descendants_len;
-    {
-        uint32_t *grown = (uint32_t *)realloc(forest->descendants, (desc_base + M) * 4 + 16);
-        AH_REQUIRE(grown, AH_ERR_OUT_OF_MEMORY, "host allocation of the descendants failed");
-        forest->descendants = grown;
+        prefault.join();
         forest->descendants_len = desc_base + M;
         // trees that are a single Descendants node never went through a scatter: their list is the input itself
         for (uint32_t t = 0; t < n_trees; t++)
@@ -827,9 +994,17 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                                       (tree_base[t + 1] - tree_base[t]) * 4, hipMemcpyDeviceToDevice, s));
         if (!ds->identity_ids && M)
             hipLaunchKernelGGL(k_rows_to_ids, dim3(2048), dim3(256), 0, s, final_perm.p, M, ds->d_ids);
-        if (M) AH_HIP(hipMemcpyAsync(forest->descendants + desc_base, final_perm.p, M * 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipStreamSynchronize(s));
+        rb.push(forest->descendants + desc_base, final_perm.p, M * 4);
+    }
+    AH_REQUIRE(rb.drain() == hipSuccess, AH_ERR_DEVICE, "device -> host copy of the forest failed");
+    forest->normals_len = normals_base + normals_bytes;
+    if (normals_cap > forest->normals_len) {  // give the head-room back (shrinks in place)
+        uint8_t *fit = (uint8_t *)realloc(forest->normals, forest->normals_len + 16);
+        if (fit) forest->normals = fit;
     }
     AH_HIP(hipStreamSynchronize(s));
+    const auto t_readback = std::chrono::steady_clock::now();
     float ms = 0.0f;
     AH_HIP(hipEventElapsedTime(&ms, bc.ev_begin, bc.ev_end));
     forest->stats.seconds_device += ms * 1e-3;
@@ -877,6 +1052,13 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             stack.pop_back();
         }
         forest->roots.push_back(new_index[tree_root[t]]);
+    }
+    if (getenv("AH_TIMING")) {
+        const auto t_end = std::chrono::steady_clock::now();
+        auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+        fprintf(stderr, "[ah] batch of %u trees: levels %.3f s (device %.3f), readback %.3f s (%.2f GB normals, %.2f GB ids), emit %.3f s\n",
+                n_trees, sec(t_batch, t_levels), ms * 1e-3, sec(t_levels, t_readback), normals_bytes / 1e9, M * 4 / 1e9,
+                sec(t_readback, t_end));
     }
     return AH_OK;
 }
