@@ -511,11 +511,11 @@ struct EventPair {
 // AH_DEBUG=1: synchronise after every launch and say which kernel finished (debugging aid only)
 bool g_debug = getenv("AH_DEBUG") != nullptr;
 // AH_ROWMAJOR=0 disables the row-major margin pass, =1 forces it whenever it is legal (A/B measurements);
-// AH_ROWMAJOR_CACHE_MB = budget for one group's normals (default 16 MiB: measured optimum on MI355X, the
-// normals of a group are shared by all XCDs through the Infinity Cache).
+// AH_ROWMAJOR_CACHE_MB = budget for one group's normals (default 6.5 MB: per-level traces of the 10M x 768 build show
+// the per-margin cost of a pass rising from 0.10-0.16 ns below it to 0.27-0.5 ns at 12.6 MB, see build_batch).
 int g_rows_force = getenv("AH_ROWMAJOR") ? atoi(getenv("AH_ROWMAJOR")) : -1;
 uint32_t g_rows_max_tc = getenv("AH_ROWMAJOR_MAX_TC") ? (uint32_t)atoi(getenv("AH_ROWMAJOR_MAX_TC")) : 16u;
-uint64_t g_rows_cache_bytes = (uint64_t)(getenv("AH_ROWMAJOR_CACHE_MB") ? atof(getenv("AH_ROWMAJOR_CACHE_MB")) : 16.0) * (1u << 20);
+uint64_t g_rows_cache_bytes = (uint64_t)((getenv("AH_ROWMAJOR_CACHE_MB") ? atof(getenv("AH_ROWMAJOR_CACHE_MB")) : 6.5) * 1e6);
 #define AH_DBG(s, what)                                                       \
     do {                                                                      \
         if (g_debug) {                                                        \
@@ -849,14 +849,37 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         // level's normals of one group stay cache-resident.
         uint32_t row_tc = 0;
         if (rows_allowed) {
+            // Group size: the largest row_tc whose normals for this level (ws) fit the cache budget (6.5 MB: beyond it
+            // the normals spill from the XCD L2s to the Infinity Cache and every extra tree costs more than it saves).
+            // Row-major or not is then decided by a cost model in ns, fitted to per-level rocprofv3 traces of the
+            // 10M x 768 x 100-tree build and scaled by the row size:
+            //   node-major  0.47 per (item, tree) pair: one HBM read of the row at ~6.85 TB/s;
+            //   row-major   per pass and row: base(row_tc) = 0.60 / 0.87 / 1.18 / 1.55 for 2 / 4 / 8 / 16 trees (the HBM
+            //               read of the row + normals served by L1/L2) + row_tc x 0.018 per MB of ws beyond 2.7 MB,
+            //               scaled by the share of (row, tree) pairs that are still splitting; plus the node_of / mask
+            //               conversion of the level (0.01-0.05 per (row, tree)).
             uint64_t pairs = 0;
             for (uint32_t i = 0; i < n_nodes; i++) pairs += level[i].count;
+            const double row_b = (double)ds->row_bytes();
+            const double active = (double)pairs / ((double)n_trees * (double)N);  // share of (row, tree) pairs still splitting
             const uint64_t nodes_per_tree = (n_nodes + n_trees - 1) / n_trees;
+            const double scale = row_b / 3072.0;
+            const double cost_node = (double)pairs * 0.47 * scale;
+            const double convert = (double)n_trees * (double)N * (0.01 + 0.04 * std::min(1.0, (double)nodes_per_tree / 256.0));
             uint32_t tc = g_rows_max_tc;
             while (tc > 1 && (uint64_t)tc * nodes_per_tree * nstride > g_rows_cache_bytes) tc >>= 1;
             while (tc > 2 && tc / 2 >= n_trees) tc >>= 1;  // do not instantiate more slots than trees
-            const uint64_t passes = (n_trees + tc - 1) / tc;
-            if (tc >= 2 && (g_rows_force == 1 || (double)pairs >= 1.25 * (double)(passes * N))) row_tc = tc;
+            // measured anomaly: the 8-tree instantiation is slower per margin than the 4-tree one as soon as its
+            // normals leave the L2 (0.25-0.31 vs 0.22-0.27 ns at 3.2-6.3 MB)
+            if (tc == 8 && (double)((uint64_t)tc * nodes_per_tree * nstride) > 2.7e6) tc = 4;
+            if (tc >= 2) {
+                const double passes = (double)((n_trees + tc - 1) / tc);
+                const double base = tc >= 16 ? 1.55 : tc == 8 ? 1.18 : tc == 4 ? 0.87 : 0.60;
+                const double ws_mb = (double)((uint64_t)tc * nodes_per_tree * nstride) / 1e6;
+                const double per_row = 0.45 + ((base - 0.45) + tc * 0.018 * std::max(0.0, ws_mb - 2.7)) * std::min(1.0, active);
+                const double cost_rows = passes * (double)N * per_row * scale + convert;
+                if (g_rows_force == 1 || cost_rows < 0.95 * cost_node) row_tc = tc;
+            }
         }
         for (int attempt = 0; attempt < 4; attempt++) {
             hipLaunchKernelGGL(k_forest_create_split, dim3(n_nodes), dim3(64), cs_shared, s, dv, d_nodes.p, cur, N,
