@@ -219,6 +219,33 @@ __global__ __launch_bounds__(kBlock) void k_forest_assign_node_of(const FNode *_
     }
 }
 
+// node_of for the next level, in row order: when the level before was row-major too, every (tree, row) pair already
+// knows its node and its side, so its child is one table lookup away — a coalesced sweep instead of the scattered
+// 4-byte writes of k_forest_assign_node_of (36 ms -> 2 ms per level at 10M x 100 trees).  `child[2 * node + side]` is
+// the index of the child in the next level, or 0xFFFFFFFF when it is a leaf (or when the parent's sides were
+// re-drawn after the row-major pass: those few nodes are then assigned the scattered way).
+__global__ __launch_bounds__(kBlock) void k_forest_advance_node_of(uint32_t *__restrict__ node_of,
+                                                                   const uint8_t *__restrict__ side_bytes,
+                                                                   const uint32_t *__restrict__ child, uint64_t total) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 4;
+    for (uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; g < total; g += stride) {
+        if (g + 4 <= total) {
+            uint4 n = *reinterpret_cast<const uint4 *>(node_of + g);
+            const uchar4 sd = *reinterpret_cast<const uchar4 *>(side_bytes + g);
+            if (n.x != 0xFFFFFFFFu) n.x = child[2 * n.x + sd.x];
+            if (n.y != 0xFFFFFFFFu) n.y = child[2 * n.y + sd.y];
+            if (n.z != 0xFFFFFFFFu) n.z = child[2 * n.z + sd.z];
+            if (n.w != 0xFFFFFFFFu) n.w = child[2 * n.w + sd.w];
+            *reinterpret_cast<uint4 *>(node_of + g) = n;
+        } else {
+            for (uint64_t e = g; e < total; e++) {
+                const uint32_t n = node_of[e];
+                if (n != 0xFFFFFFFFu) node_of[e] = child[2 * n + side_bytes[e]];
+            }
+        }
+    }
+}
+
 template <int METRIC, int TC>
 __global__ __launch_bounds__(kBlock) void k_forest_margin_rows(DataView dv, const uint32_t *__restrict__ node_of,
                                                                uint32_t tree0, uint32_t n_pass,
@@ -514,6 +541,7 @@ bool g_debug = getenv("AH_DEBUG") != nullptr;
 // AH_ROWMAJOR_CACHE_MB = budget for one group's normals (default 6.5 MB: per-level traces of the 10M x 768 build show
 // the per-margin cost of a pass rising from 0.10-0.16 ns below it to 0.27-0.5 ns at 12.6 MB, see build_batch).
 int g_rows_force = getenv("AH_ROWMAJOR") ? atoi(getenv("AH_ROWMAJOR")) : -1;
+bool g_rows_advance = !(getenv("AH_ROWMAJOR_ADVANCE") && atoi(getenv("AH_ROWMAJOR_ADVANCE")) == 0);  // A/B switch
 uint32_t g_rows_max_tc = getenv("AH_ROWMAJOR_MAX_TC") ? (uint32_t)atoi(getenv("AH_ROWMAJOR_MAX_TC")) : 16u;
 uint64_t g_rows_cache_bytes = (uint64_t)((getenv("AH_ROWMAJOR_CACHE_MB") ? atof(getenv("AH_ROWMAJOR_CACHE_MB")) : 6.5) * 1e6);
 #define AH_DBG(s, what)                                                       \
@@ -702,12 +730,18 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     AH_TRY(ctx->ensure_pinned(pin_tables + kBounce));
     // row-major margin mode (full-dataset trees, f32 metrics): node index and side byte per (tree, row)
     const bool rows_allowed = !subset_ids && !bq && ds->dims >= 32 && n_trees >= 2 && g_rows_force != 0;
-    DevBuf<uint32_t> node_of;
+    DevBuf<uint32_t> node_of, d_child;
+    DevBuf<FTile> d_fix_tiles;
     DevBuf<uint8_t> side_bytes;
     if (rows_allowed) {
-        AH_TRY(node_of.ensure((size_t)n_trees * N));
-        AH_TRY(side_bytes.ensure((size_t)n_trees * N));
+        AH_TRY(node_of.ensure((size_t)n_trees * N + 4));
+        AH_TRY(side_bytes.ensure((size_t)n_trees * N + 4));
+        AH_TRY(d_child.ensure(2 * max_nodes));
     }
+    // state carried from one level to the next for k_forest_advance_node_of
+    bool prev_rows = false;            // the previous level ran row-major: node_of / side_bytes describe it
+    std::vector<uint32_t> h_child;     // per node of the previous level: index of its two children in this level
+    std::vector<uint32_t> fix_nodes;   // nodes of this level whose parent's sides were re-drawn (retry / random)
     FNode *h_nodes = reinterpret_cast<FNode *>(ctx->h_pinned);
     FTile *h_tiles = reinterpret_cast<FTile *>(h_nodes + max_nodes);
     if (!subset_ids) {
@@ -857,7 +891,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             //   row-major   per pass and row: base(row_tc) = 0.60 / 0.87 / 1.18 / 1.55 for 2 / 4 / 8 / 16 trees (the HBM
             //               read of the row + normals served by L1/L2) + row_tc x 0.018 per MB of ws beyond 2.7 MB,
             //               scaled by the share of (row, tree) pairs that are still splitting; plus the node_of / mask
-            //               conversion of the level (0.01-0.05 per (row, tree)).
+            //               conversion of the level (0.01-0.05 per (row, tree); 0.007-0.02 when node_of is advanced in
+            //               row order from the previous row-major level).
             uint64_t pairs = 0;
             for (uint32_t i = 0; i < n_nodes; i++) pairs += level[i].count;
             const double row_b = (double)ds->row_bytes();
@@ -865,7 +900,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             const uint64_t nodes_per_tree = (n_nodes + n_trees - 1) / n_trees;
             const double scale = row_b / 3072.0;
             const double cost_node = (double)pairs * 0.47 * scale;
-            const double convert = (double)n_trees * (double)N * (0.01 + 0.04 * std::min(1.0, (double)nodes_per_tree / 256.0));
+            const double convert = (double)n_trees * (double)N *
+                                   ((prev_rows && g_rows_advance ? 0.007 : 0.01 + 0.03 * std::min(1.0, (double)nodes_per_tree / 256.0)) +
+                                    0.012 * std::min(1.0, (double)nodes_per_tree / 512.0));
             uint32_t tc = g_rows_max_tc;
             while (tc > 1 && (uint64_t)tc * nodes_per_tree * nstride > g_rows_cache_bytes) tc >>= 1;
             while (tc > 2 && tc / 2 >= n_trees) tc >>= 1;  // do not instantiate more slots than trees
@@ -892,9 +929,25 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             AH_HIP(hipEventRecord(ep.a, s));
             if (attempt == 0 && row_tc >= 2) {
                 // one pass over the rows serves up to row_tc trees (see k_forest_margin_rows)
-                AH_HIP(hipMemsetAsync(node_of.p, 0xFF, (size_t)n_trees * N * 4, s));
-                hipLaunchKernelGGL(k_forest_assign_node_of, dim3(tile_grid), dim3(kBlock), 0, s, d_nodes.p, d_tiles.p, n_tiles,
-                                   cur, N, node_of.p);
+                if (prev_rows && g_rows_advance) {
+                    AH_HIP(hipMemcpyAsync(d_child.p, h_child.data(), h_child.size() * 4, hipMemcpyHostToDevice, s));
+                    hipLaunchKernelGGL(k_forest_advance_node_of, dim3(kMaxBlocks), dim3(kBlock), 0, s, node_of.p, side_bytes.p,
+                                       d_child.p, (uint64_t)n_trees * N);
+                    if (!fix_nodes.empty()) {
+                        std::vector<FTile> fix;
+                        for (uint32_t i : fix_nodes)
+                            for (uint32_t t = 0; t < level[i].n_tiles; t++) fix.push_back(FTile{i, t * kTile});
+                        AH_TRY(d_fix_tiles.ensure(fix.size()));
+                        AH_HIP(hipMemcpyAsync(d_fix_tiles.p, fix.data(), fix.size() * sizeof(FTile), hipMemcpyHostToDevice, s));
+                        hipLaunchKernelGGL(k_forest_assign_node_of, dim3(std::min<uint32_t>((uint32_t)fix.size(), kMaxBlocks)),
+                                           dim3(kBlock), 0, s, d_nodes.p, d_fix_tiles.p, (uint32_t)fix.size(), cur, N, node_of.p);
+                        AH_HIP(hipStreamSynchronize(s));  // `fix` is a pageable staging vector
+                    }
+                } else {
+                    AH_HIP(hipMemsetAsync(node_of.p, 0xFF, (size_t)n_trees * N * 4, s));
+                    hipLaunchKernelGGL(k_forest_assign_node_of, dim3(tile_grid), dim3(kBlock), 0, s, d_nodes.p, d_tiles.p,
+                                       n_tiles, cur, N, node_of.p);
+                }
                 const unsigned row_grid = (unsigned)std::min<uint64_t>((N + 31) / 32, kMaxBlocks);
                 for (uint32_t t0 = 0; t0 < n_trees; t0 += row_tc) {
                     const uint32_t np = std::min<uint32_t>(row_tc, n_trees - t0);
@@ -959,6 +1012,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
 
         // host: materialise the split records and the next level (children lists subdivide the parent range)
         level.clear();
+        prev_rows = row_tc >= 2;
+        fix_nodes.clear();
+        if (prev_rows) h_child.assign(2 * (size_t)n_nodes, 0xFFFFFFFFu);
         for (uint32_t i = 0; i < n_nodes; i++) {
             const FNode nd = h_nodes[i];
             AH_REQUIRE(nd.state != ST_PENDING && nd.n_left <= nd.count, AH_ERR_DEVICE,
@@ -989,6 +1045,11 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     cn.tree = nd.tree;
                     cn.count = c.count;
                     cn.rec = cidx;
+                    if (prev_rows) {
+                        // sides of a first-attempt accept are the ones the row-major pass left in side_bytes
+                        if (nd.state == ST_ACCEPTED && nd.attempt == 0) h_child[2 * (size_t)i + side] = (uint32_t)level.size();
+                        else fix_nodes.push_back((uint32_t)level.size());
+                    }
                     level.push_back(cn);
                 }
                 recs.push_back(c);
