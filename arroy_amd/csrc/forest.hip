@@ -541,6 +541,10 @@ bool g_debug = getenv("AH_DEBUG") != nullptr;
 // AH_ROWMAJOR_CACHE_MB = budget for one group's normals (default 6.5 MB: per-level traces of the 10M x 768 build show
 // the per-margin cost of a pass rising from 0.10-0.16 ns below it to 0.27-0.5 ns at 12.6 MB, see build_batch).
 int g_rows_force = getenv("AH_ROWMAJOR") ? atoi(getenv("AH_ROWMAJOR")) : -1;
+// grid caps of the two margin kernels (grid-stride beyond them).  One tile / 32 rows per block measured 2 % faster
+// than a 4096-block persistent grid on the 10M x 768 build (3.55 vs 3.63 s of device time).
+uint32_t g_tile_blocks = getenv("AH_FOREST_TILE_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_TILE_BLOCKS")) : (1u << 20);
+uint32_t g_row_blocks = getenv("AH_FOREST_ROW_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_ROW_BLOCKS")) : (1u << 20);
 bool g_rows_advance = !(getenv("AH_ROWMAJOR_ADVANCE") && atoi(getenv("AH_ROWMAJOR_ADVANCE")) == 0);  // A/B switch
 uint32_t g_rows_max_tc = getenv("AH_ROWMAJOR_MAX_TC") ? (uint32_t)atoi(getenv("AH_ROWMAJOR_MAX_TC")) : 16u;
 uint64_t g_rows_cache_bytes = (uint64_t)((getenv("AH_ROWMAJOR_CACHE_MB") ? atof(getenv("AH_ROWMAJOR_CACHE_MB")) : 6.5) * 1e6);
@@ -877,7 +881,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         normals_bytes += chunk.bytes;
         AH_HIP(hipMemcpyAsync(d_nodes.p, h_nodes, n_nodes * sizeof(FNode), hipMemcpyHostToDevice, s));
         AH_HIP(hipMemcpyAsync(d_tiles.p, h_tiles, n_tiles * sizeof(FTile), hipMemcpyHostToDevice, s));
-        const unsigned tile_grid = std::min<uint32_t>(n_tiles, kMaxBlocks);
+        const unsigned tile_grid = std::min<uint32_t>(n_tiles, g_tile_blocks);
         // Row-major or node-major for the first attempt of this level?  Row-major streams all N rows once per group of
         // row_tc trees; node-major reads only the still-active items, once per tree.  The group is sized so that the
         // level's normals of one group stay cache-resident.
@@ -948,7 +952,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     hipLaunchKernelGGL(k_forest_assign_node_of, dim3(tile_grid), dim3(kBlock), 0, s, d_nodes.p, d_tiles.p,
                                        n_tiles, cur, N, node_of.p);
                 }
-                const unsigned row_grid = (unsigned)std::min<uint64_t>((N + 31) / 32, kMaxBlocks);
+                const unsigned row_grid = (unsigned)std::min<uint64_t>((N + 31) / 32, g_row_blocks);
                 for (uint32_t t0 = 0; t0 < n_trees; t0 += row_tc) {
                     const uint32_t np = std::min<uint32_t>(row_tc, n_trees - t0);
 #define AH_ROWS(M, TCV)                                                                                          \
