@@ -11,7 +11,8 @@ in HBM by the counter-based generator of include/arroy_hip_policy.h (seed 42), i
   * value = total distances/s over all ranks (every rank scans its own replica: weak scaling).
   * roofline: algorithmic bytes per launch = 1M x (4*768 + 4 header + 4 out) = 3080 B/distance
      / the average kernel time measured with HIP events on the launch stream.
-  * build: the n_trees=50 forest of the same config, trees sharded round-robin over ranks, no collective.
+  * build: the n_trees=50 forest of the same config, trees sharded round-robin over ranks, no collective;
+    build_10m: the 10M x 768, n_trees=100 forest of configs[2] ("tree-build seconds at 10M vectors"), same sharding.
   * cpu_baseline (rank 0, N=1 only): the C oracle (a restatement of arroy's AVX2+FMA path, NOT arroy) on a
     bounded sample of the same workload, all host cores.
 One JSON line on stdout (rank 0).  `--dry-run` exercises the multi-process control path on CPU (gloo).
@@ -41,6 +42,8 @@ def parse_args():
     ap.add_argument("--items", type=int, default=N_ITEMS)
     ap.add_argument("--trees", type=int, default=N_TREES)
     ap.add_argument("--no-build", action="store_true", help="skip the forest-build measurement")
+    ap.add_argument("--no-build-10m", action="store_true",
+                    help="skip the 10M x 768 x 100-tree build (BASELINE configs[2], the 'tree-build seconds at 10M' of the metric)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: test the N>1 control path (gloo)")
@@ -358,8 +361,11 @@ def main():
             cpu = cpu_baseline(args, n)
         extra = {}
         wanted = [x for x in args.extra.split(",") if x]
-        if wanted:
-            ds.close()
+        ds.close()
+        # "tree-build seconds at 10M vectors" (BASELINE.json metric, configs[2]): 100 trees sharded over the ranks
+        build_10m = None
+        if not args.no_build and not args.no_build_10m and n == N_ITEMS and "c3" not in wanted:
+            wanted.append("c3")
         if "c5" in wanted and rank == 0:
             extra["c5"] = extra_c5(local_rank)
         if "c4" in wanted and rank == 0:
@@ -374,8 +380,11 @@ def main():
             c3 = extra_c3(local_rank, lambda t: shard.tree_seeds(SEED, shard.trees_for_rank(t, rank, world)))
             barrier_sync()
             c3["seconds_max_over_ranks"] = max_over_ranks(time.perf_counter() - t0)
-            extra["c3"] = c3
+            c3["seconds"] = max_over_ranks(c3["seconds"])
+            c3["scaling"] = "strong"
+            build_10m = c3
         result["extra"] = extra
+        result["build_10m"] = build_10m
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -396,6 +405,7 @@ def main():
                          "algorithmic_bytes_per_launch": n * BYTES_PER_DISTANCE},
             "cpu_baseline": cpu,
             "build": build,
+            "build_10m": result.get("build_10m"),
         }
         if result.get("extra"):
             line["extra"] = result["extra"]
