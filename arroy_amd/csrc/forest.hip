@@ -622,6 +622,11 @@ struct Readback {
         for (auto &t : pool) t.join();
     }
     hipError_t copy(const Job &job, hipStream_t cs, hipEvent_t *ev) {
+        static const bool direct = getenv("AH_READBACK_DIRECT") != nullptr;  // A/B: let the runtime stage the copy
+        if (direct) {
+            hipError_t e = hipMemcpyAsync(job.dst, job.src, job.bytes, hipMemcpyDeviceToHost, cs);
+            return e == hipSuccess ? hipStreamSynchronize(cs) : e;
+        }
         const uint8_t *src = reinterpret_cast<const uint8_t *>(job.src);
         uint8_t *dst = reinterpret_cast<uint8_t *>(job.dst);
         size_t issued = 0, landed = 0, prev_len = 0;
@@ -773,27 +778,29 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_REQUIRE(grown, AH_ERR_OUT_OF_MEMORY, "host allocation of the descendants failed");
         forest->descendants = grown;
     }
-    struct Joiner {
+    struct Toucher {  // commits the pages of a fresh (still unwritten) host range in the background
         std::thread th;
+        void start(void *ptr, size_t bytes) {
+            join();
+            if (bytes < (8u << 20)) return;
+            uint8_t *lo = reinterpret_cast<uint8_t *>(ptr);
+            th = std::thread([lo, bytes] {
+                const size_t parts = std::min<size_t>(4, std::max<size_t>(1, bytes >> 26));
+                std::vector<std::thread> pool;
+                for (size_t p = 0; p < parts; p++)
+                    pool.emplace_back([=] {
+                        const size_t a = bytes * p / parts, b = bytes * (p + 1) / parts;
+                        for (size_t off = a; off < b; off += 4096) reinterpret_cast<volatile uint8_t *>(lo)[off] = 0;
+                    });
+                for (auto &t : pool) t.join();
+            });
+        }
         void join() {
             if (th.joinable()) th.join();
         }
-        ~Joiner() { join(); }
-    } prefault;
-    if (M * 4 >= (8u << 20)) {
-        uint8_t *lo = reinterpret_cast<uint8_t *>(forest->descendants + desc_base);
-        const size_t bytes = M * 4;
-        prefault.th = std::thread([lo, bytes] {
-            const size_t parts = std::min<size_t>(4, std::max<size_t>(1, bytes >> 26));
-            std::vector<std::thread> pool;
-            for (size_t p = 0; p < parts; p++)
-                pool.emplace_back([=] {
-                    const size_t a = bytes * p / parts, b = bytes * (p + 1) / parts;
-                    for (size_t off = a; off < b; off += 4096) reinterpret_cast<volatile uint8_t *>(lo)[off] = 0;
-                });
-            for (auto &t : pool) t.join();
-        });
-    }
+        ~Toucher() { join(); }
+    } prefault, prefault_normals;
+    prefault.start(forest->descendants + desc_base, M * 4);
     BatchCleanup bc;
     Readback rb;  // declared after `bc`: joined before the level chunks it reads are freed
     rb.start(ds->device, reinterpret_cast<uint8_t *>(ctx->h_pinned) + pin_tables, kBounce);
@@ -879,6 +886,10 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_HIP(hipMalloc((void **)&chunk.d, chunk.bytes));
         bc.chunks.push_back(chunk);
         normals_bytes += chunk.bytes;
+        // host side of this level's normals: reserved now and page-touched while the level is computed
+        prefault_normals.join();
+        AH_TRY(reserve_normals(chunk.host_off + chunk.bytes));
+        prefault_normals.start(forest->normals + chunk.host_off, chunk.bytes);
         AH_HIP(hipMemcpyAsync(d_nodes.p, h_nodes, n_nodes * sizeof(FNode), hipMemcpyHostToDevice, s));
         AH_HIP(hipMemcpyAsync(d_tiles.p, h_tiles, n_tiles * sizeof(FTile), hipMemcpyHostToDevice, s));
         const unsigned tile_grid = std::min<uint32_t>(n_tiles, g_tile_blocks);
@@ -1011,7 +1022,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_HIP(hipMemcpyAsync(h_nodes, d_nodes.p, n_nodes * sizeof(FNode), hipMemcpyDeviceToHost, s));
         AH_HIP(hipStreamSynchronize(s));
         // this level's normals are final: the worker copies them while the next level runs
-        AH_TRY(reserve_normals(chunk.host_off + chunk.bytes));
+        prefault_normals.join();  // never touch a page the worker may already have filled
         rb.push(forest->normals + chunk.host_off, chunk.d, chunk.bytes);
 
         // host: materialise the split records and the next level (children lists subdivide the parent range)
@@ -1083,16 +1094,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         if (!ds->identity_ids && M)
             hipLaunchKernelGGL(k_rows_to_ids, dim3(2048), dim3(256), 0, s, final_perm.p, M, ds->d_ids);
         AH_HIP(hipStreamSynchronize(s));
-        rb.push(forest->descendants + desc_base, final_perm.p, M * 4);
+        rb.push(forest->descendants + desc_base, final_perm.p, M * 4);  // lands while the host emits the node list
     }
-    AH_REQUIRE(rb.drain() == hipSuccess, AH_ERR_DEVICE, "device -> host copy of the forest failed");
-    forest->normals_len = normals_base + normals_bytes;
-    if (normals_cap > forest->normals_len) {  // give the head-room back (shrinks in place)
-        uint8_t *fit = (uint8_t *)realloc(forest->normals, forest->normals_len + 16);
-        if (fit) forest->normals = fit;
-    }
-    AH_HIP(hipStreamSynchronize(s));
-    const auto t_readback = std::chrono::steady_clock::now();
     float ms = 0.0f;
     AH_HIP(hipEventElapsedTime(&ms, bc.ev_begin, bc.ev_end));
     forest->stats.seconds_device += ms * 1e-3;
@@ -1141,12 +1144,20 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         }
         forest->roots.push_back(new_index[tree_root[t]]);
     }
+    const auto t_emitted = std::chrono::steady_clock::now();
+    AH_REQUIRE(rb.drain() == hipSuccess, AH_ERR_DEVICE, "device -> host copy of the forest failed");
+    forest->normals_len = normals_base + normals_bytes;
+    if (normals_cap > forest->normals_len) {  // give the head-room back (shrinks in place)
+        uint8_t *fit = (uint8_t *)realloc(forest->normals, forest->normals_len + 16);
+        if (fit) forest->normals = fit;
+    }
     if (getenv("AH_TIMING")) {
         const auto t_end = std::chrono::steady_clock::now();
         auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
-        fprintf(stderr, "[ah] batch of %u trees: levels %.3f s (device %.3f), readback %.3f s (%.2f GB normals, %.2f GB ids), emit %.3f s\n",
-                n_trees, sec(t_batch, t_levels), ms * 1e-3, sec(t_levels, t_readback), normals_bytes / 1e9, M * 4 / 1e9,
-                sec(t_readback, t_end));
+        fprintf(stderr, "[ah] batch of %u trees: levels %.3f s (device %.3f), emit %.3f s, read-back still in flight after it "
+                        "%.3f s (%.2f GB normals, %.2f GB ids)\n",
+                n_trees, sec(t_batch, t_levels), ms * 1e-3, sec(t_levels, t_emitted), sec(t_emitted, t_end),
+                normals_bytes / 1e9, M * 4 / 1e9);
     }
     return AH_OK;
 }
