@@ -303,6 +303,79 @@ __global__ __launch_bounds__(kBlock) void k_forest_margin_rows(DataView dv, cons
     }
 }
 
+// Top levels of the forest: a group of trees has so few nodes that ALL its normals of the level fit in LDS (a level's
+// nodes are ordered by tree, so a group owns the contiguous range [first_node, first_node + n_group_nodes)).  The
+// row-major pass above is bound by the L1/L2 request rate of the normals (0.097 ns per margin at 16 trees); serving them
+// from LDS leaves L1 to the row stream and the pass approaches the HBM time of the rows.  One big block per CU shares one
+// copy of the normals: 1024 threads for 8 trees (114 VGPRs), 512 for 16 trees (the 64 accumulators need > 128 VGPRs);
+// same arithmetic, bit-identical sides.
+template <int METRIC, int TC>
+__global__ __launch_bounds__(TC >= 16 ? 512 : 1024) void k_forest_margin_rows_lds(DataView dv, const uint32_t *__restrict__ node_of,
+                                                                 uint32_t tree0, uint32_t n_pass,
+                                                                 const uint8_t *__restrict__ normals, uint64_t nstride,
+                                                                 uint64_t hdr_off, uint8_t *__restrict__ side_bytes,
+                                                                 uint32_t first_node, uint32_t n_group_nodes) {
+    extern __shared__ float4 s_norm4[];
+    const uint32_t stride4 = (uint32_t)(nstride >> 4);  // record size in float4 (row bytes are a multiple of 128, + 16)
+    {
+        const float4 *g = reinterpret_cast<const float4 *>(normals + (uint64_t)first_node * nstride);
+        const uint32_t total = n_group_nodes * stride4;
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) s_norm4[i] = g[i];
+    }
+    __syncthreads();
+    const uint32_t j = threadIdx.x & 7u;
+    const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+    const uint32_t blocks = dv.dims >> 5;
+    const uint32_t hdr4 = (uint32_t)(hdr_off >> 4);
+    for (uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; row < dv.n; row += n_octets) {
+        const float *rp = dv.rows_f32 + row * dv.pitch;
+        const float4 *r4 = reinterpret_cast<const float4 *>(rp) + j;
+        uint32_t off[TC];  // float4 index of the normal record in LDS
+        bool on[TC];
+        float4 acc[TC];
+#pragma unroll
+        for (int t = 0; t < TC; t++) {
+            uint32_t node = 0xFFFFFFFFu;
+            if ((uint32_t)t < n_pass) node = node_of[(uint64_t)(tree0 + t) * dv.n + row];
+            on[t] = node != 0xFFFFFFFFu;
+            off[t] = (on[t] ? node - first_node : 0u) * stride4;
+            acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        uint32_t k = 0;
+        for (; k + 8 <= blocks; k += 8) {
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = ld_stream(r4 + (k + u) * 8);
+#pragma unroll
+            for (int t = 0; t < TC; t++) {
+                if (on[t]) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) fma_step<OP_DOT>(acc[t], s_norm4[off[t] + (k + u) * 8 + j], x[u]);
+                }
+            }
+        }
+        for (; k < blocks; k++) {
+            const float4 x = r4[k * 8];
+#pragma unroll
+            for (int t = 0; t < TC; t++)
+                if (on[t]) fma_step<OP_DOT>(acc[t], s_norm4[off[t] + k * 8 + j], x);
+        }
+#pragma unroll
+        for (int t = 0; t < TC; t++) {
+            if (on[t]) {
+                const float *np = reinterpret_cast<const float *>(s_norm4 + off[t]);
+                float d = octet_finish(acc[t]);
+                d = scalar_tail<OP_DOT>(d, np, rp, blocks << 5, dv.dims);
+                const float *nh = reinterpret_cast<const float *>(s_norm4 + off[t] + hdr4);
+                float m = d;
+                if (METRIC == AH_EUCLIDEAN || METRIC == AH_MANHATTAN) m = f_add(nh[0], d);
+                if (METRIC == AH_DOT_PRODUCT) m = f_add(d, f_mul(nh[0], dv.headers[2 * row]));
+                if (j == 0) side_bytes[(uint64_t)(tree0 + t) * dv.n + row] = (uint8_t)side_of_margin(m);
+            }
+        }
+    }
+}
+
 // side bytes (by row) -> the per-tile masks / left counts of the node-major pipeline
 __global__ __launch_bounds__(kBlock) void k_forest_masks_from_bytes(FNode *nodes, const FTile *__restrict__ tiles,
                                                                     uint32_t n_tiles, const uint32_t *__restrict__ perm,
@@ -546,6 +619,8 @@ int g_rows_force = getenv("AH_ROWMAJOR") ? atoi(getenv("AH_ROWMAJOR")) : -1;
 uint32_t g_tile_blocks = getenv("AH_FOREST_TILE_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_TILE_BLOCKS")) : (1u << 20);
 uint32_t g_row_blocks = getenv("AH_FOREST_ROW_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_ROW_BLOCKS")) : (1u << 20);
 bool g_rows_advance = !(getenv("AH_ROWMAJOR_ADVANCE") && atoi(getenv("AH_ROWMAJOR_ADVANCE")) == 0);  // A/B switch
+bool g_rows_lds = !(getenv("AH_ROWMAJOR_LDS") && atoi(getenv("AH_ROWMAJOR_LDS")) == 0);              // A/B switch
+constexpr size_t kLdsNormalsBytes = 128u << 10;  // LDS given to the normals of one tree group (of 160 KiB per CU)
 uint32_t g_rows_max_tc = getenv("AH_ROWMAJOR_MAX_TC") ? (uint32_t)atoi(getenv("AH_ROWMAJOR_MAX_TC")) : 16u;
 uint64_t g_rows_cache_bytes = (uint64_t)((getenv("AH_ROWMAJOR_CACHE_MB") ? atof(getenv("AH_ROWMAJOR_CACHE_MB")) : 6.5) * 1e6);
 #define AH_DBG(s, what)                                                       \
@@ -933,6 +1008,28 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                 if (g_rows_force == 1 || cost_rows < 0.95 * cost_node) row_tc = tc;
             }
         }
+        // Top levels: all normals of a group of >= 8 trees fit in LDS -> the LDS-resident variant of the row-major pass.
+        uint32_t lds_tc = 0;
+        std::vector<uint32_t> tree_first;  // first node of every tree in this level (nodes are ordered by tree)
+        if (rows_allowed && g_rows_lds && row_tc >= 2 && (hdr_off & 15) == 0) {
+            tree_first.assign(n_trees + 1, n_nodes);
+            bool ordered = true;
+            for (uint32_t i = n_nodes; i-- > 0;) {
+                tree_first[level[i].tree] = i;
+                if (i + 1 < n_nodes && level[i].tree > level[i + 1].tree) ordered = false;
+            }
+            for (uint32_t t = n_trees; t-- > 0;) tree_first[t] = std::min(tree_first[t], tree_first[t + 1]);
+            for (uint32_t tc = std::min<uint32_t>(16, g_rows_max_tc); ordered && tc >= 8; tc >>= 1) {
+                uint32_t worst = 0;
+                for (uint32_t t0 = 0; t0 < n_trees; t0 += tc)
+                    worst = std::max(worst, tree_first[std::min(n_trees, t0 + tc)] - tree_first[t0]);
+                if ((uint64_t)worst * nstride <= kLdsNormalsBytes) {
+                    lds_tc = tc;
+                    break;
+                }
+            }
+            if (lds_tc) row_tc = lds_tc;
+        }
         for (int attempt = 0; attempt < 4; attempt++) {
             hipLaunchKernelGGL(k_forest_create_split, dim3(n_nodes), dim3(64), cs_shared, s, dv, d_nodes.p, cur, N,
                                chunk.d, nstride, hdr_off);
@@ -964,7 +1061,38 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                                        n_tiles, cur, N, node_of.p);
                 }
                 const unsigned row_grid = (unsigned)std::min<uint64_t>((N + 31) / 32, g_row_blocks);
-                for (uint32_t t0 = 0; t0 < n_trees; t0 += row_tc) {
+                for (uint32_t t0 = 0; t0 < n_trees && lds_tc; t0 += lds_tc) {
+                    const uint32_t np = std::min<uint32_t>(lds_tc, n_trees - t0);
+                    const uint32_t first = tree_first[t0], cnt = tree_first[t0 + np] - first;
+                    if (cnt == 0) continue;
+                    const size_t sh = (size_t)cnt * nstride;
+                    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(2, (150u << 10) / std::max<size_t>(sh, 1)));
+                    const unsigned lthreads = lds_tc >= 16 ? 512u : 1024u;
+                    const unsigned lgrid = (unsigned)std::min<uint64_t>((N * 8 + lthreads - 1) / lthreads, 256u * per_cu);
+#define AH_ROWS_LDS(M, TCV)                                                                                             \
+    do {                                                                                                                \
+        static bool lds_opt_in = false; /* once per instantiation: the call is slow (~4 ms) */                          \
+        if (!lds_opt_in) {                                                                                              \
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_margin_rows_lds<M, TCV>),                \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsNormalsBytes));             \
+            lds_opt_in = true;                                                                                          \
+        }                                                                                                               \
+        hipLaunchKernelGGL((k_forest_margin_rows_lds<M, TCV>), dim3(lgrid), dim3(lthreads), sh, s, dv, node_of.p, t0, np, \
+                           chunk.d, nstride, hdr_off, side_bytes.p, first, cnt);                                        \
+    } while (0)
+#define AH_ROWS_LDS_TC(M)                  \
+    if (lds_tc == 16) AH_ROWS_LDS(M, 16);  \
+    else AH_ROWS_LDS(M, 8)
+                    switch (ds->metric) {
+                    case AH_EUCLIDEAN: AH_ROWS_LDS_TC(AH_EUCLIDEAN); break;
+                    case AH_MANHATTAN: AH_ROWS_LDS_TC(AH_MANHATTAN); break;
+                    case AH_COSINE: AH_ROWS_LDS_TC(AH_COSINE); break;
+                    default: AH_ROWS_LDS_TC(AH_DOT_PRODUCT); break;
+                    }
+#undef AH_ROWS_LDS_TC
+#undef AH_ROWS_LDS
+                }
+                for (uint32_t t0 = 0; t0 < n_trees && !lds_tc; t0 += row_tc) {
                     const uint32_t np = std::min<uint32_t>(row_tc, n_trees - t0);
 #define AH_ROWS(M, TCV)                                                                                          \
     hipLaunchKernelGGL((k_forest_margin_rows<M, TCV>), dim3(row_grid), dim3(kBlock), 0, s, dv, node_of.p, t0, np, \
