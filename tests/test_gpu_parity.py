@@ -400,6 +400,132 @@ def test_full_size_properties_1m_x_768_cosine():
     assert all(f1.tree_stats(t)["descendants"] > n // 768 for t in range(2))
 
 
+def subtree_items(forest, node):
+    """Sorted item ids under `node` (vectorised over the Descendants blob: fine for millions of items)."""
+    parts, stack = [], [int(node)]
+    while stack:
+        nd = forest.nodes[stack.pop()]
+        if nd["kind"] == 1:
+            parts.append(forest.descendants[int(nd["offset"]): int(nd["offset"]) + int(nd["count"])])
+        else:
+            stack += [int(nd["left"]), int(nd["right"])]
+    return np.sort(np.concatenate(parts)) if parts else np.zeros(0, np.uint32)
+
+
+def test_full_size_properties_10m_x_768_forest():
+    """BASELINE configs[2] shape (10M x 768 cosine; 6 trees instead of 100 to keep the suite short): size-independent
+    properties of the level-synchronous build at the size where the LDS / row-major / node-major margin kernels,
+    the row-order node_of advance and the overlapped read-back are all in play."""
+    from arroy_amd import Dataset
+    n, dims, trees = 10_000_000, 768, 6
+    ds = Dataset(D.Cosine, dims, n)
+    ds.fill_synthetic(42, 1, n)
+    ds.finalize()
+    f = ds.build_forest(list(range(100, 100 + trees)))
+    assert f.n_trees == trees
+    st = f.stats
+    assert st["margin_row_passes"] > 0 and st["levels"] >= 13
+    nodes = f.nodes
+    leaves = nodes[nodes["kind"] == 1]
+    # (1) leaves hold at most split_after items, every tree partitions the item set (each id exactly once)
+    assert int(leaves["count"].max()) <= dims and int(leaves["count"].sum()) == trees * n
+    for t in range(trees):
+        lt = leaves[leaves["tree"] == t]
+        assert int(lt["count"].sum()) == n
+    d = f.descendants
+    assert d.size == trees * n
+    for t in range(trees):  # trees own consecutive n-sized slices of the blob (final permutations)
+        counts = np.bincount(d[t * n:(t + 1) * n], minlength=n)
+        assert counts.min() == 1 and counts.max() == 1
+    # (2) split nodes at every depth: the sides recomputed by the single-node API (`ah_split_sides`, the margin
+    #     loop of src/writer.rs:1201-1207) reproduce exactly the children the forest recorded
+    rng = np.random.default_rng(1)
+    splits = np.flatnonzero(nodes["kind"] == 2)
+    by_depth = {}
+    for i in splits[rng.permutation(splits.size)[:4000]]:
+        by_depth.setdefault(int(nodes[i]["depth"]), []).append(int(i))
+    checked = 0
+    for depth, cand in sorted(by_depth.items()):
+        for i in cand[:2]:
+            nd = nodes[i]
+            if not nd["has_normal"]:
+                continue
+            left, right = subtree_items(f, nd["left"]), subtree_items(f, nd["right"])
+            if left.size + right.size > 3_000_000:
+                continue  # the top levels are covered by the smaller shapes
+            ids = np.sort(np.concatenate([left, right]))
+            hdr, vec = f.normal_of(i)
+            sides, n_left, _ = ds.split_sides(vec, hdr, sorted_ids=ids, want_margins=False)
+            assert n_left == left.size
+            assert np.array_equal(ids[sides == 0], left) and np.array_equal(ids[sides == 1], right)
+            checked += 1
+    assert checked >= 12
+    # (3) deterministic: the same seeds give the same bytes
+    g = ds.build_forest(list(range(100, 100 + trees)))
+    assert g.normals.tobytes() == f.normals.tobytes() and np.array_equal(g.descendants, d)
+    assert np.array_equal(g.nodes, nodes)
+
+
+def test_full_size_properties_1m_x_1536_dot_rerank():
+    """BASELINE configs[3] shape: 1M x 1536 dot product after `preprocess`, search_k = 10 000 candidate re-ranks."""
+    from arroy_amd import Dataset
+    n, dims, k = 1_000_000, 1536, 100
+    ds = Dataset(D.DotProduct, dims, n)
+    ds.fill_synthetic(42, 1, n)
+    max_norm = ds.preprocess_dot()
+    assert 0.0 < float(max_norm) < float(np.sqrt(np.float32(dims)))  # uniform [-1,1) components
+    ds.finalize()
+    rng = np.random.default_rng(2)
+    nq = 260  # > 2 candidates per stored row in total: the submission takes the row-major path
+    lists = [np.sort(rng.choice(n, int(rng.integers(10_000, 11_536)), replace=False)).astype(np.uint32) for _ in range(nq)]
+    qs = rng.standard_normal((nq, dims)).astype(np.float32)
+    assert sum(len(l) for l in lists) >= 2 * n
+    oi, od, oc = ds.rerank_batch(qs, lists, k)
+    assert np.all(oc == k)
+    for i in (0, 57, nq - 1):
+        # the oracle on exactly these rows (vectors regenerated by the policy generator; `built_distance` of the dot
+        # product does not read the headers, src/distance/dot_product.rs:52-56)
+        vec = np.concatenate([O.synth(42, 1, 1, dims, first_item=int(r)) for r in lists[i]])
+        sub = O.Data(3, vec)
+        q, qh = sub.query_leaf(qs[i])
+        ci, cd = sub.rerank(q, qh, None, k)
+        assert list(oi[i]) == [int(lists[i][r]) for r in ci]
+        assert_bit_equal(od[i], cd)
+        # and the single-query path agrees with the batched one
+        ei, ed = ds.rerank(k, query=qs[i], sorted_ids=lists[i])
+        assert list(ei) == list(oi[i])
+        assert_bit_equal(ed, od[i])
+
+
+@pytest.mark.parametrize("metric", [4, 5, 6])
+def test_full_size_properties_5m_x_768_bq_scan(metric):
+    """BASELINE configs[4] shape: 5M x 768 1-bit vectors, Q=1 scan for the three binary-quantized metrics."""
+    from arroy_amd import Dataset
+    cls = D.BY_METRIC[metric]
+    n, dims = 5_000_000, 768
+    ds = Dataset(cls, dims, n)
+    ds.fill_synthetic(42, 1, n)
+    ds.finalize()
+    q = O.synth(9, 1, 1, dims)[0]
+    full = ds.distances(query=q)
+    assert full.shape == (n,) and not np.isnan(full).any()
+    sample = np.sort(np.random.default_rng(3).choice(n, 4000, replace=False)).astype(np.uint32)
+    sample[:2] = (0, 1)
+    sample[-1] = n - 1
+    sample = np.unique(sample)
+    vec = np.concatenate([O.synth(42, 1, 1, dims, first_item=int(r)) for r in sample])
+    od = O.Data(metric, vec)
+    qv, qh = od.query_leaf(q)
+    assert_bit_equal(full[sample], od.distances(qv, qh))
+    assert_bit_equal(ds.distances(query=q, ids=sample), full[sample])
+    oi, odist = ds.rerank(100, query=q)
+    order = np.lexsort((np.arange(n), full))[:100]  # (distance, id): 1-bit distances tie a lot
+    assert list(oi) == list(order)
+    # normalized_distance: bq_euclidean.rs:56-58, bq_manhattan.rs:55-57, bq_cosine: identity
+    norm = {4: lambda x: x / np.float32(dims), 5: lambda x: np.maximum(x, np.float32(0)) / np.float32(dims), 6: lambda x: x}[metric]
+    assert_bit_equal(odist, norm(full[order]).astype(np.float32))
+
+
 @pytest.mark.parametrize("metric", [4, 5, 6])
 @pytest.mark.parametrize("dims", [64, 1000, 4096, 5000])
 def test_bq_scan_wide_and_narrow_rows(metric, dims):
