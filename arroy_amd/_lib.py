@@ -112,6 +112,7 @@ SIGNATURES = {
     "ah_route_items": (C.c_int, [_VP, _U32P, C.c_size_t, _U64P, _U32P]),
     "ah_bench_scan": (C.c_int, [_VP, C.c_uint32, C.c_uint64, C.c_uint32, _F32P, C.POINTER(C.c_double)]),
     "ah_bench_memcpy": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
+    "ah_bench_read": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     "ah_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
 }
 
@@ -160,6 +161,13 @@ def device_name(device: int = 0) -> str:
     buf = C.create_string_buffer(256)
     check(lib().ah_device_name(device, buf, 256))
     return buf.value.decode()
+
+
+def bench_read(device: int, nbytes: int, iterations: int) -> float:
+    """Read-only stream over `nbytes` x `iterations`; returns total milliseconds (HIP events)."""
+    ms = C.c_double(0)
+    check(lib().ah_bench_read(device, nbytes, iterations, C.byref(ms)))
+    return ms.value
 
 
 def bench_memcpy(device: int, nbytes: int, iterations: int) -> float:

@@ -930,4 +930,31 @@ int ah_bench_memcpy(int device, uint64_t bytes, uint32_t iterations, double *out
     return AH_OK;
 }
 
+int ah_bench_read(int device, uint64_t bytes, uint32_t iterations, double *out_ms_total) {
+    AH_REQUIRE(out_ms_total && iterations > 0 && bytes >= 4096, AH_ERR_INVALID_ARGUMENT, "bad arguments");
+    AH_HIP(hipSetDevice(device));
+    DevMem a, sink;
+    Context c;
+    struct Guard {
+        Context &c;
+        ~Guard() { c.destroy(); }
+    } guard{c};
+    AH_HIP(hipMalloc(&a.p, bytes));
+    AH_HIP(hipMalloc(&sink.p, 8));
+    AH_HIP(hipStreamCreate(&c.stream));
+    AH_HIP(hipEventCreate(&c.ev0));
+    AH_HIP(hipEventCreate(&c.ev1));
+    AH_HIP(hipMemsetAsync(a.p, 1, bytes, c.stream));
+    AH_HIP(hipMemsetAsync(sink.p, 0, 8, c.stream));
+    AH_TRY(launch_bench_read(a.p, bytes, sink.as<unsigned long long>(), c.stream));
+    AH_HIP(hipEventRecord(c.ev0, c.stream));
+    for (uint32_t i = 0; i < iterations; i++) AH_TRY(launch_bench_read(a.p, bytes, sink.as<unsigned long long>(), c.stream));
+    AH_HIP(hipEventRecord(c.ev1, c.stream));
+    AH_HIP(hipEventSynchronize(c.ev1));
+    float ms = 0.0f;
+    AH_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    *out_ms_total = ms;
+    return AH_OK;
+}
+
 }  // extern "C"

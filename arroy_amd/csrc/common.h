@@ -163,6 +163,7 @@ int launch_synth_fill(float *d_rows, uint32_t pitch, uint32_t dims, uint64_t fir
 int launch_build_lut(const uint32_t *d_ids, uint64_t n, uint32_t *d_lut, uint32_t lut_len, hipStream_t s);
 int launch_preprocess_dot(const DataView &dv, float *d_max_norm_bits, hipStream_t s);
 int launch_decode_item(const DataView &dv, uint32_t row, float *d_out, hipStream_t s);
+int launch_bench_read(const void *d_src, uint64_t bytes, unsigned long long *d_sink, hipStream_t s);
 
 // batch.hip
 size_t batch_key_stride(uint32_t max_n);

@@ -307,7 +307,7 @@ def main():
         scan_ms = elapsed * 1e3 / max(args.steps, 1)
         build = {"trees": args.trees, "trees_this_rank": len(my_trees), "seconds": max_over_ranks(0.001 * len(my_trees))}
         kernel_ms = scan_ms
-        copy_gbs = None
+        copy_gbs = read_gbs = None
         dev_name = "dry-run (cpu, gloo)"
         cpu = None
     else:
@@ -332,6 +332,8 @@ def main():
         cp_bytes, cp_iters = 2 << 30, 10
         cp_ms = ahlib.bench_memcpy(local_rank, cp_bytes, cp_iters)
         copy_gbs = 2 * cp_bytes * cp_iters / (cp_ms * 1e-3) / 1e9  # read + write
+        rd_bytes, rd_iters = 3 << 30, 20
+        read_gbs = rd_bytes * rd_iters / (ahlib.bench_read(local_rank, rd_bytes, rd_iters) * 1e-3) / 1e9
         build = None
         if not args.no_build and args.trees > 0:
             barrier_sync()
@@ -401,7 +403,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "ah::k_distances_f32<COSINE,false>", "kernel_ms": kernel_ms,
-                         "measured_d2d_copy_gb_per_s": copy_gbs,
+                         "measured_d2d_copy_gb_per_s": copy_gbs, "measured_read_only_gb_per_s": read_gbs,
+                         "frac_of_measured_read_ceiling": achieved / read_gbs if read_gbs else None,
                          "algorithmic_bytes_per_launch": n * BYTES_PER_DISTANCE},
             "cpu_baseline": cpu,
             "build": build,

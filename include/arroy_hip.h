@@ -298,6 +298,9 @@ AH_API int ah_bench_scan(ah_dataset *ds, uint32_t query_item, uint64_t n, uint32
                   double *out_ms_total);
 /* Device-to-device copy of `bytes` bytes, `iterations` times: the measured streaming ceiling. */
 AH_API int ah_bench_memcpy(int device, uint64_t bytes, uint32_t iterations, double *out_ms_total);
+/* Read-only stream over `bytes` bytes (16-byte loads, integer checksum, nothing written), `iterations` times: the
+ * measured read ceiling of the device, the practical bound of the scan kernels next to the 8 TB/s spec peak. */
+AH_API int ah_bench_read(int device, uint64_t bytes, uint32_t iterations, double *out_ms_total);
 /* Name of the device (hipDeviceProp_t.name / gcnArchName) into buf. */
 AH_API int ah_device_name(int device, char *buf, size_t buf_len);
 
