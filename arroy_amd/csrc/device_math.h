@@ -166,21 +166,37 @@ __device__ __forceinline__ float octet_reduce_any(const float *a, const float *b
 // Manhattan built_distance: strictly sequential sum of |p-q| (src/distance/manhattan.rs:44-46).  The
 // octet loads whole lines like the other metrics; |x-q| is elementwise-exact; the running sum is
 // handed from lane to lane in element order.
+// One 32-element block: lane j owns elements 4j..4j+3; the running sum enters at lane 0 and is handed to the next lane
+// by a DPP row shift (an ALU move, no LDS round trip); after 8 steps lane 7 holds the block's sum and one octet-wide
+// broadcast returns it to every lane (lanes other than the one whose turn it is compute values nobody reads).
+__device__ __forceinline__ float manhattan_block(float r, const float4 x, const float4 q) {
+    const float e0 = fabsf(f_sub(x.x, q.x)), e1 = fabsf(f_sub(x.y, q.y)), e2 = fabsf(f_sub(x.z, q.z)),
+                e3 = fabsf(f_sub(x.w, q.w));
+    float mine = 0.0f;
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) {
+        mine = f_add(f_add(f_add(f_add(r, e0), e1), e2), e3);
+        // row_shr:1 — lane l receives lane l-1's value (lane 0 / 8 of a 16-lane row receive a value that is never used)
+        r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0x111, 0xF, 0xF, false));
+    }
+    return __shfl(mine, 7, 8);
+}
+// `a` = query / centroid (LDS or global), `b` = the streamed row: its line-loads are issued 8 at a time ahead of the
+// serial chain, like octet_reduce_stream, so the chain's latency is not added to the memory latency.
 __device__ __forceinline__ float octet_manhattan(const float *a, const float *b, uint32_t dims, uint32_t j) {
     const uint32_t blocks = dims >> 5;
     const float4 *a4 = reinterpret_cast<const float4 *>(a) + j;
     const float4 *b4 = reinterpret_cast<const float4 *>(b) + j;
     float r = 0.0f;
-    for (uint32_t k = 0; k < blocks; k++) {
-        const float4 x = a4[k * 8], q = b4[k * 8];
-        const float e0 = fabsf(f_sub(x.x, q.x)), e1 = fabsf(f_sub(x.y, q.y)), e2 = fabsf(f_sub(x.z, q.z)),
-                    e3 = fabsf(f_sub(x.w, q.w));
+    uint32_t k = 0;
+    for (; k + 8 <= blocks; k += 8) {
+        float4 x[8];
 #pragma unroll
-        for (int jj = 0; jj < 8; jj++) {
-            float mine = f_add(f_add(f_add(f_add(r, e0), e1), e2), e3);
-            r = __shfl(mine, jj, 8);
-        }
+        for (int u = 0; u < 8; u++) x[u] = b4[(k + u) * 8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) r = manhattan_block(r, a4[(k + u) * 8], x[u]);
     }
+    for (; k < blocks; k++) r = manhattan_block(r, a4[k * 8], b4[k * 8]);
     for (uint32_t i = blocks << 5; i < dims; i++) r = f_add(r, fabsf(f_sub(a[i], b[i])));
     return r;
 }

@@ -48,7 +48,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: test the N>1 control path (gloo)")
     ap.add_argument("--extra", default="", help="comma list of extra measurements: c3 (10M build), c4 (re-rank), "
-                                               "c5 (1-bit scan); reported under the `extra` key")
+                                               "c5 (1-bit scan), metrics (every f32 metric), search, staging; reported "
+                                               "under the `extra` key")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
     return ap.parse_args()
@@ -135,6 +136,27 @@ def extra_c5(device):
                           "frac_of_hbm_peak": rate * per / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms / iters}
         ds.close()
     return {"workload": "5M x 768 1-bit vectors, Q=1 scan", "metrics": out}
+
+
+def extra_metrics(device):
+    """Q=1 scan of 1M x 768 for every f32 metric (the north star names cosine / dot / Euclid / Manhattan)."""
+    from arroy_amd import Dataset, distances
+    out = {}
+    n, iters = N_ITEMS, 50
+    for dist in (distances.Euclidean, distances.Manhattan, distances.Cosine, distances.DotProduct):
+        ds = Dataset(dist, DIMS, n, device=device)
+        ds.fill_synthetic(SEED, 1, n)
+        if dist is distances.DotProduct:
+            ds.preprocess_dot()
+        ds.finalize()
+        ds.bench_scan(7, n, 3)
+        ms, _ = ds.bench_scan(7, n, iters)
+        per = 4 * DIMS + 4 + (4 if dist is distances.Cosine else 0)
+        rate = n * iters / (ms * 1e-3)
+        out[dist.name] = {"distances_per_s": rate, "bytes_per_distance": per, "gb_per_s": rate * per / 1e9,
+                          "frac_of_hbm_peak": rate * per / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms / iters}
+        ds.close()
+    return {"workload": f"{n}x{DIMS} f32 vectors, Q=1 scan", "metrics": out}
 
 
 def _timed_callers(fn, batches, threads):
@@ -370,6 +392,8 @@ def main():
             wanted.append("c3")
         if "c5" in wanted and rank == 0:
             extra["c5"] = extra_c5(local_rank)
+        if "metrics" in wanted and rank == 0:
+            extra["metrics"] = extra_metrics(local_rank)
         if "c4" in wanted and rank == 0:
             extra["c4"] = extra_c4(local_rank)
         if "staging" in wanted and rank == 0:
