@@ -15,6 +15,8 @@ static constexpr int kBlock = 256;       // 4 waves = 32 octets
 static constexpr int kMaxBlocks = 32768;  // one tile per wave up to ~1M f32 rows / 8M 1-bit rows (measured: 1-bit scan 90 -> 80 us vs a 2048-block persistent grid), grid-stride beyond that
 // AH_SCAN_BLOCKS overrides the grid cap of the grid-stride kernels (tuning experiments only)
 static const int g_max_blocks = getenv("AH_SCAN_BLOCKS") ? atoi(getenv("AH_SCAN_BLOCKS")) : kMaxBlocks;
+// AH_MANHATTAN_ROWS=0: the octet kernel for Manhattan too (A/B switch)
+static const bool g_manhattan_rows = !(getenv("AH_MANHATTAN_ROWS") && atoi(getenv("AH_MANHATTAN_ROWS")) == 0);
 
 static inline unsigned grid_for(uint64_t work_items, int items_per_block) {
     uint64_t b = (work_items + items_per_block - 1) / items_per_block;
@@ -131,6 +133,82 @@ __global__ __launch_bounds__(kBlock) void k_distances_f32(DataView dv, const flo
             r = octet_reduce_stream<OP>(s_q4, rp, dv.dims, j);
         }
         if (j == 0) out[i] = f32_epilogue<METRIC>(r, s_hdr, dv, row);
+    }
+}
+
+// Manhattan scan / gather, dims >= 32.  `built_distance` is a strictly sequential sum (src/distance/manhattan.rs:44-46):
+// inside one row nothing can be reassociated, so the octet mapping above spends 8 VALU issue slots per element (every
+// lane of the octet steps through every hand-off) and becomes VALU-bound.  Here the parallelism is across rows instead:
+// a block takes 256 rows; per 32-element chunk the octets load 128-byte lines (coalesced, non-temporal) and park them in
+// LDS, then thread t walks row t's 32 elements sequentially — one subtract and one add-with-|.| per element, no
+// redundant work.  Rows are padded to 33 words in LDS so that the 64 lanes of a wave hit 64 different banks.
+static constexpr uint32_t kManRows = 256;
+template <bool GATHER>
+__global__ __launch_bounds__(kBlock) void k_distances_manhattan(DataView dv, const float *__restrict__ qvec,
+                                                                const uint32_t *__restrict__ ids, uint64_t n,
+                                                                float *__restrict__ out, uint32_t *err) {
+    __shared__ float s_x[kManRows * 33];
+    __shared__ uint32_t s_row[kManRows];
+    const uint32_t t = threadIdx.x, o = t >> 3, j = t & 7u;
+    const uint32_t chunks = (dv.dims + 31) >> 5;
+    const uint64_t n_tiles = (n + kManRows - 1) / kManRows;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t base = tile * kManRows;
+        const uint32_t rows_here = (uint32_t)min((uint64_t)kManRows, n - base);
+        __syncthreads();  // the previous tile's readers are done with s_row / s_x
+        uint32_t my_row = 0xFFFFFFFFu;
+        if (t < rows_here) {
+            uint64_t row = base + t;
+            if (GATHER) {
+                const uint32_t id = ids[base + t];
+                row = row_of_id(dv, id);
+                if (row == ~0ull) atomicOr(err, 1u);                                        // Error::MissingKey
+                if (base + t > 0 && id <= ids[base + t - 1]) atomicOr(err, 2u);           // contract: ascending, unique
+            }
+            my_row = row == ~0ull ? 0xFFFFFFFFu : (uint32_t)row;
+        }
+        s_row[t] = my_row;
+        __syncthreads();
+        // first chunk's lines into registers
+        float4 x[kManRows / 32];
+#pragma unroll
+        for (uint32_t p = 0; p < kManRows / 32; p++) {
+            const uint32_t r = s_row[o + 32 * p];
+            x[p] = r != 0xFFFFFFFFu ? ld_stream(reinterpret_cast<const float4 *>(dv.rows_f32 + (uint64_t)r * dv.pitch) + j)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float sum = 0.0f;
+        for (uint32_t c = 0; c < chunks; c++) {
+#pragma unroll
+            for (uint32_t p = 0; p < kManRows / 32; p++) {
+                float *dst = s_x + (o + 32 * p) * 33 + 4 * j;
+                dst[0] = x[p].x;
+                dst[1] = x[p].y;
+                dst[2] = x[p].z;
+                dst[3] = x[p].w;
+            }
+            __syncthreads();
+            if (c + 1 < chunks) {  // next chunk's lines travel while this one is summed
+#pragma unroll
+                for (uint32_t p = 0; p < kManRows / 32; p++) {
+                    const uint32_t r = s_row[o + 32 * p];
+                    x[p] = r != 0xFFFFFFFFu ? ld_stream(reinterpret_cast<const float4 *>(dv.rows_f32 + (uint64_t)r * dv.pitch) +
+                                                        (c + 1) * 8 + j)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            const uint32_t lim = min(32u, dv.dims - c * 32);
+            const float *mine = s_x + t * 33;
+            const float *q = qvec + c * 32;  // uniform: scalar loads
+            if (lim == 32) {
+#pragma unroll
+                for (uint32_t e = 0; e < 32; e++) sum = f_add(sum, fabsf(f_sub(q[e], mine[e])));
+            } else {
+                for (uint32_t e = 0; e < lim; e++) sum = f_add(sum, fabsf(f_sub(q[e], mine[e])));
+            }
+            __syncthreads();
+        }
+        if (t < rows_here) out[base + t] = my_row != 0xFFFFFFFFu ? sum : __uint_as_float(0x7FC00000u);
     }
 }
 
@@ -336,7 +414,13 @@ static int launch_distances_t(const DataView &dv, const void *qvec, const float 
                        ids, n, out, err)
         switch (dv.metric) {
         case AH_EUCLIDEAN: AH_LAUNCH_F32(AH_EUCLIDEAN); break;
-        case AH_MANHATTAN: AH_LAUNCH_F32(AH_MANHATTAN); break;
+        case AH_MANHATTAN:
+            if (g_manhattan_rows && dv.n < 0xFFFFFFFFull)
+                hipLaunchKernelGGL((k_distances_manhattan<GATHER>), dim3(grid_for(n, kManRows)), dim3(kBlock), 0, s, dv,
+                                   (const float *)qvec, ids, n, out, err);
+            else
+                AH_LAUNCH_F32(AH_MANHATTAN);
+            break;
         case AH_COSINE: AH_LAUNCH_F32(AH_COSINE); break;
         default: AH_LAUNCH_F32(AH_DOT_PRODUCT); break;
         }
