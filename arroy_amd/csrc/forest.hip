@@ -1339,13 +1339,14 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
             set_error("cannot create a HIP stream");
             st = AH_ERR_DEVICE;
         } else {
-            // Trees in flight: bounded by HBM (13 bytes per item per tree + masks + normals) or by the caller.
+            // Trees in flight: bounded by HBM (per item and tree: 3 permutations + node index + side byte + masks = 18
+            // bytes, plus the normals of all levels) or by the caller.
             size_t free_b = 0, total_b = 0;
             (void)hipMemGetInfo(&free_b, &total_b);
             uint32_t batch = options->n_trees;
             if (!subset_ids) {
                 const uint64_t per_tree =
-                    ds->n * 14 + ((ds->n / ((uint64_t)split_after + 1)) + 2) * 2 * (ds->row_bytes() + 128) + (1u << 20);
+                    ds->n * 18 + ((ds->n / ((uint64_t)split_after + 1)) + 2) * 2 * (ds->row_bytes() + 128) + (1u << 20);
                 uint64_t fit = (uint64_t)(free_b * 0.8) / per_tree;
                 if (fit < 1) fit = 1;
                 batch = (uint32_t)std::min<uint64_t>(fit, options->n_trees);
