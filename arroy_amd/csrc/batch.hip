@@ -351,7 +351,7 @@ static const int g_pair_group = getenv("AH_PAIR_GROUP") ? atoi(getenv("AH_PAIR_G
 size_t batch_invert_counter_bytes(uint64_t n_rows) { return (size_t)((n_rows + (n_rows + kScanItems - 1) / kScanItems + 64) * 4); }
 static bool invert_legal(const DataView &dv, uint64_t n_pairs) {
     return !metric_is_bq(dv.metric) && dv.metric != AH_MANHATTAN && dv.dims >= 32 && n_pairs > 0 && n_pairs < 0xFFFFFFFFull &&
-           dv.n < 0xFFFFFFFFull;
+           dv.n > 0 && dv.n < 0xFFFFFFFFull;
 }
 // policy: row-major when the submission re-reads rows (>= 2 candidates per stored row on average)
 bool batch_invert_wanted(const DataView &dv, uint64_t n_candidates) {
