@@ -320,6 +320,33 @@ def test_forest_equals_oracle(metric, n, dims, split_after):
     assert forest.stats["margin_evaluations"] == total
 
 
+def test_baseline_config_1_10k_x_128_euclidean_10_trees():
+    """BASELINE configs[0] (the reference's own CPU-runnable case, examples/build-tree-no-commit.rs shape): 10k x 128
+    Euclidean, n_trees=10, split_after = dimensions.  The whole forest equals the oracle's node for node, and searches
+    through it (default search_k, and exhaustive) equal the oracle's `nns_by_leaf`."""
+    from arroy_amd import Dataset
+    n, dims, trees = 10_000, 128, 10
+    vecs = O.synth(42, 0, n, dims)  # i.i.d. uniform [0,1): what the reference's tests and examples use
+    ds = Dataset(D.Euclidean, dims, n)
+    ds.upload_vectors(np.arange(n, dtype=np.uint32), vecs)
+    ds.finalize()
+    oracle = O.Data(0, vecs)
+    seeds = [int(x) for x in np.random.default_rng(42).integers(0, 2**63, trees)]
+    forest = ds.build_forest(seeds)
+    check_forest_valid(forest, n)
+    for t, seed in enumerate(seeds):
+        assert forest.canonical(t) == oracle.build_tree(0, seed).canonical(), f"tree {t} differs from the oracle"
+    index = ds.create_index(forest)
+    queries = O.synth(7, 0, 16, dims)
+    for count, search_k in [(10, 0), (100, 0), (20, 2**62)]:
+        got = index.search(count, queries=queries, search_k=search_k)
+        for qi in range(len(queries)):
+            qv, qh = oracle.query_leaf(queries[qi])
+            want, _ = O.search(oracle, forest, qv, qh, count, search_k, 0, None)
+            assert [i for i, _ in got[qi]] == [i for i, _ in want]
+            assert_bit_equal([d for _, d in got[qi]], [d for _, d in want])
+
+
 def test_forest_degenerate_inputs():
     from arroy_amd import Dataset
     # all items identical: every split fails 4 times, then the random fallback halves the node
