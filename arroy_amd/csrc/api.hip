@@ -655,7 +655,7 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     }
     const size_t qstride = pad256(ds->row_bytes());
     const size_t kstride = batch_key_stride(std::max<uint32_t>(max_n, 1));
-    const size_t inv_bytes = batch_invert_wanted(ds->view(), total) ? batch_invert_counter_bytes(ds->n) : 0;
+    const size_t inv_bytes = batch_invert_wanted(ds->view(), total) ? batch_invert_counter_bytes(ds->n, total) : 0;
     const size_t dev_bytes = pad256(nq * (size_t)ds->dims * 4) + nq * qstride + pad256(nq * 8) + pad256(nq * sizeof(HostSeg)) +
                              pad256(tiles.size() * sizeof(HostTile)) + pad256(total * 4) * 2 + 2 * pad256(nq * kstride * 8) +
                              pad256(nq * k * 4) * 2 + pad256(inv_bytes) + 4096;

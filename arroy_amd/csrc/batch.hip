@@ -343,12 +343,109 @@ __global__ __launch_bounds__(kBlock) void k_pairs_distances(DataView dv, const u
     }
 }
 
+// Work items of the row-run kernel: the pairs of one row, cut into groups of <= kRunGroup.  `end[r]` is the end of
+// row r's bucket after the scatter (its begin is end[r-1]).
+static constexpr int kRunGroup = 4;
+__global__ __launch_bounds__(256) void k_inv_item_count(const uint32_t *__restrict__ end, uint64_t n_rows,
+                                                        uint32_t *__restrict__ icount) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+        const uint32_t c = end[r] - (r ? end[r - 1] : 0u);
+        icount[r] = (c + kRunGroup - 1) / kRunGroup;
+    }
+}
+__global__ __launch_bounds__(256) void k_inv_item_fill(const uint32_t *__restrict__ end, uint64_t n_rows,
+                                                       const uint32_t *__restrict__ istart, uint64_t *__restrict__ items) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+        const uint32_t begin = r ? end[r - 1] : 0u, c = end[r] - begin;
+        uint64_t *dst = items + istart[r];
+        for (uint32_t i = 0; i * kRunGroup < c; i++)
+            dst[i] = (uint64_t)(begin + i * kRunGroup) | ((uint64_t)min((uint32_t)kRunGroup, c - i * kRunGroup) << 32);
+    }
+}
+
+// pass 3, row-run version: one octet per item = up to kRunGroup pairs of ONE row.  The row chunk is loaded once per
+// step and serves every pair of the item (L1 traffic: 1 row + G query operands per G pairs instead of 2G); a short
+// item repeats its last pair (only the store is guarded), so the inner loop has no branches.
+template <int METRIC>
+__global__ __launch_bounds__(kBlock) void k_pairs_distances_runs(DataView dv, const uint8_t *__restrict__ qvecs,
+                                                                 uint64_t qstride, const float *__restrict__ qhdrs,
+                                                                 const uint64_t *__restrict__ pair_rq,
+                                                                 const uint32_t *__restrict__ pair_pos,
+                                                                 const uint64_t *__restrict__ items,
+                                                                 const uint32_t *__restrict__ n_items_p,
+                                                                 float *__restrict__ out) {
+    constexpr int OP = METRIC == AH_EUCLIDEAN ? OP_EUCLID : OP_DOT;
+    constexpr int G = kRunGroup;
+    const uint32_t j = threadIdx.x & 7u;
+    const uint64_t n_items = *n_items_p;
+    const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+    const uint32_t blocks = dv.dims >> 5;
+    for (uint64_t it = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; it < n_items; it += n_octets) {
+        const uint64_t item = items[it];
+        const uint32_t first = (uint32_t)item, cnt = (uint32_t)(item >> 32);
+        const uint64_t row = pair_rq[first] >> 32;
+        const float *rp = dv.rows_f32 + row * dv.pitch;
+        const float4 *r4 = reinterpret_cast<const float4 *>(rp) + j;
+        const float4 *q4[G];
+        float4 acc[G];
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            const uint32_t qi = (uint32_t)pair_rq[first + min((uint32_t)t, cnt - 1)];
+            q4[t] = reinterpret_cast<const float4 *>(qvecs + (uint64_t)qi * qstride) + j;
+            acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        uint32_t k = 0;
+        for (; k + 2 <= blocks; k += 2) {
+            const float4 x0 = ld_stream(r4 + k * 8), x1 = ld_stream(r4 + (k + 1) * 8);
+            float4 q0[G], q1[G];
+#pragma unroll
+            for (int t = 0; t < G; t++) {
+                q0[t] = q4[t][k * 8];
+                q1[t] = q4[t][(k + 1) * 8];
+            }
+#pragma unroll
+            for (int t = 0; t < G; t++) {
+                fma_step<OP>(acc[t], q0[t], x0);
+                fma_step<OP>(acc[t], q1[t], x1);
+            }
+        }
+        for (; k < blocks; k++) {
+            const float4 x = r4[k * 8];
+#pragma unroll
+            for (int t = 0; t < G; t++) fma_step<OP>(acc[t], q4[t][k * 8], x);
+        }
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            if ((uint32_t)t < cnt) {
+                const float *qp = reinterpret_cast<const float *>(q4[t] - j);
+                float r = octet_finish(acc[t]);
+                r = scalar_tail<OP>(r, qp, rp, blocks << 5, dv.dims);
+                if (j == 0) {
+                    float d = r;
+                    if (METRIC == AH_COSINE) d = cosine_from_dot(r, qhdrs[2 * (uint32_t)pair_rq[first + t]], dv.headers[row]);
+                    if (METRIC == AH_DOT_PRODUCT) d = -r;
+                    out[pair_pos[first + t]] = d;
+                }
+            }
+        }
+    }
+}
+
 // AH_RERANK_INVERT=0 never uses the row-major path, =1 uses it whenever it is legal (A/B measurements)
 static const int g_invert_force = getenv("AH_RERANK_INVERT") ? atoi(getenv("AH_RERANK_INVERT")) : -1;
 static const int g_pair_group = getenv("AH_PAIR_GROUP") ? atoi(getenv("AH_PAIR_GROUP")) : 0;
+static const bool g_pair_runs = !(getenv("AH_PAIR_RUNS") && atoi(getenv("AH_PAIR_RUNS")) == 0);  // A/B: row-run kernel
 
 // counters: one per stored row + the scan's block totals + the grand total
-size_t batch_invert_counter_bytes(uint64_t n_rows) { return (size_t)((n_rows + (n_rows + kScanItems - 1) / kScanItems + 64) * 4); }
+// counters: per stored row a pair bucket and an item count, each with its scan block totals + grand total; then the
+// item list of the row-run kernel (<= pairs / kRunGroup + one partial item per non-empty row)
+size_t batch_invert_counter_bytes(uint64_t n_rows, uint64_t n_candidates) {
+    const uint64_t per_scan = n_rows + (n_rows + kScanItems - 1) / kScanItems + 64;
+    const uint64_t max_items = n_candidates / kRunGroup + std::min(n_rows, n_candidates) + 64;
+    return (size_t)(2 * per_scan * 4 + max_items * 8);
+}
 static bool invert_legal(const DataView &dv, uint64_t n_pairs) {
     return !metric_is_bq(dv.metric) && dv.metric != AH_MANHATTAN && dv.dims >= 32 && n_pairs > 0 && n_pairs < 0xFFFFFFFFull &&
            dv.n > 0 && dv.n < 0xFFFFFFFFull;
@@ -380,6 +477,22 @@ static void launch_inverted(const DataView &dv, uint32_t /*n_queries*/, const ui
     hipLaunchKernelGGL(k_scan_add, dim3(n_sums), dim3(256), 0, s, count, dv.n, sums);
     hipLaunchKernelGGL(k_inv_scatter, dim3(grid), dim3(kBlock), 0, s, dv, d_segs, d_tiles, n_tiles, d_ids, count, pair_rq,
                        pair_pos);
+    if (g_pair_runs) {
+        const uint64_t per_scan = dv.n + n_sums + 64;
+        uint32_t *icount = count + per_scan, *isums = icount + dv.n, *itotal = isums + n_sums;
+        uint64_t *items = reinterpret_cast<uint64_t *>(count + 2 * per_scan);
+        const unsigned rgrid = (unsigned)std::min<uint64_t>((dv.n + 255) / 256, 8192);
+        hipLaunchKernelGGL(k_inv_item_count, dim3(rgrid), dim3(256), 0, s, count, dv.n, icount);
+        hipLaunchKernelGGL(k_scan_block, dim3(n_sums), dim3(256), 0, s, icount, dv.n, isums);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, s, isums, n_sums, itotal);
+        hipLaunchKernelGGL(k_scan_add, dim3(n_sums), dim3(256), 0, s, icount, dv.n, isums);
+        hipLaunchKernelGGL(k_inv_item_fill, dim3(rgrid), dim3(256), 0, s, count, dv.n, icount, items);
+        const uint64_t max_items = n_pairs / kRunGroup + std::min<uint64_t>(dv.n, n_pairs);
+        const unsigned igrid = (unsigned)std::min<uint64_t>((max_items + kBlock / 8 - 1) / (kBlock / 8), 32768);
+        hipLaunchKernelGGL((k_pairs_distances_runs<METRIC>), dim3(igrid), dim3(kBlock), 0, s, dv, d_qvecs, qstride, d_qhdrs,
+                           pair_rq, pair_pos, items, itotal, d_dist);
+        return;
+    }
     const int group = g_pair_group == 8 ? 8 : (g_pair_group == 2 ? 2 : kPairGroup);
     const uint64_t octets = (n_pairs + group - 1) / group;
     const unsigned pgrid = (unsigned)std::min<uint64_t>((octets + kBlock / 8 - 1) / (kBlock / 8), 32768);

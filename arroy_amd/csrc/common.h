@@ -186,7 +186,7 @@ int launch_rerank_batch_prepared(const DataView &dv, uint32_t n_queries, const u
                                  uint64_t n_candidates, uint32_t *d_inv_counters);
 // row-major ("inverted") re-rank of big submissions: policy + the counter scratch it needs (see batch.hip)
 bool batch_invert_wanted(const DataView &dv, uint64_t n_candidates);
-size_t batch_invert_counter_bytes(uint64_t n_rows);
+size_t batch_invert_counter_bytes(uint64_t n_rows, uint64_t n_candidates);
 
 // split.hip
 int launch_split_sides(const DataView &dv, const void *d_nvec, const float *d_nhdr, const uint32_t *d_ids, uint64_t n,

@@ -541,7 +541,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                        pad(nq * 4) * 3 + pad(nq * sizeof(HostSeg2)) + pad((size_t)max_tiles_bound * sizeof(HostTile2)) +
                        2 * pad(nq * kstride * 8) + pad(nq * k * 4) * 2 + 4096;
     // counters of the row-major re-rank, reserved when the candidate lists could be long enough for it
-    const size_t inv_bytes = batch_invert_wanted(ds->view(), (uint64_t)nq * nns_stride) ? batch_invert_counter_bytes(ds->n) : 0;
+    const size_t inv_bytes = batch_invert_wanted(ds->view(), (uint64_t)nq * nns_stride) ? batch_invert_counter_bytes(ds->n, (uint64_t)nq * nns_stride) : 0;
     dev_bytes += pad(inv_bytes);
     AH_TRY(ctx->ensure_device(dev_bytes));
     const size_t pin_bytes = pad(nq * (size_t)ds->dims * 4) + pad(nq * 4) * 4 + pad(nq * sizeof(HostSeg2)) +
