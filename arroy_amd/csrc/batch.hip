@@ -167,11 +167,13 @@ __global__ __launch_bounds__(kBlock) void k_batch_distances_bq(DataView dv, cons
 // ---- row-major ("inverted") distances -------------------------------------------------------------------
 // A big submission re-reads the same rows many times: 1000 queries x ~10.8k candidates over 1M items touch every
 // row ~11 times, and the query-major kernel above pays one HBM read of the row (4*dims bytes) per candidate.
-// Here the (query, candidate) pairs are counting-sorted by row first, so that one octet handles kPairGroup
-// consecutive pairs that mostly share a row: the row is streamed from HBM once (kept in registers across the pairs
-// of a group, and in L2 for the neighbouring groups) while the queries — a few MB in total — come from L2 /
-// Infinity Cache.  HBM traffic drops from `pairs x 4*dims` to about `distinct rows x 4*dims`.  The arithmetic per
-// pair is the same octet reduction, so the distances are bit-identical to the query-major kernel; only the order
+// Here the (query, candidate) pairs are counting-sorted by row first (histogram, exclusive scan, scatter), so that
+// pairs of one row sit next to each other: the row is streamed from HBM once (its other uses hit L1 / L2) while the
+// queries — a few MB in total — come from L2 / Infinity Cache.  HBM traffic drops from `pairs x 4*dims` to about
+// `distinct rows x 4*dims`; the kernels are then bound by the L1/L2 request rate of the operands.  Two kernels:
+// k_pairs_distances_runs (>= 3 pairs per row on average: one octet per <= 4 pairs of ONE row, row chunk loaded once
+// per step) and k_pairs_distances (one octet per 4 consecutive pairs, both operands loaded per pair).  The arithmetic
+// per pair is the same octet reduction, so the distances are bit-identical to the query-major kernel; only the order
 // in which pairs are processed changes, and every pair writes its own output slot.
 static constexpr int kPairGroup = 4;   // pairs per octet (measured on 10M pairs x 1536 dims: 2: 5.4 ms, 4: 5.6 ms, 8: 6.1 ms)
 static constexpr uint32_t kScanItems = 2048;  // counters per scan block (256 threads x 8)
@@ -477,7 +479,9 @@ static void launch_inverted(const DataView &dv, uint32_t /*n_queries*/, const ui
     hipLaunchKernelGGL(k_scan_add, dim3(n_sums), dim3(256), 0, s, count, dv.n, sums);
     hipLaunchKernelGGL(k_inv_scatter, dim3(grid), dim3(kBlock), 0, s, dv, d_segs, d_tiles, n_tiles, d_ids, count, pair_rq,
                        pair_pos);
-    if (g_pair_runs) {
+    // row-run items pay one row operand + kRunGroup query operands each; with < 3 pairs per row most items are short and
+    // the plain pair-per-slot kernel moves fewer operands through L1
+    if (g_pair_runs && n_pairs >= 3 * dv.n) {
         const uint64_t per_scan = dv.n + n_sums + 64;
         uint32_t *icount = count + per_scan, *isums = icount + dv.n, *itotal = isums + n_sums;
         uint64_t *items = reinterpret_cast<uint64_t *>(count + 2 * per_scan);
