@@ -193,20 +193,23 @@ def test_rerank_batch_equals_single_queries():
         assert_bit_equal(od[i, : oc[i]], ed)
 
 
+@pytest.mark.parametrize("nq", [48, 6])
 @pytest.mark.parametrize("metric,dims,sparse_ids", [(0, 70, False), (2, 96, True), (3, 128, False), (2, 33, False)])
-def test_rerank_batch_row_major_path(metric, dims, sparse_ids):
+def test_rerank_batch_row_major_path(metric, dims, sparse_ids, nq):
     """A submission with >= 2 candidates per stored row is re-ranked row-major (pairs counting-sorted by row,
-    batch.hip); same distances bit for bit as the query-major kernel, the single-query path and the oracle."""
+    batch.hip); same distances bit for bit as the query-major kernel, the single-query path and the oracle.
+    nq=48: ~24 pairs per row (row-run kernel); nq=6: between 2 and 3 pairs per row (pair-per-slot kernel)."""
     cls = D.BY_METRIC[metric]
-    n, nq, k = 1500, 48, 25
+    n, k = 1500, 25
     ids = np.sort(np.random.default_rng(3).choice(40_000, n, replace=False)).astype(np.uint32) if sparse_ids else None
     ds, oracle, vecs, ids = make_data(cls, n, dims, seed=17 + metric, ids=ids)
     rng = np.random.default_rng(9)
     qs = rng.standard_normal((nq, dims)).astype(np.float32)
-    sizes = [int(x) for x in rng.integers(1, n, nq)]
+    sizes = [int(x) for x in rng.integers(1, n, nq)] if nq > 6 else [n // 3] * nq
     sizes[0], sizes[1] = n, 0  # every row, and an empty list
     lists = [np.sort(rng.choice(ids, m, replace=False)).astype(np.uint32) for m in sizes]
     assert sum(sizes) >= 2 * n  # the library's policy threshold for the row-major path
+    assert (sum(sizes) >= 3 * n) == (nq > 6)  # ... and for the row-run kernel
     oi, od, oc = ds.rerank_batch(qs, lists, k)
     for i in range(nq):
         if sizes[i] == 0:
