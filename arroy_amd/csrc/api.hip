@@ -687,13 +687,17 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     memcpy(h_q, queries, nq * (size_t)ds->dims * 4);
     memcpy(h_segs, segs.data(), nq * sizeof(HostSeg));
     if (!tiles.empty()) memcpy(h_tiles, tiles.data(), tiles.size() * sizeof(HostTile));
-    if (total)  // tens of MB for a big submission: several cores, like the staging gather
-        parallel_rows(total, [&](size_t lo, size_t hi) { memcpy(h_ids + lo, ids + base + lo, (hi - lo) * 4); });
     hipStream_t s = ctx->stream;
     AH_HIP(hipMemcpyAsync(d_qf32, h_q, nq * (size_t)ds->dims * 4, hipMemcpyHostToDevice, s));
     AH_HIP(hipMemcpyAsync(d_segs, h_segs, nq * sizeof(HostSeg), hipMemcpyHostToDevice, s));
     if (!tiles.empty()) AH_HIP(hipMemcpyAsync(d_tiles, h_tiles, tiles.size() * sizeof(HostTile), hipMemcpyHostToDevice, s));
-    if (total) AH_HIP(hipMemcpyAsync(d_ids, h_ids, total * 4, hipMemcpyHostToDevice, s));
+    // candidate ids: tens of MB for a big submission.  Slices of 2M ids are copied into the pinned buffer by several
+    // cores (like the staging gather) and sent right away, so the DMA of one slice overlaps the host copy of the next.
+    for (uint64_t lo = 0; lo < total; lo += (2u << 20)) {
+        const uint64_t len = std::min<uint64_t>(2u << 20, total - lo);
+        parallel_rows(len, [&](size_t a, size_t b) { memcpy(h_ids + lo + a, ids + base + lo + a, (b - a) * 4); });
+        AH_HIP(hipMemcpyAsync(d_ids + lo, h_ids + lo, len * 4, hipMemcpyHostToDevice, s));
+    }
     AH_HIP(hipMemsetAsync(d_err, 0, 4, s));
     AH_TRY(launch_rerank_batch(ds->view(), d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles,
                                (uint32_t)tiles.size(), d_ids, d_dist, d_ka, d_kb, kstride, max_n, (uint32_t)k, max_rounds,
