@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity sweep (not part of the test suite; run it on a GPU box for as long as you like):
+    python scripts/fuzz_gpu.py [seconds] [seed]
+Every iteration draws a metric, a shape, an id pattern and a set of operations and asserts bit-exact agreement with
+the CPU oracle, like tests/test_gpu_parity.py does for its fixed cases."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+
+import test_gpu_parity as T  # noqa: E402  (helpers: make_data, assert_bit_equal, check_forest_valid)
+from arroy_amd import distances as D  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+T.D, T.O = D, O  # the test module imports these lazily through a fixture
+
+
+def one(rng, it):
+    metric = int(rng.integers(0, 7))
+    cls = D.BY_METRIC[metric]
+    dims = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 96, 100, 127, 128, 200, 257]))
+    n = int(rng.choice([1, 2, 7, 64, 65, 300, 1000, 2049, 5000]))
+    ids = None
+    if rng.random() < 0.4:
+        span = int(n * rng.choice([2, 50, 100000]))
+        ids = np.sort(rng.choice(max(span, n + 1), n, replace=False)).astype(np.uint32)
+    scale = float(rng.choice([1.0, 1.0, 1e-3, 1e3]))
+    ds, oracle, vecs, ids = T.make_data(cls, n, dims, seed=int(rng.integers(1 << 30)), ids=ids, scale=scale)
+    desc = f"it={it} metric={metric} n={n} dims={dims} sparse={ids[-1] != n - 1} scale={scale}"
+    q = (rng.standard_normal(dims) * scale).astype(np.float32)
+    qv, qh = oracle.query_leaf(q)
+    # distances (scan + gather)
+    T.assert_bit_equal(ds.distances(query=q), oracle.distances(qv, qh), desc + " scan")
+    m = int(rng.integers(1, n + 1))
+    rows = np.sort(rng.choice(n, m, replace=False)).astype(np.uint32)
+    T.assert_bit_equal(ds.distances(query=q, ids=ids[rows]), oracle.distances(qv, qh, rows), desc + " gather")
+    # re-rank
+    k = int(rng.choice([1, 3, 10, 100, 3000]))
+    oi, od = ds.rerank(k, query=q, sorted_ids=ids[rows])
+    ei, ed = oracle.rerank(qv, qh, rows, k)
+    assert list(oi) == [int(x) for x in ei], desc + " rerank ids"
+    T.assert_bit_equal(od, ed, desc + " rerank dists")
+    # batched re-rank (both the query-major and the row-major path occur)
+    nq = int(rng.choice([1, 3, 40]))
+    qs = (rng.standard_normal((nq, dims)) * scale).astype(np.float32)
+    lists = [np.sort(rng.choice(n, int(rng.integers(0, n + 1)), replace=False)).astype(np.uint32) for _ in range(nq)]
+    kb = int(rng.choice([1, 5, 50]))
+    bi, bd, bc = ds.rerank_batch(qs, [ids[l] for l in lists], kb)
+    for i in range(nq):
+        v, h = oracle.query_leaf(qs[i])
+        ei, ed = oracle.rerank(v, h, lists[i], kb) if len(lists[i]) else (np.zeros(0, np.uint32), np.zeros(0, np.float32))
+        assert bc[i] == len(ei) and list(bi[i, : bc[i]]) == [int(x) for x in ei], desc + f" batch q={i}"
+        T.assert_bit_equal(bd[i, : bc[i]], ed, desc + f" batch q={i}")
+    # split + sides
+    if n >= 2:
+        sample = rng.choice(n, 12, replace=True).astype(np.uint32)
+        if sample[0] == sample[1]:
+            sample[1] = (sample[0] + 1) % n
+        nv, nh = ds.create_split(ids[sample])
+        ev, eh = oracle.create_split(sample)
+        assert nv.tobytes() == ev.tobytes(), desc + " normal"
+        T.assert_bit_equal(nh, eh, desc + " normal header")
+        sides, n_left, margins = ds.split_sides(nv, nh)
+        es, el, em = oracle.split_sides(ev, eh)
+        T.assert_bit_equal(margins, em, desc + " margins")
+        assert np.array_equal(sides, es) and n_left == el, desc + " sides"
+    # forest + search + routing
+    split_after = int(rng.choice([0, 1, 2, 8, 50, 300]))
+    seeds = [int(x) for x in rng.integers(0, 2**63, int(rng.integers(1, 4)))]
+    forest = ds.build_forest(seeds, split_after=split_after)
+    T.check_forest_valid(forest, n, ids=ids)
+    for t, seed in enumerate(seeds):
+        assert forest.canonical(t) == oracle.build_tree(split_after, seed).canonical(), desc + f" tree {t} sa={split_after}"
+    index = ds.create_index(forest)
+    count, search_k = int(rng.choice([1, 10, 200])), int(rng.choice([0, 1, 100, 2**62]))
+    got = index.search(count, queries=qs[: min(nq, 4)], search_k=search_k)
+    for i in range(min(nq, 4)):
+        v, h = oracle.query_leaf(qs[i])
+        want, _ = O.search(oracle, forest, v, h, count, search_k, 0, None)
+        assert [a for a, _ in got[i]] == [a for a, _ in want], desc + f" search q={i} count={count} sk={search_k}"
+        T.assert_bit_equal([b for _, b in got[i]], [b for _, b in want], desc + " search dists")
+    return desc
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    t0, it = time.time(), 0
+    while time.time() - t0 < seconds:
+        desc = one(rng, it)
+        it += 1
+        if it % 20 == 0:
+            print(f"[{time.time() - t0:6.1f}s] {it} iterations ok; last: {desc}", flush=True)
+    print(f"fuzz ok: {it} random configurations, seed {seed}")
+
+
+if __name__ == "__main__":
+    main()
