@@ -78,10 +78,55 @@ class TreeStore:
         self.nodes: Dict[int, tuple] = {}
         self.roots: List[int] = []
         self._next = 0
+        self._available: List[int] = []
 
-    def next_id(self) -> int:  # ConcurrentNodeIds::next (src/parallel.rs:239-254) without id reuse
+    def begin_build(self) -> None:
+        """`ConcurrentNodeIds::new(used_tree_node)` (src/parallel.rs:222-237, src/writer.rs:516-518): taken BEFORE the
+        build deletes anything — ids freed by earlier builds are handed out first (ascending), ids freed by this
+        build only become available to the next one."""
+        self._next = max(self.nodes) + 1 if self.nodes else 0
+        self._available = [i for i in range(self._next) if i not in self.nodes]
+
+    def next_id(self) -> int:  # ConcurrentNodeIds::next (src/parallel.rs:239-254)
+        if self._available:
+            return self._available.pop(0)
         self._next += 1
         return self._next - 1
+
+    def delete_tree(self, node: int) -> None:  # src/writer.rs:1263-1277
+        for nid in self.subtree_ids(node):
+            del self.nodes[nid]
+
+    def delete_items(self, node: int, to_delete: set, split_after: int):
+        """`delete_items_in_file` (src/writer.rs:1021-1114): remove `to_delete` below `node`; a split whose child
+        became empty is replaced by the other child, two descendants that fit together are merged into their parent.
+        Returns (new node id, ids of the branch if it is a single Descendants node else None)."""
+        nd = self.nodes[node]
+        if nd[0] == "D":
+            kept = np.array([i for i in nd[1] if int(i) not in to_delete], dtype=np.uint32)
+            if len(kept) != len(nd[1]):
+                self.nodes[node] = ("D", kept)
+            return node, kept
+        _, left, right, hdr, vec = nd
+        new_left, left_items = self.delete_items(left, to_delete, split_after)
+        new_right, right_items = self.delete_items(right, to_delete, split_after)
+        if left_items is not None and len(left_items) == 0:
+            self.nodes.pop(new_left, None)
+            self.nodes.pop(node, None)
+            return new_right, right_items
+        if right_items is not None and len(right_items) == 0:
+            self.nodes.pop(new_right, None)
+            self.nodes.pop(node, None)
+            return new_left, left_items
+        if left_items is not None and right_items is not None and len(left_items) + len(right_items) <= split_after:
+            total = np.union1d(left_items, right_items).astype(np.uint32)
+            self.nodes.pop(new_left, None)
+            self.nodes.pop(new_right, None)
+            self.nodes[node] = ("D", total)
+            return node, total
+        if new_left != left or new_right != right:
+            self.nodes[node] = ("S", new_left, new_right, hdr, vec)
+        return node, None
 
     def import_tree(self, forest: Forest, tree: int, root_id: Optional[int] = None) -> int:
         """Copy tree `tree` of a freshly built ah_forest; children get fresh ids before their parent (the order
@@ -321,17 +366,23 @@ class ArroyBuilder:
         present = set(int(i) for i in ids)
         to_delete = np.array(sorted(st.updated), dtype=np.uint32)                 # :504
         to_insert = np.array(sorted(i for i in st.updated if i in present), dtype=np.uint32)  # :505
-        # target_n_trees / delete_extra_trees (:521-522)
+        import sys
+        sys.setrecursionlimit(max(sys.getrecursionlimit(), 100000))
+        trees.begin_build()  # node ids in use are snapshotted before anything is deleted (:516-518)
+        # target_n_trees / delete_extra_trees (:521-522, 631-655): the oldest tree first, `roots.swap_remove(0)`
         want = target_n_trees(self._n_trees, w.dimensions, len(ids), len(trees.roots))
         while len(trees.roots) > want:
-            for nid in trees.subtree_ids(trees.roots.pop()):
-                del trees.nodes[nid]
-        # delete_items_from_trees (:525): updated ids leave every Descendants node (structure kept)
+            root = trees.roots[0]
+            trees.roots[0] = trees.roots[-1]
+            trees.roots.pop()
+            trees.delete_tree(root)
+        # delete_items_from_trees (:525, 979-1114): updated ids leave the trees, emptied / shrunken branches collapse
         if to_delete.size:
-            for nid, nd in trees.nodes.items():
-                if nd[0] == "D" and len(nd[1]):
-                    trees.nodes[nid] = ("D", np.setdiff1d(nd[1], to_delete, assume_unique=True).astype(np.uint32))
+            gone = set(int(i) for i in to_delete)
+            trees.roots = [trees.delete_items(root, gone, split_after)[0] for root in trees.roots]
+        trees.roots.sort()
         # insert_items_in_current_trees (:541-542): one ah_route_items call for all trees
+        grown: Dict[int, List[int]] = {}
         if to_insert.size and trees.roots:
             view, keep = trees.to_view(dist, w.dimensions)
             dense = keep[4]
@@ -339,14 +390,14 @@ class ArroyBuilder:
             old = Index(ds, None, view=view)
             leaf_of = old.route_items(to_insert, self._seeds(len(trees.roots)))
             old.close()
-            grown: Dict[int, List[int]] = {}
             for t in range(leaf_of.shape[0]):
                 for i, leaf in enumerate(leaf_of[t]):
                     grown.setdefault(back[int(leaf)], []).append(int(to_insert[i]))
             for nid, extra in grown.items():
                 trees.nodes[nid] = ("D", np.union1d(trees.nodes[nid][1], np.array(extra, dtype=np.uint32)).astype(np.uint32))
-        # descendants that no longer fit (`fit_in_descendant`, :474-477) -> incremental_index_large_descendant
-        large = [nid for nid, nd in trees.nodes.items() if nd[0] == "D" and len(nd[1]) > split_after]
+        # the descendants the routing touched and that no longer fit (`fit_in_descendant`, :474-477, 787-795) are
+        # re-split (incremental_index_large_descendant, :660-739); untouched ones are left alone, whatever their size
+        large = [nid for nid in sorted(grown) if len(trees.nodes[nid][1]) > split_after]
         if large:
             forest = ds.build_subtrees([trees.nodes[nid][1] for nid in large], self._seeds(len(large)), split_after)
             for t, nid in enumerate(large):

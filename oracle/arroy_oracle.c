@@ -1041,7 +1041,16 @@ typedef struct ao_ref_tree {
     uint32_t *desc;
     size_t desc_len, cap_desc;
     uint32_t next_id;
+    /* ConcurrentNodeIds (src/parallel.rs:206-254): ids freed by earlier builds are handed out first, in ascending
+     * order, then `current` counts up */
+    uint32_t *avail;
+    size_t n_avail, avail_pos;
 } ao_ref_tree;
+
+static uint32_t ref_next_id(ao_ref_tree *t) {
+    if (t->avail_pos < t->n_avail) return t->avail[t->avail_pos++];
+    return t->next_id++;
+}
 
 static void ref_push(ao_ref_tree *t, ao_ref_node nd) {
     if (t->n_nodes == t->cap_nodes) {
@@ -1057,7 +1066,7 @@ static uint32_t ref_build_rec(const ao_data *d, ao_ref_tree *t, uint32_t split_a
     ao_ref_node nd;
     memset(&nd, 0, sizeof nd);
     if (n <= split_after) {
-        nd.id = has_next_id ? next_id : t->next_id++;
+        nd.id = has_next_id ? next_id : ref_next_id(t);
         nd.kind = AH_NODE_DESCENDANTS;
         nd.offset = t->desc_len;
         nd.count = (uint32_t)n;
@@ -1108,7 +1117,7 @@ static uint32_t ref_build_rec(const ao_data *d, ao_ref_tree *t, uint32_t split_a
     free(sides);
     uint32_t left = ref_build_rec(d, t, split_after, rows, n_left, rng, 0, 0, scratch);
     uint32_t right = ref_build_rec(d, t, split_after, rows + n_left, n - n_left, rng, 0, 0, scratch + n_left);
-    nd.id = has_next_id ? next_id : t->next_id++; /* allocated AFTER the children (src/writer.rs:1257) */
+    nd.id = has_next_id ? next_id : ref_next_id(t); /* allocated AFTER the children (src/writer.rs:1257) */
     nd.kind = AH_NODE_SPLIT;
     nd.has_normal = (uint8_t)has_normal;
     nd.left = left;
@@ -1174,8 +1183,65 @@ AO_API size_t ao_ref_tree_nodes(const ao_ref_tree *t, const ao_ref_node **nodes,
     *desc = t->desc;
     return t->n_nodes;
 }
+/* The general form of the build step of `Writer::build` (src/writer.rs:556-591) in the reference's order, used by the
+ * incremental snapshot replays: `descendants` is the map the reference walks in
+ * insert_descendants_in_file_and_spawn_tasks (:744-844) — the Descendants nodes modified by the routing of the new
+ * items plus one all-items entry per missing tree — given here in the map's iteration order.
+ *   - the walking task gets `StdRng::from_seed(main_rng.gen())` (:575);
+ *   - an entry that fits in a descendant is written as is (no randomness);
+ *   - every other entry gets its own `StdRng::from_seed(rng.gen())` (:795), in iteration order, and becomes a task
+ *     `make_tree_in_file(.., Some(descendant_id))`: the sub-tree's root keeps the entry's node id;
+ *   - tasks run last-in-first-out on the single worker; new node ids come from `avail` first, then `current`. */
+AO_API ao_ref_tree *ao_ref_build_descendants(const ao_data *d, uint32_t split_after, const uint32_t *desc_ids,
+                                             const uint64_t *offsets, const uint32_t *rows, uint32_t n_desc,
+                                             ao_chacha *main_rng, const uint32_t *avail, uint32_t n_avail,
+                                             uint32_t current) {
+    ao_ref_tree *t = (ao_ref_tree *)calloc(1, sizeof(ao_ref_tree));
+    if (split_after == 0) split_after = d->dims;
+    t->next_id = current;
+    t->avail = (uint32_t *)malloc(sizeof(uint32_t) * (n_avail ? n_avail : 1));
+    memcpy(t->avail, avail, sizeof(uint32_t) * n_avail);
+    t->n_avail = n_avail;
+    ao_chacha rng1;
+    uint8_t s[32];
+    ao_rng_gen_seed(main_rng, s);
+    ao_rng_from_seed(&rng1, s);
+    uint8_t *task_seeds = (uint8_t *)malloc(32 * (size_t)(n_desc ? n_desc : 1));
+    uint64_t max_n = 1;
+    for (uint32_t k = 0; k < n_desc; k++) {
+        const uint64_t n = offsets[k + 1] - offsets[k];
+        if (n > max_n) max_n = n;
+        if (n > split_after) ao_rng_gen_seed(&rng1, task_seeds + 32 * (size_t)k);
+    }
+    uint32_t *work = (uint32_t *)malloc(sizeof(uint32_t) * max_n);
+    uint32_t *scratch = (uint32_t *)malloc(sizeof(uint32_t) * max_n);
+    for (uint32_t k = 0; k < n_desc; k++) { /* entries that fit: written by the walking task itself */
+        const uint64_t n = offsets[k + 1] - offsets[k];
+        if (n > split_after) continue;
+        memcpy(work, rows + offsets[k], n * sizeof(uint32_t));
+        ref_build_rec(d, t, split_after, work, n, NULL, 1, desc_ids[k], scratch);
+    }
+    for (uint32_t i = 0; i < n_desc; i++) { /* LIFO */
+        const uint32_t k = n_desc - 1 - i;
+        const uint64_t n = offsets[k + 1] - offsets[k];
+        if (n <= split_after) continue;
+        ao_chacha rng2;
+        ao_rng_from_seed(&rng2, task_seeds + 32 * (size_t)k);
+        memcpy(work, rows + offsets[k], n * sizeof(uint32_t));
+        ref_build_rec(d, t, split_after, work, n, &rng2, 1, desc_ids[k], scratch);
+    }
+    free(task_seeds);
+    free(work);
+    free(scratch);
+    return t;
+}
+AO_API uint32_t ao_ref_tree_next_id(const ao_ref_tree *t, uint32_t *avail_used) {
+    if (avail_used) *avail_used = (uint32_t)t->avail_pos;
+    return t->next_id;
+}
 AO_API void ao_ref_tree_free(ao_ref_tree *t) {
     if (!t) return;
+    free(t->avail);
     free(t->nodes);
     free(t->normals);
     free(t->desc);

@@ -84,6 +84,54 @@ def hexf(xs):
     return struct.pack("<%df" % len(xs), *xs).hex()
 
 
+def inline_snapshots(src):
+    import re
+    out = {}
+    fns = list(re.finditer(r"^fn (\w+)\(\) \{", src, re.M))
+    for i, m in enumerate(fns):
+        body = src[m.end(): fns[i + 1].start() if i + 1 < len(fns) else len(src)]
+        line0 = src[: m.start()].count("\n") + 1
+        dumps = []
+        for snap in re.findall(r'insta::assert_snapshot!\(handle, @r#"(.*?)"#\);', body, re.S):
+            if "Dumping index" not in snap or snap.count("Dumping index") != 1:
+                continue
+            trees, items, roots, item_ids = {}, {}, None, None
+            for line in snap.splitlines():
+                line = line.strip()
+                r = re.match(r"Root: Metadata \{ dimensions: (\d+), items: RoaringBitmap<\[(.*?)\]>, roots: \[(.*?)\], "
+                             r'distance: "(.*?)" \}', line)
+                if r:
+                    item_ids = [int(x) for x in r.group(2).split(",") if x.strip()]
+                    roots = [int(x) for x in r.group(3).split(",") if x.strip()]
+                    continue
+                d = re.match(r"Tree (\d+): Descendants\(Descendants \{ descendants: \[(.*?)\] \}\)", line)
+                if d:
+                    trees[d.group(1)] = {"kind": "D", "descendants": [int(x) for x in d.group(2).split(",") if x.strip()]}
+                    continue
+                sp = re.match(r"Tree (\d+): SplitPlaneNormal\(SplitPlaneNormal<(\w+)> \{ left: (\d+), right: (\d+), "
+                              r"normal: (.*) \}\)$", line)
+                if sp:
+                    node = {"kind": "S", "left": int(sp.group(3)), "right": int(sp.group(4))}
+                    nm = re.match(r'Leaf \{ header: \w+ \{ (\w+): "(.*?)" \}, vector: \[(.*?)\] \}', sp.group(5))
+                    if nm:
+                        node["bias"] = nm.group(2)
+                        node["vector"] = [c.strip() for c in nm.group(3).split(",") if "other" not in c]
+                    else:
+                        assert sp.group(5).strip() == "None", sp.group(5)
+                        node["bias"] = node["vector"] = None
+                    trees[sp.group(1)] = node
+                    continue
+                it = re.match(r"Item (\d+): Leaf\(Leaf \{ header: .*?vector: \[(.*?)\] \}\)", line)
+                if it:
+                    items[it.group(1)] = [c.strip() for c in it.group(2).split(",") if "other" not in c]
+            if roots is None:
+                continue
+            dumps.append({"roots": roots, "item_ids": item_ids, "trees": trees, "items": items})
+        if dumps:
+            out[m.group(1)] = {"source": f"src/tests/writer.rs:{line0}", "dumps": dumps}
+    return out
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference not mounted; fixtures are committed, nothing to do")
@@ -156,6 +204,9 @@ def main():
         "source": "src/tests/snapshots/arroy__tests__writer__write_and_update_lot_of_random_points.snap "
                   "(src/tests/writer.rs:296-308)",
         "dims": 30, "n_items": 100, "n_trees": 10, "roots": roots, "trees": trees, "items10": items}
+    # inline insta snapshots of the incremental writer tests (src/tests/writer.rs): for every test function the
+    # sequence of database dumps it asserts, parsed into {roots, items, trees}
+    golden["writer_inline_snapshots"] = inline_snapshots(open(f"{REF}/src/tests/writer.rs").read())
     with open(os.path.join(HERE, "reference_golden.json"), "w") as f:
         json.dump(golden, f, indent=1)
     print("wrote", os.path.join(HERE, "reference_golden.json"), len(v1), len(a1))

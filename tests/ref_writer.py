@@ -1,0 +1,201 @@
+"""Replay of arroy's `Writer::build` — full AND incremental — in the reference's own order and with the reference's own
+randomness, on top of the CPU oracle (test infrastructure, no GPU).  It exists to replay the reference's inline insta
+snapshots (src/tests/writer.rs) step by step: what is pinned is the oracle's arithmetic (create_split, side), the
+restatement of rand 0.8 and — new here — the host-side bookkeeping of incremental builds that arroy_amd/index.py
+mirrors: removal of updated items with node collapsing (`delete_items_in_file`, src/writer.rs:1021-1114), routing of
+new items through the existing planes (:1398-1459), re-splitting of the descendants that outgrew `split_after` with
+the sub-tree root keeping its node id (:660-739), node-id reuse (`ConcurrentNodeIds`, src/parallel.rs:206-254) and the
+add / drop of whole trees (:521-524, 556-561, 631-655).
+
+Nodes: {id: ("D", [ids]) | ("S", left, right, header f32[], vector bytes | None)}.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from oracle import oracle as O
+
+
+def target_n_trees(n_trees, dimensions, n_items, n_roots):  # src/writer.rs:1358-1394
+    if n_trees is not None:
+        return int(n_trees)
+    nb_vec = float(n_items)
+    if nb_vec < 10_000.0:
+        nb = 2.0 ** (math.log2(nb_vec) - 6.0) if nb_vec > 0 else 0.0
+    else:
+        nb = 2.0 ** (math.log10(nb_vec) + math.log10(float(dimensions)) + (768.0 / float(dimensions)) ** 4.0)
+    nb = int(math.ceil(nb))
+    if n_roots > nb and (nb == 0 or (n_roots - nb) / nb < 0.20):
+        nb = n_roots
+    return nb
+
+
+class RefWriter:
+    def __init__(self, metric: int, dimensions: int):
+        self.metric, self.dims = metric, dimensions
+        self.items = {}
+        self.updated = set()
+        self.nodes = {}
+        self.roots = None  # None = no metadata yet
+
+    # ---- Writer::add_item / del_item (src/writer.rs:271-377): both mark the id as updated ----
+    def add_item(self, item: int, vector):
+        self.items[int(item)] = np.asarray(vector, dtype=np.float32)
+        self.updated.add(int(item))
+
+    def del_item(self, item: int) -> bool:
+        if int(item) in self.items:
+            del self.items[int(item)]
+            self.updated.add(int(item))
+            return True
+        return False
+
+    # ---- src/writer.rs:1263-1277 ----
+    def _delete_tree(self, node):
+        nd = self.nodes.pop(node)
+        if nd[0] == "S":
+            self._delete_tree(nd[1])
+            self._delete_tree(nd[2])
+
+    # ---- delete_items_in_file, src/writer.rs:1021-1114: (new node id, items of the branch if it is one descendant) ----
+    def _delete_items(self, node, to_delete, split_after):
+        nd = self.nodes[node]
+        if nd[0] == "D":
+            kept = [i for i in nd[1] if i not in to_delete]
+            if len(kept) != len(nd[1]):
+                self.nodes[node] = ("D", kept)
+            return node, kept
+        _, left, right, hdr, vec = nd
+        new_left, left_items = self._delete_items(left, to_delete, split_after)
+        new_right, right_items = self._delete_items(right, to_delete, split_after)
+        if left_items is not None and len(left_items) == 0:
+            self.nodes.pop(new_left, None)
+            self.nodes.pop(node, None)
+            return new_right, right_items
+        if right_items is not None and len(right_items) == 0:
+            self.nodes.pop(new_right, None)
+            self.nodes.pop(node, None)
+            return new_left, left_items
+        if left_items is not None and right_items is not None:
+            if len(left_items) + len(right_items) <= split_after:
+                total = sorted(set(left_items) | set(right_items))
+                self.nodes.pop(new_left, None)
+                self.nodes.pop(new_right, None)
+                self.nodes[node] = ("D", total)
+                return node, total
+        if new_left != left or new_right != right:
+            self.nodes[node] = ("S", new_left, new_right, hdr, vec)
+        return node, None
+
+    # ---- insert_items_in_descendants_from_frozen_reader, src/writer.rs:1398-1459 ----
+    def _route(self, data, row_of, node, to_insert, out):
+        nd = self.nodes[node]
+        if nd[0] == "D":
+            out[node] = sorted(set(nd[1]) | set(to_insert))
+            return
+        _, left, right, hdr, vec = nd
+        assert vec is not None, "normal: None needs the per-tree rng (not exercised by the replayed snapshots)"
+        rows = np.array([row_of[i] for i in to_insert], dtype=np.uint32)
+        nh = np.zeros(2, dtype=np.float32)
+        nh[: len(hdr)] = hdr
+        sides, _, _ = data.split_sides(np.frombuffer(vec, dtype=np.uint8), nh, rows)
+        left_ids = [i for i, s in zip(to_insert, sides) if s == 0]
+        right_ids = [i for i, s in zip(to_insert, sides) if s == 1]
+        if left_ids:
+            self._route(data, row_of, left, left_ids, out)
+        if right_ids:
+            self._route(data, row_of, right, right_ids, out)
+
+    # ---- Writer::build, src/writer.rs:487-629 ----
+    def build(self, rng: "O.ChaCha12", n_trees=None, split_after=None):
+        split_after = split_after or self.dims
+        item_ids = sorted(self.items)
+        updated, self.updated = set(self.updated), set()
+        if len(item_ids) <= split_after:  # clear_db_and_create_a_single_leaf, :916-962
+            self.nodes = {0: ("D", item_ids)} if item_ids else {}
+            self.roots = [0] if item_ids else []
+            return
+        to_delete = updated
+        to_insert = [i for i in item_ids if i in updated]
+        roots = list(self.roots) if self.roots is not None else []
+        # ConcurrentNodeIds::new(used_tree_node): computed BEFORE anything is deleted (:516-518)
+        used = sorted(self.nodes)
+        last_id = used[-1] + 1 if used else 0
+        avail = [i for i in range(last_id) if i not in self.nodes]
+        current = last_id
+        want = target_n_trees(n_trees, self.dims, len(item_ids), len(roots))
+        for _ in range(max(0, len(roots) - want)):  # delete_extra_trees, :631-655: the oldest first, swap_remove(0)
+            if not roots:
+                break
+            root = roots[0]
+            roots[0] = roots[-1]
+            roots.pop()
+            self._delete_tree(root)
+        for i, root in enumerate(roots):  # delete_items_from_trees, :979-1017
+            roots[i], _ = self._delete_items(root, to_delete, split_after)
+        roots.sort()
+        vecs = np.stack([self.items[i] for i in item_ids])
+        ids = None if item_ids == list(range(len(item_ids))) else np.array(item_ids, dtype=np.uint32)
+        data = O.Data(self.metric, vecs, ids=ids)
+        row_of = {item: r for r, item in enumerate(item_ids)}
+        descendants = {}
+        if roots and to_insert:  # insert_items_in_current_trees, :846-889 -> insert_items_in_tree, :1118-1160
+            rng.next_u32()  # `rng.next_u64()`: the seed of the per-tree rngs (used only below `normal: None` nodes)
+            rng.next_u32()
+            for root in roots:
+                self._route(data, row_of, root, to_insert, descendants)
+
+        def next_id():
+            nonlocal current
+            if avail:
+                return avail.pop(0)
+            current += 1
+            return current - 1
+
+        for _ in range(max(0, want - len(roots))):  # :556-561
+            new_id = next_id()
+            roots.append(new_id)
+            descendants[new_id] = list(item_ids)
+        # IntMap = hashbrown with the identity hash: the walk visits the keys in ascending order (small keys)
+        order = sorted(descendants)
+        offsets = np.zeros(len(order) + 1, dtype=np.uint64)
+        rows = []
+        for k, node in enumerate(order):
+            rows += [row_of[i] for i in descendants[node]]
+            offsets[k + 1] = len(rows)
+        rows_a = np.array(rows if rows else [0], dtype=np.uint32)
+        desc_a = np.array(order if order else [0], dtype=np.uint32)
+        avail_a = np.array(avail if avail else [0], dtype=np.uint32)
+        L = O.lib()
+        L.ao_ref_build_descendants.restype = C.c_void_p
+        L.ao_ref_build_descendants.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                               C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        h = L.ao_ref_build_descendants(data.c(), split_after, desc_a.ctypes.data, offsets.ctypes.data, rows_a.ctypes.data,
+                                       len(order), C.cast(rng._st, C.c_void_p), avail_a.ctypes.data, len(avail), current)
+        h = C.c_void_p(h)
+        nodes_p, normals_p, desc_p = C.POINTER(O.AoRefNode)(), C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint32)()
+        n = L.ao_ref_tree_nodes(h, C.byref(nodes_p), C.byref(normals_p), C.byref(desc_p))
+        hs, vs = 4 * O.header_floats(self.metric), O.vector_bytes(self.metric, self.dims)
+        for i in range(n):
+            nd = nodes_p[i]
+            if nd.kind == 1:
+                self.nodes[int(nd.id)] = ("D", [int(desc_p[nd.offset + j]) for j in range(nd.count)])
+            else:
+                raw = bytes(C.string_at(C.addressof(normals_p.contents) + nd.offset, hs + vs))
+                self.nodes[int(nd.id)] = ("S", int(nd.left), int(nd.right), np.frombuffer(raw[:hs], dtype=np.float32).copy(),
+                                          raw[hs:] if nd.has_normal else None)
+        L.ao_ref_tree_free(h)
+        self.roots = roots
+
+    def dump(self):
+        """The database dump of the reference's test handle, in the shape of the parsed golden snapshots."""
+        trees = {}
+        for k, nd in self.nodes.items():
+            if nd[0] == "D":
+                trees[str(k)] = {"kind": "D", "descendants": list(nd[1])}
+            else:
+                vec = None if nd[4] is None else ["%.4f" % x for x in np.frombuffer(nd[4], dtype=np.float32)]
+                trees[str(k)] = {"kind": "S", "left": nd[1], "right": nd[2],
+                                 "bias": None if nd[4] is None else "%.4f" % nd[3][0], "vector": vec}
+        return {"roots": list(self.roots or []), "item_ids": sorted(self.items), "trees": trees}

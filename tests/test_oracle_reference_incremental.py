@@ -1,0 +1,172 @@
+"""Step-by-step replay of the reference's INCREMENTAL writer tests (src/tests/writer.rs, inline insta snapshots) with
+the oracle's restatement of the reference's randomness and order (tests/ref_writer.py).  Every database dump the
+reference asserts after every `build` — roots, item ids, every tree node with its id, children, bias and normal to
+4 decimals, every descendants list — must be reproduced exactly.  Fixtures: tests/golden/reference_golden.json
+(`writer_inline_snapshots`, extracted from the reference's test file by tests/golden/make_golden.py).  No GPU."""
+import pytest
+
+from oracle import oracle as O
+from ref_writer import RefWriter
+
+SEED = bytes([42] * 32)  # src/tests/mod.rs:105-107
+
+
+def check(golden, name, step, w):
+    want = golden["writer_inline_snapshots"][name]["dumps"][step]
+    got = w.dump()
+    assert got["roots"] == want["roots"], f"{name} dump {step}: roots"
+    assert got["item_ids"] == want["item_ids"], f"{name} dump {step}: items"
+    assert sorted(got["trees"], key=int) == sorted(want["trees"], key=int), f"{name} dump {step}: tree node ids"
+    for k, node in want["trees"].items():
+        assert got["trees"][k] == node, f"{name} dump {step}: tree node {k}"
+
+
+def line(n):  # items i -> [i, 0] (two dimensions)
+    return [(i, [float(i), 0.0]) for i in range(n)]
+
+
+def test_add_one_item_incrementally(golden):
+    w, rng = RefWriter(O.EUCLIDEAN, 2), O.ChaCha12(SEED)
+    for i, v in line(6):
+        w.add_item(i, v)
+    w.build(rng, n_trees=1)
+    check(golden, "add_one_item_incrementally", 0, w)
+    w.add_item(25, [25.0, 0.0])
+    w.build(rng, n_trees=1)
+    check(golden, "add_one_item_incrementally", 1, w)
+    w.add_item(8, [8.0, 0.0])
+    w.build(rng, n_trees=1)
+    check(golden, "add_one_item_incrementally", 2, w)
+
+
+def test_add_one_item_incrementally_to_create_a_split_node(golden):
+    w, rng = RefWriter(O.EUCLIDEAN, 2), O.ChaCha12(SEED)
+    w.add_item(0, [0.0, 0.0])
+    w.add_item(1, [1.0, 0.0])
+    w.build(rng, n_trees=1)
+    check(golden, "add_one_item_incrementally_to_create_a_split_node", 0, w)
+    w.add_item(2, [2.0, 0.0])
+    w.build(rng, n_trees=1)
+    check(golden, "add_one_item_incrementally_to_create_a_split_node", 1, w)
+
+
+def test_add_one_item_incrementally_in_small_dbs(golden):
+    w, rng = RefWriter(O.EUCLIDEAN, 2), O.ChaCha12(SEED)
+    w.build(rng, n_trees=1)
+    check(golden, "add_one_item_incrementally_in_an_empty_db", 0, w)
+    w.add_item(0, [0.0, 0.0])
+    w.build(rng, n_trees=1)
+    check(golden, "add_one_item_incrementally_in_an_empty_db", 1, w)
+    w, rng = RefWriter(O.EUCLIDEAN, 2), O.ChaCha12(SEED)
+    w.add_item(0, [0.0, 0.0])
+    w.build(rng, n_trees=1)
+    check(golden, "add_one_item_incrementally_in_a_one_item_db", 0, w)
+    w.add_item(1, [1.0, 0.0])
+    w.build(rng, n_trees=1)
+    check(golden, "add_one_item_incrementally_in_a_one_item_db", 1, w)
+
+
+def test_overwrite_one_item_incremental(golden):
+    w, rng = RefWriter(O.EUCLIDEAN, 2), O.ChaCha12(SEED)
+    for i, v in line(6):
+        w.add_item(i, v)
+    w.build(rng, n_trees=1)
+    check(golden, "overwrite_one_item_incremental", 0, w)
+    w.add_item(3, [6.0, 0.0])
+    w.build(rng, n_trees=1)
+    check(golden, "overwrite_one_item_incremental", 1, w)
+
+
+def test_delete_one_item(golden):
+    w, rng = RefWriter(O.EUCLIDEAN, 2), O.ChaCha12(SEED)
+    for i, v in line(6):
+        w.add_item(i, v)
+    w.build(rng, n_trees=1)
+    check(golden, "delete_one_item", 0, w)
+    w.del_item(3)
+    w.build(rng, n_trees=1)
+    check(golden, "delete_one_item", 1, w)
+    w.del_item(1)
+    w.build(rng, n_trees=1)
+    check(golden, "delete_one_item", 2, w)
+
+
+def test_delete_in_small_dbs(golden):
+    w, rng = RefWriter(O.EUCLIDEAN, 2), O.ChaCha12(SEED)
+    w.add_item(0, [0.0, 0.0])
+    w.build(rng, n_trees=1)
+    check(golden, "delete_one_item_in_a_one_item_db", 0, w)
+    w.del_item(0)
+    w.build(rng, n_trees=1)
+    check(golden, "delete_one_item_in_a_one_item_db", 1, w)
+    w, rng = RefWriter(O.EUCLIDEAN, 2), O.ChaCha12(SEED)
+    w.add_item(0, [0.0, 0.0])
+    w.add_item(1, [1.0, 0.0])
+    w.build(rng, n_trees=1)
+    check(golden, "delete_one_item_in_a_descendant", 0, w)
+    w.del_item(0)
+    w.build(rng, n_trees=1)
+    check(golden, "delete_one_item_in_a_descendant", 1, w)
+    w, rng = RefWriter(O.COSINE, 2), O.ChaCha12(SEED)
+    w.add_item(0, [0.0, 0.0])
+    w.build(rng)
+    check(golden, "delete_one_item_in_a_single_document_database", 0, w)
+    w.del_item(0)
+    w.build(rng)
+    check(golden, "delete_one_item_in_a_single_document_database", 1, w)
+
+
+def test_delete_one_leaf_in_a_split(golden):
+    w, rng = RefWriter(O.EUCLIDEAN, 2), O.ChaCha12(SEED)
+    for i, v in line(3):
+        w.add_item(i, v)
+    w.build(rng, n_trees=1)
+    check(golden, "delete_one_leaf_in_a_split", 0, w)
+    w.del_item(1)
+    w.build(rng, n_trees=1)
+    check(golden, "delete_one_leaf_in_a_split", 1, w)
+
+
+def test_create_root_split_node_with_empty_child(golden):
+    w, rng = RefWriter(O.EUCLIDEAN, 2), O.ChaCha12(SEED)
+    for i, v in line(6):
+        w.add_item(i, v)
+    w.build(rng, n_trees=1)
+    check(golden, "create_root_split_node_with_empty_child", 0, w)
+    w.del_item(1)
+    w.del_item(5)
+    w.build(rng, n_trees=1)
+    check(golden, "create_root_split_node_with_empty_child", 1, w)
+    w.del_item(0)
+    w.build(rng, n_trees=1)
+    check(golden, "create_root_split_node_with_empty_child", 2, w)
+
+
+def test_reuse_node_id(golden):
+    w, rng = RefWriter(O.EUCLIDEAN, 2), O.ChaCha12(SEED)
+    for i, v in line(6):
+        w.add_item(i, v)
+    w.build(rng, n_trees=1)
+    check(golden, "reuse_node_id", 0, w)
+    w.del_item(4)
+    w.build(rng, n_trees=1)
+    check(golden, "reuse_node_id", 1, w)
+    w.add_item(4, [4.0, 0.0])
+    w.build(rng, n_trees=1)
+    check(golden, "reuse_node_id", 2, w)
+    w.build(rng, n_trees=2)
+    check(golden, "reuse_node_id", 3, w)
+
+
+def test_delete_extraneous_tree(golden):
+    w, rng = RefWriter(O.EUCLIDEAN, 4), O.ChaCha12(SEED)
+    for i in range(5):
+        w.add_item(i, [float(i), 0.0, 0.0, 0.0])
+    w.build(rng)
+    check(golden, "delete_extraneous_tree", 0, w)
+    # the reference's test re-opens the index with `Writer::new(.., 0, 2)`: from here on `dimensions`, hence
+    # `fit_in_descendant`, is 2 although the stored vectors have 4 components
+    w.build(rng, n_trees=2, split_after=2)
+    check(golden, "delete_extraneous_tree", 1, w)
+    w.build(rng, n_trees=1, split_after=2)
+    check(golden, "delete_extraneous_tree", 2, w)
