@@ -204,6 +204,24 @@ def main():
         "source": "src/tests/snapshots/arroy__tests__writer__write_and_update_lot_of_random_points.snap "
                   "(src/tests/writer.rs:296-308)",
         "dims": 30, "n_items": 100, "n_trees": 10, "roots": roots, "trees": trees, "items10": items}
+    # second dump of the same test (after 50 of the 100 items were overwritten and the index rebuilt incrementally)
+    snap2 = open(f"{REF}/src/tests/snapshots/arroy__tests__writer__write_and_update_lot_of_random_points-2.snap").read()
+    trees2 = {}
+    for line in snap2.splitlines():
+        m = re.match(r"Tree (\d+): Descendants\(Descendants \{ descendants: \[(.*?)\] \}\)", line)
+        if m:
+            trees2[m.group(1)] = {"kind": "D", "descendants": [int(x) for x in m.group(2).split(",") if x.strip()]}
+            continue
+        m = re.match(r"Tree (\d+): SplitPlaneNormal\(.*left: (\d+), right: (\d+), normal: Leaf \{ header: "
+                     r"NodeHeaderEuclidean \{ bias: \"(.*?)\" \}, vector: \[(.*?)\] \}", line)
+        if m:
+            comps = [c.strip() for c in m.group(5).split(",") if "other" not in c]
+            trees2[m.group(1)] = {"kind": "S", "left": int(m.group(2)), "right": int(m.group(3)), "bias": m.group(4),
+                                  "vector10": comps}
+    roots2 = [int(x) for x in re.search(r"roots: \[(.*?)\]", snap2).group(1).split(",")]
+    golden["random_points_10_trees_updated"] = {
+        "source": "src/tests/snapshots/arroy__tests__writer__write_and_update_lot_of_random_points-2.snap "
+                  "(src/tests/writer.rs:310-320)", "roots": roots2, "trees": trees2}
     # inline insta snapshots of the incremental writer tests (src/tests/writer.rs): for every test function the
     # sequence of database dumps it asserts, parsed into {roots, items, trees}
     golden["writer_inline_snapshots"] = inline_snapshots(open(f"{REF}/src/tests/writer.rs").read())

@@ -31,6 +31,72 @@ def target_n_trees(n_trees, dimensions, n_items, n_roots):  # src/writer.rs:1358
     return nb
 
 
+class IntMapOrder:
+    """Iteration order of `nohash::IntMap<u32, _>` = std `HashMap` (hashbrown, SSE2 groups of 16) with the identity
+    hash, as far as the reference's build depends on it (the order in which `descendants` is walked decides which task
+    gets which seed, src/writer.rs:778-796).  Restated from hashbrown 0.14's `RawTable`: buckets are a power of two
+    (4, 8, then next_power_of_two(cap * 8 / 7)), a new key goes to the first empty control byte of the 16-wide window
+    starting at `hash & mask` (windows advance triangularly), growth re-inserts the old buckets in index order, and
+    iteration walks the buckets in index order.  No deletions are needed here."""
+
+    def __init__(self):
+        self.buckets = []      # key or None per bucket
+        self.items = 0
+        self.growth_left = 0
+
+    @staticmethod
+    def _cap(mask):
+        return mask if mask < 8 else ((mask + 1) // 8) * 7
+
+    def _slot(self, buckets, key):
+        n = len(buckets)
+        mask = n - 1
+        pos, stride = key & mask, 0
+        while True:
+            for bit in range(16):
+                idx = pos + bit
+                if n < 16 and idx >= n:
+                    # control bytes n..15 of a small table are always EMPTY: the reference then falls back to the
+                    # first empty bucket of the aligned group at 0
+                    if idx < 16:
+                        for j in range(n):
+                            if buckets[j] is None:
+                                return j
+                    idx -= 16  # mirrored tail
+                    if idx >= n:
+                        continue
+                if buckets[idx & mask] is None:
+                    return idx & mask
+            stride += 16
+            pos = (pos + stride) & mask
+
+    def _resize(self, capacity):
+        if capacity < 8:
+            n = 4 if capacity < 4 else 8
+        else:
+            adj = capacity * 8 // 7
+            n = 1 << (adj - 1).bit_length()
+        new = [None] * n
+        for key in self.buckets:
+            if key is not None:
+                new[self._slot(new, key)] = key
+        self.buckets = new
+        self.growth_left = self._cap(n - 1) - self.items
+
+    def insert(self, key):
+        if key in self.buckets:
+            return
+        if self.growth_left == 0:
+            full = self._cap(len(self.buckets) - 1) if self.buckets else 0
+            self._resize(max(self.items + 1, full + 1))
+        self.buckets[self._slot(self.buckets, key)] = key
+        self.items += 1
+        self.growth_left -= 1
+
+    def order(self):
+        return [k for k in self.buckets if k is not None]
+
+
 class RefWriter:
     def __init__(self, metric: int, dimensions: int):
         self.metric, self.dims = metric, dimensions
@@ -139,12 +205,36 @@ class RefWriter:
         ids = None if item_ids == list(range(len(item_ids))) else np.array(item_ids, dtype=np.uint32)
         data = O.Data(self.metric, vecs, ids=ids)
         row_of = {item: r for r, item in enumerate(item_ids)}
-        descendants = {}
+        descendants, walk = {}, IntMapOrder()
         if roots and to_insert:  # insert_items_in_current_trees, :846-889 -> insert_items_in_tree, :1118-1160
             rng.next_u32()  # `rng.next_u64()`: the seed of the per-tree rngs (used only below `normal: None` nodes)
             rng.next_u32()
+            per_root = []
             for root in roots:
-                self._route(data, row_of, root, to_insert, descendants)
+                touched = {}  # python dicts keep insertion order = the depth-first order of the routing
+                self._route(data, row_of, root, to_insert, touched)
+                m = IntMapOrder()
+                for k in touched:
+                    m.insert(k)
+                per_root.append((m, touched))
+                descendants.update(touched)
+
+            def fold(parts):  # rayon `reduce` on one thread: sequential fold of a half into a fresh map
+                acc = IntMapOrder()
+                for m, _ in parts:
+                    for k in m.order():
+                        acc.insert(k)
+                return acc
+
+            if len(per_root) >= 2:  # one split at len / 2 (Splitter with one thread), then `op(left, right)`
+                left, right = fold(per_root[: len(per_root) // 2]), fold(per_root[len(per_root) // 2:])
+                for k in right.order():
+                    left.insert(k)
+                acc = left
+            else:
+                acc = fold(per_root)
+            for k in acc.order():  # `for (item_id, desc) in desc { descendants.entry(item_id).. }`, :880-882
+                walk.insert(k)
 
         def next_id():
             nonlocal current
@@ -157,8 +247,9 @@ class RefWriter:
             new_id = next_id()
             roots.append(new_id)
             descendants[new_id] = list(item_ids)
-        # IntMap = hashbrown with the identity hash: the walk visits the keys in ascending order (small keys)
-        order = sorted(descendants)
+            walk.insert(new_id)
+        order = walk.order()  # `for (item_id, item_indices) in descendants.into_iter()`, :778
+        assert sorted(order) == sorted(descendants)
         offsets = np.zeros(len(order) + 1, dtype=np.uint64)
         rows = []
         for k, node in enumerate(order):

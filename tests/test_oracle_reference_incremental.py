@@ -170,3 +170,32 @@ def test_delete_extraneous_tree(golden):
     check(golden, "delete_extraneous_tree", 1, w)
     w.build(rng, n_trees=1, split_after=2)
     check(golden, "delete_extraneous_tree", 2, w)
+
+
+def test_write_and_update_lot_of_random_points_second_snapshot(golden):
+    """src/tests/writer.rs:296-320 + snapshots/arroy__tests__writer__write_and_update_lot_of_random_points-2.snap:
+    100 x 30-d Euclidean, 10 trees, then every even item overwritten with a fresh random vector and the index built
+    again INCREMENTALLY.  92 tree nodes.  This one depends on everything at once: one rng stream across the item
+    generation and both builds, the removal of 50 items from 10 trees with branch collapsing, their re-insertion
+    through the surviving planes, node-id reuse, and the ORDER in which the touched descendants are re-split — the
+    iteration order of hashbrown maps with the identity hash and rayon's reduce tree (tests/ref_writer.py)."""
+    import numpy as np
+    g0, g = golden["random_points_10_trees"], golden["random_points_10_trees_updated"]
+    rng = O.ChaCha12(SEED)
+    w = RefWriter(O.EUCLIDEAN, g0["dims"])
+    for i in range(g0["n_items"]):
+        w.add_item(i, [rng.gen_f32() for _ in range(g0["dims"])])
+    w.build(rng, n_trees=g0["n_trees"])
+    for i in range(0, g0["n_items"], 2):
+        w.add_item(i, [rng.gen_f32() for _ in range(g0["dims"])])
+    w.build(rng, n_trees=g0["n_trees"])
+    assert w.roots == g["roots"]
+    assert sorted(w.nodes) == sorted(int(k) for k in g["trees"])
+    for k, want in g["trees"].items():
+        got = w.nodes[int(k)]
+        if want["kind"] == "D":
+            assert got == ("D", want["descendants"]), f"tree node {k}"
+        else:
+            assert got[0] == "S" and (got[1], got[2]) == (want["left"], want["right"]), f"tree node {k}"
+            assert "%.4f" % got[3][0] == want["bias"], f"bias of tree node {k}"
+            assert ["%.4f" % x for x in np.frombuffer(got[4], dtype=np.float32)][:10] == want["vector10"], f"normal of {k}"
