@@ -1235,6 +1235,29 @@ AO_API ao_ref_tree *ao_ref_build_descendants(const ao_data *d, uint32_t split_af
     free(scratch);
     return t;
 }
+/* One `make_tree_in_file(.., Some(root_id))` (src/writer.rs:1167-1261) over `rows` with the caller's task rng and the
+ * caller's id allocator (`avail` / `*avail_pos` / `*current` are read and advanced): the building block of the
+ * low-memory replay, where a task first builds a small tree and keeps feeding items into its leaves. */
+AO_API ao_ref_tree *ao_ref_subtree(const ao_data *d, uint32_t split_after, const uint32_t *rows, uint64_t n, ao_chacha *rng,
+                                   uint32_t root_id, const uint32_t *avail, uint32_t n_avail, uint32_t *avail_pos,
+                                   uint32_t *current) {
+    ao_ref_tree *t = (ao_ref_tree *)calloc(1, sizeof(ao_ref_tree));
+    if (split_after == 0) split_after = d->dims;
+    t->next_id = *current;
+    t->avail = (uint32_t *)malloc(sizeof(uint32_t) * (n_avail ? n_avail : 1));
+    memcpy(t->avail, avail, sizeof(uint32_t) * n_avail);
+    t->n_avail = n_avail;
+    t->avail_pos = *avail_pos;
+    uint32_t *work = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint32_t *scratch = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    memcpy(work, rows, n * sizeof(uint32_t));
+    ref_build_rec(d, t, split_after, work, n, rng, 1, root_id, scratch);
+    free(work);
+    free(scratch);
+    *avail_pos = (uint32_t)t->avail_pos;
+    *current = t->next_id;
+    return t;
+}
 AO_API uint32_t ao_ref_tree_next_id(const ao_ref_tree *t, uint32_t *avail_used) {
     if (avail_used) *avail_used = (uint32_t)t->avail_pos;
     return t->next_id;

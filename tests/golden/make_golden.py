@@ -98,10 +98,13 @@ def inline_snapshots(src):
             trees, items, roots, item_ids = {}, {}, None, None
             for line in snap.splitlines():
                 line = line.strip()
-                r = re.match(r"Root: Metadata \{ dimensions: (\d+), items: RoaringBitmap<\[(.*?)\]>, roots: \[(.*?)\], "
+                r = re.match(r"Root: Metadata \{ dimensions: (\d+), items: RoaringBitmap<(.*?)>, roots: \[(.*?)\], "
                              r'distance: "(.*?)" \}', line)
                 if r:
-                    item_ids = [int(x) for x in r.group(2).split(",") if x.strip()]
+                    if r.group(2).startswith("["):
+                        item_ids = [int(x) for x in r.group(2).strip("[]").split(",") if x.strip()]
+                    else:  # "100 values between 0 and 99"
+                        item_ids = r.group(2)
                     roots = [int(x) for x in r.group(3).split(",") if x.strip()]
                     continue
                 d = re.match(r"Tree (\d+): Descendants\(Descendants \{ descendants: \[(.*?)\] \}\)", line)
@@ -222,6 +225,15 @@ def main():
     golden["random_points_10_trees_updated"] = {
         "source": "src/tests/snapshots/arroy__tests__writer__write_and_update_lot_of_random_points-2.snap "
                   "(src/tests/writer.rs:310-320)", "roots": roots2, "trees": trees2}
+    # write_and_update_lot_of_random_points_with_little_memory (src/tests/writer.rs:1378-1403): Cosine, 3 dimensions,
+    # available_memory(0): both file snapshots, every tree node
+    golden["little_memory"] = {"source": "src/tests/writer.rs:1378-1403 + its two .snap files", "dumps": []}
+    for suffix in ("", "-2"):
+        text = open(f"{REF}/src/tests/snapshots/arroy__tests__writer__write_and_update_lot_of_random_points_with_little_"
+                    f"memory{suffix}.snap").read()
+        body = "\n".join(line for line in text.splitlines() if not line.startswith(("---", "source:", "expression:")))
+        parsed = inline_snapshots('fn little_memory() {\ninsta::assert_snapshot!(handle, @r#"' + body + '"#);\n')
+        golden["little_memory"]["dumps"].append(parsed["little_memory"]["dumps"][0])
     # inline insta snapshots of the incremental writer tests (src/tests/writer.rs): for every test function the
     # sequence of database dumps it asserts, parsed into {roots, items, trees}
     golden["writer_inline_snapshots"] = inline_snapshots(open(f"{REF}/src/tests/writer.rs").read())

@@ -173,9 +173,111 @@ class RefWriter:
         if right_ids:
             self._route(data, row_of, right, right_ids, out)
 
+    # ---- fit_in_memory, src/writer.rs:1536-1584 ----
+    def _fit_in_memory(self, memory, to_insert, rng):
+        """`to_insert` (ascending list = the RoaringBitmap) is consumed; returns the next batch or None."""
+        if not to_insert:
+            return None
+        if len(to_insert) <= self.dims:
+            out, to_insert[:] = list(to_insert), []
+            return out
+        page = 4096
+        nb_page_allowed = int(memory // page)
+        largest = 4 * O.header_floats(self.metric) + (self.dims // 64 if O.is_bq(self.metric) else 4 * self.dims)
+        per_page, page_per_item = page // largest, -(-largest // page)
+        if per_page > 1:
+            nb_items = nb_page_allowed * per_page
+        elif page_per_item > 1:
+            nb_items = nb_page_allowed // page_per_item
+        else:
+            nb_items = nb_page_allowed
+        if nb_items <= self.dims:
+            nb_items = self.dims + 1
+        if nb_items >= len(to_insert):
+            out, to_insert[:] = list(to_insert), []
+            return out
+        items = []
+        for _ in range(nb_items):  # `rng.gen_range(0..to_insert.len())` on u64 (rand 0.8 UniformInt::sample_single)
+            rng_range = len(to_insert)
+            zone = ((rng_range << (64 - rng_range.bit_length())) - 1) & 0xFFFFFFFFFFFFFFFF
+            while True:
+                lo32 = rng.next_u32()
+                v = lo32 | (rng.next_u32() << 32)
+                prod = v * rng_range
+                if (prod & 0xFFFFFFFFFFFFFFFF) <= zone:
+                    idx = prod >> 64
+                    break
+            items.append(to_insert.pop(idx))  # RoaringBitmap::select(idx), then remove
+        return sorted(items)
+
+    # ---- insert_descendants_in_file_and_spawn_tasks, src/writer.rs:744-844 ----
+    def _walk(self, rng, order, dmap, stack, split_after):
+        for node in order:
+            items = dmap[node]
+            if len(items) <= split_after:
+                self.nodes[node] = ("D", sorted(items))
+            else:
+                stack.append((rng.gen_seed(), node, sorted(items)))
+
+    # ---- insert_items_in_descendants_from_tmpfile, src/writer.rs:1463-1531 ----
+    def _route_tmp(self, data, row_of, node, to_insert, local):
+        if node in local:
+            local[node] = sorted(set(local[node]) | set(to_insert))
+            return
+        _, left, right, hdr, vec = self.nodes[node]
+        assert vec is not None, "normal: None needs the task rng (not exercised by the replayed snapshots)"
+        rows = np.array([row_of[i] for i in to_insert], dtype=np.uint32)
+        nh = np.zeros(2, dtype=np.float32)
+        nh[: len(hdr)] = hdr
+        sides, _, _ = data.split_sides(np.frombuffer(vec, dtype=np.uint8), nh, rows)
+        left_ids = [i for i, s in zip(to_insert, sides) if s == 0]
+        right_ids = [i for i, s in zip(to_insert, sides) if s == 1]
+        if left_ids:
+            self._route_tmp(data, row_of, left, left_ids, local)
+        if right_ids:
+            self._route_tmp(data, row_of, right, right_ids, local)
+
+    # ---- incremental_index_large_descendant, src/writer.rs:660-739 ----
+    def _run_task(self, data, row_of, seed, node, items, memory, split_after, alloc, stack):
+        L = O.lib()
+        rng = O.ChaCha12(seed)
+        to_insert = list(items)
+        first = self._fit_in_memory(memory, to_insert, rng)
+        rows = np.array([row_of[i] for i in first], dtype=np.uint32)
+        avail_a = np.array(alloc["avail"] if alloc["avail"] else [0], dtype=np.uint32)
+        pos, cur = C.c_uint32(alloc["pos"]), C.c_uint32(alloc["current"])
+        L.ao_ref_subtree.restype = C.c_void_p
+        L.ao_ref_subtree.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
+                                     C.c_uint32, C.c_void_p, C.c_void_p]
+        h = C.c_void_p(L.ao_ref_subtree(data.c(), split_after, rows.ctypes.data, len(rows), C.cast(rng._st, C.c_void_p), node,
+                                        avail_a.ctypes.data, len(alloc["avail"]), C.byref(pos), C.byref(cur)))
+        alloc["pos"], alloc["current"] = pos.value, cur.value
+        nodes_p, normals_p, desc_p = C.POINTER(O.AoRefNode)(), C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint32)()
+        n = L.ao_ref_tree_nodes(h, C.byref(nodes_p), C.byref(normals_p), C.byref(desc_p))
+        hs, vs = 4 * O.header_floats(self.metric), O.vector_bytes(self.metric, self.dims)
+        local, order = {}, IntMapOrder()  # the task's `descendants`: leaves in the order make_tree_in_file meets them
+        for i in range(n):
+            nd = nodes_p[i]
+            if nd.kind == 1:
+                local[int(nd.id)] = [int(desc_p[nd.offset + j]) for j in range(nd.count)]
+                order.insert(int(nd.id))
+                self.nodes.pop(int(nd.id), None)
+            else:
+                raw = bytes(C.string_at(C.addressof(normals_p.contents) + nd.offset, hs + vs))
+                self.nodes[int(nd.id)] = ("S", int(nd.left), int(nd.right), np.frombuffer(raw[:hs], dtype=np.float32).copy(),
+                                          raw[hs:] if nd.has_normal else None)
+        L.ao_ref_tree_free(h)
+        while True:
+            batch = self._fit_in_memory(memory, to_insert, rng)
+            if batch is None:
+                break
+            self._route_tmp(data, row_of, node, batch, local)
+        self._walk(rng, order.order(), local, stack, split_after)
+
     # ---- Writer::build, src/writer.rs:487-629 ----
-    def build(self, rng: "O.ChaCha12", n_trees=None, split_after=None):
+    def build(self, rng: "O.ChaCha12", n_trees=None, split_after=None, available_memory=None):
         split_after = split_after or self.dims
+        memory = (1 << 64) - 1 if available_memory is None else available_memory
         item_ids = sorted(self.items)
         updated, self.updated = set(self.updated), set()
         if len(item_ids) <= split_after:  # clear_db_and_create_a_single_leaf, :916-962
@@ -188,8 +290,7 @@ class RefWriter:
         # ConcurrentNodeIds::new(used_tree_node): computed BEFORE anything is deleted (:516-518)
         used = sorted(self.nodes)
         last_id = used[-1] + 1 if used else 0
-        avail = [i for i in range(last_id) if i not in self.nodes]
-        current = last_id
+        alloc = {"avail": [i for i in range(last_id) if i not in self.nodes], "pos": 0, "current": last_id}
         want = target_n_trees(n_trees, self.dims, len(item_ids), len(roots))
         for _ in range(max(0, len(roots) - want)):  # delete_extra_trees, :631-655: the oldest first, swap_remove(0)
             if not roots:
@@ -206,18 +307,21 @@ class RefWriter:
         data = O.Data(self.metric, vecs, ids=ids)
         row_of = {item: r for r, item in enumerate(item_ids)}
         descendants, walk = {}, IntMapOrder()
-        if roots and to_insert:  # insert_items_in_current_trees, :846-889 -> insert_items_in_tree, :1118-1160
-            rng.next_u32()  # `rng.next_u64()`: the seed of the per-tree rngs (used only below `normal: None` nodes)
-            rng.next_u32()
+        pending = list(to_insert)
+        while roots:  # insert_items_in_current_trees, :846-889 (returns early without trees)
+            batch = self._fit_in_memory(memory, pending, rng)
+            if batch is None:
+                break
+            rng.next_u32()  # insert_items_in_tree, :1118-1160: `rng.next_u64()` seeds the per-tree rngs (only used
+            rng.next_u32()  # below `normal: None` nodes)
             per_root = []
             for root in roots:
                 touched = {}  # python dicts keep insertion order = the depth-first order of the routing
-                self._route(data, row_of, root, to_insert, touched)
+                self._route(data, row_of, root, batch, touched)
                 m = IntMapOrder()
                 for k in touched:
                     m.insert(k)
                 per_root.append((m, touched))
-                descendants.update(touched)
 
             def fold(parts):  # rayon `reduce` on one thread: sequential fold of a half into a fresh map
                 acc = IntMapOrder()
@@ -233,15 +337,20 @@ class RefWriter:
                 acc = left
             else:
                 acc = fold(per_root)
-            for k in acc.order():  # `for (item_id, desc) in desc { descendants.entry(item_id).. }`, :880-882
+            merged = {}
+            for _, touched in per_root:
+                for k, v in touched.items():
+                    merged[k] = sorted(set(merged.get(k, [])) | set(v))
+            for k in acc.order():  # `descendants.entry(item_id).or_default().extend(desc)`, :880-882
                 walk.insert(k)
+                descendants[k] = sorted(set(descendants.get(k, [])) | set(merged[k]))
 
         def next_id():
-            nonlocal current
-            if avail:
-                return avail.pop(0)
-            current += 1
-            return current - 1
+            if alloc["pos"] < len(alloc["avail"]):
+                alloc["pos"] += 1
+                return alloc["avail"][alloc["pos"] - 1]
+            alloc["current"] += 1
+            return alloc["current"] - 1
 
         for _ in range(max(0, want - len(roots))):  # :556-561
             new_id = next_id()
@@ -250,33 +359,14 @@ class RefWriter:
             walk.insert(new_id)
         order = walk.order()  # `for (item_id, item_indices) in descendants.into_iter()`, :778
         assert sorted(order) == sorted(descendants)
-        offsets = np.zeros(len(order) + 1, dtype=np.uint64)
-        rows = []
-        for k, node in enumerate(order):
-            rows += [row_of[i] for i in descendants[node]]
-            offsets[k + 1] = len(rows)
-        rows_a = np.array(rows if rows else [0], dtype=np.uint32)
-        desc_a = np.array(order if order else [0], dtype=np.uint32)
-        avail_a = np.array(avail if avail else [0], dtype=np.uint32)
-        L = O.lib()
-        L.ao_ref_build_descendants.restype = C.c_void_p
-        L.ao_ref_build_descendants.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
-                                               C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
-        h = L.ao_ref_build_descendants(data.c(), split_after, desc_a.ctypes.data, offsets.ctypes.data, rows_a.ctypes.data,
-                                       len(order), C.cast(rng._st, C.c_void_p), avail_a.ctypes.data, len(avail), current)
-        h = C.c_void_p(h)
-        nodes_p, normals_p, desc_p = C.POINTER(O.AoRefNode)(), C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint32)()
-        n = L.ao_ref_tree_nodes(h, C.byref(nodes_p), C.byref(normals_p), C.byref(desc_p))
-        hs, vs = 4 * O.header_floats(self.metric), O.vector_bytes(self.metric, self.dims)
-        for i in range(n):
-            nd = nodes_p[i]
-            if nd.kind == 1:
-                self.nodes[int(nd.id)] = ("D", [int(desc_p[nd.offset + j]) for j in range(nd.count)])
-            else:
-                raw = bytes(C.string_at(C.addressof(normals_p.contents) + nd.offset, hs + vs))
-                self.nodes[int(nd.id)] = ("S", int(nd.left), int(nd.right), np.frombuffer(raw[:hs], dtype=np.float32).copy(),
-                                          raw[hs:] if nd.has_normal else None)
-        L.ao_ref_tree_free(h)
+        # the walking task gets `StdRng::from_seed(rng.gen())` (:575); large entries become tasks with their own seed
+        # (:795); on one rayon thread tasks run last-in-first-out, nested spawns included
+        stack = []
+        self._walk(O.ChaCha12(rng.gen_seed()), order, descendants, stack, split_after)
+        task_memory = memory  # available_memory / current_num_threads() with one thread (:685-686)
+        while stack:
+            seed, node, items = stack.pop()
+            self._run_task(data, row_of, seed, node, items, task_memory, split_after, alloc, stack)
         self.roots = roots
 
     def dump(self):

@@ -199,3 +199,35 @@ def test_write_and_update_lot_of_random_points_second_snapshot(golden):
             assert got[0] == "S" and (got[1], got[2]) == (want["left"], want["right"]), f"tree node {k}"
             assert "%.4f" % got[3][0] == want["bias"], f"bias of tree node {k}"
             assert ["%.4f" % x for x in np.frombuffer(got[4], dtype=np.float32)][:10] == want["vector10"], f"normal of {k}"
+
+
+def test_write_and_update_lot_of_random_points_with_little_memory(golden):
+    """src/tests/writer.rs:1378-1403 + its two .snap files: COSINE, 3 dimensions, `available_memory(0)` — every task
+    first builds a tree over `dimensions + 1` randomly chosen items (`fit_in_memory`, :1536-1584, `gen_range` on u64),
+    then feeds the rest through that tree four at a time (`insert_items_in_descendants_from_tmpfile`, :1463-1531) and
+    spawns nested tasks for the leaves that overflowed (:725-737), last in first out.  188 tree nodes after the first
+    build (2 trees), 409 after 50 overwrites + 50 new items and a third tree.  Besides the order of everything, this
+    is the reference's own pin of the COSINE arithmetic: two_means with normalisation, `create_split`, `side` — every
+    normal is compared to the 4 decimals the snapshot prints, every descendants list exactly."""
+    import numpy as np
+    dumps = golden["little_memory"]["dumps"]
+    rng = O.ChaCha12(SEED)
+    w = RefWriter(O.COSINE, 3)
+    for i in range(100):
+        w.add_item(i, [rng.gen_f32() for _ in range(3)])
+    w.build(rng, n_trees=2, available_memory=0)
+    for step, todo in enumerate([None, list(range(0, 100, 2)) + list(range(100, 150))]):
+        if todo is not None:
+            for i in todo:
+                w.add_item(i, [rng.gen_f32() for _ in range(3)])
+            w.build(rng, n_trees=3, available_memory=0)
+        want = dumps[step]
+        assert w.roots == want["roots"]
+        assert sorted(w.nodes) == sorted(int(k) for k in want["trees"])
+        for k, node in want["trees"].items():
+            got = w.nodes[int(k)]
+            if node["kind"] == "D":
+                assert got == ("D", node["descendants"]), f"dump {step}: tree node {k}"
+            else:
+                assert got[0] == "S" and (got[1], got[2]) == (node["left"], node["right"]), f"dump {step}: tree node {k}"
+                assert ["%.4f" % x for x in np.frombuffer(got[4], dtype=np.float32)] == node["vector"], f"dump {step}: normal {k}"
