@@ -97,8 +97,53 @@ class IntMapOrder:
         return [k for k in self.buckets if k is not None]
 
 
+class OracleBackend:
+    """create_split / side by the CPU oracle (item ids in, item ids out)."""
+
+    def __init__(self, metric, item_ids, vecs):
+        ids = None if item_ids == list(range(len(item_ids))) else np.array(item_ids, dtype=np.uint32)
+        self.data = O.Data(metric, vecs, ids=ids)
+        self.row_of = {item: r for r, item in enumerate(item_ids)}
+
+    def create_split(self, sample_ids):
+        nv, nh = self.data.create_split(np.array([self.row_of[int(i)] for i in sample_ids], dtype=np.uint32))
+        return nv.tobytes(), np.asarray(nh, dtype=np.float32)
+
+    def split_sides(self, vec: bytes, hdr, ids):
+        nh = np.zeros(2, dtype=np.float32)
+        nh[: len(hdr)] = hdr
+        rows = np.array([self.row_of[int(i)] for i in ids], dtype=np.uint32)
+        return self.data.split_sides(np.frombuffer(vec, dtype=np.uint8), nh, rows)[0]
+
+
+class GpuBackend:
+    """The same two operations through the C ABI of libarroy_hip.so (`ah_create_split`, `ah_split_sides`)."""
+
+    def __init__(self, distance_cls, dims, item_ids, vecs):
+        from arroy_amd import Dataset
+        self.ds = Dataset(distance_cls, dims, len(item_ids))
+        self.ds.upload_vectors(np.array(item_ids, dtype=np.uint32), vecs)
+        if distance_cls.metric == 3:
+            self.ds.preprocess_dot()
+        self.ds.finalize()
+
+    def create_split(self, sample_ids):
+        nv, nh = self.ds.create_split(np.array(sample_ids, dtype=np.uint32))
+        return nv.tobytes(), np.asarray(nh, dtype=np.float32)
+
+    def split_sides(self, vec: bytes, hdr, ids):
+        nh = np.zeros(2, dtype=np.float32)
+        nh[: len(hdr)] = hdr
+        sides, _, _ = self.ds.split_sides(np.frombuffer(vec, dtype=np.uint8), nh[: max(1, len(hdr))],
+                                          sorted_ids=np.array(ids, dtype=np.uint32), want_margins=False)
+        return sides
+
+
 class RefWriter:
-    def __init__(self, metric: int, dimensions: int):
+    def __init__(self, metric: int, dimensions: int, backend_factory=None):
+        """backend_factory(item_ids, vecs) -> object with create_split / split_sides; None = the oracle, with the
+        sub-trees built by its C restatement of make_tree_in_file (fast path of the CPU tests)."""
+        self.backend_factory = backend_factory
         self.metric, self.dims = metric, dimensions
         self.items = {}
         self.updated = set()
@@ -155,23 +200,20 @@ class RefWriter:
         return node, None
 
     # ---- insert_items_in_descendants_from_frozen_reader, src/writer.rs:1398-1459 ----
-    def _route(self, data, row_of, node, to_insert, out):
+    def _route(self, be, node, to_insert, out):
         nd = self.nodes[node]
         if nd[0] == "D":
             out[node] = sorted(set(nd[1]) | set(to_insert))
             return
         _, left, right, hdr, vec = nd
         assert vec is not None, "normal: None needs the per-tree rng (not exercised by the replayed snapshots)"
-        rows = np.array([row_of[i] for i in to_insert], dtype=np.uint32)
-        nh = np.zeros(2, dtype=np.float32)
-        nh[: len(hdr)] = hdr
-        sides, _, _ = data.split_sides(np.frombuffer(vec, dtype=np.uint8), nh, rows)
+        sides = be.split_sides(vec, hdr, to_insert)
         left_ids = [i for i, s in zip(to_insert, sides) if s == 0]
         right_ids = [i for i, s in zip(to_insert, sides) if s == 1]
         if left_ids:
-            self._route(data, row_of, left, left_ids, out)
+            self._route(be, left, left_ids, out)
         if right_ids:
-            self._route(data, row_of, right, right_ids, out)
+            self._route(be, right, right_ids, out)
 
     # ---- fit_in_memory, src/writer.rs:1536-1584 ----
     def _fit_in_memory(self, memory, to_insert, rng):
@@ -220,58 +262,105 @@ class RefWriter:
                 stack.append((rng.gen_seed(), node, sorted(items)))
 
     # ---- insert_items_in_descendants_from_tmpfile, src/writer.rs:1463-1531 ----
-    def _route_tmp(self, data, row_of, node, to_insert, local):
+    def _route_tmp(self, be, node, to_insert, local):
         if node in local:
             local[node] = sorted(set(local[node]) | set(to_insert))
             return
         _, left, right, hdr, vec = self.nodes[node]
         assert vec is not None, "normal: None needs the task rng (not exercised by the replayed snapshots)"
-        rows = np.array([row_of[i] for i in to_insert], dtype=np.uint32)
-        nh = np.zeros(2, dtype=np.float32)
-        nh[: len(hdr)] = hdr
-        sides, _, _ = data.split_sides(np.frombuffer(vec, dtype=np.uint8), nh, rows)
+        sides = be.split_sides(vec, hdr, to_insert)
         left_ids = [i for i, s in zip(to_insert, sides) if s == 0]
         right_ids = [i for i, s in zip(to_insert, sides) if s == 1]
         if left_ids:
-            self._route_tmp(data, row_of, left, left_ids, local)
+            self._route_tmp(be, left, left_ids, local)
         if right_ids:
-            self._route_tmp(data, row_of, right, right_ids, local)
+            self._route_tmp(be, right, right_ids, local)
 
-    # ---- incremental_index_large_descendant, src/writer.rs:660-739 ----
-    def _run_task(self, data, row_of, seed, node, items, memory, split_after, alloc, stack):
+    # ---- make_tree_in_file, src/writer.rs:1167-1261, on any backend: [(id, node)] in creation order ----
+    def _subtree(self, be, ids, rng, root_id, alloc, split_after):
+        out = []
+
+        def next_id():
+            if alloc["pos"] < len(alloc["avail"]):
+                alloc["pos"] += 1
+                return alloc["avail"][alloc["pos"] - 1]
+            alloc["current"] += 1
+            return alloc["current"] - 1
+
+        def rec(ids, node_id):
+            if len(ids) <= split_after:
+                nid = next_id() if node_id is None else node_id
+                out.append((nid, ("D", [int(i) for i in ids])))
+                return nid
+            remaining = 3
+            while True:
+                a, b = rng.index_sample2(len(ids))  # choose_two, src/parallel.rs:342-355
+                sample = [ids[a], ids[b]] + [ids[rng.gen_range_inclusive(0, len(ids) - 1)] for _ in range(10)]  # :358-367
+                vec, hdr = be.create_split(sample)
+                sides = np.asarray(be.split_sides(vec, hdr, ids))
+                n_left = int((sides == 0).sum())
+                imb = O.lib().ao_split_imbalance(n_left, len(ids) - n_left)
+                if imb < 0.95 or remaining == 0:
+                    break
+                remaining -= 1
+            if imb > 0.99:  # randomly_split_children: true -> Left (src/lib.rs:135-141)
+                sides = np.array([0 if rng.gen_bool() else 1 for _ in ids], dtype=np.uint8)
+                vec = None
+            left = rec([i for i, s in zip(ids, sides) if s == 0], None)
+            right = rec([i for i, s in zip(ids, sides) if s == 1], None)
+            nid = next_id() if node_id is None else node_id  # allocated AFTER the children (:1257)
+            out.append((nid, ("S", left, right, np.asarray(hdr, dtype=np.float32).copy(), vec)))
+            return nid
+
+        rec(list(ids), root_id)
+        return out
+
+    def _subtree_oracle_c(self, be, ids, rng, root_id, alloc, split_after):
+        """The same through the oracle's C restatement (ao_ref_subtree): identical output, much faster."""
         L = O.lib()
-        rng = O.ChaCha12(seed)
-        to_insert = list(items)
-        first = self._fit_in_memory(memory, to_insert, rng)
-        rows = np.array([row_of[i] for i in first], dtype=np.uint32)
+        rows = np.array([be.row_of[i] for i in ids], dtype=np.uint32)
         avail_a = np.array(alloc["avail"] if alloc["avail"] else [0], dtype=np.uint32)
         pos, cur = C.c_uint32(alloc["pos"]), C.c_uint32(alloc["current"])
         L.ao_ref_subtree.restype = C.c_void_p
         L.ao_ref_subtree.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
                                      C.c_uint32, C.c_void_p, C.c_void_p]
-        h = C.c_void_p(L.ao_ref_subtree(data.c(), split_after, rows.ctypes.data, len(rows), C.cast(rng._st, C.c_void_p), node,
-                                        avail_a.ctypes.data, len(alloc["avail"]), C.byref(pos), C.byref(cur)))
+        h = C.c_void_p(L.ao_ref_subtree(be.data.c(), split_after, rows.ctypes.data, len(rows), C.cast(rng._st, C.c_void_p),
+                                        root_id, avail_a.ctypes.data, len(alloc["avail"]), C.byref(pos), C.byref(cur)))
         alloc["pos"], alloc["current"] = pos.value, cur.value
         nodes_p, normals_p, desc_p = C.POINTER(O.AoRefNode)(), C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint32)()
         n = L.ao_ref_tree_nodes(h, C.byref(nodes_p), C.byref(normals_p), C.byref(desc_p))
         hs, vs = 4 * O.header_floats(self.metric), O.vector_bytes(self.metric, self.dims)
-        local, order = {}, IntMapOrder()  # the task's `descendants`: leaves in the order make_tree_in_file meets them
+        out = []
         for i in range(n):
             nd = nodes_p[i]
             if nd.kind == 1:
-                local[int(nd.id)] = [int(desc_p[nd.offset + j]) for j in range(nd.count)]
-                order.insert(int(nd.id))
-                self.nodes.pop(int(nd.id), None)
+                out.append((int(nd.id), ("D", [int(desc_p[nd.offset + j]) for j in range(nd.count)])))
             else:
                 raw = bytes(C.string_at(C.addressof(normals_p.contents) + nd.offset, hs + vs))
-                self.nodes[int(nd.id)] = ("S", int(nd.left), int(nd.right), np.frombuffer(raw[:hs], dtype=np.float32).copy(),
-                                          raw[hs:] if nd.has_normal else None)
+                out.append((int(nd.id), ("S", int(nd.left), int(nd.right), np.frombuffer(raw[:hs], dtype=np.float32).copy(),
+                                         raw[hs:] if nd.has_normal else None)))
         L.ao_ref_tree_free(h)
+        return out
+
+    # ---- incremental_index_large_descendant, src/writer.rs:660-739 ----
+    def _run_task(self, be, seed, node, items, memory, split_after, alloc, stack):
+        rng = O.ChaCha12(seed)
+        to_insert = list(items)
+        first = self._fit_in_memory(memory, to_insert, rng)
+        build = self._subtree_oracle_c if self.backend_factory is None else self._subtree
+        local, order = {}, IntMapOrder()  # the task's `descendants`: leaves in the order make_tree_in_file meets them
+        for nid, nd in build(be, first, rng, node, alloc, split_after):
+            if nd[0] == "D":
+                local[nid] = nd[1]
+                order.insert(nid)
+                self.nodes.pop(nid, None)
+            else:
+                self.nodes[nid] = nd
         while True:
             batch = self._fit_in_memory(memory, to_insert, rng)
             if batch is None:
                 break
-            self._route_tmp(data, row_of, node, batch, local)
+            self._route_tmp(be, node, batch, local)
         self._walk(rng, order.order(), local, stack, split_after)
 
     # ---- Writer::build, src/writer.rs:487-629 ----
@@ -303,9 +392,7 @@ class RefWriter:
             roots[i], _ = self._delete_items(root, to_delete, split_after)
         roots.sort()
         vecs = np.stack([self.items[i] for i in item_ids])
-        ids = None if item_ids == list(range(len(item_ids))) else np.array(item_ids, dtype=np.uint32)
-        data = O.Data(self.metric, vecs, ids=ids)
-        row_of = {item: r for r, item in enumerate(item_ids)}
+        be = OracleBackend(self.metric, item_ids, vecs) if self.backend_factory is None else self.backend_factory(item_ids, vecs)
         descendants, walk = {}, IntMapOrder()
         pending = list(to_insert)
         while roots:  # insert_items_in_current_trees, :846-889 (returns early without trees)
@@ -317,7 +404,7 @@ class RefWriter:
             per_root = []
             for root in roots:
                 touched = {}  # python dicts keep insertion order = the depth-first order of the routing
-                self._route(data, row_of, root, batch, touched)
+                self._route(be, root, batch, touched)
                 m = IntMapOrder()
                 for k in touched:
                     m.insert(k)
@@ -366,7 +453,7 @@ class RefWriter:
         task_memory = memory  # available_memory / current_num_threads() with one thread (:685-686)
         while stack:
             seed, node, items = stack.pop()
-            self._run_task(data, row_of, seed, node, items, task_memory, split_after, alloc, stack)
+            self._run_task(be, seed, node, items, task_memory, split_after, alloc, stack)
         self.roots = roots
 
     def dump(self):

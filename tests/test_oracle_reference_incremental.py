@@ -6,7 +6,7 @@ reference asserts after every `build` — roots, item ids, every tree node with 
 import pytest
 
 from oracle import oracle as O
-from ref_writer import RefWriter
+from ref_writer import OracleBackend, RefWriter
 
 SEED = bytes([42] * 32)  # src/tests/mod.rs:105-107
 
@@ -201,18 +201,11 @@ def test_write_and_update_lot_of_random_points_second_snapshot(golden):
             assert ["%.4f" % x for x in np.frombuffer(got[4], dtype=np.float32)][:10] == want["vector10"], f"normal of {k}"
 
 
-def test_write_and_update_lot_of_random_points_with_little_memory(golden):
-    """src/tests/writer.rs:1378-1403 + its two .snap files: COSINE, 3 dimensions, `available_memory(0)` — every task
-    first builds a tree over `dimensions + 1` randomly chosen items (`fit_in_memory`, :1536-1584, `gen_range` on u64),
-    then feeds the rest through that tree four at a time (`insert_items_in_descendants_from_tmpfile`, :1463-1531) and
-    spawns nested tasks for the leaves that overflowed (:725-737), last in first out.  188 tree nodes after the first
-    build (2 trees), 409 after 50 overwrites + 50 new items and a third tree.  Besides the order of everything, this
-    is the reference's own pin of the COSINE arithmetic: two_means with normalisation, `create_split`, `side` — every
-    normal is compared to the 4 decimals the snapshot prints, every descendants list exactly."""
+def replay_little_memory(golden, backend_factory):
     import numpy as np
     dumps = golden["little_memory"]["dumps"]
     rng = O.ChaCha12(SEED)
-    w = RefWriter(O.COSINE, 3)
+    w = RefWriter(O.COSINE, 3, backend_factory=backend_factory)
     for i in range(100):
         w.add_item(i, [rng.gen_f32() for _ in range(3)])
     w.build(rng, n_trees=2, available_memory=0)
@@ -231,3 +224,20 @@ def test_write_and_update_lot_of_random_points_with_little_memory(golden):
             else:
                 assert got[0] == "S" and (got[1], got[2]) == (node["left"], node["right"]), f"dump {step}: tree node {k}"
                 assert ["%.4f" % x for x in np.frombuffer(got[4], dtype=np.float32)] == node["vector"], f"dump {step}: normal {k}"
+
+
+def test_little_memory_replay_with_the_python_tree_builder(golden):
+    """Same snapshots through RefWriter's backend interface (the path the GPU replay uses, here with the oracle as
+    backend): the Python restatement of make_tree_in_file and the C one must agree."""
+    replay_little_memory(golden, lambda item_ids, vecs: OracleBackend(O.COSINE, item_ids, vecs))
+
+
+def test_write_and_update_lot_of_random_points_with_little_memory(golden):
+    """src/tests/writer.rs:1378-1403 + its two .snap files: COSINE, 3 dimensions, `available_memory(0)` — every task
+    first builds a tree over `dimensions + 1` randomly chosen items (`fit_in_memory`, :1536-1584, `gen_range` on u64),
+    then feeds the rest through that tree four at a time (`insert_items_in_descendants_from_tmpfile`, :1463-1531) and
+    spawns nested tasks for the leaves that overflowed (:725-737), last in first out.  188 tree nodes after the first
+    build (2 trees), 409 after 50 overwrites + 50 new items and a third tree.  Besides the order of everything, this
+    is the reference's own pin of the COSINE arithmetic: two_means with normalisation, `create_split`, `side` — every
+    normal is compared to the 4 decimals the snapshot prints, every descendants list exactly."""
+    replay_little_memory(golden, None)
