@@ -461,7 +461,7 @@ bool batch_invert_wanted(const DataView &dv, uint64_t n_candidates) {
 // The pair lists live in the tournament buffers, which are idle until the distances exist:
 // keys_a: pair_rq (8 B x pairs); keys_b: pair_pos (4 B x pairs).  The counters are caller-provided scratch.
 template <int METRIC>
-static void launch_inverted(const DataView &dv, uint32_t /*n_queries*/, const uint8_t *d_qvecs, uint64_t qstride,
+static int launch_inverted(const DataView &dv, uint32_t /*n_queries*/, const uint8_t *d_qvecs, uint64_t qstride,
                             const float *d_qhdrs, const Seg *d_segs, const BTile *d_tiles, uint32_t n_tiles,
                             const uint32_t *d_ids, uint64_t n_pairs, float *d_dist, uint64_t *d_keys_a, uint64_t *d_keys_b,
                             uint32_t *d_counters, uint32_t *d_err, hipStream_t s) {
@@ -472,7 +472,7 @@ static void launch_inverted(const DataView &dv, uint32_t /*n_queries*/, const ui
     uint32_t *sums = count + dv.n;
     uint32_t *total = sums + n_sums;  // valid pairs, known to the device only
     const unsigned grid = n_tiles < 4096u ? n_tiles : 4096u;
-    (void)hipMemsetAsync(count, 0, (size_t)dv.n * 4, s);
+    AH_HIP(hipMemsetAsync(count, 0, (size_t)dv.n * 4, s));
     hipLaunchKernelGGL(k_inv_count, dim3(grid), dim3(kBlock), 0, s, dv, d_segs, d_tiles, n_tiles, d_ids, count, d_dist, d_err);
     hipLaunchKernelGGL(k_scan_block, dim3(n_sums), dim3(256), 0, s, count, dv.n, sums);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, s, sums, n_sums, total);
@@ -495,7 +495,8 @@ static void launch_inverted(const DataView &dv, uint32_t /*n_queries*/, const ui
         const unsigned igrid = (unsigned)std::min<uint64_t>((max_items + kBlock / 8 - 1) / (kBlock / 8), 32768);
         hipLaunchKernelGGL((k_pairs_distances_runs<METRIC>), dim3(igrid), dim3(kBlock), 0, s, dv, d_qvecs, qstride, d_qhdrs,
                            pair_rq, pair_pos, items, itotal, d_dist);
-        return;
+        AH_HIP(hipGetLastError());
+        return AH_OK;
     }
     const int group = g_pair_group == 8 ? 8 : (g_pair_group == 2 ? 2 : kPairGroup);
     const uint64_t octets = (n_pairs + group - 1) / group;
@@ -509,6 +510,8 @@ static void launch_inverted(const DataView &dv, uint32_t /*n_queries*/, const ui
     else
         hipLaunchKernelGGL((k_pairs_distances<METRIC, kPairGroup>), dim3(pgrid), dim3(kBlock), 0, s, dv, d_qvecs, qstride,
                            d_qhdrs, pair_rq, pair_pos, total, d_dist);
+    AH_HIP(hipGetLastError());
+    return AH_OK;
 }
 
 // ---- batched top-k ----------------------------------------------------------------------------------
@@ -646,16 +649,16 @@ int launch_rerank_batch_prepared(const DataView &dv, uint32_t n_queries, const u
         if (invert) {
             switch (dv.metric) {
             case AH_EUCLIDEAN:
-                launch_inverted<AH_EUCLIDEAN>(dv, n_queries, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, n_tiles, d_ids,
-                                              n_candidates, d_dist, d_keys_a, d_keys_b, d_inv_counters, d_err, s);
+                AH_TRY(launch_inverted<AH_EUCLIDEAN>(dv, n_queries, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, n_tiles, d_ids,
+                                              n_candidates, d_dist, d_keys_a, d_keys_b, d_inv_counters, d_err, s));
                 break;
             case AH_COSINE:
-                launch_inverted<AH_COSINE>(dv, n_queries, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, n_tiles, d_ids,
-                                           n_candidates, d_dist, d_keys_a, d_keys_b, d_inv_counters, d_err, s);
+                AH_TRY(launch_inverted<AH_COSINE>(dv, n_queries, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, n_tiles, d_ids,
+                                           n_candidates, d_dist, d_keys_a, d_keys_b, d_inv_counters, d_err, s));
                 break;
             default:
-                launch_inverted<AH_DOT_PRODUCT>(dv, n_queries, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, n_tiles, d_ids,
-                                                n_candidates, d_dist, d_keys_a, d_keys_b, d_inv_counters, d_err, s);
+                AH_TRY(launch_inverted<AH_DOT_PRODUCT>(dv, n_queries, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, n_tiles, d_ids,
+                                                n_candidates, d_dist, d_keys_a, d_keys_b, d_inv_counters, d_err, s));
                 break;
             }
         } else if (metric_is_bq(dv.metric)) {
