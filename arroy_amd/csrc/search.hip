@@ -37,7 +37,7 @@ struct SearchParams {
     uint32_t n_trees;
     const uint32_t *desc;
     const uint32_t *filter_bits;  // bitmap over item ids or nullptr
-    uint32_t filter_len_bits;
+    uint64_t filter_len_bits;  // max item id + 1 (item id u32::MAX is legal, src/tests/writer.rs:161-179)
     uint32_t search_k;            // already multiplied by the oversampling, clamped to the blob size
     uint32_t nns_stride;          // capacity of one query's candidate buffer
 };
@@ -527,7 +527,7 @@ struct HostTile2 {
 
 static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const uint32_t *query_rows, size_t nq,
                         size_t count, uint32_t search_k, uint32_t nns_stride, const uint32_t *d_filter_bits,
-                        uint32_t filter_len_bits, uint32_t *out_ids, float *out_dists, uint32_t *out_counts) {
+                        uint64_t filter_len_bits, uint32_t *out_ids, float *out_dists, uint32_t *out_counts) {
     ah_dataset *ds = ix->ds;
     hipStream_t s = ctx->stream;
     const size_t qstride = (ds->row_bytes() + 255) & ~(size_t)255;
@@ -784,10 +784,10 @@ int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_it
     // candidate filter -> bitmap over item ids
     DevMem bits_mem;
     uint32_t *d_bits = nullptr;
-    uint32_t bits_len = 0;
+    uint64_t bits_len = 0;
     if (have_filter) {
         const uint32_t max_id = ds->identity_ids ? (uint32_t)(ds->n - 1) : ds->last_id;
-        bits_len = max_id + 1;
+        bits_len = (uint64_t)max_id + 1;
         const size_t words = ((size_t)bits_len + 31) / 32;
         AH_HIP(hipMalloc(&bits_mem.p, words * 4));
         d_bits = bits_mem.as<uint32_t>();

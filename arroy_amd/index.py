@@ -41,6 +41,14 @@ class NeedBuild(RuntimeError):
         self.index = index
 
 
+class UnmatchingDistance(RuntimeError):
+    """arroy::Error::UnmatchingDistance { expected, received } (src/error.rs:34-41)."""
+
+    def __init__(self, expected: str, received: str):
+        super().__init__(f"Invalid distance provided. Got {received} but expected {expected}")
+        self.expected, self.received = expected, received
+
+
 class InvalidVecDimension(_lib.InvalidVecDimension):
     """arroy::Error::InvalidVecDimension { expected, received } (src/error.rs:17-23)."""
 
@@ -233,6 +241,12 @@ class Database:
         self.distance = distance
         self._indexes: Dict[int, _IndexState] = {}
 
+    def remap_data_type(self, distance: type[Distance]) -> "Database":
+        """`database.remap_data_type::<NodeCodec<D2>>()`: the same store seen through another distance type."""
+        other = Database(distance)
+        other._indexes = self._indexes
+        return other
+
     def _state(self, index: int) -> _IndexState:
         return self._indexes.setdefault(index, _IndexState())
 
@@ -418,6 +432,8 @@ class Reader:
         st = database._indexes.get(index)
         if st is None or st.metadata is None:
             raise MissingMetadata(index)
+        if database.distance.name != st.metadata["distance"]:  # src/reader.rs:153-158
+            raise UnmatchingDistance(st.metadata["distance"], database.distance.name)
         if st.updated:
             raise NeedBuild(index)
         return cls(database, index, st)

@@ -42,6 +42,36 @@ def test_open_db_with_wrong_dimension(api):
     assert str(e.value) == "Invalid vector dimensions. Got 3 but expected 2"
 
 
+def test_open_db_with_wrong_distance(api):
+    """src/tests/reader.rs:61-79."""
+    D, I = api
+    db = I.Database(D.Euclidean)
+    w = I.Writer(db, 0, 2)
+    w.add_item(0, [0.0, 0.0])
+    w.builder(rng()).n_trees(1).build()
+    with pytest.raises(I.UnmatchingDistance) as e:
+        I.Reader.open(db.remap_data_type(D.Manhattan), 0)
+    assert (e.value.expected, e.value.received) == ("euclidean", "manhattan")
+    assert str(e.value) == "Invalid distance provided. Got manhattan but expected euclidean"
+
+
+@pytest.mark.parametrize("item", [2**32 - 2, 2**32 - 1])
+def test_use_u32_max_for_a_vec(api, item):
+    """src/tests/writer.rs:141-179: the largest item ids are ordinary ids."""
+    D, I = api
+    db = I.Database(D.Euclidean)
+    w = I.Writer(db, 0, 3)
+    w.add_item(item, [0.0, 1.0, 2.0])
+    w.builder(rng()).n_trees(1).build()
+    reader = I.Reader.open(db, 0)
+    st = reader._st
+    assert st.trees.roots == [0] and [int(x) for x in st.trees.nodes[0][1]] == [item]
+    assert reader.item_ids() == [item]
+    assert fmt(reader.nns(5).by_vector([0.0, 1.0, 2.0])) == [f"id({item}): distance(0)"]
+    assert fmt(reader.nns(5).candidates([item]).by_item(item)) == [f"id({item}): distance(0)"]
+    assert reader.nns(5).candidates([1, 2]).by_item(item) == []
+
+
 def test_search_in_db_with_a_single_vector(api):
     """src/tests/reader.rs:81-99 (meilisearch#4296): cosine of an item with itself is 0."""
     D, I = api

@@ -124,6 +124,29 @@ def test_sparse_item_ids_and_lut(metric):
         ds.distances(item=int(ids[0]), ids=[missing])
 
 
+def test_largest_item_ids_are_ordinary_ids():
+    """Item ids u32::MAX - 1 and u32::MAX (src/tests/writer.rs:141-179) through the gather, the re-rank, the forest,
+    the device search and its candidate filter."""
+    n, dims = 300, 40
+    ids = np.concatenate([np.arange(0, 2 * (n - 2), 2), [2**32 - 2, 2**32 - 1]]).astype(np.uint32)
+    ds, oracle, vecs, ids = make_data(D.Euclidean, n, dims, seed=77, ids=ids)
+    q = vecs[-1] + np.float32(0.01)
+    qv, qh = oracle.query_leaf(q)
+    assert_bit_equal(ds.distances(query=q, ids=ids[-5:]), oracle.distances(qv, qh, np.arange(n - 5, n, dtype=np.uint32)))
+    oi, od = ds.rerank(3, query=q)
+    ei, ed = oracle.rerank(qv, qh, None, 3)
+    assert list(oi) == [int(x) for x in ei] and int(oi[0]) == 2**32 - 1
+    assert_bit_equal(od, ed)
+    forest = ds.build_forest([5, 6], split_after=16)
+    check_forest_valid(forest, n, ids=ids)
+    index = ds.create_index(forest)
+    for cand in (None, [2**32 - 1, 2**32 - 2, 4], [2**32 - 2]):
+        got = index.search(3, queries=q[None, :], search_k=2**62, candidates=cand)[0]
+        want, _ = O.search(oracle, forest, qv, qh, 3, 2**62, 0, cand)
+        assert [i for i, _ in got] == [i for i, _ in want]
+        assert_bit_equal([d for _, d in got], [d for _, d in want])
+
+
 def test_very_sparse_ids_use_binary_search():
     n, dims = 64, 32
     ids = (np.arange(n, dtype=np.uint64) * 50_000_000 + 7).astype(np.uint32)
