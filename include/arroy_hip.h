@@ -141,7 +141,10 @@ AH_API int ah_rerank_by_item(ah_dataset *ds, uint32_t query_item, const uint32_t
                       uint32_t *out_ids, float *out_distances, size_t *out_n);
 /* Many queries in one submission (candidate lists concatenated; list q is
  * ids[offsets[q] .. offsets[q+1])).  Outputs are n_queries x k, short lists padded with id
- * 0xFFFFFFFF / distance NaN; out_counts[q] = min(k, len_q). */
+ * 0xFFFFFFFF / distance NaN; out_counts[q] = min(k, len_q) says how many are real (0xFFFFFFFF is
+ * also a legal item id, src/tests/writer.rs:161-179).  Results are identical to n_queries single
+ * calls; a submission with >= 2 candidates per stored row is evaluated row-major on the device
+ * (every row leaves HBM once per submission). */
 AH_API int ah_rerank_batch(ah_dataset *ds, const float *queries, size_t n_queries, const uint32_t *ids,
                     const uint64_t *offsets, size_t k, uint32_t *out_ids, float *out_distances,
                     uint32_t *out_counts);
