@@ -368,6 +368,11 @@ class ArroyBuilder:
     def _add_trees(self, ds: Dataset, trees: TreeStore, count: int, split_after: int) -> None:
         if count <= 0:
             return
+        if count > 0xFFFF:
+            # arroy's formula (src/writer.rs:1371-1380) explodes for >= 10 000 items of fewer than 768 dimensions
+            # ((768 / dims)^4 in the exponent); the reference would then try to build that many trees.  One
+            # ah_build_forest call takes at most 65 535.
+            raise ValueError(f"{count} trees requested (arroy's target_n_trees for this shape): pass n_trees explicitly")
         forest = ds.build_forest(self._seeds(count), split_after=split_after, cancel=self._cancel, progress=self._progress)
         for t in range(forest.n_trees):
             root = trees.next_id()  # roots are allocated before their subtree (src/writer.rs:556-561)

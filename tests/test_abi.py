@@ -85,3 +85,16 @@ def test_public_headers_are_plain_c99(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.returncode, out.stderr)
     assert out.stdout.strip() == "32"
+
+
+def test_c_example_compiles_and_links(tmp_path):
+    """examples/c_abi_demo.c (build + search + node sink from plain C) must keep compiling as strict C99 and linking;
+    without a GPU it stops at `ah_device_count` with exit code 2."""
+    import subprocess
+    exe = tmp_path / "c_abi_demo"
+    lib_dir = os.path.join(ROOT, "arroy_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_abi_demo.c"), "-o", str(exe), "-L", lib_dir, "-larroy_hip",
+                           f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode in (0, 2), (out.returncode, out.stderr)
