@@ -15,6 +15,7 @@
 // draw), so this breadth-first build and the depth-first CPU oracle produce the same forest bit for bit.
 // No atomics on floats, no dependence on workgroup scheduling: results are deterministic.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -1071,11 +1072,11 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     const unsigned lgrid = (unsigned)std::min<uint64_t>((N * 8 + lthreads - 1) / lthreads, 256u * per_cu);
 #define AH_ROWS_LDS(M, TCV)                                                                                             \
     do {                                                                                                                \
-        static bool lds_opt_in[64] = {}; /* once per instantiation and device: the call is slow (~4 ms) */              \
-        if (!lds_opt_in[ds->device & 63]) {                                                                             \
+        static std::atomic<bool> lds_opt_in[64]; /* once per instantiation and device: the call waits for the stream */ \
+        if (!lds_opt_in[ds->device & 63].load(std::memory_order_acquire)) {                                                                             \
             AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_margin_rows_lds<M, TCV>),                \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsNormalsBytes));             \
-            lds_opt_in[ds->device & 63] = true;                                                                         \
+            lds_opt_in[ds->device & 63].store(true, std::memory_order_release);                                         \
         }                                                                                                               \
         hipLaunchKernelGGL((k_forest_margin_rows_lds<M, TCV>), dim3(lgrid), dim3(lthreads), sh, s, dv, node_of.p, t0, np, \
                            chunk.d, nstride, hdr_off, side_bytes.p, first, cnt);                                        \
