@@ -241,3 +241,22 @@ def test_write_and_update_lot_of_random_points_with_little_memory(golden):
     is the reference's own pin of the COSINE arithmetic: two_means with normalisation, `create_split`, `side` — every
     normal is compared to the 4 decimals the snapshot prints, every descendants list exactly."""
     replay_little_memory(golden, None)
+
+
+@pytest.mark.parametrize("name,dims,items,n_trees", [
+    ("write_one_vector", 3, [(0, [0.0, 1.0, 2.0])], None),
+    ("write_one_vector_in_one_tree", 3, [(0, [0.0, 1.0, 2.0])], 1),
+    ("write_one_vector_in_multiple_trees", 3, [(0, [0.0, 1.0, 2.0])], 10),
+    ("use_u32_max_minus_one_for_a_vec", 3, [(2**32 - 2, [0.0, 1.0, 2.0])], 1),
+    ("use_u32_max_for_a_vec", 3, [(2**32 - 1, [0.0, 1.0, 2.0])], 1),
+    ("write_vectors_until_there_is_a_descendants", 3, [(i, [float(i)] * 3) for i in range(3)], 1),
+    ("write_vectors_until_there_is_a_split", 3, [(i, [float(i)] * 3) for i in range(4)], 1),
+])
+def test_single_build_inline_snapshots(golden, name, dims, items, n_trees):
+    """The one-build tests of src/tests/writer.rs:141-293 through the same replay: whatever `n_trees` says, items that
+    fit in one descendant give ONE root with id 0 (`clear_db_and_create_a_single_leaf`, :916-962)."""
+    w, rng = RefWriter(O.EUCLIDEAN, dims), O.ChaCha12(SEED)
+    for i, v in items:
+        w.add_item(i, v)
+    w.build(rng, n_trees=n_trees)
+    check(golden, name, 0, w)
