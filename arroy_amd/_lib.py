@@ -23,10 +23,15 @@ AH_SPLIT_SAMPLES = 12
 
 
 class ArroyHipError(RuntimeError):
-    def __init__(self, status: int, message: str):
+    def __init__(self, status: int, message: str, detail=None):
         super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
         self.status = status
         self.message = message
+        # the typed fields of arroy::Error (ah_last_error_detail): InvalidVecDimension {expected, received},
+        # MissingKey {item}
+        self.item = detail.item if detail is not None else 0
+        self.expected = detail.expected if detail is not None else 0
+        self.received = detail.received if detail is not None else 0
 
 
 class InvalidVecDimension(ArroyHipError):
@@ -42,8 +47,9 @@ class MissingKey(ArroyHipError):
 
 
 class AhNode(C.Structure):
-    _fields_ = [("kind", C.c_uint8), ("has_normal", C.c_uint8), ("tree", C.c_uint16), ("left", C.c_uint32),
-                ("right", C.c_uint32), ("offset", C.c_uint64), ("count", C.c_uint32), ("depth", C.c_uint32)]
+    _fields_ = [("kind", C.c_uint8), ("has_normal", C.c_uint8), ("reserved", C.c_uint16), ("tree", C.c_uint32),
+                ("left", C.c_uint32), ("right", C.c_uint32), ("offset", C.c_uint64), ("count", C.c_uint32),
+                ("depth", C.c_uint32)]
 
 
 class AhForestView(C.Structure):
@@ -60,14 +66,28 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64)
 class AhBuildOptions(C.Structure):
     _fields_ = [("n_trees", C.c_uint32), ("split_after", C.c_uint32), ("tree_seeds", C.POINTER(C.c_uint64)),
                 ("cancel", C.POINTER(C.c_int)), ("progress", PROGRESS_FN), ("progress_user", C.c_void_p),
-                ("max_trees_in_flight", C.c_uint32)]
+                ("max_trees_in_flight", C.c_uint32), ("margin_mode", C.c_uint32)]
+
+
+class AhErrorDetail(C.Structure):
+    _fields_ = [("status", C.c_int), ("item", C.c_uint32), ("expected", C.c_uint64), ("received", C.c_uint64)]
+
+
+# ah_margin_mode (include/arroy_hip.h)
+MARGIN_AUTO, MARGIN_NODE_MAJOR = 0, 1
+MARGIN_ROWS = {2: 2, 4: 4, 8: 8, 16: 16}
+MARGIN_ROWS_LDS = {8: 0x108, 16: 0x110}
+MARGIN_EXACT_ONLY = 0x1000
+# index of every kernel family in ah_build_stats.margin_mode_launches
+MODE_LAUNCH_INDEX = {1: 0, 2: 1, 4: 2, 8: 3, 16: 4, 0x108: 5, 0x110: 6}
 
 
 class AhBuildStats(C.Structure):
     _fields_ = [("seconds_total", C.c_double), ("seconds_device", C.c_double), ("seconds_margin", C.c_double),
                 ("margin_evaluations", C.c_uint64), ("margin_launches", C.c_uint64), ("margin_row_passes", C.c_uint64), ("split_nodes", C.c_uint64),
                 ("descendant_nodes", C.c_uint64), ("dummy_normals", C.c_uint64), ("retries", C.c_uint64),
-                ("levels", C.c_uint32)]
+                ("levels", C.c_uint32), ("margin_mode_launches", C.c_uint64 * 8), ("screened_launches", C.c_uint64),
+                ("screen_fallbacks", C.c_uint64), ("screen_violations", C.c_uint64)]
 
 
 # name -> (restype, argtypes): exactly the declarations of include/arroy_hip.h
@@ -78,6 +98,10 @@ SIGNATURES = {
     "ah_abi_version": (C.c_int, []),
     "ah_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "ah_last_error": (C.c_char_p, []),
+    "ah_last_error_detail": (C.c_int, [C.POINTER(AhErrorDetail)]),
+    "ah_dataset_upload_flush": (C.c_int, [_VP]),
+    "ah_dataset_set_preprocessed": (C.c_int, [_VP, C.c_int]),
+    "ah_dataset_replicate": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_void_p)]),
     "ah_dataset_create": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
     "ah_dataset_upload_records": (C.c_int, [_VP, _U32P, _VP, C.c_size_t, C.c_size_t]),
     "ah_dataset_upload_vectors": (C.c_int, [_VP, _U32P, _F32P, C.c_size_t]),
@@ -147,8 +171,10 @@ def check(status: int) -> None:
     if status == AH_OK:
         return
     msg = lib().ah_last_error().decode("utf-8", "replace")
+    det = AhErrorDetail()
+    lib().ah_last_error_detail(C.byref(det))
     cls = {1: InvalidVecDimension, 2: BuildCancelled, 6: MissingKey}.get(status, ArroyHipError)
-    raise cls(status, msg)
+    raise cls(status, msg, det if det.status == status else None)
 
 
 def device_count() -> int:

@@ -3,6 +3,8 @@
 // a HIP kernel; there is no CPU fallback.
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
 #include <new>
 #include <thread>
 
@@ -11,6 +13,7 @@
 namespace ah {
 
 static thread_local std::string g_error;
+static thread_local ah_error_detail g_detail = {AH_OK, 0, 0, 0};
 
 void set_error(const char *fmt, ...) {
     char buf[1024];
@@ -19,6 +22,13 @@ void set_error(const char *fmt, ...) {
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     g_error = buf;
+    g_detail = ah_error_detail{AH_ERR_DEVICE, 0, 0, 0};
+}
+void set_error_status(int status) { g_detail.status = status; }
+void set_error_detail(uint32_t item, uint64_t expected, uint64_t received) {
+    g_detail.item = item;
+    g_detail.expected = expected;
+    g_detail.received = received;
 }
 const char *last_error() { return g_error.c_str(); }
 
@@ -49,6 +59,8 @@ void Context::destroy() {
     if (h_pinned) (void)hipHostFree(h_pinned);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    for (hipEvent_t &e : ev_ring)
+        if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
     d_scratch = h_pinned = nullptr;
     stream = nullptr;
@@ -69,24 +81,104 @@ struct Carver {
 static inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // The host side of staging is a gather of records out of (unaligned) storage pages into pinned memory; one core
-// cannot keep a PCIe Gen5 link busy, so large chunks are split over a few threads.
+// cannot keep a PCIe Gen5 link busy (a 32 MiB chunk takes 0.6 ms on the wire), so chunks are spread over a small
+// process-wide pool of persistent workers (spawning threads per chunk costs as much as the copy itself).
+class WorkerPool {
+   public:
+    static WorkerPool &get() {
+        static WorkerPool pool;
+        return pool;
+    }
+    size_t size() const { return threads_.size() + 1; }
+    // fn(part) for part in [0, parts), on the workers and the calling thread; returns when all parts are done
+    void run(size_t parts, const std::function<void(size_t)> &fn) {
+        if (parts <= 1 || threads_.empty()) {
+            for (size_t p = 0; p < parts; p++) fn(p);
+            return;
+        }
+        std::lock_guard<std::mutex> serial(run_mu_);  // one parallel region at a time
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &fn;
+            parts_ = parts;
+            next_ = 0;
+            pending_ = parts;
+            generation_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+   private:
+    WorkerPool() {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        unsigned n = std::min(16u, std::max(1u, hw / 2));
+        if (const char *e = getenv("AH_STAGE_THREADS")) n = (unsigned)std::max(1, atoi(e));
+        for (unsigned i = 1; i < n; i++) threads_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    void work() {
+        for (;;) {
+            size_t p;
+            const std::function<void(size_t)> *fn;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!job_ || next_ >= parts_) return;
+                p = next_++;
+                fn = job_;
+            }
+            (*fn)(p);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--pending_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(size_t)> *job_ = nullptr;
+    size_t parts_ = 0, next_ = 0, pending_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+
 static constexpr size_t kParallelGrain = 256;  // items (rows, or ids of a candidate list) worth a thread
 template <typename F>
 static void parallel_rows(size_t n, F &&fn) {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const size_t n_threads = std::min<size_t>(std::min<unsigned>(hw, 8u), n / kParallelGrain);
-    if (n_threads <= 1) {
+    WorkerPool &pool = WorkerPool::get();
+    const size_t parts = std::min<size_t>(pool.size() * 2, n / kParallelGrain);
+    if (parts <= 1) {
         fn((size_t)0, n);
         return;
     }
-    std::vector<std::thread> pool;
-    const size_t per = (n + n_threads - 1) / n_threads;
-    for (size_t t = 0; t < n_threads; t++) {
-        const size_t lo = t * per, hi = std::min(n, lo + per);
-        if (lo >= hi) break;
-        pool.emplace_back([&fn, lo, hi] { fn(lo, hi); });
-    }
-    for (auto &th : pool) th.join();
+    const size_t per = (n + parts - 1) / parts;
+    pool.run(parts, [&](size_t p) {
+        const size_t lo = p * per, hi = std::min(n, lo + per);
+        if (lo < hi) fn(lo, hi);
+    });
 }
 
 }  // namespace ah
@@ -149,6 +241,11 @@ size_t ah_vector_size(int metric, uint32_t dimensions) {
 }
 int ah_abi_version(void) { return AH_ABI_VERSION; }
 const char *ah_last_error(void) { return ah::last_error(); }
+int ah_last_error_detail(ah_error_detail *out) {
+    if (!out) return AH_ERR_INVALID_ARGUMENT;
+    *out = g_detail;
+    return AH_OK;
+}
 
 int ah_device_count(int *out_count) {
     AH_REQUIRE(out_count, AH_ERR_INVALID_ARGUMENT, "out_count is NULL");
@@ -218,15 +315,24 @@ int ah_dataset_create(int metric, uint32_t dimensions, uint64_t capacity, int de
     return AH_OK;
 }
 
+static int upload_flush(ah_dataset *ds);
+
 int ah_dataset_destroy(ah_dataset *ds) {
     if (!ds) return AH_OK;
+    (void)upload_flush(ds);
     (void)hipSetDevice(ds->device);
     (void)hipDeviceSynchronize();
+    if (ds->up_ctx) {
+        ds->pool.push_back(ds->up_ctx);
+        ds->up_ctx = nullptr;
+    }
     for (Context *c : ds->pool) {
         c->destroy();
         delete c;
     }
     ds->pool.clear();
+    if (ds->d_rows_h16) (void)hipFree(ds->d_rows_h16);
+    if (ds->d_screen_stats) (void)hipFree(ds->d_screen_stats);
     if (ds->d_rows_f32) (void)hipFree(ds->d_rows_f32);
     if (ds->d_rows_bq) (void)hipFree(ds->d_rows_bq);
     if (ds->d_headers) (void)hipFree(ds->d_headers);
@@ -239,6 +345,7 @@ int ah_dataset_destroy(ah_dataset *ds) {
 static int check_append(ah_dataset *ds, const uint32_t *item_ids, size_t n) {
     AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
     AH_REQUIRE(!ds->finalized, AH_ERR_INVALID_ARGUMENT, "dataset already finalized");
+    AH_REQUIRE(item_ids || n == 0, AH_ERR_INVALID_ARGUMENT, "item_ids is NULL");
     AH_REQUIRE(ds->n + n <= ds->capacity, AH_ERR_INVALID_ARGUMENT, "upload of %zu items exceeds capacity %llu", n,
                (unsigned long long)ds->capacity);
     for (size_t i = 0; i < n; i++) {
@@ -259,8 +366,51 @@ static void note_ids(ah_dataset *ds, const uint32_t *item_ids, size_t n) {
     ds->n += n;
 }
 
-// LMDB pages -> pinned staging (header and vector split apart, rows re-pitched to 128-byte lines) ->
-// hipMemcpyAsync, double-buffered so the host-side gather of chunk c+1 overlaps the DMA of chunk c.
+// ---- staging ring ---------------------------------------------------------------------------------------------------
+// Uploads are asynchronous until ah_dataset_finalize: the dataset keeps one Context (stream + pinned ring of kRing
+// buffers) for all its upload calls; a call returns once its records are COPIED OUT of the caller's pages (the contract:
+// no host pointer is used after return) while the last DMA transfers may still be in flight.  The host-side gather of a
+// chunk is spread over the worker pool (one core cannot keep a PCIe Gen5 link busy), chunk c+1 is gathered while chunk c
+// and c-1 travel.
+static constexpr int kRing = 3;
+static constexpr size_t kStageBytes = 32u << 20;
+
+static int upload_flush(ah_dataset *ds) {
+    if (!ds->up_ctx) return AH_OK;
+    Context *c = ds->up_ctx;
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    ds->up_ctx = nullptr;
+    for (bool &u : ds->up_used) u = false;
+    ds->up_buf = 0;
+    ds->release(c);
+    if (e != hipSuccess) {
+        set_error("staging copy failed: %s", hipGetErrorString(e));
+        set_error_status(AH_ERR_DEVICE);
+        return AH_ERR_DEVICE;
+    }
+    return AH_OK;
+}
+
+// the dataset's upload context with a pinned ring of kRing x buf_bytes (grown only when idle)
+static int upload_context(ah_dataset *ds, size_t buf_bytes, Context **out) {
+    AH_HIP(hipSetDevice(ds->device));
+    if (!ds->up_ctx) {
+        ds->up_ctx = ds->acquire();
+        AH_REQUIRE(ds->up_ctx, AH_ERR_DEVICE, "cannot create a HIP stream");
+    }
+    Context *c = ds->up_ctx;
+    for (hipEvent_t &e : c->ev_ring)
+        if (!e) AH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (c->h_cap < (size_t)kRing * buf_bytes) {
+        AH_HIP(hipStreamSynchronize(c->stream));  // the old ring may still be a DMA source
+        for (bool &u : ds->up_used) u = false;
+        AH_TRY(c->ensure_pinned((size_t)kRing * buf_bytes));
+    }
+    *out = c;
+    return AH_OK;
+}
+
+// LMDB pages -> pinned staging (header and vector split apart, rows re-pitched to 128-byte lines) -> hipMemcpyAsync.
 int ah_dataset_upload_records(ah_dataset *ds, const uint32_t *item_ids, const uint8_t *const *record_ptrs,
                               size_t record_len, size_t n) {
     AH_TRY(check_append(ds, item_ids, n));
@@ -269,21 +419,24 @@ int ah_dataset_upload_records(ah_dataset *ds, const uint32_t *item_ids, const ui
     const size_t hs = ah_header_size(ds->metric), vs = ah_vector_size(ds->metric, ds->dims);
     // src/node.rs:252-258: [LEAF_TAG=0][header][vector]; a length mismatch is what UnalignedVector::from_bytes
     // / the dimension check reports as InvalidVecDimension
-    AH_REQUIRE(record_len == 1 + hs + vs, AH_ERR_INVALID_DIMENSION,
-               "record length %zu does not match 1 + %zu + %zu for %u dimensions", record_len, hs, vs, ds->dims);
-    AH_LEASE(ds, ctx);
+    if (record_len != 1 + hs + vs) {
+        set_error("record length %zu does not match 1 + %zu + %zu for %u dimensions", record_len, hs, vs, ds->dims);
+        set_error_status(AH_ERR_INVALID_DIMENSION);
+        set_error_detail(0, 1 + hs + vs, record_len);
+        return AH_ERR_INVALID_DIMENSION;
+    }
     const size_t rb = ds->row_bytes();
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (32u << 20) / (rb + hs + 4)));
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, kStageBytes / (rb + hs + 4)));
     const size_t buf_bytes = pad256(chunk * rb) + pad256(chunk * hs) + pad256(chunk * 4);
-    AH_TRY(ctx->ensure_pinned(2 * buf_bytes));
-    hipEvent_t ev[2] = {ctx->ev0, ctx->ev1};
-    bool used[2] = {false, false};
+    Context *ctx = nullptr;
+    AH_TRY(upload_context(ds, buf_bytes, &ctx));
+    const size_t ring_stride = ctx->h_cap / kRing & ~(size_t)255;
     size_t done = 0;
-    int b = 0;
     while (done < n) {
         const size_t c = std::min(chunk, n - done);
-        uint8_t *base = reinterpret_cast<uint8_t *>(ctx->h_pinned) + (size_t)b * buf_bytes;
-        if (used[b]) AH_HIP(hipEventSynchronize(ev[b]));
+        const int b = ds->up_buf;
+        uint8_t *base = reinterpret_cast<uint8_t *>(ctx->h_pinned) + (size_t)b * ring_stride;
+        if (ds->up_used[b]) AH_HIP(hipEventSynchronize(ctx->ev_ring[b]));
         uint8_t *h_rows = base, *h_hdr = base + pad256(chunk * rb), *h_ids = h_hdr + pad256(chunk * hs);
         for (size_t i = 0; i < c; i++) {
             const uint8_t *rec = record_ptrs[done + i];
@@ -306,14 +459,15 @@ int ah_dataset_upload_records(ah_dataset *ds, const uint32_t *item_ids, const ui
         AH_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t *>(ds->d_headers) + row0 * hs, h_hdr, c * hs,
                               hipMemcpyHostToDevice, ctx->stream));
         AH_HIP(hipMemcpyAsync(ds->d_ids + row0, h_ids, c * 4, hipMemcpyHostToDevice, ctx->stream));
-        AH_HIP(hipEventRecord(ev[b], ctx->stream));
-        used[b] = true;
-        b ^= 1;
+        AH_HIP(hipEventRecord(ctx->ev_ring[b], ctx->stream));
+        ds->up_used[b] = true;
+        ds->up_buf = (b + 1) % kRing;
         done += c;
     }
-    AH_HIP(hipStreamSynchronize(ctx->stream));
     note_ids(ds, item_ids, n);
-    if (ds->metric == AH_DOT_PRODUCT) ds->dot_preprocessed = true;  // stored headers already carry norm/extra_dim
+    // The stored DotProduct headers are taken as they are: items written by `Writer::add_item` carry {0, 0} until
+    // `DotProduct::preprocess` ran over the database (src/distance/dot_product.rs:119-165), so the dataset still needs
+    // ah_preprocess_dot unless the caller states that the database was preprocessed (ah_dataset_set_preprocessed).
     return AH_OK;
 }
 
@@ -322,23 +476,44 @@ int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, const fl
     AH_TRY(check_append(ds, item_ids, n));
     if (n == 0) return AH_OK;
     AH_REQUIRE(item_ids && vectors, AH_ERR_INVALID_ARGUMENT, "NULL input");
-    AH_LEASE(ds, ctx);
     const bool bq = metric_is_bq(ds->metric);
     const uint32_t fpitch = bq ? ((ds->dims + 3u) & ~3u) : ds->pitch;  // staging pitch in floats
     const size_t frb = (size_t)fpitch * 4;
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (32u << 20) / (frb + 4)));
-    const size_t buf_bytes = pad256(chunk * frb) + pad256(chunk * 4);
-    AH_TRY(ctx->ensure_pinned(2 * buf_bytes));
-    if (bq) AH_TRY(ctx->ensure_device(2 * pad256(chunk * frb)));
-    hipEvent_t ev[2] = {ctx->ev0, ctx->ev1};
-    bool used[2] = {false, false};
-    size_t done = 0;
-    int b = 0;
     DataView dv = ds->view();
+    // Rows that need no re-pitching can travel straight from the caller's memory when it is (or can be) page-locked:
+    // AH_STAGE_REGISTER=1 registers the caller's buffer for the duration of the call (measurement aid).
+    static const bool try_register = getenv("AH_STAGE_REGISTER") && atoi(getenv("AH_STAGE_REGISTER")) != 0;
+    if (try_register && !bq && fpitch == ds->dims && n * frb >= (64u << 20)) {
+        Context *ctx = nullptr;
+        AH_TRY(upload_context(ds, pad256(std::min<size_t>(n, kStageBytes / 4) * 4), &ctx));
+        if (hipHostRegister(const_cast<float *>(vectors), n * frb, hipHostRegisterDefault) == hipSuccess) {
+            const uint64_t row0 = ds->n;
+            hipError_t e = hipMemcpyAsync(ds->d_rows_f32 + row0 * ds->pitch, vectors, n * frb, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(ds->d_ids + row0, item_ids, n * 4, hipMemcpyHostToDevice, ctx->stream);
+            int st = e == hipSuccess ? launch_headers_from_vectors(dv, row0, n, ctx->stream) : AH_ERR_DEVICE;
+            const hipError_t es = hipStreamSynchronize(ctx->stream);  // the caller's pages are the DMA source
+            (void)hipHostUnregister(const_cast<float *>(vectors));
+            AH_REQUIRE(e == hipSuccess && es == hipSuccess && st == AH_OK, AH_ERR_DEVICE, "registered staging copy failed");
+            note_ids(ds, item_ids, n);
+            return AH_OK;
+        }
+        (void)hipGetLastError();  // not registrable: fall through to the bounce path
+    }
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, kStageBytes / (frb + 4)));
+    const size_t buf_bytes = pad256(chunk * frb) + pad256(chunk * 4);
+    Context *ctx = nullptr;
+    AH_TRY(upload_context(ds, buf_bytes, &ctx));
+    const size_t ring_stride = ctx->h_cap / kRing & ~(size_t)255;
+    if (bq) {
+        if (ctx->d_cap < (size_t)kRing * pad256(chunk * frb)) AH_HIP(hipStreamSynchronize(ctx->stream));
+        AH_TRY(ctx->ensure_device((size_t)kRing * pad256(chunk * frb)));
+    }
+    size_t done = 0;
     while (done < n) {
         const size_t c = std::min(chunk, n - done);
-        uint8_t *base = reinterpret_cast<uint8_t *>(ctx->h_pinned) + (size_t)b * buf_bytes;
-        if (used[b]) AH_HIP(hipEventSynchronize(ev[b]));
+        const int b = ds->up_buf;
+        uint8_t *base = reinterpret_cast<uint8_t *>(ctx->h_pinned) + (size_t)b * ring_stride;
+        if (ds->up_used[b]) AH_HIP(hipEventSynchronize(ctx->ev_ring[b]));
         float *h_rows = reinterpret_cast<float *>(base);
         uint8_t *h_ids = base + pad256(chunk * frb);
         parallel_rows(c, [&](size_t lo, size_t hi) {
@@ -361,13 +536,24 @@ int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, const fl
         }
         AH_HIP(hipMemcpyAsync(ds->d_ids + row0, h_ids, c * 4, hipMemcpyHostToDevice, ctx->stream));
         AH_TRY(launch_headers_from_vectors(dv, row0, c, ctx->stream));
-        AH_HIP(hipEventRecord(ev[b], ctx->stream));
-        used[b] = true;
-        b ^= 1;
+        AH_HIP(hipEventRecord(ctx->ev_ring[b], ctx->stream));
+        ds->up_used[b] = true;
+        ds->up_buf = (b + 1) % kRing;
         done += c;
     }
-    AH_HIP(hipStreamSynchronize(ctx->stream));
     note_ids(ds, item_ids, n);
+    return AH_OK;
+}
+
+int ah_dataset_upload_flush(ah_dataset *ds) {
+    AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
+    return upload_flush(ds);
+}
+
+int ah_dataset_set_preprocessed(ah_dataset *ds, int preprocessed) {
+    AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
+    AH_REQUIRE(ds->metric == AH_DOT_PRODUCT, AH_ERR_INVALID_ARGUMENT, "only DotProduct datasets have a preprocess step");
+    ds->dot_preprocessed = preprocessed != 0;
     return AH_OK;
 }
 
@@ -405,6 +591,7 @@ int ah_dataset_fill_synthetic(ah_dataset *ds, uint64_t seed, int distribution, u
 int ah_dataset_finalize(ah_dataset *ds) {
     AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
     if (ds->finalized) return AH_OK;
+    AH_TRY(upload_flush(ds));  // every staged record has landed
     AH_LEASE(ds, ctx);
     if (ds->identity_ids) {
         // ids 0..n-1: no table needed; the id array is still materialised for uniform kernels
@@ -432,15 +619,90 @@ int ah_dataset_len(const ah_dataset *ds, uint64_t *out_n_items) {
     return AH_OK;
 }
 
+// One staged dataset -> a replica on another GPU of the node, device to device over xGMI (hipMemcpyPeerAsync): the
+// multi-GPU build shards TREES over replicas of the read-only dataset, so a node stages the LMDB
+// records once over PCIe and fans the HBM image out instead of staging N times.  The replica is in the same state as
+// the source (finalized or not, DotProduct preprocessed or not); the binary16 shadow is rebuilt on the replica on
+// demand (a 10 ms kernel) rather than copied.
+int ah_dataset_replicate(ah_dataset *src, int device, ah_dataset **out) {
+    AH_REQUIRE(out, AH_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    AH_REQUIRE(src, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
+    AH_TRY(upload_flush(src));
+    ah_dataset *dst = nullptr;
+    AH_TRY(ah_dataset_create(src->metric, src->dims, std::max<uint64_t>(src->capacity, 1), device, &dst));
+    int st = AH_OK;
+    do {
+        if (device != src->device) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) {
+                (void)hipSetDevice(device);
+                (void)hipDeviceEnablePeerAccess(src->device, 0);  // already enabled is fine
+                (void)hipGetLastError();
+            }
+        }
+        ContextLease lease(dst);
+        if (!lease.c) {
+            set_error("cannot create a HIP stream");
+            st = AH_ERR_DEVICE;
+            break;
+        }
+        hipStream_t s = lease.c->stream;
+        const size_t rb = src->row_bytes(), hs = ah_header_size(src->metric);
+        const void *rows_src = src->d_rows_f32 ? (const void *)src->d_rows_f32 : (const void *)src->d_rows_bq;
+        void *rows_dst = dst->d_rows_f32 ? (void *)dst->d_rows_f32 : (void *)dst->d_rows_bq;
+        hipError_t e = hipSuccess;
+        if (src->n) {
+            e = hipMemcpyPeerAsync(rows_dst, device, rows_src, src->device, src->n * rb, s);
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(dst->d_headers, device, src->d_headers, src->device, src->n * hs, s);
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(dst->d_ids, device, src->d_ids, src->device, src->n * 4, s);
+        }
+        if (e == hipSuccess && src->d_lut) {
+            e = hipMalloc((void **)&dst->d_lut, (size_t)src->lut_len * 4);
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(dst->d_lut, device, src->d_lut, src->device, (size_t)src->lut_len * 4, s);
+            dst->lut_len = src->lut_len;
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) {
+            set_error("peer copy to device %d failed: %s", device, hipGetErrorString(e));
+            set_error_status(AH_ERR_DEVICE);
+            st = AH_ERR_DEVICE;
+            break;
+        }
+        dst->n = src->n;
+        dst->identity_ids = src->identity_ids;
+        dst->last_id = src->last_id;
+        dst->h_ids = src->h_ids;
+        dst->finalized = src->finalized;
+        dst->dot_preprocessed = src->dot_preprocessed;
+    } while (0);
+    if (st != AH_OK) {
+        ah_dataset_destroy(dst);
+        return st;
+    }
+    *out = dst;
+    return AH_OK;
+}
+
 // host-side id -> row (the host mirror is only used to validate single ids; lists are resolved on device)
 static int host_row_of_id(const ah_dataset *ds, uint32_t id, uint32_t *row) {
     if (ds->identity_ids) {
-        AH_REQUIRE(id < ds->n, AH_ERR_MISSING_ITEM, "item %u does not exist", id);
+        if (id >= ds->n) {
+            set_error("item %u does not exist", id);
+            set_error_status(AH_ERR_MISSING_ITEM);
+            set_error_detail(id, 0, 0);
+            return AH_ERR_MISSING_ITEM;
+        }
         *row = id;
         return AH_OK;
     }
     auto it = std::lower_bound(ds->h_ids.begin(), ds->h_ids.end(), id);
-    AH_REQUIRE(it != ds->h_ids.end() && *it == id, AH_ERR_MISSING_ITEM, "item %u does not exist", id);
+    if (it == ds->h_ids.end() || *it != id) {
+        set_error("item %u does not exist", id);
+        set_error_status(AH_ERR_MISSING_ITEM);
+        set_error_detail(id, 0, 0);
+        return AH_ERR_MISSING_ITEM;
+    }
     *row = (uint32_t)(it - ds->h_ids.begin());
     return AH_OK;
 }
@@ -467,6 +729,7 @@ int ah_dataset_item_vector(ah_dataset *ds, uint32_t item_id, float *out_vector) 
 int ah_dataset_read_headers(ah_dataset *ds, uint64_t first_row, uint64_t n, void *out_headers) {
     AH_REQUIRE(ds && out_headers, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     AH_REQUIRE(first_row + n <= ds->n, AH_ERR_INVALID_ARGUMENT, "row range out of bounds");
+    AH_TRY(upload_flush(ds));
     AH_HIP(hipSetDevice(ds->device));
     const size_t hs = ah_header_size(ds->metric);
     AH_HIP(hipMemcpy(out_headers, reinterpret_cast<uint8_t *>(ds->d_headers) + first_row * hs, n * hs,
@@ -477,6 +740,7 @@ int ah_dataset_read_headers(ah_dataset *ds, uint64_t first_row, uint64_t n, void
 int ah_preprocess_dot(ah_dataset *ds, float *out_max_norm) {
     AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
     AH_REQUIRE(ds->metric == AH_DOT_PRODUCT, AH_ERR_INVALID_ARGUMENT, "preprocess is only defined for DotProduct");
+    AH_TRY(upload_flush(ds));
     AH_LEASE(ds, ctx);
     AH_TRY(ctx->ensure_device(256));
     AH_TRY(launch_preprocess_dot(ds->view(), reinterpret_cast<float *>(ctx->d_scratch), ctx->stream));

@@ -22,12 +22,17 @@ namespace ah {
 // ---------------------------------------------------------------------------------------------
 void set_error(const char *fmt, ...);
 const char *last_error();
+// structured part of the last failure (ah_last_error_detail): set_error() clears it, AH_REQUIRE / AH_HIP record the
+// status, the sites that know more add the item id or the expected / received sizes
+void set_error_status(int status);
+void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
 
 #define AH_HIP(expr)                                                                               \
     do {                                                                                           \
         hipError_t _e = (expr);                                                                    \
         if (_e != hipSuccess) {                                                                    \
             ::ah::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            ::ah::set_error_status((_e == hipErrorOutOfMemory) ? AH_ERR_OUT_OF_MEMORY : AH_ERR_DEVICE); \
             return (_e == hipErrorOutOfMemory) ? AH_ERR_OUT_OF_MEMORY : AH_ERR_DEVICE;             \
         }                                                                                          \
     } while (0)
@@ -42,6 +47,7 @@ const char *last_error();
     do {                                  \
         if (!(cond)) {                    \
             ::ah::set_error(__VA_ARGS__); \
+            ::ah::set_error_status(code); \
             return (code);                \
         }                                 \
     } while (0)
@@ -77,10 +83,22 @@ struct DataView {
     int identity_ids;      // ids are exactly 0..n-1
 };
 
+// binary16 shadow of an f32 dataset for the certified screen of the forest build (screen_device.h):
+//   rows   n x hpitch halves (hpitch = round_up(dims, 64): an octet reads 128-byte lines, 16 B = 8 halves per lane)
+//   stats  per row {|x~|, |x - x~|, |x|, 0}: 2-norms of the rounded row, of the rounding error and of the row, each
+//          rounded UP (so that the bound built from them is rigorous)
+struct ScreenView {
+    const uint16_t *rows;
+    const float4 *stats;
+    uint32_t hpitch;
+    float gamma_s, gamma_r;  // accumulation-error factors of the screen / of the reference f32 reduction
+};
+
 // One per concurrently calling host thread: a stream plus growable device / pinned scratch.
 struct Context {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_ring[4] = {nullptr, nullptr, nullptr, nullptr};  // staging ring (created on first use)
     void *d_scratch = nullptr;
     size_t d_cap = 0;
     void *h_pinned = nullptr;
@@ -110,6 +128,16 @@ struct ah_dataset {
     bool identity_ids = true;
     uint32_t last_id = 0;
     std::vector<uint32_t> h_ids;     // host mirror of ids (ascending) for id validation / lookups
+    // lazily built binary16 shadow (first forest build of an f32 dataset); nullptr = not built / not available
+    uint16_t *d_rows_h16 = nullptr;
+    float4 *d_screen_stats = nullptr;
+    uint32_t hpitch = 0;
+    bool screen_tried = false;
+    // staging in flight (ah_dataset_upload_*): the context whose stream / pinned ring the uploads use until
+    // ah_dataset_finalize (or ah_dataset_upload_flush) waits for them
+    ah::Context *up_ctx = nullptr;
+    int up_buf = 0;
+    bool up_used[4] = {false, false, false, false};
     std::mutex mu;
     std::vector<ah::Context *> pool;
 

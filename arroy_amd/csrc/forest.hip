@@ -25,6 +25,7 @@
 
 #include "common.h"
 #include "split_device.h"
+#include "screen_device.h"
 
 namespace ah {
 
@@ -43,7 +44,19 @@ struct FNode {
     uint32_t attempt;  // current / final split attempt (0..3)
     uint32_t state;    // ST_*
     uint32_t tile_begin, n_tiles;
-    uint32_t rec;      // host record index
+    uint32_t fix;      // the parent's sides were re-drawn after its row-major pass (retry / random fallback): the rows of
+                       // this node cannot take their node index from k_forest_advance_node_of
+};
+// What the host needs to know about a level before it can launch it (written by the k_next_* kernels, read back
+// through pinned memory): sizes, the cost model's inputs, and the first node of every tree (nodes are ordered by tree).
+struct LevelInfo {
+    uint32_t n_nodes, n_tiles, n_fix, pad;
+    unsigned long long pairs;  // items under the level's nodes = margin evaluations of a first attempt
+    unsigned long long pad2;
+    // followed by uint32_t tree_first[n_trees + 1]
+};
+struct ScreenCounters {
+    unsigned long long fallbacks, violations;
 };
 struct FTile {
     uint32_t node;
@@ -105,12 +118,14 @@ __global__ __launch_bounds__(kBlock) void k_forest_margin_f32(DataView dv, FNode
                                                               uint64_t n_items, const uint8_t *__restrict__ normals,
                                                               uint64_t nstride, uint64_t hdr_off,
                                                               uint64_t *__restrict__ masks,
-                                                              uint32_t *__restrict__ tile_left) {
+                                                              uint32_t *__restrict__ tile_left,
+                                                              const uint32_t *__restrict__ abort_flag) {
     extern __shared__ float4 s_n4[];
     __shared__ uint32_t s_left;
     const float *s_n = reinterpret_cast<const float *>(s_n4);
     const uint32_t o = threadIdx.x >> 3, j = threadIdx.x & 7u;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (__builtin_nontemporal_load(abort_flag)) return;  // build cancelled: drain (block-uniform)
         const FTile tl = tiles[tile];
         const FNode *nd = nodes + tl.node;
         if (nd->state != ST_PENDING) continue;  // block-uniform
@@ -151,11 +166,13 @@ __global__ __launch_bounds__(kBlock) void k_forest_margin_bq(DataView dv, FNode 
                                                              uint64_t n_items, const uint8_t *__restrict__ normals,
                                                              uint64_t nstride, uint64_t hdr_off,
                                                              uint64_t *__restrict__ masks,
-                                                             uint32_t *__restrict__ tile_left) {
+                                                             uint32_t *__restrict__ tile_left,
+                                                             const uint32_t *__restrict__ abort_flag) {
     extern __shared__ uint64_t s_nw[];
     __shared__ uint32_t s_left;
     __shared__ uint8_t s_side[kTile];
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (__builtin_nontemporal_load(abort_flag)) return;
         const FTile tl = tiles[tile];
         const FNode *nd = nodes + tl.node;
         if (nd->state != ST_PENDING) continue;
@@ -209,10 +226,11 @@ __global__ __launch_bounds__(kBlock) void k_forest_margin_bq(DataView dv, FNode 
 __global__ __launch_bounds__(kBlock) void k_forest_assign_node_of(const FNode *__restrict__ nodes,
                                                                   const FTile *__restrict__ tiles, uint32_t n_tiles,
                                                                   const uint32_t *__restrict__ perm, uint64_t n_items,
-                                                                  uint32_t *__restrict__ node_of) {
+                                                                  uint32_t *__restrict__ node_of, uint32_t only_fix) {
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const FTile tl = tiles[tile];
         const FNode *nd = nodes + tl.node;
+        if (only_fix && !nd->fix) continue;
         const uint32_t in_tile = min(kTile, nd->count - tl.first);
         const uint32_t *pp = perm + nd->start + tl.first;
         uint32_t *dst = node_of + (uint64_t)nd->tree * n_items;
@@ -251,10 +269,12 @@ template <int METRIC, int TC>
 __global__ __launch_bounds__(kBlock) void k_forest_margin_rows(DataView dv, const uint32_t *__restrict__ node_of,
                                                                uint32_t tree0, uint32_t n_pass,
                                                                const uint8_t *__restrict__ normals, uint64_t nstride,
-                                                               uint64_t hdr_off, uint8_t *__restrict__ side_bytes) {
+                                                               uint64_t hdr_off, uint8_t *__restrict__ side_bytes,
+                                                               const uint32_t *__restrict__ abort_flag) {
     const uint32_t j = threadIdx.x & 7u;
     const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
     const uint32_t blocks = dv.dims >> 5;
+    if (__builtin_nontemporal_load(abort_flag)) return;
     for (uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; row < dv.n; row += n_octets) {
         const float *rp = dv.rows_f32 + row * dv.pitch;
         const float4 *r4 = reinterpret_cast<const float4 *>(rp) + j;
@@ -315,8 +335,10 @@ __global__ __launch_bounds__(TC >= 16 ? 512 : 1024) void k_forest_margin_rows_ld
                                                                  uint32_t tree0, uint32_t n_pass,
                                                                  const uint8_t *__restrict__ normals, uint64_t nstride,
                                                                  uint64_t hdr_off, uint8_t *__restrict__ side_bytes,
-                                                                 uint32_t first_node, uint32_t n_group_nodes) {
+                                                                 uint32_t first_node, uint32_t n_group_nodes,
+                                                                 const uint32_t *__restrict__ abort_flag) {
     extern __shared__ float4 s_norm4[];
+    if (__builtin_nontemporal_load(abort_flag)) return;
     const uint32_t stride4 = (uint32_t)(nstride >> 4);  // record size in float4 (row bytes are a multiple of 128, + 16)
     {
         const float4 *g = reinterpret_cast<const float4 *>(normals + (uint64_t)first_node * nstride);
@@ -546,6 +568,477 @@ __global__ void k_rows_to_ids(uint32_t *perm, uint64_t total, const uint32_t *__
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) perm[g] = ids[perm[g]];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Certified binary16 screen (screen_device.h): shadow copies and the screened variants of the three margin kernels.
+// ------------------------------------------------------------------------------------------------
+
+// f32 -> binary16 for the shadow copies: round to nearest even; values that would be binary16 subnormals become 0 (the
+// measured error norm accounts for it), so the screen never depends on how v_dot2c treats subnormal inputs.
+__device__ __forceinline__ _Float16 to_shadow_half(float x) {
+    _Float16 h = (_Float16)x;
+    if (fabsf((float)h) < 6.103515625e-05f) h = (_Float16)0.0f;  // NaN stays NaN, inf stays inf (-> fallback)
+    return h;
+}
+
+// rows -> binary16 shadow + per-row stats.  One octet per row, lane j converts elements 32k + 4j .. +3 (8 bytes out).
+__global__ __launch_bounds__(kBlock) void k_shadow_rows(DataView dv, uint16_t *__restrict__ h_rows, uint32_t hpitch,
+                                                        float4 *__restrict__ stats) {
+    const uint32_t j = threadIdx.x & 7u;
+    const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+    const uint32_t blocks = dv.pitch >> 5;  // the padding of the f32 row is zero
+    for (uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; row < dv.n; row += n_octets) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(dv.rows_f32 + row * dv.pitch) + j;
+        uint2 *o2 = reinterpret_cast<uint2 *>(h_rows + row * hpitch) + j;
+        float sa = 0.f, sb = 0.f, sc = 0.f;
+        for (uint32_t k = 0; k < blocks; k++) {
+            float4 x = ld_stream(r4 + k * 8);
+            const uint32_t e0 = 32 * k + 4 * j;  // elements beyond dims (row padding) count as zeros
+            if (e0 + 0 >= dv.dims) x.x = 0.0f;
+            if (e0 + 1 >= dv.dims) x.y = 0.0f;
+            if (e0 + 2 >= dv.dims) x.z = 0.0f;
+            if (e0 + 3 >= dv.dims) x.w = 0.0f;
+            const _Float16 h0 = to_shadow_half(x.x), h1 = to_shadow_half(x.y), h2 = to_shadow_half(x.z), h3 = to_shadow_half(x.w);
+            const float y0 = (float)h0, y1 = (float)h1, y2 = (float)h2, y3 = (float)h3;
+            sa += y0 * y0 + y1 * y1 + y2 * y2 + y3 * y3;
+            const float d0 = x.x - y0, d1 = x.y - y1, d2 = x.z - y2, d3 = x.w - y3;
+            sb += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            sc += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+            f16x2_t lo = {h0, h1}, hi = {h2, h3};
+            o2[k * 8] = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+        }
+        if (hpitch > dv.pitch) o2[blocks * 8] = make_uint2(0u, 0u);  // pitch is 32 mod 64: zero the last half line
+        sa = octet_sum(sa);
+        sb = octet_sum(sb);
+        sc = octet_sum(sc);
+        // 2-norms rounded UP: the f32 sums of squares carry a relative error below (dims + 8) * 2^-24
+        const float up = 1.0f + (float)(dv.pitch + 64u) * 1.2e-7f;
+        if (j == 0) stats[row] = make_float4(sqrtf(sa) * up, sqrtf(sb) * up, sqrtf(sc) * up, 0.0f);
+    }
+}
+
+// The level's normals (records [vector][header slot]) -> shadow records [hpitch halves][NormalStats], one wave per node.
+__global__ __launch_bounds__(64) void k_forest_shadow_normals(DataView dv, const FNode *__restrict__ nodes,
+                                                              const uint8_t *__restrict__ normals, uint64_t nstride,
+                                                              uint64_t hdr_off, uint8_t *__restrict__ shadow,
+                                                              uint64_t hstride, uint32_t hpitch) {
+    const uint32_t node = blockIdx.x;
+    if (nodes[node].state != ST_PENDING) return;
+    const float *nv = reinterpret_cast<const float *>(normals + node * nstride);
+    uint16_t *out = reinterpret_cast<uint16_t *>(shadow + node * hstride);
+    float sa = 0.f, sb = 0.f, sc = 0.f;
+    for (uint32_t i = threadIdx.x; i < hpitch; i += 64) {
+        const float x = i < dv.dims ? nv[i] : 0.0f;
+        const _Float16 h = to_shadow_half(x);
+        const float y = (float)h, d = x - y;
+        sa += y * y;
+        sb += d * d;
+        sc += x * x;
+        out[i] = __builtin_bit_cast(uint16_t, h);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sa += __shfl_xor(sa, off);
+        sb += __shfl_xor(sb, off);
+        sc += __shfl_xor(sc, off);
+    }
+    if (threadIdx.x == 0) {
+        const float up = 1.0f + (float)(hpitch + 64u) * 1.2e-7f;
+        const float *nh = reinterpret_cast<const float *>(normals + node * nstride + hdr_off);
+        NormalStats st;
+        st.an = sqrtf(sa) * up;
+        st.bn = sqrtf(sb) * up;
+        st.cn = sqrtf(sc) * up;
+        st.extra = dv.metric == AH_COSINE ? 0.0f : nh[0];  // bias (Euclidean / Manhattan) or the normal's extra dimension
+        *reinterpret_cast<NormalStats *>(shadow + node * hstride + (uint64_t)hpitch * 2) = st;
+    }
+}
+
+// screen dot product of one row against one normal, octet-cooperative: lane j covers halves 64k + 8j .. +7
+// a4 = normal (LDS or global), r4 = row (global, streamed); steps = hpitch / 64.  Result on every lane of the octet.
+__device__ __forceinline__ float screen_octet_dot(const uint4 *a4, const uint4 *r4, uint32_t steps) {
+    float acc0 = 0.f, acc1 = 0.f;
+    uint32_t k = 0;
+    for (; k + 8 <= steps; k += 8) {
+        uint4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = ld_stream_u4(r4 + (k + u) * 8);
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            acc0 = screen_dot8(a4[(k + u) * 8], x[u], acc0);
+            acc1 = screen_dot8(a4[(k + u + 1) * 8], x[u + 1], acc1);
+        }
+    }
+    if (k + 4 <= steps) {
+        uint4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[u] = ld_stream_u4(r4 + (k + u) * 8);
+#pragma unroll
+        for (int u = 0; u < 4; u += 2) {
+            acc0 = screen_dot8(a4[(k + u) * 8], x[u], acc0);
+            acc1 = screen_dot8(a4[(k + u + 1) * 8], x[u + 1], acc1);
+        }
+        k += 4;
+    }
+    for (; k < steps; k++) acc0 = screen_dot8(a4[k * 8], ld_stream_u4(r4 + k * 8), acc0);
+    return octet_sum(acc0 + acc1);
+}
+
+// Node-major margin pass with the screen: as k_forest_margin_f32, but an item costs 2*dims bytes of HBM unless the
+// screen cannot decide its side (then the reference arithmetic runs for that item, from the f32 normal kept in LDS).
+template <int METRIC>
+__global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, ScreenView sv, FNode *nodes,
+                                                               const FTile *__restrict__ tiles, uint32_t n_tiles,
+                                                               const uint32_t *__restrict__ perm,
+                                                               const uint8_t *__restrict__ normals, uint64_t nstride,
+                                                               uint64_t hdr_off, const uint8_t *__restrict__ shadow,
+                                                               uint64_t hstride, uint64_t *__restrict__ masks,
+                                                               uint32_t *__restrict__ tile_left,
+                                                               const uint32_t *__restrict__ abort_flag,
+                                                               ScreenCounters *__restrict__ counters, uint32_t verify) {
+    extern __shared__ float4 s_n4[];  // [pitch floats f32 normal][hpitch halves shadow normal]
+    __shared__ uint32_t s_left, s_fb, s_bad;
+    const float *s_n = reinterpret_cast<const float *>(s_n4);
+    const uint4 *s_h4 = reinterpret_cast<const uint4 *>(s_n4 + (dv.pitch >> 2));
+    const uint32_t o = threadIdx.x >> 3, j = threadIdx.x & 7u;
+    const uint32_t steps = sv.hpitch >> 6;
+    uint32_t fallbacks = 0, bad = 0;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (__builtin_nontemporal_load(abort_flag)) return;
+        const FTile tl = tiles[tile];
+        const FNode *nd = nodes + tl.node;
+        if (nd->state != ST_PENDING) continue;  // block-uniform
+        __syncthreads();
+        {
+            const float4 *g_n4 = reinterpret_cast<const float4 *>(normals + tl.node * nstride);
+            for (uint32_t i = threadIdx.x; i < (dv.pitch >> 2); i += blockDim.x) s_n4[i] = g_n4[i];
+            const uint4 *g_h4 = reinterpret_cast<const uint4 *>(shadow + tl.node * hstride);
+            uint4 *d_h4 = reinterpret_cast<uint4 *>(s_n4 + (dv.pitch >> 2));
+            for (uint32_t i = threadIdx.x; i < (sv.hpitch >> 3); i += blockDim.x) d_h4[i] = g_h4[i];
+        }
+        if (threadIdx.x == 0) s_left = 0;
+        __syncthreads();
+        const float *g_h = reinterpret_cast<const float *>(normals + tl.node * nstride + hdr_off);
+        const LeafHdr nh = {g_h[0], g_h[1]};
+        const NormalStats ns = *reinterpret_cast<const NormalStats *>(shadow + tl.node * hstride + (uint64_t)sv.hpitch * 2);
+        const uint32_t in_tile = min(kTile, nd->count - tl.first);
+        const uint32_t *pp = perm + nd->start + tl.first;
+        uint64_t mask = 0;
+        uint32_t lefts = 0;
+        for (uint32_t i = 0; i < 64; i++) {
+            const uint32_t p = o + 32 * i;
+            if (p >= in_tile) break;
+            const uint64_t row = pp[p];
+            const uint4 *r4 = reinterpret_cast<const uint4 *>(sv.rows + row * sv.hpitch) + j;
+            const float s = screen_octet_dot(s_h4 + j, r4, steps);
+            const float row_extra = METRIC == AH_DOT_PRODUCT ? dv.headers[2 * row] : 0.0f;
+            uint32_t side;
+            const bool decided = screen_decides<METRIC>(s, sv.stats[row], ns, row_extra, sv.gamma_s, sv.gamma_r, side);
+            if (!decided || verify) {  // octet-uniform
+                const uint32_t exact = side_of_margin(margin_f32<METRIC>(dv, s_n, nh, row, j));
+                if (decided && exact != side) bad++;
+                if (!decided) fallbacks++;
+                side = exact;
+            }
+            mask |= (uint64_t)side << i;
+            lefts += side ^ 1u;
+        }
+        if (j == 0) {
+            masks[(uint64_t)tile * 32 + o] = mask;
+            if (lefts) atomicAdd(&s_left, lefts);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            tile_left[tile] = s_left;
+            if (s_left) atomicAdd(&nodes[tl.node].n_left, s_left);
+        }
+    }
+    // statistics: one atomic per block
+    __syncthreads();
+    if (threadIdx.x == 0) s_fb = s_bad = 0;
+    __syncthreads();
+    if (j == 0 && fallbacks) atomicAdd(&s_fb, fallbacks);
+    if (j == 0 && bad) atomicAdd(&s_bad, bad);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_fb) atomicAdd(&counters->fallbacks, (unsigned long long)s_fb);
+        if (s_bad) atomicAdd(&counters->violations, (unsigned long long)s_bad);
+    }
+}
+
+// exact margin of (row, normal record in global memory) by one octet: the arithmetic of k_forest_margin_rows
+template <int METRIC>
+__device__ __forceinline__ float rows_exact_margin(const DataView &dv, uint64_t row, const uint8_t *nrec, uint64_t hdr_off,
+                                                   uint32_t j) {
+    const float *rp = dv.rows_f32 + row * dv.pitch;
+    const float *np = reinterpret_cast<const float *>(nrec);
+    const float d = octet_reduce_stream<OP_DOT>(reinterpret_cast<const float4 *>(np), rp, dv.dims, j);
+    const float *nh = reinterpret_cast<const float *>(nrec + hdr_off);
+    if (METRIC == AH_EUCLIDEAN || METRIC == AH_MANHATTAN) return f_add(nh[0], d);
+    if (METRIC == AH_DOT_PRODUCT) return f_add(d, f_mul(nh[0], dv.headers[2 * row]));
+    return d;
+}
+
+// Row-major pass with the screen.  LDS_NORMALS: the shadow records of the group's nodes [first_node, +n_group_nodes) are
+// resident in LDS (top levels); otherwise they come from L2.  The f32 normals (fallback) always come from global memory.
+template <int METRIC, int TC, bool LDS_NORMALS>
+__global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock) void k_forest_screen_rows(
+    DataView dv, ScreenView sv, const uint32_t *__restrict__ node_of, uint32_t tree0, uint32_t n_pass,
+    const uint8_t *__restrict__ normals, uint64_t nstride, uint64_t hdr_off, const uint8_t *__restrict__ shadow,
+    uint64_t hstride, uint8_t *__restrict__ side_bytes, uint32_t first_node, uint32_t n_group_nodes,
+    const uint32_t *__restrict__ abort_flag, ScreenCounters *__restrict__ counters, uint32_t verify) {
+    extern __shared__ uint4 s_shadow4[];
+    __shared__ uint32_t s_fb, s_bad;
+    if (__builtin_nontemporal_load(abort_flag)) return;
+    const uint32_t hstride4 = (uint32_t)(hstride >> 4);
+    if (LDS_NORMALS) {
+        const uint4 *g = reinterpret_cast<const uint4 *>(shadow + (uint64_t)first_node * hstride);
+        const uint32_t total = n_group_nodes * hstride4;
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) s_shadow4[i] = g[i];
+    }
+    if (threadIdx.x == 0) s_fb = s_bad = 0;
+    __syncthreads();
+    const uint32_t j = threadIdx.x & 7u;
+    const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+    const uint32_t steps = sv.hpitch >> 6;
+    const uint32_t stats4 = sv.hpitch >> 3;  // uint4 index of the NormalStats inside a shadow record
+    uint32_t fallbacks = 0, bad = 0;
+    for (uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; row < dv.n; row += n_octets) {
+        const uint4 *r4 = reinterpret_cast<const uint4 *>(sv.rows + row * sv.hpitch) + j;
+        const uint4 *n4[TC];
+        uint32_t nodes_t[TC];
+        float acc[TC];
+#pragma unroll
+        for (int t = 0; t < TC; t++) {
+            uint32_t node = 0xFFFFFFFFu;
+            if ((uint32_t)t < n_pass) node = node_of[(uint64_t)(tree0 + t) * dv.n + row];
+            nodes_t[t] = node;
+            const uint32_t nn = node != 0xFFFFFFFFu ? node : first_node;
+            n4[t] = LDS_NORMALS ? s_shadow4 + (nn - first_node) * hstride4
+                                : reinterpret_cast<const uint4 *>(shadow + (uint64_t)nn * hstride);
+            acc[t] = 0.f;
+        }
+        uint32_t k = 0;
+        for (; k + 8 <= steps; k += 8) {
+            uint4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = ld_stream_u4(r4 + (k + u) * 8);
+#pragma unroll
+            for (int t = 0; t < TC; t++) {
+                if (nodes_t[t] != 0xFFFFFFFFu) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) acc[t] = screen_dot8(n4[t][(k + u) * 8 + j], x[u], acc[t]);
+                }
+            }
+        }
+        if (k + 4 <= steps) {
+            uint4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) x[u] = ld_stream_u4(r4 + (k + u) * 8);
+#pragma unroll
+            for (int t = 0; t < TC; t++) {
+                if (nodes_t[t] != 0xFFFFFFFFu) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) acc[t] = screen_dot8(n4[t][(k + u) * 8 + j], x[u], acc[t]);
+                }
+            }
+            k += 4;
+        }
+        for (; k < steps; k++) {
+            const uint4 x = ld_stream_u4(r4 + k * 8);
+#pragma unroll
+            for (int t = 0; t < TC; t++)
+                if (nodes_t[t] != 0xFFFFFFFFu) acc[t] = screen_dot8(n4[t][k * 8 + j], x, acc[t]);
+        }
+        const float4 rs = sv.stats[row];
+        const float row_extra = METRIC == AH_DOT_PRODUCT ? dv.headers[2 * row] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < TC; t++) {
+            if (nodes_t[t] != 0xFFFFFFFFu) {
+                const float s = octet_sum(acc[t]);
+                const uint4 raw = n4[t][stats4];
+                NormalStats ns;
+                ns.an = __uint_as_float(raw.x);
+                ns.bn = __uint_as_float(raw.y);
+                ns.cn = __uint_as_float(raw.z);
+                ns.extra = __uint_as_float(raw.w);
+                uint32_t side;
+                const bool decided = screen_decides<METRIC>(s, rs, ns, row_extra, sv.gamma_s, sv.gamma_r, side);
+                if (!decided || verify) {  // octet-uniform
+                    const uint32_t exact = side_of_margin(
+                        rows_exact_margin<METRIC>(dv, row, normals + (uint64_t)nodes_t[t] * nstride, hdr_off, j));
+                    if (decided && exact != side) bad++;
+                    if (!decided) fallbacks++;
+                    side = exact;
+                }
+                if (j == 0) side_bytes[(uint64_t)(tree0 + t) * dv.n + row] = (uint8_t)side;
+            }
+        }
+    }
+    if (j == 0 && fallbacks) atomicAdd(&s_fb, fallbacks);
+    if (j == 0 && bad) atomicAdd(&s_bad, bad);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_fb) atomicAdd(&counters->fallbacks, (unsigned long long)s_fb);
+        if (s_bad) atomicAdd(&counters->violations, (unsigned long long)s_bad);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The next level, built on the device: children of every split node that are still too large for a Descendants node
+// (src/writer.rs:474-477) become the next level's nodes, in node order, left child first — the order the host used to
+// produce.  Three small kernels (count per block, scan of the block sums, emit) plus the tile list; the host reads back
+// only the LevelInfo block before it launches the level, the node tables follow asynchronously for the final node list.
+// ------------------------------------------------------------------------------------------------
+struct NextCounts {
+    uint32_t kids, tiles;
+};
+__device__ __forceinline__ void child_counts(const FNode &nd, uint32_t split_after, uint32_t cnt[2], uint32_t split[2]) {
+    cnt[0] = nd.n_left;
+    cnt[1] = nd.count - nd.n_left;
+    split[0] = cnt[0] > split_after ? 1u : 0u;
+    split[1] = cnt[1] > split_after ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_next_count(const FNode *__restrict__ nodes, uint32_t n_nodes, uint32_t split_after,
+                                                    NextCounts *__restrict__ block_sums) {
+    __shared__ uint32_t s_k[4], s_t[4];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t kids = 0, tiles = 0;
+    if (i < n_nodes) {
+        uint32_t cnt[2], sp[2];
+        child_counts(nodes[i], split_after, cnt, sp);
+        kids = sp[0] + sp[1];
+        tiles = sp[0] * ((cnt[0] + kTile - 1) / kTile) + sp[1] * ((cnt[1] + kTile - 1) / kTile);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        kids += __shfl_xor(kids, off);
+        tiles += __shfl_xor(tiles, off);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        s_k[threadIdx.x >> 6] = kids;
+        s_t[threadIdx.x >> 6] = tiles;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = NextCounts{s_k[0] + s_k[1] + s_k[2] + s_k[3], s_t[0] + s_t[1] + s_t[2] + s_t[3]};
+}
+// exclusive scan of the block sums in place (one block; n_blocks <= a few thousand) + the level totals
+__global__ __launch_bounds__(1024) void k_next_scan(NextCounts *__restrict__ block_sums, uint32_t n_blocks,
+                                                    LevelInfo *__restrict__ info, uint32_t *__restrict__ tree_first,
+                                                    uint32_t n_trees) {
+    __shared__ uint32_t s_k[16], s_t[16];
+    __shared__ uint32_t s_carry_k, s_carry_t;
+    if (threadIdx.x == 0) s_carry_k = s_carry_t = 0;
+    for (uint32_t t = threadIdx.x; t <= n_trees; t += blockDim.x) tree_first[t] = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < n_blocks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const NextCounts v = i < n_blocks ? block_sums[i] : NextCounts{0u, 0u};
+        uint32_t ik = v.kids, it = v.tiles;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t uk = __shfl_up(ik, off), ut = __shfl_up(it, off);
+            if ((int)lane >= off) {
+                ik += uk;
+                it += ut;
+            }
+        }
+        if (lane == 63) {
+            s_k[wave] = ik;
+            s_t[wave] = it;
+        }
+        __syncthreads();
+        uint32_t wk = 0, wt = 0;
+        for (uint32_t w = 0; w < wave; w++) {
+            wk += s_k[w];
+            wt += s_t[w];
+        }
+        const uint32_t ck = s_carry_k, ct = s_carry_t;
+        if (i < n_blocks) block_sums[i] = NextCounts{ck + wk + ik - v.kids, ct + wt + it - v.tiles};
+        __syncthreads();
+        if (threadIdx.x == 1023) {
+            s_carry_k = ck + wk + ik;
+            s_carry_t = ct + wt + it;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        info->n_nodes = s_carry_k;
+        info->n_tiles = s_carry_t;
+        info->n_fix = 0;
+        info->pairs = 0;
+    }
+}
+__global__ __launch_bounds__(256) void k_next_emit(const FNode *__restrict__ nodes, uint32_t n_nodes, uint32_t split_after,
+                                                   const NextCounts *__restrict__ block_sums, FNode *__restrict__ next,
+                                                   uint32_t *__restrict__ child, LevelInfo *__restrict__ info,
+                                                   uint32_t *__restrict__ tree_first) {
+    __shared__ uint32_t s_k[4], s_t[4];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    FNode nd{};
+    uint32_t cnt[2] = {0, 0}, sp[2] = {0, 0};
+    if (i < n_nodes) {
+        nd = nodes[i];
+        child_counts(nd, split_after, cnt, sp);
+    }
+    const uint32_t kids = sp[0] + sp[1];
+    const uint32_t nt[2] = {sp[0] * ((cnt[0] + kTile - 1) / kTile), sp[1] * ((cnt[1] + kTile - 1) / kTile)};
+    uint32_t ik = kids, it = nt[0] + nt[1];
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t uk = __shfl_up(ik, off), ut = __shfl_up(it, off);
+        if ((int)lane >= off) {
+            ik += uk;
+            it += ut;
+        }
+    }
+    if (lane == 63) {
+        s_k[wave] = ik;
+        s_t[wave] = it;
+    }
+    __syncthreads();
+    uint32_t idx = block_sums[blockIdx.x].kids + ik - kids, tidx = block_sums[blockIdx.x].tiles + it - (nt[0] + nt[1]);
+    for (uint32_t w = 0; w < wave; w++) {
+        idx += s_k[w];
+        tidx += s_t[w];
+    }
+    if (i >= n_nodes) return;
+    // sides of a first-attempt accept are the ones a row-major pass left in side_bytes; anything else was re-drawn
+    const uint32_t fix = (nd.state == ST_ACCEPTED && nd.attempt == 0) ? 0u : 1u;
+    unsigned long long pairs = 0;
+    uint32_t n_fix = 0;
+    for (uint32_t side = 0; side < 2; side++) {
+        uint32_t link = 0xFFFFFFFFu;
+        if (sp[side]) {
+            FNode cn{};
+            cn.key = ah_node_key_child(nd.key, side);
+            cn.start = side ? nd.start + nd.n_left : nd.start;
+            cn.tree = nd.tree;
+            cn.count = cnt[side];
+            cn.tile_begin = tidx;
+            cn.n_tiles = nt[side];
+            cn.fix = fix;
+            next[idx] = cn;
+            if (!fix) link = idx;
+            atomicMin(&tree_first[nd.tree], idx);
+            pairs += cnt[side];
+            n_fix += fix;
+            idx++;
+            tidx += nt[side];
+        }
+        child[2 * (uint64_t)i + side] = link;
+    }
+    if (pairs) atomicAdd(&info->pairs, pairs);
+    if (n_fix) atomicAdd(&info->n_fix, n_fix);
+}
+// tile list of a level: one wave per node
+__global__ __launch_bounds__(256) void k_build_tiles(const FNode *__restrict__ nodes, uint32_t n_nodes,
+                                                     FTile *__restrict__ tiles) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = gridDim.x * 4;
+    for (uint32_t node = blockIdx.x * 4 + (threadIdx.x >> 6); node < n_nodes; node += n_waves) {
+        const uint32_t begin = nodes[node].tile_begin, nt = nodes[node].n_tiles;
+        for (uint32_t t = lane; t < nt; t += 64) tiles[begin + t] = FTile{node, t * kTile};
+    }
+}
+
 }  // namespace ah
 
 using namespace ah;
@@ -599,31 +1092,61 @@ struct DevBuf {
     }
 };
 
-struct LevelChunk {  // the normal records of one level stay in HBM until the end of the batch
-    uint8_t *d = nullptr;
-    uint64_t bytes = 0;
-    uint64_t host_off = 0;
-};
-
-struct EventPair {
-    hipEvent_t a, b;
+// Device memory for the normal records of all levels of a batch: a few big blocks handed out level by level (a level's
+// records are contiguous), so that a level costs no hipMalloc.  Everything is freed when the batch ends.
+struct Arena {
+    std::vector<void *> blocks;
+    uint8_t *cur = nullptr;
+    size_t left = 0, block_bytes = 0;
+    int take(size_t bytes, uint8_t **out) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes > left) {
+            size_t got = std::max(bytes, block_bytes);
+            void *p = nullptr;
+            hipError_t e = hipMalloc(&p, got);
+            if (e != hipSuccess && got > bytes) {  // tight on memory: exactly this level
+                (void)hipGetLastError();
+                got = bytes;
+                e = hipMalloc(&p, got);
+            }
+            if (e != hipSuccess) {
+                set_error("hipMalloc of %zu bytes of normals failed: %s", bytes, hipGetErrorString(e));
+                return e == hipErrorOutOfMemory ? AH_ERR_OUT_OF_MEMORY : AH_ERR_DEVICE;
+            }
+            blocks.push_back(p);
+            cur = reinterpret_cast<uint8_t *>(p);
+            left = got;
+        }
+        *out = cur;
+        cur += bytes;
+        left -= bytes;
+        return AH_OK;
+    }
+    ~Arena() {
+        for (void *p : blocks) (void)hipFree(p);
+    }
 };
 
 // AH_DEBUG=1: synchronise after every launch and say which kernel finished (debugging aid only)
 bool g_debug = getenv("AH_DEBUG") != nullptr;
-// AH_ROWMAJOR=0 disables the row-major margin pass, =1 forces it whenever it is legal (A/B measurements);
-// AH_ROWMAJOR_CACHE_MB = budget for one group's normals (default 6.5 MB: per-level traces of the 10M x 768 build show
-// the per-margin cost of a pass rising from 0.10-0.16 ns below it to 0.27-0.5 ns at 12.6 MB, see build_batch).
+// Measurement aids (the per-call knob is ah_build_options.margin_mode; these only steer AH_MARGIN_AUTO):
+// AH_ROWMAJOR=0 disables the row-major margin pass, =1 forces it whenever it is legal;
+// AH_ROWMAJOR_CACHE_MB = budget for one group's normals of a level, AH_ROWMAJOR_MAX_TC = largest tree group.
 int g_rows_force = getenv("AH_ROWMAJOR") ? atoi(getenv("AH_ROWMAJOR")) : -1;
-// grid caps of the two margin kernels (grid-stride beyond them).  One tile / 32 rows per block measured 2 % faster
-// than a 4096-block persistent grid on the 10M x 768 build (3.55 vs 3.63 s of device time).
+// grid caps of the margin kernels (grid-stride beyond them).  One tile / 32 rows per block measured 2 % faster
+// than a 4096-block persistent grid on the 10M x 768 build.
 uint32_t g_tile_blocks = getenv("AH_FOREST_TILE_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_TILE_BLOCKS")) : (1u << 20);
 uint32_t g_row_blocks = getenv("AH_FOREST_ROW_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_ROW_BLOCKS")) : (1u << 20);
 bool g_rows_advance = !(getenv("AH_ROWMAJOR_ADVANCE") && atoi(getenv("AH_ROWMAJOR_ADVANCE")) == 0);  // A/B switch
 bool g_rows_lds = !(getenv("AH_ROWMAJOR_LDS") && atoi(getenv("AH_ROWMAJOR_LDS")) == 0);              // A/B switch
 constexpr size_t kLdsNormalsBytes = 128u << 10;  // LDS given to the normals of one tree group (of 160 KiB per CU)
 uint32_t g_rows_max_tc = getenv("AH_ROWMAJOR_MAX_TC") ? (uint32_t)atoi(getenv("AH_ROWMAJOR_MAX_TC")) : 16u;
-uint64_t g_rows_cache_bytes = (uint64_t)((getenv("AH_ROWMAJOR_CACHE_MB") ? atof(getenv("AH_ROWMAJOR_CACHE_MB")) : 6.5) * 1e6);
+double g_rows_cache_mb = getenv("AH_ROWMAJOR_CACHE_MB") ? atof(getenv("AH_ROWMAJOR_CACHE_MB")) : -1.0;
+// AH_SCREEN=0: never use the certified binary16 screen (as AH_MARGIN_EXACT_ONLY on every call);
+// AH_SCREEN_VERIFY=1: the screened kernels evaluate the reference arithmetic for EVERY pair as well and count the pairs
+// whose screened side differs (ah_build_stats.screen_violations; must be 0) — a test of the bound, not a product mode.
+bool g_screen = !(getenv("AH_SCREEN") && atoi(getenv("AH_SCREEN")) == 0);
+bool g_screen_verify = getenv("AH_SCREEN_VERIFY") && atoi(getenv("AH_SCREEN_VERIFY")) != 0;
 #define AH_DBG(s, what)                                                       \
     do {                                                                      \
         if (g_debug) {                                                        \
@@ -633,27 +1156,87 @@ uint64_t g_rows_cache_bytes = (uint64_t)((getenv("AH_ROWMAJOR_CACHE_MB") ? atof(
         }                                                                     \
     } while (0)
 
-struct BatchCleanup {
-    std::vector<LevelChunk> chunks;
-    std::vector<EventPair> events;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+struct BatchCleanup {  // events / side stream of one batch
+    hipEvent_t ev_attempt[8] = {};  // begin / end of the margin pass of attempts 0..3, re-used by every level
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_level = nullptr, ev_copy[2] = {nullptr, nullptr};
+    hipStream_t side = nullptr;
+    int create() {
+        for (hipEvent_t &e : ev_attempt) AH_HIP(hipEventCreate(&e));
+        AH_HIP(hipEventCreate(&ev_begin));
+        AH_HIP(hipEventCreate(&ev_end));
+        AH_HIP(hipEventCreateWithFlags(&ev_level, hipEventDisableTiming));
+        AH_HIP(hipEventCreateWithFlags(&ev_copy[0], hipEventDisableTiming));
+        AH_HIP(hipEventCreateWithFlags(&ev_copy[1], hipEventDisableTiming));
+        AH_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        return AH_OK;
+    }
     ~BatchCleanup() {
-        for (LevelChunk &c : chunks)
-            if (c.d) (void)hipFree(c.d);
-        for (EventPair &e : events) {
-            (void)hipEventDestroy(e.a);
-            (void)hipEventDestroy(e.b);
-        }
-        if (ev_begin) (void)hipEventDestroy(ev_begin);
-        if (ev_end) (void)hipEventDestroy(ev_end);
+        if (side) (void)hipStreamSynchronize(side);
+        for (hipEvent_t e : ev_attempt)
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ev_begin, ev_end, ev_level, ev_copy[0], ev_copy[1]})
+            if (e) (void)hipEventDestroy(e);
+        if (side) (void)hipStreamDestroy(side);
     }
 };
 
+// Measured cost of one row-major pass in ns per row of 3072 bytes, as a function of the tree-group size and of the
+// bytes of normals the group streams in the level (profiles/r02_baseline: 10M x 768 x 100 trees, every level forced to
+// one group size).  While the normals fit the L2s a pass is bound by the vector-memory pipeline (one 16-byte load per 4
+// FMAs: 1.6 ns per row for 16 trees); beyond ~11 MB they come through the fabric and every group size converges to
+// (1 + tc) rows' worth of traffic at ~8 TB/s.  Linear interpolation between the measured points.
+double rows_pass_ns_per_row(uint32_t tc, double ws_mb) {
+    struct Pt { double mb, ns; };
+    static const Pt t16[] = {{0.4, 1.60}, {3.2, 1.83}, {6.3, 2.05}, {12.6, 2.33}, {25, 5.08}, {50, 6.05}, {100, 6.5}, {400, 6.8}};
+    static const Pt t8[] = {{0.2, 1.16}, {1.6, 1.22}, {3.2, 2.0}, {6.3, 2.5}, {12.6, 3.1}, {25, 3.5}, {100, 3.7}};
+    static const Pt t4[] = {{0.1, 0.73}, {0.8, 0.85}, {3.2, 0.88}, {6.3, 1.07}, {12.6, 1.45}, {25, 1.85}, {50, 2.05}, {100, 2.14}};
+    static const Pt t2[] = {{0.05, 0.49}, {0.8, 0.60}, {3.1, 0.62}, {6.3, 0.74}, {12.6, 0.99}, {25, 1.14}, {50, 1.21}};
+    const Pt *t = tc >= 16 ? t16 : tc == 8 ? t8 : tc == 4 ? t4 : t2;
+    const size_t n = tc >= 16 ? sizeof t16 / sizeof(Pt) : tc == 8 ? sizeof t8 / sizeof(Pt) : tc == 4 ? sizeof t4 / sizeof(Pt)
+                                                                                                    : sizeof t2 / sizeof(Pt);
+    if (ws_mb <= t[0].mb) return t[0].ns;
+    for (size_t i = 1; i < n; i++)
+        if (ws_mb <= t[i].mb) return t[i - 1].ns + (t[i].ns - t[i - 1].ns) * (ws_mb - t[i - 1].mb) / (t[i].mb - t[i - 1].mb);
+    return t[n - 1].ns;
+}
+
+// index into ah_build_stats.margin_mode_launches
+enum { MM_NODE = 0, MM_ROWS2 = 1, MM_ROWS4 = 2, MM_ROWS8 = 3, MM_ROWS16 = 4, MM_LDS8 = 5, MM_LDS16 = 6, MM_BQ = 7 };
+inline int mm_rows(uint32_t tc) { return tc >= 16 ? MM_ROWS16 : tc == 8 ? MM_ROWS8 : tc == 4 ? MM_ROWS4 : MM_ROWS2; }
+
 }  // namespace
 
-// `subset_ids` == nullptr: every tree covers all items (Writer::build with missing trees).  Otherwise tree t covers
-// the ascending id list subset_ids[subset_offsets[first_tree + t] .. subset_offsets[first_tree + t + 1]) — the
-// "descendants that became too large" of an incremental build (src/writer.rs:660-739).
+// Binary16 shadow of an f32 dataset (screen_device.h), built by the first forest build that wants it.  Returns false
+// (and remembers it) when the memory is not available: the build then runs in the reference arithmetic only.
+static bool ensure_screen(ah_dataset *ds, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(ds->mu);
+    if (ds->d_rows_h16) return true;
+    if (ds->screen_tried || metric_is_bq(ds->metric) || ds->dims < 32 || ds->n == 0) return false;
+    ds->screen_tried = true;
+    const uint32_t hpitch = (ds->dims + 63u) & ~63u;
+    uint16_t *rows = nullptr;
+    float4 *stats = nullptr;
+    if (hipMalloc((void **)&rows, ds->n * (size_t)hpitch * 2) != hipSuccess ||
+        hipMalloc((void **)&stats, ds->n * sizeof(float4)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (rows) (void)hipFree(rows);
+        return false;
+    }
+    const DataView dv = ds->view();
+    const unsigned grid = (unsigned)std::min<uint64_t>((ds->n + 31) / 32, 1u << 20);
+    hipLaunchKernelGGL(k_shadow_rows, dim3(grid), dim3(kBlock), 0, s, dv, rows, hpitch, stats);
+    if (hipStreamSynchronize(s) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(rows);
+        (void)hipFree(stats);
+        return false;
+    }
+    ds->d_rows_h16 = rows;
+    ds->d_screen_stats = stats;
+    ds->hpitch = hpitch;
+    return true;
+}
+
 // Device -> pageable host copies off the build's critical path.  hipMemcpy into pageable memory is staged by the
 // runtime on one thread and pays the first-touch page faults of the fresh destination there (measured: 4 GB of item
 // ids in 0.60 s = 6.7 GB/s, whatever the number of concurrent calls).  Instead a worker thread owns a pinned double
@@ -779,6 +1362,13 @@ struct Readback {
     }
 };
 
+// `subset_ids` == nullptr: every tree covers all items (Writer::build with missing trees).  Otherwise tree t covers
+// the ascending id list subset_ids[subset_offsets[first_tree + t] .. subset_offsets[first_tree + t + 1]) — the
+// "descendants that became too large" of an incremental build (src/writer.rs:660-739).
+//
+// One level = one set of launches, and ONE host wait: the host needs the next level's sizes (LevelInfo, read back
+// through pinned memory) before it can launch it; everything else about a level — its node table, from which the final
+// node list is assembled — follows on a side stream and is digested by the host while the GPU runs the next level.
 static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t first_tree, uint32_t n_trees,
                        uint32_t split_after, ah_forest *forest, Context *ctx, const uint32_t *subset_ids,
                        const uint64_t *subset_offsets) {
@@ -793,42 +1383,77 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     const bool bq = metric_is_bq(ds->metric);
     const uint64_t hdr_off = ds->row_bytes();
     const uint64_t nstride = hdr_off + 16;
+    // AH_MARGIN_MODE (measurement aid): the kernel family for callers that leave the choice to the library
+    static const uint32_t env_mode = getenv("AH_MARGIN_MODE") ? (uint32_t)strtoul(getenv("AH_MARGIN_MODE"), nullptr, 0) & 0xFFFu : 0u;
+    const uint32_t mode_req = (opt->margin_mode & 0xFFFu) ? (opt->margin_mode & 0xFFFu) : env_mode;
+    const bool exact_only = (opt->margin_mode & AH_MARGIN_EXACT_ONLY) != 0 || !g_screen;
 
     // Upper bounds known up front (every split node owns > split_after items), so nothing is reallocated
     // between levels: nodes per level <= n_trees * N / (split_after + 1), tiles <= items / kTile + nodes.
     const uint64_t max_nodes = M / ((uint64_t)split_after + 1) + n_trees;
     const uint64_t max_tiles = M / kTile + n_trees + max_nodes;
-    DevBuf<uint32_t> perm_a, perm_b, final_perm, tile_left, tile_left_off;
-    DevBuf<FNode> d_nodes;
+    DevBuf<uint32_t> perm_a, perm_b, final_perm, tile_left, tile_left_off, d_child, d_small;
+    DevBuf<FNode> d_nodes_a, d_nodes_b;
     DevBuf<FTile> d_tiles;
     DevBuf<uint64_t> masks;
+    DevBuf<NextCounts> d_block_sums;
     AH_TRY(perm_a.ensure(M));
     AH_TRY(perm_b.ensure(M));
     AH_TRY(final_perm.ensure(M));
-    AH_TRY(d_nodes.ensure(max_nodes));
+    AH_TRY(d_nodes_a.ensure(max_nodes));
+    AH_TRY(d_nodes_b.ensure(max_nodes));
     AH_TRY(d_tiles.ensure(max_tiles));
     AH_TRY(masks.ensure(max_tiles * 32));
     AH_TRY(tile_left.ensure(max_tiles));
     AH_TRY(tile_left_off.ensure(max_tiles));
+    AH_TRY(d_child.ensure(2 * max_nodes));
+    AH_TRY(d_block_sums.ensure(max_nodes / 256 + 2));
+    // small device block: [abort flag, 3 pad][ScreenCounters][LevelInfo + tree_first[n_trees + 1]]
+    const size_t info_words = (sizeof(LevelInfo) + ((size_t)n_trees + 1) * 4 + 3) / 4;
+    AH_TRY(d_small.ensure(4 + 4 + info_words));
+    uint32_t *d_abort = d_small.p;
+    ScreenCounters *d_counters = reinterpret_cast<ScreenCounters *>(d_small.p + 4);
+    LevelInfo *d_info = reinterpret_cast<LevelInfo *>(d_small.p + 8);
+    uint32_t *d_tree_first = reinterpret_cast<uint32_t *>(d_info + 1);
+    AH_HIP(hipMemsetAsync(d_small.p, 0, (8 + info_words) * 4, s));
+
+    // pinned host memory: [2 x LevelInfo block][one word for the abort flag][2 x node table][read-back bounce]
     const size_t kBounce = 64ull << 20;  // pinned double buffer of the read-back worker
-    const size_t pin_tables = (max_nodes * sizeof(FNode) + max_tiles * sizeof(FTile) + 4096 + 4095) & ~(size_t)4095;
-    AH_TRY(ctx->ensure_pinned(pin_tables + kBounce));
+    const size_t pin_info = (info_words * 4 + 255) & ~(size_t)255;
+    const size_t pin_nodes = (max_nodes * sizeof(FNode) + 4095) & ~(size_t)4095;
+    const size_t pin_head = (2 * pin_info + 256 + 4095) & ~(size_t)4095;
+    AH_TRY(ctx->ensure_pinned(pin_head + 2 * pin_nodes + kBounce));
+    uint8_t *pin = reinterpret_cast<uint8_t *>(ctx->h_pinned);
+    LevelInfo *h_info[2] = {reinterpret_cast<LevelInfo *>(pin), reinterpret_cast<LevelInfo *>(pin + pin_info)};
+    uint32_t *h_one = reinterpret_cast<uint32_t *>(pin + 2 * pin_info);
+    *h_one = 1u;
+    FNode *h_nodes[2] = {reinterpret_cast<FNode *>(pin + pin_head), reinterpret_cast<FNode *>(pin + pin_head + pin_nodes)};
+
     // row-major margin mode (full-dataset trees, f32 metrics): node index and side byte per (tree, row)
-    const bool rows_allowed = !subset_ids && !bq && ds->dims >= 32 && n_trees >= 2 && g_rows_force != 0;
-    DevBuf<uint32_t> node_of, d_child;
-    DevBuf<FTile> d_fix_tiles;
+    const bool rows_allowed = !subset_ids && !bq && ds->dims >= 32 && n_trees >= 2 &&
+                              (mode_req != AH_MARGIN_AUTO ? mode_req != AH_MARGIN_NODE_MAJOR : g_rows_force != 0);
+    DevBuf<uint32_t> node_of;
     DevBuf<uint8_t> side_bytes;
     if (rows_allowed) {
         AH_TRY(node_of.ensure((size_t)n_trees * N + 4));
         AH_TRY(side_bytes.ensure((size_t)n_trees * N + 4));
-        AH_TRY(d_child.ensure(2 * max_nodes));
     }
-    // state carried from one level to the next for k_forest_advance_node_of
-    bool prev_rows = false;            // the previous level ran row-major: node_of / side_bytes describe it
-    std::vector<uint32_t> h_child;     // per node of the previous level: index of its two children in this level
-    std::vector<uint32_t> fix_nodes;   // nodes of this level whose parent's sides were re-drawn (retry / random)
-    FNode *h_nodes = reinterpret_cast<FNode *>(ctx->h_pinned);
-    FTile *h_tiles = reinterpret_cast<FTile *>(h_nodes + max_nodes);
+    // certified binary16 screen: f32 metrics with AVX-tier rows, unless the caller (or AH_SCREEN=0) asks for f32 only
+    const bool screen = !exact_only && !bq && ds->dims >= 32 && ensure_screen(ds, s);
+    ScreenView sv{};
+    uint64_t hstride = 0;
+    if (screen) {
+        sv.rows = ds->d_rows_h16;
+        sv.stats = ds->d_screen_stats;
+        sv.hpitch = ds->hpitch;
+        // accumulation-error factors (screen_device.h), each with a 4x safety factor over the standard model:
+        //   screen: hpitch/16 dot2c per lane (2 roundings each) + 4 adds;  reference: dims/32 FMAs per chain, 6 adds of
+        //   the hsum tree, and a scalar tail of up to 31 multiply-adds (2 roundings each)
+        sv.gamma_s = (float)(4.0 * (2.0 * (ds->hpitch / 16) + 8.0) * 5.9604645e-8);
+        sv.gamma_r = (float)(4.0 * ((double)(ds->dims / 32) + 6.0 + 62.0) * 5.9604645e-8);
+        hstride = (uint64_t)ds->hpitch * 2 + 16;
+    }
+    const uint32_t verify = screen && g_screen_verify ? 1u : 0u;
     if (!subset_ids) {
         hipLaunchKernelGGL(k_init_perm, dim3(2048), dim3(256), 0, s, perm_a.p, N, n_trees);
     } else if (M) {
@@ -877,40 +1502,56 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         ~Toucher() { join(); }
     } prefault, prefault_normals;
     prefault.start(forest->descendants + desc_base, M * 4);
+    Arena arena, shadow_arena;  // declared before the read-back worker: it is joined before the chunks it reads are freed
+    arena.block_bytes = std::max<uint64_t>(32ull << 20, std::min<uint64_t>(2 * max_nodes * nstride, 16ull << 30));
+    shadow_arena.block_bytes = std::max<uint64_t>(16ull << 20, std::min<uint64_t>(max_nodes * std::max<uint64_t>(hstride, 16), 8ull << 30));
     BatchCleanup bc;
-    Readback rb;  // declared after `bc`: joined before the level chunks it reads are freed
-    rb.start(ds->device, reinterpret_cast<uint8_t *>(ctx->h_pinned) + pin_tables, kBounce);
+    AH_TRY(bc.create());
+    Readback rb;
+    rb.start(ds->device, pin + pin_head + 2 * pin_nodes, kBounce);
+
+    // ---- level 0 on the host: the roots -----------------------------------------------------------------------------
     std::vector<HostRec> recs;
-    std::vector<FNode> level;  // active (to be split) nodes of the current level
     std::vector<uint32_t> tree_root(n_trees);
+    std::vector<uint32_t> level_rec, next_rec;  // HostRec index of every node of the level being digested / of the next
     recs.reserve(4 * max_nodes / 3 + 16);
-    for (uint32_t t = 0; t < n_trees; t++) {
-        const uint32_t cnt = (uint32_t)(tree_base[t + 1] - tree_base[t]);
-        HostRec r{};
-        r.tree = t;
-        r.start = tree_base[t];
-        r.count = cnt;
-        r.depth = 0;
-        tree_root[t] = (uint32_t)recs.size();
-        if (cnt <= split_after) {  // fit_in_descendant at the root: the tree is one Descendants node
-            r.kind = AH_NODE_DESCENDANTS;
+    LevelInfo info{};
+    std::vector<uint32_t> tree_first(n_trees + 1, 0xFFFFFFFFu);
+    {
+        FNode *lv = h_nodes[0];
+        for (uint32_t t = 0; t < n_trees; t++) {
+            const uint32_t cnt = (uint32_t)(tree_base[t + 1] - tree_base[t]);
+            HostRec r{};
+            r.tree = t;
+            r.start = tree_base[t];
+            r.count = cnt;
+            r.depth = 0;
+            tree_root[t] = (uint32_t)recs.size();
+            if (cnt <= split_after) {  // fit_in_descendant at the root: the tree is one Descendants node
+                r.kind = AH_NODE_DESCENDANTS;
+                recs.push_back(r);
+                continue;
+            }
+            r.kind = AH_NODE_SPLIT;
+            FNode nd{};
+            nd.key = ah_node_key_root(opt->tree_seeds[first_tree + t]);
+            nd.start = tree_base[t];
+            nd.tree = t;
+            nd.count = cnt;
+            nd.tile_begin = info.n_tiles;
+            nd.n_tiles = (cnt + kTile - 1) / kTile;
+            tree_first[t] = info.n_nodes;
+            level_rec.push_back((uint32_t)recs.size());
             recs.push_back(r);
-            continue;
+            lv[info.n_nodes++] = nd;
+            info.n_tiles += nd.n_tiles;
+            info.pairs += cnt;
         }
-        r.kind = AH_NODE_SPLIT;
-        FNode nd{};
-        nd.key = ah_node_key_root(opt->tree_seeds[first_tree + t]);
-        nd.start = tree_base[t];
-        nd.tree = t;
-        nd.count = cnt;
-        nd.rec = (uint32_t)recs.size();
-        recs.push_back(r);
-        level.push_back(nd);
+        if (info.n_nodes) AH_HIP(hipMemcpyAsync(d_nodes_a.p, lv, info.n_nodes * sizeof(FNode), hipMemcpyHostToDevice, s));
     }
 
     uint32_t *cur = perm_a.p, *nxt = perm_b.p;
-    AH_HIP(hipEventCreate(&bc.ev_begin));
-    AH_HIP(hipEventCreate(&bc.ev_end));
+    FNode *d_cur = d_nodes_a.p, *d_next = d_nodes_b.p;
     AH_HIP(hipEventRecord(bc.ev_begin, s));
     const size_t cs_shared = (size_t)f32_space_pitch(ds->metric, ds->dims) * 4 * 3;
     AH_REQUIRE(cs_shared <= 150 * 1024, AH_ERR_INVALID_DIMENSION, "dimensions %u too large for the LDS-resident two-means",
@@ -937,149 +1578,214 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         normals_cap = want;
         return AH_OK;
     };
-    uint32_t depth = 0;
+
+    // Digest the node table of a finished level (it arrived on the side stream): split records, children, statistics,
+    // and which HostRec every node of the next level belongs to — the same walk the device did in k_next_emit.
     uint64_t items_routed = 0;
-    while (!level.empty()) {
+    auto digest_level = [&](uint32_t depth, uint32_t n_nodes, const FNode *tbl, uint64_t chunk_host_off) -> int {
+        next_rec.clear();
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            const FNode nd = tbl[i];
+            AH_REQUIRE(nd.state != ST_PENDING && nd.n_left <= nd.count, AH_ERR_DEVICE,
+                       "forest build: node %u of level %u left pending (internal error)", i, depth);
+            forest->stats.margin_evaluations += (uint64_t)(nd.attempt + 1) * nd.count;
+            forest->stats.retries += nd.attempt;
+            items_routed += nd.count;
+            const uint32_t rec_idx = level_rec[i];
+            recs[rec_idx].has_normal = nd.state == ST_ACCEPTED;
+            recs[rec_idx].normal_off = chunk_host_off + (uint64_t)i * nstride;
+            if (nd.state != ST_ACCEPTED) forest->stats.dummy_normals++;
+            const uint32_t child_cnt[2] = {nd.n_left, nd.count - nd.n_left};
+            const uint64_t child_start[2] = {nd.start, nd.start + nd.n_left};
+            for (uint32_t side = 0; side < 2; side++) {
+                HostRec c{};
+                c.tree = nd.tree;
+                c.start = child_start[side];
+                c.count = child_cnt[side];
+                c.depth = depth + 1;
+                const uint32_t cidx = (uint32_t)recs.size();
+                if (c.count <= split_after) {
+                    c.kind = AH_NODE_DESCENDANTS;
+                } else {
+                    c.kind = AH_NODE_SPLIT;
+                    next_rec.push_back(cidx);
+                }
+                recs.push_back(c);
+                if (side == 0) recs[rec_idx].left = cidx;
+                else recs[rec_idx].right = cidx;
+            }
+        }
+        level_rec.swap(next_rec);
+        forest->stats.levels = std::max(forest->stats.levels, depth + 1);
+        if (opt->progress) opt->progress(opt->progress_user, depth + 1, recs.size(), items_routed);
+        return AH_OK;
+    };
+
+    // Wait for the level on the stream.  With a cancel flag the wait polls it: a cancelled build raises the device-side
+    // abort word (on the side stream), the margin kernels still queued or running drain without work, and the call
+    // returns AH_ERR_CANCELLED as soon as the stream is idle (src/writer.rs:1178,1196 poll per node / per item).
+    bool abort_sent = false;
+    auto wait_level = [&]() -> int {
+        if (!opt->cancel) {
+            AH_HIP(hipEventSynchronize(bc.ev_level));
+            return AH_OK;
+        }
+        for (uint32_t spins = 0;; spins++) {
+            const hipError_t e = hipEventQuery(bc.ev_level);
+            if (e == hipSuccess) break;
+            if (e != hipErrorNotReady) {
+                set_error("forest build: %s", hipGetErrorString(e));
+                return AH_ERR_DEVICE;
+            }
+            if (*opt->cancel && !abort_sent) {
+                AH_HIP(hipMemcpyAsync(d_abort, h_one, 4, hipMemcpyHostToDevice, bc.side));
+                abort_sent = true;
+            }
+            if (spins < 4096) std::this_thread::yield();
+            else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        if (abort_sent || *opt->cancel) {
+            set_error("build cancelled");
+            return AH_ERR_CANCELLED;
+        }
+        return AH_OK;
+    };
+
+    uint32_t depth = 0;
+    bool prev_rows = false;     // the previous level ran row-major: node_of / side_bytes describe it, d_child links it
+    uint32_t pending_digest = 0;  // 1 + depth of the level whose node table is still to be digested (0 = none)
+    uint32_t pending_nodes = 0;
+    uint64_t pending_host_off = 0;
+    int lvl_status = AH_OK;
+    while (info.n_nodes) {
         if (opt->cancel && *opt->cancel) {
             set_error("build cancelled");
-            return AH_ERR_CANCELLED;  // Error::BuildCancelled, polled per level (src/writer.rs:1178,1196)
+            return AH_ERR_CANCELLED;  // Error::BuildCancelled
         }
         AH_REQUIRE(depth < 100000, AH_ERR_DEVICE, "forest build: depth %u exceeded (internal error)", depth);
-        const uint32_t n_nodes = (uint32_t)level.size();
-        AH_REQUIRE(n_nodes <= max_nodes, AH_ERR_DEVICE, "forest build: node bound exceeded (internal error)");
-        uint32_t n_tiles = 0;
-        for (uint32_t i = 0; i < n_nodes; i++) {
-            FNode &nd = level[i];
-            nd.tile_begin = n_tiles;
-            nd.n_tiles = (nd.count + kTile - 1) / kTile;
-            AH_REQUIRE((uint64_t)n_tiles + nd.n_tiles <= max_tiles, AH_ERR_DEVICE, "forest build: tile bound exceeded");
-            for (uint32_t t = 0; t < nd.n_tiles; t++) h_tiles[n_tiles++] = FTile{i, t * kTile};
-            h_nodes[i] = nd;
-        }
-        LevelChunk chunk;
-        chunk.bytes = (uint64_t)n_nodes * nstride;
-        chunk.host_off = normals_base + normals_bytes;
-        AH_HIP(hipMalloc((void **)&chunk.d, chunk.bytes));
-        bc.chunks.push_back(chunk);
-        normals_bytes += chunk.bytes;
+        const uint32_t n_nodes = info.n_nodes, n_tiles = info.n_tiles;
+        AH_REQUIRE(n_nodes <= max_nodes && n_tiles <= max_tiles, AH_ERR_DEVICE, "forest build: node / tile bound exceeded");
+        hipLaunchKernelGGL(k_build_tiles, dim3(std::min<uint32_t>((n_nodes + 3) / 4, kMaxBlocks)), dim3(256), 0, s, d_cur,
+                           n_nodes, d_tiles.p);
+        uint8_t *chunk_d = nullptr, *shadow_d = nullptr;
+        const uint64_t chunk_bytes = (uint64_t)n_nodes * nstride;
+        const uint64_t chunk_host_off = normals_base + normals_bytes;
+        AH_TRY(arena.take(chunk_bytes, &chunk_d));
+        if (screen) AH_TRY(shadow_arena.take((uint64_t)n_nodes * hstride, &shadow_d));
+        normals_bytes += chunk_bytes;
         // host side of this level's normals: reserved now and page-touched while the level is computed
         prefault_normals.join();
-        AH_TRY(reserve_normals(chunk.host_off + chunk.bytes));
-        prefault_normals.start(forest->normals + chunk.host_off, chunk.bytes);
-        AH_HIP(hipMemcpyAsync(d_nodes.p, h_nodes, n_nodes * sizeof(FNode), hipMemcpyHostToDevice, s));
-        AH_HIP(hipMemcpyAsync(d_tiles.p, h_tiles, n_tiles * sizeof(FTile), hipMemcpyHostToDevice, s));
+        AH_TRY(reserve_normals(chunk_host_off + chunk_bytes));
+        prefault_normals.start(forest->normals + chunk_host_off, chunk_bytes);
         const unsigned tile_grid = std::min<uint32_t>(n_tiles, g_tile_blocks);
-        // Row-major or node-major for the first attempt of this level?  Row-major streams all N rows once per group of
-        // row_tc trees; node-major reads only the still-active items, once per tree.  The group is sized so that the
-        // level's normals of one group stay cache-resident.
-        uint32_t row_tc = 0;
-        if (rows_allowed) {
-            // Group size: the largest row_tc whose normals for this level (ws) fit the cache budget (6.5 MB: beyond it
-            // the normals spill from the XCD L2s to the Infinity Cache and every extra tree costs more than it saves).
-            // Row-major or not is then decided by a cost model in ns, fitted to per-level rocprofv3 traces of the
-            // 10M x 768 x 100-tree build and scaled by the row size:
-            //   node-major  0.47 per (item, tree) pair: one HBM read of the row at ~6.85 TB/s;
-            //   row-major   per pass and row: base(row_tc) = 0.60 / 0.87 / 1.18 / 1.55 for 2 / 4 / 8 / 16 trees (the HBM
-            //               read of the row + normals served by L1/L2) + row_tc x 0.018 per MB of ws beyond 2.7 MB,
-            //               scaled by the share of (row, tree) pairs that are still splitting; plus the node_of / mask
-            //               conversion of the level (0.01-0.05 per (row, tree); 0.007-0.02 when node_of is advanced in
-            //               row order from the previous row-major level).
-            uint64_t pairs = 0;
-            for (uint32_t i = 0; i < n_nodes; i++) pairs += level[i].count;
-            const double row_b = (double)ds->row_bytes();
-            const double active = (double)pairs / ((double)n_trees * (double)N);  // share of (row, tree) pairs still splitting
-            const uint64_t nodes_per_tree = (n_nodes + n_trees - 1) / n_trees;
+
+        // ---- margin mode of the first attempt ------------------------------------------------------------------------
+        // Row-major streams all N rows once per group of row_tc trees; node-major reads only the still-active items, once
+        // per tree.  A forced mode (ah_build_options.margin_mode) pins the kernel family wherever it is legal.
+        const uint64_t rec_bytes = screen ? hstride : nstride;  // bytes of one normal as the margin pass streams it
+        const uint64_t nodes_per_tree = (n_nodes + n_trees - 1) / n_trees;
+        uint32_t row_tc = 0, lds_tc = 0;
+        if (rows_allowed && mode_req == AH_MARGIN_AUTO) {
+            // Cost model in ns per row of 3072 bytes, fitted to per-level rocprofv3 traces of the 10M x 768 x 100-tree
+            // build (profiles/): node-major = one HBM read of the row per (item, tree) pair; row-major = per pass and
+            // row the HBM read of the row plus row_tc normals through the vector memory pipeline (L2 while the group's
+            // normals of the level fit, the fabric beyond), scaled by the share of (row, tree) pairs still splitting,
+            // plus the node_of / mask conversion of the level.
+            const double row_b = (double)(screen ? (uint64_t)ds->hpitch * 2 : ds->row_bytes());
+            const double active = (double)info.pairs / ((double)n_trees * (double)N);
             const double scale = row_b / 3072.0;
-            const double cost_node = (double)pairs * 0.47 * scale;
+            const double cost_node = (double)info.pairs * 0.47 * scale;
             const double convert = (double)n_trees * (double)N *
                                    ((prev_rows && g_rows_advance ? 0.007 : 0.01 + 0.03 * std::min(1.0, (double)nodes_per_tree / 256.0)) +
                                     0.012 * std::min(1.0, (double)nodes_per_tree / 512.0));
-            uint32_t tc = g_rows_max_tc;
-            while (tc > 1 && (uint64_t)tc * nodes_per_tree * nstride > g_rows_cache_bytes) tc >>= 1;
-            while (tc > 2 && tc / 2 >= n_trees) tc >>= 1;  // do not instantiate more slots than trees
-            // measured anomaly: the 8-tree instantiation is slower per margin than the 4-tree one as soon as its
-            // normals leave the L2 (0.25-0.31 vs 0.22-0.27 ns at 3.2-6.3 MB)
-            if (tc == 8 && (double)((uint64_t)tc * nodes_per_tree * nstride) > 2.7e6) tc = 4;
-            if (tc >= 2) {
+            double best = 0.95 * cost_node;
+            for (uint32_t tc = std::min(16u, g_rows_max_tc); tc >= 2; tc >>= 1) {
+                if (tc > 2 && tc / 2 >= n_trees) continue;  // do not instantiate more slots than trees
+                const double ws_mb = (double)((uint64_t)tc * nodes_per_tree * rec_bytes) / 1e6;
+                if (g_rows_cache_mb > 0 && ws_mb > g_rows_cache_mb) continue;
                 const double passes = (double)((n_trees + tc - 1) / tc);
-                const double base = tc >= 16 ? 1.55 : tc == 8 ? 1.18 : tc == 4 ? 0.87 : 0.60;
-                const double ws_mb = (double)((uint64_t)tc * nodes_per_tree * nstride) / 1e6;
-                const double per_row = 0.45 + ((base - 0.45) + tc * 0.018 * std::max(0.0, ws_mb - 2.7)) * std::min(1.0, active);
+                const double full = rows_pass_ns_per_row(tc, ws_mb);
+                const double per_row = 0.45 + (full - 0.45) * std::min(1.0, active * 1.05);
                 const double cost_rows = passes * (double)N * per_row * scale + convert;
-                if (g_rows_force == 1 || cost_rows < 0.95 * cost_node) row_tc = tc;
+                if (cost_rows < best || (g_rows_force == 1 && row_tc == 0)) {
+                    best = std::min(best, cost_rows);
+                    row_tc = tc;
+                }
             }
+        } else if (rows_allowed) {
+            row_tc = mode_req & 0xFFu;
         }
         // Top levels: all normals of a group of >= 8 trees fit in LDS -> the LDS-resident variant of the row-major pass.
-        uint32_t lds_tc = 0;
-        std::vector<uint32_t> tree_first;  // first node of every tree in this level (nodes are ordered by tree)
-        if (rows_allowed && g_rows_lds && row_tc >= 2 && (hdr_off & 15) == 0) {
-            tree_first.assign(n_trees + 1, n_nodes);
-            bool ordered = true;
-            for (uint32_t i = n_nodes; i-- > 0;) {
-                tree_first[level[i].tree] = i;
-                if (i + 1 < n_nodes && level[i].tree > level[i + 1].tree) ordered = false;
-            }
+        const bool want_lds = mode_req == AH_MARGIN_AUTO ? g_rows_lds && row_tc >= 2 : (mode_req & 0x100u) != 0;
+        if (rows_allowed && want_lds && (rec_bytes & 15) == 0) {
+            tree_first[n_trees] = n_nodes;  // trees without a node in this level start where the next tree starts
             for (uint32_t t = n_trees; t-- > 0;) tree_first[t] = std::min(tree_first[t], tree_first[t + 1]);
-            for (uint32_t tc = std::min<uint32_t>(16, g_rows_max_tc); ordered && tc >= 8; tc >>= 1) {
+            const uint32_t tc_hi = mode_req == AH_MARGIN_AUTO ? std::min<uint32_t>(16, g_rows_max_tc) : (mode_req & 0xFFu);
+            const uint32_t tc_lo = mode_req == AH_MARGIN_AUTO ? 8u : tc_hi;
+            for (uint32_t tc = tc_hi; tc >= tc_lo && tc >= 8; tc >>= 1) {
                 uint32_t worst = 0;
                 for (uint32_t t0 = 0; t0 < n_trees; t0 += tc)
                     worst = std::max(worst, tree_first[std::min(n_trees, t0 + tc)] - tree_first[t0]);
-                if ((uint64_t)worst * nstride <= kLdsNormalsBytes) {
+                if ((uint64_t)worst * rec_bytes <= kLdsNormalsBytes) {
                     lds_tc = tc;
                     break;
                 }
             }
             if (lds_tc) row_tc = lds_tc;
+            else if (mode_req != AH_MARGIN_AUTO) row_tc = 0;  // a forced LDS mode that does not fit: node-major
         }
+
         for (int attempt = 0; attempt < 4; attempt++) {
-            hipLaunchKernelGGL(k_forest_create_split, dim3(n_nodes), dim3(64), cs_shared, s, dv, d_nodes.p, cur, N,
-                               chunk.d, nstride, hdr_off);
+            hipLaunchKernelGGL(k_forest_create_split, dim3(n_nodes), dim3(64), cs_shared, s, dv, d_cur, cur, N, chunk_d,
+                               nstride, hdr_off);
             AH_DBG(s, "create_split");
-            EventPair ep;
-            AH_HIP(hipEventCreate(&ep.a));
-            AH_HIP(hipEventCreate(&ep.b));
-            bc.events.push_back(ep);
-            AH_HIP(hipEventRecord(ep.a, s));
+            if (screen)
+                hipLaunchKernelGGL(k_forest_shadow_normals, dim3(n_nodes), dim3(64), 0, s, dv, d_cur, chunk_d, nstride, hdr_off,
+                                   shadow_d, hstride, sv.hpitch);
+            AH_HIP(hipEventRecord(bc.ev_attempt[2 * attempt], s));
             if (attempt == 0 && row_tc >= 2) {
                 // one pass over the rows serves up to row_tc trees (see k_forest_margin_rows)
                 if (prev_rows && g_rows_advance) {
-                    AH_HIP(hipMemcpyAsync(d_child.p, h_child.data(), h_child.size() * 4, hipMemcpyHostToDevice, s));
                     hipLaunchKernelGGL(k_forest_advance_node_of, dim3(kMaxBlocks), dim3(kBlock), 0, s, node_of.p, side_bytes.p,
                                        d_child.p, (uint64_t)n_trees * N);
-                    if (!fix_nodes.empty()) {
-                        std::vector<FTile> fix;
-                        for (uint32_t i : fix_nodes)
-                            for (uint32_t t = 0; t < level[i].n_tiles; t++) fix.push_back(FTile{i, t * kTile});
-                        AH_TRY(d_fix_tiles.ensure(fix.size()));
-                        AH_HIP(hipMemcpyAsync(d_fix_tiles.p, fix.data(), fix.size() * sizeof(FTile), hipMemcpyHostToDevice, s));
-                        hipLaunchKernelGGL(k_forest_assign_node_of, dim3(std::min<uint32_t>((uint32_t)fix.size(), kMaxBlocks)),
-                                           dim3(kBlock), 0, s, d_nodes.p, d_fix_tiles.p, (uint32_t)fix.size(), cur, N, node_of.p);
-                        AH_HIP(hipStreamSynchronize(s));  // `fix` is a pageable staging vector
-                    }
+                    if (info.n_fix)
+                        hipLaunchKernelGGL(k_forest_assign_node_of, dim3(std::min<uint32_t>(n_tiles, kMaxBlocks)), dim3(kBlock), 0,
+                                           s, d_cur, d_tiles.p, n_tiles, cur, N, node_of.p, 1u);
                 } else {
                     AH_HIP(hipMemsetAsync(node_of.p, 0xFF, (size_t)n_trees * N * 4, s));
-                    hipLaunchKernelGGL(k_forest_assign_node_of, dim3(tile_grid), dim3(kBlock), 0, s, d_nodes.p, d_tiles.p,
-                                       n_tiles, cur, N, node_of.p);
+                    hipLaunchKernelGGL(k_forest_assign_node_of, dim3(tile_grid), dim3(kBlock), 0, s, d_cur, d_tiles.p, n_tiles,
+                                       cur, N, node_of.p, 0u);
                 }
                 const unsigned row_grid = (unsigned)std::min<uint64_t>((N + 31) / 32, g_row_blocks);
                 for (uint32_t t0 = 0; t0 < n_trees && lds_tc; t0 += lds_tc) {
                     const uint32_t np = std::min<uint32_t>(lds_tc, n_trees - t0);
                     const uint32_t first = tree_first[t0], cnt = tree_first[t0 + np] - first;
                     if (cnt == 0) continue;
-                    const size_t sh = (size_t)cnt * nstride;
+                    const size_t sh = (size_t)cnt * rec_bytes;
                     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(2, (150u << 10) / std::max<size_t>(sh, 1)));
                     const unsigned lthreads = lds_tc >= 16 ? 512u : 1024u;
                     const unsigned lgrid = (unsigned)std::min<uint64_t>((N * 8 + lthreads - 1) / lthreads, 256u * per_cu);
-#define AH_ROWS_LDS(M, TCV)                                                                                             \
-    do {                                                                                                                \
-        static std::atomic<bool> lds_opt_in[64]; /* once per instantiation and device: the call waits for the stream */ \
-        if (!lds_opt_in[ds->device & 63].load(std::memory_order_acquire)) {                                                                             \
-            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_margin_rows_lds<M, TCV>),                \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsNormalsBytes));             \
-            lds_opt_in[ds->device & 63].store(true, std::memory_order_release);                                         \
-        }                                                                                                               \
-        hipLaunchKernelGGL((k_forest_margin_rows_lds<M, TCV>), dim3(lgrid), dim3(lthreads), sh, s, dv, node_of.p, t0, np, \
-                           chunk.d, nstride, hdr_off, side_bytes.p, first, cnt);                                        \
+#define AH_LDS_OPT_IN(KERNEL)                                                                                          \
+    do {                                                                                                               \
+        static std::atomic<bool> lds_opt_in[64]; /* once per instantiation and device */                               \
+        if (!lds_opt_in[ds->device & 63].load(std::memory_order_acquire)) {                                            \
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)kLdsNormalsBytes));                                                        \
+            lds_opt_in[ds->device & 63].store(true, std::memory_order_release);                                        \
+        }                                                                                                              \
+    } while (0)
+#define AH_ROWS_LDS(M, TCV)                                                                                              \
+    do {                                                                                                                 \
+        if (screen) {                                                                                                    \
+            AH_LDS_OPT_IN((k_forest_screen_rows<M, TCV, true>));                                                         \
+            hipLaunchKernelGGL((k_forest_screen_rows<M, TCV, true>), dim3(lgrid), dim3(lthreads), sh, s, dv, sv, node_of.p, \
+                               t0, np, chunk_d, nstride, hdr_off, shadow_d, hstride, side_bytes.p, first, cnt, d_abort,  \
+                               d_counters, verify);                                                                      \
+        } else {                                                                                                         \
+            AH_LDS_OPT_IN((k_forest_margin_rows_lds<M, TCV>));                                                           \
+            hipLaunchKernelGGL((k_forest_margin_rows_lds<M, TCV>), dim3(lgrid), dim3(lthreads), sh, s, dv, node_of.p, t0, \
+                               np, chunk_d, nstride, hdr_off, side_bytes.p, first, cnt, d_abort);                        \
+        }                                                                                                                \
     } while (0)
 #define AH_ROWS_LDS_TC(M)                  \
     if (lds_tc == 16) AH_ROWS_LDS(M, 16);  \
@@ -1092,12 +1798,20 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     }
 #undef AH_ROWS_LDS_TC
 #undef AH_ROWS_LDS
+                    forest->stats.margin_mode_launches[lds_tc == 16 ? MM_LDS16 : MM_LDS8]++;
                 }
                 for (uint32_t t0 = 0; t0 < n_trees && !lds_tc; t0 += row_tc) {
                     const uint32_t np = std::min<uint32_t>(row_tc, n_trees - t0);
-#define AH_ROWS(M, TCV)                                                                                          \
-    hipLaunchKernelGGL((k_forest_margin_rows<M, TCV>), dim3(row_grid), dim3(kBlock), 0, s, dv, node_of.p, t0, np, \
-                       chunk.d, nstride, hdr_off, side_bytes.p)
+#define AH_ROWS(M, TCV)                                                                                                    \
+    do {                                                                                                                   \
+        if (screen)                                                                                                        \
+            hipLaunchKernelGGL((k_forest_screen_rows<M, TCV, false>), dim3(row_grid), dim3(kBlock), 0, s, dv, sv, node_of.p, \
+                               t0, np, chunk_d, nstride, hdr_off, shadow_d, hstride, side_bytes.p, 0u, 0u, d_abort,        \
+                               d_counters, verify);                                                                        \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_forest_margin_rows<M, TCV>), dim3(row_grid), dim3(kBlock), 0, s, dv, node_of.p, t0, np,  \
+                               chunk_d, nstride, hdr_off, side_bytes.p, d_abort);                                          \
+    } while (0)
 #define AH_ROWS_TC(M)                       \
     switch (row_tc) {                       \
     case 16: AH_ROWS(M, 16); break;         \
@@ -1113,18 +1827,21 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     }
 #undef AH_ROWS_TC
 #undef AH_ROWS
+                    forest->stats.margin_mode_launches[mm_rows(row_tc)]++;
                 }
-                hipLaunchKernelGGL(k_forest_masks_from_bytes, dim3(tile_grid), dim3(kBlock), 0, s, d_nodes.p, d_tiles.p, n_tiles,
+                hipLaunchKernelGGL(k_forest_masks_from_bytes, dim3(tile_grid), dim3(kBlock), 0, s, d_cur, d_tiles.p, n_tiles,
                                    cur, N, side_bytes.p, masks.p, tile_left.p);
                 forest->stats.margin_row_passes += (n_trees + row_tc - 1) / row_tc;
+                if (screen) forest->stats.screened_launches += (n_trees + row_tc - 1) / row_tc;
             } else if (bq) {
-                hipLaunchKernelGGL(k_forest_margin_bq, dim3(tile_grid), dim3(kBlock), dv.pitch * 8, s, dv, d_nodes.p,
-                                   d_tiles.p, n_tiles, cur, N, chunk.d, nstride, hdr_off, masks.p, tile_left.p);
-            } else {
-                const size_t sh = (size_t)dv.pitch * 4;
-#define AH_LAUNCH(M)                                                                                            \
-    hipLaunchKernelGGL((k_forest_margin_f32<M>), dim3(tile_grid), dim3(kBlock), sh, s, dv, d_nodes.p, d_tiles.p, \
-                       n_tiles, cur, N, chunk.d, nstride, hdr_off, masks.p, tile_left.p)
+                hipLaunchKernelGGL(k_forest_margin_bq, dim3(tile_grid), dim3(kBlock), dv.pitch * 8, s, dv, d_cur, d_tiles.p,
+                                   n_tiles, cur, N, chunk_d, nstride, hdr_off, masks.p, tile_left.p, d_abort);
+                forest->stats.margin_mode_launches[MM_BQ]++;
+            } else if (screen) {
+                const size_t sh = (size_t)dv.pitch * 4 + (size_t)sv.hpitch * 2;
+#define AH_LAUNCH(M)                                                                                                  \
+    hipLaunchKernelGGL((k_forest_screen_node<M>), dim3(tile_grid), dim3(kBlock), sh, s, dv, sv, d_cur, d_tiles.p, n_tiles, \
+                       cur, chunk_d, nstride, hdr_off, shadow_d, hstride, masks.p, tile_left.p, d_abort, d_counters, verify)
                 switch (ds->metric) {
                 case AH_EUCLIDEAN: AH_LAUNCH(AH_EUCLIDEAN); break;
                 case AH_MANHATTAN: AH_LAUNCH(AH_MANHATTAN); break;
@@ -1132,79 +1849,85 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                 default: AH_LAUNCH(AH_DOT_PRODUCT); break;
                 }
 #undef AH_LAUNCH
+                forest->stats.margin_mode_launches[MM_NODE]++;
+                forest->stats.screened_launches++;
+            } else {
+                const size_t sh = (size_t)dv.pitch * 4;
+#define AH_LAUNCH(M)                                                                                            \
+    hipLaunchKernelGGL((k_forest_margin_f32<M>), dim3(tile_grid), dim3(kBlock), sh, s, dv, d_cur, d_tiles.p,    \
+                       n_tiles, cur, N, chunk_d, nstride, hdr_off, masks.p, tile_left.p, d_abort)
+                switch (ds->metric) {
+                case AH_EUCLIDEAN: AH_LAUNCH(AH_EUCLIDEAN); break;
+                case AH_MANHATTAN: AH_LAUNCH(AH_MANHATTAN); break;
+                case AH_COSINE: AH_LAUNCH(AH_COSINE); break;
+                default: AH_LAUNCH(AH_DOT_PRODUCT); break;
+                }
+#undef AH_LAUNCH
+                forest->stats.margin_mode_launches[MM_NODE]++;
             }
-            AH_HIP(hipEventRecord(ep.b, s));
+            AH_HIP(hipEventRecord(bc.ev_attempt[2 * attempt + 1], s));
             AH_DBG(s, "margin");
-            hipLaunchKernelGGL(k_forest_decide, dim3((n_nodes + 255) / 256), dim3(256), 0, s, d_nodes.p, n_nodes);
+            hipLaunchKernelGGL(k_forest_decide, dim3((n_nodes + 255) / 256), dim3(256), 0, s, d_cur, n_nodes);
             AH_DBG(s, "decide");
         }
-        hipLaunchKernelGGL(k_forest_random_sides, dim3(std::min<uint32_t>(n_tiles, kMaxBlocks)), dim3(64), 0, s,
-                           d_nodes.p, d_tiles.p, n_tiles, masks.p, tile_left.p);
+        hipLaunchKernelGGL(k_forest_random_sides, dim3(std::min<uint32_t>(n_tiles, kMaxBlocks)), dim3(64), 0, s, d_cur,
+                           d_tiles.p, n_tiles, masks.p, tile_left.p);
         AH_DBG(s, "random_sides");
-        hipLaunchKernelGGL(k_forest_tile_offsets, dim3(std::min<uint32_t>(n_nodes, kMaxBlocks)), dim3(64), 0, s,
-                           d_nodes.p, n_nodes, tile_left.p, tile_left_off.p);
+        hipLaunchKernelGGL(k_forest_tile_offsets, dim3(std::min<uint32_t>(n_nodes, kMaxBlocks)), dim3(64), 0, s, d_cur,
+                           n_nodes, tile_left.p, tile_left_off.p);
         AH_DBG(s, "tile_offsets");
-        hipLaunchKernelGGL(k_forest_scatter, dim3(tile_grid), dim3(kBlock), 0, s, d_nodes.p, d_tiles.p, n_tiles, cur, nxt,
+        hipLaunchKernelGGL(k_forest_scatter, dim3(tile_grid), dim3(kBlock), 0, s, d_cur, d_tiles.p, n_tiles, cur, nxt,
                            final_perm.p, N, masks.p, tile_left_off.p, split_after);
         AH_DBG(s, "scatter");
+        // the next level, on the device (its node table lands in the buffer the level before this one used: the side-stream
+        // copy of that table must be over)
+        if (depth >= 1) AH_HIP(hipStreamWaitEvent(s, bc.ev_copy[(depth + 1) & 1], 0));
+        const uint32_t n_blocks = (n_nodes + 255) / 256;
+        hipLaunchKernelGGL(k_next_count, dim3(n_blocks), dim3(256), 0, s, d_cur, n_nodes, split_after, d_block_sums.p);
+        hipLaunchKernelGGL(k_next_scan, dim3(1), dim3(1024), 0, s, d_block_sums.p, n_blocks, d_info, d_tree_first, n_trees);
+        hipLaunchKernelGGL(k_next_emit, dim3(n_blocks), dim3(256), 0, s, d_cur, n_nodes, split_after, d_block_sums.p, d_next,
+                           d_child.p, d_info, d_tree_first);
+        AH_DBG(s, "next_level");
         AH_HIP(hipGetLastError());
-        AH_HIP(hipMemcpyAsync(h_nodes, d_nodes.p, n_nodes * sizeof(FNode), hipMemcpyDeviceToHost, s));
-        AH_HIP(hipStreamSynchronize(s));
+        LevelInfo *hi = h_info[depth & 1];
+        AH_HIP(hipMemcpyAsync(hi, d_info, info_words * 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipEventRecord(bc.ev_level, s));
+
+        // while the level runs: digest the node table of the level before it
+        if (pending_digest) {
+            AH_HIP(hipEventSynchronize(bc.ev_copy[(pending_digest - 1) & 1]));
+            AH_TRY(digest_level(pending_digest - 1, pending_nodes, h_nodes[(pending_digest - 1) & 1], pending_host_off));
+            pending_digest = 0;
+        }
+        lvl_status = wait_level();
+        if (lvl_status != AH_OK) return lvl_status;
+        for (int attempt = 0; attempt < 4; attempt++) {
+            float m = 0.0f;
+            if (hipEventElapsedTime(&m, bc.ev_attempt[2 * attempt], bc.ev_attempt[2 * attempt + 1]) == hipSuccess)
+                forest->stats.seconds_margin += m * 1e-3;
+        }
+        forest->stats.margin_launches += 4;
+        // this level's node table follows on the side stream (the level is complete: no stream dependency needed)
+        AH_HIP(hipMemcpyAsync(h_nodes[depth & 1], d_cur, n_nodes * sizeof(FNode), hipMemcpyDeviceToHost, bc.side));
+        AH_HIP(hipEventRecord(bc.ev_copy[depth & 1], bc.side));
+        pending_digest = depth + 1;
+        pending_nodes = n_nodes;
+        pending_host_off = chunk_host_off;
         // this level's normals are final: the worker copies them while the next level runs
         prefault_normals.join();  // never touch a page the worker may already have filled
-        rb.push(forest->normals + chunk.host_off, chunk.d, chunk.bytes);
+        rb.push(forest->normals + chunk_host_off, chunk_d, chunk_bytes);
 
-        // host: materialise the split records and the next level (children lists subdivide the parent range)
-        level.clear();
+        info = *hi;
+        const uint32_t *tf = reinterpret_cast<const uint32_t *>(hi + 1);
+        for (uint32_t t = 0; t <= n_trees; t++) tree_first[t] = tf[t];
         prev_rows = row_tc >= 2;
-        fix_nodes.clear();
-        if (prev_rows) h_child.assign(2 * (size_t)n_nodes, 0xFFFFFFFFu);
-        for (uint32_t i = 0; i < n_nodes; i++) {
-            const FNode nd = h_nodes[i];
-            AH_REQUIRE(nd.state != ST_PENDING && nd.n_left <= nd.count, AH_ERR_DEVICE,
-                       "forest build: node %u left pending (internal error)", i);
-            forest->stats.margin_evaluations += (uint64_t)(nd.attempt + 1) * nd.count;
-            forest->stats.retries += nd.attempt;
-            items_routed += nd.count;
-            const uint32_t rec_idx = nd.rec;
-            recs[rec_idx].has_normal = nd.state == ST_ACCEPTED;
-            recs[rec_idx].normal_off = chunk.host_off + (uint64_t)i * nstride;
-            if (nd.state != ST_ACCEPTED) forest->stats.dummy_normals++;
-            const uint32_t child_cnt[2] = {nd.n_left, nd.count - nd.n_left};
-            const uint64_t child_start[2] = {nd.start, nd.start + nd.n_left};
-            for (uint32_t side = 0; side < 2; side++) {
-                HostRec c{};
-                c.tree = nd.tree;
-                c.start = child_start[side];
-                c.count = child_cnt[side];
-                c.depth = depth + 1;
-                const uint32_t cidx = (uint32_t)recs.size();
-                if (c.count <= split_after) {
-                    c.kind = AH_NODE_DESCENDANTS;
-                } else {
-                    c.kind = AH_NODE_SPLIT;
-                    FNode cn{};
-                    cn.key = ah_node_key_child(nd.key, side);
-                    cn.start = c.start;
-                    cn.tree = nd.tree;
-                    cn.count = c.count;
-                    cn.rec = cidx;
-                    if (prev_rows) {
-                        // sides of a first-attempt accept are the ones the row-major pass left in side_bytes
-                        if (nd.state == ST_ACCEPTED && nd.attempt == 0) h_child[2 * (size_t)i + side] = (uint32_t)level.size();
-                        else fix_nodes.push_back((uint32_t)level.size());
-                    }
-                    level.push_back(cn);
-                }
-                recs.push_back(c);
-                if (side == 0) recs[rec_idx].left = cidx;
-                else recs[rec_idx].right = cidx;
-            }
-        }
         std::swap(cur, nxt);
+        std::swap(d_cur, d_next);
         depth++;
-        forest->stats.levels = std::max(forest->stats.levels, depth);
-        if (opt->progress) opt->progress(opt->progress_user, depth, recs.size(), items_routed);
+    }
+    if (pending_digest) {
+        AH_HIP(hipEventSynchronize(bc.ev_copy[(pending_digest - 1) & 1]));
+        AH_TRY(digest_level(pending_digest - 1, pending_nodes, h_nodes[(pending_digest - 1) & 1], pending_host_off));
     }
     AH_HIP(hipEventRecord(bc.ev_end, s));
     const auto t_levels = std::chrono::steady_clock::now();
@@ -1222,17 +1945,16 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                                       (tree_base[t + 1] - tree_base[t]) * 4, hipMemcpyDeviceToDevice, s));
         if (!ds->identity_ids && M)
             hipLaunchKernelGGL(k_rows_to_ids, dim3(2048), dim3(256), 0, s, final_perm.p, M, ds->d_ids);
+        ScreenCounters sc{};
+        AH_HIP(hipMemcpyAsync(&sc, d_counters, sizeof sc, hipMemcpyDeviceToHost, s));
         AH_HIP(hipStreamSynchronize(s));
+        forest->stats.screen_fallbacks += sc.fallbacks;
+        forest->stats.screen_violations += sc.violations;
         rb.push(forest->descendants + desc_base, final_perm.p, M * 4);  // lands while the host emits the node list
     }
     float ms = 0.0f;
     AH_HIP(hipEventElapsedTime(&ms, bc.ev_begin, bc.ev_end));
     forest->stats.seconds_device += ms * 1e-3;
-    for (EventPair &ep : bc.events) {
-        float m = 0.0f;
-        if (hipEventElapsedTime(&m, ep.a, ep.b) == hipSuccess) forest->stats.seconds_margin += m * 1e-3;
-    }
-    forest->stats.margin_launches += bc.events.size();
 
     // Emit per tree in post-order (children before parents: the order TmpNodes::put receives them,
     // src/writer.rs:1235-1258), with forest-local indices.
@@ -1255,7 +1977,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             ah_node nd{};
             nd.kind = r.kind;
             nd.has_normal = r.has_normal;
-            nd.tree = (uint16_t)(first_tree + t);
+            nd.tree = first_tree + t;
             nd.count = r.count;
             nd.depth = r.depth;
             if (r.kind == AH_NODE_SPLIT) {
@@ -1300,7 +2022,13 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
     AH_REQUIRE(ds && options, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     AH_REQUIRE(ds->finalized, AH_ERR_NOT_FINALIZED, "dataset not finalized (call ah_dataset_finalize)");
     AH_REQUIRE(options->n_trees == 0 || options->tree_seeds, AH_ERR_INVALID_ARGUMENT, "tree_seeds is NULL");
-    AH_REQUIRE(options->n_trees <= 0xFFFF || subset_ids, AH_ERR_INVALID_ARGUMENT, "at most 65535 trees per call");
+    {
+        const uint32_t m = options->margin_mode & 0xFFFu;
+        AH_REQUIRE((options->margin_mode & ~(0xFFFu | AH_MARGIN_EXACT_ONLY)) == 0 &&
+                       (m == AH_MARGIN_AUTO || m == AH_MARGIN_NODE_MAJOR || m == AH_MARGIN_ROWS_2 || m == AH_MARGIN_ROWS_4 ||
+                        m == AH_MARGIN_ROWS_8 || m == AH_MARGIN_ROWS_16 || m == AH_MARGIN_ROWS_LDS_8 || m == AH_MARGIN_ROWS_LDS_16),
+                   AH_ERR_INVALID_ARGUMENT, "unknown margin_mode 0x%x", options->margin_mode);
+    }
     AH_REQUIRE(ds->metric != AH_DOT_PRODUCT || ds->dot_preprocessed, AH_ERR_NEED_PREPROCESS,
                "DotProduct needs ah_preprocess_dot before the build (src/writer.rs:964-976)");
     AH_HIP(hipSetDevice(ds->device));
@@ -1327,7 +2055,7 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
                 forest->descendants[t * ds->n + i] = ds->identity_ids ? (uint32_t)i : ds->h_ids[i];
             ah_node nd{};
             nd.kind = AH_NODE_DESCENDANTS;
-            nd.tree = (uint16_t)t;
+            nd.tree = t;
             nd.count = (uint32_t)ds->n;
             nd.offset = t * ds->n;
             forest->roots.push_back((uint32_t)forest->nodes.size());
@@ -1340,14 +2068,16 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
             set_error("cannot create a HIP stream");
             st = AH_ERR_DEVICE;
         } else {
+            // the binary16 shadow of the rows is made (once per dataset) before the batch is sized against free memory
+            if (!(options->margin_mode & AH_MARGIN_EXACT_ONLY) && g_screen) (void)ensure_screen(ds, lease.c->stream);
             // Trees in flight: bounded by HBM (per item and tree: 3 permutations + node index + side byte + masks = 18
-            // bytes, plus the normals of all levels) or by the caller.
+            // bytes, plus the normals of all levels and their shadow) or by the caller.
             size_t free_b = 0, total_b = 0;
             (void)hipMemGetInfo(&free_b, &total_b);
             uint32_t batch = options->n_trees;
             if (!subset_ids) {
                 const uint64_t per_tree =
-                    ds->n * 18 + ((ds->n / ((uint64_t)split_after + 1)) + 2) * 2 * (ds->row_bytes() + 128) + (1u << 20);
+                    ds->n * 18 + ((ds->n / ((uint64_t)split_after + 1)) + 2) * 3 * (ds->row_bytes() + 192) + (1u << 20);
                 uint64_t fit = (uint64_t)(free_b * 0.8) / per_tree;
                 if (fit < 1) fit = 1;
                 batch = (uint32_t)std::min<uint64_t>(fit, options->n_trees);

@@ -149,6 +149,10 @@ __global__ __launch_bounds__(64) void k_descend(DataView nv, SearchParams sp, co
         }
         const DNode nd = sp.nodes[node];
         if (action == AH_NODE_DESCENDANTS) {  // src/reader.rs:354-360
+            if ((uint64_t)nn + nd.b > sp.nns_stride) {  // cannot happen for a validated forest; never write out of bounds
+                failed = true;
+                continue;
+            }
             const uint32_t *ids = sp.desc + nd.a;
             if (!sp.filter_bits) {
                 for (uint32_t i = j; i < nd.b; i += 8) my_nns[nn + i] = ids[i];
@@ -358,13 +362,16 @@ __global__ void k_filter_bitmap(const uint32_t *__restrict__ ids, uint64_t n, ui
 }
 
 // normal records [vector (row_bytes)][header (16)] -> row matrix + header array of the normals view
+// Only the `valid_words32` words of the stored vector (ah_vector_size bytes) are read from the record: caller views are
+// compact ([header][vector], stride hs + vs), so the device pitch beyond them is zero-filled, never copied.
 __global__ void k_unpack_normals(const uint8_t *__restrict__ recs, const uint64_t *__restrict__ offsets, uint32_t n,
-                                 uint64_t vec_off, uint64_t hdr_off, uint32_t row_words32, uint32_t hf,
-                                 uint32_t *__restrict__ rows, float *__restrict__ headers) {
+                                 uint64_t vec_off, uint64_t hdr_off, uint32_t valid_words32, uint32_t row_words32,
+                                 uint32_t hf, uint32_t *__restrict__ rows, float *__restrict__ headers) {
     const uint32_t r = blockIdx.x;
     if (r >= n) return;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(recs + offsets[r] + vec_off);
-    for (uint32_t i = threadIdx.x; i < row_words32; i += blockDim.x) rows[(uint64_t)r * row_words32 + i] = src[i];
+    for (uint32_t i = threadIdx.x; i < row_words32; i += blockDim.x)
+        rows[(uint64_t)r * row_words32 + i] = i < valid_words32 ? src[i] : 0u;
     if (threadIdx.x < hf)
         headers[(uint64_t)r * hf + threadIdx.x] = reinterpret_cast<const float *>(recs + offsets[r] + hdr_off)[threadIdx.x];
 }
@@ -418,13 +425,32 @@ int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_ind
     AH_REQUIRE(ds && view, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     AH_REQUIRE(ds->finalized, AH_ERR_NOT_FINALIZED, "dataset not finalized");
     const ah_forest_view v = *view;
+    AH_REQUIRE(v.n_nodes == 0 || v.nodes, AH_ERR_INVALID_ARGUMENT, "nodes is NULL");
+    AH_REQUIRE(v.n_trees == 0 || v.roots, AH_ERR_INVALID_ARGUMENT, "roots is NULL");
+    AH_REQUIRE(v.descendants_len == 0 || v.descendants, AH_ERR_INVALID_ARGUMENT, "descendants is NULL");
+    AH_REQUIRE(v.descendants_len < 0xFFFFFFFFull && v.n_nodes < 0xFFFFFFFFull, AH_ERR_INVALID_ARGUMENT,
+               "forest too large for 32-bit node / descendant offsets");
+    {
+        // record geometry: the vector and the header must lie inside a record, on 4-byte boundaries
+        const uint64_t hs = ah_header_size(ds->metric), vs = ah_vector_size(ds->metric, ds->dims);
+        bool any_normal = false;
+        for (uint64_t i = 0; i < v.n_nodes && !any_normal; i++) any_normal = v.nodes[i].kind == AH_NODE_SPLIT && v.nodes[i].has_normal;
+        if (any_normal) {
+            AH_REQUIRE(v.normals, AH_ERR_INVALID_ARGUMENT, "normals is NULL");
+            AH_REQUIRE(v.normal_vector_offset + vs <= v.normal_stride && v.normal_header_offset + hs <= v.normal_stride,
+                       AH_ERR_INVALID_ARGUMENT, "normal vector / header do not fit the record stride %llu",
+                       (unsigned long long)v.normal_stride);
+            AH_REQUIRE((v.normal_vector_offset & 3) == 0 && (v.normal_header_offset & 3) == 0, AH_ERR_INVALID_ARGUMENT,
+                       "normal vector / header offsets must be multiples of 4");
+        }
+    }
     for (uint64_t i = 0; i < v.n_nodes; i++) {
         const ah_node &nd = v.nodes[i];
         if (nd.kind == AH_NODE_SPLIT) {
             AH_REQUIRE(nd.left < v.n_nodes && nd.right < v.n_nodes, AH_ERR_INVALID_ARGUMENT, "node %llu: child out of range",
                        (unsigned long long)i);
-            AH_REQUIRE(!nd.has_normal || nd.offset + v.normal_stride <= v.normals_len, AH_ERR_INVALID_ARGUMENT,
-                       "node %llu: normal record out of range", (unsigned long long)i);
+            AH_REQUIRE(!nd.has_normal || ((nd.offset & 3) == 0 && nd.offset + v.normal_stride <= v.normals_len),
+                       AH_ERR_INVALID_ARGUMENT, "node %llu: normal record out of range or misaligned", (unsigned long long)i);
         } else {
             AH_REQUIRE(nd.kind == AH_NODE_DESCENDANTS && nd.offset + nd.count <= v.descendants_len, AH_ERR_INVALID_ARGUMENT,
                        "node %llu: bad kind or descendants out of range", (unsigned long long)i);
@@ -432,8 +458,34 @@ int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_ind
     }
     for (uint32_t t = 0; t < v.n_trees; t++)
         AH_REQUIRE(v.roots[t] < v.n_nodes, AH_ERR_INVALID_ARGUMENT, "root %u out of range", t);
-    AH_REQUIRE(v.descendants_len < 0xFFFFFFFFull && v.n_nodes < 0xFFFFFFFFull, AH_ERR_INVALID_ARGUMENT,
-               "forest too large for 32-bit node / descendant offsets");
+    {
+        // The view must be a forest: every node reachable from at most one root / parent (no cycle, no shared sub-tree).
+        // The descent relies on it: a cycle would never terminate, and a Descendants node popped twice would overflow
+        // the per-query candidate buffer, which is sized for every Descendants node being collected at most once.
+        std::vector<uint8_t> seen(v.n_nodes, 0);
+        std::vector<uint32_t> stack;
+        uint64_t total_desc = 0;
+        for (uint32_t t = 0; t < v.n_trees; t++) {
+            stack.push_back(v.roots[t]);
+            while (!stack.empty()) {
+                const uint32_t i = stack.back();
+                stack.pop_back();
+                AH_REQUIRE(!seen[i], AH_ERR_INVALID_ARGUMENT,
+                           "node %u is reachable twice (cycle or shared sub-tree): the view is not a forest", i);
+                seen[i] = 1;
+                const ah_node &nd = v.nodes[i];
+                if (nd.kind == AH_NODE_SPLIT) {
+                    stack.push_back(nd.left);
+                    stack.push_back(nd.right);
+                } else {
+                    total_desc += nd.count;
+                }
+            }
+        }
+        AH_REQUIRE(total_desc <= v.descendants_len, AH_ERR_INVALID_ARGUMENT,
+                   "the Descendants nodes hold %llu ids but the blob has %llu: ranges overlap",
+                   (unsigned long long)total_desc, (unsigned long long)v.descendants_len);
+    }
     AH_HIP(hipSetDevice(ds->device));
     ah_index *ix = new (std::nothrow) ah_index();
     AH_REQUIRE(ix, AH_ERR_OUT_OF_MEMORY, "host allocation failed");
@@ -495,7 +547,8 @@ int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_ind
         AH_IX(hipMemcpy(recs.p, v.normals, v.normals_len, hipMemcpyHostToDevice));
         AH_IX(hipMemcpy(offs.p, offsets.data(), offsets.size() * 8, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_unpack_normals, dim3(ix->n_normals), dim3(256), 0, 0, recs.as<uint8_t>(), offs.as<uint64_t>(),
-                           ix->n_normals, v.normal_vector_offset, v.normal_header_offset, (uint32_t)(row_bytes / 4), hf,
+                           ix->n_normals, v.normal_vector_offset, v.normal_header_offset,
+                           (uint32_t)(ah_vector_size(ds->metric, ds->dims) / 4), (uint32_t)(row_bytes / 4), hf,
                            reinterpret_cast<uint32_t *>(ix->d_nrows), ix->d_nhdrs);
         AH_IX(hipDeviceSynchronize());
     }
@@ -751,6 +804,7 @@ int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_it
         memcpy(&out_distances[i], &nan_bits, 4);
     }
     for (size_t q = 0; q < nq; q++) out_counts[q] = 0;
+    AH_REQUIRE(!have_filter || n_filter == 0 || filter_sorted, AH_ERR_INVALID_ARGUMENT, "filter_sorted is NULL");
     if (ds->n == 0 || ix->n_trees == 0) return AH_OK;  // reader.rs:323-325
     // search_k: reader.rs:330-335; nns can never exceed the blob (every Descendants node is popped at most once)
     unsigned __int128 sk = search_k ? (unsigned __int128)search_k : (unsigned __int128)count * ix->n_trees;

@@ -27,13 +27,25 @@ def _ptr(a: Optional[np.ndarray]):
 
 
 class Dataset:
-    def __init__(self, distance: type[Distance], dimensions: int, capacity: int, device: int = 0):
+    def __init__(self, distance: type[Distance], dimensions: int, capacity: int, device: int = 0, _handle=None,
+                 _finalized: bool = False):
         self.distance = distance
         self.metric = distance.metric
         self.dimensions = int(dimensions)
+        self.device = int(device)
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().ah_dataset_create(self.metric, self.dimensions, int(capacity), device, C.byref(self._h)))
-        self.finalized = False
+        if _handle is not None:
+            self._h = _handle
+        else:
+            _lib.check(_lib.lib().ah_dataset_create(self.metric, self.dimensions, int(capacity), device, C.byref(self._h)))
+        self.finalized = _finalized
+
+    def replicate(self, device: int) -> "Dataset":
+        """A replica on another GPU of the node, copied device to device (ah_dataset_replicate): the multi-GPU build
+        shards trees over replicas of the read-only dataset."""
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ah_dataset_replicate(self._h, int(device), C.byref(h)))
+        return Dataset(self.distance, self.dimensions, 0, device=device, _handle=h, _finalized=self.finalized)
 
     # -- staging ---------------------------------------------------------------------------------
     def upload_vectors(self, item_ids: Sequence[int], vectors) -> None:
@@ -48,10 +60,14 @@ class Dataset:
             raise ValueError("ids and vectors disagree on the number of items")
         _lib.check(_lib.lib().ah_dataset_upload_vectors(self._h, _ptr(ids), _ptr(v), ids.size))
 
-    def upload_records(self, item_ids: Sequence[int], records: Sequence[bytes]) -> None:
-        """Stored item records `[0u8][header][vector]` as they sit in LMDB pages (src/node.rs:224-228)."""
+    def upload_records(self, item_ids: Sequence[int], records: Sequence[bytes], preprocessed: bool = True) -> None:
+        """Stored item records `[0u8][header][vector]` as they sit in LMDB pages (src/node.rs:224-228).
+        `preprocessed` (DotProduct only): the headers come from a built database, i.e. `DotProduct::preprocess` already
+        ran over them (ah_dataset_set_preprocessed); pass False for freshly added items."""
         ids = _u32(item_ids)
         n = ids.size
+        if self.metric == 3:
+            _lib.check(_lib.lib().ah_dataset_set_preprocessed(self._h, 1 if preprocessed else 0))
         if n == 0:
             return
         rec_len = len(records[0])
@@ -166,8 +182,15 @@ class Dataset:
         _lib.check(_lib.lib().ah_create_split(self._h, _ptr(s), _ptr(nv), _ptr(nh)))
         return nv, nh[: self.distance.header_size() // 4].copy()
 
+    def upload_record_pointers(self, item_ids, addresses, record_len: int) -> None:
+        """ah_dataset_upload_records with raw addresses (e.g. into an mmap of an LMDB data file: the real, arbitrarily
+        misaligned pointers `ImmutableLeafs::new` collects, src/parallel.rs:271-293)."""
+        ids = _u32(item_ids)
+        ptrs = (C.c_void_p * ids.size)(*[int(a) for a in addresses])
+        _lib.check(_lib.lib().ah_dataset_upload_records(self._h, _ptr(ids), ptrs, int(record_len), ids.size))
+
     def build_forest(self, tree_seeds: Sequence[int], split_after: int = 0, cancel=None, progress=None,
-                     max_trees_in_flight: int = 0) -> "Forest":
+                     max_trees_in_flight: int = 0, margin_mode: int = 0) -> "Forest":
         seeds = np.ascontiguousarray(tree_seeds, dtype=np.uint64)
         opt = _lib.AhBuildOptions()
         opt.n_trees = seeds.size
@@ -187,6 +210,7 @@ class Dataset:
             if cancel is not None and cancel():  # polled before the first level too (src/writer.rs:1178)
                 cflag.value = 1
         opt.max_trees_in_flight = int(max_trees_in_flight)
+        opt.margin_mode = int(margin_mode)
         h = C.c_void_p()
         _lib.check(_lib.lib().ah_build_forest(self._h, C.byref(opt), C.byref(h)))
         return Forest(h, self.distance, self.dimensions)
@@ -308,8 +332,8 @@ class Forest:
         _lib.check(_lib.lib().ah_forest_view_get(self._h, C.byref(v)))
         self.n_trees = int(v.n_trees)
         n = int(v.n_nodes)
-        node_dt = np.dtype([("kind", "u1"), ("has_normal", "u1"), ("tree", "<u2"), ("left", "<u4"), ("right", "<u4"),
-                            ("offset", "<u8"), ("count", "<u4"), ("depth", "<u4")], align=True)
+        node_dt = np.dtype([("kind", "u1"), ("has_normal", "u1"), ("reserved", "<u2"), ("tree", "<u4"), ("left", "<u4"),
+                            ("right", "<u4"), ("offset", "<u8"), ("count", "<u4"), ("depth", "<u4")], align=True)
         assert node_dt.itemsize == C.sizeof(_lib.AhNode)
 
         def view(ptr, count, dtype):
@@ -329,6 +353,7 @@ class Forest:
         st = _lib.AhBuildStats()
         _lib.check(_lib.lib().ah_forest_stats(self._h, C.byref(st)))
         self.stats = {f: getattr(st, f) for f, _ in _lib.AhBuildStats._fields_}
+        self.stats["margin_mode_launches"] = list(st.margin_mode_launches)
 
     def close(self) -> None:
         if self._h:

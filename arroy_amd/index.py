@@ -177,20 +177,20 @@ class TreeStore:
         order = sorted(self.nodes)
         dense = {nid: i for i, nid in enumerate(order)}
         hs, vs = distance.header_size(), distance.vector_size(dimensions)
-        node_dt = np.dtype([("kind", "u1"), ("has_normal", "u1"), ("tree", "<u2"), ("left", "<u4"), ("right", "<u4"),
-                            ("offset", "<u8"), ("count", "<u4"), ("depth", "<u4")], align=True)
+        node_dt = np.dtype([("kind", "u1"), ("has_normal", "u1"), ("reserved", "<u2"), ("tree", "<u4"), ("left", "<u4"),
+                            ("right", "<u4"), ("offset", "<u8"), ("count", "<u4"), ("depth", "<u4")], align=True)
         nodes = np.zeros(len(order), dtype=node_dt)
         normals, desc = bytearray(), []
         n_desc = 0
         for nid in order:
             nd, i = self.nodes[nid], dense[nid]
             if nd[0] == "D":
-                nodes[i] = (1, 0, 0, 0, 0, n_desc, len(nd[1]), 0)
+                nodes[i] = (1, 0, 0, 0, 0, 0, n_desc, len(nd[1]), 0)
                 desc.append(np.asarray(nd[1], dtype=np.uint32))
                 n_desc += len(nd[1])
             else:
                 has = nd[4] is not None
-                nodes[i] = (2, 1 if has else 0, 0, dense[nd[1]], dense[nd[2]], len(normals), 0, 0)
+                nodes[i] = (2, 1 if has else 0, 0, 0, dense[nd[1]], dense[nd[2]], len(normals), 0, 0)
                 if has:
                     normals += np.asarray(nd[3], dtype=np.float32).tobytes().ljust(hs, b"\0")[:hs] + nd[4]
         normals_a = np.frombuffer(bytes(normals), dtype=np.uint8).copy() if normals else np.zeros(1, np.uint8)
@@ -368,16 +368,18 @@ class ArroyBuilder:
     def _add_trees(self, ds: Dataset, trees: TreeStore, count: int, split_after: int) -> None:
         if count <= 0:
             return
-        if count > 0xFFFF:
-            # arroy's formula (src/writer.rs:1371-1380) explodes for >= 10 000 items of fewer than 768 dimensions
-            # ((768 / dims)^4 in the exponent); the reference would then try to build that many trees.  One
-            # ah_build_forest call takes at most 65 535.
-            raise ValueError(f"{count} trees requested (arroy's target_n_trees for this shape): pass n_trees explicitly")
-        forest = ds.build_forest(self._seeds(count), split_after=split_after, cancel=self._cancel, progress=self._progress)
-        for t in range(forest.n_trees):
-            root = trees.next_id()  # roots are allocated before their subtree (src/writer.rs:556-561)
-            trees.import_tree(forest, t, root_id=root)
-            trees.roots.append(root)
+        # arroy's formula (src/writer.rs:1371-1380) explodes for >= 10 000 items of fewer than 768 dimensions
+        # ((768 / dims)^4 in the exponent); the reference then builds that many trees, and so does this mirror
+        # (ah_node.tree is 32 bits since ABI v2) — in slices, so that the host-side forest stays bounded.
+        seeds = self._seeds(count)
+        for lo in range(0, count, 4096):
+            forest = ds.build_forest(seeds[lo:lo + 4096], split_after=split_after, cancel=self._cancel,
+                                     progress=self._progress)
+            for t in range(forest.n_trees):
+                root = trees.next_id()  # roots are allocated before their subtree (src/writer.rs:556-561)
+                trees.import_tree(forest, t, root_id=root)
+                trees.roots.append(root)
+            forest.close()
 
     def _incremental(self, ds: Dataset, st: "_IndexState", ids: np.ndarray, split_after: int) -> None:
         from .dataset import Index

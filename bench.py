@@ -1,26 +1,37 @@
 #!/usr/bin/env python3
 """bench.py — the headline measurement of arroy's distance-kernel hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs either way: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (one
+rank per GPU, RCCL only for the barrier and the max of the elapsed time; WORLD_SIZE must equal --gpus), or started
+directly, in which case THIS process drives the N devices from N host threads — the shape of arroy's own build, which is
+one process (`Writer::build`, src/writer.rs:556-591): the dataset is staged once on device 0 and replicated device to
+device (`ah_dataset_replicate`, xGMI), every thread owns one replica and builds the trees t = i (mod N).  Fewer than N
+visible devices is an error (exit code 3), never a silent N = 1 run.
 
 Workload (BASELINE.json configs[1]): 1M x 768-dim cosine, synthetic i.i.d. uniform[-1,1) vectors generated
 in HBM by the counter-based generator of include/arroy_hip_policy.h (seed 42), ids 0..N-1.
   * A "step" = one Q=1 batched cosine-distance scan over all 1M resident items (one kernel launch):
     `D::built_distance(query, item)` for every item, src/reader.rs:381-391 -> src/distance/cosine.rs:43-59.
     Inputs are resident in HBM when the timed region starts; outputs stay in HBM.
-  * value = total distances/s over all ranks (every rank scans its own replica: weak scaling).
+  * value = total distances/s over all devices (every device scans its own replica: weak scaling).
   * roofline: algorithmic bytes per launch = 1M x (4*768 + 4 header + 4 out) = 3080 B/distance
      / the average kernel time measured with HIP events on the launch stream.
-  * build: the n_trees=50 forest of the same config, trees sharded round-robin over ranks, no collective;
-    build_10m: the 10M x 768, n_trees=100 forest of configs[2] ("tree-build seconds at 10M vectors"), same sharding.
-  * cpu_baseline (rank 0, N=1 only): the C oracle (a restatement of arroy's AVX2+FMA path, NOT arroy) on a
-    bounded sample of the same workload, all host cores.
-One JSON line on stdout (rank 0).  `--dry-run` exercises the multi-process control path on CPU (gloo).
+  * build: the n_trees=50 forest of the same config, trees sharded round-robin over devices, no collective;
+    build_10m: the 10M x 768, n_trees=100 forest of configs[2] ("tree-build seconds at 10M vectors"), same sharding;
+    both with the certified binary16 screen (default) and, for build_10m, also in f32 arithmetic only.
+  * rerank / bq_scan / search: BASELINE configs[3], configs[4] and the on-device search, on device 0.
+  * cpu_baseline (N=1 only): the C oracle (a restatement of arroy's AVX2+FMA path, NOT arroy) on the host cores: the
+    full 1M-row scan and the full configs[1] build (50 trees over 1M x 768), unless --cpu-seconds bounds it.
+One JSON line on stdout.  `--dry-run` exercises both N>1 control paths on CPU (gloo ranks / host threads).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -32,6 +43,7 @@ N_TREES = 50
 SEED = 42
 BYTES_PER_DISTANCE = 4 * DIMS + 4 + 4  # vector + stored norm + written distance
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SCAN_KERNEL_SOURCES = ["arroy_amd/csrc/distance.hip", "arroy_amd/csrc/device_math.h", "arroy_amd/csrc/common.h"]
 
 
 def parse_args():
@@ -41,82 +53,96 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--items", type=int, default=N_ITEMS)
     ap.add_argument("--trees", type=int, default=N_TREES)
-    ap.add_argument("--no-build", action="store_true", help="skip the forest-build measurement")
+    ap.add_argument("--no-build", action="store_true", help="skip the forest-build measurements")
     ap.add_argument("--no-build-10m", action="store_true",
                     help="skip the 10M x 768 x 100-tree build (BASELINE configs[2], the 'tree-build seconds at 10M' of the metric)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
-    ap.add_argument("--dry-run", action="store_true", help="no GPU work: test the N>1 control path (gloo)")
-    ap.add_argument("--extra", default="", help="comma list of extra measurements: c3 (10M build), c4 (re-rank), "
-                                               "c5 (1-bit scan), metrics (every f32 metric), search, staging; reported "
-                                               "under the `extra` key")
+    ap.add_argument("--no-extra", action="store_true", help="skip configs[3] / configs[4] / on-device search")
+    ap.add_argument("--cpu-seconds", type=float, default=45.0, help="budget of the CPU baseline (bounds the build sample)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: test the N>1 control paths on CPU")
+    ap.add_argument("--extra", default="", help="comma list of further measurements: metrics (every f32 metric), staging")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
     return ap.parse_args()
 
 
+def scan_source_hash():
+    """sha256 over the sources of the scan kernel: the PMC traffic figure is only quoted while it matches."""
+    h = hashlib.sha256()
+    for rel in SCAN_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(args, n_items):
-    """Oracle timed on the host cores: bounded sample of the same workload (scan + a slice of the build)."""
+    """The oracle timed on the host cores, same workload as the GPU numbers: the Q=1 cosine scan over ALL rows (3 GB:
+    beyond the L3 of the host) and the configs[1] forest build over all rows, as many of the 50 trees as the time budget
+    allows (one tree per thread, every tree a full 1M x 768 build), the rest extrapolated and said so."""
+    import ctypes as C
+
     import numpy as np
 
     from oracle import oracle as O
     L = O.lib()
-    cores = L.ao_num_threads()
-    n = min(n_items, 200_000)
+    cores = int(L.ao_num_threads())
+    n = n_items
     vecs = O.synth(SEED, 1, n, DIMS)
     big = O.Data(O.COSINE, vecs)  # headers = exact norms, computed by the oracle itself (parallel)
-    import ctypes as C
     q, qh = big.item_leaf(0)
     out = np.zeros(n, dtype=np.float32)
-    # warm-up + timed repetitions for ~cpu_seconds/2
-    big.distances(q, qh)
+    big.distances(q, qh)  # warm-up
     reps, t0 = 0, time.perf_counter()
     while True:
         L.ao_distances(big.c(), q.ctypes.data_as(C.c_void_p), qh.ctypes.data_as(C.c_void_p), None, n,
                        out.ctypes.data_as(C.c_void_p))
         reps += 1
         el = time.perf_counter() - t0
-        if el > args.cpu_seconds * 0.5 or reps >= 200:
+        if el > 3.0 or reps >= 100:
             break
     scan_rate = reps * n / el
-    res = {"value": scan_rate, "unit": "distances/s", "cores": int(cores), "kind": "port",
-           "sample": f"Q=1 cosine scan over {n}x{DIMS} resident rows x {reps} reps, OpenMP on {cores} threads; "
-                     "C restatement of arroy's AVX2+FMA path (not arroy), data in RAM",
+    res = {"value": scan_rate, "unit": "distances/s", "cores": cores, "kind": "port",
+           "sample": f"Q=1 cosine scan over all {n}x{DIMS} rows ({n * DIMS * 4 / 1e9:.1f} GB, data in RAM) x {reps} reps, "
+                     f"OpenMP on {cores} threads; C restatement of arroy's AVX2+FMA path (not arroy)",
            "scan_gb_per_s": scan_rate * BYTES_PER_DISTANCE / 1e9}
     if not args.no_build:
-        nb = min(n, 100_000)
-        small = O.Data(O.COSINE, vecs[:nb], headers=big.headers[:nb])
-        seeds = np.arange(1, cores + 1, dtype=np.uint64)
+        # one probe tree bounds the sample: trees run one per thread, so `k` trees take about as long as one while k <= cores
+        seeds_all = np.arange(1, args.trees + 1, dtype=np.uint64)
         t0 = time.perf_counter()
-        evals = L.ao_build_forest_count(small.c(), 0, seeds.ctypes.data_as(C.c_void_p), len(seeds))
-        el = time.perf_counter() - t0
-        res["build_margins_per_s"] = evals / el
-        res["build_sample"] = f"{len(seeds)} trees over {nb}x{DIMS} (one tree per thread), {el:.2f}s"
+        ev1 = L.ao_build_forest_count(big.c(), 0, seeds_all[:1].ctypes.data_as(C.c_void_p), 1)
+        one = time.perf_counter() - t0
+        k = args.trees if one * 2.5 < args.cpu_seconds else 0  # 50 concurrent trees share the memory bandwidth
+        total_s, evals = one, ev1
+        if k:
+            t0 = time.perf_counter()
+            evals = L.ao_build_forest_count(big.c(), 0, seeds_all[:k].ctypes.data_as(C.c_void_p), k)
+            total_s = time.perf_counter() - t0
+        trees_timed = k if k else 1
+        res["build_margins_per_s"] = evals / total_s
+        res["build_seconds_measured"] = total_s
+        res["build_trees_measured"] = trees_timed
+        res["build_seconds_config_1"] = total_s if k == args.trees else one * args.trees / min(cores, args.trees) * max(1.0, args.trees / cores)
+        res["build_sample"] = (f"{trees_timed} of the {args.trees} trees of configs[1], each over all {n}x{DIMS} rows (one tree per "
+                               f"thread, {cores} threads): {total_s:.2f} s"
+                               + ("" if k == args.trees else "; build_seconds_config_1 is extrapolated from the single probe tree"))
     return res
 
 
 def measured_traffic(n_items):
-    """HBM bytes per scan launch from the committed rocprofv3 --pmc passes (profiles/rNN_pmc_*_size.csv; separate
-    FETCH_SIZE / WRITE_SIZE runs).  gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE counts half of a
-    16 B/lane coalesced read stream, so reads = FETCH_SIZE x 1024 x 2; writes = WRITE_SIZE x 1024."""
-    import csv
+    """HBM bytes per scan launch from the committed rocprofv3 --pmc passes (profiles/rNN_pmc_scan.json, written by
+    scripts/collect_profiles.sh from separate FETCH_SIZE / WRITE_SIZE runs; gfx950 correction per MI355X_MICROARCH.md:
+    FETCH_SIZE counts half of a 16 B/lane coalesced read stream).  The file carries the hash of the kernel sources it was
+    measured on; a mismatch means the number is stale and is not quoted."""
     import glob
     if n_items != N_ITEMS:
-        return None, None
-    fetch = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size.csv")))
-    write = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_write_size.csv")))
-    if not fetch or not write:
-        return None, None
-
-    def mean(path, counter):
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-                if "k_distances_f32<2, false>" in r["Kernel_Name"] and r["Counter_Name"] == counter]
-        return sum(vals) / len(vals) if vals else None
-
-    f, w = mean(fetch[-1], "FETCH_SIZE"), mean(write[-1], "WRITE_SIZE")
-    if f is None or w is None:
-        return None, None
-    return f * 1024 * 2 + w * 1024, f"{os.path.basename(fetch[-1])} + {os.path.basename(write[-1])}"
+        return None, "not measured for this size"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_scan.json")))
+    if not files:
+        return None, "no profiles/r*_pmc_scan.json"
+    j = json.load(open(files[-1]))
+    if j.get("source_sha16") != scan_source_hash():
+        return None, f"{os.path.basename(files[-1])} was measured on other kernel sources (stale): re-run scripts/collect_profiles.sh"
+    return float(j["hbm_bytes_per_launch"]), os.path.basename(files[-1])
 
 
 def extra_c5(device):
@@ -185,7 +211,10 @@ def extra_c4(device):
     rng = np.random.default_rng(SEED)
     queries = np.stack([ds.item_vector(int(i)) for i in rng.choice(n, 64, replace=False)])
     queries = np.tile(queries, (nq // 64 + 1, 1))[:nq]
-    lists = [np.sort(rng.choice(n, int(rng.integers(10_000, 11_536)), replace=False)).astype(np.uint32) for _ in range(nq)]
+    def cand_list():  # sorted unique random ids (what `nns.sort_unstable(); nns.dedup()` leaves, src/reader.rs:378-379)
+        m = int(rng.integers(10_000, 11_536))
+        return np.unique(rng.integers(0, n, size=m + 400, dtype=np.uint32))[:m]
+    lists = [cand_list() for _ in range(nq)]
     total = sum(len(l) for l in lists)
     per = 4 * dims + 4 + 4  # vector + id + written distance
     out = {"workload": f"{n}x{dims} dot product, {nq} queries x ~10.8k candidates, top-{k} (host in/out included)",
@@ -261,184 +290,348 @@ def extra_search(device):
     return out
 
 
-def extra_c3(device, my_seeds_fn):
-    """BASELINE configs[2]: 10M x 768 cosine, n_trees=100; this rank's share of the trees (all 100 at N=1)."""
-    from arroy_amd import Dataset, distances
-    n = 10_000_000
-    ds = Dataset(distances.Cosine, DIMS, n, device=device)
-    ds.fill_synthetic(SEED, 1, n)
-    ds.finalize()
-    seeds = my_seeds_fn(100)
+def build_stats(st, el, n, trees, my_trees, world):
+    margin_s = st.get("seconds_margin", 0.0)
+    evals = st.get("margin_evaluations", 0)
+    return {
+        "workload": f"{n}x{DIMS} cosine, n_trees={trees} (split_after={DIMS}), trees t = device (mod {world})",
+        "trees": trees, "trees_this_rank": len(my_trees), "seconds": el,
+        "seconds_library_rank0": st.get("seconds_total"), "seconds_device_rank0": st.get("seconds_device"),
+        "seconds_margin_kernel_rank0": margin_s, "margin_evaluations_rank0": evals, "levels": st.get("levels"),
+        "margins_per_s_rank0": evals / margin_s if margin_s else None,
+        # algorithmic = 4*dims bytes per (item, node visit).  Row-major passes serve several trees per HBM read of a
+        # row and the screen reads binary16 copies, so this is an EFFECTIVE rate, not a roofline fraction.
+        "margin_effective_gb_per_s_rank0": evals * 4 * DIMS / margin_s / 1e9 if margin_s else None,
+        "margin_row_major_passes_rank0": st.get("margin_row_passes"), "split_nodes_rank0": st.get("split_nodes"),
+        "retries_rank0": st.get("retries"), "dummy_normals_rank0": st.get("dummy_normals"),
+        "screened_launches_rank0": st.get("screened_launches"), "screen_fallbacks_rank0": st.get("screen_fallbacks"),
+        "margin_mode_launches_rank0": st.get("margin_mode_launches"), "scaling": "strong",
+    }
+
+
+class RankSync:
+    """Barrier + max-over-ranks for one-process-per-GPU runs (torch.distributed: RCCL, or gloo for --dry-run)."""
+
+    def __init__(self, args, rank, world, local_rank):
+        import torch
+        self.torch, self.dist, self.args, self.local_rank = torch, None, args, local_rank
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo" if args.dry_run else "nccl", rank=rank, world_size=world)
+            self.dist = dist
+
+    def barrier(self, _i=0):
+        if self.dist is not None:
+            if self.args.dry_run:
+                self.dist.barrier()
+            else:
+                self.dist.barrier(device_ids=[self.local_rank])
+        if not self.args.dry_run:
+            self.torch.cuda.synchronize()
+
+    def max(self, x, _i=0):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.args.dry_run else f"cuda:{self.local_rank}")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+class ThreadSync:
+    """Barrier + max over the N host threads of a single-process run (one thread per device)."""
+
+    def __init__(self, args, world):
+        self.args, self.world = args, world
+        self.bar = threading.Barrier(world)
+        self.vals = [0.0] * world
+        self.torch = None
+        if not args.dry_run:
+            import torch
+            self.torch = torch
+
+    def barrier(self, i):
+        self.bar.wait()
+        if self.torch is not None:
+            self.torch.cuda.synchronize(i)
+
+    def max(self, x, i):
+        self.vals[i] = x
+        self.bar.wait()
+        m = max(self.vals)
+        self.bar.wait()
+        return m
+
+    def close(self):
+        pass
+
+
+def device_work(args, rank, world, device, sync, ds_1m, result):
+    """Everything one device measures.  `ds_1m`: this device's replica of the configs[1] dataset (threads mode) or None
+    (the rank fills its own)."""
+    import arroy_amd
+    from arroy_amd import Dataset, distances, shard
+    from arroy_amd import _lib as ahlib
+    n = args.items
+    my_trees = shard.trees_for_rank(args.trees, rank, world)
+    my_seeds = shard.tree_seeds(SEED, my_trees)
+    ds = ds_1m
+    if ds is None:
+        ds = Dataset(distances.Cosine, DIMS, n, device=device)
+        ds.fill_synthetic(SEED, 1, n)
+        ds.finalize()
+    query_item = 12345 % n
+    if args.warmup > 0:
+        ds.bench_scan(query_item, n, args.warmup)
+    sync.barrier(rank)
     t0 = time.perf_counter()
-    forest = ds.build_forest(seeds)
-    el = time.perf_counter() - t0
-    st = forest.stats
-    out = {"workload": f"{n}x{DIMS} cosine, n_trees=100, trees on this rank: {len(seeds)}", "seconds": el,
-           "seconds_library": st["seconds_total"], "seconds_device": st["seconds_device"],
-           "seconds_margin_kernel": st["seconds_margin"], "margin_evaluations": st["margin_evaluations"],
-           "levels": st["levels"], "split_nodes": st["split_nodes"],
-           "margin_effective_gb_per_s": st["margin_evaluations"] * 4 * DIMS / st["seconds_margin"] / 1e9,
-           "margin_row_major_passes": st["margin_row_passes"]}
-    forest.close()
+    kernel_ms_total, _ = ds.bench_scan(query_item, n, args.steps)  # K launches, HIP events on the launch stream
+    sync.barrier(rank)
+    result["elapsed"] = sync.max(time.perf_counter() - t0, rank)
+    result["kernel_ms"] = sync.max(kernel_ms_total / args.steps, rank)
+    if rank == 0:
+        result["device"] = arroy_amd.device_name(device)
+        # measured streaming ceilings of this device, next to the spec peak
+        cp_bytes, cp_iters = 2 << 30, 10
+        cp_ms = ahlib.bench_memcpy(device, cp_bytes, cp_iters)
+        result["copy_gbs"] = 2 * cp_bytes * cp_iters / (cp_ms * 1e-3) / 1e9  # read + write
+        rd_bytes, rd_iters = 3 << 30, 20
+        result["read_gbs"] = rd_bytes * rd_iters / (ahlib.bench_read(device, rd_bytes, rd_iters) * 1e-3) / 1e9
+    if not args.no_build and args.trees > 0:
+        if my_seeds:
+            ds.build_forest(my_seeds[:1]).close()  # warm-up: binary16 shadow of the rows, scratch, pinned buffers
+        sync.barrier(rank)
+        t0 = time.perf_counter()
+        forest = ds.build_forest(my_seeds) if my_seeds else None
+        own = time.perf_counter() - t0
+        sync.barrier(rank)
+        el = sync.max(time.perf_counter() - t0, rank)
+        if rank == 0:
+            result["build"] = build_stats(forest.stats if forest is not None else {}, el, n, args.trees, my_trees, world)
+        result.setdefault("build_seconds_per_device", {})[rank] = own
+        if forest is not None:
+            forest.close()
+    if rank == 0 and world == 1 and not args.no_cpu:
+        result["cpu"] = cpu_baseline(args, n)
     ds.close()
-    return out
+    wanted = [x for x in args.extra.split(",") if x]
+    if rank == 0:
+        extra = {}
+        if not args.no_extra and n == N_ITEMS:
+            extra["bq_scan"] = extra_c5(device)
+            extra["rerank"] = extra_c4(device)
+            extra["search"] = extra_search(device)
+        if "metrics" in wanted:
+            extra["metrics"] = extra_metrics(device)
+        if "staging" in wanted:
+            extra["staging"] = extra_staging(device)
+        result["extra"] = extra
+
+
+def build_10m(args, rank, world, device, sync, ds, result):
+    """BASELINE configs[2]: 10M x 768 cosine, n_trees = 100, this device's share of the trees (all 100 at N = 1).
+    Timed twice: default (certified binary16 screen) and f32 arithmetic only (AH_MARGIN_EXACT_ONLY)."""
+    from arroy_amd import Dataset, distances, shard
+    from arroy_amd import _lib as ahlib
+    n = 10_000_000
+    if ds is None:
+        ds = Dataset(distances.Cosine, DIMS, n, device=device)
+        ds.fill_synthetic(SEED, 1, n)
+        ds.finalize()
+    trees = shard.trees_for_rank(100, rank, world)
+    seeds = shard.tree_seeds(SEED, trees)
+    out = {}
+    for key, mode in (("screened", 0), ("f32_only", ahlib.MARGIN_EXACT_ONLY)):
+        if key == "screened" and seeds:
+            ds.build_forest(seeds[:1], margin_mode=mode).close()  # warm-up (shadow copy of the rows, buffers)
+        sync.barrier(rank)
+        t0 = time.perf_counter()
+        forest = ds.build_forest(seeds, margin_mode=mode) if seeds else None
+        own = time.perf_counter() - t0
+        sync.barrier(rank)
+        el = sync.max(time.perf_counter() - t0, rank)
+        st = forest.stats if forest is not None else {}
+        if rank == 0:
+            ms = st.get("seconds_margin", 0.0)
+            out[key] = {"seconds": el, "seconds_library": st.get("seconds_total"), "seconds_device": st.get("seconds_device"),
+                        "seconds_margin_kernel": ms, "margin_evaluations": st.get("margin_evaluations"),
+                        "levels": st.get("levels"), "split_nodes": st.get("split_nodes"),
+                        "margin_effective_gb_per_s": st.get("margin_evaluations", 0) * 4 * DIMS / ms / 1e9 if ms else None,
+                        "margin_row_major_passes": st.get("margin_row_passes"),
+                        "screen_fallbacks": st.get("screen_fallbacks"), "margin_mode_launches": st.get("margin_mode_launches")}
+        result.setdefault("build_10m_seconds_per_device", {}).setdefault(key, {})[rank] = own
+        if forest is not None:
+            forest.close()
+    ds.close()
+    if rank == 0:
+        res = dict(out["screened"])
+        res["workload"] = f"{n}x{DIMS} cosine, n_trees=100, trees on device 0: {len(trees)} (t = device mod {world})"
+        res["arithmetic"] = ("certified binary16 screen decides the side of a margin when |screen| > proven error bound, "
+                             "f32 reference arithmetic for the rest (screen_fallbacks pairs); forest bit-identical to f32_only")
+        res["f32_only"] = out["f32_only"]
+        res["scaling"] = "strong"
+        result["build_10m"] = res
+
+
+def dry_run_work(args, rank, world, sync, result):
+    """Control-path test: no device work, fixed fake durations."""
+    from arroy_amd import shard
+    my_trees = shard.trees_for_rank(args.trees, rank, world)
+    sync.barrier(rank)
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    sync.barrier(rank)
+    result["elapsed"] = sync.max(time.perf_counter() - t0, rank)
+    result["kernel_ms"] = result["elapsed"] * 1e3 / max(args.steps, 1)
+    b = sync.max(0.001 * len(my_trees), rank)
+    if rank == 0:
+        result["device"] = "dry-run (cpu)"
+        result["build"] = {"trees": args.trees, "trees_this_rank": len(my_trees), "seconds": b}
 
 
 def main():
     args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if args.dry_run else "nccl", rank=rank, world_size=world)
-
-    import torch
-
-    def barrier_sync():
-        if dist is not None:
-            if args.dry_run:
-                dist.barrier()
-            else:
-                dist.barrier(device_ids=[local_rank])
-        if not args.dry_run:
-            torch.cuda.synchronize()
-
-    def max_over_ranks(x: float) -> float:
-        if dist is None:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device="cpu" if args.dry_run else f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    from arroy_amd import shard
-    my_trees = shard.trees_for_rank(args.trees, rank, world)
-    my_seeds = shard.tree_seeds(SEED, my_trees)
-
-    n = args.items
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
     result = {}
-    if args.dry_run:
-        # control-path test: no device work, fixed fake durations
-        barrier_sync()
-        t0 = time.perf_counter()
-        time.sleep(0.01 * (rank + 1))
-        barrier_sync()
-        elapsed = max_over_ranks(time.perf_counter() - t0)
-        scan_ms = elapsed * 1e3 / max(args.steps, 1)
-        build = {"trees": args.trees, "trees_this_rank": len(my_trees), "seconds": max_over_ranks(0.001 * len(my_trees))}
-        kernel_ms = scan_ms
-        copy_gbs = read_gbs = None
-        dev_name = "dry-run (cpu, gloo)"
-        cpu = None
+    if env_world > 0:
+        # one rank per process (python -m torch.distributed.run): the launcher's world must be the --gpus asked for
+        world, rank, local_rank = env_world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(2)
+        mode = "one process per GPU (torch.distributed)" if world > 1 else "single process"
+        sync = RankSync(args, rank, world, local_rank)
+        if args.dry_run:
+            dry_run_work(args, rank, world, sync, result)
+        else:
+            import arroy_amd
+            if arroy_amd.device_count() <= local_rank:
+                print(f"bench.py: rank {rank} needs device {local_rank}, {arroy_amd.device_count()} visible", file=sys.stderr)
+                sys.exit(3)
+            sync.torch.cuda.set_device(local_rank)
+            device_work(args, rank, world, local_rank, sync, None, result)
+            if not args.no_build and not args.no_build_10m and args.items == N_ITEMS:
+                build_10m(args, rank, world, local_rank, sync, None, result)
+        sync.close()
+        n_used = world
     else:
-        torch.cuda.set_device(local_rank)
-        import arroy_amd
-        from arroy_amd import Dataset, distances
-        dev_name = arroy_amd.device_name(local_rank)
-        ds = Dataset(distances.Cosine, DIMS, n, device=local_rank)
-        ds.fill_synthetic(SEED, 1, n)
-        ds.finalize()
-        query_item = 12345 % n
-        if args.warmup > 0:
-            ds.bench_scan(query_item, n, args.warmup)
-        barrier_sync()
-        t0 = time.perf_counter()
-        kernel_ms_total, _ = ds.bench_scan(query_item, n, args.steps)  # K launches, HIP events on the launch stream
-        barrier_sync()
-        elapsed = max_over_ranks(time.perf_counter() - t0)
-        kernel_ms = max_over_ranks(kernel_ms_total / args.steps)
-        # measured streaming ceiling of this device, next to the spec peak: a 2 GiB device-to-device copy
-        from arroy_amd import _lib as ahlib
-        cp_bytes, cp_iters = 2 << 30, 10
-        cp_ms = ahlib.bench_memcpy(local_rank, cp_bytes, cp_iters)
-        copy_gbs = 2 * cp_bytes * cp_iters / (cp_ms * 1e-3) / 1e9  # read + write
-        rd_bytes, rd_iters = 3 << 30, 20
-        read_gbs = rd_bytes * rd_iters / (ahlib.bench_read(local_rank, rd_bytes, rd_iters) * 1e-3) / 1e9
-        build = None
-        if not args.no_build and args.trees > 0:
-            barrier_sync()
+        # this process drives all --gpus devices: one host thread per device, dataset staged once and replicated over xGMI
+        world, rank = args.gpus, 0
+        mode = f"single process, {world} host threads (one per device), dataset replicated device to device" if world > 1 \
+            else "single process"
+        sync = ThreadSync(args, world)
+        if not args.dry_run:
+            import arroy_amd
+            have = arroy_amd.device_count()
+            if have < world:
+                print(f"bench.py: --gpus {world} but only {have} device(s) visible", file=sys.stderr)
+                sys.exit(3)
+        results = [dict() for _ in range(world)]
+        errors = []
+
+        def replicas(n_items):
+            """configs dataset on device 0 + device-to-device replicas on the others (None per device at N = 1)."""
+            if world == 1:
+                return [None], None
+            from arroy_amd import Dataset, distances
+            d0 = Dataset(distances.Cosine, DIMS, n_items, device=0)
+            d0.fill_synthetic(SEED, 1, n_items)
+            d0.finalize()
             t0 = time.perf_counter()
-            forest = ds.build_forest(my_seeds) if my_seeds else None
-            barrier_sync()
-            b_elapsed = max_over_ranks(time.perf_counter() - t0)
-            st = forest.stats if forest is not None else {}
-            margin_s = st.get("seconds_margin", 0.0)
-            evals = st.get("margin_evaluations", 0)
-            build = {
-                "workload": f"{n}x{DIMS} cosine, n_trees={args.trees} (split_after={DIMS}), trees t=rank mod {world}",
-                "trees": args.trees, "trees_this_rank": len(my_trees), "seconds": b_elapsed,
-                "seconds_library_rank0": st.get("seconds_total"),
-                "seconds_device_rank0": st.get("seconds_device"), "seconds_margin_kernel_rank0": margin_s,
-                "margin_evaluations_rank0": evals, "levels": st.get("levels"),
-                "margins_per_s_rank0": evals / margin_s if margin_s else None,
-                # algorithmic = 4*dims bytes per (item, node visit).  With row-major passes one HBM read of a row serves
-                # several trees, so this is an EFFECTIVE rate (it may exceed the HBM peak), not a roofline fraction.
-                "margin_effective_gb_per_s_rank0": evals * 4 * DIMS / margin_s / 1e9 if margin_s else None,
-                "margin_row_major_passes_rank0": st.get("margin_row_passes"),
-                "split_nodes_rank0": st.get("split_nodes"), "retries_rank0": st.get("retries"),
-                "dummy_normals_rank0": st.get("dummy_normals"), "scaling": "strong",
-            }
-        cpu = None
-        if rank == 0 and world == 1 and not args.no_cpu:
-            cpu = cpu_baseline(args, n)
-        extra = {}
-        wanted = [x for x in args.extra.split(",") if x]
-        ds.close()
-        # "tree-build seconds at 10M vectors" (BASELINE.json metric, configs[2]): 100 trees sharded over the ranks
-        build_10m = None
-        if not args.no_build and not args.no_build_10m and n == N_ITEMS and "c3" not in wanted:
-            wanted.append("c3")
-        if "c5" in wanted and rank == 0:
-            extra["c5"] = extra_c5(local_rank)
-        if "metrics" in wanted and rank == 0:
-            extra["metrics"] = extra_metrics(local_rank)
-        if "c4" in wanted and rank == 0:
-            extra["c4"] = extra_c4(local_rank)
-        if "staging" in wanted and rank == 0:
-            extra["staging"] = extra_staging(local_rank)
-        if "search" in wanted and rank == 0:
-            extra["search"] = extra_search(local_rank)
-        if "c3" in wanted:
-            barrier_sync()
-            t0 = time.perf_counter()
-            c3 = extra_c3(local_rank, lambda t: shard.tree_seeds(SEED, shard.trees_for_rank(t, rank, world)))
-            barrier_sync()
-            c3["seconds_max_over_ranks"] = max_over_ranks(time.perf_counter() - t0)
-            c3["seconds"] = max_over_ranks(c3["seconds"])
-            c3["scaling"] = "strong"
-            build_10m = c3
-        result["extra"] = extra
-        result["build_10m"] = build_10m
+            out = [d0] + [None] * (world - 1)
+
+            def rep(i):
+                out[i] = d0.replicate(i)
+            ths = [threading.Thread(target=rep, args=(i,)) for i in range(1, world)]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            el = time.perf_counter() - t0
+            return out, {"seconds": el, "replicas": world - 1,
+                         "gb_per_s_total": (world - 1) * n_items * DIMS * 4 / el / 1e9}
+
+        def run_threads(fn, datasets):
+            def body(i):
+                try:
+                    fn(i, datasets[i])
+                except BaseException as e:  # noqa: BLE001 — a failed thread must not leave the others in a barrier
+                    errors.append(repr(e))
+                    sync.bar.abort()
+            ths = [threading.Thread(target=body, args=(i,)) for i in range(world)]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            if errors:
+                print("bench.py: device thread failed: " + "; ".join(errors), file=sys.stderr)
+                sys.exit(4)
+
+        if args.dry_run:
+            run_threads(lambda i, _d: dry_run_work(args, i, world, sync, results[i]), [None] * world)
+        else:
+            dsets, rep = replicas(args.items)
+            run_threads(lambda i, d: device_work(args, i, world, i, sync, d, results[i]), dsets)
+            if rep:
+                results[0]["replicate_1m"] = rep
+            if not args.no_build and not args.no_build_10m and args.items == N_ITEMS:
+                dsets, rep = replicas(10_000_000)
+                run_threads(lambda i, d: build_10m(args, i, world, i, sync, d, results[i]), dsets)
+                if rep:
+                    results[0]["replicate_10m"] = rep
+        result = results[0]
+        for key in ("build_seconds_per_device",):
+            merged = {}
+            for r in results:
+                merged.update(r.get(key, {}))
+            if merged:
+                result[key] = merged
+        per = {}
+        for r in results:
+            for k, v in r.get("build_10m_seconds_per_device", {}).items():
+                per.setdefault(k, {}).update(v)
+        if per:
+            result["build_10m_seconds_per_device"] = per
+        n_used = world
 
     if rank == 0:
+        n = args.items
+        elapsed, kernel_ms = result["elapsed"], result["kernel_ms"]
         ms_per_step = elapsed * 1e3 / args.steps
-        value = world * n * args.steps / elapsed
+        value = n_used * n * args.steps / elapsed
         achieved = n * BYTES_PER_DISTANCE / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = (args.traffic_bytes, "--traffic-bytes") if args.traffic_bytes else measured_traffic(n)
+        traffic, traffic_src = (args.traffic_bytes, "--traffic-bytes") if args.traffic_bytes else \
+            (measured_traffic(n) if not args.dry_run else (None, "dry-run"))
+        read_gbs = result.get("read_gbs")
         line = {
-            "metric": "distances/sec, Q=1 batched 768-dim cosine scan (GB/s vs HBM roofline in `roofline`)",
-            "value": value, "unit": "distances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "distances/sec, Q=1 batched 768-dim cosine scan (GB/s vs HBM roofline in `roofline`); tree-build "
+                      "seconds at 10M vectors in `build_10m`",
+            "value": value, "unit": "distances/s", "n_gpus": n_used, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic uniform[-1,1) (counter-based generator, seed 42), generated in HBM",
             "config": {"workload": f"{n}x{DIMS} cosine Q=1 distance scan, one replica per GPU (BASELINE configs[1])",
-                       "items": n, "dims": DIMS, "metric": "cosine", "device": dev_name},
+                       "items": n, "dims": DIMS, "metric": "cosine", "device": result.get("device"), "launch": mode},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "ah::k_distances_f32<COSINE,false>", "kernel_ms": kernel_ms,
-                         "measured_d2d_copy_gb_per_s": copy_gbs, "measured_read_only_gb_per_s": read_gbs,
+                         "kernel_source_sha16": scan_source_hash(),
+                         "measured_d2d_copy_gb_per_s": result.get("copy_gbs"), "measured_read_only_gb_per_s": read_gbs,
                          "frac_of_measured_read_ceiling": achieved / read_gbs if read_gbs else None,
                          "algorithmic_bytes_per_launch": n * BYTES_PER_DISTANCE},
-            "cpu_baseline": cpu,
-            "build": build,
+            "cpu_baseline": result.get("cpu"),
+            "build": result.get("build"),
             "build_10m": result.get("build_10m"),
         }
-        if result.get("extra"):
-            line["extra"] = result["extra"]
+        for key in ("build_seconds_per_device", "build_10m_seconds_per_device", "replicate_1m", "replicate_10m"):
+            if result.get(key):
+                line[key] = result[key]
+        extra = result.get("extra") or {}
+        for key in ("rerank", "bq_scan", "search"):
+            if key in extra:
+                line[key] = extra.pop(key)
+        if extra:
+            line["extra"] = extra
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define AH_ABI_VERSION 1
+#define AH_ABI_VERSION 2   /* v2: ah_node.tree is 32 bits, ah_build_options.margin_mode, ah_build_stats.margin_mode_launches,
+                                  ah_last_error_detail, ah_dataset_replicate, ah_dataset_upload_flush */
 
 /* every entry point is exported from the shared object (it is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -80,6 +81,16 @@ AH_API int ah_abi_version(void);
 AH_API int ah_device_count(int *out_count);
 /* Text of the calling thread's last failure ("" if none).  Never NULL. */
 AH_API const char *ah_last_error(void);
+/* Structured part of the calling thread's last failure, so that the Rust side can rebuild the typed variants of
+ * arroy::Error instead of a string: AH_ERR_INVALID_DIMENSION -> Error::InvalidVecDimension { expected, received }
+ * (src/error.rs:17-23), AH_ERR_MISSING_ITEM -> Error::MissingKey { mode: "Item", item } (src/error.rs:58-67). */
+typedef struct ah_error_detail {
+    int status;          /* the ah_status the failing call returned (AH_OK if the thread has not failed yet) */
+    uint32_t item;       /* AH_ERR_MISSING_ITEM: the item id that does not exist                             */
+    uint64_t expected;   /* AH_ERR_INVALID_DIMENSION: dimensions (or record bytes) of the dataset            */
+    uint64_t received;   /* AH_ERR_INVALID_DIMENSION: what the caller passed                                 */
+} ah_error_detail;
+AH_API int ah_last_error_detail(ah_error_detail *out);
 
 /* ------------------------------------------------------------------------------------------
  * Dataset = what `ImmutableLeafs::new` builds (src/parallel.rs:271-293): instead of a map
@@ -107,8 +118,21 @@ AH_API int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, c
  * the generator of arroy_hip_policy.h, then codec + new_header as in ah_dataset_upload_vectors. */
 AH_API int ah_dataset_fill_synthetic(ah_dataset *ds, uint64_t seed, int distribution, uint64_t n_items);
 
+/* Uploads are asynchronous: a call returns once the records are copied out of the caller's pages into the pinned
+ * staging ring, the last DMA transfers may still be in flight.  ah_dataset_finalize (and every call that reads the
+ * dataset) waits for them; ah_dataset_upload_flush does only that and reports a failed transfer. */
+AH_API int ah_dataset_upload_flush(ah_dataset *ds);
+/* DotProduct only: records staged with ah_dataset_upload_records carry whatever header the database holds.  Items
+ * written by `Writer::add_item` have {extra_dim: 0, norm: 0} until `DotProduct::preprocess` ran
+ * (src/distance/dot_product.rs:119-165), so such a dataset still needs ah_preprocess_dot; a caller that staged an
+ * already built (preprocessed) database says so here (src/writer.rs:964-976 runs preprocess inside every build). */
+AH_API int ah_dataset_set_preprocessed(ah_dataset *ds, int preprocessed);
 /* Freeze the dataset (build the id -> row index).  Required before any query/build call. */
 AH_API int ah_dataset_finalize(ah_dataset *ds);
+/* A replica of `src` on another GPU of the node, copied device to device (xGMI) instead of staged again over PCIe:
+ * what the one-tree-batch-per-GPU build needs (`Writer::build` shares ONE ImmutableLeafs between all its tasks,
+ * src/writer.rs:530,556-591).  The replica has its own handle and lifetime; destroy it with ah_dataset_destroy. */
+AH_API int ah_dataset_replicate(ah_dataset *src, int device, ah_dataset **out);
 AH_API int ah_dataset_len(const ah_dataset *ds, uint64_t *out_n_items);
 /* `Reader::item_vector` (src/reader.rs:266-276): decoded f32 vector (dims floats; +-1.0 for BQ). */
 AH_API int ah_dataset_item_vector(ah_dataset *ds, uint32_t item_id, float *out_vector);
@@ -179,14 +203,39 @@ AH_API int ah_create_split(ah_dataset *ds, const uint32_t sample_ids[AH_SPLIT_SA
 
 typedef void (*ah_progress_fn)(void *user, uint32_t level, uint64_t nodes_done, uint64_t items_routed);
 
+/* How the margin pass of a level (src/writer.rs:1201-1207 for every pending node of every tree) is laid out on the
+ * device.  Every mode produces the same forest bit for bit; AUTO picks per level with a cost model.  The other values
+ * pin one kernel family for every level where it is legal (f32 metrics, dimensions >= 32, full-dataset trees, >= 2
+ * trees; LDS modes additionally need the group's normals of the level to fit in LDS) and use the node-major kernel
+ * elsewhere: they exist so that tests can compare EVERY kernel instantiation with the oracle, and for A/B timing. */
+typedef enum ah_margin_mode {
+    AH_MARGIN_AUTO = 0,
+    AH_MARGIN_NODE_MAJOR = 1,      /* one tree at a time, tiles of one node, its normal in LDS                       */
+    AH_MARGIN_ROWS_2 = 2,          /* row-major: one pass over the rows serves 2 / 4 / 8 / 16 trees, normals via L2   */
+    AH_MARGIN_ROWS_4 = 4,
+    AH_MARGIN_ROWS_8 = 8,
+    AH_MARGIN_ROWS_16 = 16,
+    AH_MARGIN_ROWS_LDS_8 = 0x108,  /* row-major, all normals of a group of 8 / 16 trees resident in LDS               */
+    AH_MARGIN_ROWS_LDS_16 = 0x110,
+    /* Flag, OR-ed into any of the above: evaluate every margin in the reference's f32 arithmetic only.  Without it the
+     * f32 metrics first evaluate a *certified screen*: the same dot product on a binary16 shadow copy of the rows and
+     * of the level's normals (half the bytes), with a rigorous bound E on |screen - reference f32 margin| derived
+     * from the measured quantisation errors ("certified screening"); only the SIGN of a margin is ever
+     * used (`D::side`, src/distance/mod.rs:103-110), so |screen| > E decides the side and every other pair (about 1 %)
+     * is recomputed with the reference arithmetic in the same kernel.  Sides — hence forests — are identical. */
+    AH_MARGIN_EXACT_ONLY = 0x1000
+} ah_margin_mode;
+
 typedef struct ah_build_options {
     uint32_t n_trees;              /* trees built by THIS call (the caller shards trees over GPUs)   */
     uint32_t split_after;          /* 0 = dimensions (src/writer.rs:474-477)                         */
     const uint64_t *tree_seeds;    /* n_trees seeds (src/writer.rs:575: one RNG per root task)       */
-    const volatile int *cancel;    /* polled between kernel batches; non-zero -> AH_ERR_CANCELLED     */
+    const volatile int *cancel;    /* polled while a level runs (src/writer.rs:1178,1196 poll per node and per item);
+                                      non-zero -> the kernels in flight drain early -> AH_ERR_CANCELLED */
     ah_progress_fn progress;       /* may be NULL (src/writer.rs:53-69 SubStep)                      */
     void *progress_user;
     uint32_t max_trees_in_flight;  /* 0 = as many as HBM allows                                      */
+    uint32_t margin_mode;          /* ah_margin_mode; 0 = AH_MARGIN_AUTO                             */
 } ah_build_options;
 
 /* Whole-forest build: `make_tree_in_file` for every tree (src/writer.rs:556-591,1167-1261) with the
@@ -206,7 +255,9 @@ enum { AH_NODE_DESCENDANTS = 1, AH_NODE_SPLIT = 2 };   /* node tags, src/node.rs
 typedef struct ah_node {
     uint8_t kind;           /* AH_NODE_DESCENDANTS | AH_NODE_SPLIT                                   */
     uint8_t has_normal;     /* 0 = `normal: None` (random split fallback, src/writer.rs:1220-1227)   */
-    uint16_t tree;          /* tree index inside this forest                                        */
+    uint16_t reserved;      /* 0                                                                    */
+    uint32_t tree;          /* tree index inside this forest (arroy's target_n_trees, src/writer.rs:1371-1380,
+                               can exceed 65 535, hence 32 bits since ABI v2)                         */
     uint32_t left, right;   /* forest-local node indices (SPLIT)                                    */
     uint64_t offset;        /* SPLIT: byte offset into the normals blob; DESCENDANTS: first id index */
     uint32_t count;         /* DESCENDANTS: number of item ids; SPLIT: items under the node         */
@@ -241,6 +292,12 @@ typedef struct ah_build_stats {
     uint64_t margin_row_passes;   /* row-major passes (each streams all rows once and serves several trees)  */
     uint64_t split_nodes, descendant_nodes, dummy_normals, retries;
     uint32_t levels;
+    /* margin launches per kernel family: [0] node-major f32, [1] rows x2, [2] rows x4, [3] rows x8, [4] rows x16,
+     * [5] LDS x8, [6] LDS x16, [7] node-major 1-bit */
+    uint64_t margin_mode_launches[8];
+    uint64_t screened_launches;   /* margin launches that ran the certified binary16 screen                  */
+    uint64_t screen_fallbacks;    /* (item, node) pairs the screen could not decide (recomputed in f32)       */
+    uint64_t screen_violations;   /* AH_SCREEN_VERIFY=1 only: decided pairs whose f32 side differs (must be 0) */
 } ah_build_stats;
 
 AH_API int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out);

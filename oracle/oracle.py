@@ -31,8 +31,9 @@ def build(force: bool = False) -> str:
 
 
 class AhNode(C.Structure):
-    _fields_ = [("kind", C.c_uint8), ("has_normal", C.c_uint8), ("tree", C.c_uint16), ("left", C.c_uint32),
-                ("right", C.c_uint32), ("offset", C.c_uint64), ("count", C.c_uint32), ("depth", C.c_uint32)]
+    _fields_ = [("kind", C.c_uint8), ("has_normal", C.c_uint8), ("reserved", C.c_uint16), ("tree", C.c_uint32),
+                ("left", C.c_uint32), ("right", C.c_uint32), ("offset", C.c_uint64), ("count", C.c_uint32),
+                ("depth", C.c_uint32)]
 
 
 class AhForestView(C.Structure):
@@ -337,12 +338,12 @@ class Tree:
 
     def as_forest(self, data: "Data"):
         """The tree as a one-tree forest object with the attributes `search()` / `forest_view()` expect."""
-        node_dt = np.dtype([("kind", "u1"), ("has_normal", "u1"), ("tree", "<u2"), ("left", "<u4"), ("right", "<u4"),
+        node_dt = np.dtype([("kind", "u1"), ("has_normal", "u1"), ("reserved", "<u2"), ("tree", "<u4"), ("left", "<u4"), ("right", "<u4"),
                             ("offset", "<u8"), ("count", "<u4"), ("depth", "<u4")], align=True)
         f = type("OracleForest", (), {})()
         f.n_trees = 1
         f.roots = np.array([self.root], dtype=np.uint32)
-        f.nodes = np.array([(k, hn, 0, l, r, off, cnt, dep) for (k, hn, l, r, off, cnt, dep) in self.nodes], dtype=node_dt)
+        f.nodes = np.array([(k, hn, 0, 0, l, r, off, cnt, dep) for (k, hn, l, r, off, cnt, dep) in self.nodes], dtype=node_dt)
         f.normals = np.frombuffer(self.normals, dtype=np.uint8).copy() if self.normals else np.zeros(0, np.uint8)
         f.normal_stride = self.stride
         f._hdr_off, f._vec_off = 0, 4 * header_floats(data.metric)

@@ -12,9 +12,9 @@ for r in rows:
         cur['cs'] += d
     elif cur is None:
         continue
-    elif 'k_forest_margin_rows' in n:
-        cur['seen'] = True; cur['rows'].append(d); cur['tc'] = re.search(r'<\d+, (\d+)>', n).group(1)
-    elif 'k_forest_margin_f32' in n or 'k_forest_margin_bq' in n:
+    elif 'k_forest_margin_rows' in n or 'k_forest_screen_rows' in n:
+        cur['seen'] = True; cur['rows'].append(d); cur['tc'] = re.search(r'<\d+, (\d+)[,>]', n).group(1)
+    elif 'k_forest_margin_f32' in n or 'k_forest_margin_bq' in n or 'k_forest_screen_node' in n:
         cur['seen'] = True; cur['node'] += d
     elif 'assign_node_of' in n: cur['assign'] += d
     elif 'masks_from_bytes' in n: cur['masks'] += d

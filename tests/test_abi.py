@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 def test_abi_scalars_without_a_gpu():
     from arroy_amd import _lib
     L = _lib.lib()
-    assert L.ah_abi_version() == 1
+    assert L.ah_abi_version() == 2
     assert [L.ah_header_size(m) for m in range(7)] == [4, 4, 4, 8, 4, 4, 4]
     assert L.ah_vector_size(2, 768) == 3072
     assert L.ah_vector_size(6, 768) == 96
@@ -71,7 +71,7 @@ def test_public_headers_are_plain_c99(tmp_path):
     src.write_text(
         '#include "arroy_hip.h"\n#include "arroy_hip_policy.h"\n#include <stdio.h>\n'
         "int main(void) {\n"
-        "  ah_build_options o; ah_forest_view v; ah_build_stats s; (void)o; (void)v; (void)s;\n"
+        "  ah_build_options o; ah_forest_view v; ah_build_stats s; ah_error_detail d; (void)o; (void)v; (void)s; (void)d;\n"
         "  uint64_t a, b; ah_choose_two(ah_node_key_root(42), 0, 10, &a, &b);\n"
         "  if (a == b || a >= 10 || b >= 10) return 2;\n"
         "  if (ah_abi_version() != AH_ABI_VERSION) return 3;\n"

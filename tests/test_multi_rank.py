@@ -45,3 +45,37 @@ def test_bench_two_ranks_over_gloo_dry_run():
     assert j["ms_per_step"] * 3 >= 19.0
     assert j["build"]["trees"] == 5 and j["build"]["trees_this_rank"] == 3
     assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def _run_bench(argv, env_extra=None):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=300,
+                          env=env, cwd=ROOT)
+
+
+def test_bench_gpus_n_started_directly_drives_n_devices_from_one_process_dry_run():
+    """`python bench.py --gpus 2` without a launcher: one process, one host thread per device (the shape of arroy's own
+    single-process build, src/writer.rs:556-591).  --dry-run exercises the control path on CPU."""
+    out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--trees", "5"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and "2 host threads" in j["config"]["launch"]
+    assert j["ms_per_step"] * 3 >= 19.0  # max over the device threads: thread 1 sleeps 20 ms
+    assert j["build"]["trees"] == 5 and j["build"]["trees_this_rank"] == 3
+
+
+def test_bench_refuses_to_run_on_fewer_devices_than_asked():
+    """--gpus N must never silently become a 1-GPU run: fewer visible devices is exit code 3, a launcher world that
+    disagrees with --gpus is exit code 2."""
+    import arroy_amd
+    if arroy_amd.device_count() < 8:
+        out = _run_bench(["--gpus", "8", "--steps", "1", "--warmup", "0", "--no-cpu"])
+        assert out.returncode == 3 and "device(s) visible" in out.stderr
+    out = _run_bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
