@@ -58,18 +58,31 @@ __device__ __forceinline__ void fma_step(float4 &acc, const float4 x, const floa
     }
 }
 
+// Cross-lane moves inside an octet as DPP modifiers (VALU data path): no LDS crossbar round trip (ds_bpermute), which
+// for short rows (128-d: 4 FMA steps) used to cost more than the arithmetic.
+//   0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = quad_perm [2,3,0,1] (lane ^ 2), 0x00 / 0xAA = broadcast lane 0 / 2 of the
+//   quad, 0x141 = row_half_mirror (lane 7 - i of the octet: the other quad)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
 // hsum256 + the 4-accumulator sum, simple_avx.rs:8-13,55-58.  `acc` holds chains 4j..4j+3 of lane j
 // of the octet.  All 8 lanes return the result.
 __device__ __forceinline__ float octet_finish(const float4 acc) {
     // x128[l] = c[l+4] + c[l]: partner lane j^1 holds the other half of the same AVX accumulator.
-    float x0 = f_add(__shfl_xor(acc.x, 1), acc.x);
-    float x1 = f_add(__shfl_xor(acc.y, 1), acc.y);
-    float x2 = f_add(__shfl_xor(acc.z, 1), acc.z);
-    float x3 = f_add(__shfl_xor(acc.w, 1), acc.w);
+    float x0 = f_add(dpp_f32<0xB1>(acc.x), acc.x);
+    float x1 = f_add(dpp_f32<0xB1>(acc.y), acc.y);
+    float x2 = f_add(dpp_f32<0xB1>(acc.z), acc.z);
+    float x3 = f_add(dpp_f32<0xB1>(acc.w), acc.w);
     // x64[0] = x128[0]+x128[2], x64[1] = x128[1]+x128[3]; x32 = x64[0]+x64[1]
     float h = f_add(f_add(x0, x2), f_add(x1, x3));
-    // lanes 2a, 2a+1 hold hsum(acc_a); result = ((h0 + h1) + h2) + h3
-    float h0 = __shfl(h, 0, 8), h1 = __shfl(h, 2, 8), h2 = __shfl(h, 4, 8), h3 = __shfl(h, 6, 8);
+    // lanes 2a, 2a+1 hold hsum(acc_a); result = ((h0 + h1) + h2) + h3.  Inside each quad: lane 0's and lane 2's value;
+    // the other quad's pair through the half-row mirror; the low quad holds (h0, h1), the high quad (h2, h3).
+    const float a = dpp_f32<0x00>(h), b = dpp_f32<0xAA>(h);
+    const float ma = dpp_f32<0x141>(a), mb = dpp_f32<0x141>(b);
+    const bool low = (threadIdx.x & 4u) == 0;
+    const float h0 = low ? a : ma, h1 = low ? b : mb, h2 = low ? ma : a, h3 = low ? mb : b;
     return f_add(f_add(f_add(h0, h1), h2), h3);
 }
 

@@ -779,6 +779,9 @@ __device__ __forceinline__ float rows_exact_margin(const DataView &dv, uint64_t 
 
 // Row-major pass with the screen.  LDS_NORMALS: the shadow records of the group's nodes [first_node, +n_group_nodes) are
 // resident in LDS (top levels); otherwise they come from L2.  The f32 normals (fallback) always come from global memory.
+// The loads of a tree's 8 normal chunks are issued together, ahead of the 32 dot2c that consume them (two independent
+// accumulation chains): the pass is bound by the vector-memory pipeline, so what matters is how many loads a wave keeps
+// in flight, not the arithmetic.
 template <int METRIC, int TC, bool LDS_NORMALS>
 __global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock) void k_forest_screen_rows(
     DataView dv, ScreenView sv, const uint32_t *__restrict__ node_of, uint32_t tree0, uint32_t n_pass,
@@ -800,20 +803,22 @@ __global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock) voi
     const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
     const uint32_t steps = sv.hpitch >> 6;
     const uint32_t stats4 = sv.hpitch >> 3;  // uint4 index of the NormalStats inside a shadow record
+    // all shadow records of the level, as uint4: LDS copy of the group or the global chunk (32-bit indices either way)
+    const uint4 *base4 = LDS_NORMALS ? s_shadow4 : reinterpret_cast<const uint4 *>(shadow);
+    const uint32_t node0 = LDS_NORMALS ? first_node : 0u;
+    const uint32_t last_tree = n_pass - 1;
     uint32_t fallbacks = 0, bad = 0;
     for (uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; row < dv.n; row += n_octets) {
         const uint4 *r4 = reinterpret_cast<const uint4 *>(sv.rows + row * sv.hpitch) + j;
-        const uint4 *n4[TC];
+        uint32_t noff[TC];  // uint4 index of (record of the node that owns the row in tree t) + j
         uint32_t nodes_t[TC];
         float acc[TC];
 #pragma unroll
         for (int t = 0; t < TC; t++) {
-            uint32_t node = 0xFFFFFFFFu;
-            if ((uint32_t)t < n_pass) node = node_of[(uint64_t)(tree0 + t) * dv.n + row];
+            // n_pass == TC except for the last odd tree of a forest (TC = 2, n_pass = 1): the spare slot repeats it
+            const uint32_t node = node_of[(uint64_t)(tree0 + min((uint32_t)t, last_tree)) * dv.n + row];
             nodes_t[t] = node;
-            const uint32_t nn = node != 0xFFFFFFFFu ? node : first_node;
-            n4[t] = LDS_NORMALS ? s_shadow4 + (nn - first_node) * hstride4
-                                : reinterpret_cast<const uint4 *>(shadow + (uint64_t)nn * hstride);
+            noff[t] = (node != 0xFFFFFFFFu ? node - node0 : 0u) * hstride4 + j;
             acc[t] = 0.f;
         }
         uint32_t k = 0;
@@ -822,11 +827,18 @@ __global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock) voi
 #pragma unroll
             for (int u = 0; u < 8; u++) x[u] = ld_stream_u4(r4 + (k + u) * 8);
 #pragma unroll
-            for (int t = 0; t < TC; t++) {
-                if (nodes_t[t] != 0xFFFFFFFFu) {
+            for (int t = 0; t < TC; t++) {  // branch-free: a row that is a leaf in tree t reads record 0 for nothing
+                const uint4 *np = base4 + noff[t] + k * 8;
+                uint4 nv[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) acc[t] = screen_dot8(n4[t][(k + u) * 8 + j], x[u], acc[t]);
+                for (int u = 0; u < 8; u++) nv[u] = np[u * 8];
+                float a0 = acc[t], a1 = 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    a0 = screen_dot8(nv[u], x[u], a0);
+                    a1 = screen_dot8(nv[u + 1], x[u + 1], a1);
                 }
+                acc[t] = a0 + a1;
             }
         }
         if (k + 4 <= steps) {
@@ -835,18 +847,24 @@ __global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock) voi
             for (int u = 0; u < 4; u++) x[u] = ld_stream_u4(r4 + (k + u) * 8);
 #pragma unroll
             for (int t = 0; t < TC; t++) {
-                if (nodes_t[t] != 0xFFFFFFFFu) {
+                const uint4 *np = base4 + noff[t] + k * 8;
+                uint4 nv[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) acc[t] = screen_dot8(n4[t][(k + u) * 8 + j], x[u], acc[t]);
+                for (int u = 0; u < 4; u++) nv[u] = np[u * 8];
+                float a0 = acc[t], a1 = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; u += 2) {
+                    a0 = screen_dot8(nv[u], x[u], a0);
+                    a1 = screen_dot8(nv[u + 1], x[u + 1], a1);
                 }
+                acc[t] = a0 + a1;
             }
             k += 4;
         }
         for (; k < steps; k++) {
             const uint4 x = ld_stream_u4(r4 + k * 8);
 #pragma unroll
-            for (int t = 0; t < TC; t++)
-                if (nodes_t[t] != 0xFFFFFFFFu) acc[t] = screen_dot8(n4[t][k * 8 + j], x, acc[t]);
+            for (int t = 0; t < TC; t++) acc[t] = screen_dot8(base4[noff[t] + k * 8], x, acc[t]);
         }
         const float4 rs = sv.stats[row];
         const float row_extra = METRIC == AH_DOT_PRODUCT ? dv.headers[2 * row] : 0.0f;
@@ -854,7 +872,7 @@ __global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock) voi
         for (int t = 0; t < TC; t++) {
             if (nodes_t[t] != 0xFFFFFFFFu) {
                 const float s = octet_sum(acc[t]);
-                const uint4 raw = n4[t][stats4];
+                const uint4 raw = base4[noff[t] - j + stats4];
                 NormalStats ns;
                 ns.an = __uint_as_float(raw.x);
                 ns.bn = __uint_as_float(raw.y);
@@ -866,10 +884,10 @@ __global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock) voi
                     const uint32_t exact = side_of_margin(
                         rows_exact_margin<METRIC>(dv, row, normals + (uint64_t)nodes_t[t] * nstride, hdr_off, j));
                     if (decided && exact != side) bad++;
-                    if (!decided) fallbacks++;
+                    if (!decided && (uint32_t)t <= last_tree) fallbacks++;
                     side = exact;
                 }
-                if (j == 0) side_bytes[(uint64_t)(tree0 + t) * dv.n + row] = (uint8_t)side;
+                if (j == 0) side_bytes[(uint64_t)(tree0 + min((uint32_t)t, last_tree)) * dv.n + row] = (uint8_t)side;
             }
         }
     }
@@ -1180,24 +1198,36 @@ struct BatchCleanup {  // events / side stream of one batch
     }
 };
 
-// Measured cost of one row-major pass in ns per row of 3072 bytes, as a function of the tree-group size and of the
-// bytes of normals the group streams in the level (profiles/r02_baseline: 10M x 768 x 100 trees, every level forced to
-// one group size).  While the normals fit the L2s a pass is bound by the vector-memory pipeline (one 16-byte load per 4
-// FMAs: 1.6 ns per row for 16 trees); beyond ~11 MB they come through the fabric and every group size converges to
-// (1 + tc) rows' worth of traffic at ~8 TB/s.  Linear interpolation between the measured points.
-double rows_pass_ns_per_row(uint32_t tc, double ws_mb) {
-    struct Pt { double mb, ns; };
-    static const Pt t16[] = {{0.4, 1.60}, {3.2, 1.83}, {6.3, 2.05}, {12.6, 2.33}, {25, 5.08}, {50, 6.05}, {100, 6.5}, {400, 6.8}};
-    static const Pt t8[] = {{0.2, 1.16}, {1.6, 1.22}, {3.2, 2.0}, {6.3, 2.5}, {12.6, 3.1}, {25, 3.5}, {100, 3.7}};
-    static const Pt t4[] = {{0.1, 0.73}, {0.8, 0.85}, {3.2, 0.88}, {6.3, 1.07}, {12.6, 1.45}, {25, 1.85}, {50, 2.05}, {100, 2.14}};
-    static const Pt t2[] = {{0.05, 0.49}, {0.8, 0.60}, {3.1, 0.62}, {6.3, 0.74}, {12.6, 0.99}, {25, 1.14}, {50, 1.21}};
-    const Pt *t = tc >= 16 ? t16 : tc == 8 ? t8 : tc == 4 ? t4 : t2;
-    const size_t n = tc >= 16 ? sizeof t16 / sizeof(Pt) : tc == 8 ? sizeof t8 / sizeof(Pt) : tc == 4 ? sizeof t4 / sizeof(Pt)
-                                                                                                    : sizeof t2 / sizeof(Pt);
-    if (ws_mb <= t[0].mb) return t[0].ns;
-    for (size_t i = 1; i < n; i++)
-        if (ws_mb <= t[i].mb) return t[i - 1].ns + (t[i].ns - t[i - 1].ns) * (ws_mb - t[i - 1].mb) / (t[i].mb - t[i - 1].mb);
-    return t[n - 1].ns;
+// Measured cost of one row-major pass in ns per row, as a function of the tree-group size and of the bytes of normals
+// the group streams in the level (profiles/r02_*: 10M x 768 x 100 trees, every level forced to one group size), for
+// the f32 kernels (rows of 3072 bytes) and for the screened kernels (binary16 rows of 1536 bytes).  While the normals fit
+// the L2s a pass is bound by the vector-memory pipeline — one 16-byte load per 4 FMAs / 4 dot2c — and costs more as the
+// octets of a wave stop sharing normals (deeper levels); beyond ~10 MB they come through the fabric and every group size
+// converges to (1 + tc) rows' worth of traffic at ~8 TB/s.  Linear interpolation between the measured points.
+struct CostPt {
+    double mb, ns;
+};
+template <size_t N>
+double interp(const CostPt (&t)[N], double mb) {
+    if (mb <= t[0].mb) return t[0].ns;
+    for (size_t i = 1; i < N; i++)
+        if (mb <= t[i].mb) return t[i - 1].ns + (t[i].ns - t[i - 1].ns) * (mb - t[i - 1].mb) / (t[i].mb - t[i - 1].mb);
+    return t[N - 1].ns;
+}
+double rows_pass_ns_per_row(uint32_t tc, double ws_mb, bool screened) {
+    static const CostPt e16[] = {{0.4, 1.60}, {3.2, 1.83}, {6.3, 2.05}, {12.6, 2.33}, {25, 5.08}, {50, 6.05}, {100, 6.5}, {400, 6.8}};
+    static const CostPt e8[] = {{0.2, 1.16}, {1.6, 1.22}, {3.2, 2.0}, {6.3, 2.5}, {12.6, 3.1}, {25, 3.5}, {100, 3.7}};
+    static const CostPt e4[] = {{0.1, 0.73}, {0.8, 0.85}, {3.2, 0.88}, {6.3, 1.07}, {12.6, 1.45}, {25, 1.85}, {50, 2.05}, {100, 2.14}};
+    static const CostPt e2[] = {{0.05, 0.49}, {0.8, 0.60}, {3.1, 0.62}, {6.3, 0.74}, {12.6, 0.99}, {25, 1.14}, {50, 1.21}};
+    static const CostPt s16[] = {{0.05, 1.51}, {0.4, 1.61}, {0.8, 1.67}, {1.6, 1.70}, {3.2, 1.81}, {6.4, 2.30}, {12.7, 2.90},
+                                 {25, 3.73}, {51, 4.23}, {102, 4.51}, {203, 4.67}};
+    static const CostPt s8[] = {{0.1, 0.80}, {0.2, 0.87}, {0.4, 0.91}, {0.8, 0.94}, {1.6, 0.96}, {3.2, 0.99}, {6.4, 1.18},
+                                {12.7, 1.73}, {25, 2.15}, {51, 2.40}, {102, 2.54}};
+    static const CostPt s4[] = {{0.01, 0.47}, {0.05, 0.49}, {0.1, 0.57}, {0.2, 0.64}, {0.4, 0.68}, {0.8, 0.70}, {3.2, 0.72},
+                                {6.4, 0.76}, {12.7, 0.85}, {25, 0.98}, {51, 1.05}};
+    static const CostPt s2[] = {{0.01, 0.32}, {0.4, 0.36}, {3.2, 0.39}, {6.4, 0.41}, {12.7, 0.51}, {25, 0.58}};
+    if (screened) return tc >= 16 ? interp(s16, ws_mb) : tc == 8 ? interp(s8, ws_mb) : tc == 4 ? interp(s4, ws_mb) : interp(s2, ws_mb);
+    return tc >= 16 ? interp(e16, ws_mb) : tc == 8 ? interp(e8, ws_mb) : tc == 4 ? interp(e4, ws_mb) : interp(e2, ws_mb);
 }
 
 // index into ah_build_stats.margin_mode_launches
@@ -1691,21 +1721,25 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             // row the HBM read of the row plus row_tc normals through the vector memory pipeline (L2 while the group's
             // normals of the level fit, the fabric beyond), scaled by the share of (row, tree) pairs still splitting,
             // plus the node_of / mask conversion of the level.
-            const double row_b = (double)(screen ? (uint64_t)ds->hpitch * 2 : ds->row_bytes());
+            // costs in ns, for rows of this dataset's size: node-major = one HBM read of the row per (item, tree) pair
+            // (0.47 ns per 3072-byte row at 6.7 TB/s; the screen reads half the bytes)
+            const double scale = screen ? (double)ds->hpitch * 2 / 1536.0 : (double)ds->row_bytes() / 3072.0;
+            const double node_ns = screen ? 0.24 : 0.47;
             const double active = (double)info.pairs / ((double)n_trees * (double)N);
-            const double scale = row_b / 3072.0;
-            const double cost_node = (double)info.pairs * 0.47 * scale;
+            const double cost_node = (double)info.pairs * node_ns * scale;
             const double convert = (double)n_trees * (double)N *
                                    ((prev_rows && g_rows_advance ? 0.007 : 0.01 + 0.03 * std::min(1.0, (double)nodes_per_tree / 256.0)) +
                                     0.012 * std::min(1.0, (double)nodes_per_tree / 512.0));
-            double best = 0.95 * cost_node;
+            double best = 0.97 * cost_node;
             for (uint32_t tc = std::min(16u, g_rows_max_tc); tc >= 2; tc >>= 1) {
                 if (tc > 2 && tc / 2 >= n_trees) continue;  // do not instantiate more slots than trees
                 const double ws_mb = (double)((uint64_t)tc * nodes_per_tree * rec_bytes) / 1e6;
                 if (g_rows_cache_mb > 0 && ws_mb > g_rows_cache_mb) continue;
-                const double passes = (double)((n_trees + tc - 1) / tc);
-                const double full = rows_pass_ns_per_row(tc, ws_mb);
-                const double per_row = 0.45 + (full - 0.45) * std::min(1.0, active * 1.05);
+                // a pass per full group, the last trees in smaller groups (16 + 16 + ... + 4): count them as a fraction
+                const double passes = (double)n_trees / tc;
+                const double full = rows_pass_ns_per_row(tc, ws_mb, screen);
+                const double floor_ns = screen ? 0.23 : 0.45;  // the HBM read of the row alone
+                const double per_row = floor_ns + (full - floor_ns) * std::min(1.0, active * 1.05);
                 const double cost_rows = passes * (double)N * per_row * scale + convert;
                 if (cost_rows < best || (g_rows_force == 1 && row_tc == 0)) {
                     best = std::min(best, cost_rows);
@@ -1720,7 +1754,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         if (rows_allowed && want_lds && (rec_bytes & 15) == 0) {
             tree_first[n_trees] = n_nodes;  // trees without a node in this level start where the next tree starts
             for (uint32_t t = n_trees; t-- > 0;) tree_first[t] = std::min(tree_first[t], tree_first[t + 1]);
-            const uint32_t tc_hi = mode_req == AH_MARGIN_AUTO ? std::min<uint32_t>(16, g_rows_max_tc) : (mode_req & 0xFFu);
+            // measured per tree and row: screened 8-tree groups 0.058 ns, 16-tree groups 0.064; f32 0.070 / 0.061
+            uint32_t tc_hi = mode_req == AH_MARGIN_AUTO ? std::min<uint32_t>(16, g_rows_max_tc) : (mode_req & 0xFFu);
+            if (mode_req == AH_MARGIN_AUTO && screen) tc_hi = std::min<uint32_t>(tc_hi, 8);
             const uint32_t tc_lo = mode_req == AH_MARGIN_AUTO ? 8u : tc_hi;
             for (uint32_t tc = tc_hi; tc >= tc_lo && tc >= 8; tc >>= 1) {
                 uint32_t worst = 0;
@@ -1800,8 +1836,12 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
 #undef AH_ROWS_LDS
                     forest->stats.margin_mode_launches[lds_tc == 16 ? MM_LDS16 : MM_LDS8]++;
                 }
-                for (uint32_t t0 = 0; t0 < n_trees && !lds_tc; t0 += row_tc) {
-                    const uint32_t np = std::min<uint32_t>(row_tc, n_trees - t0);
+                uint32_t passes = 0;
+                for (uint32_t t0 = 0; t0 < n_trees && !lds_tc;) {
+                    // the last trees of the forest take the largest instantiation that they fill (16 + 16 + ... + 4)
+                    uint32_t tcv = row_tc;
+                    while (tcv > 2 && tcv > n_trees - t0) tcv >>= 1;
+                    const uint32_t np = std::min<uint32_t>(tcv, n_trees - t0);
 #define AH_ROWS(M, TCV)                                                                                                    \
     do {                                                                                                                   \
         if (screen)                                                                                                        \
@@ -1813,7 +1853,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                                chunk_d, nstride, hdr_off, side_bytes.p, d_abort);                                          \
     } while (0)
 #define AH_ROWS_TC(M)                       \
-    switch (row_tc) {                       \
+    switch (tcv) {                          \
     case 16: AH_ROWS(M, 16); break;         \
     case 8: AH_ROWS(M, 8); break;           \
     case 4: AH_ROWS(M, 4); break;           \
@@ -1827,12 +1867,15 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     }
 #undef AH_ROWS_TC
 #undef AH_ROWS
-                    forest->stats.margin_mode_launches[mm_rows(row_tc)]++;
+                    forest->stats.margin_mode_launches[mm_rows(tcv)]++;
+                    passes++;
+                    t0 += np;
                 }
                 hipLaunchKernelGGL(k_forest_masks_from_bytes, dim3(tile_grid), dim3(kBlock), 0, s, d_cur, d_tiles.p, n_tiles,
                                    cur, N, side_bytes.p, masks.p, tile_left.p);
-                forest->stats.margin_row_passes += (n_trees + row_tc - 1) / row_tc;
-                if (screen) forest->stats.screened_launches += (n_trees + row_tc - 1) / row_tc;
+                if (lds_tc) passes = (n_trees + lds_tc - 1) / lds_tc;
+                forest->stats.margin_row_passes += passes;
+                if (screen) forest->stats.screened_launches += passes;
             } else if (bq) {
                 hipLaunchKernelGGL(k_forest_margin_bq, dim3(tile_grid), dim3(kBlock), dv.pitch * 8, s, dv, d_cur, d_tiles.p,
                                    n_tiles, cur, N, chunk_d, nstride, hdr_off, masks.p, tile_left.p, d_abort);

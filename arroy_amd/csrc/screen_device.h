@@ -45,9 +45,9 @@ __device__ __forceinline__ uint4 ld_stream_u4(const uint4 *p) {
 
 // sum over the 8 lanes of an octet (any order: the screen's accumulation error is covered by gamma_s)
 __device__ __forceinline__ float octet_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
+    v += dpp_f32<0xB1>(v);   // lane ^ 1
+    v += dpp_f32<0x4E>(v);   // lane ^ 2: every lane of a quad now holds the quad's sum
+    v += dpp_f32<0x141>(v);  // + the other quad of the octet (half-row mirror)
     return v;
 }
 

@@ -11,6 +11,10 @@ Sources (data and expected values only — no reference source code is copied):
   * literal vectors of the SIMD unit tests src/spaces/simple_avx.rs:120-133 and
     src/spaces/simple_sse.rs:120-131.
 The vectors are stored as hex-encoded little-endian f32 so the JSON round-trips bit-exactly.
+  * large_v0_6.mdb — a byte-for-byte copy of the reference's test ASSET src/tests/assets/v0_6/large.mdb (data, not
+    source; 180 224 bytes): tests/test_gpu_staging.py maps it and stages the item records from the pointers a reader
+    would get from LMDB (16-byte page headers, records at odd offsets, 768-byte+ values on overflow pages), which
+    cannot be done on the GPU box from /root/reference (absent there).
 """
 import json
 import os
@@ -65,6 +69,11 @@ def parse_mdb(path):
     walk(main["root"])
     assert len(entries) == main["entries"], (len(entries), main["entries"])
     return entries
+
+
+def copy_assets():
+    import shutil
+    shutil.copyfile(os.path.join(REF, "src/tests/assets/v0_6/large.mdb"), os.path.join(HERE, "large_v0_6.mdb"))
 
 
 def items_of(entries, dims):
@@ -138,6 +147,7 @@ def inline_snapshots(src):
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference not mounted; fixtures are committed, nothing to do")
+    copy_assets()
     large = items_of(parse_mdb(f"{REF}/src/tests/assets/v0_6/large.mdb"), 30)
     smol = items_of(parse_mdb(f"{REF}/src/tests/assets/v0_6/smol.mdb"), 2)
     assert len(large) == 100 and len(smol) == 6
