@@ -2,9 +2,12 @@
 // The forest build lives in forest.hip.  Host code only orchestrates: every arithmetic result comes from
 // a HIP kernel; there is no CPU fallback.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <functional>
+#include <immintrin.h>
 #include <new>
 #include <thread>
 
@@ -90,32 +93,39 @@ class WorkerPool {
         return pool;
     }
     size_t size() const { return threads_.size() + 1; }
-    // fn(part) for part in [0, parts), on the workers and the calling thread; returns when all parts are done
-    void run(size_t parts, const std::function<void(size_t)> &fn) {
-        if (parts <= 1 || threads_.empty()) {
+    // fn(part) for part in [0, parts), on the workers and the calling thread; returns when all parts are done.  If
+    // another caller holds the pool (concurrent readers staging candidate lists), the work simply runs inline.
+    template <typename F>
+    void run(size_t parts, F &&fn) {
+        if (parts <= 1 || threads_.empty() || !run_mu_.try_lock()) {
             for (size_t p = 0; p < parts; p++) fn(p);
             return;
         }
-        std::lock_guard<std::mutex> serial(run_mu_);  // one parallel region at a time
+        std::function<void(size_t)> job = std::ref(fn);
         {
             std::lock_guard<std::mutex> lk(mu_);
-            job_ = &fn;
+            job_ = &job;
             parts_ = parts;
-            next_ = 0;
-            pending_ = parts;
+            next_.store(0, std::memory_order_relaxed);
+            pending_.store(parts, std::memory_order_relaxed);
             generation_++;
         }
         cv_.notify_all();
-        work();
-        std::unique_lock<std::mutex> lk(mu_);
-        done_cv_.wait(lk, [this] { return pending_ == 0; });
-        job_ = nullptr;
+        work(&job, parts);
+        while (pending_.load(std::memory_order_acquire) != 0) std::this_thread::yield();  // slices are ~100 us
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = nullptr;
+        }
+        // a worker may still be between "saw the job" and "took no slice": wait until none holds the pointer
+        while (inside_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+        run_mu_.unlock();
     }
 
    private:
     WorkerPool() {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        unsigned n = std::min(16u, std::max(1u, hw / 2));
+        unsigned n = std::min(12u, std::max(1u, hw / 2));
         if (const char *e = getenv("AH_STAGE_THREADS")) n = (unsigned)std::max(1, atoi(e));
         for (unsigned i = 1; i < n; i++) threads_.emplace_back([this] { loop(); });
     }
@@ -127,49 +137,77 @@ class WorkerPool {
         cv_.notify_all();
         for (auto &t : threads_) t.join();
     }
-    void work() {
+    void work(const std::function<void(size_t)> *job, size_t parts) {
         for (;;) {
-            size_t p;
-            const std::function<void(size_t)> *fn;
-            {
-                std::lock_guard<std::mutex> lk(mu_);
-                if (!job_ || next_ >= parts_) return;
-                p = next_++;
-                fn = job_;
-            }
-            (*fn)(p);
-            {
-                std::lock_guard<std::mutex> lk(mu_);
-                if (--pending_ == 0) done_cv_.notify_all();
-            }
+            const size_t p = next_.fetch_add(1, std::memory_order_relaxed);
+            if (p >= parts) return;
+            (*job)(p);
+            pending_.fetch_sub(1, std::memory_order_release);
         }
     }
     void loop() {
         uint64_t seen = 0;
         for (;;) {
+            const std::function<void(size_t)> *job;
+            size_t parts;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
                 if (stop_) return;
                 seen = generation_;
+                job = job_;
+                parts = parts_;
+                if (!job) continue;
+                inside_.fetch_add(1, std::memory_order_acquire);
             }
-            work();
+            work(job, parts);
+            inside_.fetch_sub(1, std::memory_order_release);
         }
     }
     std::vector<std::thread> threads_;
     std::mutex mu_, run_mu_;
-    std::condition_variable cv_, done_cv_;
+    std::condition_variable cv_;
     const std::function<void(size_t)> *job_ = nullptr;
-    size_t parts_ = 0, next_ = 0, pending_ = 0;
+    size_t parts_ = 0;
+    std::atomic<size_t> next_{0}, pending_{0};
+    std::atomic<int> inside_{0};
     uint64_t generation_ = 0;
     bool stop_ = false;
 };
 
-static constexpr size_t kParallelGrain = 256;  // items (rows, or ids of a candidate list) worth a thread
+// Row copy into the pinned ring with non-temporal stores: the ring is written once and read by the DMA engine, so the
+// destination lines need not be read for ownership nor kept in the host caches (a plain memcpy of 3 KB rows moves 3 bytes
+// per byte staged; this moves 2).  `dst` is 32-byte aligned (ring rows start on 128-byte lines), `src` is arbitrary —
+// LMDB hands out vectors at odd offsets (src/parallel.rs:296-311).
+__attribute__((target("avx2"))) static void copy_row_stream_avx2(uint8_t *dst, const uint8_t *src, size_t bytes) {
+    size_t i = 0;
+    for (; i + 128 <= bytes; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 64));
+        const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 96), d);
+    }
+    for (; i + 32 <= bytes; i += 32)
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i), _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i)));
+    if (i < bytes) memcpy(dst + i, src + i, bytes - i);
+}
+static inline void copy_row(uint8_t *dst, const uint8_t *src, size_t bytes) {
+    static const bool avx2 = __builtin_cpu_supports("avx2") && !getenv("AH_STAGE_MEMCPY");
+    if (avx2 && bytes >= 512 && (reinterpret_cast<uintptr_t>(dst) & 31u) == 0) copy_row_stream_avx2(dst, src, bytes);
+    else memcpy(dst, src, bytes);
+}
+static inline void copy_fence() { _mm_sfence(); }  // non-temporal stores are ordered before the DMA is enqueued
+
+// rows / ids worth a thread: below ~2 MiB in total the copy runs inline (waking workers costs more than it saves)
 template <typename F>
-static void parallel_rows(size_t n, F &&fn) {
+static void parallel_rows(size_t n, size_t bytes_per_item, F &&fn) {
     WorkerPool &pool = WorkerPool::get();
-    const size_t parts = std::min<size_t>(pool.size() * 2, n / kParallelGrain);
+    const size_t total = n * bytes_per_item;
+    const size_t parts = total < (2u << 20) ? 1 : std::min<size_t>(pool.size(), total >> 19);
     if (parts <= 1) {
         fn((size_t)0, n);
         return;
@@ -202,6 +240,14 @@ ah::DataView ah_dataset::view() const {
     return v;
 }
 
+// Contexts (stream + events + pinned / device scratch) of destroyed datasets are kept for the next dataset on the same
+// device: page-locking a staging ring costs ~90 ms per 100 MB (measured), more than staging 1 GB of records.
+namespace {
+std::mutex g_ctx_mu;
+std::vector<std::pair<int, ah::Context *>> g_ctx_cache;  // (device, context); deliberately never destroyed at exit
+constexpr size_t kCtxCacheMax = 4;
+}  // namespace
+
 ah::Context *ah_dataset::acquire() {
     {
         std::lock_guard<std::mutex> lk(mu);
@@ -210,6 +256,15 @@ ah::Context *ah_dataset::acquire() {
             pool.pop_back();
             return c;
         }
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        for (size_t i = g_ctx_cache.size(); i-- > 0;)
+            if (g_ctx_cache[i].first == device) {
+                Context *c = g_ctx_cache[i].second;
+                g_ctx_cache.erase(g_ctx_cache.begin() + (long)i);
+                return c;
+            }
     }
     Context *c = new (std::nothrow) Context();
     if (!c) return nullptr;
@@ -327,8 +382,18 @@ int ah_dataset_destroy(ah_dataset *ds) {
         ds->up_ctx = nullptr;
     }
     for (Context *c : ds->pool) {
-        c->destroy();
-        delete c;
+        bool kept = false;
+        {
+            std::lock_guard<std::mutex> lk(g_ctx_mu);
+            if (g_ctx_cache.size() < kCtxCacheMax && c->h_cap <= (512u << 20) && c->d_cap <= (1u << 30)) {
+                g_ctx_cache.push_back({ds->device, c});
+                kept = true;
+            }
+        }
+        if (!kept) {
+            c->destroy();
+            delete c;
+        }
     }
     ds->pool.clear();
     if (ds->d_rows_h16) (void)hipFree(ds->d_rows_h16);
@@ -443,13 +508,14 @@ int ah_dataset_upload_records(ah_dataset *ds, const uint32_t *item_ids, const ui
             AH_REQUIRE(rec && rec[0] == 0, AH_ERR_INVALID_ARGUMENT, "record %zu is not a leaf (tag %d)", done + i,
                        rec ? rec[0] : -1);
         }
-        parallel_rows(c, [&](size_t lo, size_t hi) {
+        parallel_rows(c, rb + hs, [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; i++) {
                 const uint8_t *rec = record_ptrs[done + i];
                 memcpy(h_hdr + i * hs, rec + 1, hs);
-                memcpy(h_rows + i * rb, rec + 1 + hs, vs);
+                copy_row(h_rows + i * rb, rec + 1 + hs, vs);
                 if (rb > vs) memset(h_rows + i * rb + vs, 0, rb - vs);
             }
+            copy_fence();
         });
         memcpy(h_ids, item_ids + done, c * 4);
         const uint64_t row0 = ds->n + done;
@@ -501,8 +567,16 @@ int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, const fl
     }
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, kStageBytes / (frb + 4)));
     const size_t buf_bytes = pad256(chunk * frb) + pad256(chunk * 4);
+    static const bool timing = getenv("AH_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double>(b - a).count();
+    };
+    const auto t_begin = now();
+    double t_gather = 0, t_wait = 0;
     Context *ctx = nullptr;
     AH_TRY(upload_context(ds, buf_bytes, &ctx));
+    const auto t_ctx = now();
     const size_t ring_stride = ctx->h_cap / kRing & ~(size_t)255;
     if (bq) {
         if (ctx->d_cap < (size_t)kRing * pad256(chunk * frb)) AH_HIP(hipStreamSynchronize(ctx->stream));
@@ -513,15 +587,21 @@ int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, const fl
         const size_t c = std::min(chunk, n - done);
         const int b = ds->up_buf;
         uint8_t *base = reinterpret_cast<uint8_t *>(ctx->h_pinned) + (size_t)b * ring_stride;
+        const auto t0 = now();
         if (ds->up_used[b]) AH_HIP(hipEventSynchronize(ctx->ev_ring[b]));
+        const auto t1 = now();
         float *h_rows = reinterpret_cast<float *>(base);
         uint8_t *h_ids = base + pad256(chunk * frb);
-        parallel_rows(c, [&](size_t lo, size_t hi) {
+        parallel_rows(c, frb, [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; i++) {
-                memcpy(h_rows + i * fpitch, vectors + (done + i) * (size_t)ds->dims, (size_t)ds->dims * 4);
+                copy_row(reinterpret_cast<uint8_t *>(h_rows + i * fpitch),
+                         reinterpret_cast<const uint8_t *>(vectors + (done + i) * (size_t)ds->dims), (size_t)ds->dims * 4);
                 for (uint32_t e = ds->dims; e < fpitch; e++) h_rows[i * fpitch + e] = 0.0f;
             }
+            copy_fence();
         });
+        t_wait += secs(t0, t1);
+        t_gather += secs(t1, now());
         memcpy(h_ids, item_ids + done, c * 4);
         const uint64_t row0 = ds->n + done;
         if (!bq) {
@@ -541,7 +621,12 @@ int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, const fl
         ds->up_buf = (b + 1) % kRing;
         done += c;
     }
+    const auto t_loop = now();
     note_ids(ds, item_ids, n);
+    if (timing)
+        fprintf(stderr, "[ah] upload_vectors %zu x %u: context + pinned ring %.4f s, gather %.4f s, waiting for the ring %.4f s, "
+                        "launch/other %.4f s, note_ids %.4f s\n",
+                n, ds->dims, secs(t_begin, t_ctx), t_gather, t_wait, secs(t_ctx, t_loop) - t_gather - t_wait, secs(t_loop, now()));
     return AH_OK;
 }
 
@@ -959,7 +1044,7 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     // cores (like the staging gather) and sent right away, so the DMA of one slice overlaps the host copy of the next.
     for (uint64_t lo = 0; lo < total; lo += (2u << 20)) {
         const uint64_t len = std::min<uint64_t>(2u << 20, total - lo);
-        parallel_rows(len, [&](size_t a, size_t b) { memcpy(h_ids + lo + a, ids + base + lo + a, (b - a) * 4); });
+        parallel_rows(len, 4, [&](size_t a, size_t b) { memcpy(h_ids + lo + a, ids + base + lo + a, (b - a) * 4); });
         AH_HIP(hipMemcpyAsync(d_ids + lo, h_ids + lo, len * 4, hipMemcpyHostToDevice, s));
     }
     AH_HIP(hipMemsetAsync(d_err, 0, 4, s));

@@ -199,20 +199,34 @@ class Dataset:
         cflag = C.c_int(0)
         opt.cancel = C.pointer(cflag)
         keep = None
-        if cancel is not None or progress is not None:
+        watcher_stop = None
+        if progress is not None:
             def _cb(_user, level, nodes_done, items_routed):
-                if progress is not None:
-                    progress(level, nodes_done, items_routed)
-                if cancel is not None and cancel():
-                    cflag.value = 1
+                progress(level, nodes_done, items_routed)
             keep = _lib.PROGRESS_FN(_cb)
             opt.progress = keep
-            if cancel is not None and cancel():  # polled before the first level too (src/writer.rs:1178)
+        if cancel is not None:
+            # `cancel` is arroy's `Fn() -> bool` (src/writer.rs:100,117-123).  The library polls a flag while the level's
+            # kernels run; a watcher thread evaluates the closure meanwhile (ctypes releases the GIL during the call).
+            import threading
+            if cancel():  # polled before the first level too (src/writer.rs:1178)
                 cflag.value = 1
+            watcher_stop = threading.Event()
+
+            def _watch():
+                while not watcher_stop.wait(0.0005):
+                    if cancel():
+                        cflag.value = 1
+                        return
+            threading.Thread(target=_watch, daemon=True).start()
         opt.max_trees_in_flight = int(max_trees_in_flight)
         opt.margin_mode = int(margin_mode)
         h = C.c_void_p()
-        _lib.check(_lib.lib().ah_build_forest(self._h, C.byref(opt), C.byref(h)))
+        try:
+            _lib.check(_lib.lib().ah_build_forest(self._h, C.byref(opt), C.byref(h)))
+        finally:
+            if watcher_stop is not None:
+                watcher_stop.set()
         return Forest(h, self.distance, self.dimensions)
 
     def build_subtrees(self, id_lists: Sequence[Sequence[int]], tree_seeds: Sequence[int], split_after: int = 0) -> "Forest":

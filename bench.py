@@ -75,17 +75,43 @@ def scan_source_hash():
     return h.hexdigest()[:16]
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, capped by a cgroup CPU quota if there is one (a container
+    that shows 256 CPUs but is limited to a few dozen makes an all-threads OpenMP team thrash)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt and txt[0] != "max":
+            quota = float(txt[0]) / float(txt[1])
+    except OSError:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except OSError:
+            pass
+    info = {"cpu_count": os.cpu_count(), "affinity": n, "cgroup_quota_cpus": quota,
+            "loadavg": list(os.getloadavg()) if hasattr(os, "getloadavg") else None}
+    if quota:
+        n = max(1, min(n, int(quota)))
+    return n, info
+
+
 def cpu_baseline(args, n_items):
     """The oracle timed on the host cores, same workload as the GPU numbers: the Q=1 cosine scan over ALL rows (3 GB:
-    beyond the L3 of the host) and the configs[1] forest build over all rows, as many of the 50 trees as the time budget
-    allows (one tree per thread, every tree a full 1M x 768 build), the rest extrapolated and said so."""
+    beyond the L3 of the host) and the configs[1] forest build over all rows — one tree per thread, the analogue of
+    rayon's scope over the root tasks (src/writer.rs:568-591) — all 50 trees if a probe on a tenth of the rows says it
+    fits the time budget, otherwise as many as fit, the rest extrapolated and said so."""
     import ctypes as C
 
     import numpy as np
 
     from oracle import oracle as O
     L = O.lib()
-    cores = int(L.ao_num_threads())
+    cores, host = usable_cpus()
+    L.ao_set_num_threads(cores)
     n = n_items
     vecs = O.synth(SEED, 1, n, DIMS)
     big = O.Data(O.COSINE, vecs)  # headers = exact norms, computed by the oracle itself (parallel)
@@ -104,27 +130,36 @@ def cpu_baseline(args, n_items):
     res = {"value": scan_rate, "unit": "distances/s", "cores": cores, "kind": "port",
            "sample": f"Q=1 cosine scan over all {n}x{DIMS} rows ({n * DIMS * 4 / 1e9:.1f} GB, data in RAM) x {reps} reps, "
                      f"OpenMP on {cores} threads; C restatement of arroy's AVX2+FMA path (not arroy)",
-           "scan_gb_per_s": scan_rate * BYTES_PER_DISTANCE / 1e9}
+           "scan_gb_per_s": scan_rate * BYTES_PER_DISTANCE / 1e9, "host": host}
     if not args.no_build:
-        # one probe tree bounds the sample: trees run one per thread, so `k` trees take about as long as one while k <= cores
-        seeds_all = np.arange(1, args.trees + 1, dtype=np.uint64)
+        team = max(1, min(cores, args.trees))
+        L.ao_set_num_threads(team)  # n_trees >= team: the oracle runs one tree per thread
+        seeds_all = np.arange(1, max(args.trees, team) + 1, dtype=np.uint64)
+        # probe: `team` trees over a tenth of the rows (a tree over n rows costs ~ n log n row reads)
+        n_probe = max(10_000, n // 10)
+        small = O.Data(O.COSINE, vecs[:n_probe], headers=big.headers[:n_probe])
         t0 = time.perf_counter()
-        ev1 = L.ao_build_forest_count(big.c(), 0, seeds_all[:1].ctypes.data_as(C.c_void_p), 1)
-        one = time.perf_counter() - t0
-        k = args.trees if one * 2.5 < args.cpu_seconds else 0  # 50 concurrent trees share the memory bandwidth
-        total_s, evals = one, ev1
-        if k:
-            t0 = time.perf_counter()
-            evals = L.ao_build_forest_count(big.c(), 0, seeds_all[:k].ctypes.data_as(C.c_void_p), k)
-            total_s = time.perf_counter() - t0
-        trees_timed = k if k else 1
+        L.ao_build_forest_count(small.c(), 0, seeds_all.ctypes.data_as(C.c_void_p), team)
+        probe = time.perf_counter() - t0
+        import math
+        grow = (n / n_probe) * (math.log2(max(2.0, n / DIMS)) / math.log2(max(2.0, n_probe / DIMS)))
+        rounds = math.ceil(args.trees / team)
+        est_full = probe * grow * rounds
+        k = args.trees
+        if est_full > args.cpu_seconds:  # whole rounds of `team` concurrent trees that fit the budget, at least one
+            k = min(args.trees, max(1, int(args.cpu_seconds / (probe * grow))) * team)
+        t0 = time.perf_counter()
+        evals = L.ao_build_forest_count(big.c(), 0, seeds_all.ctypes.data_as(C.c_void_p), k)
+        total_s = time.perf_counter() - t0
         res["build_margins_per_s"] = evals / total_s
         res["build_seconds_measured"] = total_s
-        res["build_trees_measured"] = trees_timed
-        res["build_seconds_config_1"] = total_s if k == args.trees else one * args.trees / min(cores, args.trees) * max(1.0, args.trees / cores)
-        res["build_sample"] = (f"{trees_timed} of the {args.trees} trees of configs[1], each over all {n}x{DIMS} rows (one tree per "
-                               f"thread, {cores} threads): {total_s:.2f} s"
-                               + ("" if k == args.trees else "; build_seconds_config_1 is extrapolated from the single probe tree"))
+        res["build_trees_measured"] = k
+        res["build_threads"] = team
+        res["build_seconds_config_1"] = total_s * (args.trees / k)
+        res["build_sample"] = (f"{k} of the {args.trees} trees of configs[1], each over all {n}x{DIMS} rows, one tree per thread on "
+                               f"{team} threads: {total_s:.2f} s"
+                               + ("" if k == args.trees else f"; build_seconds_config_1 scales it by {args.trees}/{k}"))
+        L.ao_set_num_threads(cores)
     return res
 
 
@@ -250,13 +285,19 @@ def extra_staging(device):
     n = 250_000
     vecs = O.synth(SEED, 1, n, DIMS)
     ids = np.arange(n, dtype=np.uint32)
-    ds = Dataset(distances.Cosine, DIMS, n, device=device)
-    t0 = time.perf_counter()
-    ds.upload_vectors(ids, vecs)
-    ds.finalize()
-    el = time.perf_counter() - t0
-    ds.close()
-    return {"workload": f"{n}x{DIMS} f32 from pageable host memory", "seconds": el, "gb_per_s": n * DIMS * 4 / el / 1e9}
+    out = {"workload": f"{n}x{DIMS} f32 from pageable host memory, upload + finalize"}
+    for run in ("first", "second"):  # the first dataset of a process also pays for the pinned staging ring
+        tc = time.perf_counter()
+        ds = Dataset(distances.Cosine, DIMS, n, device=device)
+        t0 = time.perf_counter()
+        ds.upload_vectors(ids, vecs)
+        t1 = time.perf_counter()
+        ds.finalize()
+        el = time.perf_counter() - t0
+        ds.close()
+        out[run] = {"create_s": t0 - tc, "upload_call_s": t1 - t0, "finalize_s": el - (t1 - t0), "seconds": el,
+                    "gb_per_s": n * DIMS * 4 / el / 1e9}
+    return out
 
 
 def extra_search(device):

@@ -230,8 +230,10 @@ typedef struct ah_build_options {
     uint32_t n_trees;              /* trees built by THIS call (the caller shards trees over GPUs)   */
     uint32_t split_after;          /* 0 = dimensions (src/writer.rs:474-477)                         */
     const uint64_t *tree_seeds;    /* n_trees seeds (src/writer.rs:575: one RNG per root task)       */
-    const volatile int *cancel;    /* polled while a level runs (src/writer.rs:1178,1196 poll per node and per item);
-                                      non-zero -> the kernels in flight drain early -> AH_ERR_CANCELLED */
+    const volatile int *cancel;    /* polled while a level runs (the reference polls per node and per item,
+                                      src/writer.rs:1178,1196): non-zero -> launches that have not started yet drain
+                                      without work, the call returns AH_ERR_CANCELLED when the level's stream is idle
+                                      (at most one level: <= 0.25 s at 10M x 768 x 100 trees) */
     ah_progress_fn progress;       /* may be NULL (src/writer.rs:53-69 SubStep)                      */
     void *progress_user;
     uint32_t max_trees_in_flight;  /* 0 = as many as HBM allows                                      */
