@@ -588,7 +588,10 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     // device scratch (one carve for the whole chunk)
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const uint32_t max_tiles_bound = (uint32_t)(nq * ((size_t)nns_stride / batch_tile_candidates() + 1));
-    const size_t kstride = batch_key_stride(nns_stride);
+    // count <= 2048: the batched tournament top-k; beyond: the single-query kernels, one query after the other (the
+    // reference accepts any count, `Reader::nns(count)`; large counts are rare and not a throughput path)
+    const bool big_k = !batch_supported((uint32_t)std::min<size_t>(k, 0xFFFFFFFFu));
+    const size_t kstride = big_k ? (topk_scratch_bytes(nns_stride, std::min<size_t>(k, nns_stride)) + 15) / 16 : batch_key_stride(nns_stride);
     const uint32_t heap_cap = ix->n_nodes + ix->n_trees + 2;
     size_t dev_bytes = pad(nq * (size_t)ds->dims * 4) + pad(nq * 4) + nq * qstride + pad(nq * 8) + pad(nq * (size_t)nns_stride * 4) * 2 +
                        pad(nq * 4) * 3 + pad(nq * sizeof(HostSeg2)) + pad((size_t)max_tiles_bound * sizeof(HostTile2)) +
@@ -721,14 +724,29 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         h_segs[q] = HostSeg2{(uint64_t)q * nns_stride, n, (uint32_t)std::min<size_t>(k, n)};
         out_counts[q] = h_segs[q].k;
         max_n = std::max(max_n, n);
+        if (big_k) continue;
         max_rounds = std::max(max_rounds, batch_rounds(n, h_segs[q].k));
         for (uint32_t f = 0; f < n; f += tc) h_tiles[n_tiles++] = HostTile2{(uint32_t)q, f};
     }
-    AH_HIP(hipMemcpyAsync(d_segs, h_segs, nq * sizeof(HostSeg2), hipMemcpyHostToDevice, s));
-    if (n_tiles) AH_HIP(hipMemcpyAsync(d_tiles, h_tiles, (size_t)n_tiles * sizeof(HostTile2), hipMemcpyHostToDevice, s));
-    AH_TRY(launch_rerank_batch_prepared(dv, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, n_tiles, d_nns, d_dist,
-                                        d_ka, d_kb, kstride, max_n, (uint32_t)k, max_rounds, d_oi, d_od, d_err, s, n_candidates,
-                                        d_inv));
+    if (big_k) {
+        // d_ka (2 x nq x kstride x 8 bytes >= the single-query scratch) is free: the batch path is not used
+        AH_HIP(hipMemsetAsync(d_oi, 0xFF, nq * k * 4, s));  // padding: id 0xFFFFFFFF / NaN
+        AH_HIP(hipMemsetAsync(d_od, 0xFF, nq * k * 4, s));
+        for (size_t q = 0; q < nq; q++) {
+            const uint32_t n = h_counts[q], kk = h_segs[q].k;
+            if (kk == 0) continue;
+            const uint32_t *ids_q = d_nns + q * (size_t)nns_stride;
+            float *dist_q = d_dist + q * (size_t)nns_stride;
+            AH_TRY(launch_distances(dv, d_qvecs + q * qstride, d_qhdrs + 2 * q, ids_q, n, dist_q, d_err, s));
+            AH_TRY(launch_topk(dv, dist_q, ids_q, n, kk, d_ka, d_oi + q * k, d_od + q * k, s));
+        }
+    } else {
+        AH_HIP(hipMemcpyAsync(d_segs, h_segs, nq * sizeof(HostSeg2), hipMemcpyHostToDevice, s));
+        if (n_tiles) AH_HIP(hipMemcpyAsync(d_tiles, h_tiles, (size_t)n_tiles * sizeof(HostTile2), hipMemcpyHostToDevice, s));
+        AH_TRY(launch_rerank_batch_prepared(dv, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, n_tiles, d_nns, d_dist,
+                                            d_ka, d_kb, kstride, max_n, (uint32_t)k, max_rounds, d_oi, d_od, d_err, s,
+                                            n_candidates, d_inv));
+    }
     AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
     AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
     AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
@@ -795,8 +813,7 @@ int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_it
                "exactly one of queries / query_items must be given");
     AH_REQUIRE(out_ids && out_distances && out_counts, AH_ERR_INVALID_ARGUMENT, "NULL output");
     if (nq == 0) return AH_OK;
-    AH_REQUIRE(count > 0 && batch_supported((uint32_t)std::min<size_t>(count, 0xFFFFFFFFu)), AH_ERR_INVALID_ARGUMENT,
-               "count must be in 1..=2048 for the batched search");
+    AH_REQUIRE(count > 0 && count < 0x7FFFFFFFull, AH_ERR_INVALID_ARGUMENT, "count must be > 0");
     AH_HIP(hipSetDevice(ds->device));
     for (size_t i = 0; i < nq * count; i++) {
         out_ids[i] = 0xFFFFFFFFu;
@@ -859,7 +876,10 @@ int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_it
         }
     }
     // sub-batches bounded by scratch (~1.5 GiB of candidate buffers)
-    const size_t per_query = (size_t)stride * 8 + 2 * batch_key_stride((uint32_t)stride) * 8 + ds->row_bytes() + 4096;
+    const size_t key_bytes = batch_supported((uint32_t)std::min<size_t>(count, 0xFFFFFFFFu))
+                                 ? 2 * batch_key_stride((uint32_t)stride) * 8
+                                 : topk_scratch_bytes(stride, std::min<size_t>(count, stride)) + 64;
+    const size_t per_query = (size_t)stride * 8 + key_bytes + count * 8 + ds->row_bytes() + 4096;
     size_t chunk = std::max<size_t>(1, std::min<size_t>(nq, (1536ull << 20) / per_query));
     chunk = std::min<size_t>(chunk, 4096);
     int st = AH_OK;

@@ -332,7 +332,8 @@ AH_API int ah_index_destroy(ah_index *index);
 /* `QueryBuilder::by_vector` (queries = nq x dims f32, query_items = NULL) or `by_item` (queries = NULL,
  * query_items = nq ids) with `search_k` (0 = count * n_trees, src/reader.rs:330), `oversampling`
  * (0 = D::DEFAULT_OVERSAMPLING) and optional `candidates` (have_filter != 0: ascending ids).
- * count <= 2048.  Outputs nq x count, padded with id 0xFFFFFFFF / NaN; out_counts[q] = results of query q. */
+ * Any count (`Reader::nns(count)`); counts above 2048 leave the batched top-k for the single-query kernels, query by
+ * query.  Outputs nq x count, padded with id 0xFFFFFFFF / NaN; out_counts[q] = results of query q. */
 AH_API int ah_search_batch(ah_index *index, const float *queries, const uint32_t *query_items, size_t nq, size_t count,
                            size_t search_k, size_t oversampling, const uint32_t *filter_sorted, size_t n_filter,
                            int have_filter, uint32_t *out_ids, float *out_distances, uint32_t *out_counts);

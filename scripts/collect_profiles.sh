@@ -1,17 +1,28 @@
 #!/bin/bash
-# Run on the GPU box (gpurun -- bash scripts/collect_profiles.sh): the judged bench line, its rocprofv3 kernel summary,
-# the two PMC passes (FETCH_SIZE / WRITE_SIZE, each in its own run, no trace domains besides the kernel trace), and the
-# extra configurations.  Everything lands in gpurun_out/profiles/ and is copied into profiles/ by hand afterwards.
+# Run on the GPU box (gpurun -- bash scripts/collect_profiles.sh r02): the judged bench line, its rocprofv3 kernel summary,
+# the PMC passes of the scan kernel (FETCH_SIZE / WRITE_SIZE, each in its own run, no trace domain besides the kernel trace)
+# and the per-level breakdown of the 10M build.  Everything lands in gpurun_out/profiles/ and is copied into profiles/ by
+# hand afterwards (scripts/pmc_scan_json.py writes the traffic file bench.py reads, stamped with the kernel-source hash).
 set -u
+R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles
 mkdir -p $OUT
-python bench.py --steps 50 --warmup 5 2>$OUT/bench.err | tail -1 > $OUT/bench.json
+python bench.py --steps 50 --warmup 5 2>$OUT/${R}_bench.err | tail -1 > $OUT/${R}_bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python bench.py --steps 50 --warmup 5 --no-cpu --no-build-10m > $OUT/kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python bench.py --steps 5 --warmup 1 --no-cpu --no-build-10m > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python bench.py --steps 5 --warmup 1 --no-cpu --no-build-10m > $OUT/write.log 2>&1
-python bench.py --steps 20 --warmup 3 --no-cpu --extra c3,c4,c5,search,staging 2>$OUT/extra.err | tail -1 > $OUT/bench_extra.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktx -o ktx -- python bench.py --steps 5 --warmup 1 --no-cpu --no-build --extra c3,c4,c5,search > $OUT/ktx.log 2>&1
-python scripts/level_trace.py $OUT/ktx/ktx_kernel_trace.csv > $OUT/c3_levels.txt 2>&1
-rm -f $OUT/kt/kt_kernel_trace.csv $OUT/ktx/ktx_kernel_trace.csv   # large; the stats files are the summaries
-ls -la $OUT $OUT/*
+cp $OUT/kt/kt_kernel_stats.csv $OUT/${R}_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python bench.py --steps 5 --warmup 1 --no-cpu --no-build --no-extra > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python bench.py --steps 5 --warmup 1 --no-cpu --no-build --no-extra > $OUT/write.log 2>&1
+python scripts/pmc_summary.py $OUT/fetch/fetch_counter_collection.csv | grep -v "^[0-9]" > $OUT/${R}_pmc_fetch_size.csv
+python scripts/pmc_summary.py $OUT/write/write_counter_collection.csv | grep -v "^[0-9]" > $OUT/${R}_pmc_write_size.csv
+python scripts/pmc_scan_json.py $OUT/${R}_pmc_fetch_size.csv $OUT/${R}_pmc_write_size.csv > $OUT/${R}_pmc_scan.json
+# per-level breakdown of the 10M x 768 x 100-tree build: default (screened) and f32 only
+for mode in screened f32; do
+  if [ $mode = f32 ]; then export AH_SCREEN=0; else unset AH_SCREEN; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$mode -o kt -- python scripts/exp_build.py 10000000 100 > $OUT/${R}_build10m_${mode}.log 2>&1
+  python scripts/level_trace.py $OUT/kt_$mode/kt_kernel_trace.csv > $OUT/${R}_forest_levels_${mode}.txt 2>&1
+  cp $OUT/kt_$mode/kt_kernel_stats.csv $OUT/${R}_build10m_${mode}_kernel_stats.csv
+done
+unset AH_SCREEN
+rm -rf $OUT/kt $OUT/fetch $OUT/write $OUT/kt_screened $OUT/kt_f32
+ls -la $OUT

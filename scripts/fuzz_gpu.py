@@ -24,13 +24,13 @@ T.D, T.O = D, O  # the test module imports these lazily through a fixture
 def one(rng, it):
     metric = int(rng.integers(0, 7))
     cls = D.BY_METRIC[metric]
-    dims = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 96, 100, 127, 128, 200, 257]))
-    n = int(rng.choice([1, 2, 7, 64, 65, 300, 1000, 2049, 5000]))
+    dims = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 96, 100, 127, 128, 200, 257, 520, 768]))
+    n = int(rng.choice([1, 2, 7, 64, 65, 300, 1000, 2049, 5000, 12000]))
     ids = None
     if rng.random() < 0.4:
         span = int(n * rng.choice([2, 50, 100000]))
         ids = np.sort(rng.choice(max(span, n + 1), n, replace=False)).astype(np.uint32)
-    scale = float(rng.choice([1.0, 1.0, 1e-3, 1e3]))
+    scale = float(rng.choice([1.0, 1.0, 1e-3, 1e3, 1e-6, 3e4]))  # the last two leave the binary16 range of the screen
     ds, oracle, vecs, ids = T.make_data(cls, n, dims, seed=int(rng.integers(1 << 30)), ids=ids, scale=scale)
     desc = f"it={it} metric={metric} n={n} dims={dims} sparse={ids[-1] != n - 1} scale={scale}"
     q = (rng.standard_normal(dims) * scale).astype(np.float32)
@@ -72,13 +72,17 @@ def one(rng, it):
         assert np.array_equal(sides, es) and n_left == el, desc + " sides"
     # forest + search + routing
     split_after = int(rng.choice([0, 1, 2, 8, 50, 300]))
-    seeds = [int(x) for x in rng.integers(0, 2**63, int(rng.integers(1, 4)))]
-    forest = ds.build_forest(seeds, split_after=split_after)
+    seeds = [int(x) for x in rng.integers(0, 2**63, int(rng.choice([1, 2, 3, 9, 17])))]
+    # every margin-kernel family, with and without the certified binary16 screen (ah_margin_mode)
+    mode = int(rng.choice([0, 0, 1, 2, 4, 8, 16, 0x108, 0x110])) | (0x1000 if rng.random() < 0.3 else 0)
+    forest = ds.build_forest(seeds, split_after=split_after, margin_mode=mode)
+    desc += f" mode={mode:#x} trees={len(seeds)}"
+    assert forest.stats["screen_violations"] == 0
     T.check_forest_valid(forest, n, ids=ids)
     for t, seed in enumerate(seeds):
         assert forest.canonical(t) == oracle.build_tree(split_after, seed).canonical(), desc + f" tree {t} sa={split_after}"
     index = ds.create_index(forest)
-    count, search_k = int(rng.choice([1, 10, 200])), int(rng.choice([0, 1, 100, 2**62]))
+    count, search_k = int(rng.choice([1, 10, 200, 2500])), int(rng.choice([0, 1, 100, 2**62]))
     got = index.search(count, queries=qs[: min(nq, 4)], search_k=search_k)
     for i in range(min(nq, 4)):
         v, h = oracle.query_leaf(qs[i])

@@ -269,3 +269,22 @@ def test_build_is_cancelled_within_a_level():
         latency = time.perf_counter() - fired["t"]
         assert latency < 1.5 * level_s, f"cancel took {latency * 1e3:.1f} ms, a level runs {level_s * 1e3:.1f} ms"
     ds.close()
+
+
+def test_search_accepts_counts_beyond_the_batched_top_k():
+    """`Reader::nns(count)` takes any count (src/reader.rs:296-315); above 2048 the device search leaves the batched
+    tournament top-k for the single-query kernels.  Same results as the oracle's `nns_by_leaf`, short lists padded."""
+    ds, oracle, vecs, ids = make_data(D.Euclidean, 9000, 48, seed=8)
+    forest = ds.build_forest([1, 2, 3], split_after=64)
+    index = ds.create_index(forest)
+    queries = vecs[:3] + np.float32(0.01)
+    for count, search_k in [(3000, 5000), (2049, 2**62), (12000, 2**62)]:
+        got = index.search(count, queries=queries, search_k=search_k)
+        for qi in range(len(queries)):
+            qv, qh = oracle.query_leaf(queries[qi])
+            want, _ = O.search(oracle, forest, qv, qh, count, search_k, 0, None)
+            assert [i for i, _ in got[qi]] == [i for i, _ in want]
+            assert_bit_equal([d for _, d in got[qi]], [d for _, d in want])
+        ids_raw, d_raw, counts = index.search(count, queries=queries, search_k=search_k, raw=True)
+        for qi in range(len(queries)):
+            assert np.all(ids_raw[qi, counts[qi]:] == 0xFFFFFFFF) and np.all(np.isnan(d_raw[qi, counts[qi]:]))
