@@ -10,7 +10,8 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libarroy_hip.so")
+# AH_LIB_PATH: load another build of the library (A/B measurements of kernel variants); default: the in-tree build
+LIB_PATH = os.environ.get("AH_LIB_PATH") or os.path.join(HERE, "libarroy_hip.so")
 CSRC = os.path.join(HERE, "csrc")
 
 # ah_status (include/arroy_hip.h) -> arroy::Error (src/error.rs:6-85)

@@ -787,13 +787,44 @@ __device__ __forceinline__ float rows_exact_margin(const DataView &dv, uint64_t 
     return d;
 }
 
+#ifndef AH_SCREEN_CHUNK
+#define AH_SCREEN_CHUNK 8
+#endif
+// NS steps (64 dims each) of one row against the normals of TC trees.  Branch-free over the trees (a row that is already
+// a leaf in tree t reads record 0 for nothing): the loads of a tree's NS chunks are issued together and the compiler is
+// free to run ahead into the next trees, so a wave keeps dozens of 16-byte loads in flight.
+template <int TC, int NS>
+__device__ __forceinline__ void screen_rows_chunk(float (&acc)[TC], const uint4 *base4, const uint32_t (&noff)[TC],
+                                                  const uint4 *r4, uint32_t k) {
+    uint4 x[NS];
+#pragma unroll
+    for (int u = 0; u < NS; u++) x[u] = ld_stream_u4(r4 + (k + u) * 8);
+#pragma unroll
+    for (int t = 0; t < TC; t++) {
+        const uint4 *np = base4 + noff[t] + k * 8;
+        uint4 nv[NS];
+#pragma unroll
+        for (int u = 0; u < NS; u++) nv[u] = np[u * 8];
+        float a0 = acc[t], a1 = 0.f;
+#pragma unroll
+        for (int u = 0; u < NS; u += 2) {
+            a0 = screen_dot8(nv[u], x[u], a0);
+            a1 = screen_dot8(nv[u + 1], x[u + 1], a1);
+        }
+        acc[t] = a0 + a1;
+    }
+}
+
 // Row-major pass with the screen.  LDS_NORMALS: the shadow records of the group's nodes [first_node, +n_group_nodes) are
 // resident in LDS (top levels); otherwise they come from L2.  The f32 normals (fallback) always come from global memory.
 // The loads of a tree's 8 normal chunks are issued together, ahead of the 32 dot2c that consume them (two independent
 // accumulation chains): the pass is bound by the vector-memory pipeline, so what matters is how many loads a wave keeps
 // in flight, not the arithmetic.
+#ifndef AH_SCREEN_WAVES
+#define AH_SCREEN_WAVES 1  // minimum waves per SIMD the compiler must leave room for (caps the VGPRs of the global variant)
+#endif
 template <int METRIC, int TC, bool LDS_NORMALS>
-__global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock) void k_forest_screen_rows(
+__global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock, LDS_NORMALS ? 1 : AH_SCREEN_WAVES) void k_forest_screen_rows(
     DataView dv, ScreenView sv, const uint32_t *__restrict__ node_of, uint32_t tree0, uint32_t n_pass,
     const uint8_t *__restrict__ normals, uint64_t nstride, uint64_t hdr_off, const uint8_t *__restrict__ shadow,
     uint64_t hstride, uint8_t *__restrict__ side_bytes, uint32_t first_node, uint32_t n_group_nodes,
@@ -831,46 +862,17 @@ __global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock) voi
             noff[t] = (node != 0xFFFFFFFFu ? node - node0 : 0u) * hstride4 + j;
             acc[t] = 0.f;
         }
+        // chunks of AH_SCREEN_CHUNK steps (64 dims each), then of 4, then single steps.  Measured on 10M x 768 (12 steps):
+        // 8 + 4 beats a single chunk of 12 (the extra 16 row registers cost a wave of occupancy per SIMD: 7.7 -> 10.8 ms
+        // per 8-tree pass) — the pass is bound by loads in flight per CU, and occupancy buys more of them than unrolling.
         uint32_t k = 0;
-        for (; k + 8 <= steps; k += 8) {
-            uint4 x[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) x[u] = ld_stream_u4(r4 + (k + u) * 8);
-#pragma unroll
-            for (int t = 0; t < TC; t++) {  // branch-free: a row that is a leaf in tree t reads record 0 for nothing
-                const uint4 *np = base4 + noff[t] + k * 8;
-                uint4 nv[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) nv[u] = np[u * 8];
-                float a0 = acc[t], a1 = 0.f;
-#pragma unroll
-                for (int u = 0; u < 8; u += 2) {
-                    a0 = screen_dot8(nv[u], x[u], a0);
-                    a1 = screen_dot8(nv[u + 1], x[u + 1], a1);
-                }
-                acc[t] = a0 + a1;
-            }
-        }
+        for (; k + AH_SCREEN_CHUNK <= steps; k += AH_SCREEN_CHUNK) screen_rows_chunk<TC, AH_SCREEN_CHUNK>(acc, base4, noff, r4, k);
+#if AH_SCREEN_CHUNK > 4
         if (k + 4 <= steps) {
-            uint4 x[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) x[u] = ld_stream_u4(r4 + (k + u) * 8);
-#pragma unroll
-            for (int t = 0; t < TC; t++) {
-                const uint4 *np = base4 + noff[t] + k * 8;
-                uint4 nv[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) nv[u] = np[u * 8];
-                float a0 = acc[t], a1 = 0.f;
-#pragma unroll
-                for (int u = 0; u < 4; u += 2) {
-                    a0 = screen_dot8(nv[u], x[u], a0);
-                    a1 = screen_dot8(nv[u + 1], x[u + 1], a1);
-                }
-                acc[t] = a0 + a1;
-            }
+            screen_rows_chunk<TC, 4>(acc, base4, noff, r4, k);
             k += 4;
         }
+#endif
         for (; k < steps; k++) {
             const uint4 x = ld_stream_u4(r4 + k * 8);
 #pragma unroll
