@@ -13,7 +13,7 @@ for r in rows:
     elif cur is None:
         continue
     elif 'k_forest_margin_rows' in n or 'k_forest_screen_rows' in n:
-        cur['seen'] = True; cur['rows'].append(d); cur['tc'] = re.search(r'<\d+, (\d+)[,>]', n).group(1)
+        cur['seen'] = True; cur['rows'].append(d); cur['tc'] = max(int(re.search(r'<\d+, (\d+)[,>]', n).group(1)), cur['tc'] or 0)
     elif 'k_forest_margin_f32' in n or 'k_forest_margin_bq' in n or 'k_forest_screen_node' in n:
         cur['seen'] = True; cur['node'] += d
     elif 'assign_node_of' in n: cur['assign'] += d
