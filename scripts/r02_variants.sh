@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r02m
+OUT=gpurun_out/r02_variants
 mkdir -p $OUT
 run_kt () { # name, env...
   local name=$1; shift
