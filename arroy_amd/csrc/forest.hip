@@ -21,6 +21,7 @@
 #include <deque>
 #include <thread>
 #include <cstdlib>
+#include <immintrin.h>
 #include <new>
 
 #include "common.h"
@@ -1308,17 +1309,41 @@ struct Readback {
         started = true;
         th = std::thread([this] { run(); });
     }
-    static void spread(uint8_t *dst, const uint8_t *src, size_t bytes) {  // memcpy on up to 8 cores
+    // pinned bounce buffer -> final place, with non-temporal stores: the destination is written once and read much
+    // later by the caller, so its lines need neither be read for ownership nor stay in the host caches
+    __attribute__((target("avx2"))) static void copy_stream(uint8_t *dst, const uint8_t *src, size_t bytes) {
+        size_t i = 0;
+        const size_t head = std::min<size_t>(bytes, (32 - (reinterpret_cast<uintptr_t>(dst) & 31u)) & 31u);
+        if (head) memcpy(dst, src, head);
+        for (i = head; i + 128 <= bytes; i += 128) {
+            const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i));
+            const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 32));
+            const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 64));
+            const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i + 96));
+            _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i), a);
+            _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 32), b);
+            _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 64), c);
+            _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + i + 96), d);
+        }
+        if (i < bytes) memcpy(dst + i, src + i, bytes - i);
+        _mm_sfence();
+    }
+    static void copy_part(uint8_t *dst, const uint8_t *src, size_t bytes) {
+        static const bool avx2 = __builtin_cpu_supports("avx2");
+        if (avx2 && bytes >= 4096) copy_stream(dst, src, bytes);
+        else memcpy(dst, src, bytes);
+    }
+    static void spread(uint8_t *dst, const uint8_t *src, size_t bytes) {  // copy on up to 8 cores
         const size_t n_threads = std::min<size_t>(8, bytes >> 20);
         if (n_threads <= 1) {
-            memcpy(dst, src, bytes);
+            copy_part(dst, src, bytes);
             return;
         }
         std::vector<std::thread> pool;
         const size_t per = ((bytes + n_threads - 1) / n_threads + 4095) & ~(size_t)4095;
         for (size_t lo = 0; lo < bytes; lo += per) {
             const size_t len = std::min(per, bytes - lo);
-            pool.emplace_back([=] { memcpy(dst + lo, src + lo, len); });
+            pool.emplace_back([=] { copy_part(dst + lo, src + lo, len); });
         }
         for (auto &t : pool) t.join();
     }
@@ -1850,10 +1875,15 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                 }
                 uint32_t passes = 0;
                 for (uint32_t t0 = 0; t0 < n_trees && !lds_tc;) {
-                    // the last trees of the forest take the largest instantiation that they fill (16 + 16 + ... + 4)
+                    // The last trees of the forest take the largest instantiation that they fill (16 + 16 + ... + 4), or the
+                    // next larger one when only a few of its slots would idle (13 trees: one 16-slot pass, measured 15 ms,
+                    // instead of 8 + 4 + 1: 18-23 ms; spare slots repeat the last tree).
+                    const uint32_t rem = n_trees - t0;
                     uint32_t tcv = row_tc;
-                    while (tcv > 2 && tcv > n_trees - t0) tcv >>= 1;
-                    const uint32_t np = std::min<uint32_t>(tcv, n_trees - t0);
+                    while (tcv > 2 && tcv > rem) tcv >>= 1;
+                    for (uint32_t up = tcv << 1; up <= row_tc && tcv < rem; up <<= 1)
+                        if (up >= rem && up - rem <= (up >= 16 ? 3u : 1u)) tcv = up;
+                    const uint32_t np = std::min<uint32_t>(tcv, rem);
 #define AH_ROWS(M, TCV)                                                                                                    \
     do {                                                                                                                   \
         if (screen)                                                                                                        \
@@ -2012,44 +2042,70 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     forest->stats.seconds_device += ms * 1e-3;
 
     // Emit per tree in post-order (children before parents: the order TmpNodes::put receives them,
-    // src/writer.rs:1235-1258), with forest-local indices.
+    // src/writer.rs:1235-1258), with forest-local indices.  Trees are independent: the number of nodes of every tree
+    // is known (counted while the levels were digested), so each tree is written into its own slice by a few threads.
+    std::vector<uint64_t> tree_nodes(n_trees + 1, 0);
+    for (const HostRec &r : recs) tree_nodes[r.tree + 1]++;
+    for (uint32_t t = 0; t < n_trees; t++) tree_nodes[t + 1] += tree_nodes[t];
+    const size_t node_base = forest->nodes.size();
+    forest->nodes.resize(node_base + recs.size());
+    forest->roots.resize(forest->roots.size() + n_trees);
+    uint32_t *roots_out = forest->roots.data() + (forest->roots.size() - n_trees);
     std::vector<uint32_t> new_index(recs.size(), 0xFFFFFFFFu);
-    std::vector<std::pair<uint32_t, int>> stack;
-    forest->nodes.reserve(forest->nodes.size() + recs.size());
-    for (uint32_t t = 0; t < n_trees; t++) {
-        stack.clear();
-        stack.push_back({tree_root[t], 0});
-        while (!stack.empty()) {
-            const uint32_t ri = stack.back().first;
-            const HostRec &r = recs[ri];
-            if (r.kind == AH_NODE_SPLIT && stack.back().second == 0) {
-                stack.back().second = 1;
-                const uint32_t l = r.left, rr = r.right;
-                stack.push_back({rr, 0});
-                stack.push_back({l, 0});
-                continue;
+    std::atomic<uint64_t> n_split{0}, n_desc{0};
+    std::atomic<uint32_t> next_tree{0};
+    auto emit_trees = [&] {
+        std::vector<std::pair<uint32_t, int>> stack;
+        uint64_t splits = 0, descs = 0;
+        for (;;) {
+            const uint32_t t = next_tree.fetch_add(1, std::memory_order_relaxed);
+            if (t >= n_trees) break;
+            uint64_t out = node_base + tree_nodes[t];
+            stack.clear();
+            stack.push_back({tree_root[t], 0});
+            while (!stack.empty()) {
+                const uint32_t ri = stack.back().first;
+                const HostRec &r = recs[ri];
+                if (r.kind == AH_NODE_SPLIT && stack.back().second == 0) {
+                    stack.back().second = 1;
+                    const uint32_t l = r.left, rr = r.right;
+                    stack.push_back({rr, 0});
+                    stack.push_back({l, 0});
+                    continue;
+                }
+                ah_node nd{};
+                nd.kind = r.kind;
+                nd.has_normal = r.has_normal;
+                nd.tree = first_tree + t;
+                nd.count = r.count;
+                nd.depth = r.depth;
+                if (r.kind == AH_NODE_SPLIT) {
+                    nd.left = new_index[r.left];
+                    nd.right = new_index[r.right];
+                    nd.offset = r.normal_off;
+                    splits++;
+                } else {
+                    nd.offset = desc_base + r.start;
+                    descs++;
+                }
+                new_index[ri] = (uint32_t)out;
+                forest->nodes[out++] = nd;
+                stack.pop_back();
             }
-            ah_node nd{};
-            nd.kind = r.kind;
-            nd.has_normal = r.has_normal;
-            nd.tree = first_tree + t;
-            nd.count = r.count;
-            nd.depth = r.depth;
-            if (r.kind == AH_NODE_SPLIT) {
-                nd.left = new_index[r.left];
-                nd.right = new_index[r.right];
-                nd.offset = r.normal_off;
-                forest->stats.split_nodes++;
-            } else {
-                nd.offset = desc_base + r.start;
-                forest->stats.descendant_nodes++;
-            }
-            new_index[ri] = (uint32_t)forest->nodes.size();
-            forest->nodes.push_back(nd);
-            stack.pop_back();
+            roots_out[t] = new_index[tree_root[t]];
         }
-        forest->roots.push_back(new_index[tree_root[t]]);
+        n_split.fetch_add(splits, std::memory_order_relaxed);
+        n_desc.fetch_add(descs, std::memory_order_relaxed);
+    };
+    {
+        const size_t n_threads = recs.size() < 200000 ? 1 : std::min<size_t>({(size_t)n_trees, 8, std::max(1u, std::thread::hardware_concurrency())});
+        std::vector<std::thread> pool;
+        for (size_t i = 1; i < n_threads; i++) pool.emplace_back(emit_trees);
+        emit_trees();
+        for (auto &th : pool) th.join();
     }
+    forest->stats.split_nodes += n_split.load();
+    forest->stats.descendant_nodes += n_desc.load();
     const auto t_emitted = std::chrono::steady_clock::now();
     AH_REQUIRE(rb.drain() == hipSuccess, AH_ERR_DEVICE, "device -> host copy of the forest failed");
     forest->normals_len = normals_base + normals_bytes;

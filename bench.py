@@ -60,7 +60,8 @@ def parse_args():
     ap.add_argument("--no-extra", action="store_true", help="skip configs[3] / configs[4] / on-device search")
     ap.add_argument("--cpu-seconds", type=float, default=45.0, help="budget of the CPU baseline (bounds the build sample)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: test the N>1 control paths on CPU")
-    ap.add_argument("--extra", default="", help="comma list of further measurements: metrics (every f32 metric), staging")
+    ap.add_argument("--extra", default="", help="comma list of further measurements: metrics (every f32 metric), staging, "
+                                               "e2e (10M x 768 staged from host memory + 100-tree build)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
     return ap.parse_args()
@@ -300,6 +301,35 @@ def extra_staging(device):
     return out
 
 
+def extra_e2e(device, n=10_000_000, trees=100):
+    """Cold build end to end on one GPU: 10M x 768 f32 vectors staged from pageable host memory (pinned ring, PCIe), then
+    the 100-tree forest of configs[2].  Staging and build are timed separately (the build needs the finalized dataset)."""
+    import numpy as np
+
+    from arroy_amd import Dataset, distances, shard
+    from oracle import oracle as O
+    chunk = 1_000_000
+    try:
+        parts = [O.synth(SEED, 1, min(chunk, n - lo), DIMS, first_item=lo) for lo in range(0, n, chunk)]
+    except MemoryError:
+        return {"skipped": "host memory"}
+    ds = Dataset(distances.Cosine, DIMS, n, device=device)
+    t0 = time.perf_counter()
+    for i, p in enumerate(parts):
+        ds.upload_vectors(np.arange(i * chunk, i * chunk + len(p), dtype=np.uint32), p)
+    t1 = time.perf_counter()
+    ds.finalize()
+    t2 = time.perf_counter()
+    forest = ds.build_forest(shard.tree_seeds(SEED, range(trees)))
+    t3 = time.perf_counter()
+    out = {"workload": f"{n}x{DIMS} cosine from pageable host memory, n_trees={trees}, one GPU, cold (first build of the dataset)",
+           "staging_s": t2 - t0, "staging_calls_s": t1 - t0, "staging_gb_per_s": n * DIMS * 4 / (t2 - t0) / 1e9,
+           "build_s": t3 - t2, "total_s": t3 - t0}
+    forest.close()
+    ds.close()
+    return out
+
+
 def extra_search(device):
     """End-to-end on-device search on the configs[3] shape: 1M x 1536 dot product, 20 trees, 1000 by-vector queries,
     count=100, search_k=10000: descent + candidate collection + sort/dedup + re-rank + top-k (src/reader.rs:317-401)."""
@@ -474,6 +504,8 @@ def device_work(args, rank, world, device, sync, ds_1m, result):
             extra["metrics"] = extra_metrics(device)
         if "staging" in wanted:
             extra["staging"] = extra_staging(device)
+        if "e2e" in wanted:
+            extra["e2e"] = extra_e2e(device)
         result["extra"] = extra
 
 
