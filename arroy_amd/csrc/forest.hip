@@ -1924,9 +1924,15 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                 forest->stats.margin_mode_launches[MM_BQ]++;
             } else if (screen) {
                 const size_t sh = (size_t)dv.pitch * 4 + (size_t)sv.hpitch * 2;
-#define AH_LAUNCH(M)                                                                                                  \
-    hipLaunchKernelGGL((k_forest_screen_node<M>), dim3(tile_grid), dim3(kBlock), sh, s, dv, sv, d_cur, d_tiles.p, n_tiles, \
-                       cur, chunk_d, nstride, hdr_off, shadow_d, hstride, masks.p, tile_left.p, d_abort, d_counters, verify)
+#define AH_LAUNCH(M)                                                                                                      \
+    do {                                                                                                                  \
+        if (sh > 48 * 1024) /* very long vectors: opt in to more dynamic LDS than the default limit */                    \
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_screen_node<M>),                           \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                             \
+        hipLaunchKernelGGL((k_forest_screen_node<M>), dim3(tile_grid), dim3(kBlock), sh, s, dv, sv, d_cur, d_tiles.p,     \
+                           n_tiles, cur, chunk_d, nstride, hdr_off, shadow_d, hstride, masks.p, tile_left.p, d_abort,     \
+                           d_counters, verify);                                                                           \
+    } while (0)
                 switch (ds->metric) {
                 case AH_EUCLIDEAN: AH_LAUNCH(AH_EUCLIDEAN); break;
                 case AH_MANHATTAN: AH_LAUNCH(AH_MANHATTAN); break;
@@ -1938,9 +1944,14 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                 forest->stats.screened_launches++;
             } else {
                 const size_t sh = (size_t)dv.pitch * 4;
-#define AH_LAUNCH(M)                                                                                            \
-    hipLaunchKernelGGL((k_forest_margin_f32<M>), dim3(tile_grid), dim3(kBlock), sh, s, dv, d_cur, d_tiles.p,    \
-                       n_tiles, cur, N, chunk_d, nstride, hdr_off, masks.p, tile_left.p, d_abort)
+#define AH_LAUNCH(M)                                                                                                \
+    do {                                                                                                            \
+        if (sh > 48 * 1024)                                                                                         \
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_margin_f32<M>),                      \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                       \
+        hipLaunchKernelGGL((k_forest_margin_f32<M>), dim3(tile_grid), dim3(kBlock), sh, s, dv, d_cur, d_tiles.p,    \
+                           n_tiles, cur, N, chunk_d, nstride, hdr_off, masks.p, tile_left.p, d_abort);              \
+    } while (0)
                 switch (ds->metric) {
                 case AH_EUCLIDEAN: AH_LAUNCH(AH_EUCLIDEAN); break;
                 case AH_MANHATTAN: AH_LAUNCH(AH_MANHATTAN); break;

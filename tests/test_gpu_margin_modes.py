@@ -159,3 +159,61 @@ def test_baseline_config_2_two_full_size_trees_equal_oracle():
     forest.close()
     f2.close()
     ds.close()
+
+
+@pytest.mark.parametrize("metric", [D.Cosine, D.Euclidean])
+def test_very_long_vectors(metric):
+    """12 000 dimensions: the node's normals (f32 + binary16) no longer fit the default dynamic-LDS limit of the
+    node-major kernels, and the two-means of `create_split` uses 144 KB of LDS.  Same forests as the oracle."""
+    dims, n = 12_000, 700
+    ds, oracle, vecs, ids = make_data(metric, n, dims, seed=5)
+    for mode in (0, _lib.MARGIN_NODE_MAJOR, _lib.MARGIN_NODE_MAJOR | _lib.MARGIN_EXACT_ONLY, 4):
+        forest = ds.build_forest([3, 4, 5], split_after=60, margin_mode=mode)
+        for t, seed in enumerate([3, 4, 5]):
+            assert forest.canonical(t) == oracle.build_tree(60, seed).canonical(), (mode, t)
+        forest.close()
+    ds.close()
+
+
+def test_baseline_config_3_split_sides_equal_oracle_at_10m():
+    """BASELINE configs[2] at full size (10M x 768 cosine, default build, 20 of the 100 trees so that every row-major
+    group size occurs): the children the forest recorded for the ROOT of two trees and for sampled split nodes at every
+    depth equal the sides the ORACLE computes for the recorded normal (`D::side`, src/writer.rs:1201-1207) over the node's
+    items — the margin kernels checked at full size against the reference arithmetic, not against another GPU kernel."""
+    from arroy_amd import Dataset, shard
+    from test_gpu_parity import subtree_items
+    n, dims, trees = 10_000_000, 768, 20
+    ds = Dataset(D.Cosine, dims, n)
+    ds.fill_synthetic(42, 1, n)
+    ds.finalize()
+    f = ds.build_forest(shard.tree_seeds(42, range(trees)))
+    launches = f.stats["margin_mode_launches"]
+    assert launches[0] > 0 and sum(launches[1:5]) > 0 and launches[5] + launches[6] > 0, launches  # node-major, rows, LDS
+    assert f.stats["screened_launches"] > 0 and f.stats["screen_violations"] == 0
+    vecs = O.synth(42, 1, n, dims)
+    oracle = O.Data(O.COSINE, vecs)
+    nodes = f.nodes
+    rng = np.random.default_rng(3)
+    checked = {}
+    for t in (0, 17):
+        root = int(f.roots[t])
+        picks = [root]
+        of_tree = np.flatnonzero((nodes["kind"] == 2) & (nodes["tree"] == t) & (nodes["has_normal"] == 1))
+        by_depth = {}
+        for i in of_tree[rng.permutation(of_tree.size)]:
+            by_depth.setdefault(int(nodes[i]["depth"]), []).append(int(i))
+        for depth, cand in sorted(by_depth.items()):
+            if depth > 0:
+                picks += cand[:2]
+        for i in picks:
+            nd = nodes[i]
+            left, right = subtree_items(f, nd["left"]), subtree_items(f, nd["right"])
+            rows = np.sort(np.concatenate([left, right]))  # ids are 0..n-1: row == id
+            hdr, vec = f.normal_of(i)
+            sides, n_left, _ = oracle.split_sides(vec, hdr, rows)
+            assert n_left == left.size, (t, i, int(nd["depth"]))
+            assert np.array_equal(rows[sides == 0], left) and np.array_equal(rows[sides == 1], right), (t, i)
+            checked[int(nd["depth"])] = checked.get(int(nd["depth"]), 0) + 1
+    assert checked[0] == 2 and len(checked) >= 13, checked
+    f.close()
+    ds.close()
