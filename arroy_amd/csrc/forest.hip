@@ -799,7 +799,7 @@ __device__ __forceinline__ void screen_rows_chunk(float (&acc)[TC], const uint4 
                                                   const uint4 *r4, uint32_t k) {
     uint4 x[NS];
 #pragma unroll
-    for (int u = 0; u < NS; u++) x[u] = ld_stream_u4(r4 + (k + u) * 8);
+    for (int u = 0; u < NS; u++) x[u] = r4[(k + u) * 8];  // cached on purpose: the other tree groups re-read the chunk
 #pragma unroll
     for (int t = 0; t < TC; t++) {
         const uint4 *np = base4 + noff[t] + k * 8;
@@ -824,17 +824,40 @@ __device__ __forceinline__ void screen_rows_chunk(float (&acc)[TC], const uint4 
 #ifndef AH_SCREEN_WAVES
 #define AH_SCREEN_WAVES 1  // minimum waves per SIMD the compiler must leave room for (caps the VGPRs of the global variant)
 #endif
+// Schedule of a launch: ONE launch serves `n_groups` groups of TC trees (tree0 + g * TC ...) and blocks are numbered
+// chunk-major — block b works on rows [chunk * chunk_rows + tile * rows_per_block, ...) of group g with
+// chunk = b / (n_groups * tiles), g = (b / tiles) % n_groups, tile = b % tiles — so the passes of all groups over one chunk
+// of rows (48 MB of binary16 rows) run back to back and every pass but the first finds the chunk in the 256 MB Infinity
+// Cache.  Measured on the pass in isolation (scripts/micro/rows_pass_model.hip): a pass costs the L2 gather of its normals
+// PLUS ~4.6 ms of HBM-latency-bound row stream (11.9 ms for 16 trees, 10M rows); with the rows coming from the Infinity
+// Cache 9.1-9.6 ms; 7.8 ms if they came from L2.  The row loads must be ordinary cached loads for that (non-temporal
+// ones do not stay: 11.1 ms).  group_nodes (LDS variant): first node of every tree in the level, nodes ordered by tree.
+struct RowsSchedule {
+    uint32_t n_groups, tiles, chunk_rows, rows_per_block;
+    const uint32_t *tree_first;  // LDS variant: device copy of tree_first[n_trees + 1]
+};
 template <int METRIC, int TC, bool LDS_NORMALS>
-__global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock, LDS_NORMALS ? 1 : AH_SCREEN_WAVES) void k_forest_screen_rows(
-    DataView dv, ScreenView sv, const uint32_t *__restrict__ node_of, uint32_t tree0, uint32_t n_pass,
+__global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock,
+                             LDS_NORMALS ? 1 : (AH_SCREEN_WAVES > 1 ? AH_SCREEN_WAVES : (TC == 8 ? 4 : 1))) void k_forest_screen_rows(
+    DataView dv, ScreenView sv, const uint32_t *__restrict__ node_of, uint32_t tree_base, uint32_t n_pass,
     const uint8_t *__restrict__ normals, uint64_t nstride, uint64_t hdr_off, const uint8_t *__restrict__ shadow,
-    uint64_t hstride, uint8_t *__restrict__ side_bytes, uint32_t first_node, uint32_t n_group_nodes,
-    const AbortFlags abort_flag, ScreenCounters *__restrict__ counters, uint32_t verify) {
+    uint64_t hstride, uint8_t *__restrict__ side_bytes, RowsSchedule sch, const AbortFlags abort_flag,
+    ScreenCounters *__restrict__ counters, uint32_t verify) {
     extern __shared__ uint4 s_shadow4[];
     __shared__ uint32_t s_fb, s_bad;
     if (abort_requested(abort_flag)) return;
+    const uint32_t per_chunk = sch.n_groups * sch.tiles;
+    const uint32_t chunk = blockIdx.x / per_chunk, in_chunk = blockIdx.x % per_chunk;
+    const uint32_t group = in_chunk / sch.tiles, tile = in_chunk % sch.tiles;
+    const uint32_t tree0 = tree_base + group * TC;
+    const uint64_t row_begin = (uint64_t)chunk * sch.chunk_rows + (uint64_t)tile * sch.rows_per_block;
+    const uint64_t row_end = min(min(row_begin + sch.rows_per_block, (uint64_t)(chunk + 1) * sch.chunk_rows), dv.n);
+    if (row_begin >= row_end) return;  // block-uniform
     const uint32_t hstride4 = (uint32_t)(hstride >> 4);
+    uint32_t first_node = 0;
     if (LDS_NORMALS) {
+        first_node = sch.tree_first[tree0];
+        const uint32_t n_group_nodes = sch.tree_first[tree0 + n_pass] - first_node;
         const uint4 *g = reinterpret_cast<const uint4 *>(shadow + (uint64_t)first_node * hstride);
         const uint32_t total = n_group_nodes * hstride4;
         for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) s_shadow4[i] = g[i];
@@ -842,30 +865,42 @@ __global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock, LDS
     if (threadIdx.x == 0) s_fb = s_bad = 0;
     __syncthreads();
     const uint32_t j = threadIdx.x & 7u;
-    const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+    const uint32_t octets = blockDim.x >> 3;
     const uint32_t steps = sv.hpitch >> 6;
     const uint32_t stats4 = sv.hpitch >> 3;  // uint4 index of the NormalStats inside a shadow record
     // all shadow records of the level, as uint4: LDS copy of the group or the global chunk (32-bit indices either way)
     const uint4 *base4 = LDS_NORMALS ? s_shadow4 : reinterpret_cast<const uint4 *>(shadow);
-    const uint32_t node0 = LDS_NORMALS ? first_node : 0u;
+    const uint32_t node0 = first_node;
     const uint32_t last_tree = n_pass - 1;
+    constexpr int N = TC >= 8 ? 8 : TC;        // trees per transposing reduction
+    constexpr int SETS = TC >= 8 ? TC / 8 : 1;  // sets of N trees
+    const uint32_t my_t = octet_owned_tree<N>(j);
+    const bool owner = octet_is_owner<N>(j);
     uint32_t fallbacks = 0, bad = 0;
-    for (uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; row < dv.n; row += n_octets) {
+    for (uint64_t row = row_begin + (threadIdx.x >> 3); row < row_end; row += octets) {
+#ifdef AH_EXPERIMENT_ROWS_L2  // timing experiment only (wrong results): every row read hits the same 3 MB of rows
+        const uint4 *r4 = reinterpret_cast<const uint4 *>(sv.rows + (row & 2047) * sv.hpitch) + j;
+#else
         const uint4 *r4 = reinterpret_cast<const uint4 *>(sv.rows + row * sv.hpitch) + j;
+#endif
+        // Lane j owns tree octet_owned_tree(j) of each set of 8 trees: it loads that tree's node index (one load instruction
+        // for 8 trees), broadcasts it to the octet, and later runs the tree's epilogue.  n_pass == TC except for the last
+        // trees of a forest: spare slots repeat the last tree and are not stored.
+        uint32_t my_node[SETS];
         uint32_t noff[TC];  // uint4 index of (record of the node that owns the row in tree t) + j
-        uint32_t nodes_t[TC];
         float acc[TC];
 #pragma unroll
+        for (int st = 0; st < SETS; st++)
+            my_node[st] = node_of[(uint64_t)(tree0 + min(my_t + 8u * st, last_tree)) * dv.n + row];
+#pragma unroll
         for (int t = 0; t < TC; t++) {
-            // n_pass == TC except for the last odd tree of a forest (TC = 2, n_pass = 1): the spare slot repeats it
-            const uint32_t node = node_of[(uint64_t)(tree0 + min((uint32_t)t, last_tree)) * dv.n + row];
-            nodes_t[t] = node;
+            const uint32_t node = (uint32_t)__shfl((int)my_node[t / 8], (int)octet_owner_lane<N>(t % 8), 8);
             noff[t] = (node != 0xFFFFFFFFu ? node - node0 : 0u) * hstride4 + j;
             acc[t] = 0.f;
         }
         // chunks of AH_SCREEN_CHUNK steps (64 dims each), then of 4, then single steps.  Measured on 10M x 768 (12 steps):
         // 8 + 4 beats a single chunk of 12 (the extra 16 row registers cost a wave of occupancy per SIMD: 7.7 -> 10.8 ms
-        // per 8-tree pass) — the pass is bound by loads in flight per CU, and occupancy buys more of them than unrolling.
+        // per 8-tree pass).
         uint32_t k = 0;
         for (; k + AH_SCREEN_CHUNK <= steps; k += AH_SCREEN_CHUNK) screen_rows_chunk<TC, AH_SCREEN_CHUNK>(acc, base4, noff, r4, k);
 #if AH_SCREEN_CHUNK > 4
@@ -875,37 +910,56 @@ __global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock, LDS
         }
 #endif
         for (; k < steps; k++) {
-            const uint4 x = ld_stream_u4(r4 + k * 8);
+            const uint4 x = r4[k * 8];
 #pragma unroll
             for (int t = 0; t < TC; t++) acc[t] = screen_dot8(base4[noff[t] + k * 8], x, acc[t]);
         }
+        // Epilogue, once per tree on its owner lane: total of the octet (transposing reduction), error bound, decision.
+        // Pairs the screen cannot decide are recomputed in the reference arithmetic by the whole octet.
         const float4 rs = sv.stats[row];
         const float row_extra = METRIC == AH_DOT_PRODUCT ? dv.headers[2 * row] : 0.0f;
 #pragma unroll
-        for (int t = 0; t < TC; t++) {
-            if (nodes_t[t] != 0xFFFFFFFFu) {
-                const float s = octet_sum(acc[t]);
-                const uint4 raw = base4[noff[t] - j + stats4];
+        for (int st = 0; st < SETS; st++) {
+            const float total = octet_transpose_sum<N>(acc + 8 * st, j);
+            const uint32_t t = my_t + 8u * st;
+            const bool valid = owner && t <= last_tree && my_node[st] != 0xFFFFFFFFu;
+            uint32_t side = 0;
+            bool decided = false;
+            if (valid) {
+                const uint4 raw = base4[(my_node[st] - node0) * hstride4 + stats4];
                 NormalStats ns;
                 ns.an = __uint_as_float(raw.x);
                 ns.bn = __uint_as_float(raw.y);
                 ns.cn = __uint_as_float(raw.z);
                 ns.extra = __uint_as_float(raw.w);
-                uint32_t side;
-                const bool decided = screen_decides<METRIC>(s, rs, ns, row_extra, sv.gamma_s, sv.gamma_r, side);
-                if (!decided || verify) {  // octet-uniform
-                    const uint32_t exact = side_of_margin(
-                        rows_exact_margin<METRIC>(dv, row, normals + (uint64_t)nodes_t[t] * nstride, hdr_off, j));
-                    if (decided && exact != side) bad++;
-                    if (!decided && (uint32_t)t <= last_tree) fallbacks++;
-                    side = exact;
-                }
-                if (j == 0) side_bytes[(uint64_t)(tree0 + min((uint32_t)t, last_tree)) * dv.n + row] = (uint8_t)side;
+                decided = screen_decides<METRIC>(total, rs, ns, row_extra, sv.gamma_s, sv.gamma_r, side);
             }
+            const unsigned long long und = __ballot(valid && (!decided || verify));
+            const uint32_t mask8 = (uint32_t)(und >> (8u * ((threadIdx.x & 63u) >> 3))) & 0xFFu;
+            if (mask8) {  // octet-uniform, ~8 % of the (octet, set) pairs
+#pragma unroll
+                for (int tt = 0; tt < N; tt++) {
+                    constexpr uint32_t kOwner[8] = {octet_owner_lane<N>(0), octet_owner_lane<N>(1), octet_owner_lane<N>(2),
+                                                    octet_owner_lane<N>(3), octet_owner_lane<N>(4), octet_owner_lane<N>(5),
+                                                    octet_owner_lane<N>(6), octet_owner_lane<N>(7)};
+                    const uint32_t ol = kOwner[tt];
+                    if ((mask8 >> ol) & 1u) {
+                        const uint32_t node = (noff[8 * st + tt] - j) / hstride4 + node0;
+                        const uint32_t exact =
+                            side_of_margin(rows_exact_margin<METRIC>(dv, row, normals + (uint64_t)node * nstride, hdr_off, j));
+                        if (j == ol) {
+                            if (decided && exact != side) bad++;
+                            if (!decided) fallbacks++;
+                            side = exact;
+                        }
+                    }
+                }
+            }
+            if (valid) side_bytes[(uint64_t)(tree0 + t) * dv.n + row] = (uint8_t)side;
         }
     }
-    if (j == 0 && fallbacks) atomicAdd(&s_fb, fallbacks);
-    if (j == 0 && bad) atomicAdd(&s_bad, bad);
+    if (fallbacks) atomicAdd(&s_fb, fallbacks);
+    if (bad) atomicAdd(&s_bad, bad);
     __syncthreads();
     if (threadIdx.x == 0) {
         if (s_fb) atomicAdd(&counters->fallbacks, (unsigned long long)s_fb);
@@ -1232,13 +1286,15 @@ double rows_pass_ns_per_row(uint32_t tc, double ws_mb, bool screened) {
     static const CostPt e8[] = {{0.2, 1.16}, {1.6, 1.22}, {3.2, 2.0}, {6.3, 2.5}, {12.6, 3.1}, {25, 3.5}, {100, 3.7}};
     static const CostPt e4[] = {{0.1, 0.73}, {0.8, 0.85}, {3.2, 0.88}, {6.3, 1.07}, {12.6, 1.45}, {25, 1.85}, {50, 2.05}, {100, 2.14}};
     static const CostPt e2[] = {{0.05, 0.49}, {0.8, 0.60}, {3.1, 0.62}, {6.3, 0.74}, {12.6, 0.99}, {25, 1.14}, {50, 1.21}};
-    static const CostPt s16[] = {{0.05, 1.51}, {0.4, 1.61}, {0.8, 1.67}, {1.6, 1.70}, {3.2, 1.81}, {6.4, 2.30}, {12.7, 2.90},
-                                 {25, 3.73}, {51, 4.23}, {102, 4.51}, {203, 4.67}};
-    static const CostPt s8[] = {{0.1, 0.80}, {0.2, 0.87}, {0.4, 0.91}, {0.8, 0.94}, {1.6, 0.96}, {3.2, 0.99}, {6.4, 1.18},
-                                {12.7, 1.73}, {25, 2.15}, {51, 2.40}, {102, 2.54}};
-    static const CostPt s4[] = {{0.01, 0.47}, {0.05, 0.49}, {0.1, 0.57}, {0.2, 0.64}, {0.4, 0.68}, {0.8, 0.70}, {3.2, 0.72},
-                                {6.4, 0.76}, {12.7, 0.85}, {25, 0.98}, {51, 1.05}};
-    static const CostPt s2[] = {{0.01, 0.32}, {0.4, 0.36}, {3.2, 0.39}, {6.4, 0.41}, {12.7, 0.51}, {25, 0.58}};
+    // screened kernels, chunk-major launches, epilogue on owner lanes (gpurun r02w: 96 trees, every level forced)
+    static const CostPt s16[] = {{0.025, 1.11}, {0.2, 1.13}, {0.4, 1.20}, {0.8, 1.25}, {1.6, 1.30}, {3.2, 1.45}, {6.4, 1.99},
+                                 {12.7, 2.94}, {25, 3.57}, {51, 3.92}, {102, 4.10}, {203, 4.21}};
+    static const CostPt s8[] = {{0.012, 0.58}, {0.1, 0.61}, {0.2, 0.67}, {0.4, 0.71}, {0.8, 0.74}, {1.6, 0.77}, {3.2, 0.85},
+                                {6.4, 1.24}, {12.7, 1.66}, {25, 1.94}, {51, 2.09}, {102, 2.15}};
+    static const CostPt s4[] = {{0.025, 0.325}, {0.05, 0.353}, {0.1, 0.415}, {0.2, 0.463}, {0.4, 0.493}, {0.8, 0.511},
+                                {1.6, 0.535}, {3.2, 0.591}, {6.4, 0.759}, {12.7, 0.918}, {25, 1.04}, {51, 1.10}};
+    static const CostPt s2[] = {{0.003, 0.235}, {0.05, 0.243}, {0.1, 0.261}, {0.2, 0.274}, {0.4, 0.284}, {0.8, 0.292},
+                                {1.6, 0.314}, {3.2, 0.389}, {6.4, 0.49}, {12.7, 0.56}, {25, 0.60}};
     if (screened) return tc >= 16 ? interp(s16, ws_mb) : tc == 8 ? interp(s8, ws_mb) : tc == 4 ? interp(s4, ws_mb) : interp(s2, ws_mb);
     return tc >= 16 ? interp(e16, ws_mb) : tc == 8 ? interp(e8, ws_mb) : tc == 4 ? interp(e4, ws_mb) : interp(e2, ws_mb);
 }
@@ -1429,6 +1485,61 @@ struct Readback {
     }
 };
 
+// Launch one instantiation of k_forest_screen_rows (metric x trees per group x LDS-resident normals).
+namespace {
+struct ScreenRowsArgs {
+    DataView dv;
+    ScreenView sv;
+    const uint32_t *node_of;
+    uint32_t tree_base, n_pass;
+    const uint8_t *normals;
+    uint64_t nstride, hdr_off;
+    const uint8_t *shadow;
+    uint64_t hstride;
+    uint8_t *side_bytes;
+    RowsSchedule sch;
+    AbortFlags abort_flag;
+    ScreenCounters *counters;
+    uint32_t verify;
+};
+template <int M, int TC, bool LDS>
+int launch_screen_rows_inst(const ScreenRowsArgs &a, unsigned grid, size_t sh, hipStream_t s, int device) {
+    const unsigned threads = LDS ? (TC >= 16 ? 512u : 1024u) : (unsigned)kBlock;
+    if (LDS) {
+        static std::atomic<bool> opt_in[64];  // once per instantiation and device
+        if (!opt_in[device & 63].load(std::memory_order_acquire)) {
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_screen_rows<M, TC, LDS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsNormalsBytes));
+            opt_in[device & 63].store(true, std::memory_order_release);
+        }
+    }
+    hipLaunchKernelGGL((k_forest_screen_rows<M, TC, LDS>), dim3(grid), dim3(threads), LDS ? sh : 0, s, a.dv, a.sv, a.node_of,
+                       a.tree_base, a.n_pass, a.normals, a.nstride, a.hdr_off, a.shadow, a.hstride, a.side_bytes, a.sch,
+                       a.abort_flag, a.counters, a.verify);
+    return AH_OK;
+}
+template <int M>
+int launch_screen_rows_metric(uint32_t tc, bool lds, const ScreenRowsArgs &a, unsigned grid, size_t sh, hipStream_t s, int device) {
+    if (lds) return tc >= 16 ? launch_screen_rows_inst<M, 16, true>(a, grid, sh, s, device)
+                             : launch_screen_rows_inst<M, 8, true>(a, grid, sh, s, device);
+    switch (tc) {
+    case 16: return launch_screen_rows_inst<M, 16, false>(a, grid, sh, s, device);
+    case 8: return launch_screen_rows_inst<M, 8, false>(a, grid, sh, s, device);
+    case 4: return launch_screen_rows_inst<M, 4, false>(a, grid, sh, s, device);
+    default: return launch_screen_rows_inst<M, 2, false>(a, grid, sh, s, device);
+    }
+}
+int launch_screen_rows(int metric, uint32_t tc, bool lds, const ScreenRowsArgs &a, unsigned grid, size_t sh, hipStream_t s,
+                       int device) {
+    switch (metric) {
+    case AH_EUCLIDEAN: return launch_screen_rows_metric<AH_EUCLIDEAN>(tc, lds, a, grid, sh, s, device);
+    case AH_MANHATTAN: return launch_screen_rows_metric<AH_MANHATTAN>(tc, lds, a, grid, sh, s, device);
+    case AH_COSINE: return launch_screen_rows_metric<AH_COSINE>(tc, lds, a, grid, sh, s, device);
+    default: return launch_screen_rows_metric<AH_DOT_PRODUCT>(tc, lds, a, grid, sh, s, device);
+    }
+}
+}  // namespace
+
 // `subset_ids` == nullptr: every tree covers all items (Writer::build with missing trees).  Otherwise tree t covers
 // the ascending id list subset_ids[subset_offsets[first_tree + t] .. subset_offsets[first_tree + t + 1]) — the
 // "descendants that became too large" of an incremental build (src/writer.rs:660-739).
@@ -1482,18 +1593,22 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     ScreenCounters *d_counters = reinterpret_cast<ScreenCounters *>(d_small.p + 4);
     LevelInfo *d_info = reinterpret_cast<LevelInfo *>(d_small.p + 8);
     uint32_t *d_tree_first = reinterpret_cast<uint32_t *>(d_info + 1);
+    DevBuf<uint32_t> d_tree_first_buf;  // first node of every tree of the level, gaps closed (LDS variant of the row pass)
+    AH_TRY(d_tree_first_buf.ensure((size_t)n_trees + 2));
+    uint32_t *d_tree_first_fixed = d_tree_first_buf.p;
     AH_HIP(hipMemsetAsync(d_small.p, 0, (8 + info_words) * 4, s));
 
     // pinned host memory: [2 x LevelInfo block][one word for the abort flag][2 x node table][read-back bounce]
     const size_t kBounce = 64ull << 20;  // pinned double buffer of the read-back worker
     const size_t pin_info = (info_words * 4 + 255) & ~(size_t)255;
     const size_t pin_nodes = (max_nodes * sizeof(FNode) + 4095) & ~(size_t)4095;
-    const size_t pin_head = (2 * pin_info + 256 + 4095) & ~(size_t)4095;
+    const size_t pin_head = (3 * pin_info + 256 + 4095) & ~(size_t)4095;
     AH_TRY(ctx->ensure_pinned(pin_head + 2 * pin_nodes + kBounce));
     uint8_t *pin = reinterpret_cast<uint8_t *>(ctx->h_pinned);
     LevelInfo *h_info[2] = {reinterpret_cast<LevelInfo *>(pin), reinterpret_cast<LevelInfo *>(pin + pin_info)};
     uint32_t *h_one = reinterpret_cast<uint32_t *>(pin + 2 * pin_info);
     *h_one = 1u;
+    uint32_t *h_tree_first = reinterpret_cast<uint32_t *>(pin + 2 * pin_info + 256);  // staging of d_tree_first_fixed
     FNode *h_nodes[2] = {reinterpret_cast<FNode *>(pin + pin_head), reinterpret_cast<FNode *>(pin + pin_head + pin_nodes)};
 
     // row-major margin mode (full-dataset trees, f32 metrics): node index and side byte per (tree, row)
@@ -1751,7 +1866,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         // per tree.  A forced mode (ah_build_options.margin_mode) pins the kernel family wherever it is legal.
         const uint64_t rec_bytes = screen ? hstride : nstride;  // bytes of one normal as the margin pass streams it
         const uint64_t nodes_per_tree = (n_nodes + n_trees - 1) / n_trees;
-        uint32_t row_tc = 0, lds_tc = 0;
+        uint32_t row_tc = 0, lds_tc = 0, lds_worst = 0;
         if (rows_allowed && mode_req == AH_MARGIN_AUTO) {
             // Cost model in ns per row of 3072 bytes, fitted to per-level rocprofv3 traces of the 10M x 768 x 100-tree
             // build (profiles/): node-major = one HBM read of the row per (item, tree) pair; row-major = per pass and
@@ -1775,7 +1890,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                 // a pass per full group, the last trees in smaller groups (16 + 16 + ... + 4): count them as a fraction
                 const double passes = (double)n_trees / tc;
                 const double full = rows_pass_ns_per_row(tc, ws_mb, screen);
-                const double floor_ns = screen ? 0.23 : 0.45;  // the HBM read of the row alone
+                const double floor_ns = screen ? 0.15 : 0.45;  // the read of the row alone (screened: mostly Infinity Cache)
                 const double per_row = floor_ns + (full - floor_ns) * std::min(1.0, active * 1.05);
                 const double cost_rows = passes * (double)N * per_row * scale + convert;
                 if (cost_rows < best || (g_rows_force == 1 && row_tc == 0)) {
@@ -1791,9 +1906,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         if (rows_allowed && want_lds && (rec_bytes & 15) == 0) {
             tree_first[n_trees] = n_nodes;  // trees without a node in this level start where the next tree starts
             for (uint32_t t = n_trees; t-- > 0;) tree_first[t] = std::min(tree_first[t], tree_first[t + 1]);
-            // measured per tree and row: screened 8-tree groups 0.058 ns, 16-tree groups 0.064; f32 0.070 / 0.061
-            uint32_t tc_hi = mode_req == AH_MARGIN_AUTO ? std::min<uint32_t>(16, g_rows_max_tc) : (mode_req & 0xFFu);
-            if (mode_req == AH_MARGIN_AUTO && screen) tc_hi = std::min<uint32_t>(tc_hi, 8);
+            // measured per tree and row: screened 0.039 ns for 16-tree groups, 0.040 for 8-tree groups; f32 0.061 / 0.070
+            const uint32_t tc_hi = mode_req == AH_MARGIN_AUTO ? std::min<uint32_t>(16, g_rows_max_tc) : (mode_req & 0xFFu);
             const uint32_t tc_lo = mode_req == AH_MARGIN_AUTO ? 8u : tc_hi;
             for (uint32_t tc = tc_hi; tc >= tc_lo && tc >= 8; tc >>= 1) {
                 uint32_t worst = 0;
@@ -1801,6 +1915,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     worst = std::max(worst, tree_first[std::min(n_trees, t0 + tc)] - tree_first[t0]);
                 if ((uint64_t)worst * rec_bytes <= kLdsNormalsBytes) {
                     lds_tc = tc;
+                    lds_worst = worst;
                     break;
                 }
             }
@@ -1829,8 +1944,55 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     hipLaunchKernelGGL(k_forest_assign_node_of, dim3(tile_grid), dim3(kBlock), 0, s, d_cur, d_tiles.p, n_tiles,
                                        cur, N, node_of.p, 0u);
                 }
+                uint32_t passes = 0;
+                if (screen) {
+                    // Chunk-major launches (RowsSchedule): all full groups of the level in ONE launch, so that the passes over a
+                    // chunk of rows run back to back and find it in the Infinity Cache; the last trees (fewer than a group) in
+                    // launches of their own.  The LDS variant reads the first node of every tree from a device copy.
+                    const uint32_t gtc = lds_tc ? lds_tc : row_tc;
+                    const uint32_t rpb = lds_tc ? 1024u : 32u;  // rows per block
+                    const uint64_t hrow = (uint64_t)sv.hpitch * 2;
+                    uint32_t chunk_rows = (uint32_t)std::max<uint64_t>(rpb, ((48ull << 20) / hrow) / rpb * rpb);
+                    if (chunk_rows > N) chunk_rows = (uint32_t)((N + rpb - 1) / rpb * rpb);
+                    const uint32_t n_chunks = (uint32_t)((N + chunk_rows - 1) / chunk_rows);
+                    ScreenRowsArgs ra{dv, sv, node_of.p, 0, 0, chunk_d, nstride, hdr_off, shadow_d, hstride, side_bytes.p,
+                                      RowsSchedule{1, chunk_rows / rpb, chunk_rows, rpb, d_tree_first_fixed}, d_abort, d_counters, verify};
+                    if (lds_tc) {
+                        memcpy(h_tree_first, tree_first.data(), ((size_t)n_trees + 1) * 4);
+                        AH_HIP(hipMemcpyAsync(d_tree_first_fixed, h_tree_first, ((size_t)n_trees + 1) * 4, hipMemcpyHostToDevice, s));
+                    }
+                    const size_t lds_sh = (size_t)lds_worst * rec_bytes;
+                    auto launch = [&](uint32_t tcv, uint32_t t0, uint32_t groups, uint32_t np) -> int {
+                        ra.tree_base = t0;
+                        ra.n_pass = np;
+                        ra.sch.n_groups = groups;
+                        const uint64_t grid = (uint64_t)n_chunks * groups * ra.sch.tiles;
+                        AH_REQUIRE(grid < 0x7FFFFFFFull, AH_ERR_INVALID_ARGUMENT, "forest build: too many rows for one launch");
+                        AH_TRY(launch_screen_rows(ds->metric, tcv, lds_tc != 0, ra, (unsigned)grid, lds_sh, s, ds->device));
+                        forest->stats.margin_mode_launches[lds_tc ? (tcv >= 16 ? MM_LDS16 : MM_LDS8) : mm_rows(tcv)]++;
+                        passes += groups;
+                        return AH_OK;
+                    };
+                    const uint32_t full = n_trees / gtc;
+                    if (full) AH_TRY(launch(gtc, 0, full, gtc));
+                    for (uint32_t t0 = full * gtc; t0 < n_trees;) {
+                        // The last trees take the largest instantiation that they fill, or the next larger one when only a few
+                        // of its slots would idle (13 trees: one 16-slot pass, measured 15 ms, instead of 8 + 4 + 1: 18-23 ms;
+                        // spare slots repeat the last tree).  LDS groups exist for 8 and 16 trees only.
+                        const uint32_t rem = n_trees - t0;
+                        uint32_t tcv = gtc;
+                        if (!lds_tc) {
+                            while (tcv > 2 && tcv > rem) tcv >>= 1;
+                            for (uint32_t up = tcv << 1; up <= gtc && tcv < rem; up <<= 1)
+                                if (up >= rem && up - rem <= (up >= 16 ? 3u : 1u)) tcv = up;
+                        }
+                        const uint32_t np = std::min<uint32_t>(tcv, rem);
+                        AH_TRY(launch(tcv, t0, 1, np));
+                        t0 += np;
+                    }
+                }
                 const unsigned row_grid = (unsigned)std::min<uint64_t>((N + 31) / 32, g_row_blocks);
-                for (uint32_t t0 = 0; t0 < n_trees && lds_tc; t0 += lds_tc) {
+                for (uint32_t t0 = 0; t0 < n_trees && lds_tc && !screen; t0 += lds_tc) {
                     const uint32_t np = std::min<uint32_t>(lds_tc, n_trees - t0);
                     const uint32_t first = tree_first[t0], cnt = tree_first[t0 + np] - first;
                     if (cnt == 0) continue;
@@ -1849,16 +2011,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     } while (0)
 #define AH_ROWS_LDS(M, TCV)                                                                                              \
     do {                                                                                                                 \
-        if (screen) {                                                                                                    \
-            AH_LDS_OPT_IN((k_forest_screen_rows<M, TCV, true>));                                                         \
-            hipLaunchKernelGGL((k_forest_screen_rows<M, TCV, true>), dim3(lgrid), dim3(lthreads), sh, s, dv, sv, node_of.p, \
-                               t0, np, chunk_d, nstride, hdr_off, shadow_d, hstride, side_bytes.p, first, cnt, d_abort,  \
-                               d_counters, verify);                                                                      \
-        } else {                                                                                                         \
-            AH_LDS_OPT_IN((k_forest_margin_rows_lds<M, TCV>));                                                           \
-            hipLaunchKernelGGL((k_forest_margin_rows_lds<M, TCV>), dim3(lgrid), dim3(lthreads), sh, s, dv, node_of.p, t0, \
-                               np, chunk_d, nstride, hdr_off, side_bytes.p, first, cnt, d_abort);                        \
-        }                                                                                                                \
+        AH_LDS_OPT_IN((k_forest_margin_rows_lds<M, TCV>));                                                               \
+        hipLaunchKernelGGL((k_forest_margin_rows_lds<M, TCV>), dim3(lgrid), dim3(lthreads), sh, s, dv, node_of.p, t0, np,  \
+                           chunk_d, nstride, hdr_off, side_bytes.p, first, cnt, d_abort);                                \
     } while (0)
 #define AH_ROWS_LDS_TC(M)                  \
     if (lds_tc == 16) AH_ROWS_LDS(M, 16);  \
@@ -1873,8 +2028,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
 #undef AH_ROWS_LDS
                     forest->stats.margin_mode_launches[lds_tc == 16 ? MM_LDS16 : MM_LDS8]++;
                 }
-                uint32_t passes = 0;
-                for (uint32_t t0 = 0; t0 < n_trees && !lds_tc;) {
+                for (uint32_t t0 = 0; t0 < n_trees && !lds_tc && !screen;) {
                     // The last trees of the forest take the largest instantiation that they fill (16 + 16 + ... + 4), or the
                     // next larger one when only a few of its slots would idle (13 trees: one 16-slot pass, measured 15 ms,
                     // instead of 8 + 4 + 1: 18-23 ms; spare slots repeat the last tree).
@@ -1886,13 +2040,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     const uint32_t np = std::min<uint32_t>(tcv, rem);
 #define AH_ROWS(M, TCV)                                                                                                    \
     do {                                                                                                                   \
-        if (screen)                                                                                                        \
-            hipLaunchKernelGGL((k_forest_screen_rows<M, TCV, false>), dim3(row_grid), dim3(kBlock), 0, s, dv, sv, node_of.p, \
-                               t0, np, chunk_d, nstride, hdr_off, shadow_d, hstride, side_bytes.p, 0u, 0u, d_abort,        \
-                               d_counters, verify);                                                                        \
-        else                                                                                                               \
-            hipLaunchKernelGGL((k_forest_margin_rows<M, TCV>), dim3(row_grid), dim3(kBlock), 0, s, dv, node_of.p, t0, np,  \
-                               chunk_d, nstride, hdr_off, side_bytes.p, d_abort);                                          \
+        hipLaunchKernelGGL((k_forest_margin_rows<M, TCV>), dim3(row_grid), dim3(kBlock), 0, s, dv, node_of.p, t0, np,      \
+                           chunk_d, nstride, hdr_off, side_bytes.p, d_abort);                                              \
     } while (0)
 #define AH_ROWS_TC(M)                       \
     switch (tcv) {                          \
@@ -1915,7 +2064,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                 }
                 hipLaunchKernelGGL(k_forest_masks_from_bytes, dim3(tile_grid), dim3(kBlock), 0, s, d_cur, d_tiles.p, n_tiles,
                                    cur, N, side_bytes.p, masks.p, tile_left.p);
-                if (lds_tc) passes = (n_trees + lds_tc - 1) / lds_tc;
+                if (lds_tc && !screen) passes = (n_trees + lds_tc - 1) / lds_tc;
                 forest->stats.margin_row_passes += passes;
                 if (screen) forest->stats.screened_launches += passes;
             } else if (bq) {

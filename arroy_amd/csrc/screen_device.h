@@ -51,6 +51,46 @@ __device__ __forceinline__ float octet_sum(float v) {
     return v;
 }
 
+// Transposing reduction over an octet.  On entry lane j holds its partial sums v[0..N) for N trees; on exit every lane
+// holds the sum over the 8 lanes for ONE tree, octet_owned_tree<N>(j).  Three butterfly steps (half-row mirror, lane ^ 2,
+// lane ^ 1), each lane keeping the half of its values that its side of the exchange owns: 7 N / 2 VALU operations instead
+// of the 6 N of N separate octet sums — and, more importantly, the per-tree epilogue (error bound, decision, store)
+// then runs ONCE per tree on its owner lane instead of 8 times, and its loads / stores are issued for 8 trees at once.
+template <int N>
+__device__ __forceinline__ uint32_t octet_owned_tree(uint32_t j) {
+    return N == 8 ? j : N == 4 ? ((j >> 2) * 2u + ((j >> 1) & 1u)) : (j >> 2);
+}
+template <int N>
+__device__ __forceinline__ bool octet_is_owner(uint32_t j) {  // N < 8: several lanes end up with the same tree
+    return N == 8 ? true : N == 4 ? (j & 1u) == 0u : (j & 3u) == 0u;
+}
+template <int N>
+__host__ __device__ constexpr uint32_t octet_owner_lane(uint32_t t) {
+    return N == 8 ? t : N == 4 ? ((t >> 1) * 4u + (t & 1u) * 2u) : t * 4u;
+}
+template <int N>
+__device__ __forceinline__ float octet_transpose_sum(const float *v, uint32_t j) {
+    const bool hi = (j & 4u) != 0u, b1 = (j & 2u) != 0u, b0 = (j & 1u) != 0u;
+    if (N == 8) {
+        float w[4], u[2];
+#pragma unroll
+        for (int t = 0; t < 4; t++) w[t] = (hi ? v[t + 4] : v[t]) + dpp_f32<0x141>(hi ? v[t] : v[t + 4]);
+#pragma unroll
+        for (int t = 0; t < 2; t++) u[t] = (b1 ? w[t + 2] : w[t]) + dpp_f32<0x4E>(b1 ? w[t] : w[t + 2]);
+        return (b0 ? u[1] : u[0]) + dpp_f32<0xB1>(b0 ? u[0] : u[1]);
+    } else if (N == 4) {
+        float w[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) w[t] = (hi ? v[t + 2] : v[t]) + dpp_f32<0x141>(hi ? v[t] : v[t + 2]);
+        float r = (b1 ? w[1] : w[0]) + dpp_f32<0x4E>(b1 ? w[0] : w[1]);
+        return r + dpp_f32<0xB1>(r);
+    } else {
+        float r = (hi ? v[1] : v[0]) + dpp_f32<0x141>(hi ? v[0] : v[1]);
+        r += dpp_f32<0x4E>(r);
+        return r + dpp_f32<0xB1>(r);
+    }
+}
+
 // Per-normal record of the shadow chunk: [hpitch halves][stats: |n~|, |n - n~|, |n|, B] with B the additive term of the
 // margin that does not depend on the item (bias of Euclidean / Manhattan; 0 for Cosine; for DotProduct the normal's
 // extra dimension h0, which multiplies the item's).
