@@ -78,6 +78,7 @@ class AhErrorDetail(C.Structure):
 MARGIN_AUTO, MARGIN_NODE_MAJOR = 0, 1
 MARGIN_ROWS = {2: 2, 4: 4, 8: 8, 16: 16}
 MARGIN_ROWS_LDS = {8: 0x108, 16: 0x110}
+MARGIN_DENSE_MFMA = 0x200
 MARGIN_EXACT_ONLY = 0x1000
 # index of every kernel family in ah_build_stats.margin_mode_launches
 MODE_LAUNCH_INDEX = {1: 0, 2: 1, 4: 2, 8: 3, 16: 4, 0x108: 5, 0x110: 6}
@@ -88,7 +89,8 @@ class AhBuildStats(C.Structure):
                 ("margin_evaluations", C.c_uint64), ("margin_launches", C.c_uint64), ("margin_row_passes", C.c_uint64), ("split_nodes", C.c_uint64),
                 ("descendant_nodes", C.c_uint64), ("dummy_normals", C.c_uint64), ("retries", C.c_uint64),
                 ("levels", C.c_uint32), ("margin_mode_launches", C.c_uint64 * 8), ("screened_launches", C.c_uint64),
-                ("screen_fallbacks", C.c_uint64), ("screen_violations", C.c_uint64)]
+                ("screen_fallbacks", C.c_uint64), ("screen_violations", C.c_uint64),
+                ("dense_launches", C.c_uint64), ("dense_columns", C.c_uint64)]
 
 
 # name -> (restype, argtypes): exactly the declarations of include/arroy_hip.h

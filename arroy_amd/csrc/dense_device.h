@@ -1,0 +1,275 @@
+// dense_device.h — the top levels of the forest build as ONE matrix product on the MFMA units.
+//
+// Included by forest.hip (after FNode / ScreenCounters / AbortFlags).  Replaces, for the levels where it is cheaper,
+// the row-major passes of the margin loop (src/writer.rs:1201-1207 for every pending node of every tree).
+//
+// A single margin <normal, item> is a vector contraction (0.5 flop / byte) and the reference's f32 value has a fixed
+// summation order no matrix unit reproduces — which is why the distance scan, the re-rank and the exact margins never
+// touch MFMA.  The certified screen (screen_device.h) is different on both counts: it needs the binary16 dot product
+// in ANY accumulation order (its rounding is covered by gamma_s), and at the top of the forest the normals are few:
+// level L has n_trees * 2^L of them, every one of the N rows meets one per tree.  So the screen values of a whole
+// level are the product
+//
+//        S[N x C] = X~[N x hpitch] * N~[C x hpitch]^T          (C = nodes of the level, all trees)
+//
+// of the binary16 shadow of the rows with the binary16 shadow of the level's normals — both K-major, the layout
+// v_mfma_f32_32x32x16_f16 wants — of which row r needs the n_trees entries S[r, node_of[t][r]].  Computing all C
+// columns wastes a factor 2^L of arithmetic, but the matrix units deliver ~50x the multiply-adds of the v_dot2c
+// row-major pass and the rows leave HBM once per LEVEL instead of once per group of 8-16 trees: 10M x 768, 100 trees,
+// level 0-3: ~3-10 ms instead of 66-70 ms.  Beyond ~64 nodes per tree the waste wins and the row-major / node-major
+// passes take over (cost model in build_batch).
+//
+// Sides stay bit-identical to the reference arithmetic: |S| > E (the same rigorous bound, with gamma_s for a chain of
+// hpitch roundings) decides the side, every other pair (~1.3 %) is marked and recomputed by k_forest_exact_pairs in the
+// reference's f32 order.
+#pragma once
+
+namespace ah {
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+constexpr uint32_t kDM = 256;            // rows of X~ per block tile
+constexpr uint32_t kDN = 128;            // normals (columns) per block tile
+constexpr uint32_t kDenseThreads = 256;  // 4 waves as 2 (rows) x 2 (columns): 128 x 64 per wave = 4 x 2 MFMA tiles
+constexpr uint32_t kDenseStage = (kDM + kDN) * 128;  // one k-block (64 halves = 128 B per tile row) of both operands
+constexpr uint32_t kDensePitch = kDM + 4;             // floats per column of the transposed result tile (bank spread)
+constexpr uint32_t kDenseLds = kDN * kDensePitch * 4 > 2 * kDenseStage ? kDN * kDensePitch * 4 : 2 * kDenseStage;
+constexpr uint32_t kDenseGroup = 8;  // row tiles whose column tiles run back to back on one XCD (X~ tiles stay in its L2)
+
+// side-byte codes of the dense pass (resolved to 0 / 1 by k_forest_exact_pairs before anything else reads them)
+constexpr uint32_t kSideUndecided = 2u;  // the screen could not decide: reference arithmetic wanted
+constexpr uint32_t kSideVerify = 4u;     // AH_SCREEN_VERIFY: decided (bit 0 = side), reference arithmetic wanted as a check
+
+struct DenseArgs {
+    const uint16_t *rows;  // binary16 shadow of the rows, n x hpitch
+    const float4 *stats;   // per row {|x~|, |x - x~|, |x|, 0}
+    const float *headers;  // DotProduct: {extra_dim, norm} per row
+    uint64_t n;
+    uint32_t hpitch;
+    const uint8_t *shadow;  // the level's shadow records [hpitch halves][NormalStats], n_cols of them
+    uint64_t hstride;
+    uint32_t n_cols;
+    const FNode *nodes;  // the level's nodes (column c <-> node c; ordered by tree)
+    const uint32_t *node_of;
+    uint8_t *side_bytes;
+    float gamma_s, gamma_r;
+    uint32_t n_row_tiles, n_col_tiles, group, verify;
+};
+
+// One k-block of the block tile, global -> LDS by the DMA path (global_load_lds_dwordx4: the 64 lanes of a wave
+// instruction fill 1 KiB of LDS lane-linearly = 8 tile rows of 128 bytes; every lane fetches a 16-byte chunk of a
+// whole 128-byte line, so the global side is fully coalesced).  Slot s of tile row R holds chunk s ^ ((R >> 1) & 7):
+// the XOR is applied to the SOURCE address here and again to the ds_read_b128 address of the fragment loads, which makes
+// those conflict-free (their 16-lane groups — rows {0-3,12-15,20-27} etc. at one chunk — then cover all 64 banks).
+__device__ __forceinline__ void dense_stage(const uint8_t *const (&a_src)[8], const uint8_t *const (&b_src)[4], uint32_t kb,
+                                            uint8_t *stage, uint32_t wave) {
+    const uint64_t koff = (uint64_t)kb * 128u;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a_src[i] + koff),
+                                         (__attribute__((address_space(3))) void *)(stage + (uint32_t)(i * 4 + wave) * 1024u),
+                                         16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(b_src[i] + koff),
+                                         (__attribute__((address_space(3))) void *)(stage + (uint32_t)((8 + i) * 4 + wave) * 1024u),
+                                         16, 0, 0);
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(kDenseThreads, 1) void k_forest_dense_screen(DenseArgs a, const AbortFlags abort_flag) {
+    extern __shared__ uint4 s_dense4[];
+    uint8_t *smem = reinterpret_cast<uint8_t *>(s_dense4);
+    if (abort_requested(abort_flag)) return;
+    // block -> (row tile, column tile).  Workgroups go to the XCDs round-robin, so block b runs on XCD b & 7: the blocks
+    // of one XCD walk groups of `group` row tiles, all column tiles of a group back to back, and the group's X~ tiles
+    // (group x 384 KB) are read from HBM once and then found in that XCD's L2.
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t per_group = a.group * a.n_col_tiles;
+    const uint32_t grp = slot / per_group, within = slot % per_group;
+    const uint32_t ct = within / a.group, rt = (grp * a.group + within % a.group) * 8u + xcd;
+    if (rt >= a.n_row_tiles) return;  // block-uniform
+    const uint64_t row0 = (uint64_t)rt * kDM;
+    const uint32_t c0 = ct * kDN;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+
+    // per-lane sources of the 12 DMA pieces of a stage: piece p = 4 i + wave covers tile rows 8 p .. 8 p + 7
+    const uint8_t *a_src[8], *b_src[4];
+    {
+        const uint32_t sl = lane & 7u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t R = (uint32_t)(i * 4 + wave) * 8u + (lane >> 3);
+            const uint64_t r = min(row0 + R, a.n - 1);  // rows past the end repeat the last row (never stored)
+            a_src[i] = reinterpret_cast<const uint8_t *>(a.rows) + r * ((uint64_t)a.hpitch * 2u) + ((sl ^ ((R >> 1) & 7u)) << 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t R = (uint32_t)(i * 4 + wave) * 8u + (lane >> 3);  // row of the B region
+            const uint32_t c = min(c0 + R, a.n_cols - 1);
+            b_src[i] = a.shadow + (uint64_t)c * a.hstride + ((sl ^ ((R >> 1) & 7u)) << 4);
+        }
+    }
+    const uint32_t wm = wave >> 1, wn = wave & 1u;
+    const uint32_t m = lane & 31u, g = lane >> 5, swz = (m >> 1) & 7u;
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int im = 0; im < 4; im++)
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[im][jn][e] = 0.0f;
+
+    const uint32_t nk = a.hpitch >> 6;
+    dense_stage(a_src, b_src, 0, smem, wave);
+    for (uint32_t kb = 0; kb < nk; kb++) {
+        // this wave's DMA of stage kb has landed; after the barrier everybody's has, and every wave has finished
+        // reading the other buffer (its fragment loads were consumed by the MFMAs of iteration kb - 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kb + 1 < nk) dense_stage(a_src, b_src, kb + 1, smem + ((kb + 1) & 1u) * kDenseStage, wave);
+        const uint8_t *st = smem + (kb & 1u) * kDenseStage;
+        const uint8_t *sa = st + (wm * 128u + m) * 128u;
+        const uint8_t *sb = st + (kDM + wn * 64u + m) * 128u;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            // k-step q of the block: lanes 0-31 take halves [16 q, +8), lanes 32-63 halves [16 q + 8, +8) of their row —
+            // the same assignment for both operands, which is all the product needs (any k order: gamma_s covers it)
+            const uint32_t off = ((2u * q + g) ^ swz) << 4;
+            f16x8_t af[4], bf[2];
+#pragma unroll
+            for (int im = 0; im < 4; im++) af[im] = *reinterpret_cast<const f16x8_t *>(sa + im * 32 * 128 + off);
+#pragma unroll
+            for (int jn = 0; jn < 2; jn++) bf[jn] = *reinterpret_cast<const f16x8_t *>(sb + jn * 32 * 128 + off);
+#pragma unroll
+            for (int im = 0; im < 4; im++)
+#pragma unroll
+                for (int jn = 0; jn < 2; jn++)
+                    acc[im][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[im], bf[jn], acc[im][jn], 0, 0, 0);
+        }
+    }
+    // Result tile -> LDS, transposed: S[column][row].  D layout of the 32x32 MFMA: lane -> column (lane & 31) of the B
+    // operand (the normals), register e -> row (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the A operand (the data rows):
+    // four consecutive registers are four consecutive rows = one 16-byte store.
+    __syncthreads();  // the stage buffers are dead
+    float *S = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int im = 0; im < 4; im++)
+#pragma unroll
+        for (int jn = 0; jn < 2; jn++) {
+            const uint32_t col = wn * 64u + (uint32_t)jn * 32u + m;
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                const uint32_t row = wm * 128u + (uint32_t)im * 32u + 8u * (uint32_t)qq + 4u * g;
+                *reinterpret_cast<float4 *>(S + col * kDensePitch + row) =
+                    make_float4(acc[im][jn][4 * qq], acc[im][jn][4 * qq + 1], acc[im][jn][4 * qq + 2], acc[im][jn][4 * qq + 3]);
+            }
+        }
+    __syncthreads();
+    // Epilogue, one thread per row of the tile: for every tree that has nodes among this tile's columns, the row's node
+    // (coalesced read), its screen value, the bound, the decision; one side byte out (consecutive rows -> consecutive
+    // bytes).  Nodes are ordered by tree, so the tile's columns cover the trees [t_lo, t_hi].
+    const uint64_t row = row0 + threadIdx.x;
+    const bool live = row < a.n;
+    const uint32_t c_last = min(c0 + kDN, a.n_cols) - 1u;
+    const uint32_t t_lo = a.nodes[c0].tree, t_hi = a.nodes[c_last].tree;
+    float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+    float row_extra = 0.0f;
+    if (live) {
+        rs = a.stats[row];
+        if (METRIC == AH_DOT_PRODUCT) row_extra = a.headers[2 * row];
+    }
+    for (uint32_t t = t_lo; t <= t_hi; t += 8) {
+        uint32_t nd[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++)
+            nd[u] = (live && t + u <= t_hi) ? a.node_of[(uint64_t)(t + u) * a.n + row] : 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) {
+            const uint32_t c = nd[u] - c0;  // 0xFFFFFFFF (leaf row) and nodes of other column tiles fall outside
+            if (nd[u] != 0xFFFFFFFFu && c < kDN) {
+                const float s = S[c * kDensePitch + threadIdx.x];
+                const NormalStats ns =
+                    *reinterpret_cast<const NormalStats *>(a.shadow + (uint64_t)nd[u] * a.hstride + (uint64_t)a.hpitch * 2u);
+                uint32_t side;
+                const bool decided = screen_decides<METRIC>(s, rs, ns, row_extra, a.gamma_s, a.gamma_r, side);
+                a.side_bytes[(uint64_t)(t + u) * a.n + row] =
+                    (uint8_t)(decided ? (a.verify ? (kSideVerify | side) : side) : kSideUndecided);
+            }
+        }
+    }
+}
+
+// The pairs the dense screen left open (side byte 2; or every pair under AH_SCREEN_VERIFY), recomputed in the reference
+// arithmetic: a wave scans 1 KiB of side bytes (16 per lane), lists the marked ones in LDS and hands them to its octets,
+// eight pairs at a time — the arithmetic of k_forest_margin_rows (rows_exact_margin).
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_forest_exact_pairs(DataView dv, const uint32_t *__restrict__ node_of,
+                                                            uint8_t *__restrict__ side_bytes, uint64_t total,
+                                                            const uint8_t *__restrict__ normals, uint64_t nstride,
+                                                            uint64_t hdr_off, ScreenCounters *__restrict__ counters,
+                                                            const AbortFlags abort_flag) {
+    __shared__ uint32_t s_list[4][1024];
+    __shared__ uint32_t s_fb, s_bad;
+    if (abort_requested(abort_flag)) return;
+    if (threadIdx.x == 0) s_fb = s_bad = 0;
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, j = lane & 7u, o = lane >> 3;
+    const uint64_t n_windows = (total + 1023) >> 10;
+    uint32_t fallbacks = 0, bad = 0;
+    for (uint64_t win = (uint64_t)blockIdx.x * 4 + wave; win < n_windows; win += (uint64_t)gridDim.x * 4) {
+        const uint64_t base = win << 10;
+        // the buffer is padded (and zeroed) beyond `total`, so whole 16-byte loads are always in bounds
+        const uint4 v = *reinterpret_cast<const uint4 *>(side_bytes + base + lane * 16u);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int e = 0; e < 16; e++) cnt += ((w[e >> 2] >> (8 * (e & 3))) & 0xFEu) ? 1u : 0u;
+        uint32_t incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += up;
+        }
+        const uint32_t n_marked = __shfl(incl, 63);
+        if (n_marked == 0) continue;  // wave-uniform
+        uint32_t pos = incl - cnt;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const uint32_t b = (w[e >> 2] >> (8 * (e & 3))) & 0xFFu;
+            if (b & 0xFEu) s_list[wave][pos++] = (lane * 16u + (uint32_t)e) | (b << 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t e0 = 0; e0 < n_marked; e0 += 8) {
+            const uint32_t idx = e0 + o;
+            const bool active = idx < n_marked;
+            const uint32_t ent = active ? s_list[wave][idx] : 0u;
+            const uint64_t flat = base + (ent & 0xFFFFu);
+            const uint32_t code = ent >> 16;
+            const uint32_t node = (active && flat < total) ? node_of[flat] : 0xFFFFFFFFu;
+            if (node != 0xFFFFFFFFu) {  // octet-uniform
+                const uint64_t r = flat % dv.n;
+                const uint32_t exact = side_of_margin(rows_exact_margin<METRIC>(dv, r, normals + (uint64_t)node * nstride, hdr_off, j));
+                if (j == 0) {
+                    side_bytes[flat] = (uint8_t)exact;
+                    if (code == kSideUndecided) fallbacks++;
+                    else if ((code & 1u) != exact) bad++;
+                }
+            } else if (active && flat < total && j == 0) {
+                side_bytes[flat] = 0;  // a stale mark on a row that is a leaf in this tree: nobody reads it
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the list is re-used by the next window
+    }
+    if (fallbacks) atomicAdd(&s_fb, fallbacks);
+    if (bad) atomicAdd(&s_bad, bad);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_fb) atomicAdd(&counters->fallbacks, (unsigned long long)s_fb);
+        if (s_bad) atomicAdd(&counters->violations, (unsigned long long)s_bad);
+    }
+}
+
+}  // namespace ah

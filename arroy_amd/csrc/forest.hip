@@ -1126,6 +1126,8 @@ __global__ __launch_bounds__(256) void k_build_tiles(const FNode *__restrict__ n
 
 }  // namespace ah
 
+#include "dense_device.h"
+
 using namespace ah;
 
 // ---------------------------------------------------------------------------------------------------
@@ -1231,6 +1233,12 @@ double g_rows_cache_mb = getenv("AH_ROWMAJOR_CACHE_MB") ? atof(getenv("AH_ROWMAJ
 // AH_SCREEN_VERIFY=1: the screened kernels evaluate the reference arithmetic for EVERY pair as well and count the pairs
 // whose screened side differs (ah_build_stats.screen_violations; must be 0) — a test of the bound, not a product mode.
 bool g_screen = !(getenv("AH_SCREEN") && atoi(getenv("AH_SCREEN")) == 0);
+// Dense MFMA screen of a level (dense_device.h): AH_DENSE=0 never, =1 whenever it is legal (AUTO otherwise asks the cost
+// model); AH_DENSE_MAX_COLS = most normals of a level it is considered for; AH_DENSE_GMACS = the sustained multiply-add
+// rate the cost model assumes, in 1e9 MAC/s.
+int g_dense = getenv("AH_DENSE") ? atoi(getenv("AH_DENSE")) : -1;
+uint32_t g_dense_max_cols = getenv("AH_DENSE_MAX_COLS") ? (uint32_t)atoi(getenv("AH_DENSE_MAX_COLS")) : 16384u;
+double g_dense_gmacs = getenv("AH_DENSE_GMACS") ? atof(getenv("AH_DENSE_GMACS")) : 400e3;
 bool g_screen_verify = getenv("AH_SCREEN_VERIFY") && atoi(getenv("AH_SCREEN_VERIFY")) != 0;
 #define AH_DBG(s, what)                                                       \
     do {                                                                      \
@@ -1618,7 +1626,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     DevBuf<uint8_t> side_bytes;
     if (rows_allowed) {
         AH_TRY(node_of.ensure((size_t)n_trees * N + 4));
-        AH_TRY(side_bytes.ensure((size_t)n_trees * N + 4));
+        // padded to whole 1 KiB windows and zeroed once: k_forest_exact_pairs scans it 16 bytes per lane for marks
+        AH_TRY(side_bytes.ensure((size_t)n_trees * N + 1024 + 16));
+        AH_HIP(hipMemsetAsync(side_bytes.p, 0, (size_t)n_trees * N + 1024 + 16, s));
     }
     // certified binary16 screen: f32 metrics with AVX-tier rows, unless the caller (or AH_SCREEN=0) asks for f32 only
     const bool screen = !exact_only && !bq && ds->dims >= 32 && ensure_screen(ds, s);
@@ -1898,11 +1908,35 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     row_tc = tc;
                 }
             }
-        } else if (rows_allowed) {
+        } else if (rows_allowed && mode_req != AH_MARGIN_DENSE_MFMA) {
             row_tc = mode_req & 0xFFu;
         }
+        // Dense screen of the level on the matrix units (dense_device.h): one product rows x normals^T instead of
+        // n_trees / tc passes.  Cost: the rows leave HBM once (binary16), hpitch multiply-adds per (row, column) at the
+        // sustained MFMA rate, an epilogue per (row, tree), and the reference arithmetic for the pairs left open.
+        bool dense = false;
+        const bool dense_legal = rows_allowed && screen && g_dense != 0 && n_nodes <= g_dense_max_cols;
+        if (dense_legal && mode_req == AH_MARGIN_DENSE_MFMA) {
+            dense = true;
+        } else if (dense_legal && mode_req == AH_MARGIN_AUTO) {
+            const double cols = (double)(((uint64_t)n_nodes + kDN - 1) / kDN * kDN);
+            const double mfma_ns = cols * (double)ds->hpitch / g_dense_gmacs;  // per row
+            const double hbm_ns = (double)ds->hpitch * 2 / 6500.0;
+            const double convert = (double)n_trees * (double)N * (prev_rows && g_rows_advance ? 0.007 : 0.04);
+            const double cost_dense = (double)N * (std::max(mfma_ns, hbm_ns) + 0.05 + 0.004 * n_trees) +
+                                      (double)info.pairs * (0.012 + 0.0125 * (double)ds->row_bytes() * 2 / 6000.0) + convert;
+            double cost_other = (double)info.pairs * (0.24 * (double)ds->hpitch * 2 / 1536.0);  // node-major, screened
+            if (row_tc >= 2) {
+                const double ws_mb = (double)((uint64_t)row_tc * nodes_per_tree * rec_bytes) / 1e6;
+                const double active = std::min(1.0, 1.05 * (double)info.pairs / ((double)n_trees * (double)N));
+                const double per_row = 0.15 + (rows_pass_ns_per_row(row_tc, ws_mb, true) - 0.15) * active;
+                cost_other = std::min(cost_other, (double)n_trees / row_tc * (double)N * per_row * (double)ds->hpitch * 2 / 1536.0 + convert);
+            }
+            dense = g_dense == 1 || cost_dense < cost_other;
+        }
+        if (dense) row_tc = 16;  // the level is row-major as far as node_of / side_bytes / the next level are concerned
         // Top levels: all normals of a group of >= 8 trees fit in LDS -> the LDS-resident variant of the row-major pass.
-        const bool want_lds = mode_req == AH_MARGIN_AUTO ? g_rows_lds && row_tc >= 2 : (mode_req & 0x100u) != 0;
+        const bool want_lds = dense ? false : mode_req == AH_MARGIN_AUTO ? g_rows_lds && row_tc >= 2 : (mode_req & 0x100u) != 0;
         if (rows_allowed && want_lds && (rec_bytes & 15) == 0) {
             tree_first[n_trees] = n_nodes;  // trees without a node in this level start where the next tree starts
             for (uint32_t t = n_trees; t-- > 0;) tree_first[t] = std::min(tree_first[t], tree_first[t + 1]);
@@ -1945,7 +1979,57 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                                        cur, N, node_of.p, 0u);
                 }
                 uint32_t passes = 0;
-                if (screen) {
+                if (dense) {
+                    DenseArgs da{};
+                    da.rows = sv.rows;
+                    da.stats = sv.stats;
+                    da.headers = dv.headers;
+                    da.n = N;
+                    da.hpitch = sv.hpitch;
+                    da.shadow = shadow_d;
+                    da.hstride = hstride;
+                    da.n_cols = n_nodes;
+                    da.nodes = d_cur;
+                    da.node_of = node_of.p;
+                    da.side_bytes = side_bytes.p;
+                    // accumulation error of the product: every one of the hpitch exact binary16 products enters one f32
+                    // chain; whatever the order and the rounding mode of the matrix unit's adders (nearest or truncating,
+                    // aligned to the largest addend of a 16-wide step or not), the sum is off by less than
+                    // (hpitch + hpitch / 16) * 2^-23 * sum |x~_i n~_i|; taken twice over
+                    da.gamma_s = (float)(2.0 * ((double)sv.hpitch + (double)sv.hpitch / 16 + 16.0) * 1.1920929e-7);
+                    da.gamma_r = sv.gamma_r;
+                    da.n_row_tiles = (uint32_t)((N + kDM - 1) / kDM);
+                    da.n_col_tiles = (n_nodes + kDN - 1) / kDN;
+                    da.group = da.n_col_tiles > 1 ? kDenseGroup : 1u;
+                    da.verify = verify;
+                    const uint64_t r8 = (da.n_row_tiles + 7) / 8;
+                    const uint64_t dgrid = 8 * ((r8 + da.group - 1) / da.group) * da.group * da.n_col_tiles;
+                    AH_REQUIRE(dgrid < 0x7FFFFFFFull, AH_ERR_INVALID_ARGUMENT, "forest build: too many tiles for one launch");
+                    const unsigned egrid = (unsigned)std::min<uint64_t>((((uint64_t)n_trees * N + 1023) / 1024 + 3) / 4, 1u << 16);
+#define AH_DENSE(M)                                                                                                      \
+    do {                                                                                                                 \
+        static std::atomic<bool> dense_opt_in[64]; /* once per instantiation and device */                              \
+        if (!dense_opt_in[ds->device & 63].load(std::memory_order_acquire)) {                                            \
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_dense_screen<M>),                         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseLds));                     \
+            dense_opt_in[ds->device & 63].store(true, std::memory_order_release);                                        \
+        }                                                                                                                \
+        hipLaunchKernelGGL((k_forest_dense_screen<M>), dim3((unsigned)dgrid), dim3(kDenseThreads), kDenseLds, s, da,     \
+                           d_abort);                                                                                     \
+        hipLaunchKernelGGL((k_forest_exact_pairs<M>), dim3(egrid), dim3(256), 0, s, dv, node_of.p, side_bytes.p,         \
+                           (uint64_t)n_trees * N, chunk_d, nstride, hdr_off, d_counters, d_abort);                       \
+    } while (0)
+                    switch (ds->metric) {
+                    case AH_EUCLIDEAN: AH_DENSE(AH_EUCLIDEAN); break;
+                    case AH_MANHATTAN: AH_DENSE(AH_MANHATTAN); break;
+                    case AH_COSINE: AH_DENSE(AH_COSINE); break;
+                    default: AH_DENSE(AH_DOT_PRODUCT); break;
+                    }
+#undef AH_DENSE
+                    forest->stats.dense_launches++;
+                    forest->stats.dense_columns += n_nodes;
+                    passes = 1;
+                } else if (screen) {
                     // Chunk-major launches (RowsSchedule): all full groups of the level in ONE launch, so that the passes over a
                     // chunk of rows run back to back and find it in the Infinity Cache; the last trees (fewer than a group) in
                     // launches of their own.  The LDS variant reads the first node of every tree from a device copy.
@@ -2297,7 +2381,8 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
         const uint32_t m = options->margin_mode & 0xFFFu;
         AH_REQUIRE((options->margin_mode & ~(0xFFFu | AH_MARGIN_EXACT_ONLY)) == 0 &&
                        (m == AH_MARGIN_AUTO || m == AH_MARGIN_NODE_MAJOR || m == AH_MARGIN_ROWS_2 || m == AH_MARGIN_ROWS_4 ||
-                        m == AH_MARGIN_ROWS_8 || m == AH_MARGIN_ROWS_16 || m == AH_MARGIN_ROWS_LDS_8 || m == AH_MARGIN_ROWS_LDS_16),
+                        m == AH_MARGIN_ROWS_8 || m == AH_MARGIN_ROWS_16 || m == AH_MARGIN_ROWS_LDS_8 || m == AH_MARGIN_ROWS_LDS_16 ||
+                        m == AH_MARGIN_DENSE_MFMA),
                    AH_ERR_INVALID_ARGUMENT, "unknown margin_mode 0x%x", options->margin_mode);
     }
     AH_REQUIRE(ds->metric != AH_DOT_PRODUCT || ds->dot_preprocessed, AH_ERR_NEED_PREPROCESS,

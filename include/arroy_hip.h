@@ -34,8 +34,9 @@
 extern "C" {
 #endif
 
-#define AH_ABI_VERSION 2   /* v2: ah_node.tree is 32 bits, ah_build_options.margin_mode, ah_build_stats.margin_mode_launches,
-                                  ah_last_error_detail, ah_dataset_replicate, ah_dataset_upload_flush */
+#define AH_ABI_VERSION 3   /* v2: ah_node.tree is 32 bits, ah_build_options.margin_mode, ah_build_stats.margin_mode_launches,
+                                  ah_last_error_detail, ah_dataset_replicate, ah_dataset_upload_flush
+                              v3: AH_MARGIN_DENSE_MFMA, ah_build_stats.dense_launches / dense_columns (appended) */
 
 /* every entry point is exported from the shared object (it is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -217,6 +218,12 @@ typedef enum ah_margin_mode {
     AH_MARGIN_ROWS_16 = 16,
     AH_MARGIN_ROWS_LDS_8 = 0x108,  /* row-major, all normals of a group of 8 / 16 trees resident in LDS               */
     AH_MARGIN_ROWS_LDS_16 = 0x110,
+    /* Dense screen on the matrix units (ABI v3): the binary16 screen values of ALL (row, node) pairs of a level as one
+     * matrix product rows x normals^T (v_mfma_f32_32x32x16_f16), of which every row uses one entry per tree; pairs the
+     * screen cannot decide are recomputed in the reference's f32 arithmetic, so the forest is the same bit for bit.
+     * Cheaper than the row-major passes while a tree has few nodes (top ~6 levels); needs the screen, i.e. it is
+     * ignored (node-major instead) together with AH_MARGIN_EXACT_ONLY and beyond AH_DENSE_MAX_COLS nodes per level. */
+    AH_MARGIN_DENSE_MFMA = 0x200,
     /* Flag, OR-ed into any of the above: evaluate every margin in the reference's f32 arithmetic only.  Without it the
      * f32 metrics first evaluate a *certified screen*: the same dot product on a binary16 shadow copy of the rows and
      * of the level's normals (half the bytes), with a rigorous bound E on |screen - reference f32 margin| derived
@@ -300,6 +307,8 @@ typedef struct ah_build_stats {
     uint64_t screened_launches;   /* margin launches that ran the certified binary16 screen                  */
     uint64_t screen_fallbacks;    /* (item, node) pairs the screen could not decide (recomputed in f32)       */
     uint64_t screen_violations;   /* AH_SCREEN_VERIFY=1 only: decided pairs whose f32 side differs (must be 0) */
+    uint64_t dense_launches;      /* ABI v3: levels whose first attempt ran as one MFMA product (AH_MARGIN_DENSE_MFMA)  */
+    uint64_t dense_columns;       /* ABI v3: normals (columns) those products covered, summed over the levels          */
 } ah_build_stats;
 
 AH_API int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out);

@@ -74,7 +74,7 @@ def one(rng, it):
     split_after = int(rng.choice([0, 1, 2, 8, 50, 300]))
     seeds = [int(x) for x in rng.integers(0, 2**63, int(rng.choice([1, 2, 3, 9, 17])))]
     # every margin-kernel family, with and without the certified binary16 screen (ah_margin_mode)
-    mode = int(rng.choice([0, 0, 1, 2, 4, 8, 16, 0x108, 0x110])) | (0x1000 if rng.random() < 0.3 else 0)
+    mode = int(rng.choice([0, 0, 1, 2, 4, 8, 16, 0x108, 0x110, 0x200, 0x200])) | (0x1000 if rng.random() < 0.3 else 0)
     forest = ds.build_forest(seeds, split_after=split_after, margin_mode=mode)
     desc += f" mode={mode:#x} trees={len(seeds)}"
     assert forest.stats["screen_violations"] == 0

@@ -1,8 +1,8 @@
 """GPU parity of EVERY margin-kernel family of the forest build (src/writer.rs:1193-1233) against the CPU oracle.
 
 `ah_build_options.margin_mode` pins one kernel family for all levels where it is legal: node-major, row-major with
-2 / 4 / 8 / 16 trees per pass, row-major with the normals of 8 / 16 trees resident in LDS — each with and without the
-certified binary16 screen (AH_MARGIN_EXACT_ONLY).  Whole forests must equal the oracle's node for node at the
+2 / 4 / 8 / 16 trees per pass, row-major with the normals of 8 / 16 trees resident in LDS, the dense screen on the
+matrix units (AH_MARGIN_DENSE_MFMA) — each with and without the certified binary16 screen (AH_MARGIN_EXACT_ONLY).  Whole forests must equal the oracle's node for node at the
 dimensions the headline builds use (768 / 1536: the 8-unrolled main loops) and at short rows (128 / 256)."""
 import os
 import subprocess
@@ -29,7 +29,7 @@ def _imports():
     P.D, P.O = D, O  # make_data / check_forest_valid live in test_gpu_parity and use its lazily imported modules
 
 MODES = [("auto", _lib.MARGIN_AUTO), ("node_major", _lib.MARGIN_NODE_MAJOR), ("rows_tc2", 2), ("rows_tc4", 4), ("rows_tc8", 8),
-         ("rows_tc16", 16), ("rows_lds_tc8", 0x108), ("rows_lds_tc16", 0x110)]
+         ("rows_tc16", 16), ("rows_lds_tc8", 0x108), ("rows_lds_tc16", 0x110), ("dense_mfma", 0x200)]
 SHAPES = [("cosine768", D.Cosine, 768, 24_000), ("dot1536", D.DotProduct, 1536, 12_000), ("euclid128", D.Euclidean, 128, 30_000),
           ("manhattan256", D.Manhattan, 256, 20_000)]
 N_TREES = 16
@@ -61,7 +61,11 @@ def test_forest_equals_oracle_in_every_margin_mode(shape, mode, exact_only):
     st = forest.stats
     if mode[1] in _lib.MODE_LAUNCH_INDEX:  # the pinned kernel family really ran
         assert st["margin_mode_launches"][_lib.MODE_LAUNCH_INDEX[mode[1]]] > 0, st["margin_mode_launches"]
-    if mode[1] == _lib.MARGIN_NODE_MAJOR:
+    if mode[1] == _lib.MARGIN_DENSE_MFMA and not exact_only:  # the matrix-unit screen ran (it needs the screen)
+        assert st["dense_launches"] > 0 and st["dense_columns"] >= st["dense_launches"], st
+    elif mode[1] != _lib.MARGIN_AUTO:
+        assert st["dense_launches"] == 0
+    if mode[1] == _lib.MARGIN_NODE_MAJOR or (mode[1] == _lib.MARGIN_DENSE_MFMA and exact_only):
         assert sum(st["margin_mode_launches"][1:7]) == 0
     if exact_only:
         assert st["screened_launches"] == 0 and st["screen_fallbacks"] == 0
@@ -99,12 +103,13 @@ for cls, dims, n in [(D.Cosine, 768, 20000), (D.Euclidean, 96, 20000), (D.Manhat
         if cls is D.DotProduct:
             ds.preprocess_dot()
         ds.finalize()
-        for mode in (0, 1, 4, 16, 0x110):
+        for mode in (0, 1, 4, 16, 0x110, 0x200):
             f = ds.build_forest([1, 2, 3, 4, 5, 6, 7, 8], margin_mode=mode)
             st = f.stats
             out.append({"metric": cls.name, "dims": dims, "scale": scale, "shift": shift, "mode": mode,
                         "evals": st["margin_evaluations"], "fallbacks": st["screen_fallbacks"],
-                        "violations": st["screen_violations"], "screened": st["screened_launches"]})
+                        "violations": st["screen_violations"], "screened": st["screened_launches"],
+                        "dense": st["dense_launches"]})
             f.close()
         ds.close()
 print(json.dumps(out))
@@ -120,7 +125,8 @@ def test_screen_bound_holds_for_every_pair():
     res = subprocess.run([sys.executable, "-c", VERIFY_SCRIPT, ROOT], capture_output=True, text=True, env=env, timeout=1500)
     assert res.returncode == 0, res.stderr[-2000:]
     rows = json.loads(res.stdout.strip().splitlines()[-1])
-    assert len(rows) == 5 * 6 * 5
+    assert len(rows) == 5 * 6 * 6
+    assert all(r["dense"] > 0 for r in rows if r["mode"] == 0x200)
     for r in rows:
         assert r["violations"] == 0, r
         assert r["screened"] > 0, r
