@@ -29,13 +29,23 @@ namespace ah {
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-constexpr uint32_t kDM = 256;            // rows of X~ per block tile
-constexpr uint32_t kDN = 128;            // normals (columns) per block tile
-constexpr uint32_t kDenseThreads = 256;  // 4 waves as 2 (rows) x 2 (columns): 128 x 64 per wave = 4 x 2 MFMA tiles
-constexpr uint32_t kDenseStage = (kDM + kDN) * 128;  // one k-block (64 halves = 128 B per tile row) of both operands
-constexpr uint32_t kDensePitch = kDM + 4;             // floats per column of the transposed result tile (bank spread)
-constexpr uint32_t kDenseLds = kDN * kDensePitch * 4 > 2 * kDenseStage ? kDN * kDensePitch * 4 : 2 * kDenseStage;
+constexpr uint32_t kDM = 256;  // rows of X~ per block tile
+// Block tile = 256 rows x (64 WN) normals, WN = 2 or 4: 2 x WN waves, each owning 128 x 64 = 4 x 2 MFMA tiles (128
+// accumulator registers).  WN = 4 (512 threads, two waves per SIMD) is the workhorse; WN = 2 serves levels with at most
+// 128 normals, where the wider tile would only multiply padding.
+template <int WN>
+struct DenseShape {
+    static constexpr uint32_t kBN = 64u * WN;
+    static constexpr uint32_t kThreads = 128u * WN;
+    static constexpr uint32_t kWaves = 2u * WN;
+    static constexpr uint32_t kStage = (kDM + kBN) * 128u;  // one k-block (64 halves = 128 B per tile row) of both operands
+    static constexpr uint32_t kPiecesA = 32u / kWaves, kPiecesB = (kBN / 8u) / kWaves;  // 1 KiB DMA pieces per wave
+};
+constexpr uint32_t kDenseHalf = 128;             // columns per epilogue round
+constexpr uint32_t kDensePitch = kDM + 4;         // floats per column of the transposed result tile (bank spread)
+constexpr uint32_t kDenseLds = kDenseHalf * kDensePitch * 4;  // 133 120 B >= two stages of either shape
 constexpr uint32_t kDenseGroup = 8;  // row tiles whose column tiles run back to back on one XCD (X~ tiles stay in its L2)
+static_assert(2 * DenseShape<4>::kStage <= kDenseLds && 2 * DenseShape<2>::kStage <= kDenseLds, "stage buffers fit");
 
 // side-byte codes of the dense pass (resolved to 0 / 1 by k_forest_exact_pairs before anything else reads them)
 constexpr uint32_t kSideUndecided = 2u;  // the screen could not decide: reference arithmetic wanted
@@ -62,23 +72,27 @@ struct DenseArgs {
 // whole 128-byte line, so the global side is fully coalesced).  Slot s of tile row R holds chunk s ^ ((R >> 1) & 7):
 // the XOR is applied to the SOURCE address here and again to the ds_read_b128 address of the fragment loads, which makes
 // those conflict-free (their 16-lane groups — rows {0-3,12-15,20-27} etc. at one chunk — then cover all 64 banks).
-__device__ __forceinline__ void dense_stage(const uint8_t *const (&a_src)[8], const uint8_t *const (&b_src)[4], uint32_t kb,
-                                            uint8_t *stage, uint32_t wave) {
+template <int WN>
+__device__ __forceinline__ void dense_stage(const uint8_t *const (&a_src)[DenseShape<WN>::kPiecesA],
+                                            const uint8_t *const (&b_src)[DenseShape<WN>::kPiecesB], uint32_t kb, uint8_t *stage,
+                                            uint32_t wave) {
+    typedef DenseShape<WN> SH;
     const uint64_t koff = (uint64_t)kb * 128u;
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (uint32_t i = 0; i < SH::kPiecesA; i++)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a_src[i] + koff),
-                                         (__attribute__((address_space(3))) void *)(stage + (uint32_t)(i * 4 + wave) * 1024u),
-                                         16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(stage + (i * SH::kWaves + wave) * 1024u), 16, 0,
+                                         0);
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(b_src[i] + koff),
-                                         (__attribute__((address_space(3))) void *)(stage + (uint32_t)((8 + i) * 4 + wave) * 1024u),
-                                         16, 0, 0);
+    for (uint32_t i = 0; i < SH::kPiecesB; i++)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(b_src[i] + koff),
+            (__attribute__((address_space(3))) void *)(stage + kDM * 128u + (i * SH::kWaves + wave) * 1024u), 16, 0, 0);
 }
 
-template <int METRIC>
-__global__ __launch_bounds__(kDenseThreads, 1) void k_forest_dense_screen(DenseArgs a, const AbortFlags abort_flag) {
+template <int METRIC, int WN>
+__global__ __launch_bounds__(DenseShape<WN>::kThreads, 1) void k_forest_dense_screen(DenseArgs a, const AbortFlags abort_flag) {
+    typedef DenseShape<WN> SH;
     extern __shared__ uint4 s_dense4[];
     uint8_t *smem = reinterpret_cast<uint8_t *>(s_dense4);
     if (abort_requested(abort_flag)) return;
@@ -91,27 +105,27 @@ __global__ __launch_bounds__(kDenseThreads, 1) void k_forest_dense_screen(DenseA
     const uint32_t ct = within / a.group, rt = (grp * a.group + within % a.group) * 8u + xcd;
     if (rt >= a.n_row_tiles) return;  // block-uniform
     const uint64_t row0 = (uint64_t)rt * kDM;
-    const uint32_t c0 = ct * kDN;
+    const uint32_t c0 = ct * SH::kBN;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 
-    // per-lane sources of the 12 DMA pieces of a stage: piece p = 4 i + wave covers tile rows 8 p .. 8 p + 7
-    const uint8_t *a_src[8], *b_src[4];
+    // per-lane sources of the DMA pieces of a stage: piece p = kWaves i + wave covers tile rows 8 p .. 8 p + 7
+    const uint8_t *a_src[SH::kPiecesA], *b_src[SH::kPiecesB];
     {
         const uint32_t sl = lane & 7u;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint32_t R = (uint32_t)(i * 4 + wave) * 8u + (lane >> 3);
+        for (uint32_t i = 0; i < SH::kPiecesA; i++) {
+            const uint32_t R = (i * SH::kWaves + wave) * 8u + (lane >> 3);
             const uint64_t r = min(row0 + R, a.n - 1);  // rows past the end repeat the last row (never stored)
             a_src[i] = reinterpret_cast<const uint8_t *>(a.rows) + r * ((uint64_t)a.hpitch * 2u) + ((sl ^ ((R >> 1) & 7u)) << 4);
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t R = (uint32_t)(i * 4 + wave) * 8u + (lane >> 3);  // row of the B region
+        for (uint32_t i = 0; i < SH::kPiecesB; i++) {
+            const uint32_t R = (i * SH::kWaves + wave) * 8u + (lane >> 3);  // row of the B region
             const uint32_t c = min(c0 + R, a.n_cols - 1);
             b_src[i] = a.shadow + (uint64_t)c * a.hstride + ((sl ^ ((R >> 1) & 7u)) << 4);
         }
     }
-    const uint32_t wm = wave >> 1, wn = wave & 1u;
+    const uint32_t wm = wave / WN, wn = wave % WN;
     const uint32_t m = lane & 31u, g = lane >> 5, swz = (m >> 1) & 7u;
     f32x16_t acc[4][2];
 #pragma unroll
@@ -122,14 +136,14 @@ __global__ __launch_bounds__(kDenseThreads, 1) void k_forest_dense_screen(DenseA
             for (int e = 0; e < 16; e++) acc[im][jn][e] = 0.0f;
 
     const uint32_t nk = a.hpitch >> 6;
-    dense_stage(a_src, b_src, 0, smem, wave);
+    dense_stage<WN>(a_src, b_src, 0, smem, wave);
     for (uint32_t kb = 0; kb < nk; kb++) {
         // this wave's DMA of stage kb has landed; after the barrier everybody's has, and every wave has finished
         // reading the other buffer (its fragment loads were consumed by the MFMAs of iteration kb - 1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kb + 1 < nk) dense_stage(a_src, b_src, kb + 1, smem + ((kb + 1) & 1u) * kDenseStage, wave);
-        const uint8_t *st = smem + (kb & 1u) * kDenseStage;
+        if (kb + 1 < nk) dense_stage<WN>(a_src, b_src, kb + 1, smem + ((kb + 1) & 1u) * SH::kStage, wave);
+        const uint8_t *st = smem + (kb & 1u) * SH::kStage;
         const uint8_t *sa = st + (wm * 128u + m) * 128u;
         const uint8_t *sb = st + (kDM + wn * 64u + m) * 128u;
 #pragma unroll
@@ -149,53 +163,63 @@ __global__ __launch_bounds__(kDenseThreads, 1) void k_forest_dense_screen(DenseA
                     acc[im][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[im], bf[jn], acc[im][jn], 0, 0, 0);
         }
     }
-    // Result tile -> LDS, transposed: S[column][row].  D layout of the 32x32 MFMA: lane -> column (lane & 31) of the B
-    // operand (the normals), register e -> row (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the A operand (the data rows):
-    // four consecutive registers are four consecutive rows = one 16-byte store.
-    __syncthreads();  // the stage buffers are dead
+    // Epilogue in rounds of 128 columns.  The waves owning them park their accumulators in LDS, transposed — S[column][row];
+    // D layout of the 32x32 MFMA: lane -> column (lane & 31) of the B operand (the normals), register e -> row
+    // (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the A operand (the data rows): four consecutive registers are four
+    // consecutive rows = one 16-byte store.  Then a thread per row (and per share of the trees, with 512 threads): for
+    // every tree that has nodes among the round's columns, the row's node (coalesced read), its screen value, the bound,
+    // the decision; one side byte out (consecutive rows -> consecutive bytes).  Nodes are ordered by tree, so the
+    // columns [c_lo, c_hi] cover the trees [t_lo, t_hi].
     float *S = reinterpret_cast<float *>(smem);
-#pragma unroll
-    for (int im = 0; im < 4; im++)
-#pragma unroll
-        for (int jn = 0; jn < 2; jn++) {
-            const uint32_t col = wn * 64u + (uint32_t)jn * 32u + m;
-#pragma unroll
-            for (int qq = 0; qq < 4; qq++) {
-                const uint32_t row = wm * 128u + (uint32_t)im * 32u + 8u * (uint32_t)qq + 4u * g;
-                *reinterpret_cast<float4 *>(S + col * kDensePitch + row) =
-                    make_float4(acc[im][jn][4 * qq], acc[im][jn][4 * qq + 1], acc[im][jn][4 * qq + 2], acc[im][jn][4 * qq + 3]);
-            }
-        }
-    __syncthreads();
-    // Epilogue, one thread per row of the tile: for every tree that has nodes among this tile's columns, the row's node
-    // (coalesced read), its screen value, the bound, the decision; one side byte out (consecutive rows -> consecutive
-    // bytes).  Nodes are ordered by tree, so the tile's columns cover the trees [t_lo, t_hi].
-    const uint64_t row = row0 + threadIdx.x;
+    const uint32_t r_in = threadIdx.x & (kDM - 1u), part = threadIdx.x / kDM;
+    constexpr uint32_t kParts = SH::kThreads / kDM;
+    const uint64_t row = row0 + r_in;
     const bool live = row < a.n;
-    const uint32_t c_last = min(c0 + kDN, a.n_cols) - 1u;
-    const uint32_t t_lo = a.nodes[c0].tree, t_hi = a.nodes[c_last].tree;
     float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
     float row_extra = 0.0f;
     if (live) {
         rs = a.stats[row];
         if (METRIC == AH_DOT_PRODUCT) row_extra = a.headers[2 * row];
     }
-    for (uint32_t t = t_lo; t <= t_hi; t += 8) {
-        uint32_t nd[8];
+#pragma unroll 1
+    for (uint32_t h = 0; h < SH::kBN / kDenseHalf; h++) {
+        const uint32_t c_lo = c0 + h * kDenseHalf;
+        if (c_lo >= a.n_cols) break;  // block-uniform
+        __syncthreads();  // the stage buffers (round 0) / the previous round's tile are dead
+        if ((wn >> 1) == h) {
 #pragma unroll
-        for (uint32_t u = 0; u < 8; u++)
-            nd[u] = (live && t + u <= t_hi) ? a.node_of[(uint64_t)(t + u) * a.n + row] : 0xFFFFFFFFu;
+            for (int im = 0; im < 4; im++)
 #pragma unroll
-        for (uint32_t u = 0; u < 8; u++) {
-            const uint32_t c = nd[u] - c0;  // 0xFFFFFFFF (leaf row) and nodes of other column tiles fall outside
-            if (nd[u] != 0xFFFFFFFFu && c < kDN) {
-                const float s = S[c * kDensePitch + threadIdx.x];
-                const NormalStats ns =
-                    *reinterpret_cast<const NormalStats *>(a.shadow + (uint64_t)nd[u] * a.hstride + (uint64_t)a.hpitch * 2u);
-                uint32_t side;
-                const bool decided = screen_decides<METRIC>(s, rs, ns, row_extra, a.gamma_s, a.gamma_r, side);
-                a.side_bytes[(uint64_t)(t + u) * a.n + row] =
-                    (uint8_t)(decided ? (a.verify ? (kSideVerify | side) : side) : kSideUndecided);
+                for (int jn = 0; jn < 2; jn++) {
+                    const uint32_t col = (wn & 1u) * 64u + (uint32_t)jn * 32u + m;
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        const uint32_t rr = wm * 128u + (uint32_t)im * 32u + 8u * (uint32_t)qq + 4u * g;
+                        *reinterpret_cast<float4 *>(S + col * kDensePitch + rr) = make_float4(
+                            acc[im][jn][4 * qq], acc[im][jn][4 * qq + 1], acc[im][jn][4 * qq + 2], acc[im][jn][4 * qq + 3]);
+                    }
+                }
+        }
+        __syncthreads();
+        const uint32_t c_hi = min(c_lo + kDenseHalf, a.n_cols) - 1u;
+        const uint32_t t_lo = a.nodes[c_lo].tree, t_hi = a.nodes[c_hi].tree;
+        for (uint32_t t = t_lo + 8u * part; t <= t_hi; t += 8u * kParts) {
+            uint32_t nd[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++)
+                nd[u] = (live && t + u <= t_hi) ? a.node_of[(uint64_t)(t + u) * a.n + row] : 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+                const uint32_t c = nd[u] - c_lo;  // 0xFFFFFFFF (leaf row) and nodes of other column ranges fall outside
+                if (nd[u] != 0xFFFFFFFFu && c < kDenseHalf) {
+                    const float s = S[c * kDensePitch + r_in];
+                    const NormalStats ns =
+                        *reinterpret_cast<const NormalStats *>(a.shadow + (uint64_t)nd[u] * a.hstride + (uint64_t)a.hpitch * 2u);
+                    uint32_t side;
+                    const bool decided = screen_decides<METRIC>(s, rs, ns, row_extra, a.gamma_s, a.gamma_r, side);
+                    a.side_bytes[(uint64_t)(t + u) * a.n + row] =
+                        (uint8_t)(decided ? (a.verify ? (kSideVerify | side) : side) : kSideUndecided);
+                }
             }
         }
     }

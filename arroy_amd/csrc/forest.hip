@@ -1238,7 +1238,7 @@ bool g_screen = !(getenv("AH_SCREEN") && atoi(getenv("AH_SCREEN")) == 0);
 // rate the cost model assumes, in 1e9 MAC/s.
 int g_dense = getenv("AH_DENSE") ? atoi(getenv("AH_DENSE")) : -1;
 uint32_t g_dense_max_cols = getenv("AH_DENSE_MAX_COLS") ? (uint32_t)atoi(getenv("AH_DENSE_MAX_COLS")) : 16384u;
-double g_dense_gmacs = getenv("AH_DENSE_GMACS") ? atof(getenv("AH_DENSE_GMACS")) : 400e3;
+double g_dense_gmacs = getenv("AH_DENSE_GMACS") ? atof(getenv("AH_DENSE_GMACS")) : 495e3;
 bool g_screen_verify = getenv("AH_SCREEN_VERIFY") && atoi(getenv("AH_SCREEN_VERIFY")) != 0;
 #define AH_DBG(s, what)                                                       \
     do {                                                                      \
@@ -1877,6 +1877,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         const uint64_t rec_bytes = screen ? hstride : nstride;  // bytes of one normal as the margin pass streams it
         const uint64_t nodes_per_tree = (n_nodes + n_trees - 1) / n_trees;
         uint32_t row_tc = 0, lds_tc = 0, lds_worst = 0;
+        double best_cost = -1.0;  // AUTO: modelled cost in ns of the cheapest of node-major / row-major for this level
         if (rows_allowed && mode_req == AH_MARGIN_AUTO) {
             // Cost model in ns per row of 3072 bytes, fitted to per-level rocprofv3 traces of the 10M x 768 x 100-tree
             // build (profiles/): node-major = one HBM read of the row per (item, tree) pair; row-major = per pass and
@@ -1908,6 +1909,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     row_tc = tc;
                 }
             }
+            best_cost = best;
         } else if (rows_allowed && mode_req != AH_MARGIN_DENSE_MFMA) {
             row_tc = mode_req & 0xFFu;
         }
@@ -1919,20 +1921,16 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         if (dense_legal && mode_req == AH_MARGIN_DENSE_MFMA) {
             dense = true;
         } else if (dense_legal && mode_req == AH_MARGIN_AUTO) {
-            const double cols = (double)(((uint64_t)n_nodes + kDN - 1) / kDN * kDN);
-            const double mfma_ns = cols * (double)ds->hpitch / g_dense_gmacs;  // per row
-            const double hbm_ns = (double)ds->hpitch * 2 / 6500.0;
+            // measured (10M x 768, 100 and 13 trees, gpurun_out/dense): the product itself 0.17 ns per row + 0.0023 ns per
+            // (row, tree) of epilogue + hpitch multiply-adds per (row, padded column) at 495e3 MAC/ns (990 TF), never below
+            // the 0.40 ns per row of the narrow kernel; 0.008 ns per pair for k_forest_exact_pairs
+            const uint32_t bn = n_nodes > 128 ? 256u : 128u;
+            const double cols = (double)(((uint64_t)n_nodes + bn - 1) / bn * bn);
+            const double hscale = (double)ds->hpitch / 768.0;
+            const double per_row = std::max(0.40 * hscale, 0.17 * hscale + 0.0023 * n_trees + cols * (double)ds->hpitch / g_dense_gmacs);
             const double convert = (double)n_trees * (double)N * (prev_rows && g_rows_advance ? 0.007 : 0.04);
-            const double cost_dense = (double)N * (std::max(mfma_ns, hbm_ns) + 0.05 + 0.004 * n_trees) +
-                                      (double)info.pairs * (0.012 + 0.0125 * (double)ds->row_bytes() * 2 / 6000.0) + convert;
-            double cost_other = (double)info.pairs * (0.24 * (double)ds->hpitch * 2 / 1536.0);  // node-major, screened
-            if (row_tc >= 2) {
-                const double ws_mb = (double)((uint64_t)row_tc * nodes_per_tree * rec_bytes) / 1e6;
-                const double active = std::min(1.0, 1.05 * (double)info.pairs / ((double)n_trees * (double)N));
-                const double per_row = 0.15 + (rows_pass_ns_per_row(row_tc, ws_mb, true) - 0.15) * active;
-                cost_other = std::min(cost_other, (double)n_trees / row_tc * (double)N * per_row * (double)ds->hpitch * 2 / 1536.0 + convert);
-            }
-            dense = g_dense == 1 || cost_dense < cost_other;
+            const double cost_dense = (double)N * per_row + (double)info.pairs * 0.008 * (double)ds->row_bytes() / 3072.0 + convert;
+            dense = g_dense == 1 || best_cost < 0 || cost_dense < best_cost;
         }
         if (dense) row_tc = 16;  // the level is row-major as far as node_of / side_bytes / the next level are concerned
         // Top levels: all normals of a group of >= 8 trees fit in LDS -> the LDS-resident variant of the row-major pass.
@@ -1999,23 +1997,30 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     da.gamma_s = (float)(2.0 * ((double)sv.hpitch + (double)sv.hpitch / 16 + 16.0) * 1.1920929e-7);
                     da.gamma_r = sv.gamma_r;
                     da.n_row_tiles = (uint32_t)((N + kDM - 1) / kDM);
-                    da.n_col_tiles = (n_nodes + kDN - 1) / kDN;
+                    const bool wide = n_nodes > 128;  // 256-column tiles (512 threads) unless one 128-column tile covers the level
+                    const uint32_t dense_bn = wide ? 256u : 128u;
+                    da.n_col_tiles = (n_nodes + dense_bn - 1) / dense_bn;
                     da.group = da.n_col_tiles > 1 ? kDenseGroup : 1u;
                     da.verify = verify;
                     const uint64_t r8 = (da.n_row_tiles + 7) / 8;
                     const uint64_t dgrid = 8 * ((r8 + da.group - 1) / da.group) * da.group * da.n_col_tiles;
                     AH_REQUIRE(dgrid < 0x7FFFFFFFull, AH_ERR_INVALID_ARGUMENT, "forest build: too many tiles for one launch");
                     const unsigned egrid = (unsigned)std::min<uint64_t>((((uint64_t)n_trees * N + 1023) / 1024 + 3) / 4, 1u << 16);
-#define AH_DENSE(M)                                                                                                      \
+#define AH_DENSE_WN(M, WNV)                                                                                              \
     do {                                                                                                                 \
         static std::atomic<bool> dense_opt_in[64]; /* once per instantiation and device */                              \
         if (!dense_opt_in[ds->device & 63].load(std::memory_order_acquire)) {                                            \
-            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_dense_screen<M>),                         \
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_dense_screen<M, WNV>),                    \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseLds));                     \
             dense_opt_in[ds->device & 63].store(true, std::memory_order_release);                                        \
         }                                                                                                                \
-        hipLaunchKernelGGL((k_forest_dense_screen<M>), dim3((unsigned)dgrid), dim3(kDenseThreads), kDenseLds, s, da,     \
-                           d_abort);                                                                                     \
+        hipLaunchKernelGGL((k_forest_dense_screen<M, WNV>), dim3((unsigned)dgrid), dim3(DenseShape<WNV>::kThreads),      \
+                           kDenseLds, s, da, d_abort);                                                                   \
+    } while (0)
+#define AH_DENSE(M)                                                                                                      \
+    do {                                                                                                                 \
+        if (wide) AH_DENSE_WN(M, 4);                                                                                     \
+        else AH_DENSE_WN(M, 2);                                                                                          \
         hipLaunchKernelGGL((k_forest_exact_pairs<M>), dim3(egrid), dim3(256), 0, s, dv, node_of.p, side_bytes.p,         \
                            (uint64_t)n_trees * N, chunk_d, nstride, hdr_off, d_counters, d_abort);                       \
     } while (0)
@@ -2025,6 +2030,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     case AH_COSINE: AH_DENSE(AH_COSINE); break;
                     default: AH_DENSE(AH_DOT_PRODUCT); break;
                     }
+#undef AH_DENSE_WN
 #undef AH_DENSE
                     forest->stats.dense_launches++;
                     forest->stats.dense_columns += n_nodes;

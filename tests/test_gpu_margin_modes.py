@@ -194,7 +194,9 @@ def test_baseline_config_3_split_sides_equal_oracle_at_10m():
     ds.finalize()
     f = ds.build_forest(shard.tree_seeds(42, range(trees)))
     launches = f.stats["margin_mode_launches"]
-    assert launches[0] > 0 and sum(launches[1:5]) > 0 and launches[5] + launches[6] > 0, launches  # node-major, rows, LDS
+    # node-major (deep levels), row-major (middle), and the top levels: dense MFMA screen (or LDS-resident row-major groups)
+    assert launches[0] > 0 and sum(launches[1:5]) > 0 and launches[5] + launches[6] + f.stats["dense_launches"] > 0, launches
+    assert f.stats["dense_launches"] > 0, f.stats
     assert f.stats["screened_launches"] > 0 and f.stats["screen_violations"] == 0
     vecs = O.synth(42, 1, n, dims)
     oracle = O.Data(O.COSINE, vecs)
