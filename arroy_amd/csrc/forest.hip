@@ -93,30 +93,33 @@ __global__ void k_ids_to_rows(DataView dv, uint32_t *perm, uint64_t total, uint3
 // One wave per pending node: sample 2+10 items with the policy RNG, run create_split.
 //
 // Normal records (device layout == the layout handed to the caller): [vector, row_bytes][header, 16-byte slot].
-__global__ __launch_bounds__(64) void k_forest_create_split(DataView dv, FNode *nodes, const uint32_t *__restrict__ perm,
-                                                            uint64_t n_items, uint8_t *normals, uint64_t nstride,
-                                                            uint64_t hdr_off) {
-    FNode &nd = nodes[blockIdx.x];
-    if (nd.state != ST_PENDING) return;
+__global__ __launch_bounds__(64) void k_forest_create_split(DataView dv, FNode *nodes, uint32_t n_nodes,
+                                                            const uint32_t *__restrict__ perm, uint64_t n_items,
+                                                            uint8_t *normals, uint64_t nstride, uint64_t hdr_off) {
     extern __shared__ float4 s_buf4[];
     float *s_buf = reinterpret_cast<float *>(s_buf4);
     __shared__ uint32_t s_rows[AH_SPLIT_SAMPLES];
     const uint32_t fpitch = f32_space_pitch(dv.metric, dv.dims);
-    const uint32_t *pp = perm + nd.start;  // starts are absolute positions in the batch permutation
-    if (threadIdx.x == 0) {
-        uint64_t a, b;
-        ah_choose_two(nd.key, nd.attempt, nd.count, &a, &b);  // src/parallel.rs:342-355
-        s_rows[0] = pp[a];
-        s_rows[1] = pp[b];
-        nd.n_left = 0;
-    } else if (threadIdx.x >= 2 && threadIdx.x < AH_SPLIT_SAMPLES) {
-        s_rows[threadIdx.x] = pp[ah_choose(nd.key, nd.attempt, threadIdx.x - 2, nd.count)];  // :358-367
+    for (uint32_t node = blockIdx.x; node < n_nodes; node += gridDim.x) {  // grid-stride: see node_grid in build_batch
+        FNode &nd = nodes[node];
+        if (nd.state != ST_PENDING) continue;
+        __syncthreads();  // the previous node's samples / two-means buffers are dead
+        const uint32_t *pp = perm + nd.start;  // starts are absolute positions in the batch permutation
+        if (threadIdx.x == 0) {
+            uint64_t a, b;
+            ah_choose_two(nd.key, nd.attempt, nd.count, &a, &b);  // src/parallel.rs:342-355
+            s_rows[0] = pp[a];
+            s_rows[1] = pp[b];
+            nd.n_left = 0;
+        } else if (threadIdx.x >= 2 && threadIdx.x < AH_SPLIT_SAMPLES) {
+            s_rows[threadIdx.x] = pp[ah_choose(nd.key, nd.attempt, threadIdx.x - 2, nd.count)];  // :358-367
+        }
+        __syncthreads();
+        uint8_t *rec = normals + node * nstride;
+        float *hdr = reinterpret_cast<float *>(rec + hdr_off);
+        wave_create_split_any(dv, s_rows, s_buf, s_buf + fpitch, s_buf + 2 * fpitch, rec, hdr, threadIdx.x);
+        if (threadIdx.x == 0) hdr[2] = hdr[3] = 0.0f;  // deterministic padding
     }
-    __syncthreads();
-    uint8_t *rec = normals + blockIdx.x * nstride;
-    float *hdr = reinterpret_cast<float *>(rec + hdr_off);
-    wave_create_split_any(dv, s_rows, s_buf, s_buf + fpitch, s_buf + 2 * fpitch, rec, hdr, threadIdx.x);
-    if (threadIdx.x == 0) hdr[2] = hdr[3] = 0.0f;  // deterministic padding
 }
 
 // The margin loop (src/writer.rs:1201-1207) for all pending nodes of the level, tile by tile.
@@ -828,7 +831,9 @@ __device__ __forceinline__ void screen_rows_chunk(float (&acc)[TC], const uint4 
 // chunk-major — block b works on rows [chunk * chunk_rows + tile * rows_per_block, ...) of group g with
 // chunk = b / (n_groups * tiles), g = (b / tiles) % n_groups, tile = b % tiles — so the passes of all groups over one chunk
 // of rows (48 MB of binary16 rows) run back to back and every pass but the first finds the chunk in the 256 MB Infinity
-// Cache.  Measured on the pass in isolation (scripts/micro/rows_pass_model.hip): a pass costs the L2 gather of its normals
+// Cache (which is also why the blocks must be launched one per work item: a grid-stride loop lets the blocks drift apart,
+// the window of rows in flight spreads over many chunks and the pass takes 1.5-2x as long; bigger blocks — 128 / 512 rows —
+// lose 20-60 %).  Measured on the pass in isolation (scripts/micro/rows_pass_model.hip): a pass costs the L2 gather of its normals
 // PLUS ~4.6 ms of HBM-latency-bound row stream (11.9 ms for 16 trees, 10M rows); with the rows coming from the Infinity
 // Cache 9.1-9.6 ms; 7.8 ms if they came from L2.  The row loads must be ordinary cached loads for that (non-temporal
 // ones do not stay: 11.1 ms).  group_nodes (LDS variant): first node of every tree in the level, nodes ordered by tree.
@@ -1220,9 +1225,12 @@ bool g_debug = getenv("AH_DEBUG") != nullptr;
 // AH_ROWMAJOR=0 disables the row-major margin pass, =1 forces it whenever it is legal;
 // AH_ROWMAJOR_CACHE_MB = budget for one group's normals of a level, AH_ROWMAJOR_MAX_TC = largest tree group.
 int g_rows_force = getenv("AH_ROWMAJOR") ? atoi(getenv("AH_ROWMAJOR")) : -1;
-// grid caps of the margin kernels (grid-stride beyond them).  One tile / 32 rows per block measured 2 % faster
-// than a 4096-block persistent grid on the 10M x 768 build.
+// grid caps (grid-stride beyond them): AH_FOREST_TILE_BLOCKS for the bookkeeping kernels over tiles (default: one tile per
+// block), AH_FOREST_NODE_BLOCKS for the node-major margin kernels (default: automatic, see node_grid), AH_FOREST_ROW_BLOCKS
+// for the f32 row-major passes.
 uint32_t g_tile_blocks = getenv("AH_FOREST_TILE_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_TILE_BLOCKS")) : (1u << 20);
+uint32_t g_node_blocks = getenv("AH_FOREST_NODE_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_NODE_BLOCKS")) : 0u;  // 0 = automatic
+uint32_t g_split_blocks = getenv("AH_FOREST_SPLIT_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_SPLIT_BLOCKS")) : 65536u;  // one wave per node
 uint32_t g_row_blocks = getenv("AH_FOREST_ROW_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_ROW_BLOCKS")) : (1u << 20);
 bool g_rows_advance = !(getenv("AH_ROWMAJOR_ADVANCE") && atoi(getenv("AH_ROWMAJOR_ADVANCE")) == 0);  // A/B switch
 bool g_rows_lds = !(getenv("AH_ROWMAJOR_LDS") && atoi(getenv("AH_ROWMAJOR_LDS")) == 0);              // A/B switch
@@ -1870,6 +1878,14 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_TRY(reserve_normals(chunk_host_off + chunk_bytes));
         prefault_normals.start(forest->normals + chunk_host_off, chunk_bytes);
         const unsigned tile_grid = std::min<uint32_t>(n_tiles, g_tile_blocks);
+        // The node-major margin kernels walk their tiles with a persistent grid: at the deep levels a tile is ~1200 items
+        // (~2 MB of rows) and launching one workgroup per tile — 819 000 of them at level 13 of the 10M x 100 build — cost
+        // 20 % of the level (measured: 306 -> 236 ms, the same 1.70 TB of fabric reads, TCC_EA0_RDREQ).  The small
+        // bookkeeping kernels keep one tile per block (their random 1-byte / 4-byte gathers want every block in flight),
+        // except the byte -> mask conversion of the top levels, whose reads are still nearly sequential.
+        const unsigned node_grid = g_node_blocks ? std::min<uint32_t>(n_tiles, g_node_blocks)
+                                                 : std::min<uint32_t>(n_tiles, std::max<uint32_t>(2048u, std::min<uint32_t>(65536u, n_tiles / 16u)));
+        const unsigned masks_grid = n_nodes <= 4 * n_trees ? std::min<uint32_t>(tile_grid, 32768u) : tile_grid;
 
         // ---- margin mode of the first attempt ------------------------------------------------------------------------
         // Row-major streams all N rows once per group of row_tc trees; node-major reads only the still-active items, once
@@ -1956,8 +1972,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         }
 
         for (int attempt = 0; attempt < 4; attempt++) {
-            hipLaunchKernelGGL(k_forest_create_split, dim3(n_nodes), dim3(64), cs_shared, s, dv, d_cur, cur, N, chunk_d,
-                               nstride, hdr_off);
+            hipLaunchKernelGGL(k_forest_create_split, dim3(std::min<uint32_t>(n_nodes, g_split_blocks)), dim3(64), cs_shared, s, dv,
+                               d_cur, n_nodes, cur, N, chunk_d, nstride, hdr_off);
             AH_DBG(s, "create_split");
             if (screen)
                 hipLaunchKernelGGL(k_forest_shadow_normals, dim3(n_nodes), dim3(64), 0, s, dv, d_cur, chunk_d, nstride, hdr_off,
@@ -2040,9 +2056,11 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     // chunk of rows run back to back and find it in the Infinity Cache; the last trees (fewer than a group) in
                     // launches of their own.  The LDS variant reads the first node of every tree from a device copy.
                     const uint32_t gtc = lds_tc ? lds_tc : row_tc;
-                    const uint32_t rpb = lds_tc ? 1024u : 32u;  // rows per block
+                    static const uint32_t env_rpb = getenv("AH_ROWS_PER_BLOCK") ? (uint32_t)atoi(getenv("AH_ROWS_PER_BLOCK")) / 32u * 32u : 0u;
+                    const uint32_t rpb = lds_tc ? 1024u : env_rpb ? env_rpb : 32u;  // rows per block
                     const uint64_t hrow = (uint64_t)sv.hpitch * 2;
-                    uint32_t chunk_rows = (uint32_t)std::max<uint64_t>(rpb, ((48ull << 20) / hrow) / rpb * rpb);
+                    static const uint64_t chunk_mb = getenv("AH_ROWS_CHUNK_MB") ? (uint64_t)atoi(getenv("AH_ROWS_CHUNK_MB")) : 48;
+                    uint32_t chunk_rows = (uint32_t)std::max<uint64_t>(rpb, ((chunk_mb << 20) / hrow) / rpb * rpb);
                     if (chunk_rows > N) chunk_rows = (uint32_t)((N + rpb - 1) / rpb * rpb);
                     const uint32_t n_chunks = (uint32_t)((N + chunk_rows - 1) / chunk_rows);
                     ScreenRowsArgs ra{dv, sv, node_of.p, 0, 0, chunk_d, nstride, hdr_off, shadow_d, hstride, side_bytes.p,
@@ -2152,13 +2170,13 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     passes++;
                     t0 += np;
                 }
-                hipLaunchKernelGGL(k_forest_masks_from_bytes, dim3(tile_grid), dim3(kBlock), 0, s, d_cur, d_tiles.p, n_tiles,
+                hipLaunchKernelGGL(k_forest_masks_from_bytes, dim3(masks_grid), dim3(kBlock), 0, s, d_cur, d_tiles.p, n_tiles,
                                    cur, N, side_bytes.p, masks.p, tile_left.p);
                 if (lds_tc && !screen) passes = (n_trees + lds_tc - 1) / lds_tc;
                 forest->stats.margin_row_passes += passes;
                 if (screen) forest->stats.screened_launches += passes;
             } else if (bq) {
-                hipLaunchKernelGGL(k_forest_margin_bq, dim3(tile_grid), dim3(kBlock), dv.pitch * 8, s, dv, d_cur, d_tiles.p,
+                hipLaunchKernelGGL(k_forest_margin_bq, dim3(node_grid), dim3(kBlock), dv.pitch * 8, s, dv, d_cur, d_tiles.p,
                                    n_tiles, cur, N, chunk_d, nstride, hdr_off, masks.p, tile_left.p, d_abort);
                 forest->stats.margin_mode_launches[MM_BQ]++;
             } else if (screen) {
@@ -2168,7 +2186,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         if (sh > 48 * 1024) /* very long vectors: opt in to more dynamic LDS than the default limit */                    \
             AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_screen_node<M>),                           \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                             \
-        hipLaunchKernelGGL((k_forest_screen_node<M>), dim3(tile_grid), dim3(kBlock), sh, s, dv, sv, d_cur, d_tiles.p,     \
+        hipLaunchKernelGGL((k_forest_screen_node<M>), dim3(node_grid), dim3(kBlock), sh, s, dv, sv, d_cur, d_tiles.p,     \
                            n_tiles, cur, chunk_d, nstride, hdr_off, shadow_d, hstride, masks.p, tile_left.p, d_abort,     \
                            d_counters, verify);                                                                           \
     } while (0)
@@ -2188,7 +2206,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         if (sh > 48 * 1024)                                                                                         \
             AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_margin_f32<M>),                      \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                       \
-        hipLaunchKernelGGL((k_forest_margin_f32<M>), dim3(tile_grid), dim3(kBlock), sh, s, dv, d_cur, d_tiles.p,    \
+        hipLaunchKernelGGL((k_forest_margin_f32<M>), dim3(node_grid), dim3(kBlock), sh, s, dv, d_cur, d_tiles.p,    \
                            n_tiles, cur, N, chunk_d, nstride, hdr_off, masks.p, tile_left.p, d_abort);              \
     } while (0)
                 switch (ds->metric) {
@@ -2236,11 +2254,20 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         }
         lvl_status = wait_level();
         if (lvl_status != AH_OK) return lvl_status;
+        float attempt_ms[4] = {0.f, 0.f, 0.f, 0.f};
         for (int attempt = 0; attempt < 4; attempt++) {
             float m = 0.0f;
-            if (hipEventElapsedTime(&m, bc.ev_attempt[2 * attempt], bc.ev_attempt[2 * attempt + 1]) == hipSuccess)
+            if (hipEventElapsedTime(&m, bc.ev_attempt[2 * attempt], bc.ev_attempt[2 * attempt + 1]) == hipSuccess) {
                 forest->stats.seconds_margin += m * 1e-3;
+                attempt_ms[attempt] = m;
+            }
         }
+        static const int timing = getenv("AH_TIMING") ? atoi(getenv("AH_TIMING")) : 0;
+        if (timing >= 2)
+            fprintf(stderr, "[ah] level %2u: %8u nodes %12llu pairs  mode %s  margin pass %.2f ms (+ retries %.2f) = %.3f ns per pair\n",
+                    depth, n_nodes, (unsigned long long)info.pairs,
+                    dense ? "dense-mfma" : lds_tc ? "rows-lds" : row_tc >= 2 ? "rows" : "node-major", attempt_ms[0],
+                    attempt_ms[1] + attempt_ms[2] + attempt_ms[3], info.pairs ? attempt_ms[0] * 1e6 / (double)info.pairs : 0.0);
         forest->stats.margin_launches += 4;
         // this level's node table follows on the side stream (the level is complete: no stream dependency needed)
         AH_HIP(hipMemcpyAsync(h_nodes[depth & 1], d_cur, n_nodes * sizeof(FNode), hipMemcpyDeviceToHost, bc.side));
