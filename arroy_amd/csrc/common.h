@@ -92,6 +92,7 @@ struct ScreenView {
     const float4 *stats;
     uint32_t hpitch;
     float gamma_s, gamma_r;  // accumulation-error factors of the screen / of the reference f32 reduction
+    float4 max_stats;        // component-wise maximum of `stats` over all rows: a bound that needs no per-row load
 };
 
 // One per concurrently calling host thread: a stream plus growable device / pinned scratch.
@@ -131,6 +132,7 @@ struct ah_dataset {
     // lazily built binary16 shadow (first forest build of an f32 dataset); nullptr = not built / not available
     uint16_t *d_rows_h16 = nullptr;
     float4 *d_screen_stats = nullptr;
+    float screen_max[4] = {0.f, 0.f, 0.f, 0.f};  // component-wise maximum of the per-row stats (host copy)
     uint32_t hpitch = 0;
     bool screen_tried = false;
     // staging in flight (ah_dataset_upload_*): the context whose stream / pinned ring the uploads use until

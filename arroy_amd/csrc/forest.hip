@@ -630,6 +630,28 @@ __global__ __launch_bounds__(kBlock) void k_shadow_rows(DataView dv, uint16_t *_
     }
 }
 
+// Component-wise maximum of the per-row stats (all >= 0, so the bit patterns order like the values; inf / NaN end up on
+// top and simply disable the cheap test below).  The node-major screen tries the bound built from these maxima first — it
+// needs no per-row load — and fetches the row's own stats (a 16-byte random read = one more 128-byte line per pair) only
+// when that bound cannot decide: for rows of similar norms that is ~1.5 % of the pairs.
+__global__ __launch_bounds__(256) void k_stats_max(const float4 *__restrict__ stats, uint64_t n, uint32_t *__restrict__ out) {
+    __shared__ uint32_t s_m[3];
+    if (threadIdx.x < 3) s_m[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t a = 0, b = 0, c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float4 v = stats[i];
+        a = max(a, __float_as_uint(v.x));
+        b = max(b, __float_as_uint(v.y));
+        c = max(c, __float_as_uint(v.z));
+    }
+    atomicMax(&s_m[0], a);
+    atomicMax(&s_m[1], b);
+    atomicMax(&s_m[2], c);
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMax(&out[threadIdx.x], s_m[threadIdx.x]);
+}
+
 // The level's normals (records [vector][header slot]) -> shadow records [hpitch halves][NormalStats], one wave per node.
 __global__ __launch_bounds__(64) void k_forest_shadow_normals(DataView dv, const FNode *__restrict__ nodes,
                                                               const uint8_t *__restrict__ normals, uint64_t nstride,
@@ -745,7 +767,10 @@ __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, Scre
             const float s = screen_octet_dot(s_h4 + j, r4, steps);
             const float row_extra = METRIC == AH_DOT_PRODUCT ? dv.headers[2 * row] : 0.0f;
             uint32_t side;
-            const bool decided = screen_decides<METRIC>(s, sv.stats[row], ns, row_extra, sv.gamma_s, sv.gamma_r, side);
+            // the bound from the dataset-wide maxima first (monotone in every stat, so it is >= the row's own bound); the
+            // row's stats only when that one cannot decide
+            bool decided = screen_decides<METRIC>(s, sv.max_stats, ns, row_extra, sv.gamma_s, sv.gamma_r, side);
+            if (!decided) decided = screen_decides<METRIC>(s, sv.stats[row], ns, row_extra, sv.gamma_s, sv.gamma_r, side);
             if (!decided || verify) {  // octet-uniform
                 const uint32_t exact = side_of_margin(margin_f32<METRIC>(dv, s_n, nh, row, j));
                 if (decided && exact != side) bad++;
@@ -1340,12 +1365,22 @@ static bool ensure_screen(ah_dataset *ds, hipStream_t s) {
     const DataView dv = ds->view();
     const unsigned grid = (unsigned)std::min<uint64_t>((ds->n + 31) / 32, 1u << 20);
     hipLaunchKernelGGL(k_shadow_rows, dim3(grid), dim3(kBlock), 0, s, dv, rows, hpitch, stats);
-    if (hipStreamSynchronize(s) != hipSuccess) {
+    uint32_t *d_max = nullptr;
+    uint32_t h_max[4] = {0u, 0u, 0u, 0u};
+    bool ok = hipMalloc((void **)&d_max, 16) == hipSuccess && hipMemsetAsync(d_max, 0, 16, s) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_stats_max, dim3(1024), dim3(256), 0, s, stats, (uint64_t)ds->n, d_max);
+        ok = hipMemcpyAsync(h_max, d_max, 16, hipMemcpyDeviceToHost, s) == hipSuccess;
+    }
+    if (hipStreamSynchronize(s) != hipSuccess || !ok) {
         (void)hipGetLastError();
         (void)hipFree(rows);
         (void)hipFree(stats);
+        if (d_max) (void)hipFree(d_max);
         return false;
     }
+    (void)hipFree(d_max);
+    memcpy(ds->screen_max, h_max, 16);
     ds->d_rows_h16 = rows;
     ds->d_screen_stats = stats;
     ds->hpitch = hpitch;
@@ -1645,6 +1680,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     if (screen) {
         sv.rows = ds->d_rows_h16;
         sv.stats = ds->d_screen_stats;
+        sv.max_stats = make_float4(ds->screen_max[0], ds->screen_max[1], ds->screen_max[2], 0.0f);
         sv.hpitch = ds->hpitch;
         // accumulation-error factors (screen_device.h), each with a 4x safety factor over the standard model:
         //   screen: hpitch/16 dot2c per lane (2 roundings each) + 4 adds;  reference: dims/32 FMAs per chain, 6 adds of
