@@ -280,7 +280,8 @@ typedef struct ah_forest_view {
     const ah_node *nodes;         /* n_nodes, children before parents (post-order) inside each tree  */
     /* Normals: one fixed-size record per split node at byte `ah_node.offset` of `normals`.  Inside a record
      * the vector (metric codec, ah_vector_size bytes) sits at `normal_vector_offset` and D::Header
-     * (ah_header_size bytes) at `normal_header_offset`.  (The records are the device layout copied back
+     * (ah_header_size bytes) at `normal_header_offset`; `normal_stride` may exceed their sum (the f32 metrics pad a
+     * record to whole 128-byte lines, the padding is zero).  (The records are the device layout copied back
      * verbatim, so nothing is repacked on the host; the Rust side copies both parts into the LMDB value
      * `[2u8][left][right][header][vector]` anyway, src/node.rs:229-237.) */
     const uint8_t *normals;
