@@ -865,6 +865,8 @@ __device__ __forceinline__ void screen_rows_chunk(float (&acc)[TC], const uint4 
 // ones do not stay: 11.1 ms).  group_nodes (LDS variant): first node of every tree in the level, nodes ordered by tree.
 struct RowsSchedule {
     uint32_t n_groups, tiles, chunk_rows, rows_per_block;
+    uint32_t xcd_slots;  // 0: every (chunk, group) is spread over all XCDs; k > 0: one XCD per (chunk, group), k groups per XCD
+    uint32_t chunk0;     // first chunk of this launch (a launch is limited to 2^32 work-items, so big levels take several)
     const uint32_t *tree_first;  // LDS variant: device copy of tree_first[n_trees + 1]
 };
 template <int METRIC, int TC, bool LDS_NORMALS>
@@ -877,9 +879,26 @@ __global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock,
     extern __shared__ uint4 s_shadow4[];
     __shared__ uint32_t s_fb, s_bad;
     if (abort_requested(abort_flag)) return;
-    const uint32_t per_chunk = sch.n_groups * sch.tiles;
-    const uint32_t chunk = blockIdx.x / per_chunk, in_chunk = blockIdx.x % per_chunk;
-    const uint32_t group = in_chunk / sch.tiles, tile = in_chunk % sch.tiles;
+    uint32_t chunk, group, tile;
+    if (sch.xcd_slots) {
+        // One XCD per (chunk, group): workgroups go to the XCDs round-robin (block b -> XCD b & 7), so XCD x takes, for
+        // chunk c, the groups g = ((x - c) mod 8) + 8 k — the rotation by c evens out n_groups mod 8 over the chunks.  An
+        // XCD's L2 (4 MiB) then holds the normals of ONE group next to the row stream instead of those of the two
+        // groups that are in flight at any time when every group is spread over all eight.
+        const uint32_t x = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        const uint32_t per_chunk = sch.xcd_slots * sch.tiles;
+        chunk = sch.chunk0 + slot / per_chunk;
+        const uint32_t rem = slot % per_chunk;
+        tile = rem % sch.tiles;
+        group = ((x + 8u - (chunk & 7u)) & 7u) + 8u * (rem / sch.tiles);
+        if (group >= sch.n_groups) return;  // block-uniform
+    } else {
+        const uint32_t per_chunk = sch.n_groups * sch.tiles;
+        chunk = sch.chunk0 + blockIdx.x / per_chunk;
+        const uint32_t in_chunk = blockIdx.x % per_chunk;
+        group = in_chunk / sch.tiles;
+        tile = in_chunk % sch.tiles;
+    }
     const uint32_t tree0 = tree_base + group * TC;
     const uint64_t row_begin = (uint64_t)chunk * sch.chunk_rows + (uint64_t)tile * sch.rows_per_block;
     const uint64_t row_end = min(min(row_begin + sch.rows_per_block, (uint64_t)(chunk + 1) * sch.chunk_rows), dv.n);
@@ -1257,6 +1276,7 @@ int g_rows_force = getenv("AH_ROWMAJOR") ? atoi(getenv("AH_ROWMAJOR")) : -1;
 uint32_t g_tile_blocks = getenv("AH_FOREST_TILE_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_TILE_BLOCKS")) : (1u << 20);
 uint32_t g_node_blocks = getenv("AH_FOREST_NODE_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_NODE_BLOCKS")) : 0u;  // 0 = automatic
 uint32_t g_split_blocks = getenv("AH_FOREST_SPLIT_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_SPLIT_BLOCKS")) : 65536u;  // one wave per node
+bool g_rows_xcd = !(getenv("AH_ROWS_XCD") && atoi(getenv("AH_ROWS_XCD")) == 0);  // one XCD per (chunk, tree group): A/B switch
 uint32_t g_row_blocks = getenv("AH_FOREST_ROW_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_ROW_BLOCKS")) : (1u << 20);
 bool g_rows_advance = !(getenv("AH_ROWMAJOR_ADVANCE") && atoi(getenv("AH_ROWMAJOR_ADVANCE")) == 0);  // A/B switch
 bool g_rows_lds = !(getenv("AH_ROWMAJOR_LDS") && atoi(getenv("AH_ROWMAJOR_LDS")) == 0);              // A/B switch
@@ -1334,7 +1354,7 @@ double rows_pass_ns_per_row(uint32_t tc, double ws_mb, bool screened) {
     static const CostPt s8[] = {{0.012, 0.58}, {0.1, 0.61}, {0.2, 0.67}, {0.4, 0.71}, {0.8, 0.74}, {1.6, 0.77}, {3.2, 0.85},
                                 {6.4, 1.24}, {12.7, 1.66}, {25, 1.94}, {51, 2.09}, {102, 2.15}};
     static const CostPt s4[] = {{0.025, 0.325}, {0.05, 0.353}, {0.1, 0.415}, {0.2, 0.463}, {0.4, 0.493}, {0.8, 0.511},
-                                {1.6, 0.535}, {3.2, 0.591}, {6.4, 0.759}, {12.7, 0.918}, {25, 1.04}, {51, 1.10}};
+                                {1.7, 0.45}, {3.4, 0.50}, {6.8, 0.75}, {13.6, 0.95}, {27, 1.06}, {54, 1.12}};  // one XCD per group
     static const CostPt s2[] = {{0.003, 0.235}, {0.05, 0.243}, {0.1, 0.261}, {0.2, 0.274}, {0.4, 0.284}, {0.8, 0.292},
                                 {1.6, 0.314}, {3.2, 0.389}, {6.4, 0.49}, {12.7, 0.56}, {25, 0.60}};
     if (screened) return tc >= 16 ? interp(s16, ws_mb) : tc == 8 ? interp(s8, ws_mb) : tc == 4 ? interp(s4, ws_mb) : interp(s2, ws_mb);
@@ -1981,7 +2001,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         // n_trees / tc passes.  Cost: the rows leave HBM once (binary16), hpitch multiply-adds per (row, column) at the
         // sustained MFMA rate, an epilogue per (row, tree), and the reference arithmetic for the pairs left open.
         bool dense = false;
-        const bool dense_legal = rows_allowed && screen && g_dense != 0 && n_nodes <= g_dense_max_cols;
+        // (a launch carries at most 2^32 - 1 work-items: 512 threads x row tiles x column tiles)
+        const bool dense_legal = rows_allowed && screen && g_dense != 0 && n_nodes <= g_dense_max_cols &&
+                                 ((N + kDM - 1) / kDM + 64) * (((uint64_t)n_nodes + 127) / 128) * 512ull < 0xFFFFFFFFull;
         if (dense_legal && mode_req == AH_MARGIN_DENSE_MFMA) {
             dense = true;
         } else if (dense_legal && mode_req == AH_MARGIN_AUTO) {
@@ -2112,7 +2134,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     if (chunk_rows > N) chunk_rows = (uint32_t)((N + rpb - 1) / rpb * rpb);
                     const uint32_t n_chunks = (uint32_t)((N + chunk_rows - 1) / chunk_rows);
                     ScreenRowsArgs ra{dv, sv, node_of.p, 0, 0, chunk_d, nstride, hdr_off, shadow_d, hstride, side_bytes.p,
-                                      RowsSchedule{1, chunk_rows / rpb, chunk_rows, rpb, d_tree_first_fixed}, d_abort, d_counters, verify};
+                                      RowsSchedule{1, chunk_rows / rpb, chunk_rows, rpb, 0, 0, d_tree_first_fixed}, d_abort, d_counters, verify};
                     if (lds_tc) {
                         memcpy(h_tree_first, tree_first.data(), ((size_t)n_trees + 1) * 4);
                         AH_HIP(hipMemcpyAsync(d_tree_first_fixed, h_tree_first, ((size_t)n_trees + 1) * 4, hipMemcpyHostToDevice, s));
@@ -2122,9 +2144,20 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                         ra.tree_base = t0;
                         ra.n_pass = np;
                         ra.sch.n_groups = groups;
-                        const uint64_t grid = (uint64_t)n_chunks * groups * ra.sch.tiles;
-                        AH_REQUIRE(grid < 0x7FFFFFFFull, AH_ERR_INVALID_ARGUMENT, "forest build: too many rows for one launch");
-                        AH_TRY(launch_screen_rows(ds->metric, tcv, lds_tc != 0, ra, (unsigned)grid, lds_sh, s, ds->device));
+                        // one XCD per (chunk, group) pays for small groups of many trees (measured at 10M x 100 trees: TC=4
+                        // level 9 139 -> 124 ms, level 10 199 -> 188; TC=2 level 10 211 -> 193; TC=8 with its 12 groups on 8
+                        // XCDs: level 8 111 -> 120, so not there)
+                        ra.sch.xcd_slots = (!lds_tc && g_rows_xcd && tcv <= 4 && groups >= 16) ? (groups + 7) / 8 : 0u;
+                        // a launch carries at most 2^32 - 1 work-items: big levels go out in several launches over chunk ranges
+                        const uint64_t per_chunk = ra.sch.xcd_slots ? 8ull * ra.sch.xcd_slots * ra.sch.tiles : (uint64_t)groups * ra.sch.tiles;
+                        const uint64_t threads = lds_tc ? (tcv >= 16 ? 512u : 1024u) : (unsigned)kBlock;
+                        AH_REQUIRE(per_chunk * threads < 0xFFFFFFFFull, AH_ERR_INVALID_ARGUMENT, "forest build: too many trees for one row-major launch");
+                        const uint32_t chunks_per_launch = (uint32_t)std::min<uint64_t>(n_chunks, (0xFFFFFFFFull / threads) / per_chunk);
+                        for (uint32_t c0 = 0; c0 < n_chunks; c0 += chunks_per_launch) {
+                            ra.sch.chunk0 = c0;
+                            const uint64_t grid = (uint64_t)std::min<uint32_t>(chunks_per_launch, n_chunks - c0) * per_chunk;
+                            AH_TRY(launch_screen_rows(ds->metric, tcv, lds_tc != 0, ra, (unsigned)grid, lds_sh, s, ds->device));
+                        }
                         forest->stats.margin_mode_launches[lds_tc ? (tcv >= 16 ? MM_LDS16 : MM_LDS8) : mm_rows(tcv)]++;
                         passes += groups;
                         return AH_OK;
