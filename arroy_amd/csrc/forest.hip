@@ -825,10 +825,15 @@ __device__ __forceinline__ float rows_exact_margin(const DataView &dv, uint64_t 
 // free to run ahead into the next trees, so a wave keeps dozens of 16-byte loads in flight.
 template <int TC, int NS>
 __device__ __forceinline__ void screen_rows_chunk(float (&acc)[TC], const uint4 *base4, const uint32_t (&noff)[TC],
-                                                  const uint4 *r4, uint32_t k) {
+                                                  const uint4 *r4, uint32_t k, bool nt_rows = false) {
     uint4 x[NS];
+    if (nt_rows) {
 #pragma unroll
-    for (int u = 0; u < NS; u++) x[u] = r4[(k + u) * 8];  // cached on purpose: the other tree groups re-read the chunk
+        for (int u = 0; u < NS; u++) x[u] = ld_stream_u4(r4 + (k + u) * 8);
+    } else {
+#pragma unroll
+        for (int u = 0; u < NS; u++) x[u] = r4[(k + u) * 8];  // cached on purpose: the other tree groups re-read the chunk
+    }
 #pragma unroll
     for (int t = 0; t < TC; t++) {
         const uint4 *np = base4 + noff[t] + k * 8;
@@ -866,6 +871,7 @@ __device__ __forceinline__ void screen_rows_chunk(float (&acc)[TC], const uint4 
 struct RowsSchedule {
     uint32_t n_groups, tiles, chunk_rows, rows_per_block;
     uint32_t xcd_slots;  // 0: every (chunk, group) is spread over all XCDs; k > 0: one XCD per (chunk, group), k groups per XCD
+                         // (bit 31: stream the rows with non-temporal loads)
     uint32_t chunk0;     // first chunk of this launch (a launch is limited to 2^32 work-items, so big levels take several)
     const uint32_t *tree_first;  // LDS variant: device copy of tree_first[n_trees + 1]
 };
@@ -880,13 +886,13 @@ __global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock,
     __shared__ uint32_t s_fb, s_bad;
     if (abort_requested(abort_flag)) return;
     uint32_t chunk, group, tile;
-    if (sch.xcd_slots) {
+    if (sch.xcd_slots & 0x7FFFFFFFu) {
         // One XCD per (chunk, group): workgroups go to the XCDs round-robin (block b -> XCD b & 7), so XCD x takes, for
         // chunk c, the groups g = ((x - c) mod 8) + 8 k — the rotation by c evens out n_groups mod 8 over the chunks.  An
         // XCD's L2 (4 MiB) then holds the normals of ONE group next to the row stream instead of those of the two
         // groups that are in flight at any time when every group is spread over all eight.
         const uint32_t x = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-        const uint32_t per_chunk = sch.xcd_slots * sch.tiles;
+        const uint32_t per_chunk = (sch.xcd_slots & 0x7FFFFFFFu) * sch.tiles;
         chunk = sch.chunk0 + slot / per_chunk;
         const uint32_t rem = slot % per_chunk;
         tile = rem % sch.tiles;
@@ -952,10 +958,11 @@ __global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock,
         // 8 + 4 beats a single chunk of 12 (the extra 16 row registers cost a wave of occupancy per SIMD: 7.7 -> 10.8 ms
         // per 8-tree pass).
         uint32_t k = 0;
-        for (; k + AH_SCREEN_CHUNK <= steps; k += AH_SCREEN_CHUNK) screen_rows_chunk<TC, AH_SCREEN_CHUNK>(acc, base4, noff, r4, k);
+        const bool nt_rows = (sch.xcd_slots & 0x80000000u) != 0;
+        for (; k + AH_SCREEN_CHUNK <= steps; k += AH_SCREEN_CHUNK) screen_rows_chunk<TC, AH_SCREEN_CHUNK>(acc, base4, noff, r4, k, nt_rows);
 #if AH_SCREEN_CHUNK > 4
         if (k + 4 <= steps) {
-            screen_rows_chunk<TC, 4>(acc, base4, noff, r4, k);
+            screen_rows_chunk<TC, 4>(acc, base4, noff, r4, k, nt_rows);
             k += 4;
         }
 #endif
@@ -1354,7 +1361,7 @@ double rows_pass_ns_per_row(uint32_t tc, double ws_mb, bool screened) {
     static const CostPt s8[] = {{0.012, 0.58}, {0.1, 0.61}, {0.2, 0.67}, {0.4, 0.71}, {0.8, 0.74}, {1.6, 0.77}, {3.2, 0.85},
                                 {6.4, 1.24}, {12.7, 1.66}, {25, 1.94}, {51, 2.09}, {102, 2.15}};
     static const CostPt s4[] = {{0.025, 0.325}, {0.05, 0.353}, {0.1, 0.415}, {0.2, 0.463}, {0.4, 0.493}, {0.8, 0.511},
-                                {1.7, 0.45}, {3.4, 0.50}, {6.8, 0.75}, {13.6, 0.95}, {27, 1.06}, {54, 1.12}};  // one XCD per group
+                                {1.7, 0.45}, {3.4, 0.50}, {6.8, 0.69}, {13.6, 0.90}, {27, 1.03}, {54, 1.10}};  // one XCD per group, nt rows > 5 MB
     static const CostPt s2[] = {{0.003, 0.235}, {0.05, 0.243}, {0.1, 0.261}, {0.2, 0.274}, {0.4, 0.284}, {0.8, 0.292},
                                 {1.6, 0.314}, {3.2, 0.389}, {6.4, 0.49}, {12.7, 0.56}, {25, 0.60}};
     if (screened) return tc >= 16 ? interp(s16, ws_mb) : tc == 8 ? interp(s8, ws_mb) : tc == 4 ? interp(s4, ws_mb) : interp(s2, ws_mb);
@@ -2150,6 +2157,13 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                         ra.sch.xcd_slots = (!lds_tc && g_rows_xcd && tcv <= 4 && groups >= 16) ? (groups + 7) / 8 : 0u;
                         // a launch carries at most 2^32 - 1 work-items: big levels go out in several launches over chunk ranges
                         const uint64_t per_chunk = ra.sch.xcd_slots ? 8ull * ra.sch.xcd_slots * ra.sch.tiles : (uint64_t)groups * ra.sch.tiles;
+                        // One XCD per group: the rows of a (chunk, group) are read once by that XCD, so in its L2 they only
+                        // compete with the group's normals.  When those no longer fit (> ~5 MB) the rows are streamed with
+                        // non-temporal loads (level 10 at 10M x 100 trees: 188 -> 171 ms); while they fit, cached row loads are
+                        // better (the chunk then stays in the Infinity Cache for the other groups: level 9 125 vs 142 ms).
+                        static const int nt_env = getenv("AH_ROWS_NT") ? atoi(getenv("AH_ROWS_NT")) : -1;
+                        const bool nt_rows = nt_env >= 0 ? nt_env != 0 : (uint64_t)tcv * nodes_per_tree * rec_bytes > (5ull << 20);
+                        if (ra.sch.xcd_slots && nt_rows) ra.sch.xcd_slots |= 0x80000000u;
                         const uint64_t threads = lds_tc ? (tcv >= 16 ? 512u : 1024u) : (unsigned)kBlock;
                         AH_REQUIRE(per_chunk * threads < 0xFFFFFFFFull, AH_ERR_INVALID_ARGUMENT, "forest build: too many trees for one row-major launch");
                         const uint32_t chunks_per_launch = (uint32_t)std::min<uint64_t>(n_chunks, (0xFFFFFFFFull / threads) / per_chunk);
