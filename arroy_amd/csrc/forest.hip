@@ -2020,9 +2020,11 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             const uint32_t bn = n_nodes > 128 ? 256u : 128u;
             const double cols = (double)(((uint64_t)n_nodes + bn - 1) / bn * bn);
             const double hscale = (double)ds->hpitch / 768.0;
-            const double per_row = std::max(0.40 * hscale, 0.17 * hscale + 0.0023 * n_trees + cols * (double)ds->hpitch / g_dense_gmacs);
+            // (short rows: a tile's k-loop is a few latency-bound steps and the epilogue does not shrink with the row — never
+            // below 0.25 ns per row; the exact pass scans a byte per pair whatever the row length)
+            const double per_row = std::max(std::max(0.40 * hscale, 0.25), 0.17 * hscale + 0.0023 * n_trees + cols * (double)ds->hpitch / g_dense_gmacs);
             const double convert = (double)n_trees * (double)N * (prev_rows && g_rows_advance ? 0.007 : 0.04);
-            const double cost_dense = (double)N * per_row + (double)info.pairs * 0.008 * (double)ds->row_bytes() / 3072.0 + convert;
+            const double cost_dense = (double)N * per_row + (double)info.pairs * (0.002 + 0.006 * (double)ds->row_bytes() / 3072.0) + convert;
             dense = g_dense == 1 || best_cost < 0 || cost_dense < best_cost;
         }
         if (dense) row_tc = 16;  // the level is row-major as far as node_of / side_bytes / the next level are concerned
