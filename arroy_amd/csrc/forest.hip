@@ -539,14 +539,20 @@ __global__ __launch_bounds__(kBlock) void k_forest_scatter(const FNode *__restri
                                                            uint32_t split_after) {
     __shared__ uint64_t s_masks[32];
     __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_in[kTile], s_out[kTile];  // the tile's items as read / partitioned (lefts first)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const FTile tl = tiles[tile];
         const FNode nd = nodes[tl.node];
+        const uint32_t in_tile = min(kTile, nd.count - tl.first);
+        const uint64_t base = nd.start;
         __syncthreads();
         if (threadIdx.x < 32) s_masks[threadIdx.x] = masks[(uint64_t)tile * 32 + threadIdx.x];
+        {  // coalesced read of the tile
+            const uint32_t *src = perm_cur + base + tl.first;
+            for (uint32_t p = threadIdx.x; p < in_tile; p += kBlock) s_in[p] = src[p];
+        }
         __syncthreads();
-        const uint32_t in_tile = min(kTile, nd.count - tl.first);
         const uint32_t p0 = threadIdx.x * 8;
         const uint32_t i = p0 >> 5;
         const uint32_t nvalid = p0 < in_tile ? min(8u, in_tile - p0) : 0u;
@@ -561,19 +567,30 @@ __global__ __launch_bounds__(kBlock) void k_forest_scatter(const FNode *__restri
         }
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
-        uint32_t wave_base = 0;
-        for (uint32_t w = 0; w < wave; w++) wave_base += s_wave[w];
-        uint32_t left_before = tile_left_off[tile] + wave_base + incl - my_left;  // lefts before p0, inside the node
-        uint32_t right_before = (tl.first + p0) - left_before;
-        const uint64_t base = nd.start;
-        const uint32_t n_right = nd.count - nd.n_left;
-        uint32_t *dst_l = (nd.n_left <= split_after ? final_perm : perm_next) + base;
-        uint32_t *dst_r = (n_right <= split_after ? final_perm : perm_next) + base + nd.n_left;
-        const uint32_t *src = perm_cur + base + tl.first + p0;
+        uint32_t wave_base = 0, tile_lefts = 0;
+        for (uint32_t w = 0; w < kBlock / 64; w++) {
+            if (w < wave) wave_base += s_wave[w];
+            tile_lefts += s_wave[w];
+        }
+        // stable partition inside LDS: lefts to [0, tile_lefts), rights to [tile_lefts, in_tile), order kept
+        uint32_t lp = wave_base + incl - my_left;  // lefts of the tile before p0
+        uint32_t rp = tile_lefts + (p0 - lp);      // rights of the tile before p0, behind all lefts
         for (uint32_t e = 0; e < nvalid; e++) {
-            const uint32_t row = src[e];
-            if ((sidebits >> e) & 1u) dst_r[right_before++] = row;
-            else dst_l[left_before++] = row;
+            const uint32_t row = s_in[p0 + e];
+            if ((sidebits >> e) & 1u) s_out[rp++] = row;
+            else s_out[lp++] = row;
+        }
+        __syncthreads();
+        // two contiguous runs out, coalesced: the node's lefts before this tile = tile_left_off, its rights before it =
+        // items before the tile - lefts before the tile
+        const uint32_t lefts_before = tile_left_off[tile];
+        const uint32_t n_right = nd.count - nd.n_left;
+        uint32_t *dst_l = (nd.n_left <= split_after ? final_perm : perm_next) + base + lefts_before;
+        uint32_t *dst_r = (n_right <= split_after ? final_perm : perm_next) + base + nd.n_left + (tl.first - lefts_before);
+        for (uint32_t p = threadIdx.x; p < in_tile; p += kBlock) {
+            const uint32_t row = s_out[p];
+            if (p < tile_lefts) dst_l[p] = row;
+            else dst_r[p - tile_lefts] = row;
         }
     }
 }
