@@ -421,35 +421,53 @@ __global__ __launch_bounds__(kBlock) void k_forest_masks_from_bytes(FNode *nodes
                                                                     const uint8_t *__restrict__ side_bytes,
                                                                     uint64_t *__restrict__ masks,
                                                                     uint32_t *__restrict__ tile_left) {
-    __shared__ uint32_t s_left;
-    __shared__ uint8_t s_side[kTile];
+    // Item p of a tile is bit (p >> 5) of mask (p & 31).  Thread (wave w, lane l) takes the items 256 k + 64 w + l, k = 0..7:
+    // the ballot of its k-th side over the wave holds, for every mask o, the two bits 8 k + 2 w (lane o) and 8 k + 2 w + 1
+    // (lane o + 32).  The 32 ballots of a tile go through LDS; thread o < 32 assembles mask o from them.
+    __shared__ uint64_t s_ballot[8][kBlock / 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const FTile tl = tiles[tile];
         const FNode *nd = nodes + tl.node;
         if (nd->state != ST_PENDING) continue;
-        __syncthreads();
-        if (threadIdx.x == 0) s_left = 0;
         const uint32_t in_tile = min(kTile, nd->count - tl.first);
         const uint32_t *pp = perm + nd->start + tl.first;
         const uint8_t *sb = side_bytes + (uint64_t)nd->tree * n_items;
-        for (uint32_t p = threadIdx.x; p < in_tile; p += blockDim.x) s_side[p] = sb[pp[p]];
-        __syncthreads();
-        if (threadIdx.x < 32) {
-            uint64_t mask = 0;
-            uint32_t lefts = 0;
-            for (uint32_t i = 0; i < 64; i++) {
-                const uint32_t p = threadIdx.x + 32 * i;
-                if (p >= in_tile) break;
-                mask |= (uint64_t)s_side[p] << i;
-                lefts += s_side[p] ^ 1u;
-            }
-            masks[(uint64_t)tile * 32 + threadIdx.x] = mask;
-            if (lefts) atomicAdd(&s_left, lefts);
+        uint32_t rows[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t p = 256u * k + threadIdx.x;
+            rows[k] = p < in_tile ? pp[p] : 0xFFFFFFFFu;
+        }
+        uint32_t side[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) side[k] = rows[k] != 0xFFFFFFFFu ? (uint32_t)sb[rows[k]] : 0u;
+        __syncthreads();  // the previous tile's ballots have been consumed
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const unsigned long long bal = __ballot(side[k] & 1u);
+            if (lane == 0) s_ballot[k][wave] = bal;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            tile_left[tile] = s_left;
-            if (s_left) atomicAdd(&nodes[tl.node].n_left, s_left);
+        if (threadIdx.x < 32) {
+            const uint32_t o = threadIdx.x;
+            uint64_t mask = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++)
+#pragma unroll
+                for (uint32_t w = 0; w < kBlock / 64; w++) {
+                    const uint64_t bal = s_ballot[k][w];
+                    mask |= ((bal >> o) & 1ull) << (8 * k + 2 * w);
+                    mask |= ((bal >> (o + 32)) & 1ull) << (8 * k + 2 * w + 1);
+                }
+            const uint32_t n_mine = in_tile > o ? (in_tile - o + 31u) / 32u : 0u;  // items o, o + 32, ... of the tile
+            uint32_t lefts = n_mine - (uint32_t)__popcll((unsigned long long)mask);
+            masks[(uint64_t)tile * 32 + o] = mask;
+            for (int off = 16; off > 0; off >>= 1) lefts += __shfl_down(lefts, off, 32);
+            if (o == 0) {
+                tile_left[tile] = lefts;
+                if (lefts) atomicAdd(&nodes[tl.node].n_left, lefts);
+            }
         }
     }
 }
