@@ -226,11 +226,15 @@ __global__ __launch_bounds__(DenseShape<WN>::kThreads, 1) void k_forest_dense_sc
 }
 
 // The pairs the dense screen left open (side byte 2; or every pair under AH_SCREEN_VERIFY), recomputed in the reference
-// arithmetic: a wave scans 1 KiB of side bytes (16 per lane), lists the marked ones in LDS and hands them to its octets,
-// eight pairs at a time — the arithmetic of k_forest_margin_rows (rows_exact_margin).
+// arithmetic: a wave scans a window of 1024 rows of one tree's side bytes (16 per lane), lists the marked ones in LDS and
+// hands them to its octets, eight pairs at a time — the arithmetic of k_forest_margin_rows (rows_exact_margin).  A block
+// takes one row block (1024 rows) of four trees, and all the tree groups of a row block are handed to ONE XCD (block b runs
+// on XCD b & 7; the grid is a multiple of 8) back to back: an f32 row that is marked in several trees — on average every
+// row is, once, at 100 trees — is then found in that XCD's L2 after its first read (1024 rows = 3 MB).
+typedef uint32_t u32x4_a4_t __attribute__((ext_vector_type(4), aligned(4)));
 template <int METRIC>
 __global__ __launch_bounds__(256) void k_forest_exact_pairs(DataView dv, const uint32_t *__restrict__ node_of,
-                                                            uint8_t *__restrict__ side_bytes, uint64_t total,
+                                                            uint8_t *__restrict__ side_bytes, uint32_t n_trees,
                                                             const uint8_t *__restrict__ normals, uint64_t nstride,
                                                             uint64_t hdr_off, ScreenCounters *__restrict__ counters,
                                                             const AbortFlags abort_flag) {
@@ -240,16 +244,35 @@ __global__ __launch_bounds__(256) void k_forest_exact_pairs(DataView dv, const u
     if (threadIdx.x == 0) s_fb = s_bad = 0;
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, j = lane & 7u, o = lane >> 3;
-    const uint64_t n_windows = (total + 1023) >> 10;
+    const uint64_t blocks_per_tree = (dv.n + 1023) >> 10;
+    const uint32_t tree_groups = (n_trees + 3u) >> 2;
+    const uint64_t n_units = ((blocks_per_tree + 7) >> 3) * 8 * tree_groups;  // (row block, tree group) pairs, padded per XCD
+    const bool aligned4 = (dv.n & 3ull) == 0;  // every tree's bytes then start on a 4-byte boundary
     uint32_t fallbacks = 0, bad = 0;
-    for (uint64_t win = (uint64_t)blockIdx.x * 4 + wave; win < n_windows; win += (uint64_t)gridDim.x * 4) {
-        const uint64_t base = win << 10;
-        // the buffer is padded (and zeroed) beyond `total`, so whole 16-byte loads are always in bounds
-        const uint4 v = *reinterpret_cast<const uint4 *>(side_bytes + base + lane * 16u);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    for (uint64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const uint64_t slot = unit >> 3;
+        const uint64_t rb = (slot / tree_groups) * 8 + (unit & 7u);
+        const uint64_t t = (slot % tree_groups) * 4 + wave;
+        if (rb >= blocks_per_tree || t >= n_trees) continue;  // wave-uniform
+        const uint64_t r0 = (rb << 10) + lane * 16u;  // first row of this lane's 16 bytes
+        const uint64_t base = t * dv.n;                // the tree's side bytes / node indices
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (r0 < dv.n) {  // the buffer is padded beyond the last tree, so a whole 16-byte load is always in bounds
+            if (aligned4) {
+                const u32x4_a4_t v = *reinterpret_cast<const u32x4_a4_t *>(side_bytes + base + r0);
+                w[0] = v.x;
+                w[1] = v.y;
+                w[2] = v.z;
+                w[3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; e++) w[e >> 2] |= (uint32_t)side_bytes[base + r0 + e] << (8 * (e & 3));
+            }
+        }
         uint32_t cnt = 0;
 #pragma unroll
-        for (int e = 0; e < 16; e++) cnt += ((w[e >> 2] >> (8 * (e & 3))) & 0xFEu) ? 1u : 0u;
+        for (int e = 0; e < 16; e++)
+            cnt += (((w[e >> 2] >> (8 * (e & 3))) & 0xFEu) && r0 + e < dv.n) ? 1u : 0u;  // bytes past N belong to the next tree
         uint32_t incl = cnt;
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t up = __shfl_up(incl, off);
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(256) void k_forest_exact_pairs(DataView dv, const u
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const uint32_t b = (w[e >> 2] >> (8 * (e & 3))) & 0xFFu;
-            if (b & 0xFEu) s_list[wave][pos++] = (lane * 16u + (uint32_t)e) | (b << 16);
+            if ((b & 0xFEu) && r0 + e < dv.n) s_list[wave][pos++] = (lane * 16u + (uint32_t)e) | (b << 16);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -270,19 +293,18 @@ __global__ __launch_bounds__(256) void k_forest_exact_pairs(DataView dv, const u
             const uint32_t idx = e0 + o;
             const bool active = idx < n_marked;
             const uint32_t ent = active ? s_list[wave][idx] : 0u;
-            const uint64_t flat = base + (ent & 0xFFFFu);
+            const uint64_t r = (rb << 10) + (ent & 0xFFFFu);
             const uint32_t code = ent >> 16;
-            const uint32_t node = (active && flat < total) ? node_of[flat] : 0xFFFFFFFFu;
+            const uint32_t node = active ? node_of[base + r] : 0xFFFFFFFFu;
             if (node != 0xFFFFFFFFu) {  // octet-uniform
-                const uint64_t r = flat % dv.n;
                 const uint32_t exact = side_of_margin(rows_exact_margin<METRIC>(dv, r, normals + (uint64_t)node * nstride, hdr_off, j));
                 if (j == 0) {
-                    side_bytes[flat] = (uint8_t)exact;
+                    side_bytes[base + r] = (uint8_t)exact;
                     if (code == kSideUndecided) fallbacks++;
                     else if ((code & 1u) != exact) bad++;
                 }
-            } else if (active && flat < total && j == 0) {
-                side_bytes[flat] = 0;  // a stale mark on a row that is a leaf in this tree: nobody reads it
+            } else if (active && j == 0) {
+                side_bytes[base + r] = 0;  // a stale mark on a row that is a leaf in this tree: nobody reads it
             }
         }
         __builtin_amdgcn_wave_barrier();  // the list is re-used by the next window

@@ -2135,7 +2135,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     const uint64_t r8 = (da.n_row_tiles + 7) / 8;
                     const uint64_t dgrid = 8 * ((r8 + da.group - 1) / da.group) * da.group * da.n_col_tiles;
                     AH_REQUIRE(dgrid < 0x7FFFFFFFull, AH_ERR_INVALID_ARGUMENT, "forest build: too many tiles for one launch");
-                    const unsigned egrid = (unsigned)std::min<uint64_t>((((uint64_t)n_trees * N + 1023) / 1024 + 3) / 4, 1u << 16);
+                    const unsigned egrid =  // a multiple of 8: the kernel relies on block b and b + grid landing on the same XCD
+                        (unsigned)std::min<uint64_t>((((N + 1023) / 1024 + 7) / 8) * 8 * ((n_trees + 3) / 4), 1u << 16);
 #define AH_DENSE_WN(M, WNV)                                                                                              \
     do {                                                                                                                 \
         static std::atomic<bool> dense_opt_in[64]; /* once per instantiation and device */                              \
@@ -2152,7 +2153,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         if (wide) AH_DENSE_WN(M, 4);                                                                                     \
         else AH_DENSE_WN(M, 2);                                                                                          \
         hipLaunchKernelGGL((k_forest_exact_pairs<M>), dim3(egrid), dim3(256), 0, s, dv, node_of.p, side_bytes.p,         \
-                           (uint64_t)n_trees * N, chunk_d, nstride, hdr_off, d_counters, d_abort);                       \
+                           n_trees, chunk_d, nstride, hdr_off, d_counters, d_abort);                                     \
     } while (0)
                     switch (ds->metric) {
                     case AH_EUCLIDEAN: AH_DENSE(AH_EUCLIDEAN); break;
