@@ -397,6 +397,7 @@ int ah_dataset_destroy(ah_dataset *ds) {
     }
     ds->pool.clear();
     if (ds->d_rows_h16) (void)hipFree(ds->d_rows_h16);
+    if (ds->d_rows_i8) (void)hipFree(ds->d_rows_i8);
     if (ds->d_screen_stats) (void)hipFree(ds->d_screen_stats);
     if (ds->d_rows_f32) (void)hipFree(ds->d_rows_f32);
     if (ds->d_rows_bq) (void)hipFree(ds->d_rows_bq);

@@ -93,6 +93,12 @@ struct ScreenView {
     uint32_t hpitch;
     float gamma_s, gamma_r;  // accumulation-error factors of the screen / of the reference f32 reduction
     float4 max_stats;        // component-wise maximum of `stats` over all rows: a bound that needs no per-row load
+    // int8 copy of the rows for the first stage of the node-major screen (nullptr = stage off): rows8[n][pitch8] with one
+    // scale for the whole dataset (x~8 = scale8 * q), max8 = {max |x~8|, max |x - x~8|, max |x|, 0} over the rows
+    const int8_t *rows8;
+    uint32_t pitch8;  // bytes per row, a multiple of 128
+    float scale8;
+    float4 max8;
 };
 
 // One per concurrently calling host thread: a stream plus growable device / pinned scratch.
@@ -133,6 +139,9 @@ struct ah_dataset {
     uint16_t *d_rows_h16 = nullptr;
     float4 *d_screen_stats = nullptr;
     float screen_max[4] = {0.f, 0.f, 0.f, 0.f};  // component-wise maximum of the per-row stats (host copy)
+    int8_t *d_rows_i8 = nullptr;                 // int8 copy for the first screen stage (nullptr: not built / not useful)
+    uint32_t pitch8 = 0;
+    float scale8 = 0.f, screen8_max[2] = {0.f, 0.f};
     uint32_t hpitch = 0;
     bool screen_tried = false;
     // staging in flight (ah_dataset_upload_*): the context whose stream / pinned ring the uploads use until

@@ -688,6 +688,155 @@ __global__ __launch_bounds__(256) void k_stats_max(const float4 *__restrict__ st
     if (threadIdx.x < 3) atomicMax(&out[threadIdx.x], s_m[threadIdx.x]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// First stage of the node-major screen: an int8 copy.  The deep levels move one row per (item, node) pair and run at the
+// device's gather rate (1.6 KB per pair with the binary16 copy); the same certified-sign argument holds for ANY copy whose
+// distance to the original is measured, so a coarser copy can go first: x~8 = scale8 * q (q = int8, one scale for the
+// whole dataset), n~8 = scale_n * q_n per normal, s8 = scale8 * scale_n * <q_n, q> with an EXACT integer dot product
+// (v_dot4_i32_i8), and |s8 - r| <= |n - n~8||x~8| + |n||x - x~8| + gamma_r |n||x| (+ the roundings of the two scale
+// products).  The bound uses the dataset-wide maxima of |x~8|, |x - x~8| and |x|, so a decided pair costs its 768-byte
+// int8 row and nothing else; on the benchmark data 76 % of the pairs are decided here, the rest go on to the binary16
+// stage (and 1 % of all pairs to the reference arithmetic).  Sides stay identical by construction; AH_SCREEN_VERIFY
+// checks every pair at every stage.
+// ------------------------------------------------------------------------------------------------
+struct NormalStats8 {
+    float an, bn, cn, extra;  // as NormalStats, for the int8 copy of the normal
+    float scale, pad0, pad1, pad2;
+};
+__global__ __launch_bounds__(256) void k_rows_maxabs(DataView dv, uint32_t *__restrict__ out_bits) {
+    __shared__ uint32_t s_m;
+    if (threadIdx.x == 0) s_m = 0u;
+    __syncthreads();
+    const uint64_t total4 = dv.n * (uint64_t)(dv.pitch >> 2);  // the padding of a row is zero
+    const float4 *p = reinterpret_cast<const float4 *>(dv.rows_f32);
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float4 v = p[i];
+        // |x| as bits: orders like the value for finite numbers, inf and NaN end up above every finite one
+        m = max(max(m, __float_as_uint(v.x) & 0x7FFFFFFFu), max(__float_as_uint(v.y) & 0x7FFFFFFFu,
+                max(__float_as_uint(v.z) & 0x7FFFFFFFu, __float_as_uint(v.w) & 0x7FFFFFFFu)));
+    }
+    atomicMax(&s_m, m);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out_bits, s_m);
+}
+__device__ __forceinline__ int quantize8(float x, float inv_scale) {
+    const float q = rintf(x * inv_scale);
+    return (int)fminf(fmaxf(q, -127.0f), 127.0f);
+}
+// rows -> int8 copy; max_bits[0..1] = max over the rows of |x~8| and |x - x~8| (rounded up).  One octet per row.
+__global__ __launch_bounds__(kBlock) void k_shadow_rows8(DataView dv, int8_t *__restrict__ rows8, uint32_t pitch8, float scale,
+                                                         float inv_scale, uint32_t *__restrict__ max_bits) {
+    __shared__ uint32_t s_m[2];
+    if (threadIdx.x < 2) s_m[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t j = threadIdx.x & 7u;
+    const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+    const uint32_t blocks = dv.pitch >> 5;
+    float ma = 0.f, mb = 0.f;
+    for (uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; row < dv.n; row += n_octets) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(dv.rows_f32 + row * dv.pitch) + j;
+        uint32_t *o = reinterpret_cast<uint32_t *>(rows8 + row * pitch8);
+        float sa = 0.f, sb = 0.f;
+        for (uint32_t k = 0; k < blocks; k++) {
+            float4 x = ld_stream(r4 + k * 8);
+            const uint32_t e0 = 32 * k + 4 * j;
+            if (e0 + 0 >= dv.dims) x.x = 0.0f;
+            if (e0 + 1 >= dv.dims) x.y = 0.0f;
+            if (e0 + 2 >= dv.dims) x.z = 0.0f;
+            if (e0 + 3 >= dv.dims) x.w = 0.0f;
+            const int q0 = quantize8(x.x, inv_scale), q1 = quantize8(x.y, inv_scale), q2 = quantize8(x.z, inv_scale),
+                      q3 = quantize8(x.w, inv_scale);
+            const float y0 = (float)q0 * scale, y1 = (float)q1 * scale, y2 = (float)q2 * scale, y3 = (float)q3 * scale;
+            sa += y0 * y0 + y1 * y1 + y2 * y2 + y3 * y3;
+            const float d0 = x.x - y0, d1 = x.y - y1, d2 = x.z - y2, d3 = x.w - y3;
+            sb += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            o[k * 8 + j] = ((uint32_t)q0 & 0xFFu) | (((uint32_t)q1 & 0xFFu) << 8) | (((uint32_t)q2 & 0xFFu) << 16) | (((uint32_t)q3 & 0xFFu) << 24);
+        }
+        for (uint32_t w = (dv.pitch >> 2) + j; w < (pitch8 >> 2); w += 8) o[w] = 0u;  // zero tail of the int8 row
+        sa = octet_sum(sa);
+        sb = octet_sum(sb);
+        // rounded UP: f32 sums of squares (relative error < (pitch + 8) 2^-24), the rounding of scale * q (2^-24 |y| per
+        // element, at most 127 scale) inside the difference
+        const float up = 1.0f + (float)(dv.pitch + 64u) * 1.2e-7f;
+        ma = fmaxf(ma, sqrtf(sa) * up);
+        mb = fmaxf(mb, sqrtf(sb) * up + 127.0f * scale * 6.0e-8f * sqrtf((float)dv.pitch));
+    }
+    atomicMax(&s_m[0], __float_as_uint(ma));
+    atomicMax(&s_m[1], __float_as_uint(mb));
+    __syncthreads();
+    if (threadIdx.x < 2) atomicMax(&max_bits[threadIdx.x], s_m[threadIdx.x]);
+}
+// The level's normals -> int8 records [pitch8 bytes][NormalStats8], one wave per pending node.
+__global__ __launch_bounds__(64) void k_forest_shadow_normals8(DataView dv, const FNode *__restrict__ nodes, uint32_t n_nodes,
+                                                               const uint8_t *__restrict__ normals, uint64_t nstride,
+                                                               uint64_t hdr_off, uint8_t *__restrict__ shadow8, uint64_t stride8,
+                                                               uint32_t pitch8) {
+    for (uint32_t node = blockIdx.x; node < n_nodes; node += gridDim.x) {
+        if (nodes[node].state != ST_PENDING) continue;
+        const float *nv = reinterpret_cast<const float *>(normals + node * nstride);
+        int8_t *out = reinterpret_cast<int8_t *>(shadow8 + node * stride8);
+        uint32_t mbits = 0;
+        for (uint32_t i = threadIdx.x; i < dv.dims; i += 64) mbits = max(mbits, __float_as_uint(nv[i]) & 0x7FFFFFFFu);
+        for (int off = 32; off > 0; off >>= 1) mbits = max(mbits, (uint32_t)__shfl_xor((int)mbits, off));
+        const float m = __uint_as_float(mbits);
+        const bool ok = mbits != 0u && mbits < 0x7F800000u;  // finite and not all zero
+        const float scale = ok ? m / 127.0f : 0.0f, inv_scale = ok ? 127.0f / m : 0.0f;
+        float sa = 0.f, sb = 0.f, sc = 0.f;
+        for (uint32_t i = threadIdx.x; i < pitch8; i += 64) {
+            const float x = i < dv.dims ? nv[i] : 0.0f;
+            const int q = ok ? quantize8(x, inv_scale) : 0;
+            const float y = (float)q * scale, d = x - y;
+            sa += y * y;
+            sb += d * d;
+            sc += x * x;
+            out[i] = (int8_t)q;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            sa += __shfl_xor(sa, off);
+            sb += __shfl_xor(sb, off);
+            sc += __shfl_xor(sc, off);
+        }
+        if (threadIdx.x == 0) {
+            const float up = 1.0f + (float)(pitch8 + 64u) * 1.2e-7f;
+            const float *nh = reinterpret_cast<const float *>(normals + node * nstride + hdr_off);
+            NormalStats8 st;
+            st.an = sqrtf(sa) * up;
+            st.bn = ok ? sqrtf(sb) * up + 127.0f * scale * 6.0e-8f * sqrtf((float)pitch8) : __uint_as_float(0x7F800000u);
+            st.cn = sqrtf(sc) * up;
+            st.extra = dv.metric == AH_COSINE ? 0.0f : nh[0];
+            st.scale = scale;
+            st.pad0 = st.pad1 = st.pad2 = 0.0f;
+            *reinterpret_cast<NormalStats8 *>(shadow8 + node * stride8 + pitch8) = st;
+        }
+    }
+}
+// integer dot of one int8 row against the int8 normal in LDS, octet-cooperative: lane j covers bytes 128 k + 16 j .. +15.
+// q4 = normal (LDS) + j, r4 = row (global, streamed) + j.  Result (as float; exact below 2^24) on every lane of the octet.
+__device__ __forceinline__ int dot16_i8(const uint4 a, const uint4 b, int acc) {
+    acc = __builtin_amdgcn_sdot4((int)a.x, (int)b.x, acc, false);
+    acc = __builtin_amdgcn_sdot4((int)a.y, (int)b.y, acc, false);
+    acc = __builtin_amdgcn_sdot4((int)a.z, (int)b.z, acc, false);
+    acc = __builtin_amdgcn_sdot4((int)a.w, (int)b.w, acc, false);
+    return acc;
+}
+__device__ __forceinline__ float screen8_octet_dot(const uint4 *q4, const uint4 *r4, uint32_t steps) {
+    int acc0 = 0, acc1 = 0;
+    uint32_t k = 0;
+    for (; k + 6 <= steps; k += 6) {
+        uint4 x[6];
+#pragma unroll
+        for (int u = 0; u < 6; u++) x[u] = ld_stream_u4(r4 + (k + u) * 8);
+#pragma unroll
+        for (int u = 0; u < 6; u += 2) {
+            acc0 = dot16_i8(q4[(k + u) * 8], x[u], acc0);
+            acc1 = dot16_i8(q4[(k + u + 1) * 8], x[u + 1], acc1);
+        }
+    }
+    for (; k < steps; k++) acc0 = dot16_i8(q4[k * 8], ld_stream_u4(r4 + k * 8), acc0);
+    return octet_sum((float)acc0 + (float)acc1);
+}
+
 // The level's normals (records [vector][header slot]) -> shadow records [hpitch halves][NormalStats], one wave per node.
 __global__ __launch_bounds__(64) void k_forest_shadow_normals(DataView dv, const FNode *__restrict__ nodes,
                                                               const uint8_t *__restrict__ normals, uint64_t nstride,
@@ -762,14 +911,18 @@ __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, Scre
                                                                const uint32_t *__restrict__ perm,
                                                                const uint8_t *__restrict__ normals, uint64_t nstride,
                                                                uint64_t hdr_off, const uint8_t *__restrict__ shadow,
-                                                               uint64_t hstride, uint64_t *__restrict__ masks,
+                                                               uint64_t hstride, const uint8_t *__restrict__ shadow8,
+                                                               uint64_t stride8, uint64_t *__restrict__ masks,
                                                                uint32_t *__restrict__ tile_left,
                                                                const AbortFlags abort_flag,
                                                                ScreenCounters *__restrict__ counters, uint32_t verify) {
-    extern __shared__ float4 s_n4[];  // [pitch floats f32 normal][hpitch halves shadow normal]
+    extern __shared__ float4 s_n4[];  // [pitch floats f32 normal][hpitch halves shadow normal][pitch8 bytes int8 normal]
     __shared__ uint32_t s_left, s_fb, s_bad;
     const float *s_n = reinterpret_cast<const float *>(s_n4);
     const uint4 *s_h4 = reinterpret_cast<const uint4 *>(s_n4 + (dv.pitch >> 2));
+    const uint4 *s_q4 = s_h4 + (sv.hpitch >> 3);
+    const bool stage8 = METRIC != AH_DOT_PRODUCT && sv.rows8 != nullptr && shadow8 != nullptr;  // (DotProduct needs the row's header anyway)
+    const uint32_t steps8 = sv.pitch8 >> 7;
     const uint32_t o = threadIdx.x >> 3, j = threadIdx.x & 7u;
     const uint32_t steps = sv.hpitch >> 6;
     uint32_t fallbacks = 0, bad = 0;
@@ -785,12 +938,27 @@ __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, Scre
             const uint4 *g_h4 = reinterpret_cast<const uint4 *>(shadow + tl.node * hstride);
             uint4 *d_h4 = reinterpret_cast<uint4 *>(s_n4 + (dv.pitch >> 2));
             for (uint32_t i = threadIdx.x; i < (sv.hpitch >> 3); i += blockDim.x) d_h4[i] = g_h4[i];
+            if (stage8) {
+                const uint4 *g_q4 = reinterpret_cast<const uint4 *>(shadow8 + tl.node * stride8);
+                uint4 *d_q4 = d_h4 + (sv.hpitch >> 3);
+                for (uint32_t i = threadIdx.x; i < (sv.pitch8 >> 4); i += blockDim.x) d_q4[i] = g_q4[i];
+            }
         }
         if (threadIdx.x == 0) s_left = 0;
         __syncthreads();
         const float *g_h = reinterpret_cast<const float *>(normals + tl.node * nstride + hdr_off);
         const LeafHdr nh = {g_h[0], g_h[1]};
         const NormalStats ns = *reinterpret_cast<const NormalStats *>(shadow + tl.node * hstride + (uint64_t)sv.hpitch * 2);
+        NormalStats ns8 = {0.f, 0.f, 0.f, 0.f};
+        float scale8 = 0.0f;
+        if (stage8) {
+            const NormalStats8 raw = *reinterpret_cast<const NormalStats8 *>(shadow8 + tl.node * stride8 + sv.pitch8);
+            ns8.an = raw.an;
+            ns8.bn = raw.bn;
+            ns8.cn = raw.cn;
+            ns8.extra = raw.extra;
+            scale8 = sv.scale8 * raw.scale;
+        }
         const uint32_t in_tile = min(kTile, nd->count - tl.first);
         const uint32_t *pp = perm + nd->start + tl.first;
         uint64_t mask = 0;
@@ -799,14 +967,23 @@ __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, Scre
             const uint32_t p = o + 32 * i;
             if (p >= in_tile) break;
             const uint64_t row = pp[p];
-            const uint4 *r4 = reinterpret_cast<const uint4 *>(sv.rows + row * sv.hpitch) + j;
-            const float s = screen_octet_dot(s_h4 + j, r4, steps);
-            const float row_extra = METRIC == AH_DOT_PRODUCT ? dv.headers[2 * row] : 0.0f;
-            uint32_t side;
-            // the bound from the dataset-wide maxima first (monotone in every stat, so it is >= the row's own bound); the
-            // row's stats only when that one cannot decide
-            bool decided = screen_decides<METRIC>(s, sv.max_stats, ns, row_extra, sv.gamma_s, sv.gamma_r, side);
-            if (!decided) decided = screen_decides<METRIC>(s, sv.stats[row], ns, row_extra, sv.gamma_s, sv.gamma_r, side);
+            uint32_t side = 0;
+            bool decided = false;
+            if (stage8) {  // first stage: the int8 copy, 768 bytes of a 768-d row; bound from the dataset-wide maxima
+                const uint4 *r8 = reinterpret_cast<const uint4 *>(sv.rows8 + row * sv.pitch8) + j;
+                const float s8 = screen8_octet_dot(s_q4 + j, r8, steps8) * scale8;
+                // gamma_s = 1e-6: the two scale products and the float sum of the lane totals (exact below 2^24)
+                decided = screen_decides<METRIC>(s8, sv.max8, ns8, 0.0f, 1.0e-6f, sv.gamma_r, side);
+            }
+            if (!decided) {  // octet-uniform: second stage, the binary16 copy
+                const uint4 *r4 = reinterpret_cast<const uint4 *>(sv.rows + row * sv.hpitch) + j;
+                const float s = screen_octet_dot(s_h4 + j, r4, steps);
+                const float row_extra = METRIC == AH_DOT_PRODUCT ? dv.headers[2 * row] : 0.0f;
+                // the bound from the dataset-wide maxima first (monotone in every stat, so it is >= the row's own bound);
+                // the row's stats only when that one cannot decide
+                decided = screen_decides<METRIC>(s, sv.max_stats, ns, row_extra, sv.gamma_s, sv.gamma_r, side);
+                if (!decided) decided = screen_decides<METRIC>(s, sv.stats[row], ns, row_extra, sv.gamma_s, sv.gamma_r, side);
+            }
             if (!decided || verify) {  // octet-uniform
                 const uint32_t exact = side_of_margin(margin_f32<METRIC>(dv, s_n, nh, row, j));
                 if (decided && exact != side) bad++;
@@ -1336,6 +1513,8 @@ int g_dense = getenv("AH_DENSE") ? atoi(getenv("AH_DENSE")) : -1;
 uint32_t g_dense_max_cols = getenv("AH_DENSE_MAX_COLS") ? (uint32_t)atoi(getenv("AH_DENSE_MAX_COLS")) : 16384u;
 double g_dense_gmacs = getenv("AH_DENSE_GMACS") ? atof(getenv("AH_DENSE_GMACS")) : 495e3;
 bool g_screen_verify = getenv("AH_SCREEN_VERIFY") && atoi(getenv("AH_SCREEN_VERIFY")) != 0;
+// AH_SCREEN8=0: no int8 first stage in the node-major screen; =1: keep it even when the data quantise badly (test aid)
+int g_screen8 = getenv("AH_SCREEN8") ? atoi(getenv("AH_SCREEN8")) : -1;
 #define AH_DBG(s, what)                                                       \
     do {                                                                      \
         if (g_debug) {                                                        \
@@ -1458,6 +1637,53 @@ static bool ensure_screen(ah_dataset *ds, hipStream_t s) {
     ds->d_rows_h16 = rows;
     ds->d_screen_stats = stats;
     ds->hpitch = hpitch;
+    // The int8 copy for the first stage of the node-major screen: one scale for the dataset (largest |x| / 127).  Kept only
+    // when it will decide most pairs: the margin of a row against a normal of an unrelated direction is ~ |n||x| / sqrt(dims),
+    // the bound ~ 2 max|x - x~8| |n|, so the copy is useful while max|x - x~8| sqrt(dims) / max|x| is small (0.11 for
+    // uniform 768-d data: 76 % of the pairs decided); outliers in the data or rows of very different norms blow it up.
+    if (g_screen8 != 0 && ds->metric != AH_DOT_PRODUCT) {
+        const uint32_t pitch8 = (ds->dims + 127u) & ~127u;
+        int8_t *rows8 = nullptr;
+        uint32_t *d_m = nullptr;
+        uint32_t h_m[4] = {0u, 0u, 0u, 0u};
+        bool ok8 = hipMalloc((void **)&rows8, ds->n * (size_t)pitch8) == hipSuccess && hipMalloc((void **)&d_m, 16) == hipSuccess &&
+                   hipMemsetAsync(d_m, 0, 16, s) == hipSuccess;
+        float scale = 0.0f;
+        if (ok8) {
+            hipLaunchKernelGGL(k_rows_maxabs, dim3(4096), dim3(256), 0, s, dv, d_m);
+            ok8 = hipMemcpyAsync(h_m, d_m, 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+            ok8 = ok8 && h_m[0] != 0u && h_m[0] < 0x7F800000u;  // finite, not all zero
+        }
+        if (ok8) {
+            float maxabs;
+            memcpy(&maxabs, &h_m[0], 4);
+            scale = maxabs / 127.0f;
+            ok8 = scale > 0.0f && hipMemsetAsync(d_m, 0, 16, s) == hipSuccess;
+            if (ok8) {
+                hipLaunchKernelGGL(k_shadow_rows8, dim3(grid), dim3(kBlock), 0, s, dv, rows8, pitch8, scale, 127.0f / maxabs, d_m);
+                ok8 = hipMemcpyAsync(h_m, d_m, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+            }
+        }
+        if (ok8) {
+            float a8, b8;
+            memcpy(&a8, &h_m[0], 4);
+            memcpy(&b8, &h_m[1], 4);
+            const double quality = (double)b8 * std::sqrt((double)ds->dims) / std::max((double)ds->screen_max[2], 1e-300);
+            ok8 = std::isfinite(a8) && std::isfinite(b8) && (g_screen8 == 1 || quality < 0.25);
+            if (ok8) {
+                ds->d_rows_i8 = rows8;
+                ds->pitch8 = pitch8;
+                ds->scale8 = scale;
+                ds->screen8_max[0] = a8;
+                ds->screen8_max[1] = b8;
+            }
+        }
+        if (!ok8) {
+            (void)hipGetLastError();
+            if (rows8) (void)hipFree(rows8);
+        }
+        if (d_m) (void)hipFree(d_m);
+    }
     return true;
 }
 
@@ -1755,6 +1981,10 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         sv.rows = ds->d_rows_h16;
         sv.stats = ds->d_screen_stats;
         sv.max_stats = make_float4(ds->screen_max[0], ds->screen_max[1], ds->screen_max[2], 0.0f);
+        sv.rows8 = ds->d_rows_i8;  // nullptr: no int8 first stage
+        sv.pitch8 = ds->pitch8;
+        sv.scale8 = ds->scale8;
+        sv.max8 = make_float4(ds->screen8_max[0], ds->screen8_max[1], ds->screen_max[2], 0.0f);
         sv.hpitch = ds->hpitch;
         // accumulation-error factors (screen_device.h), each with a 4x safety factor over the standard model:
         //   screen: hpitch/16 dot2c per lane (2 roundings each) + 4 adds;  reference: dims/32 FMAs per chain, 6 adds of
@@ -1764,6 +1994,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         hstride = ((uint64_t)ds->hpitch * 2 + 16 + 127) & ~(uint64_t)127;  // whole lines, see normal_record_stride
     }
     const uint32_t verify = screen && g_screen_verify ? 1u : 0u;
+    const bool screen8 = screen && sv.rows8 != nullptr;
+    const uint64_t stride8 = screen8 ? (((uint64_t)sv.pitch8 + sizeof(NormalStats8) + 127) & ~(uint64_t)127) : 0;
     if (!subset_ids) {
         hipLaunchKernelGGL(k_init_perm, dim3(2048), dim3(256), 0, s, perm_a.p, N, n_trees);
     } else if (M) {
@@ -1812,9 +2044,10 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         ~Toucher() { join(); }
     } prefault, prefault_normals;
     prefault.start(forest->descendants + desc_base, M * 4);
-    Arena arena, shadow_arena;  // declared before the read-back worker: it is joined before the chunks it reads are freed
+    Arena arena, shadow_arena, shadow8_arena;  // declared before the read-back worker: it is joined before the chunks it reads are freed
     arena.block_bytes = std::max<uint64_t>(32ull << 20, std::min<uint64_t>(2 * max_nodes * nstride, 16ull << 30));
     shadow_arena.block_bytes = std::max<uint64_t>(16ull << 20, std::min<uint64_t>(max_nodes * std::max<uint64_t>(hstride, 16), 8ull << 30));
+    shadow8_arena.block_bytes = std::max<uint64_t>(16ull << 20, std::min<uint64_t>(max_nodes * std::max<uint64_t>(stride8, 16), 4ull << 30));
     BatchCleanup bc;
     AH_TRY(bc.create());
     Readback rb;
@@ -1977,11 +2210,12 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_REQUIRE(n_nodes <= max_nodes && n_tiles <= max_tiles, AH_ERR_DEVICE, "forest build: node / tile bound exceeded");
         hipLaunchKernelGGL(k_build_tiles, dim3(std::min<uint32_t>((n_nodes + 3) / 4, kMaxBlocks)), dim3(256), 0, s, d_cur,
                            n_nodes, d_tiles.p);
-        uint8_t *chunk_d = nullptr, *shadow_d = nullptr;
+        uint8_t *chunk_d = nullptr, *shadow_d = nullptr, *shadow8_d = nullptr;
         const uint64_t chunk_bytes = (uint64_t)n_nodes * nstride;
         const uint64_t chunk_host_off = normals_base + normals_bytes;
         AH_TRY(arena.take(chunk_bytes, &chunk_d));
         if (screen) AH_TRY(shadow_arena.take((uint64_t)n_nodes * hstride, &shadow_d));
+        if (screen8) AH_TRY(shadow8_arena.take((uint64_t)n_nodes * stride8, &shadow8_d));
         normals_bytes += chunk_bytes;
         // host side of this level's normals: reserved now and page-touched while the level is computed
         prefault_normals.join();
@@ -2013,7 +2247,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             // costs in ns, for rows of this dataset's size: node-major = one HBM read of the row per (item, tree) pair
             // (0.47 ns per 3072-byte row at 6.7 TB/s; the screen reads half the bytes)
             const double scale = screen ? (double)ds->hpitch * 2 / 1536.0 : (double)ds->row_bytes() / 3072.0;
-            const double node_ns = screen ? 0.24 : 0.47;
+            // (0.19 with the int8 first stage: 768 + 0.24 x 1600 bytes per pair on data that quantises like the benchmark's)
+            const double node_ns = screen ? (screen8 && ds->metric != AH_DOT_PRODUCT ? 0.19 : 0.24) : 0.47;
             const double active = (double)info.pairs / ((double)n_trees * (double)N);
             const double cost_node = (double)info.pairs * node_ns * scale;
             const double convert = (double)n_trees * (double)N *
@@ -2092,6 +2327,10 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             if (screen)
                 hipLaunchKernelGGL(k_forest_shadow_normals, dim3(n_nodes), dim3(64), 0, s, dv, d_cur, chunk_d, nstride, hdr_off,
                                    shadow_d, hstride, sv.hpitch);
+            // the int8 records are only read by the node-major screen: the first attempt of a row-order level skips them
+            if (screen8 && !(attempt == 0 && row_tc >= 2))
+                hipLaunchKernelGGL(k_forest_shadow_normals8, dim3(std::min<uint32_t>(n_nodes, 65536u)), dim3(64), 0, s, dv, d_cur,
+                                   n_nodes, chunk_d, nstride, hdr_off, shadow8_d, stride8, sv.pitch8);
             AH_HIP(hipEventRecord(bc.ev_attempt[2 * attempt], s));
             if (attempt == 0 && row_tc >= 2) {
                 // one pass over the rows serves up to row_tc trees (see k_forest_margin_rows)
@@ -2313,15 +2552,15 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                                    n_tiles, cur, N, chunk_d, nstride, hdr_off, masks.p, tile_left.p, d_abort);
                 forest->stats.margin_mode_launches[MM_BQ]++;
             } else if (screen) {
-                const size_t sh = (size_t)dv.pitch * 4 + (size_t)sv.hpitch * 2;
+                const size_t sh = (size_t)dv.pitch * 4 + (size_t)sv.hpitch * 2 + (screen8 ? (size_t)sv.pitch8 : 0);
 #define AH_LAUNCH(M)                                                                                                      \
     do {                                                                                                                  \
         if (sh > 48 * 1024) /* very long vectors: opt in to more dynamic LDS than the default limit */                    \
             AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_screen_node<M>),                           \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                             \
         hipLaunchKernelGGL((k_forest_screen_node<M>), dim3(node_grid), dim3(kBlock), sh, s, dv, sv, d_cur, d_tiles.p,     \
-                           n_tiles, cur, chunk_d, nstride, hdr_off, shadow_d, hstride, masks.p, tile_left.p, d_abort,     \
-                           d_counters, verify);                                                                           \
+                           n_tiles, cur, chunk_d, nstride, hdr_off, shadow_d, hstride, shadow8_d, stride8, masks.p,       \
+                           tile_left.p, d_abort, d_counters, verify);                                                     \
     } while (0)
                 switch (ds->metric) {
                 case AH_EUCLIDEAN: AH_LAUNCH(AH_EUCLIDEAN); break;

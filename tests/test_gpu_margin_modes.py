@@ -118,10 +118,10 @@ print(json.dumps(out))
 
 def test_screen_bound_holds_for_every_pair():
     """AH_SCREEN_VERIFY=1: the screened kernels also evaluate the reference arithmetic for EVERY (item, node) pair and
-    count the pairs the screen decided differently.  That count must be 0 — for data at scales where binary16 is exact
-    enough, where it underflows (1e-7: everything falls back) and where it overflows (1e5: inf -> falls back)."""
+    count the pairs a screen stage (int8, binary16, the dense MFMA product) decided differently.  That count must be 0 — for
+    data at scales where binary16 is exact enough, where it underflows (1e-7) and where it overflows (1e5: inf)."""
     import json
-    env = dict(os.environ, AH_SCREEN_VERIFY="1")
+    env = dict(os.environ, AH_SCREEN_VERIFY="1", AH_SCREEN8="1")  # int8 first stage kept even where it decides little
     res = subprocess.run([sys.executable, "-c", VERIFY_SCRIPT, ROOT], capture_output=True, text=True, env=env, timeout=1500)
     assert res.returncode == 0, res.stderr[-2000:]
     rows = json.loads(res.stdout.strip().splitlines()[-1])
@@ -133,8 +133,13 @@ def test_screen_bound_holds_for_every_pair():
     # unit-scale data: the screen decides almost everything; far outside the binary16 range: nothing, and that is fine
     unit = [r for r in rows if r["scale"] == 1.0 and r["shift"] == 0.0 and r["metric"] == "cosine" and r["dims"] == 768]
     assert all(r["fallbacks"] < 0.05 * r["evals"] for r in unit), unit
+    # binary16 cannot hold values of 1e5 x N(0, 1) (rows overflow -> measured error inf): the row-order passes and the
+    # dense product decide nothing there, and that is fine.  The node-major screen has an int8 first stage whose single
+    # scale follows the data, so it still decides most pairs (DotProduct has no int8 stage: the margin needs the row's
+    # header anyway).
     huge = [r for r in rows if r["scale"] == 1e5]
-    assert all(r["fallbacks"] >= 0.99 * r["evals"] for r in huge), huge[:3]
+    assert all(r["fallbacks"] >= 0.99 * r["evals"] for r in huge if r["metric"] == "dot-product"), huge[:3]
+    assert all(r["fallbacks"] < 0.9 * r["evals"] for r in huge if r["mode"] == 1 and r["metric"] != "dot-product"), huge[:6]
 
 
 def test_baseline_config_2_two_full_size_trees_equal_oracle():
