@@ -672,20 +672,29 @@ __global__ __launch_bounds__(kBlock) void k_shadow_rows(DataView dv, uint16_t *_
 // when that bound cannot decide: for rows of similar norms that is ~1.5 % of the pairs.
 __global__ __launch_bounds__(256) void k_stats_max(const float4 *__restrict__ stats, uint64_t n, uint32_t *__restrict__ out) {
     __shared__ uint32_t s_m[3];
+    __shared__ float s_sum;
     if (threadIdx.x < 3) s_m[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) s_sum = 0.0f;
     __syncthreads();
     uint32_t a = 0, b = 0, c = 0;
+    float sum = 0.0f;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const float4 v = stats[i];
         a = max(a, __float_as_uint(v.x));
         b = max(b, __float_as_uint(v.y));
         c = max(c, __float_as_uint(v.z));
+        sum += v.z;
     }
     atomicMax(&s_m[0], a);
     atomicMax(&s_m[1], b);
     atomicMax(&s_m[2], c);
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((threadIdx.x & 63u) == 0) atomicAdd(&s_sum, sum);
     __syncthreads();
     if (threadIdx.x < 3) atomicMax(&out[threadIdx.x], s_m[threadIdx.x]);
+    // out[3]: sum of the row norms (a float; its summation order is not fixed — it only feeds the heuristic that decides
+    // whether the int8 copy is worth keeping, never a result)
+    if (threadIdx.x == 0) atomicAdd(reinterpret_cast<float *>(out) + 3, s_sum);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1633,13 +1642,16 @@ static bool ensure_screen(ah_dataset *ds, hipStream_t s) {
         return false;
     }
     (void)hipFree(d_max);
-    memcpy(ds->screen_max, h_max, 16);
+    memcpy(ds->screen_max, h_max, 12);
+    float norm_sum;
+    memcpy(&norm_sum, &h_max[3], 4);
+    const double mean_norm = ds->n ? (double)norm_sum / (double)ds->n : 0.0;
     ds->d_rows_h16 = rows;
     ds->d_screen_stats = stats;
     ds->hpitch = hpitch;
     // The int8 copy for the first stage of the node-major screen: one scale for the dataset (largest |x| / 127).  Kept only
     // when it will decide most pairs: the margin of a row against a normal of an unrelated direction is ~ |n||x| / sqrt(dims),
-    // the bound ~ 2 max|x - x~8| |n|, so the copy is useful while max|x - x~8| sqrt(dims) / max|x| is small (0.11 for
+    // the bound ~ 2 max|x - x~8| |n|, so the copy is useful while max|x - x~8| sqrt(dims) / mean|x| is small (0.11 for
     // uniform 768-d data: 76 % of the pairs decided); outliers in the data or rows of very different norms blow it up.
     if (g_screen8 != 0 && ds->metric != AH_DOT_PRODUCT) {
         const uint32_t pitch8 = (ds->dims + 127u) & ~127u;
@@ -1668,7 +1680,8 @@ static bool ensure_screen(ah_dataset *ds, hipStream_t s) {
             float a8, b8;
             memcpy(&a8, &h_m[0], 4);
             memcpy(&b8, &h_m[1], 4);
-            const double quality = (double)b8 * std::sqrt((double)ds->dims) / std::max((double)ds->screen_max[2], 1e-300);
+            // against the MEAN row norm: rows much shorter than the longest ones have margins below a bound built from maxima
+            const double quality = (double)b8 * std::sqrt((double)ds->dims) / std::max(mean_norm, 1e-300);
             ok8 = std::isfinite(a8) && std::isfinite(b8) && (g_screen8 == 1 || quality < 0.25);
             if (ok8) {
                 ds->d_rows_i8 = rows8;
