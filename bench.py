@@ -376,7 +376,10 @@ def build_stats(st, el, n, trees, my_trees, world):
         "margin_row_major_passes_rank0": st.get("margin_row_passes"), "split_nodes_rank0": st.get("split_nodes"),
         "retries_rank0": st.get("retries"), "dummy_normals_rank0": st.get("dummy_normals"),
         "screened_launches_rank0": st.get("screened_launches"), "screen_fallbacks_rank0": st.get("screen_fallbacks"),
-        "margin_mode_launches_rank0": st.get("margin_mode_launches"), "scaling": "strong",
+        "margin_mode_launches_rank0": st.get("margin_mode_launches"),
+        # levels whose first attempt ran as one binary16 MFMA product (rows x normals^T) and the columns they covered
+        "dense_mfma_levels_rank0": st.get("dense_launches"), "dense_mfma_columns_rank0": st.get("dense_columns"),
+        "scaling": "strong",
     }
 
 
@@ -544,14 +547,16 @@ def build_10m(args, rank, world, device, sync, ds, result):
                         "levels": st.get("levels"), "split_nodes": st.get("split_nodes"),
                         "margin_effective_gb_per_s": st.get("margin_evaluations", 0) * 4 * DIMS / ms / 1e9 if ms else None,
                         "margin_row_major_passes": st.get("margin_row_passes"),
-                        "screen_fallbacks": st.get("screen_fallbacks"), "margin_mode_launches": st.get("margin_mode_launches")}
+                        "screen_fallbacks": st.get("screen_fallbacks"), "margin_mode_launches": st.get("margin_mode_launches"),
+                        "dense_mfma_levels": st.get("dense_launches"), "dense_mfma_columns": st.get("dense_columns")}
         result.setdefault("build_10m_seconds_per_device", {}).setdefault(key, {})[rank] = sorted(owns)[len(owns) // 2]
     ds.close()
     if rank == 0:
         res = dict(out["screened"])
         res["workload"] = f"{n}x{DIMS} cosine, n_trees=100, trees on device 0: {len(trees)} (t = device mod {world})"
-        res["arithmetic"] = ("certified binary16 screen decides the side of a margin when |screen| > proven error bound, "
-                             "f32 reference arithmetic for the rest (screen_fallbacks pairs); forest bit-identical to f32_only")
+        res["arithmetic"] = ("certified screens (int8 first on the node-major levels, binary16 — as one MFMA product on the top "
+                             "levels — second) decide the side of a margin when |screen| > proven error bound, f32 reference "
+                             "arithmetic for the rest (screen_fallbacks pairs); forest bit-identical to f32_only")
         res["f32_only"] = out["f32_only"]
         res["scaling"] = "strong"
         result["build_10m"] = res
