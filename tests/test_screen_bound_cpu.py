@@ -96,3 +96,39 @@ def test_a_decided_pair_never_has_the_wrong_sign(name, X):
     if name.startswith("uniform-768"):
         assert decided8 > 0.70 * total, decided8 / total    # 76 % decided by the int8 stage
         assert decided16 > 0.985 * total, decided16 / total  # §2.2: ~1 % fall back to f32
+
+
+def _rtz32(x64):
+    """float64 -> float32 rounded toward zero (a truncating adder)."""
+    y = np.float32(x64)
+    if abs(float(y)) > abs(float(x64)):
+        y = np.nextafter(y, np.float32(0.0))
+    return y
+
+
+def test_gamma_of_the_dense_product_covers_any_order_and_a_truncating_adder():
+    """The dense MFMA screen (dense_device.h) sums the hpitch exact binary16 products of a pair in one f32 chain whose order
+    and rounding mode the matrix unit does not document.  Its gamma_s = 2 (hpitch + hpitch / 16 + 16) 2^-23 must cover
+    |sum_f32 - sum_exact| / sum |x~_i n~_i| for sequential, reversed, shuffled and 16-wide-blocked orders, with round-to-
+    nearest and with truncation after every addition."""
+    rng = np.random.default_rng(3)
+    hpitch = 768
+    gamma = 2.0 * (hpitch + hpitch / 16 + 16.0) * 1.1920929e-7
+    worst = 0.0
+    for _ in range(12):
+        x = rng.uniform(-1, 1, hpitch).astype(np.float16).astype(np.float64)
+        n = (rng.standard_normal(hpitch) / np.sqrt(hpitch)).astype(np.float16).astype(np.float64)
+        p = x * n  # exact in float64 (and in f32: 11-bit x 11-bit significands)
+        exact, scale = p.sum(), np.abs(p).sum()
+        orders = [np.arange(hpitch), np.arange(hpitch)[::-1], rng.permutation(hpitch)]
+        for order in orders:
+            acc_rn, acc_tz = np.float32(0.0), np.float32(0.0)
+            for v in p[order]:
+                acc_rn = np.float32(np.float64(acc_rn) + v)        # round to nearest after every addition
+                acc_tz = _rtz32(np.float64(acc_tz) + v)             # truncate after every addition
+            blocked = np.float32(0.0)
+            for b in range(0, hpitch, 16):                           # a 16-wide step summed exactly, then one rounding
+                blocked = _rtz32(np.float64(blocked) + p[order][b:b + 16].sum())
+            for got in (acc_rn, acc_tz, blocked):
+                worst = max(worst, abs(float(got) - exact) / scale)
+    assert worst < gamma / 2, (worst, gamma)  # at least a factor 2 of head-room on these inputs
