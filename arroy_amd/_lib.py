@@ -90,7 +90,10 @@ class AhBuildStats(C.Structure):
                 ("descendant_nodes", C.c_uint64), ("dummy_normals", C.c_uint64), ("retries", C.c_uint64),
                 ("levels", C.c_uint32), ("margin_mode_launches", C.c_uint64 * 8), ("screened_launches", C.c_uint64),
                 ("screen_fallbacks", C.c_uint64), ("screen_violations", C.c_uint64),
-                ("dense_launches", C.c_uint64), ("dense_columns", C.c_uint64)]
+                ("dense_launches", C.c_uint64), ("dense_columns", C.c_uint64),
+                ("rows_xcd_launches", C.c_uint64), ("rows_nt_launches", C.c_uint64), ("rows_split_launches", C.c_uint64),
+                ("screen8_pairs", C.c_uint64), ("screen8_decided", C.c_uint64), ("screen_unavailable", C.c_uint32),
+                ("reserved0", C.c_uint32)]
 
 
 # name -> (restype, argtypes): exactly the declarations of include/arroy_hip.h
@@ -129,6 +132,11 @@ SIGNATURES = {
     "ah_build_subtrees": (C.c_int, [_VP, C.POINTER(AhBuildOptions), _U32P, _U64P, C.POINTER(C.c_void_p)]),
     "ah_forest_view_get": (C.c_int, [_VP, C.POINTER(AhForestView)]),
     "ah_forest_stats": (C.c_int, [_VP, C.POINTER(AhBuildStats)]),
+    "ah_forest_digest": (C.c_int, [_VP, _U64P, C.POINTER(C.c_uint64)]),
+    "ah_tuning_set": (C.c_int, [C.c_char_p, C.c_int64]),
+    "ah_tuning_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ah_tuning_reset": (C.c_int, []),
+    "ah_debug_launch_coverage": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _U32P, C.c_uint64]),
     "ah_forest_visit": (C.c_int, [_VP, _VP, _VP]),
     "ah_forest_destroy": (C.c_int, [_VP]),
     "ah_index_create": (C.c_int, [_VP, _VP, C.POINTER(C.c_void_p)]),
@@ -190,6 +198,51 @@ def device_name(device: int = 0) -> str:
     buf = C.create_string_buffer(256)
     check(lib().ah_device_name(device, buf, 256))
     return buf.value.decode()
+
+
+def tuning_set(name: str, value: int) -> None:
+    """ah_tuning_set: a measurement / test aid that steers the schedule of the kernels, never a result."""
+    check(lib().ah_tuning_set(name.encode(), int(value)))
+
+
+def tuning_get(name: str) -> tuple[int, int]:
+    """(current value, built-in default) of a tunable."""
+    v, d = C.c_int64(0), C.c_int64(0)
+    check(lib().ah_tuning_get(name.encode(), C.byref(v), C.byref(d)))
+    return int(v.value), int(d.value)
+
+
+class tuning:
+    """`with tuning(AH_ROWS_XCD=0, AH_DENSE=1): ...` — set tunables for a block, put the previous values back after."""
+
+    def __init__(self, **values):
+        self.values = values
+        self.saved = {}
+
+    def __enter__(self):
+        for k, v in self.values.items():
+            self.saved[k] = tuning_get(k)[0]
+            tuning_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            tuning_set(k, v)
+        return False
+
+
+def launch_coverage(kind: int, n_rows: int, dims: int, a: int, b: int = 0, device: int = 0):
+    """ah_debug_launch_coverage: how often the block -> work-item map of a build launch serves every work item."""
+    import numpy as np
+    if kind == 0:
+        shape = (b, n_rows)
+    elif kind == 1:
+        shape = ((n_rows + 255) // 256, (a + (255 if a > 128 else 127)) // (256 if a > 128 else 128))
+    else:
+        shape = (a, (n_rows + 1023) // 1024)
+    out = np.zeros(shape, dtype=np.uint32)
+    check(lib().ah_debug_launch_coverage(device, kind, n_rows, dims, a, b, out.ctypes.data_as(C.c_void_p), out.size))
+    return out
 
 
 def bench_read(device: int, nbytes: int, iterations: int) -> float:

@@ -35,6 +35,35 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received) {
 }
 const char *last_error() { return g_error.c_str(); }
 
+// ---- tunables (common.h): environment at load time, ah_tuning_set at run time ---------------------------------------
+namespace {
+struct TunableSlot {
+    const char *name;
+    long long def;
+    std::atomic<long long> value;
+};
+TunableSlot *tunable_table() {
+    static TunableSlot table[TUN_COUNT] = {
+#define AH_X(id, name, def) {name, (long long)(def), {(long long)(def)}},
+        AH_TUNABLES(AH_X)
+#undef AH_X
+    };
+    static const bool loaded = [] {
+        for (TunableSlot &t : table) {
+            const char *e = getenv(t.name);
+            if (!e) continue;
+            char *end = nullptr;
+            const long long v = strtoll(e, &end, 0);
+            t.value.store(end == e ? 1 : v, std::memory_order_relaxed);  // set but not a number ("AH_DEBUG=yes"): on
+        }
+        return true;
+    }();
+    (void)loaded;
+    return table;
+}
+}  // namespace
+long long tun(int id) { return tunable_table()[id].value.load(std::memory_order_relaxed); }
+
 int Context::ensure_device(size_t bytes) {
     if (bytes <= d_cap) return AH_OK;
     size_t cap = std::max(bytes + bytes / 4, d_cap * 2);  // headroom: similar-sized submissions must not regrow
@@ -126,7 +155,7 @@ class WorkerPool {
     WorkerPool() {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         unsigned n = std::min(12u, std::max(1u, hw / 2));
-        if (const char *e = getenv("AH_STAGE_THREADS")) n = (unsigned)std::max(1, atoi(e));
+        if (tun(TUN_STAGE_THREADS) > 0) n = (unsigned)tun(TUN_STAGE_THREADS);
         for (unsigned i = 1; i < n; i++) threads_.emplace_back([this] { loop(); });
     }
     ~WorkerPool() {
@@ -196,8 +225,8 @@ __attribute__((target("avx2"))) static void copy_row_stream_avx2(uint8_t *dst, c
     if (i < bytes) memcpy(dst + i, src + i, bytes - i);
 }
 static inline void copy_row(uint8_t *dst, const uint8_t *src, size_t bytes) {
-    static const bool avx2 = __builtin_cpu_supports("avx2") && !getenv("AH_STAGE_MEMCPY");
-    if (avx2 && bytes >= 512 && (reinterpret_cast<uintptr_t>(dst) & 31u) == 0) copy_row_stream_avx2(dst, src, bytes);
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2 && !tun(TUN_STAGE_MEMCPY) && bytes >= 512 && (reinterpret_cast<uintptr_t>(dst) & 31u) == 0) copy_row_stream_avx2(dst, src, bytes);
     else memcpy(dst, src, bytes);
 }
 static inline void copy_fence() { _mm_sfence(); }  // non-temporal stores are ordered before the DMA is enqueued
@@ -323,6 +352,31 @@ int ah_device_name(int device, char *buf, size_t buf_len) {
     return AH_OK;
 }
 
+static TunableSlot *find_tunable(const char *name) {
+    TunableSlot *t = tunable_table();
+    for (int i = 0; i < TUN_COUNT; i++)
+        if (name && strcmp(name, t[i].name) == 0) return t + i;
+    return nullptr;
+}
+int ah_tuning_set(const char *name, int64_t value) {
+    TunableSlot *t = find_tunable(name);
+    AH_REQUIRE(t, AH_ERR_INVALID_ARGUMENT, "unknown tunable %s", name ? name : "(null)");
+    t->value.store(value, std::memory_order_relaxed);
+    return AH_OK;
+}
+int ah_tuning_get(const char *name, int64_t *out_value, int64_t *out_default) {
+    TunableSlot *t = find_tunable(name);
+    AH_REQUIRE(t, AH_ERR_INVALID_ARGUMENT, "unknown tunable %s", name ? name : "(null)");
+    if (out_value) *out_value = t->value.load(std::memory_order_relaxed);
+    if (out_default) *out_default = t->def;
+    return AH_OK;
+}
+int ah_tuning_reset(void) {
+    TunableSlot *t = tunable_table();
+    for (int i = 0; i < TUN_COUNT; i++) t[i].value.store(t[i].def, std::memory_order_relaxed);
+    return AH_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // dataset
 // ---------------------------------------------------------------------------------------------
@@ -398,6 +452,8 @@ int ah_dataset_destroy(ah_dataset *ds) {
     ds->pool.clear();
     if (ds->d_rows_h16) (void)hipFree(ds->d_rows_h16);
     if (ds->d_rows_i8) (void)hipFree(ds->d_rows_i8);
+    if (ds->d_scale8_rows) (void)hipFree(ds->d_scale8_rows);
+    if (ds->d_dim_scale) (void)hipFree(ds->d_dim_scale);
     if (ds->d_screen_stats) (void)hipFree(ds->d_screen_stats);
     if (ds->d_rows_f32) (void)hipFree(ds->d_rows_f32);
     if (ds->d_rows_bq) (void)hipFree(ds->d_rows_bq);
@@ -549,7 +605,7 @@ int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, const fl
     DataView dv = ds->view();
     // Rows that need no re-pitching can travel straight from the caller's memory when it is (or can be) page-locked:
     // AH_STAGE_REGISTER=1 registers the caller's buffer for the duration of the call (measurement aid).
-    static const bool try_register = getenv("AH_STAGE_REGISTER") && atoi(getenv("AH_STAGE_REGISTER")) != 0;
+    const bool try_register = tun(TUN_STAGE_REGISTER) != 0;
     if (try_register && !bq && fpitch == ds->dims && n * frb >= (64u << 20)) {
         Context *ctx = nullptr;
         AH_TRY(upload_context(ds, pad256(std::min<size_t>(n, kStageBytes / 4) * 4), &ctx));
@@ -568,7 +624,7 @@ int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, const fl
     }
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, kStageBytes / (frb + 4)));
     const size_t buf_bytes = pad256(chunk * frb) + pad256(chunk * 4);
-    static const bool timing = getenv("AH_TIMING") != nullptr;
+    const bool timing = tun(TUN_TIMING) != 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double>(b - a).count();
@@ -647,7 +703,7 @@ int ah_dataset_fill_synthetic(ah_dataset *ds, uint64_t seed, int distribution, u
     AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
     AH_REQUIRE(!ds->finalized && ds->n == 0, AH_ERR_INVALID_ARGUMENT, "synthetic fill needs an empty dataset");
     AH_REQUIRE(n_items <= ds->capacity, AH_ERR_INVALID_ARGUMENT, "n_items exceeds capacity");
-    AH_REQUIRE(distribution == AH_SYNTH_UNIFORM_01 || distribution == AH_SYNTH_UNIFORM_PM1, AH_ERR_INVALID_ARGUMENT,
+    AH_REQUIRE(distribution >= AH_SYNTH_UNIFORM_01 && distribution <= AH_SYNTH_NORMAL_OUTLIERS, AH_ERR_INVALID_ARGUMENT,
                "unknown distribution %d", distribution);
     AH_LEASE(ds, ctx);
     DataView dv = ds->view();
@@ -715,6 +771,16 @@ int ah_dataset_replicate(ah_dataset *src, int device, ah_dataset **out) {
     *out = nullptr;
     AH_REQUIRE(src, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
     AH_TRY(upload_flush(src));
+    // the calling thread may hold another device current (a host thread per GPU): put it back on every path out
+    struct DeviceRestore {
+        int prev = -1;
+        DeviceRestore() {
+            if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        }
+        ~DeviceRestore() {
+            if (prev >= 0) (void)hipSetDevice(prev);
+        }
+    } restore_device;
     ah_dataset *dst = nullptr;
     AH_TRY(ah_dataset_create(src->metric, src->dims, std::max<uint64_t>(src->capacity, 1), device, &dst));
     int st = AH_OK;

@@ -436,9 +436,10 @@ __global__ __launch_bounds__(kBlock) void k_pairs_distances_runs(DataView dv, co
 }
 
 // AH_RERANK_INVERT=0 never uses the row-major path, =1 uses it whenever it is legal (A/B measurements)
-static const int g_invert_force = getenv("AH_RERANK_INVERT") ? atoi(getenv("AH_RERANK_INVERT")) : -1;
-static const int g_pair_group = getenv("AH_PAIR_GROUP") ? atoi(getenv("AH_PAIR_GROUP")) : 0;
-static const bool g_pair_runs = !(getenv("AH_PAIR_RUNS") && atoi(getenv("AH_PAIR_RUNS")) == 0);  // A/B: row-run kernel
+// A/B switches (tunables of common.h): AH_RERANK_INVERT, AH_PAIR_GROUP, AH_PAIR_RUNS (the row-run kernel)
+#define g_invert_force ((int)tun(TUN_RERANK_INVERT))
+#define g_pair_group ((int)tun(TUN_PAIR_GROUP))
+#define g_pair_runs (tun(TUN_PAIR_RUNS) != 0)
 
 // counters: one per stored row + the scan's block totals + the grand total
 // counters: per stored row a pair bucket and an item count, each with its scan block totals + grand total; then the

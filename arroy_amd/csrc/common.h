@@ -52,6 +52,57 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
         }                                 \
     } while (0)
 
+// ---------------------------------------------------------------------------------------------
+// Tunables: measurement and test aids.  Every one is initialised from the environment variable of the same name when
+// the library is loaded and can be changed at run time through ah_tuning_set (include/arroy_hip.h) — that is how the
+// GPU tests drive every kernel-selecting switch in-process and compare the forests.  RESULTS ARE BIT-IDENTICAL UNDER
+// EVERY SETTING; only the schedule (which kernel family, which grid, which cache policy) changes.
+//   X(identifier, "NAME", default)
+// ---------------------------------------------------------------------------------------------
+#define AH_TUNABLES(X)                                                                                                  \
+    X(DEBUG, "AH_DEBUG", 0)                     /* 1: synchronise after every launch of the build and name the kernel */  \
+    X(TIMING, "AH_TIMING", 0)                   /* 1: per-batch / per-upload timing on stderr; 2: also one line per level */ \
+    X(ROWMAJOR, "AH_ROWMAJOR", -1)              /* 0: never the row-major margin pass, 1: whenever legal, -1: cost model */ \
+    X(ROWMAJOR_CACHE_MB, "AH_ROWMAJOR_CACHE_MB", -1) /* > 0: budget for one group's normals of a level */                \
+    X(ROWMAJOR_MAX_TC, "AH_ROWMAJOR_MAX_TC", 16) /* largest tree group of a row-major pass */                            \
+    X(ROWMAJOR_ADVANCE, "AH_ROWMAJOR_ADVANCE", 1) /* 0: node_of re-scattered every level instead of advanced in row order */ \
+    X(ROWMAJOR_LDS, "AH_ROWMAJOR_LDS", 1)       /* 0: no LDS-resident variant of the row-major pass */                    \
+    X(FOREST_TILE_BLOCKS, "AH_FOREST_TILE_BLOCKS", 1 << 20) /* grid caps (grid-stride beyond) */                         \
+    X(FOREST_NODE_BLOCKS, "AH_FOREST_NODE_BLOCKS", 0)       /* node-major margin kernels; 0 = automatic */               \
+    X(FOREST_SPLIT_BLOCKS, "AH_FOREST_SPLIT_BLOCKS", 65536) /* create_split: one wave per node */                        \
+    X(FOREST_ROW_BLOCKS, "AH_FOREST_ROW_BLOCKS", 1 << 20)   /* f32 row-major passes */                                   \
+    X(ROWS_XCD, "AH_ROWS_XCD", 1)               /* 0: row-major groups spread over all XCDs (never one XCD per group) */  \
+    X(ROWS_XCD_MIN_GROUPS, "AH_ROWS_XCD_MIN_GROUPS", 16) /* fewest groups of <= 4 trees that get one XCD each */         \
+    X(ROWS_NT, "AH_ROWS_NT", -1)                /* 0 / 1: never / always stream the rows non-temporally; -1: by size */    \
+    X(ROWS_NT_BYTES, "AH_ROWS_NT_BYTES", 5 << 20) /* bytes of one group's normals beyond which the rows go non-temporal */ \
+    X(ROWS_PER_BLOCK, "AH_ROWS_PER_BLOCK", 0)   /* rows per block of the screened row-major pass (0 = 32) */              \
+    X(ROWS_CHUNK_MB, "AH_ROWS_CHUNK_MB", 48)    /* binary16 rows per chunk of the chunk-major schedule, in MiB */         \
+    X(ROWS_CHUNK_ROWS, "AH_ROWS_CHUNK_ROWS", 0) /* > 0: rows per chunk, overrides ROWS_CHUNK_MB (small test shapes) */    \
+    X(LAUNCH_MAX_ITEMS, "AH_LAUNCH_MAX_ITEMS", 0xFFFFFFFFll) /* work-items one row-major launch may carry */             \
+    X(SCREEN, "AH_SCREEN", 1)                   /* 0: reference f32 arithmetic only (as AH_MARGIN_EXACT_ONLY) */          \
+    X(SCREEN_VERIFY, "AH_SCREEN_VERIFY", 0)     /* 1: screened kernels evaluate f32 for EVERY pair, count violations */  \
+    X(SCREEN8, "AH_SCREEN8", -1)                /* 0: no int8 first stage; 1: keep it whatever the data; -1: by quality */ \
+    X(DENSE, "AH_DENSE", -1)                    /* 0: never the dense MFMA screen; 1: whenever legal; -1: cost model */    \
+    X(DENSE_MAX_COLS, "AH_DENSE_MAX_COLS", 16384)                                                                        \
+    X(DENSE_GMACS, "AH_DENSE_GMACS", 495000)    /* sustained multiply-add rate the cost model assumes, 1e9 MAC/s */       \
+    X(MARGIN_MODE, "AH_MARGIN_MODE", 0)         /* ah_margin_mode for callers that pass AH_MARGIN_AUTO */                 \
+    X(READBACK_DIRECT, "AH_READBACK_DIRECT", 0) /* 1: let the runtime stage the device -> pageable copies */             \
+    X(SCAN_BLOCKS, "AH_SCAN_BLOCKS", 0)         /* grid cap of the distance scan (0 = built-in) */                        \
+    X(MANHATTAN_ROWS, "AH_MANHATTAN_ROWS", 1)                                                                            \
+    X(RERANK_INVERT, "AH_RERANK_INVERT", -1)    /* 0 / 1: never / always the row-major re-rank of big submissions */      \
+    X(PAIR_GROUP, "AH_PAIR_GROUP", 0)                                                                                    \
+    X(PAIR_RUNS, "AH_PAIR_RUNS", 1)                                                                                      \
+    X(STAGE_THREADS, "AH_STAGE_THREADS", 0)                                                                              \
+    X(STAGE_MEMCPY, "AH_STAGE_MEMCPY", 0)                                                                                \
+    X(STAGE_REGISTER, "AH_STAGE_REGISTER", 0)
+enum Tunable {
+#define AH_X(id, name, def) TUN_##id,
+    AH_TUNABLES(AH_X)
+#undef AH_X
+        TUN_COUNT
+};
+long long tun(int id);  // current value (api.hip)
+
 inline bool metric_is_bq(int m) { return m >= AH_BQ_EUCLIDEAN && m <= AH_BQ_COSINE; }
 inline bool metric_valid(int m) { return m >= AH_EUCLIDEAN && m <= AH_BQ_COSINE; }
 inline uint32_t header_floats(int m) { return m == AH_DOT_PRODUCT ? 2u : 1u; }
@@ -93,11 +144,12 @@ struct ScreenView {
     uint32_t hpitch;
     float gamma_s, gamma_r;  // accumulation-error factors of the screen / of the reference f32 reduction
     float4 max_stats;        // component-wise maximum of `stats` over all rows: a bound that needs no per-row load
-    // int8 copy of the rows for the first stage of the node-major screen (nullptr = stage off): rows8[n][pitch8] with one
-    // scale for the whole dataset (x~8 = scale8 * q), max8 = {max |x~8|, max |x - x~8|, max |x|, 0} over the rows
+    // int8 copy of the rows for the first stage of the node-major screen (nullptr = stage off): rows8[n][pitch8] = q with
+    // x / d ~ s_r q (d: one power of two per dimension, s_r = scale8_rows[r]: one scale per row; inf = "never decide this
+    // row here"), max8 = {max |q|, max |x/d/s_r - q|, max |x|/s_r, 0} over the rows, in units of the row's scale
     const int8_t *rows8;
     uint32_t pitch8;  // bytes per row, a multiple of 128
-    float scale8;
+    const float *scale8_rows;
     float4 max8;
 };
 
@@ -140,10 +192,15 @@ struct ah_dataset {
     float4 *d_screen_stats = nullptr;
     float screen_max[4] = {0.f, 0.f, 0.f, 0.f};  // component-wise maximum of the per-row stats (host copy)
     int8_t *d_rows_i8 = nullptr;                 // int8 copy for the first screen stage (nullptr: not built / not useful)
+    float *d_scale8_rows = nullptr;              // its scale per row
+    float *d_dim_scale = nullptr;                // 2 x pitch8 floats: the power-of-two scale of every dimension, then its inverse
     uint32_t pitch8 = 0;
-    float scale8 = 0.f, screen8_max[2] = {0.f, 0.f};
+    float screen8_max[3] = {0.f, 0.f, 0.f};
+    double screen8_quality = 0.0;                // expected undecided share indicator (forest.hip: ensure_screen)
     uint32_t hpitch = 0;
-    bool screen_tried = false;
+    bool screen_never = false;                   // the screen can never apply to this dataset (1-bit metric, dims < 32)
+    bool screen8_decided = false;                // the int8 copy was built or found useless: do not try again
+    bool screen_alloc_failed = false;            // the last attempt failed for lack of memory (retried by the next build)
     // staging in flight (ah_dataset_upload_*): the context whose stream / pinned ring the uploads use until
     // ah_dataset_finalize (or ah_dataset_upload_flush) waits for them
     ah::Context *up_ctx = nullptr;

@@ -90,6 +90,24 @@ __device__ __forceinline__ void dense_stage(const uint8_t *const (&a_src)[DenseS
             (__attribute__((address_space(3))) void *)(stage + kDM * 128u + (i * SH::kWaves + wave) * 1024u), 16, 0, 0);
 }
 
+// block -> (row tile, column tile); false for the padding blocks of the last group.  Workgroups go to the XCDs
+// round-robin, so block b runs on XCD b & 7: the blocks of one XCD walk groups of `group` row tiles, all column tiles of a
+// group back to back.  Shared with k_dense_coverage (ah_debug_launch_coverage).
+__device__ __forceinline__ bool dense_block_map(uint32_t b, uint32_t group, uint32_t n_col_tiles, uint32_t n_row_tiles,
+                                                uint32_t &rt, uint32_t &ct) {
+    const uint32_t xcd = b & 7u, slot = b >> 3;
+    const uint32_t per_group = group * n_col_tiles;
+    const uint32_t grp = slot / per_group, within = slot % per_group;
+    ct = within / group;
+    rt = (grp * group + within % group) * 8u + xcd;
+    return rt < n_row_tiles;
+}
+__global__ void k_dense_coverage(uint32_t group, uint32_t n_col_tiles, uint32_t n_row_tiles, uint32_t *__restrict__ counts) {
+    uint32_t rt, ct;
+    if (!dense_block_map(blockIdx.x, group, n_col_tiles, n_row_tiles, rt, ct)) return;
+    if (threadIdx.x == 0) atomicAdd(&counts[(uint64_t)rt * n_col_tiles + ct], 1u);
+}
+
 template <int METRIC, int WN>
 __global__ __launch_bounds__(DenseShape<WN>::kThreads, 1) void k_forest_dense_screen(DenseArgs a, const AbortFlags abort_flag) {
     typedef DenseShape<WN> SH;
@@ -99,11 +117,8 @@ __global__ __launch_bounds__(DenseShape<WN>::kThreads, 1) void k_forest_dense_sc
     // block -> (row tile, column tile).  Workgroups go to the XCDs round-robin, so block b runs on XCD b & 7: the blocks
     // of one XCD walk groups of `group` row tiles, all column tiles of a group back to back, and the group's X~ tiles
     // (group x 384 KB) are read from HBM once and then found in that XCD's L2.
-    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const uint32_t per_group = a.group * a.n_col_tiles;
-    const uint32_t grp = slot / per_group, within = slot % per_group;
-    const uint32_t ct = within / a.group, rt = (grp * a.group + within % a.group) * 8u + xcd;
-    if (rt >= a.n_row_tiles) return;  // block-uniform
+    uint32_t rt, ct;
+    if (!dense_block_map(blockIdx.x, a.group, a.n_col_tiles, a.n_row_tiles, rt, ct)) return;  // block-uniform
     const uint64_t row0 = (uint64_t)rt * kDM;
     const uint32_t c0 = ct * SH::kBN;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -232,6 +247,29 @@ __global__ __launch_bounds__(DenseShape<WN>::kThreads, 1) void k_forest_dense_sc
 // on XCD b & 7; the grid is a multiple of 8) back to back: an f32 row that is marked in several trees — on average every
 // row is, once, at 100 trees — is then found in that XCD's L2 after its first read (1024 rows = 3 MB).
 typedef uint32_t u32x4_a4_t __attribute__((ext_vector_type(4), aligned(4)));
+// unit (a block's turn) + wave -> (row block of 1024 rows, tree); shared with k_exact_coverage (ah_debug_launch_coverage)
+__device__ __forceinline__ bool exact_unit_map(uint64_t unit, uint32_t wave, uint64_t blocks_per_tree, uint32_t tree_groups,
+                                               uint32_t n_trees, uint64_t &rb, uint64_t &t) {
+    const uint64_t slot = unit >> 3;
+    rb = (slot / tree_groups) * 8 + (unit & 7u);
+    t = (slot % tree_groups) * 4 + wave;
+    return rb < blocks_per_tree && t < n_trees;
+}
+__device__ __forceinline__ uint64_t exact_units(uint64_t n_rows, uint32_t n_trees, uint64_t &blocks_per_tree, uint32_t &tree_groups) {
+    blocks_per_tree = (n_rows + 1023) >> 10;
+    tree_groups = (n_trees + 3u) >> 2;
+    return ((blocks_per_tree + 7) >> 3) * 8 * tree_groups;  // (row block, tree group) pairs, padded per XCD
+}
+__global__ __launch_bounds__(256) void k_exact_coverage(uint64_t n_rows, uint32_t n_trees, uint32_t *__restrict__ counts) {
+    uint64_t blocks_per_tree;
+    uint32_t tree_groups;
+    const uint64_t n_units = exact_units(n_rows, n_trees, blocks_per_tree, tree_groups);
+    for (uint64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        uint64_t rb, t;
+        if (!exact_unit_map(unit, threadIdx.x >> 6, blocks_per_tree, tree_groups, n_trees, rb, t)) continue;
+        if ((threadIdx.x & 63u) == 0) atomicAdd(&counts[t * blocks_per_tree + rb], 1u);
+    }
+}
 template <int METRIC>
 __global__ __launch_bounds__(256) void k_forest_exact_pairs(DataView dv, const uint32_t *__restrict__ node_of,
                                                             uint8_t *__restrict__ side_bytes, uint32_t n_trees,
@@ -244,16 +282,14 @@ __global__ __launch_bounds__(256) void k_forest_exact_pairs(DataView dv, const u
     if (threadIdx.x == 0) s_fb = s_bad = 0;
     __syncthreads();
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, j = lane & 7u, o = lane >> 3;
-    const uint64_t blocks_per_tree = (dv.n + 1023) >> 10;
-    const uint32_t tree_groups = (n_trees + 3u) >> 2;
-    const uint64_t n_units = ((blocks_per_tree + 7) >> 3) * 8 * tree_groups;  // (row block, tree group) pairs, padded per XCD
+    uint64_t blocks_per_tree;
+    uint32_t tree_groups;
+    const uint64_t n_units = exact_units(dv.n, n_trees, blocks_per_tree, tree_groups);
     const bool aligned4 = (dv.n & 3ull) == 0;  // every tree's bytes then start on a 4-byte boundary
     uint32_t fallbacks = 0, bad = 0;
     for (uint64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
-        const uint64_t slot = unit >> 3;
-        const uint64_t rb = (slot / tree_groups) * 8 + (unit & 7u);
-        const uint64_t t = (slot % tree_groups) * 4 + wave;
-        if (rb >= blocks_per_tree || t >= n_trees) continue;  // wave-uniform
+        uint64_t rb, t;
+        if (!exact_unit_map(unit, wave, blocks_per_tree, tree_groups, n_trees, rb, t)) continue;  // wave-uniform
         const uint64_t r0 = (rb << 10) + lane * 16u;  // first row of this lane's 16 bytes
         const uint64_t base = t * dv.n;                // the tree's side bytes / node indices
         uint32_t w[4] = {0u, 0u, 0u, 0u};

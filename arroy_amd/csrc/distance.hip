@@ -14,9 +14,9 @@ namespace ah {
 static constexpr int kBlock = 256;       // 4 waves = 32 octets
 static constexpr int kMaxBlocks = 32768;  // one tile per wave up to ~1M f32 rows / 8M 1-bit rows (measured: 1-bit scan 90 -> 80 us vs a 2048-block persistent grid), grid-stride beyond that
 // AH_SCAN_BLOCKS overrides the grid cap of the grid-stride kernels (tuning experiments only)
-static const int g_max_blocks = getenv("AH_SCAN_BLOCKS") ? atoi(getenv("AH_SCAN_BLOCKS")) : kMaxBlocks;
+#define g_max_blocks ((int)(tun(TUN_SCAN_BLOCKS) > 0 ? tun(TUN_SCAN_BLOCKS) : kMaxBlocks))
 // AH_MANHATTAN_ROWS=0: the octet kernel for Manhattan too (A/B switch)
-static const bool g_manhattan_rows = !(getenv("AH_MANHATTAN_ROWS") && atoi(getenv("AH_MANHATTAN_ROWS")) == 0);
+#define g_manhattan_rows (tun(TUN_MANHATTAN_ROWS) != 0)
 
 static inline unsigned grid_for(uint64_t work_items, int items_per_block) {
     uint64_t b = (work_items + items_per_block - 1) / items_per_block;

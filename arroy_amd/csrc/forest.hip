@@ -67,7 +67,7 @@ struct LevelInfo {
     // followed by uint32_t tree_first[n_trees + 1]
 };
 struct ScreenCounters {
-    unsigned long long fallbacks, violations;
+    unsigned long long fallbacks, violations, stage8_pairs, stage8_decided;
 };
 struct FTile {
     uint32_t node;
@@ -630,6 +630,11 @@ __device__ __forceinline__ _Float16 to_shadow_half(float x) {
     return h;
 }
 
+// Rows whose largest |x| is below 2^-40 (and not zero) are never decided by a screen: the f32 sums of squares behind the
+// measured norms underflow there (at 1e-23 they collapse to 0 and a bound built from them would let the bias alone decide
+// a Euclidean margin).  Their stats are +inf, i.e. every pair with such a row takes the reference arithmetic.
+constexpr uint32_t kTinyBits = 0x2B800000u;  // 2^-40
+
 // rows -> binary16 shadow + per-row stats.  One octet per row, lane j converts elements 32k + 4j .. +3 (8 bytes out).
 __global__ __launch_bounds__(kBlock) void k_shadow_rows(DataView dv, uint16_t *__restrict__ h_rows, uint32_t hpitch,
                                                         float4 *__restrict__ stats) {
@@ -640,6 +645,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_rows(DataView dv, uint16_t *_
         const float4 *r4 = reinterpret_cast<const float4 *>(dv.rows_f32 + row * dv.pitch) + j;
         uint2 *o2 = reinterpret_cast<uint2 *>(h_rows + row * hpitch) + j;
         float sa = 0.f, sb = 0.f, sc = 0.f;
+        uint32_t xbits = 0u;
         for (uint32_t k = 0; k < blocks; k++) {
             float4 x = ld_stream(r4 + k * 8);
             const uint32_t e0 = 32 * k + 4 * j;  // elements beyond dims (row padding) count as zeros
@@ -647,6 +653,8 @@ __global__ __launch_bounds__(kBlock) void k_shadow_rows(DataView dv, uint16_t *_
             if (e0 + 1 >= dv.dims) x.y = 0.0f;
             if (e0 + 2 >= dv.dims) x.z = 0.0f;
             if (e0 + 3 >= dv.dims) x.w = 0.0f;
+            xbits = max(max(xbits, __float_as_uint(x.x) & 0x7FFFFFFFu), max(__float_as_uint(x.y) & 0x7FFFFFFFu,
+                        max(__float_as_uint(x.z) & 0x7FFFFFFFu, __float_as_uint(x.w) & 0x7FFFFFFFu)));
             const _Float16 h0 = to_shadow_half(x.x), h1 = to_shadow_half(x.y), h2 = to_shadow_half(x.z), h3 = to_shadow_half(x.w);
             const float y0 = (float)h0, y1 = (float)h1, y2 = (float)h2, y3 = (float)h3;
             sa += y0 * y0 + y1 * y1 + y2 * y2 + y3 * y3;
@@ -662,7 +670,12 @@ __global__ __launch_bounds__(kBlock) void k_shadow_rows(DataView dv, uint16_t *_
         sc = octet_sum(sc);
         // 2-norms rounded UP: the f32 sums of squares carry a relative error below (dims + 8) * 2^-24
         const float up = 1.0f + (float)(dv.pitch + 64u) * 1.2e-7f;
-        if (j == 0) stats[row] = make_float4(sqrtf(sa) * up, sqrtf(sb) * up, sqrtf(sc) * up, 0.0f);
+        xbits = max(xbits, (uint32_t)__shfl_xor((int)xbits, 1, 8));
+        xbits = max(xbits, (uint32_t)__shfl_xor((int)xbits, 2, 8));
+        xbits = max(xbits, (uint32_t)__shfl_xor((int)xbits, 4, 8));
+        const bool tiny = xbits != 0u && xbits < kTinyBits;
+        const float inf = __uint_as_float(0x7F800000u);
+        if (j == 0) stats[row] = tiny ? make_float4(inf, inf, inf, 0.0f) : make_float4(sqrtf(sa) * up, sqrtf(sb) * up, sqrtf(sc) * up, 0.0f);
     }
 }
 
@@ -700,128 +713,191 @@ __global__ __launch_bounds__(256) void k_stats_max(const float4 *__restrict__ st
 // ------------------------------------------------------------------------------------------------
 // First stage of the node-major screen: an int8 copy.  The deep levels move one row per (item, node) pair and run at the
 // device's gather rate (1.6 KB per pair with the binary16 copy); the same certified-sign argument holds for ANY copy whose
-// distance to the original is measured, so a coarser copy can go first: x~8 = scale8 * q (q = int8, one scale for the
-// whole dataset), n~8 = scale_n * q_n per normal, s8 = scale8 * scale_n * <q_n, q> with an EXACT integer dot product
-// (v_dot4_i32_i8), and |s8 - r| <= |n - n~8||x~8| + |n||x - x~8| + gamma_r |n||x| (+ the roundings of the two scale
-// products).  The bound uses the dataset-wide maxima of |x~8|, |x - x~8| and |x|, so a decided pair costs its 768-byte
-// int8 row and nothing else; on the benchmark data 76 % of the pairs are decided here, the rest go on to the binary16
-// stage (and 1 % of all pairs to the reference arithmetic).  Sides stay identical by construction; AH_SCREEN_VERIFY
-// checks every pair at every stage.
+// distance to the original is measured, so a coarser copy goes first.
+//
+//   rows      y = x / d (d = one power of two per DIMENSION: the largest |x_i| of the column rounded up, so a few
+//             "outlier dimensions" do not eat the 8 bits of all the others; exact, <n, x> = <n o d, x / d>), then
+//             y~ = s_r q with ONE SCALE PER ROW (s_r = max|y| / 127, q = int8): rows of very different norms and data with
+//             long tails (N(0,1): the 5-sigma entries of the dataset) quantise as well as uniform data;
+//   normals   n' = n o d, n~' = s_n (q_hi + q_lo / 256): TWO int8 digits.  The normal sits in LDS, so its second digit
+//             costs no HBM byte, and it removes the normal's half of the error bound (76 % -> ~90 % of the pairs decided
+//             on the uniform benchmark rows, ~69 % -> ~84 % on N(0,1) rows);
+//   screen    S = s_n (<q_hi, q> + <q_lo, q> / 256), integer dot products (v_dot4_i32_i8), exact;
+//   bound     |s_r S - r| <= s_r (|n' - n~'| |q| + |n'| |y/s_r - q| + g8 |n~'||q|) + gamma_r |n||x|.
+//
+// The sign of a cosine margin does not depend on s_r > 0, so for Cosine the test runs in units of s_r with the
+// DATASET-WIDE maxima of |q|, |y/s_r - q|, |x|/s_r (all dimensionless, the same for every row up to a few percent): a decided
+// pair costs its 768-byte int8 row and nothing else — no per-row load at all.  Euclidean / Manhattan add the bias in real
+// units and fetch s_r (4 bytes per pair from a 40 MB array).  DotProduct has no int8 stage (its margin needs the row's header
+// anyway).  Rows that are all zero, not finite, or so small that f32 squares underflow (max|x| < 2^-40) get q = 0 and
+// s_r = inf: they are never decided here.  Sides stay identical by construction; AH_SCREEN_VERIFY checks every pair at
+// every stage.
 // ------------------------------------------------------------------------------------------------
 struct NormalStats8 {
-    float an, bn, cn, extra;  // as NormalStats, for the int8 copy of the normal
-    float scale, pad0, pad1, pad2;
+    float an, bn, cn, extra;    // |n~'|, |n' - n~'|, |n'| (in the column-scaled space), bias
+    float scale, cn0, pad0, pad1;  // s_n; |n| in the original space (for the reference's own rounding error)
 };
-__global__ __launch_bounds__(256) void k_rows_maxabs(DataView dv, uint32_t *__restrict__ out_bits) {
-    __shared__ uint32_t s_m;
-    if (threadIdx.x == 0) s_m = 0u;
-    __syncthreads();
-    const uint64_t total4 = dv.n * (uint64_t)(dv.pitch >> 2);  // the padding of a row is zero
-    const float4 *p = reinterpret_cast<const float4 *>(dv.rows_f32);
-    uint32_t m = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (uint64_t)gridDim.x * blockDim.x) {
-        const float4 v = p[i];
-        // |x| as bits: orders like the value for finite numbers, inf and NaN end up above every finite one
-        m = max(max(m, __float_as_uint(v.x) & 0x7FFFFFFFu), max(__float_as_uint(v.y) & 0x7FFFFFFFu,
-                max(__float_as_uint(v.z) & 0x7FFFFFFFu, __float_as_uint(v.w) & 0x7FFFFFFFu)));
+
+// column-wise max |x| (as bits) over all rows: thread t of a block owns columns t, t + 256, ...
+__global__ __launch_bounds__(256) void k_col_maxabs(DataView dv, uint32_t *__restrict__ out_bits) {
+    const uint64_t rows_per_block = (dv.n + gridDim.x - 1) / gridDim.x;
+    const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_block, r1 = min(dv.n, r0 + rows_per_block);
+    for (uint32_t c = threadIdx.x; c < dv.dims; c += blockDim.x) {
+        uint32_t m = 0;
+        for (uint64_t r = r0; r < r1; r++) m = max(m, __float_as_uint(dv.rows_f32[r * dv.pitch + c]) & 0x7FFFFFFFu);
+        atomicMax(&out_bits[c], m);
     }
-    atomicMax(&s_m, m);
-    __syncthreads();
-    if (threadIdx.x == 0) atomicMax(out_bits, s_m);
+}
+// column maxima -> one power of two per dimension (d >= max|x_i|; 1 for empty / non-finite columns), and its inverse
+__global__ void k_dim_scales(const uint32_t *__restrict__ max_bits, uint32_t dims, uint32_t pitch8, float *__restrict__ d,
+                             float *__restrict__ inv_d) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pitch8) return;
+    float v = 1.0f;
+    if (i < dims) {
+        const uint32_t b = max_bits[i];
+        uint32_t e = b >> 23;                      // biased exponent of the column maximum
+        if ((b & 0x7FFFFFu) != 0u) e += 1;         // not a power of two itself: round up
+        if (b != 0u && b < 0x7F800000u && e >= 64u && e <= 190u) v = __uint_as_float(e << 23);  // 2^-63 .. 2^63, else 1
+    }
+    d[i] = v;
+    inv_d[i] = 1.0f / v;  // exact: a power of two
 }
 __device__ __forceinline__ int quantize8(float x, float inv_scale) {
     const float q = rintf(x * inv_scale);
     return (int)fminf(fmaxf(q, -127.0f), 127.0f);
 }
-// rows -> int8 copy; max_bits[0..1] = max over the rows of |x~8| and |x - x~8| (rounded up).  One octet per row.
-__global__ __launch_bounds__(kBlock) void k_shadow_rows8(DataView dv, int8_t *__restrict__ rows8, uint32_t pitch8, float scale,
-                                                         float inv_scale, uint32_t *__restrict__ max_bits) {
-    __shared__ uint32_t s_m[2];
-    if (threadIdx.x < 2) s_m[threadIdx.x] = 0u;
+__device__ __forceinline__ uint32_t octet_max_u32(uint32_t v) {
+    v = max(v, (uint32_t)__shfl_xor((int)v, 1, 8));
+    v = max(v, (uint32_t)__shfl_xor((int)v, 2, 8));
+    return max(v, (uint32_t)__shfl_xor((int)v, 4, 8));
+}
+// rows -> int8 copy with one scale per row; max_bits[0..2] = max over the rows of |q|, |y / s_r - q|, |x| / s_r (rounded up).
+// One octet per row: a pass for the row's max |y|, a pass that quantises (the row comes back from L2).
+__global__ __launch_bounds__(kBlock) void k_shadow_rows8(DataView dv, const float *__restrict__ inv_d, int8_t *__restrict__ rows8,
+                                                         uint32_t pitch8, float *__restrict__ row_scale,
+                                                         uint32_t *__restrict__ max_bits) {
+    __shared__ uint32_t s_m[3];
+    if (threadIdx.x < 3) s_m[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t j = threadIdx.x & 7u;
     const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
     const uint32_t blocks = dv.pitch >> 5;
-    float ma = 0.f, mb = 0.f;
+    const float4 *id4 = reinterpret_cast<const float4 *>(inv_d) + j;
+    float ma = 0.f, mb = 0.f, mc = 0.f;
     for (uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; row < dv.n; row += n_octets) {
         const float4 *r4 = reinterpret_cast<const float4 *>(dv.rows_f32 + row * dv.pitch) + j;
         uint32_t *o = reinterpret_cast<uint32_t *>(rows8 + row * pitch8);
-        float sa = 0.f, sb = 0.f;
+        uint32_t mbits = 0u, xbits = 0u;  // max |y|, max |x| (non-finite values end up on top)
+        for (uint32_t k = 0; k < blocks; k++) {
+            const float4 x = r4[k * 8];  // (the padding of a row is zero)
+            const float4 g = id4[k * 8];
+            mbits = max(max(mbits, __float_as_uint(x.x * g.x) & 0x7FFFFFFFu), max(__float_as_uint(x.y * g.y) & 0x7FFFFFFFu,
+                        max(__float_as_uint(x.z * g.z) & 0x7FFFFFFFu, __float_as_uint(x.w * g.w) & 0x7FFFFFFFu)));
+            xbits = max(max(xbits, __float_as_uint(x.x) & 0x7FFFFFFFu), max(__float_as_uint(x.y) & 0x7FFFFFFFu,
+                        max(__float_as_uint(x.z) & 0x7FFFFFFFu, __float_as_uint(x.w) & 0x7FFFFFFFu)));
+        }
+        mbits = octet_max_u32(mbits);
+        xbits = octet_max_u32(xbits);
+        // usable: finite, and neither the row nor its column-scaled image is so small that squares underflow
+        const bool ok = mbits >= kTinyBits && xbits >= kTinyBits && mbits < 0x7F800000u && xbits < 0x7F800000u;
+        const float m = __uint_as_float(mbits);
+        const float scale = ok ? m / 127.0f : 0.0f, inv_scale = ok ? 127.0f / m : 0.0f;
+        float sa = 0.f, sb = 0.f, sc = 0.f;
         for (uint32_t k = 0; k < blocks; k++) {
             float4 x = ld_stream(r4 + k * 8);
+            const float4 g = id4[k * 8];
             const uint32_t e0 = 32 * k + 4 * j;
             if (e0 + 0 >= dv.dims) x.x = 0.0f;
             if (e0 + 1 >= dv.dims) x.y = 0.0f;
             if (e0 + 2 >= dv.dims) x.z = 0.0f;
             if (e0 + 3 >= dv.dims) x.w = 0.0f;
-            const int q0 = quantize8(x.x, inv_scale), q1 = quantize8(x.y, inv_scale), q2 = quantize8(x.z, inv_scale),
-                      q3 = quantize8(x.w, inv_scale);
-            const float y0 = (float)q0 * scale, y1 = (float)q1 * scale, y2 = (float)q2 * scale, y3 = (float)q3 * scale;
-            sa += y0 * y0 + y1 * y1 + y2 * y2 + y3 * y3;
-            const float d0 = x.x - y0, d1 = x.y - y1, d2 = x.z - y2, d3 = x.w - y3;
+            const float y0 = x.x * g.x, y1 = x.y * g.y, y2 = x.z * g.z, y3 = x.w * g.w;  // exact: g is a power of two
+            const int q0 = quantize8(y0, inv_scale), q1 = quantize8(y1, inv_scale), q2 = quantize8(y2, inv_scale),
+                      q3 = quantize8(y3, inv_scale);
+            const float z0 = (float)q0 * scale, z1 = (float)q1 * scale, z2 = (float)q2 * scale, z3 = (float)q3 * scale;
+            sa += (float)(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);  // exact integers (< 2^24 per lane up to 8000 dims)
+            const float d0 = y0 - z0, d1 = y1 - z1, d2 = y2 - z2, d3 = y3 - z3;
             sb += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            sc += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
             o[k * 8 + j] = ((uint32_t)q0 & 0xFFu) | (((uint32_t)q1 & 0xFFu) << 8) | (((uint32_t)q2 & 0xFFu) << 16) | (((uint32_t)q3 & 0xFFu) << 24);
         }
         for (uint32_t w = (dv.pitch >> 2) + j; w < (pitch8 >> 2); w += 8) o[w] = 0u;  // zero tail of the int8 row
         sa = octet_sum(sa);
         sb = octet_sum(sb);
-        // rounded UP: f32 sums of squares (relative error < (pitch + 8) 2^-24), the rounding of scale * q (2^-24 |y| per
-        // element, at most 127 scale) inside the difference
-        const float up = 1.0f + (float)(dv.pitch + 64u) * 1.2e-7f;
-        ma = fmaxf(ma, sqrtf(sa) * up);
-        mb = fmaxf(mb, sqrtf(sb) * up + 127.0f * scale * 6.0e-8f * sqrtf((float)dv.pitch));
+        sc = octet_sum(sc);
+        if (j == 0) row_scale[row] = ok ? scale : __uint_as_float(0x7F800000u);  // inf: the row never decides here
+        if (ok) {
+            // in units of the row's scale, rounded UP: f32 sums of squares (relative error < (pitch + 8) 2^-24), the
+            // rounding of scale * q inside the difference (2^-24 |z| per element, |z| <= 127 scale), the division
+            const float up = (1.0f + (float)(dv.pitch + 64u) * 1.2e-7f) * 1.000001f;
+            ma = fmaxf(ma, sqrtf(sa) * up);
+            mb = fmaxf(mb, (sqrtf(sb) * up + 127.0f * scale * 6.0e-8f * sqrtf((float)dv.pitch)) / scale * 1.000001f);
+            mc = fmaxf(mc, sqrtf(sc) * up / scale * 1.000001f);
+        }
     }
     atomicMax(&s_m[0], __float_as_uint(ma));
     atomicMax(&s_m[1], __float_as_uint(mb));
+    atomicMax(&s_m[2], __float_as_uint(mc));
     __syncthreads();
-    if (threadIdx.x < 2) atomicMax(&max_bits[threadIdx.x], s_m[threadIdx.x]);
+    if (threadIdx.x < 3) atomicMax(&max_bits[threadIdx.x], s_m[threadIdx.x]);
 }
-// The level's normals -> int8 records [pitch8 bytes][NormalStats8], one wave per pending node.
+// The level's normals -> int8 records [pitch8 bytes q_hi][pitch8 bytes q_lo][NormalStats8], one wave per pending node.
 __global__ __launch_bounds__(64) void k_forest_shadow_normals8(DataView dv, const FNode *__restrict__ nodes, uint32_t n_nodes,
                                                                const uint8_t *__restrict__ normals, uint64_t nstride,
-                                                               uint64_t hdr_off, uint8_t *__restrict__ shadow8, uint64_t stride8,
+                                                               uint64_t hdr_off, const float *__restrict__ dim_scale,
+                                                               uint8_t *__restrict__ shadow8, uint64_t stride8,
                                                                uint32_t pitch8) {
     for (uint32_t node = blockIdx.x; node < n_nodes; node += gridDim.x) {
         if (nodes[node].state != ST_PENDING) continue;
         const float *nv = reinterpret_cast<const float *>(normals + node * nstride);
-        int8_t *out = reinterpret_cast<int8_t *>(shadow8 + node * stride8);
+        int8_t *out_hi = reinterpret_cast<int8_t *>(shadow8 + node * stride8);
+        int8_t *out_lo = out_hi + pitch8;
         uint32_t mbits = 0;
-        for (uint32_t i = threadIdx.x; i < dv.dims; i += 64) mbits = max(mbits, __float_as_uint(nv[i]) & 0x7FFFFFFFu);
+        for (uint32_t i = threadIdx.x; i < dv.dims; i += 64) mbits = max(mbits, __float_as_uint(nv[i] * dim_scale[i]) & 0x7FFFFFFFu);
         for (int off = 32; off > 0; off >>= 1) mbits = max(mbits, (uint32_t)__shfl_xor((int)mbits, off));
         const float m = __uint_as_float(mbits);
-        const bool ok = mbits != 0u && mbits < 0x7F800000u;  // finite and not all zero
+        const bool ok = mbits >= kTinyBits && mbits < 0x7F800000u;  // finite, not (nearly) zero
         const float scale = ok ? m / 127.0f : 0.0f, inv_scale = ok ? 127.0f / m : 0.0f;
-        float sa = 0.f, sb = 0.f, sc = 0.f;
+        float sa = 0.f, sb = 0.f, sc = 0.f, s0 = 0.f;
         for (uint32_t i = threadIdx.x; i < pitch8; i += 64) {
-            const float x = i < dv.dims ? nv[i] : 0.0f;
-            const int q = ok ? quantize8(x, inv_scale) : 0;
-            const float y = (float)q * scale, d = x - y;
+            const float x0 = i < dv.dims ? nv[i] : 0.0f;
+            const float x = i < dv.dims ? x0 * dim_scale[i] : 0.0f;  // exact: a power of two
+            const float t = x * inv_scale;
+            const int qh = ok ? quantize8(x, inv_scale) : 0;
+            const int ql = ok ? (int)fminf(fmaxf(rintf((t - (float)qh) * 256.0f), -127.0f), 127.0f) : 0;
+            const float y = ((float)qh + (float)ql * 0.00390625f) * scale, d = x - y;  // the digits sum exactly (16 bits)
             sa += y * y;
             sb += d * d;
             sc += x * x;
-            out[i] = (int8_t)q;
+            s0 += x0 * x0;
+            out_hi[i] = (int8_t)qh;
+            out_lo[i] = (int8_t)ql;
         }
         for (int off = 32; off > 0; off >>= 1) {
             sa += __shfl_xor(sa, off);
             sb += __shfl_xor(sb, off);
             sc += __shfl_xor(sc, off);
+            s0 += __shfl_xor(s0, off);
         }
         if (threadIdx.x == 0) {
             const float up = 1.0f + (float)(pitch8 + 64u) * 1.2e-7f;
             const float *nh = reinterpret_cast<const float *>(normals + node * nstride + hdr_off);
             NormalStats8 st;
             st.an = sqrtf(sa) * up;
-            st.bn = ok ? sqrtf(sb) * up + 127.0f * scale * 6.0e-8f * sqrtf((float)pitch8) : __uint_as_float(0x7F800000u);
+            st.bn = ok ? sqrtf(sb) * up + 128.0f * scale * 6.0e-8f * sqrtf((float)pitch8) : __uint_as_float(0x7F800000u);
             st.cn = sqrtf(sc) * up;
+            st.cn0 = sqrtf(s0) * up;
             st.extra = dv.metric == AH_COSINE ? 0.0f : nh[0];
             st.scale = scale;
-            st.pad0 = st.pad1 = st.pad2 = 0.0f;
-            *reinterpret_cast<NormalStats8 *>(shadow8 + node * stride8 + pitch8) = st;
+            st.pad0 = st.pad1 = 0.0f;
+            *reinterpret_cast<NormalStats8 *>(shadow8 + node * stride8 + 2 * (uint64_t)pitch8) = st;
         }
     }
 }
-// integer dot of one int8 row against the int8 normal in LDS, octet-cooperative: lane j covers bytes 128 k + 16 j .. +15.
-// q4 = normal (LDS) + j, r4 = row (global, streamed) + j.  Result (as float; exact below 2^24) on every lane of the octet.
+// integer dot of one int8 row against the two int8 digits of the normal in LDS, octet-cooperative: lane j covers bytes
+// 128 k + 16 j .. +15.  hi4 / lo4 = normal digits (LDS) + j, r4 = row (global, streamed) + j.
+// Result: <q_hi, q> + <q_lo, q> / 256 as float (the integers are exact; one rounding per lane total and per octet add).
 __device__ __forceinline__ int dot16_i8(const uint4 a, const uint4 b, int acc) {
     acc = __builtin_amdgcn_sdot4((int)a.x, (int)b.x, acc, false);
     acc = __builtin_amdgcn_sdot4((int)a.y, (int)b.y, acc, false);
@@ -829,8 +905,8 @@ __device__ __forceinline__ int dot16_i8(const uint4 a, const uint4 b, int acc) {
     acc = __builtin_amdgcn_sdot4((int)a.w, (int)b.w, acc, false);
     return acc;
 }
-__device__ __forceinline__ float screen8_octet_dot(const uint4 *q4, const uint4 *r4, uint32_t steps) {
-    int acc0 = 0, acc1 = 0;
+__device__ __forceinline__ float screen8_octet_dot(const uint4 *hi4, const uint4 *lo4, const uint4 *r4, uint32_t steps) {
+    int h0 = 0, h1 = 0, l0 = 0, l1 = 0;
     uint32_t k = 0;
     for (; k + 6 <= steps; k += 6) {
         uint4 x[6];
@@ -838,12 +914,38 @@ __device__ __forceinline__ float screen8_octet_dot(const uint4 *q4, const uint4 
         for (int u = 0; u < 6; u++) x[u] = ld_stream_u4(r4 + (k + u) * 8);
 #pragma unroll
         for (int u = 0; u < 6; u += 2) {
-            acc0 = dot16_i8(q4[(k + u) * 8], x[u], acc0);
-            acc1 = dot16_i8(q4[(k + u + 1) * 8], x[u + 1], acc1);
+            h0 = dot16_i8(hi4[(k + u) * 8], x[u], h0);
+            l0 = dot16_i8(lo4[(k + u) * 8], x[u], l0);
+            h1 = dot16_i8(hi4[(k + u + 1) * 8], x[u + 1], h1);
+            l1 = dot16_i8(lo4[(k + u + 1) * 8], x[u + 1], l1);
         }
     }
-    for (; k < steps; k++) acc0 = dot16_i8(q4[k * 8], ld_stream_u4(r4 + k * 8), acc0);
-    return octet_sum((float)acc0 + (float)acc1);
+    for (; k < steps; k++) {
+        const uint4 x = ld_stream_u4(r4 + k * 8);
+        h0 = dot16_i8(hi4[k * 8], x, h0);
+        l0 = dot16_i8(lo4[k * 8], x, l0);
+    }
+    return octet_sum((float)(h0 + h1) + (float)(l0 + l1) * 0.00390625f);
+}
+// the decision of the int8 stage.  S = s_n x (the digits' dot products), i.e. the screen value in units of the row's scale;
+// max8 = dataset-wide {|q|, |y / s_r - q|, |x| / s_r}; s_row = the row's scale (Euclidean / Manhattan; unused for Cosine).
+template <int METRIC>
+__device__ __forceinline__ bool screen8_decides(float S, float s_row, const float4 max8, const NormalStats8 ns, float gamma_r,
+                                                uint32_t &side) {
+    // g8 = 2e-6: the conversions and sums of the lane totals (each exact below 2^24) and the scale product
+    float e = ns.bn * max8.x + ns.cn * max8.y + 2.0e-6f * (ns.an * max8.x) + gamma_r * (ns.cn0 * max8.z);
+    float m = S;
+    if (METRIC == AH_EUCLIDEAN || METRIC == AH_MANHATTAN) {
+        // back to real units (s_row = inf for rows that must not be decided here: m and e turn NaN / inf -> undecided),
+        // then r = fl(bias + fl_ref(dot)) as in screen_decides
+        const float sd = S * s_row;
+        e = e * s_row * 1.000001f + 1.2e-7f * fabsf(sd);
+        m = ns.extra + sd;
+        e += 2.4e-7f * (fabsf(ns.extra) + fabsf(sd) + e);
+    }
+    e = e * 1.002f + 1e-30f;
+    side = (__float_as_uint(m) >> 31) ^ 1u;
+    return fabsf(m) > e;  // false for NaN / inf
 }
 
 // The level's normals (records [vector][header slot]) -> shadow records [hpitch halves][NormalStats], one wave per node.
@@ -925,16 +1027,17 @@ __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, Scre
                                                                uint32_t *__restrict__ tile_left,
                                                                const AbortFlags abort_flag,
                                                                ScreenCounters *__restrict__ counters, uint32_t verify) {
-    extern __shared__ float4 s_n4[];  // [pitch floats f32 normal][hpitch halves shadow normal][pitch8 bytes int8 normal]
-    __shared__ uint32_t s_left, s_fb, s_bad;
+    extern __shared__ float4 s_n4[];  // [pitch floats f32 normal][hpitch halves shadow normal][2 x pitch8 bytes: the int8 digits]
+    __shared__ uint32_t s_left, s_fb, s_bad, s_n8, s_d8;
     const float *s_n = reinterpret_cast<const float *>(s_n4);
     const uint4 *s_h4 = reinterpret_cast<const uint4 *>(s_n4 + (dv.pitch >> 2));
-    const uint4 *s_q4 = s_h4 + (sv.hpitch >> 3);
+    const uint4 *s_q4 = s_h4 + (sv.hpitch >> 3);        // q_hi
+    const uint4 *s_ql4 = s_q4 + (sv.pitch8 >> 4);        // q_lo
     const bool stage8 = METRIC != AH_DOT_PRODUCT && sv.rows8 != nullptr && shadow8 != nullptr;  // (DotProduct needs the row's header anyway)
     const uint32_t steps8 = sv.pitch8 >> 7;
     const uint32_t o = threadIdx.x >> 3, j = threadIdx.x & 7u;
     const uint32_t steps = sv.hpitch >> 6;
-    uint32_t fallbacks = 0, bad = 0;
+    uint32_t fallbacks = 0, bad = 0, met8 = 0, decided8 = 0;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (abort_requested(abort_flag)) return;
         const FTile tl = tiles[tile];
@@ -950,7 +1053,7 @@ __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, Scre
             if (stage8) {
                 const uint4 *g_q4 = reinterpret_cast<const uint4 *>(shadow8 + tl.node * stride8);
                 uint4 *d_q4 = d_h4 + (sv.hpitch >> 3);
-                for (uint32_t i = threadIdx.x; i < (sv.pitch8 >> 4); i += blockDim.x) d_q4[i] = g_q4[i];
+                for (uint32_t i = threadIdx.x; i < (sv.pitch8 >> 3); i += blockDim.x) d_q4[i] = g_q4[i];  // both digits
             }
         }
         if (threadIdx.x == 0) s_left = 0;
@@ -958,16 +1061,8 @@ __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, Scre
         const float *g_h = reinterpret_cast<const float *>(normals + tl.node * nstride + hdr_off);
         const LeafHdr nh = {g_h[0], g_h[1]};
         const NormalStats ns = *reinterpret_cast<const NormalStats *>(shadow + tl.node * hstride + (uint64_t)sv.hpitch * 2);
-        NormalStats ns8 = {0.f, 0.f, 0.f, 0.f};
-        float scale8 = 0.0f;
-        if (stage8) {
-            const NormalStats8 raw = *reinterpret_cast<const NormalStats8 *>(shadow8 + tl.node * stride8 + sv.pitch8);
-            ns8.an = raw.an;
-            ns8.bn = raw.bn;
-            ns8.cn = raw.cn;
-            ns8.extra = raw.extra;
-            scale8 = sv.scale8 * raw.scale;
-        }
+        NormalStats8 ns8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (stage8) ns8 = *reinterpret_cast<const NormalStats8 *>(shadow8 + tl.node * stride8 + 2 * (uint64_t)sv.pitch8);
         const uint32_t in_tile = min(kTile, nd->count - tl.first);
         const uint32_t *pp = perm + nd->start + tl.first;
         uint64_t mask = 0;
@@ -980,9 +1075,11 @@ __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, Scre
             bool decided = false;
             if (stage8) {  // first stage: the int8 copy, 768 bytes of a 768-d row; bound from the dataset-wide maxima
                 const uint4 *r8 = reinterpret_cast<const uint4 *>(sv.rows8 + row * sv.pitch8) + j;
-                const float s8 = screen8_octet_dot(s_q4 + j, r8, steps8) * scale8;
-                // gamma_s = 1e-6: the two scale products and the float sum of the lane totals (exact below 2^24)
-                decided = screen_decides<METRIC>(s8, sv.max8, ns8, 0.0f, 1.0e-6f, sv.gamma_r, side);
+                const float s_row = METRIC == AH_COSINE ? 1.0f : sv.scale8_rows[row];  // a cosine margin's sign needs no scale
+                const float s8 = screen8_octet_dot(s_q4 + j, s_ql4 + j, r8, steps8) * ns8.scale;
+                decided = screen8_decides<METRIC>(s8, s_row, sv.max8, ns8, sv.gamma_r, side);
+                met8++;
+                decided8 += decided ? 1u : 0u;
             }
             if (!decided) {  // octet-uniform: second stage, the binary16 copy
                 const uint4 *r4 = reinterpret_cast<const uint4 *>(sv.rows + row * sv.hpitch) + j;
@@ -1014,14 +1111,18 @@ __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, Scre
     }
     // statistics: one atomic per block
     __syncthreads();
-    if (threadIdx.x == 0) s_fb = s_bad = 0;
+    if (threadIdx.x == 0) s_fb = s_bad = s_n8 = s_d8 = 0;
     __syncthreads();
     if (j == 0 && fallbacks) atomicAdd(&s_fb, fallbacks);
     if (j == 0 && bad) atomicAdd(&s_bad, bad);
+    if (j == 0 && met8) atomicAdd(&s_n8, met8);
+    if (j == 0 && decided8) atomicAdd(&s_d8, decided8);
     __syncthreads();
     if (threadIdx.x == 0) {
         if (s_fb) atomicAdd(&counters->fallbacks, (unsigned long long)s_fb);
         if (s_bad) atomicAdd(&counters->violations, (unsigned long long)s_bad);
+        if (s_n8) atomicAdd(&counters->stage8_pairs, (unsigned long long)s_n8);
+        if (s_d8) atomicAdd(&counters->stage8_decided, (unsigned long long)s_d8);
     }
 }
 
@@ -1096,6 +1197,44 @@ struct RowsSchedule {
     uint32_t chunk0;     // first chunk of this launch (a launch is limited to 2^32 work-items, so big levels take several)
     const uint32_t *tree_first;  // LDS variant: device copy of tree_first[n_trees + 1]
 };
+// block -> (group, rows) of a row-major launch; false when the block has nothing to do.  Shared by the margin kernel and
+// by k_rows_schedule_coverage (the test that every (group, row) pair is served exactly once runs THIS function on the
+// device, with the grids plan_rows_launches hands the build).
+__device__ __forceinline__ bool rows_block_map(const RowsSchedule &sch, uint32_t b, uint64_t n_rows, uint32_t &group,
+                                               uint64_t &row_begin, uint64_t &row_end) {
+    uint32_t chunk, tile;
+    if (sch.xcd_slots & 0x7FFFFFFFu) {
+        // One XCD per (chunk, group): workgroups go to the XCDs round-robin (block b -> XCD b & 7), so XCD x takes, for
+        // chunk c, the groups g = ((x - c) mod 8) + 8 k — the rotation by c evens out n_groups mod 8 over the chunks.  An
+        // XCD's L2 (4 MiB) then holds the normals of ONE group next to the row stream instead of those of the two
+        // groups that are in flight at any time when every group is spread over all eight.
+        const uint32_t x = b & 7u, slot = b >> 3;
+        const uint32_t per_chunk = (sch.xcd_slots & 0x7FFFFFFFu) * sch.tiles;
+        chunk = sch.chunk0 + slot / per_chunk;
+        const uint32_t rem = slot % per_chunk;
+        tile = rem % sch.tiles;
+        group = ((x + 8u - (chunk & 7u)) & 7u) + 8u * (rem / sch.tiles);
+        if (group >= sch.n_groups) return false;
+    } else {
+        const uint32_t per_chunk = sch.n_groups * sch.tiles;
+        chunk = sch.chunk0 + b / per_chunk;
+        const uint32_t in_chunk = b % per_chunk;
+        group = in_chunk / sch.tiles;
+        tile = in_chunk % sch.tiles;
+    }
+    row_begin = (uint64_t)chunk * sch.chunk_rows + (uint64_t)tile * sch.rows_per_block;
+    row_end = min(min(row_begin + sch.rows_per_block, (uint64_t)(chunk + 1) * sch.chunk_rows), n_rows);
+    return row_begin < row_end;
+}
+// test aid (ah_debug_launch_coverage): counts[group * n_rows + row] += 1 for every row the block would serve
+__global__ void k_rows_schedule_coverage(RowsSchedule sch, uint64_t n_rows, uint32_t *__restrict__ counts) {
+    uint32_t group;
+    uint64_t row_begin, row_end;
+    if (!rows_block_map(sch, blockIdx.x, n_rows, group, row_begin, row_end)) return;
+    for (uint64_t row = row_begin + (threadIdx.x >> 3); row < row_end; row += blockDim.x >> 3)
+        if ((threadIdx.x & 7u) == 0) atomicAdd(&counts[(uint64_t)group * n_rows + row], 1u);
+}
+
 template <int METRIC, int TC, bool LDS_NORMALS>
 __global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock,
                              LDS_NORMALS ? 1 : (AH_SCREEN_WAVES > 1 ? AH_SCREEN_WAVES : (TC == 8 ? 4 : 1))) void k_forest_screen_rows(
@@ -1106,30 +1245,10 @@ __global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock,
     extern __shared__ uint4 s_shadow4[];
     __shared__ uint32_t s_fb, s_bad;
     if (abort_requested(abort_flag)) return;
-    uint32_t chunk, group, tile;
-    if (sch.xcd_slots & 0x7FFFFFFFu) {
-        // One XCD per (chunk, group): workgroups go to the XCDs round-robin (block b -> XCD b & 7), so XCD x takes, for
-        // chunk c, the groups g = ((x - c) mod 8) + 8 k — the rotation by c evens out n_groups mod 8 over the chunks.  An
-        // XCD's L2 (4 MiB) then holds the normals of ONE group next to the row stream instead of those of the two
-        // groups that are in flight at any time when every group is spread over all eight.
-        const uint32_t x = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-        const uint32_t per_chunk = (sch.xcd_slots & 0x7FFFFFFFu) * sch.tiles;
-        chunk = sch.chunk0 + slot / per_chunk;
-        const uint32_t rem = slot % per_chunk;
-        tile = rem % sch.tiles;
-        group = ((x + 8u - (chunk & 7u)) & 7u) + 8u * (rem / sch.tiles);
-        if (group >= sch.n_groups) return;  // block-uniform
-    } else {
-        const uint32_t per_chunk = sch.n_groups * sch.tiles;
-        chunk = sch.chunk0 + blockIdx.x / per_chunk;
-        const uint32_t in_chunk = blockIdx.x % per_chunk;
-        group = in_chunk / sch.tiles;
-        tile = in_chunk % sch.tiles;
-    }
+    uint32_t group;
+    uint64_t row_begin, row_end;
+    if (!rows_block_map(sch, blockIdx.x, dv.n, group, row_begin, row_end)) return;  // block-uniform
     const uint32_t tree0 = tree_base + group * TC;
-    const uint64_t row_begin = (uint64_t)chunk * sch.chunk_rows + (uint64_t)tile * sch.rows_per_block;
-    const uint64_t row_end = min(min(row_begin + sch.rows_per_block, (uint64_t)(chunk + 1) * sch.chunk_rows), dv.n);
-    if (row_begin >= row_end) return;  // block-uniform
     const uint32_t hstride4 = (uint32_t)(hstride >> 4);
     uint32_t first_node = 0;
     if (LDS_NORMALS) {
@@ -1155,11 +1274,7 @@ __global__ __launch_bounds__(LDS_NORMALS ? (TC >= 16 ? 512 : 1024) : kBlock,
     const bool owner = octet_is_owner<N>(j);
     uint32_t fallbacks = 0, bad = 0;
     for (uint64_t row = row_begin + (threadIdx.x >> 3); row < row_end; row += octets) {
-#ifdef AH_EXPERIMENT_ROWS_L2  // timing experiment only (wrong results): every row read hits the same 3 MB of rows
-        const uint4 *r4 = reinterpret_cast<const uint4 *>(sv.rows + (row & 2047) * sv.hpitch) + j;
-#else
         const uint4 *r4 = reinterpret_cast<const uint4 *>(sv.rows + row * sv.hpitch) + j;
-#endif
         // Lane j owns tree octet_owned_tree(j) of each set of 8 trees: it loads that tree's node index (one load instruction
         // for 8 trees), broadcasts it to the octet, and later runs the tree's epilogue.  n_pass == TC except for the last
         // trees of a forest: spare slots repeat the last tree and are not stored.
@@ -1492,41 +1607,13 @@ struct Arena {
     }
 };
 
-// AH_DEBUG=1: synchronise after every launch and say which kernel finished (debugging aid only)
-bool g_debug = getenv("AH_DEBUG") != nullptr;
-// Measurement aids (the per-call knob is ah_build_options.margin_mode; these only steer AH_MARGIN_AUTO):
-// AH_ROWMAJOR=0 disables the row-major margin pass, =1 forces it whenever it is legal;
-// AH_ROWMAJOR_CACHE_MB = budget for one group's normals of a level, AH_ROWMAJOR_MAX_TC = largest tree group.
-int g_rows_force = getenv("AH_ROWMAJOR") ? atoi(getenv("AH_ROWMAJOR")) : -1;
-// grid caps (grid-stride beyond them): AH_FOREST_TILE_BLOCKS for the bookkeeping kernels over tiles (default: one tile per
-// block), AH_FOREST_NODE_BLOCKS for the node-major margin kernels (default: automatic, see node_grid), AH_FOREST_ROW_BLOCKS
-// for the f32 row-major passes.
-uint32_t g_tile_blocks = getenv("AH_FOREST_TILE_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_TILE_BLOCKS")) : (1u << 20);
-uint32_t g_node_blocks = getenv("AH_FOREST_NODE_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_NODE_BLOCKS")) : 0u;  // 0 = automatic
-uint32_t g_split_blocks = getenv("AH_FOREST_SPLIT_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_SPLIT_BLOCKS")) : 65536u;  // one wave per node
-bool g_rows_xcd = !(getenv("AH_ROWS_XCD") && atoi(getenv("AH_ROWS_XCD")) == 0);  // one XCD per (chunk, tree group): A/B switch
-uint32_t g_row_blocks = getenv("AH_FOREST_ROW_BLOCKS") ? (uint32_t)atoi(getenv("AH_FOREST_ROW_BLOCKS")) : (1u << 20);
-bool g_rows_advance = !(getenv("AH_ROWMAJOR_ADVANCE") && atoi(getenv("AH_ROWMAJOR_ADVANCE")) == 0);  // A/B switch
-bool g_rows_lds = !(getenv("AH_ROWMAJOR_LDS") && atoi(getenv("AH_ROWMAJOR_LDS")) == 0);              // A/B switch
+// Measurement and test aids: the tunables of common.h (environment variable at load time, ah_tuning_set at run time).
+// The per-call knob is ah_build_options.margin_mode; the tunables only steer AH_MARGIN_AUTO and the schedule of a level.
+// None of them changes a result.
 constexpr size_t kLdsNormalsBytes = 128u << 10;  // LDS given to the normals of one tree group (of 160 KiB per CU)
-uint32_t g_rows_max_tc = getenv("AH_ROWMAJOR_MAX_TC") ? (uint32_t)atoi(getenv("AH_ROWMAJOR_MAX_TC")) : 16u;
-double g_rows_cache_mb = getenv("AH_ROWMAJOR_CACHE_MB") ? atof(getenv("AH_ROWMAJOR_CACHE_MB")) : -1.0;
-// AH_SCREEN=0: never use the certified binary16 screen (as AH_MARGIN_EXACT_ONLY on every call);
-// AH_SCREEN_VERIFY=1: the screened kernels evaluate the reference arithmetic for EVERY pair as well and count the pairs
-// whose screened side differs (ah_build_stats.screen_violations; must be 0) — a test of the bound, not a product mode.
-bool g_screen = !(getenv("AH_SCREEN") && atoi(getenv("AH_SCREEN")) == 0);
-// Dense MFMA screen of a level (dense_device.h): AH_DENSE=0 never, =1 whenever it is legal (AUTO otherwise asks the cost
-// model); AH_DENSE_MAX_COLS = most normals of a level it is considered for; AH_DENSE_GMACS = the sustained multiply-add
-// rate the cost model assumes, in 1e9 MAC/s.
-int g_dense = getenv("AH_DENSE") ? atoi(getenv("AH_DENSE")) : -1;
-uint32_t g_dense_max_cols = getenv("AH_DENSE_MAX_COLS") ? (uint32_t)atoi(getenv("AH_DENSE_MAX_COLS")) : 16384u;
-double g_dense_gmacs = getenv("AH_DENSE_GMACS") ? atof(getenv("AH_DENSE_GMACS")) : 495e3;
-bool g_screen_verify = getenv("AH_SCREEN_VERIFY") && atoi(getenv("AH_SCREEN_VERIFY")) != 0;
-// AH_SCREEN8=0: no int8 first stage in the node-major screen; =1: keep it even when the data quantise badly (test aid)
-int g_screen8 = getenv("AH_SCREEN8") ? atoi(getenv("AH_SCREEN8")) : -1;
 #define AH_DBG(s, what)                                                       \
     do {                                                                      \
-        if (g_debug) {                                                        \
+        if (tun(TUN_DEBUG)) {                                                 \
             hipError_t _e = hipStreamSynchronize(s);                          \
             fprintf(stderr, "[ah] %s: %s\n", what, hipGetErrorString(_e));    \
             fflush(stderr);                                                   \
@@ -1608,96 +1695,113 @@ static uint64_t normal_record_stride(const ah_dataset *ds) {
     return metric_is_bq(ds->metric) ? raw : (raw + 127) & ~(uint64_t)127;
 }
 
-// Binary16 shadow of an f32 dataset (screen_device.h), built by the first forest build that wants it.  Returns false
-// (and remembers it) when the memory is not available: the build then runs in the reference arithmetic only.
+// Binary16 shadow of an f32 dataset (screen_device.h) and the int8 copy of the first node-major stage, built by the first
+// forest build that wants them.  Returns false when the screen cannot be used: never for 1-bit metrics / short vectors,
+// and — NOT remembered, the next build tries again — when the memory for the copies is not available right now (another
+// build's arenas may be live); ah_build_stats.screen_unavailable then says why the build ran in f32 arithmetic only.
+static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force);
 static bool ensure_screen(ah_dataset *ds, hipStream_t s) {
     std::lock_guard<std::mutex> lk(ds->mu);
-    if (ds->d_rows_h16) return true;
-    if (ds->screen_tried || metric_is_bq(ds->metric) || ds->dims < 32 || ds->n == 0) return false;
-    ds->screen_tried = true;
-    const uint32_t hpitch = (ds->dims + 63u) & ~63u;
-    uint16_t *rows = nullptr;
-    float4 *stats = nullptr;
-    if (hipMalloc((void **)&rows, ds->n * (size_t)hpitch * 2) != hipSuccess ||
-        hipMalloc((void **)&stats, ds->n * sizeof(float4)) != hipSuccess) {
-        (void)hipGetLastError();
-        if (rows) (void)hipFree(rows);
+    if (metric_is_bq(ds->metric) || ds->dims < 32 || ds->n == 0) {
+        ds->screen_never = true;
         return false;
     }
-    const DataView dv = ds->view();
-    const unsigned grid = (unsigned)std::min<uint64_t>((ds->n + 31) / 32, 1u << 20);
-    hipLaunchKernelGGL(k_shadow_rows, dim3(grid), dim3(kBlock), 0, s, dv, rows, hpitch, stats);
-    uint32_t *d_max = nullptr;
-    uint32_t h_max[4] = {0u, 0u, 0u, 0u};
-    bool ok = hipMalloc((void **)&d_max, 16) == hipSuccess && hipMemsetAsync(d_max, 0, 16, s) == hipSuccess;
-    if (ok) {
-        hipLaunchKernelGGL(k_stats_max, dim3(1024), dim3(256), 0, s, stats, (uint64_t)ds->n, d_max);
-        ok = hipMemcpyAsync(h_max, d_max, 16, hipMemcpyDeviceToHost, s) == hipSuccess;
-    }
-    if (hipStreamSynchronize(s) != hipSuccess || !ok) {
-        (void)hipGetLastError();
-        (void)hipFree(rows);
-        (void)hipFree(stats);
-        if (d_max) (void)hipFree(d_max);
-        return false;
-    }
-    (void)hipFree(d_max);
-    memcpy(ds->screen_max, h_max, 12);
-    float norm_sum;
-    memcpy(&norm_sum, &h_max[3], 4);
-    const double mean_norm = ds->n ? (double)norm_sum / (double)ds->n : 0.0;
-    ds->d_rows_h16 = rows;
-    ds->d_screen_stats = stats;
-    ds->hpitch = hpitch;
-    // The int8 copy for the first stage of the node-major screen: one scale for the dataset (largest |x| / 127).  Kept only
-    // when it will decide most pairs: the margin of a row against a normal of an unrelated direction is ~ |n||x| / sqrt(dims),
-    // the bound ~ 2 max|x - x~8| |n|, so the copy is useful while max|x - x~8| sqrt(dims) / mean|x| is small (0.11 for
-    // uniform 768-d data: 76 % of the pairs decided); outliers in the data or rows of very different norms blow it up.
-    if (g_screen8 != 0 && ds->metric != AH_DOT_PRODUCT) {
-        const uint32_t pitch8 = (ds->dims + 127u) & ~127u;
-        int8_t *rows8 = nullptr;
-        uint32_t *d_m = nullptr;
-        uint32_t h_m[4] = {0u, 0u, 0u, 0u};
-        bool ok8 = hipMalloc((void **)&rows8, ds->n * (size_t)pitch8) == hipSuccess && hipMalloc((void **)&d_m, 16) == hipSuccess &&
-                   hipMemsetAsync(d_m, 0, 16, s) == hipSuccess;
-        float scale = 0.0f;
-        if (ok8) {
-            hipLaunchKernelGGL(k_rows_maxabs, dim3(4096), dim3(256), 0, s, dv, d_m);
-            ok8 = hipMemcpyAsync(h_m, d_m, 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-            ok8 = ok8 && h_m[0] != 0u && h_m[0] < 0x7F800000u;  // finite, not all zero
-        }
-        if (ok8) {
-            float maxabs;
-            memcpy(&maxabs, &h_m[0], 4);
-            scale = maxabs / 127.0f;
-            ok8 = scale > 0.0f && hipMemsetAsync(d_m, 0, 16, s) == hipSuccess;
-            if (ok8) {
-                hipLaunchKernelGGL(k_shadow_rows8, dim3(grid), dim3(kBlock), 0, s, dv, rows8, pitch8, scale, 127.0f / maxabs, d_m);
-                ok8 = hipMemcpyAsync(h_m, d_m, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-            }
-        }
-        if (ok8) {
-            float a8, b8;
-            memcpy(&a8, &h_m[0], 4);
-            memcpy(&b8, &h_m[1], 4);
-            // against the MEAN row norm: rows much shorter than the longest ones have margins below a bound built from maxima
-            const double quality = (double)b8 * std::sqrt((double)ds->dims) / std::max(mean_norm, 1e-300);
-            ok8 = std::isfinite(a8) && std::isfinite(b8) && (g_screen8 == 1 || quality < 0.25);
-            if (ok8) {
-                ds->d_rows_i8 = rows8;
-                ds->pitch8 = pitch8;
-                ds->scale8 = scale;
-                ds->screen8_max[0] = a8;
-                ds->screen8_max[1] = b8;
-            }
-        }
-        if (!ok8) {
+    if (!ds->d_rows_h16) {
+        ds->screen_alloc_failed = true;  // until the copies exist
+        const uint32_t hpitch = (ds->dims + 63u) & ~63u;
+        uint16_t *rows = nullptr;
+        float4 *stats = nullptr;
+        if (hipMalloc((void **)&rows, ds->n * (size_t)hpitch * 2) != hipSuccess ||
+            hipMalloc((void **)&stats, ds->n * sizeof(float4)) != hipSuccess) {
             (void)hipGetLastError();
-            if (rows8) (void)hipFree(rows8);
+            if (rows) (void)hipFree(rows);
+            return false;
         }
-        if (d_m) (void)hipFree(d_m);
+        const DataView dv = ds->view();
+        const unsigned grid = (unsigned)std::min<uint64_t>((ds->n + 31) / 32, 1u << 20);
+        hipLaunchKernelGGL(k_shadow_rows, dim3(grid), dim3(kBlock), 0, s, dv, rows, hpitch, stats);
+        uint32_t *d_max = nullptr;
+        uint32_t h_max[4] = {0u, 0u, 0u, 0u};
+        bool ok = hipMalloc((void **)&d_max, 16) == hipSuccess && hipMemsetAsync(d_max, 0, 16, s) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(k_stats_max, dim3(1024), dim3(256), 0, s, stats, (uint64_t)ds->n, d_max);
+            ok = hipMemcpyAsync(h_max, d_max, 16, hipMemcpyDeviceToHost, s) == hipSuccess;
+        }
+        if (hipStreamSynchronize(s) != hipSuccess || !ok) {
+            (void)hipGetLastError();
+            (void)hipFree(rows);
+            (void)hipFree(stats);
+            if (d_max) (void)hipFree(d_max);
+            return false;
+        }
+        (void)hipFree(d_max);
+        memcpy(ds->screen_max, h_max, 12);
+        ds->d_rows_h16 = rows;
+        ds->d_screen_stats = stats;
+        ds->hpitch = hpitch;
+        ds->screen_alloc_failed = false;
     }
+    const long long want8 = tun(TUN_SCREEN8);
+    if (want8 != 0 && ds->metric != AH_DOT_PRODUCT && !ds->d_rows_i8 && (!ds->screen8_decided || want8 == 1))
+        (void)ensure_screen8(ds, s, want8 == 1);
     return true;
+}
+// The int8 copy (rows, one scale per row, one power of two per dimension).  Kept only when it will decide most pairs: the
+// margin of a row against a normal of an unrelated direction is ~ |n||x| / sqrt(dims), the bound ~ |n| |x - x~8| (the
+// normal's two int8 digits make its own error negligible), so the copy is useful while quality = max|y/s - q| sqrt(dims)
+// / (typical |x|/s) is small: 0.06 for uniform 768-d rows (~90 % of the pairs decided), 0.2 for N(0,1) rows (~84 %); a
+// few huge entries in otherwise small rows blow it up.  `force` (AH_SCREEN8=1, a test aid) keeps it whatever the data.
+static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force) {
+    const DataView dv = ds->view();
+    const uint32_t pitch8 = (ds->dims + 127u) & ~127u;
+    const unsigned grid = (unsigned)std::min<uint64_t>((ds->n + 31) / 32, 1u << 20);
+    int8_t *rows8 = nullptr;
+    float *scales = nullptr, *dimsc = nullptr;
+    uint32_t *d_m = nullptr;  // [pitch8 column maxima][3 row maxima + pad]
+    uint32_t h_m[4] = {0u, 0u, 0u, 0u};
+    bool ok = hipMalloc((void **)&rows8, ds->n * (size_t)pitch8) == hipSuccess &&
+              hipMalloc((void **)&scales, ds->n * sizeof(float)) == hipSuccess &&
+              hipMalloc((void **)&dimsc, 2 * (size_t)pitch8 * sizeof(float)) == hipSuccess &&
+              hipMalloc((void **)&d_m, ((size_t)pitch8 + 4) * 4) == hipSuccess;
+    const bool alloc_ok = ok;
+    ok = ok && hipMemsetAsync(d_m, 0, ((size_t)pitch8 + 4) * 4, s) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_col_maxabs, dim3((unsigned)std::min<uint64_t>(4096, (ds->n + 255) / 256)), dim3(256), 0, s, dv, d_m);
+        hipLaunchKernelGGL(k_dim_scales, dim3((pitch8 + 255) / 256), dim3(256), 0, s, d_m, ds->dims, pitch8, dimsc, dimsc + pitch8);
+        hipLaunchKernelGGL(k_shadow_rows8, dim3(grid), dim3(kBlock), 0, s, dv, dimsc + pitch8, rows8, pitch8, scales, d_m + pitch8);
+        ok = hipMemcpyAsync(h_m, d_m + pitch8, 12, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    }
+    bool keep = false;
+    if (ok) {
+        float a8, b8, c8;
+        memcpy(&a8, &h_m[0], 4);
+        memcpy(&b8, &h_m[1], 4);
+        memcpy(&c8, &h_m[2], 4);
+        // against a TYPICAL |q| rather than the largest: rows are ~ isotropic after the column scaling, |q| ~ |x| / s
+        const double quality = (double)b8 * std::sqrt((double)ds->dims) / std::max((double)a8, 1e-300);
+        ds->screen8_quality = quality;
+        keep = std::isfinite(a8) && std::isfinite(b8) && std::isfinite(c8) && a8 > 0.0f && (force || quality < 0.6);
+        if (keep) {
+            ds->d_rows_i8 = rows8;
+            ds->d_scale8_rows = scales;
+            ds->d_dim_scale = dimsc;
+            ds->pitch8 = pitch8;
+            ds->screen8_max[0] = a8;
+            ds->screen8_max[1] = b8;
+            ds->screen8_max[2] = c8;
+        }
+        ds->screen8_decided = true;
+    } else {
+        (void)hipGetLastError();
+        if (alloc_ok) ds->screen8_decided = true;  // a device fault, not a lack of memory: do not loop on it
+    }
+    if (!keep) {
+        if (rows8) (void)hipFree(rows8);
+        if (scales) (void)hipFree(scales);
+        if (dimsc) (void)hipFree(dimsc);
+    }
+    if (d_m) (void)hipFree(d_m);
+    return keep;
 }
 
 // Device -> pageable host copies off the build's critical path.  hipMemcpy into pageable memory is staged by the
@@ -1768,7 +1872,7 @@ struct Readback {
         for (auto &t : pool) t.join();
     }
     hipError_t copy(const Job &job, hipStream_t cs, hipEvent_t *ev) {
-        static const bool direct = getenv("AH_READBACK_DIRECT") != nullptr;  // A/B: let the runtime stage the copy
+        const bool direct = tun(TUN_READBACK_DIRECT) != 0;  // A/B: let the runtime stage the copy
         if (direct) {
             hipError_t e = hipMemcpyAsync(job.dst, job.src, job.bytes, hipMemcpyDeviceToHost, cs);
             return e == hipSuccess ? hipStreamSynchronize(cs) : e;
@@ -1904,6 +2008,78 @@ int launch_screen_rows(int metric, uint32_t tc, bool lds, const ScreenRowsArgs &
 }
 }  // namespace
 
+// Grids of the dense MFMA screen and of the exact-pairs pass behind it (also used by ah_debug_launch_coverage).
+namespace {
+struct DensePlan {
+    uint32_t n_row_tiles, n_col_tiles, group;
+    bool wide;  // 256-column tiles (512 threads) unless one 128-column tile covers the level
+    uint64_t grid;
+};
+DensePlan dense_plan(uint64_t N, uint32_t n_cols) {
+    DensePlan p;
+    p.n_row_tiles = (uint32_t)((N + kDM - 1) / kDM);
+    p.wide = n_cols > 128;
+    const uint32_t bn = p.wide ? 256u : 128u;
+    p.n_col_tiles = (n_cols + bn - 1) / bn;
+    p.group = p.n_col_tiles > 1 ? kDenseGroup : 1u;
+    const uint64_t r8 = (p.n_row_tiles + 7) / 8;
+    p.grid = 8 * ((r8 + p.group - 1) / p.group) * p.group * p.n_col_tiles;
+    return p;
+}
+unsigned exact_pairs_grid(uint64_t N, uint32_t n_trees) {  // a multiple of 8: block b and b + grid land on the same XCD
+    return (unsigned)std::min<uint64_t>((((N + 1023) / 1024 + 7) / 8) * 8 * ((n_trees + 3) / 4), 1u << 16);
+}
+}  // namespace
+
+// Launch plan of one screened row-major pass over `groups` groups of `tcv` trees (RowsSchedule): chunk size, one XCD per
+// (chunk, group) or not, non-temporal rows or not, and the launches the pass is cut into (a launch carries at most
+// LAUNCH_MAX_ITEMS work-items).  The build and ah_debug_launch_coverage both launch exactly what this returns.
+namespace {
+struct RowsPlan {
+    RowsSchedule sch{};
+    unsigned threads = kBlock;
+    bool xcd = false, nt = false;
+    std::vector<std::pair<uint32_t, unsigned>> launches;  // (first chunk, grid)
+};
+int plan_rows_launches(uint64_t N, uint32_t hpitch, uint32_t tcv, uint32_t groups, bool lds, uint64_t group_normal_bytes,
+                       RowsPlan *plan) {
+    const uint32_t env_rpb = (uint32_t)std::max<long long>(0, tun(TUN_ROWS_PER_BLOCK)) / 32u * 32u;
+    const uint32_t rpb = lds ? 1024u : env_rpb ? env_rpb : 32u;  // rows per block
+    const uint64_t hrow = (uint64_t)hpitch * 2;
+    const uint64_t want_rows = tun(TUN_ROWS_CHUNK_ROWS) > 0 ? (uint64_t)tun(TUN_ROWS_CHUNK_ROWS)
+                                                             : ((uint64_t)std::max<long long>(1, tun(TUN_ROWS_CHUNK_MB)) << 20) / hrow;
+    uint32_t chunk_rows = (uint32_t)std::max<uint64_t>(rpb, want_rows / rpb * rpb);
+    if (chunk_rows > N) chunk_rows = (uint32_t)((N + rpb - 1) / rpb * rpb);
+    const uint32_t n_chunks = (uint32_t)((N + chunk_rows - 1) / chunk_rows);
+    RowsSchedule &sch = plan->sch;
+    sch.n_groups = groups;
+    sch.tiles = chunk_rows / rpb;
+    sch.chunk_rows = chunk_rows;
+    sch.rows_per_block = rpb;
+    // one XCD per (chunk, group) pays for small groups of many trees (measured at 10M x 100 trees: TC=4 level 9 139 -> 124 ms,
+    // level 10 199 -> 188; TC=2 level 10 211 -> 193; TC=8 with its 12 groups on 8 XCDs: level 8 111 -> 120, so not there)
+    plan->xcd = !lds && tun(TUN_ROWS_XCD) != 0 && tcv <= 4 && groups >= (uint32_t)std::max<long long>(1, tun(TUN_ROWS_XCD_MIN_GROUPS));
+    sch.xcd_slots = plan->xcd ? (groups + 7) / 8 : 0u;
+    const uint64_t per_chunk = plan->xcd ? 8ull * sch.xcd_slots * sch.tiles : (uint64_t)groups * sch.tiles;
+    // One XCD per group: the rows of a (chunk, group) are read once by that XCD, so in its L2 they only compete with the
+    // group's normals.  When those no longer fit (> ~5 MB) the rows are streamed with non-temporal loads (level 10 at 10M x
+    // 100 trees: 188 -> 171 ms); while they fit, cached row loads are better (the chunk then stays in the Infinity Cache
+    // for the other groups: level 9 125 vs 142 ms).
+    const long long nt_force = tun(TUN_ROWS_NT);
+    plan->nt = plan->xcd && (nt_force >= 0 ? nt_force != 0 : group_normal_bytes > (uint64_t)std::max<long long>(0, tun(TUN_ROWS_NT_BYTES)));
+    if (plan->nt) sch.xcd_slots |= 0x80000000u;
+    plan->threads = lds ? (tcv >= 16 ? 512u : 1024u) : (unsigned)kBlock;
+    // a launch carries at most 2^32 - 1 work-items: big levels go out in several launches over chunk ranges
+    const uint64_t max_items = (uint64_t)std::min<long long>(0xFFFFFFFFll, std::max<long long>(1, tun(TUN_LAUNCH_MAX_ITEMS)));
+    AH_REQUIRE(per_chunk * plan->threads <= max_items, AH_ERR_INVALID_ARGUMENT, "forest build: too many trees for one row-major launch");
+    const uint32_t chunks_per_launch = (uint32_t)std::min<uint64_t>(n_chunks, (max_items / plan->threads) / per_chunk);
+    plan->launches.clear();
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += chunks_per_launch)
+        plan->launches.emplace_back(c0, (unsigned)((uint64_t)std::min<uint32_t>(chunks_per_launch, n_chunks - c0) * per_chunk));
+    return AH_OK;
+}
+}  // namespace
+
 // `subset_ids` == nullptr: every tree covers all items (Writer::build with missing trees).  Otherwise tree t covers
 // the ascending id list subset_ids[subset_offsets[first_tree + t] .. subset_offsets[first_tree + t + 1]) — the
 // "descendants that became too large" of an incremental build (src/writer.rs:660-739).
@@ -1925,8 +2101,21 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     const bool bq = metric_is_bq(ds->metric);
     const uint64_t hdr_off = ds->row_bytes();
     const uint64_t nstride = normal_record_stride(ds);
+    // the tunables (common.h), read once per batch
+    const bool g_screen = tun(TUN_SCREEN) != 0, g_screen_verify = tun(TUN_SCREEN_VERIFY) != 0;
+    const int g_rows_force = (int)tun(TUN_ROWMAJOR), g_dense = (int)tun(TUN_DENSE);
+    const uint32_t g_tile_blocks = (uint32_t)std::max<long long>(1, tun(TUN_FOREST_TILE_BLOCKS));
+    const uint32_t g_node_blocks = (uint32_t)std::max<long long>(0, tun(TUN_FOREST_NODE_BLOCKS));
+    const uint32_t g_split_blocks = (uint32_t)std::max<long long>(1, tun(TUN_FOREST_SPLIT_BLOCKS));
+    const uint32_t g_row_blocks = (uint32_t)std::max<long long>(1, tun(TUN_FOREST_ROW_BLOCKS));
+    const bool g_rows_advance = tun(TUN_ROWMAJOR_ADVANCE) != 0, g_rows_lds = tun(TUN_ROWMAJOR_LDS) != 0;
+    const uint32_t g_rows_max_tc = (uint32_t)std::max<long long>(2, tun(TUN_ROWMAJOR_MAX_TC));
+    const double g_rows_cache_mb = (double)tun(TUN_ROWMAJOR_CACHE_MB);
+    const uint32_t g_dense_max_cols = (uint32_t)std::max<long long>(0, tun(TUN_DENSE_MAX_COLS));
+    const double g_dense_gmacs = (double)std::max<long long>(1, tun(TUN_DENSE_GMACS));
+    const int timing = (int)tun(TUN_TIMING);
     // AH_MARGIN_MODE (measurement aid): the kernel family for callers that leave the choice to the library
-    static const uint32_t env_mode = getenv("AH_MARGIN_MODE") ? (uint32_t)strtoul(getenv("AH_MARGIN_MODE"), nullptr, 0) & 0xFFFu : 0u;
+    const uint32_t env_mode = (uint32_t)tun(TUN_MARGIN_MODE) & 0xFFFu;
     const uint32_t mode_req = (opt->margin_mode & 0xFFFu) ? (opt->margin_mode & 0xFFFu) : env_mode;
     const bool exact_only = (opt->margin_mode & AH_MARGIN_EXACT_ONLY) != 0 || !g_screen;
 
@@ -1952,15 +2141,15 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     AH_TRY(d_block_sums.ensure(max_nodes / 256 + 2));
     // small device block: [abort flag, 3 pad][ScreenCounters][LevelInfo + tree_first[n_trees + 1]]
     const size_t info_words = (sizeof(LevelInfo) + ((size_t)n_trees + 1) * 4 + 3) / 4;
-    AH_TRY(d_small.ensure(4 + 4 + info_words));
+    AH_TRY(d_small.ensure(4 + 8 + info_words));
     const AbortFlags d_abort{d_small.p};
     ScreenCounters *d_counters = reinterpret_cast<ScreenCounters *>(d_small.p + 4);
-    LevelInfo *d_info = reinterpret_cast<LevelInfo *>(d_small.p + 8);
+    LevelInfo *d_info = reinterpret_cast<LevelInfo *>(d_small.p + 12);
     uint32_t *d_tree_first = reinterpret_cast<uint32_t *>(d_info + 1);
     DevBuf<uint32_t> d_tree_first_buf;  // first node of every tree of the level, gaps closed (LDS variant of the row pass)
     AH_TRY(d_tree_first_buf.ensure((size_t)n_trees + 2));
     uint32_t *d_tree_first_fixed = d_tree_first_buf.p;
-    AH_HIP(hipMemsetAsync(d_small.p, 0, (8 + info_words) * 4, s));
+    AH_HIP(hipMemsetAsync(d_small.p, 0, (12 + info_words) * 4, s));
 
     // pinned host memory: [2 x LevelInfo block][one word for the abort flag][2 x node table][read-back bounce]
     const size_t kBounce = 64ull << 20;  // pinned double buffer of the read-back worker
@@ -1988,16 +2177,17 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     }
     // certified binary16 screen: f32 metrics with AVX-tier rows, unless the caller (or AH_SCREEN=0) asks for f32 only
     const bool screen = !exact_only && !bq && ds->dims >= 32 && ensure_screen(ds, s);
+    if (!exact_only && !screen && ds->screen_alloc_failed) forest->stats.screen_unavailable = 1;
     ScreenView sv{};
     uint64_t hstride = 0;
     if (screen) {
         sv.rows = ds->d_rows_h16;
         sv.stats = ds->d_screen_stats;
         sv.max_stats = make_float4(ds->screen_max[0], ds->screen_max[1], ds->screen_max[2], 0.0f);
-        sv.rows8 = ds->d_rows_i8;  // nullptr: no int8 first stage
+        sv.rows8 = tun(TUN_SCREEN8) != 0 ? ds->d_rows_i8 : nullptr;  // nullptr: no int8 first stage
         sv.pitch8 = ds->pitch8;
-        sv.scale8 = ds->scale8;
-        sv.max8 = make_float4(ds->screen8_max[0], ds->screen8_max[1], ds->screen_max[2], 0.0f);
+        sv.scale8_rows = ds->d_scale8_rows;
+        sv.max8 = make_float4(ds->screen8_max[0], ds->screen8_max[1], ds->screen8_max[2], 0.0f);
         sv.hpitch = ds->hpitch;
         // accumulation-error factors (screen_device.h), each with a 4x safety factor over the standard model:
         //   screen: hpitch/16 dot2c per lane (2 roundings each) + 4 adds;  reference: dims/32 FMAs per chain, 6 adds of
@@ -2008,7 +2198,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     }
     const uint32_t verify = screen && g_screen_verify ? 1u : 0u;
     const bool screen8 = screen && sv.rows8 != nullptr;
-    const uint64_t stride8 = screen8 ? (((uint64_t)sv.pitch8 + sizeof(NormalStats8) + 127) & ~(uint64_t)127) : 0;
+    const uint64_t stride8 = screen8 ? ((2 * (uint64_t)sv.pitch8 + sizeof(NormalStats8) + 127) & ~(uint64_t)127) : 0;
     if (!subset_ids) {
         hipLaunchKernelGGL(k_init_perm, dim3(2048), dim3(256), 0, s, perm_a.p, N, n_trees);
     } else if (M) {
@@ -2343,7 +2533,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             // the int8 records are only read by the node-major screen: the first attempt of a row-order level skips them
             if (screen8 && !(attempt == 0 && row_tc >= 2))
                 hipLaunchKernelGGL(k_forest_shadow_normals8, dim3(std::min<uint32_t>(n_nodes, 65536u)), dim3(64), 0, s, dv, d_cur,
-                                   n_nodes, chunk_d, nstride, hdr_off, shadow8_d, stride8, sv.pitch8);
+                                   n_nodes, chunk_d, nstride, hdr_off, ds->d_dim_scale, shadow8_d, stride8, sv.pitch8);
             AH_HIP(hipEventRecord(bc.ev_attempt[2 * attempt], s));
             if (attempt == 0 && row_tc >= 2) {
                 // one pass over the rows serves up to row_tc trees (see k_forest_margin_rows)
@@ -2378,17 +2568,15 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     // (hpitch + hpitch / 16) * 2^-23 * sum |x~_i n~_i|; taken twice over
                     da.gamma_s = (float)(2.0 * ((double)sv.hpitch + (double)sv.hpitch / 16 + 16.0) * 1.1920929e-7);
                     da.gamma_r = sv.gamma_r;
-                    da.n_row_tiles = (uint32_t)((N + kDM - 1) / kDM);
-                    const bool wide = n_nodes > 128;  // 256-column tiles (512 threads) unless one 128-column tile covers the level
-                    const uint32_t dense_bn = wide ? 256u : 128u;
-                    da.n_col_tiles = (n_nodes + dense_bn - 1) / dense_bn;
-                    da.group = da.n_col_tiles > 1 ? kDenseGroup : 1u;
+                    const DensePlan dp = dense_plan(N, n_nodes);
+                    da.n_row_tiles = dp.n_row_tiles;
+                    da.n_col_tiles = dp.n_col_tiles;
+                    da.group = dp.group;
                     da.verify = verify;
-                    const uint64_t r8 = (da.n_row_tiles + 7) / 8;
-                    const uint64_t dgrid = 8 * ((r8 + da.group - 1) / da.group) * da.group * da.n_col_tiles;
+                    const bool wide = dp.wide;
+                    const uint64_t dgrid = dp.grid;
                     AH_REQUIRE(dgrid < 0x7FFFFFFFull, AH_ERR_INVALID_ARGUMENT, "forest build: too many tiles for one launch");
-                    const unsigned egrid =  // a multiple of 8: the kernel relies on block b and b + grid landing on the same XCD
-                        (unsigned)std::min<uint64_t>((((N + 1023) / 1024 + 7) / 8) * 8 * ((n_trees + 3) / 4), 1u << 16);
+                    const unsigned egrid = exact_pairs_grid(N, n_trees);
 #define AH_DENSE_WN(M, WNV)                                                                                              \
     do {                                                                                                                 \
         static std::atomic<bool> dense_opt_in[64]; /* once per instantiation and device */                              \
@@ -2423,46 +2611,28 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     // chunk of rows run back to back and find it in the Infinity Cache; the last trees (fewer than a group) in
                     // launches of their own.  The LDS variant reads the first node of every tree from a device copy.
                     const uint32_t gtc = lds_tc ? lds_tc : row_tc;
-                    static const uint32_t env_rpb = getenv("AH_ROWS_PER_BLOCK") ? (uint32_t)atoi(getenv("AH_ROWS_PER_BLOCK")) / 32u * 32u : 0u;
-                    const uint32_t rpb = lds_tc ? 1024u : env_rpb ? env_rpb : 32u;  // rows per block
-                    const uint64_t hrow = (uint64_t)sv.hpitch * 2;
-                    static const uint64_t chunk_mb = getenv("AH_ROWS_CHUNK_MB") ? (uint64_t)atoi(getenv("AH_ROWS_CHUNK_MB")) : 48;
-                    uint32_t chunk_rows = (uint32_t)std::max<uint64_t>(rpb, ((chunk_mb << 20) / hrow) / rpb * rpb);
-                    if (chunk_rows > N) chunk_rows = (uint32_t)((N + rpb - 1) / rpb * rpb);
-                    const uint32_t n_chunks = (uint32_t)((N + chunk_rows - 1) / chunk_rows);
                     ScreenRowsArgs ra{dv, sv, node_of.p, 0, 0, chunk_d, nstride, hdr_off, shadow_d, hstride, side_bytes.p,
-                                      RowsSchedule{1, chunk_rows / rpb, chunk_rows, rpb, 0, 0, d_tree_first_fixed}, d_abort, d_counters, verify};
+                                      RowsSchedule{}, d_abort, d_counters, verify};
                     if (lds_tc) {
                         memcpy(h_tree_first, tree_first.data(), ((size_t)n_trees + 1) * 4);
                         AH_HIP(hipMemcpyAsync(d_tree_first_fixed, h_tree_first, ((size_t)n_trees + 1) * 4, hipMemcpyHostToDevice, s));
                     }
                     const size_t lds_sh = (size_t)lds_worst * rec_bytes;
                     auto launch = [&](uint32_t tcv, uint32_t t0, uint32_t groups, uint32_t np) -> int {
+                        RowsPlan plan;
+                        AH_TRY(plan_rows_launches(N, sv.hpitch, tcv, groups, lds_tc != 0, (uint64_t)tcv * nodes_per_tree * rec_bytes, &plan));
                         ra.tree_base = t0;
                         ra.n_pass = np;
-                        ra.sch.n_groups = groups;
-                        // one XCD per (chunk, group) pays for small groups of many trees (measured at 10M x 100 trees: TC=4
-                        // level 9 139 -> 124 ms, level 10 199 -> 188; TC=2 level 10 211 -> 193; TC=8 with its 12 groups on 8
-                        // XCDs: level 8 111 -> 120, so not there)
-                        ra.sch.xcd_slots = (!lds_tc && g_rows_xcd && tcv <= 4 && groups >= 16) ? (groups + 7) / 8 : 0u;
-                        // a launch carries at most 2^32 - 1 work-items: big levels go out in several launches over chunk ranges
-                        const uint64_t per_chunk = ra.sch.xcd_slots ? 8ull * ra.sch.xcd_slots * ra.sch.tiles : (uint64_t)groups * ra.sch.tiles;
-                        // One XCD per group: the rows of a (chunk, group) are read once by that XCD, so in its L2 they only
-                        // compete with the group's normals.  When those no longer fit (> ~5 MB) the rows are streamed with
-                        // non-temporal loads (level 10 at 10M x 100 trees: 188 -> 171 ms); while they fit, cached row loads are
-                        // better (the chunk then stays in the Infinity Cache for the other groups: level 9 125 vs 142 ms).
-                        static const int nt_env = getenv("AH_ROWS_NT") ? atoi(getenv("AH_ROWS_NT")) : -1;
-                        const bool nt_rows = nt_env >= 0 ? nt_env != 0 : (uint64_t)tcv * nodes_per_tree * rec_bytes > (5ull << 20);
-                        if (ra.sch.xcd_slots && nt_rows) ra.sch.xcd_slots |= 0x80000000u;
-                        const uint64_t threads = lds_tc ? (tcv >= 16 ? 512u : 1024u) : (unsigned)kBlock;
-                        AH_REQUIRE(per_chunk * threads < 0xFFFFFFFFull, AH_ERR_INVALID_ARGUMENT, "forest build: too many trees for one row-major launch");
-                        const uint32_t chunks_per_launch = (uint32_t)std::min<uint64_t>(n_chunks, (0xFFFFFFFFull / threads) / per_chunk);
-                        for (uint32_t c0 = 0; c0 < n_chunks; c0 += chunks_per_launch) {
-                            ra.sch.chunk0 = c0;
-                            const uint64_t grid = (uint64_t)std::min<uint32_t>(chunks_per_launch, n_chunks - c0) * per_chunk;
-                            AH_TRY(launch_screen_rows(ds->metric, tcv, lds_tc != 0, ra, (unsigned)grid, lds_sh, s, ds->device));
+                        ra.sch = plan.sch;
+                        ra.sch.tree_first = d_tree_first_fixed;
+                        for (const auto &l : plan.launches) {
+                            ra.sch.chunk0 = l.first;
+                            AH_TRY(launch_screen_rows(ds->metric, tcv, lds_tc != 0, ra, l.second, lds_sh, s, ds->device));
                         }
                         forest->stats.margin_mode_launches[lds_tc ? (tcv >= 16 ? MM_LDS16 : MM_LDS8) : mm_rows(tcv)]++;
+                        forest->stats.rows_xcd_launches += plan.xcd ? plan.launches.size() : 0;
+                        forest->stats.rows_nt_launches += plan.nt ? plan.launches.size() : 0;
+                        forest->stats.rows_split_launches += plan.launches.size() - 1;
                         passes += groups;
                         return AH_OK;
                     };
@@ -2565,7 +2735,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                                    n_tiles, cur, N, chunk_d, nstride, hdr_off, masks.p, tile_left.p, d_abort);
                 forest->stats.margin_mode_launches[MM_BQ]++;
             } else if (screen) {
-                const size_t sh = (size_t)dv.pitch * 4 + (size_t)sv.hpitch * 2 + (screen8 ? (size_t)sv.pitch8 : 0);
+                const size_t sh = (size_t)dv.pitch * 4 + (size_t)sv.hpitch * 2 + (screen8 ? 2 * (size_t)sv.pitch8 : 0);
 #define AH_LAUNCH(M)                                                                                                      \
     do {                                                                                                                  \
         if (sh > 48 * 1024) /* very long vectors: opt in to more dynamic LDS than the default limit */                    \
@@ -2647,7 +2817,6 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                 attempt_ms[attempt] = m;
             }
         }
-        static const int timing = getenv("AH_TIMING") ? atoi(getenv("AH_TIMING")) : 0;
         if (timing >= 2)
             fprintf(stderr, "[ah] level %2u: %8u nodes %12llu pairs  mode %s  margin pass %.2f ms (+ retries %.2f) = %.3f ns per pair\n",
                     depth, n_nodes, (unsigned long long)info.pairs,
@@ -2697,6 +2866,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_HIP(hipStreamSynchronize(s));
         forest->stats.screen_fallbacks += sc.fallbacks;
         forest->stats.screen_violations += sc.violations;
+        forest->stats.screen8_pairs += sc.stage8_pairs;
+        forest->stats.screen8_decided += sc.stage8_decided;
         rb.push(forest->descendants + desc_base, final_perm.p, M * 4);  // lands while the host emits the node list
     }
     float ms = 0.0f;
@@ -2775,7 +2946,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         uint8_t *fit = (uint8_t *)realloc(forest->normals, forest->normals_len + 16);
         if (fit) forest->normals = fit;
     }
-    if (getenv("AH_TIMING")) {
+    if (timing) {
         const auto t_end = std::chrono::steady_clock::now();
         auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
         fprintf(stderr, "[ah] batch of %u trees: levels %.3f s (device %.3f), emit %.3f s, read-back still in flight after it "
@@ -2843,7 +3014,7 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
             st = AH_ERR_DEVICE;
         } else {
             // the binary16 shadow of the rows is made (once per dataset) before the batch is sized against free memory
-            if (!(options->margin_mode & AH_MARGIN_EXACT_ONLY) && g_screen) (void)ensure_screen(ds, lease.c->stream);
+            if (!(options->margin_mode & AH_MARGIN_EXACT_ONLY) && tun(TUN_SCREEN)) (void)ensure_screen(ds, lease.c->stream);
             // Trees in flight: bounded by HBM (per item and tree: 3 permutations + node index + side byte + masks = 18
             // bytes, plus the normals of all levels and their shadow) or by the caller.
             size_t free_b = 0, total_b = 0;
@@ -2909,6 +3080,143 @@ int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out) {
     out->normal_header_offset = forest->normal_header_offset;
     out->descendants = forest->descendants;
     out->descendants_len = forest->descendants_len;
+    return AH_OK;
+}
+
+// ---- content digest ---------------------------------------------------------------------------------------------------
+namespace {
+inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+// 64-bit hash of a byte range: four multiply-rotate lanes over 32-byte blocks (a plain word-at-a-time chain would bound the
+// digest of a 10 GB forest by the multiplier's latency), folded with the splitmix finaliser of arroy_hip_policy.h
+uint64_t hash_bytes(const void *data, size_t len, uint64_t seed) {
+    const uint8_t *p = reinterpret_cast<const uint8_t *>(data);
+    uint64_t h0 = seed ^ 0x9E3779B97F4A7C15ull, h1 = seed + 0xC2B2AE3D27D4EB4Full, h2 = ~seed, h3 = seed * 0x165667B19E3779F9ull + len;
+    size_t i = 0;
+    for (; i + 32 <= len; i += 32) {
+        uint64_t w[4];
+        memcpy(w, p + i, 32);
+        h0 = rotl64((h0 ^ w[0]) * 0x9FB21C651E98DF25ull, 29);
+        h1 = rotl64((h1 ^ w[1]) * 0xD6E8FEB86659FD93ull, 31);
+        h2 = rotl64((h2 ^ w[2]) * 0xBF58476D1CE4E5B9ull, 27);
+        h3 = rotl64((h3 ^ w[3]) * 0x94D049BB133111EBull, 33);
+    }
+    uint64_t tail[4] = {0, 0, 0, 0};
+    if (i < len) memcpy(tail, p + i, len - i);
+    h0 = (h0 ^ tail[0]) * 0x9FB21C651E98DF25ull;
+    h1 = (h1 ^ tail[1]) * 0xD6E8FEB86659FD93ull;
+    h2 = (h2 ^ tail[2]) * 0xBF58476D1CE4E5B9ull;
+    h3 = (h3 ^ tail[3]) * 0x94D049BB133111EBull;
+    return ah_mix64(ah_mix64(h0 ^ rotl64(h1, 17)) + ah_mix64(h2 ^ rotl64(h3, 41)) + len);
+}
+}  // namespace
+
+int ah_forest_digest(const ah_forest *forest, uint64_t *out_per_tree, uint64_t *out_total) {
+    AH_REQUIRE(forest && (out_per_tree || out_total), AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    const uint32_t n_trees = (uint32_t)forest->roots.size();
+    const size_t n_nodes = forest->nodes.size();
+    // the nodes of a tree are contiguous and the trees ascend (build_batch emits tree by tree)
+    std::vector<size_t> first(n_trees + 1, n_nodes);
+    for (size_t i = n_nodes; i-- > 0;) {
+        const uint32_t t = forest->nodes[i].tree;
+        AH_REQUIRE(t < n_trees, AH_ERR_INVALID_ARGUMENT, "forest digest: node %zu names tree %u of %u", i, t, n_trees);
+        first[t] = i;
+    }
+    for (uint32_t t = n_trees; t-- > 0;) first[t] = std::min(first[t], first[t + 1]);
+    // header bytes of a record: up to the 16-byte slot, but only the metric's own floats are content (the rest is zero
+    // padding either way); vector bytes: everything before the header
+    const size_t vec_off = forest->normal_vector_offset, hdr_off = forest->normal_header_offset;
+    const size_t vec_len = hdr_off > vec_off ? hdr_off - vec_off : 0;
+    const size_t hdr_len = std::min<size_t>(8, forest->normal_stride - hdr_off);
+    std::vector<uint64_t> per(n_trees, 0);
+    std::atomic<uint32_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const uint32_t t = next.fetch_add(1, std::memory_order_relaxed);
+            if (t >= n_trees) break;
+            uint64_t h = ah_mix64(0x61727279ull + t);  // the tree index is part of the content (seeds are per tree)
+            const size_t base = first[t];
+            for (size_t i = first[t]; i < first[t + 1]; i++) {
+                const ah_node &nd = forest->nodes[i];
+                if (nd.tree != t) continue;
+                uint64_t f[4] = {(uint64_t)nd.kind | (uint64_t)nd.has_normal << 8 | (uint64_t)nd.depth << 32, nd.count, 0, 0};
+                if (nd.kind == AH_NODE_SPLIT) {
+                    f[2] = nd.left - base;  // children by their position inside the tree
+                    f[3] = nd.right - base;
+                }
+                h = ah_mix64(h ^ hash_bytes(f, sizeof f, i - base));
+                if (nd.kind == AH_NODE_SPLIT) {
+                    if (nd.has_normal) {
+                        const uint8_t *rec = forest->normals + nd.offset;
+                        h = ah_mix64(h ^ hash_bytes(rec + vec_off, vec_len, 1));
+                        h = ah_mix64(h ^ hash_bytes(rec + hdr_off, hdr_len, 2));
+                    }
+                } else {
+                    h = ah_mix64(h ^ hash_bytes(forest->descendants + nd.offset, (size_t)nd.count * 4, 3));
+                }
+            }
+            per[t] = h;
+        }
+    };
+    {
+        const size_t n_threads = n_nodes < 100000 ? 1 : std::min<size_t>({(size_t)n_trees, 8, std::max(1u, std::thread::hardware_concurrency())});
+        std::vector<std::thread> pool;
+        for (size_t i = 1; i < n_threads; i++) pool.emplace_back(work);
+        work();
+        for (auto &th : pool) th.join();
+    }
+    uint64_t total = ah_mix64(n_trees);
+    for (uint32_t t = 0; t < n_trees; t++) {
+        total = ah_mix64(total ^ per[t]);
+        if (out_per_tree) out_per_tree[t] = per[t];
+    }
+    if (out_total) *out_total = total;
+    return AH_OK;
+}
+
+// Test aid: the block -> work-item maps of the build's launches, run on the device (see include/arroy_hip.h).
+int ah_debug_launch_coverage(int device, int kind, uint64_t n_rows, uint32_t dims, uint32_t a, uint32_t b, uint32_t *out_counts,
+                             uint64_t out_len) {
+    AH_REQUIRE(out_counts && n_rows && dims, AH_ERR_INVALID_ARGUMENT, "NULL / empty argument");
+    AH_HIP(hipSetDevice(device));
+    const uint32_t hpitch = (dims + 63u) & ~63u;
+    uint64_t need = 0;
+    DensePlan dp{};
+    if (kind == 0) {
+        AH_REQUIRE((a == 2 || a == 4 || a == 8 || a == 16) && b >= 1, AH_ERR_INVALID_ARGUMENT, "kind 0: a = trees per group, b = groups");
+        need = (uint64_t)b * n_rows;
+    } else if (kind == 1) {
+        AH_REQUIRE(a >= 1, AH_ERR_INVALID_ARGUMENT, "kind 1: a = columns");
+        dp = dense_plan(n_rows, a);
+        AH_REQUIRE(dp.grid < 0x7FFFFFFFull, AH_ERR_INVALID_ARGUMENT, "too many tiles for one launch");
+        need = (uint64_t)dp.n_row_tiles * dp.n_col_tiles;
+    } else if (kind == 2) {
+        AH_REQUIRE(a >= 1, AH_ERR_INVALID_ARGUMENT, "kind 2: a = trees");
+        need = (uint64_t)a * ((n_rows + 1023) >> 10);
+    } else {
+        AH_REQUIRE(false, AH_ERR_INVALID_ARGUMENT, "unknown coverage kind %d", kind);
+    }
+    AH_REQUIRE(out_len >= need, AH_ERR_INVALID_ARGUMENT, "out_counts holds %llu counters, %llu needed", (unsigned long long)out_len,
+               (unsigned long long)need);
+    DevMem d;
+    AH_HIP(hipMalloc(&d.p, need * 4));
+    AH_HIP(hipMemset(d.p, 0, need * 4));
+    if (kind == 0) {
+        RowsPlan plan;
+        // normals of a group as the build would size them for a level with 64 nodes per tree (only the nt policy reads it)
+        const uint64_t hstride = ((uint64_t)hpitch * 2 + 16 + 127) & ~(uint64_t)127;
+        AH_TRY(plan_rows_launches(n_rows, hpitch, a, b, false, (uint64_t)a * 64 * hstride, &plan));
+        for (const auto &l : plan.launches) {
+            plan.sch.chunk0 = l.first;
+            hipLaunchKernelGGL(k_rows_schedule_coverage, dim3(l.second), dim3(plan.threads), 0, 0, plan.sch, n_rows, d.as<uint32_t>());
+        }
+    } else if (kind == 1) {
+        hipLaunchKernelGGL(k_dense_coverage, dim3((unsigned)dp.grid), dim3(64), 0, 0, dp.group, dp.n_col_tiles, dp.n_row_tiles, d.as<uint32_t>());
+    } else {
+        hipLaunchKernelGGL(k_exact_coverage, dim3(exact_pairs_grid(n_rows, a)), dim3(256), 0, 0, n_rows, a, d.as<uint32_t>());
+    }
+    AH_HIP(hipGetLastError());
+    AH_HIP(hipDeviceSynchronize());
+    AH_HIP(hipMemcpy(out_counts, d.p, need * 4, hipMemcpyDeviceToHost));
     return AH_OK;
 }
 

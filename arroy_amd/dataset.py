@@ -60,13 +60,15 @@ class Dataset:
             raise ValueError("ids and vectors disagree on the number of items")
         _lib.check(_lib.lib().ah_dataset_upload_vectors(self._h, _ptr(ids), _ptr(v), ids.size))
 
-    def upload_records(self, item_ids: Sequence[int], records: Sequence[bytes], preprocessed: bool = True) -> None:
+    def upload_records(self, item_ids: Sequence[int], records: Sequence[bytes], preprocessed: Optional[bool] = None) -> None:
         """Stored item records `[0u8][header][vector]` as they sit in LMDB pages (src/node.rs:224-228).
-        `preprocessed` (DotProduct only): the headers come from a built database, i.e. `DotProduct::preprocess` already
-        ran over them (ah_dataset_set_preprocessed); pass False for freshly added items."""
+        `preprocessed` (DotProduct only): True = the headers come from a built database, i.e. `DotProduct::preprocess`
+        already ran over them (ah_dataset_set_preprocessed); False = freshly added items ({0, 0} headers); None (default)
+        leaves the dataset's flag alone, so a build over records nobody vouched for fails with AH_ERR_NEED_PREPROCESS
+        instead of silently using extra_dim = 0."""
         ids = _u32(item_ids)
         n = ids.size
-        if self.metric == 3:
+        if self.metric == 3 and preprocessed is not None:
             _lib.check(_lib.lib().ah_dataset_set_preprocessed(self._h, 1 if preprocessed else 0))
         if n == 0:
             return
@@ -368,6 +370,14 @@ class Forest:
         _lib.check(_lib.lib().ah_forest_stats(self._h, C.byref(st)))
         self.stats = {f: getattr(st, f) for f, _ in _lib.AhBuildStats._fields_}
         self.stats["margin_mode_launches"] = list(st.margin_mode_launches)
+
+    def digest(self):
+        """(total, per-tree array) 64-bit content digests (ah_forest_digest): equal for equal forests whatever the
+        margin mode, tuning or batching that built them."""
+        per = np.zeros(self.n_trees, dtype=np.uint64)
+        total = C.c_uint64(0)
+        _lib.check(_lib.lib().ah_forest_digest(self._h, _ptr(per), C.byref(total)))
+        return int(total.value), per
 
     def close(self) -> None:
         if self._h:

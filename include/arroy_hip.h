@@ -34,9 +34,11 @@
 extern "C" {
 #endif
 
-#define AH_ABI_VERSION 3   /* v2: ah_node.tree is 32 bits, ah_build_options.margin_mode, ah_build_stats.margin_mode_launches,
+#define AH_ABI_VERSION 4   /* v2: ah_node.tree is 32 bits, ah_build_options.margin_mode, ah_build_stats.margin_mode_launches,
                                   ah_last_error_detail, ah_dataset_replicate, ah_dataset_upload_flush
-                              v3: AH_MARGIN_DENSE_MFMA, ah_build_stats.dense_launches / dense_columns (appended) */
+                              v3: AH_MARGIN_DENSE_MFMA, ah_build_stats.dense_launches / dense_columns (appended)
+                              v4: ah_forest_digest, ah_tuning_set / _get / _reset, ah_debug_launch_coverage,
+                                  ah_build_stats.rows_* / screen8_* / screen_unavailable (appended) */
 
 /* every entry point is exported from the shared object (it is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -310,9 +312,23 @@ typedef struct ah_build_stats {
     uint64_t screen_violations;   /* AH_SCREEN_VERIFY=1 only: decided pairs whose f32 side differs (must be 0) */
     uint64_t dense_launches;      /* ABI v3: levels whose first attempt ran as one MFMA product (AH_MARGIN_DENSE_MFMA)  */
     uint64_t dense_columns;       /* ABI v3: normals (columns) those products covered, summed over the levels          */
+    /* ABI v4: which schedule variants of the row-major pass ran (kernel launches, not passes) */
+    uint64_t rows_xcd_launches;   /* launches that pinned every (chunk, tree group) to one XCD                          */
+    uint64_t rows_nt_launches;    /* ... of which streamed the rows with non-temporal loads                             */
+    uint64_t rows_split_launches; /* extra launches of passes cut at the work-item limit of one dispatch                */
+    uint64_t screen8_pairs;       /* (item, node) pairs that met the int8 first stage of the node-major screen          */
+    uint64_t screen8_decided;     /* ... of which that stage decided (the rest went on to the binary16 stage)           */
+    uint32_t screen_unavailable;  /* the build wanted the screen but its copies could not be allocated: f32 arithmetic  */
+    uint32_t reserved0;
 } ah_build_stats;
 
 AH_API int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out);
+/* 64-bit digest of the CONTENT of a forest, independent of how it was laid out in memory (batching, record padding):
+ * per tree, in the node order of ah_forest_view (post-order), kind / has_normal / children / count / depth of every
+ * node, header + vector bytes of every split plane, item ids of every Descendants node.  Two builds of the same
+ * dataset with the same seeds must agree whatever the margin mode or tuning: bench.py and the GPU tests compare the
+ * screened and the f32-only build of the 10M x 100-tree forest this way.  out_per_tree: n_trees values or NULL. */
+AH_API int ah_forest_digest(const ah_forest *forest, uint64_t *out_per_tree, uint64_t *out_total);
 AH_API int ah_forest_stats(const ah_forest *forest, ah_build_stats *out);
 /* Node sink in the shape `TmpNodes::put` expects (src/parallel.rs:130-147): children first, parent
  * last (post-order), per tree. `payload`: SPLIT -> the normal record of ah_forest_view (vector at
@@ -376,6 +392,23 @@ AH_API int ah_bench_memcpy(int device, uint64_t bytes, uint32_t iterations, doub
 AH_API int ah_bench_read(int device, uint64_t bytes, uint32_t iterations, double *out_ms_total);
 /* Name of the device (hipDeviceProp_t.name / gcnArchName) into buf. */
 AH_API int ah_device_name(int device, char *buf, size_t buf_len);
+
+/* Tunables: measurement / test aids that steer the SCHEDULE of the kernels (which family a level takes, grids, cache
+ * policy), never a result.  `name` is the environment variable that initialises the tunable when the library is loaded
+ * ("AH_ROWS_XCD", "AH_DENSE", "AH_SCREEN8", ...: DESIGN.md lists them).  Set them while no call is running. */
+AH_API int ah_tuning_set(const char *name, int64_t value);
+AH_API int ah_tuning_get(const char *name, int64_t *out_value, int64_t *out_default);
+AH_API int ah_tuning_reset(void);   /* every tunable back to its built-in default (not to the environment's value) */
+
+/* Test aid: run the block -> work-item maps of the build's launches on the device — the same device functions the
+ * margin kernels call and the same host-side launch plans the build uses, under the current tunables — over a shape,
+ * and count how often every work item is served (every count must be 1).
+ *   kind 0: screened row-major pass, a = trees per group (2 / 4 / 8 / 16), b = groups; out_counts[b][n_rows]
+ *   kind 1: dense MFMA screen, a = columns (normals of the level);               out_counts[row tiles of 256][column tiles]
+ *   kind 2: exact-pairs pass after the dense screen, a = trees;                   out_counts[a][ceil(n_rows / 1024)]
+ * `dims` sizes the rows as the build would.  out_len = number of counters the caller allocated (checked). */
+AH_API int ah_debug_launch_coverage(int device, int kind, uint64_t n_rows, uint32_t dims, uint32_t a, uint32_t b,
+                                    uint32_t *out_counts, uint64_t out_len);
 
 #ifdef __cplusplus
 }

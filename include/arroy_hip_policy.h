@@ -106,19 +106,40 @@ AH_HD uint32_t ah_route_side_is_left(uint64_t tree_seed, uint32_t node, uint32_t
 enum ah_synth_distribution {
     AH_SYNTH_UNIFORM_01 = 0,    /* i.i.d. uniform [0,1): what the reference's tests use
                                    (src/tests/writer.rs:302 `rng.gen()`)                     */
-    AH_SYNTH_UNIFORM_PM1 = 1    /* i.i.d. uniform [-1,1): sign-balanced margins for cosine   */
+    AH_SYNTH_UNIFORM_PM1 = 1,   /* i.i.d. uniform [-1,1): sign-balanced margins for cosine   */
+    AH_SYNTH_NORMAL = 2,        /* i.i.d. ~N(0,1): the sum of twelve uniforms minus 6
+                                   (Irwin-Hall: mean 0, variance 1, tails out to +-6), computed in integers so that host
+                                   and device agree bit for bit — no libm                      */
+    AH_SYNTH_NORMAL_OUTLIERS = 3 /* the same with a few "outlier dimensions" (dim % 97 == 13) scaled by 20, the shape
+                                   real embedding models show: one scale per dataset or per row then wastes the 8 bits of a
+                                   quantised copy on them                                      */
 };
 
 /* value of component `dim` of item `item` (item = row index, ids are 0..N-1). Exact in f32:
  * a 24-bit integer scaled by a power of two, so host and device agree bit for bit. */
 AH_HD float ah_synth_value(uint64_t seed, uint64_t item, uint32_t dim, uint32_t dims, int distribution) {
     uint64_t h = ah_mix64(ah_mix64(seed) + item * (uint64_t)dims + (uint64_t)dim);
-    uint32_t m = (uint32_t)(h >> 40);                 /* 24 random bits */
-    float u = (float)m * (1.0f / 16777216.0f);       /* [0,1) exactly */
-    if (distribution == AH_SYNTH_UNIFORM_PM1) {
-        return u * 2.0f - 1.0f;                       /* exact: 25-bit grid in [-1,1) */
+    if (distribution == AH_SYNTH_NORMAL || distribution == AH_SYNTH_NORMAL_OUTLIERS) {
+        /* twelve 20-bit uniforms out of four 64-bit draws (three each); their sum is < 12 * 2^20 < 2^24: exact */
+        uint32_t sum = 0;
+        uint32_t k;
+        for (k = 0; k < 4; k++) {
+            const uint64_t g = k == 0 ? h : ah_mix64(h + 0x9E3779B97F4A7C15ull * (uint64_t)k);
+            sum += (uint32_t)(g & 0xFFFFFu) + (uint32_t)((g >> 20) & 0xFFFFFu) + (uint32_t)((g >> 40) & 0xFFFFFu);
+        }
+        /* (sum + 6) / 2^20 - 6: the +6 centres the twelve half-open cells; |value| < 6, a multiple of 2^-20 */
+        float z = (float)((int32_t)sum - 6 * 1048576 + 6) * (1.0f / 1048576.0f);
+        if (distribution == AH_SYNTH_NORMAL_OUTLIERS && dim % 97u == 13u) z *= 20.0f; /* one IEEE multiplication: the same rounding everywhere */
+        return z;
     }
-    return u;
+    {
+        uint32_t m = (uint32_t)(h >> 40);                 /* 24 random bits */
+        float u = (float)m * (1.0f / 16777216.0f);       /* [0,1) exactly */
+        if (distribution == AH_SYNTH_UNIFORM_PM1) {
+            return u * 2.0f - 1.0f;                       /* exact: 25-bit grid in [-1,1) */
+        }
+        return u;
+    }
 }
 
 #endif /* ARROY_HIP_POLICY_H */

@@ -4,7 +4,13 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 from conftest import ROOT
+
+
+# first row of ah_synth_value(seed 42, AH_SYNTH_NORMAL, dims 8), as bits: pins the generator across compilers / devices
+PINNED_NORMAL_BITS = [[3191097216, 1057535632, 3198033120, 3212783840, 3214833192, 3208274208, 1068122128, 1041940608]]
 
 
 def declared_symbols():
@@ -26,7 +32,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 def test_abi_scalars_without_a_gpu():
     from arroy_amd import _lib
     L = _lib.lib()
-    assert L.ah_abi_version() == 3
+    assert L.ah_abi_version() == 4
     assert [L.ah_header_size(m) for m in range(7)] == [4, 4, 4, 8, 4, 4, 4]
     assert L.ah_vector_size(2, 768) == 3072
     assert L.ah_vector_size(6, 768) == 96
@@ -34,6 +40,30 @@ def test_abi_scalars_without_a_gpu():
     assert L.ah_header_size(99) == 0
     assert _lib.device_count() >= 0
     assert L.ah_last_error() is not None
+
+
+def test_tunables_without_a_gpu():
+    """ah_tuning_set / _get / _reset: the run-time form of the AH_* environment switches (schedule only, never a result)."""
+    import pytest
+
+    from arroy_amd import _lib
+    assert _lib.tuning_get("AH_ROWS_XCD") == (1, 1) and _lib.tuning_get("AH_SCREEN8")[1] == -1
+    with _lib.tuning(AH_ROWS_XCD=0, AH_LAUNCH_MAX_ITEMS=1 << 20):
+        assert _lib.tuning_get("AH_ROWS_XCD")[0] == 0 and _lib.tuning_get("AH_LAUNCH_MAX_ITEMS") == (1 << 20, 0xFFFFFFFF)
+    assert _lib.tuning_get("AH_ROWS_XCD")[0] == 1
+    _lib.tuning_set("AH_DENSE", 1)
+    _lib.check(_lib.lib().ah_tuning_reset())
+    assert _lib.tuning_get("AH_DENSE")[0] == -1
+    with pytest.raises(_lib.ArroyHipError):
+        _lib.tuning_set("AH_NO_SUCH_SWITCH", 1)
+    # every tunable the design document lists exists under that name, and the other way round
+    doc = open(os.path.join(ROOT, "DESIGN.md")).read()
+    hdr = open(os.path.join(ROOT, "arroy_amd", "csrc", "common.h")).read()
+    names = re.findall(r'X\(\w+, "(AH_[A-Z0-9_]+)"', hdr)
+    assert len(names) >= 30
+    for name in names:
+        assert _lib.tuning_get(name) is not None
+        assert name in doc, f"{name} is a tunable but DESIGN.md does not mention it"
 
 
 def test_errors_are_codes_not_exceptions_across_the_abi():
@@ -61,6 +91,13 @@ def test_policy_header_matches_between_host_compilers():
     assert y.min() >= -1.0 and y.max() < 1.0
     assert (y == x * 2 - 1).all()
     assert not (O.synth(43, 0, 4, 8) == x).all()
+    # ~N(0,1) as a sum of twelve uniforms (integers: no libm), and its variant with outlier dimensions (dim % 97 == 13)
+    z = O.synth(42, 2, 4000, 100)
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01 and float(abs(z).max()) < 6.0
+    assert (z * 1048576.0 == np.round(z * 1048576.0)).all()  # multiples of 2^-20
+    w = O.synth(42, 3, 4000, 100)
+    assert (w[:, 13] == z[:, 13] * np.float32(20.0)).all() and (np.delete(w, 13, axis=1) == np.delete(z, 13, axis=1)).all()
+    assert O.synth(42, 2, 1, 8).view(np.uint32).tolist() == PINNED_NORMAL_BITS
 
 
 def test_public_headers_are_plain_c99(tmp_path):

@@ -873,7 +873,16 @@ def test_upload_records_with_stored_headers_for_dot_and_bq(metric):
     ds_a, oracle, vecs, ids = make_data(cls, n, dims, seed=33 + metric)  # upload_vectors (+ preprocess for dot)
     records = [b"\x00" + oracle.headers[i].tobytes() + oracle.codec[i].tobytes() for i in range(n)]
     ds_b = Dataset(cls, dims, n)
-    ds_b.upload_records(np.arange(n, dtype=np.uint32), records)
+    if metric == 3:  # records nobody vouched for: the build must refuse them (freshly added items carry {0, 0} headers)
+        ds_c = Dataset(cls, dims, n)
+        ds_c.upload_records(np.arange(n, dtype=np.uint32), records)
+        ds_c.finalize()
+        from arroy_amd import _lib as ahlib
+        with pytest.raises(ahlib.ArroyHipError) as e:
+            ds_c.build_forest([5], split_after=30)
+        assert e.value.status == 8  # AH_ERR_NEED_PREPROCESS
+        ds_c.close()
+    ds_b.upload_records(np.arange(n, dtype=np.uint32), records, preprocessed=True)  # headers of a built database
     ds_b.finalize()
     assert_bit_equal(ds_a.read_headers().ravel(), ds_b.read_headers().ravel())
     assert_bit_equal(ds_a.distances(item=3), ds_b.distances(item=3))

@@ -28,28 +28,66 @@ def gamma_r(dims):
     return F(4.0 * (dims // 32 + 6.0 + 62.0) * 5.9604645e-8)
 
 
-def stage_int8(X, nv, dims):
-    """(screen value, bound) of every row against `nv`, as stage 0 of k_forest_screen_node computes them."""
+TINY = F(2.0 ** -40)  # kTinyBits of forest.hip: rows below it are never decided by a screen
+
+
+def dim_scales(X):
+    """k_col_maxabs + k_dim_scales: one power of two >= the largest |x_i| of every column (1 for empty columns)."""
+    m = np.abs(X).max(axis=0).astype(F)
+    d = np.ones_like(m)
+    ok = (m > 0) & np.isfinite(m)
+    mant, exp = np.frexp(m[ok])              # m = mant 2^exp, mant in [0.5, 1)
+    p = np.where(mant == 0.5, exp - 1, exp)  # a power of two stays itself, anything else rounds up
+    d[ok] = np.where((p >= -63) & (p <= 63), np.ldexp(F(1.0), p), F(1.0)).astype(F)
+    return d
+
+
+def stage_int8(X, nv, dims, bias=None):
+    """(screen value, bound) of every row against `nv`, as stage 0 of k_forest_screen_node computes them: rows scaled per
+    dimension (powers of two) and per row, the normal in two int8 digits; cosine (bias None) in units of the row's scale,
+    Euclidean / Manhattan in real units."""
     pitch8 = (dims + 127) // 128 * 128
-    maxabs = F(np.abs(X).max())
-    scale, inv = F(maxabs / F(127.0)), F(F(127.0) / maxabs)
-    q = np.clip(np.rint(X * inv), -127, 127).astype(np.int32)
-    y = q.astype(F) * scale
-    a8 = norm_up(y, pitch8).max()
-    b8 = (norm_up(X - y, pitch8) + F(127.0) * scale * F(6.0e-8) * np.sqrt(F(pitch8))).max()
-    xmax = norm_up(X, pitch8).max()
-    mn = F(np.abs(nv).max())
+    d = dim_scales(X)
+    Y = (X / d).astype(F)                                   # exact
+    m = np.abs(Y).max(axis=1).astype(F)
+    xm = np.abs(X).max(axis=1).astype(F)
+    ok = (m >= TINY) & (xm >= TINY) & np.isfinite(m) & np.isfinite(xm)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        scale = np.where(ok, m / F(127.0), F(0.0)).astype(F)[:, None]
+        inv = np.where(ok, F(127.0) / m, F(0.0)).astype(F)[:, None]
+    if not ok.any():  # the device keeps no int8 copy of such a dataset (ensure_screen8: max |q| == 0)
+        return np.zeros(len(X), dtype=F), np.full(len(X), F(np.inf), dtype=F)
+    q = np.clip(np.rint(Y * inv), -127, 127).astype(np.int32)
+    z = q.astype(F) * scale
+    with np.errstate(divide="ignore", invalid="ignore"):
+        up = UP(pitch8) * F(1.000001)
+        a8 = (np.sqrt((q.astype(np.int64) ** 2).sum(axis=1)).astype(F) * up)[ok].max()
+        b8 = ((norm_up(Y - z, pitch8) * F(1.000001) + F(127.0) * scale[:, 0] * F(6.0e-8) * np.sqrt(F(pitch8))) / scale[:, 0] * F(1.000001))[ok].max()
+        c8 = (norm_up(X, pitch8) * F(1.000001) / scale[:, 0] * F(1.000001))[ok].max()
+    nd = (nv * d).astype(F)                                 # exact
+    mn = F(np.abs(nd).max())
     sn, invn = F(mn / F(127.0)), F(F(127.0) / mn)
-    qn = np.clip(np.rint(nv * invn), -127, 127).astype(np.int32)
-    yn = qn.astype(F) * sn
-    an, cn = norm_up(yn, pitch8), norm_up(nv, pitch8)
-    bn = norm_up(nv - yn, pitch8) + F(127.0) * sn * F(6.0e-8) * np.sqrt(F(pitch8))
-    s8 = (q @ qn).astype(F) * F(scale * sn)  # exact integer dot, two scale products
-    e = bn * a8 + cn * b8 + F(1.0e-6) * (an * a8) + gamma_r(dims) * (cn * xmax)
-    return s8, F(e * F(1.002) + F(1e-30))
+    t = (nd * invn).astype(F)
+    qh = np.clip(np.rint(t), -127, 127).astype(np.int32)
+    ql = np.clip(np.rint((t - qh.astype(F)) * F(256.0)), -127, 127).astype(np.int32)
+    yn = ((qh.astype(F) + ql.astype(F) * F(0.00390625)) * sn).astype(F)
+    an, cn, cn0 = norm_up(yn, pitch8), norm_up(nd, pitch8), norm_up(nv, pitch8)
+    bn = norm_up(nd - yn, pitch8) + F(128.0) * sn * F(6.0e-8) * np.sqrt(F(pitch8))
+    S = ((q @ qh).astype(F) + (q @ ql).astype(F) * F(0.00390625)) * sn  # exact integer dots, one scale product
+    e = bn * a8 + cn * b8 + F(2.0e-6) * (an * a8) + gamma_r(dims) * (cn0 * c8)
+    if bias is None:
+        return S.astype(F), np.full(len(X), F(e * F(1.002) + F(1e-30)), dtype=F)
+    s_row = np.where(ok, scale[:, 0], F(np.inf)).astype(F)
+    with np.errstate(invalid="ignore", over="ignore"):
+        sd = (S * s_row).astype(F)
+        e = (e * s_row * F(1.000001) + F(1.2e-7) * np.abs(sd)).astype(F)
+        mval = (F(bias) + sd).astype(F)
+        e = (e + F(2.4e-7) * (np.abs(F(bias)) + np.abs(sd) + e)).astype(F)
+        e = (e * F(1.002) + F(1e-30)).astype(F)
+    return mval, e
 
 
-def stage_binary16(X, nv, dims):
+def stage_binary16(X, nv, dims, bias=None):
     hpitch = (dims + 63) // 64 * 64
     def shadow(v):
         h = v.astype(np.float16)
@@ -58,10 +96,18 @@ def stage_binary16(X, nv, dims):
     Xh, nh = shadow(X), shadow(nv)
     ax, bx, cx = norm_up(Xh, hpitch), norm_up(X - Xh, hpitch), norm_up(X, hpitch)
     an, bn, cn = norm_up(nh, hpitch), norm_up(nv - nh, hpitch), norm_up(nv, hpitch)
+    xm = np.abs(X).max(axis=1)
+    tiny = (xm != 0) & (xm < TINY)  # k_shadow_rows: f32 squares of such rows underflow -> stats +inf -> never decided
+    ax, bx, cx = (np.where(tiny, F(np.inf), v).astype(F) for v in (ax, bx, cx))
     gamma_s = F(4.0 * (2.0 * (hpitch // 16) + 8.0) * 5.9604645e-8)
     s = (Xh.astype(np.float64) @ nh.astype(np.float64)).astype(F)  # any accumulation order: covered by gamma_s
-    e = bn * ax + cn * bx + gamma_s * (an * ax) + gamma_r(dims) * (cn * cx)
-    return s, (e * F(1.002) + F(1e-30)).astype(F)
+    with np.errstate(invalid="ignore", over="ignore"):
+        e = (bn * ax + cn * bx + gamma_s * (an * ax) + gamma_r(dims) * (cn * cx)).astype(F)
+        if bias is not None:  # Euclidean / Manhattan: r = fl(bias + fl_ref(dot)), screen_decides
+            e = (e + F(2.4e-7) * (np.abs(F(bias)) + np.abs(s) + e)).astype(F)
+            s = (F(bias) + s).astype(F)
+        e = (e * F(1.002) + F(1e-30)).astype(F)
+    return s, e
 
 
 def cases():
@@ -71,6 +117,10 @@ def cases():
     yield "gaussian-96 x 1e-3", (rng.standard_normal((4000, 96)) * 1e-3).astype(F)
     yield "uniform-200 shifted", (rng.uniform(-1, 1, (4000, 200)) + 5.0).astype(F)
     yield "mixed norms-256", (rng.standard_normal((4000, 256)) * rng.uniform(0.01, 3.0, (4000, 1))).astype(F)
+    out = rng.standard_normal((4000, 768)).astype(F)
+    out[:, 13::97] *= F(20.0)  # a few outlier dimensions x 20 (AH_SYNTH_NORMAL_OUTLIERS)
+    yield "gaussian-768 with outlier dimensions", out
+    yield "irwin-hall-768 (AH_SYNTH_NORMAL)", O.synth(42, 2, 4000, 768)
 
 
 @pytest.mark.parametrize("name,X", list(cases()), ids=[c[0] for c in cases()])
@@ -94,8 +144,40 @@ def test_a_decided_pair_never_has_the_wrong_sign(name, X):
                 decided16 += int(dec.sum())
         total += len(X)
     if name.startswith("uniform-768"):
-        assert decided8 > 0.70 * total, decided8 / total    # 76 % decided by the int8 stage
+        assert decided8 > 0.85 * total, decided8 / total    # ~90 % decided by the int8 stage
         assert decided16 > 0.985 * total, decided16 / total  # §2.2: ~1 % fall back to f32
+    if name.startswith(("gaussian-768", "irwin-hall-768")):
+        # one scale per row (+ one power of two per dimension): Gaussian rows and outlier dimensions quantise as well as
+        # uniform rows (round 2, one scale per dataset: the copy was dropped for N(0,1) data)
+        assert decided8 > 0.70 * total, (name, decided8 / total)  # measured: 0.77 gaussian, 0.73 with outlier dimensions, 0.81 Irwin-Hall
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-6, 7e-24, 3e-31, 1e20])
+def test_euclidean_bias_never_decides_alone(scale):
+    """Round-2 advisor finding: with rows at 1e-23 the f32 sums of squares behind the measured norms underflow, the bound
+    collapsed to 0 and sign(bias) alone decided Euclidean margins — wrongly for half the pairs.  Rows below 2^-40 now carry
+    +inf stats (binary16 stage) / an infinite scale (int8 stage) and are never decided; everything else stays sound."""
+    rng = np.random.default_rng(5)
+    dims, n = 96, 4000
+    X = (rng.standard_normal((n, dims)) * scale).astype(F)
+    data = O.Data(O.EUCLIDEAN, X)
+    wrong = decided = 0
+    for _ in range(6):
+        nv, nh = data.create_split(rng.choice(n, 12, replace=False).astype(np.uint32))
+        nv = np.asarray(nv, dtype=F)[:dims]
+        bias = F(np.asarray(nh, dtype=F).ravel()[0])
+        _sides, _n_left, r = data.split_sides(nv, nh)  # reference: fl(bias + dot), AVX order
+        for stage in (stage_int8, stage_binary16):
+            m, e = stage(X, nv, dims, bias=bias)
+            with np.errstate(invalid="ignore"):
+                dec = np.abs(m) > e
+            wrong += int((np.signbit(m[dec]) != np.signbit(r[dec])).sum())
+            decided += int(dec.sum())
+    assert wrong == 0, (scale, wrong, decided)
+    if scale < 1e-12:
+        assert decided == 0  # tiny rows take the reference arithmetic
+    if scale == 1.0:
+        assert decided > 0.5 * 12 * n
 
 
 def _rtz32(x64):
