@@ -2450,8 +2450,10 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             // costs in ns, for rows of this dataset's size: node-major = one HBM read of the row per (item, tree) pair
             // (0.47 ns per 3072-byte row at 6.7 TB/s; the screen reads half the bytes)
             const double scale = screen ? (double)ds->hpitch * 2 / 1536.0 : (double)ds->row_bytes() / 3072.0;
-            // (0.20 with the int8 first stage: 768 + 0.24 x 1600 bytes per pair on data that quantises like the benchmark's)
-            const double node_ns = screen ? (screen8 && ds->metric != AH_DOT_PRODUCT ? 0.20 : 0.24) : 0.47;
+            // (0.17 with the int8 first stage: 768 + ~0.1 x 1600 bytes per pair on data that quantises like the benchmark's;
+            // worse data decide less there: scaled by the quality figure ensure_screen8 measured, 0.12 for uniform rows)
+            const double node8_ns = std::min(0.24, 0.155 + 0.125 * ds->screen8_quality);
+            const double node_ns = screen ? (screen8 && ds->metric != AH_DOT_PRODUCT ? node8_ns : 0.24) : 0.47;
             const double active = (double)info.pairs / ((double)n_trees * (double)N);
             const double cost_node = (double)info.pairs * node_ns * scale;
             const double convert = (double)n_trees * (double)N *

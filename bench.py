@@ -23,7 +23,12 @@ in HBM by the counter-based generator of include/arroy_hip_policy.h (seed 42), i
     both with the certified binary16 screen (default) and, for build_10m, also in f32 arithmetic only.
   * rerank / bq_scan / search: BASELINE configs[3], configs[4] and the on-device search, on device 0.
   * cpu_baseline (N=1 only): the C oracle (a restatement of arroy's AVX2+FMA path, NOT arroy) on the host cores: the
-    full 1M-row scan and the full configs[1] build (50 trees over 1M x 768), unless --cpu-seconds bounds it.
+    full 1M-row scan and the full configs[1] build (50 trees over 1M x 768), unless --cpu-seconds bounds it; and for
+    configs[2] 8 (or one per core) of the 100 trees over all 10M rows, scaled to 100.
+  * build_10m also carries: `identical` (content digest of the screened forest == that of the f32-only forest, computed
+    in this run; a mismatch makes bench.py exit 5), `cold` (staging from host memory + the first build of the dataset,
+    which makes the binary16 / int8 copies), `normal` (the same build on ~N(0,1) rows), `share_13` (the 13-tree share one
+    GPU of eight would build, on this GPU).
 One JSON line on stdout.  `--dry-run` exercises both N>1 control paths on CPU (gloo ranks / host threads).
 """
 import argparse
@@ -58,6 +63,9 @@ def parse_args():
                     help="skip the 10M x 768 x 100-tree build (BASELINE configs[2], the 'tree-build seconds at 10M' of the metric)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--no-extra", action="store_true", help="skip configs[3] / configs[4] / on-device search")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="build_10m from rows generated in HBM instead of 10M x 768 rows staged from host memory (skips the "
+                         "cold end-to-end figures and the configs[2] CPU baseline, which share the host copy)")
     ap.add_argument("--cpu-seconds", type=float, default=45.0, help="budget of the CPU baseline (bounds the build sample)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: test the N>1 control paths on CPU")
     ap.add_argument("--extra", default="", help="comma list of further measurements: metrics (every f32 metric), staging, "
@@ -69,11 +77,7 @@ def parse_args():
 
 def scan_source_hash():
     """sha256 over the sources of the scan kernel: the PMC traffic figure is only quoted while it matches."""
-    h = hashlib.sha256()
-    for rel in SCAN_KERNEL_SOURCES:
-        with open(os.path.join(ROOT, rel), "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()[:16]
+    return source_hash("scan")
 
 
 def usable_cpus():
@@ -164,20 +168,38 @@ def cpu_baseline(args, n_items):
     return res
 
 
-def measured_traffic(n_items):
-    """HBM bytes per scan launch from the committed rocprofv3 --pmc passes (profiles/rNN_pmc_scan.json, written by
-    scripts/collect_profiles.sh from separate FETCH_SIZE / WRITE_SIZE runs; gfx950 correction per MI355X_MICROARCH.md:
-    FETCH_SIZE counts half of a 16 B/lane coalesced read stream).  The file carries the hash of the kernel sources it was
-    measured on; a mismatch means the number is stale and is not quoted."""
+KERNEL_SOURCES = {
+    # kernel of a roofline entry -> the sources its PMC figure is stamped with
+    "scan": SCAN_KERNEL_SOURCES,
+    "rerank": ["arroy_amd/csrc/batch.hip", "arroy_amd/csrc/device_math.h", "arroy_amd/csrc/common.h"],
+    "bq_scan": SCAN_KERNEL_SOURCES,
+}
+
+
+def source_hash(which):
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES[which]:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(n_items, which="scan"):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/rNN_pmc_kernels.json, written
+    by scripts/collect_profiles.sh from separate FETCH_SIZE / WRITE_SIZE runs; gfx950 correction per MI355X_MICROARCH.md:
+    FETCH_SIZE counts half of a 16 B/lane coalesced read stream).  Every entry carries the hash of the kernel sources it
+    was measured on; a mismatch means the number is stale and is not quoted."""
     import glob
     if n_items != N_ITEMS:
         return None, "not measured for this size"
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_scan.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_kernels.json")))
     if not files:
-        return None, "no profiles/r*_pmc_scan.json"
-    j = json.load(open(files[-1]))
-    if j.get("source_sha16") != scan_source_hash():
-        return None, f"{os.path.basename(files[-1])} was measured on other kernel sources (stale): re-run scripts/collect_profiles.sh"
+        return None, "no profiles/r*_pmc_kernels.json"
+    j = json.load(open(files[-1])).get(which)
+    if not j:
+        return None, f"{os.path.basename(files[-1])} has no entry for {which}"
+    if j.get("source_sha16") != source_hash(which):
+        return None, f"{os.path.basename(files[-1])}:{which} was measured on other kernel sources (stale): re-run scripts/collect_profiles.sh"
     return float(j["hbm_bytes_per_launch"]), os.path.basename(files[-1])
 
 
@@ -197,7 +219,16 @@ def extra_c5(device):
         out[dist.name] = {"distances_per_s": rate, "bytes_per_distance": per, "gb_per_s": rate * per / 1e9,
                           "frac_of_hbm_peak": rate * per / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms / iters}
         ds.close()
-    return {"workload": "5M x 768 1-bit vectors, Q=1 scan", "metrics": out}
+    # roofline entry of the dominant kernel (BQ-cosine instantiation): algorithmic bytes per launch next to the PMC traffic
+    # (one kernel serves the three 1-bit metrics: means over them, as the PMC summary averages its dispatches)
+    traffic, src = measured_traffic(N_ITEMS, "bq_scan")
+    gbs = sum(v["gb_per_s"] for v in out.values()) / len(out)
+    roof = {"bound": "hbm", "kernel": "ah::k_distances_bq<false> (Q=1 scan of 5M rows, mean over the three 1-bit metrics)",
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "kernel_ms": sum(v["kernel_ms"] for v in out.values()) / len(out),
+            "algorithmic_bytes_per_launch": n * sum(v["bytes_per_distance"] for v in out.values()) / len(out),
+            "traffic": traffic, "traffic_source": src, "kernel_source_sha16": source_hash("bq_scan")}
+    return {"workload": "5M x 768 1-bit vectors, Q=1 scan", "metrics": out, "roofline": roof}
 
 
 def extra_metrics(device):
@@ -272,6 +303,16 @@ def extra_c4(device):
     el = _timed_callers(lambda a: ds.rerank_batch(a[0], a[1], k), [flat(0, nq)], 1)
     out["one_submission"] = {"queries_per_s": nq / el, "candidates_per_s": total / el,
                              "effective_gb_per_s": total / el * per / 1e9, "seconds": el}
+    # roofline entry of the gather kernel of the 125-query submissions: its algorithmic bytes per launch (mean over the
+    # eight submissions) next to the PMC traffic; `achieved` is the END-TO-END rate of one caller (host in/out, top-k
+    # rounds included), i.e. a lower bound of the kernel's own rate (rocprofv3 average in profiles/)
+    traffic, src = measured_traffic(N_ITEMS, "rerank")
+    one = out["callers_1"]
+    out["roofline"] = {"bound": "hbm", "kernel": "ah::k_batch_distances_f32<3> (DotProduct gather, 125-query submissions)",
+                       "achieved": one["gb_per_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": one["frac_of_hbm_peak"],
+                       "achieved_is": "end to end from one caller, host in/out and top-k included",
+                       "algorithmic_bytes_per_launch": total / len(batches) * per, "traffic": traffic, "traffic_source": src,
+                       "kernel_source_sha16": source_hash("rerank")}
     ds.close()
     return out
 
@@ -512,54 +553,191 @@ def device_work(args, rank, world, device, sync, ds_1m, result):
         result["extra"] = extra
 
 
+def host_rows_10m(n):
+    """n x 768 uniform[-1,1) rows in host memory (the generator of arroy_hip_policy.h through the oracle library: only a
+    data source here), or None when the host cannot hold them next to the CPU baseline's working set."""
+    import numpy as np
+
+    from oracle import oracle as O
+    need = n * DIMS * 4
+    try:
+        avail = next(int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable"))
+    except (OSError, StopIteration):
+        avail = 0
+    if avail < need * 1.6:
+        return None, f"host has {avail / 1e9:.0f} GB available, {need * 1.6 / 1e9:.0f} GB wanted"
+    try:
+        vecs = np.empty((n, DIMS), dtype=np.float32)
+    except MemoryError:
+        return None, "host allocation failed"
+    L = O.lib()
+    chunk = 1_000_000
+    for lo in range(0, n, chunk):
+        part = vecs[lo:lo + chunk]
+        L.ao_synth_fill(SEED, 1, lo, len(part), DIMS, part.ctypes.data)
+    return vecs, None
+
+
+def timed_builds(ds, seeds, mode, reps, rank, sync):
+    """`reps` builds of `seeds` (barrier + max over ranks each); returns (per-rank seconds, max-over-ranks seconds,
+    stats, digest) of the last one."""
+    samples, owns, st, dig = [], [], {}, None
+    for _rep in range(reps):
+        sync.barrier(rank)
+        t0 = time.perf_counter()
+        forest = ds.build_forest(seeds, margin_mode=mode) if seeds else None
+        owns.append(time.perf_counter() - t0)
+        sync.barrier(rank)
+        samples.append(sync.max(time.perf_counter() - t0, rank))
+        if forest is not None:
+            st = forest.stats
+            if _rep == reps - 1:
+                dig = forest.digest()[0]
+            forest.close()
+    return owns, samples, st, dig
+
+
+def build_entry(samples, st):
+    ms = st.get("seconds_margin", 0.0)
+    met8 = st.get("screen8_pairs", 0)
+    return {"seconds": sorted(samples)[len(samples) // 2], "seconds_samples": samples,
+            "seconds_library": st.get("seconds_total"), "seconds_device": st.get("seconds_device"),
+            "seconds_margin_kernel": ms, "margin_evaluations": st.get("margin_evaluations"),
+            "levels": st.get("levels"), "split_nodes": st.get("split_nodes"),
+            "margin_effective_gb_per_s": st.get("margin_evaluations", 0) * 4 * DIMS / ms / 1e9 if ms else None,
+            "margin_row_major_passes": st.get("margin_row_passes"),
+            "screen_fallbacks": st.get("screen_fallbacks"), "margin_mode_launches": st.get("margin_mode_launches"),
+            "dense_mfma_levels": st.get("dense_launches"), "dense_mfma_columns": st.get("dense_columns"),
+            # schedule variants of the row-major pass (launches): one XCD per tree group / non-temporal rows / extra launches
+            "rows_xcd_launches": st.get("rows_xcd_launches"), "rows_nt_launches": st.get("rows_nt_launches"),
+            "rows_split_launches": st.get("rows_split_launches"),
+            # int8 first stage of the node-major levels: pairs it met, share it decided
+            "screen8_pairs": met8, "screen8_decided_frac": st.get("screen8_decided", 0) / met8 if met8 else None,
+            "screen_unavailable": st.get("screen_unavailable")}
+
+
 def build_10m(args, rank, world, device, sync, ds, result):
     """BASELINE configs[2]: 10M x 768 cosine, n_trees = 100, this device's share of the trees (all 100 at N = 1).
-    Timed twice: default (certified binary16 screen) and f32 arithmetic only (AH_MARGIN_EXACT_ONLY)."""
+    Timed in both arithmetics — default (certified screens) and f32 only (AH_MARGIN_EXACT_ONLY) — and the two forests are
+    COMPARED in the run (content digest).  At N = 1 the rows are staged from host memory first, so that the cold
+    end-to-end time (staging + first build, which makes the shadow copies) is part of the line, and the same host copy
+    feeds the configs[2] CPU baseline."""
+    import numpy as np
+
     from arroy_amd import Dataset, distances, shard
     from arroy_amd import _lib as ahlib
     n = 10_000_000
-    if ds is None:
-        ds = Dataset(distances.Cosine, DIMS, n, device=device)
-        ds.fill_synthetic(SEED, 1, n)
-        ds.finalize()
     trees = shard.trees_for_rank(100, rank, world)
     seeds = shard.tree_seeds(SEED, trees)
-    out = {}
-    for key, mode, reps in (("screened", 0, 3), ("f32_only", ahlib.MARGIN_EXACT_ONLY, 1)):
-        if key == "screened" and seeds:
-            ds.build_forest(seeds[:1], margin_mode=mode).close()  # warm-up (shadow copy of the rows, buffers)
-        samples, owns, st = [], [], {}
-        for _rep in range(reps):
-            sync.barrier(rank)
+    out, cold, host_vecs = {}, None, None
+    if ds is None:
+        ds = Dataset(distances.Cosine, DIMS, n, device=device)
+        why = "--no-e2e" if args.no_e2e else ("one host copy per rank would not fit" if world > 1 else None)
+        if why is None:
+            host_vecs, why = host_rows_10m(n)
+        if host_vecs is not None:
+            chunk = 1_000_000
             t0 = time.perf_counter()
-            forest = ds.build_forest(seeds, margin_mode=mode) if seeds else None
-            owns.append(time.perf_counter() - t0)
-            sync.barrier(rank)
-            samples.append(sync.max(time.perf_counter() - t0, rank))
-            if forest is not None:
-                st = forest.stats
-                forest.close()
+            for lo in range(0, n, chunk):
+                ds.upload_vectors(np.arange(lo, min(n, lo + chunk), dtype=np.uint32), host_vecs[lo:lo + chunk])
+            t1 = time.perf_counter()
+            ds.finalize()
+            t2 = time.perf_counter()
+            f = ds.build_forest(seeds)  # the first build of the dataset: binary16 + int8 copies, buffers, pinned ring
+            t3 = time.perf_counter()
+            cold = {"workload": f"{n}x{DIMS} cosine staged from pageable host memory (ten 1M-row ah_dataset_upload_vectors calls), "
+                                f"then the first {len(seeds)}-tree build of the dataset (it makes the binary16 / int8 copies)",
+                    "staging_s": t2 - t0, "staging_calls_s": t1 - t0, "staging_gb_per_s": n * DIMS * 4 / (t2 - t0) / 1e9,
+                    "first_build_s": t3 - t2, "total_s": t3 - t0, "first_build_library_s": f.stats["seconds_total"]}
+            f.close()
+        else:
+            ds.fill_synthetic(SEED, 1, n)
+            ds.finalize()
+            cold = {"skipped": why}
+    if cold is None or "skipped" in cold:
+        if seeds:
+            ds.build_forest(seeds[:1]).close()  # warm-up (shadow copies of the rows, buffers)
+    digests = {}
+    for key, mode, reps in (("screened", 0, 3), ("f32_only", ahlib.MARGIN_EXACT_ONLY, 1)):
+        owns, samples, st, digests[key] = timed_builds(ds, seeds, mode, reps, rank, sync)
         if rank == 0:
-            ms = st.get("seconds_margin", 0.0)
-            out[key] = {"seconds": sorted(samples)[len(samples) // 2], "seconds_samples": samples,
-                        "seconds_library": st.get("seconds_total"), "seconds_device": st.get("seconds_device"),
-                        "seconds_margin_kernel": ms, "margin_evaluations": st.get("margin_evaluations"),
-                        "levels": st.get("levels"), "split_nodes": st.get("split_nodes"),
-                        "margin_effective_gb_per_s": st.get("margin_evaluations", 0) * 4 * DIMS / ms / 1e9 if ms else None,
-                        "margin_row_major_passes": st.get("margin_row_passes"),
-                        "screen_fallbacks": st.get("screen_fallbacks"), "margin_mode_launches": st.get("margin_mode_launches"),
-                        "dense_mfma_levels": st.get("dense_launches"), "dense_mfma_columns": st.get("dense_columns")}
+            out[key] = build_entry(samples, st)
         result.setdefault("build_10m_seconds_per_device", {}).setdefault(key, {})[rank] = sorted(owns)[len(owns) // 2]
+    identical = digests["screened"] == digests["f32_only"]
+    result.setdefault("build_10m_identical_per_device", {})[rank] = bool(identical)
+    share = None
+    if world == 1 and rank == 0:
+        # the 13 trees GPU 0 of an 8-GPU node builds (t = 0 mod 8), on this GPU: the one-GPU proxy of the 8-GPU build time
+        s13 = shard.tree_seeds(SEED, shard.trees_for_rank(100, 0, 8))
+        _o, samples13, st13, _d = timed_builds(ds, s13, 0, 3, rank, sync)
+        share = build_entry(samples13, st13)
+        share["trees"] = len(s13)
+        share["speedup_100_trees_over_share"] = out["screened"]["seconds"] / share["seconds"]
     ds.close()
+    normal = None
+    if world == 1 and rank == 0:
+        # the same build on ~N(0,1) rows (SURVEY.md 8(d), BASELINE.md 3): long-tailed data is what the quantised copies of
+        # the screen have to survive; both arithmetics again, compared by digest
+        dn = Dataset(distances.Cosine, DIMS, n, device=device)
+        dn.fill_synthetic(SEED, 2, n)
+        dn.finalize()
+        dn.build_forest(seeds[:1]).close()
+        _o, sn, stn, dig_n = timed_builds(dn, seeds, 0, 3, rank, sync)
+        _o, sx, stx, dig_x = timed_builds(dn, seeds, ahlib.MARGIN_EXACT_ONLY, 1, rank, sync)
+        normal = build_entry(sn, stn)
+        normal["data"] = "synthetic ~N(0,1) (sum of twelve uniforms, arroy_hip_policy.h AH_SYNTH_NORMAL), seed 42"
+        normal["f32_only_seconds"] = sx[0]
+        normal["identical"] = bool(dig_n == dig_x)
+        normal["digest"] = f"{dig_n:016x}"
+        result.setdefault("build_10m_identical_per_device", {})["normal"] = normal["identical"]
+        dn.close()
     if rank == 0:
         res = dict(out["screened"])
         res["workload"] = f"{n}x{DIMS} cosine, n_trees=100, trees on device 0: {len(trees)} (t = device mod {world})"
         res["arithmetic"] = ("certified screens (int8 first on the node-major levels, binary16 — as one MFMA product on the top "
                              "levels — second) decide the side of a margin when |screen| > proven error bound, f32 reference "
-                             "arithmetic for the rest (screen_fallbacks pairs); forest bit-identical to f32_only")
+                             "arithmetic for the rest (screen_fallbacks pairs); `identical` = the content digest of this "
+                             "forest equals that of the f32_only build, compared in this run")
+        res["identical"] = bool(identical)
+        res["digest"] = f"{digests['screened']:016x}"
+        res["digest_f32_only"] = f"{digests['f32_only']:016x}"
         res["f32_only"] = out["f32_only"]
+        res["cold"] = cold
+        if share is not None:
+            res["share_13"] = share
+        if normal is not None:
+            res["normal"] = normal
         res["scaling"] = "strong"
         result["build_10m"] = res
+        if host_vecs is not None and not args.no_cpu:
+            result["cpu_10m"] = cpu_baseline_10m(args, host_vecs, result.get("cpu"))
+
+
+def cpu_baseline_10m(args, vecs, cpu_1m):
+    """configs[2] on the host cores: 8 of the 100 trees over all 10M rows — one tree per core when
+    the --cpu-seconds budget allows (estimated from the configs[1] margin rate) — scaled to 100 trees, and said so."""
+    import ctypes as C
+
+    import numpy as np
+
+    from oracle import oracle as O
+    L = O.lib()
+    cores, _host = usable_cpus()
+    L.ao_set_num_threads(cores)
+    n = len(vecs)
+    data = O.Data(O.COSINE, vecs)
+    rate = (cpu_1m or {}).get("build_margins_per_s") or 60e6
+    per_tree = n * 14.05 / rate  # seconds per tree with all cores busy (14.05 margin evaluations per row and tree: GPU side)
+    k = min(100, cores) if cores >= 8 and cores * per_tree <= args.cpu_seconds else 8
+    seeds = np.arange(1, k + 1, dtype=np.uint64)
+    t0 = time.perf_counter()
+    evals = L.ao_build_forest_count(data.c(), 0, seeds.ctypes.data_as(C.c_void_p), k)
+    el = time.perf_counter() - t0
+    return {"build_seconds_config_2": el * 100.0 / k, "build_seconds_measured": el, "build_trees_measured": k,
+            "build_margins_per_s": evals / el, "cores": cores, "kind": "port",
+            "sample": f"{k} of the 100 trees of configs[2], each over all {n}x{DIMS} rows (data in RAM), OpenMP on {cores} threads "
+                      f"({'one tree per thread' if k >= cores else 'trees one after the other, margin loops parallel'}): "
+                      f"{el:.1f} s, scaled by 100/{k}; C restatement of arroy's path (not arroy)"}
 
 
 def dry_run_work(args, rank, world, sync, result):
@@ -677,6 +855,11 @@ def main():
                 per.setdefault(k, {}).update(v)
         if per:
             result["build_10m_seconds_per_device"] = per
+        same = {}
+        for r in results:
+            same.update(r.get("build_10m_identical_per_device", {}))
+        if same:
+            result["build_10m_identical_per_device"] = same
         n_used = world
 
     if rank == 0:
@@ -703,11 +886,12 @@ def main():
                          "measured_d2d_copy_gb_per_s": result.get("copy_gbs"), "measured_read_only_gb_per_s": read_gbs,
                          "frac_of_measured_read_ceiling": achieved / read_gbs if read_gbs else None,
                          "algorithmic_bytes_per_launch": n * BYTES_PER_DISTANCE},
-            "cpu_baseline": result.get("cpu"),
+            "cpu_baseline": dict(result["cpu"], build_10m=result.get("cpu_10m")) if result.get("cpu") else None,
             "build": result.get("build"),
             "build_10m": result.get("build_10m"),
         }
-        for key in ("build_seconds_per_device", "build_10m_seconds_per_device", "replicate_1m", "replicate_10m"):
+        for key in ("build_seconds_per_device", "build_10m_seconds_per_device", "build_10m_identical_per_device", "replicate_1m",
+                    "replicate_10m"):
             if result.get(key):
                 line[key] = result[key]
         extra = result.get("extra") or {}
@@ -717,6 +901,11 @@ def main():
         if extra:
             line["extra"] = extra
         print(json.dumps(line), flush=True)
+    # a screened forest that differs from the f32-only forest is a wrong result, not a slow one
+    same = result.get("build_10m_identical_per_device") or {}
+    if same and not all(same.values()):
+        print(f"bench.py: screened and f32-only forests differ: {same}", file=sys.stderr)
+        sys.exit(5)
 
 
 if __name__ == "__main__":

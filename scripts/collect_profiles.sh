@@ -1,21 +1,21 @@
 #!/bin/bash
-# Run on the GPU box (gpurun -- bash scripts/collect_profiles.sh r02): the judged bench line, its rocprofv3 kernel summary,
-# the PMC passes of the scan kernel (FETCH_SIZE / WRITE_SIZE, each in its own run, no trace domain besides the kernel trace)
+# Run on the GPU box (gpurun -- bash scripts/collect_profiles.sh r03): the judged bench line, its rocprofv3 kernel summary,
+# the PMC passes of the scan / re-rank / 1-bit scan kernels (FETCH_SIZE / WRITE_SIZE, each in its own run, no trace domain besides the kernel trace)
 # and the per-level breakdown of the 10M build.  Everything lands in gpurun_out/profiles/ and is copied into profiles/ by
-# hand afterwards (scripts/pmc_scan_json.py writes the traffic file bench.py reads, stamped with the kernel-source hash).
+# hand afterwards (scripts/pmc_kernels_json.py writes the traffic file bench.py reads, every entry stamped with its kernel-source hash).
 set -u
-R=${1:-r02}
+R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles
 mkdir -p $OUT
 python bench.py --steps 50 --warmup 5 2>$OUT/${R}_bench.err | tail -1 > $OUT/${R}_bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python bench.py --steps 50 --warmup 5 --no-cpu --no-build-10m > $OUT/kt.log 2>&1
 cp $OUT/kt/kt_kernel_stats.csv $OUT/${R}_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python bench.py --steps 5 --warmup 1 --no-cpu --no-build --no-extra > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python bench.py --steps 5 --warmup 1 --no-cpu --no-build --no-extra > $OUT/write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- env AH_BENCH_SEARCH_QUERIES=64 python bench.py --steps 5 --warmup 1 --no-cpu --no-build > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- env AH_BENCH_SEARCH_QUERIES=64 python bench.py --steps 5 --warmup 1 --no-cpu --no-build > $OUT/write.log 2>&1
 python scripts/pmc_summary.py $OUT/fetch/fetch_counter_collection.csv | grep -v "^[0-9]" > $OUT/${R}_pmc_fetch_size.csv
 python scripts/pmc_summary.py $OUT/write/write_counter_collection.csv | grep -v "^[0-9]" > $OUT/${R}_pmc_write_size.csv
-python scripts/pmc_scan_json.py $OUT/${R}_pmc_fetch_size.csv $OUT/${R}_pmc_write_size.csv > $OUT/${R}_pmc_scan.json
+python scripts/pmc_kernels_json.py $OUT/${R}_pmc_fetch_size.csv $OUT/${R}_pmc_write_size.csv > $OUT/${R}_pmc_kernels.json
 # per-level breakdown of the 10M x 768 x 100-tree build: default (screened) and f32 only
 for mode in screened f32; do
   if [ $mode = f32 ]; then export AH_SCREEN=0; else unset AH_SCREEN; fi

@@ -12,10 +12,12 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 trees = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 dims = int(sys.argv[4]) if len(sys.argv) > 4 else 768
+dist = int(sys.argv[5]) if len(sys.argv) > 5 else 1  # ah_synth_distribution: 1 uniform[-1,1), 2 ~N(0,1), 3 with outlier dimensions
 ds = Dataset(distances.Cosine, dims, n)
-ds.fill_synthetic(42, 1, n)
+ds.fill_synthetic(42, dist, n)
 ds.finalize()
-seeds = shard.tree_seeds(42, range(trees))
+# 13 trees = the share GPU 0 of an 8-GPU node builds of a 100-tree forest (t = 0 mod 8); otherwise trees 0..T-1
+seeds = shard.tree_seeds(42, shard.trees_for_rank(100, 0, 8)) if trees == 13 else shard.tree_seeds(42, range(trees))
 for r in range(reps):
     t0 = time.perf_counter()
     f = ds.build_forest(seeds)

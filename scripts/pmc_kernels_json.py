@@ -1,0 +1,42 @@
+"""profiles/rNN_pmc_kernels.json from the FETCH_SIZE / WRITE_SIZE summaries (scripts/pmc_summary.py output) of the kernels
+whose roofline entries bench.py prints: the Q=1 cosine scan, the DotProduct gather of the batched re-rank, the 1-bit scan.
+
+gfx950 correction per MI355X_MICROARCH.md (HBM section): FETCH_SIZE (KiB) reports half of a 16 B/lane coalesced read
+stream, WRITE_SIZE (KiB) is not halved.  Every entry is stamped with the hash of the kernel sources it was measured on;
+bench.py quotes a `traffic` figure only while that hash matches."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+KERNELS = {"scan": "k_distances_f32<2, false>", "rerank": "k_batch_distances_f32<3>", "bq_scan": "k_distances_bq<false>"}
+
+
+def mean_of(path, needle, counter):
+    for line in open(path):
+        f = line.strip().split(",")
+        # kernel names contain commas ("k_distances_f32<2, false>"): the last four fields are counter, n, mean, sum
+        if len(f) >= 5 and needle in line and f[-4] == counter:
+            return float(f[-2]), int(f[-3])
+    return None, 0
+
+
+out = {}
+for key, needle in KERNELS.items():
+    fetch, n_f = mean_of(sys.argv[1], needle, "FETCH_SIZE")
+    write, n_w = mean_of(sys.argv[2], needle, "WRITE_SIZE")
+    if fetch is None or write is None:
+        print(f"{needle}: not found in the PMC summaries", file=sys.stderr)
+        continue
+    out[key] = {
+        "kernel": "ah::" + needle, "dispatches_fetch": n_f, "dispatches_write": n_w,
+        "fetch_size_kib_per_launch": fetch, "write_size_kib_per_launch": write,
+        "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
+        "source_sha16": bench.source_hash(key), "sources": bench.KERNEL_SOURCES[key],
+    }
+out["correction"] = ("reads = FETCH_SIZE x 1024 x 2 (gfx950: the counter tallies 128-byte requests at 64 bytes), writes = "
+                     "WRITE_SIZE x 1024; mean over the dispatches of the profiled `python bench.py --steps 5 --warmup 1 "
+                     "--no-cpu --no-build` run")
+print(json.dumps(out, indent=1))
