@@ -81,6 +81,7 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
     X(LAUNCH_MAX_ITEMS, "AH_LAUNCH_MAX_ITEMS", 0xFFFFFFFFll) /* work-items one row-major launch may carry */             \
     X(SCREEN, "AH_SCREEN", 1)                   /* 0: reference f32 arithmetic only (as AH_MARGIN_EXACT_ONLY) */          \
     X(SCREEN_VERIFY, "AH_SCREEN_VERIFY", 0)     /* 1: screened kernels evaluate f32 for EVERY pair, count violations */  \
+    X(NODE_PREFETCH, "AH_NODE_PREFETCH", 1)     /* 0: no software pipeline in the int8 stage of the node-major screen */    \
     X(SCREEN8, "AH_SCREEN8", -1)                /* 0: no int8 first stage; 1: keep it whatever the data; -1: by quality */ \
     X(DENSE, "AH_DENSE", -1)                    /* 0: never the dense MFMA screen; 1: whenever legal; -1: cost model */    \
     X(DENSE_MAX_COLS, "AH_DENSE_MAX_COLS", 16384)                                                                        \

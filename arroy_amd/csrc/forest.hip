@@ -927,6 +927,23 @@ __device__ __forceinline__ float screen8_octet_dot(const uint4 *hi4, const uint4
     }
     return octet_sum((float)(h0 + h1) + (float)(l0 + l1) * 0.00390625f);
 }
+// the same with the row's chunks already in registers (PRE of them; chunk u exists when u < steps)
+template <int PRE>
+__device__ __forceinline__ float screen8_octet_dot_regs(const uint4 *hi4, const uint4 *lo4, const uint4 (&x)[PRE], uint32_t steps) {
+    int h0 = 0, h1 = 0, l0 = 0, l1 = 0;
+#pragma unroll
+    for (int u = 0; u < PRE; u += 2) {
+        if ((uint32_t)u < steps) {
+            h0 = dot16_i8(hi4[u * 8], x[u], h0);
+            l0 = dot16_i8(lo4[u * 8], x[u], l0);
+        }
+        if ((uint32_t)(u + 1) < steps) {
+            h1 = dot16_i8(hi4[(u + 1) * 8], x[u + 1], h1);
+            l1 = dot16_i8(lo4[(u + 1) * 8], x[u + 1], l1);
+        }
+    }
+    return octet_sum((float)(h0 + h1) + (float)(l0 + l1) * 0.00390625f);
+}
 // the decision of the int8 stage.  S = s_n x (the digits' dot products), i.e. the screen value in units of the row's scale;
 // max8 = dataset-wide {|q|, |y / s_r - q|, |x| / s_r}; s_row = the row's scale (Euclidean / Manhattan; unused for Cosine).
 template <int METRIC>
@@ -1016,7 +1033,10 @@ __device__ __forceinline__ float screen_octet_dot(const uint4 *a4, const uint4 *
 
 // Node-major margin pass with the screen: as k_forest_margin_f32, but an item costs 2*dims bytes of HBM unless the
 // screen cannot decide its side (then the reference arithmetic runs for that item, from the f32 normal kept in LDS).
-template <int METRIC>
+// PRE > 0 (int8 rows of at most PRE 128-byte steps): the int8 chunks of the NEXT item of an octet are requested before the
+// current item is evaluated, and its row index one item earlier still — an item otherwise costs two dependent memory round
+// trips (perm -> row) with nothing else in flight on the octet.
+template <int METRIC, int PRE>
 __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, ScreenView sv, FNode *nodes,
                                                                const FTile *__restrict__ tiles, uint32_t n_tiles,
                                                                const uint32_t *__restrict__ perm,
@@ -1067,16 +1087,47 @@ __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, Scre
         const uint32_t *pp = perm + nd->start + tl.first;
         uint64_t mask = 0;
         uint32_t lefts = 0;
+        // software pipeline of the int8 stage (PRE > 0): row index two items ahead, row chunks one item ahead
+        constexpr int NPRE = PRE > 0 ? PRE : 1;
+        uint4 xn[NPRE];
+        uint32_t row_n = 0, row_nn = 0;
+        if (PRE > 0 && stage8) {
+            if (o < in_tile) row_n = pp[o];
+            if (o + 32 < in_tile) row_nn = pp[o + 32];
+            if (o < in_tile) {
+                const uint4 *r8 = reinterpret_cast<const uint4 *>(sv.rows8 + (uint64_t)row_n * sv.pitch8) + j;
+#pragma unroll
+                for (int u = 0; u < NPRE; u++)
+                    if ((uint32_t)u < steps8) xn[u] = ld_stream_u4(r8 + u * 8);
+            }
+        }
         for (uint32_t i = 0; i < 64; i++) {
             const uint32_t p = o + 32 * i;
             if (p >= in_tile) break;
-            const uint64_t row = pp[p];
+            uint64_t row;
+            uint4 x[NPRE];
+            if (PRE > 0 && stage8) {
+                row = row_n;
+#pragma unroll
+                for (int u = 0; u < NPRE; u++) x[u] = xn[u];
+                row_n = row_nn;
+                if (p + 64 < in_tile) row_nn = pp[p + 64];
+                if (p + 32 < in_tile) {
+                    const uint4 *r8n = reinterpret_cast<const uint4 *>(sv.rows8 + (uint64_t)row_n * sv.pitch8) + j;
+#pragma unroll
+                    for (int u = 0; u < NPRE; u++)
+                        if ((uint32_t)u < steps8) xn[u] = ld_stream_u4(r8n + u * 8);
+                }
+            } else {
+                row = pp[p];
+            }
             uint32_t side = 0;
             bool decided = false;
             if (stage8) {  // first stage: the int8 copy, 768 bytes of a 768-d row; bound from the dataset-wide maxima
                 const uint4 *r8 = reinterpret_cast<const uint4 *>(sv.rows8 + row * sv.pitch8) + j;
                 const float s_row = METRIC == AH_COSINE ? 1.0f : sv.scale8_rows[row];  // a cosine margin's sign needs no scale
-                const float s8 = screen8_octet_dot(s_q4 + j, s_ql4 + j, r8, steps8) * ns8.scale;
+                const float s8 = (PRE > 0 ? screen8_octet_dot_regs<NPRE>(s_q4 + j, s_ql4 + j, x, steps8)
+                                          : screen8_octet_dot(s_q4 + j, s_ql4 + j, r8, steps8)) * ns8.scale;
                 decided = screen8_decides<METRIC>(s8, s_row, sv.max8, ns8, sv.gamma_r, side);
                 met8++;
                 decided8 += decided ? 1u : 0u;
@@ -2738,14 +2789,21 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                 forest->stats.margin_mode_launches[MM_BQ]++;
             } else if (screen) {
                 const size_t sh = (size_t)dv.pitch * 4 + (size_t)sv.hpitch * 2 + (screen8 ? 2 * (size_t)sv.pitch8 : 0);
-#define AH_LAUNCH(M)                                                                                                      \
+                // rows of at most six 128-byte int8 steps (768 dimensions): the pipelined variant of the int8 stage
+                const bool node_pre = screen8 && ds->metric != AH_DOT_PRODUCT && sv.pitch8 <= 6 * 128 && tun(TUN_NODE_PREFETCH) != 0;
+#define AH_LAUNCH_PRE(M, PRE)                                                                                            \
     do {                                                                                                                  \
         if (sh > 48 * 1024) /* very long vectors: opt in to more dynamic LDS than the default limit */                    \
-            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_screen_node<M>),                           \
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_screen_node<M, PRE>),                      \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                             \
-        hipLaunchKernelGGL((k_forest_screen_node<M>), dim3(node_grid), dim3(kBlock), sh, s, dv, sv, d_cur, d_tiles.p,     \
+        hipLaunchKernelGGL((k_forest_screen_node<M, PRE>), dim3(node_grid), dim3(kBlock), sh, s, dv, sv, d_cur, d_tiles.p, \
                            n_tiles, cur, chunk_d, nstride, hdr_off, shadow_d, hstride, shadow8_d, stride8, masks.p,       \
                            tile_left.p, d_abort, d_counters, verify);                                                     \
+    } while (0)
+#define AH_LAUNCH(M)                          \
+    do {                                      \
+        if (node_pre) AH_LAUNCH_PRE(M, 6);    \
+        else AH_LAUNCH_PRE(M, 0);             \
     } while (0)
                 switch (ds->metric) {
                 case AH_EUCLIDEAN: AH_LAUNCH(AH_EUCLIDEAN); break;
@@ -2754,6 +2812,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                 default: AH_LAUNCH(AH_DOT_PRODUCT); break;
                 }
 #undef AH_LAUNCH
+#undef AH_LAUNCH_PRE
                 forest->stats.margin_mode_launches[MM_NODE]++;
                 forest->stats.screened_launches++;
             } else {

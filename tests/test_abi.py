@@ -135,3 +135,25 @@ def test_c_example_compiles_and_links(tmp_path):
                            f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode in (0, 2), (out.returncode, out.stderr)
+
+
+def build_c_example(name, tmp_path):
+    import subprocess
+    exe = tmp_path / name
+    lib_dir = os.path.join(ROOT, "arroy_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", name + ".c"), "-o", str(exe), "-L", lib_dir, "-larroy_hip",
+                           f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_shim_roundtrip_example_walks_the_reference_database(tmp_path):
+    """examples/shim_roundtrip.c: the arroy-side shim in plain C on the reference's own LMDB file.  Without a GPU it still
+    maps the file, walks the B-tree and finds the 100 misaligned item records (exit code 2 = "no GPU", after the walk);
+    tests/test_gpu_staging.py runs it to the end on the GPU box."""
+    import subprocess
+    exe = build_c_example("shim_roundtrip", tmp_path)
+    out = subprocess.run([str(exe), os.path.join(ROOT, "tests", "golden", "large_v0_6.mdb")], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode in (0, 2), (out.returncode, out.stdout, out.stderr)
+    assert "100 items x 30 dims, page size 16384" in out.stdout

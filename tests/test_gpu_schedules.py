@@ -213,8 +213,11 @@ def test_baseline_config_3_all_100_trees_take_the_checked_paths():
     seeds = shard.tree_seeds(42, range(trees))
     f = ds.build_forest(seeds)
     st = f.stats
-    # the schedule variants only this build selects really ran, next to the three kernel families
-    assert st["rows_xcd_launches"] > 0 and st["rows_nt_launches"] > 0, st
+    # the schedule variant only a build with this many trees selects — groups of <= 4 trees pinned one XCD each — really
+    # ran, next to the three kernel families.  (Round 2 also streamed the rows of level 10 non-temporally; with the
+    # two-digit int8 stage that level is node-major now.  The non-temporal and multi-launch paths are forced on small
+    # shapes above and at this size below.)
+    assert st["rows_xcd_launches"] > 0, st
     assert st["dense_launches"] > 0 and st["margin_mode_launches"][0] > 0 and sum(st["margin_mode_launches"][1:5]) > 0, st
     assert st["screened_launches"] > 0 and st["screen_violations"] == 0 and st["screen_unavailable"] == 0
     assert st["screen8_pairs"] > 0 and st["screen8_decided"] > 0.7 * st["screen8_pairs"], st  # the int8 stage carries the deep levels
@@ -251,4 +254,12 @@ def test_baseline_config_3_all_100_trees_take_the_checked_paths():
     gt, gper = g.digest()
     assert (gper == per).all() and gt == total
     g.close()
+    # the round-2 schedule of this build (levels 9-10 as 25 XCD-pinned groups of 4 trees, level 10 with non-temporal rows)
+    # and a pass cut into several launches, at full size: same content
+    with _lib.tuning(AH_SCREEN8=0, AH_LAUNCH_MAX_ITEMS=1 << 30):
+        h = ds.build_forest(seeds)
+    hs = h.stats
+    assert hs["rows_xcd_launches"] > 0 and hs["rows_nt_launches"] > 0 and hs["rows_split_launches"] > 0, hs
+    assert hs["screen8_pairs"] == 0 and h.digest()[0] == total
+    h.close()
     ds.close()

@@ -100,6 +100,21 @@ def test_records_staged_from_pointers_into_a_mapped_lmdb_file(golden):
     mm.close()
 
 
+def test_shim_roundtrip_in_plain_c_on_the_reference_database(tmp_path):
+    """examples/shim_roundtrip.c end to end: records staged from pointers into the mapped large.mdb, forest built, every
+    node passed through the sink and ENCODED in the NodeCodec v0.7 layout (src/node.rs:224-241: `[2u8][left BE][right BE]
+    [header][vector]`, `[1u8][roaring]`), decoded again (src/node.rs:252-273), mirrored on the device from the decoded
+    arrays and searched: the golden neighbours of src/tests/upgrade.rs:116-128."""
+    import subprocess
+
+    from test_abi import build_c_example
+    exe = build_c_example("shim_roundtrip", tmp_path)
+    out = subprocess.run([str(exe), os.path.join(ROOT, "tests", "golden", "large_v0_6.mdb")], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "id(92): distance(2.4881108)" in out.stdout and out.stdout.strip().endswith("ok")
+
+
 def test_uploads_are_asynchronous_but_never_read_the_callers_memory_after_return():
     """The staging contract (include/arroy_hip.h): the pointers are not used after return, although the DMA of the last
     chunks may still be in flight.  Overwrite the source right after every call; the dataset must hold the originals."""
