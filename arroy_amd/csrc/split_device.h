@@ -134,27 +134,127 @@ __device__ __forceinline__ float wave_non_built_distance(const float *p, LeafHdr
     return 2.0f;
 }
 
+// Up to four reductions in ONE pass over LDS (fd >= 32): octet i of the wave evaluates (a[i], b[i]) for i < n, the other
+// octets repeat the last one; out[i] = its result on every lane.  Every octet runs exactly the arithmetic of
+// octet_reduce / octet_manhattan — same chains, same tree — so the values are those of n separate calls; what changes is
+// the LDS traffic: a ds_read_b128 returns 1 KiB to the wave whether its octets ask for the same 128 bytes or not, and
+// two_means used to spend 3-4 such passes per iteration with all eight octets computing the same number (create_split was
+// LDS-bound: 53 ms of the 10M x 100-tree build).
+template <int OP, bool MANHATTAN>
+__device__ __forceinline__ void wave_reduce_multi(const float *a0, const float *b0, const float *a1, const float *b1,
+                                                  const float *a2, const float *b2, const float *a3, const float *b3, uint32_t n,
+                                                  uint32_t fd, uint32_t lane, float (&out)[4]) {
+    const uint32_t oct = min(lane >> 3, n - 1u);
+    const float *pa = a0, *pb = b0;
+    if (oct == 1u) {
+        pa = a1;
+        pb = b1;
+    } else if (oct == 2u) {
+        pa = a2;
+        pb = b2;
+    } else if (oct == 3u) {
+        pa = a3;
+        pb = b3;
+    }
+    const float r = MANHATTAN ? octet_manhattan(pa, pb, fd, lane & 7u) : octet_reduce<OP>(pa, pb, fd, lane & 7u);
+    out[0] = __shfl(r, 0);
+    out[1] = __shfl(r, 8);
+    out[2] = __shfl(r, 16);
+    out[3] = __shfl(r, 24);
+}
+
+// non_built_distance from the reduction it needs (`red` = dot / squared distance / Manhattan sum of (p, k))
+template <int M>
+__device__ __forceinline__ float non_built_from_reduction(float red, LeafHdr ph, LeafHdr kh) {
+    if (M == AH_EUCLIDEAN || M == AH_MANHATTAN) return red;
+    if (M == AH_COSINE) return cosine_from_dot(red, ph.h0, kh.h0);
+    const float pq = f_add(red, f_mul(ph.h0, kh.h0));  // DotProduct (dot_product.rs:58-70)
+    const float ppqq = f_mul(ph.h1, kh.h1);
+    if (ppqq >= 1.17549435e-38f) return f_sub(2.0f, f_div(f_mul(2.0f, pq), f_sqrt(ppqq)));
+    return 2.0f;
+}
+// D::init from <v, v>
+template <int M>
+__device__ __forceinline__ void init_from_reduction(float vv, LeafHdr &h) {
+    if (M == AH_COSINE) h.h0 = f_sqrt(vv);
+    if (M == AH_DOT_PRODUCT) h.h1 = vv;
+}
+
 // two_means (mod.rs:126-171 / 173-223).  s_p, s_q, s_k: LDS, fpitch floats each.  rows[12] = the sampled
 // dataset rows (choose_two, then the ten `choose`).  Returns the two centroid headers.
+// fd >= 32: the reductions of an iteration — <p,k>, <q,k>, <k,k> and the D::init of the centroid the previous iteration
+// moved — go through ONE fused pass (wave_reduce_multi); the arithmetic of every value is unchanged.
 template <int M>
 __device__ __forceinline__ void wave_two_means(const DataView &dv, const uint32_t *rows, float *s_p, float *s_q,
                                                float *s_k, LeafHdr &ph, LeafHdr &qh, uint32_t fd, uint32_t fpitch,
                                                uint32_t lane) {
     const bool cosine = two_means_is_cosine(dv.metric);
+    constexpr bool kInit = M == AH_COSINE || M == AH_DOT_PRODUCT;  // D::init is a no-op for the other metrics
+    constexpr int OP = (M == AH_EUCLIDEAN || M == AH_MANHATTAN) ? OP_EUCLID : OP_DOT;
+    constexpr bool MH = M == AH_MANHATTAN;
     ph = wave_load_leaf(dv, rows[0], s_p, fd, fpitch, lane);
     qh = wave_load_leaf(dv, rows[1], s_q, fd, fpitch, lane);
+    const bool fused = fd >= 32;
+    float red[4];
     if (cosine) {
-        wave_normalize<M>(s_p, ph, fd, lane);
-        wave_normalize<M>(s_q, qh, fd, lane);
+        if (fused) {  // both norms in one pass, then both D::normalize (mod.rs:76-82; dot_product.rs:85-92)
+            wave_reduce_multi<OP_DOT, false>(s_p, s_p, s_q, s_q, s_q, s_q, s_q, s_q, 2, fd, lane, red);
+            float np = red[0], nq = red[1];
+            if (M == AH_DOT_PRODUCT) {
+                np = f_add(np, f_mul(ph.h0, ph.h0));
+                nq = f_add(nq, f_mul(qh.h0, qh.h0));
+            }
+            np = f_sqrt(np);
+            nq = f_sqrt(nq);
+            __syncthreads();
+            if (np > 0.0f) {
+                for (uint32_t i = lane; i < fd; i += 64) s_p[i] = f_div(s_p[i], np);
+                if (M == AH_DOT_PRODUCT) ph.h0 = f_div(ph.h0, np);
+            }
+            if (nq > 0.0f) {
+                for (uint32_t i = lane; i < fd; i += 64) s_q[i] = f_div(s_q[i], nq);
+                if (M == AH_DOT_PRODUCT) qh.h0 = f_div(qh.h0, nq);
+            }
+            __syncthreads();
+        } else {
+            wave_normalize<M>(s_p, ph, fd, lane);
+            wave_normalize<M>(s_q, qh, fd, lane);
+        }
     }
-    wave_init<M>(s_p, ph, fd, lane);
-    wave_init<M>(s_q, qh, fd, lane);
+    // D::init of p and q: pending until the next fused pass (a centroid's header is only read by the distances)
+    bool p_dirty = kInit, q_dirty = kInit;
+    if (!fused) {
+        wave_init<M>(s_p, ph, fd, lane);
+        wave_init<M>(s_q, qh, fd, lane);
+        p_dirty = q_dirty = false;
+    } else if (kInit) {
+        wave_reduce_multi<OP_DOT, false>(s_p, s_p, s_q, s_q, s_q, s_q, s_q, s_q, 2, fd, lane, red);
+        init_from_reduction<M>(red[0], ph);
+        init_from_reduction<M>(red[1], qh);
+        p_dirty = q_dirty = false;
+    }
     float ic = 1.0f, jc = 1.0f;
     for (int it = 0; it < 10; it++) {
         LeafHdr kh = wave_load_leaf(dv, rows[2 + it], s_k, fd, fpitch, lane);
-        float di = f_mul(ic, wave_non_built_distance<M>(s_p, ph, s_k, kh, fd, lane));
-        float dj = f_mul(jc, wave_non_built_distance<M>(s_q, qh, s_k, kh, fd, lane));
-        float norm = cosine ? wave_norm<M>(s_k, kh, fd, lane) : 1.0f;
+        float di, dj, norm;
+        if (fused) {
+            // slot 0: (p, k), slot 1: (q, k), slot 2: <k, k> (cosine family), slot 3: the pending D::init of p or q
+            const float *dirty = p_dirty ? s_p : s_q;
+            const uint32_t n = (p_dirty || q_dirty) ? 4u : (cosine ? 3u : 2u);
+            wave_reduce_multi<OP, MH>(s_p, s_k, s_q, s_k, s_k, s_k, dirty, dirty, n, fd, lane, red);
+            if (p_dirty) init_from_reduction<M>(red[3], ph);
+            else if (q_dirty) init_from_reduction<M>(red[3], qh);
+            p_dirty = q_dirty = false;
+            di = f_mul(ic, non_built_from_reduction<M>(red[0], ph, kh));
+            dj = f_mul(jc, non_built_from_reduction<M>(red[1], qh, kh));
+            float kk = red[2];
+            if (M == AH_DOT_PRODUCT) kk = f_add(kk, f_mul(kh.h0, kh.h0));
+            norm = cosine ? f_sqrt(kk) : 1.0f;
+        } else {
+            di = f_mul(ic, wave_non_built_distance<M>(s_p, ph, s_k, kh, fd, lane));
+            dj = f_mul(jc, wave_non_built_distance<M>(s_q, qh, s_k, kh, fd, lane));
+            norm = cosine ? wave_norm<M>(s_k, kh, fd, lane) : 1.0f;
+        }
         __syncthreads();
         if (norm != norm || norm <= 0.0f) continue;  // mod.rs:156-158
         if (di < dj) {
@@ -162,18 +262,22 @@ __device__ __forceinline__ void wave_two_means(const DataView &dv, const uint32_
             for (uint32_t i = lane; i < fd; i += 64)
                 s_p[i] = f_div(f_add(f_mul(s_p[i], ic), f_div(s_k[i], norm)), c1);
             __syncthreads();
-            wave_init<M>(s_p, ph, fd, lane);
+            if (fused) p_dirty = kInit;
+            else wave_init<M>(s_p, ph, fd, lane);
             ic = f_add(ic, 1.0f);
         } else if (dj < di) {
             const float c1 = f_add(jc, 1.0f);
             for (uint32_t i = lane; i < fd; i += 64)
                 s_q[i] = f_div(f_add(f_mul(s_q[i], jc), f_div(s_k[i], norm)), c1);
             __syncthreads();
-            wave_init<M>(s_q, qh, fd, lane);
+            if (fused) q_dirty = kInit;
+            else wave_init<M>(s_q, qh, fd, lane);
             jc = f_add(jc, 1.0f);
         }
         __syncthreads();
     }
+    if (p_dirty) wave_init<M>(s_p, ph, fd, lane);  // the last move's D::init
+    if (q_dirty) wave_init<M>(s_q, qh, fd, lane);
 }
 
 // create_split.  Writes the normal in the metric's codec to `out_vec` (global: pitch floats or pitch words)
@@ -196,9 +300,13 @@ __device__ __forceinline__ void wave_create_split(const DataView &dv, const uint
         wave_normalize<M>(s_k, nh, fd, lane);
         if (M == AH_EUCLIDEAN || M == AH_MANHATTAN) {
             // bias = sum_i (-n_i * (p_i + q_i)) / 2.0, sequential f32 sum (euclidean.rs:69-74)
+            // (the terms are elementwise: the lanes compute them in parallel into s_p — p is dead after this — and only the
+            // sum itself is sequential; the serial loop over three LDS operands was most of an Euclidean create_split)
+            for (uint32_t i = lane; i < fd; i += 64) s_p[i] = f_div(f_mul(-s_k[i], f_add(s_p[i], s_q[i])), 2.0f);
+            __syncthreads();
             float bias = 0.0f;
-            for (uint32_t i = 0; i < fd; i++)
-                bias = f_add(bias, f_div(f_mul(-s_k[i], f_add(s_p[i], s_q[i])), 2.0f));
+#pragma unroll 8
+            for (uint32_t i = 0; i < fd; i++) bias = f_add(bias, s_p[i]);
             nh.h0 = bias;
         }
         float *o = reinterpret_cast<float *>(out_vec);
