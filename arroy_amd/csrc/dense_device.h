@@ -205,15 +205,24 @@ __global__ __launch_bounds__(DenseShape<WN>::kThreads, 1) void k_forest_dense_sc
         }
 #pragma unroll
         for (int im = 0; im < 4; im++) {
+            // the 32 look-ups of an MFMA tile pair are requested together (one dependent load + branch per element made
+            // the epilogue latency-bound: 256 round trips per wave), then the matching elements are decided
+            uint32_t nd[2][16];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const uint32_t r_in = wm * 128u + (uint32_t)im * 32u + (uint32_t)(e & 3) + 8u * (uint32_t)(e >> 2) + 4u * g;
                 const uint64_t row = row0 + r_in;
-                if (row >= a.n) continue;  // half-wave-uniform
+#pragma unroll
+                for (int jn = 0; jn < 2; jn++)
+                    nd[jn][e] = (col_ok[jn] && row < a.n) ? a.node_of[(uint64_t)tree[jn] * a.n + row] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const uint32_t r_in = wm * 128u + (uint32_t)im * 32u + (uint32_t)(e & 3) + 8u * (uint32_t)(e >> 2) + 4u * g;
+                const uint64_t row = row0 + r_in;
 #pragma unroll
                 for (int jn = 0; jn < 2; jn++) {
-                    const uint32_t node = col_ok[jn] ? a.node_of[(uint64_t)tree[jn] * a.n + row] : 0xFFFFFFFFu;
-                    if (node == col[jn]) {
+                    if (nd[jn][e] == col[jn]) {  // (0xFFFFFFFF never equals a column)
                         const float sv = acc[im][jn][e];
                         const float row_extra = METRIC == AH_DOT_PRODUCT ? a.headers[2 * row] : 0.0f;
                         uint32_t side;
@@ -232,10 +241,16 @@ __global__ __launch_bounds__(DenseShape<WN>::kThreads, 1) void k_forest_dense_sc
         constexpr uint32_t kParts = SH::kThreads / kDM;
         const uint64_t row = row0 + r_in;
         if (row < a.n) {
-            for (uint32_t t = t_lo + part; t <= t_hi; t += kParts) {
-                const uint32_t node = a.node_of[(uint64_t)t * a.n + row];
-                // leaf rows (0xFFFFFFFF) and nodes of other column tiles fall outside [c0, c_last]
-                if (node >= c0 && node <= c_last) a.side_bytes[(uint64_t)t * a.n + row] = s_bytes[(t - t_lo) * kDM + r_in];
+            for (uint32_t t = t_lo + part; t <= t_hi; t += 8u * kParts) {
+                uint32_t nd[8];
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++)
+                    nd[u] = t + u * kParts <= t_hi ? a.node_of[(uint64_t)(t + u * kParts) * a.n + row] : 0xFFFFFFFFu;
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++)
+                    // leaf rows (0xFFFFFFFF) and nodes of other column tiles fall outside [c0, c_last]
+                    if (nd[u] >= c0 && nd[u] <= c_last)
+                        a.side_bytes[(uint64_t)(t + u * kParts) * a.n + row] = s_bytes[(t + u * kParts - t_lo) * kDM + r_in];
             }
         }
     }
