@@ -41,9 +41,11 @@ struct DenseShape {
     static constexpr uint32_t kStage = (kDM + kBN) * 128u;  // one k-block (64 halves = 128 B per tile row) of both operands
     static constexpr uint32_t kPiecesA = 32u / kWaves, kPiecesB = (kBN / 8u) / kWaves;  // 1 KiB DMA pieces per wave
 };
-constexpr uint32_t kDenseLds = 2 * DenseShape<4>::kStage;  // 131 072 B: two stages of the wide shape (the narrow one needs 98 304)
+constexpr uint32_t kDenseHalf = 128;             // columns per epilogue round
+constexpr uint32_t kDensePitch = kDM + 4;         // floats per column of the transposed result tile (bank spread)
+constexpr uint32_t kDenseLds = kDenseHalf * kDensePitch * 4;  // 133 120 B >= two stages of either shape
 constexpr uint32_t kDenseGroup = 8;  // row tiles whose column tiles run back to back on one XCD (X~ tiles stay in its L2)
-static_assert(DenseShape<4>::kBN * kDM <= kDenseLds, "the parked side bytes of a tile fit in the stage buffers");
+static_assert(2 * DenseShape<4>::kStage <= kDenseLds && 2 * DenseShape<2>::kStage <= kDenseLds, "stage buffers fit");
 
 // side-byte codes of the dense pass (resolved to 0 / 1 by k_forest_exact_pairs before anything else reads them)
 constexpr uint32_t kSideUndecided = 2u;  // the screen could not decide: reference arithmetic wanted
@@ -62,7 +64,6 @@ struct DenseArgs {
     const uint32_t *node_of;
     uint8_t *side_bytes;
     float gamma_s, gamma_r;
-    float4 max_stats;  // component-wise maximum of `stats` over all rows (inf as soon as one row is unusable)
     uint32_t n_row_tiles, n_col_tiles, group, verify;
 };
 
@@ -177,80 +178,63 @@ __global__ __launch_bounds__(DenseShape<WN>::kThreads, 1) void k_forest_dense_sc
                     acc[im][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[im], bf[jn], acc[im][jn], 0, 0, 0);
         }
     }
-    // Epilogue, straight from the accumulators.  D layout of the 32x32 MFMA: lane -> column (lane & 31) of the B operand
-    // (the normals), register e -> row (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the A operand (the data rows).  A lane
-    // owns two columns (jn = 0, 1), i.e. two nodes; element (row, column) matters iff the row's node in the column's tree
-    // IS that column — one element per (row, tree) — so every lane looks its 128 elements up in node_of (the 32 lanes of
-    // a half-wave share the row: a load fetches one or two words), decides the matching ones with the bound built from the
-    // dataset-wide row maxima (monotone in every stat, hence >= the row's own bound; the row's stats only when that
-    // cannot decide) and parks the side byte in LDS as [tree of the tile][row of the tile].  Then a thread per row writes
-    // the parked bytes of its row out, consecutive rows -> consecutive bytes.  (Until round 3 the tile was transposed
-    // through LDS in two rounds of 128 columns — 2 x 128 KB written and two more barriers — and every (row, tree) pair was
-    // decided by the row's thread from there: 35-45 % of a tile's time.)
-    uint8_t *s_bytes = smem;  // [trees of the tile][kDM]: at most kBN x 256 = 64 KB, inside the (dead) stage buffers
-    const uint32_t c_last = min(c0 + SH::kBN, a.n_cols) - 1u;
-    const uint32_t t_lo = a.nodes[c0].tree, t_hi = a.nodes[c_last].tree;
-    __syncthreads();  // every wave has consumed the last stage
-    {
-        uint32_t col[2], tree[2];
-        NormalStats ns[2];
-        bool col_ok[2];
+    // Epilogue in rounds of 128 columns.  The waves owning them park their accumulators in LDS, transposed — S[column][row];
+    // D layout of the 32x32 MFMA: lane -> column (lane & 31) of the B operand (the normals), register e -> row
+    // (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of the A operand (the data rows): four consecutive registers are four
+    // consecutive rows = one 16-byte store.  Then a thread per row (and per share of the trees, with 512 threads): for
+    // every tree that has nodes among the round's columns, the row's node (coalesced read), its screen value, the bound,
+    // the decision; one side byte out (consecutive rows -> consecutive bytes).  Nodes are ordered by tree, so the
+    // columns [c_lo, c_hi] cover the trees [t_lo, t_hi].
+    float *S = reinterpret_cast<float *>(smem);
+    const uint32_t r_in = threadIdx.x & (kDM - 1u), part = threadIdx.x / kDM;
+    constexpr uint32_t kParts = SH::kThreads / kDM;
+    const uint64_t row = row0 + r_in;
+    const bool live = row < a.n;
+    float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+    float row_extra = 0.0f;
+    if (live) {
+        rs = a.stats[row];
+        if (METRIC == AH_DOT_PRODUCT) row_extra = a.headers[2 * row];
+    }
+#pragma unroll 1
+    for (uint32_t h = 0; h < SH::kBN / kDenseHalf; h++) {
+        const uint32_t c_lo = c0 + h * kDenseHalf;
+        if (c_lo >= a.n_cols) break;  // block-uniform
+        __syncthreads();  // the stage buffers (round 0) / the previous round's tile are dead
+        if ((wn >> 1) == h) {
 #pragma unroll
-        for (int jn = 0; jn < 2; jn++) {
-            col[jn] = c0 + wn * 64u + (uint32_t)jn * 32u + m;
-            col_ok[jn] = col[jn] < a.n_cols;
-            const uint32_t cc = col_ok[jn] ? col[jn] : a.n_cols - 1u;
-            tree[jn] = a.nodes[cc].tree;
-            ns[jn] = *reinterpret_cast<const NormalStats *>(a.shadow + (uint64_t)cc * a.hstride + (uint64_t)a.hpitch * 2u);
-        }
-#pragma unroll
-        for (int im = 0; im < 4; im++) {
-            // the 32 look-ups of an MFMA tile pair are requested together (one dependent load + branch per element made
-            // the epilogue latency-bound: 256 round trips per wave), then the matching elements are decided
-            uint32_t nd[2][16];
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const uint32_t r_in = wm * 128u + (uint32_t)im * 32u + (uint32_t)(e & 3) + 8u * (uint32_t)(e >> 2) + 4u * g;
-                const uint64_t row = row0 + r_in;
-#pragma unroll
-                for (int jn = 0; jn < 2; jn++)
-                    nd[jn][e] = (col_ok[jn] && row < a.n) ? a.node_of[(uint64_t)tree[jn] * a.n + row] : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const uint32_t r_in = wm * 128u + (uint32_t)im * 32u + (uint32_t)(e & 3) + 8u * (uint32_t)(e >> 2) + 4u * g;
-                const uint64_t row = row0 + r_in;
+            for (int im = 0; im < 4; im++)
 #pragma unroll
                 for (int jn = 0; jn < 2; jn++) {
-                    if (nd[jn][e] == col[jn]) {  // (0xFFFFFFFF never equals a column)
-                        const float sv = acc[im][jn][e];
-                        const float row_extra = METRIC == AH_DOT_PRODUCT ? a.headers[2 * row] : 0.0f;
-                        uint32_t side;
-                        bool decided = screen_decides<METRIC>(sv, a.max_stats, ns[jn], row_extra, a.gamma_s, a.gamma_r, side);
-                        if (!decided) decided = screen_decides<METRIC>(sv, a.stats[row], ns[jn], row_extra, a.gamma_s, a.gamma_r, side);
-                        s_bytes[(tree[jn] - t_lo) * kDM + r_in] =
-                            (uint8_t)(decided ? (a.verify ? (kSideVerify | side) : side) : kSideUndecided);
+                    const uint32_t col = (wn & 1u) * 64u + (uint32_t)jn * 32u + m;
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        const uint32_t rr = wm * 128u + (uint32_t)im * 32u + 8u * (uint32_t)qq + 4u * g;
+                        *reinterpret_cast<float4 *>(S + col * kDensePitch + rr) = make_float4(
+                            acc[im][jn][4 * qq], acc[im][jn][4 * qq + 1], acc[im][jn][4 * qq + 2], acc[im][jn][4 * qq + 3]);
                     }
                 }
-            }
         }
-    }
-    __syncthreads();
-    {
-        const uint32_t r_in = threadIdx.x & (kDM - 1u), part = threadIdx.x / kDM;
-        constexpr uint32_t kParts = SH::kThreads / kDM;
-        const uint64_t row = row0 + r_in;
-        if (row < a.n) {
-            for (uint32_t t = t_lo + part; t <= t_hi; t += 8u * kParts) {
-                uint32_t nd[8];
+        __syncthreads();
+        const uint32_t c_hi = min(c_lo + kDenseHalf, a.n_cols) - 1u;
+        const uint32_t t_lo = a.nodes[c_lo].tree, t_hi = a.nodes[c_hi].tree;
+        for (uint32_t t = t_lo + 8u * part; t <= t_hi; t += 8u * kParts) {
+            uint32_t nd[8];
 #pragma unroll
-                for (uint32_t u = 0; u < 8; u++)
-                    nd[u] = t + u * kParts <= t_hi ? a.node_of[(uint64_t)(t + u * kParts) * a.n + row] : 0xFFFFFFFFu;
+            for (uint32_t u = 0; u < 8; u++)
+                nd[u] = (live && t + u <= t_hi) ? a.node_of[(uint64_t)(t + u) * a.n + row] : 0xFFFFFFFFu;
 #pragma unroll
-                for (uint32_t u = 0; u < 8; u++)
-                    // leaf rows (0xFFFFFFFF) and nodes of other column tiles fall outside [c0, c_last]
-                    if (nd[u] >= c0 && nd[u] <= c_last)
-                        a.side_bytes[(uint64_t)(t + u * kParts) * a.n + row] = s_bytes[(t + u * kParts - t_lo) * kDM + r_in];
+            for (uint32_t u = 0; u < 8; u++) {
+                const uint32_t c = nd[u] - c_lo;  // 0xFFFFFFFF (leaf row) and nodes of other column ranges fall outside
+                if (nd[u] != 0xFFFFFFFFu && c < kDenseHalf) {
+                    const float s = S[c * kDensePitch + r_in];
+                    const NormalStats ns =
+                        *reinterpret_cast<const NormalStats *>(a.shadow + (uint64_t)nd[u] * a.hstride + (uint64_t)a.hpitch * 2u);
+                    uint32_t side;
+                    const bool decided = screen_decides<METRIC>(s, rs, ns, row_extra, a.gamma_s, a.gamma_r, side);
+                    a.side_bytes[(uint64_t)(t + u) * a.n + row] =
+                        (uint8_t)(decided ? (a.verify ? (kSideVerify | side) : side) : kSideUndecided);
+                }
             }
         }
     }

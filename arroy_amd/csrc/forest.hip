@@ -2621,7 +2621,6 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     // (hpitch + hpitch / 16) * 2^-23 * sum |x~_i n~_i|; taken twice over
                     da.gamma_s = (float)(2.0 * ((double)sv.hpitch + (double)sv.hpitch / 16 + 16.0) * 1.1920929e-7);
                     da.gamma_r = sv.gamma_r;
-                    da.max_stats = sv.max_stats;
                     const DensePlan dp = dense_plan(N, n_nodes);
                     da.n_row_tiles = dp.n_row_tiles;
                     da.n_col_tiles = dp.n_col_tiles;
