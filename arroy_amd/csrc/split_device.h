@@ -234,38 +234,8 @@ __device__ __forceinline__ void wave_two_means(const DataView &dv, const uint32_
         p_dirty = q_dirty = false;
     }
     float ic = 1.0f, jc = 1.0f;
-    // The ten sampled leaves are known up front: the NEXT one travels from global memory into registers (up to 32 per lane:
-    // rows of at most 2048 floats) while the reductions of the current one run, instead of one more dependent round trip
-    // per iteration of a chain that is latency-bound as it is.
-    constexpr int KR = 32;
-    const bool pre = !metric_is_bq_dev(dv.metric) && fpitch <= 64u * KR;
-    float kreg[KR];
-    LeafHdr kh_next = {0.0f, 0.0f};
-    auto request_leaf = [&](uint32_t row) {
-        const float *rp = dv.rows_f32 + (uint64_t)row * dv.pitch;
-#pragma unroll
-        for (int u = 0; u < KR; u++) {
-            const uint32_t i = lane + 64u * (uint32_t)u;
-            if (i < fpitch) kreg[u] = i < dv.dims ? rp[i] : 0.0f;
-        }
-        kh_next.h0 = dv.headers[(uint64_t)row * (dv.metric == AH_DOT_PRODUCT ? 2u : 1u)];
-        if (dv.metric == AH_DOT_PRODUCT) kh_next.h1 = dv.headers[2 * (uint64_t)row + 1];
-    };
-    if (pre) request_leaf(rows[2]);
     for (int it = 0; it < 10; it++) {
-        LeafHdr kh;
-        if (pre) {
-#pragma unroll
-            for (int u = 0; u < KR; u++) {
-                const uint32_t i = lane + 64u * (uint32_t)u;
-                if (i < fpitch) s_k[i] = kreg[u];
-            }
-            kh = kh_next;
-            __syncthreads();
-            if (it + 1 < 10) request_leaf(rows[3 + it]);
-        } else {
-            kh = wave_load_leaf(dv, rows[2 + it], s_k, fd, fpitch, lane);
-        }
+        LeafHdr kh = wave_load_leaf(dv, rows[2 + it], s_k, fd, fpitch, lane);
         float di, dj, norm;
         if (fused) {
             // slot 0: (p, k), slot 1: (q, k), slot 2: <k, k> (cosine family), slot 3: the pending D::init of p or q
