@@ -15,7 +15,7 @@ namespace ah {
 
 static constexpr int kBlock = 256;
 static constexpr uint32_t kChunk = 4096;   // keys per LDS sort (32 KiB)
-static constexpr uint32_t kTileCand = 512;   // candidates per (query, tile) work item: ~2600 items per 125-query submission on 256 CUs
+static constexpr uint32_t kTileCand = 1024;
 static constexpr uint64_t kSentinel = ~0ull;
 
 struct Seg {          // one query's slice of the concatenated candidate list
@@ -87,50 +87,21 @@ __global__ __launch_bounds__(kBlock) void k_batch_distances_f32(DataView dv, con
         }
         const uint32_t in_tile = min(kTileCand, sg.n - tl.first);
         const uint64_t base = sg.off + tl.first;
-        // Long rows (>= 256 dims, not Manhattan): the gather is software-pipelined — the id of the candidate after the
-        // next, the row of the next one and its first eight line-loads are requested while the current row is reduced.
-        const bool pipe = METRIC != AH_MANHATTAN && dv.dims >= 256;
-        float4 pre[8];
-        uint32_t id_n = 0, id_nn = 0;
-        uint64_t row_n = ~0ull;
-        if (pipe) {
-            if (o < in_tile) {
-                id_n = ids[base + o];
-                row_n = row_of_id(dv, id_n);
-                if (row_n != ~0ull) octet_request_first<OP>(dv.rows_f32 + row_n * dv.pitch, pre, j);
-            }
-            if (o + kBlock / 8 < in_tile) id_nn = ids[base + o + kBlock / 8];
-        }
         for (uint32_t p = o; p < in_tile; p += kBlock / 8) {
             const uint64_t i = base + p;
-            uint32_t id;
-            uint64_t row, row_next = ~0ull;
-            if (pipe) {
-                id = id_n;
-                row = row_n;
-                id_n = id_nn;
-                if (p + kBlock / 8 < in_tile) row_next = row_of_id(dv, id_n);
-                if (p + 2 * (kBlock / 8) < in_tile) id_nn = ids[i + 2 * (kBlock / 8)];
-                row_n = row_next;
-            } else {
-                id = ids[i];
-                row = row_of_id(dv, id);
-            }
+            const uint32_t id = ids[i];
+            const uint64_t row = row_of_id(dv, id);
             if (row == ~0ull) {
                 if (j == 0) {
                     atomicOr(err, 1u);
                     out[i] = __uint_as_float(0x7FC00000u);
                 }
-                if (pipe && row_next != ~0ull) octet_request_first<OP>(dv.rows_f32 + row_next * dv.pitch, pre, j);
                 continue;
             }
             if ((tl.first + p) > 0 && id <= ids[i - 1] && j == 0) atomicOr(err, 2u);
             const float *rp = dv.rows_f32 + row * dv.pitch;
             float r;
-            if (pipe) {
-                r = octet_reduce_stream_pipe<OP>(s_q4, rp, row_next != ~0ull ? dv.rows_f32 + row_next * dv.pitch : nullptr, pre,
-                                                 dv.dims, j);
-            } else if (dv.dims >= 32) {
+            if (dv.dims >= 32) {
                 if (METRIC == AH_MANHATTAN) r = octet_manhattan(s_q, rp, dv.dims, j);
                 else r = octet_reduce_stream<OP>(s_q4, rp, dv.dims, j);
             } else if (METRIC == AH_MANHATTAN) {

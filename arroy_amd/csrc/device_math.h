@@ -136,44 +136,6 @@ __device__ __forceinline__ float octet_reduce_stream(const float4 *s_b4, const f
     return scalar_tail<OP>(r, reinterpret_cast<const float *>(s_b4), row, blocks << 5, dims);
 }
 
-// The same reduction, software-pipelined across rows for gathers (re-rank): `pre` holds the first 8 line-loads of THIS row
-// on entry (requested while the previous row was still being reduced) and those of `next_row` (if not null) on exit;
-// inside the row the loads of batch b + 1 are requested before the FMAs of batch b.  A gathered row otherwise starts with
-// a full memory round trip during which the octet has nothing in flight.  dims >= 256 (at least one batch of 8 blocks).
-// Same chains, same k order, same tree: bit-identical to octet_reduce_stream.
-template <int OP>
-__device__ __forceinline__ float octet_reduce_stream_pipe(const float4 *s_b4, const float *row, const float *next_row,
-                                                          float4 (&pre)[8], uint32_t dims, uint32_t j) {
-    const uint32_t blocks = dims >> 5, nb = blocks >> 3;
-    const float4 *r4 = reinterpret_cast<const float4 *>(row) + j;
-    const float4 *b4 = s_b4 + j;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t b = 0; b < nb; b++) {
-        float4 cur[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) cur[u] = pre[u];
-        if (b + 1 < nb) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) pre[u] = ld_stream(r4 + ((b + 1) * 8 + u) * 8);
-        } else if (next_row != nullptr) {
-            const float4 *n4 = reinterpret_cast<const float4 *>(next_row) + j;
-#pragma unroll
-            for (int u = 0; u < 8; u++) pre[u] = ld_stream(n4 + u * 8);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) fma_step<OP>(acc, b4[(b * 8 + u) * 8], cur[u]);
-    }
-    for (uint32_t k = nb << 3; k < blocks; k++) fma_step<OP>(acc, b4[k * 8], r4[k * 8]);
-    float r = octet_finish(acc);
-    return scalar_tail<OP>(r, reinterpret_cast<const float *>(s_b4), row, blocks << 5, dims);
-}
-template <int OP>
-__device__ __forceinline__ void octet_request_first(const float *row, float4 (&pre)[8], uint32_t j) {
-    const float4 *r4 = reinterpret_cast<const float4 *>(row) + j;
-#pragma unroll
-    for (int u = 0; u < 8; u++) pre[u] = ld_stream(r4 + u * 8);
-}
-
 // SSE tier (16 <= dims < 32, simple_sse.rs) and scalar tier (dims < 16, simple.rs:49-51,81-83),
 // executed by ONE thread.  16 chains, multiply THEN add (never fused); hsum128 = (x0+x2)+(x1+x3).
 template <int OP>
