@@ -84,7 +84,6 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
     X(NODE_PREFETCH, "AH_NODE_PREFETCH", 1)     /* 0: no software pipeline in the int8 stage of the node-major screen */    \
     X(SCREEN8, "AH_SCREEN8", -1)                /* 0: no int8 first stage; 1: keep it whatever the data; -1: by quality */ \
     X(DENSE, "AH_DENSE", -1)                    /* 0: never the dense MFMA screen; 1: whenever legal; -1: cost model */    \
-    X(DENSE_WAVE128, "AH_DENSE_WAVE128", 0)     /* 1: 256-column dense tiles as 4 waves of 128 x 128 instead of 8 of 128 x 64 */ \
     X(DENSE_MAX_COLS, "AH_DENSE_MAX_COLS", 16384)                                                                        \
     X(DENSE_GMACS, "AH_DENSE_GMACS", 495000)    /* sustained multiply-add rate the cost model assumes, 1e9 MAC/s */       \
     X(MARGIN_MODE, "AH_MARGIN_MODE", 0)         /* ah_margin_mode for callers that pass AH_MARGIN_AUTO */                 \

@@ -30,16 +30,12 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 constexpr uint32_t kDM = 256;  // rows of X~ per block tile
-// Block tile = 256 rows x (32 TN WN) normals: 2 x WN waves, each owning 128 x 32 TN = 4 x TN MFMA tiles.
-//   <WN 4, TN 2>  256 columns, 512 threads (two waves per SIMD), 128 accumulator registers per lane: the round-2 workhorse
-//   <WN 2, TN 2>  128 columns, 256 threads: levels with at most 128 normals, where the wider tile would only multiply padding
-//   <WN 2, TN 4>  256 columns, 256 threads (ONE wave per SIMD), 128 x 128 per wave = 256 accumulator registers (AGPRs):
-//                 8 fragment loads feed 16 MFMAs instead of 6 feeding 8 — the k-loop of the 4 x 2 shape asks LDS for
-//                 0.75 KB per MFMA, which with the DMA's own writes saturates the 128 B/clk LDS port exactly as long as the
-//                 MFMAs take (AH_DENSE_WAVE128 selects it; A/B in DESIGN.md)
-template <int WN, int TN = 2>
+// Block tile = 256 rows x (64 WN) normals, WN = 2 or 4: 2 x WN waves, each owning 128 x 64 = 4 x 2 MFMA tiles (128
+// accumulator registers).  WN = 4 (512 threads, two waves per SIMD) is the workhorse; WN = 2 serves levels with at most
+// 128 normals, where the wider tile would only multiply padding.
+template <int WN>
 struct DenseShape {
-    static constexpr uint32_t kBN = 32u * TN * WN;
+    static constexpr uint32_t kBN = 64u * WN;
     static constexpr uint32_t kThreads = 128u * WN;
     static constexpr uint32_t kWaves = 2u * WN;
     static constexpr uint32_t kStage = (kDM + kBN) * 128u;  // one k-block (64 halves = 128 B per tile row) of both operands
@@ -49,8 +45,7 @@ constexpr uint32_t kDenseHalf = 128;             // columns per epilogue round
 constexpr uint32_t kDensePitch = kDM + 4;         // floats per column of the transposed result tile (bank spread)
 constexpr uint32_t kDenseLds = kDenseHalf * kDensePitch * 4;  // 133 120 B >= two stages of either shape
 constexpr uint32_t kDenseGroup = 8;  // row tiles whose column tiles run back to back on one XCD (X~ tiles stay in its L2)
-static_assert(2 * DenseShape<4>::kStage <= kDenseLds && 2 * DenseShape<2>::kStage <= kDenseLds &&
-                  2 * DenseShape<2, 4>::kStage <= kDenseLds, "stage buffers fit");
+static_assert(2 * DenseShape<4>::kStage <= kDenseLds && 2 * DenseShape<2>::kStage <= kDenseLds, "stage buffers fit");
 
 // side-byte codes of the dense pass (resolved to 0 / 1 by k_forest_exact_pairs before anything else reads them)
 constexpr uint32_t kSideUndecided = 2u;  // the screen could not decide: reference arithmetic wanted
@@ -77,11 +72,11 @@ struct DenseArgs {
 // whole 128-byte line, so the global side is fully coalesced).  Slot s of tile row R holds chunk s ^ ((R >> 1) & 7):
 // the XOR is applied to the SOURCE address here and again to the ds_read_b128 address of the fragment loads, which makes
 // those conflict-free (their 16-lane groups — rows {0-3,12-15,20-27} etc. at one chunk — then cover all 64 banks).
-template <int WN, int TN>
-__device__ __forceinline__ void dense_stage(const uint8_t *const (&a_src)[DenseShape<WN, TN>::kPiecesA],
-                                            const uint8_t *const (&b_src)[DenseShape<WN, TN>::kPiecesB], uint32_t kb, uint8_t *stage,
+template <int WN>
+__device__ __forceinline__ void dense_stage(const uint8_t *const (&a_src)[DenseShape<WN>::kPiecesA],
+                                            const uint8_t *const (&b_src)[DenseShape<WN>::kPiecesB], uint32_t kb, uint8_t *stage,
                                             uint32_t wave) {
-    typedef DenseShape<WN, TN> SH;
+    typedef DenseShape<WN> SH;
     const uint64_t koff = (uint64_t)kb * 128u;
 #pragma unroll
     for (uint32_t i = 0; i < SH::kPiecesA; i++)
@@ -113,9 +108,9 @@ __global__ void k_dense_coverage(uint32_t group, uint32_t n_col_tiles, uint32_t 
     if (threadIdx.x == 0) atomicAdd(&counts[(uint64_t)rt * n_col_tiles + ct], 1u);
 }
 
-template <int METRIC, int WN, int TN>
-__global__ __launch_bounds__((DenseShape<WN, TN>::kThreads), 1) void k_forest_dense_screen(DenseArgs a, const AbortFlags abort_flag) {
-    typedef DenseShape<WN, TN> SH;
+template <int METRIC, int WN>
+__global__ __launch_bounds__(DenseShape<WN>::kThreads, 1) void k_forest_dense_screen(DenseArgs a, const AbortFlags abort_flag) {
+    typedef DenseShape<WN> SH;
     extern __shared__ uint4 s_dense4[];
     uint8_t *smem = reinterpret_cast<uint8_t *>(s_dense4);
     if (abort_requested(abort_flag)) return;
@@ -147,39 +142,39 @@ __global__ __launch_bounds__((DenseShape<WN, TN>::kThreads), 1) void k_forest_de
     }
     const uint32_t wm = wave / WN, wn = wave % WN;
     const uint32_t m = lane & 31u, g = lane >> 5, swz = (m >> 1) & 7u;
-    f32x16_t acc[4][TN];
+    f32x16_t acc[4][2];
 #pragma unroll
     for (int im = 0; im < 4; im++)
 #pragma unroll
-        for (int jn = 0; jn < TN; jn++)
+        for (int jn = 0; jn < 2; jn++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[im][jn][e] = 0.0f;
 
     const uint32_t nk = a.hpitch >> 6;
-    dense_stage<WN, TN>(a_src, b_src, 0, smem, wave);
+    dense_stage<WN>(a_src, b_src, 0, smem, wave);
     for (uint32_t kb = 0; kb < nk; kb++) {
         // this wave's DMA of stage kb has landed; after the barrier everybody's has, and every wave has finished
         // reading the other buffer (its fragment loads were consumed by the MFMAs of iteration kb - 1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kb + 1 < nk) dense_stage<WN, TN>(a_src, b_src, kb + 1, smem + ((kb + 1) & 1u) * SH::kStage, wave);
+        if (kb + 1 < nk) dense_stage<WN>(a_src, b_src, kb + 1, smem + ((kb + 1) & 1u) * SH::kStage, wave);
         const uint8_t *st = smem + (kb & 1u) * SH::kStage;
         const uint8_t *sa = st + (wm * 128u + m) * 128u;
-        const uint8_t *sb = st + (kDM + wn * (32u * TN) + m) * 128u;
+        const uint8_t *sb = st + (kDM + wn * 64u + m) * 128u;
 #pragma unroll
         for (uint32_t q = 0; q < 4; q++) {
             // k-step q of the block: lanes 0-31 take halves [16 q, +8), lanes 32-63 halves [16 q + 8, +8) of their row —
             // the same assignment for both operands, which is all the product needs (any k order: gamma_s covers it)
             const uint32_t off = ((2u * q + g) ^ swz) << 4;
-            f16x8_t af[4], bf[TN];
+            f16x8_t af[4], bf[2];
 #pragma unroll
             for (int im = 0; im < 4; im++) af[im] = *reinterpret_cast<const f16x8_t *>(sa + im * 32 * 128 + off);
 #pragma unroll
-            for (int jn = 0; jn < TN; jn++) bf[jn] = *reinterpret_cast<const f16x8_t *>(sb + jn * 32 * 128 + off);
+            for (int jn = 0; jn < 2; jn++) bf[jn] = *reinterpret_cast<const f16x8_t *>(sb + jn * 32 * 128 + off);
 #pragma unroll
             for (int im = 0; im < 4; im++)
 #pragma unroll
-                for (int jn = 0; jn < TN; jn++)
+                for (int jn = 0; jn < 2; jn++)
                     acc[im][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[im], bf[jn], acc[im][jn], 0, 0, 0);
         }
     }
@@ -206,12 +201,12 @@ __global__ __launch_bounds__((DenseShape<WN, TN>::kThreads), 1) void k_forest_de
         const uint32_t c_lo = c0 + h * kDenseHalf;
         if (c_lo >= a.n_cols) break;  // block-uniform
         __syncthreads();  // the stage buffers (round 0) / the previous round's tile are dead
-        if ((wn * (32u * TN)) / kDenseHalf == h) {  // this wave's columns belong to the round
+        if ((wn >> 1) == h) {
 #pragma unroll
             for (int im = 0; im < 4; im++)
 #pragma unroll
-                for (int jn = 0; jn < TN; jn++) {
-                    const uint32_t col = (wn * (32u * TN)) % kDenseHalf + (uint32_t)jn * 32u + m;
+                for (int jn = 0; jn < 2; jn++) {
+                    const uint32_t col = (wn & 1u) * 64u + (uint32_t)jn * 32u + m;
 #pragma unroll
                     for (int qq = 0; qq < 4; qq++) {
                         const uint32_t rr = wm * 128u + (uint32_t)im * 32u + 8u * (uint32_t)qq + 4u * g;

@@ -2630,26 +2630,24 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     const uint64_t dgrid = dp.grid;
                     AH_REQUIRE(dgrid < 0x7FFFFFFFull, AH_ERR_INVALID_ARGUMENT, "forest build: too many tiles for one launch");
                     const unsigned egrid = exact_pairs_grid(N, n_trees);
-#define AH_DENSE_WN(M, WNV, TNV)                                                                                         \
+#define AH_DENSE_WN(M, WNV)                                                                                              \
     do {                                                                                                                 \
         static std::atomic<bool> dense_opt_in[64]; /* once per instantiation and device */                              \
         if (!dense_opt_in[ds->device & 63].load(std::memory_order_acquire)) {                                            \
-            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_dense_screen<M, WNV, TNV>),               \
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_dense_screen<M, WNV>),                    \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseLds));                     \
             dense_opt_in[ds->device & 63].store(true, std::memory_order_release);                                        \
         }                                                                                                                \
-        hipLaunchKernelGGL((k_forest_dense_screen<M, WNV, TNV>), dim3((unsigned)dgrid),                                  \
-                           dim3(DenseShape<WNV, TNV>::kThreads), kDenseLds, s, da, d_abort);                             \
+        hipLaunchKernelGGL((k_forest_dense_screen<M, WNV>), dim3((unsigned)dgrid), dim3(DenseShape<WNV>::kThreads),      \
+                           kDenseLds, s, da, d_abort);                                                                   \
     } while (0)
 #define AH_DENSE(M)                                                                                                      \
     do {                                                                                                                 \
-        if (wide && wave128) AH_DENSE_WN(M, 2, 4);                                                                       \
-        else if (wide) AH_DENSE_WN(M, 4, 2);                                                                             \
-        else AH_DENSE_WN(M, 2, 2);                                                                                       \
+        if (wide) AH_DENSE_WN(M, 4);                                                                                     \
+        else AH_DENSE_WN(M, 2);                                                                                          \
         hipLaunchKernelGGL((k_forest_exact_pairs<M>), dim3(egrid), dim3(256), 0, s, dv, node_of.p, side_bytes.p,         \
                            n_trees, chunk_d, nstride, hdr_off, d_counters, d_abort);                                     \
     } while (0)
-                    const bool wave128 = tun(TUN_DENSE_WAVE128) != 0;
                     switch (ds->metric) {
                     case AH_EUCLIDEAN: AH_DENSE(AH_EUCLIDEAN); break;
                     case AH_MANHATTAN: AH_DENSE(AH_MANHATTAN); break;
