@@ -633,9 +633,16 @@ __global__ __launch_bounds__(kBlock) void k_batch_topk_select(const Seg *__restr
     __syncthreads();
     const uint32_t w_min = s_min;
     const uint64_t span = (uint64_t)(s_max - w_min) + 1ull;
+    // bin(w) = floor((w - w_min) * scale / 2^32), scale = floor(2048 * 2^32 / span): monotone, < 2048; one 64-bit division
+    // per block instead of one per key.  Fewer than 2048 distinct words: every word its own bin.
+    const bool direct = span <= kSelBins;
+    const uint32_t scale = direct ? 0u : (uint32_t)(((uint64_t)kSelBins << 32) / span);
+    auto bin_of = [&](uint32_t w) -> uint32_t {
+        return direct ? w - w_min : (uint32_t)(((uint64_t)(w - w_min) * scale) >> 32);
+    };
     for (uint32_t g = threadIdx.x; g < sg.n; g += kBlock) {
         const uint32_t w = (uint32_t)(select_key(dist, ids, sg.off, g, two_k) >> 32);
-        atomicAdd(&s_hist[(uint32_t)(((uint64_t)(w - w_min) * kSelBins) / span)], 1u);
+        atomicAdd(&s_hist[bin_of(w)], 1u);
     }
     __syncthreads();
     {  // the bin of the k-th smallest key: thread t owns bins 8t .. 8t+7
@@ -673,7 +680,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_topk_select(const Seg *__restr
     for (uint32_t g = threadIdx.x; g < sg.n; g += kBlock) {
         const uint64_t key = select_key(dist, ids, sg.off, g, two_k);
         const uint32_t w = (uint32_t)(key >> 32);
-        if ((uint32_t)(((uint64_t)(w - w_min) * kSelBins) / span) <= bin_k) s_cand[atomicAdd(&s_n, 1u)] = key;
+        if (bin_of(w) <= bin_k) s_cand[atomicAdd(&s_n, 1u)] = key;
     }
     __syncthreads();
     uint32_t p2 = 64;
