@@ -63,6 +63,8 @@ def parse_args():
                     help="skip the 10M x 768 x 100-tree build (BASELINE configs[2], the 'tree-build seconds at 10M' of the metric)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--no-extra", action="store_true", help="skip configs[3] / configs[4] / on-device search")
+    ap.add_argument("--no-search", action="store_true", help="skip the on-device search leg (the PMC passes: its small "
+                                                              "submissions share the re-rank kernel and would skew its per-launch mean)")
     ap.add_argument("--no-e2e", action="store_true",
                     help="build_10m from rows generated in HBM instead of 10M x 768 rows staged from host memory (skips the "
                          "cold end-to-end figures and the configs[2] CPU baseline, which share the host copy)")
@@ -543,7 +545,8 @@ def device_work(args, rank, world, device, sync, ds_1m, result):
         if not args.no_extra and n == N_ITEMS:
             extra["bq_scan"] = extra_c5(device)
             extra["rerank"] = extra_c4(device)
-            extra["search"] = extra_search(device)
+            if not args.no_search:
+                extra["search"] = extra_search(device)
         if "metrics" in wanted:
             extra["metrics"] = extra_metrics(device)
         if "staging" in wanted:

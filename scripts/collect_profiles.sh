@@ -12,8 +12,8 @@ mkdir -p $OUT
 python bench.py --steps 50 --warmup 5 2>$OUT/${R}_bench.err | tail -1 > $OUT/${R}_bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python bench.py --steps 50 --warmup 5 --no-cpu --no-build-10m > $OUT/kt.log 2>&1
 cp $OUT/kt/kt_kernel_stats.csv $OUT/${R}_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- env AH_BENCH_SEARCH_QUERIES=64 python bench.py --steps 5 --warmup 1 --no-cpu --no-build > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- env AH_BENCH_SEARCH_QUERIES=64 python bench.py --steps 5 --warmup 1 --no-cpu --no-build > $OUT/write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python bench.py --steps 5 --warmup 1 --no-cpu --no-build --no-search > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python bench.py --steps 5 --warmup 1 --no-cpu --no-build --no-search > $OUT/write.log 2>&1
 python scripts/pmc_summary.py $OUT/fetch/fetch_counter_collection.csv | grep -v "^[0-9]" > $OUT/${R}_pmc_fetch_size.csv
 python scripts/pmc_summary.py $OUT/write/write_counter_collection.csv | grep -v "^[0-9]" > $OUT/${R}_pmc_write_size.csv
 python scripts/pmc_kernels_json.py $OUT/${R}_pmc_fetch_size.csv $OUT/${R}_pmc_write_size.csv > $OUT/${R}_pmc_kernels.json

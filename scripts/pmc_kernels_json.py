@@ -38,5 +38,5 @@ for key, needle in KERNELS.items():
     }
 out["correction"] = ("reads = FETCH_SIZE x 1024 x 2 (gfx950: the counter tallies 128-byte requests at 64 bytes), writes = "
                      "WRITE_SIZE x 1024; mean over the dispatches of the profiled `python bench.py --steps 5 --warmup 1 "
-                     "--no-cpu --no-build` run")
+                     "--no-cpu --no-build --no-search` run")
 print(json.dumps(out, indent=1))
