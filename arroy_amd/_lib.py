@@ -92,7 +92,8 @@ class AhBuildStats(C.Structure):
                 ("screen_fallbacks", C.c_uint64), ("screen_violations", C.c_uint64),
                 ("dense_launches", C.c_uint64), ("dense_columns", C.c_uint64),
                 ("rows_xcd_launches", C.c_uint64), ("rows_nt_launches", C.c_uint64), ("rows_split_launches", C.c_uint64),
-                ("screen8_pairs", C.c_uint64), ("screen8_decided", C.c_uint64), ("screen_unavailable", C.c_uint32),
+                ("screen8_pairs", C.c_uint64), ("screen8_decided", C.c_uint64), ("screen8b_decided", C.c_uint64),
+                ("screen_unavailable", C.c_uint32),
                 ("reserved0", C.c_uint32)]
 
 

@@ -452,6 +452,7 @@ int ah_dataset_destroy(ah_dataset *ds) {
     ds->pool.clear();
     if (ds->d_rows_h16) (void)hipFree(ds->d_rows_h16);
     if (ds->d_rows_i8) (void)hipFree(ds->d_rows_i8);
+    if (ds->d_rows_i8_lo) (void)hipFree(ds->d_rows_i8_lo);
     if (ds->d_scale8_rows) (void)hipFree(ds->d_scale8_rows);
     if (ds->d_dim_scale) (void)hipFree(ds->d_dim_scale);
     if (ds->d_screen_stats) (void)hipFree(ds->d_screen_stats);

@@ -82,6 +82,7 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
     X(SCREEN, "AH_SCREEN", 1)                   /* 0: reference f32 arithmetic only (as AH_MARGIN_EXACT_ONLY) */          \
     X(SCREEN_VERIFY, "AH_SCREEN_VERIFY", 0)     /* 1: screened kernels evaluate f32 for EVERY pair, count violations */  \
     X(NODE_PREFETCH, "AH_NODE_PREFETCH", 1)     /* 0: no software pipeline in the int8 stage of the node-major screen */    \
+    X(SCREEN8_LO, "AH_SCREEN8_LO", 1)           /* 0: no second int8 digit of the rows (stage 1 = the binary16 row) */      \
     X(SCREEN8, "AH_SCREEN8", -1)                /* 0: no int8 first stage; 1: keep it whatever the data; -1: by quality */ \
     X(DENSE, "AH_DENSE", -1)                    /* 0: never the dense MFMA screen; 1: whenever legal; -1: cost model */    \
     X(DENSE_MAX_COLS, "AH_DENSE_MAX_COLS", 16384)                                                                        \
@@ -152,6 +153,10 @@ struct ScreenView {
     uint32_t pitch8;  // bytes per row, a multiple of 128
     const float *scale8_rows;
     float4 max8;
+    // the rows' second int8 digit (x / d ~ s_r (q + q2 / 256)): read instead of the binary16 row by the pairs the first
+    // digit cannot decide; max8b = {max |q + q2/256|, max |x/d/s_r - q - q2/256|, max |x|/s_r, 0}.  nullptr = not built
+    const int8_t *rows8_lo;
+    float4 max8b;
 };
 
 // One per concurrently calling host thread: a stream plus growable device / pinned scratch.
@@ -193,10 +198,11 @@ struct ah_dataset {
     float4 *d_screen_stats = nullptr;
     float screen_max[4] = {0.f, 0.f, 0.f, 0.f};  // component-wise maximum of the per-row stats (host copy)
     int8_t *d_rows_i8 = nullptr;                 // int8 copy for the first screen stage (nullptr: not built / not useful)
+    int8_t *d_rows_i8_lo = nullptr;              // its second digit (stage 1 of the node-major screen), optional
     float *d_scale8_rows = nullptr;              // its scale per row
     float *d_dim_scale = nullptr;                // 2 x pitch8 floats: the power-of-two scale of every dimension, then its inverse
     uint32_t pitch8 = 0;
-    float screen8_max[3] = {0.f, 0.f, 0.f};
+    float screen8_max[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // {|q|, |y/s - q|, |x|/s, |q + q2/256|, |y/s - q - q2/256|} maxima
     double screen8_quality = 0.0;                // expected undecided share indicator (forest.hip: ensure_screen)
     uint32_t hpitch = 0;
     bool screen_never = false;                   // the screen can never apply to this dataset (1-bit metric, dims < 32)

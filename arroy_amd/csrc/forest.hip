@@ -67,7 +67,7 @@ struct LevelInfo {
     // followed by uint32_t tree_first[n_trees + 1]
 };
 struct ScreenCounters {
-    unsigned long long fallbacks, violations, stage8_pairs, stage8_decided;
+    unsigned long long fallbacks, violations, stage8_pairs, stage8_decided, stage8b_decided, pad;
 };
 struct FTile {
     uint32_t node;
@@ -774,20 +774,24 @@ __device__ __forceinline__ uint32_t octet_max_u32(uint32_t v) {
 }
 // rows -> int8 copy with one scale per row; max_bits[0..2] = max over the rows of |q|, |y / s_r - q|, |x| / s_r (rounded up).
 // One octet per row: a pass for the row's max |y|, a pass that quantises (the row comes back from L2).
+// rows8_lo: the rows' SECOND int8 digit, q2 = round((y / s_r - q) 256) (stage 1 of the node-major screen: a pair the first
+// digit cannot decide reads 768 more bytes instead of the 1536-byte binary16 row); max_bits[3..4] = max |q + q2/256| and
+// max |y / s_r - q - q2/256|.
 __global__ __launch_bounds__(kBlock) void k_shadow_rows8(DataView dv, const float *__restrict__ inv_d, int8_t *__restrict__ rows8,
-                                                         uint32_t pitch8, float *__restrict__ row_scale,
-                                                         uint32_t *__restrict__ max_bits) {
-    __shared__ uint32_t s_m[3];
-    if (threadIdx.x < 3) s_m[threadIdx.x] = 0u;
+                                                         int8_t *__restrict__ rows8_lo, uint32_t pitch8,
+                                                         float *__restrict__ row_scale, uint32_t *__restrict__ max_bits) {
+    __shared__ uint32_t s_m[5];
+    if (threadIdx.x < 5) s_m[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t j = threadIdx.x & 7u;
     const uint64_t n_octets = ((uint64_t)gridDim.x * blockDim.x) >> 3;
     const uint32_t blocks = dv.pitch >> 5;
     const float4 *id4 = reinterpret_cast<const float4 *>(inv_d) + j;
-    float ma = 0.f, mb = 0.f, mc = 0.f;
+    float ma = 0.f, mb = 0.f, mc = 0.f, ma2 = 0.f, mb2 = 0.f;
     for (uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; row < dv.n; row += n_octets) {
         const float4 *r4 = reinterpret_cast<const float4 *>(dv.rows_f32 + row * dv.pitch) + j;
         uint32_t *o = reinterpret_cast<uint32_t *>(rows8 + row * pitch8);
+        uint32_t *o2 = reinterpret_cast<uint32_t *>(rows8_lo + row * pitch8);
         uint32_t mbits = 0u, xbits = 0u;  // max |y|, max |x| (non-finite values end up on top)
         for (uint32_t k = 0; k < blocks; k++) {
             const float4 x = r4[k * 8];  // (the padding of a row is zero)
@@ -803,7 +807,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow_rows8(DataView dv, const floa
         const bool ok = mbits >= kTinyBits && xbits >= kTinyBits && mbits < 0x7F800000u && xbits < 0x7F800000u;
         const float m = __uint_as_float(mbits);
         const float scale = ok ? m / 127.0f : 0.0f, inv_scale = ok ? 127.0f / m : 0.0f;
-        float sa = 0.f, sb = 0.f, sc = 0.f;
+        float sa = 0.f, sb = 0.f, sc = 0.f, sa2 = 0.f, sb2 = 0.f;
         for (uint32_t k = 0; k < blocks; k++) {
             float4 x = ld_stream(r4 + k * 8);
             const float4 g = id4[k * 8];
@@ -812,20 +816,35 @@ __global__ __launch_bounds__(kBlock) void k_shadow_rows8(DataView dv, const floa
             if (e0 + 1 >= dv.dims) x.y = 0.0f;
             if (e0 + 2 >= dv.dims) x.z = 0.0f;
             if (e0 + 3 >= dv.dims) x.w = 0.0f;
-            const float y0 = x.x * g.x, y1 = x.y * g.y, y2 = x.z * g.z, y3 = x.w * g.w;  // exact: g is a power of two
-            const int q0 = quantize8(y0, inv_scale), q1 = quantize8(y1, inv_scale), q2 = quantize8(y2, inv_scale),
-                      q3 = quantize8(y3, inv_scale);
-            const float z0 = (float)q0 * scale, z1 = (float)q1 * scale, z2 = (float)q2 * scale, z3 = (float)q3 * scale;
-            sa += (float)(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);  // exact integers (< 2^24 per lane up to 8000 dims)
-            const float d0 = y0 - z0, d1 = y1 - z1, d2 = y2 - z2, d3 = y3 - z3;
-            sb += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            const float y[4] = {x.x * g.x, x.y * g.y, x.z * g.z, x.w * g.w};  // exact: g is a power of two
+            uint32_t w1 = 0u, w2 = 0u;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float t = y[c] * inv_scale;
+                const int q = quantize8(y[c], inv_scale);
+                const int r = (int)fminf(fmaxf(rintf((t - (float)q) * 256.0f), -127.0f), 127.0f);
+                const float z = (float)q * scale, z2 = ((float)q + (float)r * 0.00390625f) * scale;  // the digits sum exactly
+                sa += (float)(q * q);  // exact integers (< 2^24 per lane up to 8000 dims)
+                const float d = y[c] - z, d2 = y[c] - z2, v2 = (float)q + (float)r * 0.00390625f;
+                sb += d * d;
+                sa2 += v2 * v2;
+                sb2 += d2 * d2;
+                w1 |= ((uint32_t)q & 0xFFu) << (8 * c);
+                w2 |= ((uint32_t)r & 0xFFu) << (8 * c);
+            }
             sc += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
-            o[k * 8 + j] = ((uint32_t)q0 & 0xFFu) | (((uint32_t)q1 & 0xFFu) << 8) | (((uint32_t)q2 & 0xFFu) << 16) | (((uint32_t)q3 & 0xFFu) << 24);
+            o[k * 8 + j] = w1;
+            if (rows8_lo) o2[k * 8 + j] = w2;
         }
-        for (uint32_t w = (dv.pitch >> 2) + j; w < (pitch8 >> 2); w += 8) o[w] = 0u;  // zero tail of the int8 row
+        for (uint32_t w = (dv.pitch >> 2) + j; w < (pitch8 >> 2); w += 8) {  // zero tail of the int8 rows
+            o[w] = 0u;
+            if (rows8_lo) o2[w] = 0u;
+        }
         sa = octet_sum(sa);
         sb = octet_sum(sb);
         sc = octet_sum(sc);
+        sa2 = octet_sum(sa2);
+        sb2 = octet_sum(sb2);
         if (j == 0) row_scale[row] = ok ? scale : __uint_as_float(0x7F800000u);  // inf: the row never decides here
         if (ok) {
             // in units of the row's scale, rounded UP: f32 sums of squares (relative error < (pitch + 8) 2^-24), the
@@ -834,13 +853,17 @@ __global__ __launch_bounds__(kBlock) void k_shadow_rows8(DataView dv, const floa
             ma = fmaxf(ma, sqrtf(sa) * up);
             mb = fmaxf(mb, (sqrtf(sb) * up + 127.0f * scale * 6.0e-8f * sqrtf((float)dv.pitch)) / scale * 1.000001f);
             mc = fmaxf(mc, sqrtf(sc) * up / scale * 1.000001f);
+            ma2 = fmaxf(ma2, sqrtf(sa2) * up);
+            mb2 = fmaxf(mb2, (sqrtf(sb2) * up + 128.0f * scale * 6.0e-8f * sqrtf((float)dv.pitch)) / scale * 1.000001f);
         }
     }
     atomicMax(&s_m[0], __float_as_uint(ma));
     atomicMax(&s_m[1], __float_as_uint(mb));
     atomicMax(&s_m[2], __float_as_uint(mc));
+    atomicMax(&s_m[3], __float_as_uint(ma2));
+    atomicMax(&s_m[4], __float_as_uint(mb2));
     __syncthreads();
-    if (threadIdx.x < 3) atomicMax(&max_bits[threadIdx.x], s_m[threadIdx.x]);
+    if (threadIdx.x < 5) atomicMax(&max_bits[threadIdx.x], s_m[threadIdx.x]);
 }
 // The level's normals -> int8 records [pitch8 bytes q_hi][pitch8 bytes q_lo][NormalStats8], one wave per pending node.
 __global__ __launch_bounds__(64) void k_forest_shadow_normals8(DataView dv, const FNode *__restrict__ nodes, uint32_t n_nodes,
@@ -1048,7 +1071,7 @@ __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, Scre
                                                                const AbortFlags abort_flag,
                                                                ScreenCounters *__restrict__ counters, uint32_t verify) {
     extern __shared__ float4 s_n4[];  // [pitch floats f32 normal][hpitch halves shadow normal][2 x pitch8 bytes: the int8 digits]
-    __shared__ uint32_t s_left, s_fb, s_bad, s_n8, s_d8;
+    __shared__ uint32_t s_left, s_fb, s_bad, s_n8, s_d8, s_d8b;
     const float *s_n = reinterpret_cast<const float *>(s_n4);
     const uint4 *s_h4 = reinterpret_cast<const uint4 *>(s_n4 + (dv.pitch >> 2));
     const uint4 *s_q4 = s_h4 + (sv.hpitch >> 3);        // q_hi
@@ -1057,7 +1080,7 @@ __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, Scre
     const uint32_t steps8 = sv.pitch8 >> 7;
     const uint32_t o = threadIdx.x >> 3, j = threadIdx.x & 7u;
     const uint32_t steps = sv.hpitch >> 6;
-    uint32_t fallbacks = 0, bad = 0, met8 = 0, decided8 = 0;
+    uint32_t fallbacks = 0, bad = 0, met8 = 0, decided8 = 0, decided8b = 0;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (abort_requested(abort_flag)) return;
         const FTile tl = tiles[tile];
@@ -1126,11 +1149,17 @@ __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, Scre
             if (stage8) {  // first stage: the int8 copy, 768 bytes of a 768-d row; bound from the dataset-wide maxima
                 const uint4 *r8 = reinterpret_cast<const uint4 *>(sv.rows8 + row * sv.pitch8) + j;
                 const float s_row = METRIC == AH_COSINE ? 1.0f : sv.scale8_rows[row];  // a cosine margin's sign needs no scale
-                const float s8 = (PRE > 0 ? screen8_octet_dot_regs<NPRE>(s_q4 + j, s_ql4 + j, x, steps8)
-                                          : screen8_octet_dot(s_q4 + j, s_ql4 + j, r8, steps8)) * ns8.scale;
-                decided = screen8_decides<METRIC>(s8, s_row, sv.max8, ns8, sv.gamma_r, side);
+                const float u8 = PRE > 0 ? screen8_octet_dot_regs<NPRE>(s_q4 + j, s_ql4 + j, x, steps8)
+                                         : screen8_octet_dot(s_q4 + j, s_ql4 + j, r8, steps8);
+                decided = screen8_decides<METRIC>(u8 * ns8.scale, s_row, sv.max8, ns8, sv.gamma_r, side);
                 met8++;
                 decided8 += decided ? 1u : 0u;
+                if (!decided && sv.rows8_lo != nullptr) {  // octet-uniform: the row's second int8 digit (768 more bytes)
+                    const uint4 *r8l = reinterpret_cast<const uint4 *>(sv.rows8_lo + row * sv.pitch8) + j;
+                    const float u8b = u8 + screen8_octet_dot(s_q4 + j, s_ql4 + j, r8l, steps8) * 0.00390625f;
+                    decided = screen8_decides<METRIC>(u8b * ns8.scale, s_row, sv.max8b, ns8, sv.gamma_r, side);
+                    decided8b += decided ? 1u : 0u;
+                }
             }
             if (!decided) {  // octet-uniform: second stage, the binary16 copy
                 const uint4 *r4 = reinterpret_cast<const uint4 *>(sv.rows + row * sv.hpitch) + j;
@@ -1162,18 +1191,20 @@ __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, Scre
     }
     // statistics: one atomic per block
     __syncthreads();
-    if (threadIdx.x == 0) s_fb = s_bad = s_n8 = s_d8 = 0;
+    if (threadIdx.x == 0) s_fb = s_bad = s_n8 = s_d8 = s_d8b = 0;
     __syncthreads();
     if (j == 0 && fallbacks) atomicAdd(&s_fb, fallbacks);
     if (j == 0 && bad) atomicAdd(&s_bad, bad);
     if (j == 0 && met8) atomicAdd(&s_n8, met8);
     if (j == 0 && decided8) atomicAdd(&s_d8, decided8);
+    if (j == 0 && decided8b) atomicAdd(&s_d8b, decided8b);
     __syncthreads();
     if (threadIdx.x == 0) {
         if (s_fb) atomicAdd(&counters->fallbacks, (unsigned long long)s_fb);
         if (s_bad) atomicAdd(&counters->violations, (unsigned long long)s_bad);
         if (s_n8) atomicAdd(&counters->stage8_pairs, (unsigned long long)s_n8);
         if (s_d8) atomicAdd(&counters->stage8_decided, (unsigned long long)s_d8);
+        if (s_d8b) atomicAdd(&counters->stage8b_decided, (unsigned long long)s_d8b);
     }
 }
 
@@ -1806,21 +1837,27 @@ static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force) {
     const DataView dv = ds->view();
     const uint32_t pitch8 = (ds->dims + 127u) & ~127u;
     const unsigned grid = (unsigned)std::min<uint64_t>((ds->n + 31) / 32, 1u << 20);
-    int8_t *rows8 = nullptr;
+    int8_t *rows8 = nullptr, *rows8_lo = nullptr;
     float *scales = nullptr, *dimsc = nullptr;
-    uint32_t *d_m = nullptr;  // [pitch8 column maxima][3 row maxima + pad]
-    uint32_t h_m[4] = {0u, 0u, 0u, 0u};
+    uint32_t *d_m = nullptr;  // [pitch8 column maxima][5 row maxima + pad]
+    uint32_t h_m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    // the rows' second digit is optional: without the memory for it stage 1 is simply the binary16 row
+    if (tun(TUN_SCREEN8_LO) != 0 && hipMalloc((void **)&rows8_lo, ds->n * (size_t)pitch8) != hipSuccess) {
+        (void)hipGetLastError();
+        rows8_lo = nullptr;
+    }
     bool ok = hipMalloc((void **)&rows8, ds->n * (size_t)pitch8) == hipSuccess &&
               hipMalloc((void **)&scales, ds->n * sizeof(float)) == hipSuccess &&
               hipMalloc((void **)&dimsc, 2 * (size_t)pitch8 * sizeof(float)) == hipSuccess &&
-              hipMalloc((void **)&d_m, ((size_t)pitch8 + 4) * 4) == hipSuccess;
+              hipMalloc((void **)&d_m, ((size_t)pitch8 + 8) * 4) == hipSuccess;
     const bool alloc_ok = ok;
-    ok = ok && hipMemsetAsync(d_m, 0, ((size_t)pitch8 + 4) * 4, s) == hipSuccess;
+    ok = ok && hipMemsetAsync(d_m, 0, ((size_t)pitch8 + 8) * 4, s) == hipSuccess;
     if (ok) {
         hipLaunchKernelGGL(k_col_maxabs, dim3((unsigned)std::min<uint64_t>(4096, (ds->n + 255) / 256)), dim3(256), 0, s, dv, d_m);
         hipLaunchKernelGGL(k_dim_scales, dim3((pitch8 + 255) / 256), dim3(256), 0, s, d_m, ds->dims, pitch8, dimsc, dimsc + pitch8);
-        hipLaunchKernelGGL(k_shadow_rows8, dim3(grid), dim3(kBlock), 0, s, dv, dimsc + pitch8, rows8, pitch8, scales, d_m + pitch8);
-        ok = hipMemcpyAsync(h_m, d_m + pitch8, 12, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+        hipLaunchKernelGGL(k_shadow_rows8, dim3(grid), dim3(kBlock), 0, s, dv, dimsc + pitch8, rows8, rows8_lo, pitch8, scales,
+                           d_m + pitch8);
+        ok = hipMemcpyAsync(h_m, d_m + pitch8, 20, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
     }
     bool keep = false;
     if (ok) {
@@ -1834,6 +1871,8 @@ static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force) {
         keep = std::isfinite(a8) && std::isfinite(b8) && std::isfinite(c8) && a8 > 0.0f && (force || quality < 0.6);
         if (keep) {
             ds->d_rows_i8 = rows8;
+            ds->d_rows_i8_lo = rows8_lo;
+            memcpy(&ds->screen8_max[3], &h_m[3], 8);
             ds->d_scale8_rows = scales;
             ds->d_dim_scale = dimsc;
             ds->pitch8 = pitch8;
@@ -1847,6 +1886,7 @@ static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force) {
         if (alloc_ok) ds->screen8_decided = true;  // a device fault, not a lack of memory: do not loop on it
     }
     if (!keep) {
+        if (rows8_lo) (void)hipFree(rows8_lo);
         if (rows8) (void)hipFree(rows8);
         if (scales) (void)hipFree(scales);
         if (dimsc) (void)hipFree(dimsc);
@@ -2192,15 +2232,15 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     AH_TRY(d_block_sums.ensure(max_nodes / 256 + 2));
     // small device block: [abort flag, 3 pad][ScreenCounters][LevelInfo + tree_first[n_trees + 1]]
     const size_t info_words = (sizeof(LevelInfo) + ((size_t)n_trees + 1) * 4 + 3) / 4;
-    AH_TRY(d_small.ensure(4 + 8 + info_words));
+    AH_TRY(d_small.ensure(4 + 12 + info_words));
     const AbortFlags d_abort{d_small.p};
     ScreenCounters *d_counters = reinterpret_cast<ScreenCounters *>(d_small.p + 4);
-    LevelInfo *d_info = reinterpret_cast<LevelInfo *>(d_small.p + 12);
+    LevelInfo *d_info = reinterpret_cast<LevelInfo *>(d_small.p + 16);
     uint32_t *d_tree_first = reinterpret_cast<uint32_t *>(d_info + 1);
     DevBuf<uint32_t> d_tree_first_buf;  // first node of every tree of the level, gaps closed (LDS variant of the row pass)
     AH_TRY(d_tree_first_buf.ensure((size_t)n_trees + 2));
     uint32_t *d_tree_first_fixed = d_tree_first_buf.p;
-    AH_HIP(hipMemsetAsync(d_small.p, 0, (12 + info_words) * 4, s));
+    AH_HIP(hipMemsetAsync(d_small.p, 0, (16 + info_words) * 4, s));
 
     // pinned host memory: [2 x LevelInfo block][one word for the abort flag][2 x node table][read-back bounce]
     const size_t kBounce = 64ull << 20;  // pinned double buffer of the read-back worker
@@ -2239,6 +2279,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         sv.pitch8 = ds->pitch8;
         sv.scale8_rows = ds->d_scale8_rows;
         sv.max8 = make_float4(ds->screen8_max[0], ds->screen8_max[1], ds->screen8_max[2], 0.0f);
+        sv.rows8_lo = tun(TUN_SCREEN8_LO) != 0 ? ds->d_rows_i8_lo : nullptr;  // nullptr: stage 1 is the binary16 row
+        sv.max8b = make_float4(ds->screen8_max[3], ds->screen8_max[4], ds->screen8_max[2], 0.0f);
         sv.hpitch = ds->hpitch;
         // accumulation-error factors (screen_device.h), each with a 4x safety factor over the standard model:
         //   screen: hpitch/16 dot2c per lane (2 roundings each) + 4 adds;  reference: dims/32 FMAs per chain, 6 adds of
@@ -2929,6 +2971,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         forest->stats.screen_violations += sc.violations;
         forest->stats.screen8_pairs += sc.stage8_pairs;
         forest->stats.screen8_decided += sc.stage8_decided;
+        forest->stats.screen8b_decided += sc.stage8b_decided;
         rb.push(forest->descendants + desc_base, final_perm.p, M * 4);  // lands while the host emits the node list
     }
     float ms = 0.0f;

@@ -317,7 +317,9 @@ typedef struct ah_build_stats {
     uint64_t rows_nt_launches;    /* ... of which streamed the rows with non-temporal loads                             */
     uint64_t rows_split_launches; /* extra launches of passes cut at the work-item limit of one dispatch                */
     uint64_t screen8_pairs;       /* (item, node) pairs that met the int8 first stage of the node-major screen          */
-    uint64_t screen8_decided;     /* ... of which that stage decided (the rest went on to the binary16 stage)           */
+    uint64_t screen8_decided;     /* ... of which its first digit decided (768 bytes of a 768-d row)                    */
+    uint64_t screen8b_decided;    /* ... and of the rest, decided by the rows' second int8 digit (768 more bytes); what is
+                                     left goes on to the binary16 stage                                                  */
     uint32_t screen_unavailable;  /* the build wanted the screen but its copies could not be allocated: f32 arithmetic  */
     uint32_t reserved0;
 } ah_build_stats;

@@ -42,7 +42,12 @@ def dim_scales(X):
     return d
 
 
-def stage_int8(X, nv, dims, bias=None):
+def stage_int8_lo(X, nv, dims, bias=None):
+    """Stage 1 of the node-major screen: stage 0 plus the rows' second int8 digit (k_shadow_rows8's rows8_lo)."""
+    return stage_int8(X, nv, dims, bias=bias, second_digit=True)
+
+
+def stage_int8(X, nv, dims, bias=None, second_digit=False):
     """(screen value, bound) of every row against `nv`, as stage 0 of k_forest_screen_node computes them: rows scaled per
     dimension (powers of two) and per row, the normal in two int8 digits; cosine (bias None) in units of the row's scale,
     Euclidean / Manhattan in real units."""
@@ -58,11 +63,15 @@ def stage_int8(X, nv, dims, bias=None):
     if not ok.any():  # the device keeps no int8 copy of such a dataset (ensure_screen8: max |q| == 0)
         return np.zeros(len(X), dtype=F), np.full(len(X), F(np.inf), dtype=F)
     q = np.clip(np.rint(Y * inv), -127, 127).astype(np.int32)
-    z = q.astype(F) * scale
+    q2 = np.zeros_like(q)
+    if second_digit:  # q2 = round((y / s_r - q) 256), the value the device rebuilds is (q + q2 / 256) s_r
+        q2 = np.clip(np.rint(((Y * inv).astype(F) - q.astype(F)) * F(256.0)), -127, 127).astype(np.int32)
+    v = (q.astype(F) + q2.astype(F) * F(0.00390625)).astype(F)
+    z = (v * scale).astype(F)
     with np.errstate(divide="ignore", invalid="ignore"):
         up = UP(pitch8) * F(1.000001)
-        a8 = (np.sqrt((q.astype(np.int64) ** 2).sum(axis=1)).astype(F) * up)[ok].max()
-        b8 = ((norm_up(Y - z, pitch8) * F(1.000001) + F(127.0) * scale[:, 0] * F(6.0e-8) * np.sqrt(F(pitch8))) / scale[:, 0] * F(1.000001))[ok].max()
+        a8 = (norm_up(v, pitch8) * F(1.000001))[ok].max()
+        b8 = ((norm_up(Y - z, pitch8) * F(1.000001) + F(128.0) * scale[:, 0] * F(6.0e-8) * np.sqrt(F(pitch8))) / scale[:, 0] * F(1.000001))[ok].max()
         c8 = (norm_up(X, pitch8) * F(1.000001) / scale[:, 0] * F(1.000001))[ok].max()
     nd = (nv * d).astype(F)                                 # exact
     mn = F(np.abs(nd).max())
@@ -73,7 +82,10 @@ def stage_int8(X, nv, dims, bias=None):
     yn = ((qh.astype(F) + ql.astype(F) * F(0.00390625)) * sn).astype(F)
     an, cn, cn0 = norm_up(yn, pitch8), norm_up(nd, pitch8), norm_up(nv, pitch8)
     bn = norm_up(nd - yn, pitch8) + F(128.0) * sn * F(6.0e-8) * np.sqrt(F(pitch8))
-    S = ((q @ qh).astype(F) + (q @ ql).astype(F) * F(0.00390625)) * sn  # exact integer dots, one scale product
+    S = ((q @ qh).astype(F) + (q @ ql).astype(F) * F(0.00390625)).astype(F)  # exact integer dots
+    if second_digit:
+        S = (S + ((q2 @ qh).astype(F) + (q2 @ ql).astype(F) * F(0.00390625)).astype(F) * F(0.00390625)).astype(F)
+    S = (S * sn).astype(F)
     e = bn * a8 + cn * b8 + F(2.0e-6) * (an * a8) + gamma_r(dims) * (cn0 * c8)
     if bias is None:
         return S.astype(F), np.full(len(X), F(e * F(1.002) + F(1e-30)), dtype=F)
@@ -128,24 +140,27 @@ def test_a_decided_pair_never_has_the_wrong_sign(name, X):
     dims = X.shape[1]
     data = O.Data(O.COSINE, X)
     rng = np.random.default_rng(dims)
-    decided8 = decided16 = total = 0
+    decided8 = decided8b = decided16 = total = 0
     for _ in range(6):
         nv, nh = data.create_split(rng.choice(len(X), 12, replace=False).astype(np.uint32))  # a real two-means normal
         nv = np.asarray(nv, dtype=F)[:dims]
         _sides, _n_left, r = data.split_sides(nv, nh)  # reference f32 margins (cosine: the dot in the AVX order)
-        for stage in (stage_int8, stage_binary16):
+        for stage in (stage_int8, stage_int8_lo, stage_binary16):
             s, e = stage(X, nv, dims)
             dec = np.abs(s) > e
             assert np.all(np.signbit(s[dec]) == np.signbit(r[dec])), f"{name}: {stage.__name__} decided a pair wrongly"
             assert np.all(r[dec] != 0)
             if stage is stage_int8:
                 decided8 += int(dec.sum())
+            elif stage is stage_int8_lo:
+                decided8b += int(dec.sum())
             else:
                 decided16 += int(dec.sum())
         total += len(X)
     if name.startswith("uniform-768"):
         assert decided8 > 0.85 * total, decided8 / total    # ~90 % decided by the int8 stage
         assert decided16 > 0.985 * total, decided16 / total  # §2.2: ~1 % fall back to f32
+        assert decided8b > 0.995 * total, decided8b / total  # the rows' second digit: 16-bit operands beat binary16's 11
     if name.startswith(("gaussian-768", "irwin-hall-768")):
         # one scale per row (+ one power of two per dimension): Gaussian rows and outlier dimensions quantise as well as
         # uniform rows (round 2, one scale per dataset: the copy was dropped for N(0,1) data)
@@ -167,7 +182,7 @@ def test_euclidean_bias_never_decides_alone(scale):
         nv = np.asarray(nv, dtype=F)[:dims]
         bias = F(np.asarray(nh, dtype=F).ravel()[0])
         _sides, _n_left, r = data.split_sides(nv, nh)  # reference: fl(bias + dot), AVX order
-        for stage in (stage_int8, stage_binary16):
+        for stage in (stage_int8, stage_int8_lo, stage_binary16):
             m, e = stage(X, nv, dims, bias=bias)
             with np.errstate(invalid="ignore"):
                 dec = np.abs(m) > e
