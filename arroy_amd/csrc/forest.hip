@@ -23,7 +23,6 @@
 #include <cstdlib>
 #include <immintrin.h>
 #include <new>
-#include <sys/mman.h>
 
 #include "common.h"
 #include "split_device.h"
@@ -2318,36 +2317,21 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_REQUIRE(grown, AH_ERR_OUT_OF_MEMORY, "host allocation of the descendants failed");
         forest->descendants = grown;
     }
-    // Commits the pages of a fresh host range in the background.  With madvise(MADV_POPULATE_WRITE) (Linux >= 5.14) the
-    // contents are left alone, so a range may be populated while the read-back worker already writes into it
-    // (`concurrent_safe`): the level loop then never waits for page faults — with the deep levels down to ~140 ms each,
-    // touching the 2.6 GB of level 13's normals had become the longest thing a level waited for.  Older kernels: a byte per
-    // page is written instead, and the caller joins before handing the range to the worker.
-    struct Toucher {
+    struct Toucher {  // commits the pages of a fresh (still unwritten) host range in the background
         std::thread th;
-        std::atomic<bool> concurrent_safe{true}, running{false};
-        bool busy() const { return running.load(std::memory_order_acquire); }
         void start(void *ptr, size_t bytes) {
             join();
             if (bytes < (8u << 20)) return;
             uint8_t *lo = reinterpret_cast<uint8_t *>(ptr);
-            running.store(true, std::memory_order_release);
-            th = std::thread([this, lo, bytes] {
-                const size_t parts = std::min<size_t>(6, std::max<size_t>(1, bytes >> 26));
+            th = std::thread([lo, bytes] {
+                const size_t parts = std::min<size_t>(4, std::max<size_t>(1, bytes >> 26));
                 std::vector<std::thread> pool;
                 for (size_t p = 0; p < parts; p++)
                     pool.emplace_back([=] {
                         const size_t a = bytes * p / parts, b = bytes * (p + 1) / parts;
-                        const uintptr_t first = (reinterpret_cast<uintptr_t>(lo) + a) & ~(uintptr_t)4095;
-                        const uintptr_t last = (reinterpret_cast<uintptr_t>(lo) + b + 4095) & ~(uintptr_t)4095;
-                        if (concurrent_safe.load(std::memory_order_relaxed) &&
-                            madvise(reinterpret_cast<void *>(first), last - first, 23 /* MADV_POPULATE_WRITE */) == 0)
-                            return;
-                        if (concurrent_safe.exchange(false)) return;  // first failure: leave this part to the page faults
                         for (size_t off = a; off < b; off += 4096) reinterpret_cast<volatile uint8_t *>(lo)[off] = 0;
                     });
                 for (auto &t : pool) t.join();
-                running.store(false, std::memory_order_release);
             });
         }
         void join() {
@@ -2419,10 +2403,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     // The host blob gets lazily committed head-room (splits in total ~1.3-1.6 x items / split_after) so that finished
     // levels can land in their final place while the build continues; it only moves when no copy is in flight.
     uint64_t normals_cap = forest->normals_len;
-    uint64_t populated_to = forest->normals_len;  // host offset up to which a background populate has been requested
     auto reserve_normals = [&](uint64_t need) -> int {
         if (need <= normals_cap) return AH_OK;
-        prefault_normals.join();  // the blob may move: nothing may be populating it
         AH_REQUIRE(rb.drain() == hipSuccess, AH_ERR_DEVICE, "device -> host copy of the normals failed");
         uint64_t want = std::max<uint64_t>(need + need / 2, normals_base + 2 * max_nodes * nstride);
         uint8_t *grown = (uint8_t *)realloc(forest->normals, want + 16);
@@ -2532,22 +2514,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         if (screen8) AH_TRY(shadow8_arena.take((uint64_t)n_nodes * stride8, &shadow8_d));
         normals_bytes += chunk_bytes;
         // host side of this level's normals: reserved now and page-touched while the level is computed
-        if (!prefault_normals.concurrent_safe.load()) prefault_normals.join();
+        prefault_normals.join();
         AH_TRY(reserve_normals(chunk_host_off + chunk_bytes));
-        if (prefault_normals.concurrent_safe.load()) {
-            // Populate AHEAD of the levels, off their critical path: the expected size of the whole forest's records (split
-            // nodes ~ 1.3 x items / split_after; 1.5 x here) from the first level on, this level's and the next one's records
-            // in any case; a task still running is left alone (the next level asks again).
-            const uint64_t est_total = (uint64_t)(1.5 * ((double)M / ((double)split_after + 1.0) + n_trees)) * nstride;
-            const uint64_t target = std::min<uint64_t>(normals_cap, std::max<uint64_t>(chunk_host_off + 3 * chunk_bytes, normals_base + est_total));
-            if (target > populated_to && !prefault_normals.busy()) {
-                const uint64_t from = std::max<uint64_t>(populated_to, chunk_host_off);
-                prefault_normals.start(forest->normals + from, (size_t)(target - from));
-                populated_to = target;
-            }
-        } else {
-            prefault_normals.start(forest->normals + chunk_host_off, chunk_bytes);
-        }
+        prefault_normals.start(forest->normals + chunk_host_off, chunk_bytes);
         const unsigned tile_grid = std::min<uint32_t>(n_tiles, g_tile_blocks);
         // The node-major margin kernels walk their tiles with a persistent grid: at the deep levels a tile is ~1200 items
         // (~2 MB of rows) and launching one workgroup per tile — 819 000 of them at level 13 of the 10M x 100 build — cost
@@ -2964,7 +2933,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         pending_nodes = n_nodes;
         pending_host_off = chunk_host_off;
         // this level's normals are final: the worker copies them while the next level runs
-        if (!prefault_normals.concurrent_safe.load()) prefault_normals.join();  // never WRITE to a page the worker may have filled
+        prefault_normals.join();  // never touch a page the worker may already have filled
         rb.push(forest->normals + chunk_host_off, chunk_d, chunk_bytes);
 
         info = *hi;
@@ -3077,7 +3046,6 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     const auto t_emitted = std::chrono::steady_clock::now();
     AH_REQUIRE(rb.drain() == hipSuccess, AH_ERR_DEVICE, "device -> host copy of the forest failed");
     forest->normals_len = normals_base + normals_bytes;
-    prefault_normals.join();  // (it may still be populating head-room)
     if (normals_cap > forest->normals_len) {  // give the head-room back (shrinks in place)
         uint8_t *fit = (uint8_t *)realloc(forest->normals, forest->normals_len + 16);
         if (fit) forest->normals = fit;
