@@ -2422,37 +2422,71 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     // and which HostRec every node of the next level belongs to — the same walk the device did in k_next_emit.
     uint64_t items_routed = 0;
     auto digest_level = [&](uint32_t depth, uint32_t n_nodes, const FNode *tbl, uint64_t chunk_host_off) -> int {
-        next_rec.clear();
-        for (uint32_t i = 0; i < n_nodes; i++) {
-            const FNode nd = tbl[i];
-            AH_REQUIRE(nd.state != ST_PENDING && nd.n_left <= nd.count, AH_ERR_DEVICE,
-                       "forest build: node %u of level %u left pending (internal error)", i, depth);
-            forest->stats.margin_evaluations += (uint64_t)(nd.attempt + 1) * nd.count;
-            forest->stats.retries += nd.attempt;
-            items_routed += nd.count;
-            const uint32_t rec_idx = level_rec[i];
-            recs[rec_idx].has_normal = nd.state == ST_ACCEPTED;
-            recs[rec_idx].normal_off = chunk_host_off + (uint64_t)i * nstride;
-            if (nd.state != ST_ACCEPTED) forest->stats.dummy_normals++;
-            const uint32_t child_cnt[2] = {nd.n_left, nd.count - nd.n_left};
-            const uint64_t child_start[2] = {nd.start, nd.start + nd.n_left};
-            for (uint32_t side = 0; side < 2; side++) {
-                HostRec c{};
-                c.tree = nd.tree;
-                c.start = child_start[side];
-                c.count = child_cnt[side];
-                c.depth = depth + 1;
-                const uint32_t cidx = (uint32_t)recs.size();
-                if (c.count <= split_after) {
-                    c.kind = AH_NODE_DESCENDANTS;
-                } else {
-                    c.kind = AH_NODE_SPLIT;
-                    next_rec.push_back(cidx);
+        // Children get the records base + 2 i (left) and base + 2 i + 1 (right) of node i, so the walk splits over a few
+        // threads (the deepest level of the 10M x 100-tree build has 819 000 nodes: 37 ms on one thread, more than the GPU
+        // needs for the level after it); the list of children that split again is concatenated in node order afterwards.
+        const size_t base = recs.size();
+        recs.resize(base + 2 * (size_t)n_nodes);
+        const unsigned n_threads = n_nodes >= 65536 ? 4u : 1u;
+        struct Part {
+            uint64_t evals = 0, retries = 0, routed = 0, dummies = 0;
+            uint32_t bad = 0xFFFFFFFFu;
+            std::vector<uint32_t> splits;
+        };
+        std::vector<Part> parts(n_threads);
+        auto walk = [&](unsigned t) {
+            Part &pt = parts[t];
+            const uint32_t lo = (uint32_t)((uint64_t)n_nodes * t / n_threads), hi = (uint32_t)((uint64_t)n_nodes * (t + 1) / n_threads);
+            pt.splits.reserve(2 * (size_t)(hi - lo));
+            for (uint32_t i = lo; i < hi; i++) {
+                const FNode nd = tbl[i];
+                if (nd.state == ST_PENDING || nd.n_left > nd.count) {
+                    pt.bad = std::min(pt.bad, i);
+                    continue;
                 }
-                recs.push_back(c);
-                if (side == 0) recs[rec_idx].left = cidx;
-                else recs[rec_idx].right = cidx;
+                pt.evals += (uint64_t)(nd.attempt + 1) * nd.count;
+                pt.retries += nd.attempt;
+                pt.routed += nd.count;
+                const uint32_t rec_idx = level_rec[i];
+                recs[rec_idx].has_normal = nd.state == ST_ACCEPTED;
+                recs[rec_idx].normal_off = chunk_host_off + (uint64_t)i * nstride;
+                if (nd.state != ST_ACCEPTED) pt.dummies++;
+                const uint32_t child_cnt[2] = {nd.n_left, nd.count - nd.n_left};
+                const uint64_t child_start[2] = {nd.start, nd.start + nd.n_left};
+                for (uint32_t side = 0; side < 2; side++) {
+                    HostRec c{};
+                    c.tree = nd.tree;
+                    c.start = child_start[side];
+                    c.count = child_cnt[side];
+                    c.depth = depth + 1;
+                    const uint32_t cidx = (uint32_t)(base + 2 * (size_t)i + side);
+                    if (c.count <= split_after) {
+                        c.kind = AH_NODE_DESCENDANTS;
+                    } else {
+                        c.kind = AH_NODE_SPLIT;
+                        pt.splits.push_back(cidx);
+                    }
+                    recs[cidx] = c;
+                    if (side == 0) recs[rec_idx].left = cidx;
+                    else recs[rec_idx].right = cidx;
+                }
             }
+        };
+        {
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < n_threads; t++) pool.emplace_back(walk, t);
+            walk(0);
+            for (auto &th : pool) th.join();
+        }
+        next_rec.clear();
+        for (const Part &pt : parts) {
+            AH_REQUIRE(pt.bad == 0xFFFFFFFFu, AH_ERR_DEVICE, "forest build: node %u of level %u left pending (internal error)",
+                       pt.bad, depth);
+            forest->stats.margin_evaluations += pt.evals;
+            forest->stats.retries += pt.retries;
+            forest->stats.dummy_normals += pt.dummies;
+            items_routed += pt.routed;
+            next_rec.insert(next_rec.end(), pt.splits.begin(), pt.splits.end());
         }
         level_rec.swap(next_rec);
         forest->stats.levels = std::max(forest->stats.levels, depth + 1);
@@ -2491,6 +2525,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     };
 
     uint32_t depth = 0;
+    auto t_prev_waited = std::chrono::steady_clock::now();
     bool prev_rows = false;     // the previous level ran row-major: node_of / side_bytes describe it, d_child links it
     uint32_t pending_digest = 0;  // 1 + depth of the level whose node table is still to be digested (0 = none)
     uint32_t pending_nodes = 0;
@@ -2502,6 +2537,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             return AH_ERR_CANCELLED;  // Error::BuildCancelled
         }
         AH_REQUIRE(depth < 100000, AH_ERR_DEVICE, "forest build: depth %u exceeded (internal error)", depth);
+        const auto t_level_top = std::chrono::steady_clock::now();
+        const double ms_tail_prev = std::chrono::duration<double, std::milli>(t_level_top - t_prev_waited).count();
         const uint32_t n_nodes = info.n_nodes, n_tiles = info.n_tiles;
         AH_REQUIRE(n_nodes <= max_nodes && n_tiles <= max_tiles, AH_ERR_DEVICE, "forest build: node / tile bound exceeded");
         hipLaunchKernelGGL(k_build_tiles, dim3(std::min<uint32_t>((n_nodes + 3) / 4, kMaxBlocks)), dim3(256), 0, s, d_cur,
@@ -2905,13 +2942,17 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_HIP(hipEventRecord(bc.ev_level, s));
 
         // while the level runs: digest the node table of the level before it
+        const auto t_launched = std::chrono::steady_clock::now();
         if (pending_digest) {
             AH_HIP(hipEventSynchronize(bc.ev_copy[(pending_digest - 1) & 1]));
             AH_TRY(digest_level(pending_digest - 1, pending_nodes, h_nodes[(pending_digest - 1) & 1], pending_host_off));
             pending_digest = 0;
         }
+        const auto t_digested = std::chrono::steady_clock::now();
         lvl_status = wait_level();
         if (lvl_status != AH_OK) return lvl_status;
+        const auto t_waited = std::chrono::steady_clock::now();
+        t_prev_waited = t_waited;
         float attempt_ms[4] = {0.f, 0.f, 0.f, 0.f};
         for (int attempt = 0; attempt < 4; attempt++) {
             float m = 0.0f;
@@ -2925,6 +2966,11 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     depth, n_nodes, (unsigned long long)info.pairs,
                     dense ? "dense-mfma" : lds_tc ? "rows-lds" : row_tc >= 2 ? "rows" : "node-major", attempt_ms[0],
                     attempt_ms[1] + attempt_ms[2] + attempt_ms[3], info.pairs ? attempt_ms[0] * 1e6 / (double)info.pairs : 0.0);
+        if (timing >= 3) {
+            auto ms_of = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "[ah]          host: after the previous wait %.2f ms, launch %.2f ms, digest of the level before %.2f ms, wait %.2f ms\n",
+                    ms_tail_prev, ms_of(t_level_top, t_launched), ms_of(t_launched, t_digested), ms_of(t_digested, t_waited));
+        }
         forest->stats.margin_launches += 4;
         // this level's node table follows on the side stream (the level is complete: no stream dependency needed)
         AH_HIP(hipMemcpyAsync(h_nodes[depth & 1], d_cur, n_nodes * sizeof(FNode), hipMemcpyDeviceToHost, bc.side));
@@ -2944,12 +2990,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         std::swap(d_cur, d_next);
         depth++;
     }
-    if (pending_digest) {
-        AH_HIP(hipEventSynchronize(bc.ev_copy[(pending_digest - 1) & 1]));
-        AH_TRY(digest_level(pending_digest - 1, pending_nodes, h_nodes[(pending_digest - 1) & 1], pending_host_off));
-    }
     AH_HIP(hipEventRecord(bc.ev_end, s));
-    const auto t_levels = std::chrono::steady_clock::now();
 
     // Results come back with plain D2H copies straight into their final place — no host-side repacking:
     //   normals      one copy per level chunk (device record layout == caller-visible layout), already under way
@@ -2974,6 +3015,12 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         forest->stats.screen8b_decided += sc.stage8b_decided;
         rb.push(forest->descendants + desc_base, final_perm.p, M * 4);  // lands while the host emits the node list
     }
+    // the last level's node table is digested only now: the 4 GB of item ids are already on their way
+    if (pending_digest) {
+        AH_HIP(hipEventSynchronize(bc.ev_copy[(pending_digest - 1) & 1]));
+        AH_TRY(digest_level(pending_digest - 1, pending_nodes, h_nodes[(pending_digest - 1) & 1], pending_host_off));
+    }
+    const auto t_levels = std::chrono::steady_clock::now();
     float ms = 0.0f;
     AH_HIP(hipEventElapsedTime(&ms, bc.ev_begin, bc.ev_end));
     forest->stats.seconds_device += ms * 1e-3;
