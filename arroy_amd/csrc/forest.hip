@@ -2324,7 +2324,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             if (bytes < (8u << 20)) return;
             uint8_t *lo = reinterpret_cast<uint8_t *>(ptr);
             th = std::thread([lo, bytes] {
-                const size_t parts = std::min<size_t>(4, std::max<size_t>(1, bytes >> 26));
+                // (eight threads: the 2.6 GB of the deepest level's normals must be committed within that level's ~140 ms, or
+                // the level loop waits for page faults before it can hand the chunk to the read-back worker)
+                const size_t parts = std::min<size_t>(8, std::max<size_t>(1, bytes >> 26));
                 std::vector<std::thread> pool;
                 for (size_t p = 0; p < parts; p++)
                     pool.emplace_back([=] {
@@ -2580,9 +2582,12 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             // costs in ns, for rows of this dataset's size: node-major = one HBM read of the row per (item, tree) pair
             // (0.47 ns per 3072-byte row at 6.7 TB/s; the screen reads half the bytes)
             const double scale = screen ? (double)ds->hpitch * 2 / 1536.0 : (double)ds->row_bytes() / 3072.0;
-            // (0.17 with the int8 first stage: 768 + ~0.1 x 1600 bytes per pair on data that quantises like the benchmark's;
-            // worse data decide less there: scaled by the quality figure ensure_screen8 measured, 0.12 for uniform rows)
-            const double node8_ns = std::min(0.24, 0.155 + 0.125 * ds->screen8_quality);
+            // (with the int8 first stage: 768 bytes + ~10 % x 768 (second digit) per pair on data that quantises like the
+            // benchmark's; worse data decide less there: scaled by the quality figure ensure_screen8 measured)
+            // (measured, 10M x 768 x 100 trees: 0.130-0.142 ns per pair on uniform rows, quality 0.12, 0.140-0.151 on ~N(0,1)
+            // rows, quality 0.18, with the rows' second digit as stage 1; 0.152-0.170 / 0.170-0.186 with the binary16 row)
+            const double node8_ns = sv.rows8_lo ? std::min(0.24, 0.115 + 0.15 * ds->screen8_quality)
+                                                : std::min(0.24, 0.155 + 0.125 * ds->screen8_quality);
             const double node_ns = screen ? (screen8 && ds->metric != AH_DOT_PRODUCT ? node8_ns : 0.24) : 0.47;
             const double active = (double)info.pairs / ((double)n_trees * (double)N);
             const double cost_node = (double)info.pairs * node_ns * scale;
@@ -2975,6 +2980,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         // this level's node table follows on the side stream (the level is complete: no stream dependency needed)
         AH_HIP(hipMemcpyAsync(h_nodes[depth & 1], d_cur, n_nodes * sizeof(FNode), hipMemcpyDeviceToHost, bc.side));
         AH_HIP(hipEventRecord(bc.ev_copy[depth & 1], bc.side));
+        // (a millisecond at most — and it must not queue behind the gigabytes of normals the worker is about to request: the
+        // digest of this table runs under the NEXT level, which at the bottom of the forest is a short one)
+        if (n_nodes >= 65536) AH_HIP(hipEventSynchronize(bc.ev_copy[depth & 1]));
         pending_digest = depth + 1;
         pending_nodes = n_nodes;
         pending_host_off = chunk_host_off;
