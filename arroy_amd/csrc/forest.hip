@@ -93,6 +93,9 @@ __global__ void k_ids_to_rows(DataView dv, uint32_t *perm, uint64_t total, uint3
 // One wave per pending node: sample 2+10 items with the policy RNG, run create_split.
 //
 // Normal records (device layout == the layout handed to the caller): [vector, row_bytes][header, 16-byte slot].
+// M = f32_space_metric(dv.metric): one instantiation per arithmetic (the switch inside one kernel made every build carry the
+// registers of the heaviest branch: 115 VGPRs and 80 spilled SGPRs for a kernel that lives on the number of waves in flight)
+template <int M>
 __global__ __launch_bounds__(64) void k_forest_create_split(DataView dv, FNode *nodes, uint32_t n_nodes,
                                                             const uint32_t *__restrict__ perm, uint64_t n_items,
                                                             uint8_t *normals, uint64_t nstride, uint64_t hdr_off) {
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(64) void k_forest_create_split(DataView dv, FNode *
         __syncthreads();
         uint8_t *rec = normals + node * nstride;
         float *hdr = reinterpret_cast<float *>(rec + hdr_off);
-        wave_create_split_any(dv, s_rows, s_buf, s_buf + fpitch, s_buf + 2 * fpitch, rec, hdr, threadIdx.x);
+        wave_create_split<M>(dv, s_rows, s_buf, s_buf + fpitch, s_buf + 2 * fpitch, rec, hdr, threadIdx.x);
         if (threadIdx.x == 0) hdr[2] = hdr[3] = 0.0f;  // deterministic padding
         for (uint32_t i = 4 + threadIdx.x; i < (uint32_t)((nstride - hdr_off) >> 2); i += 64) hdr[i] = 0.0f;
     }
@@ -2397,9 +2400,19 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     const size_t cs_shared = (size_t)f32_space_pitch(ds->metric, ds->dims) * 4 * 3;
     AH_REQUIRE(cs_shared <= 150 * 1024, AH_ERR_INVALID_DIMENSION, "dimensions %u too large for the LDS-resident two-means",
                ds->dims);
-    if (cs_shared > 48 * 1024)
-        AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_create_split),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_shared));
+    const int split_metric = f32_space_metric(ds->metric);
+#define AH_SPLIT_KERNEL(DO)                                              \
+    switch (split_metric) {                                              \
+    case AH_EUCLIDEAN: DO(k_forest_create_split<AH_EUCLIDEAN>); break;   \
+    case AH_MANHATTAN: DO(k_forest_create_split<AH_MANHATTAN>); break;   \
+    case AH_COSINE: DO(k_forest_create_split<AH_COSINE>); break;         \
+    default: DO(k_forest_create_split<AH_DOT_PRODUCT>); break;           \
+    }
+    if (cs_shared > 48 * 1024) {
+#define AH_SPLIT_OPT_IN(K) AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_shared))
+        AH_SPLIT_KERNEL(AH_SPLIT_OPT_IN)
+#undef AH_SPLIT_OPT_IN
+    }
     const uint64_t normals_base = forest->normals_len;  // this batch appends its levels after earlier batches
     uint64_t normals_bytes = 0;
     // The host blob gets lazily committed head-room (splits in total ~1.3-1.6 x items / split_after) so that finished
@@ -2586,7 +2599,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             // benchmark's; worse data decide less there: scaled by the quality figure ensure_screen8 measured)
             // (measured, 10M x 768 x 100 trees: 0.130-0.142 ns per pair on uniform rows, quality 0.12, 0.140-0.151 on ~N(0,1)
             // rows, quality 0.18, with the rows' second digit as stage 1; 0.152-0.170 / 0.170-0.186 with the binary16 row)
-            const double node8_ns = sv.rows8_lo ? std::min(0.24, 0.115 + 0.15 * ds->screen8_quality)
+            // (+0.02: the row-major entries of the tables below carry their mask conversion twice — level 9 of that build,
+            // measured both ways, takes 130.7 ms row-major and 136.9 ms node-major, and this keeps it row-major)
+            const double node8_ns = sv.rows8_lo ? std::min(0.24, 0.135 + 0.15 * ds->screen8_quality)
                                                 : std::min(0.24, 0.155 + 0.125 * ds->screen8_quality);
             const double node_ns = screen ? (screen8 && ds->metric != AH_DOT_PRODUCT ? node8_ns : 0.24) : 0.47;
             const double active = (double)info.pairs / ((double)n_trees * (double)N);
@@ -2661,8 +2676,11 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         }
 
         for (int attempt = 0; attempt < 4; attempt++) {
-            hipLaunchKernelGGL(k_forest_create_split, dim3(std::min<uint32_t>(n_nodes, g_split_blocks)), dim3(64), cs_shared, s, dv,
-                               d_cur, n_nodes, cur, N, chunk_d, nstride, hdr_off);
+#define AH_SPLIT_LAUNCH(K)                                                                                             \
+    hipLaunchKernelGGL(K, dim3(std::min<uint32_t>(n_nodes, g_split_blocks)), dim3(64), cs_shared, s, dv, d_cur, n_nodes, cur, N, \
+                       chunk_d, nstride, hdr_off)
+            AH_SPLIT_KERNEL(AH_SPLIT_LAUNCH)
+#undef AH_SPLIT_LAUNCH
             AH_DBG(s, "create_split");
             if (screen)
                 hipLaunchKernelGGL(k_forest_shadow_normals, dim3(n_nodes), dim3(64), 0, s, dv, d_cur, chunk_d, nstride, hdr_off,
