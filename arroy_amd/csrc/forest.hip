@@ -2343,7 +2343,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             if (th.joinable()) th.join();
         }
         ~Toucher() { join(); }
-    } prefault, prefault_normals;
+    } prefault, touch_normals[2];  // [level & 1]: commits the level's normals, started one level ahead
     prefault.start(forest->descendants + desc_base, M * 4);
     Arena arena, shadow_arena, shadow8_arena;  // declared before the read-back worker: it is joined before the chunks it reads are freed
     arena.block_bytes = std::max<uint64_t>(32ull << 20, std::min<uint64_t>(2 * max_nodes * nstride, 16ull << 30));
@@ -2359,6 +2359,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     std::vector<uint32_t> tree_root(n_trees);
     std::vector<uint32_t> level_rec, next_rec;  // HostRec index of every node of the level being digested / of the next
     recs.reserve(4 * max_nodes / 3 + 16);
+    size_t n_recs = 0;  // records in use; the vector itself is grown AHEAD of the digest (value-initialising 80 MB of fresh
+                        // pages on the thread that digests the deepest level was most of that digest's 35 ms)
     LevelInfo info{};
     std::vector<uint32_t> tree_first(n_trees + 1, 0xFFFFFFFFu);
     {
@@ -2370,10 +2372,11 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             r.start = tree_base[t];
             r.count = cnt;
             r.depth = 0;
-            tree_root[t] = (uint32_t)recs.size();
+            tree_root[t] = (uint32_t)n_recs;
             if (cnt <= split_after) {  // fit_in_descendant at the root: the tree is one Descendants node
                 r.kind = AH_NODE_DESCENDANTS;
                 recs.push_back(r);
+                n_recs++;
                 continue;
             }
             r.kind = AH_NODE_SPLIT;
@@ -2385,8 +2388,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             nd.tile_begin = info.n_tiles;
             nd.n_tiles = (cnt + kTile - 1) / kTile;
             tree_first[t] = info.n_nodes;
-            level_rec.push_back((uint32_t)recs.size());
+            level_rec.push_back((uint32_t)n_recs);
             recs.push_back(r);
+            n_recs++;
             lv[info.n_nodes++] = nd;
             info.n_tiles += nd.n_tiles;
             info.pairs += cnt;
@@ -2420,6 +2424,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     uint64_t normals_cap = forest->normals_len;
     auto reserve_normals = [&](uint64_t need) -> int {
         if (need <= normals_cap) return AH_OK;
+        touch_normals[0].join();  // the blob may move: nothing may be touching it
+        touch_normals[1].join();
         AH_REQUIRE(rb.drain() == hipSuccess, AH_ERR_DEVICE, "device -> host copy of the normals failed");
         uint64_t want = std::max<uint64_t>(need + need / 2, normals_base + 2 * max_nodes * nstride);
         uint8_t *grown = (uint8_t *)realloc(forest->normals, want + 16);
@@ -2440,8 +2446,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         // Children get the records base + 2 i (left) and base + 2 i + 1 (right) of node i, so the walk splits over a few
         // threads (the deepest level of the 10M x 100-tree build has 819 000 nodes: 37 ms on one thread, more than the GPU
         // needs for the level after it); the list of children that split again is concatenated in node order afterwards.
-        const size_t base = recs.size();
-        recs.resize(base + 2 * (size_t)n_nodes);
+        const size_t base = n_recs;
+        if (recs.size() < base + 2 * (size_t)n_nodes) recs.resize(base + 2 * (size_t)n_nodes);
+        n_recs = base + 2 * (size_t)n_nodes;
         const unsigned n_threads = n_nodes >= 65536 ? 4u : 1u;
         struct Part {
             uint64_t evals = 0, retries = 0, routed = 0, dummies = 0;
@@ -2505,7 +2512,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         }
         level_rec.swap(next_rec);
         forest->stats.levels = std::max(forest->stats.levels, depth + 1);
-        if (opt->progress) opt->progress(opt->progress_user, depth + 1, recs.size(), items_routed);
+        if (opt->progress) opt->progress(opt->progress_user, depth + 1, n_recs, items_routed);
         return AH_OK;
     };
 
@@ -2565,10 +2572,17 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         if (screen) AH_TRY(shadow_arena.take((uint64_t)n_nodes * hstride, &shadow_d));
         if (screen8) AH_TRY(shadow8_arena.take((uint64_t)n_nodes * stride8, &shadow8_d));
         normals_bytes += chunk_bytes;
-        // host side of this level's normals: reserved now and page-touched while the level is computed
-        prefault_normals.join();
+        // Host side of the normals: reserved now; the pages of THIS level's records were started one level ago (a level has
+        // about twice the nodes of the one before), those of the NEXT level start now — committing the 2.6 GB of the deepest
+        // level takes longer than the ~160 ms that level runs, and the loop must not wait for page faults before it can
+        // hand a chunk to the read-back worker.  Whatever the prediction missed is faulted in by the worker itself.
         AH_TRY(reserve_normals(chunk_host_off + chunk_bytes));
-        prefault_normals.start(forest->normals + chunk_host_off, chunk_bytes);
+        if (depth == 0) touch_normals[0].start(forest->normals + chunk_host_off, chunk_bytes);
+        {
+            const uint64_t next_begin = chunk_host_off + chunk_bytes;
+            const uint64_t next_len = normals_cap > next_begin ? std::min<uint64_t>(normals_cap - next_begin, 2 * chunk_bytes) : 0;
+            touch_normals[(depth + 1) & 1].start(forest->normals + next_begin, (size_t)next_len);
+        }
         const unsigned tile_grid = std::min<uint32_t>(n_tiles, g_tile_blocks);
         // The node-major margin kernels walk their tiles with a persistent grid: at the deep levels a tile is ~1200 items
         // (~2 MB of rows) and launching one workgroup per tile — 819 000 of them at level 13 of the 10M x 100 build — cost
@@ -2964,7 +2978,12 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_HIP(hipMemcpyAsync(hi, d_info, info_words * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipEventRecord(bc.ev_level, s));
 
-        // while the level runs: digest the node table of the level before it
+        // while the level runs: room for the records of the two digests to come (the level before this one, now; this one,
+        // under the next level), then digest the node table of the level before it
+        {
+            const size_t want = n_recs + 2 * (size_t)pending_nodes + 2 * (size_t)n_nodes;
+            if (recs.size() < want) recs.resize(want);
+        }
         const auto t_launched = std::chrono::steady_clock::now();
         if (pending_digest) {
             AH_HIP(hipEventSynchronize(bc.ev_copy[(pending_digest - 1) & 1]));
@@ -3005,7 +3024,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         pending_nodes = n_nodes;
         pending_host_off = chunk_host_off;
         // this level's normals are final: the worker copies them while the next level runs
-        prefault_normals.join();  // never touch a page the worker may already have filled
+        touch_normals[depth & 1].join();  // never touch a page the worker may already have filled
         rb.push(forest->normals + chunk_host_off, chunk_d, chunk_bytes);
 
         info = *hi;
@@ -3058,6 +3077,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     for (const HostRec &r : recs) tree_nodes[r.tree + 1]++;
     for (uint32_t t = 0; t < n_trees; t++) tree_nodes[t + 1] += tree_nodes[t];
     const size_t node_base = forest->nodes.size();
+    recs.resize(n_recs);
     forest->nodes.resize(node_base + recs.size());
     forest->roots.resize(forest->roots.size() + n_trees);
     uint32_t *roots_out = forest->roots.data() + (forest->roots.size() - n_trees);
@@ -3119,6 +3139,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     const auto t_emitted = std::chrono::steady_clock::now();
     AH_REQUIRE(rb.drain() == hipSuccess, AH_ERR_DEVICE, "device -> host copy of the forest failed");
     forest->normals_len = normals_base + normals_bytes;
+    touch_normals[0].join();  // (the last level started the commit of a level that never came)
+    touch_normals[1].join();
     if (normals_cap > forest->normals_len) {  // give the head-room back (shrinks in place)
         uint8_t *fit = (uint8_t *)realloc(forest->normals, forest->normals_len + 16);
         if (fit) forest->normals = fit;
