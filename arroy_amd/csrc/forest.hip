@@ -2579,8 +2579,12 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_TRY(reserve_normals(chunk_host_off + chunk_bytes));
         if (depth == 0) touch_normals[0].start(forest->normals + chunk_host_off, chunk_bytes);
         {
+            // next level: twice the nodes while the nodes are large; once they hold fewer than 2 x split_after items on
+            // average most children are Descendants and the next level is a remnant (an eighth); nothing below that
             const uint64_t next_begin = chunk_host_off + chunk_bytes;
-            const uint64_t next_len = normals_cap > next_begin ? std::min<uint64_t>(normals_cap - next_begin, 2 * chunk_bytes) : 0;
+            const double avg_items = n_nodes ? (double)info.pairs / (double)n_nodes : 0.0;
+            const uint64_t predicted = avg_items > 2.0 * split_after ? 2 * chunk_bytes : avg_items > (double)split_after ? chunk_bytes / 8 : 0;
+            const uint64_t next_len = normals_cap > next_begin ? std::min<uint64_t>(normals_cap - next_begin, predicted) : 0;
             touch_normals[(depth + 1) & 1].start(forest->normals + next_begin, (size_t)next_len);
         }
         const unsigned tile_grid = std::min<uint32_t>(n_tiles, g_tile_blocks);
