@@ -2460,7 +2460,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     // the whole final permutation starts travelling (4 GB at 10M x 100 trees: 75 ms that used to follow the last level);
     // what later levels still write — the ranges of the nodes of the level after the trigger — is packed and sent again
     // at the end.  The permutation is zeroed first so that the early pass may convert every entry to an item id.
-    const bool early_allowed = M >= (64ull << 20);
+    const bool early_allowed = M >= (uint64_t)std::max<long long>(1, tun(TUN_EARLY_IDS_MIN));
     uint32_t early_level = 0xFFFFFFFFu;  // the level whose nodes bound everything written after the early pass started
     std::vector<LateRange> late;
     if (early_allowed) AH_HIP(hipMemsetAsync(final_perm.p, 0, M * 4, s));
