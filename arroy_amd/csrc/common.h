@@ -88,7 +88,6 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
     X(DENSE_MAX_COLS, "AH_DENSE_MAX_COLS", 16384)                                                                        \
     X(DENSE_GMACS, "AH_DENSE_GMACS", 495000)    /* sustained multiply-add rate the cost model assumes, 1e9 MAC/s */       \
     X(MARGIN_MODE, "AH_MARGIN_MODE", 0)         /* ah_margin_mode for callers that pass AH_MARGIN_AUTO */                 \
-    X(EARLY_IDS_MIN, "AH_EARLY_IDS_MIN", 64 << 20) /* fewest (tree, item) entries of a batch for the two-phase read-back of the ids */ \
     X(READBACK_DIRECT, "AH_READBACK_DIRECT", 0) /* 1: let the runtime stage the device -> pageable copies */             \
     X(SCAN_BLOCKS, "AH_SCAN_BLOCKS", 0)         /* grid cap of the distance scan (0 = built-in) */                        \
     X(MANHATTAN_ROWS, "AH_MANHATTAN_ROWS", 1)                                                                            \

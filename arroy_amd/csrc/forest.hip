@@ -616,23 +616,6 @@ __global__ __launch_bounds__(kBlock) void k_forest_scatter(const FNode *__restri
     }
 }
 
-// Late ranges of the final permutation, packed for one small device -> host copy (two-phase read-back of the descendants):
-// range r = final_perm[start[r], start[r] + count[r]) goes to out[offset[r] ...], converted to item ids when `ids` is given.
-struct LateRange {
-    uint64_t start, offset;
-    uint32_t count, pad;
-};
-__global__ __launch_bounds__(256) void k_pack_late_ranges(const uint32_t *__restrict__ final_perm, const LateRange *__restrict__ ranges,
-                                                          uint32_t n_ranges, const uint32_t *__restrict__ ids,
-                                                          uint32_t *__restrict__ out) {
-    for (uint32_t r = blockIdx.x; r < n_ranges; r += gridDim.x) {
-        const LateRange lr = ranges[r];
-        for (uint32_t i = threadIdx.x; i < lr.count; i += blockDim.x) {
-            const uint32_t v = final_perm[lr.start + i];
-            out[lr.offset + i] = ids ? ids[v] : v;
-        }
-    }
-}
 __global__ void k_rows_to_ids(uint32_t *perm, uint64_t total, const uint32_t *__restrict__ ids) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) perm[g] = ids[perm[g]];
@@ -2456,14 +2439,6 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         return AH_OK;
     };
 
-    // Two-phase read-back of the item ids (big batches): once the levels still to come hold less than a tenth of the items,
-    // the whole final permutation starts travelling (4 GB at 10M x 100 trees: 75 ms that used to follow the last level);
-    // what later levels still write — the ranges of the nodes of the level after the trigger — is packed and sent again
-    // at the end.  The permutation is zeroed first so that the early pass may convert every entry to an item id.
-    const bool early_allowed = M >= (uint64_t)std::max<long long>(1, tun(TUN_EARLY_IDS_MIN));
-    uint32_t early_level = 0xFFFFFFFFu;  // the level whose nodes bound everything written after the early pass started
-    std::vector<LateRange> late;
-    if (early_allowed) AH_HIP(hipMemsetAsync(final_perm.p, 0, M * 4, s));
     // Digest the node table of a finished level (it arrived on the side stream): split records, children, statistics,
     // and which HostRec every node of the next level belongs to — the same walk the device did in k_next_emit.
     uint64_t items_routed = 0;
@@ -2471,14 +2446,6 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         // Children get the records base + 2 i (left) and base + 2 i + 1 (right) of node i, so the walk splits over a few
         // threads (the deepest level of the 10M x 100-tree build has 819 000 nodes: 37 ms on one thread, more than the GPU
         // needs for the level after it); the list of children that split again is concatenated in node order afterwards.
-        if (depth == early_level) {  // everything the levels from here on write lies inside these nodes' ranges
-            late.resize(n_nodes);
-            uint64_t off = 0;
-            for (uint32_t i = 0; i < n_nodes; i++) {
-                late[i] = LateRange{tbl[i].start, off, tbl[i].count, 0u};
-                off += tbl[i].count;
-            }
-        }
         const size_t base = n_recs;
         if (recs.size() < base + 2 * (size_t)n_nodes) recs.resize(base + 2 * (size_t)n_nodes);
         n_recs = base + 2 * (size_t)n_nodes;
@@ -3065,19 +3032,6 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         rb.push(forest->normals + chunk_host_off, chunk_d, chunk_bytes);
 
         info = *hi;
-        if (early_allowed && early_level == 0xFFFFFFFFu && info.n_nodes > 0 && (uint64_t)info.pairs * 10 <= M) {
-            // the stream is idle (the level is complete): single-node trees, ids, then the whole permutation to the worker
-            prefault.join();
-            for (uint32_t t = 0; t < n_trees; t++)
-                if (recs[tree_root[t]].kind == AH_NODE_DESCENDANTS && tree_base[t + 1] > tree_base[t])
-                    AH_HIP(hipMemcpyAsync(final_perm.p + tree_base[t], perm_a.p + tree_base[t],
-                                          (tree_base[t + 1] - tree_base[t]) * 4, hipMemcpyDeviceToDevice, s));
-            if (!ds->identity_ids && M)
-                hipLaunchKernelGGL(k_rows_to_ids, dim3(2048), dim3(256), 0, s, final_perm.p, M, ds->d_ids);
-            AH_HIP(hipStreamSynchronize(s));
-            rb.push(forest->descendants + desc_base, final_perm.p, M * 4);
-            early_level = depth + 1;
-        }
         const uint32_t *tf = reinterpret_cast<const uint32_t *>(hi + 1);
         for (uint32_t t = 0; t <= n_trees; t++) tree_first[t] = tf[t];
         prev_rows = row_tc >= 2;
@@ -3090,19 +3044,16 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     // Results come back with plain D2H copies straight into their final place — no host-side repacking:
     //   normals      one copy per level chunk (device record layout == caller-visible layout), already under way
     //   descendants  the final permutations themselves (rows -> item ids on device first)
-    const bool early = early_level != 0xFFFFFFFFu;
     {
         prefault.join();
         forest->descendants_len = desc_base + M;
-        if (!early) {
-            // trees that are a single Descendants node never went through a scatter: their list is the input itself
-            for (uint32_t t = 0; t < n_trees; t++)
-                if (recs[tree_root[t]].kind == AH_NODE_DESCENDANTS && tree_base[t + 1] > tree_base[t])
-                    AH_HIP(hipMemcpyAsync(final_perm.p + tree_base[t], perm_a.p + tree_base[t],
-                                          (tree_base[t + 1] - tree_base[t]) * 4, hipMemcpyDeviceToDevice, s));
-            if (!ds->identity_ids && M)
-                hipLaunchKernelGGL(k_rows_to_ids, dim3(2048), dim3(256), 0, s, final_perm.p, M, ds->d_ids);
-        }
+        // trees that are a single Descendants node never went through a scatter: their list is the input itself
+        for (uint32_t t = 0; t < n_trees; t++)
+            if (recs[tree_root[t]].kind == AH_NODE_DESCENDANTS && tree_base[t + 1] > tree_base[t])
+                AH_HIP(hipMemcpyAsync(final_perm.p + tree_base[t], perm_a.p + tree_base[t],
+                                      (tree_base[t + 1] - tree_base[t]) * 4, hipMemcpyDeviceToDevice, s));
+        if (!ds->identity_ids && M)
+            hipLaunchKernelGGL(k_rows_to_ids, dim3(2048), dim3(256), 0, s, final_perm.p, M, ds->d_ids);
         ScreenCounters sc{};
         AH_HIP(hipMemcpyAsync(&sc, d_counters, sizeof sc, hipMemcpyDeviceToHost, s));
         AH_HIP(hipStreamSynchronize(s));
@@ -3111,28 +3062,12 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         forest->stats.screen8_pairs += sc.stage8_pairs;
         forest->stats.screen8_decided += sc.stage8_decided;
         forest->stats.screen8b_decided += sc.stage8b_decided;
-        if (!early) rb.push(forest->descendants + desc_base, final_perm.p, M * 4);  // lands while the host emits the node list
+        rb.push(forest->descendants + desc_base, final_perm.p, M * 4);  // lands while the host emits the node list
     }
     // the last level's node table is digested only now: the 4 GB of item ids are already on their way
     if (pending_digest) {
         AH_HIP(hipEventSynchronize(bc.ev_copy[(pending_digest - 1) & 1]));
         AH_TRY(digest_level(pending_digest - 1, pending_nodes, h_nodes[(pending_digest - 1) & 1], pending_host_off));
-    }
-    // second phase of the early read-back: the ranges written after it started, packed, copied and put in place once the
-    // first phase has landed (it would otherwise overwrite them with what it read too early)
-    std::vector<uint32_t> late_host;
-    DevBuf<LateRange> d_late;   // (they outlive the worker's copy: drained below)
-    DevBuf<uint32_t> d_packed;
-    if (early && !late.empty()) {
-        const uint64_t late_total = late.back().offset + late.back().count;
-        AH_TRY(d_late.ensure(late.size()));
-        AH_TRY(d_packed.ensure(late_total));
-        AH_HIP(hipMemcpyAsync(d_late.p, late.data(), late.size() * sizeof(LateRange), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_pack_late_ranges, dim3((unsigned)std::min<size_t>(late.size(), 65536)), dim3(256), 0, s, final_perm.p,
-                           d_late.p, (uint32_t)late.size(), ds->identity_ids ? nullptr : ds->d_ids, d_packed.p);
-        late_host.resize(late_total);
-        AH_HIP(hipStreamSynchronize(s));
-        rb.push(late_host.data(), d_packed.p, late_total * 4);  // behind the first phase in the worker's queue
     }
     const auto t_levels = std::chrono::steady_clock::now();
     float ms = 0.0f;
@@ -3207,17 +3142,6 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     forest->stats.descendant_nodes += n_desc.load();
     const auto t_emitted = std::chrono::steady_clock::now();
     AH_REQUIRE(rb.drain() == hipSuccess, AH_ERR_DEVICE, "device -> host copy of the forest failed");
-    if (!late_host.empty()) {
-        uint32_t *dst = forest->descendants + desc_base;
-        const size_t n_threads = std::min<size_t>(8, std::max<size_t>(1, late.size() >> 12));
-        std::vector<std::thread> pool;
-        for (size_t t = 0; t < n_threads; t++)
-            pool.emplace_back([&, t] {
-                for (size_t r = late.size() * t / n_threads; r < late.size() * (t + 1) / n_threads; r++)
-                    memcpy(dst + late[r].start, late_host.data() + late[r].offset, (size_t)late[r].count * 4);
-            });
-        for (auto &th : pool) th.join();
-    }
     forest->normals_len = normals_base + normals_bytes;
     touch_normals[0].join();  // (the last level started the commit of a level that never came)
     touch_normals[1].join();

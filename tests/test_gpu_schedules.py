@@ -127,7 +127,7 @@ SWITCHES = [dict(AH_ROWS_XCD=0), dict(AH_ROWS_NT=1), dict(AH_ROWS_NT=0), dict(AH
             dict(AH_ROWMAJOR_ADVANCE=0), dict(AH_ROWMAJOR_MAX_TC=4), dict(AH_ROWS_PER_BLOCK=64), dict(AH_ROWS_CHUNK_MB=1),
             dict(AH_FOREST_NODE_BLOCKS=300), dict(AH_FOREST_TILE_BLOCKS=100, AH_FOREST_SPLIT_BLOCKS=50, AH_FOREST_ROW_BLOCKS=64),
             dict(AH_LAUNCH_MAX_ITEMS=1_000_000, AH_ROWS_CHUNK_ROWS=1024), dict(AH_MARGIN_MODE=8), dict(AH_READBACK_DIRECT=1),
-            dict(AH_NODE_PREFETCH=0), dict(AH_SCREEN8_LO=0), dict(AH_EARLY_IDS_MIN=1)]
+            dict(AH_NODE_PREFETCH=0), dict(AH_SCREEN8_LO=0)]
 
 
 def test_every_tunable_leaves_the_forest_digest_alone():
@@ -161,30 +161,6 @@ def test_every_tunable_leaves_the_forest_digest_alone():
         f.close()
     base.close()
     ds.close()
-
-
-def test_two_phase_read_back_of_the_item_ids_equals_the_oracle():
-    """The item ids of a big batch leave the device in two phases (the whole permutation once < 10 % of the items still split,
-    the ranges written afterwards packed and sent again): forced on the 64-tree cosine shape (AH_EARLY_IDS_MIN=1), with
-    identity ids and with sparse ids (the early pass converts rows to ids in place, the late pass on the way out)."""
-    n, trees = 48_000, 64
-    ds, seeds, ref = cosine768(n, trees)
-    with _lib.tuning(AH_EARLY_IDS_MIN=1):
-        f = ds.build_forest(seeds)
-        for t in range(trees):
-            assert f.canonical(t) == ref[t], t
-        f.close()
-    ids = np.sort(np.random.default_rng(4).choice(400_000, 30_000, replace=False)).astype(np.uint32)
-    ds2, oracle2, _vecs, ids = P.make_data(D.Euclidean, 30_000, 96, seed=8, ids=ids)
-    tree_seeds = [11, 12, 13, 14, 15, 16]
-    want = [oracle2.build_tree(40, s).canonical() for s in tree_seeds]
-    for knobs in (dict(AH_EARLY_IDS_MIN=1), dict()):
-        with _lib.tuning(**knobs):
-            g = ds2.build_forest(tree_seeds, split_after=40)
-        for t in range(len(tree_seeds)):
-            assert g.canonical(t) == want[t], (knobs, t)
-        g.close()
-    ds2.close()
 
 
 def test_screen_unavailable_is_reported_not_silent():
