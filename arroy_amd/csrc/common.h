@@ -94,6 +94,8 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
     X(RERANK_INVERT, "AH_RERANK_INVERT", -1)    /* 0 / 1: never / always the row-major re-rank of big submissions */      \
     X(PAIR_GROUP, "AH_PAIR_GROUP", 0)                                                                                    \
     X(PAIR_RUNS, "AH_PAIR_RUNS", 1)                                                                                      \
+    X(SEARCH_BITMAP, "AH_SEARCH_BITMAP", 1)     /* 0: sort + dedup of the candidates always by the bitonic network */     \
+    X(SEARCH_TILES, "AH_SEARCH_TILES", 1)       /* 0: never the leaf-tile re-rank of ah_search_batch */                   \
     X(STAGE_THREADS, "AH_STAGE_THREADS", 0)                                                                              \
     X(STAGE_MEMCPY, "AH_STAGE_MEMCPY", 0)                                                                                \
     X(STAGE_REGISTER, "AH_STAGE_REGISTER", 0)

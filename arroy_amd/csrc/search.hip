@@ -31,6 +31,21 @@ struct DNode {
     uint32_t c;     // SPLIT: normal row      DESCENDANTS: unused
 };
 
+// One popped Descendants node of one query: the leaf-tile re-rank groups these by node.
+struct Visit {
+    uint32_t node;  // index into nodes
+    uint32_t q;     // query
+    uint32_t pos;   // where the leaf's ids start in the query's candidate buffer
+    uint32_t pad;
+};
+struct VisitSink {          // all null / 0: the descent records nothing
+    Visit *visits;          // appended in pop order of whichever query gets there first
+    uint32_t *total;        // number of visits appended (may exceed cap: then bit 5 of *err is set)
+    uint32_t cap;
+    uint32_t *leaf_count;   // per node: visits of that node
+    uint32_t *err;          // bit 4: a queue overflowed its LDS slot; bit 5: more than `cap` visits
+};
+
 struct SearchParams {
     const DNode *nodes;
     const uint32_t *roots;
@@ -106,7 +121,7 @@ __global__ __launch_bounds__(64) void k_descend(DataView nv, SearchParams sp, co
                                                 uint32_t n_list, const uint8_t *__restrict__ qvecs, uint64_t qstride,
                                                 const float *__restrict__ qhdrs, uint32_t *__restrict__ nns,
                                                 uint32_t *__restrict__ nns_count, uint32_t *__restrict__ overflow,
-                                                uint64_t *heap_global, uint32_t heap_cap) {
+                                                uint64_t *heap_global, uint32_t heap_cap, VisitSink sink) {
     extern __shared__ uint64_t s_heap[];  // 8 x kHeapLds entries when the queue lives in LDS
     const uint32_t o = threadIdx.x >> 3, j = threadIdx.x & 7u;
     const uint32_t slot = blockIdx.x * 8 + o;
@@ -156,6 +171,15 @@ __global__ __launch_bounds__(64) void k_descend(DataView nv, SearchParams sp, co
             const uint32_t *ids = sp.desc + nd.a;
             if (!sp.filter_bits) {
                 for (uint32_t i = j; i < nd.b; i += 8) my_nns[nn + i] = ids[i];
+                if (sink.visits && j == 0 && nd.b) {
+                    const uint32_t slot = atomicAdd(sink.total, 1u);
+                    if (slot < sink.cap) {
+                        sink.visits[slot] = Visit{node, q, nn, 0u};
+                        atomicAdd(&sink.leaf_count[node], 1u);
+                    } else {
+                        atomicOr(sink.err, 32u);
+                    }
+                }
                 nn += nd.b;
             } else {  // descendants & candidates: order inside nns is irrelevant (sorted afterwards)
                 for (uint32_t base = 0; base < nd.b; base += 8) {
@@ -193,6 +217,7 @@ __global__ __launch_bounds__(64) void k_descend(DataView nv, SearchParams sp, co
     if (live && j == 0) {
         nns_count[q] = failed ? 0u : nn;
         overflow[q] = failed ? 1u : 0u;
+        if (failed && sink.err) atomicOr(sink.err, 16u);
     }
 }
 
@@ -243,6 +268,465 @@ __global__ __launch_bounds__(256) void k_sort_dedup_lds(uint32_t *__restrict__ n
     uint32_t w = s_scan[threadIdx.x];
     for (uint32_t i = lo; i < hi; i++)
         if (i == 0 || s_ids[i] != s_ids[i - 1]) ids[w++] = s_ids[i];
+}
+
+// The same sort + dedup when the id space is small enough for one bit per id in LDS: set the bit of every candidate,
+// then walk the words in order -- the ids come out ascending and unique, O(n + ids/32) instead of O(n log^2 n).
+// 16 waves per block (one block owns the LDS of a CU): wave v walks the words [v, v+1) * n_words/16, 64 consecutive
+// words per step, a wave prefix sum of the popcounts gives every lane its place, so one store instruction of the wave
+// lands in a few adjacent lines of the output.
+// An id beyond `id_limit` cannot be an item of the dataset: bit 0 of *err, the same error the re-rank would raise.
+static constexpr uint32_t kBitmapMaxWords = 39 * 1024;  // 156 KiB of the 160 KiB of LDS: 1 277 952 ids
+__global__ __launch_bounds__(1024) void k_dedup_bitmap_lds(uint32_t *__restrict__ nns, uint32_t stride,
+                                                           uint32_t *__restrict__ counts, uint32_t n_words,
+                                                           uint32_t id_limit, uint32_t *__restrict__ err) {
+    extern __shared__ uint32_t s_bits[];  // n_words, a multiple of 1024
+    __shared__ uint32_t s_wave[16];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n = counts[q];
+    uint32_t *ids = nns + (uint64_t)q * stride;
+    for (uint32_t t = tid; t < n_words / 4; t += 1024) reinterpret_cast<uint4 *>(s_bits)[t] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    bool bad = false;
+    for (uint32_t t0 = tid; t0 < n; t0 += 4 * 1024) {
+        uint32_t id[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) id[u] = t0 + u * 1024 < n ? ids[t0 + u * 1024] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (t0 + u * 1024 >= n) continue;
+            if (id[u] >= id_limit)
+                bad = true;
+            else
+                atomicOr(&s_bits[id[u] >> 5], 1u << (id[u] & 31));
+        }
+    }
+    if (bad) atomicOr(err, 1u);
+    __syncthreads();
+    const uint32_t per_wave = n_words / 16, first = wave * per_wave;
+    uint32_t mine = 0;
+    for (uint32_t i = lane; i < per_wave; i += 64) mine += __popc(s_bits[first + i]);
+    for (uint32_t d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if (lane == 0) s_wave[wave] = mine;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (uint32_t v = 0; v < 16; v++) {
+        const uint32_t c = s_wave[v];
+        base += v < wave ? c : 0u;
+        total += c;
+    }
+    if (tid == 0) counts[q] = total;
+    for (uint32_t i = 0; i < per_wave; i += 64) {
+        uint32_t bits = s_bits[first + i + lane];
+        const uint32_t c = __popc(bits);
+        uint32_t incl = c;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += v;
+        }
+        uint32_t w = base + incl - c;
+        const uint32_t id0 = (first + i + lane) << 5;
+        while (bits) {
+            ids[w++] = id0 + (uint32_t)__ffs(bits) - 1u;
+            bits &= bits - 1;
+        }
+        base += __shfl(incl, 63, 64);
+    }
+}
+
+// ---- leaf-tile re-rank (ah_search_batch without a candidate filter) ---------------------------------------------
+// The candidates of a query are whole leaves, and queries of one submission meet in the same leaves.  Instead of
+// sorting every query's list and inverting the (query, candidate) pairs by row, the descent records its leaf visits
+// (VisitSink); the visits are counting-sorted by node and cut into units of <= 16 visits of ONE node, and a block takes
+// a slab of the leaf's rows against the unit's queries: an octet holds R rows x Q queries of accumulators (a step of 32
+// dimensions issues R + Q loads for R*Q pairs; the row-run kernel of batch.hip: 5 loads for 4 pairs) and the octets of
+// a wave that work on the same rows share one load instruction, so a row line is fetched once for up to 16 queries
+// (measured, 1000 queries x 11k candidates over 1M x 1536: 9.5 GB of HBM reads per submission; one block per 4 queries
+// of a leaf read 15.9 GB -- concurrent misses of one line in L2 are not merged).  Every pair is still reduced by one
+// octet in the reference's order: the distances are bit-identical to the other re-rank kernels.
+// Distances land at the pair's position in the query's UNSORTED candidate list; duplicates (an item met in leaves of
+// several trees) are flagged by k_flag_duplicates, and k_search_select orders by (OrderedFloat(distance), id) -- the
+// order of the reference's (distance, position-in-the-sorted-list) keys.  What that cannot reproduce (a non-finite
+// distance: reader.rs:611-621 looks at positions; a selection that does not fit the small sort) raises a bit of *err
+// and the submission is redone by the sort + row-major path.
+
+// Two exclusive scans over the per-node visit counters in one pass (3 launches): `cursor` = first slot of the node's
+// visits in the sorted list, `ustart` = first work unit of the node (a unit = <= 16 visits of one node).  The last
+// launch also writes the units.
+static constexpr uint32_t kLeafScanItems = 2048;  // 256 threads x 8
+static constexpr uint32_t kUnitVisits = 16;
+struct TileUnit {
+    uint32_t node, first, n_vis, pad;  // sorted[first .. first + n_vis)
+};
+__device__ __forceinline__ uint2 block_exclusive_scan2(uint2 local, uint2 *s_wave, uint2 &block_total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2 incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t ux = __shfl_up(incl.x, d), uy = __shfl_up(incl.y, d);
+        if ((int)lane >= d) {
+            incl.x += ux;
+            incl.y += uy;
+        }
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint2 before = make_uint2(incl.x - local.x, incl.y - local.y);
+    block_total = make_uint2(0, 0);
+    for (uint32_t w = 0; w < 4; w++) {
+        if (w < wave) {
+            before.x += s_wave[w].x;
+            before.y += s_wave[w].y;
+        }
+        block_total.x += s_wave[w].x;
+        block_total.y += s_wave[w].y;
+    }
+    __syncthreads();
+    return before;
+}
+__global__ __launch_bounds__(256) void k_leaf_scan_block(const uint32_t *__restrict__ count, uint32_t n,
+                                                         uint32_t *__restrict__ cursor, uint32_t *__restrict__ ustart,
+                                                         uint2 *__restrict__ sums) {
+    __shared__ uint2 s_wave[4];
+    const uint32_t base = blockIdx.x * kLeafScanItems + threadIdx.x * 8;
+    uint32_t v[8];
+    uint2 local = make_uint2(0, 0);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        v[e] = base + e < n ? count[base + e] : 0u;
+        local.x += v[e];
+        local.y += (v[e] + kUnitVisits - 1) / kUnitVisits;
+    }
+    uint2 total;
+    uint2 before = block_exclusive_scan2(local, s_wave, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        if (base + e < n) {
+            cursor[base + e] = before.x;
+            ustart[base + e] = before.y;
+        }
+        before.x += v[e];
+        before.y += (v[e] + kUnitVisits - 1) / kUnitVisits;
+    }
+}
+__global__ __launch_bounds__(256) void k_leaf_scan_sums(uint2 *__restrict__ sums, uint32_t n_sums, uint32_t *__restrict__ n_units) {
+    __shared__ uint2 s_wave[4];
+    __shared__ uint2 s_carry;
+    if (threadIdx.x == 0) s_carry = make_uint2(0, 0);
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n_sums; b0 += 256) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint2 v = i < n_sums ? sums[i] : make_uint2(0, 0);
+        uint2 total;
+        const uint2 before = block_exclusive_scan2(v, s_wave, total);
+        const uint2 carry = s_carry;
+        if (i < n_sums) sums[i] = make_uint2(carry.x + before.x, carry.y + before.y);
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = make_uint2(carry.x + total.x, carry.y + total.y);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_units = s_carry.y;
+}
+__global__ __launch_bounds__(256) void k_leaf_scan_add(const uint32_t *__restrict__ count, uint32_t n,
+                                                       uint32_t *__restrict__ cursor, const uint32_t *__restrict__ ustart,
+                                                       const uint2 *__restrict__ sums, TileUnit *__restrict__ units) {
+    const uint2 add = sums[blockIdx.x];
+    const uint32_t base = blockIdx.x * kLeafScanItems;
+    for (uint32_t e = threadIdx.x; e < kLeafScanItems; e += 256) {
+        const uint32_t node = base + e;
+        if (node >= n) break;
+        const uint32_t c = count[node], first = cursor[node] + add.x;
+        cursor[node] = first;
+        TileUnit *dst = units + ustart[node] + add.y;
+        for (uint32_t i = 0; i * kUnitVisits < c; i++)
+            dst[i] = TileUnit{node, first + i * kUnitVisits, min(kUnitVisits, c - i * kUnitVisits), 0u};
+    }
+}
+// visits -> their node's run of the sorted list
+__global__ __launch_bounds__(256) void k_visit_scatter(const Visit *__restrict__ visits, const uint32_t *__restrict__ total,
+                                                       uint32_t cap, uint32_t *__restrict__ cursor, Visit *__restrict__ sorted) {
+    const uint32_t n = min(*total, cap);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Visit v = visits[i];
+        sorted[atomicAdd(&cursor[v.node], 1u)] = v;
+    }
+}
+
+// nns.dedup() without the sort: one bit per id in LDS, the second and later occurrences of an id become 0xFFFFFFFF
+// (never an item id here: the id space fits the bitmap).  unique[q] = ids left.
+__global__ __launch_bounds__(1024) void k_flag_duplicates(uint32_t *__restrict__ nns, uint32_t stride,
+                                                          const uint32_t *__restrict__ counts, uint32_t n_words,
+                                                          uint32_t id_limit, uint32_t *__restrict__ unique,
+                                                          uint32_t *__restrict__ err) {
+    extern __shared__ uint32_t s_bits[];  // n_words, a multiple of 1024
+    __shared__ uint32_t s_unique;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = counts[q];
+    uint32_t *ids = nns + (uint64_t)q * stride;
+    for (uint32_t t = tid; t < n_words / 4; t += 1024) reinterpret_cast<uint4 *>(s_bits)[t] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) s_unique = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    bool bad = false;
+    for (uint32_t t0 = tid; t0 < n; t0 += 4 * 1024) {
+        uint32_t id[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) id[u] = t0 + u * 1024 < n ? ids[t0 + u * 1024] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (t0 + u * 1024 >= n) continue;
+            if (id[u] >= id_limit) {
+                bad = true;
+                ids[t0 + u * 1024] = 0xFFFFFFFFu;
+                continue;
+            }
+            const uint32_t bit = 1u << (id[u] & 31);
+            if (atomicOr(&s_bits[id[u] >> 5], bit) & bit) ids[t0 + u * 1024] = 0xFFFFFFFFu;
+            else mine++;
+        }
+    }
+    if (bad) atomicOr(err, 1u);
+    for (uint32_t d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if ((tid & 63u) == 0 && mine) atomicAdd(&s_unique, mine);
+    __syncthreads();
+    if (tid == 0) unique[q] = s_unique;
+}
+
+// One block (4 waves) on rows [row_begin, row_end) of a leaf against the <= 16 visits of a unit.  The 8 octets of a wave
+// are QO query groups x 8/QO row groups; an octet holds R rows x Q queries of accumulators.  The octets of a wave that
+// share a row group issue the same row addresses in the same load instruction, so a row line leaves L2 once per wave for
+// up to QO*Q = 16 queries.
+template <int METRIC, int R, int Q, int QO>
+__device__ __forceinline__ void leaf_tile(const DataView &dv, const uint32_t *__restrict__ leaf_ids, uint32_t row_begin,
+                                          uint32_t n_rows, const Visit *__restrict__ vis, uint32_t n_vis,
+                                          const uint8_t *__restrict__ qvecs, uint64_t qstride,
+                                          const float *__restrict__ qhdrs, float *__restrict__ dist, uint32_t stride,
+                                          uint32_t *err) {
+    constexpr int OP = METRIC == AH_EUCLIDEAN ? OP_EUCLID : OP_DOT;
+    constexpr uint32_t RO = 8 / QO;  // row groups per wave
+    const uint32_t j = threadIdx.x & 7u, ow = (threadIdx.x >> 3) & 7u, wave = threadIdx.x >> 6;
+    const uint32_t q_oct = ow % QO, row_oct = wave * RO + ow / QO;
+    const uint32_t blocks = dv.dims >> 5;
+    const float4 *q4[Q];
+    uint32_t qi[Q];
+    float *out[Q];
+#pragma unroll
+    for (int t = 0; t < Q; t++) {
+        const Visit v = vis[min(q_oct * Q + (uint32_t)t, n_vis - 1)];
+        qi[t] = v.q;
+        q4[t] = reinterpret_cast<const float4 *>(qvecs + (uint64_t)v.q * qstride) + j;
+        out[t] = dist + (uint64_t)v.q * stride + v.pos;
+    }
+    for (uint32_t r0 = row_begin + row_oct * R; r0 < n_rows; r0 += 4 * RO * R) {
+        const float4 *r4[R];
+        uint64_t row[R];
+#pragma unroll
+        for (int u = 0; u < R; u++) {
+            row[u] = row_of_id(dv, leaf_ids[min(r0 + u, n_rows - 1)]);
+            r4[u] = reinterpret_cast<const float4 *>(dv.rows_f32 + (row[u] == ~0ull ? 0ull : row[u]) * dv.pitch) + j;
+        }
+        float4 acc[R][Q];
+#pragma unroll
+        for (int u = 0; u < R; u++)
+#pragma unroll
+            for (int t = 0; t < Q; t++) acc[u][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t k = 0; k < blocks; k++) {
+            float4 x[R], y[Q];
+#pragma unroll
+            for (int u = 0; u < R; u++) x[u] = r4[u][k * 8];
+#pragma unroll
+            for (int t = 0; t < Q; t++) y[t] = q4[t][k * 8];
+#pragma unroll
+            for (int u = 0; u < R; u++)
+#pragma unroll
+                for (int t = 0; t < Q; t++) fma_step<OP>(acc[u][t], y[t], x[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < R; u++) {
+            if (r0 + u >= n_rows) continue;
+            const float *rp = reinterpret_cast<const float *>(r4[u] - j);
+#pragma unroll
+            for (int t = 0; t < Q; t++) {
+                if (q_oct * Q + (uint32_t)t >= n_vis) continue;
+                float r = octet_finish(acc[u][t]);
+                r = scalar_tail<OP>(r, reinterpret_cast<const float *>(q4[t] - j), rp, blocks << 5, dv.dims);
+                if (j == 0) {
+                    float d = r;
+                    if (METRIC == AH_COSINE) d = cosine_from_dot(r, qhdrs[2 * (uint64_t)qi[t]], dv.headers[row[u] == ~0ull ? 0 : row[u]]);
+                    if (METRIC == AH_DOT_PRODUCT) d = -r;
+                    if (row[u] == ~0ull) {
+                        atomicOr(err, 1u);
+                        d = __uint_as_float(0x7FC00000u);
+                    }
+                    out[t][r0 + u] = d;
+                }
+            }
+        }
+    }
+}
+
+// blockIdx.x walks the units (persistent), blockIdx.y is the slab of rows of the unit's leaf: 128 rows when the unit has
+// more than 8 visits (4 rounds of 32 rows x 16 queries), 256 rows otherwise.
+static constexpr uint32_t kTileSlab = 128;
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_leaf_tiles(DataView dv, const DNode *__restrict__ nodes,
+                                                    const uint32_t *__restrict__ desc, const Visit *__restrict__ sorted,
+                                                    const TileUnit *__restrict__ units, const uint32_t *__restrict__ n_units_p,
+                                                    const uint8_t *__restrict__ qvecs, uint64_t qstride,
+                                                    const float *__restrict__ qhdrs, float *__restrict__ dist, uint32_t stride,
+                                                    uint32_t *err) {
+    const uint32_t n_units = *n_units_p;
+    for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const TileUnit unit = units[u];
+        const DNode nd = nodes[unit.node];
+        const uint32_t n_vis = unit.n_vis, slab = n_vis > 8 ? kTileSlab : 2 * kTileSlab;
+        const uint32_t row_begin = blockIdx.y * slab;
+        if (row_begin >= nd.b) continue;
+        const uint32_t row_end = min(nd.b, row_begin + slab);
+        const uint32_t *leaf_ids = desc + nd.a;
+        const Visit *vis = sorted + unit.first;
+#define AH_TILE(R, Q, QO) \
+    leaf_tile<METRIC, R, Q, QO>(dv, leaf_ids, row_begin, row_end, vis, n_vis, qvecs, qstride, qhdrs, dist, stride, err)
+        if (n_vis > 8) AH_TILE(4, 4, 4);
+        else if (n_vis > 4) AH_TILE(4, 4, 2);
+        else if (n_vis > 2) AH_TILE(4, 4, 1);
+        else if (n_vis == 2) AH_TILE(4, 2, 1);
+        else AH_TILE(8, 1, 1);
+#undef AH_TILE
+    }
+}
+
+// The k smallest (OrderedFloat(distance), id) of one query's unflagged candidates, ascending, as (id, normalized
+// distance); the slots beyond min(k, unique) are padded with 0xFFFFFFFF / NaN like k_batch_topk_emit does.  Selection as
+// in k_batch_topk_select (batch.hip): 2048 linear bins over the distance words, the bin of the k-th key by a scan, a
+// bitonic sort of the <= 1024 keys up to that bin.  err bit 2: a non-finite distance; bit 3: the selection does not fit.
+static constexpr uint32_t kSelectBins = 2048, kSelectCap = 1024;
+__global__ __launch_bounds__(256) void k_search_select(DataView dv, const uint32_t *__restrict__ nns,
+                                                       const float *__restrict__ dist_all, uint32_t stride,
+                                                       const uint32_t *__restrict__ counts,
+                                                       const uint32_t *__restrict__ unique, uint32_t k_out,
+                                                       uint32_t *__restrict__ out_ids, float *__restrict__ out_dist,
+                                                       uint32_t *err) {
+    __shared__ uint32_t s_hist[kSelectBins];
+    __shared__ uint64_t s_key[kSelectCap];
+    __shared__ uint32_t s_pos[kSelectCap];
+    __shared__ uint32_t s_min, s_max, s_wave[4], s_bin, s_count, s_n;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = counts[q], kk = min(k_out, unique[q]);
+    const uint32_t *ids = nns + (uint64_t)q * stride;
+    const float *dist = dist_all + (uint64_t)q * stride;
+    for (uint32_t t = kk + tid; t < k_out; t += 256) {
+        out_ids[(uint64_t)q * k_out + t] = 0xFFFFFFFFu;
+        out_dist[(uint64_t)q * k_out + t] = __uint_as_float(0xFFFFFFFFu);
+    }
+    if (kk == 0) return;
+    for (uint32_t b = tid; b < kSelectBins; b += 256) s_hist[b] = 0;
+    if (tid == 0) {
+        s_min = 0xFFFFFFFFu;
+        s_max = 0u;
+        s_n = 0u;
+    }
+    __syncthreads();
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (uint32_t g = tid; g < n; g += 256) {
+        if (ids[g] == 0xFFFFFFFFu) continue;
+        const uint32_t w = orderable_key(dist[g]);
+        lo = min(lo, w);
+        hi = max(hi, w);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
+    }
+    if ((tid & 63u) == 0) {
+        atomicMin(&s_min, lo);
+        atomicMax(&s_max, hi);
+    }
+    __syncthreads();
+    const uint32_t w_min = s_min;
+    if (s_max > 0xFF7FFFFFu) {  // +inf / NaN: the reference's rule looks at positions in the sorted list
+        if (tid == 0) atomicOr(err, 4u);
+        return;
+    }
+    const uint64_t span = (uint64_t)(s_max - w_min) + 1ull;
+    const bool direct = span <= kSelectBins;
+    const uint32_t scale = direct ? 0u : (uint32_t)(((uint64_t)kSelectBins << 32) / span);
+    auto bin_of = [&](uint32_t w) -> uint32_t {
+        return direct ? w - w_min : (uint32_t)(((uint64_t)(w - w_min) * scale) >> 32);
+    };
+    for (uint32_t g = tid; g < n; g += 256) {
+        if (ids[g] == 0xFFFFFFFFu) continue;
+        atomicAdd(&s_hist[bin_of(orderable_key(dist[g]))], 1u);
+    }
+    __syncthreads();
+    {  // the bin of the k-th smallest key: thread t owns bins 8t .. 8t+7
+        uint32_t c[8], mine = 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            c[u] = s_hist[tid * 8 + u];
+            mine += c[u];
+        }
+        uint32_t incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if ((int)(tid & 63u) >= off) incl += up;
+        }
+        if ((tid & 63u) == 63u) s_wave[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine;
+        for (uint32_t w = 0; w < (tid >> 6); w++) before += s_wave[w];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (before < kk && before + c[u] >= kk) {  // exactly one bin qualifies (kk <= unflagged candidates)
+                s_bin = tid * 8 + u;
+                s_count = before + c[u];
+            }
+            before += c[u];
+        }
+    }
+    __syncthreads();
+    const uint32_t n_sel = s_count, bin_k = s_bin;
+    if (n_sel > kSelectCap) {
+        if (tid == 0) atomicOr(err, 8u);
+        return;
+    }
+    for (uint32_t g = tid; g < n; g += 256) {
+        const uint32_t id = ids[g];
+        if (id == 0xFFFFFFFFu) continue;
+        const uint32_t w = orderable_key(dist[g]);
+        if (bin_of(w) <= bin_k) {
+            const uint32_t at = atomicAdd(&s_n, 1u);
+            s_key[at] = ((uint64_t)w << 32) | id;
+            s_pos[at] = g;
+        }
+    }
+    __syncthreads();
+    uint32_t p2 = 64;
+    while (p2 < n_sel) p2 <<= 1;
+    for (uint32_t t = n_sel + tid; t < p2; t += 256) s_key[t] = ~0ull;
+    for (uint32_t size = 2; size <= p2; size <<= 1) {
+        for (uint32_t str = size >> 1; str > 0; str >>= 1) {
+            __syncthreads();
+            for (uint32_t t = tid; t < (p2 >> 1); t += 256) {
+                const uint32_t a_i = 2 * t - (t & (str - 1)), b_i = a_i + str;
+                const bool up = (a_i & size) == 0;
+                const uint64_t x = s_key[a_i], y = s_key[b_i];
+                if ((x > y) == up) {
+                    s_key[a_i] = y;
+                    s_key[b_i] = x;
+                    const uint32_t px = s_pos[a_i];
+                    s_pos[a_i] = s_pos[b_i];
+                    s_pos[b_i] = px;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < kk; t += 256) {
+        out_ids[(uint64_t)q * k_out + t] = (uint32_t)s_key[t];
+        out_dist[(uint64_t)q * k_out + t] = normalized_distance(dv.metric, dist[s_pos[t]], dv.dims);
+    }
 }
 
 // Larger candidate sets: bitonic steps in global memory, all queries of the batch per launch.
@@ -599,6 +1083,18 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     // counters of the row-major re-rank, reserved when the candidate lists could be long enough for it
     const size_t inv_bytes = batch_invert_wanted(ds->view(), (uint64_t)nq * nns_stride) ? batch_invert_counter_bytes(ds->n, (uint64_t)nq * nns_stride) : 0;
     dev_bytes += pad(inv_bytes);
+    // leaf-tile re-rank (see k_leaf_tiles): which submissions take it, and its scratch
+    const uint32_t max_id = ds->identity_ids ? (uint32_t)(ds->n - 1) : ds->last_id;
+    const uint32_t bitmap_words = (uint32_t)(((uint64_t)max_id / 32 + 1 + 1023) / 1024 * 1024);
+    const bool bitmap_fits = tun(TUN_SEARCH_BITMAP) != 0 && bitmap_words <= kBitmapMaxWords;
+    const bool tiles = tun(TUN_SEARCH_TILES) != 0 && bitmap_fits && !big_k && !d_filter_bits && ds->dims >= 32 &&
+                       ix->max_desc <= 65535u * kTileSlab &&
+                       (ds->metric == AH_EUCLIDEAN || ds->metric == AH_COSINE || ds->metric == AH_DOT_PRODUCT);
+    const uint32_t visit_cap = (uint32_t)std::min<uint64_t>((uint64_t)nq * nns_stride, 2u << 20);
+    const uint32_t n_leaf_sums = (ix->n_nodes + kLeafScanItems - 1) / kLeafScanItems;
+    if (tiles)
+        dev_bytes += pad((size_t)visit_cap * sizeof(Visit)) * 2 + pad((size_t)visit_cap * sizeof(TileUnit)) +
+                     pad((size_t)ix->n_nodes * 4 + 8) + 2 * pad((size_t)ix->n_nodes * 4) + pad((size_t)n_leaf_sums * 8) + pad(nq * 4);
     AH_TRY(ctx->ensure_device(dev_bytes));
     const size_t pin_bytes = pad(nq * (size_t)ds->dims * 4) + pad(nq * 4) * 4 + pad(nq * sizeof(HostSeg2)) +
                              pad((size_t)max_tiles_bound * sizeof(HostTile2)) + pad(nq * k * 4) * 2 + 4096;
@@ -634,6 +1130,20 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     float *d_od = (float *)dtake(nq * k * 4);
     uint32_t *d_err = (uint32_t *)dtake(4);
     uint32_t *d_inv = inv_bytes ? (uint32_t *)dtake(inv_bytes) : nullptr;
+    Visit *d_visits = nullptr, *d_sorted = nullptr;
+    TileUnit *d_units = nullptr;
+    uint32_t *d_leaf_count = nullptr, *d_cursor = nullptr, *d_ustart = nullptr, *d_unique = nullptr;
+    uint2 *d_leaf_sums = nullptr;
+    if (tiles) {
+        d_visits = (Visit *)dtake((size_t)visit_cap * sizeof(Visit));
+        d_sorted = (Visit *)dtake((size_t)visit_cap * sizeof(Visit));
+        d_units = (TileUnit *)dtake((size_t)visit_cap * sizeof(TileUnit));
+        d_leaf_count = (uint32_t *)dtake((size_t)ix->n_nodes * 4 + 8);  // + the number of visits, + the number of units
+        d_cursor = (uint32_t *)dtake((size_t)ix->n_nodes * 4);
+        d_ustart = (uint32_t *)dtake((size_t)ix->n_nodes * 4);
+        d_leaf_sums = (uint2 *)dtake((size_t)n_leaf_sums * 8);
+        d_unique = (uint32_t *)dtake(nq * 4);
+    }
     float *h_q = (float *)ptake(nq * (size_t)ds->dims * 4);
     uint32_t *h_qrows = (uint32_t *)ptake(nq * 4);
     uint32_t *h_counts = (uint32_t *)ptake(nq * 4);
@@ -671,9 +1181,70 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     const size_t heap_lds = (size_t)8 * kHeapLds * 8;
     AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_descend<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)heap_lds));
+    if (tiles) {  // 2'. the leaf-tile path: descent with its visits recorded, no host round trip before the results
+        uint32_t *d_total = d_leaf_count + ix->n_nodes, *d_n_units = d_total + 1;
+        AH_HIP(hipMemsetAsync(d_leaf_count, 0, (size_t)ix->n_nodes * 4 + 8, s));
+        const VisitSink sink{d_visits, d_total, visit_cap, d_leaf_count, d_err};
+        hipLaunchKernelGGL((k_descend<false>), dim3((unsigned)((nq + 7) / 8)), dim3(64), heap_lds, s, ix->nv, sp,
+                           (const uint32_t *)nullptr, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow,
+                           (uint64_t *)nullptr, 0u, sink);
+        const size_t sh = (size_t)bitmap_words * 4;
+        if (sh > 48 * 1024)
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_flag_duplicates),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL(k_flag_duplicates, dim3((unsigned)nq), dim3(1024), sh, s, d_nns, nns_stride, d_counts, bitmap_words,
+                           max_id + 1, d_unique, d_err);
+        hipLaunchKernelGGL(k_leaf_scan_block, dim3(n_leaf_sums), dim3(256), 0, s, d_leaf_count, ix->n_nodes, d_cursor, d_ustart,
+                           d_leaf_sums);
+        hipLaunchKernelGGL(k_leaf_scan_sums, dim3(1), dim3(256), 0, s, d_leaf_sums, n_leaf_sums, d_n_units);
+        hipLaunchKernelGGL(k_leaf_scan_add, dim3(n_leaf_sums), dim3(256), 0, s, d_leaf_count, ix->n_nodes, d_cursor, d_ustart,
+                           d_leaf_sums, d_units);
+        hipLaunchKernelGGL(k_visit_scatter, dim3(256), dim3(256), 0, s, d_visits, d_total, visit_cap, d_cursor, d_sorted);
+        const unsigned tile_slabs = std::max(1u, (ix->max_desc + kTileSlab - 1) / kTileSlab);
+#define AH_TILES(M)                                                                                                          \
+    hipLaunchKernelGGL((k_leaf_tiles<M>), dim3(2048, tile_slabs), dim3(256), 0, s, dv, ix->d_nodes, ix->d_desc, d_sorted, d_units, \
+                       d_n_units, d_qvecs, qstride, d_qhdrs, d_dist, nns_stride, d_err)
+        switch (ds->metric) {
+        case AH_EUCLIDEAN: AH_TILES(AH_EUCLIDEAN); break;
+        case AH_COSINE: AH_TILES(AH_COSINE); break;
+        default: AH_TILES(AH_DOT_PRODUCT); break;
+        }
+#undef AH_TILES
+        if (tun(TUN_DEBUG)) {
+            AH_HIP(hipStreamSynchronize(s));
+            uint32_t nv = 0, np = 0;
+            AH_HIP(hipMemcpy(&nv, d_total, 4, hipMemcpyDeviceToHost));
+            AH_HIP(hipMemcpy(&np, d_n_units, 4, hipMemcpyDeviceToHost));
+            std::vector<Visit> hv(std::min(nv, visit_cap));
+            AH_HIP(hipMemcpy(hv.data(), d_visits, hv.size() * sizeof(Visit), hipMemcpyDeviceToHost));
+            std::vector<uint32_t> per(ix->n_nodes, 0);
+            for (auto &v : hv) per[v.node]++;
+            uint32_t hist[9] = {0}, leaves = 0;
+            for (uint32_t c : per)
+                if (c) { leaves++; hist[std::min(c, 8u)]++; }
+            fprintf(stderr, "[ah] search tiles: %u visits, %u leaves, %u units; visits per leaf 1..8+: %u %u %u %u %u %u %u %u\n", nv,
+                    leaves, np, hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]);
+        }
+        hipLaunchKernelGGL(k_search_select, dim3((unsigned)nq), dim3(256), 0, s, dv, d_nns, d_dist, nns_stride, d_counts,
+                           d_unique, (uint32_t)k, d_oi, d_od, d_err);
+        AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_counts, d_unique, nq * 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipStreamSynchronize(s));
+        AH_REQUIRE((*h_err & 1u) == 0, AH_ERR_MISSING_ITEM, "a descendant id does not exist in the dataset");
+        if ((*h_err & ~1u) == 0) {
+            for (size_t q = 0; q < nq; q++) out_counts[q] = (uint32_t)std::min<size_t>(k, h_counts[q]);
+            memcpy(out_ids, h_oi, nq * k * 4);
+            memcpy(out_dists, h_od, nq * k * 4);
+            return AH_OK;
+        }
+        // a case the tiles do not reproduce (bits 2..5 of *err, see k_search_select / VisitSink): redo it the long way
+        AH_HIP(hipMemsetAsync(d_err, 0, 4, s));
+    }
     hipLaunchKernelGGL((k_descend<false>), dim3((unsigned)((nq + 7) / 8)), dim3(64), heap_lds, s, ix->nv, sp,
                        (const uint32_t *)nullptr, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow,
-                       (uint64_t *)nullptr, 0u);
+                       (uint64_t *)nullptr, 0u, VisitSink{});
     AH_HIP(hipMemcpyAsync(h_overflow, d_overflow, nq * 4, hipMemcpyDeviceToHost, s));
     AH_HIP(hipStreamSynchronize(s));
     uint32_t n_over = 0;
@@ -684,15 +1255,26 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         AH_HIP(hipMalloc(&heap.p, (size_t)n_over * heap_cap * 8));
         AH_HIP(hipMemcpyAsync(d_list, h_list, n_over * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL((k_descend<true>), dim3((n_over + 7) / 8), dim3(64), 0, s, ix->nv, sp, (const uint32_t *)d_list,
-                           n_over, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, heap.as<uint64_t>(), heap_cap);
+                           n_over, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, heap.as<uint64_t>(), heap_cap,
+                           VisitSink{});
         AH_HIP(hipStreamSynchronize(s));
     }
     // 3. sort + dedup
-    AH_HIP(hipMemcpyAsync(h_counts, d_counts, nq * 4, hipMemcpyDeviceToHost, s));
-    AH_HIP(hipStreamSynchronize(s));
     uint32_t max_nn = 0;
-    for (size_t q = 0; q < nq; q++) max_nn = std::max(max_nn, h_counts[q]);
-    if (max_nn <= kSortLds) {
+    const bool by_bitmap = bitmap_fits;
+    if (!by_bitmap) {
+        AH_HIP(hipMemcpyAsync(h_counts, d_counts, nq * 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipStreamSynchronize(s));
+        for (size_t q = 0; q < nq; q++) max_nn = std::max(max_nn, h_counts[q]);
+    }
+    if (by_bitmap) {
+        const size_t sh = (size_t)bitmap_words * 4;
+        if (sh > 48 * 1024)
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dedup_bitmap_lds),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL(k_dedup_bitmap_lds, dim3((unsigned)nq), dim3(1024), sh, s, d_nns, nns_stride, d_counts,
+                           bitmap_words, max_id + 1, d_err);
+    } else if (max_nn <= kSortLds) {
         uint32_t np2 = 2;
         while (np2 < max_nn) np2 <<= 1;
         const size_t sh = (size_t)np2 * 4;

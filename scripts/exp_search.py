@@ -1,0 +1,30 @@
+"""The on-device search leg of bench.py alone (1M x 1536 dot product, 20 trees, 1000 queries), one caller, for
+rocprofv3 runs: python scripts/exp_search.py [repeats]."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from arroy_amd import Dataset, distances, shard  # noqa: E402
+
+repeats = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+n, dims, nq, k, n_trees = 1_000_000, 1536, 1000, 100, 20
+ds = Dataset(distances.DotProduct, dims, n, device=0)
+ds.fill_synthetic(bench.SEED, 1, n)
+ds.preprocess_dot()
+ds.finalize()
+forest = ds.build_forest(shard.tree_seeds(bench.SEED, range(n_trees)))
+index = ds.create_index(forest)
+rng = np.random.default_rng(bench.SEED)
+queries = np.stack([ds.item_vector(int(i)) for i in rng.choice(n, 64, replace=False)])
+queries = (np.tile(queries, (nq // 64 + 1, 1))[:nq] + rng.standard_normal((nq, dims)).astype(np.float32) * 0.05).astype(np.float32)
+times = []
+for _ in range(repeats + 1):
+    t0 = time.perf_counter()
+    ids, d, counts = index.search(k, queries=queries, search_k=10_000, raw=True)
+    times.append(time.perf_counter() - t0)
+print(json.dumps({"seconds": times[1:], "queries_per_s": nq / min(times[1:]), "checksum": int(ids.astype(np.uint64).sum())}))

@@ -690,16 +690,19 @@ def test_device_search_equals_oracle(metric):
             assert_bit_equal([d for _, d in got_i[qi]], [d for _, d in want])
 
 
-def test_device_search_big_queue_and_big_candidate_sets():
+@pytest.mark.parametrize("bitmap", [1, 0])
+def test_device_search_big_queue_and_big_candidate_sets(bitmap):
     """Tiny leaves (split_after=2) and a huge search_k: the queue overflows its LDS slot (re-run with the queue in
-    global memory) and the candidate set exceeds the LDS sort (global bitonic + dedup path)."""
+    global memory) and the candidate set exceeds the LDS sort (global bitonic + dedup path, or the LDS bitmap)."""
+    from arroy_amd._lib import tuning
     n, dims = 30000, 32
     ds, oracle, vecs, ids = make_data(D.Euclidean, n, dims, seed=31)
     forest = ds.build_forest([1, 2, 3], split_after=2)
     index = ds.create_index(forest)
     queries = np.random.default_rng(1).standard_normal((3, dims)).astype(np.float32)
     for search_k in (4000, 40000, 2**62):
-        got = index.search(15, queries=queries, search_k=search_k)
+        with tuning(AH_SEARCH_BITMAP=bitmap):
+            got = index.search(15, queries=queries, search_k=search_k)
         for qi in range(3):
             qv, qh = oracle.query_leaf(queries[qi])
             want, cand = O.search(oracle, forest, qv, qh, 15, search_k)
@@ -708,6 +711,96 @@ def test_device_search_big_queue_and_big_candidate_sets():
     # exhaustive search_k == exact top-k
     exact_ids, exact_d = ds.rerank(15, query=queries[0])
     assert [i for i, _ in index.search(15, queries=queries[:1], search_k=2**62)[0]] == list(exact_ids)
+
+
+@pytest.mark.parametrize("last_id", [39 * 1024 * 32 - 1, 39 * 1024 * 32, 2**32 - 1])
+def test_device_search_sort_dedup_paths_agree(last_id):
+    """nns.sort_unstable(); nns.dedup() (src/reader.rs:378-379) by the LDS bitmap (id space up to 39*1024*32 ids) and
+    by the bitonic network: the same answers, on sparse ids whose largest value sits on either side of the limit."""
+    from arroy_amd._lib import tuning
+    n, dims = 20000, 32
+    rng = np.random.default_rng(77)
+    ids = np.sort(rng.choice(min(last_id, 3_000_000), n - 1, replace=False)).astype(np.uint32)
+    ids = np.concatenate([ids, np.array([last_id], dtype=np.uint32)])
+    ds, oracle, vecs, ids = make_data(D.Cosine, n, dims, seed=78, ids=ids)
+    forest = ds.build_forest(list(range(20)), split_after=60)
+    index = ds.create_index(forest)
+    queries = rng.standard_normal((64, dims)).astype(np.float32)
+    res = {}
+    for bitmap in (1, 0):
+        with tuning(AH_SEARCH_BITMAP=bitmap):
+            res[bitmap] = [index.search(25, queries=queries, search_k=sk, raw=True) for sk in (0, 3000, 2**62)]
+    for a, b in zip(res[1], res[0]):
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0])
+        assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    oi, od, oc = res[1][1]
+    for qi in (0, 63):
+        qv, qh = oracle.query_leaf(queries[qi])
+        want, _ = O.search(oracle, forest, qv, qh, 25, 3000)
+        assert list(oi[qi, :oc[qi]]) == [i for i, _ in want]
+        assert_bit_equal(list(od[qi, :oc[qi]]), [d for _, d in want])
+
+
+@pytest.mark.parametrize("metric,dims", [(0, 100), (2, 64), (3, 96)])
+def test_device_search_leaf_tiles_equal_the_sorted_path(metric, dims):
+    """ah_search_batch by leaf tiles (rows of a leaf x the queries that reached it, duplicates flagged, order by
+    (distance, id)) and by sort + dedup + row-major re-rank: the same bits.  Queries in clusters of 1..7 near copies so
+    that leaves are shared by 1, 2, 3, 4 and more queries; equal vectors under different ids for the ties."""
+    from arroy_amd._lib import tuning
+    cls = D.BY_METRIC[metric]
+    n = 30000
+    ds, oracle, vecs, ids = make_data(cls, n, dims, seed=400 + metric)
+    forest = ds.build_forest(list(range(100, 112)), split_after=150)
+    index = ds.create_index(forest)
+    rng = np.random.default_rng(5)
+    queries = []
+    for c in range(40):
+        base = vecs[rng.integers(n)]
+        for _ in range(1 + c % 7):
+            queries.append(base + rng.standard_normal(dims).astype(np.float32) * 1e-3)
+    queries.append(vecs[1])  # three items hold this vector: a tie on the smallest distance
+    queries = np.asarray(queries, dtype=np.float32)
+    for count, sk in [(10, 0), (100, 3000), (1000, 6000), (1500, 20000)]:
+        res = {}
+        for t in (1, 0):
+            with tuning(AH_SEARCH_TILES=t):
+                res[t] = index.search(count, queries=queries, search_k=sk, raw=True)
+        assert np.array_equal(res[1][2], res[0][2]) and np.array_equal(res[1][0], res[0][0]), (count, sk)
+        assert np.array_equal(res[1][1].view(np.uint32), res[0][1].view(np.uint32)), (count, sk)
+    oi, od, oc = res[1]
+    for qi in (0, len(queries) - 1):
+        qv, qh = oracle.query_leaf(queries[qi])
+        want, _ = O.search(oracle, forest, qv, qh, 1500, 20000)
+        assert list(oi[qi, :oc[qi]]) == [i for i, _ in want]
+        assert_bit_equal(list(od[qi, :oc[qi]]), [d for _, d in want])
+
+
+def test_device_search_leaf_tiles_leave_non_finite_distances_to_the_sorted_path():
+    """Squared distances that overflow to +inf: reader.rs:611-621 treats such candidates by their position in the sorted
+    list, so the submission is redone by the sorted path; the answers are those of the oracle either way."""
+    from arroy_amd import Dataset
+    from arroy_amd._lib import tuning
+    n, dims = 3000, 32
+    rng = np.random.default_rng(9)
+    vecs = rng.standard_normal((n, dims)).astype(np.float32)
+    vecs[::7] *= np.float32(3e19)
+    ds = Dataset(D.Euclidean, dims, n)
+    ds.upload_vectors(np.arange(n, dtype=np.uint32), vecs)
+    ds.finalize()
+    oracle = O.Data(0, vecs)
+    forest = ds.build_forest([1, 2, 3, 4], split_after=50)
+    index = ds.create_index(forest)
+    queries = vecs[[0, 7, 8, 14]]
+    res = {}
+    for t in (1, 0):
+        with tuning(AH_SEARCH_TILES=t):
+            res[t] = index.search(40, queries=queries, search_k=2000, raw=True)
+    assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1].view(np.uint32), res[0][1].view(np.uint32))
+    assert np.isinf(res[1][1]).any()
+    for qi in range(4):
+        qv, qh = oracle.query_leaf(queries[qi])
+        want, _ = O.search(oracle, forest, qv, qh, 40, 2000)
+        assert list(res[1][0][qi, :res[1][2][qi]]) == [i for i, _ in want]
 
 
 # ---- incremental paths: routing through existing trees + sub-tree builds (src/writer.rs:660-739, 1398-1459) ----
