@@ -96,6 +96,7 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
     X(PAIR_RUNS, "AH_PAIR_RUNS", 1)                                                                                      \
     X(SEARCH_BITMAP, "AH_SEARCH_BITMAP", 1)     /* 0: sort + dedup of the candidates always by the bitonic network */     \
     X(SEARCH_TILES, "AH_SEARCH_TILES", 1)       /* 0: never the leaf-tile re-rank of ah_search_batch */                   \
+    X(SEARCH_WAVE, "AH_SEARCH_WAVE", 1)         /* 0: the descent always one octet per query (k_descend) */               \
     X(STAGE_THREADS, "AH_STAGE_THREADS", 0)                                                                              \
     X(STAGE_MEMCPY, "AH_STAGE_MEMCPY", 0)                                                                                \
     X(STAGE_REGISTER, "AH_STAGE_REGISTER", 0)

@@ -121,12 +121,14 @@ __global__ __launch_bounds__(64) void k_descend(DataView nv, SearchParams sp, co
                                                 uint32_t n_list, const uint8_t *__restrict__ qvecs, uint64_t qstride,
                                                 const float *__restrict__ qhdrs, uint32_t *__restrict__ nns,
                                                 uint32_t *__restrict__ nns_count, uint32_t *__restrict__ overflow,
-                                                uint64_t *heap_global, uint32_t heap_cap, VisitSink sink) {
+                                                uint64_t *heap_global, uint32_t heap_cap, VisitSink sink,
+                                                bool only_flagged) {
     extern __shared__ uint64_t s_heap[];  // 8 x kHeapLds entries when the queue lives in LDS
     const uint32_t o = threadIdx.x >> 3, j = threadIdx.x & 7u;
     const uint32_t slot = blockIdx.x * 8 + o;
-    const bool live = slot < n_list;
+    bool live = slot < n_list;
     const uint32_t q = live ? (query_list ? query_list[slot] : slot) : 0u;
+    if (only_flagged && live) live = overflow[q] != 0;  // the queries k_descend_wave left (its capacities, ties)
     uint64_t *heap = HEAP_GLOBAL ? heap_global + (uint64_t)slot * heap_cap : s_heap + o * kHeapLds;
     const uint32_t cap = HEAP_GLOBAL ? heap_cap : kHeapLds;
     const void *qvec = qvecs + (uint64_t)q * qstride;
@@ -218,6 +220,202 @@ __global__ __launch_bounds__(64) void k_descend(DataView nv, SearchParams sp, co
         nns_count[q] = failed ? 0u : nn;
         overflow[q] = failed ? 1u : 0u;
         if (failed && sink.err) atomicOr(sink.err, 16u);
+    }
+}
+
+// ---- one WAVE per query ------------------------------------------------------------------------------------------
+// The keys a best-first search pops never increase (a child's key is min(parent's key, +-margin)), so the candidates
+// are a static set: the leaves in decreasing key order until `search_k` ids are collected.  The 8 octets of the wave
+// run the search of the trees t = octet (mod 8) independently, each with its own queue in LDS, and RECORD the leaves
+// they pop instead of taking them.  A recorded leaf is settled once its key is strictly above every queue's top (nothing
+// unexplored can come before it); when the settled leaves hold >= search_k ids (or every queue is empty) they are
+// sorted by key and the prefix the sequential loop would have taken is copied out.  Same candidates as k_descend, about
+// an eighth of its chain of dependent pops.  What is left to k_descend (overflow[q] = 1): a queue or leaf list that
+// outgrows its LDS slot, and equal keys across the cut (the reference orders those by node id and by which parent was
+// popped first).
+static constexpr uint32_t kWaveHeap = 256;   // queue entries per octet
+static constexpr uint32_t kWaveLeaves = 64;  // recorded leaves per octet
+__global__ __launch_bounds__(64) void k_descend_wave(DataView nv, SearchParams sp, uint32_t nq,
+                                                     const uint8_t *__restrict__ qvecs, uint64_t qstride,
+                                                     const float *__restrict__ qhdrs, uint32_t *__restrict__ nns,
+                                                     uint32_t *__restrict__ nns_count, uint32_t *__restrict__ overflow,
+                                                     VisitSink sink) {
+    __shared__ uint64_t s_heap[8][kWaveHeap];
+    __shared__ uint64_t s_leaf[8][kWaveLeaves];  // key word << 32 | node
+    __shared__ uint32_t s_leaf_n[8][kWaveLeaves];
+    __shared__ uint64_t s_sorted[8 * kWaveLeaves];
+    __shared__ uint32_t s_sorted_n[8 * kWaveLeaves], s_pos[8 * kWaveLeaves];
+    const uint32_t q = blockIdx.x, o = threadIdx.x >> 3, j = threadIdx.x & 7u, lane = threadIdx.x;
+    if (q >= nq) return;
+    uint64_t *heap = s_heap[o];
+    const void *qvec = qvecs + (uint64_t)q * qstride;
+    const LeafHdr qh = {qhdrs[2 * (uint64_t)q], qhdrs[2 * (uint64_t)q + 1]};
+    uint32_t *my_nns = nns + (uint64_t)q * sp.nns_stride;
+    uint32_t hn = 0, nl = 0;  // lane 0 of the octet
+    bool failed = false;
+    if (j == 0)
+        for (uint32_t t = o; t < sp.n_trees; t += 8) heap_push(heap, hn, ((uint64_t)0xFF800000u << 32) | sp.roots[t]);
+    uint32_t threshold = 0;
+    bool all_settled = false;
+    for (;;) {
+        uint32_t action = 0, node = 0, key_word = 0;
+        if (j == 0 && hn > 0) {
+            const uint64_t key = heap_pop(heap, hn);
+            node = (uint32_t)key;
+            key_word = (uint32_t)(key >> 32);
+            action = sp.nodes[node].kind & 0xFFu;
+        }
+        action = __shfl(action, 0, 8);
+        node = __shfl(node, 0, 8);
+        key_word = __shfl(key_word, 0, 8);
+        if (action != 0) {
+            const DNode nd = sp.nodes[node];
+            if (action == AH_NODE_DESCENDANTS) {
+                if (j == 0) {
+                    if (nl == kWaveLeaves) {
+                        failed = true;
+                    } else {
+                        s_leaf[o][nl] = ((uint64_t)key_word << 32) | node;
+                        s_leaf_n[o][nl] = nd.b;
+                        nl++;
+                    }
+                }
+            } else {
+                float margin = 0.0f;
+                if (nd.kind & 0x100u) margin = descent_margin(nv, nd.c, qvec, qh, j);
+                if (j == 0) {
+                    if (hn + 2 > kWaveHeap) {
+                        failed = true;
+                    } else {
+                        const float dist = key_to_dist(key_word);
+                        const float pl = rust_min(-margin, dist), pr = rust_min(margin, dist);
+                        heap_push(heap, hn, ((uint64_t)orderable_key(pl) << 32) | nd.a);
+                        heap_push(heap, hn, ((uint64_t)orderable_key(pr) << 32) | nd.b);
+                    }
+                }
+            }
+        }
+        if (__any(failed)) {
+            if (lane == 0) {
+                nns_count[q] = 0;
+                overflow[q] = 1;
+            }
+            return;
+        }
+        // the largest key still queued anywhere, and the ids held by the leaves strictly above it
+        const bool has = j == 0 && hn > 0;
+        uint32_t top = has ? (uint32_t)(heap[0] >> 32) : 0u;
+        for (uint32_t d = 32; d > 0; d >>= 1) top = max(top, (uint32_t)__shfl_xor((int)top, d, 64));
+        const bool any_queued = __any(has);
+        const uint32_t nl_o = __shfl(nl, 0, 8);
+        uint32_t held = 0;
+        for (uint32_t i = j; i < nl_o; i += 8)
+            if (!any_queued || (uint32_t)(s_leaf[o][i] >> 32) > top) held += s_leaf_n[o][i];
+        for (uint32_t d = 32; d > 0; d >>= 1) held += __shfl_xor(held, d, 64);
+        if (!any_queued || held >= sp.search_k) {
+            threshold = top;
+            all_settled = !any_queued;
+            break;
+        }
+    }
+    // the settled leaves, sorted by decreasing key
+    const uint32_t nl_o = __shfl(nl, 0, 8);
+    uint32_t mine = 0;
+    for (uint32_t i = j; i < nl_o; i += 8) mine += (all_settled || (uint32_t)(s_leaf[o][i] >> 32) > threshold) ? 1u : 0u;
+    for (uint32_t d = 4; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 8);  // settled leaves of this octet
+    uint32_t first = 0, n_settled = 0;
+    for (uint32_t oo = 0; oo < 8; oo++) {
+        const uint32_t c = __shfl(mine, oo * 8, 64);
+        first += oo < o ? c : 0u;
+        n_settled += c;
+    }
+    if (j == 0) {
+        uint32_t w = first;
+        for (uint32_t i = 0; i < nl; i++)
+            if (all_settled || (uint32_t)(s_leaf[o][i] >> 32) > threshold) {
+                s_sorted[w] = s_leaf[o][i];
+                s_sorted_n[w] = s_leaf_n[o][i];
+                w++;
+            }
+    }
+    uint32_t p2 = 64;
+    while (p2 < n_settled) p2 <<= 1;
+    __syncthreads();
+    for (uint32_t t = n_settled + lane; t < p2; t += 64) {
+        s_sorted[t] = 0;
+        s_sorted_n[t] = 0;
+    }
+    for (uint32_t size = 2; size <= p2; size <<= 1) {
+        for (uint32_t str = size >> 1; str > 0; str >>= 1) {
+            __syncthreads();
+            for (uint32_t t = lane; t < (p2 >> 1); t += 64) {
+                const uint32_t a_i = 2 * t - (t & (str - 1)), b_i = a_i + str;
+                const bool down = (a_i & size) == 0;  // descending order
+                const uint64_t x = s_sorted[a_i], y = s_sorted[b_i];
+                if ((x < y) == down) {
+                    s_sorted[a_i] = y;
+                    s_sorted[b_i] = x;
+                    const uint32_t nx = s_sorted_n[a_i];
+                    s_sorted_n[a_i] = s_sorted_n[b_i];
+                    s_sorted_n[b_i] = nx;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // `if nns.len() >= search_k { break }` before every pop: leaf i is taken iff the leaves before it hold < search_k ids
+    const uint32_t per = p2 / 64;
+    uint32_t local = 0;
+    for (uint32_t i = 0; i < per; i++) local += s_sorted_n[lane * per + i];
+    uint32_t incl = local;
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    uint32_t before = incl - local, taken = 0, ids_taken = 0;
+    bool tie = false;
+    for (uint32_t i = 0; i < per; i++) {
+        const uint32_t e = lane * per + i;
+        if (e < n_settled && before < sp.search_k) {
+            s_pos[e] = before;
+            taken++;
+            ids_taken = before + s_sorted_n[e];
+            // the next leaf is left out: which of two equal keys pops first is the sequential queue's business
+            if (ids_taken >= sp.search_k && e + 1 < n_settled && (uint32_t)(s_sorted[e + 1] >> 32) == (uint32_t)(s_sorted[e] >> 32))
+                tie = true;
+        }
+        before += s_sorted_n[e];
+    }
+    for (uint32_t d = 32; d > 0; d >>= 1) {
+        taken += __shfl_xor(taken, d, 64);
+        ids_taken = max(ids_taken, (uint32_t)__shfl_xor((int)ids_taken, d, 64));
+    }
+    if (__any(tie) || ids_taken > sp.nns_stride) {
+        if (lane == 0) {
+            nns_count[q] = 0;
+            overflow[q] = 1;
+        }
+        return;
+    }
+    __syncthreads();
+    for (uint32_t e = o; e < taken; e += 8) {  // the taken leaves are the first `taken` of the sorted list
+        const uint32_t node = (uint32_t)s_sorted[e], pos = s_pos[e];
+        const DNode nd = sp.nodes[node];
+        const uint32_t *ids = sp.desc + nd.a;
+        for (uint32_t i = j; i < nd.b; i += 8) my_nns[pos + i] = ids[i];
+        if (sink.visits && j == 0 && nd.b) {
+            const uint32_t slot = atomicAdd(sink.total, 1u);
+            if (slot < sink.cap) {
+                sink.visits[slot] = Visit{node, q, pos, 0u};
+                atomicAdd(&sink.leaf_count[node], 1u);
+            } else {
+                atomicOr(sink.err, 32u);
+            }
+        }
+    }
+    if (lane == 0) {
+        nns_count[q] = ids_taken;
+        overflow[q] = 0;
     }
 }
 
@@ -1177,7 +1375,8 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     sp.search_k = search_k;
     sp.nns_stride = nns_stride;
     if (queries) AH_TRY(launch_prepare_queries_only(dv, d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
-    // 2. descent, queue in LDS
+    // 2. descent: one wave per query (no candidate filter), then one octet per query for what that left, queue in LDS
+    const bool wave_descent = tun(TUN_SEARCH_WAVE) != 0 && !d_filter_bits;
     const size_t heap_lds = (size_t)8 * kHeapLds * 8;
     AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_descend<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)heap_lds));
@@ -1185,9 +1384,13 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         uint32_t *d_total = d_leaf_count + ix->n_nodes, *d_n_units = d_total + 1;
         AH_HIP(hipMemsetAsync(d_leaf_count, 0, (size_t)ix->n_nodes * 4 + 8, s));
         const VisitSink sink{d_visits, d_total, visit_cap, d_leaf_count, d_err};
+        if (wave_descent) {
+            hipLaunchKernelGGL(k_descend_wave, dim3((unsigned)nq), dim3(64), 0, s, ix->nv, sp, (uint32_t)nq, d_qvecs, qstride,
+                               d_qhdrs, d_nns, d_counts, d_overflow, sink);
+        }
         hipLaunchKernelGGL((k_descend<false>), dim3((unsigned)((nq + 7) / 8)), dim3(64), heap_lds, s, ix->nv, sp,
                            (const uint32_t *)nullptr, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow,
-                           (uint64_t *)nullptr, 0u, sink);
+                           (uint64_t *)nullptr, 0u, sink, wave_descent);
         const size_t sh = (size_t)bitmap_words * 4;
         if (sh > 48 * 1024)
             AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_flag_duplicates),
@@ -1242,9 +1445,12 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         // a case the tiles do not reproduce (bits 2..5 of *err, see k_search_select / VisitSink): redo it the long way
         AH_HIP(hipMemsetAsync(d_err, 0, 4, s));
     }
+    if (wave_descent)
+        hipLaunchKernelGGL(k_descend_wave, dim3((unsigned)nq), dim3(64), 0, s, ix->nv, sp, (uint32_t)nq, d_qvecs, qstride, d_qhdrs,
+                           d_nns, d_counts, d_overflow, VisitSink{});
     hipLaunchKernelGGL((k_descend<false>), dim3((unsigned)((nq + 7) / 8)), dim3(64), heap_lds, s, ix->nv, sp,
                        (const uint32_t *)nullptr, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow,
-                       (uint64_t *)nullptr, 0u, VisitSink{});
+                       (uint64_t *)nullptr, 0u, VisitSink{}, wave_descent);
     AH_HIP(hipMemcpyAsync(h_overflow, d_overflow, nq * 4, hipMemcpyDeviceToHost, s));
     AH_HIP(hipStreamSynchronize(s));
     uint32_t n_over = 0;
@@ -1256,7 +1462,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         AH_HIP(hipMemcpyAsync(d_list, h_list, n_over * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL((k_descend<true>), dim3((n_over + 7) / 8), dim3(64), 0, s, ix->nv, sp, (const uint32_t *)d_list,
                            n_over, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, heap.as<uint64_t>(), heap_cap,
-                           VisitSink{});
+                           VisitSink{}, false);
         AH_HIP(hipStreamSynchronize(s));
     }
     // 3. sort + dedup

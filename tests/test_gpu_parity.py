@@ -762,11 +762,12 @@ def test_device_search_leaf_tiles_equal_the_sorted_path(metric, dims):
     queries = np.asarray(queries, dtype=np.float32)
     for count, sk in [(10, 0), (100, 3000), (1000, 6000), (1500, 20000)]:
         res = {}
-        for t in (1, 0):
-            with tuning(AH_SEARCH_TILES=t):
+        for t in (1, 0, 2):  # 2: the tiles after the descent of one octet per query
+            with tuning(AH_SEARCH_TILES=min(t, 1), AH_SEARCH_WAVE=1 if t < 2 else 0):
                 res[t] = index.search(count, queries=queries, search_k=sk, raw=True)
-        assert np.array_equal(res[1][2], res[0][2]) and np.array_equal(res[1][0], res[0][0]), (count, sk)
-        assert np.array_equal(res[1][1].view(np.uint32), res[0][1].view(np.uint32)), (count, sk)
+        for t in (0, 2):
+            assert np.array_equal(res[1][2], res[t][2]) and np.array_equal(res[1][0], res[t][0]), (count, sk, t)
+            assert np.array_equal(res[1][1].view(np.uint32), res[t][1].view(np.uint32)), (count, sk, t)
     oi, od, oc = res[1]
     for qi in (0, len(queries) - 1):
         qv, qh = oracle.query_leaf(queries[qi])
@@ -801,6 +802,64 @@ def test_device_search_leaf_tiles_leave_non_finite_distances_to_the_sorted_path(
         qv, qh = oracle.query_leaf(queries[qi])
         want, _ = O.search(oracle, forest, qv, qh, 40, 2000)
         assert list(res[1][0][qi, :res[1][2][qi]]) == [i for i, _ in want]
+
+
+@pytest.mark.parametrize("n_trees,split_after,search_k", [(1, 40, 500), (3, 8, 3000), (8, 200, 0), (20, 30, 2000),
+                                                         (37, 100, 2**62)])
+def test_device_search_wave_descent_takes_the_same_candidates(n_trees, split_after, search_k):
+    """k_descend_wave (8 octets search the trees of one query side by side and settle the leaves by key) against
+    k_descend (the sequential queue) and the oracle: fewer trees than octets, leaves small enough to overflow the leaf
+    lists (those queries go back to k_descend), an exhaustive search_k."""
+    from arroy_amd._lib import tuning
+    n, dims = 12000, 48
+    ds, oracle, vecs, ids = make_data(D.Euclidean, n, dims, seed=1000 + n_trees)
+    forest = ds.build_forest(list(range(n_trees)), split_after=split_after)
+    index = ds.create_index(forest)
+    rng = np.random.default_rng(n_trees)
+    queries = np.concatenate([vecs[rng.integers(n, size=20)], rng.standard_normal((20, dims)).astype(np.float32)])
+    res = {}
+    for w in (1, 0):
+        for t in (1, 0):
+            with tuning(AH_SEARCH_WAVE=w, AH_SEARCH_TILES=t):
+                res[w, t] = index.search(30, queries=queries, search_k=search_k, raw=True)
+    for key in res:
+        assert np.array_equal(res[key][2], res[0, 0][2]) and np.array_equal(res[key][0], res[0, 0][0]), key
+        assert np.array_equal(res[key][1].view(np.uint32), res[0, 0][1].view(np.uint32)), key
+    oi, od, oc = res[1, 1]
+    for qi in (0, 19, 20, 39):
+        qv, qh = oracle.query_leaf(queries[qi])
+        want, _ = O.search(oracle, forest, qv, qh, 30, search_k)
+        assert list(oi[qi, :oc[qi]]) == [i for i, _ in want]
+        assert_bit_equal(list(od[qi, :oc[qi]]), [d for _, d in want])
+
+
+def test_device_search_wave_descent_with_equal_keys():
+    """Degenerate rows (every split fails: `normal: None`, margin 0 for both children) make every key of a tree equal;
+    which leaf pops first is then decided by node ids and by which parent was popped first, so those queries are left
+    to the sequential queue and still match the oracle."""
+    from arroy_amd import Dataset
+    from arroy_amd._lib import tuning
+    n, dims = 800, 32
+    vecs = np.ones((n, dims), dtype=np.float32)
+    vecs[:40] = np.random.default_rng(3).standard_normal((40, dims)).astype(np.float32)
+    ds = Dataset(D.Euclidean, dims, n)
+    ds.upload_vectors(np.arange(n, dtype=np.uint32), vecs)
+    ds.finalize()
+    oracle = O.Data(0, vecs)
+    forest = ds.build_forest([9, 10, 11], split_after=16)
+    assert forest.stats["dummy_normals"] > 0
+    index = ds.create_index(forest)
+    queries = vecs[[0, 1, 100, 799]]
+    for sk in (50, 200, 700):
+        res = {}
+        for w in (1, 0):
+            with tuning(AH_SEARCH_WAVE=w):
+                res[w] = index.search(20, queries=queries, search_k=sk, raw=True)
+        assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1].view(np.uint32), res[0][1].view(np.uint32))
+        for qi in range(4):
+            qv, qh = oracle.query_leaf(queries[qi])
+            want, _ = O.search(oracle, forest, qv, qh, 20, sk)
+            assert list(res[1][0][qi, :res[1][2][qi]]) == [i for i, _ in want]
 
 
 # ---- incremental paths: routing through existing trees + sub-tree builds (src/writer.rs:660-739, 1398-1459) ----
