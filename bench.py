@@ -392,12 +392,19 @@ def extra_search(device):
     queries = np.stack([ds.item_vector(int(i)) for i in rng.choice(n, 64, replace=False)])
     queries = (np.tile(queries, (nq // 64 + 1, 1))[:nq] + rng.standard_normal((nq, dims)).astype(np.float32) * 0.05).astype(np.float32)
     _ids, _d, counts = index.search(k, queries=queries[:64], search_k=10_000, raw=True)
-    out = {"workload": f"{n}x{dims} dot product, {n_trees} trees, {nq} queries, count={k}, search_k=10000 (host in/out included)",
+    out = {"workload": f"{n}x{dims} dot product, {n_trees} trees, {nq} queries (64 items + noise), count={k}, search_k=10000 "
+                       "(host in/out included)",
            "forest_build_seconds": build_s, "results_per_query": float(counts.mean())}
     # best-first descent is sequential per query, so a call wants many queries: every caller submits all `nq`
     for threads in (1, 4):
         el = _timed_callers(lambda q: index.search(k, queries=q, search_k=10_000, raw=True), [queries] * threads, threads)
         out[f"callers_{threads}"] = {"queries_per_s": threads * nq / el, "queries": threads * nq, "seconds": el}
+    # the same call when no two queries start from the same item (they share leaves by chance only: more HBM rows per query)
+    far = np.stack([ds.item_vector(int(i)) for i in rng.choice(n, nq, replace=False)])
+    far = (far + rng.standard_normal((nq, dims)).astype(np.float32) * 0.05).astype(np.float32)
+    index.search(k, queries=far[:64], search_k=10_000, raw=True)
+    el = _timed_callers(lambda q: index.search(k, queries=q, search_k=10_000, raw=True), [far], 1)
+    out["callers_1_distinct_items"] = {"queries_per_s": nq / el, "queries": nq, "seconds": el}
     index.close()
     forest.close()
     ds.close()

@@ -1,5 +1,5 @@
 """The on-device search leg of bench.py alone (1M x 1536 dot product, 20 trees, 1000 queries), one caller, for
-rocprofv3 runs: python scripts/exp_search.py [repeats]."""
+rocprofv3 runs: python scripts/exp_search.py [repeats [distinct base items]]."""
 import json
 import os
 import sys
@@ -12,6 +12,7 @@ import bench  # noqa: E402
 from arroy_amd import Dataset, distances, shard  # noqa: E402
 
 repeats = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+clusters = int(sys.argv[2]) if len(sys.argv) > 2 else 64  # distinct base items of the 1000 queries (bench.py: 64)
 n, dims, nq, k, n_trees = 1_000_000, 1536, 1000, 100, 20
 ds = Dataset(distances.DotProduct, dims, n, device=0)
 ds.fill_synthetic(bench.SEED, 1, n)
@@ -20,8 +21,8 @@ ds.finalize()
 forest = ds.build_forest(shard.tree_seeds(bench.SEED, range(n_trees)))
 index = ds.create_index(forest)
 rng = np.random.default_rng(bench.SEED)
-queries = np.stack([ds.item_vector(int(i)) for i in rng.choice(n, 64, replace=False)])
-queries = (np.tile(queries, (nq // 64 + 1, 1))[:nq] + rng.standard_normal((nq, dims)).astype(np.float32) * 0.05).astype(np.float32)
+queries = np.stack([ds.item_vector(int(i)) for i in rng.choice(n, clusters, replace=False)])
+queries = (np.tile(queries, (nq // clusters + 1, 1))[:nq] + rng.standard_normal((nq, dims)).astype(np.float32) * 0.05).astype(np.float32)
 times = []
 for _ in range(repeats + 1):
     t0 = time.perf_counter()

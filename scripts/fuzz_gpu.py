@@ -89,6 +89,25 @@ def one(rng, it):
         want, _ = O.search(oracle, forest, v, h, count, search_k, 0, None)
         assert [a for a, _ in got[i]] == [a for a, _ in want], desc + f" search q={i} count={count} sk={search_k}"
         T.assert_bit_equal([b for _, b in got[i]], [b for _, b in want], desc + " search dists")
+    # the same submission by every path of ah_search_batch: wave / octet descent x leaf tiles / sorted re-rank
+    from arroy_amd._lib import tuning
+    qs2 = np.concatenate([qs, vecs[rng.integers(n, size=6)], vecs[rng.integers(n, size=3)] + np.float32(1e-4 * scale)])
+    count2, sk2 = int(rng.choice([1, 7, 64, 900])), int(rng.choice([0, 30, 700, 9000, 2**62]))
+    ref = None
+    for wave in (1, 0):
+        for tiles in (1, 0):
+            with tuning(AH_SEARCH_WAVE=wave, AH_SEARCH_TILES=tiles):
+                oi, od, oc = index.search(count2, queries=qs2, search_k=sk2, raw=True)
+            if ref is None:
+                ref = (oi, od, oc)
+                for i in (0, len(qs2) - 1):
+                    v, h = oracle.query_leaf(qs2[i])
+                    want, _ = O.search(oracle, forest, v, h, count2, sk2, 0, None)
+                    assert list(oi[i, : oc[i]]) == [a for a, _ in want], desc + f" search2 q={i} count={count2} sk={sk2}"
+                    T.assert_bit_equal(list(od[i, : oc[i]]), [b for _, b in want], desc + " search2 dists")
+            else:
+                assert np.array_equal(oc, ref[2]) and np.array_equal(oi, ref[0]), desc + f" wave={wave} tiles={tiles} sk={sk2}"
+                assert np.array_equal(od.view(np.uint32), ref[1].view(np.uint32)), desc + f" wave={wave} tiles={tiles} dists"
     return desc
 
 
