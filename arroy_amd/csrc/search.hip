@@ -694,7 +694,8 @@ __global__ __launch_bounds__(1024) void k_flag_duplicates(uint32_t *__restrict__
 // One block (4 waves) on rows [row_begin, row_end) of a leaf against the <= 16 visits of a unit.  The 8 octets of a wave
 // are QO query groups x 8/QO row groups; an octet holds R rows x Q queries of accumulators.  The octets of a wave that
 // share a row group issue the same row addresses in the same load instruction, so a row line leaves L2 once per wave for
-// up to QO*Q = 16 queries.
+// up to QO*Q = 16 queries.  This version keeps its operands in registers; it serves the units of <= 4 visits (QO = 1),
+// which are bound by the HBM reads of their rows whatever the inner loop does.
 template <int METRIC, int R, int Q, int QO>
 __device__ __forceinline__ void leaf_tile(const DataView &dv, const uint32_t *__restrict__ leaf_ids, uint32_t row_begin,
                                           uint32_t n_rows, const Visit *__restrict__ vis, uint32_t n_vis,
@@ -764,6 +765,134 @@ __device__ __forceinline__ void leaf_tile(const DataView &dv, const uint32_t *__
     }
 }
 
+// The same tile for units of 5..16 visits, with both operands streamed through a wave-private ring in LDS by the DMA path
+// (global_load_lds_dwordx4: lane l of an instruction fetches 16 bytes and they land lane-linearly, 1 KiB per instruction).
+// One step of 32 dimensions of a wave = 3 KiB: QO = 4: its 8 rows (1 instruction) + the 16 queries (2); QO = 2: 16 rows
+// (2) + 8 queries (1).  DEPTH - 1 steps are in flight while one is consumed (`s_waitcnt vmcnt` counts the
+// instructions of a step), so a wave keeps 15 KiB of loads outstanding without holding a register for them, and what
+// reaches the registers comes from LDS (ds_read_b128), not through the texture path a second time.  The LDS reads are
+// inline assembly: the compiler would otherwise wait for EVERY outstanding DMA before an LDS read it cannot tell apart.
+// Measured (1000 queries x 11 k candidates, 1M x 1536): k_leaf_tiles 2.21 -> 1.82 ms; the register version with 8 x 4 or
+// 4 x 8 accumulators per octet instead (fewer loads per pair, fewer waves): 2.9 ms -- the loop lives on loads in flight.
+// Slots: row w (0..8*4/QO-1) at 128 w; query qo*4+t at 128 (t*QO + qo), so the two octets of a 16-lane group read
+// adjacent 128-byte segments (all 64 banks once).
+static constexpr uint32_t kRingBytesPerWave = 18 * 1024;
+typedef float ring_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ring_f4 lds_read_f4(uint32_t addr) {
+    ring_f4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+// QO = 4 / 2 query groups per wave: 16 / 8 queries against 8 / 16 rows per step, DEPTH steps in the ring.  Slots: row
+// w = ro*4 + u at 128 w; query qo*4 + t at 128 (t*QO + qo) behind the rows -- the two octets of a 16-lane group then read
+// either the same 128 bytes or adjacent ones.  (The ring for units of <= 4 visits as well, 32 rows + 4 queries per step:
+// 364 k instead of 370 k queries/s, and no better on queries that share nothing -- not kept.)
+template <int METRIC, int QO, int DEPTH>
+__device__ __forceinline__ void leaf_tile_ring(const DataView &dv, const uint32_t *__restrict__ leaf_ids, uint32_t row_begin,
+                                               uint32_t n_rows, const Visit *__restrict__ vis, uint32_t n_vis,
+                                               const uint8_t *__restrict__ qvecs, uint64_t qstride,
+                                               const float *__restrict__ qhdrs, float *__restrict__ dist, uint32_t stride,
+                                               uint32_t *err, uint8_t *ring_all) {
+    constexpr int OP = METRIC == AH_EUCLIDEAN ? OP_EUCLID : OP_DOT;
+    constexpr int R = 4, Q = 4;
+    constexpr uint32_t RO = 8 / QO;                        // row groups per wave
+    constexpr uint32_t kRowInstr = RO * R / 8;             // DMA instructions for the rows of a step
+    constexpr uint32_t kQueryInstr = QO * Q / 8;
+    constexpr uint32_t kStepInstr = kRowInstr + kQueryInstr, kStepBytes = kStepInstr * 1024;
+    static_assert(DEPTH * kStepBytes <= kRingBytesPerWave, "the ring of a wave");
+    const uint32_t lane = threadIdx.x & 63u, j = lane & 7u, ow = lane >> 3, wave = threadIdx.x >> 6;
+    const uint32_t q_oct = ow % QO, ro = ow / QO;
+    const uint32_t blocks = dv.dims >> 5;
+    uint8_t *ring = ring_all + wave * kRingBytesPerWave;
+    const uint32_t ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)ring;
+    // the queries: what this lane fetches for the ring, and what this octet finishes
+    const uint8_t *q_src[kQueryInstr];
+#pragma unroll
+    for (uint32_t i = 0; i < kQueryInstr; i++) {
+        const uint32_t slot = i * 8 + ow, t = slot / QO, qo = slot % QO;
+        q_src[i] = qvecs + (uint64_t)vis[min(qo * Q + t, n_vis - 1)].q * qstride + j * 16;
+    }
+    uint32_t qi[Q];
+    float *out[Q];
+#pragma unroll
+    for (int t = 0; t < Q; t++) {
+        const Visit v = vis[min(q_oct * Q + (uint32_t)t, n_vis - 1)];
+        qi[t] = v.q;
+        out[t] = dist + (uint64_t)v.q * stride + v.pos;
+    }
+    const uint32_t x_addr = ring_addr + ro * R * 128 + j * 16;
+    const uint32_t y_addr = ring_addr + kRowInstr * 1024 + q_oct * 128 + j * 16;
+    for (uint32_t base = row_begin + wave * RO * R; base < n_rows; base += 4 * RO * R) {
+        const uint8_t *r_src[kRowInstr];
+#pragma unroll
+        for (uint32_t i = 0; i < kRowInstr; i++) {
+            const uint64_t row = row_of_id(dv, leaf_ids[min(base + i * 8 + ow, n_rows - 1)]);
+            r_src[i] = reinterpret_cast<const uint8_t *>(dv.rows_f32 + (row == ~0ull ? 0ull : row) * dv.pitch) + j * 16;
+        }
+        auto issue = [&](uint32_t k) {
+            uint8_t *slot = ring + (k % DEPTH) * kStepBytes;
+#pragma unroll
+            for (uint32_t i = 0; i < kRowInstr; i++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(r_src[i] + (uint64_t)k * 128),
+                                                 (__attribute__((address_space(3))) void *)(slot + i * 1024), 16, 0, 0);
+#pragma unroll
+            for (uint32_t i = 0; i < kQueryInstr; i++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(q_src[i] + (uint64_t)k * 128),
+                                                 (__attribute__((address_space(3))) void *)(slot + (kRowInstr + i) * 1024), 16, 0, 0);
+        };
+        for (uint32_t k = 0; k + 1 < DEPTH && k < blocks; k++) issue(k);
+        float4 acc[R][Q];
+#pragma unroll
+        for (int u = 0; u < R; u++)
+#pragma unroll
+            for (int t = 0; t < Q; t++) acc[u][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t k = 0; k < blocks; k++) {
+            if (k + DEPTH - 1 < blocks) {
+                issue(k + DEPTH - 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStepInstr * (DEPTH - 1)) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const uint32_t so = (k % DEPTH) * kStepBytes;
+            ring_f4 x[R], y[Q];
+#pragma unroll
+            for (int u = 0; u < R; u++) x[u] = lds_read_f4(x_addr + so + u * 128);
+#pragma unroll
+            for (int t = 0; t < Q; t++) y[t] = lds_read_f4(y_addr + so + t * QO * 128);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+#pragma unroll
+            for (int u = 0; u < R; u++)
+#pragma unroll
+                for (int t = 0; t < Q; t++)
+                    fma_step<OP>(acc[u][t], make_float4(y[t].x, y[t].y, y[t].z, y[t].w), make_float4(x[u].x, x[u].y, x[u].z, x[u].w));
+        }
+#pragma unroll
+        for (int u = 0; u < R; u++) {
+            const uint32_t r = base + ro * R + u;
+            if (r >= n_rows) continue;
+            const uint64_t row = row_of_id(dv, leaf_ids[r]);
+            const float *rp = dv.rows_f32 + (row == ~0ull ? 0ull : row) * dv.pitch;
+#pragma unroll
+            for (int t = 0; t < Q; t++) {
+                if (q_oct * Q + (uint32_t)t >= n_vis) continue;
+                float red = octet_finish(acc[u][t]);
+                red = scalar_tail<OP>(red, reinterpret_cast<const float *>(qvecs + (uint64_t)qi[t] * qstride), rp, blocks << 5, dv.dims);
+                if (j == 0) {
+                    float d = red;
+                    if (METRIC == AH_COSINE) d = cosine_from_dot(red, qhdrs[2 * (uint64_t)qi[t]], dv.headers[row == ~0ull ? 0 : row]);
+                    if (METRIC == AH_DOT_PRODUCT) d = -red;
+                    if (row == ~0ull) {
+                        atomicOr(err, 1u);
+                        d = __uint_as_float(0x7FC00000u);
+                    }
+                    out[t][r] = d;
+                }
+            }
+        }
+    }
+}
+
 // blockIdx.x walks the units (persistent), blockIdx.y is the slab of rows of the unit's leaf: 128 rows when the unit has
 // more than 8 visits (4 rounds of 32 rows x 16 queries), 256 rows otherwise.
 static constexpr uint32_t kTileSlab = 128;
@@ -774,6 +903,8 @@ __global__ __launch_bounds__(256) void k_leaf_tiles(DataView dv, const DNode *__
                                                     const uint8_t *__restrict__ qvecs, uint64_t qstride,
                                                     const float *__restrict__ qhdrs, float *__restrict__ dist, uint32_t stride,
                                                     uint32_t *err) {
+    extern __shared__ uint4 s_ring4[];
+    uint8_t *ring = reinterpret_cast<uint8_t *>(s_ring4);
     const uint32_t n_units = *n_units_p;
     for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const TileUnit unit = units[u];
@@ -786,12 +917,15 @@ __global__ __launch_bounds__(256) void k_leaf_tiles(DataView dv, const DNode *__
         const Visit *vis = sorted + unit.first;
 #define AH_TILE(R, Q, QO) \
     leaf_tile<METRIC, R, Q, QO>(dv, leaf_ids, row_begin, row_end, vis, n_vis, qvecs, qstride, qhdrs, dist, stride, err)
-        if (n_vis > 8) AH_TILE(4, 4, 4);
-        else if (n_vis > 4) AH_TILE(4, 4, 2);
+#define AH_RING(QO, DEPTH) \
+    leaf_tile_ring<METRIC, QO, DEPTH>(dv, leaf_ids, row_begin, row_end, vis, n_vis, qvecs, qstride, qhdrs, dist, stride, err, ring)
+        if (n_vis > 8) AH_RING(4, 6);
+        else if (n_vis > 4) AH_RING(2, 6);
         else if (n_vis > 2) AH_TILE(4, 4, 1);
         else if (n_vis == 2) AH_TILE(4, 2, 1);
         else AH_TILE(8, 1, 1);
 #undef AH_TILE
+#undef AH_RING
     }
 }
 
@@ -1404,9 +1538,13 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                            d_leaf_sums, d_units);
         hipLaunchKernelGGL(k_visit_scatter, dim3(256), dim3(256), 0, s, d_visits, d_total, visit_cap, d_cursor, d_sorted);
         const unsigned tile_slabs = std::max(1u, (ix->max_desc + kTileSlab - 1) / kTileSlab);
-#define AH_TILES(M)                                                                                                          \
-    hipLaunchKernelGGL((k_leaf_tiles<M>), dim3(2048, tile_slabs), dim3(256), 0, s, dv, ix->d_nodes, ix->d_desc, d_sorted, d_units, \
-                       d_n_units, d_qvecs, qstride, d_qhdrs, d_dist, nns_stride, d_err)
+#define AH_TILES(M)                                                                                                        \
+    do {                                                                                                                   \
+        AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_leaf_tiles<M>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)(4 * kRingBytesPerWave)));                                                         \
+        hipLaunchKernelGGL((k_leaf_tiles<M>), dim3(2048, tile_slabs), dim3(256), 4 * kRingBytesPerWave, s, dv, ix->d_nodes,    \
+                           ix->d_desc, d_sorted, d_units, d_n_units, d_qvecs, qstride, d_qhdrs, d_dist, nns_stride, d_err);     \
+    } while (0)
         switch (ds->metric) {
         case AH_EUCLIDEAN: AH_TILES(AH_EUCLIDEAN); break;
         case AH_COSINE: AH_TILES(AH_COSINE); break;
