@@ -86,15 +86,28 @@ int Context::ensure_pinned(size_t bytes) {
     h_cap = cap;
     return AH_OK;
 }
+int Context::ensure_filter(size_t bytes) {
+    if (bytes <= d_filter_cap) return AH_OK;
+    size_t cap = std::max(bytes + bytes / 4, d_filter_cap * 2);
+    cap = (cap + 4095) & ~(size_t)4095;
+    if (d_filter) AH_HIP(hipFree(d_filter));
+    d_filter = nullptr;
+    d_filter_cap = 0;
+    AH_HIP(hipMalloc(&d_filter, cap));
+    d_filter_cap = cap;
+    return AH_OK;
+}
 void Context::destroy() {
     if (d_scratch) (void)hipFree(d_scratch);
+    if (d_filter) (void)hipFree(d_filter);
     if (h_pinned) (void)hipHostFree(h_pinned);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     for (hipEvent_t &e : ev_ring)
         if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
-    d_scratch = h_pinned = nullptr;
+    d_scratch = h_pinned = d_filter = nullptr;
+    d_cap = h_cap = d_filter_cap = 0;
     stream = nullptr;
 }
 

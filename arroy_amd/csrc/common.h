@@ -171,8 +171,11 @@ struct Context {
     size_t d_cap = 0;
     void *h_pinned = nullptr;
     size_t h_cap = 0;
+    void *d_filter = nullptr;  // candidate filter of a search submission (bitmap + id list): outlives its sub-batches
+    size_t d_filter_cap = 0;
     int ensure_device(size_t bytes);
     int ensure_pinned(size_t bytes);
+    int ensure_filter(size_t bytes);
     void destroy();
 };
 

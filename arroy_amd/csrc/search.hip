@@ -36,7 +36,7 @@ struct Visit {
     uint32_t node;  // index into nodes
     uint32_t q;     // query
     uint32_t pos;   // where the leaf's ids start in the query's candidate buffer
-    uint32_t pad;
+    uint32_t n;     // how many (the leaf's size, or what the candidate filter kept of it)
 };
 struct VisitSink {          // all null / 0: the descent records nothing
     Visit *visits;          // appended in pop order of whichever query gets there first
@@ -55,6 +55,7 @@ struct SearchParams {
     uint64_t filter_len_bits;  // max item id + 1 (item id u32::MAX is legal, src/tests/writer.rs:161-179)
     uint32_t search_k;            // already multiplied by the oversampling, clamped to the blob size
     uint32_t nns_stride;          // capacity of one query's candidate buffer
+    const uint32_t *leaf_kept;    // per node: ids of the leaf the filter keeps (k_leaf_kept), or nullptr
 };
 
 __device__ __forceinline__ float key_to_dist(uint32_t k) {
@@ -112,6 +113,47 @@ __device__ __forceinline__ float descent_margin(const DataView &nv, uint32_t nro
     if (nv.metric == AH_EUCLIDEAN || nv.metric == AH_MANHATTAN) return f_add(nv.headers[nrow], d);
     if (nv.metric == AH_DOT_PRODUCT) return f_add(d, f_mul(nv.headers[2 * (uint64_t)nrow], qh.h0));
     return d;
+}
+
+// Visit record of one popped leaf (VisitSink), `n` ids written at `pos` of query q's candidate buffer.
+__device__ __forceinline__ void record_visit(const VisitSink &sink, uint32_t node, uint32_t q, uint32_t pos, uint32_t n) {
+    if (!sink.visits || n == 0) return;
+    const uint32_t slot = atomicAdd(sink.total, 1u);
+    if (slot < sink.cap) {
+        sink.visits[slot] = Visit{node, q, pos, n};
+        atomicAdd(&sink.leaf_count[node], 1u);
+    } else {
+        atomicOr(sink.err, 32u);
+    }
+}
+// `descendants & candidates` of one leaf by one octet: the kept ids, in the leaf's order, to dst (nullptr: count only);
+// returns how many.  32 ids per step (4 per lane, their bitmap words requested together); a ballot gives every lane the
+// number of kept ids before its own.  Octets of a wave may be here with different leaves or not at all: a lane reads only
+// its octet's byte of the ballot.
+__device__ __forceinline__ uint32_t copy_filtered(const SearchParams &sp, const uint32_t *__restrict__ ids, uint32_t n,
+                                                  uint32_t *__restrict__ dst, uint32_t j) {
+    const uint32_t shift = threadIdx.x & 56u;  // first lane of the octet
+    uint32_t written = 0;
+    for (uint32_t base = 0; base < n; base += 32) {
+        uint32_t id[4], keep[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = base + 8 * u + j;
+            id[u] = i < n ? ids[i] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool in = base + 8 * u + j < n && id[u] < sp.filter_len_bits;
+            keep[u] = in ? (sp.filter_bits[id[u] >> 5] >> (id[u] & 31)) & 1u : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t mask = (uint32_t)(__ballot(keep[u] != 0) >> shift) & 0xFFu;
+            if (keep[u] && dst) dst[written + __popc(mask & ((1u << j) - 1u))] = id[u];
+            written += __popc(mask);
+        }
+    }
+    return written;
 }
 
 // One octet per query.  HEAP_GLOBAL = false: queue in LDS (kHeapLds entries), overflow reported;
@@ -173,34 +215,12 @@ __global__ __launch_bounds__(64) void k_descend(DataView nv, SearchParams sp, co
             const uint32_t *ids = sp.desc + nd.a;
             if (!sp.filter_bits) {
                 for (uint32_t i = j; i < nd.b; i += 8) my_nns[nn + i] = ids[i];
-                if (sink.visits && j == 0 && nd.b) {
-                    const uint32_t slot = atomicAdd(sink.total, 1u);
-                    if (slot < sink.cap) {
-                        sink.visits[slot] = Visit{node, q, nn, 0u};
-                        atomicAdd(&sink.leaf_count[node], 1u);
-                    } else {
-                        atomicOr(sink.err, 32u);
-                    }
-                }
+                if (j == 0) record_visit(sink, node, q, nn, nd.b);
                 nn += nd.b;
             } else {  // descendants & candidates: order inside nns is irrelevant (sorted afterwards)
-                for (uint32_t base = 0; base < nd.b; base += 8) {
-                    const uint32_t i = base + j;
-                    uint32_t keep = 0, id = 0;
-                    if (i < nd.b) {
-                        id = ids[i];
-                        keep = id < sp.filter_len_bits && ((sp.filter_bits[id >> 5] >> (id & 31)) & 1u);
-                    }
-                    // prefix inside the octet
-                    uint32_t before = 0, total = 0;
-                    for (uint32_t l = 0; l < 8; l++) {
-                        const uint32_t kl = __shfl(keep, l, 8);
-                        if (l < j) before += kl;
-                        total += kl;
-                    }
-                    if (keep) my_nns[nn + before] = id;
-                    nn += total;
-                }
+                const uint32_t kept = copy_filtered(sp, ids, nd.b, my_nns + nn, j);
+                if (j == 0) record_visit(sink, node, q, nn, kept);
+                nn += kept;
             }
         } else {  // SplitPlaneNormal, src/reader.rs:361-372
             float margin = 0.0f;
@@ -223,6 +243,19 @@ __global__ __launch_bounds__(64) void k_descend(DataView nv, SearchParams sp, co
     }
 }
 
+// |descendants & candidates| of every leaf, once per filtered submission (the descent then pays one load per popped leaf
+// instead of a walk over its ids): one octet per node.
+__global__ __launch_bounds__(256) void k_leaf_kept(SearchParams sp, uint32_t n_nodes, uint32_t *__restrict__ kept) {
+    const uint32_t j = threadIdx.x & 7u;
+    const uint32_t octets = (gridDim.x * blockDim.x) >> 3;
+    for (uint32_t node = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; node < n_nodes; node += octets) {
+        const DNode nd = sp.nodes[node];
+        uint32_t c = 0;
+        if ((nd.kind & 0xFFu) == AH_NODE_DESCENDANTS) c = copy_filtered(sp, sp.desc + nd.a, nd.b, nullptr, j);
+        if (j == 0) kept[node] = c;
+    }
+}
+
 // ---- one WAVE per query ------------------------------------------------------------------------------------------
 // The keys a best-first search pops never increase (a child's key is min(parent's key, +-margin)), so the candidates
 // are a static set: the leaves in decreasing key order until `search_k` ids are collected.  The 8 octets of the wave
@@ -231,20 +264,26 @@ __global__ __launch_bounds__(64) void k_descend(DataView nv, SearchParams sp, co
 // unexplored can come before it); when the settled leaves hold >= search_k ids (or every queue is empty) they are
 // sorted by key and the prefix the sequential loop would have taken is copied out.  Same candidates as k_descend, about
 // an eighth of its chain of dependent pops.  What is left to k_descend (overflow[q] = 1): a queue or leaf list that
-// outgrows its LDS slot, and equal keys across the cut (the reference orders those by node id and by which parent was
-// popped first).
-static constexpr uint32_t kWaveHeap = 256;   // queue entries per octet
-static constexpr uint32_t kWaveLeaves = 64;  // recorded leaves per octet
+// outgrows its LDS slot, and equal keys of two octets across the cut (the reference orders those by node id and by which
+// parent was popped first; inside one octet its own pop order settles them -- every descendant on the far side of a split
+// whose margin is smaller than the key inherits it, so equal keys are common once a query goes past its own leaves).
+// kWaveHeap queue entries and kWaveLeaves recorded leaves per octet: 256 / 64 (30 KiB of LDS per query), or 1024 / 128
+// (92 KiB) for submissions whose candidate filter makes a query pop many more nodes.
+constexpr size_t wave_lds_bytes(uint32_t heap, uint32_t leaves) { return 8 * (size_t)heap * 8 + 8 * (size_t)leaves * (8 + 8 + 4 + 4 + 4 + 4); }
+template <uint32_t kWaveHeap, uint32_t kWaveLeaves>
 __global__ __launch_bounds__(64) void k_descend_wave(DataView nv, SearchParams sp, uint32_t nq,
                                                      const uint8_t *__restrict__ qvecs, uint64_t qstride,
                                                      const float *__restrict__ qhdrs, uint32_t *__restrict__ nns,
                                                      uint32_t *__restrict__ nns_count, uint32_t *__restrict__ overflow,
-                                                     VisitSink sink) {
-    __shared__ uint64_t s_heap[8][kWaveHeap];
-    __shared__ uint64_t s_leaf[8][kWaveLeaves];  // key word << 32 | node
-    __shared__ uint32_t s_leaf_n[8][kWaveLeaves];
-    __shared__ uint64_t s_sorted[8 * kWaveLeaves];
-    __shared__ uint32_t s_sorted_n[8 * kWaveLeaves], s_pos[8 * kWaveLeaves];
+                                                     VisitSink sink, bool only_flagged) {
+    extern __shared__ uint64_t s_wave_lds[];  // wave_lds_bytes(kWaveHeap, kWaveLeaves)
+    if (blockIdx.x >= nq || (only_flagged && overflow[blockIdx.x] == 0)) return;  // the second pass, with the big queues
+    uint64_t(*s_heap)[kWaveHeap] = reinterpret_cast<uint64_t(*)[kWaveHeap]>(s_wave_lds);
+    uint64_t(*s_leaf)[kWaveLeaves] = reinterpret_cast<uint64_t(*)[kWaveLeaves]>(s_wave_lds + 8 * kWaveHeap);  // key word << 32 | node
+    uint64_t *s_sorted = s_wave_lds + 8 * kWaveHeap + 8 * kWaveLeaves;
+    uint32_t(*s_leaf_n)[kWaveLeaves] = reinterpret_cast<uint32_t(*)[kWaveLeaves]>(s_sorted + 8 * kWaveLeaves);
+    uint32_t *s_sorted_n = reinterpret_cast<uint32_t *>(s_sorted + 8 * kWaveLeaves) + 8 * kWaveLeaves;
+    uint32_t *s_pos = s_sorted_n + 8 * kWaveLeaves, *s_sorted_node = s_pos + 8 * kWaveLeaves;
     const uint32_t q = blockIdx.x, o = threadIdx.x >> 3, j = threadIdx.x & 7u, lane = threadIdx.x;
     if (q >= nq) return;
     uint64_t *heap = s_heap[o];
@@ -271,12 +310,14 @@ __global__ __launch_bounds__(64) void k_descend_wave(DataView nv, SearchParams s
         if (action != 0) {
             const DNode nd = sp.nodes[node];
             if (action == AH_NODE_DESCENDANTS) {
-                if (j == 0) {
+                // the ids this leaf adds (`descendants & candidates` under a filter); a leaf that adds none is not a visit
+                const uint32_t kept = sp.leaf_kept ? sp.leaf_kept[node] : nd.b;
+                if (j == 0 && kept) {
                     if (nl == kWaveLeaves) {
                         failed = true;
                     } else {
                         s_leaf[o][nl] = ((uint64_t)key_word << 32) | node;
-                        s_leaf_n[o][nl] = nd.b;
+                        s_leaf_n[o][nl] = kept;
                         nl++;
                     }
                 }
@@ -329,11 +370,14 @@ __global__ __launch_bounds__(64) void k_descend_wave(DataView nv, SearchParams s
         first += oo < o ? c : 0u;
         n_settled += c;
     }
+    // Equal keys: inside one octet the order is the octet's own pop order (its queue is the sequential queue restricted
+    // to its trees, ties included), so the sort key is key word << 32 | octet << 16 | 0xFFFF - (index in the octet's list).
     if (j == 0) {
         uint32_t w = first;
         for (uint32_t i = 0; i < nl; i++)
             if (all_settled || (uint32_t)(s_leaf[o][i] >> 32) > threshold) {
-                s_sorted[w] = s_leaf[o][i];
+                s_sorted[w] = (s_leaf[o][i] & 0xFFFFFFFF00000000ull) | (o << 16) | (0xFFFFu - i);
+                s_sorted_node[w] = (uint32_t)s_leaf[o][i];
                 s_sorted_n[w] = s_leaf_n[o][i];
                 w++;
             }
@@ -344,6 +388,7 @@ __global__ __launch_bounds__(64) void k_descend_wave(DataView nv, SearchParams s
     for (uint32_t t = n_settled + lane; t < p2; t += 64) {
         s_sorted[t] = 0;
         s_sorted_n[t] = 0;
+        s_sorted_node[t] = 0;
     }
     for (uint32_t size = 2; size <= p2; size <<= 1) {
         for (uint32_t str = size >> 1; str > 0; str >>= 1) {
@@ -355,9 +400,11 @@ __global__ __launch_bounds__(64) void k_descend_wave(DataView nv, SearchParams s
                 if ((x < y) == down) {
                     s_sorted[a_i] = y;
                     s_sorted[b_i] = x;
-                    const uint32_t nx = s_sorted_n[a_i];
+                    const uint32_t nx = s_sorted_n[a_i], dx = s_sorted_node[a_i];
                     s_sorted_n[a_i] = s_sorted_n[b_i];
                     s_sorted_n[b_i] = nx;
+                    s_sorted_node[a_i] = s_sorted_node[b_i];
+                    s_sorted_node[b_i] = dx;
                 }
             }
         }
@@ -380,9 +427,17 @@ __global__ __launch_bounds__(64) void k_descend_wave(DataView nv, SearchParams s
             s_pos[e] = before;
             taken++;
             ids_taken = before + s_sorted_n[e];
-            // the next leaf is left out: which of two equal keys pops first is the sequential queue's business
-            if (ids_taken >= sp.search_k && e + 1 < n_settled && (uint32_t)(s_sorted[e + 1] >> 32) == (uint32_t)(s_sorted[e] >> 32))
-                tie = true;
+            // The leaf that reaches search_k.  If other settled leaves have its key, how many of them the sequential loop
+            // takes depends on their order: inside one octet that is the order above; between octets it is the sequential
+            // queue's business (node ids, and which parent was popped first) -- e.g. two leaves of 83 and 227 ids with one
+            // key and search_k = 90: the bigger node id pops first and decides whether the other is taken at all.
+            if (ids_taken >= sp.search_k) {
+                const uint32_t kw = (uint32_t)(s_sorted[e] >> 32), oct = (uint32_t)s_sorted[e] >> 16;
+                for (uint32_t g = e + 1; g < n_settled && (uint32_t)(s_sorted[g] >> 32) == kw; g++)
+                    if (((uint32_t)s_sorted[g] >> 16) != oct) tie = true;
+                for (uint32_t g = e; g-- > 0 && (uint32_t)(s_sorted[g] >> 32) == kw;)
+                    if (((uint32_t)s_sorted[g] >> 16) != oct) tie = true;
+            }
         }
         before += s_sorted_n[e];
     }
@@ -399,19 +454,15 @@ __global__ __launch_bounds__(64) void k_descend_wave(DataView nv, SearchParams s
     }
     __syncthreads();
     for (uint32_t e = o; e < taken; e += 8) {  // the taken leaves are the first `taken` of the sorted list
-        const uint32_t node = (uint32_t)s_sorted[e], pos = s_pos[e];
+        const uint32_t node = s_sorted_node[e], pos = s_pos[e];
         const DNode nd = sp.nodes[node];
         const uint32_t *ids = sp.desc + nd.a;
-        for (uint32_t i = j; i < nd.b; i += 8) my_nns[pos + i] = ids[i];
-        if (sink.visits && j == 0 && nd.b) {
-            const uint32_t slot = atomicAdd(sink.total, 1u);
-            if (slot < sink.cap) {
-                sink.visits[slot] = Visit{node, q, pos, 0u};
-                atomicAdd(&sink.leaf_count[node], 1u);
-            } else {
-                atomicOr(sink.err, 32u);
-            }
+        if (!sp.filter_bits) {
+            for (uint32_t i = j; i < nd.b; i += 8) my_nns[pos + i] = ids[i];
+        } else {
+            copy_filtered(sp, ids, nd.b, my_nns + pos, j);
         }
+        if (j == 0) record_visit(sink, node, q, pos, s_sorted_n[e]);
     }
     if (lane == 0) {
         nns_count[q] = ids_taken;
@@ -532,7 +583,7 @@ __global__ __launch_bounds__(1024) void k_dedup_bitmap_lds(uint32_t *__restrict_
     }
 }
 
-// ---- leaf-tile re-rank (ah_search_batch without a candidate filter) ---------------------------------------------
+// ---- leaf-tile re-rank of ah_search_batch -----------------------------------------------------------------------
 // The candidates of a query are whole leaves, and queries of one submission meet in the same leaves.  Instead of
 // sorting every query's list and inverting the (query, candidate) pairs by row, the descent records its leaf visits
 // (VisitSink); the visits are counting-sorted by node and cut into units of <= 16 visits of ONE node, and a block takes
@@ -897,8 +948,8 @@ __device__ __forceinline__ void leaf_tile_ring(const DataView &dv, const uint32_
 // more than 8 visits (4 rounds of 32 rows x 16 queries), 256 rows otherwise.
 static constexpr uint32_t kTileSlab = 128;
 template <int METRIC>
-__global__ __launch_bounds__(256) void k_leaf_tiles(DataView dv, const DNode *__restrict__ nodes,
-                                                    const uint32_t *__restrict__ desc, const Visit *__restrict__ sorted,
+__global__ __launch_bounds__(256) void k_leaf_tiles(DataView dv, const uint32_t *__restrict__ nns,
+                                                    const Visit *__restrict__ sorted,
                                                     const TileUnit *__restrict__ units, const uint32_t *__restrict__ n_units_p,
                                                     const uint8_t *__restrict__ qvecs, uint64_t qstride,
                                                     const float *__restrict__ qhdrs, float *__restrict__ dist, uint32_t stride,
@@ -908,13 +959,14 @@ __global__ __launch_bounds__(256) void k_leaf_tiles(DataView dv, const DNode *__
     const uint32_t n_units = *n_units_p;
     for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const TileUnit unit = units[u];
-        const DNode nd = nodes[unit.node];
+        const Visit *vis = sorted + unit.first;
+        // the leaf's ids (those the candidate filter kept) as the descent wrote them for the unit's first visit
+        const uint32_t n_leaf = vis[0].n;
         const uint32_t n_vis = unit.n_vis, slab = n_vis > 8 ? kTileSlab : 2 * kTileSlab;
         const uint32_t row_begin = blockIdx.y * slab;
-        if (row_begin >= nd.b) continue;
-        const uint32_t row_end = min(nd.b, row_begin + slab);
-        const uint32_t *leaf_ids = desc + nd.a;
-        const Visit *vis = sorted + unit.first;
+        if (row_begin >= n_leaf) continue;
+        const uint32_t row_end = min(n_leaf, row_begin + slab);
+        const uint32_t *leaf_ids = nns + (uint64_t)vis[0].q * stride + vis[0].pos;
 #define AH_TILE(R, Q, QO) \
     leaf_tile<METRIC, R, Q, QO>(dv, leaf_ids, row_begin, row_end, vis, n_vis, qvecs, qstride, qhdrs, dist, stride, err)
 #define AH_RING(QO, DEPTH) \
@@ -1396,7 +1448,8 @@ struct HostTile2 {
 
 static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const uint32_t *query_rows, size_t nq,
                         size_t count, uint32_t search_k, uint32_t nns_stride, const uint32_t *d_filter_bits,
-                        uint64_t filter_len_bits, uint32_t *out_ids, float *out_dists, uint32_t *out_counts) {
+                        uint64_t filter_len_bits, double filter_share, uint32_t *out_ids, float *out_dists,
+                        uint32_t *out_counts) {
     ah_dataset *ds = ix->ds;
     hipStream_t s = ctx->stream;
     const size_t qstride = (ds->row_bytes() + 255) & ~(size_t)255;
@@ -1419,11 +1472,12 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     const uint32_t max_id = ds->identity_ids ? (uint32_t)(ds->n - 1) : ds->last_id;
     const uint32_t bitmap_words = (uint32_t)(((uint64_t)max_id / 32 + 1 + 1023) / 1024 * 1024);
     const bool bitmap_fits = tun(TUN_SEARCH_BITMAP) != 0 && bitmap_words <= kBitmapMaxWords;
-    const bool tiles = tun(TUN_SEARCH_TILES) != 0 && bitmap_fits && !big_k && !d_filter_bits && ds->dims >= 32 &&
+    const bool tiles = tun(TUN_SEARCH_TILES) != 0 && bitmap_fits && !big_k && ds->dims >= 32 &&
                        ix->max_desc <= 65535u * kTileSlab &&
                        (ds->metric == AH_EUCLIDEAN || ds->metric == AH_COSINE || ds->metric == AH_DOT_PRODUCT);
     const uint32_t visit_cap = (uint32_t)std::min<uint64_t>((uint64_t)nq * nns_stride, 2u << 20);
     const uint32_t n_leaf_sums = (ix->n_nodes + kLeafScanItems - 1) / kLeafScanItems;
+    if (d_filter_bits) dev_bytes += pad((size_t)ix->n_nodes * 4);
     if (tiles)
         dev_bytes += pad((size_t)visit_cap * sizeof(Visit)) * 2 + pad((size_t)visit_cap * sizeof(TileUnit)) +
                      pad((size_t)ix->n_nodes * 4 + 8) + 2 * pad((size_t)ix->n_nodes * 4) + pad((size_t)n_leaf_sums * 8) + pad(nq * 4);
@@ -1462,6 +1516,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     float *d_od = (float *)dtake(nq * k * 4);
     uint32_t *d_err = (uint32_t *)dtake(4);
     uint32_t *d_inv = inv_bytes ? (uint32_t *)dtake(inv_bytes) : nullptr;
+    uint32_t *d_leaf_kept = d_filter_bits ? (uint32_t *)dtake((size_t)ix->n_nodes * 4) : nullptr;
     Visit *d_visits = nullptr, *d_sorted = nullptr;
     TileUnit *d_units = nullptr;
     uint32_t *d_leaf_count = nullptr, *d_cursor = nullptr, *d_ustart = nullptr, *d_unique = nullptr;
@@ -1509,8 +1564,25 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     sp.search_k = search_k;
     sp.nns_stride = nns_stride;
     if (queries) AH_TRY(launch_prepare_queries_only(dv, d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
-    // 2. descent: one wave per query (no candidate filter), then one octet per query for what that left, queue in LDS
-    const bool wave_descent = tun(TUN_SEARCH_WAVE) != 0 && !d_filter_bits;
+    // 2. descent: one wave per query, then one octet per query for what that left, queue in LDS
+    const bool wave_descent = tun(TUN_SEARCH_WAVE) != 0;
+    if (wave_descent && d_filter_bits) {  // what the filter keeps of every leaf
+        hipLaunchKernelGGL(k_leaf_kept, dim3(1024), dim3(256), 0, s, sp, ix->n_nodes, d_leaf_kept);
+        sp.leaf_kept = d_leaf_kept;
+    }
+    auto launch_wave = [&](const VisitSink &sink) -> int {
+        // a query pops about 1 / (kept share) as many nodes under a filter: start with the big queues (one query per CU
+        // at a time) only then; otherwise they take what the small ones (four per CU) could not hold
+        const bool small_first = !d_filter_bits || filter_share >= 0.35;
+        if (small_first)
+            hipLaunchKernelGGL((k_descend_wave<256, 64>), dim3((unsigned)nq), dim3(64), wave_lds_bytes(256, 64), s, ix->nv, sp,
+                               (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink, false);
+        AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_descend_wave<1024, 128>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave_lds_bytes(1024, 128)));
+        hipLaunchKernelGGL((k_descend_wave<1024, 128>), dim3((unsigned)nq), dim3(64), wave_lds_bytes(1024, 128), s, ix->nv, sp,
+                           (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink, small_first);
+        return AH_OK;
+    };
     const size_t heap_lds = (size_t)8 * kHeapLds * 8;
     AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_descend<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)heap_lds));
@@ -1518,19 +1590,10 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         uint32_t *d_total = d_leaf_count + ix->n_nodes, *d_n_units = d_total + 1;
         AH_HIP(hipMemsetAsync(d_leaf_count, 0, (size_t)ix->n_nodes * 4 + 8, s));
         const VisitSink sink{d_visits, d_total, visit_cap, d_leaf_count, d_err};
-        if (wave_descent) {
-            hipLaunchKernelGGL(k_descend_wave, dim3((unsigned)nq), dim3(64), 0, s, ix->nv, sp, (uint32_t)nq, d_qvecs, qstride,
-                               d_qhdrs, d_nns, d_counts, d_overflow, sink);
-        }
+        if (wave_descent) AH_TRY(launch_wave(sink));
         hipLaunchKernelGGL((k_descend<false>), dim3((unsigned)((nq + 7) / 8)), dim3(64), heap_lds, s, ix->nv, sp,
                            (const uint32_t *)nullptr, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow,
                            (uint64_t *)nullptr, 0u, sink, wave_descent);
-        const size_t sh = (size_t)bitmap_words * 4;
-        if (sh > 48 * 1024)
-            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_flag_duplicates),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL(k_flag_duplicates, dim3((unsigned)nq), dim3(1024), sh, s, d_nns, nns_stride, d_counts, bitmap_words,
-                           max_id + 1, d_unique, d_err);
         hipLaunchKernelGGL(k_leaf_scan_block, dim3(n_leaf_sums), dim3(256), 0, s, d_leaf_count, ix->n_nodes, d_cursor, d_ustart,
                            d_leaf_sums);
         hipLaunchKernelGGL(k_leaf_scan_sums, dim3(1), dim3(256), 0, s, d_leaf_sums, n_leaf_sums, d_n_units);
@@ -1542,8 +1605,8 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     do {                                                                                                                   \
         AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_leaf_tiles<M>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                    (int)(4 * kRingBytesPerWave)));                                                         \
-        hipLaunchKernelGGL((k_leaf_tiles<M>), dim3(2048, tile_slabs), dim3(256), 4 * kRingBytesPerWave, s, dv, ix->d_nodes,    \
-                           ix->d_desc, d_sorted, d_units, d_n_units, d_qvecs, qstride, d_qhdrs, d_dist, nns_stride, d_err);     \
+        hipLaunchKernelGGL((k_leaf_tiles<M>), dim3(2048, tile_slabs), dim3(256), 4 * kRingBytesPerWave, s, dv, d_nns, d_sorted, \
+                           d_units, d_n_units, d_qvecs, qstride, d_qhdrs, d_dist, nns_stride, d_err);                       \
     } while (0)
         switch (ds->metric) {
         case AH_EUCLIDEAN: AH_TILES(AH_EUCLIDEAN); break;
@@ -1566,6 +1629,13 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
             fprintf(stderr, "[ah] search tiles: %u visits, %u leaves, %u units; visits per leaf 1..8+: %u %u %u %u %u %u %u %u\n", nv,
                     leaves, np, hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]);
         }
+        // (after the tiles: they read the leaves' ids from the candidate buffers)
+        const size_t sh = (size_t)bitmap_words * 4;
+        if (sh > 48 * 1024)
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_flag_duplicates),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL(k_flag_duplicates, dim3((unsigned)nq), dim3(1024), sh, s, d_nns, nns_stride, d_counts, bitmap_words,
+                           max_id + 1, d_unique, d_err);
         hipLaunchKernelGGL(k_search_select, dim3((unsigned)nq), dim3(256), 0, s, dv, d_nns, d_dist, nns_stride, d_counts,
                            d_unique, (uint32_t)k, d_oi, d_od, d_err);
         AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
@@ -1583,9 +1653,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         // a case the tiles do not reproduce (bits 2..5 of *err, see k_search_select / VisitSink): redo it the long way
         AH_HIP(hipMemsetAsync(d_err, 0, 4, s));
     }
-    if (wave_descent)
-        hipLaunchKernelGGL(k_descend_wave, dim3((unsigned)nq), dim3(64), 0, s, ix->nv, sp, (uint32_t)nq, d_qvecs, qstride, d_qhdrs,
-                           d_nns, d_counts, d_overflow, VisitSink{});
+    if (wave_descent) AH_TRY(launch_wave(VisitSink{}));
     hipLaunchKernelGGL((k_descend<false>), dim3((unsigned)((nq + 7) / 8)), dim3(64), heap_lds, s, ix->nv, sp,
                        (const uint32_t *)nullptr, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow,
                        (uint64_t *)nullptr, 0u, VisitSink{}, wave_descent);
@@ -1778,27 +1846,23 @@ int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_it
     ContextLease lease(ds);
     AH_REQUIRE(lease.c, AH_ERR_DEVICE, "cannot create a HIP stream");
     Context *ctx = lease.c;
-    // candidate filter -> bitmap over item ids
-    DevMem bits_mem;
+    // candidate filter -> bitmap over item ids (ids beyond the largest stored id cannot match: the list is ascending)
     uint32_t *d_bits = nullptr;
     uint64_t bits_len = 0;
+    double filter_share = 1.0;  // of the stored items, about
     if (have_filter) {
         const uint32_t max_id = ds->identity_ids ? (uint32_t)(ds->n - 1) : ds->last_id;
         bits_len = (uint64_t)max_id + 1;
         const size_t words = ((size_t)bits_len + 31) / 32;
-        AH_HIP(hipMalloc(&bits_mem.p, words * 4));
-        d_bits = bits_mem.as<uint32_t>();
+        const size_t n_keep = n_filter ? (size_t)(std::upper_bound(filter_sorted, filter_sorted + n_filter, max_id) - filter_sorted) : 0;
+        filter_share = (double)n_keep / (double)ds->n;
+        AH_TRY(ctx->ensure_filter(words * 4 + n_keep * 4));
+        d_bits = reinterpret_cast<uint32_t *>(ctx->d_filter);
         AH_HIP(hipMemsetAsync(d_bits, 0, words * 4, ctx->stream));
-        std::vector<uint32_t> keep;
-        for (size_t i = 0; i < n_filter; i++)
-            if (filter_sorted[i] <= max_id) keep.push_back(filter_sorted[i]);
-        if (!keep.empty()) {
-            DevMem f;
-            AH_HIP(hipMalloc(&f.p, keep.size() * 4));
-            AH_HIP(hipMemcpyAsync(f.p, keep.data(), keep.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(k_filter_bitmap, dim3(256), dim3(256), 0, ctx->stream, f.as<uint32_t>(), (uint64_t)keep.size(),
-                               d_bits);
-            AH_HIP(hipStreamSynchronize(ctx->stream));
+        if (n_keep) {
+            uint32_t *d_list = d_bits + words;
+            AH_HIP(hipMemcpyAsync(d_list, filter_sorted, n_keep * 4, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_filter_bitmap, dim3(256), dim3(256), 0, ctx->stream, d_list, (uint64_t)n_keep, d_bits);
         }
     }
     // sub-batches bounded by scratch (~1.5 GiB of candidate buffers)
@@ -1812,7 +1876,7 @@ int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_it
     for (size_t q0 = 0; q0 < nq && st == AH_OK; q0 += chunk) {
         const size_t c = std::min(chunk, nq - q0);
         st = search_chunk(ix, ctx, queries ? queries + q0 * (size_t)ds->dims : nullptr, query_items ? rows.data() + q0 : nullptr,
-                          c, count, (uint32_t)sk_eff, (uint32_t)stride, d_bits, bits_len, out_ids + q0 * count,
+                          c, count, (uint32_t)sk_eff, (uint32_t)stride, d_bits, bits_len, filter_share, out_ids + q0 * count,
                           out_distances + q0 * count, out_counts + q0);
     }
     return st;

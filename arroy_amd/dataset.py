@@ -290,10 +290,10 @@ class Index:
             _lib.check(_lib.lib().ah_index_create(dataset._h, forest._h, C.byref(self._h)))
 
     def search(self, count: int, queries=None, items=None, search_k: int = 0, oversampling: int = 0, candidates=None,
-               raw: bool = False):
+               raw: bool = False, candidates_sorted: bool = False):
         """Batch of `QueryBuilder::by_vector` (queries: nq x dims) or `by_item` (items: nq ids).
         Returns a list (one entry per query) of [(id, distance), ...]; with raw=True the (ids, distances, counts)
-        arrays of the C ABI (no per-result Python objects)."""
+        arrays of the C ABI (no per-result Python objects).  `candidates` = `QueryBuilder::candidates`."""
         ds = self.dataset
         if queries is not None:
             q = _f32(queries)
@@ -306,7 +306,12 @@ class Index:
         else:
             it = _u32(items).ravel()
             nq, q = it.size, None
-        filt = None if candidates is None else _u32(sorted(set(int(c) for c in candidates)))
+        if candidates is None:
+            filt = None
+        elif candidates_sorted:  # already an ascending array of distinct ids (what a RoaringBitmap iterates)
+            filt = _u32(candidates)
+        else:
+            filt = _u32(sorted(set(int(c) for c in candidates)))
         oi = np.zeros((nq, count), dtype=np.uint32)
         od = np.zeros((nq, count), dtype=np.float32)
         oc = np.zeros(nq, dtype=np.uint32)

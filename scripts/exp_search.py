@@ -1,5 +1,5 @@
 """The on-device search leg of bench.py alone (1M x 1536 dot product, 20 trees, 1000 queries), one caller, for
-rocprofv3 runs: python scripts/exp_search.py [repeats [distinct base items]]."""
+rocprofv3 runs: python scripts/exp_search.py [repeats [distinct base items [filter share]]]."""
 import json
 import os
 import sys
@@ -13,6 +13,7 @@ from arroy_amd import Dataset, distances, shard  # noqa: E402
 
 repeats = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 clusters = int(sys.argv[2]) if len(sys.argv) > 2 else 64  # distinct base items of the 1000 queries (bench.py: 64)
+keep = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0   # candidate filter: this share of the items (0 = no filter)
 n, dims, nq, k, n_trees = 1_000_000, 1536, 1000, 100, 20
 ds = Dataset(distances.DotProduct, dims, n, device=0)
 ds.fill_synthetic(bench.SEED, 1, n)
@@ -23,9 +24,10 @@ index = ds.create_index(forest)
 rng = np.random.default_rng(bench.SEED)
 queries = np.stack([ds.item_vector(int(i)) for i in rng.choice(n, clusters, replace=False)])
 queries = (np.tile(queries, (nq // clusters + 1, 1))[:nq] + rng.standard_normal((nq, dims)).astype(np.float32) * 0.05).astype(np.float32)
+cand = np.sort(rng.choice(n, int(n * keep), replace=False)).astype(np.uint32) if keep > 0 else None
 times = []
 for _ in range(repeats + 1):
     t0 = time.perf_counter()
-    ids, d, counts = index.search(k, queries=queries, search_k=10_000, raw=True)
+    ids, d, counts = index.search(k, queries=queries, search_k=10_000, raw=True, candidates=cand, candidates_sorted=True)
     times.append(time.perf_counter() - t0)
 print(json.dumps({"seconds": times[1:], "queries_per_s": nq / min(times[1:]), "checksum": int(ids.astype(np.uint64).sum())}))

@@ -93,21 +93,38 @@ def one(rng, it):
     from arroy_amd._lib import tuning
     qs2 = np.concatenate([qs, vecs[rng.integers(n, size=6)], vecs[rng.integers(n, size=3)] + np.float32(1e-4 * scale)])
     count2, sk2 = int(rng.choice([1, 7, 64, 900])), int(rng.choice([0, 30, 700, 9000, 2**62]))
+    cand = None
+    if rng.random() < 0.5:  # `candidates: &RoaringBitmap`, item ids (some of them not in the database)
+        cand = [int(x) for x in rng.choice(int(ids[-1]) + 3, int(rng.integers(0, min(n, 4000) + 1)), replace=False)]
     ref = None
     for wave in (1, 0):
         for tiles in (1, 0):
             with tuning(AH_SEARCH_WAVE=wave, AH_SEARCH_TILES=tiles):
-                oi, od, oc = index.search(count2, queries=qs2, search_k=sk2, raw=True)
+                oi, od, oc = index.search(count2, queries=qs2, search_k=sk2, candidates=cand, raw=True)
             if ref is None:
                 ref = (oi, od, oc)
                 for i in (0, len(qs2) - 1):
                     v, h = oracle.query_leaf(qs2[i])
-                    want, _ = O.search(oracle, forest, v, h, count2, sk2, 0, None)
+                    want, _ = O.search(oracle, forest, v, h, count2, sk2, 0, cand)
                     assert list(oi[i, : oc[i]]) == [a for a, _ in want], desc + f" search2 q={i} count={count2} sk={sk2}"
                     T.assert_bit_equal(list(od[i, : oc[i]]), [b for _, b in want], desc + " search2 dists")
             else:
-                assert np.array_equal(oc, ref[2]) and np.array_equal(oi, ref[0]), desc + f" wave={wave} tiles={tiles} sk={sk2}"
-                assert np.array_equal(od.view(np.uint32), ref[1].view(np.uint32)), desc + f" wave={wave} tiles={tiles} dists"
+                same = np.array_equal(oc, ref[2]) and np.array_equal(oi, ref[0]) and np.array_equal(od.view(np.uint32), ref[1].view(np.uint32))
+                if not same:  # which side left the oracle, and for which query
+                    bad = [i for i in range(len(qs2)) if oc[i] != ref[2][i] or not np.array_equal(oi[i], ref[0][i])
+                           or not np.array_equal(od[i].view(np.uint32), ref[1][i].view(np.uint32))]
+                    i = bad[0]
+                    v, h = oracle.query_leaf(qs2[i])
+                    want, _ = O.search(oracle, forest, v, h, count2, sk2, 0, cand)
+                    w_ids = [a for a, _ in want]
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    np.savez(os.path.join(ROOT, "gpurun_out", "fuzz_fail.npz"), metric=metric, vecs=vecs, ids=ids, roots=forest.roots,
+                             nodes=forest.nodes, normals=forest.normals, normal_stride=forest.normal_stride, vec_off=forest._vec_off,
+                             hdr_off=forest._hdr_off, descendants=forest.descendants, query=qs2[i], count=count2, sk=sk2,
+                             first_mode=ref[0][i, :ref[2][i]], this_mode=oi[i, :oc[i]])
+                    raise AssertionError(desc + f" wave={wave} tiles={tiles} count={count2} sk={sk2} filter={None if cand is None else len(cand)} "
+                                         f"sa={split_after} queries {bad}: q={i} oracle {w_ids[:8]} this {list(oi[i, :oc[i]])[:8]} "
+                                         f"first mode {list(ref[0][i, :ref[2][i]])[:8]}")
     return desc
 
 

@@ -5,6 +5,8 @@ reference's AVX+FMA (dims >= 32), SSE (16..31) and scalar (< 16) summation order
 north star allows for f32 distances (1e-5 relative) is therefore asserted as *zero* ulps here.
 Run with:  gpurun -- python -m pytest tests -m gpu -x -q
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -760,14 +762,24 @@ def test_device_search_leaf_tiles_equal_the_sorted_path(metric, dims):
             queries.append(base + rng.standard_normal(dims).astype(np.float32) * 1e-3)
     queries.append(vecs[1])  # three items hold this vector: a tie on the smallest distance
     queries = np.asarray(queries, dtype=np.float32)
-    for count, sk in [(10, 0), (100, 3000), (1000, 6000), (1500, 20000)]:
+    keep_third = rng.choice(n, n // 3, replace=False)
+    for count, sk, cand in [(10, 0, None), (100, 3000, None), (1000, 6000, None), (1500, 20000, None),
+                            (100, 3000, keep_third), (40, 900, range(0, n, 50)), (10, 500, [7])]:
         res = {}
         for t in (1, 0, 2):  # 2: the tiles after the descent of one octet per query
             with tuning(AH_SEARCH_TILES=min(t, 1), AH_SEARCH_WAVE=1 if t < 2 else 0):
-                res[t] = index.search(count, queries=queries, search_k=sk, raw=True)
+                res[t] = index.search(count, queries=queries, search_k=sk, candidates=cand, raw=True)
         for t in (0, 2):
             assert np.array_equal(res[1][2], res[t][2]) and np.array_equal(res[1][0], res[t][0]), (count, sk, t)
             assert np.array_equal(res[1][1].view(np.uint32), res[t][1].view(np.uint32)), (count, sk, t)
+        if cand is not None:  # candidate filter: against the oracle too
+            oi, od, oc = res[1]
+            for qi in (0, 5, len(queries) - 1):
+                qv, qh = oracle.query_leaf(queries[qi])
+                want, _ = O.search(oracle, forest, qv, qh, count, sk, 0, cand)
+                assert list(oi[qi, :oc[qi]]) == [i for i, _ in want], (count, sk, qi)
+                assert_bit_equal(list(od[qi, :oc[qi]]), [d for _, d in want])
+    res[1] = index.search(1500, queries=queries, search_k=20000, raw=True)
     oi, od, oc = res[1]
     for qi in (0, len(queries) - 1):
         qv, qh = oracle.query_leaf(queries[qi])
@@ -860,6 +872,66 @@ def test_device_search_wave_descent_with_equal_keys():
             qv, qh = oracle.query_leaf(queries[qi])
             want, _ = O.search(oracle, forest, qv, qh, 20, sk)
             assert list(res[1][0][qi, :res[1][2][qi]]) == [i for i, _ in want]
+
+
+@pytest.mark.parametrize("metric,dims", [(4, 31), (6, 17), (5, 64)])
+def test_device_search_wave_descent_equal_keys_between_trees(metric, dims):
+    """Binary-quantized margins are small integers (plus a bias), so leaves of different trees often carry the same key.
+    Which of them the sequential loop takes depends on their pop order (node ids): e.g. leaves of 83 and 227 ids with
+    one key and search_k = 90 -- the one popped first may end the search alone.  k_descend_wave must leave such queries
+    to the sequential queue: every query of 300, for several search_k, against k_descend."""
+    from arroy_amd._lib import tuning
+    cls = D.BY_METRIC[metric]
+    n = 2049
+    ds, oracle, vecs, ids = make_data(cls, n, dims, seed=4242 + metric)
+    forest = ds.build_forest(list(range(17)), split_after=300)
+    index = ds.create_index(forest)
+    rng = np.random.default_rng(12)
+    queries = np.concatenate([vecs[rng.integers(n, size=150)], rng.standard_normal((150, dims)).astype(np.float32)])
+    for count, sk in [(7, 30), (3, 1), (20, 150), (10, 400)]:
+        res = {}
+        for w in (1, 0):
+            with tuning(AH_SEARCH_WAVE=w):
+                res[w] = index.search(count, queries=queries, search_k=sk, raw=True)
+        assert np.array_equal(res[1][2], res[0][2]) and np.array_equal(res[1][0], res[0][0]), (count, sk)
+        assert np.array_equal(res[1][1].view(np.uint32), res[0][1].view(np.uint32)), (count, sk)
+    oi, od, oc = res[0]
+    for qi in (0, 299):
+        qv, qh = oracle.query_leaf(queries[qi])
+        want, _ = O.search(oracle, forest, qv, qh, 10, 400)
+        assert list(oi[qi, :oc[qi]]) == [i for i, _ in want]
+
+
+def _equal_keys_fixture():
+    """tests/golden/search_equal_keys_bq.npz: a BinaryQuantizedEuclidean forest (17 trees, 2049 items, 31 dimensions) and a
+    query whose two best leaves (83 and 227 ids, in trees of different octets) carry the same key 5.0 while search_k = 90:
+    the sequential queue pops the 227-id leaf first (bigger node id) and stops there.  Found by scripts/fuzz_gpu.py; the
+    expected answer in the file is the oracle's (tests/test_oracle_golden.py checks that on the CPU)."""
+    import types
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "search_equal_keys_bq.npz"))
+    forest = types.SimpleNamespace(n_trees=len(g["roots"]), roots=g["roots"], nodes=g["nodes"], normals=g["normals"],
+                                   normal_stride=int(g["normal_stride"]), _vec_off=int(g["vec_off"]), _hdr_off=int(g["hdr_off"]),
+                                   descendants=g["descendants"])
+    return g, forest
+
+
+def test_device_search_wave_descent_equal_keys_across_the_cut():
+    from arroy_amd import Dataset
+    from arroy_amd._lib import tuning
+    from arroy_amd.dataset import Index
+    g, forest = _equal_keys_fixture()
+    cls = D.BY_METRIC[int(g["metric"])]
+    ds = Dataset(cls, g["vecs"].shape[1], len(g["vecs"]))
+    ds.upload_vectors(g["ids"], g["vecs"])
+    ds.finalize()
+    index = Index(ds, None, view=O.forest_view(forest))
+    queries = np.stack([g["query"]] * 9)  # more than one block of the octet-per-query kernel
+    for wave in (1, 0):
+        with tuning(AH_SEARCH_WAVE=wave):
+            oi, od, oc = index.search(int(g["count"]), queries=queries, search_k=int(g["sk"]), raw=True)
+        for qi in range(len(queries)):
+            assert list(oi[qi, :oc[qi]]) == list(g["want_ids"]), f"wave={wave}"
+            assert_bit_equal(list(od[qi, :oc[qi]]), list(g["want_dists"]))
 
 
 # ---- incremental paths: routing through existing trees + sub-tree builds (src/writer.rs:660-739, 1398-1459) ----

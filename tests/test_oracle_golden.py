@@ -248,3 +248,24 @@ def test_oracle_search_exhaustive_equals_full_rerank_and_respects_search_k():
         assert none == [] and len(cand) == 0
         some, cand = O.search(data, forest, qv, qh, 7, search_k=2**62, candidates=range(0, 600, 5))
         assert set(cand) == set(range(0, 600, 5))
+
+
+def test_oracle_search_pops_equal_keys_by_node_id():
+    """tests/golden/search_equal_keys_bq.npz (found by scripts/fuzz_gpu.py): the two best leaves of the query carry the
+    same key and search_k = 90 lies between their sizes (83 / 227 ids).  `BinaryHeap<(OrderedFloat<f32>, NodeId)>`
+    (src/reader.rs:338-374) pops the bigger node id first -- the 227-id leaf -- and the search ends there; the oracle
+    restates that, and the file's expected answer is what the GPU test of the same fixture must return."""
+    import os
+    import types
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "search_equal_keys_bq.npz"))
+    forest = types.SimpleNamespace(n_trees=len(g["roots"]), roots=g["roots"], nodes=g["nodes"], normals=g["normals"],
+                                   normal_stride=int(g["normal_stride"]), _vec_off=int(g["vec_off"]), _hdr_off=int(g["hdr_off"]),
+                                   descendants=g["descendants"])
+    data = O.Data(int(g["metric"]), g["vecs"], ids=g["ids"])
+    qv, qh = data.query_leaf(g["query"])
+    got, cand = O.search(data, forest, qv, qh, int(g["count"]), int(g["sk"]))
+    assert [i for i, _ in got] == list(g["want_ids"]) and len(cand) == int(g["n_candidates"]) == 227
+    assert np.array_equal(np.array([d for _, d in got], dtype=np.float32).view(np.uint32), g["want_dists"].view(np.uint32))
+    # the leaf that is NOT taken has the same key: both leaves are children reached with margin 5.0
+    leaves = {int(n["count"]) for n in g["nodes"] if n["kind"] == 1}
+    assert {83, 227} <= leaves
