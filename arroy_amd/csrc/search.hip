@@ -1565,7 +1565,8 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     sp.nns_stride = nns_stride;
     if (queries) AH_TRY(launch_prepare_queries_only(dv, d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
     // 2. descent: one wave per query, then one octet per query for what that left, queue in LDS
-    const bool wave_descent = tun(TUN_SEARCH_WAVE) != 0;
+    // (a filter that keeps under 5 % of the items makes a query pop more nodes than the queues of a wave hold)
+    const bool wave_descent = tun(TUN_SEARCH_WAVE) != 0 && (!d_filter_bits || filter_share >= 0.05);
     if (wave_descent && d_filter_bits) {  // what the filter keeps of every leaf
         hipLaunchKernelGGL(k_leaf_kept, dim3(1024), dim3(256), 0, s, sp, ix->n_nodes, d_leaf_kept);
         sp.leaf_kept = d_leaf_kept;

@@ -764,7 +764,7 @@ def test_device_search_leaf_tiles_equal_the_sorted_path(metric, dims):
     queries = np.asarray(queries, dtype=np.float32)
     keep_third = rng.choice(n, n // 3, replace=False)
     for count, sk, cand in [(10, 0, None), (100, 3000, None), (1000, 6000, None), (1500, 20000, None),
-                            (100, 3000, keep_third), (40, 900, range(0, n, 50)), (10, 500, [7])]:
+                            (100, 3000, keep_third), (100, 3000, range(0, n, 2)), (40, 900, range(0, n, 50)), (10, 500, [7])]:
         res = {}
         for t in (1, 0, 2):  # 2: the tiles after the descent of one octet per query
             with tuning(AH_SEARCH_TILES=min(t, 1), AH_SEARCH_WAVE=1 if t < 2 else 0):
