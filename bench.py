@@ -405,6 +405,12 @@ def extra_search(device):
     index.search(k, queries=far[:64], search_k=10_000, raw=True)
     el = _timed_callers(lambda q: index.search(k, queries=q, search_k=10_000, raw=True), [far], 1)
     out["callers_1_distinct_items"] = {"queries_per_s": nq / el, "queries": nq, "seconds": el}
+    # `QueryBuilder::candidates`: a filter that keeps half of the items (every search of a filtered index has one)
+    half = np.sort(rng.choice(n, n // 2, replace=False)).astype(np.uint32)
+    run = lambda q: index.search(k, queries=q, search_k=10_000, raw=True, candidates=half, candidates_sorted=True)  # noqa: E731
+    run(queries[:64])
+    el = _timed_callers(run, [queries], 1)
+    out["callers_1_filter_half"] = {"queries_per_s": nq / el, "queries": nq, "seconds": el}
     index.close()
     forest.close()
     ds.close()
