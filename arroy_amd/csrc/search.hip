@@ -985,8 +985,8 @@ __global__ __launch_bounds__(256) void k_leaf_tiles(DataView dv, const uint32_t 
 // distance); the slots beyond min(k, unique) are padded with 0xFFFFFFFF / NaN like k_batch_topk_emit does.  Selection as
 // in k_batch_topk_select (batch.hip): 2048 linear bins over the distance words, the bin of the k-th key by a scan, a
 // bitonic sort of the <= 1024 keys up to that bin.  err bit 2: a non-finite distance; bit 3: the selection does not fit.
-static constexpr uint32_t kSelectBins = 2048, kSelectCap = 1024;
-__global__ __launch_bounds__(256) void k_search_select(DataView dv, const uint32_t *__restrict__ nns,
+static constexpr uint32_t kSelectBins = 2048, kSelectCap = 1024, kSelectThreads = 1024;
+__global__ __launch_bounds__(kSelectThreads) void k_search_select(DataView dv, const uint32_t *__restrict__ nns,
                                                        const float *__restrict__ dist_all, uint32_t stride,
                                                        const uint32_t *__restrict__ counts,
                                                        const uint32_t *__restrict__ unique, uint32_t k_out,
@@ -995,17 +995,17 @@ __global__ __launch_bounds__(256) void k_search_select(DataView dv, const uint32
     __shared__ uint32_t s_hist[kSelectBins];
     __shared__ uint64_t s_key[kSelectCap];
     __shared__ uint32_t s_pos[kSelectCap];
-    __shared__ uint32_t s_min, s_max, s_wave[4], s_bin, s_count, s_n;
+    __shared__ uint32_t s_min, s_max, s_wave[kSelectThreads / 64], s_bin, s_count, s_n;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = counts[q], kk = min(k_out, unique[q]);
     const uint32_t *ids = nns + (uint64_t)q * stride;
     const float *dist = dist_all + (uint64_t)q * stride;
-    for (uint32_t t = kk + tid; t < k_out; t += 256) {
+    for (uint32_t t = kk + tid; t < k_out; t += kSelectThreads) {
         out_ids[(uint64_t)q * k_out + t] = 0xFFFFFFFFu;
         out_dist[(uint64_t)q * k_out + t] = __uint_as_float(0xFFFFFFFFu);
     }
     if (kk == 0) return;
-    for (uint32_t b = tid; b < kSelectBins; b += 256) s_hist[b] = 0;
+    for (uint32_t b = tid; b < kSelectBins; b += kSelectThreads) s_hist[b] = 0;
     if (tid == 0) {
         s_min = 0xFFFFFFFFu;
         s_max = 0u;
@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_search_select(DataView dv, const uint32
     }
     __syncthreads();
     uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-    for (uint32_t g = tid; g < n; g += 256) {
+    for (uint32_t g = tid; g < n; g += kSelectThreads) {
         if (ids[g] == 0xFFFFFFFFu) continue;
         const uint32_t w = orderable_key(dist[g]);
         lo = min(lo, w);
@@ -1039,16 +1039,17 @@ __global__ __launch_bounds__(256) void k_search_select(DataView dv, const uint32
     auto bin_of = [&](uint32_t w) -> uint32_t {
         return direct ? w - w_min : (uint32_t)(((uint64_t)(w - w_min) * scale) >> 32);
     };
-    for (uint32_t g = tid; g < n; g += 256) {
+    for (uint32_t g = tid; g < n; g += kSelectThreads) {
         if (ids[g] == 0xFFFFFFFFu) continue;
         atomicAdd(&s_hist[bin_of(orderable_key(dist[g]))], 1u);
     }
     __syncthreads();
-    {  // the bin of the k-th smallest key: thread t owns bins 8t .. 8t+7
-        uint32_t c[8], mine = 0;
+    {  // the bin of the k-th smallest key: thread t owns kPer consecutive bins
+        constexpr uint32_t kPer = kSelectBins / kSelectThreads;
+        uint32_t c[kPer], mine = 0;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            c[u] = s_hist[tid * 8 + u];
+        for (uint32_t u = 0; u < kPer; u++) {
+            c[u] = s_hist[tid * kPer + u];
             mine += c[u];
         }
         uint32_t incl = mine;
@@ -1061,9 +1062,9 @@ __global__ __launch_bounds__(256) void k_search_select(DataView dv, const uint32
         uint32_t before = incl - mine;
         for (uint32_t w = 0; w < (tid >> 6); w++) before += s_wave[w];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (uint32_t u = 0; u < kPer; u++) {
             if (before < kk && before + c[u] >= kk) {  // exactly one bin qualifies (kk <= unflagged candidates)
-                s_bin = tid * 8 + u;
+                s_bin = tid * kPer + u;
                 s_count = before + c[u];
             }
             before += c[u];
@@ -1075,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_search_select(DataView dv, const uint32
         if (tid == 0) atomicOr(err, 8u);
         return;
     }
-    for (uint32_t g = tid; g < n; g += 256) {
+    for (uint32_t g = tid; g < n; g += kSelectThreads) {
         const uint32_t id = ids[g];
         if (id == 0xFFFFFFFFu) continue;
         const uint32_t w = orderable_key(dist[g]);
@@ -1088,11 +1089,11 @@ __global__ __launch_bounds__(256) void k_search_select(DataView dv, const uint32
     __syncthreads();
     uint32_t p2 = 64;
     while (p2 < n_sel) p2 <<= 1;
-    for (uint32_t t = n_sel + tid; t < p2; t += 256) s_key[t] = ~0ull;
+    for (uint32_t t = n_sel + tid; t < p2; t += kSelectThreads) s_key[t] = ~0ull;
     for (uint32_t size = 2; size <= p2; size <<= 1) {
         for (uint32_t str = size >> 1; str > 0; str >>= 1) {
             __syncthreads();
-            for (uint32_t t = tid; t < (p2 >> 1); t += 256) {
+            for (uint32_t t = tid; t < (p2 >> 1); t += kSelectThreads) {
                 const uint32_t a_i = 2 * t - (t & (str - 1)), b_i = a_i + str;
                 const bool up = (a_i & size) == 0;
                 const uint64_t x = s_key[a_i], y = s_key[b_i];
@@ -1107,7 +1108,7 @@ __global__ __launch_bounds__(256) void k_search_select(DataView dv, const uint32
         }
     }
     __syncthreads();
-    for (uint32_t t = tid; t < kk; t += 256) {
+    for (uint32_t t = tid; t < kk; t += kSelectThreads) {
         out_ids[(uint64_t)q * k_out + t] = (uint32_t)s_key[t];
         out_dist[(uint64_t)q * k_out + t] = normalized_distance(dv.metric, dist[s_pos[t]], dv.dims);
     }
@@ -1637,7 +1638,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         hipLaunchKernelGGL(k_flag_duplicates, dim3((unsigned)nq), dim3(1024), sh, s, d_nns, nns_stride, d_counts, bitmap_words,
                            max_id + 1, d_unique, d_err);
-        hipLaunchKernelGGL(k_search_select, dim3((unsigned)nq), dim3(256), 0, s, dv, d_nns, d_dist, nns_stride, d_counts,
+        hipLaunchKernelGGL(k_search_select, dim3((unsigned)nq), dim3(kSelectThreads), 0, s, dv, d_nns, d_dist, nns_stride, d_counts,
                            d_unique, (uint32_t)k, d_oi, d_od, d_err);
         AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
