@@ -747,6 +747,49 @@ __global__ __launch_bounds__(1024) void k_flag_duplicates(uint32_t *__restrict__
 // share a row group issue the same row addresses in the same load instruction, so a row line leaves L2 once per wave for
 // up to QO*Q = 16 queries.  This version keeps its operands in registers; it serves the units of <= 4 visits (QO = 1),
 // which are bound by the HBM reads of their rows whatever the inner loop does.
+// The same for id spaces too big for a bitmap (10M items: 1.25 MB of bits): an open-addressing set of the query's
+// candidates in LDS, 32768 slots for <= 24576 candidates (a submission with longer lists takes the sorted path).  The
+// first insertion of an id wins its slot; a later one finds it there and is flagged.  0xFFFFFFFF marks an empty slot, so the
+// path is not taken when that id is stored.
+static constexpr uint32_t kHashSlots = 32768, kHashMaxCandidates = 24576;
+__global__ __launch_bounds__(1024) void k_flag_duplicates_hash(uint32_t *__restrict__ nns, uint32_t stride,
+                                                               const uint32_t *__restrict__ counts,
+                                                               uint32_t *__restrict__ unique, uint32_t *__restrict__ err) {
+    extern __shared__ uint32_t s_set[];  // kHashSlots
+    __shared__ uint32_t s_unique;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = counts[q];
+    uint32_t *ids = nns + (uint64_t)q * stride;
+    for (uint32_t t = tid; t < kHashSlots / 4; t += 1024) reinterpret_cast<uint4 *>(s_set)[t] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    if (tid == 0) s_unique = 0;
+    __syncthreads();
+    if (n > kHashMaxCandidates) {  // block-uniform; cannot happen for the strides this path is chosen for
+        if (tid == 0) atomicOr(err, 8u);
+        return;
+    }
+    uint32_t mine = 0;
+    for (uint32_t t = tid; t < n; t += 1024) {
+        const uint32_t id = ids[t];
+        uint32_t h = (id * 2654435761u) >> 17;  // Fibonacci hashing: the top 15 bits
+        for (;;) {
+            const uint32_t old = atomicCAS(&s_set[h], 0xFFFFFFFFu, id);
+            if (old == 0xFFFFFFFFu) {
+                mine++;
+                break;
+            }
+            if (old == id) {
+                ids[t] = 0xFFFFFFFFu;
+                break;
+            }
+            h = (h + 1) & (kHashSlots - 1);
+        }
+    }
+    for (uint32_t d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if ((tid & 63u) == 0 && mine) atomicAdd(&s_unique, mine);
+    __syncthreads();
+    if (tid == 0) unique[q] = s_unique;
+}
+
 template <int METRIC, int R, int Q, int QO>
 __device__ __forceinline__ void leaf_tile(const DataView &dv, const uint32_t *__restrict__ leaf_ids, uint32_t row_begin,
                                           uint32_t n_rows, const Visit *__restrict__ vis, uint32_t n_vis,
@@ -1473,7 +1516,9 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     const uint32_t max_id = ds->identity_ids ? (uint32_t)(ds->n - 1) : ds->last_id;
     const uint32_t bitmap_words = (uint32_t)(((uint64_t)max_id / 32 + 1 + 1023) / 1024 * 1024);
     const bool bitmap_fits = tun(TUN_SEARCH_BITMAP) != 0 && bitmap_words <= kBitmapMaxWords;
-    const bool tiles = tun(TUN_SEARCH_TILES) != 0 && bitmap_fits && !big_k && ds->dims >= 32 &&
+    // nns.dedup() of the tiles: the LDS bitmap, or a hash set of the candidates when the id space is too big for it
+    const bool hash_fits = nns_stride <= kHashMaxCandidates && max_id != 0xFFFFFFFFu;
+    const bool tiles = tun(TUN_SEARCH_TILES) != 0 && (bitmap_fits || hash_fits) && !big_k && ds->dims >= 32 &&
                        ix->max_desc <= 65535u * kTileSlab &&
                        (ds->metric == AH_EUCLIDEAN || ds->metric == AH_COSINE || ds->metric == AH_DOT_PRODUCT);
     const uint32_t visit_cap = (uint32_t)std::min<uint64_t>((uint64_t)nq * nns_stride, 2u << 20);
@@ -1632,12 +1677,19 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                     leaves, np, hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]);
         }
         // (after the tiles: they read the leaves' ids from the candidate buffers)
-        const size_t sh = (size_t)bitmap_words * 4;
-        if (sh > 48 * 1024)
-            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_flag_duplicates),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL(k_flag_duplicates, dim3((unsigned)nq), dim3(1024), sh, s, d_nns, nns_stride, d_counts, bitmap_words,
-                           max_id + 1, d_unique, d_err);
+        if (bitmap_fits) {
+            const size_t sh = (size_t)bitmap_words * 4;
+            if (sh > 48 * 1024)
+                AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_flag_duplicates),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+            hipLaunchKernelGGL(k_flag_duplicates, dim3((unsigned)nq), dim3(1024), sh, s, d_nns, nns_stride, d_counts, bitmap_words,
+                               max_id + 1, d_unique, d_err);
+        } else {
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_flag_duplicates_hash),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHashSlots * 4)));
+            hipLaunchKernelGGL(k_flag_duplicates_hash, dim3((unsigned)nq), dim3(1024), kHashSlots * 4, s, d_nns, nns_stride, d_counts,
+                               d_unique, d_err);
+        }
         hipLaunchKernelGGL(k_search_select, dim3((unsigned)nq), dim3(kSelectThreads), 0, s, dv, d_nns, d_dist, nns_stride, d_counts,
                            d_unique, (uint32_t)k, d_oi, d_od, d_err);
         AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));

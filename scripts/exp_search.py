@@ -1,4 +1,4 @@
-"""The on-device search leg of bench.py alone (1M x 1536 dot product, 20 trees, 1000 queries), one caller, for
+"""The on-device search leg of bench.py alone (1M x 1536 dot product, 20 trees, 1000 queries; AH_EXP_SHAPE: others), one caller, for
 rocprofv3 runs: python scripts/exp_search.py [repeats [distinct base items [filter share]]]."""
 import json
 import os
@@ -14,10 +14,14 @@ from arroy_amd import Dataset, distances, shard  # noqa: E402
 repeats = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 clusters = int(sys.argv[2]) if len(sys.argv) > 2 else 64  # distinct base items of the 1000 queries (bench.py: 64)
 keep = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0   # candidate filter: this share of the items (0 = no filter)
-n, dims, nq, k, n_trees = 1_000_000, 1536, 1000, 100, 20
-ds = Dataset(distances.DotProduct, dims, n, device=0)
+# AH_EXP_SHAPE=items,dims,trees,metric (default: the bench leg 1000000,1536,20,dot; e.g. 10000000,768,100,cosine)
+shape = os.environ.get("AH_EXP_SHAPE", "1000000,1536,20,dot").split(",")
+n, dims, n_trees, nq, k = int(shape[0]), int(shape[1]), int(shape[2]), 1000, 100
+cls = {"dot": distances.DotProduct, "cosine": distances.Cosine, "euclidean": distances.Euclidean}[shape[3]]
+ds = Dataset(cls, dims, n, device=0)
 ds.fill_synthetic(bench.SEED, 1, n)
-ds.preprocess_dot()
+if cls is distances.DotProduct:
+    ds.preprocess_dot()
 ds.finalize()
 forest = ds.build_forest(shard.tree_seeds(bench.SEED, range(n_trees)))
 index = ds.create_index(forest)

@@ -729,12 +729,15 @@ def test_device_search_sort_dedup_paths_agree(last_id):
     index = ds.create_index(forest)
     queries = rng.standard_normal((64, dims)).astype(np.float32)
     res = {}
-    for bitmap in (1, 0):
-        with tuning(AH_SEARCH_BITMAP=bitmap):
-            res[bitmap] = [index.search(25, queries=queries, search_k=sk, raw=True) for sk in (0, 3000, 2**62)]
-    for a, b in zip(res[1], res[0]):
-        assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0])
-        assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    # 1: the LDS bitmap where the id space fits it (else the hash set of the candidates); 0: never the bitmap (the hash set,
+    # or the bitonic sort when 0xFFFFFFFF is a stored id); 2: sort + dedup + row-major re-rank
+    for mode in (1, 0, 2):
+        with tuning(AH_SEARCH_BITMAP=1 if mode else 0, AH_SEARCH_TILES=0 if mode == 2 else 1):
+            res[mode] = [index.search(25, queries=queries, search_k=sk, raw=True) for sk in (0, 3000, 2**62)]
+    for mode in (0, 2):
+        for a, b in zip(res[1], res[mode]):
+            assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]), mode
+            assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), mode
     oi, od, oc = res[1][1]
     for qi in (0, 63):
         qv, qh = oracle.query_leaf(queries[qi])
