@@ -67,7 +67,8 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64)
 class AhBuildOptions(C.Structure):
     _fields_ = [("n_trees", C.c_uint32), ("split_after", C.c_uint32), ("tree_seeds", C.POINTER(C.c_uint64)),
                 ("cancel", C.POINTER(C.c_int)), ("progress", PROGRESS_FN), ("progress_user", C.c_void_p),
-                ("max_trees_in_flight", C.c_uint32), ("margin_mode", C.c_uint32)]
+                ("max_trees_in_flight", C.c_uint32), ("margin_mode", C.c_uint32), ("max_host_threads", C.c_uint32),
+                ("reserved0", C.c_uint32)]
 
 
 class AhErrorDetail(C.Structure):
@@ -95,6 +96,15 @@ class AhBuildStats(C.Structure):
                 ("screen8_pairs", C.c_uint64), ("screen8_decided", C.c_uint64), ("screen8b_decided", C.c_uint64),
                 ("screen_unavailable", C.c_uint32),
                 ("reserved0", C.c_uint32)]
+
+
+class AhSearchStats(C.Structure):
+    _fields_ = [(f, C.c_uint64) for f in (
+        "calls", "chunks", "queries", "descent_wave_small", "descent_wave_big", "descent_octet_lds", "descent_octet_global",
+        "dedup_flag_bitmap", "dedup_flag_hash", "dedup_sorted_bitmap", "dedup_sort_lds", "dedup_sort_global",
+        "rerank_tiles", "rerank_sorted", "tile_visits", "tile_units_16", "tile_units_8", "tile_units_4",
+        "fallback_chunks", "fallback_non_finite", "fallback_select", "fallback_queue", "fallback_visits", "fallback_launch",
+        "filtered_queries", "leaf_kept_passes")] + [("reserved", C.c_uint64 * 4)]
 
 
 # name -> (restype, argtypes): exactly the declarations of include/arroy_hip.h
@@ -134,6 +144,8 @@ SIGNATURES = {
     "ah_forest_view_get": (C.c_int, [_VP, C.POINTER(AhForestView)]),
     "ah_forest_stats": (C.c_int, [_VP, C.POINTER(AhBuildStats)]),
     "ah_forest_digest": (C.c_int, [_VP, _U64P, C.POINTER(C.c_uint64)]),
+    "ah_host_cache_trim": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "ah_synth_rows_host": (C.c_int, [C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _F32P]),
     "ah_tuning_set": (C.c_int, [C.c_char_p, C.c_int64]),
     "ah_tuning_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ah_tuning_reset": (C.c_int, []),
@@ -145,6 +157,7 @@ SIGNATURES = {
     "ah_index_destroy": (C.c_int, [_VP]),
     "ah_search_batch": (C.c_int, [_VP, _F32P, _U32P, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _U32P, C.c_size_t,
                                   C.c_int, _U32P, _F32P, _U32P]),
+    "ah_index_search_stats": (C.c_int, [_VP, C.POINTER(AhSearchStats), C.c_int]),
     "ah_route_items": (C.c_int, [_VP, _U32P, C.c_size_t, _U64P, _U32P]),
     "ah_bench_scan": (C.c_int, [_VP, C.c_uint32, C.c_uint64, C.c_uint32, _F32P, C.POINTER(C.c_double)]),
     "ah_bench_memcpy": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
@@ -230,6 +243,23 @@ class tuning:
         for k, v in self.saved.items():
             tuning_set(k, v)
         return False
+
+
+def host_cache_trim() -> int:
+    """ah_host_cache_trim: give the recycled host blobs of destroyed forests back to the system; returns the bytes released."""
+    out = C.c_uint64(0)
+    check(lib().ah_host_cache_trim(C.byref(out)))
+    return int(out.value)
+
+
+def synth_rows_host(seed: int, distribution: int, n: int, dims: int, first_item: int = 0, out=None):
+    """ah_synth_rows_host (benchmark harness): the policy generator's rows in host memory."""
+    import numpy as np
+    if out is None:
+        out = np.empty((n, dims), dtype=np.float32)
+    assert out.dtype == np.float32 and out.flags.c_contiguous and out.size == n * dims
+    check(lib().ah_synth_rows_host(seed, distribution, first_item, n, dims, out.ctypes.data_as(C.c_void_p)))
+    return out
 
 
 def launch_coverage(kind: int, n_rows: int, dims: int, a: int, b: int = 0, device: int = 0):

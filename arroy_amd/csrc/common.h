@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/arroy_hip.h"
@@ -97,6 +98,8 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
     X(SEARCH_BITMAP, "AH_SEARCH_BITMAP", 1)     /* 0: sort + dedup of the candidates always by the bitonic network */     \
     X(SEARCH_TILES, "AH_SEARCH_TILES", 1)       /* 0: never the leaf-tile re-rank of ah_search_batch */                   \
     X(SEARCH_WAVE, "AH_SEARCH_WAVE", 1)         /* 0: the descent always one octet per query (k_descend) */               \
+    X(HOST_THREADS, "AH_HOST_THREADS", 8)       /* host threads one build may use at a time for its output path */        \
+    X(HOST_CACHE_MB, "AH_HOST_CACHE_MB", 16384) /* committed host memory of destroyed forests kept for the next build */   \
     X(STAGE_THREADS, "AH_STAGE_THREADS", 0)                                                                              \
     X(STAGE_MEMCPY, "AH_STAGE_MEMCPY", 0)                                                                                \
     X(STAGE_REGISTER, "AH_STAGE_REGISTER", 0)
@@ -107,6 +110,22 @@ enum Tunable {
         TUN_COUNT
 };
 long long tun(int id);  // current value (api.hip)
+
+// fn(0) .. fn(n - 1), fn(0) on the calling thread and the others on threads of their own.  A thread that cannot be created
+// (std::system_error) must not cross the C ABI: its share simply runs on the caller.
+template <class F>
+inline void parallel_run(unsigned n, F fn) {
+    std::vector<std::thread> pool;
+    unsigned started = 1;
+    try {
+        pool.reserve(n);
+        for (; started < n; started++) pool.emplace_back(fn, started);
+    } catch (...) {
+    }
+    if (n) fn(0u);
+    for (unsigned t = started; t < n; t++) fn(t);
+    for (auto &th : pool) th.join();
+}
 
 inline bool metric_is_bq(int m) { return m >= AH_BQ_EUCLIDEAN && m <= AH_BQ_COSINE; }
 inline bool metric_valid(int m) { return m >= AH_EUCLIDEAN && m <= AH_BQ_COSINE; }

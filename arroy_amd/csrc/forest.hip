@@ -22,6 +22,7 @@
 #include <thread>
 #include <cstdlib>
 #include <immintrin.h>
+#include <sys/mman.h>
 #include <new>
 
 #include "common.h"
@@ -823,9 +824,11 @@ __global__ __launch_bounds__(kBlock) void k_shadow_rows8(DataView dv, const floa
             uint32_t w1 = 0u, w2 = 0u;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
+                // (!ok rows — all zero, tiny, or not finite — store q = r = 0: inf * 0 = NaN would otherwise clamp to -127 and,
+                // with Cosine's scale-free test, let a non-finite row be "decided" by the sign of garbage)
                 const float t = y[c] * inv_scale;
-                const int q = quantize8(y[c], inv_scale);
-                const int r = (int)fminf(fmaxf(rintf((t - (float)q) * 256.0f), -127.0f), 127.0f);
+                const int q = ok ? quantize8(y[c], inv_scale) : 0;
+                const int r = ok ? (int)fminf(fmaxf(rintf((t - (float)q) * 256.0f), -127.0f), 127.0f) : 0;
                 const float z = (float)q * scale, z2 = ((float)q + (float)r * 0.00390625f) * scale;  // the digits sum exactly
                 sa += (float)(q * q);  // exact integers (< 2^24 per lane up to 8000 dims)
                 const float d = y[c] - z, d2 = y[c] - z2, v2 = (float)q + (float)r * 0.00390625f;
@@ -1611,18 +1614,123 @@ using namespace ah;
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
+// ---- host memory of the forests' blobs, recycled --------------------------------------------------------------------
+// A 10M x 768 x 100-tree forest is 5.4 GB of normals + 4 GB of item ids.  Handing every build FRESH pageable memory means
+// 2.3 M first-touch page faults per build, taken by a dozen threads of one process that contend for the address-space lock
+// with each other and with the HIP runtime's own mappings — measured: 8 threads commit 4 KiB pages at 1.3 GB/s in total,
+// 2 threads at 4.9, and the round-3 driver run saw the same build take 1.47 .. 1.82 s.  So: (1) blobs are mapped with
+// MADV_HUGEPAGE on 2 MiB boundaries (512x fewer faults where transparent huge pages are available: 7.3 GB/s on 8 threads),
+// and (2) the blobs of a destroyed forest are KEPT, committed, in a process-wide pool and handed to the next build, which
+// then faults nothing at all.  AH_HOST_CACHE_MB bounds what the pool holds (0 = recycle nothing); ah_host_cache_trim
+// returns it to the system.
+struct HostBlob {
+    uint8_t *p = nullptr;
+    size_t cap = 0;        // usable bytes at p
+    size_t committed = 0;  // bytes from p whose pages have been written before (a recycled blob): nothing to fault there
+    void *map = nullptr;   // the mapping p lives in (nullptr: malloc'd — small blobs)
+    size_t map_len = 0;
+};
+class HostBlobPool {
+    std::mutex mu;
+    std::vector<HostBlob> idle;
+    size_t held = 0;  // committed bytes of the idle blobs
+    static constexpr size_t kSmall = 16u << 20, kHuge = 2u << 20;
+    static void release(HostBlob &b) {
+        if (b.map) munmap(b.map, b.map_len);
+        else free(b.p);
+        b = HostBlob{};
+    }
+
+  public:
+    // a blob of at least `bytes` bytes; false = out of memory
+    bool take(size_t bytes, HostBlob *out) {
+        bytes += 16;
+        if (bytes >= kSmall) {
+            std::lock_guard<std::mutex> lk(mu);
+            size_t best = idle.size();
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i].cap >= bytes && (best == idle.size() || idle[i].cap < idle[best].cap)) best = i;
+            if (best != idle.size()) {
+                *out = idle[best];
+                held -= std::min(held, idle[best].committed);
+                idle.erase(idle.begin() + (ptrdiff_t)best);
+                return true;
+            }
+        }
+        HostBlob b;
+        if (bytes < kSmall) {
+            b.p = reinterpret_cast<uint8_t *>(malloc(bytes));
+            if (!b.p) return false;
+            b.cap = bytes;
+        } else {
+            const size_t cap = (bytes + kHuge - 1) & ~(kHuge - 1);
+            void *m = mmap(nullptr, cap + kHuge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (m == MAP_FAILED) return false;
+            b.map = m;
+            b.map_len = cap + kHuge;
+            b.p = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(m) + kHuge - 1) & ~(uintptr_t)(kHuge - 1));
+            b.cap = cap;
+            (void)madvise(b.p, cap, MADV_HUGEPAGE);  // a hint: 4 KiB pages where it is refused
+        }
+        *out = b;
+        return true;
+    }
+    void give(HostBlob &b, size_t used) {
+        if (!b.p) return;
+        b.committed = std::min(b.cap, std::max(b.committed, used));
+        const size_t limit = (size_t)std::max<long long>(0, tun(TUN_HOST_CACHE_MB)) << 20;
+        if (!b.map || limit == 0) {
+            release(b);
+            return;
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        idle.push_back(b);
+        held += b.committed;
+        b = HostBlob{};
+        while (held > limit && !idle.empty()) {  // over the budget: the oldest go first
+            held -= std::min(held, idle.front().committed);
+            release(idle.front());
+            idle.erase(idle.begin());
+        }
+    }
+    size_t trim() {
+        std::lock_guard<std::mutex> lk(mu);
+        const size_t was = held;
+        for (HostBlob &b : idle) release(b);
+        idle.clear();
+        held = 0;
+        return was;
+    }
+};
+static HostBlobPool &host_pool() {
+    static HostBlobPool *pool = new HostBlobPool();  // never destroyed: forests may outlive static destruction order
+    return *pool;
+}
+// grow `blob` to at least `need` bytes keeping its first `keep` bytes; the old mapping goes back to the pool
+static bool host_blob_reserve(HostBlob &blob, size_t need, size_t keep) {
+    if (need + 16 <= blob.cap) return true;
+    HostBlob grown;
+    if (!host_pool().take(need, &grown)) return false;
+    if (keep) memcpy(grown.p, blob.p, keep);
+    grown.committed = std::max(grown.committed, keep);
+    host_pool().give(blob, keep);
+    blob = grown;
+    return true;
+}
+
 struct ah_forest {
     std::vector<uint32_t> roots;
     std::vector<ah_node> nodes;
-    uint8_t *normals = nullptr;  // raw (uninitialised) buffers: filled by D2H copies only, never repacked
+    HostBlob normals_blob, desc_blob;  // raw buffers: filled by D2H copies only, never repacked; recycled (HostBlobPool)
+    uint8_t *normals = nullptr;        // = normals_blob.p
     uint64_t normals_len = 0;
-    uint32_t *descendants = nullptr;
+    uint32_t *descendants = nullptr;   // = desc_blob.p
     uint64_t descendants_len = 0;
     uint64_t normal_stride = 0, normal_vector_offset = 0, normal_header_offset = 0;
     ah_build_stats stats{};
     ~ah_forest() {
-        free(normals);
-        free(descendants);
+        host_pool().give(normals_blob, normals_len);
+        host_pool().give(desc_blob, descendants_len * 4);
     }
 };
 
@@ -1914,7 +2022,7 @@ struct Readback {
     std::condition_variable cv;
     std::deque<Job> q;
     size_t pending = 0;
-    bool stop = false, started = false;
+    bool stop = false, started = false, inline_mode = false;
     hipError_t err = hipSuccess;
     int device = 0;
     uint8_t *pin = nullptr;  // 2 x half bytes of pinned memory (owned by the build's Context)
@@ -1925,7 +2033,12 @@ struct Readback {
         pin = reinterpret_cast<uint8_t *>(pinned);
         half = pinned_bytes / 2;
         started = true;
-        th = std::thread([this] { run(); });
+        try {
+            th = std::thread([this] { run(); });
+        } catch (...) {  // no worker: push() copies synchronously
+            started = false;
+            inline_mode = true;
+        }
     }
     // pinned bounce buffer -> final place, with non-temporal stores: the destination is written once and read much
     // later by the caller, so its lines need neither be read for ownership nor stay in the host caches
@@ -1951,19 +2064,18 @@ struct Readback {
         if (avx2 && bytes >= 4096) copy_stream(dst, src, bytes);
         else memcpy(dst, src, bytes);
     }
-    static void spread(uint8_t *dst, const uint8_t *src, size_t bytes) {  // copy on up to 8 cores
-        const size_t n_threads = std::min<size_t>(8, bytes >> 20);
+    unsigned copy_threads = 8;
+    void spread(uint8_t *dst, const uint8_t *src, size_t bytes) const {  // copy on up to copy_threads cores
+        const unsigned n_threads = (unsigned)std::min<size_t>(copy_threads, bytes >> 20);
         if (n_threads <= 1) {
             copy_part(dst, src, bytes);
             return;
         }
-        std::vector<std::thread> pool;
         const size_t per = ((bytes + n_threads - 1) / n_threads + 4095) & ~(size_t)4095;
-        for (size_t lo = 0; lo < bytes; lo += per) {
-            const size_t len = std::min(per, bytes - lo);
-            pool.emplace_back([=] { copy_part(dst + lo, src + lo, len); });
-        }
-        for (auto &t : pool) t.join();
+        parallel_run(n_threads, [=](unsigned t) {
+            const size_t lo = (size_t)t * per;
+            if (lo < bytes) copy_part(dst + lo, src + lo, std::min(per, bytes - lo));
+        });
     }
     hipError_t copy(const Job &job, hipStream_t cs, hipEvent_t *ev) {
         const bool direct = tun(TUN_READBACK_DIRECT) != 0;  // A/B: let the runtime stage the copy
@@ -2024,6 +2136,11 @@ struct Readback {
     }
     void push(void *dst, const void *src, size_t bytes) {
         if (!bytes) return;
+        if (inline_mode) {  // the worker thread could not be created: a plain synchronous copy
+            const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+            if (e != hipSuccess && err == hipSuccess) err = e;
+            return;
+        }
         {
             std::lock_guard<std::mutex> lk(mu);
             q.push_back(Job{dst, src, bytes});
@@ -2181,6 +2298,14 @@ int plan_rows_launches(uint64_t N, uint32_t hpitch, uint32_t tcv, uint32_t group
 // One level = one set of launches, and ONE host wait: the host needs the next level's sizes (LevelInfo, read back
 // through pinned memory) before it can launch it; everything else about a level — its node table, from which the final
 // node list is assembled — follows on a side stream and is digested by the host while the GPU runs the next level.
+// host threads one build may keep busy at a time for its output path (page commits, bounce copies, digests, node list):
+// ah_build_options.max_host_threads, else AH_HOST_THREADS (8).  Eight concurrent builds of an 8-GPU node in a 16-CPU
+// container want 2 each.
+static unsigned host_thread_budget(const ah_build_options *opt) {
+    const long long v = opt->max_host_threads ? (long long)opt->max_host_threads : tun(TUN_HOST_THREADS);
+    return (unsigned)std::min<long long>(64, std::max<long long>(1, v));
+}
+
 static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t first_tree, uint32_t n_trees,
                        uint32_t split_after, ah_forest *forest, Context *ctx, const uint32_t *subset_ids,
                        const uint64_t *subset_offsets) {
@@ -2315,36 +2440,41 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     // allocated up front and its pages are touched in the background while the GPU works (first-touch faults of
     // fresh memory, not the copy, bound a read-back of several GB).
     const uint64_t desc_base = forest->descendants_len;
-    {
-        uint32_t *grown = (uint32_t *)realloc(forest->descendants, (desc_base + M) * 4 + 16);
-        AH_REQUIRE(grown, AH_ERR_OUT_OF_MEMORY, "host allocation of the descendants failed");
-        forest->descendants = grown;
-    }
+    AH_REQUIRE(host_blob_reserve(forest->desc_blob, (desc_base + M) * 4, desc_base * 4), AH_ERR_OUT_OF_MEMORY,
+               "host allocation of the descendants failed");
+    forest->descendants = reinterpret_cast<uint32_t *>(forest->desc_blob.p);
     struct Toucher {  // commits the pages of a fresh (still unwritten) host range in the background
         std::thread th;
-        void start(void *ptr, size_t bytes) {
+        unsigned max_threads = 8;
+        // [off, off + bytes) of `blob`; what a recycled blob already has committed needs no touch
+        void start(const HostBlob &blob, size_t off, size_t bytes) {
             join();
-            if (bytes < (8u << 20)) return;
-            uint8_t *lo = reinterpret_cast<uint8_t *>(ptr);
-            th = std::thread([lo, bytes] {
-                // (eight threads: the 2.6 GB of the deepest level's normals must be committed within that level's ~140 ms, or
-                // the level loop waits for page faults before it can hand the chunk to the read-back worker)
-                const size_t parts = std::min<size_t>(8, std::max<size_t>(1, bytes >> 26));
-                std::vector<std::thread> pool;
-                for (size_t p = 0; p < parts; p++)
-                    pool.emplace_back([=] {
-                        const size_t a = bytes * p / parts, b = bytes * (p + 1) / parts;
-                        for (size_t off = a; off < b; off += 4096) reinterpret_cast<volatile uint8_t *>(lo)[off] = 0;
+            const size_t lo_off = std::max(off, blob.committed), hi_off = std::min(off + bytes, blob.cap);
+            if (hi_off <= lo_off || hi_off - lo_off < (8u << 20)) return;
+            uint8_t *lo = blob.p + lo_off;
+            const size_t len = hi_off - lo_off;
+            const unsigned budget = max_threads;
+            try {
+                th = std::thread([lo, len, budget] {
+                    // (several threads: the 2.6 GB of the deepest level's normals must be committed within that level's
+                    // ~140 ms, or the level loop waits for page faults before it can hand the chunk to the read-back worker)
+                    const unsigned parts = (unsigned)std::min<size_t>(budget, std::max<size_t>(1, len >> 26));
+                    parallel_run(parts, [=](unsigned p) {
+                        const size_t a = len * p / parts, b = len * (p + 1) / parts;
+                        for (size_t o = a; o < b; o += 4096) reinterpret_cast<volatile uint8_t *>(lo)[o] = 0;
                     });
-                for (auto &t : pool) t.join();
-            });
+                });
+            } catch (...) {  // no thread to be had: the read-back worker faults the pages in itself
+            }
         }
         void join() {
             if (th.joinable()) th.join();
         }
         ~Toucher() { join(); }
     } prefault, touch_normals[2];  // [level & 1]: commits the level's normals, started one level ahead
-    prefault.start(forest->descendants + desc_base, M * 4);
+    const unsigned host_threads = host_thread_budget(opt);
+    prefault.max_threads = touch_normals[0].max_threads = touch_normals[1].max_threads = host_threads;
+    prefault.start(forest->desc_blob, desc_base * 4, M * 4);
     Arena arena, shadow_arena, shadow8_arena;  // declared before the read-back worker: it is joined before the chunks it reads are freed
     arena.block_bytes = std::max<uint64_t>(32ull << 20, std::min<uint64_t>(2 * max_nodes * nstride, 16ull << 30));
     shadow_arena.block_bytes = std::max<uint64_t>(16ull << 20, std::min<uint64_t>(max_nodes * std::max<uint64_t>(hstride, 16), 8ull << 30));
@@ -2352,6 +2482,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     BatchCleanup bc;
     AH_TRY(bc.create());
     Readback rb;
+    rb.copy_threads = host_threads;
     rb.start(ds->device, pin + pin_head + 2 * pin_nodes, kBounce);
 
     // ---- level 0 on the host: the roots -----------------------------------------------------------------------------
@@ -2421,21 +2552,20 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     uint64_t normals_bytes = 0;
     // The host blob gets lazily committed head-room (splits in total ~1.3-1.6 x items / split_after) so that finished
     // levels can land in their final place while the build continues; it only moves when no copy is in flight.
-    uint64_t normals_cap = forest->normals_len;
-    auto reserve_normals = [&](uint64_t need) -> int {
+    uint64_t normals_cap = forest->normals_blob.cap >= 16 ? forest->normals_blob.cap - 16 : 0;
+    auto reserve_normals = [&](uint64_t need, uint64_t landed) -> int {  // landed: bytes of earlier levels / batches to keep
         if (need <= normals_cap) return AH_OK;
         touch_normals[0].join();  // the blob may move: nothing may be touching it
         touch_normals[1].join();
         AH_REQUIRE(rb.drain() == hipSuccess, AH_ERR_DEVICE, "device -> host copy of the normals failed");
         uint64_t want = std::max<uint64_t>(need + need / 2, normals_base + 2 * max_nodes * nstride);
-        uint8_t *grown = (uint8_t *)realloc(forest->normals, want + 16);
-        if (!grown) {
+        if (!host_blob_reserve(forest->normals_blob, want, landed)) {
             want = need;
-            grown = (uint8_t *)realloc(forest->normals, want + 16);
+            AH_REQUIRE(host_blob_reserve(forest->normals_blob, want, landed), AH_ERR_OUT_OF_MEMORY,
+                       "host allocation of %llu bytes of normals failed", (unsigned long long)want);
         }
-        AH_REQUIRE(grown, AH_ERR_OUT_OF_MEMORY, "host allocation of %llu bytes of normals failed", (unsigned long long)want);
-        forest->normals = grown;
-        normals_cap = want;
+        forest->normals = forest->normals_blob.p;
+        normals_cap = forest->normals_blob.cap - 16;
         return AH_OK;
     };
 
@@ -2449,7 +2579,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         const size_t base = n_recs;
         if (recs.size() < base + 2 * (size_t)n_nodes) recs.resize(base + 2 * (size_t)n_nodes);
         n_recs = base + 2 * (size_t)n_nodes;
-        const unsigned n_threads = n_nodes >= 65536 ? 4u : 1u;
+        const unsigned n_threads = n_nodes >= 65536 ? std::min(4u, host_threads) : 1u;
         struct Part {
             uint64_t evals = 0, retries = 0, routed = 0, dummies = 0;
             uint32_t bad = 0xFFFFFFFFu;
@@ -2494,12 +2624,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                 }
             }
         };
-        {
-            std::vector<std::thread> pool;
-            for (unsigned t = 1; t < n_threads; t++) pool.emplace_back(walk, t);
-            walk(0);
-            for (auto &th : pool) th.join();
-        }
+        parallel_run(n_threads, walk);
         next_rec.clear();
         for (const Part &pt : parts) {
             AH_REQUIRE(pt.bad == 0xFFFFFFFFu, AH_ERR_DEVICE, "forest build: node %u of level %u left pending (internal error)",
@@ -2576,8 +2701,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         // about twice the nodes of the one before), those of the NEXT level start now — committing the 2.6 GB of the deepest
         // level takes longer than the ~160 ms that level runs, and the loop must not wait for page faults before it can
         // hand a chunk to the read-back worker.  Whatever the prediction missed is faulted in by the worker itself.
-        AH_TRY(reserve_normals(chunk_host_off + chunk_bytes));
-        if (depth == 0) touch_normals[0].start(forest->normals + chunk_host_off, chunk_bytes);
+        AH_TRY(reserve_normals(chunk_host_off + chunk_bytes, chunk_host_off));
+        if (depth == 0) touch_normals[0].start(forest->normals_blob, chunk_host_off, chunk_bytes);
         {
             // next level: twice the nodes while the nodes are large; once they hold fewer than 2 x split_after items on
             // average most children are Descendants and the next level is a remnant (an eighth); nothing below that
@@ -2585,7 +2710,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             const double avg_items = n_nodes ? (double)info.pairs / (double)n_nodes : 0.0;
             const uint64_t predicted = avg_items > 2.0 * split_after ? 2 * chunk_bytes : avg_items > (double)split_after ? chunk_bytes / 8 : 0;
             const uint64_t next_len = normals_cap > next_begin ? std::min<uint64_t>(normals_cap - next_begin, predicted) : 0;
-            touch_normals[(depth + 1) & 1].start(forest->normals + next_begin, (size_t)next_len);
+            touch_normals[(depth + 1) & 1].start(forest->normals_blob, next_begin, (size_t)next_len);
         }
         const unsigned tile_grid = std::min<uint32_t>(n_tiles, g_tile_blocks);
         // The node-major margin kernels walk their tiles with a persistent grid: at the deep levels a tile is ~1200 items
@@ -3077,18 +3202,18 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     // Emit per tree in post-order (children before parents: the order TmpNodes::put receives them,
     // src/writer.rs:1235-1258), with forest-local indices.  Trees are independent: the number of nodes of every tree
     // is known (counted while the levels were digested), so each tree is written into its own slice by a few threads.
+    recs.resize(n_recs);  // (the vector is grown ahead of the digests with value-initialised records: count the real ones only)
     std::vector<uint64_t> tree_nodes(n_trees + 1, 0);
     for (const HostRec &r : recs) tree_nodes[r.tree + 1]++;
     for (uint32_t t = 0; t < n_trees; t++) tree_nodes[t + 1] += tree_nodes[t];
     const size_t node_base = forest->nodes.size();
-    recs.resize(n_recs);
     forest->nodes.resize(node_base + recs.size());
     forest->roots.resize(forest->roots.size() + n_trees);
     uint32_t *roots_out = forest->roots.data() + (forest->roots.size() - n_trees);
     std::vector<uint32_t> new_index(recs.size(), 0xFFFFFFFFu);
     std::atomic<uint64_t> n_split{0}, n_desc{0};
     std::atomic<uint32_t> next_tree{0};
-    auto emit_trees = [&] {
+    auto emit_trees = [&](unsigned) {
         std::vector<std::pair<uint32_t, int>> stack;
         uint64_t splits = 0, descs = 0;
         for (;;) {
@@ -3131,13 +3256,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         n_split.fetch_add(splits, std::memory_order_relaxed);
         n_desc.fetch_add(descs, std::memory_order_relaxed);
     };
-    {
-        const size_t n_threads = recs.size() < 200000 ? 1 : std::min<size_t>({(size_t)n_trees, 8, std::max(1u, std::thread::hardware_concurrency())});
-        std::vector<std::thread> pool;
-        for (size_t i = 1; i < n_threads; i++) pool.emplace_back(emit_trees);
-        emit_trees();
-        for (auto &th : pool) th.join();
-    }
+    parallel_run(recs.size() < 200000 ? 1u : std::min({n_trees, host_threads, std::max(1u, std::thread::hardware_concurrency())}),
+                 emit_trees);
     forest->stats.split_nodes += n_split.load();
     forest->stats.descendant_nodes += n_desc.load();
     const auto t_emitted = std::chrono::steady_clock::now();
@@ -3145,10 +3265,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     forest->normals_len = normals_base + normals_bytes;
     touch_normals[0].join();  // (the last level started the commit of a level that never came)
     touch_normals[1].join();
-    if (normals_cap > forest->normals_len) {  // give the head-room back (shrinks in place)
-        uint8_t *fit = (uint8_t *)realloc(forest->normals, forest->normals_len + 16);
-        if (fit) forest->normals = fit;
-    }
+    // (the head-room of the blob stays mapped: untouched pages cost nothing, and the pool hands the whole blob to the next build)
     if (timing) {
         const auto t_end = std::chrono::steady_clock::now();
         auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
@@ -3191,12 +3308,12 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
     if (!subset_ids && ds->n <= split_after) {
         // fit_in_descendant at the root (src/writer.rs:1183-1188): every tree is one Descendants node
         const uint64_t total = ds->n * options->n_trees;
-        forest->descendants = (uint32_t *)malloc(total * 4 + 16);
-        if (!forest->descendants) {
+        if (!host_blob_reserve(forest->desc_blob, total * 4, 0)) {
             delete forest;
             set_error("host allocation failed");
             return AH_ERR_OUT_OF_MEMORY;
         }
+        forest->descendants = reinterpret_cast<uint32_t *>(forest->desc_blob.p);
         forest->descendants_len = total;
         for (uint32_t t = 0; t < options->n_trees; t++) {
             for (uint64_t i = 0; i < ds->n; i++)
@@ -3332,7 +3449,7 @@ int ah_forest_digest(const ah_forest *forest, uint64_t *out_per_tree, uint64_t *
     const size_t hdr_len = std::min<size_t>(8, forest->normal_stride - hdr_off);
     std::vector<uint64_t> per(n_trees, 0);
     std::atomic<uint32_t> next{0};
-    auto work = [&] {
+    auto work = [&](unsigned) {
         for (;;) {
             const uint32_t t = next.fetch_add(1, std::memory_order_relaxed);
             if (t >= n_trees) break;
@@ -3360,13 +3477,9 @@ int ah_forest_digest(const ah_forest *forest, uint64_t *out_per_tree, uint64_t *
             per[t] = h;
         }
     };
-    {
-        const size_t n_threads = n_nodes < 100000 ? 1 : std::min<size_t>({(size_t)n_trees, 8, std::max(1u, std::thread::hardware_concurrency())});
-        std::vector<std::thread> pool;
-        for (size_t i = 1; i < n_threads; i++) pool.emplace_back(work);
-        work();
-        for (auto &th : pool) th.join();
-    }
+    parallel_run(n_nodes < 100000 ? 1u : std::min({n_trees, (uint32_t)std::max<long long>(1, tun(TUN_HOST_THREADS)),
+                                                    std::max(1u, std::thread::hardware_concurrency())}),
+                 work);
     uint64_t total = ah_mix64(n_trees);
     for (uint32_t t = 0; t < n_trees; t++) {
         total = ah_mix64(total ^ per[t]);
@@ -3454,6 +3567,27 @@ int ah_forest_visit(const ah_forest *forest, ah_node_sink_fn sink, void *user) {
 
 int ah_forest_destroy(ah_forest *forest) {
     delete forest;
+    return AH_OK;
+}
+
+int ah_host_cache_trim(uint64_t *out_bytes) {
+    const size_t was = host_pool().trim();
+    if (out_bytes) *out_bytes = was;
+    return AH_OK;
+}
+
+// Benchmark harness only: the policy header's generator on the host cores (the rows ah_dataset_fill_synthetic makes in HBM).
+int ah_synth_rows_host(uint64_t seed, int distribution, uint64_t first_item, uint64_t n, uint32_t dims, float *out) {
+    AH_REQUIRE(out || n == 0, AH_ERR_INVALID_ARGUMENT, "out is NULL");
+    AH_REQUIRE(distribution >= AH_SYNTH_UNIFORM_01 && distribution <= AH_SYNTH_NORMAL_OUTLIERS, AH_ERR_INVALID_ARGUMENT,
+               "unknown distribution %d", distribution);
+    const unsigned n_threads = (unsigned)std::min<uint64_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<uint64_t>(1, n / 1024));
+    parallel_run(std::min(n_threads, 64u), [=](unsigned t) {
+        const unsigned parts = std::min(n_threads, 64u);
+        const uint64_t lo = n * t / parts, hi = n * (t + 1) / parts;
+        for (uint64_t i = lo; i < hi; i++)
+            for (uint32_t d = 0; d < dims; d++) out[i * dims + d] = ah_synth_value(seed, first_item + i, d, dims, distribution);
+    });
     return AH_OK;
 }
 

@@ -46,7 +46,14 @@ struct VisitSink {          // all null / 0: the descent records nothing
     uint32_t *err;          // bit 4: a queue overflowed its LDS slot; bit 5: more than `cap` visits
 };
 
+// Words of the per-chunk device block [error bits][counters of ah_search_stats]: which kernel produced a query's candidates,
+// how the leaf tiles were cut.  Proof of the path taken (ah_index_search_stats), never an input of a result.
+enum SearchStatSlot {
+    SS_ERR = 0, SS_WAVE_SMALL, SS_WAVE_BIG, SS_OCTET_LDS, SS_OCTET_GLOBAL, SS_UNITS_16, SS_UNITS_8, SS_UNITS_4, SS_VISITS, SS_WORDS = 16
+};
+
 struct SearchParams {
+    uint32_t *stats;              // SS_WORDS words (may be nullptr)
     const DNode *nodes;
     const uint32_t *roots;
     uint32_t n_trees;
@@ -240,6 +247,7 @@ __global__ __launch_bounds__(64) void k_descend(DataView nv, SearchParams sp, co
         nns_count[q] = failed ? 0u : nn;
         overflow[q] = failed ? 1u : 0u;
         if (failed && sink.err) atomicOr(sink.err, 16u);
+        if (!failed && sp.stats) atomicAdd(&sp.stats[HEAP_GLOBAL ? SS_OCTET_GLOBAL : SS_OCTET_LDS], 1u);
     }
 }
 
@@ -467,6 +475,7 @@ __global__ __launch_bounds__(64) void k_descend_wave(DataView nv, SearchParams s
     if (lane == 0) {
         nns_count[q] = ids_taken;
         overflow[q] = 0;
+        if (sp.stats) atomicAdd(&sp.stats[kWaveHeap == 256 ? SS_WAVE_SMALL : SS_WAVE_BIG], 1u);
     }
 }
 
@@ -679,17 +688,31 @@ __global__ __launch_bounds__(256) void k_leaf_scan_sums(uint2 *__restrict__ sums
 }
 __global__ __launch_bounds__(256) void k_leaf_scan_add(const uint32_t *__restrict__ count, uint32_t n,
                                                        uint32_t *__restrict__ cursor, const uint32_t *__restrict__ ustart,
-                                                       const uint2 *__restrict__ sums, TileUnit *__restrict__ units) {
+                                                       const uint2 *__restrict__ sums, TileUnit *__restrict__ units,
+                                                       uint32_t *__restrict__ stats) {
     const uint2 add = sums[blockIdx.x];
     const uint32_t base = blockIdx.x * kLeafScanItems;
+    uint32_t u16 = 0, u8 = 0, u4 = 0, visits = 0;  // units by the tile variant that will serve them (k_leaf_tiles)
     for (uint32_t e = threadIdx.x; e < kLeafScanItems; e += 256) {
         const uint32_t node = base + e;
         if (node >= n) break;
         const uint32_t c = count[node], first = cursor[node] + add.x;
         cursor[node] = first;
         TileUnit *dst = units + ustart[node] + add.y;
-        for (uint32_t i = 0; i * kUnitVisits < c; i++)
-            dst[i] = TileUnit{node, first + i * kUnitVisits, min(kUnitVisits, c - i * kUnitVisits), 0u};
+        visits += c;
+        for (uint32_t i = 0; i * kUnitVisits < c; i++) {
+            const uint32_t nv = min(kUnitVisits, c - i * kUnitVisits);
+            dst[i] = TileUnit{node, first + i * kUnitVisits, nv, 0u};
+            u16 += nv > 8 ? 1u : 0u;
+            u8 += nv > 4 && nv <= 8 ? 1u : 0u;
+            u4 += nv <= 4 ? 1u : 0u;
+        }
+    }
+    if (stats) {
+        if (u16) atomicAdd(&stats[SS_UNITS_16], u16);
+        if (u8) atomicAdd(&stats[SS_UNITS_8], u8);
+        if (u4) atomicAdd(&stats[SS_UNITS_4], u4);
+        if (visits) atomicAdd(&stats[SS_VISITS], visits);
     }
 }
 // visits -> their node's run of the sorted list
@@ -1301,6 +1324,8 @@ struct ah_index {
     float *d_nhdrs = nullptr;
     uint32_t n_trees = 0, n_nodes = 0, n_normals = 0, max_desc = 0;
     uint64_t desc_len = 0;
+    std::mutex stats_mu;       // ah_search_batch may run on any number of threads
+    ah_search_stats stats{};
 };
 
 extern "C" {
@@ -1490,10 +1515,31 @@ struct HostTile2 {
     uint32_t query, first;
 };
 
+// Counters of one sub-batch -> the index's ah_search_stats.
+struct ChunkStats {
+    ah_search_stats s{};
+    void device_words(const uint32_t *w) {
+        s.descent_wave_small += w[SS_WAVE_SMALL];
+        s.descent_wave_big += w[SS_WAVE_BIG];
+        s.descent_octet_lds += w[SS_OCTET_LDS];
+        s.descent_octet_global += w[SS_OCTET_GLOBAL];
+        s.tile_units_16 += w[SS_UNITS_16];
+        s.tile_units_8 += w[SS_UNITS_8];
+        s.tile_units_4 += w[SS_UNITS_4];
+        s.tile_visits += w[SS_VISITS];
+    }
+    void commit(ah_index *ix) {
+        std::lock_guard<std::mutex> lk(ix->stats_mu);
+        uint64_t *dst = reinterpret_cast<uint64_t *>(&ix->stats);
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(&s);
+        for (size_t i = 0; i < sizeof(ah_search_stats) / 8; i++) dst[i] += src[i];
+    }
+};
+
 static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const uint32_t *query_rows, size_t nq,
                         size_t count, uint32_t search_k, uint32_t nns_stride, const uint32_t *d_filter_bits,
-                        uint64_t filter_len_bits, double filter_share, uint32_t *out_ids, float *out_dists,
-                        uint32_t *out_counts) {
+                        uint64_t filter_len_bits, double filter_share, bool wave_descent, const uint32_t *d_leaf_kept,
+                        uint32_t *out_ids, float *out_dists, uint32_t *out_counts) {
     ah_dataset *ds = ix->ds;
     hipStream_t s = ctx->stream;
     const size_t qstride = (ds->row_bytes() + 255) & ~(size_t)255;
@@ -1523,7 +1569,6 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                        (ds->metric == AH_EUCLIDEAN || ds->metric == AH_COSINE || ds->metric == AH_DOT_PRODUCT);
     const uint32_t visit_cap = (uint32_t)std::min<uint64_t>((uint64_t)nq * nns_stride, 2u << 20);
     const uint32_t n_leaf_sums = (ix->n_nodes + kLeafScanItems - 1) / kLeafScanItems;
-    if (d_filter_bits) dev_bytes += pad((size_t)ix->n_nodes * 4);
     if (tiles)
         dev_bytes += pad((size_t)visit_cap * sizeof(Visit)) * 2 + pad((size_t)visit_cap * sizeof(TileUnit)) +
                      pad((size_t)ix->n_nodes * 4 + 8) + 2 * pad((size_t)ix->n_nodes * 4) + pad((size_t)n_leaf_sums * 8) + pad(nq * 4);
@@ -1560,9 +1605,8 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     uint64_t *d_kb = (uint64_t *)dtake(nq * kstride * 8);
     uint32_t *d_oi = (uint32_t *)dtake(nq * k * 4);
     float *d_od = (float *)dtake(nq * k * 4);
-    uint32_t *d_err = (uint32_t *)dtake(4);
+    uint32_t *d_err = (uint32_t *)dtake(SS_WORDS * 4);  // [error bits][SearchStatSlot counters]
     uint32_t *d_inv = inv_bytes ? (uint32_t *)dtake(inv_bytes) : nullptr;
-    uint32_t *d_leaf_kept = d_filter_bits ? (uint32_t *)dtake((size_t)ix->n_nodes * 4) : nullptr;
     Visit *d_visits = nullptr, *d_sorted = nullptr;
     TileUnit *d_units = nullptr;
     uint32_t *d_leaf_count = nullptr, *d_cursor = nullptr, *d_ustart = nullptr, *d_unique = nullptr;
@@ -1586,7 +1630,11 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     HostTile2 *h_tiles = (HostTile2 *)ptake((size_t)max_tiles_bound * sizeof(HostTile2));
     uint32_t *h_oi = (uint32_t *)ptake(nq * k * 4);
     float *h_od = (float *)ptake(nq * k * 4);
-    uint32_t *h_err = (uint32_t *)ptake(4);
+    uint32_t *h_err = (uint32_t *)ptake(SS_WORDS * 4);
+    ChunkStats cs;
+    cs.s.chunks = 1;
+    cs.s.queries = nq;
+    if (d_filter_bits) cs.s.filtered_queries = nq;
 
     const DataView dv = ds->view();
     // 1. query leaves (src/reader.rs:46-51 by_item, :64-75 by_vector)
@@ -1598,9 +1646,10 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         AH_HIP(hipMemcpyAsync(d_qrows, h_qrows, nq * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_load_items_as_queries, dim3((unsigned)nq), dim3(64), 0, s, dv, d_qrows, d_qvecs, qstride, d_qhdrs);
     }
-    AH_HIP(hipMemsetAsync(d_err, 0, 4, s));
+    AH_HIP(hipMemsetAsync(d_err, 0, SS_WORDS * 4, s));
     // (by_vector leaves are prepared by the batch launcher below; the descent needs them first)
     SearchParams sp{};
+    sp.stats = d_err;
     sp.nodes = ix->d_nodes;
     sp.roots = ix->d_roots;
     sp.n_trees = ix->n_trees;
@@ -1611,12 +1660,9 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     sp.nns_stride = nns_stride;
     if (queries) AH_TRY(launch_prepare_queries_only(dv, d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
     // 2. descent: one wave per query, then one octet per query for what that left, queue in LDS
-    // (a filter that keeps under 5 % of the items makes a query pop more nodes than the queues of a wave hold)
-    const bool wave_descent = tun(TUN_SEARCH_WAVE) != 0 && (!d_filter_bits || filter_share >= 0.05);
-    if (wave_descent && d_filter_bits) {  // what the filter keeps of every leaf
-        hipLaunchKernelGGL(k_leaf_kept, dim3(1024), dim3(256), 0, s, sp, ix->n_nodes, d_leaf_kept);
-        sp.leaf_kept = d_leaf_kept;
-    }
+    // (ah_search_batch decides: a filter that keeps under 5 % of the items makes a query pop more nodes than the queues of
+    // a wave hold; under a filter the wave descent reads what the filter keeps of every leaf, computed once per submission)
+    if (wave_descent && d_filter_bits) sp.leaf_kept = d_leaf_kept;
     auto launch_wave = [&](const VisitSink &sink) -> int {
         // a query pops about 1 / (kept share) as many nodes under a filter: start with the big queues (one query per CU
         // at a time) only then; otherwise they take what the small ones (four per CU) could not hold
@@ -1645,7 +1691,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                            d_leaf_sums);
         hipLaunchKernelGGL(k_leaf_scan_sums, dim3(1), dim3(256), 0, s, d_leaf_sums, n_leaf_sums, d_n_units);
         hipLaunchKernelGGL(k_leaf_scan_add, dim3(n_leaf_sums), dim3(256), 0, s, d_leaf_count, ix->n_nodes, d_cursor, d_ustart,
-                           d_leaf_sums, d_units);
+                           d_leaf_sums, d_units, d_err);
         hipLaunchKernelGGL(k_visit_scatter, dim3(256), dim3(256), 0, s, d_visits, d_total, visit_cap, d_cursor, d_sorted);
         const unsigned tile_slabs = std::max(1u, (ix->max_desc + kTileSlab - 1) / kTileSlab);
 #define AH_TILES(M)                                                                                                        \
@@ -1692,20 +1738,33 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         }
         hipLaunchKernelGGL(k_search_select, dim3((unsigned)nq), dim3(kSelectThreads), 0, s, dv, d_nns, d_dist, nns_stride, d_counts,
                            d_unique, (uint32_t)k, d_oi, d_od, d_err);
+        // a launch the runtime rejected (dynamic LDS beyond the limit, another architecture) would leave *err = 0 over
+        // uninitialised results: such a submission takes the sorted path as well
+        const hipError_t launch_err = hipGetLastError();
         AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipMemcpyAsync(h_counts, d_unique, nq * 4, hipMemcpyDeviceToHost, s));
-        AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_err, d_err, SS_WORDS * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipStreamSynchronize(s));
         AH_REQUIRE((*h_err & 1u) == 0, AH_ERR_MISSING_ITEM, "a descendant id does not exist in the dataset");
-        if ((*h_err & ~1u) == 0) {
+        if ((*h_err & ~1u) == 0 && launch_err == hipSuccess) {
             for (size_t q = 0; q < nq; q++) out_counts[q] = (uint32_t)std::min<size_t>(k, h_counts[q]);
             memcpy(out_ids, h_oi, nq * k * 4);
             memcpy(out_dists, h_od, nq * k * 4);
+            cs.device_words(h_err);
+            cs.s.rerank_tiles = nq;
+            (bitmap_fits ? cs.s.dedup_flag_bitmap : cs.s.dedup_flag_hash) = nq;
+            cs.commit(ix);
             return AH_OK;
         }
         // a case the tiles do not reproduce (bits 2..5 of *err, see k_search_select / VisitSink): redo it the long way
-        AH_HIP(hipMemsetAsync(d_err, 0, 4, s));
+        cs.s.fallback_chunks = 1;
+        cs.s.fallback_non_finite = (*h_err & 4u) ? 1 : 0;
+        cs.s.fallback_select = (*h_err & 8u) ? 1 : 0;
+        cs.s.fallback_queue = (*h_err & 16u) ? 1 : 0;
+        cs.s.fallback_visits = (*h_err & 32u) ? 1 : 0;
+        cs.s.fallback_launch = launch_err != hipSuccess ? 1 : 0;
+        AH_HIP(hipMemsetAsync(d_err, 0, SS_WORDS * 4, s));
     }
     if (wave_descent) AH_TRY(launch_wave(VisitSink{}));
     hipLaunchKernelGGL((k_descend<false>), dim3((unsigned)((nq + 7) / 8)), dim3(64), heap_lds, s, ix->nv, sp,
@@ -1740,7 +1799,9 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         hipLaunchKernelGGL(k_dedup_bitmap_lds, dim3((unsigned)nq), dim3(1024), sh, s, d_nns, nns_stride, d_counts,
                            bitmap_words, max_id + 1, d_err);
+        cs.s.dedup_sorted_bitmap = nq;
     } else if (max_nn <= kSortLds) {
+        cs.s.dedup_sort_lds = nq;
         uint32_t np2 = 2;
         while (np2 < max_nn) np2 <<= 1;
         const size_t sh = (size_t)np2 * 4;
@@ -1751,6 +1812,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     } else {
         uint32_t np2 = 2;
         while (np2 < max_nn) np2 <<= 1;
+        cs.s.dedup_sort_global = nq;
         // the stride was sized to the next power of two by the caller when this path is possible
         AH_REQUIRE(np2 <= nns_stride, AH_ERR_DEVICE, "internal: candidate stride %u < %u", nns_stride, np2);
         hipLaunchKernelGGL(k_pad_ids, dim3((np2 + 255) / 256, (unsigned)nq), dim3(256), 0, s, d_nns, nns_stride, d_counts, np2);
@@ -1797,11 +1859,15 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     }
     AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
     AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
-    AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
+    AH_HIP(hipGetLastError());
+    AH_HIP(hipMemcpyAsync(h_err, d_err, SS_WORDS * 4, hipMemcpyDeviceToHost, s));
     AH_HIP(hipStreamSynchronize(s));
     AH_REQUIRE((*h_err & 1u) == 0, AH_ERR_MISSING_ITEM, "a descendant id does not exist in the dataset");
     memcpy(out_ids, h_oi, nq * k * 4);
     memcpy(out_dists, h_od, nq * k * 4);
+    cs.device_words(h_err);
+    cs.s.rerank_sorted = nq;
+    cs.commit(ix);
     return AH_OK;
 }
 
@@ -1901,7 +1967,7 @@ int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_it
     AH_REQUIRE(lease.c, AH_ERR_DEVICE, "cannot create a HIP stream");
     Context *ctx = lease.c;
     // candidate filter -> bitmap over item ids (ids beyond the largest stored id cannot match: the list is ascending)
-    uint32_t *d_bits = nullptr;
+    uint32_t *d_bits = nullptr, *d_leaf_kept = nullptr;
     uint64_t bits_len = 0;
     double filter_share = 1.0;  // of the stored items, about
     if (have_filter) {
@@ -1910,7 +1976,7 @@ int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_it
         const size_t words = ((size_t)bits_len + 31) / 32;
         const size_t n_keep = n_filter ? (size_t)(std::upper_bound(filter_sorted, filter_sorted + n_filter, max_id) - filter_sorted) : 0;
         filter_share = (double)n_keep / (double)ds->n;
-        AH_TRY(ctx->ensure_filter(words * 4 + n_keep * 4));
+        AH_TRY(ctx->ensure_filter(words * 4 + n_keep * 4 + (size_t)ix->n_nodes * 4 + 64));
         d_bits = reinterpret_cast<uint32_t *>(ctx->d_filter);
         AH_HIP(hipMemsetAsync(d_bits, 0, words * 4, ctx->stream));
         if (n_keep) {
@@ -1918,6 +1984,32 @@ int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_it
             AH_HIP(hipMemcpyAsync(d_list, filter_sorted, n_keep * 4, hipMemcpyHostToDevice, ctx->stream));
             hipLaunchKernelGGL(k_filter_bitmap, dim3(256), dim3(256), 0, ctx->stream, d_list, (uint64_t)n_keep, d_bits);
         }
+        d_leaf_kept = d_bits + words + n_keep;
+    }
+    // Descent: one wave per query unless the filter keeps under 5 % of the items (a query then pops more nodes than the
+    // queues of a wave hold).  Under a filter the wave descent reads |descendants & candidates| of every leaf, computed
+    // ONCE per submission by a pass over all Descendants ids (4 GB at 10M x 100 trees): a small submission on a big forest
+    // is cheaper by the sequential descent, which looks only at the leaves it pops.
+    bool wave_descent = tun(TUN_SEARCH_WAVE) != 0 && (!d_bits || filter_share >= 0.05);
+    uint64_t leaf_kept_passes = 0;
+    if (wave_descent && d_bits) {
+        if (nq >= 16 || ix->desc_len <= (32ull << 20)) {
+            SearchParams lp{};
+            lp.nodes = ix->d_nodes;
+            lp.desc = ix->d_desc;
+            lp.filter_bits = d_bits;
+            lp.filter_len_bits = bits_len;
+            hipLaunchKernelGGL(k_leaf_kept, dim3(1024), dim3(256), 0, ctx->stream, lp, ix->n_nodes, d_leaf_kept);
+            AH_HIP(hipGetLastError());
+            leaf_kept_passes = 1;
+        } else {
+            wave_descent = false;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(ix->stats_mu);
+        ix->stats.calls++;
+        ix->stats.leaf_kept_passes += leaf_kept_passes;
     }
     // sub-batches bounded by scratch (~1.5 GiB of candidate buffers)
     const size_t key_bytes = batch_supported((uint32_t)std::min<size_t>(count, 0xFFFFFFFFu))
@@ -1930,10 +2022,20 @@ int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_it
     for (size_t q0 = 0; q0 < nq && st == AH_OK; q0 += chunk) {
         const size_t c = std::min(chunk, nq - q0);
         st = search_chunk(ix, ctx, queries ? queries + q0 * (size_t)ds->dims : nullptr, query_items ? rows.data() + q0 : nullptr,
-                          c, count, (uint32_t)sk_eff, (uint32_t)stride, d_bits, bits_len, filter_share, out_ids + q0 * count,
+                          c, count, (uint32_t)sk_eff, (uint32_t)stride, d_bits, bits_len, filter_share, wave_descent, d_leaf_kept,
+                          out_ids + q0 * count,
                           out_distances + q0 * count, out_counts + q0);
     }
     return st;
+}
+
+// Which kernels served the searches of this index so far (ABI v5); reset != 0 zeroes the counters after the copy.
+int ah_index_search_stats(ah_index *ix, ah_search_stats *out, int reset) {
+    AH_REQUIRE(ix && out, AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lk(ix->stats_mu);
+    *out = ix->stats;
+    if (reset) ix->stats = ah_search_stats{};
+    return AH_OK;
 }
 
 }  // extern "C"

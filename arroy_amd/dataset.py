@@ -192,7 +192,7 @@ class Dataset:
         _lib.check(_lib.lib().ah_dataset_upload_records(self._h, _ptr(ids), ptrs, int(record_len), ids.size))
 
     def build_forest(self, tree_seeds: Sequence[int], split_after: int = 0, cancel=None, progress=None,
-                     max_trees_in_flight: int = 0, margin_mode: int = 0) -> "Forest":
+                     max_trees_in_flight: int = 0, margin_mode: int = 0, max_host_threads: int = 0) -> "Forest":
         seeds = np.ascontiguousarray(tree_seeds, dtype=np.uint64)
         opt = _lib.AhBuildOptions()
         opt.n_trees = seeds.size
@@ -223,6 +223,7 @@ class Dataset:
             threading.Thread(target=_watch, daemon=True).start()
         opt.max_trees_in_flight = int(max_trees_in_flight)
         opt.margin_mode = int(margin_mode)
+        opt.max_host_threads = int(max_host_threads)
         h = C.c_void_p()
         try:
             _lib.check(_lib.lib().ah_build_forest(self._h, C.byref(opt), C.byref(h)))
@@ -321,6 +322,12 @@ class Index:
         if raw:
             return oi, od, oc
         return [[(int(oi[i, j]), float(od[i, j])) for j in range(int(oc[i]))] for i in range(nq)]
+
+    def stats(self, reset: bool = False) -> dict:
+        """ah_index_search_stats: which descent tier / dedup path / re-rank path served the searches so far."""
+        st = _lib.AhSearchStats()
+        _lib.check(_lib.lib().ah_index_search_stats(self._h, C.byref(st), 1 if reset else 0))
+        return {f: int(getattr(st, f)) for f, _ in _lib.AhSearchStats._fields_ if f != "reserved"}
 
     def route_items(self, item_ids: Sequence[int], tree_seeds: Sequence[int]) -> np.ndarray:
         """Incremental routing (src/writer.rs:1398-1459): [n_trees, n] forest-local Descendants node per item."""

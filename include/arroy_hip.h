@@ -34,11 +34,13 @@
 extern "C" {
 #endif
 
-#define AH_ABI_VERSION 4   /* v2: ah_node.tree is 32 bits, ah_build_options.margin_mode, ah_build_stats.margin_mode_launches,
+#define AH_ABI_VERSION 5   /* v2: ah_node.tree is 32 bits, ah_build_options.margin_mode, ah_build_stats.margin_mode_launches,
                                   ah_last_error_detail, ah_dataset_replicate, ah_dataset_upload_flush
                               v3: AH_MARGIN_DENSE_MFMA, ah_build_stats.dense_launches / dense_columns (appended)
                               v4: ah_forest_digest, ah_tuning_set / _get / _reset, ah_debug_launch_coverage,
-                                  ah_build_stats.rows_* / screen8_* / screen_unavailable (appended) */
+                                  ah_build_stats.rows_* / screen8_* / screen_unavailable (appended)
+                              v5: ah_search_stats / ah_index_search_stats, ah_build_options.max_host_threads (appended),
+                                  ah_host_cache_trim, ah_synth_rows_host */
 
 /* every entry point is exported from the shared object (it is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -247,6 +249,10 @@ typedef struct ah_build_options {
     void *progress_user;
     uint32_t max_trees_in_flight;  /* 0 = as many as HBM allows                                      */
     uint32_t margin_mode;          /* ah_margin_mode; 0 = AH_MARGIN_AUTO                             */
+    uint32_t max_host_threads;     /* ABI v5: host threads this build may keep busy for its output path (page commits,
+                                      bounce copies, node list); 0 = 8.  The reference gives a build its rayon pool
+                                      (src/writer.rs:538-548); eight concurrent builds of an 8-GPU node share the host */
+    uint32_t reserved0;            /* 0 */
 } ah_build_options;
 
 /* Whole-forest build: `make_tree_in_file` for every tree (src/writer.rs:556-591,1167-1261) with the
@@ -366,6 +372,45 @@ AH_API int ah_search_batch(ah_index *index, const float *queries, const uint32_t
                            size_t search_k, size_t oversampling, const uint32_t *filter_sorted, size_t n_filter,
                            int have_filter, uint32_t *out_ids, float *out_distances, uint32_t *out_counts);
 
+/* Which device path served the searches of an index (ABI v5).  ah_search_batch has several tiers — four descents, three
+ * dedup paths, two re-rank paths — that return the same bits; these counters are how a caller (and the parity tests)
+ * can tell that the intended one ran instead of a silent fall-back.  All values count since the index was created or
+ * since the last call with reset != 0. */
+typedef struct ah_search_stats {
+    uint64_t calls;                 /* ah_search_batch calls that reached the device                                   */
+    uint64_t chunks;                /* sub-batches they were cut into                                                  */
+    uint64_t queries;
+    /* the descent that produced a query's candidates (src/reader.rs:341-374); the four sum to `queries` */
+    uint64_t descent_wave_small;    /* one wave per query, 256 queue entries / 64 leaves per octet                     */
+    uint64_t descent_wave_big;      /* ... its second pass, 1024 / 128                                                 */
+    uint64_t descent_octet_lds;     /* one octet per query, the sequential queue in LDS                                */
+    uint64_t descent_octet_global;  /* ... the queue in global memory (capacity = number of nodes)                     */
+    /* nns.sort_unstable(); nns.dedup() (src/reader.rs:378-379), in queries */
+    uint64_t dedup_flag_bitmap;     /* leaf tiles: duplicates flagged through one bit per id in LDS                    */
+    uint64_t dedup_flag_hash;       /* leaf tiles: ... through a hash set of the candidates in LDS (big id spaces)     */
+    uint64_t dedup_sorted_bitmap;   /* sorted path: the LDS bitmap walked in order                                     */
+    uint64_t dedup_sort_lds;        /* sorted path: bitonic sort in LDS                                                */
+    uint64_t dedup_sort_global;     /* sorted path: bitonic sort in global memory                                      */
+    /* the re-rank (src/reader.rs:381-399), in queries */
+    uint64_t rerank_tiles;          /* rows of a leaf x the queries that reached it                                    */
+    uint64_t rerank_sorted;         /* from the sorted candidate lists (the kernels of ah_rerank_batch)                */
+    uint64_t tile_visits;           /* (query, leaf) pairs the leaf tiles served                                       */
+    uint64_t tile_units_16;         /* work units of 9..16 visits of one leaf (operands through the LDS ring)          */
+    uint64_t tile_units_8;          /* ... of 5..8 visits (LDS ring)                                                   */
+    uint64_t tile_units_4;          /* ... of 1..4 visits (registers)                                                  */
+    /* sub-batches the leaf tiles handed to the sorted path, and why (one chunk may count under several reasons) */
+    uint64_t fallback_chunks;
+    uint64_t fallback_non_finite;   /* a non-finite distance: src/reader.rs:611-621 looks at positions                 */
+    uint64_t fallback_select;       /* the selection / the hash set did not fit its LDS buffers                        */
+    uint64_t fallback_queue;        /* a queue outgrew LDS (the sorted path has the global-memory queue)               */
+    uint64_t fallback_visits;       /* more leaf visits than the visit buffer holds                                    */
+    uint64_t fallback_launch;       /* the runtime rejected a launch of the tile path                                  */
+    uint64_t filtered_queries;      /* queries under a candidate filter                                                */
+    uint64_t leaf_kept_passes;      /* passes over every Descendants id for |leaf & candidates| (once per filtered call) */
+    uint64_t reserved[4];
+} ah_search_stats;
+AH_API int ah_index_search_stats(ah_index *index, ah_search_stats *out, int reset);
+
 /* Incremental insert routing, `insert_items_in_descendants_from_frozen_reader` (src/writer.rs:1398-1459), for
  * every tree of the index at once: each of the `n` items (they must already be rows of the index's dataset — the
  * reference also re-creates `ImmutableLeafs` over all current items for every build, src/writer.rs:530) walks from
@@ -394,6 +439,14 @@ AH_API int ah_bench_memcpy(int device, uint64_t bytes, uint32_t iterations, doub
 AH_API int ah_bench_read(int device, uint64_t bytes, uint32_t iterations, double *out_ms_total);
 /* Name of the device (hipDeviceProp_t.name / gcnArchName) into buf. */
 AH_API int ah_device_name(int device, char *buf, size_t buf_len);
+
+/* The blobs (normals, item ids) of destroyed forests are kept committed in a process-wide pool and handed to the next
+ * build, which then takes no page faults for its 9.4 GB of output (AH_HOST_CACHE_MB bounds the pool, default 16 GiB;
+ * 0 = keep nothing).  This returns the pool's memory to the system; *out_bytes (may be NULL) = committed bytes released. */
+AH_API int ah_host_cache_trim(uint64_t *out_bytes);
+/* Benchmark harness only: n x dims synthetic rows of the generator of arroy_hip_policy.h (the rows
+ * ah_dataset_fill_synthetic makes in HBM) in HOST memory, items first_item .. first_item + n - 1, on all host cores. */
+AH_API int ah_synth_rows_host(uint64_t seed, int distribution, uint64_t first_item, uint64_t n, uint32_t dims, float *out);
 
 /* Tunables: measurement / test aids that steer the SCHEDULE of the kernels (which family a level takes, grids, cache
  * policy), never a result.  `name` is the environment variable that initialises the tunable when the library is loaded

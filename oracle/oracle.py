@@ -440,21 +440,30 @@ def forest_view(forest) -> "AhForestView":
     return v
 
 
-def search(data: "Data", forest, qv, qh, count: int, search_k: int = 0, oversampling: int = 0, candidates=None):
-    """`Reader::nns_by_leaf` (src/reader.rs:317-401) over `forest`; returns ([(id, dist)...], candidate ids)."""
-    view = forest_view(forest)
-    filt = None if candidates is None else np.ascontiguousarray(sorted(set(int(c) for c in candidates)), dtype=np.uint32)
+def search(data: "Data", forest, qv, qh, count: int, search_k: int = 0, oversampling: int = 0, candidates=None,
+           candidates_sorted: bool = False, want_candidates: bool = True, view=None):
+    """`Reader::nns_by_leaf` (src/reader.rs:317-401) over `forest`; returns ([(id, dist)...], candidate ids).
+    candidates_sorted: `candidates` is already an ascending uint32 array of distinct ids; want_candidates=False skips the
+    copy of the candidate list (its buffer is sized by the forest's Descendants blob: gigabytes at 10M x 100 trees);
+    view: a forest_view(forest) the caller already holds."""
+    view = forest_view(forest) if view is None else view
+    if candidates is None:
+        filt = None
+    elif candidates_sorted:
+        filt = np.ascontiguousarray(candidates, dtype=np.uint32)
+    else:
+        filt = np.ascontiguousarray(sorted(set(int(c) for c in candidates)), dtype=np.uint32)
     oi = np.zeros(max(count, 1), dtype=np.uint32)
     od = np.zeros(max(count, 1), dtype=np.float32)
-    cap = int(forest.descendants.size) + 1
-    cand = np.zeros(cap, dtype=np.uint32)
+    cap = int(forest.descendants.size) + 1 if want_candidates else 0
+    cand = np.zeros(max(cap, 1), dtype=np.uint32)
     nc = C.c_size_t(0)
     qh2 = np.zeros(2, dtype=np.float32)
     qh2[: len(qh)] = qh
     m = lib().ao_search(data.c(), C.byref(view), _p(np.ascontiguousarray(qv)), _p(qh2), count, min(search_k, 2**62),
                         oversampling, None if filt is None else _p(filt), 0 if filt is None else filt.size,
-                        0 if filt is None else 1, _p(oi), _p(od), _p(cand), cap, C.byref(nc))
-    return [(int(oi[i]), float(od[i])) for i in range(m)], cand[: nc.value].copy()
+                        0 if filt is None else 1, _p(oi), _p(od), _p(cand) if want_candidates else None, cap, C.byref(nc))
+    return [(int(oi[i]), float(od[i])) for i in range(m)], cand[: nc.value if want_candidates else 0].copy()
 
 
 def route_items(data: "Data", forest, rows, tree_seeds) -> np.ndarray:
