@@ -30,7 +30,7 @@ def one(rng, it):
     if rng.random() < 0.4:
         span = int(n * rng.choice([2, 50, 100000]))
         ids = np.sort(rng.choice(max(span, n + 1), n, replace=False)).astype(np.uint32)
-    scale = float(rng.choice([1.0, 1.0, 1e-3, 1e3, 1e-6, 3e4]))  # the last two leave the binary16 range of the screen
+    scale = float(rng.choice([1.0, 1.0, 1e-3, 1e3, 1e-6, 3e4, 7e-24]))  # the last three leave the binary16 range of the screen; at 7e-24 f32 squares underflow
     ds, oracle, vecs, ids = T.make_data(cls, n, dims, seed=int(rng.integers(1 << 30)), ids=ids, scale=scale)
     desc = f"it={it} metric={metric} n={n} dims={dims} sparse={ids[-1] != n - 1} scale={scale}"
     q = (rng.standard_normal(dims) * scale).astype(np.float32)
