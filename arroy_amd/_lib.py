@@ -95,7 +95,8 @@ class AhBuildStats(C.Structure):
                 ("rows_xcd_launches", C.c_uint64), ("rows_nt_launches", C.c_uint64), ("rows_split_launches", C.c_uint64),
                 ("screen8_pairs", C.c_uint64), ("screen8_decided", C.c_uint64), ("screen8b_decided", C.c_uint64),
                 ("screen_unavailable", C.c_uint32),
-                ("reserved0", C.c_uint32)]
+                ("reserved0", C.c_uint32), ("seconds_setup", C.c_double), ("seconds_after_device", C.c_double),
+                ("host_blob_recycled", C.c_uint64)]
 
 
 class AhSearchStats(C.Structure):
@@ -105,6 +106,21 @@ class AhSearchStats(C.Structure):
         "rerank_tiles", "rerank_sorted", "tile_visits", "tile_units_16", "tile_units_8", "tile_units_4",
         "fallback_chunks", "fallback_non_finite", "fallback_select", "fallback_queue", "fallback_visits", "fallback_launch",
         "filtered_queries", "leaf_kept_passes")] + [("reserved", C.c_uint64 * 4)]
+
+
+class AhStreamNode(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("tree", C.c_uint32), ("kind", C.c_uint8), ("has_normal", C.c_uint8), ("reserved", C.c_uint16),
+                ("left", C.c_uint32), ("right", C.c_uint32), ("count", C.c_uint32), ("depth", C.c_uint32),
+                ("payload_offset", C.c_uint64)]
+
+
+class AhNodeBatch(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("level", C.c_uint32), ("n_nodes", C.c_uint64), ("nodes", C.POINTER(AhStreamNode)),
+                ("payload", C.POINTER(C.c_uint8)), ("payload_len", C.c_uint64), ("normal_stride", C.c_uint64),
+                ("normal_vector_offset", C.c_uint64), ("normal_header_offset", C.c_uint64)]
+
+
+NODE_BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(AhNodeBatch))
 
 
 # name -> (restype, argtypes): exactly the declarations of include/arroy_hip.h
@@ -140,6 +156,7 @@ SIGNATURES = {
     "ah_margins": (C.c_int, [_VP, _VP, _VP, _U32P, C.c_size_t, _F32P]),
     "ah_create_split": (C.c_int, [_VP, _U32P, _VP, _VP]),
     "ah_build_forest": (C.c_int, [_VP, C.POINTER(AhBuildOptions), C.POINTER(C.c_void_p)]),
+    "ah_build_forest_stream": (C.c_int, [_VP, C.POINTER(AhBuildOptions), NODE_BATCH_FN, _VP, _U32P, C.POINTER(AhBuildStats)]),
     "ah_build_subtrees": (C.c_int, [_VP, C.POINTER(AhBuildOptions), _U32P, _U64P, C.POINTER(C.c_void_p)]),
     "ah_forest_view_get": (C.c_int, [_VP, C.POINTER(AhForestView)]),
     "ah_forest_stats": (C.c_int, [_VP, C.POINTER(AhBuildStats)]),

@@ -2011,12 +2011,30 @@ static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force) {
 // ids in 0.60 s = 6.7 GB/s, whatever the number of concurrent calls).  Instead a worker thread owns a pinned double
 // buffer: the DMA engine fills one half while a few threads copy the other half to its final place, and the level
 // loop never waits for it — each level's normals travel while the next levels are computed.
+// One delivery of a streaming build (ah_build_forest_stream): the payloads of `nodes` lie back to back at a device address, in
+// the order of the list (split planes of a level: one record per node; item ids: the leaves in (tree, position) order).  The
+// read-back worker moves them through its pinned double buffer in pieces of whole nodes and calls the sink on every piece.
+struct StreamJob {
+    ah_node_batch head{};                // kind, level, record geometry
+    std::vector<ah_stream_node> nodes;   // payload_offset: byte offset from the job's device address, ascending, contiguous
+    uint64_t fixed_len = 0;              // bytes of one payload (split planes), or 0: count * 4 (item ids)
+};
+struct StreamTarget {
+    ah_node_batch_fn sink = nullptr;
+    void *user = nullptr;
+    std::atomic<int> sink_rc{0};         // first non-zero return of the sink: the build stops with AH_ERR_CANCELLED
+    std::atomic<int> too_big{0};         // a single payload larger than half of the pinned buffer
+    uint64_t batches = 0, bytes = 0;
+};
+
 struct Readback {
     struct Job {
         void *dst;
         const void *src;
         size_t bytes;
+        StreamJob *stream = nullptr;     // non-null: deliver to the sink (dst unused); owned by the job
     };
+    StreamTarget *target = nullptr;
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
@@ -2106,6 +2124,61 @@ struct Readback {
         }
         return e;
     }
+    // device -> pinned half -> sink, piece by piece: the DMA of piece p + 1 is in flight while the sink looks at piece p
+    hipError_t deliver(StreamJob &job, const uint8_t *src, hipStream_t cs, hipEvent_t *ev) {
+        struct Piece {
+            size_t a = 0, b = 0;      // nodes [a, b)
+            uint64_t off = 0, len = 0;
+            int buf = 0;
+            bool live = false;
+        } cur, prev;
+        auto len_of = [&](const ah_stream_node &nd) -> uint64_t { return job.fixed_len ? job.fixed_len : (uint64_t)nd.count * 4; };
+        const size_t n = job.nodes.size();
+        size_t next = 0;
+        int b = 0;
+        hipError_t e = hipSuccess;
+        while ((next < n || prev.live) && e == hipSuccess) {
+            cur = Piece{};
+            if (next < n && !target->sink_rc.load() && !target->too_big.load()) {
+                cur.a = next;
+                cur.off = job.nodes[next].payload_offset;
+                size_t k = next;
+                while (k < n && job.nodes[k].payload_offset + len_of(job.nodes[k]) - cur.off <= half) k++;
+                if (k == next) {  // one payload alone does not fit: nothing sensible to hand over
+                    target->too_big.store(1);
+                    next = n;
+                } else {
+                    cur.b = k;
+                    cur.len = job.nodes[k - 1].payload_offset + len_of(job.nodes[k - 1]) - cur.off;
+                    cur.buf = b;
+                    cur.live = true;
+                    if (cur.len) e = hipMemcpyAsync(pin + (size_t)b * half, src + cur.off, cur.len, hipMemcpyDeviceToHost, cs);
+                    if (e == hipSuccess) e = hipEventRecord(ev[b], cs);
+                    next = k;
+                    b ^= 1;
+                }
+            } else {
+                next = n;
+            }
+            if (prev.live && e == hipSuccess) {
+                e = hipEventSynchronize(ev[prev.buf]);
+                if (e == hipSuccess && !target->sink_rc.load()) {
+                    for (size_t i = prev.a; i < prev.b; i++) job.nodes[i].payload_offset -= prev.off;
+                    ah_node_batch batch = job.head;
+                    batch.n_nodes = prev.b - prev.a;
+                    batch.nodes = job.nodes.data() + prev.a;
+                    batch.payload = pin + (size_t)prev.buf * half;
+                    batch.payload_len = prev.len;
+                    const int rc = target->sink(target->user, &batch);
+                    target->batches++;
+                    target->bytes += prev.len;
+                    if (rc != 0) target->sink_rc.store(rc);
+                }
+            }
+            prev = cur;
+        }
+        return e;
+    }
     void run() {
         hipStream_t cs = nullptr;
         hipEvent_t ev[2] = {nullptr, nullptr};
@@ -2122,7 +2195,8 @@ struct Readback {
                 job = q.front();
                 q.pop_front();
             }
-            if (e == hipSuccess) e = copy(job, cs, ev);
+            if (e == hipSuccess) e = job.stream ? deliver(*job.stream, reinterpret_cast<const uint8_t *>(job.src), cs, ev) : copy(job, cs, ev);
+            delete job.stream;
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (e != hipSuccess && err == hipSuccess) err = e;
@@ -2143,7 +2217,34 @@ struct Readback {
         }
         {
             std::lock_guard<std::mutex> lk(mu);
-            q.push_back(Job{dst, src, bytes});
+            q.push_back(Job{dst, src, bytes, nullptr});
+            pending++;
+        }
+        cv.notify_all();
+    }
+    // hand a stream job (ownership included) to the worker; without a worker thread it is delivered right here
+    void push_stream(StreamJob *job, const void *src) {
+        if (job->nodes.empty()) {
+            delete job;
+            return;
+        }
+        if (inline_mode) {
+            hipStream_t cs = nullptr;
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+            if (e == hipSuccess) e = deliver(*job, reinterpret_cast<const uint8_t *>(src), cs, ev);
+            if (e != hipSuccess && err == hipSuccess) err = e;
+            if (ev[0]) (void)hipEventDestroy(ev[0]);
+            if (ev[1]) (void)hipEventDestroy(ev[1]);
+            if (cs) (void)hipStreamDestroy(cs);
+            delete job;
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            q.push_back(Job{nullptr, src, 1, job});
             pending++;
         }
         cv.notify_all();
@@ -2306,9 +2407,20 @@ static unsigned host_thread_budget(const ah_build_options *opt) {
     return (unsigned)std::min<long long>(64, std::max<long long>(1, v));
 }
 
+// State of one ah_build_forest_stream call across its batches.
+struct StreamBuild {
+    StreamTarget target;
+    uint32_t id_base = 0;       // node ids handed out by earlier batches
+    uint32_t *roots = nullptr;  // the caller's out_roots
+};
+struct LeafRec {  // a Descendants node of a streaming build: its ids are final_perm[start, start + count)
+    uint64_t start;
+    uint32_t count, id, tree, depth;
+};
+
 static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t first_tree, uint32_t n_trees,
                        uint32_t split_after, ah_forest *forest, Context *ctx, const uint32_t *subset_ids,
-                       const uint64_t *subset_offsets) {
+                       const uint64_t *subset_offsets, StreamBuild *sb = nullptr) {
     const uint64_t N = ds->n;
     const auto t_batch = std::chrono::steady_clock::now();
     std::vector<uint64_t> tree_base(n_trees + 1, 0);
@@ -2367,6 +2479,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     uint32_t *d_tree_first = reinterpret_cast<uint32_t *>(d_info + 1);
     DevBuf<uint32_t> d_tree_first_buf;  // first node of every tree of the level, gaps closed (LDS variant of the row pass)
     AH_TRY(d_tree_first_buf.ensure((size_t)n_trees + 2));
+    const auto t_setup_alloc = std::chrono::steady_clock::now();
     uint32_t *d_tree_first_fixed = d_tree_first_buf.p;
     AH_HIP(hipMemsetAsync(d_small.p, 0, (16 + info_words) * 4, s));
 
@@ -2376,6 +2489,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     const size_t pin_nodes = (max_nodes * sizeof(FNode) + 4095) & ~(size_t)4095;
     const size_t pin_head = (3 * pin_info + 256 + 4095) & ~(size_t)4095;
     AH_TRY(ctx->ensure_pinned(pin_head + 2 * pin_nodes + kBounce));
+    const auto t_setup_pin = std::chrono::steady_clock::now();
     uint8_t *pin = reinterpret_cast<uint8_t *>(ctx->h_pinned);
     LevelInfo *h_info[2] = {reinterpret_cast<LevelInfo *>(pin), reinterpret_cast<LevelInfo *>(pin + pin_info)};
     uint32_t *h_one = reinterpret_cast<uint32_t *>(pin + 2 * pin_info);
@@ -2395,7 +2509,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_HIP(hipMemsetAsync(side_bytes.p, 0, (size_t)n_trees * N + 1024 + 16, s));
     }
     // certified binary16 screen: f32 metrics with AVX-tier rows, unless the caller (or AH_SCREEN=0) asks for f32 only
+    const auto t_setup_rows = std::chrono::steady_clock::now();
     const bool screen = !exact_only && !bq && ds->dims >= 32 && ensure_screen(ds, s);
+    const auto t_setup_screen = std::chrono::steady_clock::now();
     if (!exact_only && !screen && ds->screen_alloc_failed) forest->stats.screen_unavailable = 1;
     ScreenView sv{};
     uint64_t hstride = 0;
@@ -2440,9 +2556,11 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     // allocated up front and its pages are touched in the background while the GPU works (first-touch faults of
     // fresh memory, not the copy, bound a read-back of several GB).
     const uint64_t desc_base = forest->descendants_len;
-    AH_REQUIRE(host_blob_reserve(forest->desc_blob, (desc_base + M) * 4, desc_base * 4), AH_ERR_OUT_OF_MEMORY,
-               "host allocation of the descendants failed");
-    forest->descendants = reinterpret_cast<uint32_t *>(forest->desc_blob.p);
+    if (!sb) {  // (a streaming build hands the ids to the sink from the pinned ring: no blob)
+        AH_REQUIRE(host_blob_reserve(forest->desc_blob, (desc_base + M) * 4, desc_base * 4), AH_ERR_OUT_OF_MEMORY,
+                   "host allocation of the descendants failed");
+        forest->descendants = reinterpret_cast<uint32_t *>(forest->desc_blob.p);
+    }
     struct Toucher {  // commits the pages of a fresh (still unwritten) host range in the background
         std::thread th;
         unsigned max_threads = 8;
@@ -2474,7 +2592,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     } prefault, touch_normals[2];  // [level & 1]: commits the level's normals, started one level ahead
     const unsigned host_threads = host_thread_budget(opt);
     prefault.max_threads = touch_normals[0].max_threads = touch_normals[1].max_threads = host_threads;
-    prefault.start(forest->desc_blob, desc_base * 4, M * 4);
+    if (!sb) prefault.start(forest->desc_blob, desc_base * 4, M * 4);
     Arena arena, shadow_arena, shadow8_arena;  // declared before the read-back worker: it is joined before the chunks it reads are freed
     arena.block_bytes = std::max<uint64_t>(32ull << 20, std::min<uint64_t>(2 * max_nodes * nstride, 16ull << 30));
     shadow_arena.block_bytes = std::max<uint64_t>(16ull << 20, std::min<uint64_t>(max_nodes * std::max<uint64_t>(hstride, 16), 8ull << 30));
@@ -2482,6 +2600,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     BatchCleanup bc;
     AH_TRY(bc.create());
     Readback rb;
+    rb.target = sb ? &sb->target : nullptr;
     rb.copy_threads = host_threads;
     rb.start(ds->device, pin + pin_head + 2 * pin_nodes, kBounce);
 
@@ -2494,6 +2613,10 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                         // pages on the thread that digests the deepest level was most of that digest's 35 ms)
     LevelInfo info{};
     std::vector<uint32_t> tree_first(n_trees + 1, 0xFFFFFFFFu);
+    // streaming build: the Descendants nodes, one list per level of creation (each ascending in (tree, position))
+    std::vector<std::vector<LeafRec>> stream_leaves;
+    const uint32_t id_base = sb ? sb->id_base : 0u;
+    if (sb) stream_leaves.emplace_back();
     {
         FNode *lv = h_nodes[0];
         for (uint32_t t = 0; t < n_trees; t++) {
@@ -2506,6 +2629,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             tree_root[t] = (uint32_t)n_recs;
             if (cnt <= split_after) {  // fit_in_descendant at the root: the tree is one Descendants node
                 r.kind = AH_NODE_DESCENDANTS;
+                if (sb) stream_leaves[0].push_back(LeafRec{r.start, cnt, id_base + (uint32_t)n_recs, first_tree + t, 0u});
                 recs.push_back(r);
                 n_recs++;
                 continue;
@@ -2532,6 +2656,14 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     uint32_t *cur = perm_a.p, *nxt = perm_b.p;
     FNode *d_cur = d_nodes_a.p, *d_next = d_nodes_b.p;
     AH_HIP(hipEventRecord(bc.ev_begin, s));
+    forest->stats.seconds_setup += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_batch).count();
+    if (timing) {
+        auto ms_of = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[ah] batch setup: device buffers %.1f ms, pinned %.1f ms, row-major buffers %.1f ms, screen copies %.1f ms, "
+                        "host blobs + workers + roots %.1f ms\n",
+                ms_of(t_batch, t_setup_alloc), ms_of(t_setup_alloc, t_setup_pin), ms_of(t_setup_pin, t_setup_rows),
+                ms_of(t_setup_rows, t_setup_screen), ms_of(t_setup_screen, std::chrono::steady_clock::now()));
+    }
     const size_t cs_shared = (size_t)f32_space_pitch(ds->metric, ds->dims) * 4 * 3;
     AH_REQUIRE(cs_shared <= 150 * 1024, AH_ERR_INVALID_DIMENSION, "dimensions %u too large for the LDS-resident two-means",
                ds->dims);
@@ -2572,7 +2704,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     // Digest the node table of a finished level (it arrived on the side stream): split records, children, statistics,
     // and which HostRec every node of the next level belongs to — the same walk the device did in k_next_emit.
     uint64_t items_routed = 0;
-    auto digest_level = [&](uint32_t depth, uint32_t n_nodes, const FNode *tbl, uint64_t chunk_host_off) -> int {
+    auto digest_level = [&](uint32_t depth, uint32_t n_nodes, const FNode *tbl, uint64_t chunk_host_off, const uint8_t *chunk_dev) -> int {
         // Children get the records base + 2 i (left) and base + 2 i + 1 (right) of node i, so the walk splits over a few
         // threads (the deepest level of the 10M x 100-tree build has 819 000 nodes: 37 ms on one thread, more than the GPU
         // needs for the level after it); the list of children that split again is concatenated in node order afterwards.
@@ -2584,8 +2716,22 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             uint64_t evals = 0, retries = 0, routed = 0, dummies = 0;
             uint32_t bad = 0xFFFFFFFFu;
             std::vector<uint32_t> splits;
+            std::vector<LeafRec> leaves;  // streaming build: the children that are Descendants nodes, in node order
         };
         std::vector<Part> parts(n_threads);
+        // streaming build: this level's split planes as one job for the read-back worker (record i <-> node i)
+        StreamJob *job = nullptr;
+        if (sb) {
+            job = new (std::nothrow) StreamJob();
+            AH_REQUIRE(job, AH_ERR_OUT_OF_MEMORY, "host allocation failed");
+            job->head.kind = AH_NODE_SPLIT;
+            job->head.level = depth;
+            job->head.normal_stride = nstride;
+            job->head.normal_vector_offset = 0;
+            job->head.normal_header_offset = hdr_off;
+            job->fixed_len = nstride;
+            job->nodes.resize(n_nodes);
+        }
         auto walk = [&](unsigned t) {
             Part &pt = parts[t];
             const uint32_t lo = (uint32_t)((uint64_t)n_nodes * t / n_threads), hi = (uint32_t)((uint64_t)n_nodes * (t + 1) / n_threads);
@@ -2614,6 +2760,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     const uint32_t cidx = (uint32_t)(base + 2 * (size_t)i + side);
                     if (c.count <= split_after) {
                         c.kind = AH_NODE_DESCENDANTS;
+                        if (sb) pt.leaves.push_back(LeafRec{c.start, c.count, id_base + cidx, first_tree + nd.tree, depth + 1});
                     } else {
                         c.kind = AH_NODE_SPLIT;
                         pt.splits.push_back(cidx);
@@ -2622,9 +2769,33 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     if (side == 0) recs[rec_idx].left = cidx;
                     else recs[rec_idx].right = cidx;
                 }
+                if (sb) {
+                    ah_stream_node sn{};
+                    sn.id = id_base + rec_idx;
+                    sn.tree = first_tree + nd.tree;
+                    sn.kind = AH_NODE_SPLIT;
+                    sn.has_normal = nd.state == ST_ACCEPTED;
+                    sn.left = id_base + (uint32_t)(base + 2 * (size_t)i);
+                    sn.right = sn.left + 1;
+                    sn.count = nd.count;
+                    sn.depth = depth;
+                    sn.payload_offset = (uint64_t)i * nstride;
+                    job->nodes[i] = sn;
+                }
             }
         };
         parallel_run(n_threads, walk);
+        if (sb) {
+            bool bad = false;
+            for (const Part &pt : parts) bad = bad || pt.bad != 0xFFFFFFFFu;
+            if (bad) {
+                delete job;
+            } else {
+                stream_leaves.emplace_back();
+                for (Part &pt : parts) stream_leaves.back().insert(stream_leaves.back().end(), pt.leaves.begin(), pt.leaves.end());
+                rb.push_stream(job, chunk_dev);  // the level's planes travel while the next levels are computed
+            }
+        }
         next_rec.clear();
         for (const Part &pt : parts) {
             AH_REQUIRE(pt.bad == 0xFFFFFFFFu, AH_ERR_DEVICE, "forest build: node %u of level %u left pending (internal error)",
@@ -2677,6 +2848,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     uint32_t pending_digest = 0;  // 1 + depth of the level whose node table is still to be digested (0 = none)
     uint32_t pending_nodes = 0;
     uint64_t pending_host_off = 0;
+    const uint8_t *pending_chunk_dev = nullptr;
     int lvl_status = AH_OK;
     while (info.n_nodes) {
         if (opt->cancel && *opt->cancel) {
@@ -2684,6 +2856,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             return AH_ERR_CANCELLED;  // Error::BuildCancelled
         }
         AH_REQUIRE(depth < 100000, AH_ERR_DEVICE, "forest build: depth %u exceeded (internal error)", depth);
+        if (sb && (sb->target.sink_rc.load() || sb->target.too_big.load())) break;  // reported after the loop
         const auto t_level_top = std::chrono::steady_clock::now();
         const double ms_tail_prev = std::chrono::duration<double, std::milli>(t_level_top - t_prev_waited).count();
         const uint32_t n_nodes = info.n_nodes, n_tiles = info.n_tiles;
@@ -2701,9 +2874,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         // about twice the nodes of the one before), those of the NEXT level start now — committing the 2.6 GB of the deepest
         // level takes longer than the ~160 ms that level runs, and the loop must not wait for page faults before it can
         // hand a chunk to the read-back worker.  Whatever the prediction missed is faulted in by the worker itself.
-        AH_TRY(reserve_normals(chunk_host_off + chunk_bytes, chunk_host_off));
-        if (depth == 0) touch_normals[0].start(forest->normals_blob, chunk_host_off, chunk_bytes);
-        {
+        if (!sb) AH_TRY(reserve_normals(chunk_host_off + chunk_bytes, chunk_host_off));
+        if (!sb && depth == 0) touch_normals[0].start(forest->normals_blob, chunk_host_off, chunk_bytes);
+        if (!sb) {
             // next level: twice the nodes while the nodes are large; once they hold fewer than 2 x split_after items on
             // average most children are Descendants and the next level is a remnant (an eighth); nothing below that
             const uint64_t next_begin = chunk_host_off + chunk_bytes;
@@ -3116,7 +3289,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         const auto t_launched = std::chrono::steady_clock::now();
         if (pending_digest) {
             AH_HIP(hipEventSynchronize(bc.ev_copy[(pending_digest - 1) & 1]));
-            AH_TRY(digest_level(pending_digest - 1, pending_nodes, h_nodes[(pending_digest - 1) & 1], pending_host_off));
+            AH_TRY(digest_level(pending_digest - 1, pending_nodes, h_nodes[(pending_digest - 1) & 1], pending_host_off, pending_chunk_dev));
             pending_digest = 0;
         }
         const auto t_digested = std::chrono::steady_clock::now();
@@ -3152,9 +3325,10 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         pending_digest = depth + 1;
         pending_nodes = n_nodes;
         pending_host_off = chunk_host_off;
+        pending_chunk_dev = chunk_d;
         // this level's normals are final: the worker copies them while the next level runs
         touch_normals[depth & 1].join();  // never touch a page the worker may already have filled
-        rb.push(forest->normals + chunk_host_off, chunk_d, chunk_bytes);
+        if (!sb) rb.push(forest->normals + chunk_host_off, chunk_d, chunk_bytes);  // (streaming: pushed by the level's digest)
 
         info = *hi;
         const uint32_t *tf = reinterpret_cast<const uint32_t *>(hi + 1);
@@ -3165,13 +3339,16 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         depth++;
     }
     AH_HIP(hipEventRecord(bc.ev_end, s));
+    const auto t_loop_end = std::chrono::steady_clock::now();
 
     // Results come back with plain D2H copies straight into their final place — no host-side repacking:
     //   normals      one copy per level chunk (device record layout == caller-visible layout), already under way
     //   descendants  the final permutations themselves (rows -> item ids on device first)
+    auto t_tail_prefault = t_loop_end, t_tail_sync = t_loop_end;
     {
         prefault.join();
-        forest->descendants_len = desc_base + M;
+        t_tail_prefault = std::chrono::steady_clock::now();
+        if (!sb) forest->descendants_len = desc_base + M;
         // trees that are a single Descendants node never went through a scatter: their list is the input itself
         for (uint32_t t = 0; t < n_trees; t++)
             if (recs[tree_root[t]].kind == AH_NODE_DESCENDANTS && tree_base[t + 1] > tree_base[t])
@@ -3182,22 +3359,95 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         ScreenCounters sc{};
         AH_HIP(hipMemcpyAsync(&sc, d_counters, sizeof sc, hipMemcpyDeviceToHost, s));
         AH_HIP(hipStreamSynchronize(s));
+        t_tail_sync = std::chrono::steady_clock::now();
         forest->stats.screen_fallbacks += sc.fallbacks;
         forest->stats.screen_violations += sc.violations;
         forest->stats.screen8_pairs += sc.stage8_pairs;
         forest->stats.screen8_decided += sc.stage8_decided;
         forest->stats.screen8b_decided += sc.stage8b_decided;
-        rb.push(forest->descendants + desc_base, final_perm.p, M * 4);  // lands while the host emits the node list
+        if (!sb) rb.push(forest->descendants + desc_base, final_perm.p, M * 4);  // lands while the host emits the node list
     }
     // the last level's node table is digested only now: the 4 GB of item ids are already on their way
     if (pending_digest) {
         AH_HIP(hipEventSynchronize(bc.ev_copy[(pending_digest - 1) & 1]));
-        AH_TRY(digest_level(pending_digest - 1, pending_nodes, h_nodes[(pending_digest - 1) & 1], pending_host_off));
+        AH_TRY(digest_level(pending_digest - 1, pending_nodes, h_nodes[(pending_digest - 1) & 1], pending_host_off, pending_chunk_dev));
+    }
+    if (sb) {
+        // Streaming build: the Descendants nodes, ascending in (tree, position) — i.e. in the order their ids lie in the final
+        // permutation — as one job.  Every level's list is already in that order; the levels of one tree are merged per tree
+        // (a few threads: 1.7 M leaves at 10M x 100 trees).
+        StreamJob *job = new (std::nothrow) StreamJob();
+        AH_REQUIRE(job, AH_ERR_OUT_OF_MEMORY, "host allocation failed");
+        job->head.kind = AH_NODE_DESCENDANTS;
+        job->head.normal_stride = nstride;
+        job->head.normal_header_offset = hdr_off;
+        size_t total = 0;
+        for (const auto &lv : stream_leaves) total += lv.size();
+        job->nodes.resize(total);
+        // per tree: where its leaves start in every level's list, and in the output
+        const size_t n_lv = stream_leaves.size();
+        std::vector<size_t> cut((size_t)(n_trees + 1) * n_lv, 0), out_at(n_trees + 1, 0);
+        for (size_t l = 0; l < n_lv; l++) {
+            const auto &lv = stream_leaves[l];
+            for (uint32_t t = 0; t <= n_trees; t++)
+                cut[(size_t)t * n_lv + l] = (size_t)(std::lower_bound(lv.begin(), lv.end(), tree_base[t], [](const LeafRec &r, uint64_t v) { return r.start < v; }) - lv.begin());
+        }
+        for (uint32_t t = 0; t < n_trees; t++) {
+            size_t c = 0;
+            for (size_t l = 0; l < n_lv; l++) c += cut[(size_t)(t + 1) * n_lv + l] - cut[(size_t)t * n_lv + l];
+            out_at[t + 1] = out_at[t] + c;
+        }
+        std::atomic<uint32_t> next_tree{0};
+        parallel_run(total < 100000 ? 1u : std::min(n_trees, host_threads), [&](unsigned) {
+            std::vector<LeafRec> mine;
+            for (;;) {
+                const uint32_t t = next_tree.fetch_add(1, std::memory_order_relaxed);
+                if (t >= n_trees) break;
+                mine.clear();
+                for (size_t l = 0; l < n_lv; l++)
+                    mine.insert(mine.end(), stream_leaves[l].begin() + (ptrdiff_t)cut[(size_t)t * n_lv + l],
+                                stream_leaves[l].begin() + (ptrdiff_t)cut[(size_t)(t + 1) * n_lv + l]);
+                std::sort(mine.begin(), mine.end(), [](const LeafRec &a, const LeafRec &b) { return a.start < b.start; });
+                ah_stream_node *dst = job->nodes.data() + out_at[t];
+                for (const LeafRec &r : mine) {
+                    ah_stream_node sn{};
+                    sn.id = r.id;
+                    sn.tree = r.tree;
+                    sn.kind = AH_NODE_DESCENDANTS;
+                    sn.count = r.count;
+                    sn.depth = r.depth;
+                    sn.payload_offset = r.start * 4;
+                    *dst++ = sn;
+                }
+            }
+        });
+        rb.push_stream(job, final_perm.p);
     }
     const auto t_levels = std::chrono::steady_clock::now();
     float ms = 0.0f;
     AH_HIP(hipEventElapsedTime(&ms, bc.ev_begin, bc.ev_end));
     forest->stats.seconds_device += ms * 1e-3;
+    if (sb) {
+        // no node list, no blobs: the roots, the counts, and the worker's verdict
+        recs.resize(n_recs);
+        uint64_t splits = 0, descs = 0;
+        for (const HostRec &r : recs) (r.kind == AH_NODE_SPLIT ? splits : descs)++;
+        forest->stats.split_nodes += splits;
+        forest->stats.descendant_nodes += descs;
+        for (uint32_t t = 0; t < n_trees; t++) sb->roots[first_tree + t] = id_base + tree_root[t];
+        AH_REQUIRE((uint64_t)id_base + n_recs < 0xFFFFFFFFull, AH_ERR_INVALID_ARGUMENT, "more than 2^32 tree nodes in one build");
+        sb->id_base = id_base + (uint32_t)n_recs;
+        AH_REQUIRE(rb.drain() == hipSuccess, AH_ERR_DEVICE, "device -> host copy of the forest failed");
+        AH_REQUIRE(!sb->target.too_big.load(), AH_ERR_INVALID_ARGUMENT,
+                   "a Descendants node holds more item ids than the streaming buffer (split_after too large for ah_build_forest_stream)");
+        AH_REQUIRE(!sb->target.sink_rc.load(), AH_ERR_CANCELLED, "node sink asked to stop (code %d)", sb->target.sink_rc.load());
+        forest->stats.seconds_after_device += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop_end).count();
+        if (timing)
+            fprintf(stderr, "[ah] streamed batch of %u trees: %.3f s (device %.3f), %llu sink calls, %.2f GB handed over\n", n_trees,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_batch).count(), ms * 1e-3,
+                    (unsigned long long)sb->target.batches, sb->target.bytes / 1e9);
+        return AH_OK;
+    }
 
     // Emit per tree in post-order (children before parents: the order TmpNodes::put receives them,
     // src/writer.rs:1235-1258), with forest-local indices.  Trees are independent: the number of nodes of every tree
@@ -3266,13 +3516,17 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     touch_normals[0].join();  // (the last level started the commit of a level that never came)
     touch_normals[1].join();
     // (the head-room of the blob stays mapped: untouched pages cost nothing, and the pool hands the whole blob to the next build)
+    forest->stats.host_blob_recycled += (forest->normals_blob.committed ? 1u : 0u) + (forest->desc_blob.committed ? 1u : 0u);
+    forest->stats.seconds_after_device += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop_end).count();
     if (timing) {
         const auto t_end = std::chrono::steady_clock::now();
         auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
-        fprintf(stderr, "[ah] batch of %u trees: levels %.3f s (device %.3f), emit %.3f s, read-back still in flight after it "
-                        "%.3f s (%.2f GB normals, %.2f GB ids)\n",
-                n_trees, sec(t_batch, t_levels), ms * 1e-3, sec(t_levels, t_emitted), sec(t_emitted, t_end),
-                normals_bytes / 1e9, M * 4 / 1e9);
+        fprintf(stderr, "[ah] batch of %u trees: levels %.3f s (device %.3f; after the last launch: ids' pages %.3f, stream %.3f, last "
+                        "digest %.3f), emit %.3f s, read-back still in flight after it %.3f s (%.2f GB normals%s, %.2f GB ids%s)\n",
+                n_trees, sec(t_batch, t_levels), ms * 1e-3, sec(t_loop_end, t_tail_prefault), sec(t_tail_prefault, t_tail_sync),
+                sec(t_tail_sync, t_levels), sec(t_levels, t_emitted), sec(t_emitted, t_end), normals_bytes / 1e9,
+                forest->normals_blob.committed ? ", recycled pages" : "", M * 4 / 1e9,
+                forest->desc_blob.committed ? ", recycled pages" : "");
     }
     return AH_OK;
 }
@@ -3280,7 +3534,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
 extern "C" {
 
 static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, const uint32_t *subset_ids,
-                             const uint64_t *subset_offsets, ah_forest **out) {
+                             const uint64_t *subset_offsets, ah_forest **out, StreamBuild *sb = nullptr) {
     AH_REQUIRE(out, AH_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     AH_REQUIRE(ds && options, AH_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -3307,7 +3561,7 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
     int st = AH_OK;
     if (!subset_ids && ds->n <= split_after) {
         // fit_in_descendant at the root (src/writer.rs:1183-1188): every tree is one Descendants node
-        const uint64_t total = ds->n * options->n_trees;
+        const uint64_t total = sb ? ds->n : ds->n * options->n_trees;  // (streaming: one copy of the id list serves every tree)
         if (!host_blob_reserve(forest->desc_blob, total * 4, 0)) {
             delete forest;
             set_error("host allocation failed");
@@ -3315,7 +3569,32 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
         }
         forest->descendants = reinterpret_cast<uint32_t *>(forest->desc_blob.p);
         forest->descendants_len = total;
-        for (uint32_t t = 0; t < options->n_trees; t++) {
+        if (sb) {
+            for (uint64_t i = 0; i < ds->n; i++) forest->descendants[i] = ds->identity_ids ? (uint32_t)i : ds->h_ids[i];
+            for (uint32_t t = 0; t < options->n_trees && st == AH_OK; t++) {
+                ah_stream_node sn{};
+                sn.id = t;
+                sn.tree = t;
+                sn.kind = AH_NODE_DESCENDANTS;
+                sn.count = (uint32_t)ds->n;
+                ah_node_batch batch{};
+                batch.kind = AH_NODE_DESCENDANTS;
+                batch.n_nodes = 1;
+                batch.nodes = &sn;
+                batch.payload = reinterpret_cast<const uint8_t *>(forest->descendants);
+                batch.payload_len = ds->n * 4;
+                batch.normal_stride = forest->normal_stride;
+                batch.normal_header_offset = forest->normal_header_offset;
+                const int rc = sb->target.sink(sb->target.user, &batch);
+                if (rc != 0) {
+                    set_error("node sink asked to stop (code %d)", rc);
+                    st = AH_ERR_CANCELLED;
+                }
+                sb->roots[t] = t;
+                forest->stats.descendant_nodes++;
+            }
+        }
+        for (uint32_t t = 0; t < options->n_trees && !sb; t++) {
             for (uint64_t i = 0; i < ds->n; i++)
                 forest->descendants[t * ds->n + i] = ds->identity_ids ? (uint32_t)i : ds->h_ids[i];
             ah_node nd{};
@@ -3351,7 +3630,7 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
             try {
                 for (uint32_t first = 0; first < options->n_trees && st == AH_OK; first += batch)
                     st = build_batch(ds, options, first, std::min(batch, options->n_trees - first), split_after, forest,
-                                     lease.c, subset_ids, subset_offsets);
+                                     lease.c, subset_ids, subset_offsets, sb);
             } catch (const std::bad_alloc &) {
                 set_error("host allocation failed during the forest build");
                 st = AH_ERR_OUT_OF_MEMORY;
@@ -3369,6 +3648,22 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
 
 int ah_build_forest(ah_dataset *ds, const ah_build_options *options, ah_forest **out) {
     return build_forest_impl(ds, options, nullptr, nullptr, out);
+}
+
+// The same build with the node sink inside it (include/arroy_hip.h, "Streaming build"): nothing is materialised.
+int ah_build_forest_stream(ah_dataset *ds, const ah_build_options *options, ah_node_batch_fn sink, void *user,
+                           uint32_t *out_roots, ah_build_stats *out_stats) {
+    AH_REQUIRE(sink, AH_ERR_INVALID_ARGUMENT, "sink is NULL");
+    AH_REQUIRE(options && (out_roots || options->n_trees == 0), AH_ERR_INVALID_ARGUMENT, "NULL argument");
+    StreamBuild sb;
+    sb.target.sink = sink;
+    sb.target.user = user;
+    sb.roots = out_roots;
+    ah_forest *forest = nullptr;
+    const int st = build_forest_impl(ds, options, nullptr, nullptr, &forest, &sb);
+    if (st == AH_OK && out_stats) *out_stats = forest->stats;
+    delete forest;
+    return st;
 }
 
 // `incremental_index_large_descendant` (src/writer.rs:660-739) for many descendants at once: tree t of the result is

@@ -232,6 +232,42 @@ class Dataset:
                 watcher_stop.set()
         return Forest(h, self.distance, self.dimensions)
 
+    def build_forest_stream(self, tree_seeds: Sequence[int], sink=None, split_after: int = 0, margin_mode: int = 0,
+                            max_trees_in_flight: int = 0, max_host_threads: int = 0):
+        """ah_build_forest_stream: the node sink DURING the build (`TmpNodes::put`, src/parallel.rs:130-147).  `sink(batch)`
+        receives every `_lib.AhNodeBatch` (valid only during the call; return non-zero to stop the build); with sink=None the
+        batches are collected into a `StreamedForest`.  Returns (roots, stats, collected or None)."""
+        seeds = np.ascontiguousarray(tree_seeds, dtype=np.uint64)
+        opt = _lib.AhBuildOptions()
+        opt.n_trees = seeds.size
+        opt.split_after = int(split_after)
+        opt.tree_seeds = seeds.ctypes.data_as(C.POINTER(C.c_uint64))
+        opt.margin_mode = int(margin_mode)
+        opt.max_trees_in_flight = int(max_trees_in_flight)
+        opt.max_host_threads = int(max_host_threads)
+        collected = StreamedForest(self.distance, self.dimensions) if sink is None else None
+        fn = collected.take if sink is None else sink
+        failure = []
+
+        def _cb(_user, batch_p):
+            try:
+                return int(fn(batch_p.contents) or 0)
+            except BaseException as e:  # noqa: BLE001 — nothing may unwind through the C frames
+                failure.append(e)
+                return -1
+        cb = _lib.NODE_BATCH_FN(_cb)
+        roots = np.zeros(seeds.size, dtype=np.uint32)
+        st = _lib.AhBuildStats()
+        code = _lib.lib().ah_build_forest_stream(self._h, C.byref(opt), cb, None, _ptr(roots), C.byref(st))
+        if failure:
+            raise failure[0]
+        _lib.check(code)
+        stats = {f: getattr(st, f) for f, _ in _lib.AhBuildStats._fields_}
+        stats["margin_mode_launches"] = list(st.margin_mode_launches)
+        if collected is not None:
+            collected.roots = roots
+        return roots, stats, collected
+
     def build_subtrees(self, id_lists: Sequence[Sequence[int]], tree_seeds: Sequence[int], split_after: int = 0) -> "Forest":
         """`incremental_index_large_descendant` for many item subsets at once (ah_build_subtrees)."""
         seeds = np.ascontiguousarray(tree_seeds, dtype=np.uint64)
@@ -347,6 +383,48 @@ class Index:
             self.close()
         except Exception:
             pass
+
+
+class StreamedForest:
+    """What a sink of ah_build_forest_stream has seen, kept as dictionaries (test aid: small forests)."""
+
+    def __init__(self, distance, dimensions):
+        self.distance, self.dimensions = distance, dimensions
+        self.splits, self.leaves, self.roots = {}, {}, None
+        self.batches = []  # (kind, level, n_nodes, payload_len) in arrival order
+
+    def take(self, b) -> int:
+        n = int(b.n_nodes)
+        self.batches.append((int(b.kind), int(b.level), n, int(b.payload_len)))
+        payload = np.ctypeslib.as_array(b.payload, shape=(int(b.payload_len),)) if b.payload_len else np.zeros(0, np.uint8)
+        hs, vs = self.distance.header_size(), self.distance.vector_size(self.dimensions)
+        for i in range(n):
+            nd = b.nodes[i]
+            assert nd.kind == b.kind and nd.id not in self.splits and nd.id not in self.leaves
+            off = int(nd.payload_offset)
+            if nd.kind == 2:
+                nb = None
+                if nd.has_normal:
+                    rec = payload[off: off + int(b.normal_stride)]
+                    h = rec[int(b.normal_header_offset): int(b.normal_header_offset) + hs]
+                    v = rec[int(b.normal_vector_offset): int(b.normal_vector_offset) + vs]
+                    nb = h.tobytes() + v.tobytes()  # the canonical form of Forest.canonical / the oracle: [header][vector]
+                self.splits[int(nd.id)] = (nb, int(nd.left), int(nd.right), int(nd.tree), int(nd.depth), int(nd.count))
+            else:
+                ids = payload[off: off + 4 * int(nd.count)].view(np.uint32)
+                self.leaves[int(nd.id)] = (tuple(int(x) for x in ids), int(nd.tree), int(nd.depth))
+        return 0
+
+    def canonical(self, tree: int):
+        import sys
+        sys.setrecursionlimit(100000)
+
+        def rec(i):
+            if i in self.leaves:
+                return ("D", self.leaves[i][0])
+            nb, left, right = self.splits[i][:3]
+            return ("S", nb, rec(left), rec(right))
+        return rec(int(self.roots[tree]))
 
 
 class Forest:

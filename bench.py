@@ -652,6 +652,9 @@ def build_entry(samples, st):
     return {"seconds": sorted(samples)[len(samples) // 2], "seconds_samples": samples,
             "seconds_spread": (max(samples) - min(samples)) / min(samples) if samples and min(samples) > 0 else None,
             "seconds_library": st.get("seconds_total"), "seconds_device": st.get("seconds_device"),
+            # outside the kernels (last sample): entry -> first launch, last launch -> return; output blobs recycled from the pool
+            "seconds_setup": st.get("seconds_setup"), "seconds_after_device": st.get("seconds_after_device"),
+            "host_blob_recycled": st.get("host_blob_recycled"),
             "seconds_margin_kernel": ms, "margin_evaluations": st.get("margin_evaluations"),
             "levels": st.get("levels"), "split_nodes": st.get("split_nodes"),
             "margin_effective_gb_per_s": st.get("margin_evaluations", 0) * 4 * DIMS / ms / 1e9 if ms else None,

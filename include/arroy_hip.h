@@ -40,7 +40,8 @@ extern "C" {
                               v4: ah_forest_digest, ah_tuning_set / _get / _reset, ah_debug_launch_coverage,
                                   ah_build_stats.rows_* / screen8_* / screen_unavailable (appended)
                               v5: ah_search_stats / ah_index_search_stats, ah_build_options.max_host_threads (appended),
-                                  ah_host_cache_trim, ah_synth_rows_host */
+                                  ah_host_cache_trim, ah_synth_rows_host, ah_build_forest_stream (the node sink during the
+                                  build), ah_build_stats.seconds_setup / seconds_after_device / host_blob_recycled */
 
 /* every entry point is exported from the shared object (it is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -328,6 +329,10 @@ typedef struct ah_build_stats {
                                      left goes on to the binary16 stage                                                  */
     uint32_t screen_unavailable;  /* the build wanted the screen but its copies could not be allocated: f32 arithmetic  */
     uint32_t reserved0;
+    /* ABI v5: where the wall time outside the kernels went (summed over the batches of the build) */
+    double seconds_setup;         /* entry of a batch -> its first launch (device buffers, pinned memory, host blobs)    */
+    double seconds_after_device;  /* last launch of a batch -> its return (ids' read-back, node list, teardown)          */
+    uint64_t host_blob_recycled;  /* output blobs (normals, ids) taken committed from the pool of destroyed forests     */
 } ah_build_stats;
 
 AH_API int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out);
@@ -345,6 +350,53 @@ typedef int (*ah_node_sink_fn)(void *user, uint32_t tree, uint32_t node, uint8_t
                                uint32_t right, const void *payload, size_t payload_len);
 AH_API int ah_forest_visit(const ah_forest *forest, ah_node_sink_fn sink, void *user);
 AH_API int ah_forest_destroy(ah_forest *forest);
+
+/* ------------------------------------------------------------------------------------------
+ * Streaming build (ABI v5): the node sink DURING the build.  `Writer::build` hands every finished tree node to
+ * `TmpNodes::put` (src/parallel.rs:130-147) and drains the tmp files into LMDB at the end (src/writer.rs:597-607);
+ * nothing in the reference ever needs the whole forest in one piece.  ah_build_forest_stream therefore never
+ * materialises it: the split planes of a level (as soon as the level is final) and the item-id lists (after the last
+ * level) travel device -> pinned ring -> `sink`, batch by batch, while the next levels are computed.  The host keeps
+ * 64 MiB of pinned memory and the node table instead of the 9.4 GB a 10M x 768 x 100-tree forest occupies.
+ *
+ * Order: breadth-first — a split node arrives BEFORE its children (its record names their ids; the reference's ids are
+ * arbitrary too, src/parallel.rs:239-254, and TmpNodes is an append-only log keyed by id).  Descendants nodes arrive
+ * last, in ascending (tree, position) order.  `id`s are unique over the whole call, dense from 0, assigned in creation
+ * order (a node's children are id-consecutive: left, left + 1).  `sink` is called from ONE library thread, one batch at
+ * a time; `nodes` and `payload` are valid only during the call (the payload is the pinned DMA buffer itself: copy or
+ * encode out of it).  A non-zero return stops the build: AH_ERR_CANCELLED.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ah_stream_node {
+    uint32_t id;             /* this node                                                                      */
+    uint32_t tree;           /* tree index inside this build                                                   */
+    uint8_t kind;            /* AH_NODE_SPLIT | AH_NODE_DESCENDANTS                                            */
+    uint8_t has_normal;      /* SPLIT: 0 = `normal: None` (src/writer.rs:1220-1227): no payload                 */
+    uint16_t reserved;
+    uint32_t left, right;    /* SPLIT: ids of the children                                                     */
+    uint32_t count;          /* DESCENDANTS: item ids in the payload; SPLIT: items under the node              */
+    uint32_t depth;
+    uint64_t payload_offset; /* into ah_node_batch.payload.  SPLIT: the normal record (vector at normal_vector_offset,
+                                D::Header at normal_header_offset, as in ah_forest_view); DESCENDANTS: `count` u32 item
+                                ids, ascending                                                                  */
+} ah_stream_node;
+
+typedef struct ah_node_batch {
+    uint32_t kind;           /* all nodes of a batch are of one kind                                           */
+    uint32_t level;          /* SPLIT: depth of the nodes; DESCENDANTS: 0                                      */
+    uint64_t n_nodes;
+    const ah_stream_node *nodes;
+    const uint8_t *payload;
+    uint64_t payload_len;
+    uint64_t normal_stride, normal_vector_offset, normal_header_offset;
+} ah_node_batch;
+
+typedef int (*ah_node_batch_fn)(void *user, const ah_node_batch *batch);
+
+/* `options` as for ah_build_forest.  out_roots: options->n_trees node ids (the roots, in tree order); out_stats may be
+ * NULL.  The forest is the one ah_build_forest builds for the same seeds, node for node (only the numbering differs:
+ * ah_forest_view numbers children before parents). */
+AH_API int ah_build_forest_stream(ah_dataset *ds, const ah_build_options *options, ah_node_batch_fn sink, void *user,
+                                  uint32_t *out_roots, ah_build_stats *out_stats);
 
 /* ------------------------------------------------------------------------------------------
  * Whole search on device (src/reader.rs:317-401): the forest mirrored in HBM next to its dataset, best-first

@@ -69,7 +69,7 @@ def test_search_equals_oracle_at_the_benchmarked_shape_1m_x_1536_dot_20_trees():
             assert st["descent_octet_lds"] == nq and st["descent_wave_small"] + st["descent_wave_big"] == 0, st
         if tiles:  # 1M ids fit the LDS bitmap
             assert st["rerank_tiles"] == nq and st["dedup_flag_bitmap"] == nq and st["fallback_chunks"] == 0, st
-            assert st["tile_visits"] > 20 * nq and st["tile_units_16"] + st["tile_units_8"] > 0 and st["tile_units_4"] > 0, st
+            assert st["tile_visits"] > 5 * nq and st["tile_units_16"] + st["tile_units_8"] > 0 and st["tile_units_4"] > 0, st
         else:
             assert st["rerank_sorted"] == nq and st["dedup_sorted_bitmap"] == nq and st["rerank_tiles"] == 0, st
     for combo in COMBOS[1:]:
