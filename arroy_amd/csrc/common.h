@@ -98,6 +98,7 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
     X(SEARCH_BITMAP, "AH_SEARCH_BITMAP", 1)     /* 0: sort + dedup of the candidates always by the bitonic network */     \
     X(SEARCH_TILES, "AH_SEARCH_TILES", 1)       /* 0: never the leaf-tile re-rank of ah_search_batch */                   \
     X(SEARCH_WAVE, "AH_SEARCH_WAVE", 1)         /* 0: the descent always one octet per query (k_descend) */               \
+    X(SEARCH_SCREEN, "AH_SEARCH_SCREEN", 1)     /* 0: the re-rank of ah_search_batch never screens its candidates (f32 rows for all) */ \
     X(HOST_THREADS, "AH_HOST_THREADS", 8)       /* host threads one build may use at a time for its output path */        \
     X(HOST_CACHE_MB, "AH_HOST_CACHE_MB", 16384) /* committed host memory of destroyed forests kept for the next build */   \
     X(STAGE_THREADS, "AH_STAGE_THREADS", 0)                                                                              \
@@ -315,6 +316,11 @@ int launch_rerank_batch_prepared(const DataView &dv, uint32_t n_queries, const u
 // row-major ("inverted") re-rank of big submissions: policy + the counter scratch it needs (see batch.hip)
 bool batch_invert_wanted(const DataView &dv, uint64_t n_candidates);
 size_t batch_invert_counter_bytes(uint64_t n_rows, uint64_t n_candidates);
+
+// forest.hip: the binary16 shadow of an f32 dataset (+ per-row norms), made once per dataset by whoever needs it first — the
+// certified screens of the forest build (want8: also the int8 copies of its node-major stage) or of the search's re-rank.
+// false: not applicable (1-bit metric, dims < 32) or no memory for it right now.
+bool ensure_screen(ah_dataset *ds, hipStream_t s, bool want8);
 
 // split.hip
 int launch_split_sides(const DataView &dv, const void *d_nvec, const float *d_nhdr, const uint32_t *d_ids, uint64_t n,

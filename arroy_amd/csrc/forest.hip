@@ -626,18 +626,7 @@ __global__ void k_rows_to_ids(uint32_t *perm, uint64_t total, const uint32_t *__
 // Certified binary16 screen (screen_device.h): shadow copies and the screened variants of the three margin kernels.
 // ------------------------------------------------------------------------------------------------
 
-// f32 -> binary16 for the shadow copies: round to nearest even; values that would be binary16 subnormals become 0 (the
-// measured error norm accounts for it), so the screen never depends on how v_dot2c treats subnormal inputs.
-__device__ __forceinline__ _Float16 to_shadow_half(float x) {
-    _Float16 h = (_Float16)x;
-    if (fabsf((float)h) < 6.103515625e-05f) h = (_Float16)0.0f;  // NaN stays NaN, inf stays inf (-> fallback)
-    return h;
-}
-
-// Rows whose largest |x| is below 2^-40 (and not zero) are never decided by a screen: the f32 sums of squares behind the
-// measured norms underflow there (at 1e-23 they collapse to 0 and a bound built from them would let the bias alone decide
-// a Euclidean margin).  Their stats are +inf, i.e. every pair with such a row takes the reference arithmetic.
-constexpr uint32_t kTinyBits = 0x2B800000u;  // 2^-40
+// (to_shadow_half and kTinyBits: screen_device.h — the search's certified top-k screen makes the same copies of its queries)
 
 // rows -> binary16 shadow + per-row stats.  One octet per row, lane j converts elements 32k + 4j .. +3 (8 bytes out).
 __global__ __launch_bounds__(kBlock) void k_shadow_rows(DataView dv, uint16_t *__restrict__ h_rows, uint32_t hpitch,
@@ -1893,7 +1882,9 @@ static uint64_t normal_record_stride(const ah_dataset *ds) {
 // and — NOT remembered, the next build tries again — when the memory for the copies is not available right now (another
 // build's arenas may be live); ah_build_stats.screen_unavailable then says why the build ran in f32 arithmetic only.
 static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force);
-static bool ensure_screen(ah_dataset *ds, hipStream_t s) {
+// (ensure_screen is shared with search.hip: the certified top-k screen of the re-rank uses the same copy)
+namespace ah {
+bool ensure_screen(ah_dataset *ds, hipStream_t s, bool want8) {
     std::lock_guard<std::mutex> lk(ds->mu);
     if (metric_is_bq(ds->metric) || ds->dims < 32 || ds->n == 0) {
         ds->screen_never = true;
@@ -1934,11 +1925,12 @@ static bool ensure_screen(ah_dataset *ds, hipStream_t s) {
         ds->hpitch = hpitch;
         ds->screen_alloc_failed = false;
     }
-    const long long want8 = tun(TUN_SCREEN8);
-    if (want8 != 0 && ds->metric != AH_DOT_PRODUCT && !ds->d_rows_i8 && (!ds->screen8_decided || want8 == 1))
-        (void)ensure_screen8(ds, s, want8 == 1);
+    const long long tun8 = tun(TUN_SCREEN8);
+    if (want8 && tun8 != 0 && ds->metric != AH_DOT_PRODUCT && !ds->d_rows_i8 && (!ds->screen8_decided || tun8 == 1))
+        (void)ensure_screen8(ds, s, tun8 == 1);
     return true;
 }
+}  // namespace ah
 // The int8 copy (rows, one scale per row, one power of two per dimension).  Kept only when it will decide most pairs: the
 // margin of a row against a normal of an unrelated direction is ~ |n||x| / sqrt(dims), the bound ~ |n| |x - x~8| (the
 // normal's two int8 digits make its own error negligible), so the copy is useful while quality = max|y/s - q| sqrt(dims)
@@ -2510,7 +2502,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     }
     // certified binary16 screen: f32 metrics with AVX-tier rows, unless the caller (or AH_SCREEN=0) asks for f32 only
     const auto t_setup_rows = std::chrono::steady_clock::now();
-    const bool screen = !exact_only && !bq && ds->dims >= 32 && ensure_screen(ds, s);
+    const bool screen = !exact_only && !bq && ds->dims >= 32 && ensure_screen(ds, s, true);
     const auto t_setup_screen = std::chrono::steady_clock::now();
     if (!exact_only && !screen && ds->screen_alloc_failed) forest->stats.screen_unavailable = 1;
     ScreenView sv{};
@@ -3613,7 +3605,7 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
             st = AH_ERR_DEVICE;
         } else {
             // the binary16 shadow of the rows is made (once per dataset) before the batch is sized against free memory
-            if (!(options->margin_mode & AH_MARGIN_EXACT_ONLY) && tun(TUN_SCREEN)) (void)ensure_screen(ds, lease.c->stream);
+            if (!(options->margin_mode & AH_MARGIN_EXACT_ONLY) && tun(TUN_SCREEN)) (void)ensure_screen(ds, lease.c->stream, true);
             // Trees in flight: bounded by HBM (per item and tree: 3 permutations + node index + side byte + masks = 18
             // bytes, plus the normals of all levels and their shadow) or by the caller.
             size_t free_b = 0, total_b = 0;

@@ -28,6 +28,18 @@ namespace ah {
 
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
+// f32 -> binary16 for the shadow copies: round to nearest even; values that would be binary16 subnormals become 0 (the
+// measured error norm accounts for it), so the screen never depends on how v_dot2c treats subnormal inputs.
+__device__ __forceinline__ _Float16 to_shadow_half(float x) {
+    _Float16 h = (_Float16)x;
+    if (fabsf((float)h) < 6.103515625e-05f) h = (_Float16)0.0f;  // NaN stays NaN, inf stays inf (-> fallback)
+    return h;
+}
+// Rows whose largest |x| is below 2^-40 (and not zero) are never decided by a screen: the f32 sums of squares behind the
+// measured norms underflow there (at 1e-23 they collapse to 0 and a bound built from them would let the bias alone decide
+// a Euclidean margin).  Their stats are +inf, i.e. every pair with such a row takes the reference arithmetic.
+constexpr uint32_t kTinyBits = 0x2B800000u;  // 2^-40
+
 // 8 halves (16 bytes) x 8 halves -> f32 accumulate: 4 x v_dot2c_f32_f16
 __device__ __forceinline__ float screen_dot8(const uint4 a, const uint4 b, float acc) {
     acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a.x), __builtin_bit_cast(f16x2_t, b.x), acc, false);

@@ -18,6 +18,7 @@
 
 #include "common.h"
 #include "split_device.h"
+#include "screen_device.h"
 
 namespace ah {
 
@@ -49,7 +50,8 @@ struct VisitSink {          // all null / 0: the descent records nothing
 // Words of the per-chunk device block [error bits][counters of ah_search_stats]: which kernel produced a query's candidates,
 // how the leaf tiles were cut.  Proof of the path taken (ah_index_search_stats), never an input of a result.
 enum SearchStatSlot {
-    SS_ERR = 0, SS_WAVE_SMALL, SS_WAVE_BIG, SS_OCTET_LDS, SS_OCTET_GLOBAL, SS_UNITS_16, SS_UNITS_8, SS_UNITS_4, SS_VISITS, SS_WORDS = 16
+    SS_ERR = 0, SS_WAVE_SMALL, SS_WAVE_BIG, SS_OCTET_LDS, SS_OCTET_GLOBAL, SS_UNITS_16, SS_UNITS_8, SS_UNITS_4, SS_VISITS,
+    SS_SCREENED, SS_SURVIVORS, SS_WORDS = 16
 };
 
 struct SearchParams {
@@ -1047,6 +1049,344 @@ __global__ __launch_bounds__(256) void k_leaf_tiles(DataView dv, const uint32_t 
     }
 }
 
+// ---- certified top-k screen of the re-rank (Cosine, DotProduct) ---------------------------------------------------
+// `Reader::nns_by_leaf` needs the `count` smallest (distance, id) of ~10 000 candidates (src/reader.rs:381-399): the VALUE of
+// a distance matters only for the ~1 % that can reach the top.  So the candidates are first evaluated on the binary16 shadow
+// of the rows (half the bytes: the re-rank is bound by the HBM reads of its rows) with the screen dot product
+// s = <q~, x~> and the RIGOROUS bound E >= |s - r| of screen_device.h on its distance to the reference's f32 dot product r
+// (the six 2-norms are measured when the copies are made, gamma covers both accumulations).  The metric's epilogue f
+// (cosine.rs:43-59, dot_product.rs:52-56) is non-increasing in r and every f32 operation in it is monotone, so
+//     L = f(s + E) <= d_ref <= f(s - E) = U          for every candidate.
+// Let T be the k-th smallest U over the (de-duplicated) candidates: at least k candidates have d_ref <= T, so a candidate with
+// L > T cannot be among the k smallest (distance, id) — whatever the ties.  Only the survivors (L <= T: the top k and the few
+// candidates within 2 E of them) are evaluated in the reference's f32 arithmetic, from their f32 rows, and ordered by
+// (OrderedFloat(d), id): the same bits as the unscreened path, by construction and by test (every search test runs both).
+// A non-finite screen value, or more survivors than the selection holds, sends the submission to the exact paths.
+struct ScreenSearch {
+    const uint16_t *rows16;     // n x hpitch halves (ah_dataset::d_rows_h16)
+    float4 max_stats;           // component-wise maximum over the rows of {|x~|, |x - x~|, |x|}, rounded up: the bound built
+                                // from it holds for every row and needs no per-candidate load (inf for a dataset with rows
+                                // too small to be measured: nothing is screened then)
+    float *aux;                 // Cosine: the stored norm of every candidate's row, next to its screen value
+    uint32_t hpitch;
+    float gamma_s, gamma_r;
+    const uint16_t *q16;        // nq x hpitch halves
+    const float4 *qstats;       // per query {|q~|, |q - q~|, |q|}, rounded up
+};
+
+// queries (f32 leaves at qvecs) -> binary16 copies + norms: one wave per query
+__global__ __launch_bounds__(64) void k_queries_h16(const uint8_t *__restrict__ qvecs, uint64_t qstride, uint32_t dims,
+                                                    uint32_t hpitch, uint16_t *__restrict__ q16, float4 *__restrict__ qstats) {
+    const uint32_t q = blockIdx.x;
+    const float *v = reinterpret_cast<const float *>(qvecs + (uint64_t)q * qstride);
+    uint16_t *out = q16 + (uint64_t)q * hpitch;
+    float sa = 0.f, sb = 0.f, sc = 0.f;
+    uint32_t xbits = 0u;
+    for (uint32_t i = threadIdx.x; i < hpitch; i += 64) {
+        const float x = i < dims ? v[i] : 0.0f;
+        const _Float16 h = to_shadow_half(x);
+        const float y = (float)h, d = x - y;
+        sa += y * y;
+        sb += d * d;
+        sc += x * x;
+        xbits = max(xbits, __float_as_uint(x) & 0x7FFFFFFFu);
+        out[i] = __builtin_bit_cast(uint16_t, h);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sa += __shfl_xor(sa, off);
+        sb += __shfl_xor(sb, off);
+        sc += __shfl_xor(sc, off);
+        xbits = max(xbits, (uint32_t)__shfl_xor((int)xbits, off));
+    }
+    if (threadIdx.x == 0) {
+        const float up = 1.0f + (float)(hpitch + 64u) * 1.2e-7f;
+        const bool tiny = xbits != 0u && xbits < kTinyBits;  // squares underflow: the measured norms would lie
+        const float inf = __uint_as_float(0x7F800000u);
+        qstats[q] = tiny ? make_float4(inf, inf, inf, 0.f) : make_float4(sqrtf(sa) * up, sqrtf(sb) * up, sqrtf(sc) * up, 0.f);
+    }
+}
+
+// The leaf tile of k_leaf_tiles on the binary16 copies: R rows x Q queries of screen dot products per octet, any summation
+// order (gamma_s covers it).  The value lands where the f32 tile would put the distance.
+template <int R, int Q, int QO>
+__device__ __forceinline__ void leaf_tile16(const ScreenSearch &ss, const DataView &dv, const uint32_t *__restrict__ leaf_ids,
+                                            uint32_t row_begin, uint32_t n_rows, const Visit *__restrict__ vis, uint32_t n_vis,
+                                            float *__restrict__ dist, uint32_t stride, uint32_t *err) {
+    constexpr uint32_t RO = 8 / QO;
+    const uint32_t j = threadIdx.x & 7u, ow = (threadIdx.x >> 3) & 7u, wave = threadIdx.x >> 6;
+    const uint32_t q_oct = ow % QO, row_oct = wave * RO + ow / QO;
+    const uint32_t steps = ss.hpitch >> 6;
+    const uint4 *q4[Q];
+    uint64_t out[Q];  // index of the pair of (query t, first row of the leaf) in the candidate buffers
+#pragma unroll
+    for (int t = 0; t < Q; t++) {
+        const Visit v = vis[min(q_oct * Q + (uint32_t)t, n_vis - 1)];
+        q4[t] = reinterpret_cast<const uint4 *>(ss.q16 + (uint64_t)v.q * ss.hpitch) + j;
+        out[t] = (uint64_t)v.q * stride + v.pos;
+    }
+    for (uint32_t r0 = row_begin + row_oct * R; r0 < n_rows; r0 += 4 * RO * R) {
+        const uint4 *r4[R];
+        bool missing[R];
+        float xn[R];
+#pragma unroll
+        for (int u = 0; u < R; u++) {
+            const uint64_t row = row_of_id(dv, leaf_ids[min(r0 + u, n_rows - 1)]);
+            missing[u] = row == ~0ull;
+            r4[u] = reinterpret_cast<const uint4 *>(ss.rows16 + (missing[u] ? 0ull : row) * ss.hpitch) + j;
+            xn[u] = ss.aux && !missing[u] ? dv.headers[row] : 0.0f;  // Cosine: the row's stored norm (cosine.rs:21-24)
+        }
+        float acc[R][Q];
+#pragma unroll
+        for (int u = 0; u < R; u++)
+#pragma unroll
+            for (int t = 0; t < Q; t++) acc[u][t] = 0.f;
+        for (uint32_t k = 0; k < steps; k++) {
+            uint4 x[R], y[Q];
+#pragma unroll
+            for (int u = 0; u < R; u++) x[u] = r4[u][k * 8];
+#pragma unroll
+            for (int t = 0; t < Q; t++) y[t] = q4[t][k * 8];
+#pragma unroll
+            for (int u = 0; u < R; u++)
+#pragma unroll
+                for (int t = 0; t < Q; t++) acc[u][t] = screen_dot8(x[u], y[t], acc[u][t]);
+        }
+#pragma unroll
+        for (int u = 0; u < R; u++) {
+#pragma unroll
+            for (int t = 0; t < Q; t++) {
+                const float sdot = octet_sum(acc[u][t]);
+                if (r0 + u >= n_rows || q_oct * Q + (uint32_t)t >= n_vis || j != 0) continue;
+                if (missing[u]) atomicOr(err, 1u);
+                dist[out[t] + r0 + u] = missing[u] ? __uint_as_float(0x7FC00000u) : sdot;
+                if (ss.aux) ss.aux[out[t] + r0 + u] = xn[u];
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch ss, const uint32_t *__restrict__ nns,
+                                                      const Visit *__restrict__ sorted, const TileUnit *__restrict__ units,
+                                                      const uint32_t *__restrict__ n_units_p, float *__restrict__ dist,
+                                                      uint32_t stride, uint32_t *err) {
+    const uint32_t n_units = *n_units_p;
+    for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const TileUnit unit = units[u];
+        const Visit *vis = sorted + unit.first;
+        const uint32_t n_leaf = vis[0].n;
+        const uint32_t n_vis = unit.n_vis, slab = n_vis > 8 ? kTileSlab : 2 * kTileSlab;
+        const uint32_t row_begin = blockIdx.y * slab;
+        if (row_begin >= n_leaf) continue;
+        const uint32_t row_end = min(n_leaf, row_begin + slab);
+        const uint32_t *leaf_ids = nns + (uint64_t)vis[0].q * stride + vis[0].pos;
+#define AH_TILE16(R, Q, QO) leaf_tile16<R, Q, QO>(ss, dv, leaf_ids, row_begin, row_end, vis, n_vis, dist, stride, err)
+        if (n_vis > 8) AH_TILE16(4, 4, 4);
+        else if (n_vis > 4) AH_TILE16(4, 4, 2);
+        else if (n_vis > 2) AH_TILE16(4, 4, 1);
+        else if (n_vis == 2) AH_TILE16(4, 2, 1);
+        else AH_TILE16(8, 1, 1);
+#undef AH_TILE16
+    }
+}
+
+// bounds of the reference distance of one candidate from its screen value (see above)
+// E >= |s - r_ref| for every row of the dataset: screen accumulation, the two quantisations (Cauchy-Schwarz on measured norms,
+// the rows' from their dataset-wide maxima: the bound is monotone in every one), the reference's own rounding
+__device__ __forceinline__ float screened_error(const float4 rs, const float4 qs, float gamma_s, float gamma_r) {
+    return (gamma_s * (qs.x * rs.x) + qs.y * rs.x + qs.z * rs.y + gamma_r * (qs.z * rs.z)) * 1.002f;
+}
+template <int METRIC>
+__device__ __forceinline__ void screened_bounds(float sdot, float e_query, float qn, float xn, float &lo, float &hi) {
+    const float e = e_query + 2.4e-7f * fabsf(sdot) + 1e-30f;  // + the rounding of s -+ E below
+    const float r_lo = sdot - e, r_hi = sdot + e;
+    if (METRIC == AH_DOT_PRODUCT) {  // d = -r (dot_product.rs:52-56)
+        lo = -r_hi;
+        hi = -r_lo;
+    } else {                          // cosine.rs:43-59: non-increasing in r, every f32 step monotone
+        lo = cosine_from_dot(r_hi, qn, xn);
+        hi = cosine_from_dot(r_lo, qn, xn);
+    }
+}
+
+// Selection of k_search_select with the screen in front: `dist_all` holds the SCREEN dot products of the candidates.
+// err bit 2: a non-finite screen value or distance; bit 3: more survivors than kSelectCap.
+template <int METRIC>
+__global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, ScreenSearch ss, const uint32_t *__restrict__ nns,
+                                                                 const float *__restrict__ dist_all, uint32_t stride,
+                                                                 const uint32_t *__restrict__ counts,
+                                                                 const uint32_t *__restrict__ unique, uint32_t k_out,
+                                                                 const uint8_t *__restrict__ qvecs, uint64_t qstride,
+                                                                 const float *__restrict__ qhdrs,
+                                                                 uint32_t *__restrict__ out_ids, float *__restrict__ out_dist,
+                                                                 uint32_t *err) {
+    constexpr uint32_t kBins = 2048, kCap = 1024, kThreads = 1024;
+    __shared__ uint32_t s_hist[kBins];
+    __shared__ uint64_t s_key[kCap];
+    __shared__ uint32_t s_pos[kCap];
+    __shared__ float s_val[kCap];
+    __shared__ uint32_t s_min, s_max, s_wave[kThreads / 64], s_bin, s_n, s_t, s_bad;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = counts[q], kk = min(k_out, unique[q]);
+    const uint32_t *ids = nns + (uint64_t)q * stride;
+    const float *sd = dist_all + (uint64_t)q * stride;
+    for (uint32_t t = kk + tid; t < k_out; t += kThreads) {
+        out_ids[(uint64_t)q * k_out + t] = 0xFFFFFFFFu;
+        out_dist[(uint64_t)q * k_out + t] = __uint_as_float(0xFFFFFFFFu);
+    }
+    if (kk == 0) return;
+    for (uint32_t b = tid; b < kBins; b += kThreads) s_hist[b] = 0;
+    if (tid == 0) {
+        s_min = 0xFFFFFFFFu;
+        s_max = 0u;
+        s_n = 0u;
+        s_t = 0u;
+        s_bad = 0u;
+    }
+    __syncthreads();
+    const float qn = qhdrs[2 * (uint64_t)q];
+    const float e_query = screened_error(ss.max_stats, ss.qstats[q], ss.gamma_s, ss.gamma_r);
+    const float *xns = ss.aux + (METRIC == AH_COSINE ? (uint64_t)q * stride : 0ull);
+    // keys of a candidate: orderable(U) and orderable(L), recomputed in every pass from its screen value (coalesced reads,
+    // no gather: the error bound is one number per query)
+    auto bounds_of = [&](uint32_t g, uint32_t &ukey, uint32_t &lkey) -> bool {
+        if (ids[g] == 0xFFFFFFFFu) return false;
+        const float sdot = sd[g];
+        if (!(fabsf(sdot) <= 3.0e38f)) {  // NaN or inf (a missing item, an overflow in binary16): not this path's business
+            s_bad = 1u;
+            return false;
+        }
+        float lo, hi;
+        screened_bounds<METRIC>(sdot, e_query, qn, METRIC == AH_COSINE ? xns[g] : 0.f, lo, hi);
+        ukey = orderable_key(hi);
+        lkey = orderable_key(lo);
+        return true;
+    };
+    uint32_t lo_k = 0xFFFFFFFFu, hi_k = 0u;
+    for (uint32_t g = tid; g < n; g += kThreads) {
+        uint32_t uk, lk;
+        if (!bounds_of(g, uk, lk)) continue;
+        lo_k = min(lo_k, uk);
+        hi_k = max(hi_k, uk);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo_k = min(lo_k, (uint32_t)__shfl_xor((int)lo_k, off));
+        hi_k = max(hi_k, (uint32_t)__shfl_xor((int)hi_k, off));
+    }
+    if ((tid & 63u) == 0) {
+        atomicMin(&s_min, lo_k);
+        atomicMax(&s_max, hi_k);
+    }
+    __syncthreads();
+    if (s_bad || s_max == 0xFFFFFFFFu) {  // (a NaN bound: a NaN header or norm)
+        if (tid == 0) atomicOr(err, 4u);
+        return;
+    }
+    const uint32_t w_min = s_min;
+    const uint64_t span = (uint64_t)(s_max - w_min) + 1ull;
+    const bool direct = span <= kBins;
+    const uint32_t scale = direct ? 0u : (uint32_t)(((uint64_t)kBins << 32) / span);
+    auto bin_of = [&](uint32_t w) -> uint32_t { return direct ? w - w_min : (uint32_t)(((uint64_t)(w - w_min) * scale) >> 32); };
+    for (uint32_t g = tid; g < n; g += kThreads) {
+        uint32_t uk, lk;
+        if (bounds_of(g, uk, lk)) atomicAdd(&s_hist[bin_of(uk)], 1u);
+    }
+    __syncthreads();
+    {  // the bin that holds the k-th smallest U
+        constexpr uint32_t kPer = kBins / kThreads;
+        uint32_t c[kPer], mine = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; u++) {
+            c[u] = s_hist[tid * kPer + u];
+            mine += c[u];
+        }
+        uint32_t incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if ((int)(tid & 63u) >= off) incl += up;
+        }
+        if ((tid & 63u) == 63u) s_wave[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine;
+        for (uint32_t w = 0; w < (tid >> 6); w++) before += s_wave[w];
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; u++) {
+            if (before < kk && before + c[u] >= kk) s_bin = tid * kPer + u;
+            before += c[u];
+        }
+    }
+    __syncthreads();
+    const uint32_t bin_k = s_bin;
+    // T = the largest U of that bin (>= the k-th smallest U: a valid, slightly generous threshold)
+    uint32_t t_loc = 0u;
+    for (uint32_t g = tid; g < n; g += kThreads) {
+        uint32_t uk, lk;
+        if (bounds_of(g, uk, lk) && bin_of(uk) <= bin_k) t_loc = max(t_loc, uk);
+    }
+    for (int off = 32; off > 0; off >>= 1) t_loc = max(t_loc, (uint32_t)__shfl_xor((int)t_loc, off));
+    if ((tid & 63u) == 0) atomicMax(&s_t, t_loc);
+    __syncthreads();
+    const uint32_t t_key = s_t;
+    for (uint32_t g = tid; g < n; g += kThreads) {
+        uint32_t uk, lk;
+        if (bounds_of(g, uk, lk) && lk <= t_key) {
+            const uint32_t at = atomicAdd(&s_n, 1u);
+            if (at < kCap) s_pos[at] = g;
+        }
+    }
+    __syncthreads();
+    const uint32_t n_sel = s_n;
+    if (n_sel > kCap) {
+        if (tid == 0) atomicOr(err, 8u);
+        return;
+    }
+    if (tid == 0) {
+        atomicAdd(&err[SS_SCREENED], 1u);
+        atomicAdd(&err[SS_SURVIVORS], n_sel);
+    }
+    // the survivors in the reference's arithmetic: one octet per candidate (the f32 row against the f32 query leaf)
+    const uint32_t j = tid & 7u;
+    const float *qf = reinterpret_cast<const float *>(qvecs + (uint64_t)q * qstride);
+    bool bad = false;
+    for (uint32_t e = tid >> 3; e < n_sel; e += kThreads >> 3) {
+        const uint32_t g = s_pos[e], id = ids[g];
+        const uint64_t row = row_of_id(dv, id);
+        const float r = octet_reduce_any<OP_DOT>(dv.rows_f32 + row * dv.pitch, qf, dv.dims, j);
+        const float d = METRIC == AH_COSINE ? cosine_from_dot(r, qn, dv.headers[row]) : -r;
+        if (j == 0) {
+            const uint32_t w = orderable_key(d);
+            if (w > 0xFF7FFFFFu) bad = true;  // +inf / NaN: src/reader.rs:611-621 looks at positions
+            s_key[e] = ((uint64_t)w << 32) | id;
+            s_val[e] = d;
+        }
+    }
+    if (bad) atomicOr(err, 4u);
+    __syncthreads();
+    uint32_t p2 = 64;
+    while (p2 < n_sel) p2 <<= 1;
+    for (uint32_t t = n_sel + tid; t < p2; t += kThreads) s_key[t] = ~0ull;
+    for (uint32_t size = 2; size <= p2; size <<= 1) {
+        for (uint32_t str = size >> 1; str > 0; str >>= 1) {
+            __syncthreads();
+            for (uint32_t t = tid; t < (p2 >> 1); t += kThreads) {
+                const uint32_t a_i = 2 * t - (t & (str - 1)), b_i = a_i + str;
+                const bool up = (a_i & size) == 0;
+                const uint64_t x = s_key[a_i], y = s_key[b_i];
+                if ((x > y) == up) {
+                    s_key[a_i] = y;
+                    s_key[b_i] = x;
+                    const float vx = s_val[a_i];
+                    s_val[a_i] = s_val[b_i];
+                    s_val[b_i] = vx;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < kk; t += kThreads) {
+        out_ids[(uint64_t)q * k_out + t] = (uint32_t)s_key[t];
+        out_dist[(uint64_t)q * k_out + t] = normalized_distance(dv.metric, s_val[t], dv.dims);
+    }
+}
+
 // The k smallest (OrderedFloat(distance), id) of one query's unflagged candidates, ascending, as (id, normalized
 // distance); the slots beyond min(k, unique) are padded with 0xFFFFFFFF / NaN like k_batch_topk_emit does.  Selection as
 // in k_batch_topk_select (batch.hip): 2048 linear bins over the distance words, the bin of the k-th key by a scan, a
@@ -1491,6 +1831,12 @@ int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_ind
     }
 #undef AH_IX
     (void)st;
+    // the binary16 shadow of the rows for the certified top-k screen of the re-rank (made once per dataset; the forest build
+    // of an f32 dataset has usually made it already).  No memory for it = no screen, not an error.
+    if (tun(TUN_SEARCH_SCREEN) != 0 && (ds->metric == AH_COSINE || ds->metric == AH_DOT_PRODUCT) && ds->dims >= 32 && ds->n) {
+        ContextLease lease(ds);
+        if (lease.c) (void)ensure_screen(ds, lease.c->stream, false);
+    }
     ix->nv.metric = ds->metric;
     ix->nv.dims = ds->dims;
     ix->nv.pitch = ds->pitch;
@@ -1527,6 +1873,8 @@ struct ChunkStats {
         s.tile_units_8 += w[SS_UNITS_8];
         s.tile_units_4 += w[SS_UNITS_4];
         s.tile_visits += w[SS_VISITS];
+        s.rerank_screened += w[SS_SCREENED];
+        s.screen_survivors += w[SS_SURVIVORS];
     }
     void commit(ah_index *ix) {
         std::lock_guard<std::mutex> lk(ix->stats_mu);
@@ -1569,6 +1917,10 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                        (ds->metric == AH_EUCLIDEAN || ds->metric == AH_COSINE || ds->metric == AH_DOT_PRODUCT);
     const uint32_t visit_cap = (uint32_t)std::min<uint64_t>((uint64_t)nq * nns_stride, 2u << 20);
     const uint32_t n_leaf_sums = (ix->n_nodes + kLeafScanItems - 1) / kLeafScanItems;
+    // certified top-k screen of the tile re-rank: the binary16 shadow of the rows must exist (ah_index_create makes it)
+    const bool screened = tiles && tun(TUN_SEARCH_SCREEN) != 0 && (ds->metric == AH_COSINE || ds->metric == AH_DOT_PRODUCT) &&
+                          ds->d_rows_h16 != nullptr && ds->d_screen_stats != nullptr;
+    if (screened) dev_bytes += pad(nq * (size_t)ds->hpitch * 2) + pad(nq * sizeof(float4)) + pad(nq * (size_t)nns_stride * 4);
     if (tiles)
         dev_bytes += pad((size_t)visit_cap * sizeof(Visit)) * 2 + pad((size_t)visit_cap * sizeof(TileUnit)) +
                      pad((size_t)ix->n_nodes * 4 + 8) + 2 * pad((size_t)ix->n_nodes * 4) + pad((size_t)n_leaf_sums * 8) + pad(nq * 4);
@@ -1621,6 +1973,18 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         d_leaf_sums = (uint2 *)dtake((size_t)n_leaf_sums * 8);
         d_unique = (uint32_t *)dtake(nq * 4);
     }
+    ScreenSearch ss{};
+    if (screened) {
+        ss.rows16 = ds->d_rows_h16;
+        ss.max_stats = make_float4(ds->screen_max[0], ds->screen_max[1], ds->screen_max[2], 0.0f);
+        ss.aux = ds->metric == AH_COSINE ? (float *)dtake(nq * (size_t)nns_stride * 4) : nullptr;
+        ss.hpitch = ds->hpitch;
+        // accumulation-error factors as in the forest build (forest.hip: build_batch), 4x over the standard model
+        ss.gamma_s = (float)(4.0 * (2.0 * (ds->hpitch / 16) + 8.0) * 5.9604645e-8);
+        ss.gamma_r = (float)(4.0 * ((double)(ds->dims / 32) + 6.0 + 62.0) * 5.9604645e-8);
+        ss.q16 = (const uint16_t *)dtake(nq * (size_t)ds->hpitch * 2);
+        ss.qstats = (const float4 *)dtake(nq * sizeof(float4));
+    }
     float *h_q = (float *)ptake(nq * (size_t)ds->dims * 4);
     uint32_t *h_qrows = (uint32_t *)ptake(nq * 4);
     uint32_t *h_counts = (uint32_t *)ptake(nq * 4);
@@ -1659,6 +2023,9 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     sp.search_k = search_k;
     sp.nns_stride = nns_stride;
     if (queries) AH_TRY(launch_prepare_queries_only(dv, d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
+    if (screened)
+        hipLaunchKernelGGL(k_queries_h16, dim3((unsigned)nq), dim3(64), 0, s, d_qvecs, qstride, ds->dims, ds->hpitch,
+                           const_cast<uint16_t *>(ss.q16), const_cast<float4 *>(ss.qstats));
     // 2. descent: one wave per query, then one octet per query for what that left, queue in LDS
     // (ah_search_batch decides: a filter that keeps under 5 % of the items makes a query pop more nodes than the queues of
     // a wave hold; under a filter the wave descent reads what the filter keeps of every leaf, computed once per submission)
@@ -1701,10 +2068,15 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         hipLaunchKernelGGL((k_leaf_tiles<M>), dim3(2048, tile_slabs), dim3(256), 4 * kRingBytesPerWave, s, dv, d_nns, d_sorted, \
                            d_units, d_n_units, d_qvecs, qstride, d_qhdrs, d_dist, nns_stride, d_err);                       \
     } while (0)
-        switch (ds->metric) {
-        case AH_EUCLIDEAN: AH_TILES(AH_EUCLIDEAN); break;
-        case AH_COSINE: AH_TILES(AH_COSINE); break;
-        default: AH_TILES(AH_DOT_PRODUCT); break;
+        if (screened) {  // the candidates on the binary16 copies first: half the bytes (see k_search_select_screened)
+            hipLaunchKernelGGL(k_leaf_tiles16, dim3(2048, tile_slabs), dim3(256), 0, s, dv, ss, d_nns, d_sorted, d_units, d_n_units,
+                               d_dist, nns_stride, d_err);
+        } else {
+            switch (ds->metric) {
+            case AH_EUCLIDEAN: AH_TILES(AH_EUCLIDEAN); break;
+            case AH_COSINE: AH_TILES(AH_COSINE); break;
+            default: AH_TILES(AH_DOT_PRODUCT); break;
+            }
         }
 #undef AH_TILES
         if (tun(TUN_DEBUG)) {
@@ -1736,8 +2108,15 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
             hipLaunchKernelGGL(k_flag_duplicates_hash, dim3((unsigned)nq), dim3(1024), kHashSlots * 4, s, d_nns, nns_stride, d_counts,
                                d_unique, d_err);
         }
-        hipLaunchKernelGGL(k_search_select, dim3((unsigned)nq), dim3(kSelectThreads), 0, s, dv, d_nns, d_dist, nns_stride, d_counts,
-                           d_unique, (uint32_t)k, d_oi, d_od, d_err);
+        if (screened && ds->metric == AH_COSINE)
+            hipLaunchKernelGGL((k_search_select_screened<AH_COSINE>), dim3((unsigned)nq), dim3(1024), 0, s, dv, ss, d_nns, d_dist,
+                               nns_stride, d_counts, d_unique, (uint32_t)k, d_qvecs, qstride, d_qhdrs, d_oi, d_od, d_err);
+        else if (screened)
+            hipLaunchKernelGGL((k_search_select_screened<AH_DOT_PRODUCT>), dim3((unsigned)nq), dim3(1024), 0, s, dv, ss, d_nns, d_dist,
+                               nns_stride, d_counts, d_unique, (uint32_t)k, d_qvecs, qstride, d_qhdrs, d_oi, d_od, d_err);
+        else
+            hipLaunchKernelGGL(k_search_select, dim3((unsigned)nq), dim3(kSelectThreads), 0, s, dv, d_nns, d_dist, nns_stride, d_counts,
+                               d_unique, (uint32_t)k, d_oi, d_od, d_err);
         // a launch the runtime rejected (dynamic LDS beyond the limit, another architecture) would leave *err = 0 over
         // uninitialised results: such a submission takes the sorted path as well
         const hipError_t launch_err = hipGetLastError();

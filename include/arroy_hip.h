@@ -459,7 +459,11 @@ typedef struct ah_search_stats {
     uint64_t fallback_launch;       /* the runtime rejected a launch of the tile path                                  */
     uint64_t filtered_queries;      /* queries under a candidate filter                                                */
     uint64_t leaf_kept_passes;      /* passes over every Descendants id for |leaf & candidates| (once per filtered call) */
-    uint64_t reserved[4];
+    /* certified top-k screen of the tile re-rank (Cosine / DotProduct): candidates evaluated on the binary16 copy of the
+     * rows first, only those whose proven distance interval reaches the top `count` in f32 */
+    uint64_t rerank_screened;       /* queries whose top-k went through the screen                                      */
+    uint64_t screen_survivors;      /* candidates of those queries evaluated in f32 (the rest: 2 x dims bytes each)     */
+    uint64_t reserved[2];
 } ah_search_stats;
 AH_API int ah_index_search_stats(ah_index *index, ah_search_stats *out, int reset);
 

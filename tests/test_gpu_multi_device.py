@@ -1,0 +1,105 @@
+"""One process, several devices / several concurrent builds: arroy's own shape (`Writer::build` is one process whose tasks
+share ONE ImmutableLeafs, src/writer.rs:530,556-591).  Device d holds a replica and builds the trees t = d (mod N) from its
+own host thread; the forests must be the ones a single device builds, and the caller's current device is never changed.
+The two-device test skips on a one-GPU box (the driver's 8-GPU node runs it); the concurrency test runs everywhere."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from arroy_amd import _lib  # noqa: E402
+from arroy_amd import distances as D  # noqa: E402
+
+
+def current_device() -> int:
+    hip = C.CDLL("libamdhip64.so")
+    d = C.c_int(-1)
+    assert hip.hipGetDevice(C.byref(d)) == 0
+    return d.value
+
+
+def make(n=200_000, dims=128, device=0):
+    from arroy_amd import Dataset
+    ds = Dataset(D.Euclidean, dims, n, device=device)
+    ds.fill_synthetic(7, 2, n)
+    ds.finalize()
+    return ds
+
+
+def build_sharded(replicas, seeds, max_host_threads):
+    """Tree t on replica t mod N, one host thread per replica; returns {tree index: canonical tuple}."""
+    from arroy_amd import shard
+    world = len(replicas)
+    out, errors = {}, []
+
+    def work(rank):
+        try:
+            mine = shard.trees_for_rank(len(seeds), rank, world)
+            f = replicas[rank].build_forest([seeds[t] for t in mine], max_host_threads=max_host_threads)
+            for local, t in enumerate(mine):
+                out[t] = f.canonical(local)
+            f.close()
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors
+    return out
+
+
+def test_concurrent_builds_in_one_process_equal_the_sequential_forest():
+    """Four host threads, four replicas on ONE device, two host threads of budget each: the forest of the single call."""
+    from arroy_amd import shard
+    ds = make()
+    seeds = shard.tree_seeds(42, range(10))
+    whole = ds.build_forest(seeds)
+    want = {t: whole.canonical(t) for t in range(len(seeds))}
+    whole.close()
+    before = current_device()
+    replicas = [ds] + [ds.replicate(0) for _ in range(3)]
+    assert current_device() == before
+    got = build_sharded(replicas, seeds, max_host_threads=2)
+    assert got == want
+    assert current_device() == before
+    for r in replicas[1:]:
+        r.close()
+    ds.close()
+
+
+def test_two_devices_build_disjoint_tree_sets_equal_to_the_one_device_forest():
+    import arroy_amd
+    if arroy_amd.device_count() < 2:
+        pytest.skip("needs two visible devices")
+    from arroy_amd import shard
+    n_dev = min(arroy_amd.device_count(), 8)
+    ds = make()
+    seeds = shard.tree_seeds(42, range(2 * n_dev + 1))
+    whole = ds.build_forest(seeds)
+    want = {t: whole.canonical(t) for t in range(len(seeds))}
+    whole.close()
+    before = current_device()
+    replicas = [ds] + [ds.replicate(d) for d in range(1, n_dev)]
+    assert current_device() == before, "ah_dataset_replicate must put the caller's device back"
+    # the replica answers queries with the source's bits
+    q = np.linspace(-1, 1, 128, dtype=np.float32)
+    assert replicas[-1].distances(query=q).tobytes() == ds.distances(query=q).tobytes()
+    got = build_sharded(replicas, seeds, max_host_threads=2)
+    assert got == want
+    assert current_device() == before
+    # a search on the last device's replica, through an index mirrored there
+    f = replicas[-1].build_forest(seeds[:3])
+    ix = replicas[-1].create_index(f)
+    f0 = ds.build_forest(seeds[:3])
+    ix0 = ds.create_index(f0)
+    qs = np.stack([q, -q])
+    a, b = ix.search(10, queries=qs, raw=True), ix0.search(10, queries=qs, raw=True)
+    assert all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(a, b))
+    for h in (ix, ix0, f, f0):
+        h.close()
+    for r in replicas[1:]:
+        r.close()
+    ds.close()

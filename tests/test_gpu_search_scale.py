@@ -77,6 +77,18 @@ def test_search_equals_oracle_at_the_benchmarked_shape_1m_x_1536_dot_20_trees():
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), combo
     assert_equals_oracle(res[1, 1], oracle, forest, queries, every, count, sk, what="unfiltered")
     assert int(res[1, 1][2].min()) == count
+    # the certified top-k screen of the tile re-rank (binary16 rows first, f32 for the survivors): on by default above
+    index.stats(reset=True)
+    index.search(count, queries=queries, search_k=sk, raw=True)
+    st = index.stats()
+    assert st["rerank_screened"] == nq and count * nq <= st["screen_survivors"] <= 0.2 * sk * nq, st
+    with _lib.tuning(AH_SEARCH_SCREEN=0):
+        index.stats(reset=True)
+        plain = index.search(count, queries=queries, search_k=sk, raw=True)
+        st = index.stats()
+    assert st["rerank_screened"] == 0 and st["rerank_tiles"] == nq, st
+    for a, b in zip(res[1, 1], plain):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "screen off"
     # by_item: the stored leaves (header included) as queries
     items = rng.choice(n, 32, replace=False).astype(np.uint32)
     gi = index.search(count, items=items, search_k=sk, raw=True)
@@ -144,6 +156,14 @@ def test_search_equals_oracle_on_the_headline_index_10m_x_768_cosine_100_trees()
         for a, b in zip(res[1, 1], res[combo]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), combo
     assert_equals_oracle(res[1, 1], oracle, forest, queries, range(nq), count, sk, what="10M unfiltered")
+    index.stats(reset=True)
+    index.search(count, queries=queries, search_k=sk, raw=True)
+    st = index.stats()
+    assert st["rerank_screened"] == nq and count * nq <= st["screen_survivors"] <= 0.2 * sk * nq, st
+    with _lib.tuning(AH_SEARCH_SCREEN=0):
+        plain = index.search(count, queries=queries, search_k=sk, raw=True)
+    for a, b in zip(res[1, 1], plain):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "screen off"
     keep = np.sort(rng.choice(n, n // 2, replace=False)).astype(np.uint32)
     index.stats(reset=True)
     got = index.search(count, queries=queries, search_k=sk, candidates=keep, candidates_sorted=True, raw=True)
