@@ -1086,9 +1086,16 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     const size_t qstride = pad256(ds->row_bytes());
     const size_t kstride = batch_key_stride(std::max<uint32_t>(max_n, 1));
     const size_t inv_bytes = batch_invert_wanted(ds->view(), total) ? batch_invert_counter_bytes(ds->n, total) : 0;
+    // Certified top-k screen (search.hip: k_search_select_screened): Cosine / DotProduct lists long enough for the screen to
+    // pay (the candidates on the binary16 copy of the rows — made by the first call that wants it — and only the few whose
+    // proven distance interval reaches the top k in f32).  Submissions the row-major re-rank takes are left to it.
+    bool screened = tun(TUN_RERANK_SCREEN) != 0 && (ds->metric == AH_COSINE || ds->metric == AH_DOT_PRODUCT) && ds->dims >= 32 &&
+                    inv_bytes == 0 && k <= 256 && total >= 8 * k * nq && !tiles.empty();
+    if (screened) screened = ensure_screen(ds, ctx->stream, false);
+    const size_t screen_bytes = screened ? pad256(nq * (size_t)ds->hpitch * 2) + pad256(nq * 16) + pad256(total * 4) : 0;
     const size_t dev_bytes = pad256(nq * (size_t)ds->dims * 4) + nq * qstride + pad256(nq * 8) + pad256(nq * sizeof(HostSeg)) +
                              pad256(tiles.size() * sizeof(HostTile)) + pad256(total * 4) * 2 + 2 * pad256(nq * kstride * 8) +
-                             pad256(nq * k * 4) * 2 + pad256(inv_bytes) + 4096;
+                             pad256(nq * k * 4) * 2 + pad256(inv_bytes) + screen_bytes + 4096;
     const size_t pin_bytes = pad256(nq * (size_t)ds->dims * 4) + pad256(nq * sizeof(HostSeg)) +
                              pad256(tiles.size() * sizeof(HostTile)) + pad256(total * 4) + pad256(nq * k * 4) * 2 + 4096;
     AH_TRY(ctx->ensure_device(dev_bytes));
@@ -1105,8 +1112,11 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     uint64_t *d_kb = dev.take<uint64_t>(nq * kstride);
     uint32_t *d_oi = dev.take<uint32_t>(nq * k);
     float *d_od = dev.take<float>(nq * k);
-    uint32_t *d_err = dev.take<uint32_t>(1);
+    uint32_t *d_err = dev.take<uint32_t>(16);  // [error bits][counters of the screened selection]
     uint32_t *d_inv = inv_bytes ? dev.take<uint32_t>(inv_bytes / 4) : nullptr;
+    uint16_t *d_q16 = screened ? dev.take<uint16_t>(nq * (size_t)ds->hpitch) : nullptr;
+    float4 *d_qstats = screened ? dev.take<float4>(nq) : nullptr;
+    float *d_aux = screened ? dev.take<float>(total) : nullptr;
     float *h_q = pin.take<float>(nq * (size_t)ds->dims);
     HostSeg *h_segs = pin.take<HostSeg>(nq);
     HostTile *h_tiles = pin.take<HostTile>(tiles.size());
@@ -1128,10 +1138,31 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
         parallel_rows(len, 4, [&](size_t a, size_t b) { memcpy(h_ids + lo + a, ids + base + lo + a, (b - a) * 4); });
         AH_HIP(hipMemcpyAsync(d_ids + lo, h_ids + lo, len * 4, hipMemcpyHostToDevice, s));
     }
-    AH_HIP(hipMemsetAsync(d_err, 0, 4, s));
-    AH_TRY(launch_rerank_batch(ds->view(), d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles,
-                               (uint32_t)tiles.size(), d_ids, d_dist, d_ka, d_kb, kstride, max_n, (uint32_t)k, max_rounds,
-                               d_oi, d_od, d_err, s, total, d_inv));
+    AH_HIP(hipMemsetAsync(d_err, 0, 64, s));
+    if (screened) {
+        AH_TRY(launch_prepare_queries_only(ds->view(), d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
+        AH_TRY(launch_rerank_screened(ds, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, (uint32_t)tiles.size(), tc, d_ids,
+                                      d_dist, d_aux, d_q16, d_qstats, (uint32_t)k, d_oi, d_od, d_err, s));
+        AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipStreamSynchronize(s));
+        if ((*h_err & ~1u) == 0) {
+            AH_TRY(check_err_flags(*h_err, true));
+            memcpy(out_ids, h_oi, nq * k * 4);
+            memcpy(out_distances, h_od, nq * k * 4);
+            return AH_OK;
+        }
+        // a non-finite value, or more survivors than the selection holds: the exact path, from the prepared queries
+        AH_HIP(hipMemsetAsync(d_err, 0, 64, s));
+        AH_TRY(launch_rerank_batch_prepared(ds->view(), (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, (uint32_t)tiles.size(),
+                                            d_ids, d_dist, d_ka, d_kb, kstride, max_n, (uint32_t)k, max_rounds, d_oi, d_od, d_err, s,
+                                            total, d_inv));
+    } else {
+        AH_TRY(launch_rerank_batch(ds->view(), d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles,
+                                   (uint32_t)tiles.size(), d_ids, d_dist, d_ka, d_kb, kstride, max_n, (uint32_t)k, max_rounds,
+                                   d_oi, d_od, d_err, s, total, d_inv));
+    }
     AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
     AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
     AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));

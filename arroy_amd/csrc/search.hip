@@ -1062,6 +1062,13 @@ __global__ __launch_bounds__(256) void k_leaf_tiles(DataView dv, const uint32_t 
 // candidates within 2 E of them) are evaluated in the reference's f32 arithmetic, from their f32 rows, and ordered by
 // (OrderedFloat(d), id): the same bits as the unscreened path, by construction and by test (every search test runs both).
 // A non-finite screen value, or more survivors than the selection holds, sends the submission to the exact paths.
+struct PairSeg {   // candidate list of one query of ah_rerank_batch: ids[off, off + n), k = min(count, n)  (api.hip: HostSeg)
+    uint64_t off;
+    uint32_t n, k;
+};
+struct PairTile {  // kPairTile candidates of one list, starting at `first`  (api.hip: HostTile)
+    uint32_t query, first;
+};
 struct ScreenSearch {
     const uint16_t *rows16;     // n x hpitch halves (ah_dataset::d_rows_h16)
     float4 max_stats;           // component-wise maximum over the rows of {|x~|, |x - x~|, |x|}, rounded up: the bound built
@@ -1188,6 +1195,45 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
     }
 }
 
+// Screen values of the candidate lists of ah_rerank_batch: one block per tile of a list, the query's binary16 copy in LDS, one
+// octet per candidate gathers its binary16 row (2 x dims bytes instead of the 4 x dims of k_batch_distances_f32).
+__global__ __launch_bounds__(256) void k_pairs_screen16(DataView dv, ScreenSearch ss, const PairSeg *__restrict__ segs,
+                                                        const PairTile *__restrict__ tiles, uint32_t tile_candidates,
+                                                        const uint32_t *__restrict__ ids, float *__restrict__ dist, uint32_t *err) {
+    extern __shared__ uint4 s_q4[];  // hpitch / 8
+    const PairTile tl = tiles[blockIdx.x];
+    const PairSeg seg = segs[tl.query];
+    const uint4 *g_q4 = reinterpret_cast<const uint4 *>(ss.q16 + (uint64_t)tl.query * ss.hpitch);
+    for (uint32_t i = threadIdx.x; i < (ss.hpitch >> 3); i += blockDim.x) s_q4[i] = g_q4[i];
+    __syncthreads();
+    const uint32_t j = threadIdx.x & 7u, steps = ss.hpitch >> 6;
+    const uint32_t end = min(seg.n, tl.first + tile_candidates);
+    for (uint32_t c = tl.first + (threadIdx.x >> 3); c < end; c += blockDim.x >> 3) {
+        const uint64_t row = row_of_id(dv, ids[seg.off + c]);
+        const bool missing = row == ~0ull;
+        const uint4 *r4 = reinterpret_cast<const uint4 *>(ss.rows16 + (missing ? 0ull : row) * ss.hpitch) + j;
+        float a0 = 0.f, a1 = 0.f;
+        uint32_t k = 0;
+        for (; k + 8 <= steps; k += 8) {
+            uint4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = ld_stream_u4(r4 + (k + u) * 8);
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                a0 = screen_dot8(s_q4[(k + u) * 8 + j], x[u], a0);
+                a1 = screen_dot8(s_q4[(k + u + 1) * 8 + j], x[u + 1], a1);
+            }
+        }
+        for (; k < steps; k++) a0 = screen_dot8(s_q4[k * 8 + j], ld_stream_u4(r4 + k * 8), a0);
+        const float sdot = octet_sum(a0 + a1);
+        if (j == 0) {
+            if (missing) atomicOr(err, 1u);
+            dist[seg.off + c] = missing ? __uint_as_float(0x7FC00000u) : sdot;
+            if (ss.aux) ss.aux[seg.off + c] = missing ? 0.0f : dv.headers[row];
+        }
+    }
+}
+
 // bounds of the reference distance of one candidate from its screen value (see above)
 // E >= |s - r_ref| for every row of the dataset: screen accumulation, the two quantisations (Cauchy-Schwarz on measured norms,
 // the rows' from their dataset-wide maxima: the bound is monotone in every one), the reference's own rounding
@@ -1217,7 +1263,7 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
                                                                  const uint8_t *__restrict__ qvecs, uint64_t qstride,
                                                                  const float *__restrict__ qhdrs,
                                                                  uint32_t *__restrict__ out_ids, float *__restrict__ out_dist,
-                                                                 uint32_t *err) {
+                                                                 uint32_t *err, const PairSeg *__restrict__ segs) {
     constexpr uint32_t kBins = 2048, kCap = 1024, kThreads = 1024;
     __shared__ uint32_t s_hist[kBins];
     __shared__ uint64_t s_key[kCap];
@@ -1225,9 +1271,11 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
     __shared__ float s_val[kCap];
     __shared__ uint32_t s_min, s_max, s_wave[kThreads / 64], s_bin, s_n, s_t, s_bad;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
-    const uint32_t n = counts[q], kk = min(k_out, unique[q]);
-    const uint32_t *ids = nns + (uint64_t)q * stride;
-    const float *sd = dist_all + (uint64_t)q * stride;
+    // candidates of query q: a slot of `stride` entries (ah_search_batch), or a segment of the caller's lists (ah_rerank_batch)
+    const uint64_t first = segs ? segs[q].off : (uint64_t)q * stride;
+    const uint32_t n = segs ? segs[q].n : counts[q], kk = segs ? min(k_out, segs[q].k) : min(k_out, unique[q]);
+    const uint32_t *ids = nns + first;
+    const float *sd = dist_all + first;
     for (uint32_t t = kk + tid; t < k_out; t += kThreads) {
         out_ids[(uint64_t)q * k_out + t] = 0xFFFFFFFFu;
         out_dist[(uint64_t)q * k_out + t] = __uint_as_float(0xFFFFFFFFu);
@@ -1244,11 +1292,11 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
     __syncthreads();
     const float qn = qhdrs[2 * (uint64_t)q];
     const float e_query = screened_error(ss.max_stats, ss.qstats[q], ss.gamma_s, ss.gamma_r);
-    const float *xns = ss.aux + (METRIC == AH_COSINE ? (uint64_t)q * stride : 0ull);
+    const float *xns = ss.aux + (METRIC == AH_COSINE ? first : 0ull);
     // keys of a candidate: orderable(U) and orderable(L), recomputed in every pass from its screen value (coalesced reads,
     // no gather: the error bound is one number per query)
     auto bounds_of = [&](uint32_t g, uint32_t &ukey, uint32_t &lkey) -> bool {
-        if (ids[g] == 0xFFFFFFFFu) return false;
+        if (!segs && ids[g] == 0xFFFFFFFFu) return false;  // (a flagged duplicate of the search; a caller's list may hold that id)
         const float sdot = sd[g];
         if (!(fabsf(sdot) <= 3.0e38f)) {  // NaN or inf (a missing item, an overflow in binary16): not this path's business
             s_bad = 1u;
@@ -1649,6 +1697,43 @@ __global__ void k_unpack_normals(const uint8_t *__restrict__ recs, const uint64_
         rows[(uint64_t)r * row_words32 + i] = i < valid_words32 ? src[i] : 0u;
     if (threadIdx.x < hf)
         headers[(uint64_t)r * hf + threadIdx.x] = reinterpret_cast<const float *>(recs + offsets[r] + hdr_off)[threadIdx.x];
+}
+
+// The certified top-k screen for the candidate lists of ah_rerank_batch (api.hip): screen values of every (query, candidate)
+// pair from the binary16 rows, then per query the survivors in f32 and their order.  The queries are already prepared
+// (d_qvecs / d_qhdrs).  d_q16 / d_qstats / d_aux: scratch of nq x hpitch halves, nq float4, and (Cosine) one float per candidate.
+// err bits as k_search_select_screened: the caller redoes the submission on the exact path when 4 or 8 is raised.
+int launch_rerank_screened(ah_dataset *ds, uint32_t nq, const uint8_t *d_qvecs, uint64_t qstride, const float *d_qhdrs,
+                           const void *d_segs, const void *d_tiles, uint32_t n_tiles, uint32_t tile_candidates,
+                           const uint32_t *d_ids, float *d_dist, float *d_aux, uint16_t *d_q16, float4 *d_qstats, uint32_t k_out,
+                           uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s) {
+    const DataView dv = ds->view();
+    ScreenSearch ss{};
+    ss.rows16 = ds->d_rows_h16;
+    ss.max_stats = make_float4(ds->screen_max[0], ds->screen_max[1], ds->screen_max[2], 0.0f);
+    ss.aux = ds->metric == AH_COSINE ? d_aux : nullptr;
+    ss.hpitch = ds->hpitch;
+    ss.gamma_s = (float)(4.0 * (2.0 * (ds->hpitch / 16) + 8.0) * 5.9604645e-8);
+    ss.gamma_r = (float)(4.0 * ((double)(ds->dims / 32) + 6.0 + 62.0) * 5.9604645e-8);
+    ss.q16 = d_q16;
+    ss.qstats = d_qstats;
+    hipLaunchKernelGGL(k_queries_h16, dim3(nq), dim3(64), 0, s, d_qvecs, qstride, ds->dims, ds->hpitch, d_q16, d_qstats);
+    const size_t sh = (size_t)ds->hpitch * 2;
+    if (sh > 48 * 1024)
+        AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pairs_screen16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    if (n_tiles)
+        hipLaunchKernelGGL(k_pairs_screen16, dim3(n_tiles), dim3(256), sh, s, dv, ss, reinterpret_cast<const PairSeg *>(d_segs),
+                           reinterpret_cast<const PairTile *>(d_tiles), tile_candidates, d_ids, d_dist, d_err);
+    if (ds->metric == AH_COSINE)
+        hipLaunchKernelGGL((k_search_select_screened<AH_COSINE>), dim3(nq), dim3(1024), 0, s, dv, ss, d_ids, d_dist, 0u,
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, k_out, d_qvecs, qstride, d_qhdrs, d_out_ids,
+                           d_out_dist, d_err, reinterpret_cast<const PairSeg *>(d_segs));
+    else
+        hipLaunchKernelGGL((k_search_select_screened<AH_DOT_PRODUCT>), dim3(nq), dim3(1024), 0, s, dv, ss, d_ids, d_dist, 0u,
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, k_out, d_qvecs, qstride, d_qhdrs, d_out_ids,
+                           d_out_dist, d_err, reinterpret_cast<const PairSeg *>(d_segs));
+    AH_HIP(hipGetLastError());
+    return AH_OK;
 }
 
 }  // namespace ah
@@ -2110,10 +2195,10 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         }
         if (screened && ds->metric == AH_COSINE)
             hipLaunchKernelGGL((k_search_select_screened<AH_COSINE>), dim3((unsigned)nq), dim3(1024), 0, s, dv, ss, d_nns, d_dist,
-                               nns_stride, d_counts, d_unique, (uint32_t)k, d_qvecs, qstride, d_qhdrs, d_oi, d_od, d_err);
+                               nns_stride, d_counts, d_unique, (uint32_t)k, d_qvecs, qstride, d_qhdrs, d_oi, d_od, d_err, (const PairSeg *)nullptr);
         else if (screened)
             hipLaunchKernelGGL((k_search_select_screened<AH_DOT_PRODUCT>), dim3((unsigned)nq), dim3(1024), 0, s, dv, ss, d_nns, d_dist,
-                               nns_stride, d_counts, d_unique, (uint32_t)k, d_qvecs, qstride, d_qhdrs, d_oi, d_od, d_err);
+                               nns_stride, d_counts, d_unique, (uint32_t)k, d_qvecs, qstride, d_qhdrs, d_oi, d_od, d_err, (const PairSeg *)nullptr);
         else
             hipLaunchKernelGGL(k_search_select, dim3((unsigned)nq), dim3(kSelectThreads), 0, s, dv, d_nns, d_dist, nns_stride, d_counts,
                                d_unique, (uint32_t)k, d_oi, d_od, d_err);
