@@ -106,6 +106,8 @@ void Context::destroy() {
     for (hipEvent_t &e : ev_ring)
         if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    copy_stream = nullptr;
     d_scratch = h_pinned = d_filter = nullptr;
     d_cap = h_cap = d_filter_cap = 0;
     stream = nullptr;
@@ -1131,18 +1133,75 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     AH_HIP(hipMemcpyAsync(d_qf32, h_q, nq * (size_t)ds->dims * 4, hipMemcpyHostToDevice, s));
     AH_HIP(hipMemcpyAsync(d_segs, h_segs, nq * sizeof(HostSeg), hipMemcpyHostToDevice, s));
     if (!tiles.empty()) AH_HIP(hipMemcpyAsync(d_tiles, h_tiles, tiles.size() * sizeof(HostTile), hipMemcpyHostToDevice, s));
+    AH_HIP(hipMemsetAsync(d_err, 0, 64, s));
     // candidate ids: tens of MB for a big submission.  Slices of 2M ids are copied into the pinned buffer by several
     // cores (like the staging gather) and sent right away, so the DMA of one slice overlaps the host copy of the next.
+    const uint64_t n_groups = (uint64_t)std::max<long long>(1, tun(TUN_RERANK_GROUPS));
+    const bool pipelined = screened && n_groups > 1 && total >= (512u << 10);
+    if (pipelined && !ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->copy_stream = nullptr;
+    }
+    if (pipelined && ctx->copy_stream) {
+        // The screened path takes the lists group by group: while the screen kernel of group g runs on the context's stream,
+        // the host copies the ids of group g + 1 into the pinned buffer and the copy stream sends them (review item 6: the
+        // upload of a submission used to run to its end before the first kernel started).
+        AH_TRY(launch_prepare_queries_only(ds->view(), d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
+        const uint64_t group_ids = (total + n_groups - 1) / n_groups;
+        size_t qa = 0;
+        uint32_t ta = 0;
+        bool first = true;
+        while (qa < nq) {
+            size_t qb = qa + 1;
+            while (qb < nq && segs[qb].off + segs[qb].n - segs[qa].off <= group_ids) qb++;
+            const uint64_t lo = segs[qa].off, len = segs[qb - 1].off + segs[qb - 1].n - lo;
+            uint32_t tb = ta;
+            while (tb < tiles.size() && tiles[tb].query < qb) tb++;
+            if (len) {
+                parallel_rows(len, 4, [&](size_t a, size_t b) { memcpy(h_ids + lo + a, ids + base + lo + a, (b - a) * 4); });
+                AH_HIP(hipMemcpyAsync(d_ids + lo, h_ids + lo, len * 4, hipMemcpyHostToDevice, ctx->copy_stream));
+                AH_HIP(hipEventRecord(ctx->ev0, ctx->copy_stream));
+                AH_HIP(hipStreamWaitEvent(s, ctx->ev0, 0));
+            }
+            AH_TRY(launch_rerank_screened(ds, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, ta, tb - ta, tc, d_ids, d_dist,
+                                          d_aux, d_q16, d_qstats, (uint32_t)k, d_oi, d_od, d_err, s, first, qb == nq));
+            first = false;
+            qa = qb;
+            ta = tb;
+        }
+        AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipStreamSynchronize(s));
+        if ((*h_err & ~1u) == 0) {
+            AH_TRY(check_err_flags(*h_err, true));
+            memcpy(out_ids, h_oi, nq * k * 4);
+            memcpy(out_distances, h_od, nq * k * 4);
+            return AH_OK;
+        }
+        // a non-finite value, or more survivors than the selection holds: the exact path, from the prepared queries
+        AH_HIP(hipMemsetAsync(d_err, 0, 64, s));
+        AH_TRY(launch_rerank_batch_prepared(ds->view(), (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, (uint32_t)tiles.size(),
+                                            d_ids, d_dist, d_ka, d_kb, kstride, max_n, (uint32_t)k, max_rounds, d_oi, d_od, d_err, s,
+                                            total, d_inv));
+        AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipStreamSynchronize(s));
+        AH_TRY(check_err_flags(*h_err, true));
+        memcpy(out_ids, h_oi, nq * k * 4);
+        memcpy(out_distances, h_od, nq * k * 4);
+        return AH_OK;
+    }
     for (uint64_t lo = 0; lo < total; lo += (2u << 20)) {
         const uint64_t len = std::min<uint64_t>(2u << 20, total - lo);
         parallel_rows(len, 4, [&](size_t a, size_t b) { memcpy(h_ids + lo + a, ids + base + lo + a, (b - a) * 4); });
         AH_HIP(hipMemcpyAsync(d_ids + lo, h_ids + lo, len * 4, hipMemcpyHostToDevice, s));
     }
-    AH_HIP(hipMemsetAsync(d_err, 0, 64, s));
     if (screened) {
         AH_TRY(launch_prepare_queries_only(ds->view(), d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
-        AH_TRY(launch_rerank_screened(ds, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, (uint32_t)tiles.size(), tc, d_ids,
-                                      d_dist, d_aux, d_q16, d_qstats, (uint32_t)k, d_oi, d_od, d_err, s));
+        AH_TRY(launch_rerank_screened(ds, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, 0u, (uint32_t)tiles.size(), tc, d_ids,
+                                      d_dist, d_aux, d_q16, d_qstats, (uint32_t)k, d_oi, d_od, d_err, s, true, true));
         AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));

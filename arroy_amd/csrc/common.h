@@ -98,6 +98,7 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
     X(SEARCH_BITMAP, "AH_SEARCH_BITMAP", 1)     /* 0: sort + dedup of the candidates always by the bitonic network */     \
     X(SEARCH_TILES, "AH_SEARCH_TILES", 1)       /* 0: never the leaf-tile re-rank of ah_search_batch */                   \
     X(SEARCH_WAVE, "AH_SEARCH_WAVE", 1)         /* 0: the descent always one octet per query (k_descend) */               \
+    X(RERANK_GROUPS, "AH_RERANK_GROUPS", 2)     /* groups a screened ah_rerank_batch submission is cut into (upload of group g + 1 under the kernel of g) */ \
     X(RERANK_SCREEN, "AH_RERANK_SCREEN", 1)     /* 0: ah_rerank_batch never screens its candidates (f32 rows for all) */ \
     X(SEARCH_SCREEN, "AH_SEARCH_SCREEN", 1)     /* 0: the re-rank of ah_search_batch never screens its candidates (f32 rows for all) */ \
     X(HOST_THREADS, "AH_HOST_THREADS", 8)       /* host threads one build may use at a time for its output path */        \
@@ -186,6 +187,7 @@ struct ScreenView {
 // One per concurrently calling host thread: a stream plus growable device / pinned scratch.
 struct Context {
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // uploads that run under the kernels of `stream` (created on first use)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_ring[4] = {nullptr, nullptr, nullptr, nullptr};  // staging ring (created on first use)
     void *d_scratch = nullptr;
@@ -324,10 +326,12 @@ size_t batch_invert_counter_bytes(uint64_t n_rows, uint64_t n_candidates);
 bool ensure_screen(ah_dataset *ds, hipStream_t s, bool want8);
 
 // search.hip: the certified top-k screen for the candidate lists of ah_rerank_batch (binary16 rows first, f32 for the survivors)
+// (tile_first .. tile_first + n_tiles: the tiles this call screens — the caller may launch the lists group by group while the
+// ids of the next group are still on their way; select = also run the per-query selection, i.e. this was the last group)
 int launch_rerank_screened(ah_dataset *ds, uint32_t nq, const uint8_t *d_qvecs, uint64_t qstride, const float *d_qhdrs,
-                           const void *d_segs, const void *d_tiles, uint32_t n_tiles, uint32_t tile_candidates,
+                           const void *d_segs, const void *d_tiles, uint32_t tile_first, uint32_t n_tiles, uint32_t tile_candidates,
                            const uint32_t *d_ids, float *d_dist, float *d_aux, uint16_t *d_q16, float4 *d_qstats, uint32_t k_out,
-                           uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s);
+                           uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s, bool first, bool select);
 
 // split.hip
 int launch_split_sides(const DataView &dv, const void *d_nvec, const float *d_nhdr, const uint32_t *d_ids, uint64_t n,

@@ -1704,9 +1704,9 @@ __global__ void k_unpack_normals(const uint8_t *__restrict__ recs, const uint64_
 // (d_qvecs / d_qhdrs).  d_q16 / d_qstats / d_aux: scratch of nq x hpitch halves, nq float4, and (Cosine) one float per candidate.
 // err bits as k_search_select_screened: the caller redoes the submission on the exact path when 4 or 8 is raised.
 int launch_rerank_screened(ah_dataset *ds, uint32_t nq, const uint8_t *d_qvecs, uint64_t qstride, const float *d_qhdrs,
-                           const void *d_segs, const void *d_tiles, uint32_t n_tiles, uint32_t tile_candidates,
+                           const void *d_segs, const void *d_tiles, uint32_t tile_first, uint32_t n_tiles, uint32_t tile_candidates,
                            const uint32_t *d_ids, float *d_dist, float *d_aux, uint16_t *d_q16, float4 *d_qstats, uint32_t k_out,
-                           uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s) {
+                           uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s, bool first, bool select) {
     const DataView dv = ds->view();
     ScreenSearch ss{};
     ss.rows16 = ds->d_rows_h16;
@@ -1717,13 +1717,17 @@ int launch_rerank_screened(ah_dataset *ds, uint32_t nq, const uint8_t *d_qvecs, 
     ss.gamma_r = (float)(4.0 * ((double)(ds->dims / 32) + 6.0 + 62.0) * 5.9604645e-8);
     ss.q16 = d_q16;
     ss.qstats = d_qstats;
-    hipLaunchKernelGGL(k_queries_h16, dim3(nq), dim3(64), 0, s, d_qvecs, qstride, ds->dims, ds->hpitch, d_q16, d_qstats);
+    if (first) hipLaunchKernelGGL(k_queries_h16, dim3(nq), dim3(64), 0, s, d_qvecs, qstride, ds->dims, ds->hpitch, d_q16, d_qstats);
     const size_t sh = (size_t)ds->hpitch * 2;
     if (sh > 48 * 1024)
         AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pairs_screen16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     if (n_tiles)
         hipLaunchKernelGGL(k_pairs_screen16, dim3(n_tiles), dim3(256), sh, s, dv, ss, reinterpret_cast<const PairSeg *>(d_segs),
-                           reinterpret_cast<const PairTile *>(d_tiles), tile_candidates, d_ids, d_dist, d_err);
+                           reinterpret_cast<const PairTile *>(d_tiles) + tile_first, tile_candidates, d_ids, d_dist, d_err);
+    if (!select) {
+        AH_HIP(hipGetLastError());
+        return AH_OK;
+    }
     if (ds->metric == AH_COSINE)
         hipLaunchKernelGGL((k_search_select_screened<AH_COSINE>), dim3(nq), dim3(1024), 0, s, dv, ss, d_ids, d_dist, 0u,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, k_out, d_qvecs, qstride, d_qhdrs, d_out_ids,

@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Regenerates arroy-hip.patch: the call-site changes of the `hip` feature as a unified diff against arroy v0.7.0
+(/root/reference), made by editing a scratch copy of the five touched files and diffing — so the committed patch always
+applies (`git apply --check`, tests/test_integration_patch.py) and never drifts from the edits listed here.
+
+    python integration/arroy-hip/make_patch.py [/path/to/arroy] > integration/arroy-hip/arroy-hip.patch
+"""
+import difflib
+import os
+import sys
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+
+EDITS = {
+    "Cargo.toml": [(
+        """# Enabling this feature provide a method on the reader that assert its own validity.
+assert-reader-validity = []
+""",
+        """# Enabling this feature provide a method on the reader that assert its own validity.
+assert-reader-validity = []
+
+# The hot loops (item staging, the forest build, the candidate re-rank) on an AMD MI355X through libarroy_hip.so
+# (`extern "C"`, src/hip.rs).  Link with RUSTFLAGS="-L <dir of libarroy_hip.so>".
+hip = []
+""")],
+    "src/lib.rs": [(
+        """mod error;
+mod item_iter;
+""",
+        """mod error;
+#[cfg(feature = "hip")]
+mod hip;
+mod item_iter;
+""")],
+    "src/parallel.rs": [(
+        """    /// Returns the leafs identified by the given ID.
+    pub fn get(&self, item_id: ItemId) -> heed::Result<Option<Leaf<'t, D>>> {
+        let len = match self.constant_length {
+""",
+        """    /// The stored records `[tag][header][vector]` of `items`, ascending: their ids, the pointers into the LMDB pages
+    /// and their (constant) length — what `hip::stage_leafs` copies into HBM.
+    #[cfg(feature = "hip")]
+    pub(crate) fn raw_records(&self, items: &RoaringBitmap) -> (Vec<ItemId>, Vec<*const u8>, usize) {
+        let mut ids = Vec::with_capacity(items.len() as usize);
+        let mut ptrs = Vec::with_capacity(items.len() as usize);
+        for item_id in items {
+            if let Some(ptr) = self.leafs.get(&item_id) {
+                ids.push(item_id);
+                ptrs.push(*ptr);
+            }
+        }
+        (ids, ptrs, self.constant_length.unwrap_or(0))
+    }
+
+    /// Returns the leafs identified by the given ID.
+    pub fn get(&self, item_id: ItemId) -> heed::Result<Option<Leaf<'t, D>>> {
+        let len = match self.constant_length {
+""")],
+    "src/writer.rs": [(
+        """        for _ in 0..nb_missing_trees {
+            progress.fetch_add(1, Ordering::Relaxed);
+            let new_id = concurrent_node_ids.next()?;
+            roots.push(new_id);
+            descendants.insert(new_id, item_indices.clone());
+        }
+""",
+        """        // With the `hip` feature the missing trees are built on the GPU: the items are staged once from their LMDB
+        // pages, every tree node comes back through the streaming sink WHILE the device builds the levels below it and is
+        // appended to this thread's `TmpNodes` (drained into LMDB below, with the files of the rayon tasks).
+        #[cfg(feature = "hip")]
+        let nb_missing_trees = if nb_missing_trees > 0 {
+            let staged = crate::hip::stage_leafs(&leafs, &item_indices, self.dimensions, self.index, 0, true)?;
+            let tmp_node = files_tls.get_or_try(|| match self.tmpdir.as_ref() {
+                Some(path) => TmpNodes::new_in(path).map(RefCell::new),
+                None => TmpNodes::new().map(RefCell::new),
+            })?;
+            let new_roots = crate::hip::build_new_trees(
+                &staged,
+                rng,
+                options,
+                nb_missing_trees as usize,
+                &concurrent_node_ids,
+                &mut tmp_node.borrow_mut(),
+            )?;
+            progress.fetch_add(nb_missing_trees, Ordering::Relaxed);
+            roots.extend(new_roots);
+            0
+        } else {
+            nb_missing_trees
+        };
+
+        for _ in 0..nb_missing_trees {
+            progress.fetch_add(1, Ordering::Relaxed);
+            let new_id = concurrent_node_ids.next()?;
+            roots.push(new_id);
+            descendants.insert(new_id, item_indices.clone());
+        }
+""")],
+    "src/reader.rs": [(
+        """        let mut nns_distances = Vec::with_capacity(nns.len());
+        for nn in nns {
+""",
+        """        // With the `hip` feature and a staged copy of the items (`Reader::stage_on_gpu`) the distance loop, the top-k
+        // and `normalized_distance` are one call: `(item, distance)` pairs in the same order, with the same bits.
+        #[cfg(feature = "hip")]
+        if let Some(staged) = self.hip.as_ref() {
+            let query: Vec<f32> = query_leaf.vector.iter().collect();
+            return staged.rerank(&query, &nns, opt.count);
+        }
+
+        let mut nns_distances = Vec::with_capacity(nns.len());
+        for nn in nns {
+"""), (
+        """    version: Version,
+    _marker: marker::PhantomData<D>,
+}
+
+impl<'t, D: Distance> Reader<'t, D> {
+""",
+        """    version: Version,
+    /// The items in HBM (`hip` feature): set by `Reader::stage_on_gpu`.
+    #[cfg(feature = "hip")]
+    hip: Option<Box<dyn crate::hip::Rerank + Send + Sync + 't>>,
+    _marker: marker::PhantomData<D>,
+}
+
+impl<'t, D: Distance> Reader<'t, D> {
+"""), (
+        """            items: metadata.items,
+            version,
+            _marker: marker::PhantomData,
+        })
+    }
+""",
+        """            items: metadata.items,
+            version,
+            #[cfg(feature = "hip")]
+            hip: None,
+            _marker: marker::PhantomData,
+        })
+    }
+
+    /// Copies the items into the memory of GPU `device` (`hip` feature): from then on `nns_by_vector` / `nns_by_item`
+    /// re-rank their candidates there.  The pointers into the LMDB pages are only used during this call.
+    #[cfg(feature = "hip")]
+    pub fn stage_on_gpu(&mut self, rtxn: &'t RoTxn, device: i32) -> Result<()>
+    where
+        D: 't,
+    {
+        let options = crate::writer::BuildOption::default();
+        let leafs =
+            crate::parallel::ImmutableLeafs::new(rtxn, &options, self.database, &self.items, self.index)?;
+        let staged =
+            crate::hip::stage_leafs(&leafs, &self.items, self.dimensions, self.index, device, true)?;
+        self.hip = Some(Box::new(staged));
+        Ok(())
+    }
+""")],
+}
+
+
+def main():
+    out = []
+    for rel, edits in EDITS.items():
+        old = open(os.path.join(REF, rel)).read()
+        new = old
+        for before, after in edits:
+            if new.count(before) != 1:
+                sys.exit(f"{rel}: the anchor of an edit occurs {new.count(before)} times in the reference (expected once):\n{before}")
+            new = new.replace(before, after)
+        out += difflib.unified_diff(old.splitlines(keepends=True), new.splitlines(keepends=True), f"a/{rel}", f"b/{rel}")
+    sys.stdout.write("".join(out))
+
+
+if __name__ == "__main__":
+    main()

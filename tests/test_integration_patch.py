@@ -1,0 +1,62 @@
+"""integration/arroy-hip: the Rust side of the drop-in as FILES (review item 9).  It cannot be compiled in this image (no
+cargo / rustc), but it can be kept applicable and in sync with the C header: the patch must `git apply --check` against
+the reference, be exactly what its generator produces, and `src/hip.rs` must bind only symbols the header declares, with
+struct fields in the header's order."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+REF = "/root/reference"
+HERE = os.path.join(ROOT, "integration", "arroy-hip")
+
+
+def header():
+    return open(os.path.join(ROOT, "include", "arroy_hip.h")).read()
+
+
+def rust():
+    return open(os.path.join(HERE, "src", "hip.rs")).read()
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="the reference checkout is not on this machine")
+def test_patch_applies_to_the_reference_and_matches_its_generator():
+    patch = os.path.join(HERE, "arroy-hip.patch")
+    out = subprocess.run([sys.executable, os.path.join(HERE, "make_patch.py"), REF], capture_output=True, text=True, check=True)
+    assert out.stdout == open(patch).read(), "arroy-hip.patch is stale: python integration/arroy-hip/make_patch.py > arroy-hip.patch"
+    chk = subprocess.run(["git", "apply", "--check", "--verbose", patch], cwd=REF, capture_output=True, text=True)
+    assert chk.returncode == 0, chk.stderr
+    touched = set(re.findall(r"^\+\+\+ b/(\S+)", open(patch).read(), re.M))
+    assert touched == {"Cargo.toml", "src/lib.rs", "src/parallel.rs", "src/writer.rs", "src/reader.rs"}
+
+
+def test_rust_bindings_name_only_declared_symbols():
+    declared = set(re.findall(r"^AH_API [^;(]*?\b(ah_[a-z_0-9]+)\s*\(", header(), re.M))
+    block = rust().split('extern "C" {', 1)[1].split("\n}\n", 1)[0]
+    bound = set(re.findall(r"fn (ah_[a-z_0-9]+)\(", block))
+    assert bound and bound <= declared, bound - declared
+    assert "AH_ABI_VERSION: c_int = " + re.search(r"#define AH_ABI_VERSION (\d+)", header()).group(1) in rust()
+
+
+@pytest.mark.parametrize("c_name,rust_name", [("ah_build_options", "AhBuildOptions"), ("ah_stream_node", "AhStreamNode"),
+                                              ("ah_node_batch", "AhNodeBatch"), ("ah_error_detail", "AhErrorDetail")])
+def test_repr_c_structs_follow_the_header(c_name, rust_name):
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (c_name, c_name), header(), re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    rs = re.search(r"pub struct %s \{(.*?)\n\}" % rust_name, rust(), re.S).group(1)
+    rs_fields = re.findall(r"pub (\w+):", rs)
+    # a C declaration `uint32_t left, right;` lists two fields: compare flattened name sequences
+    flat = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(",")
+        first = re.findall(r"(\w+)\s*$", names[0].replace("*", " "))[0]
+        flat.append(first)
+        flat += [re.sub(r"[\*\s]", "", x) for x in names[1:]]
+    assert rs_fields == flat, (rs_fields, flat)
