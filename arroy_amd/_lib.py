@@ -162,6 +162,7 @@ SIGNATURES = {
     "ah_forest_stats": (C.c_int, [_VP, C.POINTER(AhBuildStats)]),
     "ah_forest_digest": (C.c_int, [_VP, _U64P, C.POINTER(C.c_uint64)]),
     "ah_host_cache_trim": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "ah_device_cache_trim": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     "ah_synth_rows_host": (C.c_int, [C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _F32P]),
     "ah_tuning_set": (C.c_int, [C.c_char_p, C.c_int64]),
     "ah_tuning_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
@@ -266,6 +267,13 @@ def host_cache_trim() -> int:
     """ah_host_cache_trim: give the recycled host blobs of destroyed forests back to the system; returns the bytes released."""
     out = C.c_uint64(0)
     check(lib().ah_host_cache_trim(C.byref(out)))
+    return int(out.value)
+
+
+def device_cache_trim(device: int = -1) -> int:
+    """ah_device_cache_trim: give the idle HBM blocks of the caching allocator back to the driver; returns the bytes released."""
+    out = C.c_uint64(0)
+    check(lib().ah_device_cache_trim(int(device), C.byref(out)))
     return int(out.value)
 
 

@@ -68,10 +68,10 @@ int Context::ensure_device(size_t bytes) {
     if (bytes <= d_cap) return AH_OK;
     size_t cap = std::max(bytes + bytes / 4, d_cap * 2);  // headroom: similar-sized submissions must not regrow
     cap = (cap + 4095) & ~(size_t)4095;
-    if (d_scratch) AH_HIP(hipFree(d_scratch));
+    if (d_scratch) AH_HIP(dev_free(d_scratch));
     d_scratch = nullptr;
     d_cap = 0;
-    AH_HIP(hipMalloc(&d_scratch, cap));
+    AH_HIP(dev_malloc(&d_scratch, cap));
     d_cap = cap;
     return AH_OK;
 }
@@ -90,16 +90,150 @@ int Context::ensure_filter(size_t bytes) {
     if (bytes <= d_filter_cap) return AH_OK;
     size_t cap = std::max(bytes + bytes / 4, d_filter_cap * 2);
     cap = (cap + 4095) & ~(size_t)4095;
-    if (d_filter) AH_HIP(hipFree(d_filter));
+    if (d_filter) AH_HIP(dev_free(d_filter));
     d_filter = nullptr;
     d_filter_cap = 0;
-    AH_HIP(hipMalloc(&d_filter, cap));
+    AH_HIP(dev_malloc(&d_filter, cap));
     d_filter_cap = cap;
     return AH_OK;
 }
+// ---- caching device allocator (common.h) ------------------------------------------------------------------------------
+namespace {
+struct DevBlock {
+    void *p;
+    size_t bytes;
+    int device;
+};
+std::mutex g_dev_mu;
+std::vector<DevBlock> g_dev_idle;                     // blocks nobody uses, oldest first
+std::vector<DevBlock> g_dev_live;                     // blocks handed out (few hundred at most: a linear scan is fine)
+size_t g_dev_idle_bytes = 0;
+inline size_t dev_round(size_t bytes) {  // whole 2 MiB for the big blocks (what the driver maps anyway), 4 KiB below
+    const size_t g = bytes >= (1u << 20) ? (2u << 20) : 4096u;
+    return (std::max<size_t>(bytes, 1) + g - 1) / g * g;
+}
+}  // namespace
+
+size_t dev_cache_trim(int device) {
+    std::vector<DevBlock> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        for (size_t i = 0; i < g_dev_idle.size();) {
+            if (device < 0 || g_dev_idle[i].device == device) {
+                drop.push_back(g_dev_idle[i]);
+                g_dev_idle_bytes -= g_dev_idle[i].bytes;
+                g_dev_idle.erase(g_dev_idle.begin() + (ptrdiff_t)i);
+            } else {
+                i++;
+            }
+        }
+    }
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    size_t bytes = 0;
+    for (const DevBlock &b : drop) {
+        (void)hipSetDevice(b.device);
+        (void)hipFree(b.p);
+        bytes += b.bytes;
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return bytes;
+}
+
+size_t dev_cache_idle_bytes(int device) {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    size_t n = 0;
+    for (const DevBlock &b : g_dev_idle)
+        if (b.device == device) n += b.bytes;
+    return n;
+}
+
+hipError_t dev_malloc(void **p, size_t bytes) {
+    *p = nullptr;
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    const size_t want = dev_round(bytes);
+    const bool caching = tun(TUN_DEVICE_CACHE_MB) > 0;
+    if (caching) {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        size_t best = g_dev_idle.size();
+        for (size_t i = 0; i < g_dev_idle.size(); i++) {
+            const DevBlock &b = g_dev_idle[i];
+            // a block of the size asked for, or a little larger (never one that would strand more than an eighth)
+            if (b.device == device && b.bytes >= want && b.bytes - want <= std::max<size_t>(want / 8, 2u << 20) &&
+                (best == g_dev_idle.size() || b.bytes < g_dev_idle[best].bytes))
+                best = i;
+        }
+        if (best != g_dev_idle.size()) {
+            const DevBlock b = g_dev_idle[best];
+            g_dev_idle.erase(g_dev_idle.begin() + (ptrdiff_t)best);
+            g_dev_idle_bytes -= b.bytes;
+            g_dev_live.push_back(b);
+            *p = b.p;
+            return hipSuccess;
+        }
+    }
+    void *q = nullptr;
+    e = hipMalloc(&q, want);
+    if (e != hipSuccess && dev_cache_trim(device) > 0) {  // out of memory with idle blocks on the shelf: give them back, retry
+        (void)hipGetLastError();
+        e = hipMalloc(&q, want);
+    }
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        g_dev_live.push_back(DevBlock{q, want, device});
+    }
+    *p = q;
+    return hipSuccess;
+}
+
+hipError_t dev_free(void *p) {
+    if (!p) return hipSuccess;
+    DevBlock blk{nullptr, 0, 0};
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        for (size_t i = 0; i < g_dev_live.size(); i++)
+            if (g_dev_live[i].p == p) {
+                blk = g_dev_live[i];
+                g_dev_live.erase(g_dev_live.begin() + (ptrdiff_t)i);
+                break;
+            }
+    }
+    if (!blk.p) return hipFree(p);  // not ours (cannot happen: every allocation of the library comes from dev_malloc)
+    const size_t limit = (size_t)std::max<long long>(0, tun(TUN_DEVICE_CACHE_MB)) << 20;
+    if (limit == 0) return hipFree(p);
+    // hipFree waits for the device; a cached block must not change hands while a queued kernel may still touch it either
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != blk.device) (void)hipSetDevice(blk.device);
+    const hipError_t e = hipDeviceSynchronize();
+    if (prev >= 0 && prev != blk.device) (void)hipSetDevice(prev);
+    std::vector<DevBlock> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        g_dev_idle.push_back(blk);
+        g_dev_idle_bytes += blk.bytes;
+        while (g_dev_idle_bytes > limit && !g_dev_idle.empty()) {  // over the budget: the oldest go back to the driver
+            drop.push_back(g_dev_idle.front());
+            g_dev_idle_bytes -= g_dev_idle.front().bytes;
+            g_dev_idle.erase(g_dev_idle.begin());
+        }
+    }
+    for (const DevBlock &b : drop) {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != b.device) (void)hipSetDevice(b.device);
+        (void)hipFree(b.p);
+        if (cur >= 0 && cur != b.device) (void)hipSetDevice(cur);
+    }
+    return e;
+}
+
 void Context::destroy() {
-    if (d_scratch) (void)hipFree(d_scratch);
-    if (d_filter) (void)hipFree(d_filter);
+    if (d_scratch) (void)dev_free(d_scratch);
+    if (d_filter) (void)dev_free(d_filter);
     if (h_pinned) (void)hipHostFree(h_pinned);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
@@ -418,13 +552,13 @@ int ah_dataset_create(int metric, uint32_t dimensions, uint64_t capacity, int de
         if (metric_is_bq(metric)) {
             ds->words = bq_words(dimensions);
             ds->pitch = (ds->words + 1u) & ~1u;  // 16-byte rows
-            e = hipMalloc((void **)&ds->d_rows_bq, cap * ds->pitch * 8);
+            e = dev_malloc((void **)&ds->d_rows_bq, cap * ds->pitch * 8);
         } else {
             ds->pitch = (dimensions + 31u) & ~31u;  // 128-byte rows
-            e = hipMalloc((void **)&ds->d_rows_f32, cap * (uint64_t)ds->pitch * 4);
+            e = dev_malloc((void **)&ds->d_rows_f32, cap * (uint64_t)ds->pitch * 4);
         }
-        if (e == hipSuccess) e = hipMalloc((void **)&ds->d_headers, cap * header_floats(metric) * 4);
-        if (e == hipSuccess) e = hipMalloc((void **)&ds->d_ids, cap * 4);
+        if (e == hipSuccess) e = dev_malloc((void **)&ds->d_headers, cap * header_floats(metric) * 4);
+        if (e == hipSuccess) e = dev_malloc((void **)&ds->d_ids, cap * 4);
         if (e != hipSuccess) {
             set_error("hipMalloc of %llu items x %u dims failed: %s", (unsigned long long)cap, dimensions,
                       hipGetErrorString(e));
@@ -465,17 +599,17 @@ int ah_dataset_destroy(ah_dataset *ds) {
         }
     }
     ds->pool.clear();
-    if (ds->d_rows_h16) (void)hipFree(ds->d_rows_h16);
-    if (ds->d_rows_i8) (void)hipFree(ds->d_rows_i8);
-    if (ds->d_rows_i8_lo) (void)hipFree(ds->d_rows_i8_lo);
-    if (ds->d_scale8_rows) (void)hipFree(ds->d_scale8_rows);
-    if (ds->d_dim_scale) (void)hipFree(ds->d_dim_scale);
-    if (ds->d_screen_stats) (void)hipFree(ds->d_screen_stats);
-    if (ds->d_rows_f32) (void)hipFree(ds->d_rows_f32);
-    if (ds->d_rows_bq) (void)hipFree(ds->d_rows_bq);
-    if (ds->d_headers) (void)hipFree(ds->d_headers);
-    if (ds->d_ids) (void)hipFree(ds->d_ids);
-    if (ds->d_lut) (void)hipFree(ds->d_lut);
+    if (ds->d_rows_h16) (void)dev_free(ds->d_rows_h16);
+    if (ds->d_rows_i8) (void)dev_free(ds->d_rows_i8);
+    if (ds->d_rows_i8_lo) (void)dev_free(ds->d_rows_i8_lo);
+    if (ds->d_scale8_rows) (void)dev_free(ds->d_scale8_rows);
+    if (ds->d_dim_scale) (void)dev_free(ds->d_dim_scale);
+    if (ds->d_screen_stats) (void)dev_free(ds->d_screen_stats);
+    if (ds->d_rows_f32) (void)dev_free(ds->d_rows_f32);
+    if (ds->d_rows_bq) (void)dev_free(ds->d_rows_bq);
+    if (ds->d_headers) (void)dev_free(ds->d_headers);
+    if (ds->d_ids) (void)dev_free(ds->d_ids);
+    if (ds->d_lut) (void)dev_free(ds->d_lut);
     delete ds;
     return AH_OK;
 }
@@ -761,7 +895,7 @@ int ah_dataset_finalize(ah_dataset *ds) {
     } else {
         const uint64_t span = (uint64_t)ds->last_id + 1;
         if (span <= 8 * ds->n + (1u << 20)) {  // dense table; otherwise kernels binary-search the id array
-            AH_HIP(hipMalloc((void **)&ds->d_lut, span * 4));
+            AH_HIP(dev_malloc((void **)&ds->d_lut, span * 4));
             ds->lut_len = (uint32_t)span;
             AH_TRY(launch_build_lut(ds->d_ids, ds->n, ds->d_lut, ds->lut_len, ctx->stream));
             AH_HIP(hipStreamSynchronize(ctx->stream));
@@ -826,7 +960,7 @@ int ah_dataset_replicate(ah_dataset *src, int device, ah_dataset **out) {
             if (e == hipSuccess) e = hipMemcpyPeerAsync(dst->d_ids, device, src->d_ids, src->device, src->n * 4, s);
         }
         if (e == hipSuccess && src->d_lut) {
-            e = hipMalloc((void **)&dst->d_lut, (size_t)src->lut_len * 4);
+            e = dev_malloc((void **)&dst->d_lut, (size_t)src->lut_len * 4);
             if (e == hipSuccess) e = hipMemcpyPeerAsync(dst->d_lut, device, src->d_lut, src->device, (size_t)src->lut_len * 4, s);
             dst->lut_len = src->lut_len;
         }
@@ -1437,8 +1571,8 @@ int ah_bench_memcpy(int device, uint64_t bytes, uint32_t iterations, double *out
         Context &c;
         ~Guard() { c.destroy(); }
     } guard{c};
-    AH_HIP(hipMalloc(&a.p, bytes));
-    AH_HIP(hipMalloc(&b.p, bytes));
+    AH_HIP(dev_malloc(&a.p, bytes));
+    AH_HIP(dev_malloc(&b.p, bytes));
     AH_HIP(hipStreamCreate(&c.stream));
     AH_HIP(hipEventCreate(&c.ev0));
     AH_HIP(hipEventCreate(&c.ev1));
@@ -1463,8 +1597,8 @@ int ah_bench_read(int device, uint64_t bytes, uint32_t iterations, double *out_m
         Context &c;
         ~Guard() { c.destroy(); }
     } guard{c};
-    AH_HIP(hipMalloc(&a.p, bytes));
-    AH_HIP(hipMalloc(&sink.p, 8));
+    AH_HIP(dev_malloc(&a.p, bytes));
+    AH_HIP(dev_malloc(&sink.p, 8));
     AH_HIP(hipStreamCreate(&c.stream));
     AH_HIP(hipEventCreate(&c.ev0));
     AH_HIP(hipEventCreate(&c.ev1));

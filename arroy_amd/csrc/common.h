@@ -102,6 +102,7 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
     X(RERANK_SCREEN, "AH_RERANK_SCREEN", 1)     /* 0: ah_rerank_batch never screens its candidates (f32 rows for all) */ \
     X(SEARCH_SCREEN, "AH_SEARCH_SCREEN", 1)     /* 0: the re-rank of ah_search_batch never screens its candidates (f32 rows for all) */ \
     X(HOST_THREADS, "AH_HOST_THREADS", 8)       /* host threads one build may use at a time for its output path */        \
+    X(DEVICE_CACHE_MB, "AH_DEVICE_CACHE_MB", 196608) /* idle HBM the caching allocator keeps instead of returning it to the driver */ \
     X(HOST_CACHE_MB, "AH_HOST_CACHE_MB", 16384) /* committed host memory of destroyed forests kept for the next build */   \
     X(STAGE_THREADS, "AH_STAGE_THREADS", 0)                                                                              \
     X(STAGE_MEMCPY, "AH_STAGE_MEMCPY", 0)                                                                                \
@@ -129,6 +130,23 @@ inline void parallel_run(unsigned n, F fn) {
     for (unsigned t = started; t < n; t++) fn(t);
     for (auto &th : pool) th.join();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Device memory: a caching allocator (api.hip).  HBM that the library has obtained is handed back to the driver only by
+// ah_device_cache_trim or under memory pressure: a build of the 10M x 768 x 100-tree forest takes and returns ~28 GB of
+// scratch, and a hipMalloc that lands on memory the driver is still scrubbing after a hipFree was measured to take a
+// SECOND (r04: the first launch of every second build waited 0.9 - 1.1 s for its buffers).  dev_free keeps hipFree's
+// implicit device synchronisation, so no caller can free a block a queued kernel still uses.
+//   AH_DEVICE_CACHE_MB: most bytes kept idle per process (default 196608; 0 = plain hipMalloc / hipFree).
+// ---------------------------------------------------------------------------------------------
+hipError_t dev_malloc(void **p, size_t bytes);  // on the calling thread's current device
+template <typename T>
+inline hipError_t dev_malloc(T **p, size_t bytes) {
+    return dev_malloc(reinterpret_cast<void **>(p), bytes);
+}
+hipError_t dev_free(void *p);
+size_t dev_cache_trim(int device);         // device < 0: every device; returns the bytes given back
+size_t dev_cache_idle_bytes(int device);   // idle bytes cached for `device` (ah_build_forest adds them to hipMemGetInfo's free)
 
 inline bool metric_is_bq(int m) { return m >= AH_BQ_EUCLIDEAN && m <= AH_BQ_COSINE; }
 inline bool metric_valid(int m) { return m >= AH_EUCLIDEAN && m <= AH_BQ_COSINE; }
@@ -260,7 +278,7 @@ struct DevMem {
     DevMem(const DevMem &) = delete;
     DevMem &operator=(const DevMem &) = delete;
     ~DevMem() {
-        if (p) (void)hipFree(p);
+        if (p) (void)dev_free(p);
     }
     template <typename T>
     T *as() const {

@@ -1741,16 +1741,16 @@ struct DevBuf {
     size_t cap = 0;
     int ensure(size_t n) {
         if (n <= cap) return AH_OK;
-        if (p) AH_HIP(hipFree(p));
+        if (p) AH_HIP(dev_free(p));
         p = nullptr;
         cap = 0;
         size_t want = std::max(n, (size_t)1024);
-        AH_HIP(hipMalloc((void **)&p, want * sizeof(T)));
+        AH_HIP(dev_malloc((void **)&p, want * sizeof(T)));
         cap = want;
         return AH_OK;
     }
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p) (void)dev_free(p);
     }
 };
 
@@ -1765,11 +1765,11 @@ struct Arena {
         if (bytes > left) {
             size_t got = std::max(bytes, block_bytes);
             void *p = nullptr;
-            hipError_t e = hipMalloc(&p, got);
+            hipError_t e = dev_malloc(&p, got);
             if (e != hipSuccess && got > bytes) {  // tight on memory: exactly this level
                 (void)hipGetLastError();
                 got = bytes;
-                e = hipMalloc(&p, got);
+                e = dev_malloc(&p, got);
             }
             if (e != hipSuccess) {
                 set_error("hipMalloc of %zu bytes of normals failed: %s", bytes, hipGetErrorString(e));
@@ -1785,7 +1785,7 @@ struct Arena {
         return AH_OK;
     }
     ~Arena() {
-        for (void *p : blocks) (void)hipFree(p);
+        for (void *p : blocks) (void)dev_free(p);
     }
 };
 
@@ -1895,10 +1895,10 @@ bool ensure_screen(ah_dataset *ds, hipStream_t s, bool want8) {
         const uint32_t hpitch = (ds->dims + 63u) & ~63u;
         uint16_t *rows = nullptr;
         float4 *stats = nullptr;
-        if (hipMalloc((void **)&rows, ds->n * (size_t)hpitch * 2) != hipSuccess ||
-            hipMalloc((void **)&stats, ds->n * sizeof(float4)) != hipSuccess) {
+        if (dev_malloc((void **)&rows, ds->n * (size_t)hpitch * 2) != hipSuccess ||
+            dev_malloc((void **)&stats, ds->n * sizeof(float4)) != hipSuccess) {
             (void)hipGetLastError();
-            if (rows) (void)hipFree(rows);
+            if (rows) (void)dev_free(rows);
             return false;
         }
         const DataView dv = ds->view();
@@ -1906,19 +1906,19 @@ bool ensure_screen(ah_dataset *ds, hipStream_t s, bool want8) {
         hipLaunchKernelGGL(k_shadow_rows, dim3(grid), dim3(kBlock), 0, s, dv, rows, hpitch, stats);
         uint32_t *d_max = nullptr;
         uint32_t h_max[4] = {0u, 0u, 0u, 0u};
-        bool ok = hipMalloc((void **)&d_max, 16) == hipSuccess && hipMemsetAsync(d_max, 0, 16, s) == hipSuccess;
+        bool ok = dev_malloc((void **)&d_max, 16) == hipSuccess && hipMemsetAsync(d_max, 0, 16, s) == hipSuccess;
         if (ok) {
             hipLaunchKernelGGL(k_stats_max, dim3(1024), dim3(256), 0, s, stats, (uint64_t)ds->n, d_max);
             ok = hipMemcpyAsync(h_max, d_max, 16, hipMemcpyDeviceToHost, s) == hipSuccess;
         }
         if (hipStreamSynchronize(s) != hipSuccess || !ok) {
             (void)hipGetLastError();
-            (void)hipFree(rows);
-            (void)hipFree(stats);
-            if (d_max) (void)hipFree(d_max);
+            (void)dev_free(rows);
+            (void)dev_free(stats);
+            if (d_max) (void)dev_free(d_max);
             return false;
         }
-        (void)hipFree(d_max);
+        (void)dev_free(d_max);
         memcpy(ds->screen_max, h_max, 12);
         ds->d_rows_h16 = rows;
         ds->d_screen_stats = stats;
@@ -1945,14 +1945,14 @@ static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force) {
     uint32_t *d_m = nullptr;  // [pitch8 column maxima][5 row maxima + pad]
     uint32_t h_m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     // the rows' second digit is optional: without the memory for it stage 1 is simply the binary16 row
-    if (tun(TUN_SCREEN8_LO) != 0 && hipMalloc((void **)&rows8_lo, ds->n * (size_t)pitch8) != hipSuccess) {
+    if (tun(TUN_SCREEN8_LO) != 0 && dev_malloc((void **)&rows8_lo, ds->n * (size_t)pitch8) != hipSuccess) {
         (void)hipGetLastError();
         rows8_lo = nullptr;
     }
-    bool ok = hipMalloc((void **)&rows8, ds->n * (size_t)pitch8) == hipSuccess &&
-              hipMalloc((void **)&scales, ds->n * sizeof(float)) == hipSuccess &&
-              hipMalloc((void **)&dimsc, 2 * (size_t)pitch8 * sizeof(float)) == hipSuccess &&
-              hipMalloc((void **)&d_m, ((size_t)pitch8 + 8) * 4) == hipSuccess;
+    bool ok = dev_malloc((void **)&rows8, ds->n * (size_t)pitch8) == hipSuccess &&
+              dev_malloc((void **)&scales, ds->n * sizeof(float)) == hipSuccess &&
+              dev_malloc((void **)&dimsc, 2 * (size_t)pitch8 * sizeof(float)) == hipSuccess &&
+              dev_malloc((void **)&d_m, ((size_t)pitch8 + 8) * 4) == hipSuccess;
     const bool alloc_ok = ok;
     ok = ok && hipMemsetAsync(d_m, 0, ((size_t)pitch8 + 8) * 4, s) == hipSuccess;
     if (ok) {
@@ -1989,12 +1989,12 @@ static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force) {
         if (alloc_ok) ds->screen8_decided = true;  // a device fault, not a lack of memory: do not loop on it
     }
     if (!keep) {
-        if (rows8_lo) (void)hipFree(rows8_lo);
-        if (rows8) (void)hipFree(rows8);
-        if (scales) (void)hipFree(scales);
-        if (dimsc) (void)hipFree(dimsc);
+        if (rows8_lo) (void)dev_free(rows8_lo);
+        if (rows8) (void)dev_free(rows8);
+        if (scales) (void)dev_free(scales);
+        if (dimsc) (void)dev_free(dimsc);
     }
-    if (d_m) (void)hipFree(d_m);
+    if (d_m) (void)dev_free(d_m);
     return keep;
 }
 
@@ -2471,6 +2471,19 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     uint32_t *d_tree_first = reinterpret_cast<uint32_t *>(d_info + 1);
     DevBuf<uint32_t> d_tree_first_buf;  // first node of every tree of the level, gaps closed (LDS variant of the row pass)
     AH_TRY(d_tree_first_buf.ensure((size_t)n_trees + 2));
+    // The control structures start from zeros.  Blocks come from the caching allocator with whatever their last user left in
+    // them, and a CANCELLED level lets its bookkeeping kernels run over tables its drained margin kernels never wrote: with
+    // zeros (what fresh device memory used to hold) those kernels find empty nodes and tiles; with the item indices of
+    // another build in a tile table they would scatter out of bounds.  ~0.7 GB of memsets: 0.2 ms.
+    AH_HIP(hipMemsetAsync(d_nodes_a.p, 0, max_nodes * sizeof(FNode), s));
+    AH_HIP(hipMemsetAsync(d_nodes_b.p, 0, max_nodes * sizeof(FNode), s));
+    AH_HIP(hipMemsetAsync(d_tiles.p, 0, max_tiles * sizeof(FTile), s));
+    AH_HIP(hipMemsetAsync(masks.p, 0, max_tiles * 32 * sizeof(uint64_t), s));
+    AH_HIP(hipMemsetAsync(tile_left.p, 0, max_tiles * 4, s));
+    AH_HIP(hipMemsetAsync(tile_left_off.p, 0, max_tiles * 4, s));
+    AH_HIP(hipMemsetAsync(d_child.p, 0, 2 * max_nodes * 4, s));
+    AH_HIP(hipMemsetAsync(d_block_sums.p, 0, (max_nodes / 256 + 2) * sizeof(NextCounts), s));
+    AH_HIP(hipMemsetAsync(d_tree_first_buf.p, 0, ((size_t)n_trees + 2) * 4, s));
     const auto t_setup_alloc = std::chrono::steady_clock::now();
     uint32_t *d_tree_first_fixed = d_tree_first_buf.p;
     AH_HIP(hipMemsetAsync(d_small.p, 0, (16 + info_words) * 4, s));
@@ -3381,8 +3394,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         std::vector<size_t> cut((size_t)(n_trees + 1) * n_lv, 0), out_at(n_trees + 1, 0);
         for (size_t l = 0; l < n_lv; l++) {
             const auto &lv = stream_leaves[l];
+            // (by tree, not by position: an EMPTY child at the very end of a tree starts where the next tree does)
             for (uint32_t t = 0; t <= n_trees; t++)
-                cut[(size_t)t * n_lv + l] = (size_t)(std::lower_bound(lv.begin(), lv.end(), tree_base[t], [](const LeafRec &r, uint64_t v) { return r.start < v; }) - lv.begin());
+                cut[(size_t)t * n_lv + l] = (size_t)(std::lower_bound(lv.begin(), lv.end(), first_tree + t, [](const LeafRec &r, uint32_t v) { return r.tree < v; }) - lv.begin());
         }
         for (uint32_t t = 0; t < n_trees; t++) {
             size_t c = 0;
@@ -3399,7 +3413,10 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                 for (size_t l = 0; l < n_lv; l++)
                     mine.insert(mine.end(), stream_leaves[l].begin() + (ptrdiff_t)cut[(size_t)t * n_lv + l],
                                 stream_leaves[l].begin() + (ptrdiff_t)cut[(size_t)(t + 1) * n_lv + l]);
-                std::sort(mine.begin(), mine.end(), [](const LeafRec &a, const LeafRec &b) { return a.start < b.start; });
+                // (an empty leaf shares its position with its sibling: it goes first, so that offsets never step back)
+                std::sort(mine.begin(), mine.end(), [](const LeafRec &a, const LeafRec &b) {
+                    return a.start != b.start ? a.start < b.start : a.count < b.count;
+                });
                 ah_stream_node *dst = job->nodes.data() + out_at[t];
                 for (const LeafRec &r : mine) {
                     ah_stream_node sn{};
@@ -3610,6 +3627,7 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
             // bytes, plus the normals of all levels and their shadow) or by the caller.
             size_t free_b = 0, total_b = 0;
             (void)hipMemGetInfo(&free_b, &total_b);
+            free_b += dev_cache_idle_bytes(ds->device);  // idle blocks of the caching allocator are ours to use
             uint32_t batch = options->n_trees;
             if (!subset_ids) {
                 const uint64_t per_tree =
@@ -3801,7 +3819,7 @@ int ah_debug_launch_coverage(int device, int kind, uint64_t n_rows, uint32_t dim
     AH_REQUIRE(out_len >= need, AH_ERR_INVALID_ARGUMENT, "out_counts holds %llu counters, %llu needed", (unsigned long long)out_len,
                (unsigned long long)need);
     DevMem d;
-    AH_HIP(hipMalloc(&d.p, need * 4));
+    AH_HIP(dev_malloc(&d.p, need * 4));
     AH_HIP(hipMemset(d.p, 0, need * 4));
     if (kind == 0) {
         RowsPlan plan;
@@ -3854,6 +3872,12 @@ int ah_forest_visit(const ah_forest *forest, ah_node_sink_fn sink, void *user) {
 
 int ah_forest_destroy(ah_forest *forest) {
     delete forest;
+    return AH_OK;
+}
+
+int ah_device_cache_trim(int device, uint64_t *out_bytes) {
+    const size_t was = dev_cache_trim(device);
+    if (out_bytes) *out_bytes = was;
     return AH_OK;
 }
 

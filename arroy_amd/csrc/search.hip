@@ -1765,11 +1765,11 @@ int ah_index_destroy(ah_index *ix) {
     if (!ix) return AH_OK;
     if (ix->ds) (void)hipSetDevice(ix->ds->device);
     (void)hipDeviceSynchronize();
-    if (ix->d_nodes) (void)hipFree(ix->d_nodes);
-    if (ix->d_roots) (void)hipFree(ix->d_roots);
-    if (ix->d_desc) (void)hipFree(ix->d_desc);
-    if (ix->d_nrows) (void)hipFree(ix->d_nrows);
-    if (ix->d_nhdrs) (void)hipFree(ix->d_nhdrs);
+    if (ix->d_nodes) (void)dev_free(ix->d_nodes);
+    if (ix->d_roots) (void)dev_free(ix->d_roots);
+    if (ix->d_desc) (void)dev_free(ix->d_desc);
+    if (ix->d_nrows) (void)dev_free(ix->d_nrows);
+    if (ix->d_nhdrs) (void)dev_free(ix->d_nhdrs);
     delete ix;
     return AH_OK;
 }
@@ -1897,19 +1897,19 @@ int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_ind
             return fail(_e == hipErrorOutOfMemory ? AH_ERR_OUT_OF_MEMORY : AH_ERR_DEVICE); \
         }                                                                                  \
     } while (0)
-    AH_IX(hipMalloc((void **)&ix->d_nodes, std::max<size_t>(1, nodes.size()) * sizeof(DNode)));
-    AH_IX(hipMalloc((void **)&ix->d_roots, std::max<size_t>(1, v.n_trees) * 4));
-    AH_IX(hipMalloc((void **)&ix->d_desc, std::max<uint64_t>(1, v.descendants_len) * 4));
-    AH_IX(hipMalloc(&ix->d_nrows, std::max<size_t>(1, ix->n_normals) * row_bytes));
-    AH_IX(hipMalloc((void **)&ix->d_nhdrs, std::max<size_t>(1, ix->n_normals) * hf * 4));
+    AH_IX(dev_malloc((void **)&ix->d_nodes, std::max<size_t>(1, nodes.size()) * sizeof(DNode)));
+    AH_IX(dev_malloc((void **)&ix->d_roots, std::max<size_t>(1, v.n_trees) * 4));
+    AH_IX(dev_malloc((void **)&ix->d_desc, std::max<uint64_t>(1, v.descendants_len) * 4));
+    AH_IX(dev_malloc(&ix->d_nrows, std::max<size_t>(1, ix->n_normals) * row_bytes));
+    AH_IX(dev_malloc((void **)&ix->d_nhdrs, std::max<size_t>(1, ix->n_normals) * hf * 4));
     if (!nodes.empty()) AH_IX(hipMemcpy(ix->d_nodes, nodes.data(), nodes.size() * sizeof(DNode), hipMemcpyHostToDevice));
     if (v.n_trees) AH_IX(hipMemcpy(ix->d_roots, v.roots, v.n_trees * 4, hipMemcpyHostToDevice));
     if (v.descendants_len)
         AH_IX(hipMemcpy(ix->d_desc, v.descendants, v.descendants_len * 4, hipMemcpyHostToDevice));
     if (ix->n_normals) {
         DevMem recs, offs;
-        AH_IX(hipMalloc(&recs.p, v.normals_len));
-        AH_IX(hipMalloc(&offs.p, offsets.size() * 8));
+        AH_IX(dev_malloc(&recs.p, v.normals_len));
+        AH_IX(dev_malloc(&offs.p, offsets.size() * 8));
         AH_IX(hipMemcpy(recs.p, v.normals, v.normals_len, hipMemcpyHostToDevice));
         AH_IX(hipMemcpy(offs.p, offsets.data(), offsets.size() * 8, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_unpack_normals, dim3(ix->n_normals), dim3(256), 0, 0, recs.as<uint8_t>(), offs.as<uint64_t>(),
@@ -2245,7 +2245,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         if (h_overflow[q]) h_list[n_over++] = (uint32_t)q;
     if (n_over) {  // 2b. the rare big queues: re-run with the queue in global memory (hard capacity bound)
         DevMem heap;
-        AH_HIP(hipMalloc(&heap.p, (size_t)n_over * heap_cap * 8));
+        AH_HIP(dev_malloc(&heap.p, (size_t)n_over * heap_cap * 8));
         AH_HIP(hipMemcpyAsync(d_list, h_list, n_over * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL((k_descend<true>), dim3((n_over + 7) / 8), dim3(64), 0, s, ix->nv, sp, (const uint32_t *)d_list,
                            n_over, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, heap.as<uint64_t>(), heap_cap,

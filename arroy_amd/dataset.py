@@ -400,7 +400,9 @@ class StreamedForest:
         hs, vs = self.distance.header_size(), self.distance.vector_size(self.dimensions)
         for i in range(n):
             nd = b.nodes[i]
-            assert nd.kind == b.kind and nd.id not in self.splits and nd.id not in self.leaves
+            assert nd.kind == b.kind, f"node {nd.id} of kind {nd.kind} in a batch of kind {b.kind}"
+            assert nd.id not in self.splits and nd.id not in self.leaves, \
+                f"node {nd.id} (kind {nd.kind}, tree {nd.tree}, depth {nd.depth}, count {nd.count}) arrives twice; batches so far {self.batches[-6:]}"
             off = int(nd.payload_offset)
             if nd.kind == 2:
                 nb = None

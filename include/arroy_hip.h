@@ -40,7 +40,7 @@ extern "C" {
                               v4: ah_forest_digest, ah_tuning_set / _get / _reset, ah_debug_launch_coverage,
                                   ah_build_stats.rows_* / screen8_* / screen_unavailable (appended)
                               v5: ah_search_stats / ah_index_search_stats, ah_build_options.max_host_threads (appended),
-                                  ah_host_cache_trim, ah_synth_rows_host, ah_build_forest_stream (the node sink during the
+                                  ah_host_cache_trim, ah_device_cache_trim, ah_synth_rows_host, ah_build_forest_stream (the node sink during the
                                   build), ah_build_stats.seconds_setup / seconds_after_device / host_blob_recycled */
 
 /* every entry point is exported from the shared object (it is built with -fvisibility=hidden) */
@@ -500,6 +500,11 @@ AH_API int ah_device_name(int device, char *buf, size_t buf_len);
  * build, which then takes no page faults for its 9.4 GB of output (AH_HOST_CACHE_MB bounds the pool, default 16 GiB;
  * 0 = keep nothing).  This returns the pool's memory to the system; *out_bytes (may be NULL) = committed bytes released. */
 AH_API int ah_host_cache_trim(uint64_t *out_bytes);
+/* Device memory is cached the same way: HBM the library has obtained (datasets, their binary16 / int8 copies, the ~28 GB of
+ * scratch of a 10M x 100-tree build) goes back to the driver only under memory pressure or here — a hipMalloc that lands on
+ * memory the driver is still scrubbing after a hipFree was measured to stall a build's first launch by a second
+ * (AH_DEVICE_CACHE_MB bounds the idle bytes, default 192 GiB; 0 = plain hipMalloc / hipFree).  device < 0: every device. */
+AH_API int ah_device_cache_trim(int device, uint64_t *out_bytes);
 /* Benchmark harness only: n x dims synthetic rows of the generator of arroy_hip_policy.h (the rows
  * ah_dataset_fill_synthetic makes in HBM) in HOST memory, items first_item .. first_item + n - 1, on all host cores. */
 AH_API int ah_synth_rows_host(uint64_t seed, int distribution, uint64_t first_item, uint64_t n, uint32_t dims, float *out);

@@ -52,6 +52,10 @@ def one(rng, it):
     lists = [np.sort(rng.choice(n, int(rng.integers(0, n + 1)), replace=False)).astype(np.uint32) for _ in range(nq)]
     kb = int(rng.choice([1, 5, 50]))
     bi, bd, bc = ds.rerank_batch(qs, [ids[l] for l in lists], kb)
+    from arroy_amd._lib import tuning as _tuning
+    with _tuning(AH_RERANK_SCREEN=0):  # the certified top-k screen of the lists (default) and the f32-only path: the same bits
+        xi, xd, xc = ds.rerank_batch(qs, [ids[l] for l in lists], kb)
+    assert np.array_equal(bc, xc) and np.array_equal(bi, xi) and np.array_equal(bd.view(np.uint32), xd.view(np.uint32)), desc + " batch screen on/off"
     for i in range(nq):
         v, h = oracle.query_leaf(qs[i])
         ei, ed = oracle.rerank(v, h, lists[i], kb) if len(lists[i]) else (np.zeros(0, np.uint32), np.zeros(0, np.float32))
@@ -81,6 +85,15 @@ def one(rng, it):
     T.check_forest_valid(forest, n, ids=ids)
     for t, seed in enumerate(seeds):
         assert forest.canonical(t) == oracle.build_tree(split_after, seed).canonical(), desc + f" tree {t} sa={split_after}"
+    # the same forest through the streaming sink (ah_build_forest_stream), sometimes in several batches of trees
+    if rng.random() < 0.5:
+        in_flight = int(rng.choice([0, 0, 1, 2]))
+        try:
+            _roots, sstats, streamed = ds.build_forest_stream(seeds, split_after=split_after, margin_mode=mode, max_trees_in_flight=in_flight)
+        except BaseException as e:
+            raise AssertionError(desc + f" stream in_flight={in_flight} sa={split_after}: {e!r}")
+        assert [streamed.canonical(t) for t in range(len(seeds))] == [forest.canonical(t) for t in range(len(seeds))], desc + " stream"
+        assert len(streamed.splits) + len(streamed.leaves) == len(forest.nodes), desc + " stream node count"
     index = ds.create_index(forest)
     count, search_k = int(rng.choice([1, 10, 200, 2500])), int(rng.choice([0, 1, 100, 2**62]))
     got = index.search(count, queries=qs[: min(nq, 4)], search_k=search_k)
@@ -98,8 +111,10 @@ def one(rng, it):
         cand = [int(x) for x in rng.choice(int(ids[-1]) + 3, int(rng.integers(0, min(n, 4000) + 1)), replace=False)]
     ref = None
     for wave in (1, 0):
-        for tiles in (1, 0):
-            with tuning(AH_SEARCH_WAVE=wave, AH_SEARCH_TILES=tiles):
+        for tiles in (1, 0, 2):  # 2: the leaf tiles without the certified top-k screen (f32 rows for every candidate)
+            if tiles == 2 and wave == 0:
+                continue
+            with tuning(AH_SEARCH_WAVE=wave, AH_SEARCH_TILES=min(tiles, 1), AH_SEARCH_SCREEN=0 if tiles == 2 else 1):
                 oi, od, oc = index.search(count2, queries=qs2, search_k=sk2, candidates=cand, raw=True)
             if ref is None:
                 ref = (oi, od, oc)
