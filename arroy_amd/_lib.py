@@ -140,6 +140,7 @@ SIGNATURES = {
     "ah_dataset_upload_vectors": (C.c_int, [_VP, _U32P, _F32P, C.c_size_t]),
     "ah_dataset_fill_synthetic": (C.c_int, [_VP, C.c_uint64, C.c_int, C.c_uint64]),
     "ah_dataset_finalize": (C.c_int, [_VP]),
+    "ah_dataset_reserve_build": (C.c_int, [_VP, C.c_uint32, C.c_uint32]),
     "ah_dataset_len": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "ah_dataset_item_vector": (C.c_int, [_VP, C.c_uint32, _F32P]),
     "ah_dataset_read_headers": (C.c_int, [_VP, C.c_uint64, C.c_uint64, _VP]),

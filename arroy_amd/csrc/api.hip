@@ -189,6 +189,19 @@ hipError_t dev_malloc(void **p, size_t bytes) {
     return hipSuccess;
 }
 
+hipError_t dev_free_unused(void *p) {
+    if (!p) return hipSuccess;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    for (size_t i = 0; i < g_dev_live.size(); i++)
+        if (g_dev_live[i].p == p) {
+            g_dev_idle.push_back(g_dev_live[i]);
+            g_dev_idle_bytes += g_dev_live[i].bytes;
+            g_dev_live.erase(g_dev_live.begin() + (ptrdiff_t)i);
+            return hipSuccess;
+        }
+    return hipErrorInvalidValue;
+}
+
 hipError_t dev_free(void *p) {
     if (!p) return hipSuccess;
     DevBlock blk{nullptr, 0, 0};
@@ -577,6 +590,7 @@ static int upload_flush(ah_dataset *ds);
 
 int ah_dataset_destroy(ah_dataset *ds) {
     if (!ds) return AH_OK;
+    if (ds->reserve_thread.joinable()) ds->reserve_thread.join();
     (void)upload_flush(ds);
     (void)hipSetDevice(ds->device);
     (void)hipDeviceSynchronize();

@@ -145,6 +145,7 @@ inline hipError_t dev_malloc(T **p, size_t bytes) {
     return dev_malloc(reinterpret_cast<void **>(p), bytes);
 }
 hipError_t dev_free(void *p);
+hipError_t dev_free_unused(void *p);       // a block no kernel or copy ever touched: straight to the idle list, no device wait
 size_t dev_cache_trim(int device);         // device < 0: every device; returns the bytes given back
 size_t dev_cache_idle_bytes(int device);   // idle bytes cached for `device` (ah_build_forest adds them to hipMemGetInfo's free)
 
@@ -262,6 +263,7 @@ struct ah_dataset {
     bool up_used[4] = {false, false, false, false};
     std::mutex mu;
     std::vector<ah::Context *> pool;
+    std::thread reserve_thread;                  // ah_dataset_reserve_build: fills the device cache while records are staged
 
     ah::DataView view() const;
     size_t row_bytes() const { return ah::metric_is_bq(metric) ? (size_t)pitch * 8 : (size_t)pitch * 4; }

@@ -3560,6 +3560,7 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
     AH_REQUIRE(ds->metric != AH_DOT_PRODUCT || ds->dot_preprocessed, AH_ERR_NEED_PREPROCESS,
                "DotProduct needs ah_preprocess_dot before the build (src/writer.rs:964-976)");
     AH_HIP(hipSetDevice(ds->device));
+    if (ds->reserve_thread.joinable()) ds->reserve_thread.join();  // (ah_dataset_reserve_build still filling the cache)
     const auto t0 = std::chrono::steady_clock::now();
     const uint32_t split_after = options->split_after ? options->split_after : ds->dims;  // src/writer.rs:474-477
     ah_forest *forest = new (std::nothrow) ah_forest();
@@ -3653,6 +3654,78 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
     }
     forest->stats.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     *out = forest;
+    return AH_OK;
+}
+
+// ah_dataset_reserve_build: the device memory the first build of this dataset will ask for — the binary16 / int8 copies of the
+// rows and the scratch of an `n_trees`-tree batch — obtained NOW, on a helper thread, and parked in the caching allocator.
+// Meant to be called right after ah_dataset_create, while the records are still being staged over PCIe: fresh HBM costs the
+// driver 20+ ms per GB on a box whose memory was recently released (r04: 59 GB of fresh blocks put 1.3 s in front of a cold
+// 10M x 100-tree build's first launch and stretched its kernels from 1.33 to 1.8 s); under the 0.6 s of staging it is free.
+// Sizes mirror build_batch / ensure_screen; a mismatch only costs the cache hit.
+int ah_dataset_reserve_build(ah_dataset *ds, uint32_t n_trees, uint32_t split_after_opt) {
+    AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
+    if (ds->reserve_thread.joinable()) ds->reserve_thread.join();
+    const uint64_t N = std::max<uint64_t>(ds->n, ds->capacity);
+    if (N == 0 || n_trees == 0 || tun(TUN_DEVICE_CACHE_MB) <= 0) return AH_OK;
+    const uint32_t split_after = split_after_opt ? split_after_opt : ds->dims;
+    std::vector<size_t> sizes;
+    const bool f32 = !metric_is_bq(ds->metric) && ds->dims >= 32;
+    const bool want_screen = f32 && tun(TUN_SCREEN) != 0 && !ds->d_rows_h16;
+    const uint32_t hpitch = (ds->dims + 63u) & ~63u, pitch8 = (ds->dims + 127u) & ~127u;
+    if (want_screen) {  // ensure_screen / ensure_screen8
+        sizes.push_back(N * (size_t)hpitch * 2);
+        sizes.push_back(N * sizeof(float4));
+        if (ds->metric != AH_DOT_PRODUCT && tun(TUN_SCREEN8) != 0) {
+            if (tun(TUN_SCREEN8_LO) != 0) sizes.push_back(N * (size_t)pitch8);
+            sizes.push_back(N * (size_t)pitch8);
+            sizes.push_back(N * sizeof(float));
+        }
+    }
+    {  // build_batch, one batch of n_trees full-dataset trees
+        const uint64_t M = (uint64_t)n_trees * N;
+        const uint64_t max_nodes = M / ((uint64_t)split_after + 1) + n_trees, max_tiles = M / kTile + n_trees + max_nodes;
+        auto buf = [&](uint64_t n, size_t elem) { sizes.push_back((size_t)std::max<uint64_t>(n, 1024) * elem); };
+        buf(M, 4); buf(M, 4); buf(M, 4);                                 // the three permutations
+        buf(max_nodes, sizeof(FNode)); buf(max_nodes, sizeof(FNode));
+        buf(max_tiles, sizeof(FTile));
+        buf(max_tiles * 32, 8);                                          // side masks
+        buf(max_tiles, 4); buf(max_tiles, 4);
+        buf(2 * max_nodes, 4);
+        buf(max_nodes / 256 + 2, sizeof(NextCounts));
+        if (f32 && n_trees >= 2) {
+            buf((uint64_t)n_trees * N + 4, 4);                           // node_of
+            buf((uint64_t)n_trees * N + 1024 + 16, 1);                   // side bytes
+        }
+        const uint64_t nstride = normal_record_stride(ds);
+        sizes.push_back((size_t)std::max<uint64_t>(32ull << 20, std::min<uint64_t>(2 * max_nodes * nstride, 16ull << 30)));
+        if (f32 && tun(TUN_SCREEN) != 0) {
+            const uint64_t hstride = ((uint64_t)hpitch * 2 + 16 + 127) & ~(uint64_t)127;
+            const uint64_t stride8 = (2 * (uint64_t)pitch8 + sizeof(NormalStats8) + 127) & ~(uint64_t)127;
+            const size_t sh = (size_t)std::max<uint64_t>(16ull << 20, std::min<uint64_t>(max_nodes * hstride, 8ull << 30));
+            sizes.push_back(sh);
+            sizes.push_back(sh);  // (a 100-tree 10M build takes a second block for its deepest levels)
+            if (ds->metric != AH_DOT_PRODUCT && tun(TUN_SCREEN8) != 0)
+                sizes.push_back((size_t)std::max<uint64_t>(16ull << 20, std::min<uint64_t>(max_nodes * stride8, 4ull << 30)));
+        }
+    }
+    const int device = ds->device;
+    try {
+        ds->reserve_thread = std::thread([device, sizes] {
+            if (hipSetDevice(device) != hipSuccess) return;
+            std::vector<void *> got;
+            for (size_t b : sizes) {
+                void *p = nullptr;
+                if (dev_malloc(&p, b) != hipSuccess) {  // no room: the build will see for itself
+                    (void)hipGetLastError();
+                    break;
+                }
+                got.push_back(p);
+            }
+            for (void *p : got) (void)dev_free_unused(p);
+        });
+    } catch (...) {  // no thread: the first build allocates as before
+    }
     return AH_OK;
 }
 

@@ -78,6 +78,11 @@ class Dataset:
         ptrs = (C.c_void_p * n)(*[C.addressof(b) + 1 for b in keep])
         _lib.check(_lib.lib().ah_dataset_upload_records(self._h, _ptr(ids), ptrs, rec_len, n))
 
+    def reserve_build(self, n_trees: int, split_after: int = 0) -> None:
+        """ah_dataset_reserve_build: while the records are still being staged, obtain the device memory the first build will
+        ask for (fresh HBM can cost the driver tens of ms per GB) and park it in the library's device cache."""
+        _lib.check(_lib.lib().ah_dataset_reserve_build(self._h, int(n_trees), int(split_after)))
+
     def fill_synthetic(self, seed: int, distribution: int, n_items: int) -> None:
         _lib.check(_lib.lib().ah_dataset_fill_synthetic(self._h, seed, distribution, n_items))
 

@@ -713,6 +713,9 @@ def build_10m(args, rank, world, device, sync, ds, result):
                 result["cpu_10m"] = cpu_baseline_10m(args, host_vecs, result.get("cpu"))
             chunk = 1_000_000
             t0 = time.perf_counter()
+            # `Writer::build` knows its tree count before it collects the items: the device memory of the first build is
+            # obtained on a helper thread while the records travel (fresh HBM is not free: ah_dataset_reserve_build)
+            ds.reserve_build(len(seeds))
             for lo in range(0, n, chunk):
                 ds.upload_vectors(np.arange(lo, min(n, lo + chunk), dtype=np.uint32), host_vecs[lo:lo + chunk])
             t1 = time.perf_counter()

@@ -40,7 +40,7 @@ extern "C" {
                               v4: ah_forest_digest, ah_tuning_set / _get / _reset, ah_debug_launch_coverage,
                                   ah_build_stats.rows_* / screen8_* / screen_unavailable (appended)
                               v5: ah_search_stats / ah_index_search_stats, ah_build_options.max_host_threads (appended),
-                                  ah_host_cache_trim, ah_device_cache_trim, ah_synth_rows_host, ah_build_forest_stream (the node sink during the
+                                  ah_host_cache_trim, ah_device_cache_trim, ah_dataset_reserve_build, ah_synth_rows_host, ah_build_forest_stream (the node sink during the
                                   build), ah_build_stats.seconds_setup / seconds_after_device / host_blob_recycled */
 
 /* every entry point is exported from the shared object (it is built with -fvisibility=hidden) */
@@ -139,6 +139,12 @@ AH_API int ah_dataset_finalize(ah_dataset *ds);
  * what the one-tree-batch-per-GPU build needs (`Writer::build` shares ONE ImmutableLeafs between all its tasks,
  * src/writer.rs:530,556-591).  The replica has its own handle and lifetime; destroy it with ah_dataset_destroy. */
 AH_API int ah_dataset_replicate(ah_dataset *src, int device, ah_dataset **out);
+/* Optional, right after ah_dataset_create: obtain — on a helper thread, while the records are staged over PCIe — the device
+ * memory the first `n_trees`-tree build of this dataset will ask for (the binary16 / int8 copies of the rows, the build's
+ * scratch) and park it in the library's device cache.  Fresh HBM can cost the driver 20+ ms per GB (a box whose memory was
+ * just released by another process scrubs it); `Writer::build` knows its tree count before it collects the items
+ * (src/writer.rs:518-519).  split_after 0 = dimensions.  Never fails for lack of memory: the build then allocates itself. */
+AH_API int ah_dataset_reserve_build(ah_dataset *ds, uint32_t n_trees, uint32_t split_after);
 AH_API int ah_dataset_len(const ah_dataset *ds, uint64_t *out_n_items);
 /* `Reader::item_vector` (src/reader.rs:266-276): decoded f32 vector (dims floats; +-1.0 for BQ). */
 AH_API int ah_dataset_item_vector(ah_dataset *ds, uint32_t item_id, float *out_vector);
