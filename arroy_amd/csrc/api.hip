@@ -104,9 +104,10 @@ struct DevBlock {
     size_t bytes;
     int device;
 };
-std::mutex g_dev_mu;
-std::vector<DevBlock> g_dev_idle;                     // blocks nobody uses, oldest first
-std::vector<DevBlock> g_dev_live;                     // blocks handed out (few hundred at most: a linear scan is fine)
+// (heap-allocated and never destroyed: handles may be destroyed by finalizers that run after this library's static destructors)
+std::mutex &g_dev_mu = *new std::mutex();
+std::vector<DevBlock> &g_dev_idle = *new std::vector<DevBlock>();  // blocks nobody uses, oldest first
+std::vector<DevBlock> &g_dev_live = *new std::vector<DevBlock>();  // blocks handed out (a few hundred at most: a linear scan is fine)
 size_t g_dev_idle_bytes = 0;
 inline size_t dev_round(size_t bytes) {  // whole 2 MiB for the big blocks (what the driver maps anyway), 4 KiB below
     const size_t g = bytes >= (1u << 20) ? (2u << 20) : 4096u;

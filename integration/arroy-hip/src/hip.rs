@@ -312,10 +312,10 @@ pub fn build_new_trees<D: Distance, R: Rng>(
     let mut state =
         SinkState::<D> { tmp_nodes, node_ids, global: Vec::new(), vector_len: leafs.vector_len, error: None };
     let mut roots = vec![0u32; n_trees];
+    let done = AtomicI32::new(0);
     let code = std::thread::scope(|s| {
         // `options.cancel` is a closure: a watcher evaluates it while the device works and raises the flag the
         // library polls between launches
-        let done = AtomicI32::new(0);
         let watcher = s.spawn(|| {
             while done.load(Ordering::Relaxed) == 0 {
                 if (options.cancel)() {
