@@ -1265,11 +1265,12 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
                                                                  uint32_t *__restrict__ out_ids, float *__restrict__ out_dist,
                                                                  uint32_t *err, const PairSeg *__restrict__ segs) {
     constexpr uint32_t kBins = 2048, kCap = 1024, kThreads = 1024;
+    extern __shared__ float4 s_qf4[];  // the query leaf in f32 (row pitch): the survivors' exact distances read it 143 times
     __shared__ uint32_t s_hist[kBins];
     __shared__ uint64_t s_key[kCap];
     __shared__ uint32_t s_pos[kCap];
     __shared__ float s_val[kCap];
-    __shared__ uint32_t s_min, s_max, s_wave[kThreads / 64], s_bin, s_n, s_t, s_bad;
+    __shared__ uint32_t s_min, s_max, s_wave[kThreads / 64], s_bin, s_n, s_bad;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     // candidates of query q: a slot of `stride` entries (ah_search_batch), or a segment of the caller's lists (ah_rerank_batch)
     const uint64_t first = segs ? segs[q].off : (uint64_t)q * stride;
@@ -1282,11 +1283,14 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
     }
     if (kk == 0) return;
     for (uint32_t b = tid; b < kBins; b += kThreads) s_hist[b] = 0;
+    {
+        const float4 *g_q4 = reinterpret_cast<const float4 *>(qvecs + (uint64_t)q * qstride);
+        for (uint32_t i = tid; i < (dv.pitch >> 2); i += kThreads) s_qf4[i] = g_q4[i];
+    }
     if (tid == 0) {
         s_min = 0xFFFFFFFFu;
         s_max = 0u;
         s_n = 0u;
-        s_t = 0u;
         s_bad = 0u;
     }
     __syncthreads();
@@ -1363,16 +1367,16 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
     }
     __syncthreads();
     const uint32_t bin_k = s_bin;
-    // T = the largest U of that bin (>= the k-th smallest U: a valid, slightly generous threshold)
-    uint32_t t_loc = 0u;
-    for (uint32_t g = tid; g < n; g += kThreads) {
-        uint32_t uk, lk;
-        if (bounds_of(g, uk, lk) && bin_of(uk) <= bin_k) t_loc = max(t_loc, uk);
+    // T = the largest key of that bin (>= the k-th smallest U: a valid, slightly generous threshold).  In closed form:
+    // bin_of(w) <= bin_k  <=>  (w - w_min) * scale < (bin_k + 1) << 32  <=>  w - w_min <= ceil(((bin_k + 1) << 32) / scale) - 1
+    uint32_t t_key;
+    if (direct) {
+        t_key = w_min + bin_k;
+    } else {
+        const uint64_t lim = ((uint64_t)bin_k + 1ull) << 32;
+        const uint64_t d = (lim + scale - 1ull) / scale;
+        t_key = (uint32_t)min((uint64_t)w_min + d - 1ull, (uint64_t)s_max);
     }
-    for (int off = 32; off > 0; off >>= 1) t_loc = max(t_loc, (uint32_t)__shfl_xor((int)t_loc, off));
-    if ((tid & 63u) == 0) atomicMax(&s_t, t_loc);
-    __syncthreads();
-    const uint32_t t_key = s_t;
     for (uint32_t g = tid; g < n; g += kThreads) {
         uint32_t uk, lk;
         if (bounds_of(g, uk, lk) && lk <= t_key) {
@@ -1391,13 +1395,13 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
         atomicAdd(&err[SS_SURVIVORS], n_sel);
     }
     // the survivors in the reference's arithmetic: one octet per candidate (the f32 row against the f32 query leaf)
+    // (octet_reduce_stream: the reference's chains and tree, the row's first eight lines requested before the first use)
     const uint32_t j = tid & 7u;
-    const float *qf = reinterpret_cast<const float *>(qvecs + (uint64_t)q * qstride);
     bool bad = false;
     for (uint32_t e = tid >> 3; e < n_sel; e += kThreads >> 3) {
         const uint32_t g = s_pos[e], id = ids[g];
         const uint64_t row = row_of_id(dv, id);
-        const float r = octet_reduce_any<OP_DOT>(dv.rows_f32 + row * dv.pitch, qf, dv.dims, j);
+        const float r = octet_reduce_stream<OP_DOT>(s_qf4, dv.rows_f32 + row * dv.pitch, dv.dims, j);
         const float d = METRIC == AH_COSINE ? cosine_from_dot(r, qn, dv.headers[row]) : -r;
         if (j == 0) {
             const uint32_t w = orderable_key(d);
@@ -1728,12 +1732,19 @@ int launch_rerank_screened(ah_dataset *ds, uint32_t nq, const uint8_t *d_qvecs, 
         AH_HIP(hipGetLastError());
         return AH_OK;
     }
+    const size_t sel_lds = (size_t)ds->pitch * 4;
+    if (sel_lds > 32 * 1024) {
+        AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_select_screened<AH_COSINE>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+        AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_select_screened<AH_DOT_PRODUCT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+    }
     if (ds->metric == AH_COSINE)
-        hipLaunchKernelGGL((k_search_select_screened<AH_COSINE>), dim3(nq), dim3(1024), 0, s, dv, ss, d_ids, d_dist, 0u,
+        hipLaunchKernelGGL((k_search_select_screened<AH_COSINE>), dim3(nq), dim3(1024), sel_lds, s, dv, ss, d_ids, d_dist, 0u,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, k_out, d_qvecs, qstride, d_qhdrs, d_out_ids,
                            d_out_dist, d_err, reinterpret_cast<const PairSeg *>(d_segs));
     else
-        hipLaunchKernelGGL((k_search_select_screened<AH_DOT_PRODUCT>), dim3(nq), dim3(1024), 0, s, dv, ss, d_ids, d_dist, 0u,
+        hipLaunchKernelGGL((k_search_select_screened<AH_DOT_PRODUCT>), dim3(nq), dim3(1024), sel_lds, s, dv, ss, d_ids, d_dist, 0u,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, k_out, d_qvecs, qstride, d_qhdrs, d_out_ids,
                            d_out_dist, d_err, reinterpret_cast<const PairSeg *>(d_segs));
     AH_HIP(hipGetLastError());
@@ -2197,11 +2208,18 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
             hipLaunchKernelGGL(k_flag_duplicates_hash, dim3((unsigned)nq), dim3(1024), kHashSlots * 4, s, d_nns, nns_stride, d_counts,
                                d_unique, d_err);
         }
+        const size_t sel_lds = (size_t)ds->pitch * 4;  // the query leaf in f32
+        if (screened && sel_lds > 32 * 1024) {
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_select_screened<AH_COSINE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_select_screened<AH_DOT_PRODUCT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
+        }
         if (screened && ds->metric == AH_COSINE)
-            hipLaunchKernelGGL((k_search_select_screened<AH_COSINE>), dim3((unsigned)nq), dim3(1024), 0, s, dv, ss, d_nns, d_dist,
+            hipLaunchKernelGGL((k_search_select_screened<AH_COSINE>), dim3((unsigned)nq), dim3(1024), sel_lds, s, dv, ss, d_nns, d_dist,
                                nns_stride, d_counts, d_unique, (uint32_t)k, d_qvecs, qstride, d_qhdrs, d_oi, d_od, d_err, (const PairSeg *)nullptr);
         else if (screened)
-            hipLaunchKernelGGL((k_search_select_screened<AH_DOT_PRODUCT>), dim3((unsigned)nq), dim3(1024), 0, s, dv, ss, d_nns, d_dist,
+            hipLaunchKernelGGL((k_search_select_screened<AH_DOT_PRODUCT>), dim3((unsigned)nq), dim3(1024), sel_lds, s, dv, ss, d_nns, d_dist,
                                nns_stride, d_counts, d_unique, (uint32_t)k, d_qvecs, qstride, d_qhdrs, d_oi, d_od, d_err, (const PairSeg *)nullptr);
         else
             hipLaunchKernelGGL(k_search_select, dim3((unsigned)nq), dim3(kSelectThreads), 0, s, dv, d_nns, d_dist, nns_stride, d_counts,
