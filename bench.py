@@ -72,6 +72,11 @@ def parse_args():
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: test the N>1 control paths on CPU")
     ap.add_argument("--extra", default="", help="comma list of further measurements: metrics (every f32 metric), staging, "
                                                "e2e (10M x 768 staged from host memory + 100-tree build)")
+    ap.add_argument("--scan-only", action="store_true",
+                    help="child mode of the live PMC passes: fill the configs[1] dataset, launch the scan --steps times, exit")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure `roofline.traffic` in this run (two `rocprofv3 --pmc` child runs of the scan, ~15 s each); "
+                         "quote the stored profiles/rNN_pmc_kernels.json figure instead")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
     return ap.parse_args()
@@ -203,6 +208,55 @@ def measured_traffic(n_items, which="scan"):
     if j.get("source_sha16") != source_hash(which):
         return None, f"{os.path.basename(files[-1])}:{which} was measured on other kernel sources (stale): re-run scripts/collect_profiles.sh"
     return float(j["hbm_bytes_per_launch"]), os.path.basename(files[-1])
+
+
+def live_traffic(n_items, steps=6):
+    """HBM bytes per launch of the scan kernel MEASURED IN THIS RUN: two child runs of `bench.py --scan-only` under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (each counter its own pass, no other trace domain — as the guide's
+    HBM section prescribes), the dispatches of `k_distances_f32<2, false>` averaged, gfx950 correction applied (FETCH_SIZE
+    tallies 128-byte requests at 64 bytes: x 2; WRITE_SIZE as is; both in KiB).  Returns (bytes or None, how)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if tool is None:
+        return None, "rocprofv3 not found"
+    means = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="ah_pmc_")
+        try:
+            cmd = [tool, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
+                   os.path.abspath(__file__), "--scan-only", "--steps", str(steps), "--items", str(n_items)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            vals = {}
+            for root, _d, files in os.walk(tmp):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        for r in csv.DictReader(open(os.path.join(root, f))):
+                            if "k_distances_f32<2, false>" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                                vals[r["Dispatch_Id"]] = vals.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+            if not vals:
+                return None, f"no {counter} rows for the scan kernel in the child run"
+            means[counter] = sum(vals.values()) / len(vals)
+        except (subprocess.SubprocessError, OSError, KeyError, ValueError) as e:
+            return None, f"live {counter} pass failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return means["FETCH_SIZE"] * 1024 * 2 + means["WRITE_SIZE"] * 1024, \
+        f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs, {steps + 1} dispatches each"
+
+
+def scan_only(args):
+    """Child of live_traffic: the configs[1] dataset and the scan launches, nothing else (no torch, no timing)."""
+    from arroy_amd import Dataset, distances
+    ds = Dataset(distances.Cosine, DIMS, args.items, device=0)
+    ds.fill_synthetic(SEED, 1, args.items)
+    ds.finalize()
+    ds.bench_scan(12345 % args.items, args.items, 1)
+    ds.bench_scan(12345 % args.items, args.items, args.steps)
+    ds.close()
 
 
 def extra_c5(device):
@@ -867,6 +921,9 @@ def dry_run_work(args, rank, world, sync, result):
 
 def main():
     args = parse_args()
+    if args.scan_only:
+        scan_only(args)
+        return
     env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
     result = {}
     if env_world > 0:
@@ -980,6 +1037,15 @@ def main():
         achieved = n * BYTES_PER_DISTANCE / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = (args.traffic_bytes, "--traffic-bytes") if args.traffic_bytes else \
             (measured_traffic(n) if not args.dry_run else (None, "dry-run"))
+        stored = {"traffic": traffic, "source": traffic_src}
+        if not args.dry_run and not args.no_live_pmc and not args.traffic_bytes and n_used == 1 and env_world <= 1:
+            # the counters of THIS run (round-3 review: a stored figure is not a measurement of the driver's run); the stored,
+            # hash-stamped figure stays next to it and is what is quoted if the child runs cannot be made
+            live, how = live_traffic(n)
+            if live is not None:
+                traffic, traffic_src = live, how
+            else:
+                stored["live_attempt"] = how
         read_gbs = result.get("read_gbs")
         line = {
             "metric": "distances/sec, Q=1 batched 768-dim cosine scan (GB/s vs HBM roofline in `roofline`); tree-build "
@@ -991,6 +1057,7 @@ def main():
                        "items": n, "dims": DIMS, "metric": "cosine", "device": result.get("device"), "launch": mode},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_stored": stored,
                          "kernel": "ah::k_distances_f32<COSINE,false>", "kernel_ms": kernel_ms,
                          "kernel_source_sha16": scan_source_hash(),
                          "measured_d2d_copy_gb_per_s": result.get("copy_gbs"), "measured_read_only_gb_per_s": read_gbs,
