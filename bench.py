@@ -74,6 +74,9 @@ def parse_args():
                                                "e2e (10M x 768 staged from host memory + 100-tree build)")
     ap.add_argument("--scan-only", action="store_true",
                     help="child mode of the live PMC passes: fill the configs[1] dataset, launch the scan --steps times, exit")
+    ap.add_argument("--pmc-child", default="scan", choices=["scan", "rerank", "bq_scan"],
+                    help="with --scan-only: which roofline kernel the child launches (the Q=1 scan, the f32 re-rank gather of a "
+                         "125-query submission, the 1-bit scan)")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not measure `roofline.traffic` in this run (two `rocprofv3 --pmc` child runs of the scan, ~15 s each); "
                          "quote the stored profiles/rNN_pmc_kernels.json figure instead")
@@ -210,7 +213,10 @@ def measured_traffic(n_items, which="scan"):
     return float(j["hbm_bytes_per_launch"]), os.path.basename(files[-1])
 
 
-def live_traffic(n_items, steps=6):
+PMC_KERNELS = {"scan": "k_distances_f32<2, false>", "rerank": "k_batch_distances_f32<3>", "bq_scan": "k_distances_bq<false>"}
+
+
+def live_traffic(n_items, steps=6, which="scan"):
     """HBM bytes per launch of the scan kernel MEASURED IN THIS RUN: two child runs of `bench.py --scan-only` under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (each counter its own pass, no other trace domain — as the guide's
     HBM section prescribes), the dispatches of `k_distances_f32<2, false>` averaged, gfx950 correction applied (FETCH_SIZE
@@ -227,30 +233,67 @@ def live_traffic(n_items, steps=6):
         tmp = tempfile.mkdtemp(prefix="ah_pmc_")
         try:
             cmd = [tool, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
-                   os.path.abspath(__file__), "--scan-only", "--steps", str(steps), "--items", str(n_items)]
+                   os.path.abspath(__file__), "--scan-only", "--pmc-child", which, "--steps", str(steps), "--items", str(n_items)]
             env = dict(os.environ, TMPDIR="/tmp")
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, check=True)
             vals = {}
             for root, _d, files in os.walk(tmp):
                 for f in files:
                     if f.endswith("counter_collection.csv"):
                         for r in csv.DictReader(open(os.path.join(root, f))):
-                            if "k_distances_f32<2, false>" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                            if PMC_KERNELS[which] in r["Kernel_Name"] and r["Counter_Name"] == counter:
                                 vals[r["Dispatch_Id"]] = vals.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
             if not vals:
-                return None, f"no {counter} rows for the scan kernel in the child run"
+                return None, f"no {counter} rows for {PMC_KERNELS[which]} in the child run"
             means[counter] = sum(vals.values()) / len(vals)
         except (subprocess.SubprocessError, OSError, KeyError, ValueError) as e:
             return None, f"live {counter} pass failed: {type(e).__name__}"
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
     return means["FETCH_SIZE"] * 1024 * 2 + means["WRITE_SIZE"] * 1024, \
-        f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs, {steps + 1} dispatches each"
+        f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs, {len(vals)} dispatches of {PMC_KERNELS[which]} each"
+
+
+def rerank_lists(rng, n, nq):
+    """nq candidate lists of configs[3]: 10 000 .. 11 535 sorted unique random ids each (what `nns.sort_unstable(); nns.dedup()`
+    leaves, src/reader.rs:378-379)."""
+    import numpy as np
+
+    def one():
+        m = int(rng.integers(10_000, 11_536))
+        return np.unique(rng.integers(0, n, size=m + 400, dtype=np.uint32))[:m]
+    return [one() for _ in range(nq)]
 
 
 def scan_only(args):
-    """Child of live_traffic: the configs[1] dataset and the scan launches, nothing else (no torch, no timing)."""
+    """Child of live_traffic: the dataset and the launches of ONE roofline kernel, nothing else (no torch, no timing)."""
+    import numpy as np
+
     from arroy_amd import Dataset, distances
+    from arroy_amd import _lib as ahlib
+    if args.pmc_child == "rerank":  # the f32 gather of 125-query submissions (configs[3]), as extra_c4 times it
+        n, dims = 1_000_000, 1536
+        ds = Dataset(distances.DotProduct, dims, n, device=0)
+        ds.fill_synthetic(SEED, 1, n)
+        ds.preprocess_dot()
+        ds.finalize()
+        rng = np.random.default_rng(SEED)
+        queries = np.stack([ds.item_vector(int(i)) for i in rng.choice(n, 64, replace=False)])
+        queries = np.tile(queries, (2, 1))[:125]
+        with ahlib.tuning(AH_RERANK_SCREEN=0):
+            for _ in range(args.steps):
+                ds.rerank_batch(queries, rerank_lists(rng, n, 125), 100)
+        ds.close()
+        return
+    if args.pmc_child == "bq_scan":  # the three 1-bit metrics, as extra_c5 (its roofline entry is their mean)
+        n = 5_000_000
+        for dist in (distances.BinaryQuantizedCosine, distances.BinaryQuantizedEuclidean, distances.BinaryQuantizedManhattan):
+            ds = Dataset(dist, DIMS, n, device=0)
+            ds.fill_synthetic(SEED, 1, n)
+            ds.finalize()
+            ds.bench_scan(7, n, args.steps)
+            ds.close()
+        return
     ds = Dataset(distances.Cosine, DIMS, args.items, device=0)
     ds.fill_synthetic(SEED, 1, args.items)
     ds.finalize()
@@ -334,10 +377,7 @@ def extra_c4(device):
     rng = np.random.default_rng(SEED)
     queries = np.stack([ds.item_vector(int(i)) for i in rng.choice(n, 64, replace=False)])
     queries = np.tile(queries, (nq // 64 + 1, 1))[:nq]
-    def cand_list():  # sorted unique random ids (what `nns.sort_unstable(); nns.dedup()` leaves, src/reader.rs:378-379)
-        m = int(rng.integers(10_000, 11_536))
-        return np.unique(rng.integers(0, n, size=m + 400, dtype=np.uint32))[:m]
-    lists = [cand_list() for _ in range(nq)]
+    lists = rerank_lists(rng, n, nq)
     total = sum(len(l) for l in lists)
     per = 4 * dims + 4 + 4  # vector + id + written distance
     out = {"workload": f"{n}x{dims} dot product, {nq} queries x ~10.8k candidates, top-{k} (host in/out included)",
@@ -1077,6 +1117,18 @@ def main():
                 line[key] = extra.pop(key)
         if extra:
             line["extra"] = extra
+        if not args.dry_run and not args.no_live_pmc and n_used == 1 and env_world <= 1:
+            # the other two roofline entries: their kernels' HBM traffic measured in this run as well
+            for key in ("rerank", "bq_scan"):
+                roof = (line.get(key) or {}).get("roofline")
+                if roof is None:
+                    continue
+                live, how = live_traffic(N_ITEMS, steps=3, which=key)
+                roof["traffic_stored"] = {"traffic": roof.get("traffic"), "source": roof.get("traffic_source")}
+                if live is not None:
+                    roof["traffic"], roof["traffic_source"] = live, how
+                else:
+                    roof["traffic_stored"]["live_attempt"] = how
         srch = line.get("search")
         print(json.dumps(line), flush=True)
     # a screened forest that differs from the f32-only forest is a wrong result, not a slow one
