@@ -1081,6 +1081,11 @@ def main():
         if not args.dry_run and not args.no_live_pmc and not args.traffic_bytes and n_used == 1 and env_world <= 1:
             # the counters of THIS run (round-3 review: a stored figure is not a measurement of the driver's run); the stored,
             # hash-stamped figure stays next to it and is what is quoted if the child runs cannot be made
+            try:  # the children are other processes: give them the HBM this one only keeps cached
+                from arroy_amd import _lib as ahlib
+                ahlib.device_cache_trim()
+            except Exception:  # noqa: BLE001
+                pass
             live, how = live_traffic(n)
             if live is not None:
                 traffic, traffic_src = live, how
