@@ -103,3 +103,46 @@ def test_two_devices_build_disjoint_tree_sets_equal_to_the_one_device_forest():
     for r in replicas[1:]:
         r.close()
     ds.close()
+
+
+def test_reserved_and_recycled_memory_never_changes_a_forest():
+    """The memory side of a build — ah_dataset_reserve_build (device memory obtained on a helper thread while records are
+    staged), the caching device allocator, the recycled host blobs — must be invisible in the result: same digest with fresh
+    memory, with recycled memory, after the caches were trimmed, and with the caches switched off."""
+    from arroy_amd import Dataset, shard
+    n, dims = 400_000, 96  # (12 trees x 400 000 ids = 19 MB: both output blobs are above the pool's 16 MB floor)
+    seeds = shard.tree_seeds(7, range(12))
+
+    def fresh(reserve):
+        ds = Dataset(D.Cosine, dims, n)
+        if reserve:
+            ds.reserve_build(len(seeds))
+            ds.reserve_build(len(seeds))  # a second call joins the first helper
+        ds.fill_synthetic(3, 2, n)
+        ds.finalize()
+        return ds
+    ds = fresh(False)
+    f = ds.build_forest(seeds)
+    want = f.digest()[0]
+    assert f.stats["host_blob_recycled"] in (0, 1, 2)
+    f.close()
+    g = ds.build_forest(seeds)  # blobs and device scratch recycled from the build before
+    assert g.digest()[0] == want and g.stats["host_blob_recycled"] == 2, g.stats
+    g.close()
+    assert _lib.host_cache_trim() > 0 and _lib.device_cache_trim() > 0
+    h = ds.build_forest(seeds)  # ... and fresh again
+    assert h.digest()[0] == want and h.stats["host_blob_recycled"] == 0
+    h.close()
+    with _lib.tuning(AH_DEVICE_CACHE_MB=0, AH_HOST_CACHE_MB=0):
+        k = ds.build_forest(seeds)
+        assert k.digest()[0] == want
+        k.close()
+    ds.close()
+    dr = fresh(True)
+    r = dr.build_forest(seeds)
+    assert r.digest()[0] == want
+    r.close()
+    dr.close()
+    unused = Dataset(D.Cosine, dims, n)
+    unused.reserve_build(1000)  # destroyed while (or right after) the helper runs
+    unused.close()
