@@ -85,6 +85,7 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
     X(NODE_PREFETCH, "AH_NODE_PREFETCH", 1)     /* 0: no software pipeline in the int8 stage of the node-major screen */    \
     X(SCREEN8_LO, "AH_SCREEN8_LO", 1)           /* 0: no second int8 digit of the rows (stage 1 = the binary16 row) */      \
     X(SCREEN8, "AH_SCREEN8", -1)                /* 0: no int8 first stage; 1: keep it whatever the data; -1: by quality */ \
+    X(MASK_BITS, "AH_MASK_BITS", -1)            /* 0 / 1: never / always pack a row-major level's sides into bits before the tiles gather them; -1: by size */ \
     X(DENSE, "AH_DENSE", -1)                    /* 0: never the dense MFMA screen; 1: whenever legal; -1: cost model */    \
     X(DENSE_MAX_COLS, "AH_DENSE_MAX_COLS", 16384)                                                                        \
     X(DENSE_GMACS, "AH_DENSE_GMACS", 495000)    /* sustained multiply-add rate the cost model assumes, 1e9 MAC/s */       \

@@ -418,11 +418,31 @@ __global__ __launch_bounds__(TC >= 16 ? 512 : 1024) void k_forest_margin_rows_ld
     }
 }
 
-// side bytes (by row) -> the per-tile masks / left counts of the node-major pipeline
+// The side bytes of a level (0 / 1 per (tree, row)) as one bit each, bit g of the flat array = pair g = tree * N + row.
+// k_forest_masks_from_bytes reads the sides in the order of the trees' permutations, i.e. at random: a tree's bits are
+// N / 8 bytes (1.25 MB at 10M rows: they stay in an L2) where its bytes are N (10 MB: most gathers go out to the fabric).
+__global__ __launch_bounds__(256) void k_forest_pack_sides(const uint8_t *__restrict__ side_bytes, uint64_t n_words,
+                                                           uint32_t *__restrict__ bits) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(side_bytes + w * 32);
+        const uint4 b = *reinterpret_cast<const uint4 *>(side_bytes + w * 32 + 16);
+        // bits 0 / 8 / 16 / 24 of a word -> bits 24..27 of the product (no two partial products meet, nothing carries)
+        const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t out = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) out |= ((((v[e] & 0x01010101u) * 0x01020408u) >> 24) & 0xFu) << (4 * e);
+        bits[w] = out;
+    }
+}
+
+// side bytes (by row) -> the per-tile masks / left counts of the node-major pipeline.  `side_bits` != nullptr: the same
+// sides, packed by k_forest_pack_sides.
 __global__ __launch_bounds__(kBlock) void k_forest_masks_from_bytes(FNode *nodes, const FTile *__restrict__ tiles,
                                                                     uint32_t n_tiles, const uint32_t *__restrict__ perm,
                                                                     uint64_t n_items,
                                                                     const uint8_t *__restrict__ side_bytes,
+                                                                    const uint32_t *__restrict__ side_bits,
                                                                     uint64_t *__restrict__ masks,
                                                                     uint32_t *__restrict__ tile_left) {
     // Item p of a tile is bit (p >> 5) of mask (p & 31).  Thread (wave w, lane l) takes the items 256 k + 64 w + l, k = 0..7:
@@ -444,8 +464,17 @@ __global__ __launch_bounds__(kBlock) void k_forest_masks_from_bytes(FNode *nodes
             rows[k] = p < in_tile ? pp[p] : 0xFFFFFFFFu;
         }
         uint32_t side[8];
+        if (side_bits) {
+            const uint64_t g0 = (uint64_t)nd->tree * n_items;
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) side[k] = rows[k] != 0xFFFFFFFFu ? (uint32_t)sb[rows[k]] : 0u;
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint64_t g = g0 + rows[k];
+                side[k] = rows[k] != 0xFFFFFFFFu ? side_bits[g >> 5] >> (uint32_t)(g & 31u) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) side[k] = rows[k] != 0xFFFFFFFFu ? (uint32_t)sb[rows[k]] : 0u;
+        }
         __syncthreads();  // the previous tile's ballots have been consumed
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
@@ -2507,11 +2536,17 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                               (mode_req != AH_MARGIN_AUTO ? mode_req != AH_MARGIN_NODE_MAJOR : g_rows_force != 0);
     DevBuf<uint32_t> node_of;
     DevBuf<uint8_t> side_bytes;
+    DevBuf<uint32_t> side_bits;
     if (rows_allowed) {
         AH_TRY(node_of.ensure((size_t)n_trees * N + 4));
         // padded to whole 1 KiB windows and zeroed once: k_forest_exact_pairs scans it 16 bytes per lane for marks
         AH_TRY(side_bytes.ensure((size_t)n_trees * N + 1024 + 16));
         AH_HIP(hipMemsetAsync(side_bytes.p, 0, (size_t)n_trees * N + 1024 + 16, s));
+        // the same sides one bit each for the permutation-order gather of k_forest_masks_from_bytes (worth its pass from
+        // the size on at which a tree's bytes no longer sit in an L2)
+        if ((tun(TUN_MASK_BITS) > 0 || (tun(TUN_MASK_BITS) < 0 && N >= (1u << 20))) &&
+            side_bits.ensure(((size_t)n_trees * N + 31) / 32 + 4) != AH_OK)
+            (void)hipGetLastError();  // no room: the tiles gather the bytes
     }
     // certified binary16 screen: f32 metrics with AVX-tier rows, unless the caller (or AH_SCREEN=0) asks for f32 only
     const auto t_setup_rows = std::chrono::steady_clock::now();
@@ -3201,8 +3236,13 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     passes++;
                     t0 += np;
                 }
+                if (side_bits.p) {
+                    const uint64_t n_words = ((uint64_t)n_trees * N + 31) / 32;
+                    hipLaunchKernelGGL(k_forest_pack_sides, dim3((uint32_t)std::min<uint64_t>((n_words + 255) / 256, 1u << 16)),
+                                       dim3(256), 0, s, side_bytes.p, n_words, side_bits.p);
+                }
                 hipLaunchKernelGGL(k_forest_masks_from_bytes, dim3(masks_grid), dim3(kBlock), 0, s, d_cur, d_tiles.p, n_tiles,
-                                   cur, N, side_bytes.p, masks.p, tile_left.p);
+                                   cur, N, side_bytes.p, side_bits.p, masks.p, tile_left.p);
                 if (lds_tc && !screen) passes = (n_trees + lds_tc - 1) / lds_tc;
                 forest->stats.margin_row_passes += passes;
                 if (screen) forest->stats.screened_launches += passes;
@@ -3696,6 +3736,8 @@ int ah_dataset_reserve_build(ah_dataset *ds, uint32_t n_trees, uint32_t split_af
         if (f32 && n_trees >= 2) {
             buf((uint64_t)n_trees * N + 4, 4);                           // node_of
             buf((uint64_t)n_trees * N + 1024 + 16, 1);                   // side bytes
+            if (tun(TUN_MASK_BITS) > 0 || (tun(TUN_MASK_BITS) < 0 && N >= (1u << 20)))
+                buf(((uint64_t)n_trees * N + 31) / 32 + 4, 4);           // ... and bits
         }
         const uint64_t nstride = normal_record_stride(ds);
         sizes.push_back((size_t)std::max<uint64_t>(32ull << 20, std::min<uint64_t>(2 * max_nodes * nstride, 16ull << 30)));

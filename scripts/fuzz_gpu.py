@@ -79,8 +79,10 @@ def one(rng, it):
     seeds = [int(x) for x in rng.integers(0, 2**63, int(rng.choice([1, 2, 3, 9, 17])))]
     # every margin-kernel family, with and without the certified binary16 screen (ah_margin_mode)
     mode = int(rng.choice([0, 0, 1, 2, 4, 8, 16, 0x108, 0x110, 0x200, 0x200])) | (0x1000 if rng.random() < 0.3 else 0)
-    forest = ds.build_forest(seeds, split_after=split_after, margin_mode=mode)
-    desc += f" mode={mode:#x} trees={len(seeds)}"
+    mask_bits = int(rng.integers(0, 2))  # the sides of a row-major level gathered as bits / as bytes
+    with _tuning(AH_MASK_BITS=mask_bits):
+        forest = ds.build_forest(seeds, split_after=split_after, margin_mode=mode)
+    desc += f" mode={mode:#x} trees={len(seeds)} mask_bits={mask_bits}"
     assert forest.stats["screen_violations"] == 0
     T.check_forest_valid(forest, n, ids=ids)
     for t, seed in enumerate(seeds):

@@ -127,7 +127,7 @@ SWITCHES = [dict(AH_ROWS_XCD=0), dict(AH_ROWS_NT=1), dict(AH_ROWS_NT=0), dict(AH
             dict(AH_ROWMAJOR_ADVANCE=0), dict(AH_ROWMAJOR_MAX_TC=4), dict(AH_ROWS_PER_BLOCK=64), dict(AH_ROWS_CHUNK_MB=1),
             dict(AH_FOREST_NODE_BLOCKS=300), dict(AH_FOREST_TILE_BLOCKS=100, AH_FOREST_SPLIT_BLOCKS=50, AH_FOREST_ROW_BLOCKS=64),
             dict(AH_LAUNCH_MAX_ITEMS=1_000_000, AH_ROWS_CHUNK_ROWS=1024), dict(AH_MARGIN_MODE=8), dict(AH_READBACK_DIRECT=1),
-            dict(AH_NODE_PREFETCH=0), dict(AH_SCREEN8_LO=0)]
+            dict(AH_NODE_PREFETCH=0), dict(AH_SCREEN8_LO=0), dict(AH_MASK_BITS=1)]
 
 
 def test_every_tunable_leaves_the_forest_digest_alone():

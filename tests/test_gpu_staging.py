@@ -115,6 +115,18 @@ def test_shim_roundtrip_in_plain_c_on_the_reference_database(tmp_path):
     assert "id(92): distance(2.4881108)" in out.stdout and out.stdout.strip().endswith("ok")
 
 
+def test_c_abi_demo_runs_to_the_end(tmp_path):
+    """examples/c_abi_demo.c from plain C99: build, search (the item itself first), the node sink after the build and the
+    batch sink DURING the build — the streamed forest has the node and item counts of the materialised one."""
+    import subprocess
+
+    from test_abi import build_c_example
+    exe = build_c_example("c_abi_demo", tmp_path)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "streamed:" in out.stdout and "holding 80000 items" in out.stdout and out.stdout.strip().endswith("ok")
+
+
 def test_uploads_are_asynchronous_but_never_read_the_callers_memory_after_return():
     """The staging contract (include/arroy_hip.h): the pointers are not used after return, although the DMA of the last
     chunks may still be in flight.  Overwrite the source right after every call; the dataset must hold the originals."""
