@@ -2965,20 +2965,44 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             const double convert = (double)n_trees * (double)N *
                                    ((prev_rows && g_rows_advance ? 0.007 : 0.01 + 0.03 * std::min(1.0, (double)nodes_per_tree / 256.0)) +
                                     0.012 * std::min(1.0, (double)nodes_per_tree / 512.0));
-            double best = 0.97 * cost_node;
+            // The group size is chosen with the last trees counted as a fraction of a pass (n_trees / tc: the table of pass
+            // costs was fitted that way, and it ranks the group sizes as the measurements do).  What the chosen schedule
+            // is then compared with — node-major here, the dense product below — is its cost with the groups the launch loop
+            // really forms for the last trees (16 + ... + 4, or one more full group when only a few of its slots would idle:
+            // idle slots cost what busy ones cost).  Counting 13 trees as 13/16 of a pass kept level 5 of a 13-tree share
+            // row-major at 13 ms where the dense product takes 11, and level 9 row-major at 19.5 where node-major takes 18.3.
+            double best = 0.97 * cost_node, best_sel = -1.0;
+            uint32_t tc_sel = 0;
+            const double floor_ns = screen ? 0.15 : 0.45;  // the read of the row alone (screened: mostly Infinity Cache)
+            auto rows_per_row = [&](uint32_t tc) {
+                const double ws_mb = (double)((uint64_t)tc * nodes_per_tree * rec_bytes) / 1e6;
+                return floor_ns + (rows_pass_ns_per_row(tc, ws_mb, screen) - floor_ns) * std::min(1.0, active * 1.05);
+            };
             for (uint32_t tc = std::min(16u, g_rows_max_tc); tc >= 2; tc >>= 1) {
                 if (tc > 2 && tc / 2 >= n_trees) continue;  // do not instantiate more slots than trees
                 const double ws_mb = (double)((uint64_t)tc * nodes_per_tree * rec_bytes) / 1e6;
                 if (g_rows_cache_mb > 0 && ws_mb > g_rows_cache_mb) continue;
-                // a pass per full group, the last trees in smaller groups (16 + 16 + ... + 4): count them as a fraction
-                const double passes = (double)n_trees / tc;
-                const double full = rows_pass_ns_per_row(tc, ws_mb, screen);
-                const double floor_ns = screen ? 0.15 : 0.45;  // the read of the row alone (screened: mostly Infinity Cache)
-                const double per_row = floor_ns + (full - floor_ns) * std::min(1.0, active * 1.05);
-                const double cost_rows = passes * (double)N * per_row * scale + convert;
-                if (cost_rows < best || (g_rows_force == 1 && row_tc == 0)) {
+                const double cost_sel = (double)n_trees / tc * (double)N * rows_per_row(tc) * scale + convert;
+                if (best_sel < 0 || cost_sel < best_sel) {
+                    best_sel = cost_sel;
+                    tc_sel = tc;
+                }
+            }
+            if (tc_sel) {
+                double passes = (double)(n_trees / tc_sel);
+                for (uint32_t t0 = n_trees / tc_sel * tc_sel; t0 < n_trees;) {
+                    const uint32_t rem = n_trees - t0;
+                    uint32_t tcv = tc_sel;
+                    while (tcv > 2 && tcv > rem) tcv >>= 1;
+                    for (uint32_t up = tcv << 1; up <= tc_sel && tcv < rem; up <<= 1)
+                        if (up >= rem && up - rem <= (up >= 16 ? 3u : 1u)) tcv = up;
+                    passes += (double)tcv / tc_sel;
+                    t0 += std::min(tcv, rem);
+                }
+                const double cost_rows = passes * (double)N * rows_per_row(tc_sel) * scale + convert;
+                if (cost_rows < best || g_rows_force == 1) {
                     best = std::min(best, cost_rows);
-                    row_tc = tc;
+                    row_tc = tc_sel;
                 }
             }
             best_cost = best;
