@@ -2965,44 +2965,40 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             const double convert = (double)n_trees * (double)N *
                                    ((prev_rows && g_rows_advance ? 0.007 : 0.01 + 0.03 * std::min(1.0, (double)nodes_per_tree / 256.0)) +
                                     0.012 * std::min(1.0, (double)nodes_per_tree / 512.0));
-            // The group size is chosen with the last trees counted as a fraction of a pass (n_trees / tc: the table of pass
-            // costs was fitted that way, and it ranks the group sizes as the measurements do).  What the chosen schedule
-            // is then compared with — node-major here, the dense product below — is its cost with the groups the launch loop
-            // really forms for the last trees (16 + ... + 4, or one more full group when only a few of its slots would idle:
-            // idle slots cost what busy ones cost).  Counting 13 trees as 13/16 of a pass kept level 5 of a 13-tree share
-            // row-major at 13 ms where the dense product takes 11, and level 9 row-major at 19.5 where node-major takes 18.3.
-            double best = 0.97 * cost_node, best_sel = -1.0;
-            uint32_t tc_sel = 0;
+            // A tc-slot schedule costs what its launches cost: the full groups in one chunk-major launch, then the groups the
+            // launch loop below forms for the last trees (16 + ... + 4, or one more full group when only a few of its slots
+            // would idle: idle slots cost what busy ones cost), each a launch of its own and priced as the pass of ITS size.
+            // The table of pass costs was fitted on 96-tree builds, six or more groups in flight; a launch of one or two
+            // 16-slot groups has the L2s to itself and behaves like one with half the normals (13-tree share, levels 6-9
+            // forced both ways: 13.1 / 13.5 / 15.5 / 21.7 ms as one 16-slot pass — the table says 12.5 / 13.1 / 14.7 / 20.5
+            // that way — and 16.9 / 17.2 / 17.8 / 20.7 as 8 + 4 + 1, which the table prices as it stands).
+            // Counting 13 trees as 13/16 of a 16-slot pass and 13/8 of an 8-slot one kept level 5 of that share row-major
+            // (13 ms; the dense product takes 11), level 8 on 8 + 4 + 1 and level 9 row-major (19.5; node-major 18.3).
+            double best = 0.97 * cost_node;
             const double floor_ns = screen ? 0.15 : 0.45;  // the read of the row alone (screened: mostly Infinity Cache)
-            auto rows_per_row = [&](uint32_t tc) {
-                const double ws_mb = (double)((uint64_t)tc * nodes_per_tree * rec_bytes) / 1e6;
-                return floor_ns + (rows_pass_ns_per_row(tc, ws_mb, screen) - floor_ns) * std::min(1.0, active * 1.05);
+            auto launch_ns_per_row = [&](uint32_t tcv, uint32_t groups) {
+                double ws_mb = (double)((uint64_t)tcv * nodes_per_tree * rec_bytes) / 1e6;
+                if (groups <= 2 && tcv >= 16) ws_mb *= 0.5;
+                return groups * (floor_ns + (rows_pass_ns_per_row(tcv, ws_mb, screen) - floor_ns) * std::min(1.0, active * 1.05));
             };
             for (uint32_t tc = std::min(16u, g_rows_max_tc); tc >= 2; tc >>= 1) {
                 if (tc > 2 && tc / 2 >= n_trees) continue;  // do not instantiate more slots than trees
                 const double ws_mb = (double)((uint64_t)tc * nodes_per_tree * rec_bytes) / 1e6;
                 if (g_rows_cache_mb > 0 && ws_mb > g_rows_cache_mb) continue;
-                const double cost_sel = (double)n_trees / tc * (double)N * rows_per_row(tc) * scale + convert;
-                if (best_sel < 0 || cost_sel < best_sel) {
-                    best_sel = cost_sel;
-                    tc_sel = tc;
-                }
-            }
-            if (tc_sel) {
-                double passes = (double)(n_trees / tc_sel);
-                for (uint32_t t0 = n_trees / tc_sel * tc_sel; t0 < n_trees;) {
+                double ns_per_row = n_trees / tc ? launch_ns_per_row(tc, n_trees / tc) : 0.0;
+                for (uint32_t t0 = n_trees / tc * tc; t0 < n_trees;) {
                     const uint32_t rem = n_trees - t0;
-                    uint32_t tcv = tc_sel;
+                    uint32_t tcv = tc;
                     while (tcv > 2 && tcv > rem) tcv >>= 1;
-                    for (uint32_t up = tcv << 1; up <= tc_sel && tcv < rem; up <<= 1)
+                    for (uint32_t up = tcv << 1; up <= tc && tcv < rem; up <<= 1)
                         if (up >= rem && up - rem <= (up >= 16 ? 3u : 1u)) tcv = up;
-                    passes += (double)tcv / tc_sel;
+                    ns_per_row += launch_ns_per_row(tcv, 1);
                     t0 += std::min(tcv, rem);
                 }
-                const double cost_rows = passes * (double)N * rows_per_row(tc_sel) * scale + convert;
-                if (cost_rows < best || g_rows_force == 1) {
+                const double cost_rows = (double)N * ns_per_row * scale + convert;
+                if (cost_rows < best || (g_rows_force == 1 && row_tc == 0)) {
                     best = std::min(best, cost_rows);
-                    row_tc = tc_sel;
+                    row_tc = tc;
                 }
             }
             best_cost = best;
