@@ -827,10 +827,10 @@ def build_10m(args, rank, world, device, sync, ds, result):
                     "staging_s": t2 - t0, "staging_calls_s": t1 - t0, "staging_gb_per_s": n * DIMS * 4 / (t2 - t0) / 1e9,
                     "first_build_s": t3 - t2b, "total_s": (t2 - t0) + (t3 - t2b), "first_build_library_s": f.stats["seconds_total"],
                     "first_build_device_s": f.stats["seconds_device"],
-                    "note": "ah_dataset_reserve_build runs under the staging: on a box whose HBM is fresh the driver's allocation of "
-                            "the ~64 GB the first build needs (binary16 / int8 copies + scratch; ~20 ms per fresh GB, serialised with "
-                            "the copies) shows up in staging_s (1.7-1.8 s instead of 0.6) rather than in first_build_s (2.6 s without "
-                            "the call); total_s is 3.3 s either way there, 2.1 s on a box whose HBM was used before"}
+                    "note": "ah_dataset_reserve_build runs under the staging.  The driver wipes released or never-used HBM at ~33 GB/s "
+                            "and a hipMalloc handed such memory waits for it (scripts/micro/fresh_hbm2.py): as the first process on a box "
+                            "this leg's ~95 GB reach past the clean range and staging_s is 1.7-1.8 s instead of 0.6 (without the call "
+                            "first_build_s would be 2.6 s instead); total_s is 3.3 s either way there, 2.1 s behind other GPU processes"}
             f.close()
         else:
             ds.fill_synthetic(SEED, 1, n)
