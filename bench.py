@@ -799,6 +799,10 @@ def build_10m(args, rank, world, device, sync, ds, result):
     seeds = shard.tree_seeds(SEED, trees)
     out, cold, host_vecs = {}, None, None
     if ds is None:
+        # This leg starts from a process that holds nothing: what the legs before it left in the library's device cache goes back
+        # to the driver here.  The driver wipes released HBM in the background (~33 GB/s) — the CPU leg below gives it
+        # the time — and a cold build should not find its buffers in another leg's leftovers either.
+        ahlib.device_cache_trim()
         ds = Dataset(distances.Cosine, DIMS, n, device=device)
         why = "--no-e2e" if args.no_e2e else ("one host copy per rank would not fit" if world > 1 else None)
         if why is None:
@@ -827,10 +831,10 @@ def build_10m(args, rank, world, device, sync, ds, result):
                     "staging_s": t2 - t0, "staging_calls_s": t1 - t0, "staging_gb_per_s": n * DIMS * 4 / (t2 - t0) / 1e9,
                     "first_build_s": t3 - t2b, "total_s": (t2 - t0) + (t3 - t2b), "first_build_library_s": f.stats["seconds_total"],
                     "first_build_device_s": f.stats["seconds_device"],
-                    "note": "ah_dataset_reserve_build runs under the staging.  The driver wipes released or never-used HBM at ~33 GB/s "
-                            "and a hipMalloc handed such memory waits for it (scripts/micro/fresh_hbm2.py): as the first process on a box "
-                            "this leg's ~95 GB reach past the clean range and staging_s is 1.7-1.8 s instead of 0.6 (without the call "
-                            "first_build_s would be 2.6 s instead); total_s is 3.3 s either way there, 2.1 s behind other GPU processes"}
+                    "note": "ah_dataset_reserve_build runs under the staging.  The driver wipes released HBM at ~33 GB/s and a hipMalloc "
+                            "handed such memory waits for it (scripts/micro/fresh_hbm2.py); the legs before this one give their device "
+                            "memory back (ah_device_cache_trim) before the CPU leg, so that this one finds clean memory: total_s 2.1 s "
+                            "(3.3 s when their ~25 GB stayed cached and this leg's ~95 GB reached past the clean range of a fresh box)"}
             f.close()
         else:
             ds.fill_synthetic(SEED, 1, n)
