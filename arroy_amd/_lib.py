@@ -169,6 +169,7 @@ SIGNATURES = {
     "ah_tuning_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ah_tuning_reset": (C.c_int, []),
     "ah_debug_launch_coverage": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _U32P, C.c_uint64]),
+    "ah_debug_dense_tiles": (C.c_int, [C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ah_forest_visit": (C.c_int, [_VP, _VP, _VP]),
     "ah_forest_destroy": (C.c_int, [_VP]),
     "ah_index_create": (C.c_int, [_VP, _VP, C.POINTER(C.c_void_p)]),
@@ -294,7 +295,9 @@ def launch_coverage(kind: int, n_rows: int, dims: int, a: int, b: int = 0, devic
     if kind == 0:
         shape = (b, n_rows)
     elif kind == 1:
-        shape = ((n_rows + 255) // 256, (a + (255 if a > 128 else 127)) // (256 if a > 128 else 128))
+        tr, tc = C.c_uint32(0), C.c_uint32(0)
+        check(lib().ah_debug_dense_tiles(n_rows, a, C.byref(tr), C.byref(tc)))
+        shape = ((n_rows + tr.value - 1) // tr.value, (a + tc.value - 1) // tc.value)
     else:
         shape = (a, (n_rows + 1023) // 1024)
     out = np.zeros(shape, dtype=np.uint32)

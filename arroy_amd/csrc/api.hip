@@ -18,15 +18,35 @@ namespace ah {
 static thread_local std::string g_error;
 static thread_local ah_error_detail g_detail = {AH_OK, 0, 0, 0};
 
+static thread_local int g_guard_depth = 0;  // > 0: this thread is inside an extern "C" entry point (guarded(), common.h)
+
 void set_error(const char *fmt, ...) {
     char buf[1024];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    g_error = buf;
+    const int depth = g_guard_depth;
+    g_guard_depth = 0;  // (the message itself is never the allocation that AH_FAIL_ALLOC_AFTER fails)
+    try {
+        g_error = buf;
+    } catch (...) {  // not even the message fits in memory: the status code still says what happened
+        g_error.clear();
+    }
+    g_guard_depth = depth;
     g_detail = ah_error_detail{AH_ERR_DEVICE, 0, 0, 0};
 }
+int guard_enter() { return g_guard_depth++; }
+void guard_leave() { g_guard_depth--; }
+int guard_failed(const char *what, int kind, const char *text) noexcept {
+    const int status = kind == 0 ? AH_ERR_OUT_OF_MEMORY : AH_ERR_DEVICE;
+    if (kind == 0) set_error("%s: host allocation failed", what);
+    else if (kind == 1) set_error("%s: unexpected C++ exception: %s", what, text ? text : "");
+    else set_error("%s: unexpected C++ exception", what);
+    set_error_status(status);
+    return status;
+}
+bool guard_active() { return g_guard_depth > 0; }
 void set_error_status(int status) { g_detail.status = status; }
 void set_error_detail(uint32_t item, uint64_t expected, uint64_t received) {
     g_detail.item = item;
@@ -82,6 +102,7 @@ int Context::ensure_pinned(size_t bytes) {
     if (h_pinned) AH_HIP(hipHostFree(h_pinned));
     h_pinned = nullptr;
     h_cap = 0;
+    AH_REQUIRE(!fail_alloc_tick(), AH_ERR_OUT_OF_MEMORY, "pinned host allocation of %zu bytes failed (AH_FAIL_ALLOC_AFTER)", cap);
     AH_HIP(hipHostMalloc(&h_pinned, cap, hipHostMallocDefault));
     h_cap = cap;
     return AH_OK;
@@ -114,6 +135,41 @@ inline size_t dev_round(size_t bytes) {  // whole 2 MiB for the big blocks (what
     return (std::max<size_t>(bytes, 1) + g - 1) / g * g;
 }
 }  // namespace
+
+// AH_FAIL_ALLOC_AFTER=n (test aid): the n-th allocation counted from the moment the tunable was set fails — device blocks
+// (dev_malloc), pinned host memory, the forests' host blobs and every `operator new` of this library (below).
+bool fail_alloc_tick() {
+    if (tun(TUN_FAIL_ALLOC_AFTER) <= 0) return false;
+    TunableSlot &t = tunable_table()[TUN_FAIL_ALLOC_AFTER];
+    long long v = t.value.load(std::memory_order_relaxed);
+    while (v > 0)
+        if (t.value.compare_exchange_weak(v, v - 1, std::memory_order_relaxed)) return v == 1;
+    return false;
+}
+
+namespace {
+std::atomic<int> g_live_datasets[64];
+std::atomic<int> g_live_total{0};
+}  // namespace
+void dataset_born(int device) {
+    g_live_datasets[device & 63].fetch_add(1, std::memory_order_relaxed);
+    g_live_total.fetch_add(1, std::memory_order_relaxed);
+}
+void dataset_gone(int device) {
+    const bool last_here = g_live_datasets[device & 63].fetch_sub(1, std::memory_order_acq_rel) == 1;
+    const bool last = g_live_total.fetch_sub(1, std::memory_order_acq_rel) == 1;
+    if (tun(TUN_CACHE_KEEP_IDLE) != 0) return;
+    if (last_here) (void)dev_cache_trim(device);
+    if (last) (void)host_cache_trim();
+}
+
+size_t dev_cache_live_bytes(int device) {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    size_t n = 0;
+    for (const DevBlock &b : g_dev_live)
+        if (device < 0 || b.device == device) n += b.bytes;
+    return n;
+}
 
 size_t dev_cache_trim(int device) {
     std::vector<DevBlock> drop;
@@ -149,8 +205,9 @@ size_t dev_cache_idle_bytes(int device) {
     return n;
 }
 
-hipError_t dev_malloc(void **p, size_t bytes) {
+hipError_t dev_malloc(void **p, size_t bytes, bool optional) {
     *p = nullptr;
+    if (fail_alloc_tick()) return hipErrorOutOfMemory;
     int device = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
@@ -177,7 +234,7 @@ hipError_t dev_malloc(void **p, size_t bytes) {
     }
     void *q = nullptr;
     e = hipMalloc(&q, want);
-    if (e != hipSuccess && dev_cache_trim(device) > 0) {  // out of memory with idle blocks on the shelf: give them back, retry
+    if (e != hipSuccess && !optional && dev_cache_trim(device) > 0) {  // out of memory with idle blocks on the shelf: give them back, retry
         (void)hipGetLastError();
         e = hipMalloc(&q, want);
     }
@@ -190,17 +247,43 @@ hipError_t dev_malloc(void **p, size_t bytes) {
     return hipSuccess;
 }
 
+// idle blocks beyond the budget, oldest first (called with g_dev_mu held; the caller frees them after unlocking)
+static void dev_idle_over_budget(size_t limit, std::vector<DevBlock> *drop) {
+    while (g_dev_idle_bytes > limit && !g_dev_idle.empty()) {
+        drop->push_back(g_dev_idle.front());
+        g_dev_idle_bytes -= g_dev_idle.front().bytes;
+        g_dev_idle.erase(g_dev_idle.begin());
+    }
+}
+static void dev_release_blocks(const std::vector<DevBlock> &drop) {
+    for (const DevBlock &b : drop) {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != b.device) (void)hipSetDevice(b.device);
+        (void)hipFree(b.p);
+        if (cur >= 0 && cur != b.device) (void)hipSetDevice(cur);
+    }
+}
+
 hipError_t dev_free_unused(void *p) {
     if (!p) return hipSuccess;
-    std::lock_guard<std::mutex> lk(g_dev_mu);
-    for (size_t i = 0; i < g_dev_live.size(); i++)
-        if (g_dev_live[i].p == p) {
-            g_dev_idle.push_back(g_dev_live[i]);
-            g_dev_idle_bytes += g_dev_live[i].bytes;
-            g_dev_live.erase(g_dev_live.begin() + (ptrdiff_t)i);
-            return hipSuccess;
-        }
-    return hipErrorInvalidValue;
+    const size_t limit = (size_t)std::max<long long>(0, tun(TUN_DEVICE_CACHE_MB)) << 20;
+    std::vector<DevBlock> drop;
+    hipError_t e = hipErrorInvalidValue;
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        for (size_t i = 0; i < g_dev_live.size(); i++)
+            if (g_dev_live[i].p == p) {
+                g_dev_idle.push_back(g_dev_live[i]);
+                g_dev_idle_bytes += g_dev_live[i].bytes;
+                g_dev_live.erase(g_dev_live.begin() + (ptrdiff_t)i);
+                e = hipSuccess;
+                break;
+            }
+        dev_idle_over_budget(limit, &drop);  // (ah_dataset_reserve_build parks tens of GB: within the same budget)
+    }
+    dev_release_blocks(drop);
+    return e;
 }
 
 hipError_t dev_free(void *p) {
@@ -229,19 +312,9 @@ hipError_t dev_free(void *p) {
         std::lock_guard<std::mutex> lk(g_dev_mu);
         g_dev_idle.push_back(blk);
         g_dev_idle_bytes += blk.bytes;
-        while (g_dev_idle_bytes > limit && !g_dev_idle.empty()) {  // over the budget: the oldest go back to the driver
-            drop.push_back(g_dev_idle.front());
-            g_dev_idle_bytes -= g_dev_idle.front().bytes;
-            g_dev_idle.erase(g_dev_idle.begin());
-        }
+        dev_idle_over_budget(limit, &drop);  // over the budget: the oldest go back to the driver
     }
-    for (const DevBlock &b : drop) {
-        int cur = -1;
-        (void)hipGetDevice(&cur);
-        if (cur != b.device) (void)hipSetDevice(b.device);
-        (void)hipFree(b.p);
-        if (cur >= 0 && cur != b.device) (void)hipSetDevice(cur);
-    }
+    dev_release_blocks(drop);
     return e;
 }
 
@@ -411,7 +484,35 @@ static void parallel_rows(size_t n, size_t bytes_per_item, F &&fn) {
     });
 }
 
+bool guard_active();
 }  // namespace ah
+
+// The library's own allocation functions (hidden visibility: they replace `operator new` for the objects linked into
+// libarroy_hip.so only, never for the embedding process).  malloc / free underneath, like libstdc++'s, so memory may cross
+// between the two; the one addition is AH_FAIL_ALLOC_AFTER (common.h): inside an entry point the n-th allocation throws
+// std::bad_alloc, which is how tests/test_gpu_faults.py proves that every entry point turns it into a status code.
+static inline void *ah_alloc_or_null(size_t n) {
+    if (ah::guard_active() && ah::fail_alloc_tick()) return nullptr;
+    return malloc(n ? n : 1);
+}
+void *operator new(size_t n) {
+    void *p = ah_alloc_or_null(n);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void *operator new[](size_t n) {
+    void *p = ah_alloc_or_null(n);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void *operator new(size_t n, const std::nothrow_t &) noexcept { return ah_alloc_or_null(n); }
+void *operator new[](size_t n, const std::nothrow_t &) noexcept { return ah_alloc_or_null(n); }
+void operator delete(void *p) noexcept { free(p); }
+void operator delete[](void *p) noexcept { free(p); }
+void operator delete(void *p, size_t) noexcept { free(p); }
+void operator delete[](void *p, size_t) noexcept { free(p); }
+void operator delete(void *p, const std::nothrow_t &) noexcept { free(p); }
+void operator delete[](void *p, const std::nothrow_t &) noexcept { free(p); }
 
 using namespace ah;
 
@@ -489,12 +590,15 @@ size_t ah_vector_size(int metric, uint32_t dimensions) {
 int ah_abi_version(void) { return AH_ABI_VERSION; }
 const char *ah_last_error(void) { return ah::last_error(); }
 int ah_last_error_detail(ah_error_detail *out) {
+    AH_GUARDED("ah_last_error_detail")
     if (!out) return AH_ERR_INVALID_ARGUMENT;
     *out = g_detail;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_device_count(int *out_count) {
+    AH_GUARDED("ah_device_count")
     AH_REQUIRE(out_count, AH_ERR_INVALID_ARGUMENT, "out_count is NULL");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -504,15 +608,18 @@ int ah_device_count(int *out_count) {
     }
     *out_count = n;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_device_name(int device, char *buf, size_t buf_len) {
+    AH_GUARDED("ah_device_name")
     AH_REQUIRE(buf && buf_len, AH_ERR_INVALID_ARGUMENT, "buf is NULL");
     hipDeviceProp_t p;
     AH_HIP(hipGetDeviceProperties(&p, device));
     snprintf(buf, buf_len, "%s (%s, %d CUs, %.1f GiB)", p.name, p.gcnArchName, p.multiProcessorCount,
              (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
     return AH_OK;
+    AH_GUARDED_END
 }
 
 static TunableSlot *find_tunable(const char *name) {
@@ -522,28 +629,35 @@ static TunableSlot *find_tunable(const char *name) {
     return nullptr;
 }
 int ah_tuning_set(const char *name, int64_t value) {
+    AH_GUARDED("ah_tuning_set")
     TunableSlot *t = find_tunable(name);
     AH_REQUIRE(t, AH_ERR_INVALID_ARGUMENT, "unknown tunable %s", name ? name : "(null)");
     t->value.store(value, std::memory_order_relaxed);
     return AH_OK;
+    AH_GUARDED_END
 }
 int ah_tuning_get(const char *name, int64_t *out_value, int64_t *out_default) {
+    AH_GUARDED("ah_tuning_get")
     TunableSlot *t = find_tunable(name);
     AH_REQUIRE(t, AH_ERR_INVALID_ARGUMENT, "unknown tunable %s", name ? name : "(null)");
     if (out_value) *out_value = t->value.load(std::memory_order_relaxed);
     if (out_default) *out_default = t->def;
     return AH_OK;
+    AH_GUARDED_END
 }
 int ah_tuning_reset(void) {
+    AH_GUARDED("ah_tuning_reset")
     TunableSlot *t = tunable_table();
     for (int i = 0; i < TUN_COUNT; i++) t[i].value.store(t[i].def, std::memory_order_relaxed);
     return AH_OK;
+    AH_GUARDED_END
 }
 
 // ---------------------------------------------------------------------------------------------
 // dataset
 // ---------------------------------------------------------------------------------------------
 int ah_dataset_create(int metric, uint32_t dimensions, uint64_t capacity, int device, ah_dataset **out) {
+    AH_GUARDED("ah_dataset_create")
     AH_REQUIRE(out, AH_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     AH_REQUIRE(metric_valid(metric), AH_ERR_INVALID_ARGUMENT, "unknown metric %d", metric);
@@ -583,15 +697,19 @@ int ah_dataset_create(int metric, uint32_t dimensions, uint64_t capacity, int de
         ah_dataset_destroy(ds);
         return st;
     }
+    dataset_born(device);
+    ds->counted = true;
     *out = ds;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 static int upload_flush(ah_dataset *ds);
 
 int ah_dataset_destroy(ah_dataset *ds) {
+    AH_GUARDED("ah_dataset_destroy")
     if (!ds) return AH_OK;
-    if (ds->reserve_thread.joinable()) ds->reserve_thread.join();
+    ds->join_reserve();
     (void)upload_flush(ds);
     (void)hipSetDevice(ds->device);
     (void)hipDeviceSynchronize();
@@ -625,8 +743,12 @@ int ah_dataset_destroy(ah_dataset *ds) {
     if (ds->d_headers) (void)dev_free(ds->d_headers);
     if (ds->d_ids) (void)dev_free(ds->d_ids);
     if (ds->d_lut) (void)dev_free(ds->d_lut);
+    const bool counted = ds->counted;
+    const int device = ds->device;
     delete ds;
+    if (counted) dataset_gone(device);  // the last dataset of the device / the process: the caches go back (common.h)
     return AH_OK;
+    AH_GUARDED_END
 }
 
 static int check_append(ah_dataset *ds, const uint32_t *item_ids, size_t n) {
@@ -700,6 +822,7 @@ static int upload_context(ah_dataset *ds, size_t buf_bytes, Context **out) {
 // LMDB pages -> pinned staging (header and vector split apart, rows re-pitched to 128-byte lines) -> hipMemcpyAsync.
 int ah_dataset_upload_records(ah_dataset *ds, const uint32_t *item_ids, const uint8_t *const *record_ptrs,
                               size_t record_len, size_t n) {
+    AH_GUARDED("ah_dataset_upload_records")
     AH_TRY(check_append(ds, item_ids, n));
     if (n == 0) return AH_OK;
     AH_REQUIRE(item_ids && record_ptrs, AH_ERR_INVALID_ARGUMENT, "NULL input");
@@ -757,10 +880,12 @@ int ah_dataset_upload_records(ah_dataset *ds, const uint32_t *item_ids, const ui
     // `DotProduct::preprocess` ran over the database (src/distance/dot_product.rs:119-165), so the dataset still needs
     // ah_preprocess_dot unless the caller states that the database was preprocessed (ah_dataset_set_preprocessed).
     return AH_OK;
+    AH_GUARDED_END
 }
 
 // Writer::add_item for a batch: stage f32 rows, then codec + new_header on device.
 int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, const float *vectors, size_t n) {
+    AH_GUARDED("ah_dataset_upload_vectors")
     AH_TRY(check_append(ds, item_ids, n));
     if (n == 0) return AH_OK;
     AH_REQUIRE(item_ids && vectors, AH_ERR_INVALID_ARGUMENT, "NULL input");
@@ -850,21 +975,27 @@ int ah_dataset_upload_vectors(ah_dataset *ds, const uint32_t *item_ids, const fl
                         "launch/other %.4f s, note_ids %.4f s\n",
                 n, ds->dims, secs(t_begin, t_ctx), t_gather, t_wait, secs(t_ctx, t_loop) - t_gather - t_wait, secs(t_loop, now()));
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_dataset_upload_flush(ah_dataset *ds) {
+    AH_GUARDED("ah_dataset_upload_flush")
     AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
     return upload_flush(ds);
+    AH_GUARDED_END
 }
 
 int ah_dataset_set_preprocessed(ah_dataset *ds, int preprocessed) {
+    AH_GUARDED("ah_dataset_set_preprocessed")
     AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
     AH_REQUIRE(ds->metric == AH_DOT_PRODUCT, AH_ERR_INVALID_ARGUMENT, "only DotProduct datasets have a preprocess step");
     ds->dot_preprocessed = preprocessed != 0;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_dataset_fill_synthetic(ah_dataset *ds, uint64_t seed, int distribution, uint64_t n_items) {
+    AH_GUARDED("ah_dataset_fill_synthetic")
     AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
     AH_REQUIRE(!ds->finalized && ds->n == 0, AH_ERR_INVALID_ARGUMENT, "synthetic fill needs an empty dataset");
     AH_REQUIRE(n_items <= ds->capacity, AH_ERR_INVALID_ARGUMENT, "n_items exceeds capacity");
@@ -893,9 +1024,11 @@ int ah_dataset_fill_synthetic(ah_dataset *ds, uint64_t seed, int distribution, u
     ds->last_id = n_items ? (uint32_t)(n_items - 1) : 0;
     ds->h_ids.clear();  // identity: no host mirror needed
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_dataset_finalize(ah_dataset *ds) {
+    AH_GUARDED("ah_dataset_finalize")
     AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
     if (ds->finalized) return AH_OK;
     AH_TRY(upload_flush(ds));  // every staged record has landed
@@ -918,12 +1051,15 @@ int ah_dataset_finalize(ah_dataset *ds) {
     }
     ds->finalized = true;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_dataset_len(const ah_dataset *ds, uint64_t *out_n_items) {
+    AH_GUARDED("ah_dataset_len")
     AH_REQUIRE(ds && out_n_items, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     *out_n_items = ds->n;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 // One staged dataset -> a replica on another GPU of the node, device to device over xGMI (hipMemcpyPeerAsync): the
@@ -932,6 +1068,7 @@ int ah_dataset_len(const ah_dataset *ds, uint64_t *out_n_items) {
 // the source (finalized or not, DotProduct preprocessed or not); the binary16 shadow is rebuilt on the replica on
 // demand (a 10 ms kernel) rather than copied.
 int ah_dataset_replicate(ah_dataset *src, int device, ah_dataset **out) {
+    AH_GUARDED("ah_dataset_replicate")
     AH_REQUIRE(out, AH_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     AH_REQUIRE(src, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
@@ -999,6 +1136,7 @@ int ah_dataset_replicate(ah_dataset *src, int device, ah_dataset **out) {
     }
     *out = dst;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 // host-side id -> row (the host mirror is only used to validate single ids; lists are resolved on device)
@@ -1029,6 +1167,7 @@ static int host_row_of_id(const ah_dataset *ds, uint32_t id, uint32_t *row) {
     AH_REQUIRE((ds)->finalized, AH_ERR_NOT_FINALIZED, "dataset not finalized (call ah_dataset_finalize)")
 
 int ah_dataset_item_vector(ah_dataset *ds, uint32_t item_id, float *out_vector) {
+    AH_GUARDED("ah_dataset_item_vector")
     AH_NEED_FINALIZED(ds);
     AH_REQUIRE(out_vector, AH_ERR_INVALID_ARGUMENT, "out_vector is NULL");
     uint32_t row;
@@ -1041,9 +1180,11 @@ int ah_dataset_item_vector(ah_dataset *ds, uint32_t item_id, float *out_vector) 
     AH_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(out_vector, ctx->h_pinned, (size_t)ds->dims * 4);
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_dataset_read_headers(ah_dataset *ds, uint64_t first_row, uint64_t n, void *out_headers) {
+    AH_GUARDED("ah_dataset_read_headers")
     AH_REQUIRE(ds && out_headers, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     AH_REQUIRE(first_row + n <= ds->n, AH_ERR_INVALID_ARGUMENT, "row range out of bounds");
     AH_TRY(upload_flush(ds));
@@ -1052,9 +1193,11 @@ int ah_dataset_read_headers(ah_dataset *ds, uint64_t first_row, uint64_t n, void
     AH_HIP(hipMemcpy(out_headers, reinterpret_cast<uint8_t *>(ds->d_headers) + first_row * hs, n * hs,
                      hipMemcpyDeviceToHost));
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_preprocess_dot(ah_dataset *ds, float *out_max_norm) {
+    AH_GUARDED("ah_preprocess_dot")
     AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
     AH_REQUIRE(ds->metric == AH_DOT_PRODUCT, AH_ERR_INVALID_ARGUMENT, "preprocess is only defined for DotProduct");
     AH_TRY(upload_flush(ds));
@@ -1067,6 +1210,7 @@ int ah_preprocess_dot(ah_dataset *ds, float *out_max_norm) {
     ds->dot_preprocessed = true;
     if (out_max_norm) *out_max_norm = m;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1146,11 +1290,15 @@ static int distances_impl(ah_dataset *ds, const float *query, const uint32_t *qu
 }
 
 int ah_distances_by_vector(ah_dataset *ds, const float *query, const uint32_t *item_ids, size_t n, float *out) {
+    AH_GUARDED("ah_distances_by_vector")
     AH_REQUIRE(query, AH_ERR_INVALID_ARGUMENT, "query is NULL");
     return distances_impl(ds, query, nullptr, item_ids, n, out);
+    AH_GUARDED_END
 }
 int ah_distances_by_item(ah_dataset *ds, uint32_t query_item, const uint32_t *item_ids, size_t n, float *out) {
+    AH_GUARDED("ah_distances_by_item")
     return distances_impl(ds, nullptr, &query_item, item_ids, n, out);
+    AH_GUARDED_END
 }
 
 static int rerank_impl(ah_dataset *ds, const float *query, const uint32_t *query_item, const uint32_t *sorted_ids,
@@ -1198,12 +1346,16 @@ static int rerank_impl(ah_dataset *ds, const float *query, const uint32_t *query
 
 int ah_rerank_by_vector(ah_dataset *ds, const float *query, const uint32_t *sorted_ids, size_t n, size_t k,
                         uint32_t *out_ids, float *out_distances, size_t *out_n) {
+    AH_GUARDED("ah_rerank_by_vector")
     AH_REQUIRE(query, AH_ERR_INVALID_ARGUMENT, "query is NULL");
     return rerank_impl(ds, query, nullptr, sorted_ids, n, k, out_ids, out_distances, out_n);
+    AH_GUARDED_END
 }
 int ah_rerank_by_item(ah_dataset *ds, uint32_t query_item, const uint32_t *sorted_ids, size_t n, size_t k,
                       uint32_t *out_ids, float *out_distances, size_t *out_n) {
+    AH_GUARDED("ah_rerank_by_item")
     return rerank_impl(ds, nullptr, &query_item, sorted_ids, n, k, out_ids, out_distances, out_n);
+    AH_GUARDED_END
 }
 
 // Many queries in one submission.  Fast path (k <= 2048): five launches for the whole batch (batch.hip).
@@ -1383,6 +1535,7 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
 
 int ah_rerank_batch(ah_dataset *ds, const float *queries, size_t n_queries, const uint32_t *ids,
                     const uint64_t *offsets, size_t k, uint32_t *out_ids, float *out_distances, uint32_t *out_counts) {
+    AH_GUARDED("ah_rerank_batch")
     AH_NEED_FINALIZED(ds);
     AH_REQUIRE(queries && ids && offsets && out_ids && out_distances && out_counts, AH_ERR_INVALID_ARGUMENT,
                "NULL argument");
@@ -1419,6 +1572,7 @@ int ah_rerank_batch(ah_dataset *ds, const float *queries, size_t n_queries, cons
         q0 = q1;
     }
     return AH_OK;
+    AH_GUARDED_END
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1426,6 +1580,7 @@ int ah_rerank_batch(ah_dataset *ds, const float *queries, size_t n_queries, cons
 // ---------------------------------------------------------------------------------------------
 int ah_split_sides(ah_dataset *ds, const void *normal_vector, const void *normal_header, const uint32_t *sorted_ids,
                    size_t n, uint8_t *side_bits, uint64_t *out_n_left, float *out_margins) {
+    AH_GUARDED("ah_split_sides")
     AH_NEED_FINALIZED(ds);
     AH_REQUIRE(normal_vector && normal_header && side_bits && out_n_left, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     if (!sorted_ids) n = ds->n;
@@ -1476,12 +1631,14 @@ int ah_split_sides(ah_dataset *ds, const void *normal_vector, const void *normal
     if (out_margins) memcpy(out_margins, h_marg, n * 4);
     *out_n_left = *h_left;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 // `D::margin(&normal, query_leaf)` for many stored normals at once: the dataset's ROWS are split-plane normals
 // (header = the normal's header), the broadcast operand is the query leaf.  src/reader.rs:366-369.
 int ah_margins(ah_dataset *normals, const void *leaf_vector, const void *leaf_header, const uint32_t *item_ids,
                size_t n, float *out_margins) {
+    AH_GUARDED("ah_margins")
     ah_dataset *ds = normals;
     AH_NEED_FINALIZED(ds);
     AH_REQUIRE(leaf_vector && leaf_header && (out_margins || n == 0), AH_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -1520,10 +1677,12 @@ int ah_margins(ah_dataset *normals, const void *leaf_vector, const void *leaf_he
     AH_TRY(check_err_flags(*h_err, false));
     memcpy(out_margins, h_m, n * 4);
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_create_split(ah_dataset *ds, const uint32_t sample_ids[AH_SPLIT_SAMPLES], void *out_normal_vector,
                     void *out_normal_header) {
+    AH_GUARDED("ah_create_split")
     AH_NEED_FINALIZED(ds);
     AH_REQUIRE(sample_ids && out_normal_vector && out_normal_header, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     AH_REQUIRE(ds->metric != AH_DOT_PRODUCT || ds->dot_preprocessed, AH_ERR_NEED_PREPROCESS,
@@ -1550,6 +1709,7 @@ int ah_create_split(ah_dataset *ds, const uint32_t sample_ids[AH_SPLIT_SAMPLES],
     memcpy(out_normal_vector, h_nv, vs);
     memcpy(out_normal_header, h_nh, hs);
     return AH_OK;
+    AH_GUARDED_END
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1557,6 +1717,7 @@ int ah_create_split(ah_dataset *ds, const uint32_t sample_ids[AH_SPLIT_SAMPLES],
 // ---------------------------------------------------------------------------------------------
 int ah_bench_scan(ah_dataset *ds, uint32_t query_item, uint64_t n, uint32_t iterations, float *out,
                   double *out_ms_total) {
+    AH_GUARDED("ah_bench_scan")
     AH_NEED_FINALIZED(ds);
     AH_REQUIRE(out_ms_total && iterations > 0 && n > 0 && n <= ds->n, AH_ERR_INVALID_ARGUMENT, "bad arguments");
     AH_LEASE(ds, ctx);
@@ -1575,9 +1736,11 @@ int ah_bench_scan(ah_dataset *ds, uint32_t query_item, uint64_t n, uint32_t iter
     *out_ms_total = ms;
     if (out) AH_HIP(hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost));
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_bench_memcpy(int device, uint64_t bytes, uint32_t iterations, double *out_ms_total) {
+    AH_GUARDED("ah_bench_memcpy")
     AH_REQUIRE(out_ms_total && iterations > 0 && bytes > 0, AH_ERR_INVALID_ARGUMENT, "bad arguments");
     AH_HIP(hipSetDevice(device));
     DevMem a, b;
@@ -1601,9 +1764,11 @@ int ah_bench_memcpy(int device, uint64_t bytes, uint32_t iterations, double *out
     AH_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
     *out_ms_total = ms;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_bench_read(int device, uint64_t bytes, uint32_t iterations, double *out_ms_total) {
+    AH_GUARDED("ah_bench_read")
     AH_REQUIRE(out_ms_total && iterations > 0 && bytes >= 4096, AH_ERR_INVALID_ARGUMENT, "bad arguments");
     AH_HIP(hipSetDevice(device));
     DevMem a, sink;
@@ -1628,6 +1793,7 @@ int ah_bench_read(int device, uint64_t bytes, uint32_t iterations, double *out_m
     AH_HIP(hipEventElapsedTime(&ms, c.ev0, c.ev1));
     *out_ms_total = ms;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 }  // extern "C"

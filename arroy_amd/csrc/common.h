@@ -7,8 +7,10 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -27,6 +29,34 @@ const char *last_error();
 // status, the sites that know more add the item id or the expected / received sizes
 void set_error_status(int status);
 void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
+
+// Every `extern "C"` entry point runs its body through guarded(): no C++ exception crosses the ABI (the reference catches
+// worker panics at src/writer.rs:799-827 and turns them into Error::Panic, src/error.rs:84-85).  std::bad_alloc becomes
+// AH_ERR_OUT_OF_MEMORY, anything else AH_ERR_DEVICE, both with ah_last_error() text.  While a thread is inside guarded()
+// the library's own `operator new` (api.hip) honours AH_FAIL_ALLOC_AFTER — only there: helper threads have nobody to
+// catch for them.
+int guard_enter();            // returns the previous depth
+void guard_leave();
+int guard_failed(const char *what, int kind, const char *text) noexcept;  // kind 0: bad_alloc, 1: std::exception, 2: unknown
+template <class F>
+inline int guarded(const char *what, F &&f) noexcept {
+    struct Scope {
+        Scope() { guard_enter(); }
+        ~Scope() { guard_leave(); }
+    } scope;
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return guard_failed(what, 0, nullptr);
+    } catch (const std::exception &e) {
+        return guard_failed(what, 1, e.what());
+    } catch (...) {
+        return guard_failed(what, 2, nullptr);
+    }
+}
+#define AH_GUARDED(name) return ::ah::guarded(name, [&]() -> int {
+#define AH_GUARDED_END \
+    });
 
 #define AH_HIP(expr)                                                                               \
     do {                                                                                           \
@@ -88,6 +118,10 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
     X(MASK_BITS, "AH_MASK_BITS", -1)            /* 0 / 1: never / always pack a row-major level's sides into bits before the tiles gather them; -1: by size */ \
     X(DENSE, "AH_DENSE", -1)                    /* 0: never the dense MFMA screen; 1: whenever legal; -1: cost model */    \
     X(DENSE_MAX_COLS, "AH_DENSE_MAX_COLS", 16384)                                                                        \
+    X(DENSE_NARROW, "AH_DENSE_NARROW", -1)      /* 0: never the narrow dense kernel (rows straight to registers) */         \
+    X(DENSE_NARROW_MAX_COLS, "AH_DENSE_NARROW_MAX_COLS", 256) /* most columns of a level the narrow dense kernel takes */  \
+    X(DENSE_DEBUG, "AH_DENSE_DEBUG", 0)         /* experiments: 1 = narrow kernel without its epilogue, 2 = without its k-loop (WRONG RESULTS) */ \
+    X(DENSE_NARROW_STREAM, "AH_DENSE_NARROW_STREAM", -1) /* 0 / 1: never / always non-temporal row loads there; -1: when one column tile */ \
     X(DENSE_GMACS, "AH_DENSE_GMACS", 495000)    /* sustained multiply-add rate the cost model assumes, 1e9 MAC/s */       \
     X(MARGIN_MODE, "AH_MARGIN_MODE", 0)         /* ah_margin_mode for callers that pass AH_MARGIN_AUTO */                 \
     X(READBACK_DIRECT, "AH_READBACK_DIRECT", 0) /* 1: let the runtime stage the device -> pageable copies */             \
@@ -103,8 +137,10 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
     X(RERANK_SCREEN, "AH_RERANK_SCREEN", 1)     /* 0: ah_rerank_batch never screens its candidates (f32 rows for all) */ \
     X(SEARCH_SCREEN, "AH_SEARCH_SCREEN", 1)     /* 0: the re-rank of ah_search_batch never screens its candidates (f32 rows for all) */ \
     X(HOST_THREADS, "AH_HOST_THREADS", 8)       /* host threads one build may use at a time for its output path */        \
-    X(DEVICE_CACHE_MB, "AH_DEVICE_CACHE_MB", 196608) /* idle HBM the caching allocator keeps instead of returning it to the driver */ \
+    X(DEVICE_CACHE_MB, "AH_DEVICE_CACHE_MB", 98304) /* idle HBM the caching allocator keeps while a dataset lives on the device */ \
     X(HOST_CACHE_MB, "AH_HOST_CACHE_MB", 16384) /* committed host memory of destroyed forests kept for the next build */   \
+    X(CACHE_KEEP_IDLE, "AH_CACHE_KEEP_IDLE", 0) /* 1: keep both caches even when the last dataset (of a device / of the process) is destroyed */ \
+    X(FAIL_ALLOC_AFTER, "AH_FAIL_ALLOC_AFTER", 0) /* test aid: the n-th host / device allocation from now on fails (0 = off) */ \
     X(STAGE_THREADS, "AH_STAGE_THREADS", 0)                                                                              \
     X(STAGE_MEMCPY, "AH_STAGE_MEMCPY", 0)                                                                                \
     X(STAGE_REGISTER, "AH_STAGE_REGISTER", 0)
@@ -138,13 +174,24 @@ inline void parallel_run(unsigned n, F fn) {
 // scratch, and a hipMalloc that lands on memory the driver is still scrubbing after a hipFree was measured to take a
 // SECOND (r04: the first launch of every second build waited 0.9 - 1.1 s for its buffers).  dev_free keeps hipFree's
 // implicit device synchronisation, so no caller can free a block a queued kernel still uses.
-//   AH_DEVICE_CACHE_MB: most bytes kept idle per process (default 196608; 0 = plain hipMalloc / hipFree).
+//   AH_DEVICE_CACHE_MB: most bytes kept idle per process (default 98304; 0 = plain hipMalloc / hipFree).
+// The cache lives as long as a dataset does: when the LAST dataset of a device is destroyed its idle blocks go back to the
+// driver (and the host blob pool with the last dataset of the process), so an embedding application that is done with the
+// library holds none of its memory (AH_CACHE_KEEP_IDLE=1 keeps them; bench.py sets it between its configurations).
 // ---------------------------------------------------------------------------------------------
-hipError_t dev_malloc(void **p, size_t bytes);  // on the calling thread's current device
+// optional: an allocation the caller can do without (the screens' copies) — no trim-and-retry when the device is full
+hipError_t dev_malloc(void **p, size_t bytes, bool optional = false);  // on the calling thread's current device
 template <typename T>
-inline hipError_t dev_malloc(T **p, size_t bytes) {
-    return dev_malloc(reinterpret_cast<void **>(p), bytes);
+inline hipError_t dev_malloc(T **p, size_t bytes, bool optional = false) {
+    return dev_malloc(reinterpret_cast<void **>(p), bytes, optional);
 }
+// datasets alive per device (ah_dataset_create / _replicate / _destroy): the caches' lifetime
+void dataset_born(int device);
+void dataset_gone(int device);
+size_t host_cache_trim();                    // forest.hip: the pool of destroyed forests' blobs; returns the bytes released
+size_t dev_cache_live_bytes(int device);     // bytes handed out and not yet freed (ah_device_cache_stats)
+// test aid (AH_FAIL_ALLOC_AFTER): true when THIS allocation is the one that must fail
+bool fail_alloc_tick();
 hipError_t dev_free(void *p);
 hipError_t dev_free_unused(void *p);       // a block no kernel or copy ever touched: straight to the idle list, no device wait
 size_t dev_cache_trim(int device);         // device < 0: every device; returns the bytes given back
@@ -256,7 +303,10 @@ struct ah_dataset {
     uint32_t hpitch = 0;
     bool screen_never = false;                   // the screen can never apply to this dataset (1-bit metric, dims < 32)
     bool screen8_decided = false;                // the int8 copy was built or found useless: do not try again
-    bool screen_alloc_failed = false;            // the last attempt failed for lack of memory (retried by the next build)
+    bool screen_alloc_failed = false;            // the last attempt failed for lack of memory (retried by the next BUILD only)
+    // the copies above are published: d_rows_h16 / d_screen_stats / hpitch / screen_max are final and may be read without
+    // `mu` (store-release in ensure_screen after the last of them is written, load-acquire by the search paths)
+    std::atomic<bool> screen_ready{false};
     // staging in flight (ah_dataset_upload_*): the context whose stream / pinned ring the uploads use until
     // ah_dataset_finalize (or ah_dataset_upload_flush) waits for them
     ah::Context *up_ctx = nullptr;
@@ -264,8 +314,24 @@ struct ah_dataset {
     bool up_used[4] = {false, false, false, false};
     std::mutex mu;
     std::vector<ah::Context *> pool;
+    bool counted = false;                        // dataset_born() ran for this handle (its destroy then runs dataset_gone())
     std::thread reserve_thread;                  // ah_dataset_reserve_build: fills the device cache while records are staged
 
+    // Wait for ah_dataset_reserve_build's helper, whoever gets there first (concurrent builds on one dataset are allowed: the
+    // handle is moved out under `mu`, so exactly one caller joins it; a failing join must not cross the C ABI)
+    void join_reserve() {
+        std::thread t;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            t = std::move(reserve_thread);
+        }
+        if (t.joinable()) {
+            try {
+                t.join();
+            } catch (...) {
+            }
+        }
+    }
     ah::DataView view() const;
     size_t row_bytes() const { return ah::metric_is_bq(metric) ? (size_t)pitch * 8 : (size_t)pitch * 4; }
     ah::Context *acquire();
@@ -344,7 +410,9 @@ size_t batch_invert_counter_bytes(uint64_t n_rows, uint64_t n_candidates);
 // forest.hip: the binary16 shadow of an f32 dataset (+ per-row norms), made once per dataset by whoever needs it first — the
 // certified screens of the forest build (want8: also the int8 copies of its node-major stage) or of the search's re-rank.
 // false: not applicable (1-bit metric, dims < 32) or no memory for it right now.
-bool ensure_screen(ah_dataset *ds, hipStream_t s, bool want8);
+// retry_failed: ask for the memory again although an earlier attempt found none (the builds do; the readers do not — a
+// read-only process short on HBM must not allocate, fail and free 2 x dims bytes per item on every call).
+bool ensure_screen(ah_dataset *ds, hipStream_t s, bool want8, bool retry_failed = false);
 
 // search.hip: the certified top-k screen for the candidate lists of ah_rerank_batch (binary16 rows first, f32 for the survivors)
 // (tile_first .. tile_first + n_tiles: the tiles this call screens — the caller may launch the lists group by group while the

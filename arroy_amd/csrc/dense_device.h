@@ -28,6 +28,7 @@ namespace ah {
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kDM = 256;  // rows of X~ per block tile
 // Block tile = 256 rows x (64 WN) normals, WN = 2 or 4: 2 x WN waves, each owning 128 x 64 = 4 x 2 MFMA tiles (128
@@ -234,6 +235,211 @@ __global__ __launch_bounds__(DenseShape<WN>::kThreads, 1) void k_forest_dense_sc
                     const bool decided = screen_decides<METRIC>(s, rs, ns, row_extra, a.gamma_s, a.gamma_r, side);
                     a.side_bytes[(uint64_t)(t + u) * a.n + row] =
                         (uint8_t)(decided ? (a.verify ? (kSideVerify | side) : side) : kSideUndecided);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The narrow product (round 5): levels with a few hundred columns at most, where the product is bound by the 2 * hpitch
+// bytes per row that leave HBM, not by the matrix units.  k_forest_dense_screen stages BOTH operands through LDS with a
+// full `vmcnt(0)` + barrier per k-block and keeps one block of 133 KB per CU: a tile's twelve k-blocks each expose an HBM
+// round trip and nothing overlaps a tile's epilogue — 5.5-9 ms per level where the rows' HBM time is 1.9 ms (10M x 768).
+// Here
+//   * the ROWS never touch LDS: a compute wave owns 32 rows and fetches its A fragments straight into registers, lane
+//     (m, g) the half line [64 g, 64 g + 64) of row m per k-block (4 x 16 B; the two lanes of a row cover the 128-byte
+//     line), two k-blocks ahead of the one being multiplied — 8 KB in flight per wave, across the barriers (raw
+//     `s_barrier`: no memory wait is attached to it);
+//   * only the NORMALS (L2-resident: C x 1.6 KB) go through LDS, a ring of three 64-half k-blocks filled by LDS-DMA two
+//     ahead by a LOADER wave that does nothing else.  The roles are split because hipcc orders every LDS read behind
+//     the latest LDS-DMA of the same wave and, once both kinds of load are pending, waits for `vmcnt(0)`: in a wave that
+//     issues both, the register prefetch is drained every third k-block (seen in the ISA).  A wave that only issues DMA and a
+//     wave that only loads registers get exact counted waits from the compiler;
+//   * k-step i of a k-block multiplies halves [32 g + 8 i, + 8) of both operands (any k order: gamma_s covers it);
+//   * a block is 5 compute waves x 32 rows + the loader against 32 NT columns (NT = 2 / 4), 24 / 48 KB of LDS: two blocks
+//     share a CU (12 waves of <= 168 registers), so one block's epilogue runs under the other's loads;
+//   * the epilogue is wave-private: column tile by column tile the wave parks its 32 x 32 accumulators in LDS
+//     (transposed), then lane = row (the two half-waves split the trees) reads the row's node per tree (128-byte
+//     coalesced), picks its column, decides, and writes the side byte.
+// Same screen values up to the order of the f32 additions (covered by gamma_s), same bound, same marks for
+// k_forest_exact_pairs: forests stay bit-identical.
+constexpr uint32_t kNarrowWaves = 5;                      // compute waves of a block (+ 1 loader wave)
+constexpr uint32_t kNarrowRows = 32u * kNarrowWaves;      // rows of X~ per block
+constexpr uint32_t kNarrowThreads = 64u * (kNarrowWaves + 1u);
+template <int NT>
+struct NarrowShape {
+    static constexpr uint32_t kCT = 32u * NT;         // columns (normals) per block
+    static constexpr uint32_t kStage = kCT * 128u;    // one k-block (64 halves) of the block's normals
+    static constexpr uint32_t kStages = 3;
+    static constexpr uint32_t kPieces = kCT / 8u;     // 1 KiB DMA pieces per stage
+    static constexpr uint32_t kEpiWave = 32u * 36u * 4u + 32u * 16u;  // per wave: S[32 columns][36] floats + 32 NormalStats
+    static constexpr uint32_t kLds =
+        kStages * kStage > kNarrowWaves * kEpiWave ? kStages * kStage : kNarrowWaves * kEpiWave;
+};
+
+template <int METRIC, int NT, bool STREAM>
+__global__ __launch_bounds__(kNarrowThreads, 2) void k_forest_dense_narrow(DenseArgs a, const AbortFlags abort_flag) {
+    typedef NarrowShape<NT> SH;
+    extern __shared__ uint4 s_dense4[];
+    uint8_t *smem = reinterpret_cast<uint8_t *>(s_dense4);
+    if (abort_requested(abort_flag)) return;
+    uint32_t rt, ct;
+    if (!dense_block_map(blockIdx.x, a.group, a.n_col_tiles, a.n_row_tiles, rt, ct)) return;  // block-uniform
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t c0 = ct * SH::kCT;
+    const uint32_t nk = a.hpitch >> 6;
+    if (wave == kNarrowWaves) {
+        // ---- loader: piece p of a stage covers the tile's columns 8 p .. 8 p + 7 (slot s of column R holds chunk
+        // s ^ ((R >> 1) & 7), as in k_forest_dense_screen: the fragment reads of the compute waves are conflict-free)
+        const uint8_t *b_src[SH::kPieces];
+#pragma unroll
+        for (uint32_t p = 0; p < SH::kPieces; p++) {
+            const uint32_t R = p * 8u + (lane >> 3);
+            const uint32_t c = min(c0 + R, a.n_cols - 1);
+            b_src[p] = a.shadow + (uint64_t)c * a.hstride + (((lane & 7u) ^ ((R >> 1) & 7u)) << 4);
+        }
+#define AH_NARROW_DMA(KB, SET)                                                                                            \
+    _Pragma("unroll") for (uint32_t p_ = 0; p_ < SH::kPieces; p_++) __builtin_amdgcn_global_load_lds(                     \
+        (const __attribute__((address_space(1))) void *)(b_src[p_] + (uint64_t)(KB) * 128u),                              \
+        (__attribute__((address_space(3))) void *)(smem + (SET) * SH::kStage + p_ * 1024u), 16, 0, 0)
+        if (!(a.verify & 0x200u)) {  // (AH_DENSE_DEBUG, experiments only)
+        AH_NARROW_DMA(0, 0);
+        if (nk > 1) AH_NARROW_DMA(1, 1);
+        }
+        for (uint32_t kb = 0; kb < nk && !(a.verify & 0x200u); kb++) {
+            // stage kb has landed (stage kb + 1 may still fly); after the barrier everybody has finished with the buffer
+            // of stage kb - 1, which stage kb + 2 overwrites
+            if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SH::kPieces) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kb + 2 < nk) {
+                const uint32_t set = (kb + 2) % 3u;
+                AH_NARROW_DMA(kb + 2, set);
+            }
+        }
+#undef AH_NARROW_DMA
+        __builtin_amdgcn_s_barrier();  // the compute waves' "ring is dead" barrier
+        return;
+    }
+    // v_mfma_f32_16x16x32_f16: lane (m, kg) = (lane & 15, lane >> 4) holds halves [8 kg, 8 kg + 8) of k-step s (32 halves) of
+    // row / column m.  The four lanes of a row therefore fetch 64 CONTIGUOUS bytes per load instruction (16 rows x one
+    // 64-byte sector: 16 sector look-ups per KiB; the 32x32x16 shape has two lanes per row and costs 64 — measured 2x slower)
+    const uint32_t m = lane & 15u, kg = lane >> 4;
+    const uint64_t row_base = (uint64_t)rt * kNarrowRows + wave * 32u;
+    // A: row tile i (16 rows) of the wave, k-block kb at + 128 kb, k-step s at + 64 s (rows past the end repeat the last
+    // row: never stored)
+    const uint4 *a_src[2];
+#pragma unroll
+    for (uint32_t i = 0; i < 2; i++)
+        a_src[i] = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(a.rows) +
+                                                  min(row_base + 16u * i + m, a.n - 1) * ((uint64_t)a.hpitch * 2u) + 16u * kg);
+    f32x4_t acc[2][2 * NT];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2 * NT; j++) acc[i][j] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    // the epilogue's row owner: lane & 31 (both half-waves)
+    const uint32_t er = lane & 31u, eh = lane >> 5;
+    const uint64_t row = row_base + er;
+    const bool live = row < a.n;
+    float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+    float row_extra = 0.0f;
+    if (live) {
+        rs = a.stats[row];
+        if (METRIC == AH_DOT_PRODUCT) row_extra = a.headers[2 * row];
+    }
+    uint4 ar[3][4];  // [set][2 i + s]
+#define AH_NARROW_ISSUE(KB, SET)                                                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) ar[SET][i_] =                                                        \
+        STREAM ? ld_stream_u4(a_src[i_ >> 1] + (uint64_t)(KB) * 8u + 4u * (i_ & 1))                                       \
+               : a_src[i_ >> 1][(uint64_t)(KB) * 8u + 4u * (i_ & 1)]
+    // one k-block.  STEADY: k-block kb + SET + 2 exists (no conditional issue: the compiler's wait counts stay exact).
+    // Fragment of column n = 16 j + m at k-step s: chunk 4 s + kg of the column's 128-byte line, at slot chunk ^ ((n >> 1) & 7)
+    // (the loader's source swizzle): the 16-lane groups of a ds_read_b128 then cover all 64 banks
+#define AH_NARROW_STEP(SET, STEADY)                                                                                       \
+    if (STEADY || kb + (SET) < nk) {                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* my reads of stage kb + SET - 1 have returned */             \
+        __builtin_amdgcn_s_barrier();                                                                                     \
+        asm volatile("" ::: "memory");                                                                                    \
+        if (STEADY || kb + (SET) + 2 < nk) AH_NARROW_ISSUE(kb + (SET) + 2, ((SET) + 2) % 3);                              \
+        __builtin_amdgcn_sched_barrier(0); /* the prefetch is issued HERE, not wherever the scheduler finds a gap */       \
+        const uint8_t *sb_ = smem + (SET) * SH::kStage + m * 128u;                                                        \
+        _Pragma("unroll") for (uint32_t s_ = 0; s_ < 2; s_++) {                                                           \
+            const f16x8_t a0_ = __builtin_bit_cast(f16x8_t, ar[SET][s_]);                                                 \
+            const f16x8_t a1_ = __builtin_bit_cast(f16x8_t, ar[SET][2 + s_]);                                             \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2 * NT; j_++) {                                                       \
+                /* column 16 j + m: (n >> 1) & 7 = ((m >> 1) + 8 j) & 7 = (m >> 1) & 7 */                                  \
+                const f16x8_t b_ = *reinterpret_cast<const f16x8_t *>(sb_ + j_ * 2048 + (((4u * s_ + kg) ^ ((m >> 1) & 7u)) << 4)); \
+                acc[0][j_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0_, b_, acc[0][j_], 0, 0, 0);                        \
+                acc[1][j_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1_, b_, acc[1][j_], 0, 0, 0);                        \
+            }                                                                                                             \
+        }                                                                                                                 \
+    }
+    AH_NARROW_ISSUE(0, 0);
+    AH_NARROW_ISSUE(nk > 1 ? 1u : 0u, 1);  // (unconditional: a one-k-block row fetches that block twice, nobody reads the copy)
+    uint32_t kb = (a.verify & 0x200u) ? nk : 0;  // (AH_DENSE_DEBUG, experiments only)
+    for (; kb + 5 <= nk; kb += 3) {
+        AH_NARROW_STEP(0, true)
+        AH_NARROW_STEP(1, true)
+        AH_NARROW_STEP(2, true)
+    }
+    for (; kb < nk; kb += 3) {
+        AH_NARROW_STEP(0, false)
+        AH_NARROW_STEP(1, false)
+        AH_NARROW_STEP(2, false)
+    }
+#undef AH_NARROW_STEP
+#undef AH_NARROW_ISSUE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the ring is dead (every wave's fragment reads have returned): it becomes the waves'
+    asm volatile("" ::: "memory");  // private epilogue tiles
+    if (a.verify & 0x100u) {  // (AH_DENSE_DEBUG, experiments only: no epilogue)
+        if (acc[0][0][0] == 123.456f) a.side_bytes[row] = 1;
+        return;
+    }
+    // Epilogue, 32 columns at a time, private to the wave.  D layout of the 16x16 MFMA: lane -> column (lane & 15) of the B
+    // operand (the normals), register e -> row 4 (lane >> 4) + e of the A operand (the wave's rows): the four registers
+    // are four consecutive rows = one 16-byte store of S[column][row].
+    float *S = reinterpret_cast<float *>(smem + wave * SH::kEpiWave);
+    NormalStats *nst = reinterpret_cast<NormalStats *>(smem + wave * SH::kEpiWave + 32u * 36u * 4u);
+#pragma unroll
+    for (int jn = 0; jn < NT; jn++) {
+        const uint32_t c_lo = c0 + (uint32_t)jn * 32u;
+        if (c_lo >= a.n_cols) break;  // block-uniform
+        const uint32_t c_hi = min(c_lo + 32u, a.n_cols) - 1u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the previous round's readers are done (one wave: program order)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const f32x4_t v = acc[i][2 * jn + jj];
+                *reinterpret_cast<float4 *>(S + (16u * (uint32_t)jj + m) * 36u + 16u * (uint32_t)i + 4u * kg) =
+                    make_float4(v[0], v[1], v[2], v[3]);
+            }
+        if (lane < 32u && c_lo + lane <= c_hi)
+            nst[lane] = *reinterpret_cast<const NormalStats *>(a.shadow + (uint64_t)(c_lo + lane) * a.hstride + (uint64_t)a.hpitch * 2u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // nodes are ordered by tree: the round's columns [c_lo, c_hi] cover the trees [t_lo, t_hi]
+        const uint32_t t_lo = a.nodes[c_lo].tree, t_hi = a.nodes[c_hi].tree;
+        for (uint32_t t = t_lo + eh; t <= t_hi; t += 8u) {
+            uint32_t nd[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++)
+                nd[u] = (live && t + 2u * u <= t_hi) ? a.node_of[(uint64_t)(t + 2u * u) * a.n + row] : 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t c = nd[u] - c_lo;  // 0xFFFFFFFF (leaf row) and nodes of other column tiles fall outside
+                if (nd[u] != 0xFFFFFFFFu && c < 32u) {
+                    uint32_t side;
+                    const bool decided = screen_decides<METRIC>(S[c * 36u + er], rs, nst[c], row_extra, a.gamma_s, a.gamma_r, side);
+                    a.side_bytes[(uint64_t)(t + 2u * u) * a.n + row] =
+                        (uint8_t)(decided ? ((a.verify & 1u) ? (kSideVerify | side) : side) : kSideUndecided);
                 }
             }
         }

@@ -1645,6 +1645,7 @@ struct HostBlob {
     uint8_t *p = nullptr;
     size_t cap = 0;        // usable bytes at p
     size_t committed = 0;  // bytes from p whose pages have been written before (a recycled blob): nothing to fault there
+    bool recycled = false; // came out of the pool (HostBlobPool::take), not from a fresh mapping
     void *map = nullptr;   // the mapping p lives in (nullptr: malloc'd — small blobs)
     size_t map_len = 0;
 };
@@ -1666,15 +1667,20 @@ class HostBlobPool {
         if (bytes >= kSmall) {
             std::lock_guard<std::mutex> lk(mu);
             size_t best = idle.size();
+            // the smallest blob that fits, and never one more than twice the size asked for: a 20 MB request must not walk off
+            // with the 5 GB blob the next big build is counting on
             for (size_t i = 0; i < idle.size(); i++)
-                if (idle[i].cap >= bytes && (best == idle.size() || idle[i].cap < idle[best].cap)) best = i;
+                if (idle[i].cap >= bytes && idle[i].cap <= 2 * bytes + kHuge && (best == idle.size() || idle[i].cap < idle[best].cap))
+                    best = i;
             if (best != idle.size()) {
                 *out = idle[best];
+                out->recycled = true;
                 held -= std::min(held, idle[best].committed);
                 idle.erase(idle.begin() + (ptrdiff_t)best);
                 return true;
             }
         }
+        if (fail_alloc_tick()) return false;
         HostBlob b;
         if (bytes < kSmall) {
             b.p = reinterpret_cast<uint8_t *>(malloc(bytes));
@@ -1724,6 +1730,9 @@ static HostBlobPool &host_pool() {
     static HostBlobPool *pool = new HostBlobPool();  // never destroyed: forests may outlive static destruction order
     return *pool;
 }
+namespace ah {
+size_t host_cache_trim() { return host_pool().trim(); }
+}  // namespace ah
 // grow `blob` to at least `need` bytes keeping its first `keep` bytes; the old mapping goes back to the pool
 static bool host_blob_reserve(HostBlob &blob, size_t need, size_t keep) {
     if (need + 16 <= blob.cap) return true;
@@ -1913,21 +1922,25 @@ static uint64_t normal_record_stride(const ah_dataset *ds) {
 static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force);
 // (ensure_screen is shared with search.hip: the certified top-k screen of the re-rank uses the same copy)
 namespace ah {
-bool ensure_screen(ah_dataset *ds, hipStream_t s, bool want8) {
+bool ensure_screen(ah_dataset *ds, hipStream_t s, bool want8, bool retry_failed) {
     std::lock_guard<std::mutex> lk(ds->mu);
     if (metric_is_bq(ds->metric) || ds->dims < 32 || ds->n == 0) {
         ds->screen_never = true;
         return false;
     }
     if (!ds->d_rows_h16) {
+        // a reader that found no memory for the copies does not ask again on every call (each attempt would cost an
+        // allocation of n x hpitch x 2 bytes): the next build does
+        if (ds->screen_alloc_failed && !retry_failed) return false;
         ds->screen_alloc_failed = true;  // until the copies exist
         const uint32_t hpitch = (ds->dims + 63u) & ~63u;
         uint16_t *rows = nullptr;
         float4 *stats = nullptr;
-        if (dev_malloc((void **)&rows, ds->n * (size_t)hpitch * 2) != hipSuccess ||
-            dev_malloc((void **)&stats, ds->n * sizeof(float4)) != hipSuccess) {
+        // (optional allocations: a full device does not make them empty the cache)
+        if (dev_malloc((void **)&rows, ds->n * (size_t)hpitch * 2, true) != hipSuccess ||
+            dev_malloc((void **)&stats, ds->n * sizeof(float4), true) != hipSuccess) {
             (void)hipGetLastError();
-            if (rows) (void)dev_free(rows);
+            if (rows) (void)dev_free_unused(rows);
             return false;
         }
         const DataView dv = ds->view();
@@ -1949,10 +1962,11 @@ bool ensure_screen(ah_dataset *ds, hipStream_t s, bool want8) {
         }
         (void)dev_free(d_max);
         memcpy(ds->screen_max, h_max, 12);
-        ds->d_rows_h16 = rows;
-        ds->d_screen_stats = stats;
         ds->hpitch = hpitch;
+        ds->d_screen_stats = stats;
+        ds->d_rows_h16 = rows;
         ds->screen_alloc_failed = false;
+        ds->screen_ready.store(true, std::memory_order_release);  // readers without `mu` look at this flag only
     }
     const long long tun8 = tun(TUN_SCREEN8);
     if (want8 && tun8 != 0 && ds->metric != AH_DOT_PRODUCT && !ds->d_rows_i8 && (!ds->screen8_decided || tun8 == 1))
@@ -2345,16 +2359,35 @@ int launch_screen_rows(int metric, uint32_t tc, bool lds, const ScreenRowsArgs &
 namespace {
 struct DensePlan {
     uint32_t n_row_tiles, n_col_tiles, group;
-    bool wide;  // 256-column tiles (512 threads) unless one 128-column tile covers the level
+    bool wide;    // k_forest_dense_screen: 256-column tiles (512 threads) unless one 128-column tile covers the level
+    int narrow;   // 0: k_forest_dense_screen (256-row tiles); 2 / 4: k_forest_dense_narrow<NT> (160-row tiles, 32 NT columns)
+    bool stream;  // narrow: rows read once per level (one column tile): non-temporal loads
+    uint32_t tile_rows, tile_cols, threads, lds;
     uint64_t grid;
 };
 DensePlan dense_plan(uint64_t N, uint32_t n_cols) {
-    DensePlan p;
-    p.n_row_tiles = (uint32_t)((N + kDM - 1) / kDM);
-    p.wide = n_cols > 128;
-    const uint32_t bn = p.wide ? 256u : 128u;
-    p.n_col_tiles = (n_cols + bn - 1) / bn;
-    p.group = p.n_col_tiles > 1 ? kDenseGroup : 1u;
+    DensePlan p{};
+    // the narrow kernel while the level is bound by the rows' HBM time rather than by the matrix units
+    const long long narrow_max = tun(TUN_DENSE_NARROW_MAX_COLS), narrow_force = tun(TUN_DENSE_NARROW);
+    p.narrow = narrow_force == 0 || (long long)n_cols > narrow_max ? 0 : (n_cols <= 64 ? 2 : 4);
+    if (p.narrow) {
+        p.tile_rows = kNarrowRows;
+        p.tile_cols = 32u * (uint32_t)p.narrow;
+        p.threads = kNarrowThreads;
+        p.lds = p.narrow == 2 ? NarrowShape<2>::kLds : NarrowShape<4>::kLds;
+        p.wide = false;
+    } else {
+        p.wide = n_cols > 128;
+        p.tile_rows = kDM;
+        p.tile_cols = p.wide ? 256u : 128u;
+        p.threads = p.wide ? DenseShape<4>::kThreads : DenseShape<2>::kThreads;
+        p.lds = kDenseLds;
+    }
+    p.n_row_tiles = (uint32_t)((N + p.tile_rows - 1) / p.tile_rows);
+    p.n_col_tiles = (n_cols + p.tile_cols - 1) / p.tile_cols;
+    p.group = p.n_col_tiles > 1 ? (p.narrow ? 12u : kDenseGroup) : 1u;  // ~3 MB of X~ tiles per group and XCD
+    const long long st = tun(TUN_DENSE_NARROW_STREAM);
+    p.stream = p.narrow && (st < 0 ? p.n_col_tiles == 1 : st != 0);
     const uint64_t r8 = (p.n_row_tiles + 7) / 8;
     p.grid = 8 * ((r8 + p.group - 1) / p.group) * p.group * p.n_col_tiles;
     return p;
@@ -2550,7 +2583,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     }
     // certified binary16 screen: f32 metrics with AVX-tier rows, unless the caller (or AH_SCREEN=0) asks for f32 only
     const auto t_setup_rows = std::chrono::steady_clock::now();
-    const bool screen = !exact_only && !bq && ds->dims >= 32 && ensure_screen(ds, s, true);
+    const bool screen = !exact_only && !bq && ds->dims >= 32 && ensure_screen(ds, s, true, true);
     const auto t_setup_screen = std::chrono::steady_clock::now();
     if (!exact_only && !screen && ds->screen_alloc_failed) forest->stats.screen_unavailable = 1;
     ScreenView sv{};
@@ -3103,7 +3136,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     da.n_row_tiles = dp.n_row_tiles;
                     da.n_col_tiles = dp.n_col_tiles;
                     da.group = dp.group;
-                    da.verify = verify;
+                    da.verify = verify | ((uint32_t)tun(TUN_DENSE_DEBUG) << 8);
                     const bool wide = dp.wide;
                     const uint64_t dgrid = dp.grid;
                     AH_REQUIRE(dgrid < 0x7FFFFFFFull, AH_ERR_INVALID_ARGUMENT, "forest build: too many tiles for one launch");
@@ -3119,9 +3152,20 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         hipLaunchKernelGGL((k_forest_dense_screen<M, WNV>), dim3((unsigned)dgrid), dim3(DenseShape<WNV>::kThreads),      \
                            kDenseLds, s, da, d_abort);                                                                   \
     } while (0)
+#define AH_DENSE_NARROW(M, NTV)                                                                                          \
+    do {                                                                                                                 \
+        if (dp.stream)                                                                                                   \
+            hipLaunchKernelGGL((k_forest_dense_narrow<M, NTV, true>), dim3((unsigned)dgrid), dim3(kNarrowThreads),       \
+                               NarrowShape<NTV>::kLds, s, da, d_abort);                                                  \
+        else                                                                                                             \
+            hipLaunchKernelGGL((k_forest_dense_narrow<M, NTV, false>), dim3((unsigned)dgrid), dim3(kNarrowThreads),      \
+                               NarrowShape<NTV>::kLds, s, da, d_abort);                                                  \
+    } while (0)
 #define AH_DENSE(M)                                                                                                      \
     do {                                                                                                                 \
-        if (wide) AH_DENSE_WN(M, 4);                                                                                     \
+        if (dp.narrow == 2) AH_DENSE_NARROW(M, 2);                                                                       \
+        else if (dp.narrow == 4) AH_DENSE_NARROW(M, 4);                                                                  \
+        else if (wide) AH_DENSE_WN(M, 4);                                                                                \
         else AH_DENSE_WN(M, 2);                                                                                          \
         hipLaunchKernelGGL((k_forest_exact_pairs<M>), dim3(egrid), dim3(256), 0, s, dv, node_of.p, side_bytes.p,         \
                            n_trees, chunk_d, nstride, hdr_off, d_counters, d_abort);                                     \
@@ -3133,6 +3177,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     default: AH_DENSE(AH_DOT_PRODUCT); break;
                     }
 #undef AH_DENSE_WN
+#undef AH_DENSE_NARROW
 #undef AH_DENSE
                     forest->stats.dense_launches++;
                     forest->stats.dense_columns += n_nodes;
@@ -3585,7 +3630,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     touch_normals[0].join();  // (the last level started the commit of a level that never came)
     touch_normals[1].join();
     // (the head-room of the blob stays mapped: untouched pages cost nothing, and the pool hands the whole blob to the next build)
-    forest->stats.host_blob_recycled += (forest->normals_blob.committed ? 1u : 0u) + (forest->desc_blob.committed ? 1u : 0u);
+    forest->stats.host_blob_recycled += (forest->normals_blob.recycled ? 1u : 0u) + (forest->desc_blob.recycled ? 1u : 0u);
     forest->stats.seconds_after_device += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop_end).count();
     if (timing) {
         const auto t_end = std::chrono::steady_clock::now();
@@ -3620,7 +3665,7 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
     AH_REQUIRE(ds->metric != AH_DOT_PRODUCT || ds->dot_preprocessed, AH_ERR_NEED_PREPROCESS,
                "DotProduct needs ah_preprocess_dot before the build (src/writer.rs:964-976)");
     AH_HIP(hipSetDevice(ds->device));
-    if (ds->reserve_thread.joinable()) ds->reserve_thread.join();  // (ah_dataset_reserve_build still filling the cache)
+    ds->join_reserve();  // (ah_dataset_reserve_build still filling the cache)
     const auto t0 = std::chrono::steady_clock::now();
     const uint32_t split_after = options->split_after ? options->split_after : ds->dims;  // src/writer.rs:474-477
     ah_forest *forest = new (std::nothrow) ah_forest();
@@ -3683,7 +3728,7 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
             st = AH_ERR_DEVICE;
         } else {
             // the binary16 shadow of the rows is made (once per dataset) before the batch is sized against free memory
-            if (!(options->margin_mode & AH_MARGIN_EXACT_ONLY) && tun(TUN_SCREEN)) (void)ensure_screen(ds, lease.c->stream, true);
+            if (!(options->margin_mode & AH_MARGIN_EXACT_ONLY) && tun(TUN_SCREEN)) (void)ensure_screen(ds, lease.c->stream, true, true);
             // Trees in flight: bounded by HBM (per item and tree: 3 permutations + node index + side byte + masks = 18
             // bytes, plus the normals of all levels and their shadow) or by the caller.
             size_t free_b = 0, total_b = 0;
@@ -3724,8 +3769,9 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
 // 10M x 100-tree build's first launch and stretched its kernels from 1.33 to 1.8 s); under the 0.6 s of staging it is free.
 // Sizes mirror build_batch / ensure_screen; a mismatch only costs the cache hit.
 int ah_dataset_reserve_build(ah_dataset *ds, uint32_t n_trees, uint32_t split_after_opt) {
+    AH_GUARDED("ah_dataset_reserve_build")
     AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
-    if (ds->reserve_thread.joinable()) ds->reserve_thread.join();
+    ds->join_reserve();
     const uint64_t N = std::max<uint64_t>(ds->n, ds->capacity);
     if (N == 0 || n_trees == 0 || tun(TUN_DEVICE_CACHE_MB) <= 0) return AH_OK;
     const uint32_t split_after = split_after_opt ? split_after_opt : ds->dims;
@@ -3773,7 +3819,7 @@ int ah_dataset_reserve_build(ah_dataset *ds, uint32_t n_trees, uint32_t split_af
     }
     const int device = ds->device;
     try {
-        ds->reserve_thread = std::thread([device, sizes] {
+        std::thread helper([device, sizes] {
             if (hipSetDevice(device) != hipSuccess) return;
             std::vector<void *> got;
             for (size_t b : sizes) {
@@ -3786,18 +3832,29 @@ int ah_dataset_reserve_build(ah_dataset *ds, uint32_t n_trees, uint32_t split_af
             }
             for (void *p : got) (void)dev_free_unused(p);
         });
+        std::thread stale;  // (a helper another thread started since the join above: wait for that one too)
+        {
+            std::lock_guard<std::mutex> lk(ds->mu);
+            stale = std::move(ds->reserve_thread);
+            ds->reserve_thread = std::move(helper);
+        }
+        if (stale.joinable()) stale.join();
     } catch (...) {  // no thread: the first build allocates as before
     }
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_build_forest(ah_dataset *ds, const ah_build_options *options, ah_forest **out) {
+    AH_GUARDED("ah_build_forest")
     return build_forest_impl(ds, options, nullptr, nullptr, out);
+    AH_GUARDED_END
 }
 
 // The same build with the node sink inside it (include/arroy_hip.h, "Streaming build"): nothing is materialised.
 int ah_build_forest_stream(ah_dataset *ds, const ah_build_options *options, ah_node_batch_fn sink, void *user,
                            uint32_t *out_roots, ah_build_stats *out_stats) {
+    AH_GUARDED("ah_build_forest_stream")
     AH_REQUIRE(sink, AH_ERR_INVALID_ARGUMENT, "sink is NULL");
     AH_REQUIRE(options && (out_roots || options->n_trees == 0), AH_ERR_INVALID_ARGUMENT, "NULL argument");
     StreamBuild sb;
@@ -3809,12 +3866,14 @@ int ah_build_forest_stream(ah_dataset *ds, const ah_build_options *options, ah_n
     if (st == AH_OK && out_stats) *out_stats = forest->stats;
     delete forest;
     return st;
+    AH_GUARDED_END
 }
 
 // `incremental_index_large_descendant` (src/writer.rs:660-739) for many descendants at once: tree t of the result is
 // `make_tree_in_file` over the ascending id list item_ids[offsets[t] .. offsets[t+1]).
 int ah_build_subtrees(ah_dataset *ds, const ah_build_options *options, const uint32_t *item_ids, const uint64_t *offsets,
                       ah_forest **out) {
+    AH_GUARDED("ah_build_subtrees")
     AH_REQUIRE(options, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     AH_REQUIRE((item_ids && offsets) || options->n_trees == 0, AH_ERR_INVALID_ARGUMENT, "NULL id lists");
     for (uint32_t t = 0; t < options->n_trees; t++) {
@@ -3825,9 +3884,11 @@ int ah_build_subtrees(ah_dataset *ds, const ah_build_options *options, const uin
     }
     static const uint32_t dummy = 0;
     return build_forest_impl(ds, options, item_ids ? item_ids : &dummy, offsets, out);
+    AH_GUARDED_END
 }
 
 int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out) {
+    AH_GUARDED("ah_forest_view_get")
     AH_REQUIRE(forest && out, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     out->n_trees = (uint32_t)forest->roots.size();
     out->n_nodes = forest->nodes.size();
@@ -3841,6 +3902,7 @@ int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out) {
     out->descendants = forest->descendants;
     out->descendants_len = forest->descendants_len;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 // ---- content digest ---------------------------------------------------------------------------------------------------
@@ -3871,6 +3933,7 @@ uint64_t hash_bytes(const void *data, size_t len, uint64_t seed) {
 }  // namespace
 
 int ah_forest_digest(const ah_forest *forest, uint64_t *out_per_tree, uint64_t *out_total) {
+    AH_GUARDED("ah_forest_digest")
     AH_REQUIRE(forest && (out_per_tree || out_total), AH_ERR_INVALID_ARGUMENT, "NULL argument");
     const uint32_t n_trees = (uint32_t)forest->roots.size();
     const size_t n_nodes = forest->nodes.size();
@@ -3927,11 +3990,13 @@ int ah_forest_digest(const ah_forest *forest, uint64_t *out_per_tree, uint64_t *
     }
     if (out_total) *out_total = total;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 // Test aid: the block -> work-item maps of the build's launches, run on the device (see include/arroy_hip.h).
 int ah_debug_launch_coverage(int device, int kind, uint64_t n_rows, uint32_t dims, uint32_t a, uint32_t b, uint32_t *out_counts,
                              uint64_t out_len) {
+    AH_GUARDED("ah_debug_launch_coverage")
     AH_REQUIRE(out_counts && n_rows && dims, AH_ERR_INVALID_ARGUMENT, "NULL / empty argument");
     AH_HIP(hipSetDevice(device));
     const uint32_t hpitch = (dims + 63u) & ~63u;
@@ -3974,17 +4039,31 @@ int ah_debug_launch_coverage(int device, int kind, uint64_t n_rows, uint32_t dim
     AH_HIP(hipDeviceSynchronize());
     AH_HIP(hipMemcpy(out_counts, d.p, need * 4, hipMemcpyDeviceToHost));
     return AH_OK;
+    AH_GUARDED_END
+}
+
+int ah_debug_dense_tiles(uint64_t n_rows, uint32_t n_cols, uint32_t *out_tile_rows, uint32_t *out_tile_cols) {
+    AH_GUARDED("ah_debug_dense_tiles")
+    AH_REQUIRE(n_rows && n_cols && out_tile_rows && out_tile_cols, AH_ERR_INVALID_ARGUMENT, "NULL / empty argument");
+    const DensePlan dp = dense_plan(n_rows, n_cols);
+    *out_tile_rows = dp.tile_rows;
+    *out_tile_cols = dp.tile_cols;
+    return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_forest_stats(const ah_forest *forest, ah_build_stats *out) {
+    AH_GUARDED("ah_forest_stats")
     AH_REQUIRE(forest && out, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     *out = forest->stats;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 // payload: SPLIT -> the normal record (vector at normal_vector_offset, header at normal_header_offset) or
 // NULL for `normal: None`; DESCENDANTS -> u32 item ids.
 int ah_forest_visit(const ah_forest *forest, ah_node_sink_fn sink, void *user) {
+    AH_GUARDED("ah_forest_visit")
     AH_REQUIRE(forest && sink, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     for (size_t i = 0; i < forest->nodes.size(); i++) {
         const ah_node &nd = forest->nodes[i];
@@ -4003,27 +4082,35 @@ int ah_forest_visit(const ah_forest *forest, ah_node_sink_fn sink, void *user) {
         AH_REQUIRE(rc == 0, AH_ERR_CANCELLED, "node sink asked to stop (code %d)", rc);
     }
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_forest_destroy(ah_forest *forest) {
+    AH_GUARDED("ah_forest_destroy")
     delete forest;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_device_cache_trim(int device, uint64_t *out_bytes) {
+    AH_GUARDED("ah_device_cache_trim")
     const size_t was = dev_cache_trim(device);
     if (out_bytes) *out_bytes = was;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_host_cache_trim(uint64_t *out_bytes) {
+    AH_GUARDED("ah_host_cache_trim")
     const size_t was = host_pool().trim();
     if (out_bytes) *out_bytes = was;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 // Benchmark harness only: the policy header's generator on the host cores (the rows ah_dataset_fill_synthetic makes in HBM).
 int ah_synth_rows_host(uint64_t seed, int distribution, uint64_t first_item, uint64_t n, uint32_t dims, float *out) {
+    AH_GUARDED("ah_synth_rows_host")
     AH_REQUIRE(out || n == 0, AH_ERR_INVALID_ARGUMENT, "out is NULL");
     AH_REQUIRE(distribution >= AH_SYNTH_UNIFORM_01 && distribution <= AH_SYNTH_NORMAL_OUTLIERS, AH_ERR_INVALID_ARGUMENT,
                "unknown distribution %d", distribution);
@@ -4035,6 +4122,7 @@ int ah_synth_rows_host(uint64_t seed, int distribution, uint64_t first_item, uin
             for (uint32_t d = 0; d < dims; d++) out[i * dims + d] = ah_synth_value(seed, first_item + i, d, dims, distribution);
     });
     return AH_OK;
+    AH_GUARDED_END
 }
 
 }  // extern "C"

@@ -1773,6 +1773,7 @@ extern "C" {
 int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_index **out);
 
 int ah_index_destroy(ah_index *ix) {
+    AH_GUARDED("ah_index_destroy")
     if (!ix) return AH_OK;
     if (ix->ds) (void)hipSetDevice(ix->ds->device);
     (void)hipDeviceSynchronize();
@@ -1783,20 +1784,24 @@ int ah_index_destroy(ah_index *ix) {
     if (ix->d_nhdrs) (void)dev_free(ix->d_nhdrs);
     delete ix;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 // Mirror a forest in HBM next to its dataset.  The forest handle may be destroyed afterwards.
 int ah_index_create(ah_dataset *ds, const ah_forest *forest, ah_index **out) {
+    AH_GUARDED("ah_index_create")
     AH_REQUIRE(out, AH_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     AH_REQUIRE(forest, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     ah_forest_view v;
     AH_TRY(ah_forest_view_get(forest, &v));
     return ah_index_create_from_view(ds, &v, out);
+    AH_GUARDED_END
 }
 
 // Same from caller-owned arrays (e.g. tree nodes decoded from LMDB by `Reader::open`); nothing is retained.
 int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_index **out) {
+    AH_GUARDED("ah_index_create_from_view")
     AH_REQUIRE(out, AH_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
     AH_REQUIRE(ds && view, AH_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -1951,6 +1956,7 @@ int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_ind
     ix->nv.identity_ids = 1;
     *out = ix;
     return AH_OK;
+    AH_GUARDED_END
 }
 
 struct HostSeg2 {
@@ -2019,7 +2025,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     const uint32_t n_leaf_sums = (ix->n_nodes + kLeafScanItems - 1) / kLeafScanItems;
     // certified top-k screen of the tile re-rank: the binary16 shadow of the rows must exist (ah_index_create makes it)
     const bool screened = tiles && tun(TUN_SEARCH_SCREEN) != 0 && (ds->metric == AH_COSINE || ds->metric == AH_DOT_PRODUCT) &&
-                          ds->d_rows_h16 != nullptr && ds->d_screen_stats != nullptr;
+                          ds->screen_ready.load(std::memory_order_acquire);  // (published: common.h)
     if (screened) dev_bytes += pad(nq * (size_t)ds->hpitch * 2) + pad(nq * sizeof(float4)) + pad(nq * (size_t)nns_stride * 4);
     if (tiles)
         dev_bytes += pad((size_t)visit_cap * sizeof(Visit)) * 2 + pad((size_t)visit_cap * sizeof(TileUnit)) +
@@ -2360,6 +2366,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
 // Route `n` items (already present in the index's dataset) down every tree of the index.
 // out_leaf[t * n + i] = forest-local index of the Descendants node item i reaches in tree t.
 int ah_route_items(ah_index *ix, const uint32_t *item_ids, size_t n, const uint64_t *tree_seeds, uint32_t *out_leaf) {
+    AH_GUARDED("ah_route_items")
     AH_REQUIRE(ix && ix->ds, AH_ERR_INVALID_ARGUMENT, "index is NULL");
     AH_REQUIRE((item_ids && out_leaf && tree_seeds) || n == 0, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n == 0 || ix->n_trees == 0) return AH_OK;
@@ -2397,6 +2404,7 @@ int ah_route_items(ah_index *ix, const uint32_t *item_ids, size_t n, const uint6
     AH_REQUIRE((*h_err & 1u) == 0, AH_ERR_MISSING_ITEM, "an item to route does not exist in the dataset");
     memcpy(out_leaf, h_leaf, pairs * 4);
     return AH_OK;
+    AH_GUARDED_END
 }
 
 // `QueryBuilder::{by_vector, by_item}` for a batch (src/reader.rs:46-75, 317-401).
@@ -2407,6 +2415,7 @@ int ah_route_items(ah_index *ix, const uint32_t *item_ids, size_t n, const uint6
 int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_items, size_t nq, size_t count,
                     size_t search_k, size_t oversampling, const uint32_t *filter_sorted, size_t n_filter, int have_filter,
                     uint32_t *out_ids, float *out_distances, uint32_t *out_counts) {
+    AH_GUARDED("ah_search_batch")
     AH_REQUIRE(ix && ix->ds, AH_ERR_INVALID_ARGUMENT, "index is NULL");
     ah_dataset *ds = ix->ds;
     AH_REQUIRE((queries != nullptr) != (query_items != nullptr), AH_ERR_INVALID_ARGUMENT,
@@ -2513,15 +2522,18 @@ int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_it
                           out_distances + q0 * count, out_counts + q0);
     }
     return st;
+    AH_GUARDED_END
 }
 
 // Which kernels served the searches of this index so far (ABI v5); reset != 0 zeroes the counters after the copy.
 int ah_index_search_stats(ah_index *ix, ah_search_stats *out, int reset) {
+    AH_GUARDED("ah_index_search_stats")
     AH_REQUIRE(ix && out, AH_ERR_INVALID_ARGUMENT, "NULL argument");
     std::lock_guard<std::mutex> lk(ix->stats_mu);
     *out = ix->stats;
     if (reset) ix->stats = ah_search_stats{};
     return AH_OK;
+    AH_GUARDED_END
 }
 
 }  // extern "C"

@@ -34,14 +34,15 @@
 extern "C" {
 #endif
 
-#define AH_ABI_VERSION 5   /* v2: ah_node.tree is 32 bits, ah_build_options.margin_mode, ah_build_stats.margin_mode_launches,
+#define AH_ABI_VERSION 6   /* v2: ah_node.tree is 32 bits, ah_build_options.margin_mode, ah_build_stats.margin_mode_launches,
                                   ah_last_error_detail, ah_dataset_replicate, ah_dataset_upload_flush
                               v3: AH_MARGIN_DENSE_MFMA, ah_build_stats.dense_launches / dense_columns (appended)
                               v4: ah_forest_digest, ah_tuning_set / _get / _reset, ah_debug_launch_coverage,
                                   ah_build_stats.rows_* / screen8_* / screen_unavailable (appended)
                               v5: ah_search_stats / ah_index_search_stats, ah_build_options.max_host_threads (appended),
                                   ah_host_cache_trim, ah_device_cache_trim, ah_dataset_reserve_build, ah_synth_rows_host, ah_build_forest_stream (the node sink during the
-                                  build), ah_build_stats.seconds_setup / seconds_after_device / host_blob_recycled */
+                                  build), ah_build_stats.seconds_setup / seconds_after_device / host_blob_recycled
+                              v6: ah_debug_dense_tiles */
 
 /* every entry point is exported from the shared object (it is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -526,11 +527,15 @@ AH_API int ah_tuning_reset(void);   /* every tunable back to its built-in defaul
  * margin kernels call and the same host-side launch plans the build uses, under the current tunables — over a shape,
  * and count how often every work item is served (every count must be 1).
  *   kind 0: screened row-major pass, a = trees per group (2 / 4 / 8 / 16), b = groups; out_counts[b][n_rows]
- *   kind 1: dense MFMA screen, a = columns (normals of the level);               out_counts[row tiles of 256][column tiles]
+ *   kind 1: dense MFMA screen, a = columns (normals of the level);               out_counts[row tiles][column tiles] (ah_debug_dense_tiles)
  *   kind 2: exact-pairs pass after the dense screen, a = trees;                   out_counts[a][ceil(n_rows / 1024)]
  * `dims` sizes the rows as the build would.  out_len = number of counters the caller allocated (checked). */
 AH_API int ah_debug_launch_coverage(int device, int kind, uint64_t n_rows, uint32_t dims, uint32_t a, uint32_t b,
                                     uint32_t *out_counts, uint64_t out_len);
+/* Test aid (ABI v6): the tile shape the dense MFMA screen takes for a level of `n_cols` normals under the current tunables
+ * (the narrow kernel: 160 rows x 64 / 128 columns; the wide one: 256 x 128 / 256) — kind 1 of ah_debug_launch_coverage
+ * counts [ceil(n_rows / tile_rows)][ceil(n_cols / tile_cols)] tiles. */
+AH_API int ah_debug_dense_tiles(uint64_t n_rows, uint32_t n_cols, uint32_t *out_tile_rows, uint32_t *out_tile_cols);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ use crate::unaligned_vector::UnalignedVector;
 use crate::writer::BuildOption;
 use crate::{Error, ItemId, Result};
 
-pub const AH_ABI_VERSION: c_int = 5;
+pub const AH_ABI_VERSION: c_int = 6;
 const AH_NODE_DESCENDANTS: u8 = 1;
 
 #[repr(C)]

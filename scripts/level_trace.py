@@ -15,7 +15,7 @@ for r in rows:
         continue
     elif 'k_forest_margin_rows' in n or 'k_forest_screen_rows' in n:
         cur['seen'] = True; cur['rows'].append(d); cur['tc'] = max(int(re.search(r'<\d+, (\d+)[,>]', n).group(1)), cur['tc'] or 0)
-    elif 'k_forest_dense_screen' in n:
+    elif 'k_forest_dense_screen' in n or 'k_forest_dense_narrow' in n:
         cur['seen'] = True; cur['dense'] += d; cur['tc'] = 'mfma'
     elif 'k_forest_exact_pairs' in n:
         cur['seen'] = True; cur['exact'] += d

@@ -32,7 +32,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 def test_abi_scalars_without_a_gpu():
     from arroy_amd import _lib
     L = _lib.lib()
-    assert L.ah_abi_version() == 5
+    assert L.ah_abi_version() == 6
     assert [L.ah_header_size(m) for m in range(7)] == [4, 4, 4, 8, 4, 4, 4]
     assert L.ah_vector_size(2, 768) == 3072
     assert L.ah_vector_size(6, 768) == 96
