@@ -169,6 +169,8 @@ SIGNATURES = {
     "ah_tuning_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ah_tuning_reset": (C.c_int, []),
     "ah_debug_launch_coverage": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _U32P, C.c_uint64]),
+    "ah_forest_digest_keyed": (C.c_int, [_VP, _U64P, _U64P]),
+    "ah_device_cache_stats": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ah_debug_dense_tiles": (C.c_int, [C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ah_forest_visit": (C.c_int, [_VP, _VP, _VP]),
     "ah_forest_destroy": (C.c_int, [_VP]),
@@ -317,3 +319,10 @@ def bench_memcpy(device: int, nbytes: int, iterations: int) -> float:
     ms = C.c_double(0)
     check(lib().ah_bench_memcpy(device, nbytes, iterations, C.byref(ms)))
     return ms.value
+
+
+def device_cache_stats(device: int = -1):
+    """(live, idle) bytes of HBM the library holds on `device` (ah_device_cache_stats; < 0: every device)."""
+    live, idle = C.c_uint64(0), C.c_uint64(0)
+    check(lib().ah_device_cache_stats(device, C.byref(live), C.byref(idle)))
+    return live.value, idle.value

@@ -119,9 +119,8 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(DENSE, "AH_DENSE", -1)                    /* 0: never the dense MFMA screen; 1: whenever legal; -1: cost model */    \
     X(DENSE_MAX_COLS, "AH_DENSE_MAX_COLS", 16384)                                                                        \
     X(DENSE_NARROW, "AH_DENSE_NARROW", -1)      /* 0: never the narrow dense kernel (rows straight to registers) */         \
-    X(DENSE_NARROW_MAX_COLS, "AH_DENSE_NARROW_MAX_COLS", 256) /* most columns of a level the narrow dense kernel takes */  \
-    X(DENSE_DEBUG, "AH_DENSE_DEBUG", 0)         /* experiments: 1 = narrow kernel without its epilogue, 2 = without its k-loop (WRONG RESULTS) */ \
-    X(DENSE_NARROW_STREAM, "AH_DENSE_NARROW_STREAM", -1) /* 0 / 1: never / always non-temporal row loads there; -1: when one column tile */ \
+    X(DENSE_NARROW_MAX_COLS, "AH_DENSE_NARROW_MAX_COLS", 64) /* most columns of a level the narrow dense kernel takes */   \
+    X(DENSE_NARROW_STREAM, "AH_DENSE_NARROW_STREAM", 0) /* 1: non-temporal row loads there (measured slower: 3.4 -> 4.1 ms per level) */ \
     X(DENSE_GMACS, "AH_DENSE_GMACS", 495000)    /* sustained multiply-add rate the cost model assumes, 1e9 MAC/s */       \
     X(MARGIN_MODE, "AH_MARGIN_MODE", 0)         /* ah_margin_mode for callers that pass AH_MARGIN_AUTO */                 \
     X(READBACK_DIRECT, "AH_READBACK_DIRECT", 0) /* 1: let the runtime stage the device -> pageable copies */             \
@@ -177,7 +176,7 @@ inline void parallel_run(unsigned n, F fn) {
 //   AH_DEVICE_CACHE_MB: most bytes kept idle per process (default 98304; 0 = plain hipMalloc / hipFree).
 // The cache lives as long as a dataset does: when the LAST dataset of a device is destroyed its idle blocks go back to the
 // driver (and the host blob pool with the last dataset of the process), so an embedding application that is done with the
-// library holds none of its memory (AH_CACHE_KEEP_IDLE=1 keeps them; bench.py sets it between its configurations).
+// library holds none of its memory (AH_CACHE_KEEP_IDLE=1 keeps them).
 // ---------------------------------------------------------------------------------------------
 // optional: an allocation the caller can do without (the screens' copies) — no trim-and-retry when the device is full
 hipError_t dev_malloc(void **p, size_t bytes, bool optional = false);  // on the calling thread's current device

@@ -264,6 +264,12 @@ __global__ __launch_bounds__(DenseShape<WN>::kThreads, 1) void k_forest_dense_sc
 //     coalesced), picks its column, decides, and writes the side byte.
 // Same screen values up to the order of the f32 additions (covered by gamma_s), same bound, same marks for
 // k_forest_exact_pairs: forests stay bit-identical.
+#ifndef AH_NARROW_SETS
+#define AH_NARROW_SETS 3u   // A register sets (k-blocks in flight per wave + 1); 4 measured slower: 3.2 -> 4.0 ms per level
+#endif
+#ifndef AH_NARROW_PRELOAD
+#define AH_NARROW_PRELOAD 1  // the epilogue's node indices requested before the k-loop (1) or at the epilogue's start (0)
+#endif
 constexpr uint32_t kNarrowWaves = 5;                      // compute waves of a block (+ 1 loader wave)
 constexpr uint32_t kNarrowRows = 32u * kNarrowWaves;      // rows of X~ per block
 constexpr uint32_t kNarrowThreads = 64u * (kNarrowWaves + 1u);
@@ -273,9 +279,9 @@ struct NarrowShape {
     static constexpr uint32_t kStage = kCT * 128u;    // one k-block (64 halves) of the block's normals
     static constexpr uint32_t kStages = 3;
     static constexpr uint32_t kPieces = kCT / 8u;     // 1 KiB DMA pieces per stage
-    static constexpr uint32_t kEpiWave = 32u * 36u * 4u + 32u * 16u;  // per wave: S[32 columns][36] floats + 32 NormalStats
-    static constexpr uint32_t kLds =
-        kStages * kStage > kNarrowWaves * kEpiWave ? kStages * kStage : kNarrowWaves * kEpiWave;
+    static constexpr uint32_t kEpiWave = 32u * 36u * 4u;  // per wave: S[32 columns][36] floats (overlays the dead ring)
+    static constexpr uint32_t kRing = kStages * kStage > kNarrowWaves * kEpiWave ? kStages * kStage : kNarrowWaves * kEpiWave;
+    static constexpr uint32_t kLds = kRing + kCT * 16u;  // + the NormalStats of the tile's columns (written once by the loader)
 };
 
 template <int METRIC, int NT, bool STREAM>
@@ -299,15 +305,21 @@ __global__ __launch_bounds__(kNarrowThreads, 2) void k_forest_dense_narrow(Dense
             const uint32_t c = min(c0 + R, a.n_cols - 1);
             b_src[p] = a.shadow + (uint64_t)c * a.hstride + (((lane & 7u) ^ ((R >> 1) & 7u)) << 4);
         }
+        // the statistics of the tile's normals, for the compute waves' epilogues (visible to them through the k-loop's barriers)
+        {
+            NormalStats *nst_all = reinterpret_cast<NormalStats *>(smem + SH::kRing);
+#pragma unroll
+            for (uint32_t h = 0; h < SH::kCT / 64u; h++)
+                nst_all[64u * h + lane] = *reinterpret_cast<const NormalStats *>(
+                    a.shadow + (uint64_t)min(c0 + 64u * h + lane, a.n_cols - 1) * a.hstride + (uint64_t)a.hpitch * 2u);
+        }
 #define AH_NARROW_DMA(KB, SET)                                                                                            \
     _Pragma("unroll") for (uint32_t p_ = 0; p_ < SH::kPieces; p_++) __builtin_amdgcn_global_load_lds(                     \
         (const __attribute__((address_space(1))) void *)(b_src[p_] + (uint64_t)(KB) * 128u),                              \
         (__attribute__((address_space(3))) void *)(smem + (SET) * SH::kStage + p_ * 1024u), 16, 0, 0)
-        if (!(a.verify & 0x200u)) {  // (AH_DENSE_DEBUG, experiments only)
         AH_NARROW_DMA(0, 0);
         if (nk > 1) AH_NARROW_DMA(1, 1);
-        }
-        for (uint32_t kb = 0; kb < nk && !(a.verify & 0x200u); kb++) {
+        for (uint32_t kb = 0; kb < nk; kb++) {
             // stage kb has landed (stage kb + 1 may still fly); after the barrier everybody has finished with the buffer
             // of stage kb - 1, which stage kb + 2 overwrites
             if (kb + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SH::kPieces) : "memory");
@@ -340,22 +352,40 @@ __global__ __launch_bounds__(kNarrowThreads, 2) void k_forest_dense_narrow(Dense
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2 * NT; j++) acc[i][j] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-    // the epilogue's row owner: lane & 31 (both half-waves)
+    // the epilogue's row owner: lane & 31 (both half-waves: they split the trees, half h takes trees T0 + h + 2 u)
     const uint32_t er = lane & 31u, eh = lane >> 5;
     const uint64_t row = row_base + er;
     const bool live = row < a.n;
+    // Everything the epilogue reads from memory is requested NOW, before the k-loop, and waits in registers: the row's
+    // statistics and the row's node in the first 16 trees of the tile (all of them for a 13-tree share); the statistics of
+    // the tile's normals wait in LDS (the loader put them there).  An epilogue that starts these loads after the last MFMA exposes one HBM round trip per round of 32
+    // columns (measured: 1.1 of the 3.5 ms of a 10M x 768 level).
     float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
     float row_extra = 0.0f;
-    if (live) {
-        rs = a.stats[row];
-        if (METRIC == AH_DOT_PRODUCT) row_extra = a.headers[2 * row];
+    const uint32_t T0 = a.nodes[c0].tree, T1 = a.nodes[min(c0 + SH::kCT, a.n_cols) - 1u].tree;
+    uint32_t nd0[8];
+#define AH_NARROW_LOAD_ND0()                                                                                              \
+    _Pragma("unroll") for (uint32_t u = 0; u < 8; u++) {                                                                  \
+        const uint32_t t = T0 + eh + 2u * u;                                                                              \
+        const uint32_t v = a.node_of[(uint64_t)min(t, T1) * a.n + min(row, a.n - 1)];                                     \
+        nd0[u] = (live && t <= T1) ? v : 0xFFFFFFFFu; /* (clamped loads, masked: no conditional register writes) */       \
     }
-    uint4 ar[3][4];  // [set][2 i + s]
+    {
+        const uint64_t r = min(row, a.n - 1);
+        rs = a.stats[r];
+        if (METRIC == AH_DOT_PRODUCT) row_extra = a.headers[2 * r];
+    }
+#if AH_NARROW_PRELOAD
+    AH_NARROW_LOAD_ND0()
+#endif
+    // A ring: kSets register sets of one k-block each (4 x 16 B per lane: [2 i + s]), kSets - 1 k-blocks in flight per wave
+    constexpr uint32_t kSets = NT == 2 ? AH_NARROW_SETS : 3u, kAhead = kSets - 1u;
+    uint4 ar[kSets][4];
 #define AH_NARROW_ISSUE(KB, SET)                                                                                          \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) ar[SET][i_] =                                                        \
         STREAM ? ld_stream_u4(a_src[i_ >> 1] + (uint64_t)(KB) * 8u + 4u * (i_ & 1))                                       \
                : a_src[i_ >> 1][(uint64_t)(KB) * 8u + 4u * (i_ & 1)]
-    // one k-block.  STEADY: k-block kb + SET + 2 exists (no conditional issue: the compiler's wait counts stay exact).
+    // one k-block.  STEADY: k-block kb + SET + kAhead exists (no conditional issue: the compiler's wait counts stay exact).
     // Fragment of column n = 16 j + m at k-step s: chunk 4 s + kg of the column's 128-byte line, at slot chunk ^ ((n >> 1) & 7)
     // (the loader's source swizzle): the 16-lane groups of a ds_read_b128 then cover all 64 banks
 #define AH_NARROW_STEP(SET, STEADY)                                                                                       \
@@ -363,9 +393,9 @@ __global__ __launch_bounds__(kNarrowThreads, 2) void k_forest_dense_narrow(Dense
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* my reads of stage kb + SET - 1 have returned */             \
         __builtin_amdgcn_s_barrier();                                                                                     \
         asm volatile("" ::: "memory");                                                                                    \
-        if (STEADY || kb + (SET) + 2 < nk) AH_NARROW_ISSUE(kb + (SET) + 2, ((SET) + 2) % 3);                              \
+        if (STEADY || kb + (SET) + kAhead < nk) AH_NARROW_ISSUE(kb + (SET) + kAhead, ((SET) + kAhead) % kSets);           \
         __builtin_amdgcn_sched_barrier(0); /* the prefetch is issued HERE, not wherever the scheduler finds a gap */       \
-        const uint8_t *sb_ = smem + (SET) * SH::kStage + m * 128u;                                                        \
+        const uint8_t *sb_ = smem + ((kb + (SET)) % SH::kStages) * SH::kStage + m * 128u;                                 \
         _Pragma("unroll") for (uint32_t s_ = 0; s_ < 2; s_++) {                                                           \
             const f16x8_t a0_ = __builtin_bit_cast(f16x8_t, ar[SET][s_]);                                                 \
             const f16x8_t a1_ = __builtin_bit_cast(f16x8_t, ar[SET][2 + s_]);                                             \
@@ -377,38 +407,51 @@ __global__ __launch_bounds__(kNarrowThreads, 2) void k_forest_dense_narrow(Dense
             }                                                                                                             \
         }                                                                                                                 \
     }
-    AH_NARROW_ISSUE(0, 0);
-    AH_NARROW_ISSUE(nk > 1 ? 1u : 0u, 1);  // (unconditional: a one-k-block row fetches that block twice, nobody reads the copy)
-    uint32_t kb = (a.verify & 0x200u) ? nk : 0;  // (AH_DENSE_DEBUG, experiments only)
-    for (; kb + 5 <= nk; kb += 3) {
+    // (unconditional prologue: a short row fetches its last k-block more than once, nobody reads the copies)
+#pragma unroll
+    for (uint32_t p = 0; p < kAhead; p++) AH_NARROW_ISSUE(min(p, nk - 1u), p);
+    uint32_t kb = 0;
+    for (; kb + 2u * kSets - 1u <= nk; kb += kSets) {
         AH_NARROW_STEP(0, true)
         AH_NARROW_STEP(1, true)
         AH_NARROW_STEP(2, true)
+        if (kSets == 4) AH_NARROW_STEP(kSets - 1, true)
     }
-    for (; kb < nk; kb += 3) {
+    for (; kb < nk; kb += kSets) {
         AH_NARROW_STEP(0, false)
         AH_NARROW_STEP(1, false)
         AH_NARROW_STEP(2, false)
+        if (kSets == 4) AH_NARROW_STEP(kSets - 1, false)
     }
 #undef AH_NARROW_STEP
 #undef AH_NARROW_ISSUE
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // the ring is dead (every wave's fragment reads have returned): it becomes the waves'
     asm volatile("" ::: "memory");  // private epilogue tiles
-    if (a.verify & 0x100u) {  // (AH_DENSE_DEBUG, experiments only: no epilogue)
-        if (acc[0][0][0] == 123.456f) a.side_bytes[row] = 1;
-        return;
-    }
     // Epilogue, 32 columns at a time, private to the wave.  D layout of the 16x16 MFMA: lane -> column (lane & 15) of the B
     // operand (the normals), register e -> row 4 (lane >> 4) + e of the A operand (the wave's rows): the four registers
     // are four consecutive rows = one 16-byte store of S[column][row].
+#if !AH_NARROW_PRELOAD
+    AH_NARROW_LOAD_ND0()
+#endif
+#undef AH_NARROW_LOAD_ND0
     float *S = reinterpret_cast<float *>(smem + wave * SH::kEpiWave);
-    NormalStats *nst = reinterpret_cast<NormalStats *>(smem + wave * SH::kEpiWave + 32u * 36u * 4u);
+    const NormalStats *nst_all = reinterpret_cast<const NormalStats *>(smem + SH::kRing);
+    // 0xFFFFFFFF (leaf row / no such tree) and nodes of other rounds fall outside
+#define AH_NARROW_DECIDE(T, NODE)                                                                                         \
+    do {                                                                                                                  \
+        const uint32_t node_ = (NODE), c_ = node_ - c_lo;                                                                 \
+        if (node_ != 0xFFFFFFFFu && c_ < 32u) {                                                                           \
+            uint32_t side_;                                                                                               \
+            const bool decided_ = screen_decides<METRIC>(S[c_ * 36u + er], rs, nst[c_], row_extra, a.gamma_s, a.gamma_r, side_); \
+            a.side_bytes[(uint64_t)(T) * a.n + row] =                                                                     \
+                (uint8_t)(decided_ ? (a.verify ? (kSideVerify | side_) : side_) : kSideUndecided);                 \
+        }                                                                                                                 \
+    } while (0)
 #pragma unroll
     for (int jn = 0; jn < NT; jn++) {
         const uint32_t c_lo = c0 + (uint32_t)jn * 32u;
         if (c_lo >= a.n_cols) break;  // block-uniform
-        const uint32_t c_hi = min(c_lo + 32u, a.n_cols) - 1u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // the previous round's readers are done (one wave: program order)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -420,30 +463,26 @@ __global__ __launch_bounds__(kNarrowThreads, 2) void k_forest_dense_narrow(Dense
                 *reinterpret_cast<float4 *>(S + (16u * (uint32_t)jj + m) * 36u + 16u * (uint32_t)i + 4u * kg) =
                     make_float4(v[0], v[1], v[2], v[3]);
             }
-        if (lane < 32u && c_lo + lane <= c_hi)
-            nst[lane] = *reinterpret_cast<const NormalStats *>(a.shadow + (uint64_t)(c_lo + lane) * a.hstride + (uint64_t)a.hpitch * 2u);
+        const NormalStats *nst = nst_all + 32 * jn;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // nodes are ordered by tree: the round's columns [c_lo, c_hi] cover the trees [t_lo, t_hi]
-        const uint32_t t_lo = a.nodes[c_lo].tree, t_hi = a.nodes[c_hi].tree;
-        for (uint32_t t = t_lo + eh; t <= t_hi; t += 8u) {
-            uint32_t nd[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++)
-                nd[u] = (live && t + 2u * u <= t_hi) ? a.node_of[(uint64_t)(t + 2u * u) * a.n + row] : 0xFFFFFFFFu;
+        for (uint32_t u = 0; u < 8; u++) AH_NARROW_DECIDE(T0 + eh + 2u * u, nd0[u]);
+        if (T1 >= T0 + 16u) {  // more than 16 trees in the tile (block-uniform): the rest on demand, eight loads in flight
+            // nodes are ordered by tree: the round's columns cover the trees [t_lo, t_hi]
+            const uint32_t t_lo = max(a.nodes[c_lo].tree, T0 + 16u), t_hi = a.nodes[min(c_lo + 32u, a.n_cols) - 1u].tree;
+            for (uint32_t t = t_lo + ((t_lo ^ T0 ^ eh) & 1u); t <= t_hi; t += 16u) {  // half h keeps the trees of its parity
+                uint32_t nd[8];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t c = nd[u] - c_lo;  // 0xFFFFFFFF (leaf row) and nodes of other column tiles fall outside
-                if (nd[u] != 0xFFFFFFFFu && c < 32u) {
-                    uint32_t side;
-                    const bool decided = screen_decides<METRIC>(S[c * 36u + er], rs, nst[c], row_extra, a.gamma_s, a.gamma_r, side);
-                    a.side_bytes[(uint64_t)(t + 2u * u) * a.n + row] =
-                        (uint8_t)(decided ? ((a.verify & 1u) ? (kSideVerify | side) : side) : kSideUndecided);
-                }
+                for (uint32_t u = 0; u < 8; u++)
+                    nd[u] = (live && t + 2u * u <= t_hi) ? a.node_of[(uint64_t)(t + 2u * u) * a.n + row] : 0xFFFFFFFFu;
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++) AH_NARROW_DECIDE(t + 2u * u, nd[u]);
             }
         }
     }
+#undef AH_NARROW_DECIDE
 }
 
 // The pairs the dense screen left open (side byte 2; or every pair under AH_SCREEN_VERIFY), recomputed in the reference

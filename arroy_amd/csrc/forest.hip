@@ -3136,7 +3136,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     da.n_row_tiles = dp.n_row_tiles;
                     da.n_col_tiles = dp.n_col_tiles;
                     da.group = dp.group;
-                    da.verify = verify | ((uint32_t)tun(TUN_DENSE_DEBUG) << 8);
+                    da.verify = verify;
                     const bool wide = dp.wide;
                     const uint64_t dgrid = dp.grid;
                     AH_REQUIRE(dgrid < 0x7FFFFFFFull, AH_ERR_INVALID_ARGUMENT, "forest build: too many tiles for one launch");
@@ -3932,8 +3932,19 @@ uint64_t hash_bytes(const void *data, size_t len, uint64_t seed) {
 }
 }  // namespace
 
+static int forest_digest_impl(const ah_forest *forest, const uint64_t *tree_keys, uint64_t *out_per_tree, uint64_t *out_total);
 int ah_forest_digest(const ah_forest *forest, uint64_t *out_per_tree, uint64_t *out_total) {
     AH_GUARDED("ah_forest_digest")
+    return forest_digest_impl(forest, nullptr, out_per_tree, out_total);
+    AH_GUARDED_END
+}
+int ah_forest_digest_keyed(const ah_forest *forest, const uint64_t *tree_keys, uint64_t *out_per_tree) {
+    AH_GUARDED("ah_forest_digest_keyed")
+    AH_REQUIRE(tree_keys, AH_ERR_INVALID_ARGUMENT, "tree_keys is NULL");
+    return forest_digest_impl(forest, tree_keys, out_per_tree, nullptr);
+    AH_GUARDED_END
+}
+static int forest_digest_impl(const ah_forest *forest, const uint64_t *tree_keys, uint64_t *out_per_tree, uint64_t *out_total) {
     AH_REQUIRE(forest && (out_per_tree || out_total), AH_ERR_INVALID_ARGUMENT, "NULL argument");
     const uint32_t n_trees = (uint32_t)forest->roots.size();
     const size_t n_nodes = forest->nodes.size();
@@ -3956,7 +3967,8 @@ int ah_forest_digest(const ah_forest *forest, uint64_t *out_per_tree, uint64_t *
         for (;;) {
             const uint32_t t = next.fetch_add(1, std::memory_order_relaxed);
             if (t >= n_trees) break;
-            uint64_t h = ah_mix64(0x61727279ull + t);  // the tree index is part of the content (seeds are per tree)
+            // the tree's identity is part of the content (seeds are per tree): its index in this forest, or the caller's key
+            uint64_t h = ah_mix64(0x61727279ull + (tree_keys ? tree_keys[t] : (uint64_t)t));
             const size_t base = first[t];
             for (size_t i = first[t]; i < first[t + 1]; i++) {
                 const ah_node &nd = forest->nodes[i];
@@ -3990,7 +4002,6 @@ int ah_forest_digest(const ah_forest *forest, uint64_t *out_per_tree, uint64_t *
     }
     if (out_total) *out_total = total;
     return AH_OK;
-    AH_GUARDED_END
 }
 
 // Test aid: the block -> work-item maps of the build's launches, run on the device (see include/arroy_hip.h).
@@ -4098,6 +4109,22 @@ int ah_device_cache_trim(int device, uint64_t *out_bytes) {
     if (out_bytes) *out_bytes = was;
     return AH_OK;
     AH_GUARDED_END
+}
+
+int ah_device_cache_stats(int device, uint64_t *out_live_bytes, uint64_t *out_idle_bytes) {
+    if (out_live_bytes) *out_live_bytes = dev_cache_live_bytes(device);
+    if (out_idle_bytes) {
+        uint64_t idle = 0;
+        if (device >= 0) {
+            idle = dev_cache_idle_bytes(device);
+        } else {
+            int n_dev = 0;
+            if (hipGetDeviceCount(&n_dev) != hipSuccess) n_dev = 0;
+            for (int d = 0; d < n_dev; d++) idle += dev_cache_idle_bytes(d);
+        }
+        *out_idle_bytes = idle;
+    }
+    return AH_OK;
 }
 
 int ah_host_cache_trim(uint64_t *out_bytes) {

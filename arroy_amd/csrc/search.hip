@@ -1871,6 +1871,12 @@ int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_ind
     AH_HIP(hipSetDevice(ds->device));
     ah_index *ix = new (std::nothrow) ah_index();
     AH_REQUIRE(ix, AH_ERR_OUT_OF_MEMORY, "host allocation failed");
+    struct IndexGuard {  // every way out before the last line (error codes AND exceptions) destroys the half-made index
+        ah_index *p;
+        ~IndexGuard() {
+            if (p) (void)ah_index_destroy(p);
+        }
+    } guard{ix};
     ix->ds = ds;
     ix->n_trees = v.n_trees;
     ix->n_nodes = (uint32_t)v.n_nodes;
@@ -1901,10 +1907,7 @@ int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_ind
     const uint32_t hf = header_floats(ds->metric);
     const size_t row_bytes = ds->row_bytes();
     int st = AH_OK;
-    auto fail = [&](int code) {
-        ah_index_destroy(ix);
-        return code;
-    };
+    auto fail = [&](int code) { return code; };  // (the guard destroys the index)
 #define AH_IX(expr)                                                                        \
     do {                                                                                   \
         hipError_t _e = (expr);                                                            \
@@ -1954,6 +1957,7 @@ int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_ind
     ix->nv.lut = nullptr;
     ix->nv.lut_len = 0;
     ix->nv.identity_ids = 1;
+    guard.p = nullptr;
     *out = ix;
     return AH_OK;
     AH_GUARDED_END

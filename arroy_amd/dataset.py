@@ -468,6 +468,13 @@ class Forest:
         self.stats = {f: getattr(st, f) for f, _ in _lib.AhBuildStats._fields_}
         self.stats["margin_mode_launches"] = list(st.margin_mode_launches)
 
+    def view_struct(self) -> "_lib.AhForestView":
+        """The ah_forest_view of this forest (pointers into the handle's own buffers: valid while the forest lives) — what
+        `Index(ds, None, view=...)` / ah_index_create_from_view takes."""
+        v = _lib.AhForestView()
+        _lib.check(_lib.lib().ah_forest_view_get(self._h, C.byref(v)))
+        return v
+
     def digest(self):
         """(total, per-tree array) 64-bit content digests (ah_forest_digest): equal for equal forests whatever the
         margin mode, tuning or batching that built them."""
@@ -475,6 +482,15 @@ class Forest:
         total = C.c_uint64(0)
         _lib.check(_lib.lib().ah_forest_digest(self._h, _ptr(per), C.byref(total)))
         return int(total.value), per
+
+    def digest_keyed(self, tree_keys: Sequence[int]) -> np.ndarray:
+        """Per-tree digests with `tree_keys[t]` in place of the tree's index inside this forest (ah_forest_digest_keyed): the
+        digest of a tree is then the same whichever share / device built it."""
+        keys = np.ascontiguousarray(tree_keys, dtype=np.uint64)
+        assert keys.size == self.n_trees
+        per = np.zeros(self.n_trees, dtype=np.uint64)
+        _lib.check(_lib.lib().ah_forest_digest_keyed(self._h, _ptr(keys), _ptr(per)))
+        return per
 
     def close(self) -> None:
         if self._h:

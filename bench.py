@@ -70,6 +70,15 @@ def parse_args():
                          "cold end-to-end figures and the configs[2] CPU baseline, which share the host copy)")
     ap.add_argument("--cpu-seconds", type=float, default=45.0, help="budget of the CPU baseline (bounds the build sample)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: test the N>1 control paths on CPU")
+    ap.add_argument("--virtual", action="store_true",
+                    help="N > 1 on ONE GPU: every rank / device thread uses device 0 (its own replica of the dataset, its own share "
+                         "of the trees) — the real N > 1 code path end to end where only one GPU is at hand; the big build then "
+                         "defaults to 1M items (N replicas of 10M x 768 and their screen copies do not fit one device)")
+    ap.add_argument("--build-items", type=int, default=None,
+                    help="items of the configs[2] build leg (default 10,000,000; 1,000,000 under --virtual)")
+    ap.add_argument("--check-union", action="store_true",
+                    help="N > 1: rank 0 also builds ALL trees and the union of the shares' per-tree digests must equal that build's "
+                         "(exit 6 otherwise); always on under --virtual")
     ap.add_argument("--extra", default="", help="comma list of further measurements: metrics (every f32 metric), staging, "
                                                "e2e (10M x 768 staged from host memory + 100-tree build)")
     ap.add_argument("--scan-only", action="store_true",
@@ -527,23 +536,100 @@ def extra_search(device):
     el = _timed_callers(run, [queries], 1)
     out["callers_1_filter_half"] = {"queries_per_s": nq / el, "queries": nq, "seconds": el}
     out["stats"] = index.stats()  # which descent tier / dedup path / re-rank path served the timed calls (ah_index_search_stats)
-    out.update(verify_search(ds, index, forest, n, dims, k, queries, far, half))
+    from oracle import oracle as O  # the checker (and the one-core CPU figure of the latency table): nothing timed above runs through it
+    odata = O.Data(O.DOT_PRODUCT, O.synth(SEED, 1, n, dims))
+    odata.preprocess_dot()
+    out["latency"] = search_latency(ds, index, forest, far, n, dims, k, rng, odata)
+    out.update(verify_search(ds, index, forest, n, dims, k, queries, far, half, od=odata))
     index.close()
     forest.close()
     ds.close()
     return out
 
 
-def verify_search(ds, index, forest, n, dims, k, queries, far, half, per_set=12):
+def _percentiles(samples_s):
+    import numpy as np
+    a = np.sort(np.asarray(samples_s)) * 1e6
+    return {"calls": int(a.size), "p50_us": float(a[a.size // 2]), "p90_us": float(a[int(a.size * 0.9)]),
+            "p99_us": float(a[min(a.size - 1, int(a.size * 0.99))]), "mean_us": float(a.mean()), "min_us": float(a[0])}
+
+
+def search_latency(ds, index, forest, far, n, dims, k, rng, odata, calls=300):
+    """Per-call latency of the paths arroy's API takes one query at a time (`QueryBuilder::by_vector`, src/reader.rs:46-75, one
+    `nns_by_leaf` per call, src/reader.rs:317-401): ah_search_batch at nq = 1 / 8 / 64 (distinct queries every call: nothing is
+    answered from a warm leaf set) and ah_rerank_by_vector over one candidate list of configs[3] (10 000 - 11 535 sorted ids),
+    straight through the C ABI with pre-built arguments (what a Rust caller pays; the ctypes call itself is ~2 us), host in/out
+    and synchronisation included.  Beside them: the oracle's time for the same query on ONE host core."""
+    import ctypes as C
+
+    import numpy as np
+
+    from arroy_amd import _lib as ahlib
+    L = ahlib.lib()
+    out = {"note": "wall time of one call through the C ABI (arguments pre-built, results written to caller memory); every call "
+                   "takes queries it has not seen before",
+           "search_k": 10_000, "count": k}
+    for nq in (1, 8, 64):
+        oi, od, oc = np.zeros((nq, k), np.uint32), np.zeros((nq, k), np.float32), np.zeros(nq, np.uint32)
+        args_tail = (nq, k, 10_000, 0, None, 0, 0, oi.ctypes.data_as(C.c_void_p), od.ctypes.data_as(C.c_void_p), oc.ctypes.data_as(C.c_void_p))
+        qs = [np.ascontiguousarray(far[(i * nq) % (len(far) - nq):][:nq]) for i in range(calls + 20)]
+        ptrs = [q.ctypes.data_as(C.c_void_p) for q in qs]
+        samples = []
+        for i, qp in enumerate(ptrs):
+            t0 = time.perf_counter()
+            st = L.ah_search_batch(index._h, qp, None, *args_tail)
+            el = time.perf_counter() - t0
+            if st != 0:
+                ahlib.check(st)
+            if i >= 20:
+                samples.append(el)
+        e = _percentiles(samples)
+        e["p50_us_per_query"] = e["p50_us"] / nq
+        out[f"search_nq_{nq}"] = e
+    # the re-rank alone (what integration/arroy-hip/src/hip.rs wires today: the descent stays in Rust)
+    lists = rerank_lists(rng, n, 32)
+    oi, od, on = np.zeros(k, np.uint32), np.zeros(k, np.float32), C.c_size_t(0)
+    samples = []
+    for i in range(calls + 20):
+        ids = lists[i % len(lists)]
+        q = far[i % len(far)]
+        t0 = time.perf_counter()
+        st = L.ah_rerank_by_vector(ds._h, q.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), ids.size, k,
+                                   oi.ctypes.data_as(C.c_void_p), od.ctypes.data_as(C.c_void_p), C.byref(on))
+        el = time.perf_counter() - t0
+        if st != 0:
+            ahlib.check(st)
+        if i >= 20:
+            samples.append(el)
+    out["rerank_by_vector"] = _percentiles(samples)
+    out["rerank_by_vector"]["candidates"] = "10 000 - 11 535 sorted ids per call (configs[3])"
+    # the oracle on one core, same queries / lists (the reference would add its LMDB page walks on top)
+    from oracle import oracle as O
+    cs, cr = [], []
+    for i in range(6):
+        qv, qh = odata.query_leaf(far[i])
+        t0 = time.perf_counter()
+        O.search(odata, forest, qv, qh, k, 10_000, 0, None, want_candidates=False)
+        cs.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        odata.rerank(qv, qh, lists[i], k)
+        cr.append(time.perf_counter() - t0)
+    out["cpu_one_core"] = {"kind": "port", "search_us_per_query": float(np.median(cs)) * 1e6,
+                           "rerank_us_per_query": float(np.median(cr)) * 1e6, "queries": len(cs),
+                           "note": "oracle/arroy_oracle.c (ao_search / ao_rerank), rows in RAM, one thread"}
+    return out
+
+
+def verify_search(ds, index, forest, n, dims, k, queries, far, half, per_set=12, od=None):
     """`search.verified`: sampled queries of the timed sets — clustered, distinct items, under the half filter — answered
     again by the device and compared with the CPU oracle (`Reader::nns_by_leaf` restated, src/reader.rs:317-401) on the
     same forest: ids equal, distances bit-equal.  The oracle is the checker here, nothing timed runs through it."""
     import numpy as np
 
     from oracle import oracle as O
-    vecs = O.synth(SEED, 1, n, dims)
-    od = O.Data(O.DOT_PRODUCT, vecs)
-    od.preprocess_dot()
+    if od is None:
+        od = O.Data(O.DOT_PRODUCT, O.synth(SEED, 1, n, dims))
+        od.preprocess_dot()
     checked, bad = 0, []
     for name, qs, cand in (("clustered", queries, None), ("distinct", far, None), ("filter_half", queries, half)):
         pick = np.linspace(0, len(qs) - 1, per_set).astype(int)
@@ -593,15 +679,20 @@ class RankSync:
     def __init__(self, args, rank, world, local_rank):
         import torch
         self.torch, self.dist, self.args, self.local_rank = torch, None, args, local_rank
+        # RCCL wants one rank per device: the ranks of a --virtual run share device 0 and talk over gloo (control path only —
+        # there is no collective on the data path either way)
+        self.cpu_group = bool(args.dry_run or args.virtual)
         if world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo" if args.dry_run else "nccl", rank=rank, world_size=world)
+            dist.init_process_group("gloo" if self.cpu_group else "nccl", rank=rank, world_size=world)
             self.dist = dist
 
     def barrier(self, _i=0):
+        if not self.args.dry_run:
+            self.torch.cuda.synchronize()  # this rank's device work is done before it reports to the barrier
         if self.dist is not None:
-            if self.args.dry_run:
+            if self.cpu_group:
                 self.dist.barrier()
             else:
                 self.dist.barrier(device_ids=[self.local_rank])
@@ -611,9 +702,17 @@ class RankSync:
     def max(self, x, _i=0):
         if self.dist is None:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.args.dry_run else f"cuda:{self.local_rank}")
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.cpu_group else f"cuda:{self.local_rank}")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def gather(self, obj, _i=0):
+        """`obj` of every rank, in rank order, on every rank."""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(out, obj)
+        return out
 
     def close(self):
         if self.dist is not None:
@@ -627,6 +726,7 @@ class ThreadSync:
         self.args, self.world = args, world
         self.bar = threading.Barrier(world)
         self.vals = [0.0] * world
+        self.objs = [None] * world
         self.torch = None
         if not args.dry_run:
             import torch
@@ -635,7 +735,7 @@ class ThreadSync:
     def barrier(self, i):
         self.bar.wait()
         if self.torch is not None:
-            self.torch.cuda.synchronize(i)
+            self.torch.cuda.synchronize(0 if self.args.virtual else i)
 
     def max(self, x, i):
         self.vals[i] = x
@@ -643,6 +743,13 @@ class ThreadSync:
         m = max(self.vals)
         self.bar.wait()
         return m
+
+    def gather(self, obj, i):
+        self.objs[i] = obj
+        self.bar.wait()
+        out = list(self.objs)
+        self.bar.wait()
+        return out
 
     def close(self):
         pass
@@ -742,14 +849,15 @@ def host_rows_10m(n):
     return vecs, None
 
 
-def timed_builds(ds, seeds, mode, reps, rank, sync):
+def timed_builds(ds, seeds, mode, reps, rank, sync, host_threads=0, tree_keys=None, keyed_out=None):
     """`reps` builds of `seeds` (barrier + max over ranks each); returns (per-rank seconds, max-over-ranks seconds,
-    stats, digest) of the last one."""
+    stats, digest) of the last one.  tree_keys + keyed_out: the last forest's per-tree digests keyed by the trees' indices in
+    the whole index (the same whichever share builds a tree) are stored as keyed_out[tree index] = digest."""
     samples, owns, st, dig = [], [], {}, None
     for _rep in range(reps):
         sync.barrier(rank)
         t0 = time.perf_counter()
-        forest = ds.build_forest(seeds, margin_mode=mode) if seeds else None
+        forest = ds.build_forest(seeds, margin_mode=mode, max_host_threads=host_threads) if seeds else None
         owns.append(time.perf_counter() - t0)
         sync.barrier(rank)
         samples.append(sync.max(time.perf_counter() - t0, rank))
@@ -757,8 +865,30 @@ def timed_builds(ds, seeds, mode, reps, rank, sync):
             st = forest.stats
             if _rep == reps - 1:
                 dig = forest.digest()[0]
+                if tree_keys is not None and keyed_out is not None:
+                    for t, d in zip(tree_keys, forest.digest_keyed(tree_keys)):
+                        keyed_out[int(t)] = int(d)
             forest.close()
     return owns, samples, st, dig
+
+
+class _NoSync:
+    """timed_builds for one rank on its own (the reference build of --check-union)."""
+
+    def barrier(self, _i=0):
+        pass
+
+    def max(self, x, _i=0):
+        return x
+
+
+def union_digest(per_tree):
+    """One 64-bit value over {tree index: keyed digest} in tree order: equal at every N (and for every sharding) iff every
+    tree is the same tree."""
+    h = 0xCBF29CE484222325
+    for t in sorted(per_tree):
+        h = ((h ^ (int(per_tree[t]) & 0xFFFFFFFFFFFFFFFF)) * 0x100000001B3 + t) & 0xFFFFFFFFFFFFFFFF
+    return h
 
 
 def build_entry(samples, st):
@@ -794,9 +924,13 @@ def build_10m(args, rank, world, device, sync, ds, result):
 
     from arroy_amd import Dataset, distances, shard
     from arroy_amd import _lib as ahlib
-    n = 10_000_000
+    n = args.build_items
     trees = shard.trees_for_rank(100, rank, world)
     seeds = shard.tree_seeds(SEED, trees)
+    # N > 1: the devices' builds share the host (src/writer.rs:538-548 gives ONE build the whole rayon pool): every build gets
+    # its share of the cores for its output path instead of the default eight threads each
+    host_threads = max(1, usable_cpus()[0] // world) if world > 1 else 0
+    keyed = {}
     out, cold, host_vecs = {}, None, None
     if ds is None:
         # This leg starts from a process that holds nothing: what the legs before it left in the library's device cache goes back
@@ -845,10 +979,19 @@ def build_10m(args, rank, world, device, sync, ds, result):
             ds.build_forest(seeds[:1]).close()  # warm-up (shadow copies of the rows, buffers)
     digests = {}
     for key, mode, reps in (("screened", 0, 3), ("f32_only", ahlib.MARGIN_EXACT_ONLY, 1)):
-        owns, samples, st, digests[key] = timed_builds(ds, seeds, mode, reps, rank, sync)
+        owns, samples, st, digests[key] = timed_builds(ds, seeds, mode, reps, rank, sync, host_threads, trees,
+                                                       keyed if key == "screened" else None)
         if rank == 0:
             out[key] = build_entry(samples, st)
         result.setdefault("build_10m_seconds_per_device", {}).setdefault(key, {})[rank] = sorted(owns)[len(owns) // 2]
+        if key == "screened":
+            # what a slow device of an N-GPU run looks like from one line: its own wall time (median and samples), the kernels,
+            # the host-side head and tail of the build, the host threads it was allowed
+            result.setdefault("build_10m_per_device", {})[rank] = {
+                "device": device, "trees": len(trees), "seconds": sorted(owns)[len(owns) // 2], "seconds_samples": owns,
+                "seconds_device": st.get("seconds_device"), "seconds_setup": st.get("seconds_setup"),
+                "seconds_after_device": st.get("seconds_after_device"), "max_host_threads": host_threads or 8,
+                "host_blob_recycled": st.get("host_blob_recycled")}
     stream = None
     if world == 1 and rank == 0:
         # the same build through ah_build_forest_stream: split planes per level and item ids handed to a sink from the pinned
@@ -875,6 +1018,26 @@ def build_10m(args, rank, world, device, sync, ds, result):
                           "the node table, instead of the 9.4 GB of the materialised forest"}
     identical = digests["screened"] == digests["f32_only"]
     result.setdefault("build_10m_identical_per_device", {})[rank] = bool(identical)
+    # The shares put together: every tree's digest keyed by its index in the whole index (the same whichever device built it).
+    # `union.digest` is one value over all 100 of them — equal at N = 1, 2, 4, 8 iff every run built the same forest; with
+    # --check-union (always under --virtual) rank 0 also builds all 100 trees itself and compares tree by tree.
+    all_keyed = {}
+    for part in sync.gather(keyed, rank):
+        all_keyed.update(part)
+    union = None
+    if rank == 0:
+        union = {"trees": len(all_keyed), "digest": f"{union_digest(all_keyed):016x}", "complete": sorted(all_keyed) == list(range(100))}
+    if world > 1 and (args.check_union or args.virtual):
+        ref = {}
+        if rank == 0:
+            every = list(range(100))
+            timed_builds(ds, shard.tree_seeds(SEED, every), 0, 1, 0, _NoSync(), host_threads, every, ref)
+            bad = sorted(t for t in every if all_keyed.get(t) != ref.get(t))
+            union.update(checked_against_one_device_build=True, identical=not bad, differing_trees=bad[:10])
+            result["build_10m_union_ok"] = not bad
+        sync.barrier(rank)
+    if rank == 0:
+        result["build_10m_union"] = union
     share = None
     if world == 1 and rank == 0:
         # the 13 trees GPU 0 of an 8-GPU node builds (t = 0 mod 8), on this GPU: the one-GPU proxy of the 8-GPU build time
@@ -972,6 +1135,8 @@ def dry_run_work(args, rank, world, sync, result):
 
 def main():
     args = parse_args()
+    if args.build_items is None:
+        args.build_items = 1_000_000 if args.virtual else 10_000_000
     if args.scan_only:
         scan_only(args)
         return
@@ -989,13 +1154,23 @@ def main():
             dry_run_work(args, rank, world, sync, result)
         else:
             import arroy_amd
+            if args.virtual:
+                local_rank = 0  # every rank on device 0: the N > 1 path of this process model on one GPU
             if arroy_amd.device_count() <= local_rank:
                 print(f"bench.py: rank {rank} needs device {local_rank}, {arroy_amd.device_count()} visible", file=sys.stderr)
                 sys.exit(3)
+            sync.local_rank = local_rank
             sync.torch.cuda.set_device(local_rank)
             device_work(args, rank, world, local_rank, sync, None, result)
             if not args.no_build and not args.no_build_10m and args.items == N_ITEMS:
                 build_10m(args, rank, world, local_rank, sync, None, result)
+        if not args.dry_run and world > 1:
+            for key in ("build_10m_per_device", "build_seconds_per_device", "build_10m_identical_per_device"):
+                merged = {}
+                for part in sync.gather(result.get(key, {}), rank):
+                    merged.update(part)
+                if merged:
+                    result[key] = merged
         sync.close()
         n_used = world
     else:
@@ -1007,7 +1182,7 @@ def main():
         if not args.dry_run:
             import arroy_amd
             have = arroy_amd.device_count()
-            if have < world:
+            if have < (1 if args.virtual else world):
                 print(f"bench.py: --gpus {world} but only {have} device(s) visible", file=sys.stderr)
                 sys.exit(3)
         results = [dict() for _ in range(world)]
@@ -1025,7 +1200,7 @@ def main():
             out = [d0] + [None] * (world - 1)
 
             def rep(i):
-                out[i] = d0.replicate(i)
+                out[i] = d0.replicate(0 if args.virtual else i)
             ths = [threading.Thread(target=rep, args=(i,)) for i in range(1, world)]
             [t.start() for t in ths]
             [t.join() for t in ths]
@@ -1050,13 +1225,14 @@ def main():
         if args.dry_run:
             run_threads(lambda i, _d: dry_run_work(args, i, world, sync, results[i]), [None] * world)
         else:
+            dev_of = (lambda i: 0) if args.virtual else (lambda i: i)
             dsets, rep = replicas(args.items)
-            run_threads(lambda i, d: device_work(args, i, world, i, sync, d, results[i]), dsets)
+            run_threads(lambda i, d: device_work(args, i, world, dev_of(i), sync, d, results[i]), dsets)
             if rep:
                 results[0]["replicate_1m"] = rep
             if not args.no_build and not args.no_build_10m and args.items == N_ITEMS:
-                dsets, rep = replicas(10_000_000)
-                run_threads(lambda i, d: build_10m(args, i, world, i, sync, d, results[i]), dsets)
+                dsets, rep = replicas(args.build_items)
+                run_threads(lambda i, d: build_10m(args, i, world, dev_of(i), sync, d, results[i]), dsets)
                 if rep:
                     results[0]["replicate_10m"] = rep
         result = results[0]
@@ -1077,6 +1253,11 @@ def main():
             same.update(r.get("build_10m_identical_per_device", {}))
         if same:
             result["build_10m_identical_per_device"] = same
+        perdev = {}
+        for r in results:
+            perdev.update(r.get("build_10m_per_device", {}))
+        if perdev:
+            result["build_10m_per_device"] = perdev
         n_used = world
 
     srch = None
@@ -1123,8 +1304,11 @@ def main():
             "build": result.get("build"),
             "build_10m": result.get("build_10m"),
         }
-        for key in ("build_seconds_per_device", "build_10m_seconds_per_device", "build_10m_identical_per_device", "replicate_1m",
-                    "replicate_10m"):
+        if args.virtual:
+            line["config"]["virtual_devices"] = (f"{n_used} ranks / device threads, all on device 0: the N > 1 code path on one GPU — "
+                                                 "a correctness and diagnosability run, not a throughput figure")
+        for key in ("build_seconds_per_device", "build_10m_seconds_per_device", "build_10m_identical_per_device",
+                    "build_10m_per_device", "build_10m_union", "replicate_1m", "replicate_10m"):
             if result.get(key):
                 line[key] = result[key]
         extra = result.get("extra") or {}
@@ -1152,6 +1336,10 @@ def main():
     if same and not all(same.values()):
         print(f"bench.py: screened and f32-only forests differ: {same}", file=sys.stderr)
         sys.exit(5)
+    if result.get("build_10m_union_ok") is False:
+        print(f"bench.py: the union of the devices' shares differs from the one-device build: {result.get('build_10m_union')}",
+              file=sys.stderr)
+        sys.exit(6)
     # ... and so is a search whose answers differ from the oracle's
     if srch is not None and srch.get("verified") is False:
         print(f"bench.py: on-device search differs from the oracle: {srch.get('mismatches')}", file=sys.stderr)

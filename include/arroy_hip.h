@@ -42,7 +42,7 @@ extern "C" {
                               v5: ah_search_stats / ah_index_search_stats, ah_build_options.max_host_threads (appended),
                                   ah_host_cache_trim, ah_device_cache_trim, ah_dataset_reserve_build, ah_synth_rows_host, ah_build_forest_stream (the node sink during the
                                   build), ah_build_stats.seconds_setup / seconds_after_device / host_blob_recycled
-                              v6: ah_debug_dense_tiles */
+                              v6: ah_debug_dense_tiles, ah_device_cache_stats, ah_forest_digest_keyed */
 
 /* every entry point is exported from the shared object (it is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -349,6 +349,11 @@ AH_API int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out);
  * dataset with the same seeds must agree whatever the margin mode or tuning: bench.py and the GPU tests compare the
  * screened and the f32-only build of the 10M x 100-tree forest this way.  out_per_tree: n_trees values or NULL. */
 AH_API int ah_forest_digest(const ah_forest *forest, uint64_t *out_per_tree, uint64_t *out_total);
+/* ABI v6: the per-tree digests with the caller's key in place of the tree's index inside THIS forest — e.g. the tree's
+ * index in the whole index when the forest is one GPU's share of it (trees t = device mod G, src/writer.rs:556-591): the
+ * digest of tree t is then the same whichever share, batch or device built it, and the union of the shares' digests can be
+ * compared with the digests of a one-GPU build (bench.py does, `build_10m.union`).  tree_keys / out_per_tree: n_trees values. */
+AH_API int ah_forest_digest_keyed(const ah_forest *forest, const uint64_t *tree_keys, uint64_t *out_per_tree);
 AH_API int ah_forest_stats(const ah_forest *forest, ah_build_stats *out);
 /* Node sink in the shape `TmpNodes::put` expects (src/parallel.rs:130-147): children first, parent
  * last (post-order), per tree. `payload`: SPLIT -> the normal record of ah_forest_view (vector at
@@ -510,8 +515,13 @@ AH_API int ah_host_cache_trim(uint64_t *out_bytes);
 /* Device memory is cached the same way: HBM the library has obtained (datasets, their binary16 / int8 copies, the ~28 GB of
  * scratch of a 10M x 100-tree build) goes back to the driver only under memory pressure or here — a hipMalloc that lands on
  * memory the driver is still scrubbing after a hipFree was measured to stall a build's first launch by a second
- * (AH_DEVICE_CACHE_MB bounds the idle bytes, default 192 GiB; 0 = plain hipMalloc / hipFree).  device < 0: every device. */
+ * (AH_DEVICE_CACHE_MB bounds the idle bytes, default 96 GiB; 0 = plain hipMalloc / hipFree).  device < 0: every device. */
 AH_API int ah_device_cache_trim(int device, uint64_t *out_bytes);
+/* ABI v6: what the library holds on `device` (< 0: every device) right now — bytes handed out to its datasets, indexes,
+ * builds and per-thread scratch (`live`), and bytes parked in the cache (`idle`).  Either pointer may be NULL.  The caches
+ * live as long as a dataset does: when the last dataset of a device is destroyed its idle blocks go back to the driver, and
+ * with the last dataset of the process the host blob pool goes back to the system (AH_CACHE_KEEP_IDLE=1 keeps them). */
+AH_API int ah_device_cache_stats(int device, uint64_t *out_live_bytes, uint64_t *out_idle_bytes);
 /* Benchmark harness only: n x dims synthetic rows of the generator of arroy_hip_policy.h (the rows
  * ah_dataset_fill_synthetic makes in HBM) in HOST memory, items first_item .. first_item + n - 1, on all host cores. */
 AH_API int ah_synth_rows_host(uint64_t seed, int distribution, uint64_t first_item, uint64_t n, uint32_t dims, float *out);

@@ -17,13 +17,17 @@ configs = [
     ("narrow512", dict(AH_DENSE_NARROW_MAX_COLS=512)),
     ("narrow1024", dict(AH_DENSE_NARROW_MAX_COLS=1024)),
     ("narrow4096", dict(AH_DENSE_NARROW_MAX_COLS=4096)),
+    ("narrow64", dict(AH_DENSE_NARROW_MAX_COLS=64, AH_DENSE_NARROW_STREAM=0)),
+    ("narrow64_nt", dict(AH_DENSE_NARROW_MAX_COLS=64, AH_DENSE_NARROW_STREAM=1)),
+    ("narrow128", dict(AH_DENSE_NARROW_MAX_COLS=128, AH_DENSE_NARROW_STREAM=0)),
+    ("narrow128_nt", dict(AH_DENSE_NARROW_MAX_COLS=128, AH_DENSE_NARROW_STREAM=1)),
 ]
 if len(sys.argv) > 3:
     configs = [c for c in configs if c[0] in sys.argv[3].split(",")]
 ds = Dataset(distances.Cosine, dims, n)
 ds.fill_synthetic(42, 1, n)
 ds.finalize()
-for trees in (13, 100):
+for trees in [int(t) for t in os.environ.get('R05_TREES', '13,100').split(',')]:
     seeds = shard.tree_seeds(42, shard.trees_for_rank(100, 0, 8)) if trees == 13 else shard.tree_seeds(42, range(trees))
     ref = None
     for name, knobs in configs:

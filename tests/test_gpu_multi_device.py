@@ -146,3 +146,61 @@ def test_reserved_and_recycled_memory_never_changes_a_forest():
     unused = Dataset(D.Cosine, dims, n)
     unused.reserve_build(1000)  # destroyed while (or right after) the helper runs
     unused.close()
+
+
+# ---- bench.py --gpus N on ONE GPU (--virtual): the un-dry-run N > 1 path end to end -------------------------------------------
+
+def _bench(argv, launcher=None, timeout=900):
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = ([sys.executable] + launcher if launcher else [sys.executable]) + [os.path.join(ROOT, "bench.py")] + argv
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def _check_virtual_line(out, world):
+    import json
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == world and "virtual_devices" in j["config"]
+    u = j["build_10m_union"]
+    # every tree of the 100 was built by exactly one rank, and tree by tree the shares equal rank 0's own 100-tree build
+    assert u["trees"] == 100 and u["complete"] and u["checked_against_one_device_build"] and u["identical"], u
+    per = j["build_10m_per_device"]
+    assert sorted(int(k) for k in per) == list(range(world))
+    for r, d in per.items():
+        assert d["trees"] in (100 // world, 100 // world + 1) and d["seconds"] > 0 and d["seconds_device"] > 0, (r, d)
+        assert d["seconds_setup"] is not None and d["seconds_after_device"] is not None and d["max_host_threads"] >= 1
+    same = j["build_10m_identical_per_device"]
+    assert all(same.values()) and len([k for k in same if k != "normal"]) == world  # screened == f32-only on every rank
+    assert j["build"]["trees_this_rank"] == len(range(0, 50, world))
+    return j
+
+
+def test_bench_four_virtual_devices_on_one_gpu_threads():
+    """`python bench.py --gpus 4 --virtual`: one process, four device threads, the 1M x 768 dataset staged once and replicated
+    (ah_dataset_replicate onto the same device), every thread builds its trees t = rank (mod 4); the union of the shares'
+    per-tree digests must equal a one-device build of all 100 trees (bench.py exits 6 otherwise)."""
+    out = _bench(["--gpus", "4", "--virtual", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-extra", "--no-live-pmc"])
+    j = _check_virtual_line(out, 4)
+    assert j["replicate_10m"]["replicas"] == 3 and j["replicate_10m"]["gb_per_s_total"] > 0
+    assert "4 host threads" in j["config"]["launch"]
+
+
+def test_bench_two_virtual_devices_one_process_per_rank():
+    """The launch the driver uses for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`), two ranks
+    on the one GPU: each rank fills its own dataset, builds its share, rank 0 gathers the per-device figures and checks the
+    union (gloo for the control path: RCCL wants one rank per device)."""
+    out = _bench(["--gpus", "2", "--virtual", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-extra", "--no-live-pmc"],
+                 launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29577"])
+    j = _check_virtual_line(out, 2)
+    assert "one process per GPU" in j["config"]["launch"]
