@@ -105,7 +105,7 @@ class AhSearchStats(C.Structure):
         "dedup_flag_bitmap", "dedup_flag_hash", "dedup_sorted_bitmap", "dedup_sort_lds", "dedup_sort_global",
         "rerank_tiles", "rerank_sorted", "tile_visits", "tile_units_16", "tile_units_8", "tile_units_4",
         "fallback_chunks", "fallback_non_finite", "fallback_select", "fallback_queue", "fallback_visits", "fallback_launch",
-        "filtered_queries", "leaf_kept_passes", "rerank_screened", "screen_survivors")] + [("reserved", C.c_uint64 * 2)]
+        "filtered_queries", "leaf_kept_passes", "rerank_screened", "screen_survivors", "descent_block")] + [("reserved", C.c_uint64 * 1)]
 
 
 class AhStreamNode(C.Structure):

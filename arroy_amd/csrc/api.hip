@@ -36,6 +36,8 @@ void set_error(const char *fmt, ...) {
     g_guard_depth = depth;
     g_detail = ah_error_detail{AH_ERR_DEVICE, 0, 0, 0};
 }
+NoFailScope::NoFailScope() : saved(g_guard_depth) { g_guard_depth = 0; }
+NoFailScope::~NoFailScope() { g_guard_depth = saved; }
 int guard_enter() { return g_guard_depth++; }
 void guard_leave() { g_guard_depth--; }
 int guard_failed(const char *what, int kind, const char *text) noexcept {
@@ -172,6 +174,7 @@ size_t dev_cache_live_bytes(int device) {
 }
 
 size_t dev_cache_trim(int device) {
+    NoFailScope no_fail;
     std::vector<DevBlock> drop;
     {
         std::lock_guard<std::mutex> lk(g_dev_mu);
@@ -213,6 +216,12 @@ hipError_t dev_malloc(void **p, size_t bytes, bool optional) {
     if (e != hipSuccess) return e;
     const size_t want = dev_round(bytes);
     const bool caching = tun(TUN_DEVICE_CACHE_MB) > 0;
+    try {  // room for the block's record BEFORE the block is taken: a failed push_back afterwards would lose it
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        g_dev_live.reserve(g_dev_live.size() + 1);
+    } catch (...) {
+        return hipErrorOutOfMemory;
+    }
     if (caching) {
         std::lock_guard<std::mutex> lk(g_dev_mu);
         size_t best = g_dev_idle.size();
@@ -267,6 +276,7 @@ static void dev_release_blocks(const std::vector<DevBlock> &drop) {
 
 hipError_t dev_free_unused(void *p) {
     if (!p) return hipSuccess;
+    NoFailScope no_fail;
     const size_t limit = (size_t)std::max<long long>(0, tun(TUN_DEVICE_CACHE_MB)) << 20;
     std::vector<DevBlock> drop;
     hipError_t e = hipErrorInvalidValue;
@@ -288,6 +298,7 @@ hipError_t dev_free_unused(void *p) {
 
 hipError_t dev_free(void *p) {
     if (!p) return hipSuccess;
+    NoFailScope no_fail;
     DevBlock blk{nullptr, 0, 0};
     {
         std::lock_guard<std::mutex> lk(g_dev_mu);
@@ -319,6 +330,7 @@ hipError_t dev_free(void *p) {
 }
 
 void Context::destroy() {
+    NoFailScope no_fail;
     if (d_scratch) (void)dev_free(d_scratch);
     if (d_filter) (void)dev_free(d_filter);
     if (h_pinned) (void)hipHostFree(h_pinned);
@@ -570,6 +582,7 @@ ah::Context *ah_dataset::acquire() {
     return c;
 }
 void ah_dataset::release(ah::Context *c) {
+    NoFailScope no_fail;
     std::lock_guard<std::mutex> lk(mu);
     pool.push_back(c);
 }
@@ -709,6 +722,7 @@ static int upload_flush(ah_dataset *ds);
 int ah_dataset_destroy(ah_dataset *ds) {
     AH_GUARDED("ah_dataset_destroy")
     if (!ds) return AH_OK;
+    NoFailScope no_fail;
     ds->join_reserve();
     (void)upload_flush(ds);
     (void)hipSetDevice(ds->device);

@@ -35,6 +35,14 @@ void set_error_detail(uint32_t item, uint64_t expected, uint64_t received);
 // AH_ERR_OUT_OF_MEMORY, anything else AH_ERR_DEVICE, both with ah_last_error() text.  While a thread is inside guarded()
 // the library's own `operator new` (api.hip) honours AH_FAIL_ALLOC_AFTER — only there: helper threads have nobody to
 // catch for them.
+// Release paths (destructors, ah_*_destroy, the allocators' free side) must never be the allocation AH_FAIL_ALLOC_AFTER fails:
+// a vector that grows by one element while a block is parked would throw out of a destructor.  NoFailScope suspends the
+// fault injection of the calling thread for its lifetime.
+struct NoFailScope {
+    int saved;
+    NoFailScope();
+    ~NoFailScope();
+};
 int guard_enter();            // returns the previous depth
 void guard_leave();
 int guard_failed(const char *what, int kind, const char *text) noexcept;  // kind 0: bad_alloc, 1: std::exception, 2: unknown
@@ -132,6 +140,7 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(SEARCH_BITMAP, "AH_SEARCH_BITMAP", 1)     /* 0: sort + dedup of the candidates always by the bitonic network */     \
     X(SEARCH_TILES, "AH_SEARCH_TILES", 1)       /* 0: never the leaf-tile re-rank of ah_search_batch */                   \
     X(SEARCH_WAVE, "AH_SEARCH_WAVE", 1)         /* 0: the descent always one octet per query (k_descend) */               \
+    X(SEARCH_BLOCK_MAX_QUERIES, "AH_SEARCH_BLOCK_MAX_QUERIES", 64) /* submissions of at most this many queries descend with one BLOCK (32 octets) per query; 0: never */ \
     X(RERANK_GROUPS, "AH_RERANK_GROUPS", 2)     /* groups a screened ah_rerank_batch submission is cut into (upload of group g + 1 under the kernel of g) */ \
     X(RERANK_SCREEN, "AH_RERANK_SCREEN", 1)     /* 0: ah_rerank_batch never screens its candidates (f32 rows for all) */ \
     X(SEARCH_SCREEN, "AH_SEARCH_SCREEN", 1)     /* 0: the re-rank of ah_search_batch never screens its candidates (f32 rows for all) */ \

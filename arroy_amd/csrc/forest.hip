@@ -1701,6 +1701,7 @@ class HostBlobPool {
     }
     void give(HostBlob &b, size_t used) {
         if (!b.p) return;
+        NoFailScope no_fail;
         b.committed = std::min(b.cap, std::max(b.committed, used));
         const size_t limit = (size_t)std::max<long long>(0, tun(TUN_HOST_CACHE_MB)) << 20;
         if (!b.map || limit == 0) {
@@ -1718,6 +1719,7 @@ class HostBlobPool {
         }
     }
     size_t trim() {
+        NoFailScope no_fail;
         std::lock_guard<std::mutex> lk(mu);
         const size_t was = held;
         for (HostBlob &b : idle) release(b);
@@ -1803,6 +1805,7 @@ struct Arena {
         if (bytes > left) {
             size_t got = std::max(bytes, block_bytes);
             void *p = nullptr;
+            blocks.reserve(blocks.size() + 1);  // (may throw: BEFORE the block exists, so that it cannot be lost)
             hipError_t e = dev_malloc(&p, got);
             if (e != hipSuccess && got > bytes) {  // tight on memory: exactly this level
                 (void)hipGetLastError();
@@ -4098,6 +4101,7 @@ int ah_forest_visit(const ah_forest *forest, ah_node_sink_fn sink, void *user) {
 
 int ah_forest_destroy(ah_forest *forest) {
     AH_GUARDED("ah_forest_destroy")
+    NoFailScope no_fail;
     delete forest;
     return AH_OK;
     AH_GUARDED_END

@@ -51,7 +51,7 @@ struct VisitSink {          // all null / 0: the descent records nothing
 // how the leaf tiles were cut.  Proof of the path taken (ah_index_search_stats), never an input of a result.
 enum SearchStatSlot {
     SS_ERR = 0, SS_WAVE_SMALL, SS_WAVE_BIG, SS_OCTET_LDS, SS_OCTET_GLOBAL, SS_UNITS_16, SS_UNITS_8, SS_UNITS_4, SS_VISITS,
-    SS_SCREENED, SS_SURVIVORS, SS_WORDS = 16
+    SS_SCREENED, SS_SURVIVORS, SS_BLOCK, SS_WORDS = 16
 };
 
 struct SearchParams {
@@ -478,6 +478,261 @@ __global__ __launch_bounds__(64) void k_descend_wave(DataView nv, SearchParams s
         nns_count[q] = ids_taken;
         overflow[q] = 0;
         if (sp.stats) atomicAdd(&sp.stats[kWaveHeap == 256 ? SS_WAVE_SMALL : SS_WAVE_BIG], 1u);
+    }
+}
+
+// ---- one BLOCK per query: the small submissions ------------------------------------------------------------------
+// arroy's API takes one query per call (src/reader.rs:46-75) and the wave descent's time does not depend on how many queries a
+// call brings: ~66 dependent pops of 4.5 us each = 0.3 ms for ONE query, two thirds of the whole call (round-5 kernel trace of
+// nq = 1).  With few queries the device is idle, so a query gets kOct = 32 octets instead of 8: the octets search the trees
+// t = octet (mod 32) — one tree each for the usual 10 - 30 trees — and the chain shrinks to the pops of ONE tree (~20).  Same
+// rules as k_descend_wave, the cross-octet reductions (largest queued key, ids held above it, failure) through LDS and block
+// barriers instead of wave shuffles; what it cannot hold (kHeap queue entries / kLeaves leaves per octet, equal keys of two
+// octets across the cut) is left to the passes behind it exactly like the wave kernel's leftovers.
+template <uint32_t kOct, uint32_t kHeap, uint32_t kLeaves>
+constexpr size_t block_descend_lds_bytes() {
+    return (size_t)kOct * kHeap * 8 + (size_t)kOct * kLeaves * (8 + 8 + 4 + 4 + 4 + 4) + 256;
+}
+template <uint32_t kOct, uint32_t kHeap, uint32_t kLeaves>
+__global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchParams sp, uint32_t nq,
+                                                            const uint8_t *__restrict__ qvecs, uint64_t qstride,
+                                                            const float *__restrict__ qhdrs, uint32_t *__restrict__ nns,
+                                                            uint32_t *__restrict__ nns_count, uint32_t *__restrict__ overflow,
+                                                            VisitSink sink) {
+    constexpr uint32_t kThreads = 8 * kOct, kWaves = kThreads / 64, kCap = kOct * kLeaves;
+    static_assert((kThreads & (kThreads - 1)) == 0 && kCap >= kThreads, "power-of-two block, sort network at least as wide");
+    extern __shared__ uint64_t s_blk_lds[];
+    uint64_t(*s_heap)[kHeap] = reinterpret_cast<uint64_t(*)[kHeap]>(s_blk_lds);
+    uint64_t(*s_leaf)[kLeaves] = reinterpret_cast<uint64_t(*)[kLeaves]>(s_blk_lds + (size_t)kOct * kHeap);  // key word << 32 | node
+    uint64_t *s_sorted = s_blk_lds + (size_t)kOct * kHeap + kCap;
+    uint32_t(*s_leaf_n)[kLeaves] = reinterpret_cast<uint32_t(*)[kLeaves]>(s_sorted + kCap);
+    uint32_t *s_sorted_n = reinterpret_cast<uint32_t *>(s_sorted + kCap) + kCap;
+    uint32_t *s_pos = s_sorted_n + kCap, *s_sorted_node = s_pos + kCap;
+    uint32_t *s_red = s_sorted_node + kCap;  // 64 words of scratch for the block reductions
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, o = tid >> 3, j = tid & 7u, wave = tid >> 6, wl = tid & 63u;
+    if (q >= nq) return;
+    // block-wide max / sum / or of one value per thread (all threads call; two barriers each)
+    auto block_max = [&](uint32_t v) {
+        for (uint32_t d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+        __syncthreads();
+        if (wl == 0) s_red[wave] = v;
+        __syncthreads();
+        uint32_t r = 0;
+        for (uint32_t w = 0; w < kWaves; w++) r = max(r, s_red[w]);
+        return r;
+    };
+    auto block_sum = [&](uint32_t v) {
+        for (uint32_t d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+        __syncthreads();
+        if (wl == 0) s_red[wave] = v;
+        __syncthreads();
+        uint32_t r = 0;
+        for (uint32_t w = 0; w < kWaves; w++) r += s_red[w];
+        return r;
+    };
+    uint64_t *heap = s_heap[o];
+    const void *qvec = qvecs + (uint64_t)q * qstride;
+    const LeafHdr qh = {qhdrs[2 * (uint64_t)q], qhdrs[2 * (uint64_t)q + 1]};
+    uint32_t *my_nns = nns + (uint64_t)q * sp.nns_stride;
+    uint32_t hn = 0, nl = 0;  // lane 0 of the octet
+    bool failed = false;
+    if (j == 0)
+        for (uint32_t t = o; t < sp.n_trees; t += kOct) heap_push(heap, hn, ((uint64_t)0xFF800000u << 32) | sp.roots[t]);
+    uint32_t threshold = 0;
+    bool all_settled = false;
+    for (;;) {
+        uint32_t action = 0, node = 0, key_word = 0;
+        if (j == 0 && hn > 0) {
+            const uint64_t key = heap_pop(heap, hn);
+            node = (uint32_t)key;
+            key_word = (uint32_t)(key >> 32);
+            action = sp.nodes[node].kind & 0xFFu;
+        }
+        action = __shfl(action, 0, 8);
+        node = __shfl(node, 0, 8);
+        key_word = __shfl(key_word, 0, 8);
+        if (action != 0) {
+            const DNode nd = sp.nodes[node];
+            if (action == AH_NODE_DESCENDANTS) {
+                const uint32_t kept = sp.leaf_kept ? sp.leaf_kept[node] : nd.b;
+                if (j == 0 && kept) {
+                    if (nl == kLeaves) {
+                        failed = true;
+                    } else {
+                        s_leaf[o][nl] = ((uint64_t)key_word << 32) | node;
+                        s_leaf_n[o][nl] = kept;
+                        nl++;
+                    }
+                }
+            } else {
+                float margin = 0.0f;
+                if (nd.kind & 0x100u) margin = descent_margin(nv, nd.c, qvec, qh, j);
+                if (j == 0) {
+                    if (hn + 2 > kHeap) {
+                        failed = true;
+                    } else {
+                        const float dist = key_to_dist(key_word);
+                        const float pl = rust_min(-margin, dist), pr = rust_min(margin, dist);
+                        heap_push(heap, hn, ((uint64_t)orderable_key(pl) << 32) | nd.a);
+                        heap_push(heap, hn, ((uint64_t)orderable_key(pr) << 32) | nd.b);
+                    }
+                }
+            }
+        }
+        // the largest key still queued anywhere, whether anything is queued at all, a failure — one barrier; then the ids held by
+        // the leaves strictly above that key — a second one.  (Two scratch rows alternate: a wave can be at most one reduction
+        // ahead of the slowest, so a row is never overwritten before everybody has read it.)
+        const bool has = j == 0 && hn > 0;
+        uint32_t top = has ? (uint32_t)(heap[0] >> 32) : 0u, flags = (has ? 1u : 0u) | (failed ? 2u : 0u);
+        for (uint32_t d = 32; d > 0; d >>= 1) {
+            top = max(top, (uint32_t)__shfl_xor((int)top, d, 64));
+            flags |= (uint32_t)__shfl_xor((int)flags, d, 64);
+        }
+        if (wl == 0) {
+            s_red[wave] = top;
+            s_red[8 + wave] = flags;
+        }
+        __syncthreads();
+        top = flags = 0;
+        for (uint32_t w = 0; w < kWaves; w++) {
+            top = max(top, s_red[w]);
+            flags |= s_red[8 + w];
+        }
+        if (flags & 2u) {
+            if (tid == 0) {
+                nns_count[q] = 0;
+                overflow[q] = 1;
+            }
+            return;
+        }
+        const bool any_queued = (flags & 1u) != 0;
+        const uint32_t nl_o = __shfl(nl, 0, 8);
+        uint32_t held = 0;
+        for (uint32_t i = j; i < nl_o; i += 8)
+            if (!any_queued || (uint32_t)(s_leaf[o][i] >> 32) > top) held += s_leaf_n[o][i];
+        for (uint32_t d = 32; d > 0; d >>= 1) held += __shfl_xor(held, d, 64);
+        if (wl == 0) s_red[16 + wave] = held;
+        __syncthreads();
+        held = 0;
+        for (uint32_t w = 0; w < kWaves; w++) held += s_red[16 + w];
+        if (!any_queued || held >= sp.search_k) {
+            threshold = top;
+            all_settled = !any_queued;
+            break;
+        }
+    }
+    // the settled leaves, sorted by decreasing key
+    const uint32_t nl_o = __shfl(nl, 0, 8);
+    uint32_t mine = 0;
+    for (uint32_t i = j; i < nl_o; i += 8) mine += (all_settled || (uint32_t)(s_leaf[o][i] >> 32) > threshold) ? 1u : 0u;
+    for (uint32_t d = 4; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 8);  // settled leaves of this octet
+    __syncthreads();
+    if (j == 0) s_pos[o] = mine;  // (s_pos is free until the prefix below)
+    __syncthreads();
+    uint32_t first = 0, n_settled = 0;
+    for (uint32_t oo = 0; oo < kOct; oo++) {
+        const uint32_t c = s_pos[oo];
+        first += oo < o ? c : 0u;
+        n_settled += c;
+    }
+    __syncthreads();
+    // Equal keys: inside one octet the order is the octet's own pop order (see k_descend_wave): the sort key is
+    // key word << 32 | octet << 16 | 0xFFFF - (index in the octet's list)
+    if (j == 0) {
+        uint32_t w = first;
+        for (uint32_t i = 0; i < nl; i++)
+            if (all_settled || (uint32_t)(s_leaf[o][i] >> 32) > threshold) {
+                s_sorted[w] = (s_leaf[o][i] & 0xFFFFFFFF00000000ull) | (o << 16) | (0xFFFFu - i);
+                s_sorted_node[w] = (uint32_t)s_leaf[o][i];
+                s_sorted_n[w] = s_leaf_n[o][i];
+                w++;
+            }
+    }
+    uint32_t p2 = kThreads;
+    while (p2 < n_settled) p2 <<= 1;
+    __syncthreads();
+    for (uint32_t t = n_settled + tid; t < p2; t += kThreads) {
+        s_sorted[t] = 0;
+        s_sorted_n[t] = 0;
+        s_sorted_node[t] = 0;
+    }
+    for (uint32_t size = 2; size <= p2; size <<= 1) {
+        for (uint32_t str = size >> 1; str > 0; str >>= 1) {
+            __syncthreads();
+            for (uint32_t t = tid; t < (p2 >> 1); t += kThreads) {
+                const uint32_t a_i = 2 * t - (t & (str - 1)), b_i = a_i + str;
+                const bool down = (a_i & size) == 0;  // descending order
+                const uint64_t x = s_sorted[a_i], y = s_sorted[b_i];
+                if ((x < y) == down) {
+                    s_sorted[a_i] = y;
+                    s_sorted[b_i] = x;
+                    const uint32_t nx = s_sorted_n[a_i], dx = s_sorted_node[a_i];
+                    s_sorted_n[a_i] = s_sorted_n[b_i];
+                    s_sorted_n[b_i] = nx;
+                    s_sorted_node[a_i] = s_sorted_node[b_i];
+                    s_sorted_node[b_i] = dx;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // `if nns.len() >= search_k { break }` before every pop: leaf i is taken iff the leaves before it hold < search_k ids
+    const uint32_t per = p2 / kThreads;
+    uint32_t local = 0;
+    for (uint32_t i = 0; i < per; i++) local += s_sorted_n[tid * per + i];
+    uint32_t incl = local;
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d, 64);
+        if (wl >= d) incl += v;
+    }
+    if (wl == 63) s_red[32 + wave] = incl;  // (the upper half of the scratch: block_max / block_sum use the lower)
+    __syncthreads();
+    uint32_t before = incl - local;
+    for (uint32_t w = 0; w < wave; w++) before += s_red[32 + w];
+    uint32_t taken = 0, ids_taken = 0;
+    bool tie = false;
+    for (uint32_t i = 0; i < per; i++) {
+        const uint32_t e = tid * per + i;
+        if (e < n_settled && before < sp.search_k) {
+            s_pos[e] = before;
+            taken++;
+            ids_taken = before + s_sorted_n[e];
+            if (ids_taken >= sp.search_k) {  // the leaf that reaches search_k: equal keys of another octet around it -> sequential queue
+                const uint32_t kw = (uint32_t)(s_sorted[e] >> 32), oct = (uint32_t)s_sorted[e] >> 16;
+                for (uint32_t g = e + 1; g < n_settled && (uint32_t)(s_sorted[g] >> 32) == kw; g++)
+                    if (((uint32_t)s_sorted[g] >> 16) != oct) tie = true;
+                for (uint32_t g = e; g-- > 0 && (uint32_t)(s_sorted[g] >> 32) == kw;)
+                    if (((uint32_t)s_sorted[g] >> 16) != oct) tie = true;
+            }
+        }
+        before += s_sorted_n[e];
+    }
+    taken = block_sum(taken);
+    ids_taken = block_max(ids_taken);
+    const uint32_t any_tie = block_max(tie ? 1u : 0u);
+    if (any_tie || ids_taken > sp.nns_stride) {
+        if (tid == 0) {
+            nns_count[q] = 0;
+            overflow[q] = 1;
+        }
+        return;
+    }
+    __syncthreads();
+    for (uint32_t e = o; e < taken; e += kOct) {  // the taken leaves are the first `taken` of the sorted list
+        const uint32_t node = s_sorted_node[e], pos = s_pos[e];
+        const DNode nd = sp.nodes[node];
+        const uint32_t *ids = sp.desc + nd.a;
+        if (!sp.filter_bits) {
+            for (uint32_t i = j; i < nd.b; i += 8) my_nns[pos + i] = ids[i];
+        } else {
+            copy_filtered(sp, ids, nd.b, my_nns + pos, j);
+        }
+        if (j == 0) record_visit(sink, node, q, pos, s_sorted_n[e]);
+    }
+    if (tid == 0) {
+        nns_count[q] = ids_taken;
+        overflow[q] = 0;
+        if (sp.stats) atomicAdd(&sp.stats[SS_BLOCK], 1u);
     }
 }
 
@@ -1775,6 +2030,7 @@ int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_ind
 int ah_index_destroy(ah_index *ix) {
     AH_GUARDED("ah_index_destroy")
     if (!ix) return AH_OK;
+    NoFailScope no_fail;
     if (ix->ds) (void)hipSetDevice(ix->ds->device);
     (void)hipDeviceSynchronize();
     if (ix->d_nodes) (void)dev_free(ix->d_nodes);
@@ -1979,6 +2235,7 @@ struct ChunkStats {
         s.descent_wave_big += w[SS_WAVE_BIG];
         s.descent_octet_lds += w[SS_OCTET_LDS];
         s.descent_octet_global += w[SS_OCTET_GLOBAL];
+        s.descent_block += w[SS_BLOCK];
         s.tile_units_16 += w[SS_UNITS_16];
         s.tile_units_8 += w[SS_UNITS_8];
         s.tile_units_4 += w[SS_UNITS_4];
@@ -2144,18 +2401,37 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         // a query pops about 1 / (kept share) as many nodes under a filter: start with the big queues (one query per CU
         // at a time) only then; otherwise they take what the small ones (four per CU) could not hold
         const bool small_first = !d_filter_bits || filter_share >= 0.35;
-        if (small_first)
+        // few queries: a block of 32 octets per query (one tree per octet: a third of the chain of dependent pops) while the
+        // device has the room — arroy's own API is one query per call (src/reader.rs:46-75)
+        const long long block_max_nq = tun(TUN_SEARCH_BLOCK_MAX_QUERIES);
+        static std::atomic<bool> lds_opt_in[64];  // once per device: the kernels that want more than 64 KiB of LDS
+        constexpr size_t block_lds = block_descend_lds_bytes<32, 128, 32>();
+        const void *wave_big = reinterpret_cast<const void *>(k_descend_wave<1024, 128>);
+        const void *block_fn = reinterpret_cast<const void *>(k_descend_block<32, 128, 32>);
+        if (!lds_opt_in[ds->device & 63].load(std::memory_order_acquire)) {
+            AH_HIP(hipFuncSetAttribute(wave_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave_lds_bytes(1024, 128)));
+            AH_HIP(hipFuncSetAttribute(block_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds));
+            lds_opt_in[ds->device & 63].store(true, std::memory_order_release);
+        }
+        if (small_first && (long long)nq <= block_max_nq)
+            hipLaunchKernelGGL((k_descend_block<32, 128, 32>), dim3((unsigned)nq), dim3(256), block_lds, s, ix->nv, sp, (uint32_t)nq,
+                               d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink);
+        else if (small_first)
             hipLaunchKernelGGL((k_descend_wave<256, 64>), dim3((unsigned)nq), dim3(64), wave_lds_bytes(256, 64), s, ix->nv, sp,
                                (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink, false);
-        AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_descend_wave<1024, 128>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave_lds_bytes(1024, 128)));
         hipLaunchKernelGGL((k_descend_wave<1024, 128>), dim3((unsigned)nq), dim3(64), wave_lds_bytes(1024, 128), s, ix->nv, sp,
                            (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink, small_first);
         return AH_OK;
     };
     const size_t heap_lds = (size_t)8 * kHeapLds * 8;
-    AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_descend<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)heap_lds));
+    {
+        static std::atomic<bool> heap_opt_in[64];  // once per device (a runtime call per search is microseconds of a 0.2 ms call)
+        if (!heap_opt_in[ds->device & 63].load(std::memory_order_acquire)) {
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_descend<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)heap_lds));
+            heap_opt_in[ds->device & 63].store(true, std::memory_order_release);
+        }
+    }
     if (tiles) {  // 2'. the leaf-tile path: descent with its visits recorded, no host round trip before the results
         uint32_t *d_total = d_leaf_count + ix->n_nodes, *d_n_units = d_total + 1;
         AH_HIP(hipMemsetAsync(d_leaf_count, 0, (size_t)ix->n_nodes * 4 + 8, s));

@@ -70,7 +70,9 @@ def parse_args():
                          "cold end-to-end figures and the configs[2] CPU baseline, which share the host copy)")
     ap.add_argument("--cpu-seconds", type=float, default=45.0, help="budget of the CPU baseline (bounds the build sample)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: test the N>1 control paths on CPU")
-    ap.add_argument("--virtual", action="store_true",
+    # (`--virtual-devices` under torch.distributed.run: its own parser takes a bare `--virtual` for an abbreviation of its
+    # `--virtual-local-rank`, wherever on the command line it stands)
+    ap.add_argument("--virtual", "--virtual-devices", dest="virtual", action="store_true",
                     help="N > 1 on ONE GPU: every rank / device thread uses device 0 (its own replica of the dataset, its own share "
                          "of the trees) — the real N > 1 code path end to end where only one GPU is at hand; the big build then "
                          "defaults to 1M items (N replicas of 10M x 768 and their screen copies do not fit one device)")

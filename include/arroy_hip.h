@@ -42,7 +42,7 @@ extern "C" {
                               v5: ah_search_stats / ah_index_search_stats, ah_build_options.max_host_threads (appended),
                                   ah_host_cache_trim, ah_device_cache_trim, ah_dataset_reserve_build, ah_synth_rows_host, ah_build_forest_stream (the node sink during the
                                   build), ah_build_stats.seconds_setup / seconds_after_device / host_blob_recycled
-                              v6: ah_debug_dense_tiles, ah_device_cache_stats, ah_forest_digest_keyed */
+                              v6: ah_debug_dense_tiles, ah_device_cache_stats, ah_forest_digest_keyed, ah_search_stats.descent_block */
 
 /* every entry point is exported from the shared object (it is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -444,7 +444,8 @@ typedef struct ah_search_stats {
     uint64_t calls;                 /* ah_search_batch calls that reached the device                                   */
     uint64_t chunks;                /* sub-batches they were cut into                                                  */
     uint64_t queries;
-    /* the descent that produced a query's candidates (src/reader.rs:341-374); the four sum to `queries` */
+    /* the descent that produced a query's candidates (src/reader.rs:341-374); these four and `descent_block` below sum to
+     * `queries` */
     uint64_t descent_wave_small;    /* one wave per query, 256 queue entries / 64 leaves per octet                     */
     uint64_t descent_wave_big;      /* ... its second pass, 1024 / 128                                                 */
     uint64_t descent_octet_lds;     /* one octet per query, the sequential queue in LDS                                */
@@ -475,7 +476,9 @@ typedef struct ah_search_stats {
      * rows first, only those whose proven distance interval reaches the top `count` in f32 */
     uint64_t rerank_screened;       /* queries whose top-k went through the screen                                      */
     uint64_t screen_survivors;      /* candidates of those queries evaluated in f32 (the rest: 2 x dims bytes each)     */
-    uint64_t reserved[2];
+    uint64_t descent_block;         /* ABI v6: one block (32 octets, one tree each) per query: submissions of few queries;
+                                       a fifth tier of the descent — the five sum to `queries` */
+    uint64_t reserved[1];
 } ah_search_stats;
 AH_API int ah_index_search_stats(ah_index *index, ah_search_stats *out, int reset);
 

@@ -81,8 +81,8 @@ mod item_iter;
                 nb_missing_trees as usize,
                 &concurrent_node_ids,
                 &mut tmp_node.borrow_mut(),
+                &progress, // `SubStep.current`: credited level by level while the device builds
             )?;
-            progress.fetch_add(nb_missing_trees, Ordering::Relaxed);
             roots.extend(new_roots);
             0
         } else {
@@ -105,7 +105,7 @@ mod item_iter;
         #[cfg(feature = "hip")]
         if let Some(staged) = self.hip.as_ref() {
             let query: Vec<f32> = query_leaf.vector.iter().collect();
-            return staged.rerank(&query, &nns, opt.count);
+            return crate::hip::Rerank::rerank(staged.as_ref(), &query, &nns, opt.count);
         }
 
         let mut nns_distances = Vec::with_capacity(nns.len());
@@ -118,9 +118,9 @@ mod item_iter;
 impl<'t, D: Distance> Reader<'t, D> {
 """,
         """    version: Version,
-    /// The items in HBM (`hip` feature): set by `Reader::stage_on_gpu`.
+    /// The items and the tree nodes in HBM (`hip` feature): set by `Reader::stage_on_gpu`.
     #[cfg(feature = "hip")]
-    hip: Option<Box<dyn crate::hip::Rerank + Send + Sync + 't>>,
+    hip: Option<Box<crate::hip::HipSearch<D>>>,
     _marker: marker::PhantomData<D>,
 }
 
@@ -140,8 +140,9 @@ impl<'t, D: Distance> Reader<'t, D> {
         })
     }
 
-    /// Copies the items into the memory of GPU `device` (`hip` feature): from then on `nns_by_vector` / `nns_by_item`
-    /// re-rank their candidates there.  The pointers into the LMDB pages are only used during this call.
+    /// Copies the items AND the tree nodes into the memory of GPU `device` (`hip` feature): from then on `nns_by_vector` /
+    /// `nns_by_item` re-rank their candidates there, and `nns_by_vectors_on_gpu` answers whole batches of queries on the
+    /// device.  The pointers into the LMDB pages are only used during this call.
     #[cfg(feature = "hip")]
     pub fn stage_on_gpu(&mut self, rtxn: &'t RoTxn, device: i32) -> Result<()>
     where
@@ -152,8 +153,57 @@ impl<'t, D: Distance> Reader<'t, D> {
             crate::parallel::ImmutableLeafs::new(rtxn, &options, self.database, &self.items, self.index)?;
         let staged =
             crate::hip::stage_leafs(&leafs, &self.items, self.dimensions, self.index, device, true)?;
-        self.hip = Some(Box::new(staged));
+        // Every node reachable from the roots, in ascending `NodeId` order: the forest-local index of a node is its rank, so the
+        // ties of the reference's `BinaryHeap<(OrderedFloat<f32>, NodeId)>` fall the same way on the device.
+        let mut reachable: Vec<NodeId> = self.roots.iter().map(NodeId::tree).collect();
+        let mut next = 0;
+        while next < reachable.len() {
+            let key = Key::new(self.index, reachable[next]);
+            if let GenericReadNode::SplitPlaneNormal(GenericReadSplitPlaneNormal { left, right, .. }) =
+                self.database_get(rtxn, &key)?.ok_or(Error::missing_key(key))?
+            {
+                reachable.push(left);
+                reachable.push(right);
+            }
+            next += 1;
+        }
+        reachable.sort_unstable();
+        reachable.dedup();
+        let rank = |id: &NodeId| reachable.binary_search(id).map(|i| i as u32).map_err(|_| Error::missing_key(Key::new(self.index, *id)));
+        let vector_len = crate::hip::vector_len::<D>(self.dimensions);
+        let mut image = crate::hip::ForestImage::new::<D>(vector_len);
+        for id in &reachable {
+            let key = Key::new(self.index, *id);
+            match self.database_get(rtxn, &key)?.ok_or(Error::missing_key(key))? {
+                GenericReadNode::Leaf(_) => image.push_descendants(std::iter::once(id.item)),
+                GenericReadNode::Descendants(Descendants { descendants }) => image.push_descendants(descendants.iter()),
+                GenericReadNode::SplitPlaneNormal(GenericReadSplitPlaneNormal { normal, left, right }) => {
+                    image.push_split::<D>(rank(&left)?, rank(&right)?, normal.as_ref())
+                }
+            }
+        }
+        for root in self.roots.iter() {
+            image.push_root(rank(&NodeId::tree(root))?);
+        }
+        self.hip = Some(Box::new(crate::hip::HipSearch::new(staged, &image, self.dimensions)?));
         Ok(())
+    }
+
+    /// `nns_by_vector` for many queries at once, entirely on the GPU (`hip` feature, after `stage_on_gpu`): best-first descent,
+    /// candidate collection, sort + dedup, distances, top-`count` and `normalized_distance` of every query in ONE call —
+    /// `vectors` holds the queries back to back (`dimensions` floats each).  Same lists, same order, same bits as calling
+    /// `nns(count).search_k(..).oversampling(..).candidates(..).by_vector(..)` once per query.
+    #[cfg(feature = "hip")]
+    pub fn nns_by_vectors_on_gpu(
+        &self,
+        vectors: &[f32],
+        count: usize,
+        search_k: Option<NonZeroUsize>,
+        oversampling: Option<NonZeroUsize>,
+        candidates: Option<&RoaringBitmap>,
+    ) -> Result<Vec<Vec<(ItemId, f32)>>> {
+        let staged = self.hip.as_ref().ok_or_else(|| Error::Panic("Reader::stage_on_gpu has not been called".to_string()))?;
+        staged.search_batch(vectors, count, search_k.map_or(0, NonZeroUsize::get), oversampling.map_or(0, NonZeroUsize::get), candidates)
     }
 """)],
 }

@@ -1,14 +1,20 @@
 //! MI355X back end of arroy's hot loops (cargo feature `hip`).
 //!
-//! Thin `extern "C"` bindings of `libarroy_hip.so` (`include/arroy_hip.h`, ABI v5) plus the three places where arroy
-//! hands a whole *loop* to the GPU instead of running it per item:
+//! Thin `extern "C"` bindings of `libarroy_hip.so` (`include/arroy_hip.h`, ABI v6) plus the places where arroy hands a
+//! whole *loop* to the GPU instead of running it per item:
 //!
 //! * [`stage_leafs`]  — `ImmutableLeafs::new` (`src/parallel.rs`): the stored item records, straight from their LMDB
 //!   pages, into HBM (`ah_dataset_upload_records`);
 //! * [`build_new_trees`] — the `rayon::scope` over the root descendants + `make_tree_in_file` (`src/writer.rs`): whole
 //!   trees built on the device and handed back node by node WHILE they are built (`ah_build_forest_stream`), encoded
 //!   with `NodeCodec` and appended to a `TmpNodes` exactly like the CPU path does;
-//! * [`Rerank`] — the distance loop + `median_based_top_k` of `Reader::nns_by_leaf` (`src/reader.rs`).
+//! * [`Rerank`] — the distance loop + `median_based_top_k` of `Reader::nns_by_leaf` (`src/reader.rs`);
+//! * [`HipSearch`] — the WHOLE `nns_by_leaf` (best-first descent, candidate collection, sort + dedup, re-rank, top-k) for a
+//!   batch of queries in one call (`ah_search_batch`), over a mirror of the tree nodes made by `Reader::stage_on_gpu`
+//!   ([`ForestImage`] -> `ah_index_create_from_view`);
+//! * [`route_items`], [`build_subtrees`], [`preprocess_dot`] — the incremental insert
+//!   (`insert_items_in_descendants_from_frozen_reader`, `incremental_index_large_descendant`) and
+//!   `DotProduct::preprocess` on the device: bound and wrapped here, call sites not patched yet.
 //!
 //! LMDB, roaring, `NodeCodec`, `TmpNodes`, node-id allocation, the RNG and the public API stay as they are.
 //! Link with `RUSTFLAGS="-L <dir of libarroy_hip.so>"`; the library needs `libamdhip64` at run time.
@@ -16,9 +22,9 @@
 use std::borrow::Cow;
 use std::ffi::CStr;
 use std::marker::PhantomData;
-use std::mem::{size_of, MaybeUninit};
+use std::mem::{align_of, offset_of, size_of, MaybeUninit};
 use std::os::raw::{c_char, c_int, c_void};
-use std::sync::atomic::{AtomicI32, Ordering};
+use std::sync::atomic::{AtomicI32, AtomicU64, Ordering};
 
 use bytemuck::pod_read_unaligned;
 use rand::Rng;
@@ -33,10 +39,50 @@ use crate::{Error, ItemId, Result};
 
 pub const AH_ABI_VERSION: c_int = 6;
 const AH_NODE_DESCENDANTS: u8 = 1;
+const AH_NODE_SPLIT: u8 = 2;
 
 #[repr(C)]
 pub struct AhDataset {
     _p: [u8; 0],
+}
+
+#[repr(C)]
+pub struct AhIndex {
+    _p: [u8; 0],
+}
+
+#[repr(C)]
+pub struct AhForest {
+    _p: [u8; 0],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct AhNode {
+    pub kind: u8,       // AH_NODE_DESCENDANTS | AH_NODE_SPLIT
+    pub has_normal: u8, // 0 = `normal: None`
+    pub reserved: u16,
+    pub tree: u32,
+    pub left: u32,      // forest-local node indices (SPLIT)
+    pub right: u32,
+    pub offset: u64,    // SPLIT: byte offset into `normals`; DESCENDANTS: first id index
+    pub count: u32,
+    pub depth: u32,
+}
+
+#[repr(C)]
+pub struct AhForestView {
+    pub n_trees: u32,
+    pub n_nodes: u64,
+    pub roots: *const u32,
+    pub nodes: *const AhNode,
+    pub normals: *const u8,
+    pub normals_len: u64,
+    pub normal_stride: u64,
+    pub normal_vector_offset: u64,
+    pub normal_header_offset: u64,
+    pub descendants: *const u32,
+    pub descendants_len: u64,
 }
 
 #[repr(C)]
@@ -122,7 +168,98 @@ extern "C" {
         out_dists: *mut f32,
         out_n: *mut usize,
     ) -> c_int;
+    fn ah_index_create_from_view(ds: *mut AhDataset, view: *const AhForestView, out: *mut *mut AhIndex) -> c_int;
+    fn ah_index_destroy(index: *mut AhIndex) -> c_int;
+    fn ah_search_batch(
+        index: *mut AhIndex,
+        queries: *const f32,
+        query_items: *const u32,
+        nq: usize,
+        count: usize,
+        search_k: usize,
+        oversampling: usize,
+        filter_sorted: *const u32,
+        n_filter: usize,
+        have_filter: c_int,
+        out_ids: *mut u32,
+        out_dists: *mut f32,
+        out_counts: *mut u32,
+    ) -> c_int;
+    fn ah_route_items(index: *mut AhIndex, item_ids: *const u32, n: usize, tree_seeds: *const u64, out_leaf: *mut u32) -> c_int;
+    fn ah_build_subtrees(
+        ds: *mut AhDataset,
+        options: *const AhBuildOptions,
+        item_ids: *const u32,
+        offsets: *const u64,
+        out: *mut *mut AhForest,
+    ) -> c_int;
+    fn ah_forest_view_get(forest: *const AhForest, out: *mut AhForestView) -> c_int;
+    fn ah_forest_destroy(forest: *mut AhForest) -> c_int;
+    fn ah_preprocess_dot(ds: *mut AhDataset, out_max_norm: *mut f32) -> c_int;
+    fn ah_dataset_read_headers(ds: *mut AhDataset, first_row: u64, n: u64, out_headers: *mut c_void) -> c_int;
 }
+
+// ---- layout self-checks: generated by integration/arroy-hip/tools/gen_layout.py from include/arroy_hip.h ----
+const _: () = assert!(size_of::<AhBuildOptions>() == 56 && align_of::<AhBuildOptions>() == 8);
+const _: () = assert!(offset_of!(AhBuildOptions, n_trees) == 0);
+const _: () = assert!(offset_of!(AhBuildOptions, split_after) == 4);
+const _: () = assert!(offset_of!(AhBuildOptions, tree_seeds) == 8);
+const _: () = assert!(offset_of!(AhBuildOptions, cancel) == 16);
+const _: () = assert!(offset_of!(AhBuildOptions, progress) == 24);
+const _: () = assert!(offset_of!(AhBuildOptions, progress_user) == 32);
+const _: () = assert!(offset_of!(AhBuildOptions, max_trees_in_flight) == 40);
+const _: () = assert!(offset_of!(AhBuildOptions, margin_mode) == 44);
+const _: () = assert!(offset_of!(AhBuildOptions, max_host_threads) == 48);
+const _: () = assert!(offset_of!(AhBuildOptions, reserved0) == 52);
+const _: () = assert!(size_of::<AhErrorDetail>() == 24 && align_of::<AhErrorDetail>() == 8);
+const _: () = assert!(offset_of!(AhErrorDetail, status) == 0);
+const _: () = assert!(offset_of!(AhErrorDetail, item) == 4);
+const _: () = assert!(offset_of!(AhErrorDetail, expected) == 8);
+const _: () = assert!(offset_of!(AhErrorDetail, received) == 16);
+const _: () = assert!(size_of::<AhStreamNode>() == 40 && align_of::<AhStreamNode>() == 8);
+const _: () = assert!(offset_of!(AhStreamNode, id) == 0);
+const _: () = assert!(offset_of!(AhStreamNode, tree) == 4);
+const _: () = assert!(offset_of!(AhStreamNode, kind) == 8);
+const _: () = assert!(offset_of!(AhStreamNode, has_normal) == 9);
+const _: () = assert!(offset_of!(AhStreamNode, reserved) == 10);
+const _: () = assert!(offset_of!(AhStreamNode, left) == 12);
+const _: () = assert!(offset_of!(AhStreamNode, right) == 16);
+const _: () = assert!(offset_of!(AhStreamNode, count) == 20);
+const _: () = assert!(offset_of!(AhStreamNode, depth) == 24);
+const _: () = assert!(offset_of!(AhStreamNode, payload_offset) == 32);
+const _: () = assert!(size_of::<AhNodeBatch>() == 64 && align_of::<AhNodeBatch>() == 8);
+const _: () = assert!(offset_of!(AhNodeBatch, kind) == 0);
+const _: () = assert!(offset_of!(AhNodeBatch, level) == 4);
+const _: () = assert!(offset_of!(AhNodeBatch, n_nodes) == 8);
+const _: () = assert!(offset_of!(AhNodeBatch, nodes) == 16);
+const _: () = assert!(offset_of!(AhNodeBatch, payload) == 24);
+const _: () = assert!(offset_of!(AhNodeBatch, payload_len) == 32);
+const _: () = assert!(offset_of!(AhNodeBatch, normal_stride) == 40);
+const _: () = assert!(offset_of!(AhNodeBatch, normal_vector_offset) == 48);
+const _: () = assert!(offset_of!(AhNodeBatch, normal_header_offset) == 56);
+const _: () = assert!(size_of::<AhNode>() == 32 && align_of::<AhNode>() == 8);
+const _: () = assert!(offset_of!(AhNode, kind) == 0);
+const _: () = assert!(offset_of!(AhNode, has_normal) == 1);
+const _: () = assert!(offset_of!(AhNode, reserved) == 2);
+const _: () = assert!(offset_of!(AhNode, tree) == 4);
+const _: () = assert!(offset_of!(AhNode, left) == 8);
+const _: () = assert!(offset_of!(AhNode, right) == 12);
+const _: () = assert!(offset_of!(AhNode, offset) == 16);
+const _: () = assert!(offset_of!(AhNode, count) == 24);
+const _: () = assert!(offset_of!(AhNode, depth) == 28);
+const _: () = assert!(size_of::<AhForestView>() == 88 && align_of::<AhForestView>() == 8);
+const _: () = assert!(offset_of!(AhForestView, n_trees) == 0);
+const _: () = assert!(offset_of!(AhForestView, n_nodes) == 8);
+const _: () = assert!(offset_of!(AhForestView, roots) == 16);
+const _: () = assert!(offset_of!(AhForestView, nodes) == 24);
+const _: () = assert!(offset_of!(AhForestView, normals) == 32);
+const _: () = assert!(offset_of!(AhForestView, normals_len) == 40);
+const _: () = assert!(offset_of!(AhForestView, normal_stride) == 48);
+const _: () = assert!(offset_of!(AhForestView, normal_vector_offset) == 56);
+const _: () = assert!(offset_of!(AhForestView, normal_header_offset) == 64);
+const _: () = assert!(offset_of!(AhForestView, descendants) == 72);
+const _: () = assert!(offset_of!(AhForestView, descendants_len) == 80);
+// ---- end of the generated block ----
 
 /// `ah_status` -> `arroy::Error` (src/error.rs).  Nothing unwinds across the ABI; the typed variants are rebuilt from
 /// `ah_last_error_detail` (thread-local, like `ah_last_error`).
@@ -160,6 +297,15 @@ fn metric_of<D: Distance>() -> Result<c_int> {
         "binary quantized cosine" => 6,
         other => return Err(Error::Panic(format!("libarroy_hip.so does not implement the distance `{other}`"))),
     })
+}
+
+/// Bytes of one stored vector of `D` at `dimensions` (`UnalignedVector` codecs: 4 per dimension, or one bit per dimension in
+/// whole 64-bit words).
+pub fn vector_len<D: Distance>(dimensions: usize) -> usize {
+    match D::name() {
+        "binary quantized euclidean" | "binary quantized manhattan" | "binary quantized cosine" => dimensions.div_ceil(64) * 8,
+        _ => dimensions * 4,
+    }
 }
 
 /// The HBM-resident image of `ImmutableLeafs` (an `ah_dataset`).  Immutable once staged; `Sync` like the reference's
@@ -294,16 +440,19 @@ pub fn build_new_trees<D: Distance, R: Rng>(
     n_trees: usize,
     node_ids: &ConcurrentNodeIds,
     tmp_nodes: &mut TmpNodes<D>,
+    progress: &AtomicU64,
 ) -> Result<Vec<ItemId>> {
     let seeds: Vec<u64> = (0..n_trees).map(|_| rng.gen()).collect(); // as `StdRng::from_seed(rng.gen())` per task
     let cancel = AtomicI32::new(0);
+    // `SubStep.current` of the reference counts descendants handled: the build bumps it by its `n_trees` roots, level by level
+    let progress_state = ProgressState { counter: progress, n_trees: n_trees as u64, reported: AtomicU64::new(0) };
     let opt = AhBuildOptions {
         n_trees: n_trees as u32,
         split_after: options.split_after.unwrap_or(0) as u32,
         tree_seeds: seeds.as_ptr(),
         cancel: cancel.as_ptr() as *const c_int,
-        progress: None,
-        progress_user: std::ptr::null_mut(),
+        progress: Some(progress_trampoline),
+        progress_user: &progress_state as *const ProgressState as *mut c_void,
         max_trees_in_flight: 0,
         margin_mode: 0,
         max_host_threads: 0,
@@ -343,7 +492,36 @@ pub fn build_new_trees<D: Distance, R: Rng>(
         return Err(e);
     }
     check(code, leafs.index)?;
+    progress_state.finish();
     roots.into_iter().map(|r| state.global_id(r)).collect()
+}
+
+/// `ah_progress_fn` -> the `SubStep.current` counter of `WriterProgress` (src/writer.rs): the library reports every finished
+/// level; a forest of `n_items / split_after` leaves per tree has about 16 of them, so the `n_trees` units of the sub-step
+/// are credited a sixteenth per level and the remainder when the build returns.
+struct ProgressState<'a> {
+    counter: &'a AtomicU64,
+    n_trees: u64,
+    reported: AtomicU64,
+}
+
+impl ProgressState<'_> {
+    fn credit(&self, target: u64) {
+        let target = target.min(self.n_trees);
+        let before = self.reported.fetch_max(target, Ordering::Relaxed);
+        if target > before {
+            self.counter.fetch_add(target - before, Ordering::Relaxed);
+        }
+    }
+
+    fn finish(&self) {
+        self.credit(self.n_trees);
+    }
+}
+
+extern "C" fn progress_trampoline(user: *mut c_void, level: u32, _nodes_done: u64, _items_routed: u64) {
+    let state = unsafe { &*(user as *const ProgressState) };
+    state.credit(state.n_trees * (level as u64 + 1) / 16);
 }
 
 /// The distance loop + `median_based_top_k` + `normalized_distance` of `Reader::nns_by_leaf`: `nns` sorted and
@@ -365,4 +543,232 @@ impl<D: Distance> Rerank for HipLeafs<D> {
         )?;
         Ok(ids.into_iter().zip(dists).take(n).collect())
     }
+}
+
+/// The tree nodes of an index in the shape `ah_index_create_from_view` takes (`ah_forest_view`): filled by
+/// `Reader::stage_on_gpu` from the nodes it decodes out of LMDB.  Node identity — the tie-break of the reference's
+/// `BinaryHeap<(OrderedFloat<f32>, NodeId)>` — is the forest-local index, so the caller pushes the nodes in ascending
+/// `NodeId` order (`(mode, item)`, src/node_id.rs) and every tie falls like the reference's.
+pub struct ForestImage {
+    nodes: Vec<AhNode>,
+    roots: Vec<u32>,
+    normals: Vec<u8>,
+    descendants: Vec<u32>,
+    vector_len: usize,
+    header_len: usize,
+    stride: usize,
+}
+
+impl ForestImage {
+    /// `vector_len`: bytes of one stored vector; the record of a normal is `[vector][header]`, padded to 4 bytes.
+    pub fn new<D: Distance>(vector_len: usize) -> ForestImage {
+        let header_len = size_of::<D::Header>();
+        let stride = (vector_len + header_len + 3) & !3;
+        ForestImage { nodes: Vec::new(), roots: Vec::new(), normals: Vec::new(), descendants: Vec::new(), vector_len, header_len, stride }
+    }
+
+    pub fn push_root(&mut self, local: u32) {
+        self.roots.push(local);
+    }
+
+    /// A `SplitPlaneNormal`; `left` / `right` are forest-local indices (ranks of the children's `NodeId`s).
+    pub fn push_split<D: Distance>(&mut self, left: u32, right: u32, normal: Option<&Leaf<D>>) {
+        let offset = self.normals.len() as u64;
+        if let Some(normal) = normal {
+            let bytes = normal.vector.as_bytes();
+            debug_assert_eq!(bytes.len(), self.vector_len);
+            self.normals.extend_from_slice(bytes);
+            self.normals.extend_from_slice(bytemuck::bytes_of(&normal.header));
+            self.normals.resize(offset as usize + self.stride, 0);
+        }
+        self.nodes.push(AhNode {
+            kind: AH_NODE_SPLIT,
+            has_normal: normal.is_some() as u8,
+            reserved: 0,
+            tree: 0,
+            left,
+            right,
+            offset,
+            count: 0,
+            depth: 0,
+        });
+    }
+
+    /// A `Descendants` node, or an item a split points to directly (`NodeId::item`: a one-id list).
+    pub fn push_descendants(&mut self, ids: impl Iterator<Item = ItemId>) {
+        let offset = self.descendants.len() as u64;
+        self.descendants.extend(ids);
+        let count = (self.descendants.len() as u64 - offset) as u32;
+        self.nodes.push(AhNode {
+            kind: AH_NODE_DESCENDANTS,
+            has_normal: 0,
+            reserved: 0,
+            tree: 0,
+            left: 0,
+            right: 0,
+            offset,
+            count,
+            depth: 0,
+        });
+    }
+
+    fn view(&self) -> AhForestView {
+        AhForestView {
+            n_trees: self.roots.len() as u32,
+            n_nodes: self.nodes.len() as u64,
+            roots: self.roots.as_ptr(),
+            nodes: self.nodes.as_ptr(),
+            normals: self.normals.as_ptr(),
+            normals_len: self.normals.len() as u64,
+            normal_stride: self.stride as u64,
+            normal_vector_offset: 0,
+            normal_header_offset: self.vector_len as u64,
+            descendants: self.descendants.as_ptr(),
+            descendants_len: self.descendants.len() as u64,
+        }
+    }
+}
+
+/// Items AND tree nodes in HBM: what `Reader::stage_on_gpu` keeps.  `rerank` serves `nns_by_leaf` as before (the descent stays in
+/// Rust); `search_batch` is the whole `nns_by_leaf` of many queries in one call.
+pub struct HipSearch<D> {
+    leafs: HipLeafs<D>,
+    index: *mut AhIndex,
+    dimensions: usize,
+}
+unsafe impl<D> Send for HipSearch<D> {}
+unsafe impl<D> Sync for HipSearch<D> {}
+
+impl<D> Drop for HipSearch<D> {
+    fn drop(&mut self) {
+        unsafe { ah_index_destroy(self.index) }; // before `leafs`: the dataset must outlive the index
+    }
+}
+
+impl<D: Distance> HipSearch<D> {
+    /// Copies `image` to the device of `leafs` (validated there: a forest, ranges inside the blobs); nothing of it is kept.
+    pub fn new(leafs: HipLeafs<D>, image: &ForestImage, dimensions: usize) -> Result<HipSearch<D>> {
+        let mut index = std::ptr::null_mut();
+        check(unsafe { ah_index_create_from_view(leafs.ds, &image.view(), &mut index) }, leafs.index)?;
+        Ok(HipSearch { leafs, index, dimensions })
+    }
+
+    /// `QueryBuilder::by_vector` for `queries.len() / dimensions` queries at once: `(item, distance)` lists in the reference's
+    /// order with the reference's bits.  `search_k` 0 = `count * n_trees`, `oversampling` 0 = `D::DEFAULT_OVERSAMPLING`
+    /// (src/reader.rs `nns_by_leaf`); `candidates` = `QueryBuilder::candidates`.
+    pub fn search_batch(
+        &self,
+        queries: &[f32],
+        count: usize,
+        search_k: usize,
+        oversampling: usize,
+        candidates: Option<&RoaringBitmap>,
+    ) -> Result<Vec<Vec<(ItemId, f32)>>> {
+        if self.dimensions == 0 || queries.len() % self.dimensions != 0 {
+            return Err(Error::InvalidVecDimension { expected: self.dimensions, received: queries.len() });
+        }
+        let nq = queries.len() / self.dimensions;
+        let filter: Option<Vec<u32>> = candidates.map(|c| c.iter().collect()); // ascending: RoaringBitmap order
+        let (mut ids, mut dists, mut counts) = (vec![0u32; nq * count], vec![0f32; nq * count], vec![0u32; nq]);
+        check(
+            unsafe {
+                ah_search_batch(
+                    self.index,
+                    queries.as_ptr(),
+                    std::ptr::null(),
+                    nq,
+                    count,
+                    search_k,
+                    oversampling,
+                    filter.as_ref().map_or(std::ptr::null(), |f| f.as_ptr()),
+                    filter.as_ref().map_or(0, |f| f.len()),
+                    filter.is_some() as c_int,
+                    ids.as_mut_ptr(),
+                    dists.as_mut_ptr(),
+                    counts.as_mut_ptr(),
+                )
+            },
+            self.leafs.index,
+        )?;
+        Ok((0..nq)
+            .map(|q| {
+                let n = counts[q] as usize;
+                ids[q * count..][..n].iter().copied().zip(dists[q * count..][..n].iter().copied()).collect()
+            })
+            .collect())
+    }
+
+    /// `insert_items_in_descendants_from_frozen_reader` (src/writer.rs) for every tree at once: the Descendants node (a
+    /// forest-local index of the image this index was made from) each of `items` lands in, `[tree][item]`.  `tree_seeds`
+    /// key the coin thrown at `normal: None` nodes (include/arroy_hip_policy.h).
+    pub fn route_items(&self, items: &[ItemId], tree_seeds: &[u64]) -> Result<Vec<u32>> {
+        let mut out = vec![0u32; items.len() * tree_seeds.len()];
+        check(
+            unsafe { ah_route_items(self.index, items.as_ptr(), items.len(), tree_seeds.as_ptr(), out.as_mut_ptr()) },
+            self.leafs.index,
+        )?;
+        Ok(out)
+    }
+}
+
+impl<D: Distance> Rerank for HipSearch<D> {
+    fn rerank(&self, query: &[f32], nns: &[ItemId], count: usize) -> Result<Vec<(ItemId, f32)>> {
+        self.leafs.rerank(query, nns, count)
+    }
+}
+
+/// `incremental_index_large_descendant` (src/writer.rs): `make_tree_in_file` over every Descendants node that outgrew
+/// `split_after`, all of them in one call — sub-tree `t` covers the ascending ids `subsets[t]`.  The nodes come back through
+/// `visit` in post-order per sub-tree (children before parents, as `TmpNodes::put` receives them), with sub-forest-local
+/// indices: `(subtree, node, split: Option<(left, right, normal record)>, descendants)`.
+pub fn build_subtrees<D: Distance, R: Rng>(
+    leafs: &HipLeafs<D>,
+    rng: &mut R,
+    options: &BuildOption,
+    subsets: &[Vec<ItemId>],
+    mut visit: impl FnMut(&AhNode, &AhForestView) -> Result<()>,
+) -> Result<()> {
+    let seeds: Vec<u64> = (0..subsets.len()).map(|_| rng.gen()).collect();
+    let mut offsets = Vec::with_capacity(subsets.len() + 1);
+    let mut ids = Vec::new();
+    offsets.push(0u64);
+    for s in subsets {
+        ids.extend_from_slice(s);
+        offsets.push(ids.len() as u64);
+    }
+    let opt = AhBuildOptions {
+        n_trees: subsets.len() as u32,
+        split_after: options.split_after.unwrap_or(0) as u32,
+        tree_seeds: seeds.as_ptr(),
+        cancel: std::ptr::null(),
+        progress: None,
+        progress_user: std::ptr::null_mut(),
+        max_trees_in_flight: 0,
+        margin_mode: 0,
+        max_host_threads: 0,
+        reserved0: 0,
+    };
+    let mut forest = std::ptr::null_mut();
+    check(unsafe { ah_build_subtrees(leafs.ds, &opt, ids.as_ptr(), offsets.as_ptr(), &mut forest) }, leafs.index)?;
+    let mut view = MaybeUninit::<AhForestView>::zeroed();
+    let outcome = check(unsafe { ah_forest_view_get(forest, view.as_mut_ptr()) }, leafs.index).and_then(|()| {
+        let view = unsafe { view.assume_init() };
+        let nodes = unsafe { std::slice::from_raw_parts(view.nodes, view.n_nodes as usize) };
+        nodes.iter().try_for_each(|nd| visit(nd, &view))
+    });
+    unsafe { ah_forest_destroy(forest) };
+    outcome
+}
+
+/// `DotProduct::preprocess` (src/distance/dot_product.rs) on the staged items: the max norm, then `extra_dim` / `norm` of
+/// every item, on the device; returns the headers in item order (8 bytes each) for the caller to write back into LMDB.
+pub fn preprocess_dot<D: Distance>(leafs: &HipLeafs<D>, n_items: usize) -> Result<Vec<[f32; 2]>> {
+    let mut max_norm = 0f32;
+    check(unsafe { ah_preprocess_dot(leafs.ds, &mut max_norm) }, leafs.index)?;
+    let mut headers = vec![[0f32; 2]; n_items];
+    check(
+        unsafe { ah_dataset_read_headers(leafs.ds, 0, n_items as u64, headers.as_mut_ptr() as *mut c_void) },
+        leafs.index,
+    )?;
+    Ok(headers)
 }

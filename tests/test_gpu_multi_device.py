@@ -199,7 +199,7 @@ def test_bench_two_virtual_devices_one_process_per_rank():
     """The launch the driver uses for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`), two ranks
     on the one GPU: each rank fills its own dataset, builds its share, rank 0 gathers the per-device figures and checks the
     union (gloo for the control path: RCCL wants one rank per device)."""
-    out = _bench(["--gpus", "2", "--virtual", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-extra", "--no-live-pmc"],
+    out = _bench(["--gpus", "2", "--virtual-devices", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-extra", "--no-live-pmc"],
                  launcher=["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                            "--master-port", "29577"])
     j = _check_virtual_line(out, 2)

@@ -63,6 +63,7 @@ def test_search_equals_oracle_at_the_benchmarked_shape_1m_x_1536_dot_20_trees():
             st = index.stats()
         assert st["queries"] == nq and st["calls"] == 1, st
         assert st["descent_wave_small"] + st["descent_wave_big"] + st["descent_octet_lds"] + st["descent_octet_global"] == nq, st
+        assert st["descent_block"] == 0, st  # 128 queries: above AH_SEARCH_BLOCK_MAX_QUERIES
         if wave:  # the small queues of the wave descent hold an unfiltered search_k = 10 000 query
             assert st["descent_wave_small"] >= 0.9 * nq, st
         else:
@@ -97,6 +98,21 @@ def test_search_equals_oracle_at_the_benchmarked_shape_1m_x_1536_dot_20_trees():
         want, _ = O.search(oracle, forest, qv, qh, count, sk, want_candidates=False)
         assert list(gi[0][qi]) == [i for i, _ in want]
         assert gi[1][qi].view(np.uint32).tolist() == np.array([d for _, d in want], np.float32).view(np.uint32).tolist()
+    # the descent of the SMALL submissions (one block of 32 octets per query, k_descend_block): the same 128 queries through it,
+    # as one call and one query per call (arroy's own API shape, src/reader.rs:46-75) — the bits of the wave descent
+    with _lib.tuning(AH_SEARCH_BLOCK_MAX_QUERIES=1024):
+        index.stats(reset=True)
+        blk = index.search(count, queries=queries, search_k=sk, raw=True)
+        st = index.stats()
+    assert st["descent_block"] >= 0.9 * nq and st["descent_block"] + st["descent_wave_big"] + st["descent_octet_lds"] + \
+        st["descent_octet_global"] == nq and st["descent_wave_small"] == 0, st
+    for a, b in zip(res[1, 1], blk):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    index.stats(reset=True)
+    for qi in (0, 17, 64, 99, 127):
+        one = index.search(count, queries=queries[qi:qi + 1], search_k=sk, raw=True)
+        assert np.array_equal(one[0][0], res[1, 1][0][qi]) and one[1][0].tobytes() == res[1, 1][1][qi].tobytes(), qi
+    assert index.stats()["descent_block"] == 5
     # `QueryBuilder::candidates`: half, 10 % and 3 % of the items
     for share in (0.5, 0.10, 0.03):
         keep = np.sort(rng.choice(n, int(n * share), replace=False)).astype(np.uint32)
@@ -114,6 +130,13 @@ def test_search_equals_oracle_at_the_benchmarked_shape_1m_x_1536_dot_20_trees():
             assert st["descent_wave_small"] + st["descent_wave_big"] == 0 and st["leaf_kept_passes"] == 0, st
         with _lib.tuning(AH_SEARCH_WAVE=0, AH_SEARCH_TILES=0):
             slow = index.search(count, queries=queries, search_k=sk, candidates=keep, candidates_sorted=True, raw=True)
+        if share == 0.5:  # ... and the block descent under the same filter
+            with _lib.tuning(AH_SEARCH_BLOCK_MAX_QUERIES=1024):
+                index.stats(reset=True)
+                blk = index.search(count, queries=queries, search_k=sk, candidates=keep, candidates_sorted=True, raw=True)
+                assert index.stats()["descent_block"] >= 0.75 * nq
+            for a, b in zip(got, blk):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), share
         for a, b in zip(got, slow):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), share
         assert_equals_oracle(got, oracle, forest, queries, range(0, nq, 4), count, sk, cand=keep, what=f"filter {share}")
@@ -146,8 +169,8 @@ def test_search_equals_oracle_on_the_headline_index_10m_x_768_cosine_100_trees()
             res[wave, tiles] = index.search(count, queries=queries, search_k=sk, raw=True)
             st = index.stats()
         assert st["queries"] == nq, st
-        if wave:
-            assert st["descent_wave_small"] + st["descent_wave_big"] >= 0.9 * nq, st
+        if wave:  # (32 queries: a block per query)
+            assert st["descent_block"] + st["descent_wave_big"] >= 0.9 * nq and st["descent_wave_small"] == 0, st
         if tiles:  # 10M ids: the hash set of the candidates, not the bitmap
             assert st["rerank_tiles"] == nq and st["dedup_flag_hash"] == nq and st["dedup_flag_bitmap"] == 0, st
         else:

@@ -42,8 +42,23 @@ def test_rust_bindings_name_only_declared_symbols():
     assert "AH_ABI_VERSION: c_int = " + re.search(r"#define AH_ABI_VERSION (\d+)", header()).group(1) in rust()
 
 
+def test_layout_self_checks_are_what_the_header_compiles_to():
+    """`const _: () = assert!(size_of::<T>() == ..)` / `offset_of!(T, f) == ..` for every #[repr(C)] struct: the block in
+    src/hip.rs must be exactly what tools/gen_layout.py prints from the C compiler's view of include/arroy_hip.h (sizes,
+    alignments, offsets: a field whose TYPE drifts no longer compiles on the Rust side)."""
+    sys.path.insert(0, os.path.join(HERE, "tools"))
+    import gen_layout
+    block = gen_layout.block()
+    assert block.count("const _: () = assert!(") >= 55
+    assert block in rust(), "src/hip.rs: layout block is stale: python integration/arroy-hip/tools/gen_layout.py"
+    # every #[repr(C)] struct with fields has its checks
+    for name in re.findall(r"#\[repr\(C\)\]\n(?:#\[derive[^\n]*\n)?pub struct (\w+) \{\n    pub (?!_p)", rust()):
+        assert f"size_of::<{name}>()" in block, name
+
+
 @pytest.mark.parametrize("c_name,rust_name", [("ah_build_options", "AhBuildOptions"), ("ah_stream_node", "AhStreamNode"),
-                                              ("ah_node_batch", "AhNodeBatch"), ("ah_error_detail", "AhErrorDetail")])
+                                              ("ah_node_batch", "AhNodeBatch"), ("ah_error_detail", "AhErrorDetail"),
+                                              ("ah_node", "AhNode"), ("ah_forest_view", "AhForestView")])
 def test_repr_c_structs_follow_the_header(c_name, rust_name):
     body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (c_name, c_name), header(), re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
