@@ -114,6 +114,33 @@ __device__ __forceinline__ float octet_reduce(const float *a, const float *b, ui
     return scalar_tail<OP>(r, a, b, blocks << 5, dims);
 }
 
+// The same reduction — same chains, same order, same bits — with the line-loads of a whole chunk of the streamed operand `a`
+// requested before the first multiply-add, the chunk as large as the row allows (48 blocks of 32 dims, then 24, 12, 6, 3, 1):
+// for callers whose time is the LATENCY of one row after the other (the tree descent: a pop's margin reads a 6 KB normal
+// nobody has touched before; with four loads in flight a 1536-d margin is twelve round trips to L2 / HBM, here it is one).
+// `b` (the query) is expected in LDS or L1-hot.  Costs up to 192 registers: for kernels that run a few waves per CU.
+template <int OP, int CH>
+__device__ __forceinline__ void octet_wide_chunks(float4 &acc, const float4 *a4, const float4 *b4, uint32_t &k, uint32_t blocks) {
+    while (k + CH <= blocks) {
+        float4 x[CH];
+#pragma unroll
+        for (int u = 0; u < CH; u++) x[u] = a4[(k + u) * 8];
+#pragma unroll
+        for (int u = 0; u < CH; u++) fma_step<OP>(acc, x[u], b4[(k + u) * 8]);
+        k += CH;
+    }
+    if constexpr (CH > 1) octet_wide_chunks<OP, CH / 2>(acc, a4, b4, k, blocks);
+}
+template <int OP>
+__device__ __forceinline__ float octet_reduce_wide(const float *a, const float *b, uint32_t dims, uint32_t j) {
+    const uint32_t blocks = dims >> 5;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t k = 0;
+    octet_wide_chunks<OP, 48>(acc, reinterpret_cast<const float4 *>(a) + j, reinterpret_cast<const float4 *>(b) + j, k, blocks);
+    float r = octet_finish(acc);
+    return scalar_tail<OP>(r, a, b, blocks << 5, dims);
+}
+
 // Same reduction with the streamed operand `row` in global memory (read once, non-temporal) and the broadcast
 // operand `s_b4` (query / normal) in LDS: 8 line-loads (128 B per lane, 8 KiB per wave) are issued before the
 // first use so HBM latency is covered by loads in flight rather than by occupancy alone.  dims >= 32.

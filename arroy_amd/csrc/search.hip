@@ -118,7 +118,9 @@ __device__ __forceinline__ float descent_margin(const DataView &nv, uint32_t nro
     }
     const float *np = nv.rows_f32 + (uint64_t)nrow * nv.pitch;
     const float *qp = reinterpret_cast<const float *>(qvec);
-    const float d = octet_reduce_any<OP_DOT>(np, qp, nv.dims, j);
+    // (the whole normal requested at once: the descent is a chain of such margins, one per pop; qvec: LDS in the wave / block
+    // kernels)
+    const float d = nv.dims >= 32 ? octet_reduce_wide<OP_DOT>(np, qp, nv.dims, j) : octet_reduce_any<OP_DOT>(np, qp, nv.dims, j);
     if (nv.metric == AH_EUCLIDEAN || nv.metric == AH_MANHATTAN) return f_add(nv.headers[nrow], d);
     if (nv.metric == AH_DOT_PRODUCT) return f_add(d, f_mul(nv.headers[2 * (uint64_t)nrow], qh.h0));
     return d;
@@ -297,7 +299,14 @@ __global__ __launch_bounds__(64) void k_descend_wave(DataView nv, SearchParams s
     const uint32_t q = blockIdx.x, o = threadIdx.x >> 3, j = threadIdx.x & 7u, lane = threadIdx.x;
     if (q >= nq) return;
     uint64_t *heap = s_heap[o];
-    const void *qvec = qvecs + (uint64_t)q * qstride;
+    // the query leaf in LDS (behind the queues; qstride bytes): every margin of the descent reads it
+    uint4 *s_q4 = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(s_wave_lds) + wave_lds_bytes(kWaveHeap, kWaveLeaves));
+    {
+        const uint4 *g_q4 = reinterpret_cast<const uint4 *>(qvecs + (uint64_t)q * qstride);
+        for (uint32_t i = lane; i < (uint32_t)(qstride >> 4); i += 64) s_q4[i] = g_q4[i];
+        __syncthreads();
+    }
+    const void *qvec = s_q4;
     const LeafHdr qh = {qhdrs[2 * (uint64_t)q], qhdrs[2 * (uint64_t)q + 1]};
     uint32_t *my_nns = nns + (uint64_t)q * sp.nns_stride;
     uint32_t hn = 0, nl = 0;  // lane 0 of the octet
@@ -531,7 +540,14 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
         return r;
     };
     uint64_t *heap = s_heap[o];
-    const void *qvec = qvecs + (uint64_t)q * qstride;
+    // the query leaf in LDS (behind everything else; qstride bytes): every margin of the descent reads it
+    uint4 *s_q4 = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(s_blk_lds) + block_descend_lds_bytes<kOct, kHeap, kLeaves>());
+    {
+        const uint4 *g_q4 = reinterpret_cast<const uint4 *>(qvecs + (uint64_t)q * qstride);
+        for (uint32_t i = tid; i < (uint32_t)(qstride >> 4); i += kThreads) s_q4[i] = g_q4[i];
+        __syncthreads();
+    }
+    const void *qvec = s_q4;
     const LeafHdr qh = {qhdrs[2 * (uint64_t)q], qhdrs[2 * (uint64_t)q + 1]};
     uint32_t *my_nns = nns + (uint64_t)q * sp.nns_stride;
     uint32_t hn = 0, nl = 0;  // lane 0 of the octet
@@ -2405,21 +2421,23 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         // device has the room — arroy's own API is one query per call (src/reader.rs:46-75)
         const long long block_max_nq = tun(TUN_SEARCH_BLOCK_MAX_QUERIES);
         static std::atomic<bool> lds_opt_in[64];  // once per device: the kernels that want more than 64 KiB of LDS
-        constexpr size_t block_lds = block_descend_lds_bytes<32, 128, 32>();
+        // (+ qstride bytes each: the query leaf's copy in LDS; a leaf of more than 32 KiB is refused above)
+        const size_t block_lds = block_descend_lds_bytes<32, 128, 32>() + qstride;
         const void *wave_big = reinterpret_cast<const void *>(k_descend_wave<1024, 128>);
         const void *block_fn = reinterpret_cast<const void *>(k_descend_block<32, 128, 32>);
         if (!lds_opt_in[ds->device & 63].load(std::memory_order_acquire)) {
-            AH_HIP(hipFuncSetAttribute(wave_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave_lds_bytes(1024, 128)));
-            AH_HIP(hipFuncSetAttribute(block_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds));
+            AH_HIP(hipFuncSetAttribute(wave_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wave_lds_bytes(1024, 128) + (32u << 10))));
+            AH_HIP(hipFuncSetAttribute(block_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(block_descend_lds_bytes<32, 128, 32>() + (32u << 10))));
             lds_opt_in[ds->device & 63].store(true, std::memory_order_release);
         }
         if (small_first && (long long)nq <= block_max_nq)
             hipLaunchKernelGGL((k_descend_block<32, 128, 32>), dim3((unsigned)nq), dim3(256), block_lds, s, ix->nv, sp, (uint32_t)nq,
                                d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink);
         else if (small_first)
-            hipLaunchKernelGGL((k_descend_wave<256, 64>), dim3((unsigned)nq), dim3(64), wave_lds_bytes(256, 64), s, ix->nv, sp,
+            hipLaunchKernelGGL((k_descend_wave<256, 64>), dim3((unsigned)nq), dim3(64), wave_lds_bytes(256, 64) + qstride, s, ix->nv, sp,
                                (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink, false);
-        hipLaunchKernelGGL((k_descend_wave<1024, 128>), dim3((unsigned)nq), dim3(64), wave_lds_bytes(1024, 128), s, ix->nv, sp,
+        hipLaunchKernelGGL((k_descend_wave<1024, 128>), dim3((unsigned)nq), dim3(64), wave_lds_bytes(1024, 128) + qstride, s, ix->nv, sp,
                            (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink, small_first);
         return AH_OK;
     };
@@ -2765,7 +2783,8 @@ int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_it
     // queues of a wave hold).  Under a filter the wave descent reads |descendants & candidates| of every leaf, computed
     // ONCE per submission by a pass over all Descendants ids (4 GB at 10M x 100 trees): a small submission on a big forest
     // is cheaper by the sequential descent, which looks only at the leaves it pops.
-    bool wave_descent = tun(TUN_SEARCH_WAVE) != 0 && (!d_bits || filter_share >= 0.05);
+    // (the wave / block descents keep the query leaf in LDS: up to 32 KiB of it, i.e. 8192 f32 dimensions)
+    bool wave_descent = tun(TUN_SEARCH_WAVE) != 0 && (!d_bits || filter_share >= 0.05) && ((ds->row_bytes() + 255) & ~(size_t)255) <= (32u << 10);
     uint64_t leaf_kept_passes = 0;
     if (wave_descent && d_bits) {
         if (nq >= 16 || ix->desc_len <= (32ull << 20)) {

@@ -20,12 +20,12 @@ ds.finalize()
 forest = ds.build_forest(shard.tree_seeds(42, range(n_trees)))
 index = ds.create_index(forest)
 rng = np.random.default_rng(42)
-far = np.stack([ds.item_vector(int(i)) for i in rng.choice(n, 1000, replace=False)])
+far = np.stack([ds.item_vector(int(i)) for i in rng.choice(n, 2000, replace=False)])
 far = (far + rng.standard_normal(far.shape).astype(np.float32) * 0.05).astype(np.float32)
 index.search(k, queries=far[:64], search_k=10_000, raw=True)
 samples = []
 for i in range(calls + 20):
-    q = far[(i * nq) % (1000 - nq):][:nq]
+    q = far[(i * nq) % (2000 - nq):][:nq]
     t0 = time.perf_counter()
     index.search(k, queries=q, search_k=10_000, raw=True)
     if i >= 20:
