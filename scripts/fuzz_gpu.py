@@ -80,9 +80,10 @@ def one(rng, it):
     # every margin-kernel family, with and without the certified binary16 screen (ah_margin_mode)
     mode = int(rng.choice([0, 0, 1, 2, 4, 8, 16, 0x108, 0x110, 0x200, 0x200])) | (0x1000 if rng.random() < 0.3 else 0)
     mask_bits = int(rng.integers(0, 2))  # the sides of a row-major level gathered as bits / as bytes
-    with _tuning(AH_MASK_BITS=mask_bits):
+    narrow = int(rng.choice([64, 128, 256, 0]))  # widest level the narrow dense kernel takes (64 / 128-column shapes; 0: never)
+    with _tuning(AH_MASK_BITS=mask_bits, AH_DENSE_NARROW_MAX_COLS=narrow, AH_DENSE_NARROW_STREAM=int(rng.integers(0, 2))):
         forest = ds.build_forest(seeds, split_after=split_after, margin_mode=mode)
-    desc += f" mode={mode:#x} trees={len(seeds)} mask_bits={mask_bits}"
+    desc += f" mode={mode:#x} trees={len(seeds)} mask_bits={mask_bits} narrow={narrow}"
     assert forest.stats["screen_violations"] == 0
     T.check_forest_valid(forest, n, ids=ids)
     for t, seed in enumerate(seeds):
@@ -112,11 +113,12 @@ def one(rng, it):
     if rng.random() < 0.5:  # `candidates: &RoaringBitmap`, item ids (some of them not in the database)
         cand = [int(x) for x in rng.choice(int(ids[-1]) + 3, int(rng.integers(0, min(n, 4000) + 1)), replace=False)]
     ref = None
-    for wave in (1, 0):
+    for wave in (2, 1, 0):  # 2: one block of 32 octets per query (the default for submissions this small); 1: one wave; 0: one octet
         for tiles in (1, 0, 2):  # 2: the leaf tiles without the certified top-k screen (f32 rows for every candidate)
             if tiles == 2 and wave == 0:
                 continue
-            with tuning(AH_SEARCH_WAVE=wave, AH_SEARCH_TILES=min(tiles, 1), AH_SEARCH_SCREEN=0 if tiles == 2 else 1):
+            with tuning(AH_SEARCH_WAVE=min(wave, 1), AH_SEARCH_BLOCK_MAX_QUERIES=64 if wave == 2 else 0, AH_SEARCH_TILES=min(tiles, 1),
+                        AH_SEARCH_SCREEN=0 if tiles == 2 else 1):
                 oi, od, oc = index.search(count2, queries=qs2, search_k=sk2, candidates=cand, raw=True)
             if ref is None:
                 ref = (oi, od, oc)
