@@ -49,7 +49,7 @@ rm -rf $OUT/kt_b
     set -- $cfg
     nq=$1; calls=$2; shift 2
     env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_s -o kt -- python scripts/exp_latency.py $nq $calls > $OUT/lat.log 2>&1
-    echo "## $nq queries per call, $* : $(tail -2 $OUT/lat.log | head -1)"
+    echo "## $nq queries per call, $* : $(grep "^nq=" $OUT/lat.log | tail -1)"
     python scripts/kstats.py $OUT/kt_s/kt_kernel_stats.csv k_descend k_leaf k_search_select k_flag k_queries k_visit k_prepare
     rm -rf $OUT/kt_s
   done
