@@ -1130,9 +1130,11 @@ def dry_run_work(args, rank, world, sync, result):
     result["elapsed"] = sync.max(time.perf_counter() - t0, rank)
     result["kernel_ms"] = result["elapsed"] * 1e3 / max(args.steps, 1)
     b = sync.max(0.001 * len(my_trees), rank)
+    # the per-device figures of an N > 1 line travel by sync.gather (rank order, every rank gets all of them)
+    per_rank = sync.gather({"rank": rank, "trees": len(my_trees)}, rank)
     if rank == 0:
         result["device"] = "dry-run (cpu)"
-        result["build"] = {"trees": args.trees, "trees_this_rank": len(my_trees), "seconds": b}
+        result["build"] = {"trees": args.trees, "trees_this_rank": len(my_trees), "seconds": b, "per_rank": per_rank}
 
 
 def main():

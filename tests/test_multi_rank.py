@@ -10,6 +10,23 @@ import sys
 from conftest import ROOT
 
 
+def test_union_digest_is_independent_of_the_sharding():
+    """bench.py folds {tree index: keyed digest} into one value in tree order: whoever built which tree, the value is the same."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    per_tree = {t: (t * 0x9E3779B97F4A7C15 + 12345) & 0xFFFFFFFFFFFFFFFF for t in range(100)}
+    whole = bench.union_digest(per_tree)
+    for world in (2, 4, 8):
+        merged = {}
+        for r in reversed(range(world)):  # any arrival order
+            merged.update({t: per_tree[t] for t in range(r, 100, world)})
+        assert bench.union_digest(merged) == whole
+    per_tree[37] ^= 1
+    assert bench.union_digest(per_tree) != whole
+
+
 def test_tree_sharding_is_a_partition_and_seeds_do_not_depend_on_world_size():
     from arroy_amd import shard
     for n_trees in (0, 1, 7, 50, 100):
@@ -44,6 +61,8 @@ def test_bench_two_ranks_over_gloo_dry_run():
     # max over ranks: rank 1 sleeps 20 ms, rank 0 10 ms
     assert j["ms_per_step"] * 3 >= 19.0
     assert j["build"]["trees"] == 5 and j["build"]["trees_this_rank"] == 3
+    # the gather that carries the per-device figures of an N > 1 line (build_10m_per_device, the union of the shares' digests)
+    assert j["build"]["per_rank"] == [{"rank": 0, "trees": 3}, {"rank": 1, "trees": 2}]
     assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
 
 
@@ -68,6 +87,7 @@ def test_bench_gpus_n_started_directly_drives_n_devices_from_one_process_dry_run
     assert j["n_gpus"] == 2 and "2 host threads" in j["config"]["launch"]
     assert j["ms_per_step"] * 3 >= 19.0  # max over the device threads: thread 1 sleeps 20 ms
     assert j["build"]["trees"] == 5 and j["build"]["trees_this_rank"] == 3
+    assert j["build"]["per_rank"] == [{"rank": 0, "trees": 3}, {"rank": 1, "trees": 2}]
 
 
 def test_bench_refuses_to_run_on_fewer_devices_than_asked():
