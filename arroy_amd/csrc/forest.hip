@@ -3045,9 +3045,10 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         // n_trees / tc passes.  Cost: the rows leave HBM once (binary16), hpitch multiply-adds per (row, column) at the
         // sustained MFMA rate, an epilogue per (row, tree), and the reference arithmetic for the pairs left open.
         bool dense = false;
-        // (a launch carries at most 2^32 - 1 work-items: 512 threads x row tiles x column tiles)
+        // (a launch carries at most 2^32 - 1 work-items: threads x row tiles x column tiles of the shape the level would take)
+        const DensePlan dp_legal = dense_plan(N, std::max(n_nodes, 1u));
         const bool dense_legal = rows_allowed && screen && g_dense != 0 && n_nodes <= g_dense_max_cols &&
-                                 ((N + kDM - 1) / kDM + 64) * (((uint64_t)n_nodes + 127) / 128) * 512ull < 0xFFFFFFFFull;
+                                 (dp_legal.grid + 64) * (uint64_t)dp_legal.threads < 0xFFFFFFFFull && dp_legal.grid < 0x7FFFFFFFull;
         if (dense_legal && mode_req == AH_MARGIN_DENSE_MFMA) {
             dense = true;
         } else if (dense_legal && mode_req == AH_MARGIN_AUTO) {

@@ -2285,7 +2285,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     const uint32_t heap_cap = ix->n_nodes + ix->n_trees + 2;
     size_t dev_bytes = pad(nq * (size_t)ds->dims * 4) + pad(nq * 4) + nq * qstride + pad(nq * 8) + pad(nq * (size_t)nns_stride * 4) * 2 +
                        pad(nq * 4) * 3 + pad(nq * sizeof(HostSeg2)) + pad((size_t)max_tiles_bound * sizeof(HostTile2)) +
-                       2 * pad(nq * kstride * 8) + pad(nq * k * 4) * 2 + 4096;
+                       2 * pad(nq * kstride * 8) + pad(nq * k * 4) * 2 + pad(SS_WORDS * 4) + pad(nq * 4) + 4096;
     // counters of the row-major re-rank, reserved when the candidate lists could be long enough for it
     const size_t inv_bytes = batch_invert_wanted(ds->view(), (uint64_t)nq * nns_stride) ? batch_invert_counter_bytes(ds->n, (uint64_t)nq * nns_stride) : 0;
     dev_bytes += pad(inv_bytes);
@@ -2341,10 +2341,13 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     uint32_t *d_oi = (uint32_t *)dtake(nq * k * 4);
     float *d_od = (float *)dtake(nq * k * 4);
     uint32_t *d_err = (uint32_t *)dtake(SS_WORDS * 4);  // [error bits][SearchStatSlot counters]
+    // (d_oi, d_od, d_err, d_unique lie back to back, and so do their pinned mirrors below: the tile path reads all four
+    // back with ONE copy — a call of one query is a dozen launches and copies of ~5 us each)
+    uint32_t *d_unique = (uint32_t *)dtake(nq * 4);
     uint32_t *d_inv = inv_bytes ? (uint32_t *)dtake(inv_bytes) : nullptr;
     Visit *d_visits = nullptr, *d_sorted = nullptr;
     TileUnit *d_units = nullptr;
-    uint32_t *d_leaf_count = nullptr, *d_cursor = nullptr, *d_ustart = nullptr, *d_unique = nullptr;
+    uint32_t *d_leaf_count = nullptr, *d_cursor = nullptr, *d_ustart = nullptr;
     uint2 *d_leaf_sums = nullptr;
     if (tiles) {
         d_visits = (Visit *)dtake((size_t)visit_cap * sizeof(Visit));
@@ -2354,7 +2357,6 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         d_cursor = (uint32_t *)dtake((size_t)ix->n_nodes * 4);
         d_ustart = (uint32_t *)dtake((size_t)ix->n_nodes * 4);
         d_leaf_sums = (uint2 *)dtake((size_t)n_leaf_sums * 8);
-        d_unique = (uint32_t *)dtake(nq * 4);
     }
     ScreenSearch ss{};
     if (screened) {
@@ -2370,7 +2372,6 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     }
     float *h_q = (float *)ptake(nq * (size_t)ds->dims * 4);
     uint32_t *h_qrows = (uint32_t *)ptake(nq * 4);
-    uint32_t *h_counts = (uint32_t *)ptake(nq * 4);
     uint32_t *h_overflow = (uint32_t *)ptake(nq * 4);
     uint32_t *h_list = (uint32_t *)ptake(nq * 4);
     HostSeg2 *h_segs = (HostSeg2 *)ptake(nq * sizeof(HostSeg2));
@@ -2378,6 +2379,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     uint32_t *h_oi = (uint32_t *)ptake(nq * k * 4);
     float *h_od = (float *)ptake(nq * k * 4);
     uint32_t *h_err = (uint32_t *)ptake(SS_WORDS * 4);
+    uint32_t *h_counts = (uint32_t *)ptake(nq * 4);
     ChunkStats cs;
     cs.s.chunks = 1;
     cs.s.queries = nq;
@@ -2501,14 +2503,21 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         // (after the tiles: they read the leaves' ids from the candidate buffers)
         if (bitmap_fits) {
             const size_t sh = (size_t)bitmap_words * 4;
-            if (sh > 48 * 1024)
+            static std::atomic<uint32_t> flag_lds[64];  // largest bitmap this device's kernel has been opted in for
+            if (sh > 48 * 1024 && flag_lds[ds->device & 63].load(std::memory_order_acquire) < sh) {
                 AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_flag_duplicates),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+                flag_lds[ds->device & 63].store((uint32_t)sh, std::memory_order_release);
+            }
             hipLaunchKernelGGL(k_flag_duplicates, dim3((unsigned)nq), dim3(1024), sh, s, d_nns, nns_stride, d_counts, bitmap_words,
                                max_id + 1, d_unique, d_err);
         } else {
-            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_flag_duplicates_hash),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHashSlots * 4)));
+            static std::atomic<bool> hash_opt_in[64];
+            if (!hash_opt_in[ds->device & 63].load(std::memory_order_acquire)) {
+                AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_flag_duplicates_hash),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHashSlots * 4)));
+                hash_opt_in[ds->device & 63].store(true, std::memory_order_release);
+            }
             hipLaunchKernelGGL(k_flag_duplicates_hash, dim3((unsigned)nq), dim3(1024), kHashSlots * 4, s, d_nns, nns_stride, d_counts,
                                d_unique, d_err);
         }
@@ -2531,10 +2540,8 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         // a launch the runtime rejected (dynamic LDS beyond the limit, another architecture) would leave *err = 0 over
         // uninitialised results: such a submission takes the sorted path as well
         const hipError_t launch_err = hipGetLastError();
-        AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
-        AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
-        AH_HIP(hipMemcpyAsync(h_counts, d_unique, nq * 4, hipMemcpyDeviceToHost, s));
-        AH_HIP(hipMemcpyAsync(h_err, d_err, SS_WORDS * 4, hipMemcpyDeviceToHost, s));
+        // ids, distances, status words and counts: one copy (the four buffers are carved back to back on both sides)
+        AH_HIP(hipMemcpyAsync(h_oi, d_oi, 2 * pad(nq * k * 4) + pad(SS_WORDS * 4) + nq * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipStreamSynchronize(s));
         AH_REQUIRE((*h_err & 1u) == 0, AH_ERR_MISSING_ITEM, "a descendant id does not exist in the dataset");
         if ((*h_err & ~1u) == 0 && launch_err == hipSuccess) {
