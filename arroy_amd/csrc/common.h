@@ -132,6 +132,7 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(DENSE_GMACS, "AH_DENSE_GMACS", 495000)    /* sustained multiply-add rate the cost model assumes, 1e9 MAC/s */       \
     X(MARGIN_MODE, "AH_MARGIN_MODE", 0)         /* ah_margin_mode for callers that pass AH_MARGIN_AUTO */                 \
     X(READBACK_DIRECT, "AH_READBACK_DIRECT", 0) /* 1: let the runtime stage the device -> pageable copies */             \
+    X(READBACK_MB, "AH_READBACK_MB", 256)       /* pinned double buffer of a build's read-back worker, MiB (both halves) */ \
     X(SCAN_BLOCKS, "AH_SCAN_BLOCKS", 0)         /* grid cap of the distance scan (0 = built-in) */                        \
     X(MANHATTAN_ROWS, "AH_MANHATTAN_ROWS", 1)                                                                            \
     X(RERANK_INVERT, "AH_RERANK_INVERT", -1)    /* 0 / 1: never / always the row-major re-rank of big submissions */      \
@@ -141,6 +142,7 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(SEARCH_TILES, "AH_SEARCH_TILES", 1)       /* 0: never the leaf-tile re-rank of ah_search_batch */                   \
     X(SEARCH_WAVE, "AH_SEARCH_WAVE", 1)         /* 0: the descent always one octet per query (k_descend) */               \
     X(SEARCH_BLOCK_MAX_QUERIES, "AH_SEARCH_BLOCK_MAX_QUERIES", 64) /* submissions of at most this many queries descend with one BLOCK (32 octets) per query; 0: never */ \
+    X(SEARCH_SMALL_UNITS_MAX_QUERIES, "AH_SEARCH_SMALL_UNITS_MAX_QUERIES", 64) /* up to this many queries a call: one block places the leaf visits (k_units_small) */ \
     X(RERANK_GROUPS, "AH_RERANK_GROUPS", 2)     /* groups a screened ah_rerank_batch submission is cut into (upload of group g + 1 under the kernel of g) */ \
     X(RERANK_SCREEN, "AH_RERANK_SCREEN", 1)     /* 0: ah_rerank_batch never screens its candidates (f32 rows for all) */ \
     X(SEARCH_SCREEN, "AH_SEARCH_SCREEN", 1)     /* 0: the re-rank of ah_search_batch never screens its candidates (f32 rows for all) */ \

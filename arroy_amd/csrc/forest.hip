@@ -2554,7 +2554,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     AH_HIP(hipMemsetAsync(d_small.p, 0, (16 + info_words) * 4, s));
 
     // pinned host memory: [2 x LevelInfo block][one word for the abort flag][2 x node table][read-back bounce]
-    const size_t kBounce = 64ull << 20;  // pinned double buffer of the read-back worker
+    // pinned double buffer of the read-back worker (a streaming build hands a sink at most one half at a time)
+    const size_t kBounce = (size_t)std::min<long long>(4096, std::max<long long>(2, tun(TUN_READBACK_MB))) << 20;
     const size_t pin_info = (info_words * 4 + 255) & ~(size_t)255;
     const size_t pin_nodes = (max_nodes * sizeof(FNode) + 4095) & ~(size_t)4095;
     const size_t pin_head = (3 * pin_info + 256 + 4095) & ~(size_t)4095;

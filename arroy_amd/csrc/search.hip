@@ -106,6 +106,7 @@ __device__ __forceinline__ float rust_min(float a, float b) {
 
 // `D::margin(&normal, query_leaf)` with the normal a ROW of the normals matrix `nv` and the query leaf in
 // global memory (qvec / qh).  All 8 lanes of the octet participate; every lane gets the result.
+template <bool Q_LDS = false>
 __device__ __forceinline__ float descent_margin(const DataView &nv, uint32_t nrow, const void *qvec, LeafHdr qh,
                                                 uint32_t j) {
     if (metric_is_bq_dev(nv.metric)) {
@@ -120,9 +121,13 @@ __device__ __forceinline__ float descent_margin(const DataView &nv, uint32_t nro
     const float *qp = reinterpret_cast<const float *>(qvec);
     // (the whole normal requested at once: the descent is a chain of such margins, one per pop; qvec: LDS in the wave / block
     // kernels)
-    const float d = nv.dims >= 32 ? octet_reduce_wide<OP_DOT>(np, qp, nv.dims, j) : octet_reduce_any<OP_DOT>(np, qp, nv.dims, j);
-    if (nv.metric == AH_EUCLIDEAN || nv.metric == AH_MANHATTAN) return f_add(nv.headers[nrow], d);
-    if (nv.metric == AH_DOT_PRODUCT) return f_add(d, f_mul(nv.headers[2 * (uint64_t)nrow], qh.h0));
+    // (the normal's header requested with its vector, not after the reduction: the loads of the wide reduction are fenced)
+    float hdr = 0.0f;
+    if (nv.metric == AH_EUCLIDEAN || nv.metric == AH_MANHATTAN) hdr = nv.headers[nrow];
+    else if (nv.metric == AH_DOT_PRODUCT) hdr = nv.headers[2 * (uint64_t)nrow];
+    const float d = nv.dims >= 32 ? octet_reduce_wide<OP_DOT, Q_LDS>(np, qp, nv.dims, j) : octet_reduce_any<OP_DOT>(np, qp, nv.dims, j);
+    if (nv.metric == AH_EUCLIDEAN || nv.metric == AH_MANHATTAN) return f_add(hdr, d);
+    if (nv.metric == AH_DOT_PRODUCT) return f_add(d, f_mul(hdr, qh.h0));
     return d;
 }
 
@@ -132,7 +137,7 @@ __device__ __forceinline__ void record_visit(const VisitSink &sink, uint32_t nod
     const uint32_t slot = atomicAdd(sink.total, 1u);
     if (slot < sink.cap) {
         sink.visits[slot] = Visit{node, q, pos, n};
-        atomicAdd(&sink.leaf_count[node], 1u);
+        if (sink.leaf_count) atomicAdd(&sink.leaf_count[node], 1u);
     } else {
         atomicOr(sink.err, 32u);
     }
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(64) void k_descend_wave(DataView nv, SearchParams s
                 }
             } else {
                 float margin = 0.0f;
-                if (nd.kind & 0x100u) margin = descent_margin(nv, nd.c, qvec, qh, j);
+                if (nd.kind & 0x100u) margin = descent_margin<true>(nv, nd.c, qvec, qh, j);
                 if (j == 0) {
                     if (hn + 2 > kWaveHeap) {
                         failed = true;
@@ -500,9 +505,9 @@ __global__ __launch_bounds__(64) void k_descend_wave(DataView nv, SearchParams s
 // octets across the cut) is left to the passes behind it exactly like the wave kernel's leftovers.
 template <uint32_t kOct, uint32_t kHeap, uint32_t kLeaves>
 constexpr size_t block_descend_lds_bytes() {
-    return (size_t)kOct * kHeap * 8 + (size_t)kOct * kLeaves * (8 + 8 + 4 + 4 + 4 + 4) + 256;
+    return (size_t)kOct * kHeap * 8 + (size_t)kOct * kLeaves * (8 + 8 + 4 + 4 + 4 + 4 + 4) + 256;
 }
-template <uint32_t kOct, uint32_t kHeap, uint32_t kLeaves>
+template <uint32_t kOct, uint32_t kHeap, uint32_t kLeaves, uint32_t kPops>
 __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchParams sp, uint32_t nq,
                                                             const uint8_t *__restrict__ qvecs, uint64_t qstride,
                                                             const float *__restrict__ qhdrs, uint32_t *__restrict__ nns,
@@ -518,6 +523,7 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
     uint32_t *s_sorted_n = reinterpret_cast<uint32_t *>(s_sorted + kCap) + kCap;
     uint32_t *s_pos = s_sorted_n + kCap, *s_sorted_node = s_pos + kCap;
     uint32_t *s_red = s_sorted_node + kCap;  // 64 words of scratch for the block reductions
+    uint32_t(*s_leaf_a)[kLeaves] = reinterpret_cast<uint32_t(*)[kLeaves]>(s_red + 64);  // first id of the leaf in the blob (DNode::a)
     const uint32_t q = blockIdx.x, tid = threadIdx.x, o = tid >> 3, j = tid & 7u, wave = tid >> 6, wl = tid & 63u;
     if (q >= nq) return;
     // block-wide max / sum / or of one value per thread (all threads call; two barriers each)
@@ -550,57 +556,112 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
     const void *qvec = s_q4;
     const LeafHdr qh = {qhdrs[2 * (uint64_t)q], qhdrs[2 * (uint64_t)q + 1]};
     uint32_t *my_nns = nns + (uint64_t)q * sp.nns_stride;
-    uint32_t hn = 0, nl = 0;  // lane 0 of the octet
+    // The octet's queue is an UNSORTED array in LDS, popped by an arg-max over the octet's eight lanes: the keys are unique (the
+    // node is their low word), so the pops come in the order a binary heap would give them, and a queue of the ~10 - 30 entries
+    // one tree holds costs two or three LDS reads per lane and three shuffles instead of a lane-0 sift of dependent LDS round
+    // trips.  hn / nl / failed are octet-uniform (every lane keeps them; lane 0 writes LDS).
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    uint32_t hn = 0, nl = 0;
     bool failed = false;
-    if (j == 0)
-        for (uint32_t t = o; t < sp.n_trees; t += kOct) heap_push(heap, hn, ((uint64_t)0xFF800000u << 32) | sp.roots[t]);
+    for (uint32_t t = o; t < sp.n_trees; t += kOct) {
+        if (hn == kHeap) {
+            failed = true;
+            break;
+        }
+        if (j == 0) heap[hn] = ((uint64_t)0xFF800000u << 32) | sp.roots[t];
+        hn++;
+    }
+    auto octet_sync = [] {  // lane 0's LDS stores before the other lanes' loads (one wave: program order is enough for the hardware)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    uint64_t best = 0;
+    uint32_t bi = kNone;
+    auto queue_argmax = [&] {  // (best, bi) <- the largest key queued by this octet and where it sits; bi = kNone: nothing queued
+        octet_sync();
+        best = 0;
+        bi = kNone;
+        for (uint32_t i = j; i < hn; i += 8) {
+            const uint64_t k = heap[i];
+            if (bi == kNone || k > best) {
+                best = k;
+                bi = i;
+            }
+        }
+#pragma unroll
+        for (uint32_t d = 1; d < 8; d <<= 1) {
+            const uint32_t o_hi = __shfl_xor((uint32_t)(best >> 32), d, 8), o_lo = __shfl_xor((uint32_t)best, d, 8);
+            const uint32_t o_i = __shfl_xor(bi, d, 8);
+            const uint64_t ok = ((uint64_t)o_hi << 32) | o_lo;
+            if (o_i != kNone && (bi == kNone || ok > best)) {
+                best = ok;
+                bi = o_i;
+            }
+        }
+    };
+    // the two children of the split popped last: their records are requested beside the split's normal, and the next pop of
+    // this tree is nearly always one of them — one dependent trip to memory per level instead of two
+    uint32_t c_id[2] = {kNone, kNone};
+    DNode c_nd[2] = {};
+    queue_argmax();
     uint32_t threshold = 0;
     bool all_settled = false;
     for (;;) {
-        uint32_t action = 0, node = 0, key_word = 0;
-        if (j == 0 && hn > 0) {
-            const uint64_t key = heap_pop(heap, hn);
-            node = (uint32_t)key;
-            key_word = (uint32_t)(key >> 32);
-            action = sp.nodes[node].kind & 0xFFu;
-        }
-        action = __shfl(action, 0, 8);
-        node = __shfl(node, 0, 8);
-        key_word = __shfl(key_word, 0, 8);
-        if (action != 0) {
-            const DNode nd = sp.nodes[node];
-            if (action == AH_NODE_DESCENDANTS) {
-                const uint32_t kept = sp.leaf_kept ? sp.leaf_kept[node] : nd.b;
-                if (j == 0 && kept) {
-                    if (nl == kLeaves) {
-                        failed = true;
-                    } else {
-                        s_leaf[o][nl] = ((uint64_t)key_word << 32) | node;
-                        s_leaf_n[o][nl] = kept;
-                        nl++;
+        // kPops pops of every octet per block-wide check: a pop beyond the point where the check would have stopped only settles
+        // more leaves than needed (the cut below is by the sorted prefix), it never changes which ones are taken
+#pragma unroll 1
+        for (uint32_t rep = 0; rep < kPops; rep++) {
+            if (bi != kNone && !failed) {  // octet-uniform
+                const uint32_t node = (uint32_t)best, key_word = (uint32_t)(best >> 32);
+                hn--;
+                if (j == 0 && bi != hn) heap[bi] = heap[hn];
+                DNode nd;
+                if (node == c_id[0]) nd = c_nd[0];
+                else if (node == c_id[1]) nd = c_nd[1];
+                else nd = sp.nodes[node];
+                if ((nd.kind & 0xFFu) == AH_NODE_DESCENDANTS) {
+                    const uint32_t kept = sp.leaf_kept ? sp.leaf_kept[node] : nd.b;
+                    if (kept) {
+                        if (nl == kLeaves) {
+                            failed = true;
+                        } else {
+                            if (j == 0) {
+                                s_leaf[o][nl] = ((uint64_t)key_word << 32) | node;
+                                s_leaf_n[o][nl] = kept;
+                                s_leaf_a[o][nl] = nd.a;
+                            }
+                            nl++;
+                        }
                     }
-                }
-            } else {
-                float margin = 0.0f;
-                if (nd.kind & 0x100u) margin = descent_margin(nv, nd.c, qvec, qh, j);
-                if (j == 0) {
+                } else if ((nd.kind & 0xFFu) != 0) {
+                    c_id[0] = nd.a;
+                    c_id[1] = nd.b;
+                    c_nd[0] = sp.nodes[nd.a];
+                    c_nd[1] = sp.nodes[nd.b];
+                    float margin = 0.0f;
+                    if (nd.kind & 0x100u) margin = descent_margin<true>(nv, nd.c, qvec, qh, j);
                     if (hn + 2 > kHeap) {
                         failed = true;
                     } else {
                         const float dist = key_to_dist(key_word);
                         const float pl = rust_min(-margin, dist), pr = rust_min(margin, dist);
-                        heap_push(heap, hn, ((uint64_t)orderable_key(pl) << 32) | nd.a);
-                        heap_push(heap, hn, ((uint64_t)orderable_key(pr) << 32) | nd.b);
+                        if (j == 0) {
+                            heap[hn] = ((uint64_t)orderable_key(pl) << 32) | nd.a;
+                            heap[hn + 1] = ((uint64_t)orderable_key(pr) << 32) | nd.b;
+                        }
+                        hn += 2;
                     }
                 }
+                queue_argmax();
             }
         }
         // the largest key still queued anywhere, whether anything is queued at all, a failure — one barrier; then the ids held by
         // the leaves strictly above that key — a second one.  (Two scratch rows alternate: a wave can be at most one reduction
         // ahead of the slowest, so a row is never overwritten before everybody has read it.)
-        const bool has = j == 0 && hn > 0;
-        uint32_t top = has ? (uint32_t)(heap[0] >> 32) : 0u, flags = (has ? 1u : 0u) | (failed ? 2u : 0u);
-        for (uint32_t d = 32; d > 0; d >>= 1) {
+        const bool has = bi != kNone;
+        uint32_t top = has ? (uint32_t)(best >> 32) : 0u, flags = (has ? 1u : 0u) | (failed ? 2u : 0u);
+        for (uint32_t d = 32; d >= 8; d >>= 1) {
             top = max(top, (uint32_t)__shfl_xor((int)top, d, 64));
             flags |= (uint32_t)__shfl_xor((int)flags, d, 64);
         }
@@ -622,9 +683,8 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
             return;
         }
         const bool any_queued = (flags & 1u) != 0;
-        const uint32_t nl_o = __shfl(nl, 0, 8);
         uint32_t held = 0;
-        for (uint32_t i = j; i < nl_o; i += 8)
+        for (uint32_t i = j; i < nl; i += 8)
             if (!any_queued || (uint32_t)(s_leaf[o][i] >> 32) > top) held += s_leaf_n[o][i];
         for (uint32_t d = 32; d > 0; d >>= 1) held += __shfl_xor(held, d, 64);
         if (wl == 0) s_red[16 + wave] = held;
@@ -672,10 +732,12 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
         s_sorted_n[t] = 0;
         s_sorted_node[t] = 0;
     }
-    for (uint32_t size = 2; size <= p2; size <<= 1) {
+    uint32_t p2s = 2;  // the network only spans the settled leaves: the zero padding behind them is already in place
+    while (p2s < n_settled) p2s <<= 1;
+    for (uint32_t size = 2; size <= p2s; size <<= 1) {
         for (uint32_t str = size >> 1; str > 0; str >>= 1) {
             __syncthreads();
-            for (uint32_t t = tid; t < (p2 >> 1); t += kThreads) {
+            for (uint32_t t = tid; t < (p2s >> 1); t += kThreads) {
                 const uint32_t a_i = 2 * t - (t & (str - 1)), b_i = a_i + str;
                 const bool down = (a_i & size) == 0;  // descending order
                 const uint64_t x = s_sorted[a_i], y = s_sorted[b_i];
@@ -734,16 +796,65 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
         return;
     }
     __syncthreads();
-    for (uint32_t e = o; e < taken; e += kOct) {  // the taken leaves are the first `taken` of the sorted list
-        const uint32_t node = s_sorted_node[e], pos = s_pos[e];
-        const DNode nd = sp.nodes[node];
-        const uint32_t *ids = sp.desc + nd.a;
-        if (!sp.filter_bits) {
-            for (uint32_t i = j; i < nd.b; i += 8) my_nns[pos + i] = ids[i];
-        } else {
-            copy_filtered(sp, ids, nd.b, my_nns + pos, j);
+    if (!sp.filter_bits) {
+        // The taken leaves are the first `taken` of the sorted list and their ids one flat range [0, ids_taken) of the query's
+        // candidate buffer: position p belongs to the last leaf whose first position is <= p.  Every thread copies positions
+        // p = tid (mod 256) — a leaf per octet left 12 octets copying ~800 ids each, 8 lanes wide, while 20 watched.
+        // (a leaf's first id in the blob was kept when the leaf was popped: the sort key says which octet popped it and when)
+        uint32_t my_first[(kCap + kThreads - 1) / kThreads];
+#pragma unroll
+        for (uint32_t r = 0; r < (kCap + kThreads - 1) / kThreads; r++) {
+            const uint32_t e = tid + r * kThreads;
+            my_first[r] = 0;
+            if (e < taken) {
+                const uint32_t w = (uint32_t)s_sorted[e];
+                my_first[r] = s_leaf_a[w >> 16][0xFFFFu - (w & 0xFFFFu)];
+                record_visit(sink, s_sorted_node[e], q, s_pos[e], s_sorted_n[e]);
+            }
         }
-        if (j == 0) record_visit(sink, node, q, pos, s_sorted_n[e]);
+        __syncthreads();
+        uint32_t *s_first = reinterpret_cast<uint32_t *>(s_sorted);  // (the sort keys are dead now)
+#pragma unroll
+        for (uint32_t r = 0; r < (kCap + kThreads - 1) / kThreads; r++)
+            if (tid + r * kThreads < taken) s_first[tid + r * kThreads] = my_first[r];
+        __syncthreads();
+        // positions p = tid, tid + 256, ... rise: the leaf of p is found once and then walked forward (a search per position
+        // was 24 000 cycles of dependent LDS reads per thread)
+        constexpr uint32_t kFly = 20;
+        uint32_t e = 0;
+        {
+            uint32_t hi = taken;  // the last e with s_pos[e] <= tid
+            while (hi - e > 1) {
+                const uint32_t mid = (e + hi) >> 1;
+                if (s_pos[mid] <= tid) e = mid;
+                else hi = mid;
+            }
+        }
+        uint32_t next_first = e + 1 < taken ? s_pos[e + 1] : 0xFFFFFFFFu, base = taken ? s_first[e] - s_pos[e] : 0u;
+        for (uint32_t p0 = tid; p0 < ids_taken; p0 += kFly * kThreads) {
+            uint32_t id[kFly];
+#pragma unroll
+            for (uint32_t u = 0; u < kFly; u++) {
+                const uint32_t p = p0 + u * kThreads;
+                while (p >= next_first) {
+                    e++;
+                    next_first = e + 1 < taken ? s_pos[e + 1] : 0xFFFFFFFFu;
+                    base = s_first[e] - s_pos[e];
+                }
+                id[u] = p < ids_taken ? sp.desc[base + p] : 0u;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (uint32_t u = 0; u < kFly; u++)
+                if (p0 + u * kThreads < ids_taken) my_nns[p0 + u * kThreads] = id[u];
+        }
+    } else {
+        for (uint32_t e = o; e < taken; e += kOct) {
+            const uint32_t node = s_sorted_node[e], pos = s_pos[e];
+            const DNode nd = sp.nodes[node];
+            copy_filtered(sp, sp.desc + nd.a, nd.b, my_nns + pos, j);
+            if (j == 0) record_visit(sink, node, q, pos, s_sorted_n[e]);
+        }
     }
     if (tid == 0) {
         nns_count[q] = ids_taken;
@@ -995,6 +1106,90 @@ __global__ __launch_bounds__(256) void k_visit_scatter(const Visit *__restrict__
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const Visit v = visits[i];
         sorted[atomicAdd(&cursor[v.node], 1u)] = v;
+    }
+}
+
+// The same for a SMALL submission (arroy's own API is one query per call, src/reader.rs:46-75): the three scans above walk a
+// counter per node of the index (and a fourth launch zeroes them) to place what for one query is a dozen visits.  One block
+// sorts the visits by node in LDS instead — runs of one node are the node's visits, every 16 of a run a unit.  More than
+// kSmallVisits visits: bit 5 of *err, the submission takes the long way like any other overflow of the visit list.
+static constexpr uint32_t kSmallVisits = 2048;
+__global__ __launch_bounds__(256) void k_units_small(const Visit *__restrict__ visits, const uint32_t *__restrict__ total,
+                                                     uint32_t cap, Visit *__restrict__ sorted, TileUnit *__restrict__ units,
+                                                     uint32_t *__restrict__ n_units, uint32_t *__restrict__ stats) {
+    __shared__ uint64_t s_key[kSmallVisits];  // node << 32 | index into visits
+    __shared__ uint32_t s_wave[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n = *total;
+    if (n > cap || n > kSmallVisits) {  // block-uniform
+        if (tid == 0) {
+            atomicOr(&stats[SS_ERR], 32u);
+            *n_units = 0;
+        }
+        return;
+    }
+    uint32_t p2 = 2;
+    while (p2 < n) p2 <<= 1;
+    for (uint32_t i = tid; i < p2; i += 256) s_key[i] = i < n ? ((uint64_t)visits[i].node << 32) | i : ~0ull;
+    for (uint32_t size = 2; size <= p2; size <<= 1)
+        for (uint32_t str = size >> 1; str > 0; str >>= 1) {
+            __syncthreads();
+            for (uint32_t t = tid; t < (p2 >> 1); t += 256) {
+                const uint32_t a_i = 2 * t - (t & (str - 1)), b_i = a_i + str;
+                const bool up = (a_i & size) == 0;  // ascending
+                const uint64_t x = s_key[a_i], y = s_key[b_i];
+                if ((x > y) == up) {
+                    s_key[a_i] = y;
+                    s_key[b_i] = x;
+                }
+            }
+        }
+    __syncthreads();
+    auto lower_bound = [&](uint64_t key) {  // first position of the sorted keys that is >= key
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_key[mid] < key) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo;
+    };
+    // thread t owns the positions [t per, (t + 1) per): the units come out in node order like the scans' would
+    const uint32_t per = (n + 255u) / 256u;
+    uint32_t mine = 0;
+    for (uint32_t p = tid * per; p < min(n, (tid + 1) * per); p++) {
+        const uint64_t key = s_key[p];
+        sorted[p] = visits[(uint32_t)key];
+        mine += ((p - lower_bound(key & 0xFFFFFFFF00000000ull)) % kUnitVisits) == 0 ? 1u : 0u;
+    }
+    uint32_t incl = mine;
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t u = incl - mine, all = 0;
+    for (uint32_t w = 0; w < 4; w++) {
+        u += w < wave ? s_wave[w] : 0u;
+        all += s_wave[w];
+    }
+    uint32_t u16 = 0, u8 = 0, u4 = 0;
+    for (uint32_t p = tid * per; p < min(n, (tid + 1) * per); p++) {
+        const uint64_t key = s_key[p], node_key = key & 0xFFFFFFFF00000000ull;
+        if (((p - lower_bound(node_key)) % kUnitVisits) != 0) continue;
+        const uint32_t nv = min(kUnitVisits, lower_bound(node_key + (1ull << 32)) - p);
+        units[u++] = TileUnit{(uint32_t)(key >> 32), p, nv, 0u};
+        u16 += nv > 8 ? 1u : 0u;
+        u8 += nv > 4 && nv <= 8 ? 1u : 0u;
+        u4 += nv <= 4 ? 1u : 0u;
+    }
+    if (u16) atomicAdd(&stats[SS_UNITS_16], u16);
+    if (u8) atomicAdd(&stats[SS_UNITS_8], u8);
+    if (u4) atomicAdd(&stats[SS_UNITS_4], u4);
+    if (tid == 0) {
+        if (n) atomicAdd(&stats[SS_VISITS], n);
+        *n_units = all;
     }
 }
 
@@ -2426,7 +2621,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         // (+ qstride bytes each: the query leaf's copy in LDS; a leaf of more than 32 KiB is refused above)
         const size_t block_lds = block_descend_lds_bytes<32, 128, 32>() + qstride;
         const void *wave_big = reinterpret_cast<const void *>(k_descend_wave<1024, 128>);
-        const void *block_fn = reinterpret_cast<const void *>(k_descend_block<32, 128, 32>);
+        const void *block_fn = reinterpret_cast<const void *>(k_descend_block<32, 128, 32, 2>);
         if (!lds_opt_in[ds->device & 63].load(std::memory_order_acquire)) {
             AH_HIP(hipFuncSetAttribute(wave_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wave_lds_bytes(1024, 128) + (32u << 10))));
             AH_HIP(hipFuncSetAttribute(block_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2434,7 +2629,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
             lds_opt_in[ds->device & 63].store(true, std::memory_order_release);
         }
         if (small_first && (long long)nq <= block_max_nq)
-            hipLaunchKernelGGL((k_descend_block<32, 128, 32>), dim3((unsigned)nq), dim3(256), block_lds, s, ix->nv, sp, (uint32_t)nq,
+            hipLaunchKernelGGL((k_descend_block<32, 128, 32, 2>), dim3((unsigned)nq), dim3(256), block_lds, s, ix->nv, sp, (uint32_t)nq,
                                d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink);
         else if (small_first)
             hipLaunchKernelGGL((k_descend_wave<256, 64>), dim3((unsigned)nq), dim3(64), wave_lds_bytes(256, 64) + qstride, s, ix->nv, sp,
@@ -2454,18 +2649,25 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     }
     if (tiles) {  // 2'. the leaf-tile path: descent with its visits recorded, no host round trip before the results
         uint32_t *d_total = d_leaf_count + ix->n_nodes, *d_n_units = d_total + 1;
-        AH_HIP(hipMemsetAsync(d_leaf_count, 0, (size_t)ix->n_nodes * 4 + 8, s));
-        const VisitSink sink{d_visits, d_total, visit_cap, d_leaf_count, d_err};
+        // a small submission places its visits with one block (k_units_small) and needs no counter per node
+        const bool small_units = (long long)nq <= tun(TUN_SEARCH_SMALL_UNITS_MAX_QUERIES);
+        if (small_units) AH_HIP(hipMemsetAsync(d_total, 0, 8, s));
+        else AH_HIP(hipMemsetAsync(d_leaf_count, 0, (size_t)ix->n_nodes * 4 + 8, s));
+        const VisitSink sink{d_visits, d_total, visit_cap, small_units ? nullptr : d_leaf_count, d_err};
         if (wave_descent) AH_TRY(launch_wave(sink));
         hipLaunchKernelGGL((k_descend<false>), dim3((unsigned)((nq + 7) / 8)), dim3(64), heap_lds, s, ix->nv, sp,
                            (const uint32_t *)nullptr, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow,
                            (uint64_t *)nullptr, 0u, sink, wave_descent);
-        hipLaunchKernelGGL(k_leaf_scan_block, dim3(n_leaf_sums), dim3(256), 0, s, d_leaf_count, ix->n_nodes, d_cursor, d_ustart,
-                           d_leaf_sums);
-        hipLaunchKernelGGL(k_leaf_scan_sums, dim3(1), dim3(256), 0, s, d_leaf_sums, n_leaf_sums, d_n_units);
-        hipLaunchKernelGGL(k_leaf_scan_add, dim3(n_leaf_sums), dim3(256), 0, s, d_leaf_count, ix->n_nodes, d_cursor, d_ustart,
-                           d_leaf_sums, d_units, d_err);
-        hipLaunchKernelGGL(k_visit_scatter, dim3(256), dim3(256), 0, s, d_visits, d_total, visit_cap, d_cursor, d_sorted);
+        if (small_units) {
+            hipLaunchKernelGGL(k_units_small, dim3(1), dim3(256), 0, s, d_visits, d_total, visit_cap, d_sorted, d_units, d_n_units, d_err);
+        } else {
+            hipLaunchKernelGGL(k_leaf_scan_block, dim3(n_leaf_sums), dim3(256), 0, s, d_leaf_count, ix->n_nodes, d_cursor, d_ustart,
+                               d_leaf_sums);
+            hipLaunchKernelGGL(k_leaf_scan_sums, dim3(1), dim3(256), 0, s, d_leaf_sums, n_leaf_sums, d_n_units);
+            hipLaunchKernelGGL(k_leaf_scan_add, dim3(n_leaf_sums), dim3(256), 0, s, d_leaf_count, ix->n_nodes, d_cursor, d_ustart,
+                               d_leaf_sums, d_units, d_err);
+            hipLaunchKernelGGL(k_visit_scatter, dim3(256), dim3(256), 0, s, d_visits, d_total, visit_cap, d_cursor, d_sorted);
+        }
         const unsigned tile_slabs = std::max(1u, (ix->max_desc + kTileSlab - 1) / kTileSlab);
 #define AH_TILES(M)                                                                                                        \
     do {                                                                                                                   \
