@@ -173,19 +173,23 @@ __device__ __forceinline__ float octet_reduce_wide(const float *a, const float *
 // Same reduction with the streamed operand `row` in global memory (read once, non-temporal) and the broadcast
 // operand `s_b4` (query / normal) in LDS: 8 line-loads (128 B per lane, 8 KiB per wave) are issued before the
 // first use so HBM latency is covered by loads in flight rather than by occupancy alone.  dims >= 32.
-template <int OP>
+template <int OP, int FLY = 8, bool FENCE = false>
 __device__ __forceinline__ float octet_reduce_stream(const float4 *s_b4, const float *row, uint32_t dims, uint32_t j) {
     const uint32_t blocks = dims >> 5;
     const float4 *r4 = reinterpret_cast<const float4 *>(row) + j;
     const float4 *b4 = s_b4 + j;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t k = 0;
-    for (; k + 8 <= blocks; k += 8) {
-        float4 x[8];
+    for (; k + FLY <= blocks; k += FLY) {
+        float4 x[FLY];
 #pragma unroll
-        for (int u = 0; u < 8; u++) x[u] = ld_stream(r4 + (k + u) * 8);
+        for (int u = 0; u < FLY; u++) x[u] = ld_stream(r4 + (k + u) * 8);
+        // FENCE: all FLY requests leave before the first use (a latency-bound caller — few octets, nothing else to switch to —
+        // cannot afford the scheduler sinking loads to their uses; see octet_wide_chunks)
+        if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 8; u++) fma_step<OP>(acc, b4[(k + u) * 8], x[u]);
+        for (int u = 0; u < FLY; u++) fma_step<OP>(acc, b4[(k + u) * 8], x[u]);
+        if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
     }
     for (; k < blocks; k++) fma_step<OP>(acc, b4[k * 8], r4[k * 8]);
     float r = octet_finish(acc);

@@ -51,7 +51,7 @@ struct VisitSink {          // all null / 0: the descent records nothing
 // how the leaf tiles were cut.  Proof of the path taken (ah_index_search_stats), never an input of a result.
 enum SearchStatSlot {
     SS_ERR = 0, SS_WAVE_SMALL, SS_WAVE_BIG, SS_OCTET_LDS, SS_OCTET_GLOBAL, SS_UNITS_16, SS_UNITS_8, SS_UNITS_4, SS_VISITS,
-    SS_SCREENED, SS_SURVIVORS, SS_BLOCK, SS_WORDS = 16
+    SS_SCREENED, SS_SURVIVORS, SS_BLOCK, SS_VISIT_TOTAL, SS_N_UNITS, SS_DONE, SS_WORDS = 16
 };
 
 struct SearchParams {
@@ -512,7 +512,8 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
                                                             const uint8_t *__restrict__ qvecs, uint64_t qstride,
                                                             const float *__restrict__ qhdrs, uint32_t *__restrict__ nns,
                                                             uint32_t *__restrict__ nns_count, uint32_t *__restrict__ overflow,
-                                                            VisitSink sink) {
+                                                            VisitSink sink, bool last_pass, const float *__restrict__ raw_queries,
+                                                            float *__restrict__ qhdrs_out) {
     constexpr uint32_t kThreads = 8 * kOct, kWaves = kThreads / 64, kCap = kOct * kLeaves;
     static_assert((kThreads & (kThreads - 1)) == 0 && kCap >= kThreads, "power-of-two block, sort network at least as wide");
     extern __shared__ uint64_t s_blk_lds[];
@@ -548,13 +549,45 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
     uint64_t *heap = s_heap[o];
     // the query leaf in LDS (behind everything else; qstride bytes): every margin of the descent reads it
     uint4 *s_q4 = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(s_blk_lds) + block_descend_lds_bytes<kOct, kHeap, kLeaves>());
-    {
+    LeafHdr qh;
+    if (raw_queries) {
+        // `QueryBuilder::by_vector` (src/reader.rs:64-75) done here for a small submission of an f32 metric: what k_prepare_queries
+        // would have left in qvecs / qhdrs for the kernels behind this one, and the leaf straight into LDS (raw_queries may be the
+        // caller's pinned staging buffer, read over the link)
+        const float *src = raw_queries + (uint64_t)q * nv.dims;
+        float *dst = reinterpret_cast<float *>(const_cast<uint8_t *>(qvecs) + (uint64_t)q * qstride), *s_q = reinterpret_cast<float *>(s_q4);
+        for (uint32_t i0 = tid; i0 < nv.pitch; i0 += 8 * kThreads) {  // (eight reads over the link in flight per thread, not one)
+            float v[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) v[u] = i0 + u * kThreads < nv.dims ? src[i0 + u * kThreads] : 0.0f;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++)
+                if (i0 + u * kThreads < nv.pitch) {
+                    s_q[i0 + u * kThreads] = v[u];
+                    dst[i0 + u * kThreads] = v[u];
+                }
+        }
+        __syncthreads();
+        if (nv.metric == AH_COSINE && tid < 8) {
+            const float norm = f_sqrt(octet_reduce_any<OP_DOT>(s_q, s_q, nv.dims, tid));
+            if (tid == 0) s_red[63] = __float_as_uint(norm);
+        } else if (tid == 0) {
+            s_red[63] = 0u;
+        }
+        __syncthreads();
+        qh = LeafHdr{__uint_as_float(s_red[63]), 0.0f};
+        if (tid == 0) {
+            qhdrs_out[2 * (uint64_t)q] = qh.h0;
+            qhdrs_out[2 * (uint64_t)q + 1] = 0.0f;
+        }
+    } else {
         const uint4 *g_q4 = reinterpret_cast<const uint4 *>(qvecs + (uint64_t)q * qstride);
         for (uint32_t i = tid; i < (uint32_t)(qstride >> 4); i += kThreads) s_q4[i] = g_q4[i];
         __syncthreads();
+        qh = LeafHdr{qhdrs[2 * (uint64_t)q], qhdrs[2 * (uint64_t)q + 1]};
     }
     const void *qvec = s_q4;
-    const LeafHdr qh = {qhdrs[2 * (uint64_t)q], qhdrs[2 * (uint64_t)q + 1]};
     uint32_t *my_nns = nns + (uint64_t)q * sp.nns_stride;
     // The octet's queue is an UNSORTED array in LDS, popped by an arg-max over the octet's eight lanes: the keys are unique (the
     // node is their low word), so the pops come in the order a binary heap would give them, and a queue of the ~10 - 30 entries
@@ -679,6 +712,7 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
             if (tid == 0) {
                 nns_count[q] = 0;
                 overflow[q] = 1;
+                if (last_pass && sink.err) atomicOr(sink.err, 16u);  // nobody behind this kernel: the submission takes the long way
             }
             return;
         }
@@ -792,6 +826,7 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
         if (tid == 0) {
             nns_count[q] = 0;
             overflow[q] = 1;
+            if (last_pass && sink.err) atomicOr(sink.err, 16u);
         }
         return;
     }
@@ -1109,16 +1144,65 @@ __global__ __launch_bounds__(256) void k_visit_scatter(const Visit *__restrict__
     }
 }
 
+// (one wave per query; `lane` = the thread's index in it)
+__device__ __forceinline__ void query_h16(uint32_t q, uint32_t lane, const uint8_t *__restrict__ qvecs, uint64_t qstride, uint32_t dims,
+                                          uint32_t hpitch, uint16_t *__restrict__ q16, float4 *__restrict__ qstats) {
+    const float *v = reinterpret_cast<const float *>(qvecs + (uint64_t)q * qstride);
+    uint16_t *out = q16 + (uint64_t)q * hpitch;
+    float sa = 0.f, sb = 0.f, sc = 0.f;
+    uint32_t xbits = 0u;
+    for (uint32_t i = lane; i < hpitch; i += 64) {
+        const float x = i < dims ? v[i] : 0.0f;
+        const _Float16 h = to_shadow_half(x);
+        const float y = (float)h, d = x - y;
+        sa += y * y;
+        sb += d * d;
+        sc += x * x;
+        xbits = max(xbits, __float_as_uint(x) & 0x7FFFFFFFu);
+        out[i] = __builtin_bit_cast(uint16_t, h);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sa += __shfl_xor(sa, off);
+        sb += __shfl_xor(sb, off);
+        sc += __shfl_xor(sc, off);
+        xbits = max(xbits, (uint32_t)__shfl_xor((int)xbits, off));
+    }
+    if (lane == 0) {
+        const float up = 1.0f + (float)(hpitch + 64u) * 1.2e-7f;
+        const bool tiny = xbits != 0u && xbits < kTinyBits;  // squares underflow: the measured norms would lie
+        const float inf = __uint_as_float(0x7F800000u);
+        qstats[q] = tiny ? make_float4(inf, inf, inf, 0.f) : make_float4(sqrtf(sa) * up, sqrtf(sb) * up, sqrtf(sc) * up, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_queries_h16(const uint8_t *__restrict__ qvecs, uint64_t qstride, uint32_t dims,
+                                                    uint32_t hpitch, uint16_t *__restrict__ q16, float4 *__restrict__ qstats) {
+    query_h16(blockIdx.x, threadIdx.x, qvecs, qstride, dims, hpitch, q16, qstats);
+}
+
 // The same for a SMALL submission (arroy's own API is one query per call, src/reader.rs:46-75): the three scans above walk a
 // counter per node of the index (and a fourth launch zeroes them) to place what for one query is a dozen visits.  One block
 // sorts the visits by node in LDS instead — runs of one node are the node's visits, every 16 of a run a unit.  More than
 // kSmallVisits visits: bit 5 of *err, the submission takes the long way like any other overflow of the visit list.
 static constexpr uint32_t kSmallVisits = 2048;
+// Blocks 1 .. n_h16 of the launch are the queries' binary16 copies (k_queries_h16's work, wanted by the same consumer — the
+// leaf tiles — and as independent of the descent): one launch less on a path that is mostly launches.
+struct QueriesH16 {
+    const uint8_t *qvecs;
+    uint64_t qstride;
+    uint32_t dims, hpitch;
+    uint16_t *q16;
+    float4 *qstats;
+};
 __global__ __launch_bounds__(256) void k_units_small(const Visit *__restrict__ visits, const uint32_t *__restrict__ total,
                                                      uint32_t cap, Visit *__restrict__ sorted, TileUnit *__restrict__ units,
-                                                     uint32_t *__restrict__ n_units, uint32_t *__restrict__ stats) {
+                                                     uint32_t *__restrict__ n_units, uint32_t *__restrict__ stats, QueriesH16 h16) {
     __shared__ uint64_t s_key[kSmallVisits];  // node << 32 | index into visits
     __shared__ uint32_t s_wave[4];
+    if (blockIdx.x != 0) {
+        if (threadIdx.x < 64) query_h16(blockIdx.x - 1, threadIdx.x, h16.qvecs, h16.qstride, h16.dims, h16.hpitch, h16.q16, h16.qstats);
+        return;
+    }
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n = *total;
     if (n > cap || n > kSmallVisits) {  // block-uniform
@@ -1481,6 +1565,7 @@ __device__ __forceinline__ void leaf_tile_ring(const DataView &dv, const uint32_
 // blockIdx.x walks the units (persistent), blockIdx.y is the slab of rows of the unit's leaf: 128 rows when the unit has
 // more than 8 visits (4 rounds of 32 rows x 16 queries), 256 rows otherwise.
 static constexpr uint32_t kTileSlab = 128;
+static constexpr uint32_t kTileSmallSlab = 64;  // rows per block of k_leaf_tiles16 in a small submission (32 octets x 2 rows)
 template <int METRIC>
 __global__ __launch_bounds__(256) void k_leaf_tiles(DataView dv, const uint32_t *__restrict__ nns,
                                                     const Visit *__restrict__ sorted,
@@ -1548,40 +1633,9 @@ struct ScreenSearch {
 };
 
 // queries (f32 leaves at qvecs) -> binary16 copies + norms: one wave per query
-__global__ __launch_bounds__(64) void k_queries_h16(const uint8_t *__restrict__ qvecs, uint64_t qstride, uint32_t dims,
-                                                    uint32_t hpitch, uint16_t *__restrict__ q16, float4 *__restrict__ qstats) {
-    const uint32_t q = blockIdx.x;
-    const float *v = reinterpret_cast<const float *>(qvecs + (uint64_t)q * qstride);
-    uint16_t *out = q16 + (uint64_t)q * hpitch;
-    float sa = 0.f, sb = 0.f, sc = 0.f;
-    uint32_t xbits = 0u;
-    for (uint32_t i = threadIdx.x; i < hpitch; i += 64) {
-        const float x = i < dims ? v[i] : 0.0f;
-        const _Float16 h = to_shadow_half(x);
-        const float y = (float)h, d = x - y;
-        sa += y * y;
-        sb += d * d;
-        sc += x * x;
-        xbits = max(xbits, __float_as_uint(x) & 0x7FFFFFFFu);
-        out[i] = __builtin_bit_cast(uint16_t, h);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        sa += __shfl_xor(sa, off);
-        sb += __shfl_xor(sb, off);
-        sc += __shfl_xor(sc, off);
-        xbits = max(xbits, (uint32_t)__shfl_xor((int)xbits, off));
-    }
-    if (threadIdx.x == 0) {
-        const float up = 1.0f + (float)(hpitch + 64u) * 1.2e-7f;
-        const bool tiny = xbits != 0u && xbits < kTinyBits;  // squares underflow: the measured norms would lie
-        const float inf = __uint_as_float(0x7F800000u);
-        qstats[q] = tiny ? make_float4(inf, inf, inf, 0.f) : make_float4(sqrtf(sa) * up, sqrtf(sb) * up, sqrtf(sc) * up, 0.f);
-    }
-}
-
 // The leaf tile of k_leaf_tiles on the binary16 copies: R rows x Q queries of screen dot products per octet, any summation
 // order (gamma_s covers it).  The value lands where the f32 tile would put the distance.
-template <int R, int Q, int QO>
+template <int R, int Q, int QO, int KF = 1>
 __device__ __forceinline__ void leaf_tile16(const ScreenSearch &ss, const DataView &dv, const uint32_t *__restrict__ leaf_ids,
                                             uint32_t row_begin, uint32_t n_rows, const Visit *__restrict__ vis, uint32_t n_vis,
                                             float *__restrict__ dist, uint32_t stride, uint32_t *err) {
@@ -1613,7 +1667,30 @@ __device__ __forceinline__ void leaf_tile16(const ScreenSearch &ss, const DataVi
         for (int u = 0; u < R; u++)
 #pragma unroll
             for (int t = 0; t < Q; t++) acc[u][t] = 0.f;
-        for (uint32_t k = 0; k < steps; k++) {
+        uint32_t k = 0;
+        if constexpr (KF > 1) {
+            // the small submissions' variant: KF steps of every row and query requested before the first use — with a dozen
+            // leaves in the whole launch there is no other wave to switch to, and a step per trip to memory was 24 trips
+            for (; k + KF <= steps; k += KF) {
+                uint4 x[KF][R], y[KF][Q];
+#pragma unroll
+                for (int f = 0; f < KF; f++) {
+#pragma unroll
+                    for (int u = 0; u < R; u++) x[f][u] = r4[u][(k + f) * 8];
+#pragma unroll
+                    for (int t = 0; t < Q; t++) y[f][t] = q4[t][(k + f) * 8];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int f = 0; f < KF; f++)
+#pragma unroll
+                    for (int u = 0; u < R; u++)
+#pragma unroll
+                        for (int t = 0; t < Q; t++) acc[u][t] = screen_dot8(x[f][u], y[f][t], acc[u][t]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        for (; k < steps; k++) {
             uint4 x[R], y[Q];
 #pragma unroll
             for (int u = 0; u < R; u++) x[u] = r4[u][k * 8];
@@ -1637,6 +1714,7 @@ __device__ __forceinline__ void leaf_tile16(const ScreenSearch &ss, const DataVi
         }
     }
 }
+template <bool SMALL>
 __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch ss, const uint32_t *__restrict__ nns,
                                                       const Visit *__restrict__ sorted, const TileUnit *__restrict__ units,
                                                       const uint32_t *__restrict__ n_units_p, float *__restrict__ dist,
@@ -1646,12 +1724,26 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
         const TileUnit unit = units[u];
         const Visit *vis = sorted + unit.first;
         const uint32_t n_leaf = vis[0].n;
-        const uint32_t n_vis = unit.n_vis, slab = n_vis > 8 ? kTileSlab : 2 * kTileSlab;
+        // SMALL (its own kernel: the registers of the in-flight variant would cost the big submissions their occupancy): a small
+        // submission — the leaves of one or two queries in slabs of kTileSmallSlab rows, two rows per octet with the whole row
+        // in flight; the launch's grid.y counts those slabs
+        const bool fly = SMALL && unit.n_vis <= 2;
+        const uint32_t n_vis = unit.n_vis, slab = fly ? kTileSmallSlab : (n_vis > 8 ? kTileSlab : 2 * kTileSlab);
         const uint32_t row_begin = blockIdx.y * slab;
         if (row_begin >= n_leaf) continue;
         const uint32_t row_end = min(n_leaf, row_begin + slab);
         const uint32_t *leaf_ids = nns + (uint64_t)vis[0].q * stride + vis[0].pos;
 #define AH_TILE16(R, Q, QO) leaf_tile16<R, Q, QO>(ss, dv, leaf_ids, row_begin, row_end, vis, n_vis, dist, stride, err)
+        if constexpr (SMALL) {
+            if (fly && n_vis == 1) {
+                leaf_tile16<2, 1, 1, 24>(ss, dv, leaf_ids, row_begin, row_end, vis, n_vis, dist, stride, err);
+                continue;
+            }
+            if (fly) {
+                leaf_tile16<2, 2, 1, 12>(ss, dv, leaf_ids, row_begin, row_end, vis, n_vis, dist, stride, err);
+                continue;
+            }
+        }
         if (n_vis > 8) AH_TILE16(4, 4, 4);
         else if (n_vis > 4) AH_TILE16(4, 4, 2);
         else if (n_vis > 2) AH_TILE16(4, 4, 1);
@@ -1721,15 +1813,20 @@ __device__ __forceinline__ void screened_bounds(float sdot, float e_query, float
 
 // Selection of k_search_select with the screen in front: `dist_all` holds the SCREEN dot products of the candidates.
 // err bit 2: a non-finite screen value or distance; bit 3: more survivors than kSelectCap.
-template <int METRIC>
-__global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, ScreenSearch ss, const uint32_t *__restrict__ nns,
+template <int METRIC, bool FLAG>
+__device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenSearch ss, const uint32_t *__restrict__ nns,
                                                                  const float *__restrict__ dist_all, uint32_t stride,
                                                                  const uint32_t *__restrict__ counts,
                                                                  const uint32_t *__restrict__ unique, uint32_t k_out,
                                                                  const uint8_t *__restrict__ qvecs, uint64_t qstride,
                                                                  const float *__restrict__ qhdrs,
                                                                  uint32_t *__restrict__ out_ids, float *__restrict__ out_dist,
-                                                                 uint32_t *err, const PairSeg *__restrict__ segs) {
+                                                                 uint32_t *err, const PairSeg *__restrict__ segs,
+                                                                 uint32_t flag_words, uint32_t id_limit,
+                                                                 uint32_t *__restrict__ unique_out) {
+    // FLAG (a small submission of ah_search_batch, n <= 16 384): nns.dedup() done here, on the ids this block holds in registers
+    // anyway — k_flag_duplicates' bitmap (flag_words words of dynamic LDS behind the query leaf) without its launch, its trip to
+    // the candidate buffer and back, and the `unique` it would have left is written to unique_out
     constexpr uint32_t kBins = 2048, kCap = 1024, kThreads = 1024;
     extern __shared__ float4 s_qf4[];  // the query leaf in f32 (row pitch): the survivors' exact distances read it 143 times
     __shared__ uint32_t s_hist[kBins];
@@ -1740,14 +1837,20 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     // candidates of query q: a slot of `stride` entries (ah_search_batch), or a segment of the caller's lists (ah_rerank_batch)
     const uint64_t first = segs ? segs[q].off : (uint64_t)q * stride;
-    const uint32_t n = segs ? segs[q].n : counts[q], kk = segs ? min(k_out, segs[q].k) : min(k_out, unique[q]);
+    const uint32_t n = segs ? segs[q].n : counts[q];
+    uint32_t kk = FLAG ? 0u : (segs ? min(k_out, segs[q].k) : min(k_out, unique[q]));
     const uint32_t *ids = nns + first;
     const float *sd = dist_all + first;
-    for (uint32_t t = kk + tid; t < k_out; t += kThreads) {
-        out_ids[(uint64_t)q * k_out + t] = 0xFFFFFFFFu;
-        out_dist[(uint64_t)q * k_out + t] = __uint_as_float(0xFFFFFFFFu);
+    uint32_t *s_bits = reinterpret_cast<uint32_t *>(s_qf4 + (dv.pitch >> 2));  // FLAG: one bit per item id
+    if constexpr (!FLAG) {
+        for (uint32_t t = kk + tid; t < k_out; t += kThreads) {
+            out_ids[(uint64_t)q * k_out + t] = 0xFFFFFFFFu;
+            out_dist[(uint64_t)q * k_out + t] = __uint_as_float(0xFFFFFFFFu);
+        }
+        if (kk == 0) return;
+    } else {
+        for (uint32_t t = tid; t < flag_words / 4; t += kThreads) reinterpret_cast<uint4 *>(s_bits)[t] = make_uint4(0, 0, 0, 0);
     }
-    if (kk == 0) return;
     for (uint32_t b = tid; b < kBins; b += kThreads) s_hist[b] = 0;
     {
         const float4 *g_q4 = reinterpret_cast<const float4 *>(qvecs + (uint64_t)q * qstride);
@@ -1758,33 +1861,92 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
         s_max = 0u;
         s_n = 0u;
         s_bad = 0u;
+        s_bin = 0u;  // (FLAG: the count of distinct ids until the histogram's scan takes the word over)
     }
     __syncthreads();
     const float qn = qhdrs[2 * (uint64_t)q];
     const float e_query = screened_error(ss.max_stats, ss.qstats[q], ss.gamma_s, ss.gamma_r);
     const float *xns = ss.aux + (METRIC == AH_COSINE ? first : 0ull);
-    // keys of a candidate: orderable(U) and orderable(L), recomputed in every pass from its screen value (coalesced reads,
-    // no gather: the error bound is one number per query)
-    auto bounds_of = [&](uint32_t g, uint32_t &ukey, uint32_t &lkey) -> bool {
-        if (!segs && ids[g] == 0xFFFFFFFFu) return false;  // (a flagged duplicate of the search; a caller's list may hold that id)
-        const float sdot = sd[g];
+    // Keys of a candidate: orderable(U) and orderable(L) from its screen value (the error bound is one number per query).  The
+    // three passes below see every candidate; its keys are computed ONCE, into registers (thread t owns the candidates
+    // t + 1024 r, r < kOwn, all their loads in flight together): three loops of dependent loads were 30 trips to memory for a
+    // single query's 10 000 candidates.  What a list holds beyond 16 384 candidates is read again in every pass.
+    constexpr uint32_t kOwn = 16;
+    if (FLAG && n > kOwn * kThreads) {  // (the host does not choose FLAG for such a stride)
+        if (tid == 0) atomicOr(err, 8u);
+        return;
+    }
+    auto keys_of = [&](uint32_t id, float sdot, float xn, uint32_t &ukey, uint32_t &lkey) -> bool {
+        if (!segs && id == 0xFFFFFFFFu) return false;  // (a flagged duplicate of the search; a caller's list may hold that id)
         if (!(fabsf(sdot) <= 3.0e38f)) {  // NaN or inf (a missing item, an overflow in binary16): not this path's business
             s_bad = 1u;
             return false;
         }
         float lo, hi;
-        screened_bounds<METRIC>(sdot, e_query, qn, METRIC == AH_COSINE ? xns[g] : 0.f, lo, hi);
+        screened_bounds<METRIC>(sdot, e_query, qn, xn, lo, hi);
         ukey = orderable_key(hi);
         lkey = orderable_key(lo);
         return true;
     };
-    uint32_t lo_k = 0xFFFFFFFFu, hi_k = 0u;
-    for (uint32_t g = tid; g < n; g += kThreads) {
-        uint32_t uk, lk;
-        if (!bounds_of(g, uk, lk)) continue;
-        lo_k = min(lo_k, uk);
-        hi_k = max(hi_k, uk);
+    uint32_t own_u[kOwn], own_l[kOwn], own_id[kOwn], own_ok = 0;
+    {
+        float v_sd[kOwn], v_xn[kOwn];
+#pragma unroll
+        for (uint32_t r = 0; r < kOwn; r++) {
+            const uint32_t g = tid + r * kThreads;
+            own_id[r] = g < n ? ids[g] : 0xFFFFFFFFu;
+            v_sd[r] = g < n ? sd[g] : 0.0f;
+            v_xn[r] = (METRIC == AH_COSINE && g < n) ? xns[g] : 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FLAG) {  // the second and later occurrences of an id drop out (which one stays does not matter: same id, same row)
+            uint32_t mine = 0;
+            bool bad_id = false;
+#pragma unroll
+            for (uint32_t r = 0; r < kOwn; r++) {
+                if (tid + r * kThreads >= n) continue;
+                if (own_id[r] >= id_limit) {
+                    bad_id = true;
+                    own_id[r] = 0xFFFFFFFFu;
+                    continue;
+                }
+                const uint32_t bit = 1u << (own_id[r] & 31);
+                if (atomicOr(&s_bits[own_id[r] >> 5], bit) & bit) own_id[r] = 0xFFFFFFFFu;
+                else mine++;
+            }
+            if (bad_id) atomicOr(err, 1u);
+            for (uint32_t d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+            if ((tid & 63u) == 0 && mine) atomicAdd(&s_bin, mine);
+            __syncthreads();
+            const uint32_t n_unique = s_bin;
+            kk = min(k_out, n_unique);
+            if (tid == 0) unique_out[q] = n_unique;
+            for (uint32_t t = kk + tid; t < k_out; t += kThreads) {
+                out_ids[(uint64_t)q * k_out + t] = 0xFFFFFFFFu;
+                out_dist[(uint64_t)q * k_out + t] = __uint_as_float(0xFFFFFFFFu);
+            }
+            if (kk == 0) return;  // block-uniform
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < kOwn; r++) {
+            own_u[r] = own_l[r] = 0;
+            if (tid + r * kThreads < n && keys_of(own_id[r], v_sd[r], v_xn[r], own_u[r], own_l[r])) own_ok |= 1u << r;
+        }
     }
+#define AH_SELECT_REST(G, ID, UK, LK, BODY)                                                     \
+    for (uint32_t G = tid + kOwn * kThreads; G < n; G += kThreads) {                            \
+        uint32_t UK, LK;                                                                        \
+        const uint32_t ID = ids[G];                                                             \
+        if (keys_of(ID, sd[G], METRIC == AH_COSINE ? xns[G] : 0.0f, UK, LK)) { BODY; }          \
+    }
+    uint32_t lo_k = 0xFFFFFFFFu, hi_k = 0u;
+#pragma unroll
+    for (uint32_t r = 0; r < kOwn; r++)
+        if (own_ok >> r & 1u) {
+            lo_k = min(lo_k, own_u[r]);
+            hi_k = max(hi_k, own_u[r]);
+        }
+    AH_SELECT_REST(g, id, uk, lk, (lo_k = min(lo_k, uk), hi_k = max(hi_k, uk)))
     for (int off = 32; off > 0; off >>= 1) {
         lo_k = min(lo_k, (uint32_t)__shfl_xor((int)lo_k, off));
         hi_k = max(hi_k, (uint32_t)__shfl_xor((int)hi_k, off));
@@ -1803,10 +1965,10 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
     const bool direct = span <= kBins;
     const uint32_t scale = direct ? 0u : (uint32_t)(((uint64_t)kBins << 32) / span);
     auto bin_of = [&](uint32_t w) -> uint32_t { return direct ? w - w_min : (uint32_t)(((uint64_t)(w - w_min) * scale) >> 32); };
-    for (uint32_t g = tid; g < n; g += kThreads) {
-        uint32_t uk, lk;
-        if (bounds_of(g, uk, lk)) atomicAdd(&s_hist[bin_of(uk)], 1u);
-    }
+#pragma unroll
+    for (uint32_t r = 0; r < kOwn; r++)
+        if (own_ok >> r & 1u) atomicAdd(&s_hist[bin_of(own_u[r])], 1u);
+    AH_SELECT_REST(g, id, uk, lk, atomicAdd(&s_hist[bin_of(uk)], 1u))
     __syncthreads();
     {  // the bin that holds the k-th smallest U
         constexpr uint32_t kPer = kBins / kThreads;
@@ -1843,13 +2005,18 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
         const uint64_t d = (lim + scale - 1ull) / scale;
         t_key = (uint32_t)min((uint64_t)w_min + d - 1ull, (uint64_t)s_max);
     }
-    for (uint32_t g = tid; g < n; g += kThreads) {
-        uint32_t uk, lk;
-        if (bounds_of(g, uk, lk) && lk <= t_key) {
+    // the survivors: their ids (s_pos), in the order the atomics hand out
+#pragma unroll
+    for (uint32_t r = 0; r < kOwn; r++)
+        if ((own_ok >> r & 1u) && own_l[r] <= t_key) {
             const uint32_t at = atomicAdd(&s_n, 1u);
-            if (at < kCap) s_pos[at] = g;
+            if (at < kCap) s_pos[at] = own_id[r];
         }
-    }
+    AH_SELECT_REST(g, id, uk, lk, if (lk <= t_key) {
+        const uint32_t at = atomicAdd(&s_n, 1u);
+        if (at < kCap) s_pos[at] = id;
+    })
+#undef AH_SELECT_REST
     __syncthreads();
     const uint32_t n_sel = s_n;
     if (n_sel > kCap) {
@@ -1860,15 +2027,16 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
         atomicAdd(&err[SS_SCREENED], 1u);
         atomicAdd(&err[SS_SURVIVORS], n_sel);
     }
-    // the survivors in the reference's arithmetic: one octet per candidate (the f32 row against the f32 query leaf)
-    // (octet_reduce_stream: the reference's chains and tree, the row's first eight lines requested before the first use)
+    // the survivors in the reference's arithmetic: one octet per candidate (the f32 row against the f32 query leaf; the
+    // reference's chains and tree, sixteen lines of the row requested before the first use)
     const uint32_t j = tid & 7u;
     bool bad = false;
     for (uint32_t e = tid >> 3; e < n_sel; e += kThreads >> 3) {
-        const uint32_t g = s_pos[e], id = ids[g];
+        const uint32_t id = s_pos[e];
         const uint64_t row = row_of_id(dv, id);
-        const float r = octet_reduce_stream<OP_DOT>(s_qf4, dv.rows_f32 + row * dv.pitch, dv.dims, j);
-        const float d = METRIC == AH_COSINE ? cosine_from_dot(r, qn, dv.headers[row]) : -r;
+        const float xh = METRIC == AH_COSINE ? dv.headers[row] : 0.0f;
+        const float r = octet_reduce_stream<OP_DOT, 16, true>(s_qf4, dv.rows_f32 + row * dv.pitch, dv.dims, j);
+        const float d = METRIC == AH_COSINE ? cosine_from_dot(r, qn, xh) : -r;
         if (j == 0) {
             const uint32_t w = orderable_key(d);
             if (w > 0xFF7FFFFFu) bad = true;  // +inf / NaN: src/reader.rs:611-621 looks at positions
@@ -1878,30 +2046,45 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
     }
     if (bad) atomicOr(err, 4u);
     __syncthreads();
-    uint32_t p2 = 64;
-    while (p2 < n_sel) p2 <<= 1;
-    for (uint32_t t = n_sel + tid; t < p2; t += kThreads) s_key[t] = ~0ull;
-    for (uint32_t size = 2; size <= p2; size <<= 1) {
-        for (uint32_t str = size >> 1; str > 0; str >>= 1) {
-            __syncthreads();
-            for (uint32_t t = tid; t < (p2 >> 1); t += kThreads) {
-                const uint32_t a_i = 2 * t - (t & (str - 1)), b_i = a_i + str;
-                const bool up = (a_i & size) == 0;
-                const uint64_t x = s_key[a_i], y = s_key[b_i];
-                if ((x > y) == up) {
-                    s_key[a_i] = y;
-                    s_key[b_i] = x;
-                    const float vx = s_val[a_i];
-                    s_val[a_i] = s_val[b_i];
-                    s_val[b_i] = vx;
-                }
-            }
+    // ascending (OrderedFloat(distance), id): a survivor's place is the number of smaller keys (unique: the id is their low
+    // word) — n_sel broadcast reads per thread and one barrier instead of a sorting network's 36 - 55
+    for (uint32_t e = tid; e < n_sel; e += kThreads) {
+        const uint64_t mine = s_key[e];
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < n_sel; i++) {  // (a caller's list may repeat an id: equal keys keep their order)
+            const uint64_t other = s_key[i];
+            rank += (other < mine || (other == mine && i < e)) ? 1u : 0u;
+        }
+        if (rank < kk) {
+            out_ids[(uint64_t)q * k_out + rank] = (uint32_t)mine;
+            out_dist[(uint64_t)q * k_out + rank] = normalized_distance(dv.metric, s_val[e], dv.dims);
         }
     }
-    __syncthreads();
-    for (uint32_t t = tid; t < kk; t += kThreads) {
-        out_ids[(uint64_t)q * k_out + t] = (uint32_t)s_key[t];
-        out_dist[(uint64_t)q * k_out + t] = normalized_distance(dv.metric, s_val[t], dv.dims);
+}
+
+// host_status != nullptr (a small submission; out_ids / out_dist / unique_out are then the caller's pinned buffers): the block
+// that finishes last copies the status words there as well, and the call needs no copy back — only the wait for this kernel.
+template <int METRIC, bool FLAG = false>
+__global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, ScreenSearch ss, const uint32_t *__restrict__ nns,
+                                                                 const float *__restrict__ dist_all, uint32_t stride,
+                                                                 const uint32_t *__restrict__ counts,
+                                                                 const uint32_t *__restrict__ unique, uint32_t k_out,
+                                                                 const uint8_t *__restrict__ qvecs, uint64_t qstride,
+                                                                 const float *__restrict__ qhdrs,
+                                                                 uint32_t *__restrict__ out_ids, float *__restrict__ out_dist,
+                                                                 uint32_t *err, const PairSeg *__restrict__ segs,
+                                                                 uint32_t flag_words = 0, uint32_t id_limit = 0,
+                                                                 uint32_t *__restrict__ unique_out = nullptr,
+                                                                 uint32_t *__restrict__ host_status = nullptr) {
+    search_select_screened_body<METRIC, FLAG>(dv, ss, nns, dist_all, stride, counts, unique, k_out, qvecs, qstride, qhdrs, out_ids, out_dist,
+                                              err, segs, flag_words, id_limit, unique_out);
+    if (host_status) {  // (every return of the body is block-uniform)
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(&err[SS_DONE], 1u) + 1u == gridDim.x) {
+            __threadfence();
+            for (uint32_t w = 0; w < SS_WORDS; w++) host_status[w] = __hip_atomic_load(&err[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -2582,9 +2765,12 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
 
     const DataView dv = ds->view();
     // 1. query leaves (src/reader.rs:46-51 by_item, :64-75 by_vector)
+    // (a small submission: the kernel that prepares the query leaves reads the pinned staging buffer itself — 6 KB over the link
+    // cost less than the copy engine's launch)
+    const bool zero_copy_queries = queries && (long long)nq <= tun(TUN_SEARCH_SMALL_UNITS_MAX_QUERIES);
     if (queries) {
         memcpy(h_q, queries, nq * (size_t)ds->dims * 4);
-        AH_HIP(hipMemcpyAsync(d_qf32, h_q, nq * (size_t)ds->dims * 4, hipMemcpyHostToDevice, s));
+        if (!zero_copy_queries) AH_HIP(hipMemcpyAsync(d_qf32, h_q, nq * (size_t)ds->dims * 4, hipMemcpyHostToDevice, s));
     } else {
         memcpy(h_qrows, query_rows, nq * 4);
         AH_HIP(hipMemcpyAsync(d_qrows, h_qrows, nq * 4, hipMemcpyHostToDevice, s));
@@ -2602,14 +2788,22 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     sp.filter_len_bits = filter_len_bits;
     sp.search_k = search_k;
     sp.nns_stride = nns_stride;
-    if (queries) AH_TRY(launch_prepare_queries_only(dv, d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
-    if (screened)
+    // (... and when the block descent is the first kernel to want the leaves, it prepares them itself)
+    const bool fuse_prepare = zero_copy_queries && tiles && wave_descent && !metric_is_bq_dev(ds->metric) &&
+                              (!d_filter_bits || filter_share >= 0.35) && (long long)nq <= tun(TUN_SEARCH_BLOCK_MAX_QUERIES) &&
+                              tun(TUN_SEARCH_FUSED_PREPARE) != 0;
+    if (queries && !fuse_prepare)
+        AH_TRY(launch_prepare_queries_only(dv, zero_copy_queries ? h_q : d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
+    // (a small submission on the leaf-tile path makes the binary16 copies of its queries in the launch that places its visits)
+    const bool small_units = tiles && (long long)nq <= tun(TUN_SEARCH_SMALL_UNITS_MAX_QUERIES);
+    if (screened && !small_units)
         hipLaunchKernelGGL(k_queries_h16, dim3((unsigned)nq), dim3(64), 0, s, d_qvecs, qstride, ds->dims, ds->hpitch,
                            const_cast<uint16_t *>(ss.q16), const_cast<float4 *>(ss.qstats));
     // 2. descent: one wave per query, then one octet per query for what that left, queue in LDS
     // (ah_search_batch decides: a filter that keeps under 5 % of the items makes a query pop more nodes than the queues of
     // a wave hold; under a filter the wave descent reads what the filter keeps of every leaf, computed once per submission)
     if (wave_descent && d_filter_bits) sp.leaf_kept = d_leaf_kept;
+    bool passes_done = false;  // set by launch_wave: the block descent was the whole descent
     auto launch_wave = [&](const VisitSink &sink) -> int {
         // a query pops about 1 / (kept share) as many nodes under a filter: start with the big queues (one query per CU
         // at a time) only then; otherwise they take what the small ones (four per CU) could not hold
@@ -2628,10 +2822,19 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                                        (int)(block_descend_lds_bytes<32, 128, 32>() + (32u << 10))));
             lds_opt_in[ds->device & 63].store(true, std::memory_order_release);
         }
-        if (small_first && (long long)nq <= block_max_nq)
+        if (small_first && (long long)nq <= block_max_nq) {
+            // On the leaf-tile path nothing runs behind the block kernel: what it cannot hold (rare: its capacities, equal keys
+            // of two octets across the cut) raises bit 4 of *err and the submission is redone the long way, instead of every
+            // small call paying two more launches for passes that find nothing to do.
+            const bool last_pass = sink.visits != nullptr;
             hipLaunchKernelGGL((k_descend_block<32, 128, 32, 2>), dim3((unsigned)nq), dim3(256), block_lds, s, ix->nv, sp, (uint32_t)nq,
-                               d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink);
-        else if (small_first)
+                               d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink, last_pass,
+                               (last_pass && fuse_prepare) ? (const float *)h_q : (const float *)nullptr, d_qhdrs);
+            if (last_pass) {
+                passes_done = true;
+                return AH_OK;
+            }
+        } else if (small_first)
             hipLaunchKernelGGL((k_descend_wave<256, 64>), dim3((unsigned)nq), dim3(64), wave_lds_bytes(256, 64) + qstride, s, ix->nv, sp,
                                (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink, false);
         hipLaunchKernelGGL((k_descend_wave<1024, 128>), dim3((unsigned)nq), dim3(64), wave_lds_bytes(1024, 128) + qstride, s, ix->nv, sp,
@@ -2648,18 +2851,20 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         }
     }
     if (tiles) {  // 2'. the leaf-tile path: descent with its visits recorded, no host round trip before the results
-        uint32_t *d_total = d_leaf_count + ix->n_nodes, *d_n_units = d_total + 1;
+        // (the visit and unit counters live in spare words of the status block: one memset clears them with it)
+        uint32_t *d_total = d_err + SS_VISIT_TOTAL, *d_n_units = d_err + SS_N_UNITS;
         // a small submission places its visits with one block (k_units_small) and needs no counter per node
-        const bool small_units = (long long)nq <= tun(TUN_SEARCH_SMALL_UNITS_MAX_QUERIES);
-        if (small_units) AH_HIP(hipMemsetAsync(d_total, 0, 8, s));
-        else AH_HIP(hipMemsetAsync(d_leaf_count, 0, (size_t)ix->n_nodes * 4 + 8, s));
+        if (!small_units) AH_HIP(hipMemsetAsync(d_leaf_count, 0, (size_t)ix->n_nodes * 4, s));
         const VisitSink sink{d_visits, d_total, visit_cap, small_units ? nullptr : d_leaf_count, d_err};
         if (wave_descent) AH_TRY(launch_wave(sink));
-        hipLaunchKernelGGL((k_descend<false>), dim3((unsigned)((nq + 7) / 8)), dim3(64), heap_lds, s, ix->nv, sp,
-                           (const uint32_t *)nullptr, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow,
-                           (uint64_t *)nullptr, 0u, sink, wave_descent);
+        if (!passes_done)
+            hipLaunchKernelGGL((k_descend<false>), dim3((unsigned)((nq + 7) / 8)), dim3(64), heap_lds, s, ix->nv, sp,
+                               (const uint32_t *)nullptr, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow,
+                               (uint64_t *)nullptr, 0u, sink, wave_descent);
         if (small_units) {
-            hipLaunchKernelGGL(k_units_small, dim3(1), dim3(256), 0, s, d_visits, d_total, visit_cap, d_sorted, d_units, d_n_units, d_err);
+            const QueriesH16 h16{d_qvecs, qstride, ds->dims, ds->hpitch, const_cast<uint16_t *>(ss.q16), const_cast<float4 *>(ss.qstats)};
+            hipLaunchKernelGGL(k_units_small, dim3(1u + (screened ? (unsigned)nq : 0u)), dim3(256), 0, s, d_visits, d_total, visit_cap,
+                               d_sorted, d_units, d_n_units, d_err, h16);
         } else {
             hipLaunchKernelGGL(k_leaf_scan_block, dim3(n_leaf_sums), dim3(256), 0, s, d_leaf_count, ix->n_nodes, d_cursor, d_ustart,
                                d_leaf_sums);
@@ -2677,8 +2882,16 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                            d_units, d_n_units, d_qvecs, qstride, d_qhdrs, d_dist, nns_stride, d_err);                       \
     } while (0)
         if (screened) {  // the candidates on the binary16 copies first: half the bytes (see k_search_select_screened)
-            hipLaunchKernelGGL(k_leaf_tiles16, dim3(2048, tile_slabs), dim3(256), 0, s, dv, ss, d_nns, d_sorted, d_units, d_n_units,
-                               d_dist, nns_stride, d_err);
+            // a small submission: slabs of 64 rows (a dozen leaves then fill 150 CUs instead of 50) and a grid that does not
+            // dispatch 24 000 blocks to find 12 units
+            const unsigned small_slabs = std::max(1u, (ix->max_desc + kTileSmallSlab - 1) / kTileSmallSlab);
+            const bool small_tiles = (long long)nq <= tun(TUN_SEARCH_SMALL_TILES_MAX_QUERIES) && small_slabs <= 65535u;
+            if (small_tiles)
+                hipLaunchKernelGGL((k_leaf_tiles16<true>), dim3(std::min<unsigned>(2048u, 32u * (unsigned)nq), small_slabs), dim3(256), 0, s,
+                                   dv, ss, d_nns, d_sorted, d_units, d_n_units, d_dist, nns_stride, d_err);
+            else
+                hipLaunchKernelGGL((k_leaf_tiles16<false>), dim3(2048, tile_slabs), dim3(256), 0, s, dv, ss, d_nns, d_sorted, d_units,
+                                   d_n_units, d_dist, nns_stride, d_err);
         } else {
             switch (ds->metric) {
             case AH_EUCLIDEAN: AH_TILES(AH_EUCLIDEAN); break;
@@ -2703,7 +2916,22 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                     leaves, np, hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]);
         }
         // (after the tiles: they read the leaves' ids from the candidate buffers)
-        if (bitmap_fits) {
+        // a small submission: nns.dedup() inside the selection kernel (FLAG), when the bitmap fits beside its other LDS
+        const size_t sel_lds = (size_t)ds->pitch * 4;  // the query leaf in f32
+        const size_t fused_lds = sel_lds + (size_t)bitmap_words * 4;
+        const bool fused_flag = small_units && screened && bitmap_fits && nns_stride <= 16384 && fused_lds + (26u << 10) <= (160u << 10) &&
+                                tun(TUN_SEARCH_FUSED_FLAG) != 0;
+        if (fused_flag) {
+            *h_err = 0xFFFFFFFFu;  // (overwritten by the selection kernel's last block: a launch that never ran reads as a failure)
+            static std::atomic<uint32_t> fused_opt_in[64][2];  // [device][metric]: largest dynamic LDS opted in for
+            const int mi = ds->metric == AH_COSINE ? 0 : 1;
+            if (fused_opt_in[ds->device & 63][mi].load(std::memory_order_acquire) < fused_lds) {
+                const void *fn = mi == 0 ? reinterpret_cast<const void *>(k_search_select_screened<AH_COSINE, true>)
+                                         : reinterpret_cast<const void *>(k_search_select_screened<AH_DOT_PRODUCT, true>);
+                AH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
+                fused_opt_in[ds->device & 63][mi].store((uint32_t)fused_lds, std::memory_order_release);
+            }
+        } else if (bitmap_fits) {
             const size_t sh = (size_t)bitmap_words * 4;
             static std::atomic<uint32_t> flag_lds[64];  // largest bitmap this device's kernel has been opted in for
             if (sh > 48 * 1024 && flag_lds[ds->device & 63].load(std::memory_order_acquire) < sh) {
@@ -2723,14 +2951,21 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
             hipLaunchKernelGGL(k_flag_duplicates_hash, dim3((unsigned)nq), dim3(1024), kHashSlots * 4, s, d_nns, nns_stride, d_counts,
                                d_unique, d_err);
         }
-        const size_t sel_lds = (size_t)ds->pitch * 4;  // the query leaf in f32
-        if (screened && sel_lds > 32 * 1024) {
+        if (screened && sel_lds > 32 * 1024 && !fused_flag) {
             AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_select_screened<AH_COSINE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
             AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_select_screened<AH_DOT_PRODUCT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
         }
-        if (screened && ds->metric == AH_COSINE)
+        if (fused_flag && ds->metric == AH_COSINE)
+            hipLaunchKernelGGL((k_search_select_screened<AH_COSINE, true>), dim3((unsigned)nq), dim3(1024), fused_lds, s, dv, ss, d_nns, d_dist,
+                               nns_stride, d_counts, d_unique, (uint32_t)k, d_qvecs, qstride, d_qhdrs, h_oi, h_od, d_err, (const PairSeg *)nullptr,
+                               bitmap_words, max_id + 1, h_counts, h_err);
+        else if (fused_flag)
+            hipLaunchKernelGGL((k_search_select_screened<AH_DOT_PRODUCT, true>), dim3((unsigned)nq), dim3(1024), fused_lds, s, dv, ss, d_nns,
+                               d_dist, nns_stride, d_counts, d_unique, (uint32_t)k, d_qvecs, qstride, d_qhdrs, h_oi, h_od, d_err,
+                               (const PairSeg *)nullptr, bitmap_words, max_id + 1, h_counts, h_err);
+        else if (screened && ds->metric == AH_COSINE)
             hipLaunchKernelGGL((k_search_select_screened<AH_COSINE>), dim3((unsigned)nq), dim3(1024), sel_lds, s, dv, ss, d_nns, d_dist,
                                nns_stride, d_counts, d_unique, (uint32_t)k, d_qvecs, qstride, d_qhdrs, d_oi, d_od, d_err, (const PairSeg *)nullptr);
         else if (screened)
@@ -2743,9 +2978,10 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         // uninitialised results: such a submission takes the sorted path as well
         const hipError_t launch_err = hipGetLastError();
         // ids, distances, status words and counts: one copy (the four buffers are carved back to back on both sides)
-        AH_HIP(hipMemcpyAsync(h_oi, d_oi, 2 * pad(nq * k * 4) + pad(SS_WORDS * 4) + nq * 4, hipMemcpyDeviceToHost, s));
+        // (fused_flag: the selection kernel wrote ids, distances, counts and status into the pinned buffers itself)
+        if (!fused_flag) AH_HIP(hipMemcpyAsync(h_oi, d_oi, 2 * pad(nq * k * 4) + pad(SS_WORDS * 4) + nq * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipStreamSynchronize(s));
-        AH_REQUIRE((*h_err & 1u) == 0, AH_ERR_MISSING_ITEM, "a descendant id does not exist in the dataset");
+        AH_REQUIRE((*h_err & 1u) == 0 || *h_err == 0xFFFFFFFFu, AH_ERR_MISSING_ITEM, "a descendant id does not exist in the dataset");
         if ((*h_err & ~1u) == 0 && launch_err == hipSuccess) {
             for (size_t q = 0; q < nq; q++) out_counts[q] = (uint32_t)std::min<size_t>(k, h_counts[q]);
             memcpy(out_ids, h_oi, nq * k * 4);
