@@ -1239,7 +1239,7 @@ struct QueryBufs {
 
 // Device scratch layout for one query call.  Returns the carver positioned after the query block.
 static int stage_query(ah_dataset *ds, Context *ctx, const float *query, const uint32_t *query_item, size_t extra_dev,
-                       size_t extra_pinned, QueryBufs *qb, Carver *dev_out, Carver *pin_out) {
+                       size_t extra_pinned, QueryBufs *qb, Carver *dev_out, Carver *pin_out, bool zero_copy = false) {
     const size_t qbytes = pad256(ds->row_bytes()) + pad256(8) + pad256((size_t)ds->dims * 4) + pad256(4);
     AH_TRY(ctx->ensure_device(qbytes + extra_dev));
     AH_TRY(ctx->ensure_pinned(pad256((size_t)ds->dims * 4) + extra_pinned));
@@ -1253,8 +1253,9 @@ static int stage_query(ah_dataset *ds, Context *ctx, const float *query, const u
     DataView dv = ds->view();
     if (query) {
         memcpy(h_q, query, (size_t)ds->dims * 4);
-        AH_HIP(hipMemcpyAsync(qb->d_qf32, h_q, (size_t)ds->dims * 4, hipMemcpyHostToDevice, ctx->stream));
-        AH_TRY(launch_prepare_query(dv, qb->d_qf32, qb->d_qvec, qb->d_qhdr, ctx->stream));
+        // (zero_copy: a latency-bound caller — the kernel reads the pinned staging buffer over the link, no copy is queued)
+        if (!zero_copy) AH_HIP(hipMemcpyAsync(qb->d_qf32, h_q, (size_t)ds->dims * 4, hipMemcpyHostToDevice, ctx->stream));
+        AH_TRY(launch_prepare_query(dv, zero_copy ? h_q : qb->d_qf32, qb->d_qvec, qb->d_qhdr, ctx->stream));
     } else {
         uint32_t row;
         AH_TRY(host_row_of_id(ds, *query_item, &row));
@@ -1329,13 +1330,18 @@ static int rerank_impl(ah_dataset *ds, const float *query, const uint32_t *query
     Carver dev(nullptr), pin(nullptr);
     const size_t extra_dev = pad256(n * 4) * 2 + pad256(kk * 4) * 2 + pad256(topk_scratch_bytes(n, kk));
     const size_t extra_pin = pad256(n * 4) + pad256(kk * 4) * 2 + 256;
-    AH_TRY(stage_query(ds, ctx, query, query_item, extra_dev, extra_pin, &qb, &dev, &pin));
+    // One short list (arroy's own call: search_k = 10 000-odd candidates of one query, src/reader.rs:381-399) is latency, not
+    // bandwidth: the kernels read the query and the ids from the pinned staging buffers themselves, one block selects and writes
+    // the results and the status word into pinned memory (k_topk_small) — four queue entries instead of twelve.
+    const bool small = topk_small_fits(n, kk) && tun(TUN_RERANK_SMALL) != 0;
+    AH_TRY(stage_query(ds, ctx, query, query_item, extra_dev, extra_pin, &qb, &dev, &pin, small && !metric_is_bq(ds->metric)));
     uint32_t *d_ids = nullptr;
     if (sorted_ids) {
         d_ids = dev.take<uint32_t>(n);
         uint32_t *h_ids = pin.take<uint32_t>(n);
         memcpy(h_ids, sorted_ids, n * 4);
-        AH_HIP(hipMemcpyAsync(d_ids, h_ids, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (small) d_ids = h_ids;
+        else AH_HIP(hipMemcpyAsync(d_ids, h_ids, n * 4, hipMemcpyHostToDevice, ctx->stream));
     }
     float *d_dist = dev.take<float>(n);
     uint32_t *d_oi = dev.take<uint32_t>(kk);
@@ -1346,6 +1352,19 @@ static int rerank_impl(ah_dataset *ds, const float *query, const uint32_t *query
     uint32_t *h_err = pin.take<uint32_t>(1);
     DataView dv = ds->view();
     AH_TRY(launch_distances(dv, qb.d_qvec, qb.d_qhdr, d_ids, n, d_dist, qb.d_err, ctx->stream));
+    if (small) {
+        *h_err = 0xFFFFFFFFu;  // (overwritten by the kernel: a launch that never ran reads as "take the general path")
+        AH_TRY(launch_topk_small(dv, d_dist, d_ids, n, kk, h_oi, h_od, qb.d_err, h_err, ctx->stream));
+        AH_HIP(hipStreamSynchronize(ctx->stream));
+        if (*h_err != 0xFFFFFFFFu && (*h_err & (4u | 8u)) == 0) {
+            AH_TRY(check_err_flags(*h_err, true));
+            memcpy(out_ids, h_oi, kk * 4);
+            memcpy(out_distances, h_od, kk * 4);
+            *out_n = kk;
+            return AH_OK;
+        }
+        // a non-finite distance, or too many equal keys around the k-th: the general selection on the distances already there
+    }
     AH_TRY(launch_topk(dv, d_dist, d_ids, n, kk, d_tk, d_oi, d_od, ctx->stream));
     AH_HIP(hipMemcpyAsync(h_oi, d_oi, kk * 4, hipMemcpyDeviceToHost, ctx->stream));
     AH_HIP(hipMemcpyAsync(h_od, d_od, kk * 4, hipMemcpyDeviceToHost, ctx->stream));

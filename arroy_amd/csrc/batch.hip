@@ -761,7 +761,8 @@ bool batch_supported(uint32_t k) { return k <= kChunk / 2; }
 int launch_prepare_queries_only(const DataView &dv, const float *d_q_f32, uint32_t n_queries, uint8_t *d_qvecs,
                                 uint64_t qstride, float *d_qhdrs, hipStream_t s) {
     if (n_queries)
-        hipLaunchKernelGGL(k_prepare_queries, dim3(n_queries), dim3(64), 0, s, dv, d_q_f32, d_qvecs, qstride, d_qhdrs);
+        hipLaunchKernelGGL(k_prepare_queries, dim3(n_queries), dim3(metric_is_bq_dev(dv.metric) ? 64 : 512), 0, s, dv, d_q_f32, d_qvecs, qstride,
+                           d_qhdrs);  // (d_q_f32 may be pinned host memory: few dependent reads per thread)
     AH_HIP(hipGetLastError());
     return AH_OK;
 }

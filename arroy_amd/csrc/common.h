@@ -136,6 +136,7 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(SCAN_BLOCKS, "AH_SCAN_BLOCKS", 0)         /* grid cap of the distance scan (0 = built-in) */                        \
     X(MANHATTAN_ROWS, "AH_MANHATTAN_ROWS", 1)                                                                            \
     X(RERANK_INVERT, "AH_RERANK_INVERT", -1)    /* 0 / 1: never / always the row-major re-rank of big submissions */      \
+    X(RERANK_SMALL, "AH_RERANK_SMALL", 1)       /* 0: ah_rerank_by_vector / _by_item never take the one-launch selection of short lists (k_topk_small) */ \
     X(PAIR_GROUP, "AH_PAIR_GROUP", 0)                                                                                    \
     X(PAIR_RUNS, "AH_PAIR_RUNS", 1)                                                                                      \
     X(SEARCH_BITMAP, "AH_SEARCH_BITMAP", 1)     /* 0: sort + dedup of the candidates always by the bitonic network */     \
@@ -387,6 +388,10 @@ int launch_distances(const DataView &dv, const void *d_qvec, const float *d_qhdr
 size_t topk_scratch_bytes(uint64_t n, size_t k);
 int launch_topk(const DataView &dv, const float *d_dist, const uint32_t *d_ids, uint64_t n, size_t k, void *d_scratch,
                 uint32_t *d_out_ids, float *d_out_dist, hipStream_t s);
+// one launch for one short list (n <= 16 384, k <= 1024): results and the status word straight into pinned host memory
+bool topk_small_fits(uint64_t n, size_t k);
+int launch_topk_small(const DataView &dv, const float *d_dist, const uint32_t *ids, uint64_t n, size_t k, uint32_t *out_ids,
+                      float *out_dist, uint32_t *d_err, uint32_t *host_err, hipStream_t s);
 int launch_headers_from_vectors(const DataView &dv, uint64_t first_row, uint64_t n, hipStream_t s);
 int launch_quantize_rows(const float *d_src, uint32_t src_pitch, uint32_t dims, uint64_t *d_dst, uint32_t dst_pitch,
                          uint32_t words, uint64_t n, hipStream_t s);

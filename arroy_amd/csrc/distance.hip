@@ -449,7 +449,9 @@ int launch_distances(const DataView &dv, const void *d_qvec, const float *d_qhdr
 }
 
 int launch_prepare_query(const DataView &dv, const float *d_query_f32, void *d_qvec, float *d_qhdr, hipStream_t s) {
-    hipLaunchKernelGGL(k_prepare_query, dim3(1), dim3(64), 0, s, dv, d_query_f32, d_qvec, d_qhdr);
+    // (a thread per element of the usual query: d_query_f32 may be the caller's pinned buffer, and a read over the link that
+    // waits for the one before it is 1.5 us)
+    hipLaunchKernelGGL(k_prepare_query, dim3(1), dim3(metric_is_bq_dev(dv.metric) ? 64 : 1024), 0, s, dv, d_query_f32, d_qvec, d_qhdr);
     AH_HIP(hipGetLastError());
     return AH_OK;
 }
@@ -560,6 +562,147 @@ __global__ void k_topk_emit(DataView dv, const uint64_t *__restrict__ keys, cons
     uint32_t id = ids ? ids[pos] : (dv.identity_ids ? pos : dv.ids[pos]);
     out_ids[t] = id;
     out_dist[t] = normalized_distance(dv.metric, dist[pos], dv.dims);
+}
+
+// The same selection for ONE short list in ONE launch (arroy re-ranks one query per call, src/reader.rs:381-399, and its
+// candidate list is search_k = 10 000-odd ids): n <= kSmallTopkMax distances, k <= kSmallTopkCap.  A block holds every
+// (distance, id) in registers (thread t owns the positions t + 1024 r), finds the histogram bin of the k-th smallest key, ranks
+// the <= kSmallTopkCap keys up to that bin by counting (keys are unique: the position is their low word) and writes ids,
+// normalized distances and the call's status word straight into the caller's PINNED buffers — the two tournament rounds,
+// the emit kernel and three copies back of the general path were 170 of a call's 220 us.
+// *err bit 2: a non-finite distance (src/reader.rs:611-621 looks at positions); bit 3: more than kSmallTopkCap keys up to
+// the k-th's bin.  Either way nothing is written and the caller takes the general path.
+static constexpr uint32_t kSmallTopkMax = 16384, kSmallTopkCap = 1024, kSmallTopkBins = 2048;
+__global__ __launch_bounds__(1024) void k_topk_small(DataView dv, const float *__restrict__ dist, const uint32_t *__restrict__ ids,
+                                                     uint32_t n, uint32_t k, uint32_t *__restrict__ out_ids,
+                                                     float *__restrict__ out_dist, uint32_t *err, uint32_t *__restrict__ host_err) {
+    constexpr uint32_t kThreads = 1024, kOwn = kSmallTopkMax / kThreads;
+    __shared__ uint32_t s_hist[kSmallTopkBins];
+    __shared__ uint64_t s_key[kSmallTopkCap];
+    __shared__ uint32_t s_id[kSmallTopkCap];
+    __shared__ float s_val[kSmallTopkCap];
+    __shared__ uint32_t s_min, s_max, s_wave[kThreads / 64], s_bin, s_count, s_n;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t b = tid; b < kSmallTopkBins; b += kThreads) s_hist[b] = 0;
+    if (tid == 0) {
+        s_min = 0xFFFFFFFFu;
+        s_max = 0u;
+        s_n = 0u;
+    }
+    float own_d[kOwn];
+    uint32_t own_id[kOwn];
+#pragma unroll
+    for (uint32_t r = 0; r < kOwn; r++) {
+        const uint32_t g = tid + r * kThreads;
+        own_d[r] = g < n ? dist[g] : 0.0f;
+        own_id[r] = g < n ? (ids ? ids[g] : (dv.identity_ids ? g : dv.ids[g])) : 0u;
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (all the loads in flight before the first use)
+    __syncthreads();
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+    for (uint32_t r = 0; r < kOwn; r++)
+        if (tid + r * kThreads < n) {
+            const uint32_t w = orderable_key(own_d[r]);
+            lo = min(lo, w);
+            hi = max(hi, w);
+        }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, off));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, off));
+    }
+    if ((tid & 63u) == 0) {
+        atomicMin(&s_min, lo);
+        atomicMax(&s_max, hi);
+    }
+    __syncthreads();
+    const uint32_t w_min = s_min;
+    uint32_t fail = s_max > 0xFF7FFFFFu ? 4u : 0u;  // +inf / NaN somewhere
+    uint32_t n_sel = 0;
+    if (!fail) {
+        const uint64_t span = (uint64_t)(s_max - w_min) + 1ull;
+        const bool direct = span <= kSmallTopkBins;
+        const uint32_t scale = direct ? 0u : (uint32_t)(((uint64_t)kSmallTopkBins << 32) / span);
+        auto bin_of = [&](uint32_t w) -> uint32_t { return direct ? w - w_min : (uint32_t)(((uint64_t)(w - w_min) * scale) >> 32); };
+#pragma unroll
+        for (uint32_t r = 0; r < kOwn; r++)
+            if (tid + r * kThreads < n) atomicAdd(&s_hist[bin_of(orderable_key(own_d[r]))], 1u);
+        __syncthreads();
+        {  // the bin of the k-th smallest key: thread t owns kPer consecutive bins
+            constexpr uint32_t kPer = kSmallTopkBins / kThreads;
+            uint32_t c[kPer], mine = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < kPer; u++) {
+                c[u] = s_hist[tid * kPer + u];
+                mine += c[u];
+            }
+            uint32_t incl = mine;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off);
+                if ((int)(tid & 63u) >= off) incl += up;
+            }
+            if ((tid & 63u) == 63u) s_wave[tid >> 6] = incl;
+            __syncthreads();
+            uint32_t before = incl - mine;
+            for (uint32_t w = 0; w < (tid >> 6); w++) before += s_wave[w];
+#pragma unroll
+            for (uint32_t u = 0; u < kPer; u++) {
+                if (before < k && before + c[u] >= k) {  // exactly one bin qualifies (k <= n)
+                    s_bin = tid * kPer + u;
+                    s_count = before + c[u];
+                }
+                before += c[u];
+            }
+        }
+        __syncthreads();
+        n_sel = s_count;
+        const uint32_t bin_k = s_bin;
+        if (n_sel > kSmallTopkCap) {
+            fail = 8u;
+        } else {
+#pragma unroll
+            for (uint32_t r = 0; r < kOwn; r++) {
+                const uint32_t g = tid + r * kThreads;
+                if (g >= n) continue;
+                const uint32_t w = orderable_key(own_d[r]);
+                if (bin_of(w) <= bin_k) {
+                    const uint32_t at = atomicAdd(&s_n, 1u);
+                    s_key[at] = ((uint64_t)w << 32) | g;  // (distance, position): the ids are ascending, so this is (distance, id)
+                    s_id[at] = own_id[r];
+                    s_val[at] = own_d[r];
+                }
+            }
+            __syncthreads();
+            for (uint32_t e = tid; e < n_sel; e += kThreads) {
+                const uint64_t mine = s_key[e];
+                uint32_t rank = 0, i = 0;
+                for (; i + 8 <= n_sel; i += 8) {
+                    uint64_t other[8];
+#pragma unroll
+                    for (uint32_t u = 0; u < 8; u++) other[u] = s_key[i + u];
+#pragma unroll
+                    for (uint32_t u = 0; u < 8; u++) rank += other[u] < mine ? 1u : 0u;
+                }
+                for (; i < n_sel; i++) rank += s_key[i] < mine ? 1u : 0u;
+                if (rank < k) {
+                    out_ids[rank] = s_id[e];
+                    out_dist[rank] = normalized_distance(dv.metric, s_val[e], dv.dims);
+                }
+            }
+        }
+    }
+    if (tid == 0) {  // the status word: what the kernels before this one raised, and this one's verdict
+        const uint32_t before = fail ? atomicOr(err, fail) : __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (host_err) *host_err = before | fail;
+    }
+}
+// n and k within the kernel's limits?
+bool topk_small_fits(uint64_t n, size_t k) { return n <= kSmallTopkMax && k <= kSmallTopkCap && k <= n; }
+int launch_topk_small(const DataView &dv, const float *d_dist, const uint32_t *ids, uint64_t n, size_t k, uint32_t *out_ids,
+                      float *out_dist, uint32_t *d_err, uint32_t *host_err, hipStream_t s) {
+    hipLaunchKernelGGL(k_topk_small, dim3(1), dim3(1024), 0, s, dv, d_dist, ids, (uint32_t)n, (uint32_t)k, out_ids, out_dist, d_err, host_err);
+    AH_HIP(hipGetLastError());
+    return AH_OK;
 }
 
 static uint64_t next_pow2(uint64_t x) {

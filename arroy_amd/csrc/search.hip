@@ -2051,7 +2051,15 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
     for (uint32_t e = tid; e < n_sel; e += kThreads) {
         const uint64_t mine = s_key[e];
         uint32_t rank = 0;
-        for (uint32_t i = 0; i < n_sel; i++) {  // (a caller's list may repeat an id: equal keys keep their order)
+        uint32_t i = 0;
+        for (; i + 8 <= n_sel; i += 8) {  // (eight broadcast reads in flight: the loop is LDS latency, not work)
+            uint64_t other[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) other[u] = s_key[i + u];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) rank += (other[u] < mine || (other[u] == mine && i + u < e)) ? 1u : 0u;
+        }
+        for (; i < n_sel; i++) {  // (a caller's list may repeat an id: equal keys keep their order)
             const uint64_t other = s_key[i];
             rank += (other < mine || (other == mine && i < e)) ? 1u : 0u;
         }
