@@ -1,0 +1,165 @@
+"""The SMALL submissions (arroy's API is one query per call: `QueryBuilder::by_vector` -> `nns_by_leaf`, src/reader.rs:46-75,
+317-401) take their own device path since round 5 — a block of 32 octets descends (and prepares the query leaf from the caller's
+pinned buffer), one block places the leaf visits and makes the binary16 copies, the leaf tiles keep whole rows in flight, the
+selection flags duplicates itself and writes results and status straight into pinned memory; `ah_rerank_by_vector` of a short list
+selects with one launch (k_topk_small).  Every one of those has a switch: the answers with any of them off, all of them off, and
+the oracle's must be the same bits; and what the small kernels cannot hold must fall back, not truncate."""
+import numpy as np
+import pytest
+
+from arroy_amd import _lib
+from arroy_amd import distances as D
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SMALL_KNOBS = ["AH_SEARCH_BLOCK_MAX_QUERIES", "AH_SEARCH_SMALL_UNITS_MAX_QUERIES", "AH_SEARCH_SMALL_TILES_MAX_QUERIES",
+               "AH_SEARCH_FUSED_FLAG", "AH_SEARCH_FUSED_PREPARE"]
+
+
+def same(a, b):
+    return np.array_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes() and np.array_equal(a[2], b[2])
+
+
+@pytest.fixture(scope="module", params=[(D.DotProduct, O.DOT_PRODUCT), (D.Cosine, O.COSINE), (D.Euclidean, O.EUCLIDEAN)],
+                ids=["dot", "cosine", "euclidean"])
+def world(request):
+    from arroy_amd import Dataset, shard
+    metric, ometric = request.param
+    n, dims, trees = 60_000, 200, 12
+    vecs = O.synth(7, 2, n, dims)
+    ds = Dataset(metric, dims, n)
+    ds.upload_vectors(np.arange(n, dtype=np.uint32), vecs)
+    od = O.Data(ometric, vecs)
+    if metric is D.DotProduct:
+        ds.preprocess_dot()
+        od.preprocess_dot()
+    ds.finalize()
+    forest = ds.build_forest(shard.tree_seeds(7, range(trees)))
+    index = ds.create_index(forest)
+    rng = np.random.default_rng(3)
+    queries = (vecs[rng.choice(n, 80, replace=False)] + rng.standard_normal((80, dims)).astype(np.float32) * np.float32(0.1)).astype(np.float32)
+    yield ds, od, forest, index, queries, vecs
+    index.close()
+    forest.close()
+    ds.close()
+
+
+def oracle_search(od, forest, q, count, sk, cand=None):
+    qv, qh = od.query_leaf(q)
+    want, _ = O.search(od, forest, qv, qh, count, sk, 0, cand, candidates_sorted=True, want_candidates=False)
+    return want
+
+
+def test_small_submissions_equal_the_oracle_and_every_switch_setting(world):
+    _ds, od, forest, index, queries, _vecs = world
+    count, sk = 25, 1500
+    for nq in (1, 2, 7, 8, 9, 33, 64):
+        qs = queries[:nq]
+        index.stats(reset=True)
+        base = index.search(count, queries=qs, search_k=sk, raw=True)
+        st = index.stats()
+        assert st["descent_block"] == nq and st["rerank_tiles"] == nq and st["fallback_chunks"] == 0, (nq, st)
+        for qi in range(nq):
+            want = oracle_search(od, forest, qs[qi], count, sk)
+            assert int(base[2][qi]) == len(want) and list(base[0][qi, :len(want)]) == [i for i, _ in want], (nq, qi)
+            assert base[1][qi, :len(want)].tobytes() == np.array([d for _, d in want], dtype=np.float32).tobytes(), (nq, qi)
+        for knob in SMALL_KNOBS:  # one off at a time
+            with _lib.tuning(**{knob: 0}):
+                assert same(index.search(count, queries=qs, search_k=sk, raw=True), base), (nq, knob)
+        with _lib.tuning(**{k: 0 for k in SMALL_KNOBS}):  # the big submissions' path on the same queries
+            assert same(index.search(count, queries=qs, search_k=sk, raw=True), base), nq
+        # the same queries one per call
+        for qi in (0, nq - 1):
+            one = index.search(count, queries=qs[qi:qi + 1], search_k=sk, raw=True)
+            assert np.array_equal(one[0][0], base[0][qi]) and one[1][0].tobytes() == base[1][qi].tobytes()
+
+
+def test_small_submissions_by_item_and_under_a_filter(world):
+    _ds, od, forest, index, queries, vecs = world
+    n = vecs.shape[0]
+    count, sk = 10, 800
+    items = np.array([3, 59_999, 1234, 777, 31_000], dtype=np.uint32)
+    got = index.search(count, items=items, search_k=sk, raw=True)
+    with _lib.tuning(**{k: 0 for k in SMALL_KNOBS}):
+        assert same(index.search(count, items=items, search_k=sk, raw=True), got)
+    for share in (0.5, 0.05):
+        cand = np.arange(0, n, int(1 / share), dtype=np.uint32)
+        got = index.search(count, queries=queries[:5], search_k=sk, candidates=cand, candidates_sorted=True, raw=True)
+        for qi in range(5):
+            want = oracle_search(od, forest, queries[qi], count, sk, cand)
+            assert list(got[0][qi, :got[2][qi]]) == [i for i, _ in want], (share, qi)
+        with _lib.tuning(**{k: 0 for k in SMALL_KNOBS}):
+            assert same(index.search(count, queries=queries[:5], search_k=sk, candidates=cand, candidates_sorted=True, raw=True), got)
+
+
+def test_more_visits_than_the_one_block_unit_builder_holds_fall_back(world):
+    """k_units_small sorts at most 2048 leaf visits: 64 queries with a search_k that makes each of them pop more than 32 leaves
+    overflow it — bit 5 of the status word, the submission is redone on the sorted path, the answers are the oracle's."""
+    _ds, od, forest, index, queries, vecs = world
+    n = vecs.shape[0]
+    count, sk = 10, n // 3
+    index.stats(reset=True)
+    got = index.search(count, queries=queries[:64], search_k=sk, raw=True)
+    st = index.stats()
+    assert st["fallback_chunks"] >= 1 or st["tile_visits"] <= 2048, st
+    for qi in (0, 17, 63):
+        want = oracle_search(od, forest, queries[qi], count, sk)
+        assert list(got[0][qi, :got[2][qi]]) == [i for i, _ in want], qi
+        assert got[1][qi, :len(want)].tobytes() == np.array([d for _, d in want], dtype=np.float32).tobytes(), qi
+
+
+def test_rerank_of_one_short_list_one_launch_equals_the_general_path_and_the_oracle(world):
+    ds, od, _forest, _index, queries, vecs = world
+    n = vecs.shape[0]
+    rng = np.random.default_rng(11)
+    for n_ids, k in ((1, 1), (5, 10), (1000, 100), (10_000, 100), (16_384, 1024), (16_385, 10), (12_000, 1025)):
+        ids = np.sort(rng.choice(n, n_ids, replace=False)).astype(np.uint32)
+        for q in (queries[0], vecs[int(ids[0])]):
+            got = ds.rerank(k, query=q, sorted_ids=ids)
+            want = od.rerank(*od.query_leaf(q), ids, k)
+            assert got[0].tolist() == want[0].tolist() and got[1].tobytes() == want[1].tobytes(), (n_ids, k)
+            with _lib.tuning(AH_RERANK_SMALL=0):
+                gen = ds.rerank(k, query=q, sorted_ids=ids)
+            assert gen[0].tolist() == got[0].tolist() and gen[1].tobytes() == got[1].tobytes(), (n_ids, k)
+    # by item, and "all items" of a small dataset
+    got = ds.rerank(7, item=4242, sorted_ids=np.arange(0, n, 9, dtype=np.uint32))
+    want = od.rerank(*od.item_leaf(4242), np.arange(0, n, 9, dtype=np.uint32), 7) if hasattr(od, "item_leaf") else None
+    if want is not None:
+        assert got[0].tolist() == want[0].tolist() and got[1].tobytes() == want[1].tobytes()
+    # unsorted / repeated ids are still refused
+    with pytest.raises(_lib.ArroyHipError):
+        ds.rerank(3, query=queries[0], sorted_ids=np.array([5, 4, 9], dtype=np.uint32))
+    with pytest.raises(_lib.ArroyHipError):
+        ds.rerank(3, query=queries[0], sorted_ids=np.array([5, 5, 9], dtype=np.uint32))
+    with pytest.raises(_lib.ArroyHipError):  # an id that is not stored
+        ds.rerank(3, query=queries[0], sorted_ids=np.array([5, n + 10], dtype=np.uint32))
+
+
+def test_rerank_one_launch_falls_back_on_ties_beyond_its_capacity_and_on_non_finite_distances():
+    """2000 copies of one vector: all distances equal, the k-th key's bin holds more than 1024 keys — k_topk_small raises bit 3
+    and the general selection answers.  A query with an inf component: non-finite distances, bit 2, the reference's rule on
+    positions (src/reader.rs:611-621) is the general path's business."""
+    from arroy_amd import Dataset
+    n, dims = 3000, 64
+    vecs = O.synth(5, 1, n, dims)
+    vecs[:2000] = vecs[0]
+    for metric, ometric in ((D.Euclidean, O.EUCLIDEAN), (D.DotProduct, O.DOT_PRODUCT)):
+        ds = Dataset(metric, dims, n)
+        ds.upload_vectors(np.arange(n, dtype=np.uint32), vecs)
+        ds.finalize()
+        od = O.Data(ometric, vecs)
+        ids = np.arange(n, dtype=np.uint32)
+        for k in (10, 1500):
+            got = ds.rerank(k, query=vecs[1], sorted_ids=ids)
+            want = od.rerank(*od.query_leaf(vecs[1]), ids, k)
+            assert got[0].tolist() == want[0].tolist() and got[1].tobytes() == want[1].tobytes(), k
+        bad = vecs[5].copy()
+        bad[3] = np.inf
+        got = ds.rerank(20, query=bad, sorted_ids=ids)
+        with _lib.tuning(AH_RERANK_SMALL=0):
+            gen = ds.rerank(20, query=bad, sorted_ids=ids)
+        assert got[0].tolist() == gen[0].tolist() and got[1].tobytes() == gen[1].tobytes()
+        want = od.rerank(*od.query_leaf(bad), ids, 20)
+        assert got[0].tolist() == want[0].tolist()
+        ds.close()
