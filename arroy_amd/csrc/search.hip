@@ -1565,6 +1565,9 @@ __device__ __forceinline__ void leaf_tile_ring(const DataView &dv, const uint32_
 // blockIdx.x walks the units (persistent), blockIdx.y is the slab of rows of the unit's leaf: 128 rows when the unit has
 // more than 8 visits (4 rounds of 32 rows x 16 queries), 256 rows otherwise.
 static constexpr uint32_t kTileSlab = 128;
+#ifndef AH_TILES16_KF
+#define AH_TILES16_KF 1  // k-steps of a leaf tile requested together in the big submissions' variants (A/B: see DESIGN.md)
+#endif
 static constexpr uint32_t kTileSmallSlab = 64;  // rows per block of k_leaf_tiles16 in a small submission (32 octets x 2 rows)
 template <int METRIC>
 __global__ __launch_bounds__(256) void k_leaf_tiles(DataView dv, const uint32_t *__restrict__ nns,
@@ -1733,7 +1736,7 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
         if (row_begin >= n_leaf) continue;
         const uint32_t row_end = min(n_leaf, row_begin + slab);
         const uint32_t *leaf_ids = nns + (uint64_t)vis[0].q * stride + vis[0].pos;
-#define AH_TILE16(R, Q, QO) leaf_tile16<R, Q, QO>(ss, dv, leaf_ids, row_begin, row_end, vis, n_vis, dist, stride, err)
+#define AH_TILE16(R, Q, QO) leaf_tile16<R, Q, QO, AH_TILES16_KF>(ss, dv, leaf_ids, row_begin, row_end, vis, n_vis, dist, stride, err)
         if constexpr (SMALL) {
             if (fly && n_vis == 1) {
                 leaf_tile16<2, 1, 1, 24>(ss, dv, leaf_ids, row_begin, row_end, vis, n_vis, dist, stride, err);
