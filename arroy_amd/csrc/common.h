@@ -146,6 +146,7 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(SEARCH_SMALL_UNITS_MAX_QUERIES, "AH_SEARCH_SMALL_UNITS_MAX_QUERIES", 64) /* up to this many queries a call: one block places the leaf visits (k_units_small) */ \
     X(SEARCH_FUSED_FLAG, "AH_SEARCH_FUSED_FLAG", 1) /* 0: a small submission flags its duplicate candidates with k_flag_duplicates, not inside the selection */ \
     X(SEARCH_FUSED_PREPARE, "AH_SEARCH_FUSED_PREPARE", 1) /* 0: a small submission prepares its query leaves with k_prepare_queries, not inside the block descent */ \
+    X(SEARCH_SINGLE_FUSED, "AH_SEARCH_SINGLE_FUSED", 1) /* 0: a one-query submission places its leaf visits with k_units_small like the other small ones */ \
     X(SEARCH_SMALL_TILES_MAX_QUERIES, "AH_SEARCH_SMALL_TILES_MAX_QUERIES", 8) /* up to this many queries a call: leaf tiles in slabs of 64 rows, whole rows in flight */ \
     X(RERANK_GROUPS, "AH_RERANK_GROUPS", 2)     /* groups a screened ah_rerank_batch submission is cut into (upload of group g + 1 under the kernel of g) */ \
     X(RERANK_SCREEN, "AH_RERANK_SCREEN", 1)     /* 0: ah_rerank_batch never screens its candidates (f32 rows for all) */ \

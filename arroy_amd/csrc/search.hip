@@ -495,6 +495,68 @@ __global__ __launch_bounds__(64) void k_descend_wave(DataView nv, SearchParams s
     }
 }
 
+// A work unit of the leaf-tile re-rank: <= kUnitVisits visits of one node (k_leaf_scan_* / k_units_small / the block descent of
+// a single query write them, k_leaf_tiles* read them).
+static constexpr uint32_t kUnitVisits = 16;
+struct TileUnit {
+    uint32_t node, first, n_vis, pad;  // sorted[first .. first + n_vis)
+};
+
+// Blocks 1 .. n_h16 of the launch are the queries' binary16 copies (k_queries_h16's work, wanted by the same consumer — the
+// leaf tiles — and as independent of the descent): one launch less on a path that is mostly launches.
+struct QueriesH16 {
+    const uint8_t *qvecs;
+    uint64_t qstride;
+    uint32_t dims, hpitch;
+    uint16_t *q16;
+    float4 *qstats;
+};
+// (one wave per query; `lane` = the thread's index in it)
+__device__ __forceinline__ void query_h16(uint32_t q, uint32_t lane, const uint8_t *__restrict__ qvecs, uint64_t qstride, uint32_t dims,
+                                          uint32_t hpitch, uint16_t *__restrict__ q16, float4 *__restrict__ qstats) {
+    const float *v = reinterpret_cast<const float *>(qvecs + (uint64_t)q * qstride);
+    uint16_t *out = q16 + (uint64_t)q * hpitch;
+    float sa = 0.f, sb = 0.f, sc = 0.f;
+    uint32_t xbits = 0u;
+    for (uint32_t i = lane; i < hpitch; i += 64) {
+        const float x = i < dims ? v[i] : 0.0f;
+        const _Float16 h = to_shadow_half(x);
+        const float y = (float)h, d = x - y;
+        sa += y * y;
+        sb += d * d;
+        sc += x * x;
+        xbits = max(xbits, __float_as_uint(x) & 0x7FFFFFFFu);
+        out[i] = __builtin_bit_cast(uint16_t, h);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sa += __shfl_xor(sa, off);
+        sb += __shfl_xor(sb, off);
+        sc += __shfl_xor(sc, off);
+        xbits = max(xbits, (uint32_t)__shfl_xor((int)xbits, off));
+    }
+    if (lane == 0) {
+        const float up = 1.0f + (float)(hpitch + 64u) * 1.2e-7f;
+        const bool tiny = xbits != 0u && xbits < kTinyBits;  // squares underflow: the measured norms would lie
+        const float inf = __uint_as_float(0x7F800000u);
+        qstats[q] = tiny ? make_float4(inf, inf, inf, 0.f) : make_float4(sqrtf(sa) * up, sqrtf(sb) * up, sqrtf(sc) * up, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_queries_h16(const uint8_t *__restrict__ qvecs, uint64_t qstride, uint32_t dims,
+                                                    uint32_t hpitch, uint16_t *__restrict__ q16, float4 *__restrict__ qstats) {
+    query_h16(blockIdx.x, threadIdx.x, qvecs, qstride, dims, hpitch, q16, qstats);
+}
+
+
+// A submission of ONE query on the leaf-tile path: its visits are nobody else's, so every taken leaf is a unit of one visit and
+// the block descent writes units and the (trivially sorted) visit list itself — and makes the query's binary16 copy while it
+// is at it: the call loses the launch that would sort a dozen visits.  units == nullptr: off.
+struct SingleQueryOut {
+    TileUnit *units;
+    Visit *sorted;
+    uint32_t *n_units;
+    QueriesH16 h16;  // q16 == nullptr: no binary16 copy wanted
+};
 // ---- one BLOCK per query: the small submissions ------------------------------------------------------------------
 // arroy's API takes one query per call (src/reader.rs:46-75) and the wave descent's time does not depend on how many queries a
 // call brings: ~66 dependent pops of 4.5 us each = 0.3 ms for ONE query, two thirds of the whole call (round-5 kernel trace of
@@ -513,7 +575,7 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
                                                             const float *__restrict__ qhdrs, uint32_t *__restrict__ nns,
                                                             uint32_t *__restrict__ nns_count, uint32_t *__restrict__ overflow,
                                                             VisitSink sink, bool last_pass, const float *__restrict__ raw_queries,
-                                                            float *__restrict__ qhdrs_out) {
+                                                            float *__restrict__ qhdrs_out, SingleQueryOut single) {
     constexpr uint32_t kThreads = 8 * kOct, kWaves = kThreads / 64, kCap = kOct * kLeaves;
     static_assert((kThreads & (kThreads - 1)) == 0 && kCap >= kThreads, "power-of-two block, sort network at least as wide");
     extern __shared__ uint64_t s_blk_lds[];
@@ -588,6 +650,8 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
         qh = LeafHdr{qhdrs[2 * (uint64_t)q], qhdrs[2 * (uint64_t)q + 1]};
     }
     const void *qvec = s_q4;
+    if (single.units && single.h16.q16 && tid < 64)  // (the leaf in global memory was written before the barriers above, or by an earlier kernel)
+        query_h16(q, tid, single.h16.qvecs, single.h16.qstride, single.h16.dims, single.h16.hpitch, single.h16.q16, single.h16.qstats);
     uint32_t *my_nns = nns + (uint64_t)q * sp.nns_stride;
     // The octet's queue is an UNSORTED array in LDS, popped by an arg-max over the octet's eight lanes: the keys are unique (the
     // node is their low word), so the pops come in the order a binary heap would give them, and a queue of the ~10 - 30 entries
@@ -844,7 +908,12 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
             if (e < taken) {
                 const uint32_t w = (uint32_t)s_sorted[e];
                 my_first[r] = s_leaf_a[w >> 16][0xFFFFu - (w & 0xFFFFu)];
-                record_visit(sink, s_sorted_node[e], q, s_pos[e], s_sorted_n[e]);
+                if (single.units) {
+                    single.units[e] = TileUnit{s_sorted_node[e], e, 1u, 0u};
+                    single.sorted[e] = Visit{s_sorted_node[e], q, s_pos[e], s_sorted_n[e]};
+                } else {
+                    record_visit(sink, s_sorted_node[e], q, s_pos[e], s_sorted_n[e]);
+                }
             }
         }
         __syncthreads();
@@ -888,13 +957,28 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
             const uint32_t node = s_sorted_node[e], pos = s_pos[e];
             const DNode nd = sp.nodes[node];
             copy_filtered(sp, sp.desc + nd.a, nd.b, my_nns + pos, j);
-            if (j == 0) record_visit(sink, node, q, pos, s_sorted_n[e]);
+            if (j == 0) {
+                if (single.units) {
+                    single.units[e] = TileUnit{node, e, 1u, 0u};
+                    single.sorted[e] = Visit{node, q, pos, s_sorted_n[e]};
+                } else {
+                    record_visit(sink, node, q, pos, s_sorted_n[e]);
+                }
+            }
         }
     }
     if (tid == 0) {
         nns_count[q] = ids_taken;
         overflow[q] = 0;
         if (sp.stats) atomicAdd(&sp.stats[SS_BLOCK], 1u);
+        if (single.units) {
+            *single.n_units = taken;
+            if (sink.total) *sink.total = taken;
+            if (sp.stats && taken) {
+                atomicAdd(&sp.stats[SS_VISITS], taken);
+                atomicAdd(&sp.stats[SS_UNITS_4], taken);
+            }
+        }
     }
 }
 
@@ -1031,10 +1115,6 @@ __global__ __launch_bounds__(1024) void k_dedup_bitmap_lds(uint32_t *__restrict_
 // visits in the sorted list, `ustart` = first work unit of the node (a unit = <= 16 visits of one node).  The last
 // launch also writes the units.
 static constexpr uint32_t kLeafScanItems = 2048;  // 256 threads x 8
-static constexpr uint32_t kUnitVisits = 16;
-struct TileUnit {
-    uint32_t node, first, n_vis, pad;  // sorted[first .. first + n_vis)
-};
 __device__ __forceinline__ uint2 block_exclusive_scan2(uint2 local, uint2 *s_wave, uint2 &block_total) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint2 incl = local;
@@ -1144,56 +1224,11 @@ __global__ __launch_bounds__(256) void k_visit_scatter(const Visit *__restrict__
     }
 }
 
-// (one wave per query; `lane` = the thread's index in it)
-__device__ __forceinline__ void query_h16(uint32_t q, uint32_t lane, const uint8_t *__restrict__ qvecs, uint64_t qstride, uint32_t dims,
-                                          uint32_t hpitch, uint16_t *__restrict__ q16, float4 *__restrict__ qstats) {
-    const float *v = reinterpret_cast<const float *>(qvecs + (uint64_t)q * qstride);
-    uint16_t *out = q16 + (uint64_t)q * hpitch;
-    float sa = 0.f, sb = 0.f, sc = 0.f;
-    uint32_t xbits = 0u;
-    for (uint32_t i = lane; i < hpitch; i += 64) {
-        const float x = i < dims ? v[i] : 0.0f;
-        const _Float16 h = to_shadow_half(x);
-        const float y = (float)h, d = x - y;
-        sa += y * y;
-        sb += d * d;
-        sc += x * x;
-        xbits = max(xbits, __float_as_uint(x) & 0x7FFFFFFFu);
-        out[i] = __builtin_bit_cast(uint16_t, h);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        sa += __shfl_xor(sa, off);
-        sb += __shfl_xor(sb, off);
-        sc += __shfl_xor(sc, off);
-        xbits = max(xbits, (uint32_t)__shfl_xor((int)xbits, off));
-    }
-    if (lane == 0) {
-        const float up = 1.0f + (float)(hpitch + 64u) * 1.2e-7f;
-        const bool tiny = xbits != 0u && xbits < kTinyBits;  // squares underflow: the measured norms would lie
-        const float inf = __uint_as_float(0x7F800000u);
-        qstats[q] = tiny ? make_float4(inf, inf, inf, 0.f) : make_float4(sqrtf(sa) * up, sqrtf(sb) * up, sqrtf(sc) * up, 0.f);
-    }
-}
-
-__global__ __launch_bounds__(64) void k_queries_h16(const uint8_t *__restrict__ qvecs, uint64_t qstride, uint32_t dims,
-                                                    uint32_t hpitch, uint16_t *__restrict__ q16, float4 *__restrict__ qstats) {
-    query_h16(blockIdx.x, threadIdx.x, qvecs, qstride, dims, hpitch, q16, qstats);
-}
-
 // The same for a SMALL submission (arroy's own API is one query per call, src/reader.rs:46-75): the three scans above walk a
 // counter per node of the index (and a fourth launch zeroes them) to place what for one query is a dozen visits.  One block
 // sorts the visits by node in LDS instead — runs of one node are the node's visits, every 16 of a run a unit.  More than
 // kSmallVisits visits: bit 5 of *err, the submission takes the long way like any other overflow of the visit list.
 static constexpr uint32_t kSmallVisits = 2048;
-// Blocks 1 .. n_h16 of the launch are the queries' binary16 copies (k_queries_h16's work, wanted by the same consumer — the
-// leaf tiles — and as independent of the descent): one launch less on a path that is mostly launches.
-struct QueriesH16 {
-    const uint8_t *qvecs;
-    uint64_t qstride;
-    uint32_t dims, hpitch;
-    uint16_t *q16;
-    float4 *qstats;
-};
 __global__ __launch_bounds__(256) void k_units_small(const Visit *__restrict__ visits, const uint32_t *__restrict__ total,
                                                      uint32_t cap, Visit *__restrict__ sorted, TileUnit *__restrict__ units,
                                                      uint32_t *__restrict__ n_units, uint32_t *__restrict__ stats, QueriesH16 h16) {
@@ -2815,6 +2850,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     // a wave hold; under a filter the wave descent reads what the filter keeps of every leaf, computed once per submission)
     if (wave_descent && d_filter_bits) sp.leaf_kept = d_leaf_kept;
     bool passes_done = false;  // set by launch_wave: the block descent was the whole descent
+    bool units_done = false;   // ... and it wrote the leaf tiles' work units as well (one query)
     auto launch_wave = [&](const VisitSink &sink) -> int {
         // a query pops about 1 / (kept share) as many nodes under a filter: start with the big queues (one query per CU
         // at a time) only then; otherwise they take what the small ones (four per CU) could not hold
@@ -2838,9 +2874,19 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
             // of two octets across the cut) raises bit 4 of *err and the submission is redone the long way, instead of every
             // small call paying two more launches for passes that find nothing to do.
             const bool last_pass = sink.visits != nullptr;
+            // (one query: its units and its binary16 copy come out of the descent itself, see SingleQueryOut)
+            SingleQueryOut single{};
+            if (last_pass && nq == 1 && small_units && tun(TUN_SEARCH_SINGLE_FUSED) != 0) {
+                single.units = d_units;
+                single.sorted = d_sorted;
+                single.n_units = d_err + SS_N_UNITS;
+                if (screened)
+                    single.h16 = QueriesH16{d_qvecs, qstride, ds->dims, ds->hpitch, const_cast<uint16_t *>(ss.q16), const_cast<float4 *>(ss.qstats)};
+                units_done = true;
+            }
             hipLaunchKernelGGL((k_descend_block<32, 128, 32, 2>), dim3((unsigned)nq), dim3(256), block_lds, s, ix->nv, sp, (uint32_t)nq,
                                d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink, last_pass,
-                               (last_pass && fuse_prepare) ? (const float *)h_q : (const float *)nullptr, d_qhdrs);
+                               (last_pass && fuse_prepare) ? (const float *)h_q : (const float *)nullptr, d_qhdrs, single);
             if (last_pass) {
                 passes_done = true;
                 return AH_OK;
@@ -2872,7 +2918,9 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
             hipLaunchKernelGGL((k_descend<false>), dim3((unsigned)((nq + 7) / 8)), dim3(64), heap_lds, s, ix->nv, sp,
                                (const uint32_t *)nullptr, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow,
                                (uint64_t *)nullptr, 0u, sink, wave_descent);
-        if (small_units) {
+        if (units_done) {
+            // (nothing to place)
+        } else if (small_units) {
             const QueriesH16 h16{d_qvecs, qstride, ds->dims, ds->hpitch, const_cast<uint16_t *>(ss.q16), const_cast<float4 *>(ss.qstats)};
             hipLaunchKernelGGL(k_units_small, dim3(1u + (screened ? (unsigned)nq : 0u)), dim3(256), 0, s, d_visits, d_total, visit_cap,
                                d_sorted, d_units, d_n_units, d_err, h16);

@@ -50,8 +50,17 @@ rm -rf $OUT/kt_b
     nq=$1; calls=$2; shift 2
     env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_s -o kt -- python scripts/exp_latency.py $nq $calls > $OUT/lat.log 2>&1
     echo "## $nq queries per call, $* : $(grep "^nq=" $OUT/lat.log | tail -1)"
-    python scripts/kstats.py $OUT/kt_s/kt_kernel_stats.csv k_descend k_leaf k_search_select k_flag k_queries k_visit k_prepare
+    python scripts/kstats.py $OUT/kt_s/kt_kernel_stats.csv k_descend k_leaf k_search_select k_flag k_queries k_visit k_prepare k_units
     rm -rf $OUT/kt_s
+  done
+  env rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_s -o kt -- python scripts/exp_rerank_latency.py 300 > $OUT/lat.log 2>&1
+  echo "## ah_rerank_by_vector, one list of 10 000 - 11 535 sorted ids per call (scripts/exp_rerank_latency.py): $(grep "^rerank_by_vector" $OUT/lat.log | tail -1)"
+  python scripts/kstats.py $OUT/kt_s/kt_kernel_stats.csv k_prepare_query k_distances k_topk
+  rm -rf $OUT/kt_s
+  echo "## the same with AH_RERANK_SMALL=0 (the general selection: two tournament rounds, emit, three copies back): $(AH_RERANK_SMALL=0 python scripts/exp_rerank_latency.py 300 2>&1 | tail -1)"
+  echo "## ah_search_batch nq = 1 with the small submissions' switches off one at a time (wall time per call, python wrapper included)"
+  for knob in AH_SEARCH_BLOCK_MAX_QUERIES AH_SEARCH_SMALL_UNITS_MAX_QUERIES AH_SEARCH_SMALL_TILES_MAX_QUERIES AH_SEARCH_FUSED_FLAG AH_SEARCH_FUSED_PREPARE; do
+    echo "$knob=0: $(env $knob=0 python scripts/exp_latency.py 1 300 2>&1 | grep "^nq=" | tail -1)"
   done
 } > $OUT/${R}_search_call_kernels.txt 2>&1
 python bench.py --gpus 4 --virtual --steps 10 --warmup 2 --no-cpu --no-extra --no-live-pmc 2>$OUT/virtual4.err | tail -1 > $OUT/${R}_bench_virtual_4_threads.json

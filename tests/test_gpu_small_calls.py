@@ -14,7 +14,7 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 SMALL_KNOBS = ["AH_SEARCH_BLOCK_MAX_QUERIES", "AH_SEARCH_SMALL_UNITS_MAX_QUERIES", "AH_SEARCH_SMALL_TILES_MAX_QUERIES",
-               "AH_SEARCH_FUSED_FLAG", "AH_SEARCH_FUSED_PREPARE"]
+               "AH_SEARCH_FUSED_FLAG", "AH_SEARCH_FUSED_PREPARE", "AH_SEARCH_SINGLE_FUSED"]
 
 
 def same(a, b):
