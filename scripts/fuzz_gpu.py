@@ -46,6 +46,11 @@ def one(rng, it):
     ei, ed = oracle.rerank(qv, qh, rows, k)
     assert list(oi) == [int(x) for x in ei], desc + " rerank ids"
     T.assert_bit_equal(od, ed, desc + " rerank dists")
+    from arroy_amd._lib import tuning as _tuning0
+    with _tuning0(AH_RERANK_SMALL=0):  # the general selection behind the one-launch one (k_topk_small) of short lists
+        gi, gd = ds.rerank(k, query=q, sorted_ids=ids[rows])
+    assert list(gi) == list(oi), desc + " rerank small / general ids"
+    T.assert_bit_equal(gd, od, desc + " rerank small / general dists")
     # batched re-rank (both the query-major and the row-major path occur)
     nq = int(rng.choice([1, 3, 40]))
     qs = (rng.standard_normal((nq, dims)) * scale).astype(np.float32)
@@ -117,9 +122,19 @@ def one(rng, it):
         for tiles in (1, 0, 2):  # 2: the leaf tiles without the certified top-k screen (f32 rows for every candidate)
             if tiles == 2 and wave == 0:
                 continue
+            # (the small submissions' own kernels — unit builder, in-flight leaf tiles, fused flags / query preparation — on or off at
+            # random: every combination returns the same bits)
+            small = dict(AH_SEARCH_SMALL_UNITS_MAX_QUERIES=int(rng.choice([0, 64])), AH_SEARCH_SMALL_TILES_MAX_QUERIES=int(rng.choice([0, 8, 64])),
+                         AH_SEARCH_FUSED_FLAG=int(rng.integers(0, 2)), AH_SEARCH_FUSED_PREPARE=int(rng.integers(0, 2)),
+                         AH_SEARCH_SINGLE_FUSED=int(rng.integers(0, 2))) if ref is not None else {}
             with tuning(AH_SEARCH_WAVE=min(wave, 1), AH_SEARCH_BLOCK_MAX_QUERIES=64 if wave == 2 else 0, AH_SEARCH_TILES=min(tiles, 1),
-                        AH_SEARCH_SCREEN=0 if tiles == 2 else 1):
+                        AH_SEARCH_SCREEN=0 if tiles == 2 else 1, **small):
                 oi, od, oc = index.search(count2, queries=qs2, search_k=sk2, candidates=cand, raw=True)
+                if wave == 2:  # ... and a call of ONE query (arroy's own shape) is the same row
+                    pick = int(rng.integers(0, len(qs2)))
+                    o1 = index.search(count2, queries=qs2[pick:pick + 1], search_k=sk2, candidates=cand, raw=True)
+                    assert o1[2][0] == oc[pick] and np.array_equal(o1[0][0], oi[pick]) and np.array_equal(o1[1][0].view(np.uint32), od[pick].view(np.uint32)), \
+                        desc + f" one-query call differs from its row in the batch: tiles={tiles} q={pick} count={count2} sk={sk2} {small}"
             if ref is None:
                 ref = (oi, od, oc)
                 for i in (0, len(qs2) - 1):
