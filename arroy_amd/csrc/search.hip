@@ -830,26 +830,32 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
         s_sorted_n[t] = 0;
         s_sorted_node[t] = 0;
     }
-    uint32_t p2s = 2;  // the network only spans the settled leaves: the zero padding behind them is already in place
-    while (p2s < n_settled) p2s <<= 1;
-    for (uint32_t size = 2; size <= p2s; size <<= 1) {
-        for (uint32_t str = size >> 1; str > 0; str >>= 1) {
-            __syncthreads();
-            for (uint32_t t = tid; t < (p2s >> 1); t += kThreads) {
-                const uint32_t a_i = 2 * t - (t & (str - 1)), b_i = a_i + str;
-                const bool down = (a_i & size) == 0;  // descending order
-                const uint64_t x = s_sorted[a_i], y = s_sorted[b_i];
-                if ((x < y) == down) {
-                    s_sorted[a_i] = y;
-                    s_sorted[b_i] = x;
-                    const uint32_t nx = s_sorted_n[a_i], dx = s_sorted_node[a_i];
-                    s_sorted_n[a_i] = s_sorted_n[b_i];
-                    s_sorted_n[b_i] = nx;
-                    s_sorted_node[a_i] = s_sorted_node[b_i];
-                    s_sorted_node[b_i] = dx;
-                }
+    // descending by key: a leaf's place is the number of larger keys (unique: octet and pop index are their low word) — n_settled
+    // broadcast reads per leaf and two barriers, where a sorting network over two or three dozen leaves was fifteen
+    {
+        constexpr uint32_t kMine = kCap / kThreads;
+        uint64_t my_key[kMine];
+        uint32_t my_n[kMine], my_node[kMine], my_rank[kMine];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < kMine; r++) {
+            const uint32_t e = tid + r * kThreads;
+            my_rank[r] = 0;
+            if (e < n_settled) {
+                my_key[r] = s_sorted[e];
+                my_n[r] = s_sorted_n[e];
+                my_node[r] = s_sorted_node[e];
+                for (uint32_t g = 0; g < n_settled; g++) my_rank[r] += s_sorted[g] > my_key[r] ? 1u : 0u;
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < kMine; r++)
+            if (tid + r * kThreads < n_settled) {
+                s_sorted[my_rank[r]] = my_key[r];
+                s_sorted_n[my_rank[r]] = my_n[r];
+                s_sorted_node[my_rank[r]] = my_node[r];
+            }
     }
     __syncthreads();
     // `if nns.len() >= search_k { break }` before every pop: leaf i is taken iff the leaves before it hold < search_k ids
@@ -2884,9 +2890,9 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                     single.h16 = QueriesH16{d_qvecs, qstride, ds->dims, ds->hpitch, const_cast<uint16_t *>(ss.q16), const_cast<float4 *>(ss.qstats)};
                 units_done = true;
             }
+            const float *raw = (last_pass && fuse_prepare) ? (const float *)h_q : (const float *)nullptr;
             hipLaunchKernelGGL((k_descend_block<32, 128, 32, 2>), dim3((unsigned)nq), dim3(256), block_lds, s, ix->nv, sp, (uint32_t)nq,
-                               d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink, last_pass,
-                               (last_pass && fuse_prepare) ? (const float *)h_q : (const float *)nullptr, d_qhdrs, single);
+                               d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink, last_pass, raw, d_qhdrs, single);
             if (last_pass) {
                 passes_done = true;
                 return AH_OK;
