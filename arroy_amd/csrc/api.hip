@@ -341,8 +341,6 @@ void Context::destroy() {
     if (stream) (void)hipStreamDestroy(stream);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     copy_stream = nullptr;
-    if (aux_stream) (void)hipStreamDestroy(aux_stream);
-    aux_stream = nullptr;
     d_scratch = h_pinned = d_filter = nullptr;
     d_cap = h_cap = d_filter_cap = 0;
     stream = nullptr;
@@ -1483,18 +1481,6 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
         // the host copies the ids of group g + 1 into the pinned buffer and the copy stream sends them (review item 6: the
         // upload of a submission used to run to its end before the first kernel started).
         AH_TRY(launch_prepare_queries_only(ds->view(), d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
-        if (!ctx->aux_stream && tun(TUN_RERANK_SELECT_OVERLAP) != 0 &&
-            hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess) {
-            (void)hipGetLastError();
-            ctx->aux_stream = nullptr;
-        }
-        hipStream_t sel_stream = tun(TUN_RERANK_SELECT_OVERLAP) != 0 ? ctx->aux_stream : nullptr;
-        struct AuxDrain {  // whatever way this call ends, nothing of it is left running beside the context's stream
-            hipStream_t st;
-            ~AuxDrain() {
-                if (st) (void)hipStreamSynchronize(st);
-            }
-        } aux_drain{sel_stream};
         const uint64_t group_ids = (total + n_groups - 1) / n_groups;
         size_t qa = 0;
         uint32_t ta = 0;
@@ -1511,24 +1497,11 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
                 AH_HIP(hipEventRecord(ctx->ev0, ctx->copy_stream));
                 AH_HIP(hipStreamWaitEvent(s, ctx->ev0, 0));
             }
-            // the selection of this group's queries runs on a second stream under the screen of the next group (a block per query,
-            // latency- rather than bandwidth-bound: 0.2 ms per 125 queries that used to follow the last screen)
             AH_TRY(launch_rerank_screened(ds, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, ta, tb - ta, tc, d_ids, d_dist,
-                                          d_aux, d_q16, d_qstats, (uint32_t)k, d_oi, d_od, d_err, s, first, false));
-            if (sel_stream) {
-                AH_HIP(hipEventRecord(ctx->ev1, s));
-                AH_HIP(hipStreamWaitEvent(sel_stream, ctx->ev1, 0));
-            }
-            AH_TRY(launch_rerank_screened(ds, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, 0u, 0u, tc, d_ids, d_dist, d_aux,
-                                          d_q16, d_qstats, (uint32_t)k, d_oi, d_od, d_err, s, false, true, (uint32_t)qa, (uint32_t)(qb - qa),
-                                          sel_stream));
+                                          d_aux, d_q16, d_qstats, (uint32_t)k, d_oi, d_od, d_err, s, first, qb == nq));
             first = false;
             qa = qb;
             ta = tb;
-        }
-        if (sel_stream) {  // the copies back wait for the last selection
-            AH_HIP(hipEventRecord(ctx->ev1, sel_stream));
-            AH_HIP(hipStreamWaitEvent(s, ctx->ev1, 0));
         }
         AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));

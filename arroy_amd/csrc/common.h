@@ -137,7 +137,6 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(MANHATTAN_ROWS, "AH_MANHATTAN_ROWS", 1)                                                                            \
     X(RERANK_INVERT, "AH_RERANK_INVERT", -1)    /* 0 / 1: never / always the row-major re-rank of big submissions */      \
     X(RERANK_SMALL, "AH_RERANK_SMALL", 1)       /* 0: ah_rerank_by_vector / _by_item never take the one-launch selection of short lists (k_topk_small) */ \
-    X(RERANK_SELECT_OVERLAP, "AH_RERANK_SELECT_OVERLAP", 1) /* 0: the selection of a screened re-rank submission runs after its last screen, not group by group on a second stream */ \
     X(PAIR_GROUP, "AH_PAIR_GROUP", 0)                                                                                    \
     X(PAIR_RUNS, "AH_PAIR_RUNS", 1)                                                                                      \
     X(SEARCH_BITMAP, "AH_SEARCH_BITMAP", 1)     /* 0: sort + dedup of the candidates always by the bitonic network */     \
@@ -271,8 +270,6 @@ struct ScreenView {
 struct Context {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // uploads that run under the kernels of `stream` (created on first use)
-    hipStream_t aux_stream = nullptr;   // kernels that run beside those of `stream` (the selection of one group of lists under the
-                                        // screen of the next; created on first use)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_ring[4] = {nullptr, nullptr, nullptr, nullptr};  // staging ring (created on first use)
     void *d_scratch = nullptr;
@@ -442,8 +439,7 @@ bool ensure_screen(ah_dataset *ds, hipStream_t s, bool want8, bool retry_failed 
 int launch_rerank_screened(ah_dataset *ds, uint32_t nq, const uint8_t *d_qvecs, uint64_t qstride, const float *d_qhdrs,
                            const void *d_segs, const void *d_tiles, uint32_t tile_first, uint32_t n_tiles, uint32_t tile_candidates,
                            const uint32_t *d_ids, float *d_dist, float *d_aux, uint16_t *d_q16, float4 *d_qstats, uint32_t k_out,
-                           uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s, bool first, bool select,
-                           uint32_t sel_first = 0, uint32_t sel_count = 0xFFFFFFFFu, hipStream_t sel_stream = nullptr);
+                           uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s, bool first, bool select);
 
 // split.hip
 int launch_split_sides(const DataView &dv, const void *d_nvec, const float *d_nhdr, const uint32_t *d_ids, uint64_t n,

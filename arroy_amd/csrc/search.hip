@@ -1867,7 +1867,7 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
                                                                  uint32_t *__restrict__ out_ids, float *__restrict__ out_dist,
                                                                  uint32_t *err, const PairSeg *__restrict__ segs,
                                                                  uint32_t flag_words, uint32_t id_limit,
-                                                                 uint32_t *__restrict__ unique_out, uint32_t q_first) {
+                                                                 uint32_t *__restrict__ unique_out) {
     // FLAG (a small submission of ah_search_batch, n <= 16 384): nns.dedup() done here, on the ids this block holds in registers
     // anyway — k_flag_duplicates' bitmap (flag_words words of dynamic LDS behind the query leaf) without its launch, its trip to
     // the candidate buffer and back, and the `unique` it would have left is written to unique_out
@@ -1878,7 +1878,7 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
     __shared__ uint32_t s_pos[kCap];
     __shared__ float s_val[kCap];
     __shared__ uint32_t s_min, s_max, s_wave[kThreads / 64], s_bin, s_n, s_bad;
-    const uint32_t q = blockIdx.x + q_first, tid = threadIdx.x;  // (q_first: the launch covers the queries of one group of lists)
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
     // candidates of query q: a slot of `stride` entries (ah_search_batch), or a segment of the caller's lists (ah_rerank_batch)
     const uint64_t first = segs ? segs[q].off : (uint64_t)q * stride;
     const uint32_t n = segs ? segs[q].n : counts[q];
@@ -2127,9 +2127,9 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
                                                                  uint32_t *err, const PairSeg *__restrict__ segs,
                                                                  uint32_t flag_words = 0, uint32_t id_limit = 0,
                                                                  uint32_t *__restrict__ unique_out = nullptr,
-                                                                 uint32_t *__restrict__ host_status = nullptr, uint32_t q_first = 0) {
+                                                                 uint32_t *__restrict__ host_status = nullptr) {
     search_select_screened_body<METRIC, FLAG>(dv, ss, nns, dist_all, stride, counts, unique, k_out, qvecs, qstride, qhdrs, out_ids, out_dist,
-                                              err, segs, flag_words, id_limit, unique_out, q_first);
+                                              err, segs, flag_words, id_limit, unique_out);
     if (host_status) {  // (every return of the body is block-uniform)
         __threadfence();
         __syncthreads();
@@ -2411,8 +2411,7 @@ __global__ void k_unpack_normals(const uint8_t *__restrict__ recs, const uint64_
 int launch_rerank_screened(ah_dataset *ds, uint32_t nq, const uint8_t *d_qvecs, uint64_t qstride, const float *d_qhdrs,
                            const void *d_segs, const void *d_tiles, uint32_t tile_first, uint32_t n_tiles, uint32_t tile_candidates,
                            const uint32_t *d_ids, float *d_dist, float *d_aux, uint16_t *d_q16, float4 *d_qstats, uint32_t k_out,
-                           uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s, bool first, bool select,
-                           uint32_t sel_first, uint32_t sel_count, hipStream_t sel_stream) {
+                           uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s, bool first, bool select) {
     const DataView dv = ds->view();
     ScreenSearch ss{};
     ss.rows16 = ds->d_rows_h16;
@@ -2441,22 +2440,14 @@ int launch_rerank_screened(ah_dataset *ds, uint32_t nq, const uint8_t *d_qvecs, 
         AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_select_screened<AH_DOT_PRODUCT>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
     }
-    // the selection of the queries [sel_first, sel_first + sel_count) — every query of the call by default; a caller that screens its
-    // lists group by group selects group g on sel_stream while group g + 1 is screened on s (it orders the two with events)
-    sel_first = std::min(sel_first, nq);
-    sel_count = std::min(sel_count, nq - sel_first);
-    hipStream_t ss_stream = sel_stream ? sel_stream : s;
-    if (sel_count == 0) return AH_OK;
     if (ds->metric == AH_COSINE)
-        hipLaunchKernelGGL((k_search_select_screened<AH_COSINE>), dim3(sel_count), dim3(1024), sel_lds, ss_stream, dv, ss, d_ids, d_dist, 0u,
+        hipLaunchKernelGGL((k_search_select_screened<AH_COSINE>), dim3(nq), dim3(1024), sel_lds, s, dv, ss, d_ids, d_dist, 0u,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, k_out, d_qvecs, qstride, d_qhdrs, d_out_ids,
-                           d_out_dist, d_err, reinterpret_cast<const PairSeg *>(d_segs), 0u, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                           sel_first);
+                           d_out_dist, d_err, reinterpret_cast<const PairSeg *>(d_segs));
     else
-        hipLaunchKernelGGL((k_search_select_screened<AH_DOT_PRODUCT>), dim3(sel_count), dim3(1024), sel_lds, ss_stream, dv, ss, d_ids, d_dist,
-                           0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr, k_out, d_qvecs, qstride, d_qhdrs, d_out_ids,
-                           d_out_dist, d_err, reinterpret_cast<const PairSeg *>(d_segs), 0u, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                           sel_first);
+        hipLaunchKernelGGL((k_search_select_screened<AH_DOT_PRODUCT>), dim3(nq), dim3(1024), sel_lds, s, dv, ss, d_ids, d_dist, 0u,
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, k_out, d_qvecs, qstride, d_qhdrs, d_out_ids,
+                           d_out_dist, d_err, reinterpret_cast<const PairSeg *>(d_segs));
     AH_HIP(hipGetLastError());
     return AH_OK;
 }
