@@ -96,7 +96,13 @@ class AhBuildStats(C.Structure):
                 ("screen8_pairs", C.c_uint64), ("screen8_decided", C.c_uint64), ("screen8b_decided", C.c_uint64),
                 ("screen_unavailable", C.c_uint32),
                 ("reserved0", C.c_uint32), ("seconds_setup", C.c_double), ("seconds_after_device", C.c_double),
-                ("host_blob_recycled", C.c_uint64)]
+                ("host_blob_recycled", C.c_uint64), ("seconds_reserve", C.c_double), ("seconds_reserve_wait", C.c_double)]
+
+
+class AhRerankStats(C.Structure):
+    _fields_ = [("calls", C.c_uint64), ("queries", C.c_uint64), ("candidates", C.c_uint64), ("seconds_wall", C.c_double),
+                ("seconds_prep", C.c_double), ("seconds_ids", C.c_double), ("seconds_enqueue", C.c_double),
+                ("seconds_sync_wait", C.c_double), ("seconds_device_span", C.c_double)]
 
 
 class AhSearchStats(C.Structure):
@@ -141,6 +147,7 @@ SIGNATURES = {
     "ah_dataset_fill_synthetic": (C.c_int, [_VP, C.c_uint64, C.c_int, C.c_uint64]),
     "ah_dataset_finalize": (C.c_int, [_VP]),
     "ah_dataset_reserve_build": (C.c_int, [_VP, C.c_uint32, C.c_uint32]),
+    "ah_dataset_rerank_stats": (C.c_int, [_VP, C.POINTER(AhRerankStats), C.c_int]),
     "ah_dataset_len": (C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     "ah_dataset_item_vector": (C.c_int, [_VP, C.c_uint32, _F32P]),
     "ah_dataset_read_headers": (C.c_int, [_VP, C.c_uint64, C.c_uint64, _VP]),

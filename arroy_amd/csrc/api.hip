@@ -336,6 +336,9 @@ void Context::destroy() {
     if (h_pinned) (void)hipHostFree(h_pinned);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (ev_t0) (void)hipEventDestroy(ev_t0);
+    if (ev_t1) (void)hipEventDestroy(ev_t1);
+    ev_t0 = ev_t1 = nullptr;
     for (hipEvent_t &e : ev_ring)
         if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
@@ -1013,7 +1016,7 @@ int ah_dataset_fill_synthetic(ah_dataset *ds, uint64_t seed, int distribution, u
     AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
     AH_REQUIRE(!ds->finalized && ds->n == 0, AH_ERR_INVALID_ARGUMENT, "synthetic fill needs an empty dataset");
     AH_REQUIRE(n_items <= ds->capacity, AH_ERR_INVALID_ARGUMENT, "n_items exceeds capacity");
-    AH_REQUIRE(distribution >= AH_SYNTH_UNIFORM_01 && distribution <= AH_SYNTH_NORMAL_OUTLIERS, AH_ERR_INVALID_ARGUMENT,
+    AH_REQUIRE(distribution >= AH_SYNTH_UNIFORM_01 && distribution <= AH_SYNTH_LAST, AH_ERR_INVALID_ARGUMENT,
                "unknown distribution %d", distribution);
     AH_LEASE(ds, ctx);
     DataView dv = ds->view();
@@ -1081,6 +1084,92 @@ int ah_dataset_len(const ah_dataset *ds, uint64_t *out_n_items) {
 // records once over PCIe and fans the HBM image out instead of staging N times.  The replica is in the same state as
 // the source (finalized or not, DotProduct preprocessed or not); the binary16 shadow is rebuilt on the replica on
 // demand (a 10 ms kernel) rather than copied.
+// ah_dataset_replicate's copy engine.  Peer copies (xGMI) when the destination can address the source — the calling
+// sequence of the reference's one-process build, one replica per GPU (src/writer.rs:556-591 shares ONE read-only view) — and a
+// copy through pinned host memory when it cannot (no peer access between the two devices, IOMMU / container restrictions, or a
+// peer copy that fails): slower, never wrong.  Either way the head and the tail of every replicated array are read back from
+// both devices and compared before the replica is handed out.
+struct ReplicaCopier {
+    int src_dev, dst_dev;
+    hipStream_t s;          // a stream of the destination device
+    bool peer = false;      // peer copies are in use
+    bool bounced = false;   // at least one array went through the host
+    void *h_bounce = nullptr;
+    static constexpr size_t kBounce = 64u << 20;
+    std::string why;
+
+    ReplicaCopier(int sd, int dd, hipStream_t st) : src_dev(sd), dst_dev(dd), s(st) {
+        if (tun(TUN_REPLICATE_HOST_BOUNCE) != 0) {
+            why = "AH_REPLICATE_HOST_BOUNCE";
+            return;
+        }
+        if (sd == dd) {
+            peer = true;  // (a copy inside one device)
+            return;
+        }
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dd, sd) != hipSuccess || !can) {
+            (void)hipGetLastError();
+            why = "hipDeviceCanAccessPeer says no";
+            return;
+        }
+        (void)hipSetDevice(dd);
+        const hipError_t e = hipDeviceEnablePeerAccess(sd, 0);
+        (void)hipGetLastError();
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+            why = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e);
+            return;
+        }
+        peer = true;
+    }
+    ~ReplicaCopier() {
+        if (h_bounce) (void)hipHostFree(h_bounce);
+    }
+    hipError_t through_host(void *dst, const void *src, size_t bytes) {
+        bounced = true;
+        hipError_t e = hipSuccess;
+        if (!h_bounce && (e = hipHostMalloc(&h_bounce, kBounce, hipHostMallocDefault)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        for (size_t off = 0; off < bytes && e == hipSuccess; off += kBounce) {
+            const size_t len = std::min(kBounce, bytes - off);
+            (void)hipSetDevice(src_dev);
+            e = hipMemcpy(h_bounce, (const uint8_t *)src + off, len, hipMemcpyDeviceToHost);
+            (void)hipSetDevice(dst_dev);
+            if (e == hipSuccess) e = hipMemcpy((uint8_t *)dst + off, h_bounce, len, hipMemcpyHostToDevice);
+        }
+        return e;
+    }
+    // head and tail (up to 4 KiB each) of the two arrays, read back from both devices
+    bool same_ends(const void *dst, const void *src, size_t bytes) {
+        const size_t len = std::min<size_t>(bytes, 4096);
+        uint8_t a[4096], b[4096];
+        for (size_t off : {(size_t)0, bytes - len}) {
+            (void)hipSetDevice(src_dev);
+            if (hipMemcpy(a, (const uint8_t *)src + off, len, hipMemcpyDeviceToHost) != hipSuccess) return false;
+            (void)hipSetDevice(dst_dev);
+            if (hipMemcpy(b, (const uint8_t *)dst + off, len, hipMemcpyDeviceToHost) != hipSuccess) return false;
+            if (memcmp(a, b, len) != 0) return false;
+        }
+        return true;
+    }
+    hipError_t copy(void *dst, const void *src, size_t bytes) {
+        if (bytes == 0) return hipSuccess;
+        hipError_t e = hipSuccess;
+        if (peer) {
+            e = hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e == hipSuccess && same_ends(dst, src, bytes)) return hipSuccess;
+            // a peer copy that fails, or that "succeeds" and delivers other bytes: do not trust the link again in this call
+            (void)hipGetLastError();
+            why = e != hipSuccess ? std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e) : "the peer copy delivered other bytes";
+            peer = false;
+        }
+        e = through_host(dst, src, bytes);
+        if (e == hipSuccess && !same_ends(dst, src, bytes)) e = hipErrorUnknown;
+        return e;
+    }
+};
+
 int ah_dataset_replicate(ah_dataset *src, int device, ah_dataset **out) {
     AH_GUARDED("ah_dataset_replicate")
     AH_REQUIRE(out, AH_ERR_INVALID_ARGUMENT, "out is NULL");
@@ -1101,42 +1190,41 @@ int ah_dataset_replicate(ah_dataset *src, int device, ah_dataset **out) {
     AH_TRY(ah_dataset_create(src->metric, src->dims, std::max<uint64_t>(src->capacity, 1), device, &dst));
     int st = AH_OK;
     do {
-        if (device != src->device) {
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) {
-                (void)hipSetDevice(device);
-                (void)hipDeviceEnablePeerAccess(src->device, 0);  // already enabled is fine
-                (void)hipGetLastError();
-            }
-        }
         ContextLease lease(dst);
         if (!lease.c) {
             set_error("cannot create a HIP stream");
             st = AH_ERR_DEVICE;
             break;
         }
-        hipStream_t s = lease.c->stream;
+        (void)hipSetDevice(device);
+        ReplicaCopier cp(src->device, device, lease.c->stream);
         const size_t rb = src->row_bytes(), hs = ah_header_size(src->metric);
         const void *rows_src = src->d_rows_f32 ? (const void *)src->d_rows_f32 : (const void *)src->d_rows_bq;
         void *rows_dst = dst->d_rows_f32 ? (void *)dst->d_rows_f32 : (void *)dst->d_rows_bq;
         hipError_t e = hipSuccess;
         if (src->n) {
-            e = hipMemcpyPeerAsync(rows_dst, device, rows_src, src->device, src->n * rb, s);
-            if (e == hipSuccess) e = hipMemcpyPeerAsync(dst->d_headers, device, src->d_headers, src->device, src->n * hs, s);
-            if (e == hipSuccess) e = hipMemcpyPeerAsync(dst->d_ids, device, src->d_ids, src->device, src->n * 4, s);
+            e = cp.copy(rows_dst, rows_src, src->n * rb);
+            if (e == hipSuccess) e = cp.copy(dst->d_headers, src->d_headers, src->n * hs);
+            if (e == hipSuccess) e = cp.copy(dst->d_ids, src->d_ids, src->n * 4);
         }
         if (e == hipSuccess && src->d_lut) {
+            (void)hipSetDevice(device);
             e = dev_malloc((void **)&dst->d_lut, (size_t)src->lut_len * 4);
-            if (e == hipSuccess) e = hipMemcpyPeerAsync(dst->d_lut, device, src->d_lut, src->device, (size_t)src->lut_len * 4, s);
+            if (e == hipSuccess) e = cp.copy(dst->d_lut, src->d_lut, (size_t)src->lut_len * 4);
             dst->lut_len = src->lut_len;
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) {
-            set_error("peer copy to device %d failed: %s", device, hipGetErrorString(e));
+            (void)hipGetLastError();
+            set_error("replicating the dataset from device %d to device %d failed%s%s: %s (peer access: %s)", src->device, device,
+                      cp.bounced ? " even through pinned host memory" : "", cp.why.empty() ? "" : (" [" + cp.why + "]").c_str(),
+                      e == hipErrorUnknown ? "the replica differs from its source" : hipGetErrorString(e), cp.peer ? "yes" : "no");
             set_error_status(AH_ERR_DEVICE);
             st = AH_ERR_DEVICE;
             break;
         }
+        if (cp.bounced && tun(TUN_TIMING) != 0)
+            fprintf(stderr, "[arroy-hip] replicate %d -> %d went through pinned host memory (%s)\n", src->device, device, cp.why.c_str());
+        dst->replicated_through_host = cp.bounced;
         dst->n = src->n;
         dst->identity_ids = src->identity_ids;
         dst->last_id = src->last_id;
@@ -1401,11 +1489,71 @@ struct HostTile {
     uint32_t query, first;
 };
 
+// AH_RERANK_TIMING=1: the wall time of one sub-batch of ah_rerank_batch by phase (include/arroy_hip.h: ah_rerank_stats).  The
+// phases are disjoint stretches of the calling thread's time; the destructor runs after the last synchronisation of whichever
+// return path was taken and adds them to the dataset's totals.
+struct RerankProbe {
+    using clk = std::chrono::steady_clock;
+    ah_dataset *ds;
+    Context *ctx;
+    bool on;
+    clk::time_point t_in, t_mark;
+    double prep = 0, ids = 0, enqueue = 0, wait = 0;
+    bool span = false;
+    uint64_t nq, total;
+    RerankProbe(ah_dataset *d, Context *c, uint64_t q, uint64_t t) : ds(d), ctx(c), on(tun(TUN_RERANK_TIMING) != 0), nq(q), total(t) {
+        if (on) t_in = t_mark = clk::now();
+    }
+    // time since the last mark goes to `*bucket`
+    void lap(double RerankProbe::*bucket) {
+        if (!on) return;
+        const auto now = clk::now();
+        this->*bucket += std::chrono::duration<double>(now - t_mark).count();
+        t_mark = now;
+    }
+    void first_enqueue(hipStream_t s) {  // the device span starts here
+        if (!on) return;
+        if (!ctx->ev_t0 && (hipEventCreate(&ctx->ev_t0) != hipSuccess || hipEventCreate(&ctx->ev_t1) != hipSuccess)) {
+            (void)hipGetLastError();
+            return;
+        }
+        span = hipEventRecord(ctx->ev_t0, s) == hipSuccess;
+    }
+    ~RerankProbe() {
+        if (!on) return;
+        lap(&RerankProbe::enqueue);  // (output copies after the last wait)
+        float ms = 0.0f;
+        if (span && hipEventRecord(ctx->ev_t1, ctx->stream) == hipSuccess && hipEventSynchronize(ctx->ev_t1) == hipSuccess &&
+            hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1) != hipSuccess)
+            ms = 0.0f;
+        (void)hipGetLastError();
+        const double wall = std::chrono::duration<double>(clk::now() - t_in).count();
+        std::lock_guard<std::mutex> lk(ds->mu);
+        ah_rerank_stats &r = ds->rr_stats;
+        r.calls += 1;
+        r.queries += nq;
+        r.candidates += total;
+        r.seconds_wall += wall;
+        r.seconds_prep += prep;
+        r.seconds_ids += ids;
+        r.seconds_enqueue += enqueue;
+        r.seconds_sync_wait += wait;
+        r.seconds_device_span += ms * 1e-3;
+    }
+};
+#define AH_RR_SYNC(stream_)                       \
+    do {                                          \
+        probe.lap(&RerankProbe::enqueue);         \
+        AH_HIP(hipStreamSynchronize(stream_));    \
+        probe.lap(&RerankProbe::wait);            \
+    } while (0)
+
 static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries, size_t nq, const uint32_t *ids,
                               const uint64_t *offsets, size_t k, uint32_t *out_ids, float *out_distances,
                               uint32_t *out_counts) {
     const uint64_t base = offsets[0];
     const uint64_t total = offsets[nq] - base;
+    RerankProbe probe(ds, ctx, nq, total);
     uint32_t max_n = 0, max_rounds = 0;
     std::vector<HostSeg> segs(nq);
     std::vector<HostTile> tiles;
@@ -1464,6 +1612,8 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     memcpy(h_segs, segs.data(), nq * sizeof(HostSeg));
     if (!tiles.empty()) memcpy(h_tiles, tiles.data(), tiles.size() * sizeof(HostTile));
     hipStream_t s = ctx->stream;
+    probe.lap(&RerankProbe::prep);
+    probe.first_enqueue(s);
     AH_HIP(hipMemcpyAsync(d_qf32, h_q, nq * (size_t)ds->dims * 4, hipMemcpyHostToDevice, s));
     AH_HIP(hipMemcpyAsync(d_segs, h_segs, nq * sizeof(HostSeg), hipMemcpyHostToDevice, s));
     if (!tiles.empty()) AH_HIP(hipMemcpyAsync(d_tiles, h_tiles, tiles.size() * sizeof(HostTile), hipMemcpyHostToDevice, s));
@@ -1492,7 +1642,9 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
             uint32_t tb = ta;
             while (tb < tiles.size() && tiles[tb].query < qb) tb++;
             if (len) {
+                probe.lap(&RerankProbe::enqueue);
                 parallel_rows(len, 4, [&](size_t a, size_t b) { memcpy(h_ids + lo + a, ids + base + lo + a, (b - a) * 4); });
+                probe.lap(&RerankProbe::ids);
                 AH_HIP(hipMemcpyAsync(d_ids + lo, h_ids + lo, len * 4, hipMemcpyHostToDevice, ctx->copy_stream));
                 AH_HIP(hipEventRecord(ctx->ev0, ctx->copy_stream));
                 AH_HIP(hipStreamWaitEvent(s, ctx->ev0, 0));
@@ -1506,7 +1658,7 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
         AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
-        AH_HIP(hipStreamSynchronize(s));
+        AH_RR_SYNC(s);
         if ((*h_err & ~1u) == 0) {
             AH_TRY(check_err_flags(*h_err, true));
             memcpy(out_ids, h_oi, nq * k * 4);
@@ -1521,7 +1673,7 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
         AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
-        AH_HIP(hipStreamSynchronize(s));
+        AH_RR_SYNC(s);
         AH_TRY(check_err_flags(*h_err, true));
         memcpy(out_ids, h_oi, nq * k * 4);
         memcpy(out_distances, h_od, nq * k * 4);
@@ -1529,7 +1681,9 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     }
     for (uint64_t lo = 0; lo < total; lo += (2u << 20)) {
         const uint64_t len = std::min<uint64_t>(2u << 20, total - lo);
+        probe.lap(&RerankProbe::enqueue);
         parallel_rows(len, 4, [&](size_t a, size_t b) { memcpy(h_ids + lo + a, ids + base + lo + a, (b - a) * 4); });
+        probe.lap(&RerankProbe::ids);
         AH_HIP(hipMemcpyAsync(d_ids + lo, h_ids + lo, len * 4, hipMemcpyHostToDevice, s));
     }
     if (screened) {
@@ -1539,7 +1693,7 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
         AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
-        AH_HIP(hipStreamSynchronize(s));
+        AH_RR_SYNC(s);
         if ((*h_err & ~1u) == 0) {
             AH_TRY(check_err_flags(*h_err, true));
             memcpy(out_ids, h_oi, nq * k * 4);
@@ -1559,7 +1713,7 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
     AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
     AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
-    AH_HIP(hipStreamSynchronize(s));
+    AH_RR_SYNC(s);
     AH_TRY(check_err_flags(*h_err, true));
     memcpy(out_ids, h_oi, nq * k * 4);
     memcpy(out_distances, h_od, nq * k * 4);
@@ -1604,6 +1758,16 @@ int ah_rerank_batch(ah_dataset *ds, const float *queries, size_t n_queries, cons
                                   out_distances + q0 * k, out_counts + q0));
         q0 = q1;
     }
+    return AH_OK;
+    AH_GUARDED_END
+}
+
+int ah_dataset_rerank_stats(ah_dataset *ds, ah_rerank_stats *out, int reset) {
+    AH_GUARDED("ah_dataset_rerank_stats")
+    AH_REQUIRE(ds, AH_ERR_INVALID_ARGUMENT, "dataset is NULL");
+    std::lock_guard<std::mutex> lk(ds->mu);
+    if (out) *out = ds->rr_stats;
+    if (reset) ds->rr_stats = ah_rerank_stats{};
     return AH_OK;
     AH_GUARDED_END
 }

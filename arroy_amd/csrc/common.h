@@ -143,6 +143,7 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(SEARCH_TILES, "AH_SEARCH_TILES", 1)       /* 0: never the leaf-tile re-rank of ah_search_batch */                   \
     X(SEARCH_WAVE, "AH_SEARCH_WAVE", 1)         /* 0: the descent always one octet per query (k_descend) */               \
     X(SEARCH_BLOCK_MAX_QUERIES, "AH_SEARCH_BLOCK_MAX_QUERIES", 64) /* submissions of at most this many queries descend with one BLOCK (32 octets) per query; 0: never */ \
+    X(SEARCH_SMALL_GATE, "AH_SEARCH_SMALL_GATE", 1) /* 0: small submissions start on the block descent / k_units_small whatever the estimate of the leaves they open says */ \
     X(SEARCH_SMALL_UNITS_MAX_QUERIES, "AH_SEARCH_SMALL_UNITS_MAX_QUERIES", 64) /* up to this many queries a call: one block places the leaf visits (k_units_small) */ \
     X(SEARCH_FUSED_FLAG, "AH_SEARCH_FUSED_FLAG", 1) /* 0: a small submission flags its duplicate candidates with k_flag_duplicates, not inside the selection */ \
     X(SEARCH_FUSED_PREPARE, "AH_SEARCH_FUSED_PREPARE", 1) /* 0: a small submission prepares its query leaves with k_prepare_queries, not inside the block descent */ \
@@ -150,6 +151,8 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(SEARCH_SMALL_TILES_MAX_QUERIES, "AH_SEARCH_SMALL_TILES_MAX_QUERIES", 8) /* up to this many queries a call: leaf tiles in slabs of 64 rows, whole rows in flight */ \
     X(RERANK_GROUPS, "AH_RERANK_GROUPS", 2)     /* groups a screened ah_rerank_batch submission is cut into (upload of group g + 1 under the kernel of g) */ \
     X(RERANK_SCREEN, "AH_RERANK_SCREEN", 1)     /* 0: ah_rerank_batch never screens its candidates (f32 rows for all) */ \
+    X(REPLICATE_HOST_BOUNCE, "AH_REPLICATE_HOST_BOUNCE", 0) /* 1: ah_dataset_replicate copies through pinned host memory even where peer access works (test aid) */ \
+    X(RERANK_TIMING, "AH_RERANK_TIMING", 0)     /* 1: ah_rerank_batch accounts its wall time by phase (ah_dataset_rerank_stats) */ \
     X(SEARCH_SCREEN, "AH_SEARCH_SCREEN", 1)     /* 0: the re-rank of ah_search_batch never screens its candidates (f32 rows for all) */ \
     X(HOST_THREADS, "AH_HOST_THREADS", 8)       /* host threads one build may use at a time for its output path */        \
     X(DEVICE_CACHE_MB, "AH_DEVICE_CACHE_MB", 98304) /* idle HBM the caching allocator keeps while a dataset lives on the device */ \
@@ -271,6 +274,7 @@ struct Context {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // uploads that run under the kernels of `stream` (created on first use)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // AH_RERANK_TIMING: first enqueue .. stream idle of one submission (created on first use)
     hipEvent_t ev_ring[4] = {nullptr, nullptr, nullptr, nullptr};  // staging ring (created on first use)
     void *d_scratch = nullptr;
     size_t d_cap = 0;
@@ -331,6 +335,10 @@ struct ah_dataset {
     std::vector<ah::Context *> pool;
     bool counted = false;                        // dataset_born() ran for this handle (its destroy then runs dataset_gone())
     std::thread reserve_thread;                  // ah_dataset_reserve_build: fills the device cache while records are staged
+    bool replicated_through_host = false;        // ah_dataset_replicate made this replica without peer access (diagnostic)
+    ah_rerank_stats rr_stats{};                  // AH_RERANK_TIMING=1: where ah_rerank_batch's wall time went (under `mu`)
+    double reserve_seconds = 0.0;                // ... how long that helper ran (written by it, read after the join)
+    double reserve_wait_seconds = 0.0;           // ... and how long the first build then waited for it (ah_build_stats, ABI v7)
 
     // Wait for ah_dataset_reserve_build's helper, whoever gets there first (concurrent builds on one dataset are allowed: the
     // handle is moved out under `mu`, so exactly one caller joins it; a failing join must not cross the C ABI)

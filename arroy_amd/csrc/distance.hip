@@ -831,7 +831,9 @@ int launch_quantize_rows(const float *d_src, uint32_t src_pitch, uint32_t dims, 
     return AH_OK;
 }
 
-// Synthetic rows (include/arroy_hip_policy.h): one thread per float4 of the padded row.
+// Synthetic rows (include/arroy_hip_policy.h): one thread per float4 of the padded row.  The two structured distributions
+// compute the row's part (its cluster / its 32 factors) once per thread instead of once per component; the values are those
+// of ah_synth_value (tests/test_gpu_synth.py compares every component with the host's).
 __global__ void k_synth_fill(float *__restrict__ rows, uint32_t pitch, uint32_t dims, uint64_t first_item, uint64_t n,
                              uint64_t seed, int distribution) {
     const uint64_t per_row = pitch >> 2;
@@ -839,13 +841,34 @@ __global__ void k_synth_fill(float *__restrict__ rows, uint32_t pitch, uint32_t 
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
         const uint64_t row = g / per_row;
+        const uint64_t item = first_item + row;
         const uint32_t c = (uint32_t)(g % per_row) * 4;
-        float4 v;
-        v.x = c + 0 < dims ? ah_synth_value(seed, first_item + row, c + 0, dims, distribution) : 0.0f;
-        v.y = c + 1 < dims ? ah_synth_value(seed, first_item + row, c + 1, dims, distribution) : 0.0f;
-        v.z = c + 2 < dims ? ah_synth_value(seed, first_item + row, c + 2, dims, distribution) : 0.0f;
-        v.w = c + 3 < dims ? ah_synth_value(seed, first_item + row, c + 3, dims, distribution) : 0.0f;
-        reinterpret_cast<float4 *>(rows)[g] = v;
+        float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (distribution == AH_SYNTH_CLUSTERED) {
+            int is_copy;
+            const uint32_t cl = ah_synth_cluster_of(seed, item, &is_copy);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++)
+                if (c + j < dims)
+                    e[j] = ah_synth_clustered_from(ah_synth_centre_q20(seed, cl, c + j, dims),
+                                                   is_copy ? 0 : ah_synth_normal_q20(ah_synth_hash(seed, item, c + j, dims)));
+        } else if (distribution == AH_SYNTH_LOW_RANK) {
+            int32_t signal[4] = {0, 0, 0, 0};
+            for (uint32_t k = 0; k < AH_SYNTH_FACTORS; k++) {
+                const int32_t f = ah_synth_factor(seed, item, k);
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++)
+                    if (c + j < dims) signal[j] += f * ah_synth_loading(seed, k, c + j, dims);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++)
+                if (c + j < dims) e[j] = ah_synth_low_rank_from(signal[j], ah_synth_normal_q20(ah_synth_hash(seed, item, c + j, dims)));
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++)
+                if (c + j < dims) e[j] = ah_synth_value(seed, item, c + j, dims, distribution);
+        }
+        reinterpret_cast<float4 *>(rows)[g] = make_float4(e[0], e[1], e[2], e[3]);
     }
 }
 int launch_synth_fill(float *d_rows, uint32_t pitch, uint32_t dims, uint64_t first_item, uint64_t n, uint64_t seed,

@@ -3670,7 +3670,11 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
     AH_REQUIRE(ds->metric != AH_DOT_PRODUCT || ds->dot_preprocessed, AH_ERR_NEED_PREPROCESS,
                "DotProduct needs ah_preprocess_dot before the build (src/writer.rs:964-976)");
     AH_HIP(hipSetDevice(ds->device));
-    ds->join_reserve();  // (ah_dataset_reserve_build still filling the cache)
+    {
+        const auto tw = std::chrono::steady_clock::now();
+        ds->join_reserve();  // (ah_dataset_reserve_build still filling the cache)
+        ds->reserve_wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+    }
     const auto t0 = std::chrono::steady_clock::now();
     const uint32_t split_after = options->split_after ? options->split_after : ds->dims;  // src/writer.rs:474-477
     ah_forest *forest = new (std::nothrow) ah_forest();
@@ -3763,6 +3767,12 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
         return st;
     }
     forest->stats.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    {  // the reserve helper's figures go to the first build that joined it
+        std::lock_guard<std::mutex> lk(ds->mu);
+        forest->stats.seconds_reserve = ds->reserve_seconds;
+        forest->stats.seconds_reserve_wait = ds->reserve_wait_seconds;
+        ds->reserve_seconds = ds->reserve_wait_seconds = 0.0;
+    }
     *out = forest;
     return AH_OK;
 }
@@ -3823,8 +3833,10 @@ int ah_dataset_reserve_build(ah_dataset *ds, uint32_t n_trees, uint32_t split_af
         }
     }
     const int device = ds->device;
+    double *const took = &ds->reserve_seconds;  // (the handle outlives the helper: every build and the destroy join it)
     try {
-        std::thread helper([device, sizes] {
+        std::thread helper([device, sizes, took] {
+            const auto th = std::chrono::steady_clock::now();
             if (hipSetDevice(device) != hipSuccess) return;
             std::vector<void *> got;
             for (size_t b : sizes) {
@@ -3836,6 +3848,7 @@ int ah_dataset_reserve_build(ah_dataset *ds, uint32_t n_trees, uint32_t split_af
                 got.push_back(p);
             }
             for (void *p : got) (void)dev_free_unused(p);
+            *took += std::chrono::duration<double>(std::chrono::steady_clock::now() - th).count();
         });
         std::thread stale;  // (a helper another thread started since the join above: wait for that one too)
         {
@@ -4145,14 +4158,17 @@ int ah_host_cache_trim(uint64_t *out_bytes) {
 int ah_synth_rows_host(uint64_t seed, int distribution, uint64_t first_item, uint64_t n, uint32_t dims, float *out) {
     AH_GUARDED("ah_synth_rows_host")
     AH_REQUIRE(out || n == 0, AH_ERR_INVALID_ARGUMENT, "out is NULL");
-    AH_REQUIRE(distribution >= AH_SYNTH_UNIFORM_01 && distribution <= AH_SYNTH_NORMAL_OUTLIERS, AH_ERR_INVALID_ARGUMENT,
+    AH_REQUIRE(distribution >= AH_SYNTH_UNIFORM_01 && distribution <= AH_SYNTH_LAST, AH_ERR_INVALID_ARGUMENT,
                "unknown distribution %d", distribution);
+    // the per-dataset part of the structured distributions (cluster centres / factor loadings), computed once
+    std::vector<int32_t> table(ah_synth_table_len(dims, distribution));
+    if (!table.empty()) ah_synth_table_fill(seed, dims, distribution, table.data());
+    const int32_t *tab = table.empty() ? nullptr : table.data();
     const unsigned n_threads = (unsigned)std::min<uint64_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<uint64_t>(1, n / 1024));
     parallel_run(std::min(n_threads, 64u), [=](unsigned t) {
         const unsigned parts = std::min(n_threads, 64u);
         const uint64_t lo = n * t / parts, hi = n * (t + 1) / parts;
-        for (uint64_t i = lo; i < hi; i++)
-            for (uint32_t d = 0; d < dims; d++) out[i * dims + d] = ah_synth_value(seed, first_item + i, d, dims, distribution);
+        for (uint64_t i = lo; i < hi; i++) ah_synth_row(seed, first_item + i, dims, distribution, tab, out + i * dims);
     });
     return AH_OK;
     AH_GUARDED_END

@@ -2464,6 +2464,7 @@ struct ah_index {
     void *d_nrows = nullptr;
     float *d_nhdrs = nullptr;
     uint32_t n_trees = 0, n_nodes = 0, n_normals = 0, max_desc = 0;
+    uint32_t n_leaves = 0;  // Descendants nodes (desc_len / n_leaves: the mean leaf, what the small-submission gate estimates with)
     uint64_t desc_len = 0;
     std::mutex stats_mu;       // ah_search_batch may run on any number of threads
     ah_search_stats stats{};
@@ -2601,6 +2602,7 @@ int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_ind
             d.a = (uint32_t)nd.offset;
             d.b = nd.count;
             ix->max_desc = std::max(ix->max_desc, nd.count);
+            ix->n_leaves++;
         }
         nodes[i] = d;
     }
@@ -2820,6 +2822,21 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     // (a small submission: the kernel that prepares the query leaves reads the pinned staging buffer itself — 6 KB over the link
     // cost less than the copy engine's launch)
     const bool zero_copy_queries = queries && (long long)nq <= tun(TUN_SEARCH_SMALL_UNITS_MAX_QUERIES);
+    // The small-submission kernels have hard capacities and, on the leaf-tile path, nothing behind them: k_descend_block holds 32
+    // leaves per octet (trees t = octet mod 32), k_units_small kSmallVisits visits per call; past either the whole chunk is
+    // redone the long way — correct, and more than twice the latency (round-5 advice: 128-d data at search_k = 10 000 opens
+    // ~100 leaves per query, a 3-tree index more than 32 per tree).  So: an estimate of the leaves one query opens — search_k
+    // items at the index's mean leaf size (what a filter keeps of it), a quarter more for leaves smaller than the mean — decides
+    // on the host whether a call starts there at all.  AH_SEARCH_SMALL_GATE=0: as before (the overflow tests force the
+    // fall-backs with it).
+    bool block_fits = true, small_units_fit = true;
+    if (tun(TUN_SEARCH_SMALL_GATE) != 0 && ix->n_leaves) {
+        const double mean_leaf = std::max(1.0, (double)ix->desc_len / ix->n_leaves * (d_filter_bits ? std::max(filter_share, 1e-3) : 1.0));
+        const double est_leaves = 1.25 * (double)search_k / mean_leaf + 2.0;
+        block_fits = est_leaves / std::max(1u, std::min(ix->n_trees, 32u)) <= 24.0;
+        small_units_fit = (double)nq * est_leaves <= 0.8 * kSmallVisits;
+    }
+    const bool block_ok = block_fits && (long long)nq <= tun(TUN_SEARCH_BLOCK_MAX_QUERIES);
     if (queries) {
         memcpy(h_q, queries, nq * (size_t)ds->dims * 4);
         if (!zero_copy_queries) AH_HIP(hipMemcpyAsync(d_qf32, h_q, nq * (size_t)ds->dims * 4, hipMemcpyHostToDevice, s));
@@ -2841,13 +2858,14 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     sp.search_k = search_k;
     sp.nns_stride = nns_stride;
     // (... and when the block descent is the first kernel to want the leaves, it prepares them itself)
-    const bool fuse_prepare = zero_copy_queries && tiles && wave_descent && !metric_is_bq_dev(ds->metric) &&
-                              (!d_filter_bits || filter_share >= 0.35) && (long long)nq <= tun(TUN_SEARCH_BLOCK_MAX_QUERIES) &&
-                              tun(TUN_SEARCH_FUSED_PREPARE) != 0;
+    // (a small submission on the leaf-tile path makes the binary16 copies of its queries in the launch that places its visits)
+    const bool small_units = tiles && small_units_fit && (long long)nq <= tun(TUN_SEARCH_SMALL_UNITS_MAX_QUERIES);
+    // (small_units: otherwise k_queries_h16 below wants the leaves BEFORE the descent — until round 6 a call with the block
+    // descent on and k_units_small off screened against copies of unprepared leaves and was saved by the fall-back only)
+    const bool fuse_prepare = zero_copy_queries && tiles && small_units && wave_descent && !metric_is_bq_dev(ds->metric) &&
+                              (!d_filter_bits || filter_share >= 0.35) && block_ok && tun(TUN_SEARCH_FUSED_PREPARE) != 0;
     if (queries && !fuse_prepare)
         AH_TRY(launch_prepare_queries_only(dv, zero_copy_queries ? h_q : d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
-    // (a small submission on the leaf-tile path makes the binary16 copies of its queries in the launch that places its visits)
-    const bool small_units = tiles && (long long)nq <= tun(TUN_SEARCH_SMALL_UNITS_MAX_QUERIES);
     if (screened && !small_units)
         hipLaunchKernelGGL(k_queries_h16, dim3((unsigned)nq), dim3(64), 0, s, d_qvecs, qstride, ds->dims, ds->hpitch,
                            const_cast<uint16_t *>(ss.q16), const_cast<float4 *>(ss.qstats));
@@ -2863,7 +2881,6 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         const bool small_first = !d_filter_bits || filter_share >= 0.35;
         // few queries: a block of 32 octets per query (one tree per octet: a third of the chain of dependent pops) while the
         // device has the room — arroy's own API is one query per call (src/reader.rs:46-75)
-        const long long block_max_nq = tun(TUN_SEARCH_BLOCK_MAX_QUERIES);
         static std::atomic<bool> lds_opt_in[64];  // once per device: the kernels that want more than 64 KiB of LDS
         // (+ qstride bytes each: the query leaf's copy in LDS; a leaf of more than 32 KiB is refused above)
         const size_t block_lds = block_descend_lds_bytes<32, 128, 32>() + qstride;
@@ -2875,7 +2892,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                                        (int)(block_descend_lds_bytes<32, 128, 32>() + (32u << 10))));
             lds_opt_in[ds->device & 63].store(true, std::memory_order_release);
         }
-        if (small_first && (long long)nq <= block_max_nq) {
+        if (small_first && block_ok) {
             // On the leaf-tile path nothing runs behind the block kernel: what it cannot hold (rare: its capacities, equal keys
             // of two octets across the cut) raises bit 4 of *err and the submission is redone the long way, instead of every
             // small call paying two more launches for passes that find nothing to do.
@@ -3065,6 +3082,9 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         cs.s.fallback_visits = (*h_err & 32u) ? 1 : 0;
         cs.s.fallback_launch = launch_err != hipSuccess ? 1 : 0;
         AH_HIP(hipMemsetAsync(d_err, 0, SS_WORDS * 4, s));
+        // (the block descent was the only writer of the query leaves under fuse_prepare: a launch the runtime rejected has left them
+        // unprepared — the passes below read them; preparing them again when it did run changes nothing)
+        if (queries && fuse_prepare) AH_TRY(launch_prepare_queries_only(dv, h_q, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
     }
     if (wave_descent) AH_TRY(launch_wave(VisitSink{}));
     hipLaunchKernelGGL((k_descend<false>), dim3((unsigned)((nq + 7) / 8)), dim3(64), heap_lds, s, ix->nv, sp,

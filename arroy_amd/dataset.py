@@ -162,6 +162,12 @@ class Dataset:
                                               _ptr(oc)))
         return oi, od, oc
 
+    def rerank_stats(self, reset: bool = False) -> dict:
+        """ah_dataset_rerank_stats: where ah_rerank_batch's wall time went (kept while the tunable AH_RERANK_TIMING is 1)."""
+        st = _lib.AhRerankStats()
+        _lib.check(_lib.lib().ah_dataset_rerank_stats(self._h, C.byref(st), 1 if reset else 0))
+        return {f: getattr(st, f) for f, _ in _lib.AhRerankStats._fields_}
+
     # -- build side --------------------------------------------------------------------------------
     def split_sides(self, normal_vector: np.ndarray, normal_header, sorted_ids=None, want_margins: bool = True):
         """The margin loop (src/writer.rs:1201-1207). Returns (sides u8 per item, n_left, margins)."""

@@ -43,6 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_ITEMS = 1_000_000
+ORACLE_TREES = (0, 99)  # trees of the 10M x 768 x 100 build the oracle also builds, whole, on the host cores (build_10m.oracle_tree)
 DIMS = 768
 N_TREES = 50
 SEED = 42
@@ -83,6 +84,9 @@ def parse_args():
                          "(exit 6 otherwise); always on under --virtual")
     ap.add_argument("--extra", default="", help="comma list of further measurements: metrics (every f32 metric), staging, "
                                                "e2e (10M x 768 staged from host memory + 100-tree build)")
+    ap.add_argument("--cold-child", action="store_true",
+                    help="child mode: the cold end-to-end build of configs[2] (staging from host memory + first build), alone in "
+                         "this process; prints one JSON object")
     ap.add_argument("--scan-only", action="store_true",
                     help="child mode of the live PMC passes: fill the configs[1] dataset, launch the scan --steps times, exit")
     ap.add_argument("--pmc-child", default="scan", choices=["scan", "rerank", "bq_scan"],
@@ -362,19 +366,33 @@ def extra_metrics(device):
     return {"workload": f"{n}x{DIMS} f32 vectors, Q=1 scan", "metrics": out}
 
 
-def _timed_callers(fn, batches, threads):
-    """Seconds to push `batches` through `fn` from `threads` concurrent callers: the median of five timed passes (two
-    untimed passes first so every caller's stream, pinned staging and scratch exist at their final size)."""
+def _timed_callers(fn, batches, threads, passes=9, spread=None):
+    """Seconds to push `batches` through `fn` from `threads` concurrent callers: the median of nine timed passes (two
+    untimed passes first so every caller's stream, pinned staging and scratch exist at their final size).  One caller runs
+    the batches from this thread (no pool hand-off in the timed region).  spread: dict that receives min / max of the passes."""
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(threads) as pool:
+
+    def one_pass(pool):
+        if pool is None:
+            for b in batches:
+                fn(b)
+        else:
+            list(pool.map(fn, batches))
+    pool = ThreadPoolExecutor(threads) if threads > 1 else None
+    try:
         for _ in range(2):
-            list(pool.map(fn, batches))
+            one_pass(pool)
         samples = []
-        for _ in range(5):  # a pass is 2-15 ms: one sample of it is at the mercy of one late thread; the median of five
+        for _ in range(passes):  # a pass is 2-15 ms: one sample of it is at the mercy of one late thread
             t0 = time.perf_counter()
-            list(pool.map(fn, batches))
+            one_pass(pool)
             samples.append(time.perf_counter() - t0)
-        return sorted(samples)[2]
+    finally:
+        if pool is not None:
+            pool.shutdown()
+    if spread is not None:
+        spread.update(min=min(samples), max=max(samples), passes=passes)
+    return sorted(samples)[passes // 2]
 
 
 def extra_c4(device):
@@ -408,21 +426,38 @@ def extra_c4(device):
     # the ~1.5 % whose proven distance interval reaches the top k) — `gb_per_s` counts the bytes THAT path needs per candidate,
     # `f32_equivalent_gb_per_s` the 4 x dims + 8 of the reference's loop (an EFFECTIVE rate, not a roofline fraction)
     per_screen = 2 * dims + 4 + 4 + 0.015 * 4 * dims
+    def phases(threads):
+        """Where one pass's wall time goes inside the library (ah_dataset_rerank_stats, AH_RERANK_TIMING=1; an extra pass, not
+        one of the timed ones): seconds per pass of 1000 queries, summed over the calling threads."""
+        with ahlib.tuning(AH_RERANK_TIMING=1):
+            ds.rerank_stats(reset=True)
+            _timed_callers(lambda a: ds.rerank_batch(a[0], a[1], k), batches, threads, passes=3)
+            st = ds.rerank_stats(reset=True)
+        n_pass = 5  # two warm-up passes + three timed
+        return {key[8:]: st[key] / n_pass for key in st if key.startswith("seconds_")}
     for threads in (1, 4):
-        el = _timed_callers(lambda a: ds.rerank_batch(a[0], a[1], k), batches, threads)
+        sp = {}
+        el = _timed_callers(lambda a: ds.rerank_batch(a[0], a[1], k), batches, threads, spread=sp)
         out[f"callers_{threads}"] = {"queries_per_s": nq / el, "candidates_per_s": total / el,
                                      "gb_per_s": total / el * per_screen / 1e9,
                                      "frac_of_hbm_peak": total / el * per_screen / 1e9 / HBM_PEAK_GBS,
-                                     "f32_equivalent_gb_per_s": total / el * per / 1e9, "seconds": el,
+                                     "f32_equivalent_gb_per_s": total / el * per / 1e9, "seconds": el, "seconds_passes": sp,
+                                     "seconds_by_phase": phases(threads),
                                      "bytes_per_candidate": per_screen, "path": "certified top-k screen (binary16 rows, f32 survivors)"}
     with ahlib.tuning(AH_RERANK_SCREEN=0):  # the f32 gather for every candidate (rounds 1-3)
         for threads in (1, 4):
-            el = _timed_callers(lambda a: ds.rerank_batch(a[0], a[1], k), batches, threads)
+            sp = {}
+            el = _timed_callers(lambda a: ds.rerank_batch(a[0], a[1], k), batches, threads, spread=sp)
             out[f"callers_{threads}_f32_only"] = {"queries_per_s": nq / el, "candidates_per_s": total / el,
                                                   "gb_per_s": total / el * per / 1e9,
-                                                  "frac_of_hbm_peak": total / el * per / 1e9 / HBM_PEAK_GBS, "seconds": el}
+                                                  "frac_of_hbm_peak": total / el * per / 1e9 / HBM_PEAK_GBS, "seconds": el,
+                                                  "seconds_passes": sp, "seconds_by_phase": phases(threads)}
     # one submission with all queries: >= 2 candidates per stored row, so the library re-ranks row-major
     # (each row leaves HBM once per submission instead of once per candidate; DESIGN.md §4)
+    out["phases_note"] = ("seconds_by_phase: one pass of the 1000 queries inside ah_rerank_batch, summed over the callers — prep "
+                          "(tables, scratch, query copy), ids (host copies of the candidate ids into pinned memory), enqueue, "
+                          "sync_wait (the host was done and the device was not: the device-bound share), device_span (HIP events, "
+                          "first enqueue -> stream idle); wall - device_span = what the host alone costs the call")
     el = _timed_callers(lambda a: ds.rerank_batch(a[0], a[1], k), [flat(0, nq)], 1)
     out["one_submission"] = {"queries_per_s": nq / el, "candidates_per_s": total / el,
                              "effective_gb_per_s": total / el * per / 1e9, "seconds": el}
@@ -851,10 +886,82 @@ def host_rows_10m(n):
     return vecs, None
 
 
-def timed_builds(ds, seeds, mode, reps, rank, sync, host_threads=0, tree_keys=None, keyed_out=None):
+def cold_child(args):
+    """`bench.py --cold-child`: the COLD end-to-end build of configs[2], alone in a process that has done nothing else on the
+    device — 10M x 768 f32 rows in pageable host memory -> ten ah_dataset_upload_vectors calls (pinned ring, PCIe) -> finalize
+    -> the first 100-tree build of the dataset (which also makes the binary16 / int8 copies).  The parent starts it BEFORE it
+    touches the GPU itself: what `cold.total_s` means is "first process on the box", not "behind whatever ran before" (round-5
+    review: 2.07 s vs 3.17 s between two runs, depending on how much recently released HBM the driver was still wiping).
+    Prints one JSON object."""
+    import numpy as np
+
+    from arroy_amd import Dataset, distances, shard
+    n = args.build_items
+    seeds = shard.tree_seeds(SEED, range(100))
+    t_rows = time.perf_counter()
+    host_vecs, why = host_rows_10m(n)
+    t_rows = time.perf_counter() - t_rows
+    if host_vecs is None:
+        print(json.dumps({"skipped": why}), flush=True)
+        return
+    chunk = 1_000_000
+    tc = time.perf_counter()
+    ds = Dataset(distances.Cosine, DIMS, n, device=0)
+    t0 = time.perf_counter()
+    # `Writer::build` knows its tree count before it collects the items: the device memory of the first build is obtained on a
+    # helper thread while the records travel (fresh HBM is not free: ah_dataset_reserve_build)
+    ds.reserve_build(len(seeds))
+    for lo in range(0, n, chunk):
+        ds.upload_vectors(np.arange(lo, min(n, lo + chunk), dtype=np.uint32), host_vecs[lo:lo + chunk])
+    t1 = time.perf_counter()
+    ds.finalize()
+    t2 = time.perf_counter()
+    f = ds.build_forest(seeds)  # the first build of the dataset
+    t3 = time.perf_counter()
+    st = f.stats
+    dig = f.digest()[0]
+    f.close()
+    t4 = time.perf_counter()
+    g = ds.build_forest(seeds)  # ... and the second, for the same process's warm figure
+    t5 = time.perf_counter()
+    out = {"workload": f"{n}x{DIMS} cosine staged from pageable host memory (ten 1M-row ah_dataset_upload_vectors calls), then the "
+                       f"first {len(seeds)}-tree build of the dataset (it makes the binary16 / int8 copies)",
+           "means": "a process of its own, started by bench.py before the parent touched the device: the first work this box's GPU sees",
+           "create_s": t0 - tc, "staging_s": t2 - t0, "staging_calls_s": t1 - t0, "staging_gb_per_s": n * DIMS * 4 / (t2 - t0) / 1e9,
+           "first_build_s": t3 - t2, "total_s": t3 - t0, "first_build_library_s": st["seconds_total"],
+           "first_build_device_s": st["seconds_device"], "first_build_setup_s": st.get("seconds_setup"),
+           "reserve_thread_s": st.get("seconds_reserve"), "first_build_waited_for_reserve_s": st.get("seconds_reserve_wait"),
+           "second_build_s": t5 - t4, "digest": f"{dig:016x}", "host_rows_s": t_rows}
+    g.close()
+    ds.close()
+    print(json.dumps(out), flush=True)
+
+
+def run_cold_child(args):
+    """Start `bench.py --cold-child` and wait for it (the parent has not touched the GPU yet).  Returns its JSON or a reason."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cold-child", "--build-items", str(args.build_items)]
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    except (subprocess.SubprocessError, OSError) as e:
+        return {"skipped": f"cold child failed: {type(e).__name__}"}
+    for ln in reversed(p.stdout.strip().splitlines()):
+        try:
+            out = json.loads(ln)
+            out["child_process_s"] = time.perf_counter() - t0
+            return out
+        except ValueError:
+            continue
+    return {"skipped": f"cold child rc={p.returncode}: {p.stderr.strip()[-300:]}"}
+
+
+def timed_builds(ds, seeds, mode, reps, rank, sync, host_threads=0, tree_keys=None, keyed_out=None, hash_trees=None):
     """`reps` builds of `seeds` (barrier + max over ranks each); returns (per-rank seconds, max-over-ranks seconds,
     stats, digest) of the last one.  tree_keys + keyed_out: the last forest's per-tree digests keyed by the trees' indices in
-    the whole index (the same whichever share builds a tree) are stored as keyed_out[tree index] = digest."""
+    the whole index (the same whichever share builds a tree) are stored as keyed_out[tree index] = digest.
+    hash_trees: {position in `seeds`: None} -> filled with the content hash of that whole tree of the last forest (the form the
+    oracle's tree is hashed in: oracle.tree_hash — the checker, after the timed region)."""
     samples, owns, st, dig = [], [], {}, None
     for _rep in range(reps):
         sync.barrier(rank)
@@ -870,6 +977,10 @@ def timed_builds(ds, seeds, mode, reps, rank, sync, host_threads=0, tree_keys=No
                 if tree_keys is not None and keyed_out is not None:
                     for t, d in zip(tree_keys, forest.digest_keyed(tree_keys)):
                         keyed_out[int(t)] = int(d)
+                if hash_trees:
+                    from oracle import oracle as O
+                    for t in hash_trees:
+                        hash_trees[t] = O.tree_hash(forest, t, 4, 4 * DIMS)
             forest.close()
     return owns, samples, st, dig
 
@@ -933,56 +1044,36 @@ def build_10m(args, rank, world, device, sync, ds, result):
     # its share of the cores for its output path instead of the default eight threads each
     host_threads = max(1, usable_cpus()[0] // world) if world > 1 else 0
     keyed = {}
-    out, cold, host_vecs = {}, None, None
+    out, cold, host_vecs = {}, result.get("cold_10m"), None
     if ds is None:
-        # This leg starts from a process that holds nothing: what the legs before it left in the library's device cache goes back
-        # to the driver here.  The driver wipes released HBM in the background (~33 GB/s) — the CPU leg below gives it
-        # the time — and a cold build should not find its buffers in another leg's leftovers either.
+        # What the legs before this one left in the library's device cache goes back to the driver here (the driver wipes
+        # released HBM in the background, ~33 GB/s, DESIGN.md §3 — the CPU leg below gives it the time).
         ahlib.device_cache_trim()
         ds = Dataset(distances.Cosine, DIMS, n, device=device)
         why = "--no-e2e" if args.no_e2e else ("one host copy per rank would not fit" if world > 1 else None)
-        if why is None:
+        if why is None and not args.no_cpu:
             host_vecs, why = host_rows_10m(n)
         if host_vecs is not None:
-            # the CPU leg of configs[2] runs first and the host copy is dropped right after the staging: no GPU build is
-            # timed next to 30.7 GB of rows it does not need (round-3 review: the driver's box punished that)
-            if not args.no_cpu:
-                result["cpu_10m"] = cpu_baseline_10m(args, host_vecs, result.get("cpu"))
-            chunk = 1_000_000
-            t0 = time.perf_counter()
-            # `Writer::build` knows its tree count before it collects the items: the device memory of the first build is
-            # obtained on a helper thread while the records travel (fresh HBM is not free: ah_dataset_reserve_build)
-            ds.reserve_build(len(seeds))
-            for lo in range(0, n, chunk):
-                ds.upload_vectors(np.arange(lo, min(n, lo + chunk), dtype=np.uint32), host_vecs[lo:lo + chunk])
-            t1 = time.perf_counter()
-            ds.finalize()
-            t2 = time.perf_counter()
-            host_vecs = None  # 30.7 GB back to the system before the first build
-            t2b = time.perf_counter()
-            f = ds.build_forest(seeds)  # the first build of the dataset: binary16 + int8 copies, buffers, pinned ring
-            t3 = time.perf_counter()
-            cold = {"workload": f"{n}x{DIMS} cosine staged from pageable host memory (ten 1M-row ah_dataset_upload_vectors calls), "
-                                f"then the first {len(seeds)}-tree build of the dataset (it makes the binary16 / int8 copies)",
-                    "staging_s": t2 - t0, "staging_calls_s": t1 - t0, "staging_gb_per_s": n * DIMS * 4 / (t2 - t0) / 1e9,
-                    "first_build_s": t3 - t2b, "total_s": (t2 - t0) + (t3 - t2b), "first_build_library_s": f.stats["seconds_total"],
-                    "first_build_device_s": f.stats["seconds_device"],
-                    "note": "ah_dataset_reserve_build runs under the staging.  The driver wipes released HBM at ~33 GB/s and a hipMalloc "
-                            "handed such memory waits for it (scripts/micro/fresh_hbm2.py); the legs before this one give their device "
-                            "memory back (ah_device_cache_trim) before the CPU leg, so that this one finds clean memory: total_s 2.1 s "
-                            "(3.3 s when their ~25 GB stayed cached and this leg's ~95 GB reached past the clean range of a fresh box)"}
-            f.close()
-        else:
-            ds.fill_synthetic(SEED, 1, n)
-            ds.finalize()
-            cold = {"skipped": why}
-    if cold is None or "skipped" in cold:
-        if seeds:
-            ds.build_forest(seeds[:1]).close()  # warm-up (shadow copies of the rows, buffers)
+            # the CPU leg of configs[2] (and the oracle's whole trees) from a host copy of the rows; the copy is dropped before any
+            # GPU build is timed (round-3 review: the driver's box punished 30.7 GB of idle rows next to the builds)
+            result["cpu_10m"] = cpu_baseline_10m(args, host_vecs, result.get("cpu"))
+            host_vecs = None
+        # the same rows, generated in HBM (bit-identical to the host generator's: tests/test_gpu_structured.py); the staged,
+        # cold build is the `cold` child process that ran before this process touched the device
+        ds.fill_synthetic(SEED, 1, n)
+        ds.finalize()
+        if cold is None:
+            cold = {"skipped": why or "no cold child (see --no-e2e / --virtual / N > 1)"}
+    if seeds:
+        ds.build_forest(seeds[:1]).close()  # warm-up (shadow copies of the rows, buffers)
     digests = {}
+    # whole trees of THIS build against the oracle's (built on the host cores from the same rows in the CPU leg above)
+    want_whole = (result.get("cpu_10m") or {}).get("oracle_trees") if world == 1 else None
+    gpu_whole = {t: None for t in want_whole} if want_whole else None
     for key, mode, reps in (("screened", 0, 3), ("f32_only", ahlib.MARGIN_EXACT_ONLY, 1)):
         owns, samples, st, digests[key] = timed_builds(ds, seeds, mode, reps, rank, sync, host_threads, trees,
-                                                       keyed if key == "screened" else None)
+                                                       keyed if key == "screened" else None,
+                                                       gpu_whole if key == "screened" else None)
         if rank == 0:
             out[key] = build_entry(samples, st)
         result.setdefault("build_10m_seconds_per_device", {}).setdefault(key, {})[rank] = sorted(owns)[len(owns) // 2]
@@ -1053,23 +1144,42 @@ def build_10m(args, rank, world, device, sync, ds, result):
         share["speedup_from_medians"] = out["screened"]["seconds"] / share["seconds"]
         share["speedup_from_device_seconds"] = out["screened"]["seconds_device"] / share["seconds_device"]
     ds.close()
-    normal = None
+    oracle_tree = None
+    if want_whole:
+        same = {t: gpu_whole[t] == want_whole[t]["hash"] for t in want_whole}
+        oracle_tree = {"trees": sorted(want_whole), "identical": all(same.values()), "per_tree": same,
+                       "hashes": {t: gpu_whole[t] for t in gpu_whole}, "oracle": want_whole,
+                       "oracle_seconds": result["cpu_10m"].get("oracle_trees_seconds"),
+                       "what": "whole trees of the 100-tree build (two_means, every split plane, every side, every Descendants "
+                               "list: the canonical form hashed, oracle.tree_hash) against the trees the CPU oracle builds from the "
+                               "same 10M x 768 rows and seeds (src/writer.rs:1167-1261, src/distance/mod.rs:126-171)"}
+        result.setdefault("build_10m_identical_per_device", {})["oracle_tree"] = oracle_tree["identical"]
+    other_data = {}
     if world == 1 and rank == 0:
-        # the same build on ~N(0,1) rows: long-tailed data is what the quantised copies of
-        # the screen have to survive; both arithmetics again, compared by digest
-        dn = Dataset(distances.Cosine, DIMS, n, device=device)
-        dn.fill_synthetic(SEED, 2, n)
-        dn.finalize()
-        dn.build_forest(seeds[:1]).close()
-        _o, sn, stn, dig_n = timed_builds(dn, seeds, 0, 3, rank, sync)
-        _o, sx, stx, dig_x = timed_builds(dn, seeds, ahlib.MARGIN_EXACT_ONLY, 1, rank, sync)
-        normal = build_entry(sn, stn)
-        normal["data"] = "synthetic ~N(0,1) (sum of twelve uniforms, arroy_hip_policy.h AH_SYNTH_NORMAL), seed 42"
-        normal["f32_only_seconds"] = sx[0]
-        normal["identical"] = bool(dig_n == dig_x)
-        normal["digest"] = f"{dig_n:016x}"
-        result.setdefault("build_10m_identical_per_device", {})["normal"] = normal["identical"]
-        dn.close()
+        # the same build on rows that are not uniform: ~N(0,1) (long-tailed data is what the
+        # quantised copies of the screen have to survive) and CLUSTERED rows (4096 skewed clusters, centre + N(0,1)/16, one row in
+        # 61 an exact copy of its centre — the shape imported embeddings have; margins crowd the planes, imbalance retries and the
+        # random fallback fire, the screens decide least).  Both arithmetics again, compared by digest.
+        for name, dist, desc in (("normal", 2, "synthetic ~N(0,1) (sum of twelve uniforms, arroy_hip_policy.h AH_SYNTH_NORMAL), seed 42"),
+                                 ("clustered", 4, "synthetic CLUSTERED (arroy_hip_policy.h AH_SYNTH_CLUSTERED: 4096 centres ~N(0,1) of "
+                                                  "skewed sizes, rows = centre + N(0,1)/16, 1 row in 61 an exact duplicate of its centre), seed 42")):
+            dn = Dataset(distances.Cosine, DIMS, n, device=device)
+            dn.fill_synthetic(SEED, dist, n)
+            dn.finalize()
+            dn.build_forest(seeds[:1]).close()
+            _o, sn, stn, dig_n = timed_builds(dn, seeds, 0, 3, rank, sync)
+            _o, sx, stx, dig_x = timed_builds(dn, seeds, ahlib.MARGIN_EXACT_ONLY, 1, rank, sync)
+            e = build_entry(sn, stn)
+            e["data"] = desc
+            e["f32_only_seconds"] = sx[0]
+            e["identical"] = bool(dig_n == dig_x)
+            e["digest"] = f"{dig_n:016x}"
+            e["retries"], e["dummy_normals"] = stn.get("retries"), stn.get("dummy_normals")
+            ev = stn.get("margin_evaluations") or 0
+            e["screen_fallbacks_frac"] = stn.get("screen_fallbacks", 0) / ev if ev else None
+            result.setdefault("build_10m_identical_per_device", {})[name] = e["identical"]
+            other_data[name] = e
+            dn.close()
     if rank == 0:
         res = dict(out["screened"])
         res["workload"] = f"{n}x{DIMS} cosine, n_trees=100, trees on device 0: {len(trees)} (t = device mod {world})"
@@ -1086,8 +1196,11 @@ def build_10m(args, rank, world, device, sync, ds, result):
         res["cold"] = cold
         if share is not None:
             res["share_13"] = share
-        if normal is not None:
-            res["normal"] = normal
+        res.update(other_data)
+        if oracle_tree is not None:
+            res["oracle_tree"] = oracle_tree
+        ev = out["screened"].get("margin_evaluations") or 0
+        res["screen_fallbacks_frac"] = (out["screened"].get("screen_fallbacks") or 0) / ev if ev else None
         res["scaling"] = "strong"
         result["build_10m"] = res
 
@@ -1112,11 +1225,124 @@ def cpu_baseline_10m(args, vecs, cpu_1m):
     t0 = time.perf_counter()
     evals = L.ao_build_forest_count(data.c(), 0, seeds.ctypes.data_as(C.c_void_p), k)
     el = time.perf_counter() - t0
+    # ... and WHOLE trees of the headline build for the parity check of build_10m (`oracle_tree`): trees 0 and 99 of the 100, with
+    # bench.py's own seeds, margin loops on all cores; only their content hashes are kept
+    from arroy_amd import shard
+    whole = {}
+    t0 = time.perf_counter()
+    for t in ORACLE_TREES:
+        tr = data.build_tree(0, shard.tree_seeds(SEED, [t])[0])
+        whole[t] = {"hash": O.tree_hash(tr.as_forest(data), 0, 4, 4 * DIMS), "nodes": len(tr.nodes), "retries": tr.retries,
+                    "dummy_normals": tr.dummy_normals, "margin_evaluations": tr.margin_evals}
+        del tr
+    whole_s = time.perf_counter() - t0
     return {"build_seconds_config_2": el * 100.0 / k, "build_seconds_measured": el, "build_trees_measured": k,
+            "oracle_trees": whole, "oracle_trees_seconds": whole_s,
             "build_margins_per_s": evals / el, "cores": cores, "kind": "port",
             "sample": f"{k} of the 100 trees of configs[2], each over all {n}x{DIMS} rows (data in RAM), OpenMP on {cores} threads "
                       f"({'one tree per thread' if k >= cores else 'trees one after the other, margin loops parallel'}): "
                       f"{el:.1f} s, scaled by 100/{k}; C restatement of arroy's path (not arroy)"}
+
+
+def _dig(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or d.get(k) is None:
+            return None
+        d = d[k]
+    return d
+
+
+def _r(x, nd=4):
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}") if abs(x) < 1e4 else round(x, 1)
+    return x
+
+
+def flat_scalars(line):
+    """The numbers this project is judged on, as flat top-level scalars of the JSON line (round-5 review: the nested line is
+    > 8 KB, the driver keeps top-level scalars and a short tail)."""
+    b, c = line.get("build_10m") or {}, _dig(line, "cpu_baseline", "build_10m") or {}
+    out = {
+        "build_1m_seconds": _dig(line, "build", "seconds"),
+        "build_10m_seconds": b.get("seconds"), "build_10m_seconds_device": b.get("seconds_device"),
+        "build_10m_f32_only_seconds": _dig(b, "f32_only", "seconds"),
+        "build_10m_identical": b.get("identical"), "build_10m_screen_fallbacks_frac": b.get("screen_fallbacks_frac"),
+        "build_10m_screen8_decided_frac": b.get("screen8_decided_frac"),
+        "build_10m_oracle_tree_identical": _dig(b, "oracle_tree", "identical"),
+        "build_10m_normal_seconds": _dig(b, "normal", "seconds"), "build_10m_normal_identical": _dig(b, "normal", "identical"),
+        "build_10m_clustered_seconds": _dig(b, "clustered", "seconds"),
+        "build_10m_clustered_seconds_device": _dig(b, "clustered", "seconds_device"),
+        "build_10m_clustered_identical": _dig(b, "clustered", "identical"),
+        "build_10m_clustered_screen8_decided_frac": _dig(b, "clustered", "screen8_decided_frac"),
+        "build_10m_clustered_screen_fallbacks_frac": _dig(b, "clustered", "screen_fallbacks_frac"),
+        "build_10m_clustered_f32_only_seconds": _dig(b, "clustered", "f32_only_seconds"),
+        "build_10m_clustered_retries": _dig(b, "clustered", "retries"),
+        "build_10m_clustered_dummy_normals": _dig(b, "clustered", "dummy_normals"),
+        "share_13_seconds": _dig(b, "share_13", "seconds"), "share_13_seconds_device": _dig(b, "share_13", "seconds_device"),
+        "share_13_speedup": _dig(b, "share_13", "speedup_100_trees_over_share"),
+        "stream_seconds": _dig(b, "stream", "seconds"), "stream_seconds_after_device": _dig(b, "stream", "seconds_after_device"),
+        "cold_total_s": _dig(b, "cold", "total_s"), "cold_staging_gb_per_s": _dig(b, "cold", "staging_gb_per_s"),
+        "cold_first_build_s": _dig(b, "cold", "first_build_s"), "cold_reserve_thread_s": _dig(b, "cold", "reserve_thread_s"),
+        "cpu_build_10m_seconds": c.get("build_seconds_config_2"), "cpu_build_1m_seconds": _dig(line, "cpu_baseline", "build_seconds_config_1"),
+        "rerank_callers_1_qps": _dig(line, "rerank", "callers_1", "queries_per_s"),
+        "rerank_callers_1_frac": _dig(line, "rerank", "callers_1", "frac_of_hbm_peak"),
+        "rerank_callers_4_qps": _dig(line, "rerank", "callers_4", "queries_per_s"),
+        "rerank_f32_qps": _dig(line, "rerank", "callers_1_f32_only", "queries_per_s"),
+        "rerank_f32_frac": _dig(line, "rerank", "callers_1_f32_only", "frac_of_hbm_peak"),
+        "rerank_one_submission_qps": _dig(line, "rerank", "one_submission", "queries_per_s"),
+        "rerank_callers_1_sync_wait_share": None,
+        "bq_scan_frac": _dig(line, "bq_scan", "roofline", "frac"),
+        "search_clustered_qps": _dig(line, "search", "callers_1", "queries_per_s"),
+        "search_distinct_qps": _dig(line, "search", "callers_1_distinct_items", "queries_per_s"),
+        "search_filter_half_qps": _dig(line, "search", "callers_1_filter_half", "queries_per_s"),
+        "search_nq1_p50_us": _dig(line, "search", "latency", "search_nq_1", "p50_us"),
+        "search_nq1_p99_us": _dig(line, "search", "latency", "search_nq_1", "p99_us"),
+        "search_nq8_p50_us": _dig(line, "search", "latency", "search_nq_8", "p50_us"),
+        "rerank_by_vector_p50_us": _dig(line, "search", "latency", "rerank_by_vector", "p50_us"),
+        "search_verified": _dig(line, "search", "verified"),
+        "replicate_10m_gb_per_s_total": _dig(line, "replicate_10m", "gb_per_s_total"),
+        "build_10m_union_digest": _dig(line, "build_10m_union", "digest"),
+        "build_10m_union_identical": _dig(line, "build_10m_union", "identical"),
+    }
+    ph = _dig(line, "rerank", "callers_1", "seconds_by_phase")
+    if ph and ph.get("wall"):
+        out["rerank_callers_1_sync_wait_share"] = ph.get("sync_wait", 0.0) / ph["wall"]
+    per = line.get("build_10m_per_device") or {}
+    for r, v in sorted(per.items(), key=lambda kv: int(kv[0])):
+        if len(per) > 1:  # an N > 1 line: every device's own seconds
+            out[f"build_10m_device_{r}_seconds"] = v.get("seconds")
+            out[f"build_10m_device_{r}_seconds_device"] = v.get("seconds_device")
+    return {k: v for k, v in out.items() if v is not None}
+
+
+def summary_line(line, flat):
+    """< 1.9 KB (the driver keeps a 2 KB tail of stdout): the contract keys, `roofline` / `cpu_baseline` cut to their contract fields, the flat scalars rounded."""
+    keep = ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype")
+    out = {"metric": "distances/sec, Q=1 768-dim cosine scan; build seconds at 10M", "summary": True}
+    out.update({k: _r(line.get(k), 6) for k in keep})
+    out["data"] = "synthetic"
+    out["config"] = {"workload": "1M x 768 cosine Q=1 scan (configs[1])"}
+    roof = line.get("roofline") or {}
+    out["roofline"] = {k: _r(roof.get(k), 5) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    cpu = line.get("cpu_baseline") or {}
+    if cpu:
+        out["cpu_baseline"] = {"value": _r(cpu.get("value"), 4), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+                               "sample": "Q=1 scan of all 1M rows, OpenMP"}
+    short = {"build_10m": "b10m", "clustered": "clu", "seconds": "s", "identical": "same", "screen": "scr", "fallbacks": "fb",
+             "decided": "dec", "callers_": "c", "search": "srch", "rerank": "rr", "device": "dev", "oracle_tree": "otree"}
+    for k, v in flat.items():
+        kk = k
+        for a, b in short.items():
+            kk = kk.replace(a, b)
+        out[kk] = _r(v)
+    # under 1.9 KB whatever a later round adds: the least telling scalars go first (never reached at today's key count)
+    drop = ["b10m_union_digest", "cpu_build_1m_s", "rr_one_submission_qps", "srch_filter_half_qps", "stream_s_after_dev",
+            "b10m_clu_dummy_normals", "b10m_clu_retries", "b10m_clu_f32_only_s", "cold_reserve_thread_s", "rr_by_vector_p50_us"]
+    while len(json.dumps(out, separators=(",", ":"))) > 1900 and drop:
+        out.pop(drop.pop(0), None)
+    return out
 
 
 def dry_run_work(args, rank, world, sync, result):
@@ -1144,8 +1370,16 @@ def main():
     if args.scan_only:
         scan_only(args)
         return
+    if args.cold_child:
+        cold_child(args)
+        return
     env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
     result = {}
+    cold_pre = None
+    if (args.gpus == 1 and env_world <= 1 and not (args.dry_run or args.virtual or args.no_e2e or args.no_build or args.no_build_10m)
+            and args.items == N_ITEMS):
+        cold_pre = run_cold_child(args)  # BEFORE this process touches the device (cold_child's docstring)
+        result["cold_10m"] = cold_pre
     if env_world > 0:
         # one rank per process (python -m torch.distributed.run): the launcher's world must be the --gpus asked for
         world, rank, local_rank = env_world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
@@ -1190,6 +1424,8 @@ def main():
                 print(f"bench.py: --gpus {world} but only {have} device(s) visible", file=sys.stderr)
                 sys.exit(3)
         results = [dict() for _ in range(world)]
+        if cold_pre is not None:
+            results[0]["cold_10m"] = cold_pre
         errors = []
 
         def replicas(n_items):
@@ -1334,7 +1570,14 @@ def main():
                 else:
                     roof["traffic_stored"]["live_attempt"] = how
         srch = line.get("search")
+        flat = flat_scalars(line)
+        # top-level scalars — what the driver's record keeps of a line this long (`parsed`) — appended LAST, so that a tail of
+        # the one stdout line shows them too (round-5 review: share_13 / stream / cold were cut off a > 8 KB line)
+        line.update(flat)
         print(json.dumps(line), flush=True)
+        # the same in short on stderr (stdout stays ONE JSON line, as the contract says): the headline keys, `roofline` and
+        # `cpu_baseline` abridged, every flat scalar, under 1.9 KB
+        print(json.dumps(summary_line(line, flat), separators=(",", ":")), file=sys.stderr, flush=True)
     # a screened forest that differs from the f32-only forest is a wrong result, not a slow one
     same = result.get("build_10m_identical_per_device") or {}
     if same and not all(same.values()):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AH_ABI_VERSION 6   /* v2: ah_node.tree is 32 bits, ah_build_options.margin_mode, ah_build_stats.margin_mode_launches,
+#define AH_ABI_VERSION 7   /* v2: ah_node.tree is 32 bits, ah_build_options.margin_mode, ah_build_stats.margin_mode_launches,
                                   ah_last_error_detail, ah_dataset_replicate, ah_dataset_upload_flush
                               v3: AH_MARGIN_DENSE_MFMA, ah_build_stats.dense_launches / dense_columns (appended)
                               v4: ah_forest_digest, ah_tuning_set / _get / _reset, ah_debug_launch_coverage,
@@ -42,7 +42,11 @@ extern "C" {
                               v5: ah_search_stats / ah_index_search_stats, ah_build_options.max_host_threads (appended),
                                   ah_host_cache_trim, ah_device_cache_trim, ah_dataset_reserve_build, ah_synth_rows_host, ah_build_forest_stream (the node sink during the
                                   build), ah_build_stats.seconds_setup / seconds_after_device / host_blob_recycled
-                              v6: ah_debug_dense_tiles, ah_device_cache_stats, ah_forest_digest_keyed, ah_search_stats.descent_block */
+                              v6: ah_debug_dense_tiles, ah_device_cache_stats, ah_forest_digest_keyed, ah_search_stats.descent_block
+                              v7: ah_build_stats.seconds_reserve / seconds_reserve_wait (appended), ah_rerank_stats /
+                                  ah_dataset_rerank_stats, AH_SYNTH_CLUSTERED / AH_SYNTH_LOW_RANK (arroy_hip_policy.h),
+                                  ah_dataset_replicate falls back to a copy through pinned host memory when the two devices
+                                  have no peer access */
 
 /* every entry point is exported from the shared object (it is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -185,6 +189,22 @@ AH_API int ah_rerank_by_item(ah_dataset *ds, uint32_t query_item, const uint32_t
 AH_API int ah_rerank_batch(ah_dataset *ds, const float *queries, size_t n_queries, const uint32_t *ids,
                     const uint64_t *offsets, size_t k, uint32_t *out_ids, float *out_distances,
                     uint32_t *out_counts);
+
+/* ABI v7.  Where the wall time of ah_rerank_batch went, summed over the calls of every thread since the last reset — kept
+ * only while the tunable AH_RERANK_TIMING is 1 (ah_tuning_set; two extra events and a few clock reads per submission).  A
+ * submission that is slow on one box and not on another shows here whether the host (prep / ids / enqueue) or the device
+ * (sync_wait) paid: bench.py prints it next to the re-rank figures. */
+typedef struct ah_rerank_stats {
+    uint64_t calls;               /* ah_rerank_batch calls (their sub-batches summed)                                     */
+    uint64_t queries, candidates;
+    double seconds_wall;          /* entry -> return                                                                      */
+    double seconds_prep;          /* entry -> first enqueue: argument checks, segment / tile tables, scratch, query copy  */
+    double seconds_ids;           /* host copies of the candidate ids into pinned memory (they overlap the device's work) */
+    double seconds_enqueue;       /* launching copies and kernels (the calls themselves, not their execution)             */
+    double seconds_sync_wait;     /* blocked in hipStreamSynchronize: the device still had work when the host was done    */
+    double seconds_device_span;   /* HIP events: first enqueue of the submission -> its stream idle                       */
+} ah_rerank_stats;
+AH_API int ah_dataset_rerank_stats(ah_dataset *ds, ah_rerank_stats *out, int reset);
 
 /* ------------------------------------------------------------------------------------------
  * Build side (src/writer.rs:1193-1233, 1398-1531; src/distance/mod.rs:126-223)
@@ -340,6 +360,9 @@ typedef struct ah_build_stats {
     double seconds_setup;         /* entry of a batch -> its first launch (device buffers, pinned memory, host blobs)    */
     double seconds_after_device;  /* last launch of a batch -> its return (ids' read-back, node list, teardown)          */
     uint64_t host_blob_recycled;  /* output blobs (normals, ids) taken committed from the pool of destroyed forests     */
+    /* ABI v7: ah_dataset_reserve_build, as the first build after it saw it */
+    double seconds_reserve;       /* run time of the helper thread that obtained the build's device memory under the staging */
+    double seconds_reserve_wait;  /* ... and how long this build waited for it before it started (NOT in seconds_total)      */
 } ah_build_stats;
 
 AH_API int ah_forest_view_get(const ah_forest *forest, ah_forest_view *out);

@@ -37,7 +37,7 @@ use crate::unaligned_vector::UnalignedVector;
 use crate::writer::BuildOption;
 use crate::{Error, ItemId, Result};
 
-pub const AH_ABI_VERSION: c_int = 6;
+pub const AH_ABI_VERSION: c_int = 7;
 const AH_NODE_DESCENDANTS: u8 = 1;
 const AH_NODE_SPLIT: u8 = 2;
 

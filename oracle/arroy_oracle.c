@@ -927,10 +927,19 @@ AO_API uint64_t ao_build_forest_count(const ao_data *d, uint32_t split_after, co
 
 /* Synthetic data of the benchmark harness (include/arroy_hip_policy.h). */
 AO_API void ao_synth_fill(uint64_t seed, int distribution, uint64_t first_item, uint64_t n, uint32_t dims, float *out) {
+    /* the per-dataset part of the structured distributions (cluster centres / factor loadings), computed once */
+    const uint64_t tlen = ah_synth_table_len(dims, distribution);
+    int32_t *table = tlen ? (int32_t *)malloc(tlen * sizeof(int32_t)) : NULL;
+    if (table) ah_synth_table_fill(seed, dims, distribution, table);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)n; i++)
-        for (uint32_t j = 0; j < dims; j++)
-            out[(uint64_t)i * dims + j] = ah_synth_value(seed, first_item + (uint64_t)i, j, dims, distribution);
+        ah_synth_row(seed, first_item + (uint64_t)i, dims, distribution, table, out + (uint64_t)i * dims);
+    free(table);
+}
+
+/* One component straight from the definition (tests: the row-wise fill above must agree with it). */
+AO_API float ao_synth_value(uint64_t seed, uint64_t item, uint32_t dim, uint32_t dims, int distribution) {
+    return ah_synth_value(seed, item, dim, dims, distribution);
 }
 
 AO_API int ao_num_threads(void) { return omp_get_max_threads(); }

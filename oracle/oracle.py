@@ -125,6 +125,8 @@ def lib() -> C.CDLL:
         L.ao_build_forest_count.restype = C.c_uint64
         L.ao_build_forest_count.argtypes = [C.POINTER(AoData), C.c_uint32, C.c_void_p, C.c_uint32]
         L.ao_synth_fill.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
+        L.ao_synth_value.restype = C.c_float
+        L.ao_synth_value.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
         L.ao_build_tree_reference_order.restype = C.c_void_p
         L.ao_build_tree_reference_order.argtypes = [C.POINTER(AoData), C.c_uint32, C.c_void_p]
         L.ao_build_forest_reference_order.restype = C.c_void_p
@@ -360,6 +362,43 @@ class Tree:
             return ("D", tuple(int(x) for x in self.descendants[offset:offset + count]))
         nb = self.normals[offset:offset + self.stride] if has_normal else None
         return ("S", nb, self.canonical(left), self.canonical(right))
+
+
+# enum ah_synth_distribution (include/arroy_hip_policy.h)
+SYNTH_UNIFORM_01, SYNTH_UNIFORM_PM1, SYNTH_NORMAL, SYNTH_NORMAL_OUTLIERS, SYNTH_CLUSTERED, SYNTH_LOW_RANK = range(6)
+SYNTH_NAMES = ("uniform01", "uniform_pm1", "normal", "normal_outliers", "clustered", "low_rank")
+
+
+def tree_hash(forest, tree: int, header_size: int, vector_size: int) -> str:
+    """Numbering-independent content hash of one tree — equal iff `canonical()` is equal, without the nested tuples (a tree
+    over 10M items has 10M ids and ~26 000 nodes).  `forest`: an arroy_amd.Forest or `Tree.as_forest(data)` (the same
+    attributes).  Leaf: H("D" | ids); split: H("S" | normal record [header][vector] or "N" | left | right), bottom-up
+    with an explicit stack."""
+    import hashlib
+    nodes, desc, normals = forest.nodes, forest.descendants, forest.normals
+    stride, ho, vo = int(forest.normal_stride), int(forest._hdr_off), int(forest._vec_off)
+    done = {}
+    stack = [int(forest.roots[tree])]
+    while stack:
+        i = stack[-1]
+        nd = nodes[i]
+        if nd["kind"] == 1:
+            off, cnt = int(nd["offset"]), int(nd["count"])
+            done[i] = hashlib.blake2b(b"D" + np.ascontiguousarray(desc[off:off + cnt], dtype="<u4").tobytes(), digest_size=16).digest()
+            stack.pop()
+            continue
+        left, right = int(nd["left"]), int(nd["right"])
+        if left in done and right in done:
+            if nd["has_normal"]:
+                rec = normals[int(nd["offset"]): int(nd["offset"]) + stride]
+                nb = b"V" + rec[ho:ho + header_size].tobytes() + rec[vo:vo + vector_size].tobytes()
+            else:
+                nb = b"N"
+            done[i] = hashlib.blake2b(b"S" + nb + done.pop(left) + done.pop(right), digest_size=16).digest()
+            stack.pop()
+        else:
+            stack += [x for x in (left, right) if x not in done]
+    return done[int(forest.roots[tree])].hex()
 
 
 def synth(seed: int, distribution: int, n: int, dims: int, first_item: int = 0) -> np.ndarray:

@@ -31,8 +31,11 @@ def one(rng, it):
         span = int(n * rng.choice([2, 50, 100000]))
         ids = np.sort(rng.choice(max(span, n + 1), n, replace=False)).astype(np.uint32)
     scale = float(rng.choice([1.0, 1.0, 1e-3, 1e3, 1e-6, 3e4, 7e-24]))  # the last three leave the binary16 range of the screen; at 7e-24 f32 squares underflow
-    ds, oracle, vecs, ids = T.make_data(cls, n, dims, seed=int(rng.integers(1 << 30)), ids=ids, scale=scale)
-    desc = f"it={it} metric={metric} n={n} dims={dims} sparse={ids[-1] != n - 1} scale={scale}"
+    # half of the draws: numpy's i.i.d. N(0,1); the rest the policy header's outlier / clustered (with exact duplicates) /
+    # low-rank rows — margins crowding the planes, imbalance retries, the random fallback
+    dist = [None, None, None, 3, 4, 5][int(rng.integers(0, 6))]
+    ds, oracle, vecs, ids = T.make_data(cls, n, dims, seed=int(rng.integers(1 << 30)), ids=ids, scale=scale, dist=dist)
+    desc = f"it={it} metric={metric} n={n} dims={dims} sparse={ids[-1] != n - 1} scale={scale} dist={dist}"
     q = (rng.standard_normal(dims) * scale).astype(np.float32)
     qv, qh = oracle.query_leaf(q)
     # distances (scan + gather)

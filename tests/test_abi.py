@@ -11,6 +11,9 @@ from conftest import ROOT
 
 # first row of ah_synth_value(seed 42, AH_SYNTH_NORMAL, dims 8), as bits: pins the generator across compilers / devices
 PINNED_NORMAL_BITS = [[3191097216, 1057535632, 3198033120, 3212783840, 3214833192, 3208274208, 1068122128, 1041940608]]
+# ... and of AH_SYNTH_CLUSTERED / AH_SYNTH_LOW_RANK (the structured distributions of round 6)
+PINNED_CLUSTERED_BITS = [[3187003504, 3205884967, 3212976908, 3216004463, 1074059183, 3218876601, 1073384969, 3200919612]]
+PINNED_LOW_RANK_BITS = [[3195146240, 1058129408, 1071143936, 3199393792, 1067211520, 1075205248, 1076122752, 1070983168]]
 
 
 def declared_symbols():
@@ -32,7 +35,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 def test_abi_scalars_without_a_gpu():
     from arroy_amd import _lib
     L = _lib.lib()
-    assert L.ah_abi_version() == 6
+    assert L.ah_abi_version() == 7
     assert [L.ah_header_size(m) for m in range(7)] == [4, 4, 4, 8, 4, 4, 4]
     assert L.ah_vector_size(2, 768) == 3072
     assert L.ah_vector_size(6, 768) == 96
@@ -98,6 +101,32 @@ def test_policy_header_matches_between_host_compilers():
     w = O.synth(42, 3, 4000, 100)
     assert (w[:, 13] == z[:, 13] * np.float32(20.0)).all() and (np.delete(w, 13, axis=1) == np.delete(z, 13, axis=1)).all()
     assert O.synth(42, 2, 1, 8).view(np.uint32).tolist() == PINNED_NORMAL_BITS
+
+
+def test_structured_synthetic_distributions():
+    """AH_SYNTH_CLUSTERED / AH_SYNTH_LOW_RANK: the row-wise fills (oracle and library, tables computed once) equal the
+    per-component definition `ah_synth_value`; the data has the structure the names promise."""
+    from arroy_amd import _lib
+    from oracle import oracle as O
+    L = O.lib()
+    assert O.synth(42, O.SYNTH_CLUSTERED, 1, 8).view(np.uint32).tolist() == PINNED_CLUSTERED_BITS
+    assert O.synth(42, O.SYNTH_LOW_RANK, 1, 8).view(np.uint32).tolist() == PINNED_LOW_RANK_BITS
+    rng = np.random.default_rng(0)
+    n, dims = 30_000, 48
+    for dist in (O.SYNTH_CLUSTERED, O.SYNTH_LOW_RANK):
+        a = O.synth(9, dist, n, dims, first_item=1000)
+        assert _lib.synth_rows_host(9, dist, n, dims, first_item=1000).tobytes() == a.tobytes()
+        for _ in range(500):
+            i, d = int(rng.integers(0, n)), int(rng.integers(0, dims))
+            assert np.float32(L.ao_synth_value(9, 1000 + i, d, dims, dist)).tobytes() == a[i, d].tobytes(), (dist, i, d)
+        assert abs(float(a.std()) - 1.0) < 0.1
+    c = O.synth(9, O.SYNTH_CLUSTERED, n, dims)
+    _u, inverse, counts = np.unique(c, axis=0, return_inverse=True, return_counts=True)
+    in_groups = int((counts[inverse] > 1).sum())  # rows that have an exact twin: copies of the centres of the big clusters
+    assert counts.max() >= 3 and 0.004 * n < in_groups < n / 61 * 1.3
+    r = O.synth(9, O.SYNTH_LOW_RANK, 2000, 96)
+    sv = np.linalg.svd(r - r.mean(0), compute_uv=False)
+    assert sv[31] > 4 * sv[32]  # 32 factors carry the rows, the rest is the 7 % noise
 
 
 def test_public_headers_are_plain_c99(tmp_path):

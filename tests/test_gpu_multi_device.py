@@ -70,6 +70,38 @@ def test_concurrent_builds_in_one_process_equal_the_sequential_forest():
     ds.close()
 
 
+@pytest.mark.parametrize("sparse", [False, True])
+def test_replicate_through_pinned_host_memory_when_there_is_no_peer_access(sparse):
+    """ABI v7: ah_dataset_replicate checks every array it copied (head and tail read back from both devices) and falls back to
+    a copy through pinned host memory when the destination cannot address the source (or the peer copy fails / delivers other
+    bytes).  AH_REPLICATE_HOST_BOUNCE=1 forces that path where peer access works: the replica must be the dataset — ids,
+    headers, rows, the id lookup table of a sparse id set — bit for bit, and build the same forest."""
+    from arroy_amd import Dataset, shard
+    n, dims = 150_000, 100
+    ds = Dataset(D.Cosine, dims, n)
+    rng = np.random.default_rng(3)
+    vecs = rng.standard_normal((n, dims)).astype(np.float32)
+    ids = np.sort(rng.choice(8 * n, n, replace=False)).astype(np.uint32) if sparse else np.arange(n, dtype=np.uint32)
+    ds.upload_vectors(ids, vecs)
+    ds.finalize()
+    seeds = shard.tree_seeds(5, range(3))
+    want = ds.build_forest(seeds)
+    with _lib.tuning(AH_REPLICATE_HOST_BOUNCE=1):
+        rep = ds.replicate(0)
+    assert len(rep) == n and rep.read_headers().tobytes() == ds.read_headers().tobytes()
+    for i in (0, 1, n // 2, n - 1):
+        assert rep.item_vector(int(ids[i])).tobytes() == vecs[i].tobytes()
+    got = rep.build_forest(seeds)
+    assert got.digest()[0] == want.digest()[0]
+    q = vecs[17]
+    a, b = ds.rerank(20, query=q), rep.rerank(20, query=q)
+    assert list(a[0]) == list(b[0]) and a[1].tobytes() == b[1].tobytes()
+    for x in (got, want):
+        x.close()
+    rep.close()
+    ds.close()
+
+
 def test_two_devices_build_disjoint_tree_sets_equal_to_the_one_device_forest():
     import arroy_amd
     if arroy_amd.device_count() < 2:

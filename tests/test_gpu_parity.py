@@ -39,10 +39,15 @@ def assert_bit_equal(a, b, what=""):
     assert bad.size == 0, f"{what}: {bad.size} of {a.size} differ, first at {bad[:5]}: {a[bad[:5]]} vs {b[bad[:5]]}"
 
 
-def make_data(metric_cls, n, dims, seed, ids=None, scale=1.0):
+def make_data(metric_cls, n, dims, seed, ids=None, scale=1.0, dist=None):
+    """dist: None = numpy's N(0,1) * scale, or a distribution of include/arroy_hip_policy.h (the structured ones: clustered
+    rows with exact duplicates, rows near a 32-dimensional subspace), scaled the same way."""
     from arroy_amd import Dataset
     rng = np.random.default_rng(seed)
-    vecs = (rng.standard_normal((n, dims)) * scale).astype(np.float32)
+    if dist is None:
+        vecs = (rng.standard_normal((n, dims)) * scale).astype(np.float32)
+    else:
+        vecs = (O.synth(seed, dist, n, dims).astype(np.float64) * scale).astype(np.float32)
     # a few exact duplicates and zeros: ties and degenerate norms
     if n > 10:
         vecs[3] = vecs[1]

@@ -66,7 +66,11 @@ def test_small_submissions_equal_the_oracle_and_every_switch_setting(world):
             assert base[1][qi, :len(want)].tobytes() == np.array([d for _, d in want], dtype=np.float32).tobytes(), (nq, qi)
         for knob in SMALL_KNOBS:  # one off at a time
             with _lib.tuning(**{knob: 0}):
+                index.stats(reset=True)
                 assert same(index.search(count, queries=qs, search_k=sk, raw=True), base), (nq, knob)
+                # ... and none of the combinations is "saved" by the fall-back (round 6: block descent on + k_units_small off
+                # used to screen against binary16 copies of query leaves nobody had prepared yet)
+                assert index.stats()["fallback_chunks"] == 0, (nq, knob, index.stats())
         with _lib.tuning(**{k: 0 for k in SMALL_KNOBS}):  # the big submissions' path on the same queries
             assert same(index.search(count, queries=qs, search_k=sk, raw=True), base), nq
         # the same queries one per call
@@ -99,10 +103,18 @@ def test_more_visits_than_the_one_block_unit_builder_holds_fall_back(world):
     _ds, od, forest, index, queries, vecs = world
     n = vecs.shape[0]
     count, sk = 10, n // 3
-    index.stats(reset=True)
-    got = index.search(count, queries=queries[:64], search_k=sk, raw=True)
-    st = index.stats()
+    with _lib.tuning(AH_SEARCH_SMALL_GATE=0):  # as before round 6: the call starts on the small kernels whatever it will open
+        index.stats(reset=True)
+        got = index.search(count, queries=queries[:64], search_k=sk, raw=True)
+        st = index.stats()
     assert st["fallback_chunks"] >= 1 or st["tile_visits"] <= 2048, st
+    # default: the host's estimate of the leaves a query opens (search_k / mean leaf + trees) sends such a call past the small
+    # kernels from the start — the same answers, no chunk redone (round-5 advice)
+    index.stats(reset=True)
+    gated = index.search(count, queries=queries[:64], search_k=sk, raw=True)
+    st = index.stats()
+    assert st["fallback_chunks"] == 0 and st["tile_visits"] > 2048, st
+    assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(got, gated))
     for qi in (0, 17, 63):
         want = oracle_search(od, forest, queries[qi], count, sk)
         assert list(got[0][qi, :got[2][qi]]) == [i for i, _ in want], qi
