@@ -2827,13 +2827,15 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     // redone the long way — correct, and more than twice the latency (round-5 advice: 128-d data at search_k = 10 000 opens
     // ~100 leaves per query, a 3-tree index more than 32 per tree).  So: an estimate of the leaves one query opens — search_k
     // items at the index's mean leaf size (what a filter keeps of it), a quarter more for leaves smaller than the mean — decides
-    // on the host whether a call starts there at all.  AH_SEARCH_SMALL_GATE=0: as before (the overflow tests force the
+    // on the host whether a call starts there at all (at most 8 estimated leaves per octet, 0.8 x kSmallVisits visits per call).  AH_SEARCH_SMALL_GATE=0: as before (the overflow tests force the
     // fall-backs with it).
     bool block_fits = true, small_units_fit = true;
     if (tun(TUN_SEARCH_SMALL_GATE) != 0 && ix->n_leaves) {
         const double mean_leaf = std::max(1.0, (double)ix->desc_len / ix->n_leaves * (d_filter_bits ? std::max(filter_share, 1e-3) : 1.0));
         const double est_leaves = 1.25 * (double)search_k / mean_leaf + 2.0;
-        block_fits = est_leaves / std::max(1u, std::min(ix->n_trees, 32u)) <= 24.0;
+        // (measured, round 6: 64 queries x ~18 estimated leaves per octet overflowed the block kernel — the best-first order does
+        // not spread a query's leaves evenly over the trees; the benchmarked shapes sit near 1 per octet)
+        block_fits = est_leaves / std::max(1u, std::min(ix->n_trees, 32u)) <= 8.0;
         small_units_fit = (double)nq * est_leaves <= 0.8 * kSmallVisits;
     }
     const bool block_ok = block_fits && (long long)nq <= tun(TUN_SEARCH_BLOCK_MAX_QUERIES);

@@ -95,6 +95,119 @@ mod item_iter;
             roots.push(new_id);
             descendants.insert(new_id, item_indices.clone());
         }
+"""), (
+        # insert_items_in_current_trees: a big insertion goes down all the existing trees on the GPU
+        """        if roots.is_empty() {
+            return Ok(IntMap::default());
+        }
+
+        let mut descendants = IntMap::<ItemId, RoaringBitmap>::default();
+""",
+        """        if roots.is_empty() {
+            return Ok(IntMap::default());
+        }
+
+        // With the `hip` feature a big insertion is routed on the GPU: the new items and the split planes of the existing
+        // trees are staged, every item goes down every tree in one call (`D::side` at each split, a keyed coin where the
+        // normal is `None`), and the Descendants nodes that received items come back as `stored items | new items`.  A
+        // small one keeps the walk below: a few margins per item and tree cost less than mirroring the trees in HBM.
+        #[cfg(feature = "hip")]
+        if to_insert.len() >= crate::hip::ROUTE_MIN_ITEMS {
+            return crate::hip::route_into_current_trees(
+                rng,
+                options,
+                &to_insert,
+                roots,
+                frozen_reader.leafs,
+                frozen_reader.trees,
+                self.dimensions,
+                self.index,
+                &progress,
+            );
+        }
+
+        let mut descendants = IntMap::<ItemId, RoaringBitmap>::default();
+"""), (
+        # insert_descendants_in_file_and_spawn_tasks: the large descendants of one call become ONE device call
+        """        let mut tmp_node = tmp_node.borrow_mut();
+
+        for (item_id, item_indices) in descendants.into_iter() {
+            options.cancelled()?;
+            if error_snd.is_full() {
+                return Ok(());
+            }
+            if let Some(nb_descendants_progress) = nb_descendants_progress {
+""",
+        """        let mut tmp_node = tmp_node.borrow_mut();
+        // With the `hip` feature the descendants that outgrew `split_after` are not handed to rayon tasks one by one
+        // (`incremental_index_large_descendant`): they are collected and built as sub-trees in ONE device call after the loop.
+        #[cfg(feature = "hip")]
+        let mut large: Vec<(ItemId, RoaringBitmap)> = Vec::new();
+
+        for (item_id, item_indices) in descendants.into_iter() {
+            options.cancelled()?;
+            if error_snd.is_full() {
+                return Ok(());
+            }
+            if let Some(nb_descendants_progress) = nb_descendants_progress {
+"""), (
+        """            } else {
+                let tmp_nodes = tmp_nodes.clone();
+                let rng = StdRng::from_seed(rng.gen());
+                let error_snd = error_snd.clone();
+                let nb_items_progress = nb_items_progress.clone();
+                scope.spawn(move |s| {
+""",
+        """            } else {
+                #[cfg(feature = "hip")]
+                {
+                    large.push((item_id, item_indices));
+                    continue;
+                }
+                #[cfg(not(feature = "hip"))]
+                {
+                let tmp_nodes = tmp_nodes.clone();
+                let rng = StdRng::from_seed(rng.gen());
+                let error_snd = error_snd.clone();
+                let nb_items_progress = nb_items_progress.clone();
+                scope.spawn(move |s| {
+"""), (
+        """                            let _ = error_snd.try_send(Error::Panic(msg.to_string()));
+                        }
+                    }
+                });
+            }
+        }
+
+        if nb_descendants_progress.is_some() {
+""",
+        """                            let _ = error_snd.try_send(Error::Panic(msg.to_string()));
+                        }
+                    }
+                });
+                }
+            }
+        }
+
+        #[cfg(feature = "hip")]
+        if !large.is_empty() {
+            // `make_tree_in_file` over every large descendant, and over whatever is still too large below it, on the device:
+            // only the members of these descendants are staged; the nodes land in this thread's `TmpNodes`, children first,
+            // the root of every sub-tree under the id of the descendant it replaces.
+            crate::hip::build_large_descendants(
+                &mut rng,
+                options,
+                frozen_reader.leafs,
+                frozen_reader.concurrent_node_ids,
+                self.dimensions,
+                self.index,
+                large,
+                &mut tmp_node,
+                &nb_items_progress,
+            )?;
+        }
+
+        if nb_descendants_progress.is_some() {
 """)],
     "src/reader.rs": [(
         """        let mut nns_distances = Vec::with_capacity(nns.len());
@@ -168,8 +281,23 @@ impl<'t, D: Distance> Reader<'t, D> {
             next += 1;
         }
         reachable.sort_unstable();
-        reachable.dedup();
-        let rank = |id: &NodeId| reachable.binary_search(id).map(|i| i as u32).map_err(|_| Error::missing_key(Key::new(self.index, *id)));
+        // A tree node is reached once (the trees are a forest).  An ITEM that splits point to directly (`Leaf` children, written
+        // by older arroy versions, src/reader.rs) may hang under several parents: it stays once per parent — a one-id leaf each,
+        // equal `NodeId`s are interchangeable in the reference's heap — because `ah_index_create_from_view` takes forests only.
+        reachable.dedup_by(|a, b| a == b && a.mode != crate::NodeMode::Item);
+        let mut handed_out = std::collections::BTreeMap::<NodeId, u32>::new();
+        let mut rank = |id: &NodeId| -> Result<u32> {
+            let first = reachable.partition_point(|x| x < id);
+            if first == reachable.len() || reachable[first] != *id {
+                return Err(Error::missing_key(Key::new(self.index, *id)));
+            }
+            if id.mode != crate::NodeMode::Item {
+                return Ok(first as u32);
+            }
+            let nth = handed_out.entry(*id).or_insert(0);
+            *nth += 1;
+            Ok(first as u32 + *nth - 1)
+        };
         let vector_len = crate::hip::vector_len::<D>(self.dimensions);
         let mut image = crate::hip::ForestImage::new::<D>(vector_len);
         for id in &reachable {
@@ -205,6 +333,55 @@ impl<'t, D: Distance> Reader<'t, D> {
         let staged = self.hip.as_ref().ok_or_else(|| Error::Panic("Reader::stage_on_gpu has not been called".to_string()))?;
         staged.search_batch(vectors, count, search_k.map_or(0, NonZeroUsize::get), oversampling.map_or(0, NonZeroUsize::get), candidates)
     }
+
+    /// `nns_by_item` for many items at once, entirely on the GPU (`hip` feature, after `stage_on_gpu`): the query leaves are the
+    /// stored items themselves (header included), as `QueryBuilder::by_item` reads them.  An id that is not stored is
+    /// `Error::MissingKey` (the reference answers `None` for that one item).
+    #[cfg(feature = "hip")]
+    pub fn nns_by_items_on_gpu(
+        &self,
+        items: &[ItemId],
+        count: usize,
+        search_k: Option<NonZeroUsize>,
+        oversampling: Option<NonZeroUsize>,
+        candidates: Option<&RoaringBitmap>,
+    ) -> Result<Vec<Vec<(ItemId, f32)>>> {
+        let staged = self.hip.as_ref().ok_or_else(|| Error::Panic("Reader::stage_on_gpu has not been called".to_string()))?;
+        staged.search_batch_items(items, count, search_k.map_or(0, NonZeroUsize::get), oversampling.map_or(0, NonZeroUsize::get), candidates)
+    }
+""")],
+    "src/distance/dot_product.rs": [(
+        """        // Step one: compute the norm of each vector and find the maximum norm
+        let mut max_norm = 0.0;
+""",
+        """        // With the `hip` feature both passes' arithmetic runs on the GPU: the records are staged from the pages the first
+        // iterator walks, the device computes the max norm and every item's `{extra_dim, norm}` (the same f32 operations in the
+        // same order), and the second pass below only writes the headers back.
+        #[cfg(feature = "hip")]
+        {
+            let headers = crate::hip::preprocess_dot_records::<Self>(new_iter(wtxn)?)
+                .map_err(|e| heed::Error::Encoding(Box::new(e)))?;
+            if let Some(headers) = headers {
+                let mut cursor = new_iter(wtxn)?;
+                let mut nth = 0;
+                while let Some((item_id, node)) = cursor.next().transpose()? {
+                    let leaf = match node.leaf() {
+                        Some(leaf) => leaf,
+                        None => break,
+                    };
+                    let mut leaf = leaf.into_owned();
+                    leaf.header.extra_dim = headers[nth][0];
+                    leaf.header.norm = headers[nth][1];
+                    nth += 1;
+                    // safety: We do not keep a reference to the current value, we own it.
+                    unsafe { cursor.put_current(&item_id, &Node::Leaf(leaf))? };
+                }
+                return Ok(());
+            }
+        }
+
+        // Step one: compute the norm of each vector and find the maximum norm
+        let mut max_norm = 0.0;
 """)],
 }
 

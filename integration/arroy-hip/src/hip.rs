@@ -1,6 +1,6 @@
 //! MI355X back end of arroy's hot loops (cargo feature `hip`).
 //!
-//! Thin `extern "C"` bindings of `libarroy_hip.so` (`include/arroy_hip.h`, ABI v6) plus the places where arroy hands a
+//! Thin `extern "C"` bindings of `libarroy_hip.so` (`include/arroy_hip.h`, ABI v7) plus the places where arroy hands a
 //! whole *loop* to the GPU instead of running it per item:
 //!
 //! * [`stage_leafs`]  — `ImmutableLeafs::new` (`src/parallel.rs`): the stored item records, straight from their LMDB
@@ -12,9 +12,14 @@
 //! * [`HipSearch`] — the WHOLE `nns_by_leaf` (best-first descent, candidate collection, sort + dedup, re-rank, top-k) for a
 //!   batch of queries in one call (`ah_search_batch`), over a mirror of the tree nodes made by `Reader::stage_on_gpu`
 //!   ([`ForestImage`] -> `ah_index_create_from_view`);
-//! * [`route_items`], [`build_subtrees`], [`preprocess_dot`] — the incremental insert
-//!   (`insert_items_in_descendants_from_frozen_reader`, `incremental_index_large_descendant`) and
-//!   `DotProduct::preprocess` on the device: bound and wrapped here, call sites not patched yet.
+//! * [`route_into_current_trees`] — `Writer::insert_items_in_current_trees` (`insert_items_in_descendants_from_frozen_reader`
+//!   for every tree): a big insertion is sent down all the existing trees in one call (`ah_route_items`) over a mirror of the
+//!   tree nodes made from `ImmutableTrees` ([`image_of_trees`]);
+//! * [`build_large_descendants`] — the `incremental_index_large_descendant` tasks of one
+//!   `insert_descendants_in_file_and_spawn_tasks` call: every Descendants node that outgrew `split_after` becomes a sub-tree in
+//!   ONE device call (`ah_build_subtrees`), its nodes appended to the caller's `TmpNodes`;
+//! * [`preprocess_dot_records`] — both passes of `DotProduct::preprocess` (the max norm, every item's `extra_dim` / `norm`) on
+//!   the device, from the pages the reference's first pass walks; the second pass only writes the headers back.
 //!
 //! LMDB, roaring, `NodeCodec`, `TmpNodes`, node-id allocation, the RNG and the public API stay as they are.
 //! Link with `RUSTFLAGS="-L <dir of libarroy_hip.so>"`; the library needs `libamdhip64` at run time.
@@ -27,15 +32,16 @@ use std::os::raw::{c_char, c_int, c_void};
 use std::sync::atomic::{AtomicI32, AtomicU64, Ordering};
 
 use bytemuck::pod_read_unaligned;
-use rand::Rng;
+use nohash::IntMap;
+use rand::{Rng, RngCore};
 use roaring::RoaringBitmap;
 
 use crate::distance::Distance;
 use crate::node::{Descendants, Leaf, Node, SplitPlaneNormal};
-use crate::parallel::{ConcurrentNodeIds, ImmutableLeafs, TmpNodes};
+use crate::parallel::{ConcurrentNodeIds, ImmutableLeafs, ImmutableTrees, TmpNodes};
 use crate::unaligned_vector::UnalignedVector;
 use crate::writer::BuildOption;
-use crate::{Error, ItemId, Result};
+use crate::{Error, ItemId, Key, Result};
 
 pub const AH_ABI_VERSION: c_int = 7;
 const AH_NODE_DESCENDANTS: u8 = 1;
@@ -667,15 +673,41 @@ impl<D: Distance> HipSearch<D> {
         if self.dimensions == 0 || queries.len() % self.dimensions != 0 {
             return Err(Error::InvalidVecDimension { expected: self.dimensions, received: queries.len() });
         }
-        let nq = queries.len() / self.dimensions;
+        self.search(queries.as_ptr(), std::ptr::null(), queries.len() / self.dimensions, count, search_k, oversampling, candidates)
+    }
+
+    /// `QueryBuilder::by_item` for many stored items at once: the query leaves are the items' own records in HBM, header
+    /// included (src/reader.rs `by_item` -> `item_leaf` -> `nns_by_leaf`).  An id that is not stored is `Error::MissingKey`.
+    pub fn search_batch_items(
+        &self,
+        items: &[ItemId],
+        count: usize,
+        search_k: usize,
+        oversampling: usize,
+        candidates: Option<&RoaringBitmap>,
+    ) -> Result<Vec<Vec<(ItemId, f32)>>> {
+        self.search(std::ptr::null(), items.as_ptr(), items.len(), count, search_k, oversampling, candidates)
+    }
+
+    #[allow(clippy::too_many_arguments)]
+    fn search(
+        &self,
+        queries: *const f32,
+        query_items: *const u32,
+        nq: usize,
+        count: usize,
+        search_k: usize,
+        oversampling: usize,
+        candidates: Option<&RoaringBitmap>,
+    ) -> Result<Vec<Vec<(ItemId, f32)>>> {
         let filter: Option<Vec<u32>> = candidates.map(|c| c.iter().collect()); // ascending: RoaringBitmap order
         let (mut ids, mut dists, mut counts) = (vec![0u32; nq * count], vec![0f32; nq * count], vec![0u32; nq]);
         check(
             unsafe {
                 ah_search_batch(
                     self.index,
-                    queries.as_ptr(),
-                    std::ptr::null(),
+                    queries,
+                    query_items,
                     nq,
                     count,
                     search_k,
@@ -720,13 +752,13 @@ impl<D: Distance> Rerank for HipSearch<D> {
 /// `incremental_index_large_descendant` (src/writer.rs): `make_tree_in_file` over every Descendants node that outgrew
 /// `split_after`, all of them in one call — sub-tree `t` covers the ascending ids `subsets[t]`.  The nodes come back through
 /// `visit` in post-order per sub-tree (children before parents, as `TmpNodes::put` receives them), with sub-forest-local
-/// indices: `(subtree, node, split: Option<(left, right, normal record)>, descendants)`.
+/// indices: `visit(node index, node, view)`; `view.roots[t]` is the root of sub-tree `t`.
 pub fn build_subtrees<D: Distance, R: Rng>(
     leafs: &HipLeafs<D>,
     rng: &mut R,
     options: &BuildOption,
     subsets: &[Vec<ItemId>],
-    mut visit: impl FnMut(&AhNode, &AhForestView) -> Result<()>,
+    mut visit: impl FnMut(u32, &AhNode, &AhForestView) -> Result<()>,
 ) -> Result<()> {
     let seeds: Vec<u64> = (0..subsets.len()).map(|_| rng.gen()).collect();
     let mut offsets = Vec::with_capacity(subsets.len() + 1);
@@ -754,7 +786,7 @@ pub fn build_subtrees<D: Distance, R: Rng>(
     let outcome = check(unsafe { ah_forest_view_get(forest, view.as_mut_ptr()) }, leafs.index).and_then(|()| {
         let view = unsafe { view.assume_init() };
         let nodes = unsafe { std::slice::from_raw_parts(view.nodes, view.n_nodes as usize) };
-        nodes.iter().try_for_each(|nd| visit(nd, &view))
+        nodes.iter().enumerate().try_for_each(|(i, nd)| visit(i as u32, nd, &view))
     });
     unsafe { ah_forest_destroy(forest) };
     outcome
@@ -762,7 +794,7 @@ pub fn build_subtrees<D: Distance, R: Rng>(
 
 /// `DotProduct::preprocess` (src/distance/dot_product.rs) on the staged items: the max norm, then `extra_dim` / `norm` of
 /// every item, on the device; returns the headers in item order (8 bytes each) for the caller to write back into LMDB.
-pub fn preprocess_dot<D: Distance>(leafs: &HipLeafs<D>, n_items: usize) -> Result<Vec<[f32; 2]>> {
+fn preprocess_dot<D: Distance>(leafs: &HipLeafs<D>, n_items: usize) -> Result<Vec<[f32; 2]>> {
     let mut max_norm = 0f32;
     check(unsafe { ah_preprocess_dot(leafs.ds, &mut max_norm) }, leafs.index)?;
     let mut headers = vec![[0f32; 2]; n_items];
@@ -771,4 +803,204 @@ pub fn preprocess_dot<D: Distance>(leafs: &HipLeafs<D>, n_items: usize) -> Resul
         leafs.index,
     )?;
     Ok(headers)
+}
+
+/// Smallest insertion `Writer::insert_items_in_current_trees` routes on the GPU: below it the reference's own walk — a few
+/// margins per item and tree, no staging — is cheaper than mirroring the split planes of every tree in HBM.
+pub const ROUTE_MIN_ITEMS: u64 = 4096;
+
+/// The tree nodes reachable from `roots` as a [`ForestImage`], from the frozen view `Writer::build` holds
+/// (`ImmutableTrees`, src/parallel.rs): local index = rank of the node's id, so ties between nodes fall as in the reference.
+/// Also returns the id of every local node.
+pub fn image_of_trees<D: Distance>(
+    trees: &ImmutableTrees<D>,
+    roots: &[ItemId],
+    index: u16,
+    dimensions: usize,
+) -> Result<(ForestImage, Vec<ItemId>)> {
+    let get = |id: ItemId| -> Result<Node<D>> { trees.get(id)?.ok_or_else(|| Error::missing_key(Key::tree(index, id))) };
+    let mut reachable: Vec<ItemId> = roots.to_vec();
+    let mut next = 0;
+    while next < reachable.len() {
+        if let Node::SplitPlaneNormal(SplitPlaneNormal { left, right, .. }) = get(reachable[next])? {
+            reachable.push(left);
+            reachable.push(right);
+        }
+        next += 1;
+    }
+    reachable.sort_unstable();
+    reachable.dedup();
+    let rank = |id: ItemId| {
+        reachable.binary_search(&id).map(|i| i as u32).map_err(|_| Error::missing_key(Key::tree(index, id)))
+    };
+    let mut image = ForestImage::new::<D>(vector_len::<D>(dimensions));
+    for id in &reachable {
+        match get(*id)? {
+            Node::Leaf(_) => unreachable!("a tree node is a Descendants or a SplitPlaneNormal"),
+            Node::Descendants(Descendants { descendants }) => image.push_descendants(descendants.iter()),
+            Node::SplitPlaneNormal(SplitPlaneNormal { normal, left, right }) => {
+                image.push_split::<D>(rank(left)?, rank(right)?, normal.as_ref())
+            }
+        }
+    }
+    for root in roots {
+        image.push_root(rank(*root)?);
+    }
+    Ok((image, reachable))
+}
+
+/// `Writer::insert_items_in_current_trees` (src/writer.rs) on the GPU: every item of `to_insert` goes down every tree of
+/// `roots` (`insert_items_in_descendants_from_frozen_reader`: `D::side` at every split, a coin where `normal` is `None`) in
+/// one `ah_route_items` call; returns, like the reference, the Descendants nodes that received items, each as
+/// `its stored items | the new ones`.  Only the NEW items are staged (their rows are the only ones the margins read) plus
+/// the split planes of the trees.  The coin of a `normal: None` node is keyed by `(seed + root, node, item)` — the
+/// reference seeds one sequential `R::seed_from_u64(seed + root)` per tree with the same `seed`.
+#[allow(clippy::too_many_arguments)]
+pub fn route_into_current_trees<D: Distance, R: Rng>(
+    rng: &mut R,
+    options: &BuildOption,
+    to_insert: &RoaringBitmap,
+    roots: &[ItemId],
+    leafs: &ImmutableLeafs<D>,
+    trees: &ImmutableTrees<D>,
+    dimensions: usize,
+    index: u16,
+    progress: &AtomicU64,
+) -> Result<IntMap<ItemId, RoaringBitmap>> {
+    options.cancelled()?;
+    let staged = stage_leafs(leafs, to_insert, dimensions, index, 0, true)?;
+    let (image, node_of_local) = image_of_trees(trees, roots, index, dimensions)?;
+    let search = HipSearch::new(staged, &image, dimensions)?;
+    let seed = rng.next_u64(); // `repeat_n(rng.next_u64(), roots.len())`
+    let seeds: Vec<u64> = roots.iter().map(|root| seed.wrapping_add(*root as u64)).collect();
+    let items: Vec<ItemId> = to_insert.iter().collect();
+    let landed = search.route_items(&items, &seeds)?; // [tree][item] -> local index of a Descendants node
+    let mut descendants = IntMap::<ItemId, RoaringBitmap>::default();
+    for tree in 0..roots.len() {
+        options.cancelled()?;
+        for (i, item) in items.iter().enumerate() {
+            let node = node_of_local[landed[tree * items.len() + i] as usize];
+            descendants.entry(node).or_default().insert(*item); // ascending: `items` is the bitmap's order
+        }
+        progress.fetch_add(items.len() as u64, Ordering::Relaxed);
+    }
+    for (node, bitmap) in descendants.iter_mut() {
+        // `descendants.into_owned() | to_insert`
+        match trees.get(*node)?.ok_or_else(|| Error::missing_key(Key::tree(index, *node)))? {
+            Node::Descendants(Descendants { descendants: stored }) => *bitmap |= stored.as_ref(),
+            _ => unreachable!("ah_route_items ends at Descendants nodes"),
+        }
+    }
+    Ok(descendants)
+}
+
+/// The `incremental_index_large_descendant` tasks of one `insert_descendants_in_file_and_spawn_tasks` call
+/// (src/writer.rs): `large` = the Descendants nodes that no longer fit (`(their id, their items)`).  Only their members are
+/// staged; `ah_build_subtrees` builds every sub-tree down to nodes that fit (`make_tree_in_file` + the recursion of the spawned
+/// tasks) in one call, and the nodes are appended to `tmp_nodes` children first, as `make_tree_in_file` writes them: the root
+/// of a sub-tree keeps the id of the descendant it replaces (`next_id: Some(descendant_id)`), every other node takes the next
+/// free id.  The whole subset is resident in HBM, so the reference's `fit_in_memory` rounds have nothing to do here.
+#[allow(clippy::too_many_arguments)]
+pub fn build_large_descendants<D: Distance, R: Rng>(
+    rng: &mut R,
+    options: &BuildOption,
+    leafs: &ImmutableLeafs<D>,
+    node_ids: &ConcurrentNodeIds,
+    dimensions: usize,
+    index: u16,
+    large: Vec<(ItemId, RoaringBitmap)>,
+    tmp_nodes: &mut TmpNodes<D>,
+    items_progress: &AtomicU64,
+) -> Result<()> {
+    options.cancelled()?;
+    let mut members = RoaringBitmap::new();
+    for (_, items) in &large {
+        members |= items;
+    }
+    let staged = stage_leafs(leafs, &members, dimensions, index, 0, true)?;
+    let subsets: Vec<Vec<ItemId>> = large.iter().map(|(_, items)| items.iter().collect()).collect();
+    let vector_len = staged.vector_len;
+    let mut global: Vec<ItemId> = Vec::new(); // sub-forest-local index -> tree node id
+    let mut roots_known = false;
+    build_subtrees(&staged, rng, options, &subsets, |i, nd, view| {
+        if !roots_known {
+            global = vec![UNSET; view.n_nodes as usize];
+            let roots = unsafe { std::slice::from_raw_parts(view.roots, view.n_trees as usize) };
+            for (t, root) in roots.iter().enumerate() {
+                global[*root as usize] = large[t].0;
+            }
+            roots_known = true;
+        }
+        if global[i as usize] == UNSET {
+            global[i as usize] = node_ids.next()?;
+        }
+        let id = global[i as usize];
+        if nd.kind == AH_NODE_DESCENDANTS {
+            let ids = unsafe { std::slice::from_raw_parts(view.descendants.add(nd.offset as usize), nd.count as usize) };
+            let bitmap =
+                RoaringBitmap::from_sorted_iter(ids.iter().copied()).map_err(|e| Error::Panic(e.to_string()))?;
+            items_progress.fetch_add(nd.count as u64, Ordering::Relaxed);
+            tmp_nodes.put(id, &Node::Descendants(Descendants { descendants: Cow::Owned(bitmap) }))?;
+        } else {
+            let normal = if nd.has_normal != 0 {
+                let rec = unsafe {
+                    std::slice::from_raw_parts(view.normals.add(nd.offset as usize), view.normal_stride as usize)
+                };
+                let header: D::Header =
+                    pod_read_unaligned(&rec[view.normal_header_offset as usize..][..size_of::<D::Header>()]);
+                let vector =
+                    UnalignedVector::<D::VectorCodec>::from_bytes(&rec[view.normal_vector_offset as usize..][..vector_len])
+                        .map_err(|e| Error::Panic(format!("{e:?}")))?;
+                Some(Leaf { header, vector })
+            } else {
+                None
+            };
+            // post-order: both children were visited (and named) before their parent
+            let (left, right) = (global[nd.left as usize], global[nd.right as usize]);
+            tmp_nodes.put(id, &Node::SplitPlaneNormal(SplitPlaneNormal { normal, left, right }))?;
+        }
+        Ok(())
+    })
+}
+
+/// Both passes of `DotProduct::preprocess` (src/distance/dot_product.rs) on the device.  `iter` is the reference's own
+/// first-pass iterator over the stored items (ascending keys): the records are staged straight from the pages it walks,
+/// `ah_preprocess_dot` computes the max norm and every item's `{extra_dim, norm}` with the reference's arithmetic, and the
+/// headers come back in iteration order for the caller's second pass to write with `put_current`.  `Ok(None)`: a vector codec
+/// that does not borrow from the page — the caller keeps the CPU passes.
+pub fn preprocess_dot_records<'a, D: Distance>(
+    iter: impl Iterator<Item = heed::Result<(Key, Node<'a, D>)>>,
+) -> Result<Option<Vec<[f32; 2]>>> {
+    let (mut ids, mut ptrs, mut vector_len, mut index) = (Vec::new(), Vec::<*const u8>::new(), 0usize, 0u16);
+    for result in iter {
+        let (key, node) = result?;
+        let leaf = match node.leaf() {
+            Some(leaf) => leaf,
+            None => break,
+        };
+        match leaf.vector {
+            Cow::Borrowed(vector) => {
+                let bytes = vector.as_bytes();
+                vector_len = bytes.len();
+                index = key.index;
+                ids.push(key.node.item);
+                // the stored record `[tag][header][vector]` this vector was decoded out of (src/node.rs)
+                ptrs.push(unsafe { bytes.as_ptr().sub(1 + size_of::<D::Header>()) });
+            }
+            Cow::Owned(_) => return Ok(None),
+        }
+    }
+    if ids.is_empty() {
+        return Ok(Some(Vec::new()));
+    }
+    assert_eq!(unsafe { ah_abi_version() }, AH_ABI_VERSION, "libarroy_hip.so of another ABI version");
+    let mut ds = std::ptr::null_mut();
+    check(unsafe { ah_dataset_create(metric_of::<D>()?, (vector_len / 4) as u32, ids.len() as u64, 0, &mut ds) }, index)?;
+    let staged = HipLeafs::<D> { ds, index, vector_len, _marker: PhantomData };
+    let record_len = 1 + size_of::<D::Header>() + vector_len;
+    for (ids, ptrs) in ids.chunks(1 << 16).zip(ptrs.chunks(1 << 16)) {
+        check(unsafe { ah_dataset_upload_records(ds, ids.as_ptr(), ptrs.as_ptr(), record_len, ids.len()) }, index)?;
+    }
+    check(unsafe { ah_dataset_finalize(ds) }, index)?;
+    preprocess_dot(&staged, ids.len()).map(Some)
 }

@@ -115,6 +115,77 @@ def test_shim_roundtrip_in_plain_c_on_the_reference_database(tmp_path):
     assert "id(92): distance(2.4881108)" in out.stdout and out.stdout.strip().endswith("ok")
 
 
+def test_shim_incremental_in_plain_c_equals_the_oracles_replay(tmp_path, golden):
+    """examples/shim_incremental.c: the INCREMENTAL half of the Rust shim (integration/arroy-hip: `route_into_current_trees`,
+    `build_large_descendants`) through the C ABI in the patch's call order — index over items 0..89 of the reference's
+    large.mdb, ten items added, routed down the existing trees on a dataset that holds ONLY the new items and a tree mirror
+    WITHOUT item lists, the outgrown descendants re-split in one ah_build_subtrees call over ONLY their members, ids handed out
+    like `make_tree_in_file` does.  The updated forest must equal, node for node, what the CPU oracle makes of the same steps
+    (src/writer.rs:846-889,1398-1459 `ao_route_items`; :660-739,1167-1261 `ao_build_tree_on`)."""
+    import subprocess
+
+    from oracle import oracle as O
+    from test_abi import build_c_example
+    exe = build_c_example("shim_incremental", tmp_path)
+    dump = tmp_path / "forest.bin"
+    mdb = os.path.join(ROOT, "tests", "golden", "large_v0_6.mdb")
+    out = subprocess.run([str(exe), mdb, str(dump)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert out.stdout.strip().endswith("ok") and "outgrew split_after" in out.stdout
+    # ---- the C side's updated forest
+    raw = dump.read_bytes()
+    n_trees, n_nodes, normals_len, desc_len, stride, vec_off, hdr_off = np.frombuffer(raw, "<u8", 7)
+    node_dt = np.dtype([("kind", "u1"), ("has_normal", "u1"), ("reserved", "<u2"), ("tree", "<u4"), ("left", "<u4"), ("right", "<u4"),
+                        ("offset", "<u8"), ("count", "<u4"), ("depth", "<u4")], align=True)
+    at = 56
+    roots = np.frombuffer(raw, "<u4", int(n_trees), at); at += 4 * int(n_trees)
+    nodes = np.frombuffer(raw, node_dt, int(n_nodes), at); at += node_dt.itemsize * int(n_nodes)
+    normals = np.frombuffer(raw, "u1", int(normals_len), at); at += int(normals_len)
+    desc = np.frombuffer(raw, "<u4", int(desc_len), at)
+    dims, hs = 30, 4
+
+    def canonical_c(i):
+        nd = nodes[i]
+        if nd["kind"] == 1:
+            return ("D", tuple(int(x) for x in desc[int(nd["offset"]): int(nd["offset"]) + int(nd["count"])]))
+        rec = normals[int(nd["offset"]): int(nd["offset"]) + int(stride)]
+        nb = rec[int(hdr_off): int(hdr_off) + hs].tobytes() + rec[int(vec_off): int(vec_off) + 4 * dims].tobytes() if nd["has_normal"] else None
+        return ("S", nb, canonical_c(int(nd["left"])), canonical_c(int(nd["right"])))
+    # ---- the oracle's replay of the same steps
+    g = golden["large_v0_6"]
+    assert g["ids"] == list(range(100))
+    vecs = np.stack([hex_f32(h) for h in g["vectors_hex"]])
+    od = O.Data(O.EUCLIDEAN, vecs)
+    new = np.arange(90, 100, dtype=np.uint32)
+    resplit = 0
+    for t in range(int(n_trees)):
+        tree = od.build_tree(8, 42 + t, rows=np.arange(90, dtype=np.uint32))
+        assert tree.dummy_normals == 0
+        f = tree.as_forest(od)
+        leaf_of = O.route_items(od, f, new, [0x5EED + int(roots[t])])[0]
+        grown = {}
+        for item, leaf in zip(new, leaf_of):
+            grown.setdefault(int(leaf), []).append(int(item))
+
+        def canonical_o(i):
+            kind, has_normal, left, right, offset, count, _depth = tree.nodes[i]
+            if kind == 1:
+                stored = [int(x) for x in tree.descendants[offset:offset + count]]
+                if i not in grown:
+                    return ("D", tuple(stored))
+                merged = sorted(stored + grown[i])
+                if len(merged) <= 8:
+                    return ("D", tuple(merged))
+                nonlocal_resplit.append(1)
+                return od.build_tree(8, 1000 + 1000 * t + merged[0], rows=np.array(merged, dtype=np.uint32)).canonical()
+            nb = tree.normals[offset:offset + tree.stride] if has_normal else None
+            return ("S", nb, canonical_o(left), canonical_o(right))
+        nonlocal_resplit = []
+        assert canonical_c(int(roots[t])) == canonical_o(tree.root), f"tree {t} of the updated forest differs from the oracle's replay"
+        resplit += len(nonlocal_resplit)
+    assert resplit >= 1
+
+
 def test_c_abi_demo_runs_to_the_end(tmp_path):
     """examples/c_abi_demo.c from plain C99: build, search (the item itself first), the node sink after the build and the
     batch sink DURING the build — the streamed forest has the node and item counts of the materialised one."""

@@ -31,7 +31,32 @@ def test_patch_applies_to_the_reference_and_matches_its_generator():
     chk = subprocess.run(["git", "apply", "--check", "--verbose", patch], cwd=REF, capture_output=True, text=True)
     assert chk.returncode == 0, chk.stderr
     touched = set(re.findall(r"^\+\+\+ b/(\S+)", open(patch).read(), re.M))
-    assert touched == {"Cargo.toml", "src/lib.rs", "src/parallel.rs", "src/writer.rs", "src/reader.rs"}
+    assert touched == {"Cargo.toml", "src/lib.rs", "src/parallel.rs", "src/writer.rs", "src/reader.rs", "src/distance/dot_product.rs"}
+
+
+def test_every_public_function_of_hip_rs_has_a_call_site():
+    """Round-5 review: `route_items`, `build_subtrees` and `preprocess_dot` were bindings nothing called — an arroy built with
+    `--features hip` still routed every update through rayon.  Every `pub fn` of src/hip.rs must be called from the patch
+    (`hip::name(`, `.name(`, `::name(`) or from another function of hip.rs that is."""
+    src, patch = rust(), open(os.path.join(HERE, "arroy-hip.patch")).read()
+    added = "\n".join(l[1:] for l in patch.splitlines() if l.startswith("+") and not l.startswith("+++"))
+    names = re.findall(r"^\s*pub fn (\w+)", src, re.M)
+    assert len(names) >= 14, names
+    called_from_patch = {n for n in names if re.search(r"(?:hip::|::|\.)%s(?:::<[^>]*>)?\(" % n, added)}
+    # transitive closure inside hip.rs: the body of a reachable function names the others it calls
+    bodies = {n: src.split("fn %s" % n, 1)[1].split("\n}\n", 1)[0] for n in names}
+    reach, grew = set(called_from_patch), True
+    while grew:
+        grew = False
+        for n in list(reach):
+            for m in names:
+                if m not in reach and re.search(r"\b%s(?:::<[^>]*>)?\(" % m, bodies[n]):
+                    reach.add(m)
+                    grew = True
+    missing = sorted(set(names) - reach)
+    assert not missing, f"pub fn of hip.rs without a call site in arroy-hip.patch: {missing}"
+    for must in ("route_into_current_trees", "build_large_descendants", "preprocess_dot_records", "search_batch_items", "build_new_trees"):
+        assert must in called_from_patch, must
 
 
 def test_rust_bindings_name_only_declared_symbols():
