@@ -102,7 +102,8 @@ class AhBuildStats(C.Structure):
 class AhRerankStats(C.Structure):
     _fields_ = [("calls", C.c_uint64), ("queries", C.c_uint64), ("candidates", C.c_uint64), ("seconds_wall", C.c_double),
                 ("seconds_prep", C.c_double), ("seconds_ids", C.c_double), ("seconds_enqueue", C.c_double),
-                ("seconds_sync_wait", C.c_double), ("seconds_device_span", C.c_double)]
+                ("seconds_sync_wait", C.c_double), ("seconds_device_span", C.c_double), ("queries_screened", C.c_uint64),
+                ("survivors", C.c_uint64), ("chunks_int8", C.c_uint64), ("chunks_int8_retried", C.c_uint64)]
 
 
 class AhSearchStats(C.Structure):
@@ -111,7 +112,8 @@ class AhSearchStats(C.Structure):
         "dedup_flag_bitmap", "dedup_flag_hash", "dedup_sorted_bitmap", "dedup_sort_lds", "dedup_sort_global",
         "rerank_tiles", "rerank_sorted", "tile_visits", "tile_units_16", "tile_units_8", "tile_units_4",
         "fallback_chunks", "fallback_non_finite", "fallback_select", "fallback_queue", "fallback_visits", "fallback_launch",
-        "filtered_queries", "leaf_kept_passes", "rerank_screened", "screen_survivors", "descent_block")] + [("reserved", C.c_uint64 * 1)]
+        "filtered_queries", "leaf_kept_passes", "rerank_screened", "screen_survivors", "descent_block", "rerank_screened8",
+        "screen8_retried_chunks")]
 
 
 class AhStreamNode(C.Structure):

@@ -1576,7 +1576,11 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     bool screened = tun(TUN_RERANK_SCREEN) != 0 && (ds->metric == AH_COSINE || ds->metric == AH_DOT_PRODUCT) && ds->dims >= 32 &&
                     inv_bytes == 0 && k <= 256 && total >= 8 * k * nq && !tiles.empty();
     if (screened) screened = ensure_screen(ds, ctx->stream, false);
-    const size_t screen_bytes = screened ? pad256(nq * (size_t)ds->hpitch * 2) + pad256(nq * 16) + pad256(total * 4) : 0;
+    // ... and, round 6, on the int8 copy before that: half the bytes again per candidate, a wider band of survivors
+    const bool screened8 = screened && tun(TUN_RERANK_SCREEN8) != 0 && !ds->rerank8_off.load(std::memory_order_relaxed) &&
+                           ensure_screen8_search(ds, ctx->stream);
+    const size_t screen_bytes = (screened ? pad256(nq * (size_t)ds->hpitch * 2) + pad256(nq * 16) + pad256(total * 4) : 0) +
+                                (screened8 ? pad256(nq * (size_t)ds->pitch8 * 2) + pad256(nq * 16) + pad256(total * 4) : 0);
     const size_t dev_bytes = pad256(nq * (size_t)ds->dims * 4) + nq * qstride + pad256(nq * 8) + pad256(nq * sizeof(HostSeg)) +
                              pad256(tiles.size() * sizeof(HostTile)) + pad256(total * 4) * 2 + 2 * pad256(nq * kstride * 8) +
                              pad256(nq * k * 4) * 2 + pad256(inv_bytes) + screen_bytes + 4096;
@@ -1601,13 +1605,41 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     uint16_t *d_q16 = screened ? dev.take<uint16_t>(nq * (size_t)ds->hpitch) : nullptr;
     float4 *d_qstats = screened ? dev.take<float4>(nq) : nullptr;
     float *d_aux = screened ? dev.take<float>(total) : nullptr;
+    int8_t *d_q8 = screened8 ? dev.take<int8_t>(nq * (size_t)ds->pitch8 * 2) : nullptr;
+    float4 *d_q8stats = screened8 ? dev.take<float4>(nq) : nullptr;
+    float *d_aux8 = screened8 ? dev.take<float>(total) : nullptr;
     float *h_q = pin.take<float>(nq * (size_t)ds->dims);
     HostSeg *h_segs = pin.take<HostSeg>(nq);
     HostTile *h_tiles = pin.take<HostTile>(tiles.size());
     uint32_t *h_ids = pin.take<uint32_t>(total);
     uint32_t *h_oi = pin.take<uint32_t>(nq * k);
     float *h_od = pin.take<float>(nq * k);
-    uint32_t *h_err = pin.take<uint32_t>(1);
+    uint32_t *h_err = pin.take<uint32_t>(16);  // [error bits][the selection's counters: words 9, 10 of search.hip's SearchStatSlot]
+    // More survivors than the selection holds (bit 3) on the int8 stage is not a reason to leave the screen: the same lists once
+    // more on the binary16 rows.  A dataset where that keeps happening (candidates closer together than the int8 error) stops
+    // trying: `rerank8_off` after 8 such submissions out of the last <= 64.
+    bool retried8 = false;
+    auto note_screened = [&](const uint32_t *words) {  // ah_rerank_stats: how the screen went (always kept: three additions)
+        std::lock_guard<std::mutex> lk(ds->mu);
+        ds->rr_stats.queries_screened += words[9];
+        ds->rr_stats.survivors += words[10];
+        ds->rr_stats.chunks_int8 += screened8 && !retried8 ? 1 : 0;
+        ds->rr_stats.chunks_int8_retried += retried8 ? 1 : 0;
+    };
+    auto retry_on_binary16 = [&](uint32_t err_bits) -> int {
+        if (!screened8 || (err_bits & ~1u) != 8u) return AH_OK;
+        retried8 = true;
+        const uint32_t fails = ds->rerank8_fails.fetch_add(1, std::memory_order_relaxed) + 1;
+        if (fails >= 8) ds->rerank8_off.store(true, std::memory_order_relaxed);
+        AH_HIP(hipMemsetAsync(d_err, 0, 64, ctx->stream));
+        AH_TRY(launch_rerank_screened(ds, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, 0u, (uint32_t)tiles.size(), tc, d_ids,
+                                      d_dist, d_aux, d_q16, d_qstats, (uint32_t)k, d_oi, d_od, d_err, ctx->stream, true, true));
+        AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+        AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, ctx->stream));
+        AH_HIP(hipMemcpyAsync(h_err, d_err, 64, hipMemcpyDeviceToHost, ctx->stream));
+        AH_HIP(hipStreamSynchronize(ctx->stream));
+        return AH_OK;
+    };
     memcpy(h_q, queries, nq * (size_t)ds->dims * 4);
     memcpy(h_segs, segs.data(), nq * sizeof(HostSeg));
     if (!tiles.empty()) memcpy(h_tiles, tiles.data(), tiles.size() * sizeof(HostTile));
@@ -1650,16 +1682,19 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
                 AH_HIP(hipStreamWaitEvent(s, ctx->ev0, 0));
             }
             AH_TRY(launch_rerank_screened(ds, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, ta, tb - ta, tc, d_ids, d_dist,
-                                          d_aux, d_q16, d_qstats, (uint32_t)k, d_oi, d_od, d_err, s, first, qb == nq));
+                                          d_aux, d_q16, d_qstats, (uint32_t)k, d_oi, d_od, d_err, s, first, qb == nq, d_q8, d_q8stats,
+                                          d_aux8));
             first = false;
             qa = qb;
             ta = tb;
         }
         AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
-        AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_err, d_err, 64, hipMemcpyDeviceToHost, s));
         AH_RR_SYNC(s);
+        AH_TRY(retry_on_binary16(*h_err));
         if ((*h_err & ~1u) == 0) {
+            note_screened(h_err);
             AH_TRY(check_err_flags(*h_err, true));
             memcpy(out_ids, h_oi, nq * k * 4);
             memcpy(out_distances, h_od, nq * k * 4);
@@ -1672,7 +1707,7 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
                                             total, d_inv));
         AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
-        AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_err, d_err, 64, hipMemcpyDeviceToHost, s));
         AH_RR_SYNC(s);
         AH_TRY(check_err_flags(*h_err, true));
         memcpy(out_ids, h_oi, nq * k * 4);
@@ -1689,12 +1724,14 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     if (screened) {
         AH_TRY(launch_prepare_queries_only(ds->view(), d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
         AH_TRY(launch_rerank_screened(ds, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_segs, d_tiles, 0u, (uint32_t)tiles.size(), tc, d_ids,
-                                      d_dist, d_aux, d_q16, d_qstats, (uint32_t)k, d_oi, d_od, d_err, s, true, true));
+                                      d_dist, d_aux, d_q16, d_qstats, (uint32_t)k, d_oi, d_od, d_err, s, true, true, d_q8, d_q8stats, d_aux8));
         AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
-        AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
+        AH_HIP(hipMemcpyAsync(h_err, d_err, 64, hipMemcpyDeviceToHost, s));
         AH_RR_SYNC(s);
+        AH_TRY(retry_on_binary16(*h_err));
         if ((*h_err & ~1u) == 0) {
+            note_screened(h_err);
             AH_TRY(check_err_flags(*h_err, true));
             memcpy(out_ids, h_oi, nq * k * 4);
             memcpy(out_distances, h_od, nq * k * 4);
@@ -1712,7 +1749,7 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     }
     AH_HIP(hipMemcpyAsync(h_oi, d_oi, nq * k * 4, hipMemcpyDeviceToHost, s));
     AH_HIP(hipMemcpyAsync(h_od, d_od, nq * k * 4, hipMemcpyDeviceToHost, s));
-    AH_HIP(hipMemcpyAsync(h_err, d_err, 4, hipMemcpyDeviceToHost, s));
+    AH_HIP(hipMemcpyAsync(h_err, d_err, 64, hipMemcpyDeviceToHost, s));
     AH_RR_SYNC(s);
     AH_TRY(check_err_flags(*h_err, true));
     memcpy(out_ids, h_oi, nq * k * 4);

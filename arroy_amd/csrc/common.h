@@ -150,6 +150,9 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(SEARCH_SINGLE_FUSED, "AH_SEARCH_SINGLE_FUSED", 1) /* 0: a one-query submission places its leaf visits with k_units_small like the other small ones */ \
     X(SEARCH_SMALL_TILES_MAX_QUERIES, "AH_SEARCH_SMALL_TILES_MAX_QUERIES", 8) /* up to this many queries a call: leaf tiles in slabs of 64 rows, whole rows in flight */ \
     X(RERANK_GROUPS, "AH_RERANK_GROUPS", 2)     /* groups a screened ah_rerank_batch submission is cut into (upload of group g + 1 under the kernel of g) */ \
+    X(RERANK_SCREEN8, "AH_RERANK_SCREEN8", 1)   /* 0: the screen of ah_rerank_batch starts on the binary16 rows, never on the int8 copy */ \
+    X(SEARCH_SCREEN8_MAX_VISITS, "AH_SEARCH_SCREEN8_MAX_VISITS", 4) /* leaves reached by at most this many queries of a call are screened on the int8 rows, the others on the binary16 rows */ \
+    X(SEARCH_SCREEN8, "AH_SEARCH_SCREEN8", 1)   /* 0: the tile re-rank of ah_search_batch likewise */ \
     X(RERANK_SCREEN, "AH_RERANK_SCREEN", 1)     /* 0: ah_rerank_batch never screens its candidates (f32 rows for all) */ \
     X(REPLICATE_HOST_BOUNCE, "AH_REPLICATE_HOST_BOUNCE", 0) /* 1: ah_dataset_replicate copies through pinned host memory even where peer access works (test aid) */ \
     X(RERANK_TIMING, "AH_RERANK_TIMING", 0)     /* 1: ah_rerank_batch accounts its wall time by phase (ah_dataset_rerank_stats) */ \
@@ -326,6 +329,9 @@ struct ah_dataset {
     // the copies above are published: d_rows_h16 / d_screen_stats / hpitch / screen_max are final and may be read without
     // `mu` (store-release in ensure_screen after the last of them is written, load-acquire by the search paths)
     std::atomic<bool> screen_ready{false};
+    std::atomic<uint32_t> rerank8_fails{0};      // ah_rerank_batch submissions whose int8 stage left too many survivors
+    std::atomic<bool> rerank8_off{false};        // ... often enough that the dataset's re-rank starts on the binary16 rows from now on
+    std::atomic<bool> screen8_ready{false};      // ... and d_rows_i8 / d_scale8_rows / d_dim_scale / pitch8 / screen8_max likewise
     // staging in flight (ah_dataset_upload_*): the context whose stream / pinned ring the uploads use until
     // ah_dataset_finalize (or ah_dataset_upload_flush) waits for them
     ah::Context *up_ctx = nullptr;
@@ -440,6 +446,7 @@ size_t batch_invert_counter_bytes(uint64_t n_rows, uint64_t n_candidates);
 // retry_failed: ask for the memory again although an earlier attempt found none (the builds do; the readers do not — a
 // read-only process short on HBM must not allocate, fail and free 2 x dims bytes per item on every call).
 bool ensure_screen(ah_dataset *ds, hipStream_t s, bool want8, bool retry_failed = false);
+bool ensure_screen8_search(ah_dataset *ds, hipStream_t s);
 
 // search.hip: the certified top-k screen for the candidate lists of ah_rerank_batch (binary16 rows first, f32 for the survivors)
 // (tile_first .. tile_first + n_tiles: the tiles this call screens — the caller may launch the lists group by group while the
@@ -447,7 +454,8 @@ bool ensure_screen(ah_dataset *ds, hipStream_t s, bool want8, bool retry_failed 
 int launch_rerank_screened(ah_dataset *ds, uint32_t nq, const uint8_t *d_qvecs, uint64_t qstride, const float *d_qhdrs,
                            const void *d_segs, const void *d_tiles, uint32_t tile_first, uint32_t n_tiles, uint32_t tile_candidates,
                            const uint32_t *d_ids, float *d_dist, float *d_aux, uint16_t *d_q16, float4 *d_qstats, uint32_t k_out,
-                           uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s, bool first, bool select);
+                           uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s, bool first, bool select,
+                           int8_t *d_q8 = nullptr, float4 *d_q8stats = nullptr, float *d_aux8 = nullptr);
 
 // split.hip
 int launch_split_sides(const DataView &dv, const void *d_nvec, const float *d_nhdr, const uint32_t *d_ids, uint64_t n,

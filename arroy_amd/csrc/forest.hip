@@ -785,10 +785,6 @@ __global__ void k_dim_scales(const uint32_t *__restrict__ max_bits, uint32_t dim
     d[i] = v;
     inv_d[i] = 1.0f / v;  // exact: a power of two
 }
-__device__ __forceinline__ int quantize8(float x, float inv_scale) {
-    const float q = rintf(x * inv_scale);
-    return (int)fminf(fmaxf(q, -127.0f), 127.0f);
-}
 __device__ __forceinline__ uint32_t octet_max_u32(uint32_t v) {
     v = max(v, (uint32_t)__shfl_xor((int)v, 1, 8));
     v = max(v, (uint32_t)__shfl_xor((int)v, 2, 8));
@@ -869,7 +865,9 @@ __global__ __launch_bounds__(kBlock) void k_shadow_rows8(DataView dv, const floa
         sc = octet_sum(sc);
         sa2 = octet_sum(sa2);
         sb2 = octet_sum(sb2);
-        if (j == 0) row_scale[row] = ok ? scale : __uint_as_float(0x7F800000u);  // inf: the row never decides here
+        // inf: the row never decides here.  An all-zero row is exact at scale 0 (q = 0, every product with it is 0): the top-k
+        // screen of the search (search.hip) then needs no fall-back for the zero vectors real corpora hold
+        if (j == 0) row_scale[row] = ok ? scale : (xbits == 0u ? 0.0f : __uint_as_float(0x7F800000u));
         if (ok) {
             // in units of the row's scale, rounded UP: f32 sums of squares (relative error < (pitch + 8) 2^-24), the
             // rounding of scale * q inside the difference (2^-24 |z| per element, |z| <= 127 scale), the division
@@ -945,13 +943,6 @@ __global__ __launch_bounds__(64) void k_forest_shadow_normals8(DataView dv, cons
 // integer dot of one int8 row against the two int8 digits of the normal in LDS, octet-cooperative: lane j covers bytes
 // 128 k + 16 j .. +15.  hi4 / lo4 = normal digits (LDS) + j, r4 = row (global, streamed) + j.
 // Result: <q_hi, q> + <q_lo, q> / 256 as float (the integers are exact; one rounding per lane total and per octet add).
-__device__ __forceinline__ int dot16_i8(const uint4 a, const uint4 b, int acc) {
-    acc = __builtin_amdgcn_sdot4((int)a.x, (int)b.x, acc, false);
-    acc = __builtin_amdgcn_sdot4((int)a.y, (int)b.y, acc, false);
-    acc = __builtin_amdgcn_sdot4((int)a.z, (int)b.z, acc, false);
-    acc = __builtin_amdgcn_sdot4((int)a.w, (int)b.w, acc, false);
-    return acc;
-}
 __device__ __forceinline__ float screen8_octet_dot(const uint4 *hi4, const uint4 *lo4, const uint4 *r4, uint32_t steps) {
     int h0 = 0, h1 = 0, l0 = 0, l1 = 0;
     uint32_t k = 0;
@@ -1922,7 +1913,7 @@ static uint64_t normal_record_stride(const ah_dataset *ds) {
 // forest build that wants them.  Returns false when the screen cannot be used: never for 1-bit metrics / short vectors,
 // and — NOT remembered, the next build tries again — when the memory for the copies is not available right now (another
 // build's arenas may be live); ah_build_stats.screen_unavailable then says why the build ran in f32 arithmetic only.
-static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force);
+static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force, bool want_lo = true);
 // (ensure_screen is shared with search.hip: the certified top-k screen of the re-rank uses the same copy)
 namespace ah {
 bool ensure_screen(ah_dataset *ds, hipStream_t s, bool want8, bool retry_failed) {
@@ -1976,13 +1967,25 @@ bool ensure_screen(ah_dataset *ds, hipStream_t s, bool want8, bool retry_failed)
         (void)ensure_screen8(ds, s, tun8 == 1);
     return true;
 }
+// The int8 copy for the SEARCH side (round 6: the first stage of the certified top-k screen of ah_search_batch /
+// ah_rerank_batch): the copy the node-major levels of the build use — made here for DotProduct as well, whose build has no use
+// for it (and therefore without the second digit of the rows, which only the build's stage 1 reads).
+bool ensure_screen8_search(ah_dataset *ds, hipStream_t s) {
+    if (ds->screen8_ready.load(std::memory_order_acquire)) return true;
+    std::lock_guard<std::mutex> lk(ds->mu);
+    if ((ds->metric != AH_COSINE && ds->metric != AH_DOT_PRODUCT) || ds->dims < 32 || ds->n == 0) return false;
+    if (ds->d_rows_i8) return ds->screen8_ready.load(std::memory_order_acquire);
+    const long long tun8 = tun(TUN_SCREEN8);
+    if (tun8 == 0 || (ds->screen8_decided && tun8 != 1)) return false;  // found useless (or unavailable) before
+    return ensure_screen8(ds, s, tun8 == 1, ds->metric != AH_DOT_PRODUCT);
+}
 }  // namespace ah
 // The int8 copy (rows, one scale per row, one power of two per dimension).  Kept only when it will decide most pairs: the
 // margin of a row against a normal of an unrelated direction is ~ |n||x| / sqrt(dims), the bound ~ |n| |x - x~8| (the
 // normal's two int8 digits make its own error negligible), so the copy is useful while quality = max|y/s - q| sqrt(dims)
 // / (typical |x|/s) is small: 0.06 for uniform 768-d rows (~90 % of the pairs decided), 0.2 for N(0,1) rows (~84 %); a
 // few huge entries in otherwise small rows blow it up.  `force` (AH_SCREEN8=1, a test aid) keeps it whatever the data.
-static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force) {
+static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force, bool want_lo) {
     const DataView dv = ds->view();
     const uint32_t pitch8 = (ds->dims + 127u) & ~127u;
     const unsigned grid = (unsigned)std::min<uint64_t>((ds->n + 31) / 32, 1u << 20);
@@ -1991,7 +1994,7 @@ static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force) {
     uint32_t *d_m = nullptr;  // [pitch8 column maxima][5 row maxima + pad]
     uint32_t h_m[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     // the rows' second digit is optional: without the memory for it stage 1 is simply the binary16 row
-    if (tun(TUN_SCREEN8_LO) != 0 && dev_malloc((void **)&rows8_lo, ds->n * (size_t)pitch8) != hipSuccess) {
+    if (want_lo && tun(TUN_SCREEN8_LO) != 0 && dev_malloc((void **)&rows8_lo, ds->n * (size_t)pitch8) != hipSuccess) {
         (void)hipGetLastError();
         rows8_lo = nullptr;
     }
@@ -2017,6 +2020,9 @@ static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force) {
         // against a TYPICAL |q| rather than the largest: rows are ~ isotropic after the column scaling, |q| ~ |x| / s
         const double quality = (double)b8 * std::sqrt((double)ds->dims) / std::max((double)a8, 1e-300);
         ds->screen8_quality = quality;
+        if (tun(TUN_TIMING) != 0)
+            fprintf(stderr, "[ah] int8 copy of %llu x %u rows: max |q| %.1f, max |y/s - q| %.2f, max |x|/s %.1f, quality %.3f (kept below 0.6)\n",
+                    (unsigned long long)ds->n, ds->dims, (double)a8, (double)b8, (double)c8, quality);
         keep = std::isfinite(a8) && std::isfinite(b8) && std::isfinite(c8) && a8 > 0.0f && (force || quality < 0.6);
         if (keep) {
             ds->d_rows_i8 = rows8;
@@ -2028,6 +2034,7 @@ static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force) {
             ds->screen8_max[0] = a8;
             ds->screen8_max[1] = b8;
             ds->screen8_max[2] = c8;
+            ds->screen8_ready.store(true, std::memory_order_release);  // (readers without `mu`: the search paths)
         }
         ds->screen8_decided = true;
     } else {

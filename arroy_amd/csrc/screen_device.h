@@ -49,6 +49,20 @@ __device__ __forceinline__ float screen_dot8(const uint4 a, const uint4 b, float
     return acc;
 }
 
+// int8 copies (forest.hip: k_shadow_rows8; search.hip: the queries' digits): round to nearest, clamped to +-127
+__device__ __forceinline__ int quantize8(float x, float inv_scale) {
+    const float q = rintf(x * inv_scale);
+    return (int)fminf(fmaxf(q, -127.0f), 127.0f);
+}
+// 16 int8 (16 bytes) x 16 int8 -> i32 accumulate: 4 x v_dot4_i32_i8, exact
+__device__ __forceinline__ int dot16_i8(const uint4 a, const uint4 b, int acc) {
+    acc = __builtin_amdgcn_sdot4((int)a.x, (int)b.x, acc, false);
+    acc = __builtin_amdgcn_sdot4((int)a.y, (int)b.y, acc, false);
+    acc = __builtin_amdgcn_sdot4((int)a.z, (int)b.z, acc, false);
+    acc = __builtin_amdgcn_sdot4((int)a.w, (int)b.w, acc, false);
+    return acc;
+}
+
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 ld_stream_u4(const uint4 *p) {
     u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));

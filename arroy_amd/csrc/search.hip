@@ -1674,7 +1674,68 @@ struct ScreenSearch {
     float gamma_s, gamma_r;
     const uint16_t *q16;        // nq x hpitch halves
     const float4 *qstats;       // per query {|q~|, |q - q~|, |q|}, rounded up
+    // Round 6 — the int8 copy of the rows as the FIRST stage (rows8 != nullptr): the screen values come from 1 byte per
+    // dimension instead of 2, with an error bound per candidate, E = A_q x s_r (the query's part x the row's scale, forest.hip:
+    // k_shadow_rows8); the interval argument of the selection is the same, only more candidates survive into the f32 pass
+    // (~2.5 % instead of ~1.4 % at 1536-d) — 1.7 KB per candidate instead of 3.2.
+    const int8_t *rows8;        // n x pitch8 (ah_dataset::d_rows_i8)
+    const float *row_scale8;    // n (ah_dataset::d_scale8_rows; 0 for an all-zero row, inf for a row that must not be screened)
+    const float *dim_scale;     // pitch8 powers of two (the columns' scales)
+    uint32_t pitch8;
+    float4 max8;                // dataset-wide maxima of {|q|, |y / s_r - q|, |x| / s_r} over the rows
+    const int8_t *q8;           // nq x 2 x pitch8: the queries' two int8 digits in the column-scaled space
+    const float4 *q8stats;      // per query {s_q, A_q, 0, 0}
+    float *aux8;                // per candidate, next to its screen value: the row's scale s_r
 };
+
+// queries (f32 leaves at qvecs) -> two int8 digits of q' = q o d (d: the columns' power-of-two scales, so <q, x> = <q', y> with
+// the rows' y = x / d) and the query's share of the error bound (forest.hip: k_forest_shadow_normals8 / screen8_decides — the
+// query plays the normal's part): A_q = |q' - q~'| max|q8| + |q'| max|y/s - q8| + 2e-6 |q~'| max|q8| + gamma_r |q| max|x|/s,
+// so that |s_r S - r_ref| <= A_q s_r for every row.  One wave per query.
+__device__ __forceinline__ void query_i8(uint32_t q, uint32_t lane, const uint8_t *__restrict__ qvecs, uint64_t qstride, uint32_t dims,
+                                         const ScreenSearch &ss, float gamma_r) {
+    const float *v = reinterpret_cast<const float *>(qvecs + (uint64_t)q * qstride);
+    int8_t *out_hi = const_cast<int8_t *>(ss.q8) + (uint64_t)q * 2 * ss.pitch8, *out_lo = out_hi + ss.pitch8;
+    uint32_t mbits = 0;
+    for (uint32_t i = lane; i < dims; i += 64) mbits = max(mbits, __float_as_uint(v[i] * ss.dim_scale[i]) & 0x7FFFFFFFu);
+    for (int off = 32; off > 0; off >>= 1) mbits = max(mbits, (uint32_t)__shfl_xor((int)mbits, off));
+    const float m = __uint_as_float(mbits);
+    const bool ok = mbits >= kTinyBits && mbits < 0x7F800000u;  // finite, not (nearly) zero
+    const float scale = ok ? m / 127.0f : 0.0f, inv_scale = ok ? 127.0f / m : 0.0f;
+    float sa = 0.f, sb = 0.f, sc = 0.f, s0 = 0.f;
+    for (uint32_t i = lane; i < ss.pitch8; i += 64) {
+        const float x0 = i < dims ? v[i] : 0.0f;
+        const float x = i < dims ? x0 * ss.dim_scale[i] : 0.0f;  // exact: a power of two
+        const float t = x * inv_scale;
+        const int qh = ok ? quantize8(x, inv_scale) : 0;
+        const int ql = ok ? (int)fminf(fmaxf(rintf((t - (float)qh) * 256.0f), -127.0f), 127.0f) : 0;
+        const float y = ((float)qh + (float)ql * 0.00390625f) * scale, d = x - y;  // the digits sum exactly (16 bits)
+        sa += y * y;
+        sb += d * d;
+        sc += x * x;
+        s0 += x0 * x0;
+        out_hi[i] = (int8_t)qh;
+        out_lo[i] = (int8_t)ql;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sa += __shfl_xor(sa, off);
+        sb += __shfl_xor(sb, off);
+        sc += __shfl_xor(sc, off);
+        s0 += __shfl_xor(s0, off);
+    }
+    if (lane == 0) {
+        const float up = 1.0f + (float)(ss.pitch8 + 64u) * 1.2e-7f;
+        const float inf = __uint_as_float(0x7F800000u);
+        const float an = sqrtf(sa) * up, cn = sqrtf(sc) * up, cn0 = sqrtf(s0) * up;
+        // a query that is all zero is exact (every digit 0, every product 0); one too small or not finite is never screened
+        const float bn = ok ? sqrtf(sb) * up + 128.0f * scale * 6.0e-8f * sqrtf((float)ss.pitch8) : (mbits == 0u ? 0.0f : inf);
+        const float a = (bn * ss.max8.x + cn * ss.max8.y + 2.0e-6f * (an * ss.max8.x) + gamma_r * (cn0 * ss.max8.z)) * 1.000001f * 1.002f;
+        const_cast<float4 *>(ss.q8stats)[q] = make_float4(scale, a, 0.0f, 0.0f);
+    }
+}
+__global__ __launch_bounds__(64) void k_queries_i8(const uint8_t *__restrict__ qvecs, uint64_t qstride, uint32_t dims, ScreenSearch ss) {
+    query_i8(blockIdx.x, threadIdx.x, qvecs, qstride, dims, ss, ss.gamma_r);
+}
 
 // queries (f32 leaves at qvecs) -> binary16 copies + norms: one wave per query
 // The leaf tile of k_leaf_tiles on the binary16 copies: R rows x Q queries of screen dot products per octet, any summation
@@ -1754,6 +1815,7 @@ __device__ __forceinline__ void leaf_tile16(const ScreenSearch &ss, const DataVi
                 if (missing[u]) atomicOr(err, 1u);
                 dist[out[t] + r0 + u] = missing[u] ? __uint_as_float(0x7FC00000u) : sdot;
                 if (ss.aux) ss.aux[out[t] + r0 + u] = xn[u];
+                if (ss.aux8) ss.aux8[out[t] + r0 + u] = -1.0f;  // (a submission that mixes the stages: this value is a binary16 one)
             }
         }
     }
@@ -1762,10 +1824,11 @@ template <bool SMALL>
 __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch ss, const uint32_t *__restrict__ nns,
                                                       const Visit *__restrict__ sorted, const TileUnit *__restrict__ units,
                                                       const uint32_t *__restrict__ n_units_p, float *__restrict__ dist,
-                                                      uint32_t stride, uint32_t *err) {
+                                                      uint32_t stride, uint32_t *err, uint32_t min_vis = 0) {
     const uint32_t n_units = *n_units_p;
     for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const TileUnit unit = units[u];
+        if (unit.n_vis < min_vis) continue;  // (the units of few visits went to k_leaf_tiles8)
         const Visit *vis = sorted + unit.first;
         const uint32_t n_leaf = vis[0].n;
         // SMALL (its own kernel: the registers of the in-flight variant would cost the big submissions their occupancy): a small
@@ -1794,6 +1857,103 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
         else if (n_vis == 2) AH_TILE16(4, 2, 1);
         else AH_TILE16(8, 1, 1);
 #undef AH_TILE16
+    }
+}
+
+// The leaf tile on the INT8 copy of the rows (round 6): R rows x Q queries per octet, both int8 digits of every query against the
+// row's bytes (v_dot4_i32_i8, exact integers); the value s_q s_r (<hi, q8> + <lo, q8> / 256) lands where the binary16 tile would
+// put its screen value, the row's scale next to it (aux8: the candidate's own error bound is A_q s_r).
+template <int R, int Q, int QO>
+__device__ __forceinline__ void leaf_tile8(const ScreenSearch &ss, const DataView &dv, const uint32_t *__restrict__ leaf_ids,
+                                           uint32_t row_begin, uint32_t n_rows, const Visit *__restrict__ vis, uint32_t n_vis,
+                                           float *__restrict__ dist, uint32_t stride, uint32_t *err) {
+    constexpr uint32_t RO = 8 / QO;
+    const uint32_t j = threadIdx.x & 7u, ow = (threadIdx.x >> 3) & 7u, wave = threadIdx.x >> 6;
+    const uint32_t q_oct = ow % QO, row_oct = wave * RO + ow / QO;
+    const uint32_t steps = ss.pitch8 >> 7, lo_off = ss.pitch8 >> 4;  // (uint4 units)
+    const uint4 *q4[Q];
+    uint64_t out[Q];
+    float s_q[Q];
+#pragma unroll
+    for (int t = 0; t < Q; t++) {
+        const Visit v = vis[min(q_oct * Q + (uint32_t)t, n_vis - 1)];
+        q4[t] = reinterpret_cast<const uint4 *>(ss.q8 + (uint64_t)v.q * 2 * ss.pitch8) + j;
+        out[t] = (uint64_t)v.q * stride + v.pos;
+        s_q[t] = ss.q8stats[v.q].x;
+    }
+    for (uint32_t r0 = row_begin + row_oct * R; r0 < n_rows; r0 += 4 * RO * R) {
+        const uint4 *r4[R];
+        bool missing[R];
+        float xn[R], sr[R];
+#pragma unroll
+        for (int u = 0; u < R; u++) {
+            const uint64_t row = row_of_id(dv, leaf_ids[min(r0 + u, n_rows - 1)]);
+            missing[u] = row == ~0ull;
+            r4[u] = reinterpret_cast<const uint4 *>(ss.rows8 + (missing[u] ? 0ull : row) * ss.pitch8) + j;
+            xn[u] = ss.aux && !missing[u] ? dv.headers[row] : 0.0f;
+            sr[u] = missing[u] ? 0.0f : ss.row_scale8[row];
+        }
+        int ah[R][Q], al[R][Q];
+#pragma unroll
+        for (int u = 0; u < R; u++)
+#pragma unroll
+            for (int t = 0; t < Q; t++) ah[u][t] = al[u][t] = 0;
+        for (uint32_t k = 0; k < steps; k++) {
+            uint4 x[R], yh[Q], yl[Q];
+#pragma unroll
+            for (int u = 0; u < R; u++) x[u] = r4[u][k * 8];
+#pragma unroll
+            for (int t = 0; t < Q; t++) {
+                yh[t] = q4[t][k * 8];
+                yl[t] = q4[t][lo_off + k * 8];
+            }
+#pragma unroll
+            for (int u = 0; u < R; u++)
+#pragma unroll
+                for (int t = 0; t < Q; t++) {
+                    ah[u][t] = dot16_i8(yh[t], x[u], ah[u][t]);
+                    al[u][t] = dot16_i8(yl[t], x[u], al[u][t]);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < R; u++) {
+#pragma unroll
+            for (int t = 0; t < Q; t++) {
+                const float v = octet_sum((float)ah[u][t] + (float)al[u][t] * 0.00390625f);
+                if (r0 + u >= n_rows || q_oct * Q + (uint32_t)t >= n_vis || j != 0) continue;
+                if (missing[u]) atomicOr(err, 1u);
+                dist[out[t] + r0 + u] = missing[u] ? __uint_as_float(0x7FC00000u) : (v * s_q[t]) * sr[u];
+                ss.aux8[out[t] + r0 + u] = sr[u];
+                if (ss.aux) ss.aux[out[t] + r0 + u] = xn[u];
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_leaf_tiles8(DataView dv, ScreenSearch ss, const uint32_t *__restrict__ nns,
+                                                     const Visit *__restrict__ sorted, const TileUnit *__restrict__ units,
+                                                     const uint32_t *__restrict__ n_units_p, float *__restrict__ dist,
+                                                     uint32_t stride, uint32_t *err, uint32_t max_vis) {
+    const uint32_t n_units = *n_units_p;
+    for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const TileUnit unit = units[u];
+        // Only the units of few visits: a row read for many queries is no longer the bound of its tile — the dot products are,
+        // and they cost the same on either copy — while the int8 bound doubles the survivors of every query (measured, round 6:
+        // 1000 queries from 64 base items 533 k -> 501 k queries/s with every unit on int8; 1000 unrelated ones 344 k -> 406 k)
+        if (unit.n_vis > max_vis) continue;
+        const Visit *vis = sorted + unit.first;
+        const uint32_t n_leaf = vis[0].n;
+        const uint32_t n_vis = unit.n_vis, slab = n_vis > 8 ? kTileSlab : 2 * kTileSlab;
+        const uint32_t row_begin = blockIdx.y * slab;
+        if (row_begin >= n_leaf) continue;
+        const uint32_t row_end = min(n_leaf, row_begin + slab);
+        const uint32_t *leaf_ids = nns + (uint64_t)vis[0].q * stride + vis[0].pos;
+#define AH_TILE8(R, Q, QO) leaf_tile8<R, Q, QO>(ss, dv, leaf_ids, row_begin, row_end, vis, n_vis, dist, stride, err)
+        if (n_vis > 8) AH_TILE8(4, 4, 4);
+        else if (n_vis > 4) AH_TILE8(4, 4, 2);
+        else if (n_vis > 2) AH_TILE8(4, 4, 1);
+        else if (n_vis == 2) AH_TILE8(4, 2, 1);
+        else AH_TILE8(8, 1, 1);
+#undef AH_TILE8
     }
 }
 
@@ -1831,6 +1991,55 @@ __global__ __launch_bounds__(256) void k_pairs_screen16(DataView dv, ScreenSearc
         if (j == 0) {
             if (missing) atomicOr(err, 1u);
             dist[seg.off + c] = missing ? __uint_as_float(0x7FC00000u) : sdot;
+            if (ss.aux) ss.aux[seg.off + c] = missing ? 0.0f : dv.headers[row];
+        }
+    }
+}
+
+// The same on the int8 copy of the rows (round 6): the query's two int8 digits in LDS, one octet per candidate gathers
+// pitch8 bytes — the row's scale travels with the value (aux8) for the candidate's own error bound.
+__global__ __launch_bounds__(256) void k_pairs_screen8(DataView dv, ScreenSearch ss, const PairSeg *__restrict__ segs,
+                                                       const PairTile *__restrict__ tiles, uint32_t tile_candidates,
+                                                       const uint32_t *__restrict__ ids, float *__restrict__ dist, uint32_t *err) {
+    extern __shared__ uint4 s_q4[];  // 2 x pitch8 / 16: hi digits, lo digits
+    const PairTile tl = tiles[blockIdx.x];
+    const PairSeg seg = segs[tl.query];
+    const uint4 *g_q4 = reinterpret_cast<const uint4 *>(ss.q8 + (uint64_t)tl.query * 2 * ss.pitch8);
+    for (uint32_t i = threadIdx.x; i < (ss.pitch8 >> 3); i += blockDim.x) s_q4[i] = g_q4[i];
+    __syncthreads();
+    const uint32_t j = threadIdx.x & 7u, steps = ss.pitch8 >> 7;
+    const uint4 *hi4 = s_q4 + j, *lo4 = s_q4 + (ss.pitch8 >> 4) + j;
+    const float s_q = ss.q8stats[tl.query].x;
+    const uint32_t end = min(seg.n, tl.first + tile_candidates);
+    for (uint32_t c = tl.first + (threadIdx.x >> 3); c < end; c += blockDim.x >> 3) {
+        const uint64_t row = row_of_id(dv, ids[seg.off + c]);
+        const bool missing = row == ~0ull;
+        const uint4 *r4 = reinterpret_cast<const uint4 *>(ss.rows8 + (missing ? 0ull : row) * ss.pitch8) + j;
+        int h0 = 0, h1 = 0, l0 = 0, l1 = 0;
+        uint32_t k = 0;
+        for (; k + 6 <= steps; k += 6) {
+            uint4 x[6];
+#pragma unroll
+            for (int u = 0; u < 6; u++) x[u] = ld_stream_u4(r4 + (k + u) * 8);
+#pragma unroll
+            for (int u = 0; u < 6; u += 2) {
+                h0 = dot16_i8(hi4[(k + u) * 8], x[u], h0);
+                l0 = dot16_i8(lo4[(k + u) * 8], x[u], l0);
+                h1 = dot16_i8(hi4[(k + u + 1) * 8], x[u + 1], h1);
+                l1 = dot16_i8(lo4[(k + u + 1) * 8], x[u + 1], l1);
+            }
+        }
+        for (; k < steps; k++) {
+            const uint4 x = ld_stream_u4(r4 + k * 8);
+            h0 = dot16_i8(hi4[k * 8], x, h0);
+            l0 = dot16_i8(lo4[k * 8], x, l0);
+        }
+        const float v = octet_sum((float)(h0 + h1) + (float)(l0 + l1) * 0.00390625f);
+        if (j == 0) {
+            if (missing) atomicOr(err, 1u);
+            const float s_r = missing ? 0.0f : ss.row_scale8[row];
+            dist[seg.off + c] = missing ? __uint_as_float(0x7FC00000u) : (v * s_q) * s_r;  // (inf scale x 0 digits = NaN: not screened)
+            ss.aux8[seg.off + c] = s_r;
             if (ss.aux) ss.aux[seg.off + c] = missing ? 0.0f : dv.headers[row];
         }
     }
@@ -1909,8 +2118,13 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
     }
     __syncthreads();
     const float qn = qhdrs[2 * (uint64_t)q];
-    const float e_query = screened_error(ss.max_stats, ss.qstats[q], ss.gamma_s, ss.gamma_r);
+    // int8 first stage: the error bound is the query's A_q times the candidate's row scale; binary16: one number per query
+    // (a negative "row scale": the value came from the binary16 rows — a submission may mix the two, see k_leaf_tiles8)
+    const bool s8 = ss.aux8 != nullptr;
+    const float e_query = ss.qstats ? screened_error(ss.max_stats, ss.qstats[q], ss.gamma_s, ss.gamma_r) : 0.0f;
+    const float a8 = s8 ? ss.q8stats[q].y : 0.0f;
     const float *xns = ss.aux + (METRIC == AH_COSINE ? first : 0ull);
+    const float *srs = ss.aux8 + (s8 ? first : 0ull);
     // Keys of a candidate: orderable(U) and orderable(L) from its screen value (the error bound is one number per query).  The
     // three passes below see every candidate; its keys are computed ONCE, into registers (thread t owns the candidates
     // t + 1024 r, r < kOwn, all their loads in flight together): three loops of dependent loads were 30 trips to memory for a
@@ -1920,27 +2134,28 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
         if (tid == 0) atomicOr(err, 8u);
         return;
     }
-    auto keys_of = [&](uint32_t id, float sdot, float xn, uint32_t &ukey, uint32_t &lkey) -> bool {
+    auto keys_of = [&](uint32_t id, float sdot, float xn, float sr, uint32_t &ukey, uint32_t &lkey) -> bool {
         if (!segs && id == 0xFFFFFFFFu) return false;  // (a flagged duplicate of the search; a caller's list may hold that id)
         if (!(fabsf(sdot) <= 3.0e38f)) {  // NaN or inf (a missing item, an overflow in binary16): not this path's business
             s_bad = 1u;
             return false;
         }
         float lo, hi;
-        screened_bounds<METRIC>(sdot, e_query, qn, xn, lo, hi);
+        screened_bounds<METRIC>(sdot, (s8 && !(sr < 0.0f)) ? a8 * sr + 1.3e-7f * fabsf(sdot) : e_query, qn, xn, lo, hi);
         ukey = orderable_key(hi);
         lkey = orderable_key(lo);
         return true;
     };
     uint32_t own_u[kOwn], own_l[kOwn], own_id[kOwn], own_ok = 0;
     {
-        float v_sd[kOwn], v_xn[kOwn];
+        float v_sd[kOwn], v_xn[kOwn], v_sr[kOwn];
 #pragma unroll
         for (uint32_t r = 0; r < kOwn; r++) {
             const uint32_t g = tid + r * kThreads;
             own_id[r] = g < n ? ids[g] : 0xFFFFFFFFu;
             v_sd[r] = g < n ? sd[g] : 0.0f;
             v_xn[r] = (METRIC == AH_COSINE && g < n) ? xns[g] : 0.0f;
+            v_sr[r] = (s8 && g < n) ? srs[g] : 0.0f;
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (FLAG) {  // the second and later occurrences of an id drop out (which one stays does not matter: same id, same row)
@@ -1974,14 +2189,14 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
 #pragma unroll
         for (uint32_t r = 0; r < kOwn; r++) {
             own_u[r] = own_l[r] = 0;
-            if (tid + r * kThreads < n && keys_of(own_id[r], v_sd[r], v_xn[r], own_u[r], own_l[r])) own_ok |= 1u << r;
+            if (tid + r * kThreads < n && keys_of(own_id[r], v_sd[r], v_xn[r], v_sr[r], own_u[r], own_l[r])) own_ok |= 1u << r;
         }
     }
 #define AH_SELECT_REST(G, ID, UK, LK, BODY)                                                     \
     for (uint32_t G = tid + kOwn * kThreads; G < n; G += kThreads) {                            \
         uint32_t UK, LK;                                                                        \
         const uint32_t ID = ids[G];                                                             \
-        if (keys_of(ID, sd[G], METRIC == AH_COSINE ? xns[G] : 0.0f, UK, LK)) { BODY; }          \
+        if (keys_of(ID, sd[G], METRIC == AH_COSINE ? xns[G] : 0.0f, s8 ? srs[G] : 0.0f, UK, LK)) { BODY; } \
     }
     uint32_t lo_k = 0xFFFFFFFFu, hi_k = 0u;
 #pragma unroll
@@ -2411,7 +2626,8 @@ __global__ void k_unpack_normals(const uint8_t *__restrict__ recs, const uint64_
 int launch_rerank_screened(ah_dataset *ds, uint32_t nq, const uint8_t *d_qvecs, uint64_t qstride, const float *d_qhdrs,
                            const void *d_segs, const void *d_tiles, uint32_t tile_first, uint32_t n_tiles, uint32_t tile_candidates,
                            const uint32_t *d_ids, float *d_dist, float *d_aux, uint16_t *d_q16, float4 *d_qstats, uint32_t k_out,
-                           uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s, bool first, bool select) {
+                           uint32_t *d_out_ids, float *d_out_dist, uint32_t *d_err, hipStream_t s, bool first, bool select,
+                           int8_t *d_q8, float4 *d_q8stats, float *d_aux8) {
     const DataView dv = ds->view();
     ScreenSearch ss{};
     ss.rows16 = ds->d_rows_h16;
@@ -2422,13 +2638,32 @@ int launch_rerank_screened(ah_dataset *ds, uint32_t nq, const uint8_t *d_qvecs, 
     ss.gamma_r = (float)(4.0 * ((double)(ds->dims / 32) + 6.0 + 62.0) * 5.9604645e-8);
     ss.q16 = d_q16;
     ss.qstats = d_qstats;
-    if (first) hipLaunchKernelGGL(k_queries_h16, dim3(nq), dim3(64), 0, s, d_qvecs, qstride, ds->dims, ds->hpitch, d_q16, d_qstats);
-    const size_t sh = (size_t)ds->hpitch * 2;
-    if (sh > 48 * 1024)
-        AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pairs_screen16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    if (n_tiles)
-        hipLaunchKernelGGL(k_pairs_screen16, dim3(n_tiles), dim3(256), sh, s, dv, ss, reinterpret_cast<const PairSeg *>(d_segs),
-                           reinterpret_cast<const PairTile *>(d_tiles) + tile_first, tile_candidates, d_ids, d_dist, d_err);
+    if (d_q8) {  // the int8 copy of the rows first (the caller has made sure it exists: ensure_screen8_search)
+        ss.rows8 = ds->d_rows_i8;
+        ss.row_scale8 = ds->d_scale8_rows;
+        ss.dim_scale = ds->d_dim_scale;
+        ss.pitch8 = ds->pitch8;
+        ss.max8 = make_float4(ds->screen8_max[0], ds->screen8_max[1], ds->screen8_max[2], 0.0f);
+        ss.q8 = d_q8;
+        ss.q8stats = d_q8stats;
+        ss.aux8 = d_aux8;
+        ss.qstats = nullptr;  // (every candidate of a list is screened on the int8 rows: no binary16 copy of the queries is made)
+        if (first) hipLaunchKernelGGL(k_queries_i8, dim3(nq), dim3(64), 0, s, d_qvecs, qstride, ds->dims, ss);
+        const size_t sh8 = (size_t)ds->pitch8 * 2;
+        if (sh8 > 48 * 1024)
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pairs_screen8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh8));
+        if (n_tiles)
+            hipLaunchKernelGGL(k_pairs_screen8, dim3(n_tiles), dim3(256), sh8, s, dv, ss, reinterpret_cast<const PairSeg *>(d_segs),
+                               reinterpret_cast<const PairTile *>(d_tiles) + tile_first, tile_candidates, d_ids, d_dist, d_err);
+    } else {
+        if (first) hipLaunchKernelGGL(k_queries_h16, dim3(nq), dim3(64), 0, s, d_qvecs, qstride, ds->dims, ds->hpitch, d_q16, d_qstats);
+        const size_t sh = (size_t)ds->hpitch * 2;
+        if (sh > 48 * 1024)
+            AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pairs_screen16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        if (n_tiles)
+            hipLaunchKernelGGL(k_pairs_screen16, dim3(n_tiles), dim3(256), sh, s, dv, ss, reinterpret_cast<const PairSeg *>(d_segs),
+                               reinterpret_cast<const PairTile *>(d_tiles) + tile_first, tile_candidates, d_ids, d_dist, d_err);
+    }
     if (!select) {
         AH_HIP(hipGetLastError());
         return AH_OK;
@@ -2468,6 +2703,8 @@ struct ah_index {
     uint64_t desc_len = 0;
     std::mutex stats_mu;       // ah_search_batch may run on any number of threads
     ah_search_stats stats{};
+    std::atomic<uint32_t> search8_fails{0};  // sub-batches whose int8 stage left too many survivors ...
+    std::atomic<bool> search8_off{false};    // ... eight of them: the index's tile re-rank starts on the binary16 rows from now on
 };
 
 extern "C" {
@@ -2647,7 +2884,8 @@ int ah_index_create_from_view(ah_dataset *ds, const ah_forest_view *view, ah_ind
     // of an f32 dataset has usually made it already).  No memory for it = no screen, not an error.
     if (tun(TUN_SEARCH_SCREEN) != 0 && (ds->metric == AH_COSINE || ds->metric == AH_DOT_PRODUCT) && ds->dims >= 32 && ds->n) {
         ContextLease lease(ds);
-        if (lease.c) (void)ensure_screen(ds, lease.c->stream, false);
+        if (lease.c && ensure_screen(ds, lease.c->stream, false) && tun(TUN_SEARCH_SCREEN8) != 0)
+            (void)ensure_screen8_search(ds, lease.c->stream);  // ... and the int8 copy in front of it (round 6), likewise
     }
     ix->nv.metric = ds->metric;
     ix->nv.dims = ds->dims;
@@ -2702,7 +2940,7 @@ struct ChunkStats {
 static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const uint32_t *query_rows, size_t nq,
                         size_t count, uint32_t search_k, uint32_t nns_stride, const uint32_t *d_filter_bits,
                         uint64_t filter_len_bits, double filter_share, bool wave_descent, const uint32_t *d_leaf_kept,
-                        uint32_t *out_ids, float *out_dists, uint32_t *out_counts) {
+                        uint32_t *out_ids, float *out_dists, uint32_t *out_counts, bool allow8 = true) {
     ah_dataset *ds = ix->ds;
     hipStream_t s = ctx->stream;
     const size_t qstride = (ds->row_bytes() + 255) & ~(size_t)255;
@@ -2736,6 +2974,11 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     const bool screened = tiles && tun(TUN_SEARCH_SCREEN) != 0 && (ds->metric == AH_COSINE || ds->metric == AH_DOT_PRODUCT) &&
                           ds->screen_ready.load(std::memory_order_acquire);  // (published: common.h)
     if (screened) dev_bytes += pad(nq * (size_t)ds->hpitch * 2) + pad(nq * sizeof(float4)) + pad(nq * (size_t)nns_stride * 4);
+    // ... and on the int8 copy before that (round 6; the big submissions: the small ones make their binary16 copies inside
+    // their own kernels and stay as they are): see ScreenSearch
+    const bool screened8 = screened && allow8 && tun(TUN_SEARCH_SCREEN8) != 0 && !ix->search8_off.load(std::memory_order_relaxed) &&
+                           (long long)nq > tun(TUN_SEARCH_SMALL_UNITS_MAX_QUERIES) && ds->screen8_ready.load(std::memory_order_acquire);
+    if (screened8) dev_bytes += pad(nq * (size_t)ds->pitch8 * 2) + pad(nq * sizeof(float4)) + pad(nq * (size_t)nns_stride * 4);
     if (tiles)
         dev_bytes += pad((size_t)visit_cap * sizeof(Visit)) * 2 + pad((size_t)visit_cap * sizeof(TileUnit)) +
                      pad((size_t)ix->n_nodes * 4 + 8) + 2 * pad((size_t)ix->n_nodes * 4) + pad((size_t)n_leaf_sums * 8) + pad(nq * 4);
@@ -2801,6 +3044,16 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         ss.gamma_r = (float)(4.0 * ((double)(ds->dims / 32) + 6.0 + 62.0) * 5.9604645e-8);
         ss.q16 = (const uint16_t *)dtake(nq * (size_t)ds->hpitch * 2);
         ss.qstats = (const float4 *)dtake(nq * sizeof(float4));
+    }
+    if (screened8) {
+        ss.rows8 = ds->d_rows_i8;
+        ss.row_scale8 = ds->d_scale8_rows;
+        ss.dim_scale = ds->d_dim_scale;
+        ss.pitch8 = ds->pitch8;
+        ss.max8 = make_float4(ds->screen8_max[0], ds->screen8_max[1], ds->screen8_max[2], 0.0f);
+        ss.q8 = (const int8_t *)dtake(nq * (size_t)ds->pitch8 * 2);
+        ss.q8stats = (const float4 *)dtake(nq * sizeof(float4));
+        ss.aux8 = (float *)dtake(nq * (size_t)nns_stride * 4);
     }
     float *h_q = (float *)ptake(nq * (size_t)ds->dims * 4);
     uint32_t *h_qrows = (uint32_t *)ptake(nq * 4);
@@ -2868,6 +3121,8 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                               (!d_filter_bits || filter_share >= 0.35) && block_ok && tun(TUN_SEARCH_FUSED_PREPARE) != 0;
     if (queries && !fuse_prepare)
         AH_TRY(launch_prepare_queries_only(dv, zero_copy_queries ? h_q : d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
+    if (screened8)  // (never a small submission: see above)
+        hipLaunchKernelGGL(k_queries_i8, dim3((unsigned)nq), dim3(64), 0, s, d_qvecs, qstride, ds->dims, ss);
     if (screened && !small_units)
         hipLaunchKernelGGL(k_queries_h16, dim3((unsigned)nq), dim3(64), 0, s, d_qvecs, qstride, ds->dims, ds->hpitch,
                            const_cast<uint16_t *>(ss.q16), const_cast<float4 *>(ss.qstats));
@@ -2965,7 +3220,15 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         hipLaunchKernelGGL((k_leaf_tiles<M>), dim3(2048, tile_slabs), dim3(256), 4 * kRingBytesPerWave, s, dv, d_nns, d_sorted, \
                            d_units, d_n_units, d_qvecs, qstride, d_qhdrs, d_dist, nns_stride, d_err);                       \
     } while (0)
-        if (screened) {  // the candidates on the binary16 copies first: half the bytes (see k_search_select_screened)
+        if (screened8) {
+            // the leaves few queries reached on the int8 copy (a quarter of the f32 bytes, a wider band of survivors), the leaves
+            // many queries share on the binary16 copy as before; the selection takes every candidate's bound from its own stage
+            const uint32_t max_vis8 = (uint32_t)std::max<long long>(1, tun(TUN_SEARCH_SCREEN8_MAX_VISITS));
+            hipLaunchKernelGGL(k_leaf_tiles8, dim3(2048, tile_slabs), dim3(256), 0, s, dv, ss, d_nns, d_sorted, d_units, d_n_units, d_dist,
+                               nns_stride, d_err, max_vis8);
+            hipLaunchKernelGGL((k_leaf_tiles16<false>), dim3(2048, tile_slabs), dim3(256), 0, s, dv, ss, d_nns, d_sorted, d_units,
+                               d_n_units, d_dist, nns_stride, d_err, max_vis8 + 1);
+        } else if (screened) {  // the candidates on the binary16 copies first: half the bytes (see k_search_select_screened)
             // a small submission: slabs of 64 rows (a dozen leaves then fill 150 CUs instead of 50) and a grid that does not
             // dispatch 24 000 blocks to find 12 units
             const unsigned small_slabs = std::max(1u, (ix->max_desc + kTileSmallSlab - 1) / kTileSmallSlab);
@@ -3072,9 +3335,21 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
             memcpy(out_dists, h_od, nq * k * 4);
             cs.device_words(h_err);
             cs.s.rerank_tiles = nq;
+            cs.s.rerank_screened8 = screened8 ? h_err[SS_SCREENED] : 0;
             (bitmap_fits ? cs.s.dedup_flag_bitmap : cs.s.dedup_flag_hash) = nq;
             cs.commit(ix);
             return AH_OK;
+        }
+        if (screened8 && launch_err == hipSuccess && (*h_err & ~1u) == 8u) {
+            // more survivors than the selection holds on the int8 stage (candidates closer together than its error bound): the
+            // same sub-batch once more with the binary16 rows first — not the long way
+            if (ix->search8_fails.fetch_add(1, std::memory_order_relaxed) + 1 >= 8) ix->search8_off.store(true, std::memory_order_relaxed);
+            {
+                std::lock_guard<std::mutex> lk(ix->stats_mu);
+                ix->stats.screen8_retried_chunks += 1;
+            }
+            return search_chunk(ix, ctx, queries, query_rows, nq, count, search_k, nns_stride, d_filter_bits, filter_len_bits, filter_share,
+                                wave_descent, d_leaf_kept, out_ids, out_dists, out_counts, false);
         }
         // a case the tiles do not reproduce (bits 2..5 of *err, see k_search_select / VisitSink): redo it the long way
         cs.s.fallback_chunks = 1;

@@ -44,7 +44,7 @@ extern "C" {
                                   build), ah_build_stats.seconds_setup / seconds_after_device / host_blob_recycled
                               v6: ah_debug_dense_tiles, ah_device_cache_stats, ah_forest_digest_keyed, ah_search_stats.descent_block
                               v7: ah_build_stats.seconds_reserve / seconds_reserve_wait (appended), ah_rerank_stats /
-                                  ah_dataset_rerank_stats, AH_SYNTH_CLUSTERED / AH_SYNTH_LOW_RANK (arroy_hip_policy.h),
+                                  ah_dataset_rerank_stats, ah_search_stats.rerank_screened8 / screen8_retried_chunks, AH_SYNTH_CLUSTERED / AH_SYNTH_LOW_RANK (arroy_hip_policy.h),
                                   ah_dataset_replicate falls back to a copy through pinned host memory when the two devices
                                   have no peer access */
 
@@ -203,6 +203,11 @@ typedef struct ah_rerank_stats {
     double seconds_enqueue;       /* launching copies and kernels (the calls themselves, not their execution)             */
     double seconds_sync_wait;     /* blocked in hipStreamSynchronize: the device still had work when the host was done    */
     double seconds_device_span;   /* HIP events: first enqueue of the submission -> its stream idle                       */
+    /* how the certified top-k screen went (kept whatever AH_RERANK_TIMING says) */
+    uint64_t queries_screened;    /* queries answered through the screen (int8 or binary16 rows first, f32 for the survivors) */
+    uint64_t survivors;           /* ... candidates of theirs evaluated in f32                                            */
+    uint64_t chunks_int8;         /* sub-batches whose screen started on the int8 copy of the rows and stayed there       */
+    uint64_t chunks_int8_retried; /* ... that left more survivors than the selection holds and ran again on binary16 rows */
 } ah_rerank_stats;
 AH_API int ah_dataset_rerank_stats(ah_dataset *ds, ah_rerank_stats *out, int reset);
 
@@ -501,7 +506,10 @@ typedef struct ah_search_stats {
     uint64_t screen_survivors;      /* candidates of those queries evaluated in f32 (the rest: 2 x dims bytes each)     */
     uint64_t descent_block;         /* ABI v6: one block (32 octets, one tree each) per query: submissions of few queries;
                                        a fifth tier of the descent — the five sum to `queries` */
-    uint64_t reserved[1];
+    /* ABI v7: the int8 copy of the rows as the first stage of that screen (big submissions; 1 byte per dimension) */
+    uint64_t rerank_screened8;      /* queries (of rerank_screened) whose candidates were evaluated on the int8 rows first */
+    uint64_t screen8_retried_chunks; /* sub-batches whose int8 stage left more survivors than the selection holds: done again
+                                       with the binary16 rows first (eight of them switch the int8 stage of the index off)  */
 } ah_search_stats;
 AH_API int ah_index_search_stats(ah_index *index, ah_search_stats *out, int reset);
 

@@ -83,6 +83,17 @@ def test_search_equals_oracle_at_the_benchmarked_shape_1m_x_1536_dot_20_trees():
     index.search(count, queries=queries, search_k=sk, raw=True)
     st = index.stats()
     assert st["rerank_screened"] == nq and count * nq <= st["screen_survivors"] <= 0.2 * sk * nq, st
+    # ... and, round 6, on the int8 copy of the rows before that (a big submission): the same bits with the int8 stage off,
+    # fewer survivors then (the binary16 bound is tighter), and the counters say which stage served the queries
+    assert st["rerank_screened8"] == nq and st["screen8_retried_chunks"] == 0, st
+    survivors8 = st["screen_survivors"]
+    with _lib.tuning(AH_SEARCH_SCREEN8=0):
+        index.stats(reset=True)
+        half = index.search(count, queries=queries, search_k=sk, raw=True)
+        st = index.stats()
+    assert st["rerank_screened"] == nq and st["rerank_screened8"] == 0 and count * nq <= st["screen_survivors"] < survivors8, st
+    for a, b in zip(res[1, 1], half):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "int8 stage off"
     with _lib.tuning(AH_SEARCH_SCREEN=0):
         index.stats(reset=True)
         plain = index.search(count, queries=queries, search_k=sk, raw=True)
@@ -183,6 +194,16 @@ def test_search_equals_oracle_on_the_headline_index_10m_x_768_cosine_100_trees()
     index.search(count, queries=queries, search_k=sk, raw=True)
     st = index.stats()
     assert st["rerank_screened"] == nq and count * nq <= st["screen_survivors"] <= 0.2 * sk * nq, st
+    # the int8 first stage (round 6) serves the BIG submissions: the 32 queries three times over in one call (Cosine: the
+    # candidate's stored norm and its row scale both travel with the screen value) — the bits of the 32-query call
+    big = np.concatenate([queries, queries, queries])
+    index.stats(reset=True)
+    got8 = index.search(count, queries=big, search_k=sk, raw=True)
+    st = index.stats()
+    assert st["rerank_screened8"] + 96 * st["screen8_retried_chunks"] == 96 and st["rerank_screened"] == 96, st
+    for rep in range(3):
+        for a, b in zip(res[1, 1], got8):
+            assert np.array_equal(a.view(np.uint32), b[rep * nq:(rep + 1) * nq].view(np.uint32)), "int8 first stage"
     with _lib.tuning(AH_SEARCH_SCREEN=0):
         plain = index.search(count, queries=queries, search_k=sk, raw=True)
     for a, b in zip(res[1, 1], plain):
