@@ -426,6 +426,11 @@ def extra_c4(device):
     # the ~1.5 % whose proven distance interval reaches the top k) — `gb_per_s` counts the bytes THAT path needs per candidate,
     # `f32_equivalent_gb_per_s` the 4 x dims + 8 of the reference's loop (an EFFECTIVE rate, not a roofline fraction)
     per_screen = 2 * dims + 4 + 4 + 0.015 * 4 * dims
+    # round 6: the int8 copy of the rows in front of it (1 x dims bytes + the row's scale per candidate, a wider band of survivors —
+    # measured below, `survivors_per_query`); a dataset whose candidates sit closer together than the int8 bound (clustered rows)
+    # switches the stage off by itself and stays on the binary16 rows
+    def per_screen8(survivors_per_candidate):
+        return dims + 4 + 4 + 4 + 4 + survivors_per_candidate * 4 * dims
     def phases(threads):
         """Where one pass's wall time goes inside the library (ah_dataset_rerank_stats, AH_RERANK_TIMING=1; an extra pass, not
         one of the timed ones): seconds per pass of 1000 queries, summed over the calling threads."""
@@ -435,15 +440,24 @@ def extra_c4(device):
             st = ds.rerank_stats(reset=True)
         n_pass = 5  # two warm-up passes + three timed
         return {key[8:]: st[key] / n_pass for key in st if key.startswith("seconds_")}
-    for threads in (1, 4):
+    def screened_leg(threads, int8):
         sp = {}
+        ds.rerank_stats(reset=True)
         el = _timed_callers(lambda a: ds.rerank_batch(a[0], a[1], k), batches, threads, spread=sp)
-        out[f"callers_{threads}"] = {"queries_per_s": nq / el, "candidates_per_s": total / el,
-                                     "gb_per_s": total / el * per_screen / 1e9,
-                                     "frac_of_hbm_peak": total / el * per_screen / 1e9 / HBM_PEAK_GBS,
-                                     "f32_equivalent_gb_per_s": total / el * per / 1e9, "seconds": el, "seconds_passes": sp,
-                                     "seconds_by_phase": phases(threads),
-                                     "bytes_per_candidate": per_screen, "path": "certified top-k screen (binary16 rows, f32 survivors)"}
+        st = ds.rerank_stats(reset=True)
+        on8 = int8 and st["chunks_int8"] > 0
+        surv = st["survivors"] / max(1, st["queries_screened"])
+        per_c = per_screen8(surv * nq / total) if on8 else per_screen
+        return {"queries_per_s": nq / el, "candidates_per_s": total / el, "gb_per_s": total / el * per_c / 1e9,
+                "frac_of_hbm_peak": total / el * per_c / 1e9 / HBM_PEAK_GBS,
+                "f32_equivalent_gb_per_s": total / el * per / 1e9, "seconds": el, "seconds_passes": sp,
+                "seconds_by_phase": phases(threads), "bytes_per_candidate": per_c, "survivors_per_query": surv,
+                "int8_sub_batches": st["chunks_int8"], "int8_sub_batches_redone_on_binary16": st["chunks_int8_retried"],
+                "path": "certified top-k screen (" + ("int8 rows first, " if on8 else "binary16 rows, ") + "f32 survivors)"}
+    for threads in (1, 4):
+        out[f"callers_{threads}"] = screened_leg(threads, True)
+    with ahlib.tuning(AH_RERANK_SCREEN8=0):  # round 4's screen: binary16 rows for every candidate
+        out["callers_1_binary16"] = screened_leg(1, False)
     with ahlib.tuning(AH_RERANK_SCREEN=0):  # the f32 gather for every candidate (rounds 1-3)
         for threads in (1, 4):
             sp = {}
@@ -472,10 +486,16 @@ def extra_c4(device):
                        "algorithmic_bytes_per_launch": total / len(batches) * per, "traffic": traffic, "traffic_source": src,
                        "kernel_source_sha16": source_hash("rerank")}
     scr = out["callers_1"]
-    out["roofline_screened"] = {"bound": "hbm", "kernel": "ah::k_pairs_screen16 + k_search_select_screened<3> (binary16 gather, f32 survivors)",
+    out["roofline_screened"] = {"bound": "hbm", "kernel": "ah::k_pairs_screen8 + k_search_select_screened<3> (int8 gather, f32 survivors)"
+                                if scr["int8_sub_batches"] else "ah::k_pairs_screen16 + k_search_select_screened<3> (binary16 gather, f32 survivors)",
                                 "achieved": scr["gb_per_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": scr["frac_of_hbm_peak"],
-                                "achieved_is": "end to end from one caller; bytes per candidate = 2 x dims + 8 + 1.5 % x 4 x dims",
-                                "algorithmic_bytes_per_launch": total / len(batches) * per_screen}
+                                "achieved_is": "end to end from one caller; bytes per candidate = dims + 16 + survivors x 4 x dims (int8 rows "
+                                               "first) or 2 x dims + 8 + 1.5 % x 4 x dims (binary16 rows): fewer bytes per candidate, so a "
+                                               "higher queries/s at a LOWER fraction — compare queries_per_s with callers_1_binary16",
+                                "algorithmic_bytes_per_launch": total / len(batches) * scr["bytes_per_candidate"]}
+    b16 = out["callers_1_binary16"]
+    out["roofline_screened_binary16"] = {"bound": "hbm", "achieved": b16["gb_per_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": b16["frac_of_hbm_peak"], "kernel": "ah::k_pairs_screen16 + k_search_select_screened<3>"}
     ds.close()
     return out
 
@@ -1288,6 +1308,8 @@ def flat_scalars(line):
         "cpu_build_10m_seconds": c.get("build_seconds_config_2"), "cpu_build_1m_seconds": _dig(line, "cpu_baseline", "build_seconds_config_1"),
         "rerank_callers_1_qps": _dig(line, "rerank", "callers_1", "queries_per_s"),
         "rerank_callers_1_frac": _dig(line, "rerank", "callers_1", "frac_of_hbm_peak"),
+        "rerank_callers_1_binary16_qps": _dig(line, "rerank", "callers_1_binary16", "queries_per_s"),
+        "rerank_callers_1_survivors_per_query": _dig(line, "rerank", "callers_1", "survivors_per_query"),
         "rerank_callers_4_qps": _dig(line, "rerank", "callers_4", "queries_per_s"),
         "rerank_f32_qps": _dig(line, "rerank", "callers_1_f32_only", "queries_per_s"),
         "rerank_f32_frac": _dig(line, "rerank", "callers_1_f32_only", "frac_of_hbm_peak"),
