@@ -113,7 +113,7 @@ class AhSearchStats(C.Structure):
         "rerank_tiles", "rerank_sorted", "tile_visits", "tile_units_16", "tile_units_8", "tile_units_4",
         "fallback_chunks", "fallback_non_finite", "fallback_select", "fallback_queue", "fallback_visits", "fallback_launch",
         "filtered_queries", "leaf_kept_passes", "rerank_screened", "screen_survivors", "descent_block", "rerank_screened8",
-        "screen8_retried_chunks")]
+        "screen8_retried_chunks", "descent_multi")]
 
 
 class AhStreamNode(C.Structure):

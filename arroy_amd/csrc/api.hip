@@ -120,6 +120,17 @@ int Context::ensure_filter(size_t bytes) {
     d_filter_cap = cap;
     return AH_OK;
 }
+int Context::ensure_multi(size_t bytes) {
+    if (d_multi) return AH_OK;
+    AH_HIP(dev_malloc(&d_multi, bytes));
+    const hipError_t e = hipMemsetAsync(d_multi, 0, bytes, stream);  // (stream order: before the first kernel that reads it)
+    if (e != hipSuccess) {
+        (void)dev_free(d_multi);
+        d_multi = nullptr;
+        AH_HIP(e);
+    }
+    return AH_OK;
+}
 // ---- caching device allocator (common.h) ------------------------------------------------------------------------------
 namespace {
 struct DevBlock {
@@ -333,6 +344,8 @@ void Context::destroy() {
     NoFailScope no_fail;
     if (d_scratch) (void)dev_free(d_scratch);
     if (d_filter) (void)dev_free(d_filter);
+    if (d_multi) (void)dev_free(d_multi);
+    d_multi = nullptr;
     if (h_pinned) (void)hipHostFree(h_pinned);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);

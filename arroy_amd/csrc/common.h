@@ -149,6 +149,11 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(SEARCH_FUSED_PREPARE, "AH_SEARCH_FUSED_PREPARE", 1) /* 0: a small submission prepares its query leaves with k_prepare_queries, not inside the block descent */ \
     X(SEARCH_SINGLE_FUSED, "AH_SEARCH_SINGLE_FUSED", 1) /* 0: a one-query submission places its leaf visits with k_units_small like the other small ones */ \
     X(SEARCH_SMALL_TILES_MAX_QUERIES, "AH_SEARCH_SMALL_TILES_MAX_QUERIES", 8) /* up to this many queries a call: leaf tiles in slabs of 64 rows, whole rows in flight */ \
+    X(SEARCH_MULTI, "AH_SEARCH_MULTI", 1)       /* 0: a small submission never deals a query's trees over several blocks (k_descend_multi) */ \
+    X(SEARCH_MULTI_TREES_PER_BLOCK, "AH_SEARCH_MULTI_TREES_PER_BLOCK", 8) /* ... trees per block (1 - 8: one per octet of its descent wave) */ \
+    X(SEARCH_MULTI_IDS_BY_TILES, "AH_SEARCH_MULTI_IDS_BY_TILES", 1) /* 0: the last block of k_descend_multi copies a single query's ids itself */ \
+    X(SEARCH_MULTI_TRACE, "AH_SEARCH_MULTI_TRACE", 0) /* 1: ah_search_batch prints where the blocks of query 0 spent their time (stderr) */ \
+    X(SEARCH_MULTI_MAX_QUERIES, "AH_SEARCH_MULTI_MAX_QUERIES", 8) /* ... up to this many queries a call (at most 8: the control block's size) */ \
     X(RERANK_GROUPS, "AH_RERANK_GROUPS", 2)     /* groups a screened ah_rerank_batch submission is cut into (upload of group g + 1 under the kernel of g) */ \
     X(RERANK_SCREEN8, "AH_RERANK_SCREEN8", 1)   /* 0: the screen of ah_rerank_batch starts on the binary16 rows, never on the int8 copy */ \
     X(SEARCH_SCREEN8_MAX_VISITS, "AH_SEARCH_SCREEN8_MAX_VISITS", 4) /* leaves reached by at most this many queries of a call are screened on the int8 rows, the others on the binary16 rows */ \
@@ -285,6 +290,8 @@ struct Context {
     size_t h_cap = 0;
     void *d_filter = nullptr;  // candidate filter of a search submission (bitmap + id list): outlives its sub-batches
     size_t d_filter_cap = 0;
+    void *d_multi = nullptr;   // control block of k_descend_multi (search.hip): zero between calls, allocated on first use
+    int ensure_multi(size_t bytes);
     int ensure_device(size_t bytes);
     int ensure_pinned(size_t bytes);
     int ensure_filter(size_t bytes);

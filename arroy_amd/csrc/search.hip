@@ -51,7 +51,7 @@ struct VisitSink {          // all null / 0: the descent records nothing
 // how the leaf tiles were cut.  Proof of the path taken (ah_index_search_stats), never an input of a result.
 enum SearchStatSlot {
     SS_ERR = 0, SS_WAVE_SMALL, SS_WAVE_BIG, SS_OCTET_LDS, SS_OCTET_GLOBAL, SS_UNITS_16, SS_UNITS_8, SS_UNITS_4, SS_VISITS,
-    SS_SCREENED, SS_SURVIVORS, SS_BLOCK, SS_VISIT_TOTAL, SS_N_UNITS, SS_DONE, SS_WORDS = 16
+    SS_SCREENED, SS_SURVIVORS, SS_BLOCK, SS_VISIT_TOTAL, SS_N_UNITS, SS_DONE, SS_MULTI, SS_WORDS = 16
 };
 
 struct SearchParams {
@@ -556,6 +556,10 @@ struct SingleQueryOut {
     Visit *sorted;
     uint32_t *n_units;
     QueriesH16 h16;  // q16 == nullptr: no binary16 copy wanted
+    // k_descend_multi, no candidate filter: the leaves' ids are NOT copied into the candidate buffer by the descent's last block
+    // (10 000 ids through one compute unit: 7 us) — TileUnit::pad carries 1 + the leaf's first id in the blob and the ~150
+    // blocks of k_leaf_tiles16<true> copy the ids of the rows they evaluate (the selection reads them from the buffer as before)
+    bool ids_by_tiles;
 };
 // ---- one BLOCK per query: the small submissions ------------------------------------------------------------------
 // arroy's API takes one query per call (src/reader.rs:46-75) and the wave descent's time does not depend on how many queries a
@@ -977,6 +981,517 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
         nns_count[q] = ids_taken;
         overflow[q] = 0;
         if (sp.stats) atomicAdd(&sp.stats[SS_BLOCK], 1u);
+        if (single.units) {
+            *single.n_units = taken;
+            if (sink.total) *sink.total = taken;
+            if (sp.stats && taken) {
+                atomicAdd(&sp.stats[SS_VISITS], taken);
+                atomicAdd(&sp.stats[SS_UNITS_4], taken);
+            }
+        }
+    }
+}
+
+// ---- several BLOCKS per query: one query on more than one CU (round 6) --------------------------------------------------
+// k_descend_block runs a whole query on ONE compute unit: every pop round sends ~20 normals of 6 KB through one texture
+// path (0.8 us of a ~3.7 us round) and 255 CUs watch.  The candidate set is order-independent (k_descend_wave: the leaves
+// in decreasing key order until search_k ids are held), so the trees can be dealt over G blocks, t = block (mod G), each
+// a WAVE of eight octets with a queue each — no block barrier inside the loop — and the blocks only have to agree on when
+// to stop.  What block g needs for that: a key x with "the leaves already popped ANYWHERE with key >= x hold >= search_k
+// ids" (then the cut T* of the sequential loop is >= x) and every key still queued in g below x (then g has popped all of
+// its leaves with key >= T*, ties included).  Leaves another block has not reported yet only delay the stop (more pops
+// than needed, never other candidates), so the exchange is one-way and needs no fence: every popped leaf is published as
+// ONE 64-bit word (key word << 32 | ids) by an agent-scope atomic store into a slot that was zero, and a second wave of
+// every block — the descent wave never waits for memory it does not need — polls the other blocks' next slots, keeps all
+// known leaves in LDS and recomputes x.  The last block to finish (a counter) gathers every list, orders the leaves as
+// k_descend_block does (octet order inside a list, equal keys of two lists across the cut -> the sequential descent) and
+// copies the ids; it also wipes what the query wrote, so the control block (Context::d_multi) is zero between calls.
+static constexpr uint32_t kMultiMaxBlocks = 16, kMultiLeaves = 32, kMultiLists = kMultiMaxBlocks * 8, kMultiMaxQueries = 8;
+static constexpr uint32_t kMultiKnown = 1024, kMultiCap = 1024;
+struct MultiCtl {
+    uint32_t done, failed, pad[14];
+    unsigned long long leaf[kMultiLists][kMultiLeaves];  // key word << 32 | ids the leaf adds (never 0); list = block * 8 + octet
+    unsigned long long info[kMultiLists][kMultiLeaves];  // node << 32 | first id of the leaf in the blob
+    uint32_t trace[kMultiMaxBlocks][8];                  // AH_SEARCH_MULTI_TRACE: 10 ns ticks since the block started (see the kernel)
+};
+size_t multi_ctl_bytes() { return (size_t)kMultiMaxQueries * sizeof(MultiCtl); }
+template <uint32_t kHeap>
+constexpr size_t multi_descend_lds_bytes() {
+    return (size_t)8 * kHeap * 8 + (size_t)8 * kMultiLeaves * (8 + 4 + 4) + (size_t)kMultiKnown * 8 + (size_t)kMultiCap * (8 + 4 + 4 + 4 + 4) +
+           64 * 4 + 32 * 4;
+}
+enum MultiWord { MW_N_KNOWN = 0, MW_STOP_X, MW_FINISH, MW_REMOTE_FAILED, MW_LOCAL_FAILED, MW_LAST, MW_N_MERGED };
+__device__ __forceinline__ uint32_t lds_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ unsigned long long lds_load64(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ unsigned long long dev_load64(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void dev_store64(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <uint32_t kHeap, uint32_t kPops>
+__global__ __launch_bounds__(256) void k_descend_multi(DataView nv, SearchParams sp, uint32_t nq, const uint8_t *__restrict__ qvecs,
+                                                       uint64_t qstride, const float *__restrict__ qhdrs, uint32_t *__restrict__ nns,
+                                                       uint32_t *__restrict__ nns_count, uint32_t *__restrict__ overflow, VisitSink sink,
+                                                       const float *__restrict__ raw_queries, float *__restrict__ qhdrs_out,
+                                                       SingleQueryOut single, MultiCtl *__restrict__ ctls, uint32_t G) {
+    constexpr uint32_t kThreads = 256, kLeaves = kMultiLeaves, kCap = kMultiCap;
+    extern __shared__ uint64_t s_multi_lds[];
+    uint64_t(*s_heap)[kHeap] = reinterpret_cast<uint64_t(*)[kHeap]>(s_multi_lds);
+    uint64_t(*s_leaf)[kLeaves] = reinterpret_cast<uint64_t(*)[kLeaves]>(s_multi_lds + (size_t)8 * kHeap);  // key word << 32 | node
+    unsigned long long *s_known = reinterpret_cast<unsigned long long *>(s_multi_lds + (size_t)8 * kHeap + 8 * kLeaves);
+    uint64_t *s_sorted = s_multi_lds + (size_t)8 * kHeap + 8 * kLeaves + kMultiKnown;
+    uint32_t *s_sorted_n = reinterpret_cast<uint32_t *>(s_sorted + kCap);
+    uint32_t *s_pos = s_sorted_n + kCap, *s_sorted_node = s_pos + kCap, *s_sorted_first = s_sorted_node + kCap;
+    uint32_t(*s_leaf_n)[kLeaves] = reinterpret_cast<uint32_t(*)[kLeaves]>(s_sorted_first + kCap);
+    uint32_t(*s_leaf_a)[kLeaves] = reinterpret_cast<uint32_t(*)[kLeaves]>(s_sorted_first + kCap + 8 * kLeaves);
+    uint32_t *s_red = s_sorted_first + kCap + 16 * kLeaves;  // 64 words of scratch for the block reductions
+    uint32_t *s_mw = s_red + 64;                             // 32 control words (MultiWord)
+    const uint32_t q = blockIdx.x / G, g = blockIdx.x - q * G, tid = threadIdx.x, o = (tid >> 3) & 7u, j = tid & 7u, wave = tid >> 6, wl = tid & 63u;
+    if (q >= nq) return;
+    MultiCtl *ctl = ctls + q;
+    const uint64_t t_start = wall_clock64();
+    auto stamp = [&](uint32_t slot) {  // (thread 0 of the block; never read by the kernels: ah_search_batch prints them on request)
+        if (tid == 0) ctl->trace[g][slot] = (uint32_t)(wall_clock64() - t_start);
+    };
+    constexpr uint32_t kWaves = kThreads / 64;
+    auto block_max = [&](uint32_t v) {
+        for (uint32_t d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+        __syncthreads();
+        if (wl == 0) s_red[wave] = v;
+        __syncthreads();
+        uint32_t r = 0;
+        for (uint32_t w = 0; w < kWaves; w++) r = max(r, s_red[w]);
+        return r;
+    };
+    auto block_sum = [&](uint32_t v) {
+        for (uint32_t d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+        __syncthreads();
+        if (wl == 0) s_red[wave] = v;
+        __syncthreads();
+        uint32_t r = 0;
+        for (uint32_t w = 0; w < kWaves; w++) r += s_red[w];
+        return r;
+    };
+    for (uint32_t i = tid; i < kMultiKnown; i += kThreads) s_known[i] = 0ull;
+    if (tid < 32) s_mw[tid] = 0u;
+    // the query leaf in LDS (behind everything else; qstride bytes) — as in k_descend_block; block 0 of the query leaves what the
+    // kernels behind the descent read (the prepared leaf, its header, the binary16 copy) in global memory
+    uint4 *s_q4 = reinterpret_cast<uint4 *>(reinterpret_cast<uint8_t *>(s_multi_lds) + multi_descend_lds_bytes<kHeap>());
+    LeafHdr qh;
+    if (raw_queries) {
+        const float *src = raw_queries + (uint64_t)q * nv.dims;
+        float *dst = reinterpret_cast<float *>(const_cast<uint8_t *>(qvecs) + (uint64_t)q * qstride), *s_q = reinterpret_cast<float *>(s_q4);
+        for (uint32_t i0 = tid; i0 < nv.pitch; i0 += 8 * kThreads) {
+            float v[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) v[u] = i0 + u * kThreads < nv.dims ? src[i0 + u * kThreads] : 0.0f;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++)
+                if (i0 + u * kThreads < nv.pitch) {
+                    s_q[i0 + u * kThreads] = v[u];
+                    if (g == 0) dst[i0 + u * kThreads] = v[u];
+                }
+        }
+        __syncthreads();
+        if (nv.metric == AH_COSINE && tid < 8) {
+            const float norm = f_sqrt(octet_reduce_any<OP_DOT>(s_q, s_q, nv.dims, tid));
+            if (tid == 0) s_red[63] = __float_as_uint(norm);
+        } else if (tid == 0) {
+            s_red[63] = 0u;
+        }
+        __syncthreads();
+        qh = LeafHdr{__uint_as_float(s_red[63]), 0.0f};
+        if (tid == 0 && g == 0) {
+            qhdrs_out[2 * (uint64_t)q] = qh.h0;
+            qhdrs_out[2 * (uint64_t)q + 1] = 0.0f;
+        }
+    } else {
+        const uint4 *g_q4 = reinterpret_cast<const uint4 *>(qvecs + (uint64_t)q * qstride);
+        for (uint32_t i = tid; i < (uint32_t)(qstride >> 4); i += kThreads) s_q4[i] = g_q4[i];
+        __syncthreads();
+        qh = LeafHdr{qhdrs[2 * (uint64_t)q], qhdrs[2 * (uint64_t)q + 1]};
+    }
+    const void *qvec = s_q4;
+    stamp(0);
+    // (wave 3 idles until the merge: the binary16 copy of a single query is its business; it reads the leaf block 0 wrote above)
+    if (g == 0 && single.units && single.h16.q16 && wave == 3)
+        query_h16(q, wl, single.h16.qvecs, single.h16.qstride, single.h16.dims, single.h16.hpitch, single.h16.q16, single.h16.qstats);
+    uint32_t *my_nns = nns + (uint64_t)q * sp.nns_stride;
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    if (wave == 0) {
+        // ---- the descent: eight octets, a queue each (k_descend_block's loop, its block-wide reductions as shuffles) ----
+        uint64_t *heap = s_heap[o];
+        uint32_t hn = 0, nl = 0, published = 0;
+        bool failed = false;
+        for (uint32_t t = g + G * o; t < sp.n_trees; t += G * 8) {
+            if (hn == kHeap) {
+                failed = true;
+                break;
+            }
+            if (j == 0) heap[hn] = ((uint64_t)0xFF800000u << 32) | sp.roots[t];
+            hn++;
+        }
+        auto octet_sync = [] {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        uint64_t best = 0;
+        uint32_t bi = kNone;
+        auto queue_argmax = [&] {
+            octet_sync();
+            best = 0;
+            bi = kNone;
+            for (uint32_t i = j; i < hn; i += 8) {
+                const uint64_t k = heap[i];
+                if (bi == kNone || k > best) {
+                    best = k;
+                    bi = i;
+                }
+            }
+#pragma unroll
+            for (uint32_t d = 1; d < 8; d <<= 1) {
+                const uint32_t o_hi = __shfl_xor((uint32_t)(best >> 32), d, 8), o_lo = __shfl_xor((uint32_t)best, d, 8);
+                const uint32_t o_i = __shfl_xor(bi, d, 8);
+                const uint64_t ok = ((uint64_t)o_hi << 32) | o_lo;
+                if (o_i != kNone && (bi == kNone || ok > best)) {
+                    best = ok;
+                    bi = o_i;
+                }
+            }
+        };
+        uint32_t c_id[2] = {kNone, kNone};
+        DNode c_nd[2] = {};
+        queue_argmax();
+        for (;;) {
+#pragma unroll 1
+            for (uint32_t rep = 0; rep < kPops; rep++) {
+                if (bi != kNone && !failed) {  // octet-uniform
+                    const uint32_t node = (uint32_t)best, key_word = (uint32_t)(best >> 32);
+                    hn--;
+                    if (j == 0 && bi != hn) heap[bi] = heap[hn];
+                    DNode nd;
+                    if (node == c_id[0]) nd = c_nd[0];
+                    else if (node == c_id[1]) nd = c_nd[1];
+                    else nd = sp.nodes[node];
+                    if ((nd.kind & 0xFFu) == AH_NODE_DESCENDANTS) {
+                        const uint32_t kept = sp.leaf_kept ? sp.leaf_kept[node] : nd.b;
+                        if (kept) {
+                            if (nl == kLeaves) {
+                                failed = true;
+                            } else {
+                                if (j == 0) {
+                                    s_leaf[o][nl] = ((uint64_t)key_word << 32) | node;
+                                    s_leaf_n[o][nl] = kept;
+                                    s_leaf_a[o][nl] = nd.a;
+                                }
+                                nl++;
+                            }
+                        }
+                    } else if ((nd.kind & 0xFFu) != 0) {
+                        c_id[0] = nd.a;
+                        c_id[1] = nd.b;
+                        c_nd[0] = sp.nodes[nd.a];
+                        c_nd[1] = sp.nodes[nd.b];
+                        float margin = 0.0f;
+                        if (nd.kind & 0x100u) margin = descent_margin<true>(nv, nd.c, qvec, qh, j);
+                        if (hn + 2 > kHeap) {
+                            failed = true;
+                        } else {
+                            const float dist = key_to_dist(key_word);
+                            const float pl = rust_min(-margin, dist), pr = rust_min(margin, dist);
+                            if (j == 0) {
+                                heap[hn] = ((uint64_t)orderable_key(pl) << 32) | nd.a;
+                                heap[hn + 1] = ((uint64_t)orderable_key(pr) << 32) | nd.b;
+                            }
+                            hn += 2;
+                        }
+                    }
+                    queue_argmax();
+                }
+            }
+            // the leaves this octet popped since the last round: to the other blocks (one word each, nobody waits for the
+            // stores) and to this block's own list of known leaves
+            if (j == 0) {
+                for (uint32_t i = published; i < nl; i++) {
+                    const unsigned long long w = (s_leaf[o][i] & 0xFFFFFFFF00000000ull) | s_leaf_n[o][i];
+                    dev_store64(&ctl->leaf[g * 8 + o][i], w);
+                    dev_store64(&ctl->info[g * 8 + o][i], (s_leaf[o][i] << 32) | s_leaf_a[o][i]);
+                    const uint32_t at = atomicAdd(&s_mw[MW_N_KNOWN], 1u);
+                    if (at < kMultiKnown) __hip_atomic_store(&s_known[at], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else failed = true;
+                }
+            }
+            published = nl;
+            failed = __shfl((int)failed, 0, 8) != 0;
+            const bool has = bi != kNone;
+            uint32_t top = has ? (uint32_t)(best >> 32) : 0u, flags = (has ? 1u : 0u) | (failed ? 2u : 0u);
+            for (uint32_t d = 32; d >= 8; d >>= 1) {
+                top = max(top, (uint32_t)__shfl_xor((int)top, d, 64));
+                flags |= (uint32_t)__shfl_xor((int)flags, d, 64);
+            }
+            if (flags & 2u) {
+                if (wl == 0) {
+                    atomicOr(&ctl->failed, 1u);
+                    lds_store(&s_mw[MW_LOCAL_FAILED], 1u);
+                }
+                break;
+            }
+            if (!(flags & 1u)) break;                        // nothing queued in this block any more
+            if (lds_load(&s_mw[MW_REMOTE_FAILED])) break;    // another block gave up: so does the query
+            const uint32_t stop_x = lds_load(&s_mw[MW_STOP_X]);
+            if (stop_x != 0u && top < stop_x) break;         // everything this block could still add lies behind the cut
+        }
+        if (wl == 0) lds_store(&s_mw[MW_FINISH], 1u);
+        stamp(1);
+    } else if (wave == 1) {
+        // ---- the exchange: lane l watches the lists l and l + 64 of the other blocks -------------------------------
+        uint32_t cursor[2] = {0u, 0u};
+        const uint32_t n_lists = G * 8;
+        for (;;) {
+            if (lds_load(&s_mw[MW_FINISH])) break;
+            unsigned long long w[2] = {0ull, 0ull};
+#pragma unroll
+            for (uint32_t u = 0; u < 2; u++) {
+                const uint32_t list = wl + 64 * u;
+                if (list < n_lists && (list >> 3) != g && cursor[u] < kLeaves) w[u] = dev_load64(&ctl->leaf[list][cursor[u]]);
+            }
+            uint32_t remote_failed = 0;
+            if (wl == 0) remote_failed = __hip_atomic_load(&ctl->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (uint32_t u = 0; u < 2; u++)
+                if (w[u] != 0ull) {
+                    cursor[u]++;
+                    const uint32_t at = atomicAdd(&s_mw[MW_N_KNOWN], 1u);
+                    if (at < kMultiKnown) __hip_atomic_store(&s_known[at], w[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else remote_failed = 1;  // (more leaves than the list holds: the long way)
+                }
+            if (__any(remote_failed != 0) && wl == 0) {
+                lds_store(&s_mw[MW_REMOTE_FAILED], 1u);
+                if (remote_failed) atomicOr(&ctl->failed, 1u);
+            }
+            // x = the largest key at which the known leaves hold search_k ids (0: not yet)
+            const uint32_t n_known = min(lds_load(&s_mw[MW_N_KNOWN]), kMultiKnown);
+            uint32_t x = 0;
+            for (uint32_t i = wl; i < n_known; i += 64) {
+                const unsigned long long wi = lds_load64(&s_known[i]);
+                const uint32_t ki = (uint32_t)(wi >> 32);
+                if (wi == 0ull || ki <= x) continue;
+                uint32_t sum = 0;
+                for (uint32_t e = 0; e < n_known; e++) {
+                    const unsigned long long we = lds_load64(&s_known[e]);
+                    sum += (uint32_t)(we >> 32) >= ki ? (uint32_t)we : 0u;
+                }
+                if (sum >= sp.search_k) x = ki;
+            }
+            for (uint32_t d = 32; d > 0; d >>= 1) x = max(x, (uint32_t)__shfl_xor((int)x, d, 64));
+            if (wl == 0 && x > lds_load(&s_mw[MW_STOP_X])) lds_store(&s_mw[MW_STOP_X], x);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();  // this block's slots before its count
+        s_mw[MW_LAST] = atomicAdd(&ctl->done, 1u) + 1u == G ? 1u : 0u;
+    }
+    stamp(2);
+    __syncthreads();
+    if (!s_mw[MW_LAST]) return;
+    __threadfence();
+    // ---- the last block of the query: every list, wiped as it is read --------------------------------------------
+    {
+        const uint32_t n_slots = G * 8 * kLeaves;
+        for (uint32_t s0 = tid; s0 < n_slots; s0 += 4 * kThreads) {
+            unsigned long long w[4], inf[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t sl = s0 + u * kThreads;
+                w[u] = sl < n_slots ? dev_load64(&ctl->leaf[0][0] + sl) : 0ull;
+                inf[u] = sl < n_slots ? dev_load64(&ctl->info[0][0] + sl) : 0ull;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t sl = s0 + u * kThreads;
+                if (w[u] == 0ull) continue;
+                dev_store64(&ctl->leaf[0][0] + sl, 0ull);
+                dev_store64(&ctl->info[0][0] + sl, 0ull);
+                const uint32_t at = atomicAdd(&s_mw[MW_N_MERGED], 1u);
+                if (at < kCap) {
+                    const uint32_t list = sl / kLeaves, i = sl % kLeaves;
+                    s_sorted[at] = (w[u] & 0xFFFFFFFF00000000ull) | (list << 16) | (0xFFFFu - i);
+                    s_sorted_n[at] = (uint32_t)w[u];
+                    s_sorted_node[at] = (uint32_t)(inf[u] >> 32);
+                    s_sorted_first[at] = (uint32_t)inf[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    stamp(3);
+    const uint32_t n_merged = s_mw[MW_N_MERGED];
+    const bool any_failed = n_merged > kCap || __hip_atomic_load(&ctl->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    __syncthreads();
+    if (tid == 0) {  // (every block has left: the control words are this block's to clear)
+        __hip_atomic_store(&ctl->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->failed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (any_failed) {
+        if (tid == 0) {
+            nns_count[q] = 0;
+            overflow[q] = 1;
+            if (sink.err) atomicOr(sink.err, 16u);  // nobody behind this kernel: the submission takes the long way
+        }
+        return;
+    }
+    const uint32_t n_settled = n_merged;
+    uint32_t p2 = kThreads;
+    while (p2 < n_settled) p2 <<= 1;
+    // descending by key: a leaf's place is the number of larger keys (unique: list and pop index are their low word)
+    {
+        constexpr uint32_t kMine = kCap / kThreads;
+        uint64_t my_key[kMine];
+        uint32_t my_n[kMine], my_node[kMine], my_first[kMine], my_rank[kMine];
+#pragma unroll
+        for (uint32_t r = 0; r < kMine; r++) {
+            const uint32_t e = tid + r * kThreads;
+            my_rank[r] = 0;
+            if (e < n_settled) {
+                my_key[r] = s_sorted[e];
+                my_n[r] = s_sorted_n[e];
+                my_node[r] = s_sorted_node[e];
+                my_first[r] = s_sorted_first[e];
+                for (uint32_t t = 0; t < n_settled; t++) my_rank[r] += s_sorted[t] > my_key[r] ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < kMine; r++)
+            if (tid + r * kThreads < n_settled) {
+                s_sorted[my_rank[r]] = my_key[r];
+                s_sorted_n[my_rank[r]] = my_n[r];
+                s_sorted_node[my_rank[r]] = my_node[r];
+                s_sorted_first[my_rank[r]] = my_first[r];
+            }
+        for (uint32_t t = n_settled + tid; t < p2; t += kThreads) {
+            s_sorted[t] = 0;
+            s_sorted_n[t] = 0;
+            s_sorted_node[t] = 0;
+            s_sorted_first[t] = 0;
+        }
+    }
+    __syncthreads();
+    // `if nns.len() >= search_k { break }` before every pop: leaf i is taken iff the leaves before it hold < search_k ids
+    const uint32_t per = p2 / kThreads;
+    uint32_t local = 0;
+    for (uint32_t i = 0; i < per; i++) local += s_sorted_n[tid * per + i];
+    uint32_t incl = local;
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d, 64);
+        if (wl >= d) incl += v;
+    }
+    if (wl == 63) s_red[32 + wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - local;
+    for (uint32_t w = 0; w < wave; w++) before += s_red[32 + w];
+    uint32_t taken = 0, ids_taken = 0;
+    bool tie = false;
+    for (uint32_t i = 0; i < per; i++) {
+        const uint32_t e = tid * per + i;
+        if (e < n_settled && before < sp.search_k) {
+            s_pos[e] = before;
+            taken++;
+            ids_taken = before + s_sorted_n[e];
+            if (ids_taken >= sp.search_k) {  // the leaf that reaches search_k: equal keys of another list around it -> sequential queue
+                const uint32_t kw = (uint32_t)(s_sorted[e] >> 32), lst = (uint32_t)s_sorted[e] >> 16;
+                for (uint32_t t = e + 1; t < n_settled && (uint32_t)(s_sorted[t] >> 32) == kw; t++)
+                    if (((uint32_t)s_sorted[t] >> 16) != lst) tie = true;
+                for (uint32_t t = e; t-- > 0 && (uint32_t)(s_sorted[t] >> 32) == kw;)
+                    if (((uint32_t)s_sorted[t] >> 16) != lst) tie = true;
+            }
+        }
+        before += s_sorted_n[e];
+    }
+    taken = block_sum(taken);
+    ids_taken = block_max(ids_taken);
+    const uint32_t any_tie = block_max(tie ? 1u : 0u);
+    if (any_tie || ids_taken > sp.nns_stride) {
+        if (tid == 0) {
+            nns_count[q] = 0;
+            overflow[q] = 1;
+            if (sink.err) atomicOr(sink.err, 16u);
+        }
+        return;
+    }
+    __syncthreads();
+    stamp(4);
+    if (!sp.filter_bits) {
+        // the taken leaves' ids are one flat range [0, ids_taken) of the query's candidate buffer (k_descend_block)
+        const bool ids_by_tiles = single.units && single.ids_by_tiles;
+        for (uint32_t e = tid; e < taken; e += kThreads) {
+            if (single.units) {
+                single.units[e] = TileUnit{s_sorted_node[e], e, 1u, ids_by_tiles ? s_sorted_first[e] + 1u : 0u};
+                single.sorted[e] = Visit{s_sorted_node[e], q, s_pos[e], s_sorted_n[e]};
+            } else {
+                record_visit(sink, s_sorted_node[e], q, s_pos[e], s_sorted_n[e]);
+            }
+        }
+        constexpr uint32_t kFly = 20;
+        uint32_t e = 0;
+        {
+            uint32_t hi = taken;  // the last e with s_pos[e] <= tid
+            while (hi - e > 1) {
+                const uint32_t mid = (e + hi) >> 1;
+                if (s_pos[mid] <= tid) e = mid;
+                else hi = mid;
+            }
+        }
+        uint32_t next_first = e + 1 < taken ? s_pos[e + 1] : 0xFFFFFFFFu, base = taken ? s_sorted_first[e] - s_pos[e] : 0u;
+        for (uint32_t p0 = tid; p0 < (ids_by_tiles ? 0u : ids_taken); p0 += kFly * kThreads) {
+            uint32_t id[kFly];
+#pragma unroll
+            for (uint32_t u = 0; u < kFly; u++) {
+                const uint32_t p = p0 + u * kThreads;
+                while (p >= next_first) {
+                    e++;
+                    next_first = e + 1 < taken ? s_pos[e + 1] : 0xFFFFFFFFu;
+                    base = s_sorted_first[e] - s_pos[e];
+                }
+                id[u] = p < ids_taken ? sp.desc[base + p] : 0u;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (uint32_t u = 0; u < kFly; u++)
+                if (p0 + u * kThreads < ids_taken) my_nns[p0 + u * kThreads] = id[u];
+        }
+    } else {
+        for (uint32_t e = tid >> 3; e < taken; e += kThreads / 8) {
+            const uint32_t node = s_sorted_node[e], pos = s_pos[e];
+            const DNode nd = sp.nodes[node];
+            copy_filtered(sp, sp.desc + nd.a, nd.b, my_nns + pos, j);
+            if (j == 0) {
+                if (single.units) {
+                    single.units[e] = TileUnit{node, e, 1u, 0u};
+                    single.sorted[e] = Visit{node, q, pos, s_sorted_n[e]};
+                } else {
+                    record_visit(sink, node, q, pos, s_sorted_n[e]);
+                }
+            }
+        }
+    }
+    stamp(5);
+    if (tid == 0) {
+        ctl->trace[g][6] = n_merged;
+        ctl->trace[g][7] = taken;
+        nns_count[q] = ids_taken;
+        overflow[q] = 0;
+        if (sp.stats) {
+            atomicAdd(&sp.stats[SS_BLOCK], 1u);
+            atomicAdd(&sp.stats[SS_MULTI], 1u);
+        }
         if (single.units) {
             *single.n_units = taken;
             if (sink.total) *sink.total = taken;
@@ -1743,7 +2258,7 @@ __global__ __launch_bounds__(64) void k_queries_i8(const uint8_t *__restrict__ q
 template <int R, int Q, int QO, int KF = 1>
 __device__ __forceinline__ void leaf_tile16(const ScreenSearch &ss, const DataView &dv, const uint32_t *__restrict__ leaf_ids,
                                             uint32_t row_begin, uint32_t n_rows, const Visit *__restrict__ vis, uint32_t n_vis,
-                                            float *__restrict__ dist, uint32_t stride, uint32_t *err) {
+                                            float *__restrict__ dist, uint32_t stride, uint32_t *err, uint32_t *__restrict__ copy_ids_to = nullptr) {
     constexpr uint32_t RO = 8 / QO;
     const uint32_t j = threadIdx.x & 7u, ow = (threadIdx.x >> 3) & 7u, wave = threadIdx.x >> 6;
     const uint32_t q_oct = ow % QO, row_oct = wave * RO + ow / QO;
@@ -1762,7 +2277,10 @@ __device__ __forceinline__ void leaf_tile16(const ScreenSearch &ss, const DataVi
         float xn[R];
 #pragma unroll
         for (int u = 0; u < R; u++) {
-            const uint64_t row = row_of_id(dv, leaf_ids[min(r0 + u, n_rows - 1)]);
+            const uint32_t id_u = leaf_ids[min(r0 + u, n_rows - 1)];
+            // (a single query whose descent left the ids in the blob: SingleQueryOut::ids_by_tiles)
+            if (copy_ids_to && q_oct == 0 && j == 0 && r0 + u < n_rows) copy_ids_to[r0 + u] = id_u;
+            const uint64_t row = row_of_id(dv, id_u);
             missing[u] = row == ~0ull;
             r4[u] = reinterpret_cast<const uint4 *>(ss.rows16 + (missing[u] ? 0ull : row) * ss.hpitch) + j;
             xn[u] = ss.aux && !missing[u] ? dv.headers[row] : 0.0f;  // Cosine: the row's stored norm (cosine.rs:21-24)
@@ -1824,7 +2342,8 @@ template <bool SMALL>
 __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch ss, const uint32_t *__restrict__ nns,
                                                       const Visit *__restrict__ sorted, const TileUnit *__restrict__ units,
                                                       const uint32_t *__restrict__ n_units_p, float *__restrict__ dist,
-                                                      uint32_t stride, uint32_t *err, uint32_t min_vis = 0) {
+                                                      uint32_t stride, uint32_t *err, uint32_t min_vis = 0,
+                                                      const uint32_t *__restrict__ blob = nullptr) {
     const uint32_t n_units = *n_units_p;
     for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const TileUnit unit = units[u];
@@ -1843,7 +2362,10 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
 #define AH_TILE16(R, Q, QO) leaf_tile16<R, Q, QO, AH_TILES16_KF>(ss, dv, leaf_ids, row_begin, row_end, vis, n_vis, dist, stride, err)
         if constexpr (SMALL) {
             if (fly && n_vis == 1) {
-                leaf_tile16<2, 1, 1, 24>(ss, dv, leaf_ids, row_begin, row_end, vis, n_vis, dist, stride, err);
+                // (unit.pad != 0: the ids are still in the blob, this launch copies them — SingleQueryOut::ids_by_tiles)
+                const bool from_blob = blob && unit.pad != 0u;
+                leaf_tile16<2, 1, 1, 24>(ss, dv, from_blob ? blob + (unit.pad - 1u) : leaf_ids, row_begin, row_end, vis, n_vis, dist, stride, err,
+                                         from_blob ? const_cast<uint32_t *>(leaf_ids) : nullptr);
                 continue;
             }
             if (fly) {
@@ -2294,7 +2816,8 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
         const uint32_t id = s_pos[e];
         const uint64_t row = row_of_id(dv, id);
         const float xh = METRIC == AH_COSINE ? dv.headers[row] : 0.0f;
-        const float r = octet_reduce_stream<OP_DOT, 16, true>(s_qf4, dv.rows_f32 + row * dv.pitch, dv.dims, j);
+        // (a small submission — FLAG — is this one block on an idle device: 24 lines in flight, two trips per 1536-d row, not three)
+        const float r = octet_reduce_stream<OP_DOT, FLAG ? 24 : 16, true>(s_qf4, dv.rows_f32 + row * dv.pitch, dv.dims, j);
         const float d = METRIC == AH_COSINE ? cosine_from_dot(r, qn, xh) : -r;
         if (j == 0) {
             const uint32_t w = orderable_key(d);
@@ -2922,6 +3445,7 @@ struct ChunkStats {
         s.descent_octet_lds += w[SS_OCTET_LDS];
         s.descent_octet_global += w[SS_OCTET_GLOBAL];
         s.descent_block += w[SS_BLOCK];
+        s.descent_multi += w[SS_MULTI];
         s.tile_units_16 += w[SS_UNITS_16];
         s.tile_units_8 += w[SS_UNITS_8];
         s.tile_units_4 += w[SS_UNITS_4];
@@ -3130,6 +3654,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     // (ah_search_batch decides: a filter that keeps under 5 % of the items makes a query pop more nodes than the queues of
     // a wave hold; under a filter the wave descent reads what the filter keeps of every leaf, computed once per submission)
     if (wave_descent && d_filter_bits) sp.leaf_kept = d_leaf_kept;
+    uint32_t multi_launched = 0;  // blocks per query of k_descend_multi, when that was the descent
     bool passes_done = false;  // set by launch_wave: the block descent was the whole descent
     bool units_done = false;   // ... and it wrote the leaf tiles' work units as well (one query)
     auto launch_wave = [&](const VisitSink &sink) -> int {
@@ -3143,7 +3668,9 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         const size_t block_lds = block_descend_lds_bytes<32, 128, 32>() + qstride;
         const void *wave_big = reinterpret_cast<const void *>(k_descend_wave<1024, 128>);
         const void *block_fn = reinterpret_cast<const void *>(k_descend_block<32, 128, 32, 2>);
+        const void *multi_fn = reinterpret_cast<const void *>(k_descend_multi<128, 1>);
         if (!lds_opt_in[ds->device & 63].load(std::memory_order_acquire)) {
+            AH_HIP(hipFuncSetAttribute(multi_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(multi_descend_lds_bytes<128>() + (32u << 10))));
             AH_HIP(hipFuncSetAttribute(wave_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(wave_lds_bytes(1024, 128) + (32u << 10))));
             AH_HIP(hipFuncSetAttribute(block_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(block_descend_lds_bytes<32, 128, 32>() + (32u << 10))));
@@ -3163,10 +3690,27 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                 if (screened)
                     single.h16 = QueriesH16{d_qvecs, qstride, ds->dims, ds->hpitch, const_cast<uint16_t *>(ss.q16), const_cast<float4 *>(ss.qstats)};
                 units_done = true;
+                // (k_leaf_tiles16<true> will be the tile launch: the condition of `small_tiles` below)
+                single.ids_by_tiles = screened && !d_filter_bits && tun(TUN_SEARCH_MULTI_IDS_BY_TILES) != 0 &&
+                                      (long long)nq <= tun(TUN_SEARCH_SMALL_TILES_MAX_QUERIES) &&
+                                      std::max(1u, (ix->max_desc + kTileSmallSlab - 1) / kTileSmallSlab) <= 65535u;
             }
             const float *raw = (last_pass && fuse_prepare) ? (const float *)h_q : (const float *)nullptr;
-            hipLaunchKernelGGL((k_descend_block<32, 128, 32, 2>), dim3((unsigned)nq), dim3(256), block_lds, s, ix->nv, sp, (uint32_t)nq,
-                               d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink, last_pass, raw, d_qhdrs, single);
+            // A handful of queries, more trees than one wave has octets: the trees of a query dealt over G blocks of one descent wave
+            // each (k_descend_multi) — one query on G compute units.  Only as the last pass (what it cannot hold takes the long way).
+            const uint32_t per_block = (uint32_t)std::min<long long>(8, std::max<long long>(1, tun(TUN_SEARCH_MULTI_TREES_PER_BLOCK)));
+            const uint32_t multi_blocks = std::min<uint32_t>(kMultiMaxBlocks, (ix->n_trees + per_block - 1) / per_block);
+            const bool multi = last_pass && tun(TUN_SEARCH_MULTI) != 0 && multi_blocks >= 2 &&
+                               (long long)nq <= std::min<long long>(tun(TUN_SEARCH_MULTI_MAX_QUERIES), kMultiMaxQueries);
+            if (multi) {
+                AH_TRY(ctx->ensure_multi(multi_ctl_bytes()));
+                hipLaunchKernelGGL((k_descend_multi<128, 1>), dim3((unsigned)nq * multi_blocks), dim3(256), multi_descend_lds_bytes<128>() + qstride,
+                                   s, ix->nv, sp, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink, raw, d_qhdrs, single,
+                                   reinterpret_cast<MultiCtl *>(ctx->d_multi), multi_blocks);
+                multi_launched = multi_blocks;
+            } else
+                hipLaunchKernelGGL((k_descend_block<32, 128, 32, 2>), dim3((unsigned)nq), dim3(256), block_lds, s, ix->nv, sp, (uint32_t)nq,
+                                   d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink, last_pass, raw, d_qhdrs, single);
             if (last_pass) {
                 passes_done = true;
                 return AH_OK;
@@ -3235,7 +3779,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
             const bool small_tiles = (long long)nq <= tun(TUN_SEARCH_SMALL_TILES_MAX_QUERIES) && small_slabs <= 65535u;
             if (small_tiles)
                 hipLaunchKernelGGL((k_leaf_tiles16<true>), dim3(std::min<unsigned>(2048u, 32u * (unsigned)nq), small_slabs), dim3(256), 0, s,
-                                   dv, ss, d_nns, d_sorted, d_units, d_n_units, d_dist, nns_stride, d_err);
+                                   dv, ss, d_nns, d_sorted, d_units, d_n_units, d_dist, nns_stride, d_err, 0u, ix->d_desc);
             else
                 hipLaunchKernelGGL((k_leaf_tiles16<false>), dim3(2048, tile_slabs), dim3(256), 0, s, dv, ss, d_nns, d_sorted, d_units,
                                    d_n_units, d_dist, nns_stride, d_err);
@@ -3328,6 +3872,17 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         // (fused_flag: the selection kernel wrote ids, distances, counts and status into the pinned buffers itself)
         if (!fused_flag) AH_HIP(hipMemcpyAsync(h_oi, d_oi, 2 * pad(nq * k * 4) + pad(SS_WORDS * 4) + nq * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipStreamSynchronize(s));
+        if (multi_launched && tun(TUN_SEARCH_MULTI_TRACE) != 0) {  // where the blocks of query 0 spent their time (10 ns ticks -> us)
+            std::vector<uint32_t> tr((size_t)kMultiMaxBlocks * 8);
+            AH_HIP(hipMemcpy(tr.data(), &reinterpret_cast<MultiCtl *>(ctx->d_multi)->trace[0][0], tr.size() * 4, hipMemcpyDeviceToHost));
+            for (uint32_t b = 0; b < multi_launched; b++)
+                fprintf(stderr, "[ah] multi block %u: query in LDS %.2f us, descent left %.2f, counted %.2f%s\n", b, tr[b * 8] * 0.01, tr[b * 8 + 1] * 0.01,
+                        tr[b * 8 + 2] * 0.01, tr[b * 8 + 5] > tr[b * 8 + 2] ? "  <- last" : "");
+            for (uint32_t b = 0; b < multi_launched; b++)
+                if (tr[b * 8 + 5] > tr[b * 8 + 2])
+                    fprintf(stderr, "[ah]   last block %u: lists gathered %.2f us, ordered %.2f, ids copied %.2f (%u leaves known, %u taken)\n", b,
+                            tr[b * 8 + 3] * 0.01, tr[b * 8 + 4] * 0.01, tr[b * 8 + 5] * 0.01, tr[b * 8 + 6], tr[b * 8 + 7]);
+        }
         AH_REQUIRE((*h_err & 1u) == 0 || *h_err == 0xFFFFFFFFu, AH_ERR_MISSING_ITEM, "a descendant id does not exist in the dataset");
         if ((*h_err & ~1u) == 0 && launch_err == hipSuccess) {
             for (size_t q = 0; q < nq; q++) out_counts[q] = (uint32_t)std::min<size_t>(k, h_counts[q]);

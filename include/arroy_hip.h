@@ -44,7 +44,7 @@ extern "C" {
                                   build), ah_build_stats.seconds_setup / seconds_after_device / host_blob_recycled
                               v6: ah_debug_dense_tiles, ah_device_cache_stats, ah_forest_digest_keyed, ah_search_stats.descent_block
                               v7: ah_build_stats.seconds_reserve / seconds_reserve_wait (appended), ah_rerank_stats /
-                                  ah_dataset_rerank_stats, ah_search_stats.rerank_screened8 / screen8_retried_chunks, AH_SYNTH_CLUSTERED / AH_SYNTH_LOW_RANK (arroy_hip_policy.h),
+                                  ah_dataset_rerank_stats, ah_search_stats.rerank_screened8 / screen8_retried_chunks / descent_multi, AH_SYNTH_CLUSTERED / AH_SYNTH_LOW_RANK (arroy_hip_policy.h),
                                   ah_dataset_replicate falls back to a copy through pinned host memory when the two devices
                                   have no peer access */
 
@@ -510,6 +510,8 @@ typedef struct ah_search_stats {
     uint64_t rerank_screened8;      /* queries (of rerank_screened) whose candidates were evaluated on the int8 rows first */
     uint64_t screen8_retried_chunks; /* sub-batches whose int8 stage left more survivors than the selection holds: done again
                                        with the binary16 rows first (eight of them switch the int8 stage of the index off)  */
+    uint64_t descent_multi;         /* queries (of descent_block) whose trees were dealt over several blocks, one wave of
+                                       eight octets each: one query on more than one compute unit (submissions of <= 8 queries) */
 } ah_search_stats;
 AH_API int ah_index_search_stats(ah_index *index, ah_search_stats *out, int reset);
 

@@ -129,7 +129,11 @@ def one(rng, it):
             # random: every combination returns the same bits)
             small = dict(AH_SEARCH_SMALL_UNITS_MAX_QUERIES=int(rng.choice([0, 64])), AH_SEARCH_SMALL_TILES_MAX_QUERIES=int(rng.choice([0, 8, 64])),
                          AH_SEARCH_FUSED_FLAG=int(rng.integers(0, 2)), AH_SEARCH_FUSED_PREPARE=int(rng.integers(0, 2)),
-                         AH_SEARCH_SINGLE_FUSED=int(rng.integers(0, 2))) if ref is not None else {}
+                         AH_SEARCH_SINGLE_FUSED=int(rng.integers(0, 2)),
+                         # (round 6: the trees of a query dealt over several blocks, 1 - 8 trees each; the single query's ids copied by
+                         # the tile launch or by the descent)
+                         AH_SEARCH_MULTI=int(rng.integers(0, 2)), AH_SEARCH_MULTI_TREES_PER_BLOCK=int(rng.integers(1, 9)),
+                         AH_SEARCH_MULTI_IDS_BY_TILES=int(rng.integers(0, 2))) if ref is not None else {}
             with tuning(AH_SEARCH_WAVE=min(wave, 1), AH_SEARCH_BLOCK_MAX_QUERIES=64 if wave == 2 else 0, AH_SEARCH_TILES=min(tiles, 1),
                         AH_SEARCH_SCREEN=0 if tiles == 2 else 1, **small):
                 oi, od, oc = index.search(count2, queries=qs2, search_k=sk2, candidates=cand, raw=True)
@@ -138,6 +142,10 @@ def one(rng, it):
                     o1 = index.search(count2, queries=qs2[pick:pick + 1], search_k=sk2, candidates=cand, raw=True)
                     assert o1[2][0] == oc[pick] and np.array_equal(o1[0][0], oi[pick]) and np.array_equal(o1[1][0].view(np.uint32), od[pick].view(np.uint32)), \
                         desc + f" one-query call differs from its row in the batch: tiles={tiles} q={pick} count={count2} sk={sk2} {small}"
+                    # ... and a call of five (up to 8 queries a call take k_descend_multi when the index has more than 8 trees)
+                    o5 = index.search(count2, queries=qs2[:5], search_k=sk2, candidates=cand, raw=True)
+                    assert np.array_equal(o5[2], oc[:5]) and np.array_equal(o5[0], oi[:5]) and np.array_equal(o5[1].view(np.uint32), od[:5].view(np.uint32)), \
+                        desc + f" five-query call differs from its rows in the batch: tiles={tiles} count={count2} sk={sk2} {small}"
             if ref is None:
                 ref = (oi, od, oc)
                 for i in (0, len(qs2) - 1):

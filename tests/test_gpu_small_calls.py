@@ -14,7 +14,7 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 SMALL_KNOBS = ["AH_SEARCH_BLOCK_MAX_QUERIES", "AH_SEARCH_SMALL_UNITS_MAX_QUERIES", "AH_SEARCH_SMALL_TILES_MAX_QUERIES",
-               "AH_SEARCH_FUSED_FLAG", "AH_SEARCH_FUSED_PREPARE", "AH_SEARCH_SINGLE_FUSED"]
+               "AH_SEARCH_FUSED_FLAG", "AH_SEARCH_FUSED_PREPARE", "AH_SEARCH_SINGLE_FUSED", "AH_SEARCH_MULTI"]
 
 
 def same(a, b):
@@ -60,6 +60,8 @@ def test_small_submissions_equal_the_oracle_and_every_switch_setting(world):
         base = index.search(count, queries=qs, search_k=sk, raw=True)
         st = index.stats()
         assert st["descent_block"] == nq and st["rerank_tiles"] == nq and st["fallback_chunks"] == 0, (nq, st)
+        # round 6: up to 8 queries a call, the 12 trees of a query are dealt over two blocks (k_descend_multi)
+        assert st["descent_multi"] == (nq if nq <= 8 else 0), (nq, st)
         for qi in range(nq):
             want = oracle_search(od, forest, qs[qi], count, sk)
             assert int(base[2][qi]) == len(want) and list(base[0][qi, :len(want)]) == [i for i, _ in want], (nq, qi)
@@ -95,6 +97,72 @@ def test_small_submissions_by_item_and_under_a_filter(world):
             assert list(got[0][qi, :got[2][qi]]) == [i for i, _ in want], (share, qi)
         with _lib.tuning(**{k: 0 for k in SMALL_KNOBS}):
             assert same(index.search(count, queries=queries[:5], search_k=sk, candidates=cand, candidates_sorted=True, raw=True), got)
+
+
+def test_one_query_on_several_compute_units_many_trees_repeated_calls_and_overflow():
+    """k_descend_multi (round 6): 44 trees -> six blocks of one descent wave per query.  The control block the blocks talk through
+    is wiped by the last block of every query: the same call twenty times over gives the same bits (a stale slot would add a
+    phantom leaf).  A search_k that makes a queue pop more than the 32 leaves a list holds raises the failure word: every block
+    leaves, the submission is redone the long way, and the next small call finds the control block clean."""
+    from arroy_amd import Dataset, shard
+    n, dims, trees = 40_000, 64, 44
+    vecs = O.synth(11, 2, n, dims)
+    ds = Dataset(D.Cosine, dims, n)
+    ds.upload_vectors(np.arange(n, dtype=np.uint32), vecs)
+    ds.finalize()
+    od = O.Data(O.COSINE, vecs)
+    forest = ds.build_forest(shard.tree_seeds(11, range(trees)))
+    index = ds.create_index(forest)
+    rng = np.random.default_rng(5)
+    queries = (vecs[rng.choice(n, 24, replace=False)] + rng.standard_normal((24, dims)).astype(np.float32) * np.float32(0.05)).astype(np.float32)
+    count, sk = 20, 2000
+    try:
+        for nq in (1, 3, 8):
+            index.stats(reset=True)
+            base = index.search(count, queries=queries[:nq], search_k=sk, raw=True)
+            st = index.stats()
+            assert st["descent_multi"] == nq and st["fallback_chunks"] == 0, (nq, st)
+            for qi in range(nq):
+                want = oracle_search(od, forest, queries[qi], count, sk)
+                assert list(base[0][qi, :base[2][qi]]) == [i for i, _ in want], (nq, qi)
+                assert base[1][qi, :len(want)].tobytes() == np.array([d for _, d in want], dtype=np.float32).tobytes(), (nq, qi)
+            for _ in range(20):
+                assert same(index.search(count, queries=queries[:nq], search_k=sk, raw=True), base), nq
+            with _lib.tuning(AH_SEARCH_MULTI=0):
+                assert same(index.search(count, queries=queries[:nq], search_k=sk, raw=True), base), nq
+        # different queries call after call (nothing of the previous call may survive in the control block)
+        for i in range(16):
+            got = index.search(count, queries=queries[i:i + 2], search_k=sk, raw=True)
+            with _lib.tuning(AH_SEARCH_MULTI=0):
+                assert same(index.search(count, queries=queries[i:i + 2], search_k=sk, raw=True), got), i
+        # overflow: leaves of <= 64 ids, search_k = n / 2 -> hundreds of leaves per tree
+        with _lib.tuning(AH_SEARCH_SMALL_GATE=0):
+            index.stats(reset=True)
+            big = index.search(count, queries=queries[:2], search_k=n // 2, raw=True)
+            st = index.stats()
+            assert st["fallback_chunks"] >= 1 and st["fallback_queue"] >= 1 and st["descent_multi"] == 0, st
+        for qi in range(2):
+            want = oracle_search(od, forest, queries[qi], count, n // 2)
+            assert list(big[0][qi, :big[2][qi]]) == [i for i, _ in want], qi
+        index.stats(reset=True)
+        again = index.search(count, queries=queries[:3], search_k=sk, raw=True)
+        assert index.stats()["descent_multi"] == 3
+        with _lib.tuning(AH_SEARCH_MULTI=0):
+            assert same(index.search(count, queries=queries[:3], search_k=sk, raw=True), again)
+        # under a filter (the kept ids of a leaf are copied octet by octet) and by item
+        cand = np.arange(0, n, 2, dtype=np.uint32)
+        got = index.search(count, queries=queries[:4], search_k=sk, candidates=cand, candidates_sorted=True, raw=True)
+        for qi in range(4):
+            want = oracle_search(od, forest, queries[qi], count, sk, cand)
+            assert list(got[0][qi, :got[2][qi]]) == [i for i, _ in want], qi
+        items = np.array([5, 39_999, 1234], dtype=np.uint32)
+        got = index.search(count, items=items, search_k=sk, raw=True)
+        with _lib.tuning(AH_SEARCH_MULTI=0):
+            assert same(index.search(count, items=items, search_k=sk, raw=True), got)
+    finally:
+        index.close()
+        forest.close()
+        ds.close()
 
 
 def test_more_visits_than_the_one_block_unit_builder_holds_fall_back(world):

@@ -160,3 +160,98 @@ def test_the_cut_inside_equal_keys_of_two_octets_is_given_up():
     assert sequential(f, 90) == [3]            # node 3 > node 0: the 227-id leaf alone
     assert wave_model(f, 90) is None           # trees 0 and 1 are different octets: left to the sequential queue
     assert sorted(wave_model(f, 400)) == sorted(sequential(f, 400))  # everything is taken: no cut inside the group
+
+
+def multi_model(forest, search_k, n_blocks, rng, leaf_cap=32):
+    """k_descend_multi (round 6): the trees dealt over `n_blocks` blocks of eight queues (t = block + n_blocks * (octet + 8 i)),
+    every block popping at its own pace and learning of the other blocks' leaves LATE (a random delay per leaf).  A block
+    stops when its queues are empty, or when the leaves it knows of — its own and the reported ones, settled or not — hold
+    search_k ids at some key x and everything it still has queued lies strictly below x.  The last block orders ALL popped
+    leaves (key, list, pop order) and takes the prefix; a cut through equal keys of two lists is left to the sequential
+    queue.  Returns the taken leaves or None."""
+    heaps = [[[] for _ in range(8)] for _ in range(n_blocks)]
+    lists = [[[] for _ in range(8)] for _ in range(n_blocks)]   # (key, node, ids) in the queue's pop order
+    known = [[] for _ in range(n_blocks)]                       # (key, ids) a block knows of
+    in_flight = []                                              # (arrival step, destination block, key, ids)
+    for t, r in enumerate(forest.roots):
+        g, slot = t % n_blocks, t // n_blocks
+        heapq.heappush(heaps[g][slot % 8], (-float("inf"), -r))
+    running = [True] * n_blocks
+    step = 0
+    while any(running):
+        step += 1
+        for g in range(n_blocks):
+            if not running[g] or rng.random() < 0.3:  # a block that is slow this step
+                continue
+            for o in range(8):
+                if not heaps[g][o]:
+                    continue
+                nk, nn = heapq.heappop(heaps[g][o])
+                key, node = -nk, -nn
+                if forest.nodes[node][0] == "leaf":
+                    ids = forest.nodes[node][1]
+                    if ids == 0:
+                        continue
+                    if len(lists[g][o]) == leaf_cap:
+                        return None
+                    lists[g][o].append((key, node, ids))
+                    known[g].append((key, ids))
+                    for other in range(n_blocks):
+                        if other != g:
+                            in_flight.append((step + int(rng.integers(0, 6)), other, key, ids))
+                else:
+                    for ck, child in children(forest, node, key):
+                        heapq.heappush(heaps[g][o], (-ck, -child))
+        late = [x for x in in_flight if x[0] > step]
+        for item in in_flight:
+            if item[0] <= step:
+                known[item[1]].append((item[2], item[3]))
+        in_flight = late
+        for g in range(n_blocks):
+            if not running[g]:
+                continue
+            tops = [-h[0][0] for h in heaps[g] if h]
+            if not tops:
+                running[g] = False
+                continue
+            # x = the largest key at which the known leaves hold search_k ids
+            x, held = None, 0
+            for key, ids in sorted(known[g], reverse=True):
+                held += ids
+                if held >= search_k:
+                    x = key  # (every leaf with this key or a greater one is counted by the time the sum is reached, or later: >=)
+                    break
+            if x is not None and max(tops) < x:
+                running[g] = False
+    merged = [(key, g * 8 + o, i, node, ids) for g in range(n_blocks) for o in range(8)
+              for i, (key, node, ids) in enumerate(lists[g][o])]
+    merged.sort(key=lambda e: (-e[0], -e[1], e[2]))
+    taken, held = [], 0
+    for key, lst, _i, node, ids in merged:
+        if held >= search_k:
+            break
+        taken.append(node)
+        held += ids
+        if held >= search_k and any(k2 == key and l2 != lst for (k2, l2, *_r) in merged):
+            return None
+    return taken
+
+
+@pytest.mark.parametrize("tie_level", [0.0, 0.3, 0.9])
+def test_multi_block_model_takes_the_sequential_candidates(tie_level):
+    rng = np.random.default_rng(int(tie_level * 10) + 77)
+    answered = given_up = 0
+    for _ in range(600):
+        n_trees = int(rng.choice([9, 12, 17, 20, 33, 100]))
+        n_blocks = min(16, (n_trees + 7) // 8)
+        forest = Forest(rng, n_trees, int(rng.integers(1, 6)), tie_level)
+        total = sum(n[1] for n in forest.nodes if n[0] == "leaf")
+        search_k = int(rng.choice([1, 5, 30, 90, 300, total, 10 * total]))
+        want = sequential(forest, search_k)
+        got = multi_model(forest, search_k, n_blocks, rng)
+        if got is None:
+            given_up += 1
+            continue
+        answered += 1
+        assert sorted(got) == sorted(n for n in want if forest.nodes[n][1]), (n_trees, n_blocks, search_k)
+    assert answered > given_up or tie_level > 0.5, (answered, given_up)
