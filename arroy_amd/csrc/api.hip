@@ -143,6 +143,7 @@ std::mutex &g_dev_mu = *new std::mutex();
 std::vector<DevBlock> &g_dev_idle = *new std::vector<DevBlock>();  // blocks nobody uses, oldest first
 std::vector<DevBlock> &g_dev_live = *new std::vector<DevBlock>();  // blocks handed out (a few hundred at most: a linear scan is fine)
 size_t g_dev_idle_bytes = 0;
+size_t g_dev_pending = 0;  // records promised to dev_malloc calls that have not pushed theirs yet (under g_dev_mu)
 inline size_t dev_round(size_t bytes) {  // whole 2 MiB for the big blocks (what the driver maps anyway), 4 KiB below
     const size_t g = bytes >= (1u << 20) ? (2u << 20) : 4096u;
     return (std::max<size_t>(bytes, 1) + g - 1) / g * g;
@@ -227,12 +228,26 @@ hipError_t dev_malloc(void **p, size_t bytes, bool optional) {
     if (e != hipSuccess) return e;
     const size_t want = dev_round(bytes);
     const bool caching = tun(TUN_DEVICE_CACHE_MB) > 0;
-    try {  // room for the block's record BEFORE the block is taken: a failed push_back afterwards would lose it
+    // Room for the block's record BEFORE the block is taken (a failed push_back afterwards would lose it) — and kept for THIS
+    // caller: the slots promised to calls still between here and their push_back are counted (`g_dev_pending`), so two concurrent
+    // allocations cannot be promised the same one (round-5 advice); growth is geometric, not one exact-fit reallocation per block.
+    try {
         std::lock_guard<std::mutex> lk(g_dev_mu);
-        g_dev_live.reserve(g_dev_live.size() + 1);
+        const size_t need = g_dev_live.size() + g_dev_pending + 1;
+        if (g_dev_live.capacity() < need) g_dev_live.reserve(std::max(need, 2 * g_dev_live.capacity()));
+        g_dev_pending++;
     } catch (...) {
         return hipErrorOutOfMemory;
     }
+    struct Promise {  // gives the slot back on every way out that did not use it
+        bool used = false;
+        ~Promise() {
+            if (!used) {
+                std::lock_guard<std::mutex> lk(g_dev_mu);
+                g_dev_pending--;
+            }
+        }
+    } promise;
     if (caching) {
         std::lock_guard<std::mutex> lk(g_dev_mu);
         size_t best = g_dev_idle.size();
@@ -248,6 +263,8 @@ hipError_t dev_malloc(void **p, size_t bytes, bool optional) {
             g_dev_idle.erase(g_dev_idle.begin() + (ptrdiff_t)best);
             g_dev_idle_bytes -= b.bytes;
             g_dev_live.push_back(b);
+            g_dev_pending--;
+            promise.used = true;
             *p = b.p;
             return hipSuccess;
         }
@@ -262,6 +279,8 @@ hipError_t dev_malloc(void **p, size_t bytes, bool optional) {
     {
         std::lock_guard<std::mutex> lk(g_dev_mu);
         g_dev_live.push_back(DevBlock{q, want, device});
+        g_dev_pending--;
+        promise.used = true;
     }
     *p = q;
     return hipSuccess;

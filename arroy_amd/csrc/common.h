@@ -152,6 +152,7 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(SEARCH_MULTI, "AH_SEARCH_MULTI", 1)       /* 0: a small submission never deals a query's trees over several blocks (k_descend_multi) */ \
     X(SEARCH_MULTI_TREES_PER_BLOCK, "AH_SEARCH_MULTI_TREES_PER_BLOCK", 8) /* ... trees per block (1 - 8: one per octet of its descent wave) */ \
     X(SEARCH_MULTI_IDS_BY_TILES, "AH_SEARCH_MULTI_IDS_BY_TILES", 1) /* 0: the last block of k_descend_multi copies a single query's ids itself */ \
+    X(SEARCH_SPIN_WAIT, "AH_SEARCH_SPIN_WAIT", 1) /* 0: a small submission waits with hipStreamSynchronize instead of polling the status word its last kernel writes into pinned memory */ \
     X(SEARCH_MULTI_TRACE, "AH_SEARCH_MULTI_TRACE", 0) /* 1: ah_search_batch prints where the blocks of query 0 spent their time (stderr) */ \
     X(SEARCH_MULTI_MAX_QUERIES, "AH_SEARCH_MULTI_MAX_QUERIES", 8) /* ... up to this many queries a call (at most 8: the control block's size) */ \
     X(RERANK_GROUPS, "AH_RERANK_GROUPS", 2)     /* groups a screened ah_rerank_batch submission is cut into (upload of group g + 1 under the kernel of g) */ \

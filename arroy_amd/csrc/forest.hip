@@ -4138,6 +4138,7 @@ int ah_device_cache_trim(int device, uint64_t *out_bytes) {
 }
 
 int ah_device_cache_stats(int device, uint64_t *out_live_bytes, uint64_t *out_idle_bytes) {
+    AH_GUARDED("ah_device_cache_stats")
     if (out_live_bytes) *out_live_bytes = dev_cache_live_bytes(device);
     if (out_idle_bytes) {
         uint64_t idle = 0;
@@ -4151,6 +4152,7 @@ int ah_device_cache_stats(int device, uint64_t *out_live_bytes, uint64_t *out_id
         *out_idle_bytes = idle;
     }
     return AH_OK;
+    AH_GUARDED_END
 }
 
 int ah_host_cache_trim(uint64_t *out_bytes) {

@@ -14,6 +14,7 @@
 // with the queue in global memory (capacity = number of nodes, a hard bound: every node is pushed at most
 // once).
 #include <algorithm>
+#include <chrono>
 #include <new>
 
 #include "common.h"
@@ -1013,6 +1014,7 @@ struct MultiCtl {
     unsigned long long leaf[kMultiLists][kMultiLeaves];  // key word << 32 | ids the leaf adds (never 0); list = block * 8 + octet
     unsigned long long info[kMultiLists][kMultiLeaves];  // node << 32 | first id of the leaf in the blob
     uint32_t trace[kMultiMaxBlocks][8];                  // AH_SEARCH_MULTI_TRACE: 10 ns ticks since the block started (see the kernel)
+    uint32_t sel_trace[16];                              // ... and of the selection kernel behind it (k_search_select_screened<*, true>)
 };
 size_t multi_ctl_bytes() { return (size_t)kMultiMaxQueries * sizeof(MultiCtl); }
 template <uint32_t kHeap>
@@ -2258,7 +2260,8 @@ __global__ __launch_bounds__(64) void k_queries_i8(const uint8_t *__restrict__ q
 template <int R, int Q, int QO, int KF = 1>
 __device__ __forceinline__ void leaf_tile16(const ScreenSearch &ss, const DataView &dv, const uint32_t *__restrict__ leaf_ids,
                                             uint32_t row_begin, uint32_t n_rows, const Visit *__restrict__ vis, uint32_t n_vis,
-                                            float *__restrict__ dist, uint32_t stride, uint32_t *err, uint32_t *__restrict__ copy_ids_to = nullptr) {
+                                            float *__restrict__ dist, uint32_t stride, uint32_t *err, uint32_t *__restrict__ copy_ids_to = nullptr,
+                                            const Visit *only_visit = nullptr) {
     constexpr uint32_t RO = 8 / QO;
     const uint32_t j = threadIdx.x & 7u, ow = (threadIdx.x >> 3) & 7u, wave = threadIdx.x >> 6;
     const uint32_t q_oct = ow % QO, row_oct = wave * RO + ow / QO;
@@ -2267,7 +2270,8 @@ __device__ __forceinline__ void leaf_tile16(const ScreenSearch &ss, const DataVi
     uint64_t out[Q];  // index of the pair of (query t, first row of the leaf) in the candidate buffers
 #pragma unroll
     for (int t = 0; t < Q; t++) {
-        const Visit v = vis[min(q_oct * Q + (uint32_t)t, n_vis - 1)];
+        // (only_visit: the unit's one visit, already in the caller's registers — a trip to memory less on a small submission's chain)
+        const Visit v = only_visit ? *only_visit : vis[min(q_oct * Q + (uint32_t)t, n_vis - 1)];
         q4[t] = reinterpret_cast<const uint4 *>(ss.q16 + (uint64_t)v.q * ss.hpitch) + j;
         out[t] = (uint64_t)v.q * stride + v.pos;
     }
@@ -2343,13 +2347,24 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
                                                       const Visit *__restrict__ sorted, const TileUnit *__restrict__ units,
                                                       const uint32_t *__restrict__ n_units_p, float *__restrict__ dist,
                                                       uint32_t stride, uint32_t *err, uint32_t min_vis = 0,
-                                                      const uint32_t *__restrict__ blob = nullptr) {
+                                                      const uint32_t *__restrict__ blob = nullptr, uint32_t speculate = 0) {
+    // SMALL + speculate (the host: both tables hold at least gridDim.x entries): the block's first unit and the visit with the
+    // unit's number are requested together with the unit count — a single query's units are its visits in order, and the chain
+    // count -> unit -> visit -> ids -> rows of dependent trips to memory is most of such a launch's time
+    TileUnit unit_first{};
+    Visit visit_first{};
+    if (SMALL && speculate) {
+        unit_first = units[blockIdx.x];
+        visit_first = sorted[blockIdx.x];
+    }
     const uint32_t n_units = *n_units_p;
     for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const TileUnit unit = units[u];
+        const bool spec = SMALL && speculate && u == blockIdx.x;
+        const TileUnit unit = spec ? unit_first : units[u];
         if (unit.n_vis < min_vis) continue;  // (the units of few visits went to k_leaf_tiles8)
         const Visit *vis = sorted + unit.first;
-        const uint32_t n_leaf = vis[0].n;
+        const Visit v0 = (spec && unit.first == u) ? visit_first : vis[0];
+        const uint32_t n_leaf = v0.n;
         // SMALL (its own kernel: the registers of the in-flight variant would cost the big submissions their occupancy): a small
         // submission — the leaves of one or two queries in slabs of kTileSmallSlab rows, two rows per octet with the whole row
         // in flight; the launch's grid.y counts those slabs
@@ -2358,14 +2373,14 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
         const uint32_t row_begin = blockIdx.y * slab;
         if (row_begin >= n_leaf) continue;
         const uint32_t row_end = min(n_leaf, row_begin + slab);
-        const uint32_t *leaf_ids = nns + (uint64_t)vis[0].q * stride + vis[0].pos;
+        const uint32_t *leaf_ids = nns + (uint64_t)v0.q * stride + v0.pos;
 #define AH_TILE16(R, Q, QO) leaf_tile16<R, Q, QO, AH_TILES16_KF>(ss, dv, leaf_ids, row_begin, row_end, vis, n_vis, dist, stride, err)
         if constexpr (SMALL) {
             if (fly && n_vis == 1) {
                 // (unit.pad != 0: the ids are still in the blob, this launch copies them — SingleQueryOut::ids_by_tiles)
                 const bool from_blob = blob && unit.pad != 0u;
                 leaf_tile16<2, 1, 1, 24>(ss, dv, from_blob ? blob + (unit.pad - 1u) : leaf_ids, row_begin, row_end, vis, n_vis, dist, stride, err,
-                                         from_blob ? const_cast<uint32_t *>(leaf_ids) : nullptr);
+                                         from_blob ? const_cast<uint32_t *>(leaf_ids) : nullptr, &v0);
                 continue;
             }
             if (fly) {
@@ -2598,7 +2613,11 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
                                                                  uint32_t *__restrict__ out_ids, float *__restrict__ out_dist,
                                                                  uint32_t *err, const PairSeg *__restrict__ segs,
                                                                  uint32_t flag_words, uint32_t id_limit,
-                                                                 uint32_t *__restrict__ unique_out) {
+                                                                 uint32_t *__restrict__ unique_out, uint32_t *__restrict__ trace = nullptr) {
+    const uint64_t t_start = trace ? wall_clock64() : 0ull;
+    auto stamp = [&](uint32_t slot) {  // (AH_SEARCH_MULTI_TRACE: where a single query's selection spends its time)
+        if (trace && threadIdx.x == 0 && blockIdx.x == 0) trace[slot] = (uint32_t)(wall_clock64() - t_start);
+    };
     // FLAG (a small submission of ah_search_batch, n <= 16 384): nns.dedup() done here, on the ids this block holds in registers
     // anyway — k_flag_duplicates' bitmap (flag_words words of dynamic LDS behind the query leaf) without its launch, its trip to
     // the candidate buffer and back, and the `unique` it would have left is written to unique_out
@@ -2639,6 +2658,7 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
         s_bin = 0u;  // (FLAG: the count of distinct ids until the histogram's scan takes the word over)
     }
     __syncthreads();
+    stamp(0);
     const float qn = qhdrs[2 * (uint64_t)q];
     // int8 first stage: the error bound is the query's A_q times the candidate's row scale; binary16: one number per query
     // (a negative "row scale": the value came from the binary16 rows — a submission may mix the two, see k_leaf_tiles8)
@@ -2680,6 +2700,8 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
             v_sr[r] = (s8 && g < n) ? srs[g] : 0.0f;
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (trace && own_id[0] == 0x12345678u && v_sd[kOwn - 1] == 1.5f) trace[15] = 1;  // (trace only: the loads have arrived at the stamp)
+        stamp(1);
         if constexpr (FLAG) {  // the second and later occurrences of an id drop out (which one stays does not matter: same id, same row)
             uint32_t mine = 0;
             bool bad_id = false;
@@ -2708,6 +2730,7 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
             }
             if (kk == 0) return;  // block-uniform
         }
+        stamp(2);
 #pragma unroll
         for (uint32_t r = 0; r < kOwn; r++) {
             own_u[r] = own_l[r] = 0;
@@ -2741,6 +2764,7 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
         if (tid == 0) atomicOr(err, 4u);
         return;
     }
+    stamp(3);
     const uint32_t w_min = s_min;
     const uint64_t span = (uint64_t)(s_max - w_min) + 1ull;
     const bool direct = span <= kBins;
@@ -2775,6 +2799,7 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
         }
     }
     __syncthreads();
+    stamp(4);
     const uint32_t bin_k = s_bin;
     // T = the largest key of that bin (>= the k-th smallest U: a valid, slightly generous threshold).  In closed form:
     // bin_of(w) <= bin_k  <=>  (w - w_min) * scale < (bin_k + 1) << 32  <=>  w - w_min <= ceil(((bin_k + 1) << 32) / scale) - 1
@@ -2799,6 +2824,7 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
     })
 #undef AH_SELECT_REST
     __syncthreads();
+    stamp(5);
     const uint32_t n_sel = s_n;
     if (n_sel > kCap) {
         if (tid == 0) atomicOr(err, 8u);
@@ -2816,8 +2842,7 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
         const uint32_t id = s_pos[e];
         const uint64_t row = row_of_id(dv, id);
         const float xh = METRIC == AH_COSINE ? dv.headers[row] : 0.0f;
-        // (a small submission — FLAG — is this one block on an idle device: 24 lines in flight, two trips per 1536-d row, not three)
-        const float r = octet_reduce_stream<OP_DOT, FLAG ? 24 : 16, true>(s_qf4, dv.rows_f32 + row * dv.pitch, dv.dims, j);
+        const float r = octet_reduce_stream<OP_DOT, 16, true>(s_qf4, dv.rows_f32 + row * dv.pitch, dv.dims, j);
         const float d = METRIC == AH_COSINE ? cosine_from_dot(r, qn, xh) : -r;
         if (j == 0) {
             const uint32_t w = orderable_key(d);
@@ -2828,6 +2853,7 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
     }
     if (bad) atomicOr(err, 4u);
     __syncthreads();
+    stamp(6);
     // ascending (OrderedFloat(distance), id): a survivor's place is the number of smaller keys (unique: the id is their low
     // word) — n_sel broadcast reads per thread and one barrier instead of a sorting network's 36 - 55
     for (uint32_t e = tid; e < n_sel; e += kThreads) {
@@ -2850,6 +2876,8 @@ __device__ __forceinline__ void search_select_screened_body(DataView dv, ScreenS
             out_dist[(uint64_t)q * k_out + rank] = normalized_distance(dv.metric, s_val[e], dv.dims);
         }
     }
+    stamp(7);
+    if (trace && threadIdx.x == 0 && blockIdx.x == 0) trace[9] = n_sel;
 }
 
 // host_status != nullptr (a small submission; out_ids / out_dist / unique_out are then the caller's pinned buffers): the block
@@ -2865,15 +2893,23 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
                                                                  uint32_t *err, const PairSeg *__restrict__ segs,
                                                                  uint32_t flag_words = 0, uint32_t id_limit = 0,
                                                                  uint32_t *__restrict__ unique_out = nullptr,
-                                                                 uint32_t *__restrict__ host_status = nullptr) {
+                                                                 uint32_t *__restrict__ host_status = nullptr,
+                                                                 uint32_t *__restrict__ trace = nullptr) {
+    const uint64_t t_start = trace ? wall_clock64() : 0ull;
     search_select_screened_body<METRIC, FLAG>(dv, ss, nns, dist_all, stride, counts, unique, k_out, qvecs, qstride, qhdrs, out_ids, out_dist,
-                                              err, segs, flag_words, id_limit, unique_out);
+                                              err, segs, flag_words, id_limit, unique_out, trace);
     if (host_status) {  // (every return of the body is block-uniform)
-        __threadfence();
+        // The results went to the caller's pinned buffers: system-scope fences, and word 0 of the status LAST — the host may be
+        // polling that word instead of waiting for the stream (AH_SEARCH_SPIN_WAIT), and what it reads after it must be there.
+        __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0 && atomicAdd(&err[SS_DONE], 1u) + 1u == gridDim.x) {
-            __threadfence();
-            for (uint32_t w = 0; w < SS_WORDS; w++) host_status[w] = __hip_atomic_load(&err[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            for (uint32_t w = 1; w < SS_WORDS; w++) host_status[w] = __hip_atomic_load(&err[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(&host_status[0], __hip_atomic_load(&err[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            if (trace) trace[8] = (uint32_t)(wall_clock64() - t_start);
         }
     }
 }
@@ -3779,7 +3815,8 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
             const bool small_tiles = (long long)nq <= tun(TUN_SEARCH_SMALL_TILES_MAX_QUERIES) && small_slabs <= 65535u;
             if (small_tiles)
                 hipLaunchKernelGGL((k_leaf_tiles16<true>), dim3(std::min<unsigned>(2048u, 32u * (unsigned)nq), small_slabs), dim3(256), 0, s,
-                                   dv, ss, d_nns, d_sorted, d_units, d_n_units, d_dist, nns_stride, d_err, 0u, ix->d_desc);
+                                   dv, ss, d_nns, d_sorted, d_units, d_n_units, d_dist, nns_stride, d_err, 0u, ix->d_desc,
+                                   visit_cap >= std::min<unsigned>(2048u, 32u * (unsigned)nq) ? 1u : 0u);
             else
                 hipLaunchKernelGGL((k_leaf_tiles16<false>), dim3(2048, tile_slabs), dim3(256), 0, s, dv, ss, d_nns, d_sorted, d_units,
                                    d_n_units, d_dist, nns_stride, d_err);
@@ -3848,14 +3885,15 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
             AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_select_screened<AH_DOT_PRODUCT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sel_lds));
         }
+        uint32_t *sel_trace = multi_launched && tun(TUN_SEARCH_MULTI_TRACE) != 0 ? &reinterpret_cast<MultiCtl *>(ctx->d_multi)->sel_trace[0] : nullptr;
         if (fused_flag && ds->metric == AH_COSINE)
             hipLaunchKernelGGL((k_search_select_screened<AH_COSINE, true>), dim3((unsigned)nq), dim3(1024), fused_lds, s, dv, ss, d_nns, d_dist,
                                nns_stride, d_counts, d_unique, (uint32_t)k, d_qvecs, qstride, d_qhdrs, h_oi, h_od, d_err, (const PairSeg *)nullptr,
-                               bitmap_words, max_id + 1, h_counts, h_err);
+                               bitmap_words, max_id + 1, h_counts, h_err, sel_trace);
         else if (fused_flag)
             hipLaunchKernelGGL((k_search_select_screened<AH_DOT_PRODUCT, true>), dim3((unsigned)nq), dim3(1024), fused_lds, s, dv, ss, d_nns,
                                d_dist, nns_stride, d_counts, d_unique, (uint32_t)k, d_qvecs, qstride, d_qhdrs, h_oi, h_od, d_err,
-                               (const PairSeg *)nullptr, bitmap_words, max_id + 1, h_counts, h_err);
+                               (const PairSeg *)nullptr, bitmap_words, max_id + 1, h_counts, h_err, sel_trace);
         else if (screened && ds->metric == AH_COSINE)
             hipLaunchKernelGGL((k_search_select_screened<AH_COSINE>), dim3((unsigned)nq), dim3(1024), sel_lds, s, dv, ss, d_nns, d_dist,
                                nns_stride, d_counts, d_unique, (uint32_t)k, d_qvecs, qstride, d_qhdrs, d_oi, d_od, d_err, (const PairSeg *)nullptr);
@@ -3871,7 +3909,24 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         // ids, distances, status words and counts: one copy (the four buffers are carved back to back on both sides)
         // (fused_flag: the selection kernel wrote ids, distances, counts and status into the pinned buffers itself)
         if (!fused_flag) AH_HIP(hipMemcpyAsync(h_oi, d_oi, 2 * pad(nq * k * 4) + pad(SS_WORDS * 4) + nq * 4, hipMemcpyDeviceToHost, s));
-        AH_HIP(hipStreamSynchronize(s));
+        // fused_flag: the selection's last block writes the status into pinned memory as the last thing the submission does (word 0
+        // after everything else, system-scope release).  Polling that word returns as soon as it lands; the runtime's own wait adds
+        // the end-of-kernel bookkeeping and its wake-up (AH_SEARCH_SPIN_WAIT=0: hipStreamSynchronize as before; it is also what
+        // happens after 2 ms without an answer — a launch that never ran).  Everything queued later runs behind this submission in
+        // stream order, so its scratch is safe to reuse.
+        bool answered = false;
+        if (fused_flag && launch_err == hipSuccess && tun(TUN_SEARCH_SPIN_WAIT) != 0) {
+            const auto t_spin = std::chrono::steady_clock::now();
+            for (uint32_t spin = 0;; spin++) {
+                if (__atomic_load_n(h_err, __ATOMIC_ACQUIRE) != 0xFFFFFFFFu) {
+                    answered = true;
+                    break;
+                }
+                __builtin_ia32_pause();
+                if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(2)) break;
+            }
+        }
+        if (!answered) AH_HIP(hipStreamSynchronize(s));
         if (multi_launched && tun(TUN_SEARCH_MULTI_TRACE) != 0) {  // where the blocks of query 0 spent their time (10 ns ticks -> us)
             std::vector<uint32_t> tr((size_t)kMultiMaxBlocks * 8);
             AH_HIP(hipMemcpy(tr.data(), &reinterpret_cast<MultiCtl *>(ctx->d_multi)->trace[0][0], tr.size() * 4, hipMemcpyDeviceToHost));
@@ -3880,8 +3935,15 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                         tr[b * 8 + 2] * 0.01, tr[b * 8 + 5] > tr[b * 8 + 2] ? "  <- last" : "");
             for (uint32_t b = 0; b < multi_launched; b++)
                 if (tr[b * 8 + 5] > tr[b * 8 + 2])
-                    fprintf(stderr, "[ah]   last block %u: lists gathered %.2f us, ordered %.2f, ids copied %.2f (%u leaves known, %u taken)\n", b,
+                    fprintf(stderr, "[ah]   (stale unless marked) last block %u: lists gathered %.2f us, ordered %.2f, ids copied %.2f (%u leaves known, %u taken)\n", b,
                             tr[b * 8 + 3] * 0.01, tr[b * 8 + 4] * 0.01, tr[b * 8 + 5] * 0.01, tr[b * 8 + 6], tr[b * 8 + 7]);
+        }
+        if (multi_launched && tun(TUN_SEARCH_MULTI_TRACE) != 0) {
+            uint32_t st[16];
+            AH_HIP(hipMemcpy(st, &reinterpret_cast<MultiCtl *>(ctx->d_multi)->sel_trace[0], sizeof(st), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[ah] selection: leaf + tables in LDS %.2f us, candidates in registers %.2f, duplicates flagged %.2f, key range %.2f, "
+                    "k-th bin %.2f, survivors listed %.2f (%u), f32 distances %.2f, ranked + written %.2f, status written %.2f\n", st[0] * 0.01,
+                    st[1] * 0.01, st[2] * 0.01, st[3] * 0.01, st[4] * 0.01, st[5] * 0.01, st[9], st[6] * 0.01, st[7] * 0.01, st[8] * 0.01);
         }
         AH_REQUIRE((*h_err & 1u) == 0 || *h_err == 0xFFFFFFFFu, AH_ERR_MISSING_ITEM, "a descendant id does not exist in the dataset");
         if ((*h_err & ~1u) == 0 && launch_err == hipSuccess) {

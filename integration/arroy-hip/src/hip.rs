@@ -203,6 +203,7 @@ extern "C" {
     fn ah_forest_destroy(forest: *mut AhForest) -> c_int;
     fn ah_preprocess_dot(ds: *mut AhDataset, out_max_norm: *mut f32) -> c_int;
     fn ah_dataset_read_headers(ds: *mut AhDataset, first_row: u64, n: u64, out_headers: *mut c_void) -> c_int;
+    fn ah_tuning_set(name: *const c_char, value: i64) -> c_int;
 }
 
 // ---- layout self-checks: generated by integration/arroy-hip/tools/gen_layout.py from include/arroy_hip.h ----
@@ -345,6 +346,15 @@ pub fn stage_leafs<D: Distance>(
     preprocessed: bool,
 ) -> Result<HipLeafs<D>> {
     assert_eq!(unsafe { ah_abi_version() }, AH_ABI_VERSION, "libarroy_hip.so of another ABI version");
+    // A `Writer` stages one dataset per build and drops it afterwards: by default the library would give its cached device
+    // memory and host blobs back every time the last dataset goes (a fresh 30 GB `hipMalloc` is ~1 s of page scrubbing on the
+    // next build).  arroy keeps them for the life of the process unless the operator says otherwise in the environment.
+    static KEEP_CACHES: std::sync::Once = std::sync::Once::new();
+    KEEP_CACHES.call_once(|| {
+        if std::env::var_os("AH_CACHE_KEEP_IDLE").is_none() {
+            let _ = unsafe { ah_tuning_set(b"AH_CACHE_KEEP_IDLE\0".as_ptr() as *const c_char, 1) };
+        }
+    });
     let mut ds = std::ptr::null_mut();
     check(unsafe { ah_dataset_create(metric_of::<D>()?, dimensions as u32, items.len(), device, &mut ds) }, index)?;
     let (ids, ptrs, record_len) = leafs.raw_records(items);
