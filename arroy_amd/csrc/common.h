@@ -155,6 +155,7 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(SEARCH_SPIN_WAIT, "AH_SEARCH_SPIN_WAIT", 1) /* 0: a small submission waits with hipStreamSynchronize instead of polling the status word its last kernel writes into pinned memory */ \
     X(SEARCH_MULTI_TRACE, "AH_SEARCH_MULTI_TRACE", 0) /* 1: ah_search_batch prints where the blocks of query 0 spent their time (stderr) */ \
     X(SEARCH_MULTI_MAX_QUERIES, "AH_SEARCH_MULTI_MAX_QUERIES", 8) /* ... up to this many queries a call (at most 8: the control block's size) */ \
+    X(EXACT_WIDE, "AH_EXACT_WIDE", 1)           /* 0: k_forest_exact_pairs streams the row eight lines at a time (rounds 2-5) instead of asking for row and normal whole */ \
     X(RERANK_GROUPS, "AH_RERANK_GROUPS", 2)     /* groups a screened ah_rerank_batch submission is cut into (upload of group g + 1 under the kernel of g) */ \
     X(RERANK_SCREEN8, "AH_RERANK_SCREEN8", 1)   /* 0: the screen of ah_rerank_batch starts on the binary16 rows, never on the int8 copy */ \
     X(SEARCH_SCREEN8_MAX_VISITS, "AH_SEARCH_SCREEN8_MAX_VISITS", 4) /* leaves reached by at most this many queries of a call are screened on the int8 rows, the others on the binary16 rows */ \

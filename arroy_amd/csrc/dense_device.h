@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void k_exact_coverage(uint64_t n_rows, uint32_
         if ((threadIdx.x & 63u) == 0) atomicAdd(&counts[t * blocks_per_tree + rb], 1u);
     }
 }
-template <int METRIC>
+template <int METRIC, bool WIDE = false>
 __global__ __launch_bounds__(256) void k_forest_exact_pairs(DataView dv, const uint32_t *__restrict__ node_of,
                                                             uint8_t *__restrict__ side_bytes, uint32_t n_trees,
                                                             const uint8_t *__restrict__ normals, uint64_t nstride,
@@ -578,7 +578,8 @@ __global__ __launch_bounds__(256) void k_forest_exact_pairs(DataView dv, const u
             const uint32_t code = ent >> 16;
             const uint32_t node = active ? node_of[base + r] : 0xFFFFFFFFu;
             if (node != 0xFFFFFFFFu) {  // octet-uniform
-                const uint32_t exact = side_of_margin(rows_exact_margin<METRIC>(dv, r, normals + (uint64_t)node * nstride, hdr_off, j));
+                const uint32_t exact = side_of_margin(WIDE ? rows_exact_margin_wide<METRIC>(dv, r, normals + (uint64_t)node * nstride, hdr_off, j)
+                                                           : rows_exact_margin<METRIC>(dv, r, normals + (uint64_t)node * nstride, hdr_off, j));
                 if (j == 0) {
                     side_bytes[base + r] = (uint8_t)exact;
                     if (code == kSideUndecided) fallbacks++;

@@ -1236,6 +1236,24 @@ __device__ __forceinline__ float rows_exact_margin(const DataView &dv, uint64_t 
     return d;
 }
 
+// The same bits with every line of the row AND of the normal requested before the first multiply-add (octet_reduce_wide: two
+// trips to memory per pair — node index, then both operands — instead of one per eight lines): k_forest_exact_pairs, whose waves
+// spend their time between dependent loads (192 registers: for kernels that live on loads in flight, not on occupancy).
+template <int METRIC>
+__device__ __forceinline__ float rows_exact_margin_wide(const DataView &dv, uint64_t row, const uint8_t *nrec, uint64_t hdr_off,
+                                                        uint32_t j) {
+    const float *rp = dv.rows_f32 + row * dv.pitch;
+    const float *np = reinterpret_cast<const float *>(nrec);
+    const float *nh = reinterpret_cast<const float *>(nrec + hdr_off);
+    float h0 = 0.0f, rh = 0.0f;
+    if (METRIC == AH_EUCLIDEAN || METRIC == AH_MANHATTAN || METRIC == AH_DOT_PRODUCT) h0 = nh[0];
+    if (METRIC == AH_DOT_PRODUCT) rh = dv.headers[2 * row];
+    const float d = octet_reduce_wide<OP_DOT, false>(np, rp, dv.dims, j);  // (normal x row: the operand order of octet_reduce_stream above)
+    if (METRIC == AH_EUCLIDEAN || METRIC == AH_MANHATTAN) return f_add(h0, d);
+    if (METRIC == AH_DOT_PRODUCT) return f_add(d, f_mul(h0, rh));
+    return d;
+}
+
 #ifndef AH_SCREEN_CHUNK
 #define AH_SCREEN_CHUNK 8
 #endif
@@ -3179,8 +3197,12 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         else if (dp.narrow == 4) AH_DENSE_NARROW(M, 4);                                                                  \
         else if (wide) AH_DENSE_WN(M, 4);                                                                                \
         else AH_DENSE_WN(M, 2);                                                                                          \
-        hipLaunchKernelGGL((k_forest_exact_pairs<M>), dim3(egrid), dim3(256), 0, s, dv, node_of.p, side_bytes.p,         \
-                           n_trees, chunk_d, nstride, hdr_off, d_counters, d_abort);                                     \
+        if (tun(TUN_EXACT_WIDE) != 0)                                                                                    \
+            hipLaunchKernelGGL((k_forest_exact_pairs<M, true>), dim3(egrid), dim3(256), 0, s, dv, node_of.p, side_bytes.p, \
+                               n_trees, chunk_d, nstride, hdr_off, d_counters, d_abort);                                 \
+        else                                                                                                             \
+            hipLaunchKernelGGL((k_forest_exact_pairs<M>), dim3(egrid), dim3(256), 0, s, dv, node_of.p, side_bytes.p,     \
+                               n_trees, chunk_d, nstride, hdr_off, d_counters, d_abort);                                 \
     } while (0)
                     switch (ds->metric) {
                     case AH_EUCLIDEAN: AH_DENSE(AH_EUCLIDEAN); break;

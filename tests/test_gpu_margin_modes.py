@@ -230,3 +230,28 @@ def test_baseline_config_3_split_sides_equal_oracle_at_10m():
     assert checked[0] == 2 and len(checked) >= 13, checked
     f.close()
     ds.close()
+
+
+@pytest.mark.parametrize("shape", [(D.Cosine, 768, 30_000, 100), (D.Euclidean, 128, 40_000, 64), (D.DotProduct, 256, 30_000, 90)],
+                         ids=["cosine768", "euclid128", "dot256"])
+def test_dense_levels_of_several_tiles_and_both_ways_of_reading_the_exact_pairs_equal_the_oracle(shape):
+    """20 trees make dense levels of 320 and 640 columns (several 256-column tiles, the last one partly padding).  Round 6:
+    `k_forest_exact_pairs` asks for every line of a pair's row and normal before its first multiply-add (`AH_EXACT_WIDE`, the same
+    chains in the same order as the streamed reduction of rounds 2-5).  Whole forests against the oracle with the screen's
+    self-check on, and the same bits either way."""
+    cls, dims, n, split_after = shape
+    ds, oracle, _vecs, _ids = make_data(cls, n, dims, seed=dims + 17)
+    seeds = [int(x) for x in np.random.default_rng(dims + 1).integers(0, 2**63, 20)]
+    ref = [oracle.build_tree(split_after, s).canonical() for s in seeds]
+    digests = set()
+    for knobs in (dict(), dict(AH_EXACT_WIDE=0)):
+        with _lib.tuning(AH_SCREEN_VERIFY=1, **knobs):
+            forest = ds.build_forest(seeds, split_after=split_after, margin_mode=_lib.MARGIN_DENSE_MFMA)
+        st = forest.stats
+        assert st["dense_launches"] >= 6 and st["screen_violations"] == 0, (knobs, st)
+        for t in range(len(seeds)):
+            assert forest.canonical(t) == ref[t], f"tree {t} differs from the oracle with {knobs}"
+        digests.add(forest.digest()[0])
+        forest.close()
+    assert len(digests) == 1
+    ds.close()
