@@ -87,6 +87,7 @@ TunableSlot *tunable_table() {
 long long tun(int id) { return tunable_table()[id].value.load(std::memory_order_relaxed); }
 
 int Context::ensure_device(size_t bytes) {
+    clean_status = nullptr;  // (whoever carves the scratch next may write anywhere in it)
     if (bytes <= d_cap) return AH_OK;
     size_t cap = std::max(bytes + bytes / 4, d_cap * 2);  // headroom: similar-sized submissions must not regrow
     cap = (cap + 4095) & ~(size_t)4095;

@@ -153,6 +153,8 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(SEARCH_MULTI_TREES_PER_BLOCK, "AH_SEARCH_MULTI_TREES_PER_BLOCK", 8) /* ... trees per block (1 - 8: one per octet of its descent wave) */ \
     X(SEARCH_MULTI_IDS_BY_TILES, "AH_SEARCH_MULTI_IDS_BY_TILES", 1) /* 0: the last block of k_descend_multi copies a single query's ids itself */ \
     X(SEARCH_SPIN_WAIT, "AH_SEARCH_SPIN_WAIT", 1) /* 0: a small submission waits with hipStreamSynchronize instead of polling the status word its last kernel writes into pinned memory */ \
+    X(SEARCH_FLAT_TILES, "AH_SEARCH_FLAT_TILES", 1) /* 0: a single query's tile launch keeps the 2-D grid (units x slabs) of the small submissions */ \
+    X(SEARCH_STATUS_WIPE, "AH_SEARCH_STATUS_WIPE", 1) /* 0: every search submission clears its status block with a memset of its own */ \
     X(SEARCH_MULTI_TRACE, "AH_SEARCH_MULTI_TRACE", 0) /* 1: ah_search_batch prints where the blocks of query 0 spent their time (stderr) */ \
     X(SEARCH_MULTI_MAX_QUERIES, "AH_SEARCH_MULTI_MAX_QUERIES", 8) /* ... up to this many queries a call (at most 8: the control block's size) */ \
     X(EXACT_WIDE, "AH_EXACT_WIDE", 1)           /* 0: k_forest_exact_pairs streams the row eight lines at a time (rounds 2-5) instead of asking for row and normal whole */ \
@@ -293,6 +295,10 @@ struct Context {
     void *d_filter = nullptr;  // candidate filter of a search submission (bitmap + id list): outlives its sub-batches
     size_t d_filter_cap = 0;
     void *d_multi = nullptr;   // control block of k_descend_multi (search.hip): zero between calls, allocated on first use
+    // the status block of the last small search submission, if its selection kernel left it zeroed behind itself and nothing has
+    // carved the scratch since (ensure_device forgets it): the next submission that lays its status block at the same address
+    // skips the memset in front of its first kernel
+    void *clean_status = nullptr;
     int ensure_multi(size_t bytes);
     int ensure_device(size_t bytes);
     int ensure_pinned(size_t bytes);

@@ -1015,6 +1015,7 @@ struct MultiCtl {
     unsigned long long info[kMultiLists][kMultiLeaves];  // node << 32 | first id of the leaf in the blob
     uint32_t trace[kMultiMaxBlocks][8];                  // AH_SEARCH_MULTI_TRACE: 10 ns ticks since the block started (see the kernel)
     uint32_t sel_trace[16];                              // ... and of the selection kernel behind it (k_search_select_screened<*, true>)
+    uint32_t tile_trace[8];                              // ... and of the tile launch between them (maxima over its blocks)
 };
 size_t multi_ctl_bytes() { return (size_t)kMultiMaxQueries * sizeof(MultiCtl); }
 template <uint32_t kHeap>
@@ -2347,7 +2348,57 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
                                                       const Visit *__restrict__ sorted, const TileUnit *__restrict__ units,
                                                       const uint32_t *__restrict__ n_units_p, float *__restrict__ dist,
                                                       uint32_t stride, uint32_t *err, uint32_t min_vis = 0,
-                                                      const uint32_t *__restrict__ blob = nullptr, uint32_t speculate = 0) {
+                                                      const uint32_t *__restrict__ blob = nullptr, uint32_t speculate = 0,
+                                                      uint32_t *__restrict__ trace = nullptr, uint32_t flat = 0) {
+    const uint64_t t_start = trace ? wall_clock64() : 0ull;
+    auto stamp = [&](uint32_t slot) {  // (AH_SEARCH_MULTI_TRACE: the latest block's time at each point, 10 ns ticks)
+        if (trace && threadIdx.x == 0) atomicMax(&trace[slot], (uint32_t)(wall_clock64() - t_start));
+    };
+    if constexpr (SMALL) {
+        if (flat) {
+            // ONE query whose descent wrote the units itself (unit e = visit e = one leaf): block b is item b of the list of
+            // (leaf, slab of 64 rows) pairs.  The 2-D grid of the general path dispatches 32 x (largest leaf / 64) = 768 blocks of
+            // this 324-register kernel (one per CU at a time) to find ~156 with work: three rounds of dispatch, the last useful
+            // block starting late — 21.8 us of kernel for 8 us of slab.  Here every wave reads the first 128 units and visits (one
+            // trip, with the count), scans their slab counts and picks its item: the useful blocks are the FIRST blocks.
+            const uint32_t lane = threadIdx.x & 63u;
+            const uint4 va = reinterpret_cast<const uint4 *>(sorted)[lane], vb = reinterpret_cast<const uint4 *>(sorted)[lane + 64u];
+            const uint4 ua = reinterpret_cast<const uint4 *>(units)[lane], ub = reinterpret_cast<const uint4 *>(units)[lane + 64u];
+            const uint32_t n_units = *n_units_p;
+            if (n_units > 128u) {  // (block-uniform; the descent's lists hold more, a query never opens that many leaves in practice)
+                if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(err, 16u);
+                return;
+            }
+            const bool in0 = lane < n_units, in1 = lane + 64u < n_units;
+            uint32_t p0 = in0 ? (va.w + kTileSmallSlab - 1u) / kTileSmallSlab : 0u, p1 = in1 ? (vb.w + kTileSmallSlab - 1u) / kTileSmallSlab : 0u;
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t a = __shfl_up(p0, d, 64), c = __shfl_up(p1, d, 64);
+                if (lane >= d) {
+                    p0 += a;
+                    p1 += c;
+                }
+            }
+            p1 += __shfl(p0, 63, 64);
+            const uint32_t b = blockIdx.x;
+            const uint32_t e = (uint32_t)__popcll(__ballot(in0 && p0 <= b)) + (uint32_t)__popcll(__ballot(in1 && p1 <= b));
+            if (e >= n_units) return;  // block-uniform: beyond the last item
+            const uint32_t before0 = __shfl(p0, (int)((e + 63u) & 63u), 64), before1 = __shfl(p1, (int)((e + 63u) & 63u), 64);
+            const uint32_t before = e == 0u ? 0u : (e - 1u < 64u ? before0 : before1);
+            const int src = (int)(e & 63u);
+            const bool hi = e >= 64u;
+            const Visit v0{(uint32_t)__shfl((int)(hi ? vb.x : va.x), src, 64), (uint32_t)__shfl((int)(hi ? vb.y : va.y), src, 64),
+                           (uint32_t)__shfl((int)(hi ? vb.z : va.z), src, 64), (uint32_t)__shfl((int)(hi ? vb.w : va.w), src, 64)};
+            const uint32_t pad = (uint32_t)__shfl((int)(hi ? ub.w : ua.w), src, 64);
+            stamp(0);
+            const uint32_t row_begin = (b - before) * kTileSmallSlab, row_end = min(v0.n, row_begin + kTileSmallSlab);
+            const uint32_t *leaf_ids = nns + (uint64_t)v0.q * stride + v0.pos;
+            const bool from_blob = blob && pad != 0u;
+            leaf_tile16<2, 1, 1, 24>(ss, dv, from_blob ? blob + (pad - 1u) : leaf_ids, row_begin, row_end, sorted + e, 1u, dist, stride, err,
+                                     from_blob ? const_cast<uint32_t *>(leaf_ids) : nullptr, &v0);
+            stamp(1);
+            return;
+        }
+    }
     // SMALL + speculate (the host: both tables hold at least gridDim.x entries): the block's first unit and the visit with the
     // unit's number are requested together with the unit count — a single query's units are its visits in order, and the chain
     // count -> unit -> visit -> ids -> rows of dependent trips to memory is most of such a launch's time
@@ -2365,6 +2416,8 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
         const Visit *vis = sorted + unit.first;
         const Visit v0 = (spec && unit.first == u) ? visit_first : vis[0];
         const uint32_t n_leaf = v0.n;
+        if (trace && n_leaf == 0xFFFFFFF0u) trace[7] = 1;  // (trace only: the unit and its visit have arrived at the stamp)
+        stamp(0);
         // SMALL (its own kernel: the registers of the in-flight variant would cost the big submissions their occupancy): a small
         // submission — the leaves of one or two queries in slabs of kTileSmallSlab rows, two rows per octet with the whole row
         // in flight; the launch's grid.y counts those slabs
@@ -2381,6 +2434,7 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
                 const bool from_blob = blob && unit.pad != 0u;
                 leaf_tile16<2, 1, 1, 24>(ss, dv, from_blob ? blob + (unit.pad - 1u) : leaf_ids, row_begin, row_end, vis, n_vis, dist, stride, err,
                                          from_blob ? const_cast<uint32_t *>(leaf_ids) : nullptr, &v0);
+                stamp(1);
                 continue;
             }
             if (fly) {
@@ -2909,6 +2963,8 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
             __threadfence_system();
             __hip_atomic_store(&host_status[0], __hip_atomic_load(&err[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELEASE,
                                __HIP_MEMORY_SCOPE_SYSTEM);
+            // every block is done with the status block: wiped for the next submission (Context::clean_status)
+            for (uint32_t w = 0; w < SS_WORDS; w++) __hip_atomic_store(&err[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (trace) trace[8] = (uint32_t)(wall_clock64() - t_start);
         }
     }
@@ -3542,6 +3598,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     if (tiles)
         dev_bytes += pad((size_t)visit_cap * sizeof(Visit)) * 2 + pad((size_t)visit_cap * sizeof(TileUnit)) +
                      pad((size_t)ix->n_nodes * 4 + 8) + 2 * pad((size_t)ix->n_nodes * 4) + pad((size_t)n_leaf_sums * 8) + pad(nq * 4);
+    void *const clean_status = ctx->clean_status;  // (ensure_device forgets it: see Context)
     AH_TRY(ctx->ensure_device(dev_bytes));
     const size_t pin_bytes = pad(nq * (size_t)ds->dims * 4) + pad(nq * 4) * 4 + pad(nq * sizeof(HostSeg2)) +
                              pad((size_t)max_tiles_bound * sizeof(HostTile2)) + pad(nq * k * 4) * 2 + 4096;
@@ -3660,7 +3717,9 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         AH_HIP(hipMemcpyAsync(d_qrows, h_qrows, nq * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_load_items_as_queries, dim3((unsigned)nq), dim3(64), 0, s, dv, d_qrows, d_qvecs, qstride, d_qhdrs);
     }
-    AH_HIP(hipMemsetAsync(d_err, 0, SS_WORDS * 4, s));
+    // (the selection kernel of the previous small submission wiped its status block after copying it out: same place, same stream
+    // — no memset node in front of this call's first kernel)
+    if (!(clean_status == (void *)d_err && tun(TUN_SEARCH_STATUS_WIPE) != 0)) AH_HIP(hipMemsetAsync(d_err, 0, SS_WORDS * 4, s));
     // (by_vector leaves are prepared by the batch launcher below; the descent needs them first)
     SearchParams sp{};
     sp.stats = d_err;
@@ -3813,10 +3872,17 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
             // dispatch 24 000 blocks to find 12 units
             const unsigned small_slabs = std::max(1u, (ix->max_desc + kTileSmallSlab - 1) / kTileSmallSlab);
             const bool small_tiles = (long long)nq <= tun(TUN_SEARCH_SMALL_TILES_MAX_QUERIES) && small_slabs <= 65535u;
-            if (small_tiles)
+            // (one query whose units came out of its descent: a flat list of (leaf, slab) items, see the kernel)
+            const bool flat_tiles = small_tiles && units_done && nq == 1 && visit_cap >= 128u && tun(TUN_SEARCH_FLAT_TILES) != 0;
+            uint32_t *tile_trace =
+                multi_launched && tun(TUN_SEARCH_MULTI_TRACE) != 0 ? &reinterpret_cast<MultiCtl *>(ctx->d_multi)->tile_trace[0] : nullptr;
+            if (flat_tiles)
+                hipLaunchKernelGGL((k_leaf_tiles16<true>), dim3(nns_stride / kTileSmallSlab + 129u), dim3(256), 0, s, dv, ss, d_nns, d_sorted,
+                                   d_units, d_n_units, d_dist, nns_stride, d_err, 0u, ix->d_desc, 0u, tile_trace, 1u);
+            else if (small_tiles)
                 hipLaunchKernelGGL((k_leaf_tiles16<true>), dim3(std::min<unsigned>(2048u, 32u * (unsigned)nq), small_slabs), dim3(256), 0, s,
                                    dv, ss, d_nns, d_sorted, d_units, d_n_units, d_dist, nns_stride, d_err, 0u, ix->d_desc,
-                                   visit_cap >= std::min<unsigned>(2048u, 32u * (unsigned)nq) ? 1u : 0u);
+                                   visit_cap >= std::min<unsigned>(2048u, 32u * (unsigned)nq) ? 1u : 0u, tile_trace);
             else
                 hipLaunchKernelGGL((k_leaf_tiles16<false>), dim3(2048, tile_slabs), dim3(256), 0, s, dv, ss, d_nns, d_sorted, d_units,
                                    d_n_units, d_dist, nns_stride, d_err);
@@ -3941,12 +4007,17 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         if (multi_launched && tun(TUN_SEARCH_MULTI_TRACE) != 0) {
             uint32_t st[16];
             AH_HIP(hipMemcpy(st, &reinterpret_cast<MultiCtl *>(ctx->d_multi)->sel_trace[0], sizeof(st), hipMemcpyDeviceToHost));
+            uint32_t tt[8];
+            AH_HIP(hipMemcpy(tt, &reinterpret_cast<MultiCtl *>(ctx->d_multi)->tile_trace[0], sizeof(tt), hipMemcpyDeviceToHost));
+            AH_HIP(hipMemset(&reinterpret_cast<MultiCtl *>(ctx->d_multi)->tile_trace[0], 0, sizeof(tt)));
+            fprintf(stderr, "[ah] tiles (latest block since ITS start): unit + visit known %.2f us, slab done %.2f us\n", tt[0] * 0.01, tt[1] * 0.01);
             fprintf(stderr, "[ah] selection: leaf + tables in LDS %.2f us, candidates in registers %.2f, duplicates flagged %.2f, key range %.2f, "
                     "k-th bin %.2f, survivors listed %.2f (%u), f32 distances %.2f, ranked + written %.2f, status written %.2f\n", st[0] * 0.01,
                     st[1] * 0.01, st[2] * 0.01, st[3] * 0.01, st[4] * 0.01, st[5] * 0.01, st[9], st[6] * 0.01, st[7] * 0.01, st[8] * 0.01);
         }
         AH_REQUIRE((*h_err & 1u) == 0 || *h_err == 0xFFFFFFFFu, AH_ERR_MISSING_ITEM, "a descendant id does not exist in the dataset");
         if ((*h_err & ~1u) == 0 && launch_err == hipSuccess) {
+            if (fused_flag) ctx->clean_status = d_err;  // (its selection kernel ran to its end and wiped the block behind itself)
             for (size_t q = 0; q < nq; q++) out_counts[q] = (uint32_t)std::min<size_t>(k, h_counts[q]);
             memcpy(out_ids, h_oi, nq * k * 4);
             memcpy(out_dists, h_od, nq * k * 4);
