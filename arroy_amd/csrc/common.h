@@ -155,6 +155,7 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(SEARCH_SPIN_WAIT, "AH_SEARCH_SPIN_WAIT", 1) /* 0: a small submission waits with hipStreamSynchronize instead of polling the status word its last kernel writes into pinned memory */ \
     X(SEARCH_FLAT_TILES, "AH_SEARCH_FLAT_TILES", 1) /* 0: a single query's tile launch keeps the 2-D grid (units x slabs) of the small submissions */ \
     X(SEARCH_STATUS_WIPE, "AH_SEARCH_STATUS_WIPE", 1) /* 0: every search submission clears its status block with a memset of its own */ \
+    X(SEARCH_ITEM_LIST, "AH_SEARCH_ITEM_LIST", 1) /* 0: the tile launch of a small submission keeps its 2-D grid (units x slabs) instead of the (unit, slab) list k_units_small leaves */ \
     X(SEARCH_MULTI_TRACE, "AH_SEARCH_MULTI_TRACE", 0) /* 1: ah_search_batch prints where the blocks of query 0 spent their time (stderr) */ \
     X(SEARCH_MULTI_MAX_QUERIES, "AH_SEARCH_MULTI_MAX_QUERIES", 8) /* ... up to this many queries a call (at most 8: the control block's size) */ \
     X(EXACT_WIDE, "AH_EXACT_WIDE", 1)           /* 0: k_forest_exact_pairs streams the row eight lines at a time (rounds 2-5) instead of asking for row and normal whole */ \

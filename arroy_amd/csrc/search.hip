@@ -502,6 +502,12 @@ static constexpr uint32_t kUnitVisits = 16;
 struct TileUnit {
     uint32_t node, first, n_vis, pad;  // sorted[first .. first + n_vis)
 };
+static constexpr uint32_t kTileSlab = 128;       // rows per block and unit of more than 8 visits (twice that up to 8): k_leaf_tiles*
+static constexpr uint32_t kTileSmallSlab = 64;   // rows per block of k_leaf_tiles16 in a small submission (32 octets x 2 rows)
+// rows of a unit's leaf one block of k_leaf_tiles16 takes (small: the small submissions' variant of the kernel)
+__host__ __device__ constexpr uint32_t tile_slab_rows(uint32_t n_vis, bool small) {
+    return small && n_vis <= 2 ? kTileSmallSlab : (n_vis > 8 ? kTileSlab : 2 * kTileSlab);
+}
 
 // Blocks 1 .. n_h16 of the launch are the queries' binary16 copies (k_queries_h16's work, wanted by the same consumer — the
 // leaf tiles — and as independent of the descent): one launch less on a path that is mostly launches.
@@ -1755,9 +1761,13 @@ __global__ __launch_bounds__(256) void k_visit_scatter(const Visit *__restrict__
 static constexpr uint32_t kSmallVisits = 2048;
 __global__ __launch_bounds__(256) void k_units_small(const Visit *__restrict__ visits, const uint32_t *__restrict__ total,
                                                      uint32_t cap, Visit *__restrict__ sorted, TileUnit *__restrict__ units,
-                                                     uint32_t *__restrict__ n_units, uint32_t *__restrict__ stats, QueriesH16 h16) {
+                                                     uint32_t *__restrict__ n_units, uint32_t *__restrict__ stats, QueriesH16 h16,
+                                                     uint32_t *__restrict__ items = nullptr, uint32_t items_cap = 0) {
+    // items (round 6, a few queries a call): [count][unit << 16 | slab] — the (unit, slab of its leaf) pairs k_leaf_tiles16<true>
+    // has work for, so that its launch is one block per pair instead of a 2-D grid of 32 nq x (largest leaf's slabs) blocks of
+    // which a fifth find work (items[0] = 0xFFFFFFFF: more pairs than the list holds, the launch walks its grid as before)
     __shared__ uint64_t s_key[kSmallVisits];  // node << 32 | index into visits
-    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_wave[4], s_wave_items[4];
     if (blockIdx.x != 0) {
         if (threadIdx.x < 64) query_h16(blockIdx.x - 1, threadIdx.x, h16.qvecs, h16.qstride, h16.dims, h16.hpitch, h16.q16, h16.qstats);
         return;
@@ -1768,6 +1778,7 @@ __global__ __launch_bounds__(256) void k_units_small(const Visit *__restrict__ v
         if (tid == 0) {
             atomicOr(&stats[SS_ERR], 32u);
             *n_units = 0;
+            if (items) items[0] = 0u;
         }
         return;
     }
@@ -1818,14 +1829,40 @@ __global__ __launch_bounds__(256) void k_units_small(const Visit *__restrict__ v
         all += s_wave[w];
     }
     uint32_t u16 = 0, u8 = 0, u4 = 0;
+    constexpr uint32_t kMine = kSmallVisits / 256;  // units a thread can own
+    uint32_t my_unit[kMine], my_slabs[kMine], n_mine = 0, my_items = 0;
     for (uint32_t p = tid * per; p < min(n, (tid + 1) * per); p++) {
         const uint64_t key = s_key[p], node_key = key & 0xFFFFFFFF00000000ull;
         if (((p - lower_bound(node_key)) % kUnitVisits) != 0) continue;
         const uint32_t nv = min(kUnitVisits, lower_bound(node_key + (1ull << 32)) - p);
+        const uint32_t slab = tile_slab_rows(nv, true), n_leaf = visits[(uint32_t)key].n;
+        my_unit[n_mine] = u;
+        my_slabs[n_mine] = (n_leaf + slab - 1u) / slab;
+        my_items += my_slabs[n_mine];
+        n_mine++;
         units[u++] = TileUnit{(uint32_t)(key >> 32), p, nv, 0u};
         u16 += nv > 8 ? 1u : 0u;
         u8 += nv > 4 && nv <= 8 ? 1u : 0u;
         u4 += nv <= 4 ? 1u : 0u;
+    }
+    if (items) {  // block-uniform
+        uint32_t incl_i = my_items;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(incl_i, d, 64);
+            if (lane >= d) incl_i += v;
+        }
+        if (lane == 63) s_wave_items[wave] = incl_i;
+        __syncthreads();
+        uint32_t at = incl_i - my_items, all_items = 0;
+        for (uint32_t w = 0; w < 4; w++) {
+            at += w < wave ? s_wave_items[w] : 0u;
+            all_items += s_wave_items[w];
+        }
+        const bool fits = all_items < items_cap && all < 65536u;
+        if (fits)
+            for (uint32_t i = 0; i < n_mine; i++)
+                for (uint32_t sl = 0; sl < my_slabs[i]; sl++) items[1u + at++] = (my_unit[i] << 16) | min(sl, 0xFFFFu);
+        if (tid == 0) items[0] = fits ? all_items : 0xFFFFFFFFu;
     }
     if (u16) atomicAdd(&stats[SS_UNITS_16], u16);
     if (u8) atomicAdd(&stats[SS_UNITS_8], u8);
@@ -2123,11 +2160,9 @@ __device__ __forceinline__ void leaf_tile_ring(const DataView &dv, const uint32_
 
 // blockIdx.x walks the units (persistent), blockIdx.y is the slab of rows of the unit's leaf: 128 rows when the unit has
 // more than 8 visits (4 rounds of 32 rows x 16 queries), 256 rows otherwise.
-static constexpr uint32_t kTileSlab = 128;
 #ifndef AH_TILES16_KF
 #define AH_TILES16_KF 1  // k-steps of a leaf tile requested together in the big submissions' variants (A/B: see DESIGN.md)
 #endif
-static constexpr uint32_t kTileSmallSlab = 64;  // rows per block of k_leaf_tiles16 in a small submission (32 octets x 2 rows)
 template <int METRIC>
 __global__ __launch_bounds__(256) void k_leaf_tiles(DataView dv, const uint32_t *__restrict__ nns,
                                                     const Visit *__restrict__ sorted,
@@ -2349,7 +2384,8 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
                                                       const uint32_t *__restrict__ n_units_p, float *__restrict__ dist,
                                                       uint32_t stride, uint32_t *err, uint32_t min_vis = 0,
                                                       const uint32_t *__restrict__ blob = nullptr, uint32_t speculate = 0,
-                                                      uint32_t *__restrict__ trace = nullptr, uint32_t flat = 0) {
+                                                      uint32_t *__restrict__ trace = nullptr, uint32_t flat = 0,
+                                                      const uint32_t *__restrict__ items = nullptr) {
     const uint64_t t_start = trace ? wall_clock64() : 0ull;
     auto stamp = [&](uint32_t slot) {  // (AH_SEARCH_MULTI_TRACE: the latest block's time at each point, 10 ns ticks)
         if (trace && threadIdx.x == 0) atomicMax(&trace[slot], (uint32_t)(wall_clock64() - t_start));
@@ -2408,9 +2444,20 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
         unit_first = units[blockIdx.x];
         visit_first = sorted[blockIdx.x];
     }
+    // items (a few queries a call, k_units_small): the (unit, slab) pairs with work, one block each — or, items[0] = 0xFFFFFFFF or
+    // items == nullptr, the 2-D grid: blockIdx.x walks the units, blockIdx.y is the slab
+    uint32_t n_items = SMALL && items ? items[0] : 0xFFFFFFFFu;
+    const bool listed = n_items != 0xFFFFFFFFu;
     const uint32_t n_units = *n_units_p;
-    for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const bool spec = SMALL && speculate && u == blockIdx.x;
+    const uint32_t n_work = listed ? n_items : n_units;
+    for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+        uint32_t u = w, slab_index = blockIdx.y;
+        if (listed) {
+            const uint32_t it = items[1u + w];
+            u = it >> 16;
+            slab_index = it & 0xFFFFu;
+        }
+        const bool spec = SMALL && speculate && !listed && u == blockIdx.x;
         const TileUnit unit = spec ? unit_first : units[u];
         if (unit.n_vis < min_vis) continue;  // (the units of few visits went to k_leaf_tiles8)
         const Visit *vis = sorted + unit.first;
@@ -2422,9 +2469,11 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
         // submission — the leaves of one or two queries in slabs of kTileSmallSlab rows, two rows per octet with the whole row
         // in flight; the launch's grid.y counts those slabs
         const bool fly = SMALL && unit.n_vis <= 2;
-        const uint32_t n_vis = unit.n_vis, slab = fly ? kTileSmallSlab : (n_vis > 8 ? kTileSlab : 2 * kTileSlab);
-        const uint32_t row_begin = blockIdx.y * slab;
-        if (row_begin >= n_leaf) continue;
+        const uint32_t n_vis = unit.n_vis, slab = tile_slab_rows(n_vis, SMALL);
+        // (an item names its slab; without the list the launch's grid.y counts the slabs — and a launch sized for the list that
+        // finds it overflowed, grid.y = 1, walks them)
+        for (; slab_index * slab < n_leaf; slab_index += listed ? 0xFFFFu : gridDim.y) {
+        const uint32_t row_begin = slab_index * slab;
         const uint32_t row_end = min(n_leaf, row_begin + slab);
         const uint32_t *leaf_ids = nns + (uint64_t)v0.q * stride + v0.pos;
 #define AH_TILE16(R, Q, QO) leaf_tile16<R, Q, QO, AH_TILES16_KF>(ss, dv, leaf_ids, row_begin, row_end, vis, n_vis, dist, stride, err)
@@ -2448,6 +2497,7 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
         else if (n_vis == 2) AH_TILE16(4, 2, 1);
         else AH_TILE16(8, 1, 1);
 #undef AH_TILE16
+        }
     }
 }
 
@@ -3595,9 +3645,14 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     const bool screened8 = screened && allow8 && tun(TUN_SEARCH_SCREEN8) != 0 && !ix->search8_off.load(std::memory_order_relaxed) &&
                            (long long)nq > tun(TUN_SEARCH_SMALL_UNITS_MAX_QUERIES) && ds->screen8_ready.load(std::memory_order_acquire);
     if (screened8) dev_bytes += pad(nq * (size_t)ds->pitch8 * 2) + pad(nq * sizeof(float4)) + pad(nq * (size_t)nns_stride * 4);
+    // (a few queries a call: the list of (unit, slab) pairs k_units_small leaves for the tile launch)
+    const size_t items_cap = tiles && (long long)nq <= tun(TUN_SEARCH_SMALL_UNITS_MAX_QUERIES) && tun(TUN_SEARCH_ITEM_LIST) != 0
+                                 ? nq * ((size_t)nns_stride / kTileSmallSlab + 1) + kSmallVisits + 1
+                                 : 0;
     if (tiles)
         dev_bytes += pad((size_t)visit_cap * sizeof(Visit)) * 2 + pad((size_t)visit_cap * sizeof(TileUnit)) +
-                     pad((size_t)ix->n_nodes * 4 + 8) + 2 * pad((size_t)ix->n_nodes * 4) + pad((size_t)n_leaf_sums * 8) + pad(nq * 4);
+                     pad((size_t)ix->n_nodes * 4 + 8) + 2 * pad((size_t)ix->n_nodes * 4) + pad((size_t)n_leaf_sums * 8) + pad(nq * 4) +
+                     pad(items_cap * 4);
     void *const clean_status = ctx->clean_status;  // (ensure_device forgets it: see Context)
     AH_TRY(ctx->ensure_device(dev_bytes));
     const size_t pin_bytes = pad(nq * (size_t)ds->dims * 4) + pad(nq * 4) * 4 + pad(nq * sizeof(HostSeg2)) +
@@ -3639,7 +3694,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     uint32_t *d_inv = inv_bytes ? (uint32_t *)dtake(inv_bytes) : nullptr;
     Visit *d_visits = nullptr, *d_sorted = nullptr;
     TileUnit *d_units = nullptr;
-    uint32_t *d_leaf_count = nullptr, *d_cursor = nullptr, *d_ustart = nullptr;
+    uint32_t *d_leaf_count = nullptr, *d_cursor = nullptr, *d_ustart = nullptr, *d_items = nullptr;
     uint2 *d_leaf_sums = nullptr;
     if (tiles) {
         d_visits = (Visit *)dtake((size_t)visit_cap * sizeof(Visit));
@@ -3649,6 +3704,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         d_cursor = (uint32_t *)dtake((size_t)ix->n_nodes * 4);
         d_ustart = (uint32_t *)dtake((size_t)ix->n_nodes * 4);
         d_leaf_sums = (uint2 *)dtake((size_t)n_leaf_sums * 8);
+        if (items_cap) d_items = (uint32_t *)dtake(items_cap * 4);
     }
     ScreenSearch ss{};
     if (screened) {
@@ -3752,6 +3808,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     uint32_t multi_launched = 0;  // blocks per query of k_descend_multi, when that was the descent
     bool passes_done = false;  // set by launch_wave: the block descent was the whole descent
     bool units_done = false;   // ... and it wrote the leaf tiles' work units as well (one query)
+    bool items_made = false;   // k_units_small left the list of (unit, slab) pairs for the tile launch
     auto launch_wave = [&](const VisitSink &sink) -> int {
         // a query pops about 1 / (kept share) as many nodes under a filter: start with the big queues (one query per CU
         // at a time) only then; otherwise they take what the small ones (four per CU) could not hold
@@ -3842,7 +3899,8 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         } else if (small_units) {
             const QueriesH16 h16{d_qvecs, qstride, ds->dims, ds->hpitch, const_cast<uint16_t *>(ss.q16), const_cast<float4 *>(ss.qstats)};
             hipLaunchKernelGGL(k_units_small, dim3(1u + (screened ? (unsigned)nq : 0u)), dim3(256), 0, s, d_visits, d_total, visit_cap,
-                               d_sorted, d_units, d_n_units, d_err, h16);
+                               d_sorted, d_units, d_n_units, d_err, h16, d_items, (uint32_t)items_cap);
+            items_made = d_items != nullptr;
         } else {
             hipLaunchKernelGGL(k_leaf_scan_block, dim3(n_leaf_sums), dim3(256), 0, s, d_leaf_count, ix->n_nodes, d_cursor, d_ustart,
                                d_leaf_sums);
@@ -3879,6 +3937,9 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
             if (flat_tiles)
                 hipLaunchKernelGGL((k_leaf_tiles16<true>), dim3(nns_stride / kTileSmallSlab + 129u), dim3(256), 0, s, dv, ss, d_nns, d_sorted,
                                    d_units, d_n_units, d_dist, nns_stride, d_err, 0u, ix->d_desc, 0u, tile_trace, 1u);
+            else if (small_tiles && items_made)  // one block per listed (unit, slab) pair (grid.y = 1: an overflowed list is walked)
+                hipLaunchKernelGGL((k_leaf_tiles16<true>), dim3((unsigned)std::min<size_t>(items_cap, 2048)), dim3(256), 0, s, dv, ss, d_nns,
+                                   d_sorted, d_units, d_n_units, d_dist, nns_stride, d_err, 0u, ix->d_desc, 0u, tile_trace, 0u, d_items);
             else if (small_tiles)
                 hipLaunchKernelGGL((k_leaf_tiles16<true>), dim3(std::min<unsigned>(2048u, 32u * (unsigned)nq), small_slabs), dim3(256), 0, s,
                                    dv, ss, d_nns, d_sorted, d_units, d_n_units, d_dist, nns_stride, d_err, 0u, ix->d_desc,

@@ -5,7 +5,7 @@ timeout 900 python -m pytest tests/test_gpu_small_calls.py tests/test_gpu_search
 for cfg in "AH_SEARCH_FLAT_TILES=1" "AH_SEARCH_FLAT_TILES=0" "AH_SEARCH_STATUS_WIPE=0" "AH_SEARCH_MULTI=0"; do
   echo "== nq=1 $cfg: $(env $cfg timeout 300 python scripts/exp_latency.py 1 400 2>&1 | grep '^nq=' | tail -1)"
 done
-echo "== nq=8: $(timeout 300 python scripts/exp_latency.py 8 400 2>&1 | grep '^nq=' | tail -1)"
+for cfg in "AH_SEARCH_ITEM_LIST=1" "AH_SEARCH_ITEM_LIST=0"; do for q in 2 8; do echo "== nq=$q $cfg: $(env $cfg timeout 300 python scripts/exp_latency.py $q 400 2>&1 | grep "^nq=" | tail -1)"; done; done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python scripts/exp_latency.py 1 300 > $OUT/lat.log 2>&1
 echo "## default: $(grep '^nq=' $OUT/lat.log | tail -1)"
 python scripts/kstats.py $OUT/kt/kt_kernel_stats.csv k_descend k_leaf k_search_select k_units fillBuffer; rm -rf $OUT/kt
