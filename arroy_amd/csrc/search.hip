@@ -3007,8 +3007,9 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
         // polling that word instead of waiting for the stream (AH_SEARCH_SPIN_WAIT), and what it reads after it must be there.
         __threadfence_system();
         __syncthreads();
-        if (threadIdx.x == 0 && atomicAdd(&err[SS_DONE], 1u) + 1u == gridDim.x) {
-            __threadfence_system();
+        // (one query: this block is the last one by construction — no counter, no second fence)
+        if (threadIdx.x == 0 && (gridDim.x == 1u || atomicAdd(&err[SS_DONE], 1u) + 1u == gridDim.x)) {
+            if (gridDim.x != 1u) __threadfence_system();
             for (uint32_t w = 1; w < SS_WORDS; w++) host_status[w] = __hip_atomic_load(&err[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __threadfence_system();
             __hip_atomic_store(&host_status[0], __hip_atomic_load(&err[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELEASE,
