@@ -2077,9 +2077,25 @@ static bool ensure_screen8(ah_dataset *ds, hipStream_t s, bool force, bool want_
 // One delivery of a streaming build (ah_build_forest_stream): the payloads of `nodes` lie back to back at a device address, in
 // the order of the list (split planes of a level: one record per node; item ids: the leaves in (tree, position) order).  The
 // read-back worker moves them through its pinned double buffer in pieces of whole nodes and calls the sink on every piece.
+// (a list of 819 000 nodes is 39 MB: value-initialising it on the launching thread — page faults of fresh memory included — was
+// most of the 37 ms a streaming build's deepest digest took; the threads that fill it touch its pages instead)
+struct StreamNodeRaw {
+    ah_stream_node v;
+    StreamNodeRaw() {}  // NOLINT: no initialisation on purpose
+};
+static_assert(sizeof(StreamNodeRaw) == sizeof(ah_stream_node), "a plain wrapper");
+struct StreamNodeList {
+    std::vector<StreamNodeRaw> raw;
+    void resize(size_t n) { raw.resize(n); }
+    size_t size() const { return raw.size(); }
+    bool empty() const { return raw.empty(); }
+    ah_stream_node *data() { return reinterpret_cast<ah_stream_node *>(raw.data()); }
+    ah_stream_node &operator[](size_t i) { return raw[i].v; }
+    const ah_stream_node &operator[](size_t i) const { return raw[i].v; }
+};
 struct StreamJob {
     ah_node_batch head{};                // kind, level, record geometry
-    std::vector<ah_stream_node> nodes;   // payload_offset: byte offset from the job's device address, ascending, contiguous
+    StreamNodeList nodes;                // payload_offset: byte offset from the job's device address, ascending, contiguous
     uint64_t fixed_len = 0;              // bytes of one payload (split planes), or 0: count * 4 (item ids)
 };
 struct StreamTarget {
@@ -2813,7 +2829,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         const size_t base = n_recs;
         if (recs.size() < base + 2 * (size_t)n_nodes) recs.resize(base + 2 * (size_t)n_nodes);
         n_recs = base + 2 * (size_t)n_nodes;
-        const unsigned n_threads = n_nodes >= 65536 ? std::min(4u, host_threads) : 1u;
+        // (a streaming build also writes the level's 48-byte stream nodes and collects its leaves: twice the threads)
+        const unsigned n_threads = n_nodes >= 65536 ? std::min(sb ? 8u : 4u, host_threads) : 1u;
         struct Part {
             uint64_t evals = 0, retries = 0, routed = 0, dummies = 0;
             uint32_t bad = 0xFFFFFFFFu;
@@ -2838,6 +2855,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             Part &pt = parts[t];
             const uint32_t lo = (uint32_t)((uint64_t)n_nodes * t / n_threads), hi = (uint32_t)((uint64_t)n_nodes * (t + 1) / n_threads);
             pt.splits.reserve(2 * (size_t)(hi - lo));
+            if (sb) pt.leaves.reserve(2 * (size_t)(hi - lo));
             for (uint32_t i = lo; i < hi; i++) {
                 const FNode nd = tbl[i];
                 if (nd.state == ST_PENDING || nd.n_left > nd.count) {
