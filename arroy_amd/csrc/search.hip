@@ -1357,6 +1357,60 @@ __global__ __launch_bounds__(256) void k_descend_multi(DataView nv, SearchParams
         return;
     }
     const uint32_t n_settled = n_merged;
+    uint32_t taken = 0, ids_taken = 0, any_tie = 0;
+    if (n_settled <= 64u) {
+        // The usual case (a query opens two or three dozen leaves): ordered, summed and cut by ONE wave — a leaf per lane, ranks
+        // by counting, the prefix by shuffles — and one block barrier, where the general path below takes a dozen.
+        if (wave == 0) {
+            const bool in = wl < n_settled;
+            const uint64_t key = in ? s_sorted[wl] : 0ull;
+            const uint32_t kn = in ? s_sorted_n[wl] : 0u, knode = in ? s_sorted_node[wl] : 0u, kfirst = in ? s_sorted_first[wl] : 0u;
+            uint32_t rank = 0;
+            for (uint32_t t = 0; t < n_settled; t++) rank += s_sorted[t] > key ? 1u : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (in) {
+                s_sorted[rank] = key;
+                s_sorted_n[rank] = kn;
+                s_sorted_node[rank] = knode;
+                s_sorted_first[rank] = kfirst;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t nn = in ? s_sorted_n[wl] : 0u;  // (in sorted order now)
+            uint32_t incl = nn;
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t v = __shfl_up(incl, d, 64);
+                if (wl >= d) incl += v;
+            }
+            const uint32_t before = incl - nn;
+            const bool take = in && before < sp.search_k;
+            if (take) s_pos[wl] = before;
+            bool tie = false;
+            if (take && before + nn >= sp.search_k) {  // the leaf that reaches search_k: equal keys of another list around it -> sequential queue
+                const uint64_t mine = s_sorted[wl];
+                const uint32_t kw = (uint32_t)(mine >> 32), lst = (uint32_t)mine >> 16;
+                for (uint32_t t = wl + 1; t < n_settled && (uint32_t)(s_sorted[t] >> 32) == kw; t++)
+                    if (((uint32_t)s_sorted[t] >> 16) != lst) tie = true;
+                for (uint32_t t = wl; t-- > 0 && (uint32_t)(s_sorted[t] >> 32) == kw;)
+                    if (((uint32_t)s_sorted[t] >> 16) != lst) tie = true;
+            }
+            uint32_t it = take ? before + nn : 0u;
+            for (uint32_t d = 32; d > 0; d >>= 1) it = max(it, (uint32_t)__shfl_xor((int)it, d, 64));
+            const uint32_t n_take = (uint32_t)__popcll(__ballot(take));
+            const bool tie_any = __ballot(tie) != 0ull;
+            if (wl == 0) {
+                s_mw[8] = n_take;
+                s_mw[9] = it;
+                s_mw[10] = tie_any ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+        taken = s_mw[8];
+        ids_taken = s_mw[9];
+        any_tie = s_mw[10];
+    } else {
     uint32_t p2 = kThreads;
     while (p2 < n_settled) p2 <<= 1;
     // descending by key: a leaf's place is the number of larger keys (unique: list and pop index are their low word)
@@ -1406,7 +1460,6 @@ __global__ __launch_bounds__(256) void k_descend_multi(DataView nv, SearchParams
     __syncthreads();
     uint32_t before = incl - local;
     for (uint32_t w = 0; w < wave; w++) before += s_red[32 + w];
-    uint32_t taken = 0, ids_taken = 0;
     bool tie = false;
     for (uint32_t i = 0; i < per; i++) {
         const uint32_t e = tid * per + i;
@@ -1426,7 +1479,9 @@ __global__ __launch_bounds__(256) void k_descend_multi(DataView nv, SearchParams
     }
     taken = block_sum(taken);
     ids_taken = block_max(ids_taken);
-    const uint32_t any_tie = block_max(tie ? 1u : 0u);
+    any_tie = block_max(tie ? 1u : 0u);
+    __syncthreads();
+    }
     if (any_tie || ids_taken > sp.nns_stride) {
         if (tid == 0) {
             nns_count[q] = 0;
@@ -1435,7 +1490,6 @@ __global__ __launch_bounds__(256) void k_descend_multi(DataView nv, SearchParams
         }
         return;
     }
-    __syncthreads();
     stamp(4);
     if (!sp.filter_bits) {
         // the taken leaves' ids are one flat range [0, ids_taken) of the query's candidate buffer (k_descend_block)
