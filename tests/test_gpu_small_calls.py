@@ -168,6 +168,43 @@ def test_one_query_on_several_compute_units_many_trees_repeated_calls_and_overfl
         ds.close()
 
 
+def test_one_query_calls_from_many_threads_at_once(world):
+    """`Reader: Sync` — arroy's readers call `nns_by_vector` from many threads.  Every call leases a context of the dataset (its
+    own stream, scratch, pinned buffer and — round 6 — control block of `k_descend_multi`); a context serves one thread after the
+    other, so the status block a call finds "wiped by the previous small submission" was wiped by ANOTHER thread's call, the host
+    polls a pinned word while seven other streams are busy, and calls of one and of three queries alternate on the same scratch.
+    Eight threads x 60 calls against the answers of the big submissions' path."""
+    import threading
+    _ds, _od, _forest, index, queries, _vecs = world
+    count, sk = 25, 1500
+    with _lib.tuning(**{k: 0 for k in SMALL_KNOBS}):
+        want = index.search(count, queries=queries, search_k=sk, raw=True)
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(60):
+                nq = 1 if (rep + tid) % 3 else 3
+                a = (tid * 11 + rep * 5) % (len(queries) - nq)
+                got = index.search(count, queries=queries[a:a + nq], search_k=sk, raw=True)
+                ok = np.array_equal(got[0], want[0][a:a + nq]) and got[1].tobytes() == want[1][a:a + nq].tobytes() and \
+                    np.array_equal(got[2], want[2][a:a + nq])
+                if not ok:
+                    errors.append((tid, rep, nq, a))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    index.stats(reset=True)
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:4]
+    st = index.stats()
+    assert st["fallback_chunks"] == 0 and st["descent_multi"] == st["queries"] == 8 * 60 + 8 * 20 * 2, st
+
+
 def test_more_visits_than_the_one_block_unit_builder_holds_fall_back(world):
     """k_units_small sorts at most 2048 leaf visits: 64 queries with a search_k that makes each of them pop more than 32 leaves
     overflow it — bit 5 of the status word, the submission is redone on the sorted path, the answers are the oracle's."""
