@@ -4423,15 +4423,17 @@ int ah_search_batch(ah_index *ix, const float *queries, const uint32_t *query_it
     const size_t per_query = (size_t)stride * 8 + key_bytes + count * 8 + ds->row_bytes() + 4096;
     size_t chunk = std::max<size_t>(1, std::min<size_t>(nq, (1536ull << 20) / per_query));
     chunk = std::min<size_t>(chunk, 4096);
-    int st = AH_OK;
-    for (size_t q0 = 0; q0 < nq && st == AH_OK; q0 += chunk) {
-        const size_t c = std::min(chunk, nq - q0);
-        st = search_chunk(ix, ctx, queries ? queries + q0 * (size_t)ds->dims : nullptr, query_items ? rows.data() + q0 : nullptr,
-                          c, count, (uint32_t)sk_eff, (uint32_t)stride, d_bits, bits_len, filter_share, wave_descent, d_leaf_kept,
-                          out_ids + q0 * count,
-                          out_distances + q0 * count, out_counts + q0);
-    }
-    return st;
+    auto run_range = [&](Context *c, size_t qa, size_t qb) -> int {
+        int st = AH_OK;
+        for (size_t q0 = qa; q0 < qb && st == AH_OK; q0 += chunk) {
+            const size_t cn = std::min(chunk, qb - q0);
+            st = search_chunk(ix, c, queries ? queries + q0 * (size_t)ds->dims : nullptr, query_items ? rows.data() + q0 : nullptr, cn, count,
+                              (uint32_t)sk_eff, (uint32_t)stride, d_bits, bits_len, filter_share, wave_descent, d_leaf_kept,
+                              out_ids + q0 * count, out_distances + q0 * count, out_counts + q0);
+        }
+        return st;
+    };
+    return run_range(ctx, 0, nq);
     AH_GUARDED_END
 }
 
