@@ -2455,8 +2455,23 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
             const uint4 va = reinterpret_cast<const uint4 *>(sorted)[lane], vb = reinterpret_cast<const uint4 *>(sorted)[lane + 64u];
             const uint4 ua = reinterpret_cast<const uint4 *>(units)[lane], ub = reinterpret_cast<const uint4 *>(units)[lane + 64u];
             const uint32_t n_units = *n_units_p;
-            if (n_units > 128u) {  // (block-uniform; the descent's lists hold more, a query never opens that many leaves in practice)
-                if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(err, 16u);
+            auto slab_of_leaf = [&](const Visit &v0, uint32_t pad, uint32_t e, uint32_t slab_index) {
+                const uint32_t row_begin = slab_index * kTileSmallSlab, row_end = min(v0.n, row_begin + kTileSmallSlab);
+                const uint32_t *leaf_ids = nns + (uint64_t)v0.q * stride + v0.pos;
+                const bool from_blob = blob && pad != 0u;
+                leaf_tile16<2, 1, 1, 24>(ss, dv, from_blob ? blob + (pad - 1u) : leaf_ids, row_begin, row_end, sorted + e, 1u, dist, stride, err,
+                                         from_blob ? const_cast<uint32_t *>(leaf_ids) : nullptr, &v0);
+            };
+            if (n_units > 128u) {
+                // (block-uniform, rare: a query that opens more leaves than one scan covers — a large search_k on an index of a
+                // hundred trees.  Every block walks the visit list itself and takes the items of its number modulo the grid.)
+                uint32_t item = 0;
+                for (uint32_t e = 0; e < n_units; e++) {
+                    const Visit v0 = sorted[e];
+                    const uint32_t slabs = (v0.n + kTileSmallSlab - 1u) / kTileSmallSlab;
+                    for (uint32_t sl = 0; sl < slabs; sl++, item++)
+                        if (item % gridDim.x == blockIdx.x) slab_of_leaf(v0, units[e].pad, e, sl);
+                }
                 return;
             }
             const bool in0 = lane < n_units, in1 = lane + 64u < n_units;
@@ -2480,11 +2495,7 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
                            (uint32_t)__shfl((int)(hi ? vb.z : va.z), src, 64), (uint32_t)__shfl((int)(hi ? vb.w : va.w), src, 64)};
             const uint32_t pad = (uint32_t)__shfl((int)(hi ? ub.w : ua.w), src, 64);
             stamp(0);
-            const uint32_t row_begin = (b - before) * kTileSmallSlab, row_end = min(v0.n, row_begin + kTileSmallSlab);
-            const uint32_t *leaf_ids = nns + (uint64_t)v0.q * stride + v0.pos;
-            const bool from_blob = blob && pad != 0u;
-            leaf_tile16<2, 1, 1, 24>(ss, dv, from_blob ? blob + (pad - 1u) : leaf_ids, row_begin, row_end, sorted + e, 1u, dist, stride, err,
-                                     from_blob ? const_cast<uint32_t *>(leaf_ids) : nullptr, &v0);
+            slab_of_leaf(v0, pad, e, b - before);
             stamp(1);
             return;
         }

@@ -152,6 +152,16 @@ def test_one_query_on_several_compute_units_many_trees_repeated_calls_and_overfl
         assert index.stats()["descent_multi"] == 3
         with _lib.tuning(AH_SEARCH_MULTI=0):
             assert same(index.search(count, queries=queries[:3], search_k=sk, raw=True), again)
+        # more leaves than the one-scan item list of the single query's tile launch covers (128): every block walks the visits
+        index.stats(reset=True)
+        wide = index.search(count, queries=queries[:1], search_k=8000, raw=True)
+        st = index.stats()
+        assert st["descent_multi"] == 1 and st["fallback_chunks"] == 0 and st["tile_visits"] > 128, st
+        want = oracle_search(od, forest, queries[0], count, 8000)
+        assert list(wide[0][0, :wide[2][0]]) == [i for i, _ in want]
+        assert wide[1][0, :len(want)].tobytes() == np.array([d for _, d in want], dtype=np.float32).tobytes()
+        with _lib.tuning(AH_SEARCH_FLAT_TILES=0):
+            assert same(index.search(count, queries=queries[:1], search_k=8000, raw=True), wide)
         # under a filter (the kept ids of a leaf are copied octet by octet) and by item
         cand = np.arange(0, n, 2, dtype=np.uint32)
         got = index.search(count, queries=queries[:4], search_k=sk, candidates=cand, candidates_sorted=True, raw=True)
