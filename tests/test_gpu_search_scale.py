@@ -196,6 +196,18 @@ def test_search_equals_oracle_on_the_headline_index_10m_x_768_cosine_100_trees()
     assert st["rerank_screened"] == nq and count * nq <= st["screen_survivors"] <= 0.2 * sk * nq, st
     # the int8 first stage (round 6) serves the BIG submissions: the 32 queries three times over in one call (Cosine: the
     # candidate's stored norm and its row scale both travel with the screen value) — the bits of the 32-query call
+    # arroy's own shape on the headline index: ONE query a call (and five) — 100 trees dealt over 13 blocks of one descent wave each
+    # (`k_descend_multi`), the single query's ids copied by its flat tile launch — the rows of the 32-query call, bit for bit
+    index.stats(reset=True)
+    for qi in (0, 13, nq - 1):
+        one = index.search(count, queries=queries[qi:qi + 1], search_k=sk, raw=True)
+        for a, b in zip(res[1, 1], one):
+            assert np.array_equal(a[qi:qi + 1].view(np.uint32), b.view(np.uint32)), f"one query a call: {qi}"
+    five = index.search(count, queries=queries[7:12], search_k=sk, raw=True)
+    for a, b in zip(res[1, 1], five):
+        assert np.array_equal(a[7:12].view(np.uint32), b.view(np.uint32)), "five queries a call"
+    st = index.stats()
+    assert st["descent_multi"] == 8 and st["fallback_chunks"] == 0, st
     big = np.concatenate([queries, queries, queries])
     index.stats(reset=True)
     got8 = index.search(count, queries=big, search_k=sk, raw=True)
