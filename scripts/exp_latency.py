@@ -12,10 +12,14 @@ from arroy_amd import Dataset, distances, shard  # noqa: E402
 
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-n, dims, k, n_trees = 1_000_000, 1536, 100, 20
-ds = Dataset(distances.DotProduct, dims, n)
+# AH_EXP_SHAPE=items,dims,trees,metric (default: the bench leg 1000000,1536,20,dot; e.g. 10000000,768,100,cosine)
+shape = os.environ.get("AH_EXP_SHAPE", "1000000,1536,20,dot").split(",")
+n, dims, k, n_trees = int(shape[0]), int(shape[1]), 100, int(shape[2])
+cls = {"dot": distances.DotProduct, "cosine": distances.Cosine, "euclidean": distances.Euclidean}[shape[3]]
+ds = Dataset(cls, dims, n)
 ds.fill_synthetic(42, 1, n)
-ds.preprocess_dot()
+if cls is distances.DotProduct:
+    ds.preprocess_dot()
 ds.finalize()
 forest = ds.build_forest(shard.tree_seeds(42, range(n_trees)))
 index = ds.create_index(forest)
