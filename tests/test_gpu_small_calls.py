@@ -293,3 +293,16 @@ def test_rerank_one_launch_falls_back_on_ties_beyond_its_capacity_and_on_non_fin
         want = od.rerank(*od.query_leaf(bad), ids, 20)
         assert got[0].tolist() == want[0].tolist()
         ds.close()
+
+
+def test_five_thousand_one_query_calls_in_a_row_never_read_a_result_early():
+    """The one-query call ends with the host polling a status word its last kernel writes into pinned memory AFTER the results
+    (system-scope release), and starts without a memset because the previous call's selection wiped the status block: a result read
+    before it landed, or a stale word, would show as a mismatch somewhere in a few thousand back-to-back calls
+    (scripts/stress_one_query.py: 30 000 calls, 0 mismatches, on the round's box)."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, "scripts/stress_one_query.py", "5000"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and " 0 mismatches" in out.stdout, out.stdout[-500:] + out.stderr[-500:]
