@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(256) void k_descend_multi(DataView nv, SearchParams
                                                        uint64_t qstride, const float *__restrict__ qhdrs, uint32_t *__restrict__ nns,
                                                        uint32_t *__restrict__ nns_count, uint32_t *__restrict__ overflow, VisitSink sink,
                                                        const float *__restrict__ raw_queries, float *__restrict__ qhdrs_out,
-                                                       SingleQueryOut single, MultiCtl *__restrict__ ctls, uint32_t G) {
+                                                       SingleQueryOut single, MultiCtl *__restrict__ ctls, uint32_t G, uint32_t trace_on) {
     constexpr uint32_t kThreads = 256, kLeaves = kMultiLeaves, kCap = kMultiCap;
     extern __shared__ uint64_t s_multi_lds[];
     uint64_t(*s_heap)[kHeap] = reinterpret_cast<uint64_t(*)[kHeap]>(s_multi_lds);
@@ -1062,9 +1062,9 @@ __global__ __launch_bounds__(256) void k_descend_multi(DataView nv, SearchParams
     const uint32_t q = blockIdx.x / G, g = blockIdx.x - q * G, tid = threadIdx.x, o = (tid >> 3) & 7u, j = tid & 7u, wave = tid >> 6, wl = tid & 63u;
     if (q >= nq) return;
     MultiCtl *ctl = ctls + q;
-    const uint64_t t_start = wall_clock64();
-    auto stamp = [&](uint32_t slot) {  // (thread 0 of the block; never read by the kernels: ah_search_batch prints them on request)
-        if (tid == 0) ctl->trace[g][slot] = (uint32_t)(wall_clock64() - t_start);
+    const uint64_t t_start = trace_on ? wall_clock64() : 0ull;
+    auto stamp = [&](uint32_t slot) {  // (AH_SEARCH_MULTI_TRACE; thread 0 of the block; never read by the kernels)
+        if (trace_on && tid == 0) ctl->trace[g][slot] = (uint32_t)(wall_clock64() - t_start);
     };
     constexpr uint32_t kWaves = kThreads / 64;
     auto block_max = [&](uint32_t v) {
@@ -1547,8 +1547,10 @@ __global__ __launch_bounds__(256) void k_descend_multi(DataView nv, SearchParams
     }
     stamp(5);
     if (tid == 0) {
-        ctl->trace[g][6] = n_merged;
-        ctl->trace[g][7] = taken;
+        if (trace_on) {
+            ctl->trace[g][6] = n_merged;
+            ctl->trace[g][7] = taken;
+        }
         nns_count[q] = ids_taken;
         overflow[q] = 0;
         if (sp.stats) {
@@ -3924,7 +3926,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                 AH_TRY(ctx->ensure_multi(multi_ctl_bytes()));
                 hipLaunchKernelGGL((k_descend_multi<128, 1>), dim3((unsigned)nq * multi_blocks), dim3(256), multi_descend_lds_bytes<128>() + qstride,
                                    s, ix->nv, sp, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, d_nns, d_counts, d_overflow, sink, raw, d_qhdrs, single,
-                                   reinterpret_cast<MultiCtl *>(ctx->d_multi), multi_blocks);
+                                   reinterpret_cast<MultiCtl *>(ctx->d_multi), multi_blocks, tun(TUN_SEARCH_MULTI_TRACE) != 0 ? 1u : 0u);
                 multi_launched = multi_blocks;
             } else
                 hipLaunchKernelGGL((k_descend_block<32, 128, 32, 2>), dim3((unsigned)nq), dim3(256), block_lds, s, ix->nv, sp, (uint32_t)nq,
