@@ -156,6 +156,7 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(SEARCH_FLAT_TILES, "AH_SEARCH_FLAT_TILES", 1) /* 0: a single query's tile launch keeps the 2-D grid (units x slabs) of the small submissions */ \
     X(SEARCH_STATUS_WIPE, "AH_SEARCH_STATUS_WIPE", 1) /* 0: every search submission clears its status block with a memset of its own */ \
     X(SEARCH_ITEM_LIST, "AH_SEARCH_ITEM_LIST", 1) /* 0: the tile launch of a small submission keeps its 2-D grid (units x slabs) instead of the (unit, slab) list k_units_small leaves */ \
+    X(SEARCH_MULTI_OWN_UNITS, "AH_SEARCH_MULTI_OWN_UNITS", 1) /* 0: a call of 2 - 8 queries sorts the leaf visits of all its queries by leaf (k_units_small) instead of every query's descent writing its own units */ \
     X(SEARCH_MULTI_TRACE, "AH_SEARCH_MULTI_TRACE", 0) /* 1: ah_search_batch prints where the blocks of query 0 spent their time (stderr) */ \
     X(SEARCH_MULTI_MAX_QUERIES, "AH_SEARCH_MULTI_MAX_QUERIES", 8) /* ... up to this many queries a call (at most 8: the control block's size) */ \
     X(EXACT_WIDE, "AH_EXACT_WIDE", 1)           /* 0: k_forest_exact_pairs streams the row eight lines at a time (rounds 2-5) instead of asking for row and normal whole */ \

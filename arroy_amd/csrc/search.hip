@@ -567,6 +567,9 @@ struct SingleQueryOut {
     // (10 000 ids through one compute unit: 7 us) — TileUnit::pad carries 1 + the leaf's first id in the blob and the ~150
     // blocks of k_leaf_tiles16<true> copy the ids of the rows they evaluate (the selection reads them from the buffer as before)
     bool ids_by_tiles;
+    // k_descend_multi, a few queries a call (round 6): query q's units and visits at [q * per_query, ...), its unit count at
+    // n_units[q] — every query its own list, no launch to sort the visits of all queries by leaf (0: one query, lists at 0)
+    uint32_t per_query;
 };
 // ---- one BLOCK per query: the small submissions ------------------------------------------------------------------
 // arroy's API takes one query per call (src/reader.rs:46-75) and the wave descent's time does not depend on how many queries a
@@ -1352,6 +1355,7 @@ __global__ __launch_bounds__(256) void k_descend_multi(DataView nv, SearchParams
         if (tid == 0) {
             nns_count[q] = 0;
             overflow[q] = 1;
+            if (single.units) single.n_units[q] = 0;  // (the tile launch behind this kernel runs whatever happened here)
             if (sink.err) atomicOr(sink.err, 16u);  // nobody behind this kernel: the submission takes the long way
         }
         return;
@@ -1486,6 +1490,7 @@ __global__ __launch_bounds__(256) void k_descend_multi(DataView nv, SearchParams
         if (tid == 0) {
             nns_count[q] = 0;
             overflow[q] = 1;
+            if (single.units) single.n_units[q] = 0;
             if (sink.err) atomicOr(sink.err, 16u);
         }
         return;
@@ -1494,10 +1499,12 @@ __global__ __launch_bounds__(256) void k_descend_multi(DataView nv, SearchParams
     if (!sp.filter_bits) {
         // the taken leaves' ids are one flat range [0, ids_taken) of the query's candidate buffer (k_descend_block)
         const bool ids_by_tiles = single.units && single.ids_by_tiles;
+        TileUnit *const my_units = single.units ? single.units + (size_t)q * single.per_query : nullptr;
+        Visit *const my_sorted = single.units ? single.sorted + (size_t)q * single.per_query : nullptr;
         for (uint32_t e = tid; e < taken; e += kThreads) {
             if (single.units) {
-                single.units[e] = TileUnit{s_sorted_node[e], e, 1u, ids_by_tiles ? s_sorted_first[e] + 1u : 0u};
-                single.sorted[e] = Visit{s_sorted_node[e], q, s_pos[e], s_sorted_n[e]};
+                my_units[e] = TileUnit{s_sorted_node[e], e, 1u, ids_by_tiles ? s_sorted_first[e] + 1u : 0u};
+                my_sorted[e] = Visit{s_sorted_node[e], q, s_pos[e], s_sorted_n[e]};
             } else {
                 record_visit(sink, s_sorted_node[e], q, s_pos[e], s_sorted_n[e]);
             }
@@ -1537,8 +1544,8 @@ __global__ __launch_bounds__(256) void k_descend_multi(DataView nv, SearchParams
             copy_filtered(sp, sp.desc + nd.a, nd.b, my_nns + pos, j);
             if (j == 0) {
                 if (single.units) {
-                    single.units[e] = TileUnit{node, e, 1u, 0u};
-                    single.sorted[e] = Visit{node, q, pos, s_sorted_n[e]};
+                    single.units[(size_t)q * single.per_query + e] = TileUnit{node, e, 1u, 0u};
+                    single.sorted[(size_t)q * single.per_query + e] = Visit{node, q, pos, s_sorted_n[e]};
                 } else {
                     record_visit(sink, node, q, pos, s_sorted_n[e]);
                 }
@@ -1558,8 +1565,8 @@ __global__ __launch_bounds__(256) void k_descend_multi(DataView nv, SearchParams
             atomicAdd(&sp.stats[SS_MULTI], 1u);
         }
         if (single.units) {
-            *single.n_units = taken;
-            if (sink.total) *sink.total = taken;
+            single.n_units[q] = taken;
+            if (sink.total && nq == 1u) *sink.total = taken;
             if (sp.stats && taken) {
                 atomicAdd(&sp.stats[SS_VISITS], taken);
                 atomicAdd(&sp.stats[SS_UNITS_4], taken);
@@ -2441,7 +2448,7 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
                                                       uint32_t stride, uint32_t *err, uint32_t min_vis = 0,
                                                       const uint32_t *__restrict__ blob = nullptr, uint32_t speculate = 0,
                                                       uint32_t *__restrict__ trace = nullptr, uint32_t flat = 0,
-                                                      const uint32_t *__restrict__ items = nullptr) {
+                                                      const uint32_t *__restrict__ items = nullptr, uint32_t per_query = 0) {
     const uint64_t t_start = trace ? wall_clock64() : 0ull;
     auto stamp = [&](uint32_t slot) {  // (AH_SEARCH_MULTI_TRACE: the latest block's time at each point, 10 ns ticks)
         if (trace && threadIdx.x == 0) atomicMax(&trace[slot], (uint32_t)(wall_clock64() - t_start));
@@ -2453,10 +2460,13 @@ __global__ __launch_bounds__(256) void k_leaf_tiles16(DataView dv, ScreenSearch 
             // this 324-register kernel (one per CU at a time) to find ~156 with work: three rounds of dispatch, the last useful
             // block starting late — 21.8 us of kernel for 8 us of slab.  Here every wave reads the first 128 units and visits (one
             // trip, with the count), scans their slab counts and picks its item: the useful blocks are the FIRST blocks.
+            // (a few queries a call: blockIdx.y is the query, its lists at [y * per_query, ...), its count at n_units_p[y])
+            sorted += (size_t)blockIdx.y * per_query;
+            units += (size_t)blockIdx.y * per_query;
             const uint32_t lane = threadIdx.x & 63u;
             const uint4 va = reinterpret_cast<const uint4 *>(sorted)[lane], vb = reinterpret_cast<const uint4 *>(sorted)[lane + 64u];
             const uint4 ua = reinterpret_cast<const uint4 *>(units)[lane], ub = reinterpret_cast<const uint4 *>(units)[lane + 64u];
-            const uint32_t n_units = *n_units_p;
+            const uint32_t n_units = n_units_p[blockIdx.y];
             auto slab_of_leaf = [&](const Visit &v0, uint32_t pad, uint32_t e, uint32_t slab_index) {
                 const uint32_t row_begin = slab_index * kTileSmallSlab, row_end = min(v0.n, row_begin + kTileSmallSlab);
                 const uint32_t *leaf_ids = nns + (uint64_t)v0.q * stride + v0.pos;
@@ -3720,7 +3730,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     if (tiles)
         dev_bytes += pad((size_t)visit_cap * sizeof(Visit)) * 2 + pad((size_t)visit_cap * sizeof(TileUnit)) +
                      pad((size_t)ix->n_nodes * 4 + 8) + 2 * pad((size_t)ix->n_nodes * 4) + pad((size_t)n_leaf_sums * 8) + pad(nq * 4) +
-                     pad(items_cap * 4);
+                     pad(items_cap * 4) + pad(nq * 4);
     void *const clean_status = ctx->clean_status;  // (ensure_device forgets it: see Context)
     AH_TRY(ctx->ensure_device(dev_bytes));
     const size_t pin_bytes = pad(nq * (size_t)ds->dims * 4) + pad(nq * 4) * 4 + pad(nq * sizeof(HostSeg2)) +
@@ -3762,7 +3772,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     uint32_t *d_inv = inv_bytes ? (uint32_t *)dtake(inv_bytes) : nullptr;
     Visit *d_visits = nullptr, *d_sorted = nullptr;
     TileUnit *d_units = nullptr;
-    uint32_t *d_leaf_count = nullptr, *d_cursor = nullptr, *d_ustart = nullptr, *d_items = nullptr;
+    uint32_t *d_leaf_count = nullptr, *d_cursor = nullptr, *d_ustart = nullptr, *d_items = nullptr, *d_unit_counts = nullptr;
     uint2 *d_leaf_sums = nullptr;
     if (tiles) {
         d_visits = (Visit *)dtake((size_t)visit_cap * sizeof(Visit));
@@ -3773,6 +3783,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         d_ustart = (uint32_t *)dtake((size_t)ix->n_nodes * 4);
         d_leaf_sums = (uint2 *)dtake((size_t)n_leaf_sums * 8);
         if (items_cap) d_items = (uint32_t *)dtake(items_cap * 4);
+        d_unit_counts = (uint32_t *)dtake(nq * 4);
     }
     ScreenSearch ss{};
     if (screened) {
@@ -3877,6 +3888,7 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     bool passes_done = false;  // set by launch_wave: the block descent was the whole descent
     bool units_done = false;   // ... and it wrote the leaf tiles' work units as well (one query)
     bool items_made = false;   // k_units_small left the list of (unit, slab) pairs for the tile launch
+    uint32_t units_per_query_used = 0;  // > 0: every query's descent wrote its own units (SingleQueryOut::per_query)
     auto launch_wave = [&](const VisitSink &sink) -> int {
         // a query pops about 1 / (kept share) as many nodes under a filter: start with the big queues (one query per CU
         // at a time) only then; otherwise they take what the small ones (four per CU) could not hold
@@ -3902,11 +3914,26 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
             // small call paying two more launches for passes that find nothing to do.
             const bool last_pass = sink.visits != nullptr;
             // (one query: its units and its binary16 copy come out of the descent itself, see SingleQueryOut)
+            // A handful of queries, more trees than one wave has octets: the trees of a query dealt over G blocks of one descent wave
+            // each (k_descend_multi) — one query on G compute units.  Only as the last pass (what it cannot hold takes the long way).
+            const uint32_t per_block = (uint32_t)std::min<long long>(8, std::max<long long>(1, tun(TUN_SEARCH_MULTI_TREES_PER_BLOCK)));
+            const uint32_t multi_blocks = std::min<uint32_t>(kMultiMaxBlocks, (ix->n_trees + per_block - 1) / per_block);
+            const bool multi = last_pass && tun(TUN_SEARCH_MULTI) != 0 && multi_blocks >= 2 &&
+                               (long long)nq <= std::min<long long>(tun(TUN_SEARCH_MULTI_MAX_QUERIES), kMultiMaxQueries);
+            // ... and a few queries whose descents write their own units, query by query (the flat tile launch reads them with
+            // blockIdx.y = query): no launch that sorts a hundred visits of all queries by leaf.  Queries that open the same leaf
+            // read its rows once each.
+            const uint32_t units_per_query = (uint32_t)(visit_cap / std::max<size_t>(nq, 1));
+            const bool own_units = multi && nq > 1 && screened && units_per_query >= kMultiCap && tun(TUN_SEARCH_MULTI_OWN_UNITS) != 0 &&
+                                   (long long)nq <= tun(TUN_SEARCH_SMALL_TILES_MAX_QUERIES) && tun(TUN_SEARCH_FLAT_TILES) != 0 &&
+                                   std::max(1u, (ix->max_desc + kTileSmallSlab - 1) / kTileSmallSlab) <= 65535u;
             SingleQueryOut single{};
-            if (last_pass && nq == 1 && small_units && tun(TUN_SEARCH_SINGLE_FUSED) != 0) {
+            if (last_pass && (nq == 1 || own_units) && small_units && tun(TUN_SEARCH_SINGLE_FUSED) != 0) {
                 single.units = d_units;
                 single.sorted = d_sorted;
-                single.n_units = d_err + SS_N_UNITS;
+                single.n_units = nq == 1 ? d_err + SS_N_UNITS : d_unit_counts;
+                single.per_query = nq == 1 ? 0u : units_per_query;
+                units_per_query_used = single.per_query;
                 if (screened)
                     single.h16 = QueriesH16{d_qvecs, qstride, ds->dims, ds->hpitch, const_cast<uint16_t *>(ss.q16), const_cast<float4 *>(ss.qstats)};
                 units_done = true;
@@ -3916,12 +3943,6 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                                       std::max(1u, (ix->max_desc + kTileSmallSlab - 1) / kTileSmallSlab) <= 65535u;
             }
             const float *raw = (last_pass && fuse_prepare) ? (const float *)h_q : (const float *)nullptr;
-            // A handful of queries, more trees than one wave has octets: the trees of a query dealt over G blocks of one descent wave
-            // each (k_descend_multi) — one query on G compute units.  Only as the last pass (what it cannot hold takes the long way).
-            const uint32_t per_block = (uint32_t)std::min<long long>(8, std::max<long long>(1, tun(TUN_SEARCH_MULTI_TREES_PER_BLOCK)));
-            const uint32_t multi_blocks = std::min<uint32_t>(kMultiMaxBlocks, (ix->n_trees + per_block - 1) / per_block);
-            const bool multi = last_pass && tun(TUN_SEARCH_MULTI) != 0 && multi_blocks >= 2 &&
-                               (long long)nq <= std::min<long long>(tun(TUN_SEARCH_MULTI_MAX_QUERIES), kMultiMaxQueries);
             if (multi) {
                 AH_TRY(ctx->ensure_multi(multi_ctl_bytes()));
                 hipLaunchKernelGGL((k_descend_multi<128, 1>), dim3((unsigned)nq * multi_blocks), dim3(256), multi_descend_lds_bytes<128>() + qstride,
@@ -3999,12 +4020,14 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
             const unsigned small_slabs = std::max(1u, (ix->max_desc + kTileSmallSlab - 1) / kTileSmallSlab);
             const bool small_tiles = (long long)nq <= tun(TUN_SEARCH_SMALL_TILES_MAX_QUERIES) && small_slabs <= 65535u;
             // (one query whose units came out of its descent: a flat list of (leaf, slab) items, see the kernel)
-            const bool flat_tiles = small_tiles && units_done && nq == 1 && visit_cap >= 128u && tun(TUN_SEARCH_FLAT_TILES) != 0;
+            const bool flat_tiles = small_tiles && units_done && (nq == 1 || units_per_query_used) && visit_cap >= 128u &&
+                                    tun(TUN_SEARCH_FLAT_TILES) != 0;
             uint32_t *tile_trace =
                 multi_launched && tun(TUN_SEARCH_MULTI_TRACE) != 0 ? &reinterpret_cast<MultiCtl *>(ctx->d_multi)->tile_trace[0] : nullptr;
             if (flat_tiles)
-                hipLaunchKernelGGL((k_leaf_tiles16<true>), dim3(nns_stride / kTileSmallSlab + 129u), dim3(256), 0, s, dv, ss, d_nns, d_sorted,
-                                   d_units, d_n_units, d_dist, nns_stride, d_err, 0u, ix->d_desc, 0u, tile_trace, 1u);
+                hipLaunchKernelGGL((k_leaf_tiles16<true>), dim3(nns_stride / kTileSmallSlab + 129u, (unsigned)nq), dim3(256), 0, s, dv, ss, d_nns,
+                                   d_sorted, d_units, nq == 1 ? d_n_units : d_unit_counts, d_dist, nns_stride, d_err, 0u, ix->d_desc, 0u, tile_trace,
+                                   1u, (const uint32_t *)nullptr, units_per_query_used);
             else if (small_tiles && items_made)  // one block per listed (unit, slab) pair (grid.y = 1: an overflowed list is walked)
                 hipLaunchKernelGGL((k_leaf_tiles16<true>), dim3((unsigned)std::min<size_t>(items_cap, 2048)), dim3(256), 0, s, dv, ss, d_nns,
                                    d_sorted, d_units, d_n_units, d_dist, nns_stride, d_err, 0u, ix->d_desc, 0u, tile_trace, 0u, d_items);

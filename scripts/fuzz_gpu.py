@@ -135,7 +135,7 @@ def one(rng, it):
                          AH_SEARCH_MULTI=int(rng.integers(0, 2)), AH_SEARCH_MULTI_TREES_PER_BLOCK=int(rng.integers(1, 9)),
                          AH_SEARCH_MULTI_IDS_BY_TILES=int(rng.integers(0, 2)), AH_SEARCH_FLAT_TILES=int(rng.integers(0, 2)),
                          AH_SEARCH_ITEM_LIST=int(rng.integers(0, 2)), AH_SEARCH_STATUS_WIPE=int(rng.integers(0, 2)),
-                         AH_SEARCH_SPIN_WAIT=int(rng.integers(0, 2))) if ref is not None else {}
+                         AH_SEARCH_SPIN_WAIT=int(rng.integers(0, 2)), AH_SEARCH_MULTI_OWN_UNITS=int(rng.integers(0, 2))) if ref is not None else {}
             with tuning(AH_SEARCH_WAVE=min(wave, 1), AH_SEARCH_BLOCK_MAX_QUERIES=64 if wave == 2 else 0, AH_SEARCH_TILES=min(tiles, 1),
                         AH_SEARCH_SCREEN=0 if tiles == 2 else 1, **small):
                 oi, od, oc = index.search(count2, queries=qs2, search_k=sk2, candidates=cand, raw=True)

@@ -17,7 +17,8 @@ SMALL_KNOBS = ["AH_SEARCH_BLOCK_MAX_QUERIES", "AH_SEARCH_SMALL_UNITS_MAX_QUERIES
                "AH_SEARCH_FUSED_FLAG", "AH_SEARCH_FUSED_PREPARE", "AH_SEARCH_SINGLE_FUSED", "AH_SEARCH_MULTI",
                # round 6: who copies a single query's ids, the tile launch's grid (flat list for one query, item list for a few), the
                # status block wiped by the selection, the wait on the pinned status word
-               "AH_SEARCH_MULTI_IDS_BY_TILES", "AH_SEARCH_FLAT_TILES", "AH_SEARCH_ITEM_LIST", "AH_SEARCH_STATUS_WIPE", "AH_SEARCH_SPIN_WAIT"]
+               "AH_SEARCH_MULTI_IDS_BY_TILES", "AH_SEARCH_FLAT_TILES", "AH_SEARCH_ITEM_LIST", "AH_SEARCH_STATUS_WIPE", "AH_SEARCH_SPIN_WAIT",
+               "AH_SEARCH_MULTI_OWN_UNITS"]
 
 
 def same(a, b):
