@@ -3085,15 +3085,22 @@ __global__ __launch_bounds__(1024) void k_search_select_screened(DataView dv, Sc
         __threadfence_system();
         __syncthreads();
         // (one query: this block is the last one by construction — no counter, no second fence)
-        if (threadIdx.x == 0 && (gridDim.x == 1u || atomicAdd(&err[SS_DONE], 1u) + 1u == gridDim.x)) {
-            if (gridDim.x != 1u) __threadfence_system();
-            for (uint32_t w = 1; w < SS_WORDS; w++) host_status[w] = __hip_atomic_load(&err[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence_system();
-            __hip_atomic_store(&host_status[0], __hip_atomic_load(&err[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELEASE,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-            // every block is done with the status block: wiped for the next submission (Context::clean_status)
-            for (uint32_t w = 0; w < SS_WORDS; w++) __hip_atomic_store(&err[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (trace) trace[8] = (uint32_t)(wall_clock64() - t_start);
+        // The first wave of the last block: lane w carries status word w (sixteen loads and stores side by side, not one after the
+        // other), word 0 after a fence of its own, then the wipe for the next submission (Context::clean_status).
+        if (threadIdx.x < 64u) {
+            uint32_t last = 0;
+            if (threadIdx.x == 0) last = (gridDim.x == 1u || atomicAdd(&err[SS_DONE], 1u) + 1u == gridDim.x) ? 1u : 0u;
+            last = (uint32_t)__shfl((int)last, 0, 64);
+            if (last) {  // wave-uniform
+                if (gridDim.x != 1u) __threadfence_system();
+                const uint32_t w = threadIdx.x;
+                const uint32_t word = w < SS_WORDS ? __hip_atomic_load(&err[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                if (w >= 1u && w < SS_WORDS) host_status[w] = word;
+                __threadfence_system();
+                if (w == 0u) __hip_atomic_store(&host_status[0], word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (w < SS_WORDS) __hip_atomic_store(&err[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (trace && w == 0u) trace[8] = (uint32_t)(wall_clock64() - t_start);
+            }
         }
     }
 }
