@@ -163,6 +163,7 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(RERANK_GROUPS, "AH_RERANK_GROUPS", 2)     /* groups a screened ah_rerank_batch submission is cut into (upload of group g + 1 under the kernel of g) */ \
     X(RERANK_SCREEN8, "AH_RERANK_SCREEN8", 1)   /* 0: the screen of ah_rerank_batch starts on the binary16 rows, never on the int8 copy */ \
     X(SEARCH_SCREEN8_MAX_VISITS, "AH_SEARCH_SCREEN8_MAX_VISITS", 4) /* leaves reached by at most this many queries of a call are screened on the int8 rows, the others on the binary16 rows */ \
+    X(SEARCH_SCREEN8_MIN_QUERIES, "AH_SEARCH_SCREEN8_MIN_QUERIES", 65) /* ... from this many queries a call (never the in-flight tiles of <= AH_SEARCH_SMALL_TILES_MAX_QUERIES queries; 9 .. 64 measured: no gain) */ \
     X(SEARCH_SCREEN8, "AH_SEARCH_SCREEN8", 1)   /* 0: the tile re-rank of ah_search_batch likewise */ \
     X(RERANK_SCREEN, "AH_RERANK_SCREEN", 1)     /* 0: ah_rerank_batch never screens its candidates (f32 rows for all) */ \
     X(REPLICATE_HOST_BOUNCE, "AH_REPLICATE_HOST_BOUNCE", 0) /* 1: ah_dataset_replicate copies through pinned host memory even where peer access works (test aid) */ \

@@ -3725,10 +3725,13 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
     const bool screened = tiles && tun(TUN_SEARCH_SCREEN) != 0 && (ds->metric == AH_COSINE || ds->metric == AH_DOT_PRODUCT) &&
                           ds->screen_ready.load(std::memory_order_acquire);  // (published: common.h)
     if (screened) dev_bytes += pad(nq * (size_t)ds->hpitch * 2) + pad(nq * sizeof(float4)) + pad(nq * (size_t)nns_stride * 4);
-    // ... and on the int8 copy before that (round 6; the big submissions: the small ones make their binary16 copies inside
-    // their own kernels and stay as they are): see ScreenSearch
+    // ... and on the int8 copy before that (round 6): the submissions of at least AH_SEARCH_SCREEN8_MIN_QUERIES queries (65: past
+    // the small ones' unit builder).  From 9 queries a call the leaf tiles are bound by the bytes of their rows (64 queries: 294 of
+    // the call's 508 us) and the int8 rows do cut them to 249 — but the wider band of survivors costs the selection 65 -> 95 us
+    // and the queries' digits a launch: 511 us against 502, measured, so the default leaves those calls on binary16; see ScreenSearch
     const bool screened8 = screened && allow8 && tun(TUN_SEARCH_SCREEN8) != 0 && !ix->search8_off.load(std::memory_order_relaxed) &&
-                           (long long)nq > tun(TUN_SEARCH_SMALL_UNITS_MAX_QUERIES) && ds->screen8_ready.load(std::memory_order_acquire);
+                           (long long)nq > std::max(tun(TUN_SEARCH_SMALL_TILES_MAX_QUERIES), tun(TUN_SEARCH_SCREEN8_MIN_QUERIES) - 1) &&
+                           ds->screen8_ready.load(std::memory_order_acquire);
     if (screened8) dev_bytes += pad(nq * (size_t)ds->pitch8 * 2) + pad(nq * sizeof(float4)) + pad(nq * (size_t)nns_stride * 4);
     // (a few queries a call: the list of (unit, slab) pairs k_units_small leaves for the tile launch)
     const size_t items_cap = tiles && (long long)nq <= tun(TUN_SEARCH_SMALL_UNITS_MAX_QUERIES) && tun(TUN_SEARCH_ITEM_LIST) != 0
@@ -3882,8 +3885,6 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
                               (!d_filter_bits || filter_share >= 0.35) && block_ok && tun(TUN_SEARCH_FUSED_PREPARE) != 0;
     if (queries && !fuse_prepare)
         AH_TRY(launch_prepare_queries_only(dv, zero_copy_queries ? h_q : d_qf32, (uint32_t)nq, d_qvecs, qstride, d_qhdrs, s));
-    if (screened8)  // (never a small submission: see above)
-        hipLaunchKernelGGL(k_queries_i8, dim3((unsigned)nq), dim3(64), 0, s, d_qvecs, qstride, ds->dims, ss);
     if (screened && !small_units)
         hipLaunchKernelGGL(k_queries_h16, dim3((unsigned)nq), dim3(64), 0, s, d_qvecs, qstride, ds->dims, ds->hpitch,
                            const_cast<uint16_t *>(ss.q16), const_cast<float4 *>(ss.qstats));
@@ -4016,6 +4017,8 @@ static int search_chunk(ah_index *ix, Context *ctx, const float *queries, const 
         if (screened8) {
             // the leaves few queries reached on the int8 copy (a quarter of the f32 bytes, a wider band of survivors), the leaves
             // many queries share on the binary16 copy as before; the selection takes every candidate's bound from its own stage
+            // (the queries' int8 digits here, behind the descent: a small submission's query leaves are prepared BY its descent)
+            hipLaunchKernelGGL(k_queries_i8, dim3((unsigned)nq), dim3(64), 0, s, d_qvecs, qstride, ds->dims, ss);
             const uint32_t max_vis8 = (uint32_t)std::max<long long>(1, tun(TUN_SEARCH_SCREEN8_MAX_VISITS));
             hipLaunchKernelGGL(k_leaf_tiles8, dim3(2048, tile_slabs), dim3(256), 0, s, dv, ss, d_nns, d_sorted, d_units, d_n_units, d_dist,
                                nns_stride, d_err, max_vis8);
