@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(8 * kOct) void k_descend_block(DataView nv, SearchP
 // known leaves in LDS and recomputes x.  The last block to finish (a counter) gathers every list, orders the leaves as
 // k_descend_block does (octet order inside a list, equal keys of two lists across the cut -> the sequential descent) and
 // copies the ids; it also wipes what the query wrote, so the control block (Context::d_multi) is zero between calls.
-static constexpr uint32_t kMultiMaxBlocks = 16, kMultiLeaves = 32, kMultiLists = kMultiMaxBlocks * 8, kMultiMaxQueries = 8;
+static constexpr uint32_t kMultiMaxBlocks = 16, kMultiLeaves = 32, kMultiLists = kMultiMaxBlocks * 8, kMultiMaxQueries = 32;
 static constexpr uint32_t kMultiKnown = 1024, kMultiCap = 1024;
 struct MultiCtl {
     uint32_t done, failed, pad[14];
@@ -1287,21 +1287,47 @@ __global__ __launch_bounds__(256) void k_descend_multi(DataView nv, SearchParams
                 lds_store(&s_mw[MW_REMOTE_FAILED], 1u);
                 if (remote_failed) atomicOr(&ctl->failed, 1u);
             }
-            // x = the largest key at which the known leaves hold search_k ids (0: not yet)
+            // x = the largest key at which the known leaves hold search_k ids (0: not yet).  Bit by bit from the top — "do the
+            // leaves with key >= x | bit still hold search_k ids?" — on the lane's share of the list in registers: 32 sums of
+            // n / 64 terms.  (The first version compared every leaf with every other, n^2 / 64 LDS reads per lane: at a few
+            // hundred known leaves one pass took tens of microseconds, the descent popped on meanwhile, the list grew, the pass
+            // got slower — until a queue's 32-leaf list overflowed and a query that opens 170 leaves took the long way every
+            // other call.)
+            // (Up to 128 leaves — the usual two or three dozen — the all-pairs pass is the quicker one: half a microsecond.)
             const uint32_t n_known = min(lds_load(&s_mw[MW_N_KNOWN]), kMultiKnown);
             uint32_t x = 0;
-            for (uint32_t i = wl; i < n_known; i += 64) {
-                const unsigned long long wi = lds_load64(&s_known[i]);
-                const uint32_t ki = (uint32_t)(wi >> 32);
-                if (wi == 0ull || ki <= x) continue;
-                uint32_t sum = 0;
-                for (uint32_t e = 0; e < n_known; e++) {
-                    const unsigned long long we = lds_load64(&s_known[e]);
-                    sum += (uint32_t)(we >> 32) >= ki ? (uint32_t)we : 0u;
+            if (n_known <= 128u) {
+                for (uint32_t i = wl; i < n_known; i += 64) {
+                    const unsigned long long wi = lds_load64(&s_known[i]);
+                    const uint32_t ki = (uint32_t)(wi >> 32);
+                    if (wi == 0ull || ki <= x) continue;
+                    uint32_t sum = 0;
+                    for (uint32_t e = 0; e < n_known; e++) {
+                        const unsigned long long we = lds_load64(&s_known[e]);
+                        sum += (uint32_t)(we >> 32) >= ki ? (uint32_t)we : 0u;
+                    }
+                    if (sum >= sp.search_k) x = ki;
                 }
-                if (sum >= sp.search_k) x = ki;
+                for (uint32_t d = 32; d > 0; d >>= 1) x = max(x, (uint32_t)__shfl_xor((int)x, d, 64));
+            } else {
+                constexpr uint32_t kMineKnown = kMultiKnown / 64;
+                uint32_t k_key[kMineKnown], k_cnt[kMineKnown];
+#pragma unroll
+                for (uint32_t r = 0; r < kMineKnown; r++) {
+                    const uint32_t i = wl + 64u * r;
+                    const unsigned long long wi = i < n_known ? lds_load64(&s_known[i]) : 0ull;
+                    k_key[r] = (uint32_t)(wi >> 32);
+                    k_cnt[r] = (uint32_t)wi;  // (0 for a slot whose word has not landed yet: it counts for nothing)
+                }
+                for (uint32_t bit = 0x80000000u; bit != 0u; bit >>= 1) {
+                    const uint32_t t = x | bit;
+                    uint32_t sum = 0;
+#pragma unroll
+                    for (uint32_t r = 0; r < kMineKnown; r++) sum += k_key[r] >= t ? k_cnt[r] : 0u;
+                    for (uint32_t d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+                    if (sum >= sp.search_k) x = t;
+                }
             }
-            for (uint32_t d = 32; d > 0; d >>= 1) x = max(x, (uint32_t)__shfl_xor((int)x, d, 64));
             if (wl == 0 && x > lds_load(&s_mw[MW_STOP_X])) lds_store(&s_mw[MW_STOP_X], x);
         }
     }

@@ -511,7 +511,7 @@ typedef struct ah_search_stats {
     uint64_t screen8_retried_chunks; /* sub-batches whose int8 stage left more survivors than the selection holds: done again
                                        with the binary16 rows first (eight of them switch the int8 stage of the index off)  */
     uint64_t descent_multi;         /* queries (of descent_block) whose trees were dealt over several blocks, one wave of
-                                       eight octets each: one query on more than one compute unit (submissions of <= 8 queries) */
+                                       eight octets each: one query on more than one compute unit (submissions of <= 32 queries) */
 } ah_search_stats;
 AH_API int ah_index_search_stats(ah_index *index, ah_search_stats *out, int reset);
 
