@@ -95,7 +95,7 @@ class AhBuildStats(C.Structure):
                 ("rows_xcd_launches", C.c_uint64), ("rows_nt_launches", C.c_uint64), ("rows_split_launches", C.c_uint64),
                 ("screen8_pairs", C.c_uint64), ("screen8_decided", C.c_uint64), ("screen8b_decided", C.c_uint64),
                 ("screen_unavailable", C.c_uint32),
-                ("reserved0", C.c_uint32), ("seconds_setup", C.c_double), ("seconds_after_device", C.c_double),
+                ("tail_groups", C.c_uint32), ("seconds_setup", C.c_double), ("seconds_after_device", C.c_double),
                 ("host_blob_recycled", C.c_uint64), ("seconds_reserve", C.c_double), ("seconds_reserve_wait", C.c_double)]
 
 

@@ -1621,6 +1621,45 @@ __global__ __launch_bounds__(256) void k_next_emit(const FNode *__restrict__ nod
     if (pairs) atomicAdd(&info->pairs, pairs);
     if (n_fix) atomicAdd(&info->n_fix, n_fix);
 }
+// A level cut into groups of trees (the tail of build_batch): per group the tiles and the items under its nodes, and its
+// nodes' tile indices rebased to the group's first tile — from there on the group is a level of its own over the shared
+// tile tables.  One block per group; nodes [first[g], first[g + 1]) of the level's table.
+struct GroupCuts {
+    uint32_t first[33];
+};
+struct GroupInfo {
+    uint32_t n_tiles, n_fix;
+    unsigned long long pairs;
+};
+__global__ __launch_bounds__(256) void k_fork_groups(FNode *__restrict__ nodes, GroupCuts cuts, GroupInfo *__restrict__ out) {
+    __shared__ unsigned long long s_pairs[4];
+    __shared__ uint32_t s_fix[4];
+    const uint32_t lo = cuts.first[blockIdx.x], hi = cuts.first[blockIdx.x + 1];
+    uint32_t t0 = 0, t1 = 0;
+    if (hi > lo) {
+        t0 = nodes[lo].tile_begin;
+        t1 = nodes[hi - 1].tile_begin + nodes[hi - 1].n_tiles;
+    }
+    __syncthreads();  // every thread holds the first tile before the first node is rebased
+    unsigned long long pairs = 0;
+    uint32_t fix = 0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+        pairs += nodes[i].count;
+        fix += nodes[i].fix;
+        nodes[i].tile_begin -= t0;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        pairs += __shfl_xor(pairs, off);
+        fix += __shfl_xor(fix, off);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        s_pairs[threadIdx.x >> 6] = pairs;
+        s_fix[threadIdx.x >> 6] = fix;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        out[blockIdx.x] = GroupInfo{t1 - t0, s_fix[0] + s_fix[1] + s_fix[2] + s_fix[3], s_pairs[0] + s_pairs[1] + s_pairs[2] + s_pairs[3]};
+}
 // tile list of a level: one wave per node
 __global__ __launch_bounds__(256) void k_build_tiles(const FNode *__restrict__ nodes, uint32_t n_nodes,
                                                      FTile *__restrict__ tiles) {
@@ -2553,7 +2592,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     const uint64_t max_nodes = M / ((uint64_t)split_after + 1) + n_trees;
     const uint64_t max_tiles = M / kTile + n_trees + max_nodes;
     DevBuf<uint32_t> perm_a, perm_b, final_perm, tile_left, tile_left_off, d_child, d_small;
-    DevBuf<FNode> d_nodes_a, d_nodes_b;
+    DevBuf<FNode> d_nodes_a, d_nodes_b, d_nodes_c;  // (c: the tail in groups of trees)
+    DevBuf<GroupInfo> d_groups;
     DevBuf<FTile> d_tiles;
     DevBuf<uint64_t> masks;
     DevBuf<NextCounts> d_block_sums;
@@ -2725,6 +2765,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     // ---- level 0 on the host: the roots -----------------------------------------------------------------------------
     std::vector<HostRec> recs;
     std::vector<uint32_t> tree_root(n_trees);
+    std::vector<uint64_t> tree_count(n_trees, 1);  // nodes of every tree so far: its root, then two per digested split
     std::vector<uint32_t> level_rec, next_rec;  // HostRec index of every node of the level being digested / of the next
     recs.reserve(4 * max_nodes / 3 + 16);
     size_t n_recs = 0;  // records in use; the vector itself is grown AHEAD of the digest (value-initialising 80 MB of fresh
@@ -2822,7 +2863,10 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     // Digest the node table of a finished level (it arrived on the side stream): split records, children, statistics,
     // and which HostRec every node of the next level belongs to — the same walk the device did in k_next_emit.
     uint64_t items_routed = 0;
-    auto digest_level = [&](uint32_t depth, uint32_t n_nodes, const FNode *tbl, uint64_t chunk_host_off, const uint8_t *chunk_dev) -> int {
+    // `rec_of`: HostRec index of every node of the level (level_rec of the level-by-level loop; a slice of the parent
+    // level's list for the first level of a tree group of the tail)
+    auto digest_level = [&](uint32_t depth, uint32_t n_nodes, const FNode *tbl, uint64_t chunk_host_off, const uint8_t *chunk_dev,
+                            const uint32_t *rec_of) -> int {
         // Children get the records base + 2 i (left) and base + 2 i + 1 (right) of node i, so the walk splits over a few
         // threads (the deepest level of the 10M x 100-tree build has 819 000 nodes: 37 ms on one thread, more than the GPU
         // needs for the level after it); the list of children that split again is concatenated in node order afterwards.
@@ -2836,6 +2880,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             uint32_t bad = 0xFFFFFFFFu;
             std::vector<uint32_t> splits;
             std::vector<LeafRec> leaves;  // streaming build: the children that are Descendants nodes, in node order
+            std::vector<std::pair<uint32_t, uint32_t>> runs;  // (tree, nodes of it in this part): the table is ordered by tree
         };
         std::vector<Part> parts(n_threads);
         // streaming build: this level's split planes as one job for the read-back worker (record i <-> node i)
@@ -2862,10 +2907,12 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     pt.bad = std::min(pt.bad, i);
                     continue;
                 }
+                if (pt.runs.empty() || pt.runs.back().first != nd.tree) pt.runs.push_back({nd.tree, 0u});
+                pt.runs.back().second++;
                 pt.evals += (uint64_t)(nd.attempt + 1) * nd.count;
                 pt.retries += nd.attempt;
                 pt.routed += nd.count;
-                const uint32_t rec_idx = level_rec[i];
+                const uint32_t rec_idx = rec_of[i];
                 recs[rec_idx].has_normal = nd.state == ST_ACCEPTED;
                 recs[rec_idx].normal_off = chunk_host_off + (uint64_t)i * nstride;
                 if (nd.state != ST_ACCEPTED) pt.dummies++;
@@ -2925,6 +2972,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             forest->stats.dummy_normals += pt.dummies;
             items_routed += pt.routed;
             next_rec.insert(next_rec.end(), pt.splits.begin(), pt.splits.end());
+            for (const auto &run : pt.runs) tree_count[run.first] += 2ull * run.second;
         }
         level_rec.swap(next_rec);
         forest->stats.levels = std::max(forest->stats.levels, depth + 1);
@@ -2963,13 +3011,190 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     };
 
     uint32_t depth = 0;
+    uint32_t step = 0;  // levels launched so far: the parity of the double buffers (== depth until the tail runs in groups)
     auto t_prev_waited = std::chrono::steady_clock::now();
     bool prev_rows = false;     // the previous level ran row-major: node_of / side_bytes describe it, d_child links it
     uint32_t pending_digest = 0;  // 1 + depth of the level whose node table is still to be digested (0 = none)
+    uint32_t pending_step = 0;    // ... the step it ran as
     uint32_t pending_nodes = 0;
     uint64_t pending_host_off = 0;
     const uint8_t *pending_chunk_dev = nullptr;
+    int64_t pending_rec_off = -1;      // >= 0: its record indices are level_rec_full[off ...] (first level of a tree group)
+    bool pending_fork_parent = false;  // it is the level the groups were cut from: its children's list is kept whole
     int lvl_status = AH_OK;
+
+    // ---- the tail in groups of trees (AH_BUILD_TAIL_GROUPS) ----------------------------------------------------------
+    // The item ids of a tree are final with its last scatter, and 95 % of them (10M x 768 x 100 trees) are still under
+    // splitting nodes when the last big level starts: level by level, the 4 GB of ids and the 2.6 GB of that level's
+    // normals leave the device after the last launch — 0.10 s of 1.43.  So the last big level and whatever follows it
+    // run GROUP BY GROUP (contiguous ranges of trees, each to its end): the ids and normals of group g travel while
+    // group g + 1 computes, and only the last group's are left for the tail.  A group is a level-by-level build of fewer
+    // trees over the same tables: its nodes are a slice of the level's table (tile indices rebased by k_fork_groups), its
+    // levels always node-major (they are by then), its records digested like any level's.  The forest is the same node
+    // for node — trees never interact — only the order of the normals in the blob (and the ids of a streaming build)
+    // follows the order of the launches.
+    const uint32_t g_tail_groups = (uint32_t)std::min<long long>(32, std::max<long long>(0, tun(TUN_TAIL_GROUPS)));
+    const double g_tail_node_items = (double)std::max<long long>(1, tun(TUN_TAIL_NODE_ITEMS));
+    const uint64_t g_tail_min_items = (uint64_t)std::max<long long>(0, tun(TUN_TAIL_MIN_MB)) * (1u << 20) / 4;
+    bool grouped = false, fork_now = false, group_first_level = false;
+    uint32_t group_n0 = 0;
+    std::vector<uint32_t> level_rec_full;
+    std::vector<uint32_t> group_tree;        // tree range of group g: [group_tree[g], group_tree[g + 1])
+    int pending_hand = -1;                   // group whose item ids are final and still to be handed to the read-back worker
+    FNode *group_spare = nullptr;            // third node table of the grouped tail
+    std::function<int(uint32_t, uint32_t)> hand_over_ids;  // (defined below, once the leaves' merge exists)
+    auto digest_pending = [&]() -> int {
+        if (!pending_digest) return AH_OK;
+        AH_HIP(hipEventSynchronize(bc.ev_copy[pending_step & 1]));
+        const uint32_t *rec_of = pending_rec_off >= 0 ? level_rec_full.data() + pending_rec_off : level_rec.data();
+        AH_TRY(digest_level(pending_digest - 1, pending_nodes, h_nodes[pending_step & 1], pending_host_off, pending_chunk_dev, rec_of));
+        if (pending_fork_parent) {
+            level_rec_full.swap(level_rec);
+            pending_fork_parent = false;
+        }
+        pending_digest = 0;
+        return AH_OK;
+    };
+    // Streaming build: the Descendants nodes of trees [tA, tB), ascending in (tree, position) — i.e. in the order their ids lie
+    // in the final permutation — as one job.  Every level's list is already in that order; the levels of one tree are merged
+    // per tree (a few threads: 1.7 M leaves at 10M x 100 trees).
+    auto push_leaves_job = [&](uint32_t tA, uint32_t tB) -> int {
+        StreamJob *job = new (std::nothrow) StreamJob();
+        AH_REQUIRE(job, AH_ERR_OUT_OF_MEMORY, "host allocation failed");
+        job->head.kind = AH_NODE_DESCENDANTS;
+        job->head.normal_stride = nstride;
+        job->head.normal_header_offset = hdr_off;
+        // per tree: where its leaves start in every level's list, and in the output
+        const size_t n_lv = stream_leaves.size();
+        const uint32_t nt = tB - tA;
+        std::vector<size_t> cut((size_t)(nt + 1) * n_lv, 0), out_at(nt + 1, 0);
+        for (size_t l = 0; l < n_lv; l++) {
+            const auto &lv = stream_leaves[l];
+            // (by tree, not by position: an EMPTY child at the very end of a tree starts where the next tree does)
+            for (uint32_t t = 0; t <= nt; t++)
+                cut[(size_t)t * n_lv + l] = (size_t)(std::lower_bound(lv.begin(), lv.end(), first_tree + tA + t, [](const LeafRec &r, uint32_t v) { return r.tree < v; }) - lv.begin());
+        }
+        for (uint32_t t = 0; t < nt; t++) {
+            size_t c = 0;
+            for (size_t l = 0; l < n_lv; l++) c += cut[(size_t)(t + 1) * n_lv + l] - cut[(size_t)t * n_lv + l];
+            out_at[t + 1] = out_at[t] + c;
+        }
+        const size_t total = out_at[nt];
+        job->nodes.resize(total);
+        std::atomic<uint32_t> next_tree{0};
+        parallel_run(total < 100000 ? 1u : std::min(nt, host_threads), [&](unsigned) {
+            std::vector<LeafRec> mine;
+            for (;;) {
+                const uint32_t t = next_tree.fetch_add(1, std::memory_order_relaxed);
+                if (t >= nt) break;
+                mine.clear();
+                for (size_t l = 0; l < n_lv; l++)
+                    mine.insert(mine.end(), stream_leaves[l].begin() + (ptrdiff_t)cut[(size_t)t * n_lv + l],
+                                stream_leaves[l].begin() + (ptrdiff_t)cut[(size_t)(t + 1) * n_lv + l]);
+                // (an empty leaf shares its position with its sibling: it goes first, so that offsets never step back)
+                std::sort(mine.begin(), mine.end(), [](const LeafRec &a, const LeafRec &b) {
+                    return a.start != b.start ? a.start < b.start : a.count < b.count;
+                });
+                ah_stream_node *dst = job->nodes.data() + out_at[t];
+                for (const LeafRec &r : mine) {
+                    ah_stream_node sn{};
+                    sn.id = r.id;
+                    sn.tree = r.tree;
+                    sn.kind = AH_NODE_DESCENDANTS;
+                    sn.count = r.count;
+                    sn.depth = r.depth;
+                    sn.payload_offset = r.start * 4;
+                    *dst++ = sn;
+                }
+            }
+        });
+        rb.push_stream(job, final_perm.p);
+        return AH_OK;
+    };
+    // The item ids of trees [tA, tB) are final (every kernel that writes them has been waited for): rows -> item ids where the
+    // two differ (on the side stream: the main one is busy with the next group), then to the worker — the blob's slice of a
+    // materialised forest, the leaves' job of a streaming build.
+    hand_over_ids = [&](uint32_t tA, uint32_t tB) -> int {
+        const uint64_t a = tree_base[tA], b = tree_base[tB];
+        if (b > a && !ds->identity_ids) {
+            hipLaunchKernelGGL(k_rows_to_ids, dim3(2048), dim3(256), 0, bc.side, final_perm.p + a, b - a, ds->d_ids);
+            AH_HIP(hipStreamSynchronize(bc.side));
+        }
+        if (sb) return push_leaves_job(tA, tB);
+        prefault.join();
+        rb.push(forest->descendants + desc_base + a, final_perm.p + a, (b - a) * 4);
+        return AH_OK;
+    };
+    // Emit per tree in post-order (children before parents: the order TmpNodes::put receives them,
+    // src/writer.rs:1235-1258), with forest-local indices.  Trees are independent: the number of nodes of every tree
+    // is known (counted while the levels were digested), so each tree is written into its own slice by a few threads —
+    // all trees after the last level, or, when the tail runs in groups, a group's trees under the next group's kernels.
+    const size_t node_base = forest->nodes.size(), roots_base = forest->roots.size();
+    size_t emit_cursor = node_base;  // forest->nodes index of the next tree to be emitted
+    uint32_t emit_tree = 0;          // trees [0, emit_tree) are emitted
+    std::vector<uint32_t> new_index;
+    std::atomic<uint64_t> n_split{0}, n_desc{0};
+    auto emit_range = [&](uint32_t tA, uint32_t tB) -> int {
+        if (sb || tB <= tA) return AH_OK;
+        AH_REQUIRE(tA == emit_tree, AH_ERR_DEVICE, "forest build: trees emitted out of order (internal error)");
+        std::vector<uint64_t> off(tB - tA + 1, 0);
+        for (uint32_t t = tA; t < tB; t++) off[t - tA + 1] = off[t - tA] + tree_count[t];
+        const uint64_t total = off[tB - tA];
+        forest->nodes.resize(emit_cursor + total);
+        if (forest->roots.size() < roots_base + n_trees) forest->roots.resize(roots_base + n_trees);
+        new_index.resize(n_recs, 0xFFFFFFFFu);
+        uint32_t *roots_out = forest->roots.data() + roots_base;
+        std::atomic<uint32_t> next_tree{tA};
+        auto emit_trees = [&](unsigned) {
+            std::vector<std::pair<uint32_t, int>> stack;
+            uint64_t splits = 0, descs = 0;
+            for (;;) {
+                const uint32_t t = next_tree.fetch_add(1, std::memory_order_relaxed);
+                if (t >= tB) break;
+                uint64_t out = emit_cursor + off[t - tA];
+                stack.clear();
+                stack.push_back({tree_root[t], 0});
+                while (!stack.empty()) {
+                    const uint32_t ri = stack.back().first;
+                    const HostRec &r = recs[ri];
+                    if (r.kind == AH_NODE_SPLIT && stack.back().second == 0) {
+                        stack.back().second = 1;
+                        const uint32_t l = r.left, rr = r.right;
+                        stack.push_back({rr, 0});
+                        stack.push_back({l, 0});
+                        continue;
+                    }
+                    ah_node nd{};
+                    nd.kind = r.kind;
+                    nd.has_normal = r.has_normal;
+                    nd.tree = first_tree + t;
+                    nd.count = r.count;
+                    nd.depth = r.depth;
+                    if (r.kind == AH_NODE_SPLIT) {
+                        nd.left = new_index[r.left];
+                        nd.right = new_index[r.right];
+                        nd.offset = r.normal_off;
+                        splits++;
+                    } else {
+                        nd.offset = desc_base + r.start;
+                        descs++;
+                    }
+                    new_index[ri] = (uint32_t)out;
+                    forest->nodes[out++] = nd;
+                    stack.pop_back();
+                }
+                roots_out[t] = new_index[tree_root[t]];
+            }
+            n_split.fetch_add(splits, std::memory_order_relaxed);
+            n_desc.fetch_add(descs, std::memory_order_relaxed);
+        };
+        parallel_run(total < 200000 ? 1u : std::min({tB - tA, host_threads, std::max(1u, std::thread::hardware_concurrency())}),
+                     emit_trees);
+        emit_cursor += total;
+        emit_tree = tB;
+        return AH_OK;
+    };
+    auto run_levels = [&]() -> int {
     while (info.n_nodes) {
         if (opt->cancel && *opt->cancel) {
             set_error("build cancelled");
@@ -2981,30 +3206,6 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         const double ms_tail_prev = std::chrono::duration<double, std::milli>(t_level_top - t_prev_waited).count();
         const uint32_t n_nodes = info.n_nodes, n_tiles = info.n_tiles;
         AH_REQUIRE(n_nodes <= max_nodes && n_tiles <= max_tiles, AH_ERR_DEVICE, "forest build: node / tile bound exceeded");
-        hipLaunchKernelGGL(k_build_tiles, dim3(std::min<uint32_t>((n_nodes + 3) / 4, kMaxBlocks)), dim3(256), 0, s, d_cur,
-                           n_nodes, d_tiles.p);
-        uint8_t *chunk_d = nullptr, *shadow_d = nullptr, *shadow8_d = nullptr;
-        const uint64_t chunk_bytes = (uint64_t)n_nodes * nstride;
-        const uint64_t chunk_host_off = normals_base + normals_bytes;
-        AH_TRY(arena.take(chunk_bytes, &chunk_d));
-        if (screen) AH_TRY(shadow_arena.take((uint64_t)n_nodes * hstride, &shadow_d));
-        if (screen8) AH_TRY(shadow8_arena.take((uint64_t)n_nodes * stride8, &shadow8_d));
-        normals_bytes += chunk_bytes;
-        // Host side of the normals: reserved now; the pages of THIS level's records were started one level ago (a level has
-        // about twice the nodes of the one before), those of the NEXT level start now — committing the 2.6 GB of the deepest
-        // level takes longer than the ~160 ms that level runs, and the loop must not wait for page faults before it can
-        // hand a chunk to the read-back worker.  Whatever the prediction missed is faulted in by the worker itself.
-        if (!sb) AH_TRY(reserve_normals(chunk_host_off + chunk_bytes, chunk_host_off));
-        if (!sb && depth == 0) touch_normals[0].start(forest->normals_blob, chunk_host_off, chunk_bytes);
-        if (!sb) {
-            // next level: twice the nodes while the nodes are large; once they hold fewer than 2 x split_after items on
-            // average most children are Descendants and the next level is a remnant (an eighth); nothing below that
-            const uint64_t next_begin = chunk_host_off + chunk_bytes;
-            const double avg_items = n_nodes ? (double)info.pairs / (double)n_nodes : 0.0;
-            const uint64_t predicted = avg_items > 2.0 * split_after ? 2 * chunk_bytes : avg_items > (double)split_after ? chunk_bytes / 8 : 0;
-            const uint64_t next_len = normals_cap > next_begin ? std::min<uint64_t>(normals_cap - next_begin, predicted) : 0;
-            touch_normals[(depth + 1) & 1].start(forest->normals_blob, next_begin, (size_t)next_len);
-        }
         const unsigned tile_grid = std::min<uint32_t>(n_tiles, g_tile_blocks);
         // The node-major margin kernels walk their tiles with a persistent grid: at the deep levels a tile is ~1200 items
         // (~2 MB of rows) and launching one workgroup per tile — 819 000 of them at level 13 of the 10M x 100 build — cost
@@ -3022,7 +3223,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         const uint64_t nodes_per_tree = (n_nodes + n_trees - 1) / n_trees;
         uint32_t row_tc = 0, lds_tc = 0, lds_worst = 0;
         double best_cost = -1.0;  // AUTO: modelled cost in ns of the cheapest of node-major / row-major for this level
-        if (rows_allowed && mode_req == AH_MARGIN_AUTO) {
+        if (grouped) {
+            // a tree group of the tail: node-major (what the level it was cut from had chosen)
+        } else if (rows_allowed && mode_req == AH_MARGIN_AUTO) {
             // Cost model in ns per row of 3072 bytes, fitted to per-level rocprofv3 traces of the 10M x 768 x 100-tree
             // build (profiles/): node-major = one HBM read of the row per (item, tree) pair; row-major = per pass and
             // row the HBM read of the row plus row_tc normals through the vector memory pipeline (L2 while the group's
@@ -3091,7 +3294,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         bool dense = false;
         // (a launch carries at most 2^32 - 1 work-items: threads x row tiles x column tiles of the shape the level would take)
         const DensePlan dp_legal = dense_plan(N, std::max(n_nodes, 1u));
-        const bool dense_legal = rows_allowed && screen && g_dense != 0 && n_nodes <= g_dense_max_cols &&
+        const bool dense_legal = !grouped && rows_allowed && screen && g_dense != 0 && n_nodes <= g_dense_max_cols &&
                                  (dp_legal.grid + 64) * (uint64_t)dp_legal.threads < 0xFFFFFFFFull && dp_legal.grid < 0x7FFFFFFFull;
         if (dense_legal && mode_req == AH_MARGIN_DENSE_MFMA) {
             dense = true;
@@ -3112,7 +3315,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         if (dense) row_tc = 16;  // the level is row-major as far as node_of / side_bytes / the next level are concerned
         // Top levels: all normals of a group of >= 8 trees fit in LDS -> the LDS-resident variant of the row-major pass.
         const bool want_lds = dense ? false : mode_req == AH_MARGIN_AUTO ? g_rows_lds && row_tc >= 2 : (mode_req & 0x100u) != 0;
-        if (rows_allowed && want_lds && (rec_bytes & 15) == 0) {
+        if (!grouped && rows_allowed && want_lds && (rec_bytes & 15) == 0) {
             tree_first[n_trees] = n_nodes;  // trees without a node in this level start where the next tree starts
             for (uint32_t t = n_trees; t-- > 0;) tree_first[t] = std::min(tree_first[t], tree_first[t + 1]);
             // measured per tree and row: screened 0.039 ns for 16-tree groups, 0.040 for 8-tree groups; f32 0.061 / 0.070
@@ -3132,6 +3335,44 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             else if (mode_req != AH_MARGIN_AUTO) row_tc = 0;  // a forced LDS mode that does not fit: node-major
         }
 
+        // ---- the tail in groups? (see above) ---------------------------------------------------------------------------
+        // This level would run node-major, most of its children will be Descendants nodes (fewer than 2 x split_after
+        // items per node on average), every tree still has nodes in it, and the ids under them are worth the trouble:
+        // hand the level back unlaunched; the caller cuts it into groups of trees.
+        if (!grouped && !fork_now && g_tail_groups >= 2 && n_trees >= 2 && !subset_ids && row_tc < 2 && !dense &&
+            info.pairs >= g_tail_min_items && (double)info.pairs <= g_tail_node_items * (double)split_after * (double)n_nodes) {
+            bool all = true;
+            for (uint32_t t = 0; t < n_trees && all; t++)
+                all = tree_first[t] != 0xFFFFFFFFu && (t == 0 ? tree_first[0] == 0 : tree_first[t] > tree_first[t - 1]);
+            if (all) {
+                fork_now = true;
+                return AH_OK;
+            }
+        }
+        hipLaunchKernelGGL(k_build_tiles, dim3(std::min<uint32_t>((n_nodes + 3) / 4, kMaxBlocks)), dim3(256), 0, s, d_cur,
+                           n_nodes, d_tiles.p);
+        uint8_t *chunk_d = nullptr, *shadow_d = nullptr, *shadow8_d = nullptr;
+        const uint64_t chunk_bytes = (uint64_t)n_nodes * nstride;
+        const uint64_t chunk_host_off = normals_base + normals_bytes;
+        AH_TRY(arena.take(chunk_bytes, &chunk_d));
+        if (screen) AH_TRY(shadow_arena.take((uint64_t)n_nodes * hstride, &shadow_d));
+        if (screen8) AH_TRY(shadow8_arena.take((uint64_t)n_nodes * stride8, &shadow8_d));
+        normals_bytes += chunk_bytes;
+        // Host side of the normals: reserved now; the pages of THIS level's records were started one level ago (a level has
+        // about twice the nodes of the one before), those of the NEXT level start now — committing the 2.6 GB of the deepest
+        // level takes longer than the ~160 ms that level runs, and the loop must not wait for page faults before it can
+        // hand a chunk to the read-back worker.  Whatever the prediction missed is faulted in by the worker itself.
+        if (!sb) AH_TRY(reserve_normals(chunk_host_off + chunk_bytes, chunk_host_off));
+        if (!sb && depth == 0) touch_normals[0].start(forest->normals_blob, chunk_host_off, chunk_bytes);
+        if (!sb) {
+            // next level: twice the nodes while the nodes are large; once they hold fewer than 2 x split_after items on
+            // average most children are Descendants and the next level is a remnant (an eighth); nothing below that
+            const uint64_t next_begin = chunk_host_off + chunk_bytes;
+            const double avg_items = n_nodes ? (double)info.pairs / (double)n_nodes : 0.0;
+            const uint64_t predicted = avg_items > 2.0 * split_after ? 2 * chunk_bytes : avg_items > (double)split_after ? chunk_bytes / 8 : 0;
+            const uint64_t next_len = normals_cap > next_begin ? std::min<uint64_t>(normals_cap - next_begin, predicted) : 0;
+            touch_normals[(step + 1) & 1].start(forest->normals_blob, next_begin, (size_t)next_len);
+        }
         for (int attempt = 0; attempt < 4; attempt++) {
 #define AH_SPLIT_LAUNCH(K)                                                                                             \
     hipLaunchKernelGGL(K, dim3(std::min<uint32_t>(n_nodes, g_split_blocks)), dim3(64), cs_shared, s, dv, d_cur, n_nodes, cur, N, \
@@ -3430,7 +3671,9 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_DBG(s, "scatter");
         // the next level, on the device (its node table lands in the buffer the level before this one used: the side-stream
         // copy of that table must be over)
-        if (depth >= 1) AH_HIP(hipStreamWaitEvent(s, bc.ev_copy[(depth + 1) & 1], 0));
+        if (step >= 1) AH_HIP(hipStreamWaitEvent(s, bc.ev_copy[(step + 1) & 1], 0));
+        // (a group's first level emits into the table the group before it may have finished in: that copy is one step old)
+        if (grouped && step >= 1) AH_HIP(hipStreamWaitEvent(s, bc.ev_copy[step & 1], 0));
         const uint32_t n_blocks = (n_nodes + 255) / 256;
         hipLaunchKernelGGL(k_next_count, dim3(n_blocks), dim3(256), 0, s, d_cur, n_nodes, split_after, d_block_sums.p);
         hipLaunchKernelGGL(k_next_scan, dim3(1), dim3(1024), 0, s, d_block_sums.p, n_blocks, d_info, d_tree_first, n_trees);
@@ -3438,7 +3681,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                            d_child.p, d_info, d_tree_first);
         AH_DBG(s, "next_level");
         AH_HIP(hipGetLastError());
-        LevelInfo *hi = h_info[depth & 1];
+        LevelInfo *hi = h_info[step & 1];
         AH_HIP(hipMemcpyAsync(hi, d_info, info_words * 4, hipMemcpyDeviceToHost, s));
         AH_HIP(hipEventRecord(bc.ev_level, s));
 
@@ -3449,10 +3692,13 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             if (recs.size() < want) recs.resize(want);
         }
         const auto t_launched = std::chrono::steady_clock::now();
-        if (pending_digest) {
-            AH_HIP(hipEventSynchronize(bc.ev_copy[(pending_digest - 1) & 1]));
-            AH_TRY(digest_level(pending_digest - 1, pending_nodes, h_nodes[(pending_digest - 1) & 1], pending_host_off, pending_chunk_dev));
-            pending_digest = 0;
+        AH_TRY(digest_pending());
+        // the group before this one is complete (its last level was waited for, its last table is digested): its ids travel
+        // under this group's kernels
+        if (pending_hand >= 0) {
+            AH_TRY(hand_over_ids(group_tree[pending_hand], group_tree[pending_hand + 1]));
+            AH_TRY(emit_range(group_tree[pending_hand], group_tree[pending_hand + 1]));
+            pending_hand = -1;
         }
         const auto t_digested = std::chrono::steady_clock::now();
         lvl_status = wait_level();
@@ -3479,17 +3725,19 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         }
         forest->stats.margin_launches += 4;
         // this level's node table follows on the side stream (the level is complete: no stream dependency needed)
-        AH_HIP(hipMemcpyAsync(h_nodes[depth & 1], d_cur, n_nodes * sizeof(FNode), hipMemcpyDeviceToHost, bc.side));
-        AH_HIP(hipEventRecord(bc.ev_copy[depth & 1], bc.side));
+        AH_HIP(hipMemcpyAsync(h_nodes[step & 1], d_cur, n_nodes * sizeof(FNode), hipMemcpyDeviceToHost, bc.side));
+        AH_HIP(hipEventRecord(bc.ev_copy[step & 1], bc.side));
         // (a millisecond at most — and it must not queue behind the gigabytes of normals the worker is about to request: the
         // digest of this table runs under the NEXT level, which at the bottom of the forest is a short one)
-        if (n_nodes >= 65536) AH_HIP(hipEventSynchronize(bc.ev_copy[depth & 1]));
+        if (n_nodes >= 65536) AH_HIP(hipEventSynchronize(bc.ev_copy[step & 1]));
         pending_digest = depth + 1;
+        pending_step = step;
+        pending_rec_off = group_first_level ? (int64_t)group_n0 : -1;
         pending_nodes = n_nodes;
         pending_host_off = chunk_host_off;
         pending_chunk_dev = chunk_d;
         // this level's normals are final: the worker copies them while the next level runs
-        touch_normals[depth & 1].join();  // never touch a page the worker may already have filled
+        touch_normals[step & 1].join();  // never touch a page the worker may already have filled
         if (!sb) rb.push(forest->normals + chunk_host_off, chunk_d, chunk_bytes);  // (streaming: pushed by the level's digest)
 
         info = *hi;
@@ -3498,8 +3746,78 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         prev_rows = row_tc >= 2;
         std::swap(cur, nxt);
         std::swap(d_cur, d_next);
+        if (group_first_level) {  // the group's first table was a slice of the level's: from here on it has two of its own
+            d_next = group_spare;
+            group_first_level = false;
+        }
         depth++;
+        step++;
     }
+    return AH_OK;
+    };
+    auto run_tail_groups = [&]() -> int {
+        if (!fork_now) return AH_OK;
+        const uint32_t K = std::min(g_tail_groups, n_trees);
+        group_tree.resize(K + 1);
+        GroupCuts cuts{};
+        // shrinking groups: group g + 1 computes while group g's ids and normals travel (~0.76 of the time its kernels took at
+        // PCIe rate), and only the last group's are left after the last launch — so the last one is the smallest
+        {
+            const double ratio = (double)std::min<long long>(100, std::max<long long>(10, tun(TUN_TAIL_RATIO))) / 100.0;
+            double total_w = 0.0, w = 1.0, cum = 0.0;
+            for (uint32_t g = 0; g < K; g++, w *= ratio) total_w += w;
+            group_tree[0] = 0;
+            w = 1.0;
+            for (uint32_t g = 1; g < K; g++, w *= ratio) {
+                cum += w;
+                const uint32_t at = (uint32_t)std::llround((double)n_trees * cum / total_w);
+                group_tree[g] = std::min(std::max(at, group_tree[g - 1] + 1), n_trees - (K - g));  // at least one tree each
+            }
+            group_tree[K] = n_trees;
+        }
+        for (uint32_t g = 0; g <= K; g++) cuts.first[g] = g < K ? tree_first[group_tree[g]] : info.n_nodes;
+        AH_TRY(d_nodes_c.ensure(max_nodes));
+        AH_TRY(d_groups.ensure(32));
+        AH_HIP(hipMemsetAsync(d_nodes_c.p, 0, max_nodes * sizeof(FNode), s));  // (zeros: see the tables above)
+        hipLaunchKernelGGL(k_fork_groups, dim3(K), dim3(256), 0, s, d_cur, cuts, d_groups.p);
+        GroupInfo gi[32];
+        AH_HIP(hipMemcpyAsync(gi, d_groups.p, K * sizeof(GroupInfo), hipMemcpyDeviceToHost, s));
+        AH_HIP(hipStreamSynchronize(s));
+        // the records of the level's nodes: the children's list of the level before it, digested under the first group
+        if (pending_digest) pending_fork_parent = true;
+        else level_rec_full.swap(level_rec);
+        FNode *const table = d_cur, *const other = d_next;
+        uint32_t *const cur_f = cur, *const nxt_f = nxt;
+        const uint32_t depth_f = depth;
+        grouped = true;
+        group_spare = d_nodes_c.p;
+        forest->stats.tail_groups += K;
+        if (timing)
+            fprintf(stderr, "[ah] tail: level %u on (%u nodes, %llu pairs) in %u groups of trees\n", depth, info.n_nodes,
+                    (unsigned long long)info.pairs, K);
+        for (uint32_t g = 0; g < K; g++) {
+            const uint32_t n0 = cuts.first[g], n1 = cuts.first[g + 1];
+            info = LevelInfo{};
+            info.n_nodes = n1 - n0;
+            info.n_tiles = gi[g].n_tiles;
+            info.n_fix = gi[g].n_fix;
+            info.pairs = gi[g].pairs;
+            d_cur = table + n0;
+            d_next = other;
+            cur = cur_f;
+            nxt = nxt_f;
+            depth = depth_f;
+            prev_rows = false;
+            group_first_level = true;
+            group_n0 = n0;
+            AH_TRY(run_levels());
+            if (sb && (sb->target.sink_rc.load() || sb->target.too_big.load())) break;  // reported after the loop
+            pending_hand = (int)g;  // handed over under the next group's first level (the last group's: after the loop)
+        }
+        return AH_OK;
+    };
+    AH_TRY(run_levels());
+    AH_TRY(run_tail_groups());
     AH_HIP(hipEventRecord(bc.ev_end, s));
     const auto t_loop_end = std::chrono::steady_clock::now();
 
@@ -3512,11 +3830,12 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         t_tail_prefault = std::chrono::steady_clock::now();
         if (!sb) forest->descendants_len = desc_base + M;
         // trees that are a single Descendants node never went through a scatter: their list is the input itself
-        for (uint32_t t = 0; t < n_trees; t++)
+        // (a tail in groups has no such tree, and its ids were converted group by group)
+        for (uint32_t t = 0; t < n_trees && !fork_now; t++)
             if (recs[tree_root[t]].kind == AH_NODE_DESCENDANTS && tree_base[t + 1] > tree_base[t])
                 AH_HIP(hipMemcpyAsync(final_perm.p + tree_base[t], perm_a.p + tree_base[t],
                                       (tree_base[t + 1] - tree_base[t]) * 4, hipMemcpyDeviceToDevice, s));
-        if (!ds->identity_ids && M)
+        if (!ds->identity_ids && M && !fork_now)
             hipLaunchKernelGGL(k_rows_to_ids, dim3(2048), dim3(256), 0, s, final_perm.p, M, ds->d_ids);
         ScreenCounters sc{};
         AH_HIP(hipMemcpyAsync(&sc, d_counters, sizeof sc, hipMemcpyDeviceToHost, s));
@@ -3527,67 +3846,18 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         forest->stats.screen8_pairs += sc.stage8_pairs;
         forest->stats.screen8_decided += sc.stage8_decided;
         forest->stats.screen8b_decided += sc.stage8b_decided;
-        if (!sb) rb.push(forest->descendants + desc_base, final_perm.p, M * 4);  // lands while the host emits the node list
+        if (!sb && !fork_now) rb.push(forest->descendants + desc_base, final_perm.p, M * 4);  // lands while the host emits the node list
+        if (!sb && fork_now && pending_hand >= 0) {  // (the last group's)
+            AH_TRY(hand_over_ids(group_tree[pending_hand], group_tree[pending_hand + 1]));
+            pending_hand = -1;
+        }
     }
     // the last level's node table is digested only now: the 4 GB of item ids are already on their way
-    if (pending_digest) {
-        AH_HIP(hipEventSynchronize(bc.ev_copy[(pending_digest - 1) & 1]));
-        AH_TRY(digest_level(pending_digest - 1, pending_nodes, h_nodes[(pending_digest - 1) & 1], pending_host_off, pending_chunk_dev));
-    }
+    AH_TRY(digest_pending());
     if (sb) {
-        // Streaming build: the Descendants nodes, ascending in (tree, position) — i.e. in the order their ids lie in the final
-        // permutation — as one job.  Every level's list is already in that order; the levels of one tree are merged per tree
-        // (a few threads: 1.7 M leaves at 10M x 100 trees).
-        StreamJob *job = new (std::nothrow) StreamJob();
-        AH_REQUIRE(job, AH_ERR_OUT_OF_MEMORY, "host allocation failed");
-        job->head.kind = AH_NODE_DESCENDANTS;
-        job->head.normal_stride = nstride;
-        job->head.normal_header_offset = hdr_off;
-        size_t total = 0;
-        for (const auto &lv : stream_leaves) total += lv.size();
-        job->nodes.resize(total);
-        // per tree: where its leaves start in every level's list, and in the output
-        const size_t n_lv = stream_leaves.size();
-        std::vector<size_t> cut((size_t)(n_trees + 1) * n_lv, 0), out_at(n_trees + 1, 0);
-        for (size_t l = 0; l < n_lv; l++) {
-            const auto &lv = stream_leaves[l];
-            // (by tree, not by position: an EMPTY child at the very end of a tree starts where the next tree does)
-            for (uint32_t t = 0; t <= n_trees; t++)
-                cut[(size_t)t * n_lv + l] = (size_t)(std::lower_bound(lv.begin(), lv.end(), first_tree + t, [](const LeafRec &r, uint32_t v) { return r.tree < v; }) - lv.begin());
-        }
-        for (uint32_t t = 0; t < n_trees; t++) {
-            size_t c = 0;
-            for (size_t l = 0; l < n_lv; l++) c += cut[(size_t)(t + 1) * n_lv + l] - cut[(size_t)t * n_lv + l];
-            out_at[t + 1] = out_at[t] + c;
-        }
-        std::atomic<uint32_t> next_tree{0};
-        parallel_run(total < 100000 ? 1u : std::min(n_trees, host_threads), [&](unsigned) {
-            std::vector<LeafRec> mine;
-            for (;;) {
-                const uint32_t t = next_tree.fetch_add(1, std::memory_order_relaxed);
-                if (t >= n_trees) break;
-                mine.clear();
-                for (size_t l = 0; l < n_lv; l++)
-                    mine.insert(mine.end(), stream_leaves[l].begin() + (ptrdiff_t)cut[(size_t)t * n_lv + l],
-                                stream_leaves[l].begin() + (ptrdiff_t)cut[(size_t)(t + 1) * n_lv + l]);
-                // (an empty leaf shares its position with its sibling: it goes first, so that offsets never step back)
-                std::sort(mine.begin(), mine.end(), [](const LeafRec &a, const LeafRec &b) {
-                    return a.start != b.start ? a.start < b.start : a.count < b.count;
-                });
-                ah_stream_node *dst = job->nodes.data() + out_at[t];
-                for (const LeafRec &r : mine) {
-                    ah_stream_node sn{};
-                    sn.id = r.id;
-                    sn.tree = r.tree;
-                    sn.kind = AH_NODE_DESCENDANTS;
-                    sn.count = r.count;
-                    sn.depth = r.depth;
-                    sn.payload_offset = r.start * 4;
-                    *dst++ = sn;
-                }
-            }
-        });
-        rb.push_stream(job, final_perm.p);
+        if (!fork_now) AH_TRY(push_leaves_job(0, n_trees));
+        else if (pending_hand >= 0) AH_TRY(hand_over_ids(group_tree[pending_hand], group_tree[pending_hand + 1]));
+        pending_hand = -1;
     }
     const auto t_levels = std::chrono::steady_clock::now();
     float ms = 0.0f;
@@ -3615,65 +3885,10 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         return AH_OK;
     }
 
-    // Emit per tree in post-order (children before parents: the order TmpNodes::put receives them,
-    // src/writer.rs:1235-1258), with forest-local indices.  Trees are independent: the number of nodes of every tree
-    // is known (counted while the levels were digested), so each tree is written into its own slice by a few threads.
-    recs.resize(n_recs);  // (the vector is grown ahead of the digests with value-initialised records: count the real ones only)
-    std::vector<uint64_t> tree_nodes(n_trees + 1, 0);
-    for (const HostRec &r : recs) tree_nodes[r.tree + 1]++;
-    for (uint32_t t = 0; t < n_trees; t++) tree_nodes[t + 1] += tree_nodes[t];
-    const size_t node_base = forest->nodes.size();
-    forest->nodes.resize(node_base + recs.size());
-    forest->roots.resize(forest->roots.size() + n_trees);
-    uint32_t *roots_out = forest->roots.data() + (forest->roots.size() - n_trees);
-    std::vector<uint32_t> new_index(recs.size(), 0xFFFFFFFFu);
-    std::atomic<uint64_t> n_split{0}, n_desc{0};
-    std::atomic<uint32_t> next_tree{0};
-    auto emit_trees = [&](unsigned) {
-        std::vector<std::pair<uint32_t, int>> stack;
-        uint64_t splits = 0, descs = 0;
-        for (;;) {
-            const uint32_t t = next_tree.fetch_add(1, std::memory_order_relaxed);
-            if (t >= n_trees) break;
-            uint64_t out = node_base + tree_nodes[t];
-            stack.clear();
-            stack.push_back({tree_root[t], 0});
-            while (!stack.empty()) {
-                const uint32_t ri = stack.back().first;
-                const HostRec &r = recs[ri];
-                if (r.kind == AH_NODE_SPLIT && stack.back().second == 0) {
-                    stack.back().second = 1;
-                    const uint32_t l = r.left, rr = r.right;
-                    stack.push_back({rr, 0});
-                    stack.push_back({l, 0});
-                    continue;
-                }
-                ah_node nd{};
-                nd.kind = r.kind;
-                nd.has_normal = r.has_normal;
-                nd.tree = first_tree + t;
-                nd.count = r.count;
-                nd.depth = r.depth;
-                if (r.kind == AH_NODE_SPLIT) {
-                    nd.left = new_index[r.left];
-                    nd.right = new_index[r.right];
-                    nd.offset = r.normal_off;
-                    splits++;
-                } else {
-                    nd.offset = desc_base + r.start;
-                    descs++;
-                }
-                new_index[ri] = (uint32_t)out;
-                forest->nodes[out++] = nd;
-                stack.pop_back();
-            }
-            roots_out[t] = new_index[tree_root[t]];
-        }
-        n_split.fetch_add(splits, std::memory_order_relaxed);
-        n_desc.fetch_add(descs, std::memory_order_relaxed);
-    };
-    parallel_run(recs.size() < 200000 ? 1u : std::min({n_trees, host_threads, std::max(1u, std::thread::hardware_concurrency())}),
-                 emit_trees);
+    // the node list of the trees not emitted yet (all of them, unless the tail ran in groups)
+    AH_TRY(emit_range(emit_tree, n_trees));
+    AH_REQUIRE(emit_cursor - node_base == n_recs, AH_ERR_DEVICE, "forest build: %zu nodes emitted of %zu (internal error)",
+               emit_cursor - node_base, n_recs);
     forest->stats.split_nodes += n_split.load();
     forest->stats.descendant_nodes += n_desc.load();
     const auto t_emitted = std::chrono::steady_clock::now();

@@ -1033,6 +1033,9 @@ def build_entry(samples, st):
             # outside the kernels (last sample): entry -> first launch, last launch -> return; output blobs recycled from the pool
             "seconds_setup": st.get("seconds_setup"), "seconds_after_device": st.get("seconds_after_device"),
             "host_blob_recycled": st.get("host_blob_recycled"),
+            # groups of trees the last big level and what followed it ran in (their ids and normals left the device under the next
+            # group's kernels; 0: every level for all trees, the ids after the last launch)
+            "tail_groups": st.get("tail_groups"),
             "seconds_margin_kernel": ms, "margin_evaluations": st.get("margin_evaluations"),
             "levels": st.get("levels"), "split_nodes": st.get("split_nodes"),
             "margin_effective_gb_per_s": st.get("margin_evaluations", 0) * 4 * DIMS / ms / 1e9 if ms else None,
@@ -1105,6 +1108,18 @@ def build_10m(args, rank, world, device, sync, ds, result):
                 "seconds_device": st.get("seconds_device"), "seconds_setup": st.get("seconds_setup"),
                 "seconds_after_device": st.get("seconds_after_device"), "max_host_threads": host_threads or 8,
                 "host_blob_recycled": st.get("host_blob_recycled")}
+    if world == 1 and rank == 0 and seeds:
+        # A/B in this run: every level for all trees to the end (AH_BUILD_TAIL_GROUPS=0, the build of rounds 1-5: the 4 GB of ids
+        # and the last level's normals leave the device after the last launch)
+        with ahlib.tuning(AH_BUILD_TAIL_GROUPS=0):
+            _o, samples_l, st_l, dig_l = timed_builds(ds, seeds, 0, 2, rank, _NoSync(), host_threads, trees, None, None)
+        out["screened"]["level_by_level"] = {"seconds": min(samples_l), "seconds_samples": samples_l,
+                                             "seconds_device": st_l.get("seconds_device"),
+                                             "seconds_after_device": st_l.get("seconds_after_device"),
+                                             "tail_groups": st_l.get("tail_groups"), "identical": dig_l == digests["screened"]}
+        if dig_l != digests["screened"]:
+            print("FOREST MISMATCH: the build with the tail in groups of trees differs from the level-by-level build", file=sys.stderr)
+            sys.exit(5)
     stream = None
     if world == 1 and rank == 0:
         # the same build through ah_build_forest_stream: split planes per level and item ids handed to a sink from the pinned
@@ -1287,6 +1302,8 @@ def flat_scalars(line):
     out = {
         "build_1m_seconds": _dig(line, "build", "seconds"),
         "build_10m_seconds": b.get("seconds"), "build_10m_seconds_device": b.get("seconds_device"),
+        "build_10m_seconds_after_device": b.get("seconds_after_device"), "build_10m_tail_groups": b.get("tail_groups"),
+        "build_10m_level_by_level_seconds": _dig(b, "level_by_level", "seconds"),
         "build_10m_f32_only_seconds": _dig(b, "f32_only", "seconds"),
         "build_10m_identical": b.get("identical"), "build_10m_screen_fallbacks_frac": b.get("screen_fallbacks_frac"),
         "build_10m_screen8_decided_frac": b.get("screen8_decided_frac"),

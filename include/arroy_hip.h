@@ -360,7 +360,9 @@ typedef struct ah_build_stats {
     uint64_t screen8b_decided;    /* ... and of the rest, decided by the rows' second int8 digit (768 more bytes); what is
                                      left goes on to the binary16 stage                                                  */
     uint32_t screen_unavailable;  /* the build wanted the screen but its copies could not be allocated: f32 arithmetic  */
-    uint32_t reserved0;
+    uint32_t tail_groups;         /* (was reserved) groups of trees the last big level and what followed it ran in, summed
+                                     over the batches: their ids and normals left the device under the next group's
+                                     kernels (AH_BUILD_TAIL_GROUPS); 0 = every level for all trees                      */
     /* ABI v5: where the wall time outside the kernels went (summed over the batches of the build) */
     double seconds_setup;         /* entry of a batch -> its first launch (device buffers, pinned memory, host blobs)    */
     double seconds_after_device;  /* last launch of a batch -> its return (ids' read-back, node list, teardown)          */
@@ -400,8 +402,11 @@ AH_API int ah_forest_destroy(ah_forest *forest);
  * 64 MiB of pinned memory and the node table instead of the 9.4 GB a 10M x 768 x 100-tree forest occupies.
  *
  * Order: breadth-first — a split node arrives BEFORE its children (its record names their ids; the reference's ids are
- * arbitrary too, src/parallel.rs:239-254, and TmpNodes is an append-only log keyed by id).  Descendants nodes arrive
- * last, in ascending (tree, position) order.  `id`s are unique over the whole call, dense from 0, assigned in creation
+ * arbitrary too, src/parallel.rs:239-254, and TmpNodes is an append-only log keyed by id).  The Descendants nodes of a
+ * tree arrive after all of its split nodes, in ascending (tree, position) order over the whole call: after the last
+ * level, or — when the last big level and what follows it run in groups of trees (AH_BUILD_TAIL_GROUPS, the default
+ * for builds whose id lists are worth it) — a group's Descendants as soon as that group is complete, i.e. between the
+ * split planes of the groups after it.  `id`s are unique over the whole call, dense from 0, assigned in creation
  * order (a node's children are id-consecutive: left, left + 1).  `sink` is called from ONE library thread, one batch at
  * a time; `nodes` and `payload` are valid only during the call (the payload is the pinned DMA buffer itself: copy or
  * encode out of it).  A non-zero return stops the build: AH_ERR_CANCELLED.

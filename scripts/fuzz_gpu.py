@@ -89,9 +89,13 @@ def one(rng, it):
     mode = int(rng.choice([0, 0, 1, 2, 4, 8, 16, 0x108, 0x110, 0x200, 0x200])) | (0x1000 if rng.random() < 0.3 else 0)
     mask_bits = int(rng.integers(0, 2))  # the sides of a row-major level gathered as bits / as bytes
     narrow = int(rng.choice([64, 128, 256, 0]))  # widest level the narrow dense kernel takes (64 / 128-column shapes; 0: never)
-    with _tuning(AH_MASK_BITS=mask_bits, AH_DENSE_NARROW_MAX_COLS=narrow, AH_DENSE_NARROW_STREAM=int(rng.integers(0, 2))):
+    # the tail of the build in groups of trees (0: every level for all trees), from levels of various fullness on; AH_ROWMAJOR=0
+    # makes every level node-major, i.e. one that may be cut
+    tail = dict(AH_BUILD_TAIL_GROUPS=int(rng.choice([0, 2, 3, 4, 7, 32])), AH_BUILD_TAIL_MIN_MB=0,
+                AH_BUILD_TAIL_NODE_ITEMS=int(rng.choice([1, 2, 2, 4, 64])), AH_ROWMAJOR=int(rng.choice([-1, -1, 0])))
+    with _tuning(AH_MASK_BITS=mask_bits, AH_DENSE_NARROW_MAX_COLS=narrow, AH_DENSE_NARROW_STREAM=int(rng.integers(0, 2)), **tail):
         forest = ds.build_forest(seeds, split_after=split_after, margin_mode=mode)
-    desc += f" mode={mode:#x} trees={len(seeds)} mask_bits={mask_bits} narrow={narrow}"
+    desc += f" mode={mode:#x} trees={len(seeds)} mask_bits={mask_bits} narrow={narrow} tail={tail} groups_run={forest.stats['tail_groups']}"
     assert forest.stats["screen_violations"] == 0
     T.check_forest_valid(forest, n, ids=ids)
     for t, seed in enumerate(seeds):
@@ -100,7 +104,8 @@ def one(rng, it):
     if rng.random() < 0.5:
         in_flight = int(rng.choice([0, 0, 1, 2]))
         try:
-            _roots, sstats, streamed = ds.build_forest_stream(seeds, split_after=split_after, margin_mode=mode, max_trees_in_flight=in_flight)
+            with _tuning(**tail):
+                _roots, sstats, streamed = ds.build_forest_stream(seeds, split_after=split_after, margin_mode=mode, max_trees_in_flight=in_flight)
         except BaseException as e:
             raise AssertionError(desc + f" stream in_flight={in_flight} sa={split_after}: {e!r}")
         assert [streamed.canonical(t) for t in range(len(seeds))] == [forest.canonical(t) for t in range(len(seeds))], desc + " stream"

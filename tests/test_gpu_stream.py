@@ -90,7 +90,8 @@ def test_stream_at_full_size_10m_x_768_100_trees():
     per_tree_counts = np.bincount(nodes["tree"], minlength=trees)
     forest.close()
     seen = {"splits": 0, "leaves": 0, "plane_sum": 0, "ids_weighted": 0, "pos": 0, "ids": 0, "last_level": -1, "desc_started": False,
-            "per_tree": np.zeros(trees, dtype=np.int64)}
+            "per_tree": np.zeros(trees, dtype=np.int64), "desc_of": np.zeros(trees, dtype=bool),
+            "level_of": np.full(trees, -1, dtype=np.int64), "last_desc_tree": -1}
 
     def sink(b):
         m = int(b.n_nodes)
@@ -101,13 +102,19 @@ def test_stream_at_full_size_10m_x_768_100_trees():
         seen["per_tree"] += np.bincount(nd["tree"], minlength=trees)
         payload = np.ctypeslib.as_array(b.payload, shape=(int(b.payload_len),))
         if b.kind == 2:
-            assert not seen["desc_started"] and int(b.level) >= seen["last_level"]
-            seen["last_level"] = int(b.level)
+            # a tree's split planes all arrive before its Descendants nodes (the tail of this build runs in groups of trees:
+            # a group's ids travel while the next group's last levels are computed), level by level for any one tree
+            assert not seen["desc_of"][nd["tree"]].any() and (int(b.level) >= seen["level_of"][nd["tree"]]).all()
+            seen["level_of"][nd["tree"]] = int(b.level)
+            seen["last_level"] = max(seen["last_level"], int(b.level))
             seen["splits"] += m
             recs = payload.reshape(m, int(b.normal_stride))[:, :vec_bytes + 4]
             seen["plane_sum"] += int(recs.view(np.uint32).sum(dtype=np.uint64))
         else:
             seen["desc_started"] = True
+            assert int(nd["tree"][0]) >= seen["last_desc_tree"] and (np.diff(nd["tree"].astype(np.int64)) >= 0).all()
+            seen["last_desc_tree"] = int(nd["tree"][-1])
+            seen["desc_of"][nd["tree"]] = True
             seen["leaves"] += m
             ids = payload.view(np.uint32)
             assert int(nd["count"].sum()) == ids.size and int(nd["count"].max()) <= dims
@@ -122,4 +129,5 @@ def test_stream_at_full_size_10m_x_768_100_trees():
     assert seen["plane_sum"] == want_plane_sum                                      # every split plane's vector + first header word
     assert (seen["per_tree"] == per_tree_counts).all() and len(set(int(r) for r in roots)) == trees
     assert stats["screen_violations"] == 0 and stats["host_blob_recycled"] == 0
+    assert stats["tail_groups"] == 4 and seen["desc_of"].all()  # (AH_BUILD_TAIL_GROUPS' default: level 13 on, group by group)
     ds.close()
