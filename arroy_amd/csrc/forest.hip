@@ -3014,13 +3014,47 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     uint32_t step = 0;  // levels launched so far: the parity of the double buffers (== depth until the tail runs in groups)
     auto t_prev_waited = std::chrono::steady_clock::now();
     bool prev_rows = false;     // the previous level ran row-major: node_of / side_bytes describe it, d_child links it
-    uint32_t pending_digest = 0;  // 1 + depth of the level whose node table is still to be digested (0 = none)
-    uint32_t pending_step = 0;    // ... the step it ran as
-    uint32_t pending_nodes = 0;
-    uint64_t pending_host_off = 0;
-    const uint8_t *pending_chunk_dev = nullptr;
-    int64_t pending_rec_off = -1;      // >= 0: its record indices are level_rec_full[off ...] (first level of a tree group)
-    bool pending_fork_parent = false;  // it is the level the groups were cut from: its children's list is kept whole
+    // Node tables that arrived on the side stream and are still to be digested, oldest first.  A table is digested under a
+    // level that runs long enough to cover it (~45 ns per node on four threads against ~0.15 ns per pair on the device): the
+    // table of the last big level — 819 000 nodes, 35 ms — used to be digested under the 9 ms remnant level after it, and
+    // the loop, the hand-over of the ids and the next group of trees waited for it.  The tables live in a ring over the two
+    // pinned table buffers; a table that finds no room there forces the oldest digests first.
+    struct PendingTable {
+        uint32_t depth, step, n_nodes;
+        size_t ring_off;
+        uint64_t host_off;
+        const uint8_t *chunk_dev;
+        int64_t rec_off;      // >= 0: its record indices are level_rec_full[off ...] (first level of a tree group)
+        bool fork_parent;     // it is the level the groups were cut from: its children's list is kept whole
+        int group_done;       // >= 0: the last level of that tree group — its node list (its leaves' job) can follow
+    };
+    std::deque<PendingTable> tables;
+    uint8_t *const ring_base = reinterpret_cast<uint8_t *>(h_nodes[0]);
+    const size_t ring_cap = 2 * pin_nodes;
+    size_t ring_head = 0;
+    auto ring_alloc = [&](size_t bytes, size_t *off) -> bool {  // FIFO ring; head == tail only when nothing is live
+        if (tables.empty()) ring_head = 0;
+        const size_t tail = tables.empty() ? 0 : tables.front().ring_off;
+        if (tables.empty() || ring_head > tail) {
+            if (ring_head + bytes <= ring_cap) {
+                *off = ring_head;
+                ring_head += bytes;
+                return true;
+            }
+            if (!tables.empty() && bytes < tail) {
+                *off = 0;
+                ring_head = bytes;
+                return true;
+            }
+            return false;
+        }
+        if (ring_head + bytes < tail) {
+            *off = ring_head;
+            ring_head += bytes;
+            return true;
+        }
+        return false;
+    };
     int lvl_status = AH_OK;
 
     // ---- the tail in groups of trees (AH_BUILD_TAIL_GROUPS) ----------------------------------------------------------
@@ -3043,18 +3077,29 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     int pending_hand = -1;                   // group whose item ids are final and still to be handed to the read-back worker
     FNode *group_spare = nullptr;            // third node table of the grouped tail
     std::function<int(uint32_t, uint32_t)> hand_over_ids;  // (defined below, once the leaves' merge exists)
-    auto digest_pending = [&]() -> int {
-        if (!pending_digest) return AH_OK;
-        AH_HIP(hipEventSynchronize(bc.ev_copy[pending_step & 1]));
-        const uint32_t *rec_of = pending_rec_off >= 0 ? level_rec_full.data() + pending_rec_off : level_rec.data();
-        AH_TRY(digest_level(pending_digest - 1, pending_nodes, h_nodes[pending_step & 1], pending_host_off, pending_chunk_dev, rec_of));
-        if (pending_fork_parent) {
-            level_rec_full.swap(level_rec);
-            pending_fork_parent = false;
-        }
-        pending_digest = 0;
+    std::function<int(uint32_t, uint32_t)> group_complete;  // node list / leaves' job of a finished group (defined below)
+    auto digest_front = [&]() -> int {
+        const PendingTable e = tables.front();
+        // (copies on the side stream complete in order: the event of this parity was recorded by this table's copy or a later one)
+        AH_HIP(hipEventSynchronize(bc.ev_copy[e.step & 1]));
+        const uint32_t *rec_of = e.rec_off >= 0 ? level_rec_full.data() + e.rec_off : level_rec.data();
+        AH_TRY(digest_level(e.depth, e.n_nodes, reinterpret_cast<const FNode *>(ring_base + e.ring_off), e.host_off, e.chunk_dev, rec_of));
+        if (e.fork_parent) level_rec_full.swap(level_rec);
+        tables.pop_front();
+        if (e.group_done >= 0) AH_TRY(group_complete(group_tree[e.group_done], group_tree[e.group_done + 1]));
         return AH_OK;
     };
+    // the tables a level of `pairs` margin evaluations covers (all of them: pairs = ~0)
+    auto digest_under = [&](uint64_t pairs) -> int {
+        double budget = (double)pairs / 450.0;  // nodes: 45 ns each against 0.15 ns per pair, half of the level at most
+        // (a table of a few thousand nodes is a fraction of a millisecond: always — progress reports stay level by level)
+        while (!tables.empty() && ((double)tables.front().n_nodes <= budget || tables.front().n_nodes < 16384u)) {
+            budget -= (double)tables.front().n_nodes;
+            AH_TRY(digest_front());
+        }
+        return AH_OK;
+    };
+    auto digest_pending = [&]() -> int { return digest_under(~0ull); };
     // Streaming build: the Descendants nodes of trees [tA, tB), ascending in (tree, position) — i.e. in the order their ids lie
     // in the final permutation — as one job.  Every level's list is already in that order; the levels of one tree are merged
     // per tree (a few threads: 1.7 M leaves at 10M x 100 trees).
@@ -3112,15 +3157,15 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         return AH_OK;
     };
     // The item ids of trees [tA, tB) are final (every kernel that writes them has been waited for): rows -> item ids where the
-    // two differ (on the side stream: the main one is busy with the next group), then to the worker — the blob's slice of a
-    // materialised forest, the leaves' job of a streaming build.
+    // two differ (on the side stream: the main one is busy with the next group), then — the blob's slice of a materialised
+    // forest — to the worker.  (A streaming build hands them over as the leaves' job, once the group's tables are digested.)
     hand_over_ids = [&](uint32_t tA, uint32_t tB) -> int {
         const uint64_t a = tree_base[tA], b = tree_base[tB];
         if (b > a && !ds->identity_ids) {
             hipLaunchKernelGGL(k_rows_to_ids, dim3(2048), dim3(256), 0, bc.side, final_perm.p + a, b - a, ds->d_ids);
             AH_HIP(hipStreamSynchronize(bc.side));
         }
-        if (sb) return push_leaves_job(tA, tB);
+        if (sb) return AH_OK;
         prefault.join();
         rb.push(forest->descendants + desc_base + a, final_perm.p + a, (b - a) * 4);
         return AH_OK;
@@ -3194,6 +3239,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         emit_tree = tB;
         return AH_OK;
     };
+    group_complete = [&](uint32_t tA, uint32_t tB) -> int { return sb ? push_leaves_job(tA, tB) : emit_range(tA, tB); };
     auto run_levels = [&]() -> int {
     while (info.n_nodes) {
         if (opt->cancel && *opt->cancel) {
@@ -3688,18 +3734,17 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         // while the level runs: room for the records of the two digests to come (the level before this one, now; this one,
         // under the next level), then digest the node table of the level before it
         {
-            const size_t want = n_recs + 2 * (size_t)pending_nodes + 2 * (size_t)n_nodes;
+            size_t want = n_recs + 2 * (size_t)n_nodes;
+            for (const PendingTable &e : tables) want += 2 * (size_t)e.n_nodes;
             if (recs.size() < want) recs.resize(want);
         }
         const auto t_launched = std::chrono::steady_clock::now();
-        AH_TRY(digest_pending());
-        // the group before this one is complete (its last level was waited for, its last table is digested): its ids travel
-        // under this group's kernels
+        // the group before this one is complete (its last level was waited for): its ids travel under this group's kernels
         if (pending_hand >= 0) {
             AH_TRY(hand_over_ids(group_tree[pending_hand], group_tree[pending_hand + 1]));
-            AH_TRY(emit_range(group_tree[pending_hand], group_tree[pending_hand + 1]));
             pending_hand = -1;
         }
+        AH_TRY(digest_under(info.pairs));
         const auto t_digested = std::chrono::steady_clock::now();
         lvl_status = wait_level();
         if (lvl_status != AH_OK) return lvl_status;
@@ -3725,17 +3770,16 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         }
         forest->stats.margin_launches += 4;
         // this level's node table follows on the side stream (the level is complete: no stream dependency needed)
-        AH_HIP(hipMemcpyAsync(h_nodes[step & 1], d_cur, n_nodes * sizeof(FNode), hipMemcpyDeviceToHost, bc.side));
+        size_t table_off = 0;
+        const size_t table_bytes = ((size_t)n_nodes * sizeof(FNode) + 4095) & ~(size_t)4095;
+        while (!ring_alloc(table_bytes, &table_off)) AH_TRY(digest_front());  // (no room: the oldest tables first)
+        AH_HIP(hipMemcpyAsync(ring_base + table_off, d_cur, n_nodes * sizeof(FNode), hipMemcpyDeviceToHost, bc.side));
         AH_HIP(hipEventRecord(bc.ev_copy[step & 1], bc.side));
         // (a millisecond at most — and it must not queue behind the gigabytes of normals the worker is about to request: the
         // digest of this table runs under the NEXT level, which at the bottom of the forest is a short one)
         if (n_nodes >= 65536) AH_HIP(hipEventSynchronize(bc.ev_copy[step & 1]));
-        pending_digest = depth + 1;
-        pending_step = step;
-        pending_rec_off = group_first_level ? (int64_t)group_n0 : -1;
-        pending_nodes = n_nodes;
-        pending_host_off = chunk_host_off;
-        pending_chunk_dev = chunk_d;
+        tables.push_back(PendingTable{depth, step, n_nodes, table_off, chunk_host_off, chunk_d,
+                                      group_first_level ? (int64_t)group_n0 : -1, false, -1});
         // this level's normals are final: the worker copies them while the next level runs
         touch_normals[step & 1].join();  // never touch a page the worker may already have filled
         if (!sb) rb.push(forest->normals + chunk_host_off, chunk_d, chunk_bytes);  // (streaming: pushed by the level's digest)
@@ -3784,7 +3828,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_HIP(hipMemcpyAsync(gi, d_groups.p, K * sizeof(GroupInfo), hipMemcpyDeviceToHost, s));
         AH_HIP(hipStreamSynchronize(s));
         // the records of the level's nodes: the children's list of the level before it, digested under the first group
-        if (pending_digest) pending_fork_parent = true;
+        if (!tables.empty()) tables.back().fork_parent = true;
         else level_rec_full.swap(level_rec);
         FNode *const table = d_cur, *const other = d_next;
         uint32_t *const cur_f = cur, *const nxt_f = nxt;
@@ -3812,7 +3856,10 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             group_n0 = n0;
             AH_TRY(run_levels());
             if (sb && (sb->target.sink_rc.load() || sb->target.too_big.load())) break;  // reported after the loop
-            pending_hand = (int)g;  // handed over under the next group's first level (the last group's: after the loop)
+            // its ids: handed over under the next group's first level (the last group's: after the loop); its node list (the
+            // leaves' job of a streaming build): when its last table has been digested
+            pending_hand = (int)g;
+            if (!tables.empty()) tables.back().group_done = (int)g;
         }
         return AH_OK;
     };
@@ -3847,18 +3894,14 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         forest->stats.screen8_decided += sc.stage8_decided;
         forest->stats.screen8b_decided += sc.stage8b_decided;
         if (!sb && !fork_now) rb.push(forest->descendants + desc_base, final_perm.p, M * 4);  // lands while the host emits the node list
-        if (!sb && fork_now && pending_hand >= 0) {  // (the last group's)
+        if (fork_now && pending_hand >= 0) {  // (the last group's)
             AH_TRY(hand_over_ids(group_tree[pending_hand], group_tree[pending_hand + 1]));
             pending_hand = -1;
         }
     }
     // the last level's node table is digested only now: the 4 GB of item ids are already on their way
     AH_TRY(digest_pending());
-    if (sb) {
-        if (!fork_now) AH_TRY(push_leaves_job(0, n_trees));
-        else if (pending_hand >= 0) AH_TRY(hand_over_ids(group_tree[pending_hand], group_tree[pending_hand + 1]));
-        pending_hand = -1;
-    }
+    if (sb && !fork_now) AH_TRY(push_leaves_job(0, n_trees));  // (in groups: every group's job followed its last table)
     const auto t_levels = std::chrono::steady_clock::now();
     float ms = 0.0f;
     AH_HIP(hipEventElapsedTime(&ms, bc.ev_begin, bc.ev_end));

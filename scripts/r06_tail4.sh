@@ -1,7 +1,7 @@
 #!/bin/bash
 OUT=gpurun_out/r06t; mkdir -p $OUT
 timeout 900 python -m pytest tests/test_gpu_tail_groups.py tests/test_gpu_stream.py -x -q -m gpu > $OUT/tests4.log 2>&1; echo "tests rc=$?"; tail -3 $OUT/tests4.log
-for CFG in "4 100" "4 76" "5 76" "4 60" "5 85" "4 76"; do
+for CFG in "4 100" "4 76" "5 76" "5 100" "6 100" "6 85"; do
   set -- $CFG
   echo "== groups $1 ratio $2"
   AH_BUILD_TAIL_GROUPS=$1 AH_BUILD_TAIL_RATIO=$2 AH_TIMING=1 timeout 300 python scripts/exp_build.py 10000000 100 4 2>&1 | python -c "

@@ -129,5 +129,5 @@ def test_stream_at_full_size_10m_x_768_100_trees():
     assert seen["plane_sum"] == want_plane_sum                                      # every split plane's vector + first header word
     assert (seen["per_tree"] == per_tree_counts).all() and len(set(int(r) for r in roots)) == trees
     assert stats["screen_violations"] == 0 and stats["host_blob_recycled"] == 0
-    assert stats["tail_groups"] == 4 and seen["desc_of"].all()  # (AH_BUILD_TAIL_GROUPS' default: level 13 on, group by group)
+    assert stats["tail_groups"] == 5 and seen["desc_of"].all()  # (AH_BUILD_TAIL_GROUPS' default: level 13 on, group by group)
     ds.close()
