@@ -1780,8 +1780,9 @@ static HostBlobPool &host_pool() {
     static HostBlobPool *pool = new HostBlobPool();  // never destroyed: forests may outlive static destruction order
     return *pool;
 }
+static size_t records_pool_trim();  // (the node records of the last build, below)
 namespace ah {
-size_t host_cache_trim() { return host_pool().trim(); }
+size_t host_cache_trim() { return host_pool().trim() + records_pool_trim(); }
 }  // namespace ah
 // grow `blob` to at least `need` bytes keeping its first `keep` bytes; the old mapping goes back to the pool
 static bool host_blob_reserve(HostBlob &blob, size_t need, size_t keep) {
@@ -1822,6 +1823,38 @@ struct HostRec {  // one tree node, in creation (breadth-first) order
     uint32_t depth;
     uint64_t normal_off = 0;  // byte offset of the normal record inside the forest's normals buffer
 };
+// The records of a build and their index vector, kept for the next build of the process like the forests' blobs (and under
+// the same switch, AH_HOST_CACHE_MB; ah_host_cache_trim frees them): 136 MB + 14 MB at 10M x 100 trees, whose fresh pages
+// used to be faulted in under the levels by the launching thread and unmapped — 11 ms — between the last copy and the return.
+struct RecordsPool {
+    std::mutex mu;
+    std::vector<HostRec> recs;
+    std::vector<uint32_t> index;
+};
+static RecordsPool &records_pool() {
+    static RecordsPool *pool = new RecordsPool();  // never destroyed (see host_pool)
+    return *pool;
+}
+struct RecordsLease {  // takes the pooled vectors for one batch and gives the larger ones back
+    std::vector<HostRec> &recs;
+    std::vector<uint32_t> &index;
+    RecordsLease(std::vector<HostRec> &r, std::vector<uint32_t> &i) : recs(r), index(i) {
+        if (tun(TUN_HOST_CACHE_MB) <= 0) return;
+        RecordsPool &pool = records_pool();
+        std::lock_guard<std::mutex> lk(pool.mu);
+        recs.swap(pool.recs);
+        index.swap(pool.index);
+        recs.clear();
+        index.clear();
+    }
+    ~RecordsLease() {
+        if (tun(TUN_HOST_CACHE_MB) <= 0) return;
+        RecordsPool &pool = records_pool();
+        std::lock_guard<std::mutex> lk(pool.mu);
+        if (recs.capacity() > pool.recs.capacity()) recs.swap(pool.recs);
+        if (index.capacity() > pool.index.capacity()) index.swap(pool.index);
+    }
+};
 
 template <typename T>
 struct DevBuf {
@@ -1837,9 +1870,12 @@ struct DevBuf {
         cap = want;
         return AH_OK;
     }
-    ~DevBuf() {
+    void release() {
         if (p) (void)dev_free(p);
+        p = nullptr;
+        cap = 0;
     }
+    ~DevBuf() { release(); }
 };
 
 // Device memory for the normal records of all levels of a batch: a few big blocks handed out level by level (a level's
@@ -1961,6 +1997,17 @@ inline int mm_rows(uint32_t tc) { return tc >= 16 ? MM_ROWS16 : tc == 8 ? MM_ROW
 // costs the L1 three 64-byte accesses instead of two — measured with TCP_TOTAL_CACHE_ACCESSES, that was 6.1e9 accesses
 // per 16-tree pass against 4.1e9 useful, in a pass that runs at ~80 % of the L1's access rate.  Callers see the stride
 // in ah_forest_view.normal_stride.
+static size_t records_pool_trim() {
+    RecordsPool &pool = records_pool();
+    std::vector<HostRec> r;
+    std::vector<uint32_t> i;
+    {
+        std::lock_guard<std::mutex> lk(pool.mu);
+        r.swap(pool.recs);
+        i.swap(pool.index);
+    }
+    return r.capacity() * sizeof(HostRec) + i.capacity() * sizeof(uint32_t);
+}
 static uint64_t normal_record_stride(const ah_dataset *ds) {
     const uint64_t raw = ds->row_bytes() + 16;
     return metric_is_bq(ds->metric) ? raw : (raw + 127) & ~(uint64_t)127;
@@ -2764,10 +2811,15 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
 
     // ---- level 0 on the host: the roots -----------------------------------------------------------------------------
     std::vector<HostRec> recs;
+    std::vector<uint32_t> new_index;  // (emit_range's: record -> forest-local node index)
+    RecordsLease records_lease(recs, new_index);
     std::vector<uint32_t> tree_root(n_trees);
     std::vector<uint64_t> tree_count(n_trees, 1);  // nodes of every tree so far: its root, then two per digested split
     std::vector<uint32_t> level_rec, next_rec;  // HostRec index of every node of the level being digested / of the next
-    recs.reserve(4 * max_nodes / 3 + 16);
+    // (room for every node of a balanced forest — leaves of split_after / 2 .. split_after items, as many split nodes — so that
+    // the vector never moves: at 10M x 100 trees the 1.7 M + 1.7 M records outgrew the former 4 / 3 x max_nodes at the last big
+    // level, and copying 136 MB of records held the launching thread for 38 ms with the device idle; untouched pages cost nothing)
+    recs.reserve(4 * max_nodes + n_trees + 16);
     size_t n_recs = 0;  // records in use; the vector itself is grown AHEAD of the digest (value-initialising 80 MB of fresh
                         // pages on the thread that digests the deepest level was most of that digest's 35 ms)
     LevelInfo info{};
@@ -3078,6 +3130,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     FNode *group_spare = nullptr;            // third node table of the grouped tail
     std::function<int(uint32_t, uint32_t)> hand_over_ids;  // (defined below, once the leaves' merge exists)
     std::function<int(uint32_t, uint32_t)> group_complete;  // node list / leaves' job of a finished group (defined below)
+    std::deque<int> done_groups;  // groups whose tables are all digested and whose node list is still to be emitted
     auto digest_front = [&]() -> int {
         const PendingTable e = tables.front();
         // (copies on the side stream complete in order: the event of this parity was recorded by this table's copy or a later one)
@@ -3086,16 +3139,31 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         AH_TRY(digest_level(e.depth, e.n_nodes, reinterpret_cast<const FNode *>(ring_base + e.ring_off), e.host_off, e.chunk_dev, rec_of));
         if (e.fork_parent) level_rec_full.swap(level_rec);
         tables.pop_front();
-        if (e.group_done >= 0) AH_TRY(group_complete(group_tree[e.group_done], group_tree[e.group_done + 1]));
+        if (e.group_done >= 0) {
+            // a streaming build's leaves' job starts the transfer of the group's ids: at once; a node list only costs host time
+            if (sb) AH_TRY(group_complete(group_tree[e.group_done], group_tree[e.group_done + 1]));
+            else done_groups.push_back(e.group_done);
+        }
         return AH_OK;
     };
     // the tables a level of `pairs` margin evaluations covers (all of them: pairs = ~0)
     auto digest_under = [&](uint64_t pairs) -> int {
-        double budget = (double)pairs / 450.0;  // nodes: 45 ns each against 0.15 ns per pair, half of the level at most
+        // host nanoseconds the level covers: 0.14 ns per pair on the device, three quarters of it at most; a table costs ~45 ns
+        // per node (four threads), a node list ~10 ns per node (eight) — both next to the read-back worker's copy threads
+        double budget = (double)pairs * 0.105;
         // (a table of a few thousand nodes is a fraction of a millisecond: always — progress reports stay level by level)
-        while (!tables.empty() && ((double)tables.front().n_nodes <= budget || tables.front().n_nodes < 16384u)) {
-            budget -= (double)tables.front().n_nodes;
+        while (!tables.empty() && (45.0 * tables.front().n_nodes <= budget || tables.front().n_nodes < 16384u)) {
+            budget -= 45.0 * tables.front().n_nodes;
             AH_TRY(digest_front());
+        }
+        while (!done_groups.empty()) {
+            const uint32_t tA = group_tree[done_groups.front()], tB = group_tree[done_groups.front() + 1];
+            double nodes = 0.0;
+            for (uint32_t t = tA; t < tB; t++) nodes += (double)tree_count[t];
+            if (10.0 * nodes > budget) break;
+            budget -= 10.0 * nodes;
+            done_groups.pop_front();
+            AH_TRY(group_complete(tA, tB));
         }
         return AH_OK;
     };
@@ -3177,7 +3245,6 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     const size_t node_base = forest->nodes.size(), roots_base = forest->roots.size();
     size_t emit_cursor = node_base;  // forest->nodes index of the next tree to be emitted
     uint32_t emit_tree = 0;          // trees [0, emit_tree) are emitted
-    std::vector<uint32_t> new_index;
     std::atomic<uint64_t> n_split{0}, n_desc{0};
     auto emit_range = [&](uint32_t tA, uint32_t tB) -> int {
         if (sb || tB <= tA) return AH_OK;
@@ -4058,9 +4125,15 @@ static int build_forest_impl(ah_dataset *ds, const ah_build_options *options, co
             }
             if (options->max_trees_in_flight) batch = std::min(batch, options->max_trees_in_flight);
             try {
-                for (uint32_t first = 0; first < options->n_trees && st == AH_OK; first += batch)
+                for (uint32_t first = 0; first < options->n_trees && st == AH_OK; first += batch) {
+                    const auto tb = std::chrono::steady_clock::now();
                     st = build_batch(ds, options, first, std::min(batch, options->n_trees - first), split_after, forest,
                                      lease.c, subset_ids, subset_offsets, sb);
+                    if (tun(TUN_TIMING))
+                        fprintf(stderr, "[ah] build: %.1f ms before the batch, the batch and the teardown of its buffers %.1f ms\n",
+                                std::chrono::duration<double, std::milli>(tb - t0).count(),
+                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count());
+                }
             } catch (const std::bad_alloc &) {
                 set_error("host allocation failed during the forest build");
                 st = AH_ERR_OUT_OF_MEMORY;

@@ -158,6 +158,21 @@ def test_forest_builds_survive_every_allocation_failure(world):
     assert OOM in seen, seen
     _roots, _stats, streamed = ds.build_forest_stream(seeds)
     assert [streamed.canonical(t) for t in range(TREES)] == ref
+    # the same with the tail of the build in groups of trees (its third node table and the groups' read-back are allocations
+    # of their own, made in the middle of the level loop)
+    with _lib.tuning(AH_BUILD_TAIL_GROUPS=3, AH_BUILD_TAIL_MIN_MB=0, AH_ROWMAJOR=0):
+        f = ds.build_forest(seeds)
+        assert f.stats["tail_groups"] == 3 and f.digest()[0] == want
+        f.close()
+        seen = sweep(lambda: ds.build_forest(seeds), cleanup=lambda f: f.close())
+        assert OOM in seen, seen
+        f = ds.build_forest(seeds)
+        assert f.digest()[0] == want
+        f.close()
+        seen = sweep(lambda: ds.build_forest_stream(seeds))
+        assert OOM in seen, seen
+        _roots, stats, streamed = ds.build_forest_stream(seeds)
+        assert stats["tail_groups"] == 3 and [streamed.canonical(t) for t in range(TREES)] == ref
 
 
 def test_dataset_staging_survives_every_allocation_failure(world):
