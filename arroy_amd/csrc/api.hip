@@ -98,14 +98,86 @@ int Context::ensure_device(size_t bytes) {
     d_cap = cap;
     return AH_OK;
 }
+// One pinned block obtained ahead of time (ah_dataset_reserve_build's helper thread, while the records are staged): pinning the
+// ~0.4 GB a 10M x 100-tree build wants for its node tables and read-back buffer takes the driver ~120 ms, which a cold first
+// build used to spend between its entry and its first launch.  The next context of that device that has to grow takes it.
+namespace {
+struct PinnedSpare {
+    std::mutex mu;
+    void *p = nullptr;
+    size_t cap = 0;
+    int device = -1;
+};
+PinnedSpare &pinned_spare() {
+    static PinnedSpare *s = new PinnedSpare();  // never destroyed (contexts may outlive static destruction order)
+    return *s;
+}
+}  // namespace
+void pinned_spare_fill(int device, size_t bytes) {
+    PinnedSpare &sp = pinned_spare();
+    const size_t cap = (bytes + bytes / 4 + 4095) & ~(size_t)4095;
+    {
+        std::lock_guard<std::mutex> lk(sp.mu);
+        if (sp.p && sp.device == device && sp.cap >= cap) return;
+    }
+    void *p = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();  // no pinned memory to be had now: the build asks for itself
+        return;
+    }
+    void *old = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(sp.mu);
+        old = sp.p;
+        sp.p = p;
+        sp.cap = cap;
+        sp.device = device;
+    }
+    if (old) (void)hipHostFree(old);
+}
+size_t pinned_spare_trim() {
+    PinnedSpare &sp = pinned_spare();
+    void *p = nullptr;
+    size_t cap = 0;
+    {
+        std::lock_guard<std::mutex> lk(sp.mu);
+        p = sp.p;
+        cap = sp.cap;
+        sp.p = nullptr;
+        sp.cap = 0;
+        sp.device = -1;
+    }
+    if (p) (void)hipHostFree(p);
+    return p ? cap : 0;
+}
 int Context::ensure_pinned(size_t bytes) {
     if (bytes <= h_cap) return AH_OK;
     size_t cap = std::max(bytes + bytes / 4, h_cap * 2);
     cap = (cap + 4095) & ~(size_t)4095;
+    AH_REQUIRE(!fail_alloc_tick(), AH_ERR_OUT_OF_MEMORY, "pinned host allocation of %zu bytes failed (AH_FAIL_ALLOC_AFTER)", cap);
+    void *spare = nullptr;
+    size_t spare_cap = 0;
+    {
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        PinnedSpare &sp = pinned_spare();
+        std::lock_guard<std::mutex> lk(sp.mu);
+        if (sp.p && sp.device == dev && sp.cap >= bytes) {
+            spare = sp.p;
+            spare_cap = sp.cap;
+            sp.p = nullptr;
+            sp.cap = 0;
+            sp.device = -1;
+        }
+    }
     if (h_pinned) AH_HIP(hipHostFree(h_pinned));
     h_pinned = nullptr;
     h_cap = 0;
-    AH_REQUIRE(!fail_alloc_tick(), AH_ERR_OUT_OF_MEMORY, "pinned host allocation of %zu bytes failed (AH_FAIL_ALLOC_AFTER)", cap);
+    if (spare) {
+        h_pinned = spare;
+        h_cap = spare_cap;
+        return AH_OK;
+    }
     AH_HIP(hipHostMalloc(&h_pinned, cap, hipHostMallocDefault));
     h_cap = cap;
     return AH_OK;

@@ -226,6 +226,8 @@ inline hipError_t dev_malloc(T **p, size_t bytes, bool optional = false) {
 void dataset_born(int device);
 void dataset_gone(int device);
 size_t host_cache_trim();                    // forest.hip: the pool of destroyed forests' blobs; returns the bytes released
+void pinned_spare_fill(int device, size_t bytes);  // api.hip: a pinned block obtained ahead of the context that will want it
+size_t pinned_spare_trim();                  // ... given back if nobody took it; returns its bytes
 size_t dev_cache_live_bytes(int device);     // bytes handed out and not yet freed (ah_device_cache_stats)
 // test aid (AH_FAIL_ALLOC_AFTER): true when THIS allocation is the one that must fail
 bool fail_alloc_tick();

@@ -1782,7 +1782,7 @@ static HostBlobPool &host_pool() {
 }
 static size_t records_pool_trim();  // (the node records of the last build, below)
 namespace ah {
-size_t host_cache_trim() { return host_pool().trim() + records_pool_trim(); }
+size_t host_cache_trim() { return host_pool().trim() + records_pool_trim() + pinned_spare_trim(); }
 }  // namespace ah
 // grow `blob` to at least `need` bytes keeping its first `keep` bytes; the old mapping goes back to the pool
 static bool host_blob_reserve(HostBlob &blob, size_t need, size_t keep) {
@@ -4214,12 +4214,24 @@ int ah_dataset_reserve_build(ah_dataset *ds, uint32_t n_trees, uint32_t split_af
                 sizes.push_back((size_t)std::max<uint64_t>(16ull << 20, std::min<uint64_t>(max_nodes * stride8, 4ull << 30)));
         }
     }
+    // ... and the pinned host memory of that batch (node tables, level info, the read-back worker's double buffer)
+    size_t pinned_bytes = 0;
+    {
+        const uint64_t M = (uint64_t)n_trees * N;
+        const uint64_t max_nodes = M / ((uint64_t)split_after + 1) + n_trees;
+        const size_t info_words = (sizeof(LevelInfo) + ((size_t)n_trees + 1) * 4 + 3) / 4;
+        const size_t pin_info = (info_words * 4 + 255) & ~(size_t)255;
+        const size_t pin_nodes = (max_nodes * sizeof(FNode) + 4095) & ~(size_t)4095;
+        const size_t pin_head = (3 * pin_info + 256 + 4095) & ~(size_t)4095;
+        pinned_bytes = pin_head + 2 * pin_nodes + ((size_t)std::min<long long>(4096, std::max<long long>(2, tun(TUN_READBACK_MB))) << 20);
+    }
     const int device = ds->device;
     double *const took = &ds->reserve_seconds;  // (the handle outlives the helper: every build and the destroy join it)
     try {
-        std::thread helper([device, sizes, took] {
+        std::thread helper([device, sizes, took, pinned_bytes] {
             const auto th = std::chrono::steady_clock::now();
             if (hipSetDevice(device) != hipSuccess) return;
+            pinned_spare_fill(device, pinned_bytes);
             std::vector<void *> got;
             for (size_t b : sizes) {
                 void *p = nullptr;

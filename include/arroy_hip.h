@@ -278,7 +278,10 @@ typedef struct ah_build_options {
                                       src/writer.rs:1178,1196): non-zero -> launches that have not started yet drain
                                       without work, the call returns AH_ERR_CANCELLED when the level's stream is idle
                                       (at most one level: <= 0.25 s at 10M x 768 x 100 trees) */
-    ah_progress_fn progress;       /* may be NULL (src/writer.rs:53-69 SubStep)                      */
+    ah_progress_fn progress;       /* may be NULL (src/writer.rs:53-69 SubStep).  Called once per digested level with
+                                      `level` = depth + 1: ascending, except at the bottom of a build whose last levels
+                                      run group of trees by group of trees (AH_BUILD_TAIL_GROUPS), where every group
+                                      reports its own last levels; nodes_done / items_routed never decrease */
     void *progress_user;
     uint32_t max_trees_in_flight;  /* 0 = as many as HBM allows                                      */
     uint32_t margin_mode;          /* ah_margin_mode; 0 = AH_MARGIN_AUTO                             */

@@ -23,10 +23,17 @@ python bench.py --steps 50 --warmup 5 2>$OUT/${R}_bench.err | tail -1 > $OUT/${R
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python bench.py --steps 50 --warmup 5 --no-cpu --no-build-10m --no-live-pmc > $OUT/kt.log 2>&1
 cp $OUT/kt/kt_kernel_stats.csv $OUT/${R}_kernel_stats.csv
 rm -rf $OUT/kt
-AH_TIMING=2 python scripts/exp_build.py 10000000 100 2 2>&1 | tail -19 > $OUT/${R}_levels_timing_100trees.txt
-AH_TIMING=2 python scripts/exp_build.py 10000000 13 2 2>&1 | tail -19 > $OUT/${R}_levels_timing_13trees.txt
+# (the second build of each: 15 levels, the last two group of trees by group of trees — AH_BUILD_TAIL_GROUPS — i.e. 13 + 2 x 5 level lines)
+AH_TIMING=2 python scripts/exp_build.py 10000000 100 2 2>&1 | tail -28 > $OUT/${R}_levels_timing_100trees.txt
+AH_TIMING=2 python scripts/exp_build.py 10000000 13 2 2>&1 | tail -28 > $OUT/${R}_levels_timing_13trees.txt
+AH_BUILD_TAIL_GROUPS=0 AH_TIMING=2 python scripts/exp_build.py 10000000 100 2 2>&1 | tail -19 > $OUT/${R}_levels_timing_100trees_level_by_level.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_b -o kt -- python scripts/exp_build.py 10000000 100 > $OUT/${R}_build10m_screened.log 2>&1
-python scripts/level_trace.py $OUT/kt_b/kt_kernel_trace.csv > $OUT/${R}_forest_levels_screened.txt 2>&1
+{
+  echo "# kernel time per level of the 10M x 768 x 100-tree build (rocprofv3 --kernel-trace, scripts/level_trace.py).  The script numbers the"
+  echo "# levels by counting k_next_scan launches: L13 and L14 run group of trees by group of trees (AH_BUILD_TAIL_GROUPS = 5), so the lines"
+  echo "# L13 .. L22 are level 13 and level 14 of groups 0 .. 4 (30 / 23 / 19 / 15 / 13 trees) in turn."
+  python scripts/level_trace.py $OUT/kt_b/kt_kernel_trace.csv
+} > $OUT/${R}_forest_levels_screened.txt 2>&1
 cp $OUT/kt_b/kt_kernel_stats.csv $OUT/${R}_build10m_screened_kernel_stats.csv
 rm -rf $OUT/kt_b
 {
