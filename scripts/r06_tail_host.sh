@@ -1,6 +1,6 @@
 #!/bin/bash
 OUT=gpurun_out/r06t; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_tail_groups.py tests/test_gpu_stream.py tests/test_gpu_faults.py -x -q -m gpu > $OUT/tests6.log 2>&1; echo "tests rc=$?"; tail -3 $OUT/tests6.log
+timeout 900 python -m pytest tests/test_gpu_tail_groups.py tests/test_gpu_stream.py tests/test_gpu_faults.py -x -q -m gpu > $OUT/tests_host.log 2>&1; echo "tests rc=$?"; tail -3 $OUT/tests_host.log
 AH_TIMING=3 timeout 300 python scripts/exp_build.py 10000000 100 4 > $OUT/exp6.log 2>&1
 grep "^{" $OUT/exp6.log | python -c "
 import sys, json

@@ -1,6 +1,6 @@
 #!/bin/bash
 OUT=gpurun_out/r06t; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_tail_groups.py tests/test_gpu_stream.py -x -q -m gpu > $OUT/tests4.log 2>&1; echo "tests rc=$?"; tail -3 $OUT/tests4.log
+timeout 900 python -m pytest tests/test_gpu_tail_groups.py tests/test_gpu_stream.py -x -q -m gpu > $OUT/tests_sweep.log 2>&1; echo "tests rc=$?"; tail -3 $OUT/tests_sweep.log
 for CFG in "4 100" "4 76" "5 76" "5 100" "6 100" "6 85"; do
   set -- $CFG
   echo "== groups $1 ratio $2"
