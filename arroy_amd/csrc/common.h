@@ -133,6 +133,7 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(MARGIN_MODE, "AH_MARGIN_MODE", 0)         /* ah_margin_mode for callers that pass AH_MARGIN_AUTO */                 \
     X(READBACK_DIRECT, "AH_READBACK_DIRECT", 0) /* 1: let the runtime stage the device -> pageable copies */             \
     X(READBACK_MB, "AH_READBACK_MB", 256)       /* pinned double buffer of a build's read-back worker, MiB (both halves) */ \
+    X(RETRY_GATE, "AH_RETRY_GATE", 1)           /* 0: the retry attempts of a level run over every node and tile even when the attempt before left none pending (rounds 1-6a) */ \
     X(TAIL_GROUPS, "AH_BUILD_TAIL_GROUPS", 5)   /* the last big level of a build and what follows it run tree group by tree group, each group's item ids and normals travelling under the next group's kernels (0 / 1: all trees level by level to the end) */ \
     X(TAIL_MIN_MB, "AH_BUILD_TAIL_MIN_MB", 64)  /* ... when the ids still under splitting nodes are at least this many MiB */ \
     X(TAIL_NODE_ITEMS, "AH_BUILD_TAIL_NODE_ITEMS", 2) /* ... from the first node-major level on whose nodes hold at most this many x split_after items on average (2: most children are Descendants nodes) */ \

@@ -42,10 +42,18 @@ enum { ST_PENDING = 0, ST_ACCEPTED = 1, ST_RANDOM = 2 };
 // write has landed cost nothing.  The read is an ordinary cached load on purpose — an uncached (system-scope) read of
 // one word by ~100 000 blocks per launch serialises on that address and was measured to cost 70 % of the build
 // (0.088 s -> 0.150 s at 1M x 768), so a kernel that is already running may keep seeing a stale line and finish.
+// `gate` (the retry attempts of a level, nullptr otherwise): the number of nodes the attempt before left pending.  On most
+// data a level's first attempt settles every node, and the three attempts that follow — five launches each, over every node
+// and tile of the level — found nothing to do at 0.9-2.3 ms per level of the 10M x 100-tree build: with the count at zero
+// their blocks leave at once.
 struct AbortFlags {
     const uint32_t *dev;
+    const uint32_t *gate;
 };
+// (read once, when a block starts: a second dependent load in front of every tile of the node-major kernels' loops cost the
+// retries of a build that HAS retries 75 ms — 10M clustered rows, 741 k re-drawn splits)
 __device__ __forceinline__ bool abort_requested(const AbortFlags f) { return __builtin_nontemporal_load(f.dev) != 0u; }
+__device__ __forceinline__ bool gate_closed(const uint32_t *gate) { return gate != nullptr && __builtin_nontemporal_load(gate) == 0u; }
 
 struct FNode {
     uint64_t key;      // ah_node_key_* of this node
@@ -99,10 +107,12 @@ __global__ void k_ids_to_rows(DataView dv, uint32_t *perm, uint64_t total, uint3
 template <int M>
 __global__ __launch_bounds__(64) void k_forest_create_split(DataView dv, FNode *nodes, uint32_t n_nodes,
                                                             const uint32_t *__restrict__ perm, uint64_t n_items,
-                                                            uint8_t *normals, uint64_t nstride, uint64_t hdr_off) {
+                                                            uint8_t *normals, uint64_t nstride, uint64_t hdr_off,
+                                                            const uint32_t *gate) {
     extern __shared__ float4 s_buf4[];
     float *s_buf = reinterpret_cast<float *>(s_buf4);
     __shared__ uint32_t s_rows[AH_SPLIT_SAMPLES];
+    if (gate_closed(gate)) return;
     const uint32_t fpitch = f32_space_pitch(dv.metric, dv.dims);
     for (uint32_t node = blockIdx.x; node < n_nodes; node += gridDim.x) {  // grid-stride: see node_grid in build_batch
         FNode &nd = nodes[node];
@@ -143,6 +153,7 @@ __global__ __launch_bounds__(kBlock) void k_forest_margin_f32(DataView dv, FNode
     __shared__ uint32_t s_left;
     const float *s_n = reinterpret_cast<const float *>(s_n4);
     const uint32_t o = threadIdx.x >> 3, j = threadIdx.x & 7u;
+    if (gate_closed(abort_flag.gate)) return;  // a retry attempt with no node left pending
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (abort_requested(abort_flag)) return;  // build cancelled: drain (block-uniform)
         const FTile tl = tiles[tile];
@@ -190,6 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_forest_margin_bq(DataView dv, FNode 
     extern __shared__ uint64_t s_nw[];
     __shared__ uint32_t s_left;
     __shared__ uint8_t s_side[kTile];
+    if (gate_closed(abort_flag.gate)) return;  // a retry attempt with no node left pending
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (abort_requested(abort_flag)) return;
         const FTile tl = tiles[tile];
@@ -506,25 +518,31 @@ __global__ __launch_bounds__(kBlock) void k_forest_masks_from_bytes(FNode *nodes
 }
 
 // split_imbalance (src/writer.rs:1348-1353, f64) and the accept / retry / random decision (:1209-1227).
-__global__ void k_forest_decide(FNode *nodes, uint32_t n_nodes) {
+__global__ void k_forest_decide(FNode *nodes, uint32_t n_nodes, uint32_t *pend_out, const uint32_t *gate) {
+    if (gate_closed(gate)) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    FNode &nd = nodes[i];
-    if (nd.state != ST_PENDING) return;
-    const double ls = (double)nd.n_left, rs = (double)(nd.count - nd.n_left);
-    const double f = ls / (ls + rs + 2.220446049250313e-16);
-    const double g = 1.0 - f;
-    const double imb = f > g ? f : g;
-    if (imb < 0.95 || nd.attempt == 3) {
-        if (imb > 0.99) {
-            nd.state = ST_RANDOM;
-            nd.n_left = 0;
+    bool again = false;
+    if (i < n_nodes && nodes[i].state == ST_PENDING) {
+        FNode &nd = nodes[i];
+        const double ls = (double)nd.n_left, rs = (double)(nd.count - nd.n_left);
+        const double f = ls / (ls + rs + 2.220446049250313e-16);
+        const double g = 1.0 - f;
+        const double imb = f > g ? f : g;
+        if (imb < 0.95 || nd.attempt == 3) {
+            if (imb > 0.99) {
+                nd.state = ST_RANDOM;
+                nd.n_left = 0;
+            } else {
+                nd.state = ST_ACCEPTED;
+            }
         } else {
-            nd.state = ST_ACCEPTED;
+            nd.attempt += 1;  // remaining_attempts -= 1; n_left is reset by the next create_split
+            again = true;
         }
-    } else {
-        nd.attempt += 1;  // remaining_attempts -= 1; n_left is reset by the next create_split
     }
+    // nodes left pending, counted once per wave (the gate of the next attempt's launches)
+    const unsigned long long m = __ballot(again);
+    if (pend_out && m && (threadIdx.x & 63u) == 0) atomicAdd(pend_out, (uint32_t)__popcll(m));
 }
 
 // randomly_split_children (src/writer.rs:1310-1326) with the policy coin, same mask layout.
@@ -892,7 +910,8 @@ __global__ __launch_bounds__(64) void k_forest_shadow_normals8(DataView dv, cons
                                                                const uint8_t *__restrict__ normals, uint64_t nstride,
                                                                uint64_t hdr_off, const float *__restrict__ dim_scale,
                                                                uint8_t *__restrict__ shadow8, uint64_t stride8,
-                                                               uint32_t pitch8) {
+                                                               uint32_t pitch8, const uint32_t *gate) {
+    if (gate_closed(gate)) return;
     for (uint32_t node = blockIdx.x; node < n_nodes; node += gridDim.x) {
         if (nodes[node].state != ST_PENDING) continue;
         const float *nv = reinterpret_cast<const float *>(normals + node * nstride);
@@ -1007,9 +1026,11 @@ __device__ __forceinline__ bool screen8_decides(float S, float s_row, const floa
 __global__ __launch_bounds__(64) void k_forest_shadow_normals(DataView dv, const FNode *__restrict__ nodes,
                                                               const uint8_t *__restrict__ normals, uint64_t nstride,
                                                               uint64_t hdr_off, uint8_t *__restrict__ shadow,
-                                                              uint64_t hstride, uint32_t hpitch) {
-    const uint32_t node = blockIdx.x;
-    if (nodes[node].state != ST_PENDING) return;
+                                                              uint64_t hstride, uint32_t hpitch, uint32_t n_nodes,
+                                                              const uint32_t *gate) {
+    if (gate_closed(gate)) return;
+    for (uint32_t node = blockIdx.x; node < n_nodes; node += gridDim.x) {
+    if (nodes[node].state != ST_PENDING) continue;
     const float *nv = reinterpret_cast<const float *>(normals + node * nstride);
     uint16_t *out = reinterpret_cast<uint16_t *>(shadow + node * hstride);
     float sa = 0.f, sb = 0.f, sc = 0.f;
@@ -1036,6 +1057,7 @@ __global__ __launch_bounds__(64) void k_forest_shadow_normals(DataView dv, const
         st.cn = sqrtf(sc) * up;
         st.extra = dv.metric == AH_COSINE ? 0.0f : nh[0];  // bias (Euclidean / Manhattan) or the normal's extra dimension
         *reinterpret_cast<NormalStats *>(shadow + node * hstride + (uint64_t)hpitch * 2) = st;
+    }
     }
 }
 
@@ -1096,6 +1118,7 @@ __global__ __launch_bounds__(kBlock) void k_forest_screen_node(DataView dv, Scre
     const uint32_t o = threadIdx.x >> 3, j = threadIdx.x & 7u;
     const uint32_t steps = sv.hpitch >> 6;
     uint32_t fallbacks = 0, bad = 0, met8 = 0, decided8 = 0, decided8b = 0;
+    if (gate_closed(abort_flag.gate)) return;  // a retry attempt with no node left pending
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         if (abort_requested(abort_flag)) return;
         const FTile tl = tiles[tile];
@@ -1515,10 +1538,11 @@ __global__ __launch_bounds__(256) void k_next_count(const FNode *__restrict__ no
 // exclusive scan of the block sums in place (one block; n_blocks <= a few thousand) + the level totals
 __global__ __launch_bounds__(1024) void k_next_scan(NextCounts *__restrict__ block_sums, uint32_t n_blocks,
                                                     LevelInfo *__restrict__ info, uint32_t *__restrict__ tree_first,
-                                                    uint32_t n_trees) {
+                                                    uint32_t n_trees, uint32_t *__restrict__ pend) {
     __shared__ uint32_t s_k[16], s_t[16];
     __shared__ uint32_t s_carry_k, s_carry_t;
     if (threadIdx.x == 0) s_carry_k = s_carry_t = 0;
+    if (threadIdx.x < 3) pend[threadIdx.x] = 0;  // the level's attempts are over: the next level counts its own pending nodes
     for (uint32_t t = threadIdx.x; t <= n_trees; t += blockDim.x) tree_first[t] = 0xFFFFFFFFu;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -2629,6 +2653,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     const uint32_t g_dense_max_cols = (uint32_t)std::max<long long>(0, tun(TUN_DENSE_MAX_COLS));
     const double g_dense_gmacs = (double)std::max<long long>(1, tun(TUN_DENSE_GMACS));
     const int timing = (int)tun(TUN_TIMING);
+    const bool g_retry_gate = tun(TUN_RETRY_GATE) != 0;
     // AH_MARGIN_MODE (measurement aid): the kernel family for callers that leave the choice to the library
     const uint32_t env_mode = (uint32_t)tun(TUN_MARGIN_MODE) & 0xFFFu;
     const uint32_t mode_req = (opt->margin_mode & 0xFFFu) ? (opt->margin_mode & 0xFFFu) : env_mode;
@@ -2658,7 +2683,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     // small device block: [abort flag, 3 pad][ScreenCounters][LevelInfo + tree_first[n_trees + 1]]
     const size_t info_words = (sizeof(LevelInfo) + ((size_t)n_trees + 1) * 4 + 3) / 4;
     AH_TRY(d_small.ensure(4 + 12 + info_words));
-    const AbortFlags d_abort{d_small.p};
+    const AbortFlags d_abort{d_small.p, nullptr};
     ScreenCounters *d_counters = reinterpret_cast<ScreenCounters *>(d_small.p + 4);
     LevelInfo *d_info = reinterpret_cast<LevelInfo *>(d_small.p + 16);
     uint32_t *d_tree_first = reinterpret_cast<uint32_t *>(d_info + 1);
@@ -3491,19 +3516,22 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             touch_normals[(step + 1) & 1].start(forest->normals_blob, next_begin, (size_t)next_len);
         }
         for (int attempt = 0; attempt < 4; attempt++) {
+            // (attempts 1-3: gated by the number of nodes the attempt before left pending, d_small[attempt])
+            const uint32_t *gate = attempt && g_retry_gate ? d_small.p + attempt : nullptr;
+            const AbortFlags abort_a{d_small.p, gate};
 #define AH_SPLIT_LAUNCH(K)                                                                                             \
     hipLaunchKernelGGL(K, dim3(std::min<uint32_t>(n_nodes, g_split_blocks)), dim3(64), cs_shared, s, dv, d_cur, n_nodes, cur, N, \
-                       chunk_d, nstride, hdr_off)
+                       chunk_d, nstride, hdr_off, gate)
             AH_SPLIT_KERNEL(AH_SPLIT_LAUNCH)
 #undef AH_SPLIT_LAUNCH
             AH_DBG(s, "create_split");
             if (screen)
-                hipLaunchKernelGGL(k_forest_shadow_normals, dim3(n_nodes), dim3(64), 0, s, dv, d_cur, chunk_d, nstride, hdr_off,
-                                   shadow_d, hstride, sv.hpitch);
+                hipLaunchKernelGGL(k_forest_shadow_normals, dim3(std::min<uint32_t>(n_nodes, attempt ? 65536u : 1u << 20)), dim3(64), 0, s,
+                                   dv, d_cur, chunk_d, nstride, hdr_off, shadow_d, hstride, sv.hpitch, n_nodes, gate);
             // the int8 records are only read by the node-major screen: the first attempt of a row-order level skips them
             if (screen8 && !(attempt == 0 && row_tc >= 2))
                 hipLaunchKernelGGL(k_forest_shadow_normals8, dim3(std::min<uint32_t>(n_nodes, 65536u)), dim3(64), 0, s, dv, d_cur,
-                                   n_nodes, chunk_d, nstride, hdr_off, ds->d_dim_scale, shadow8_d, stride8, sv.pitch8);
+                                   n_nodes, chunk_d, nstride, hdr_off, ds->d_dim_scale, shadow8_d, stride8, sv.pitch8, gate);
             AH_HIP(hipEventRecord(bc.ev_attempt[2 * attempt], s));
             if (attempt == 0 && row_tc >= 2) {
                 // one pass over the rows serves up to row_tc trees (see k_forest_margin_rows)
@@ -3723,7 +3751,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                 if (screen) forest->stats.screened_launches += passes;
             } else if (bq) {
                 hipLaunchKernelGGL(k_forest_margin_bq, dim3(node_grid), dim3(kBlock), dv.pitch * 8, s, dv, d_cur, d_tiles.p,
-                                   n_tiles, cur, N, chunk_d, nstride, hdr_off, masks.p, tile_left.p, d_abort);
+                                   n_tiles, cur, N, chunk_d, nstride, hdr_off, masks.p, tile_left.p, abort_a);
                 forest->stats.margin_mode_launches[MM_BQ]++;
             } else if (screen) {
                 const size_t sh = (size_t)dv.pitch * 4 + (size_t)sv.hpitch * 2 + (screen8 ? 2 * (size_t)sv.pitch8 : 0);
@@ -3736,7 +3764,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                             \
         hipLaunchKernelGGL((k_forest_screen_node<M, PRE>), dim3(node_grid), dim3(kBlock), sh, s, dv, sv, d_cur, d_tiles.p, \
                            n_tiles, cur, chunk_d, nstride, hdr_off, shadow_d, hstride, shadow8_d, stride8, masks.p,       \
-                           tile_left.p, d_abort, d_counters, verify);                                                     \
+                           tile_left.p, abort_a, d_counters, verify);                                                     \
     } while (0)
 #define AH_LAUNCH(M)                          \
     do {                                      \
@@ -3761,7 +3789,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             AH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_forest_margin_f32<M>),                      \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                       \
         hipLaunchKernelGGL((k_forest_margin_f32<M>), dim3(node_grid), dim3(kBlock), sh, s, dv, d_cur, d_tiles.p,    \
-                           n_tiles, cur, N, chunk_d, nstride, hdr_off, masks.p, tile_left.p, d_abort);              \
+                           n_tiles, cur, N, chunk_d, nstride, hdr_off, masks.p, tile_left.p, abort_a);              \
     } while (0)
                 switch (ds->metric) {
                 case AH_EUCLIDEAN: AH_LAUNCH(AH_EUCLIDEAN); break;
@@ -3774,7 +3802,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             }
             AH_HIP(hipEventRecord(bc.ev_attempt[2 * attempt + 1], s));
             AH_DBG(s, "margin");
-            hipLaunchKernelGGL(k_forest_decide, dim3((n_nodes + 255) / 256), dim3(256), 0, s, d_cur, n_nodes);
+            hipLaunchKernelGGL(k_forest_decide, dim3((n_nodes + 255) / 256), dim3(256), 0, s, d_cur, n_nodes,
+                               attempt < 3 ? d_small.p + attempt + 1 : nullptr, gate);
             AH_DBG(s, "decide");
         }
         hipLaunchKernelGGL(k_forest_random_sides, dim3(std::min<uint32_t>(n_tiles, kMaxBlocks)), dim3(64), 0, s, d_cur,
@@ -3793,7 +3822,8 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
         if (grouped && step >= 1) AH_HIP(hipStreamWaitEvent(s, bc.ev_copy[step & 1], 0));
         const uint32_t n_blocks = (n_nodes + 255) / 256;
         hipLaunchKernelGGL(k_next_count, dim3(n_blocks), dim3(256), 0, s, d_cur, n_nodes, split_after, d_block_sums.p);
-        hipLaunchKernelGGL(k_next_scan, dim3(1), dim3(1024), 0, s, d_block_sums.p, n_blocks, d_info, d_tree_first, n_trees);
+        hipLaunchKernelGGL(k_next_scan, dim3(1), dim3(1024), 0, s, d_block_sums.p, n_blocks, d_info, d_tree_first, n_trees,
+                           d_small.p + 1);
         hipLaunchKernelGGL(k_next_emit, dim3(n_blocks), dim3(256), 0, s, d_cur, n_nodes, split_after, d_block_sums.p, d_next,
                            d_child.p, d_info, d_tree_first);
         AH_DBG(s, "next_level");
