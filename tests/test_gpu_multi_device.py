@@ -65,6 +65,11 @@ def test_concurrent_builds_in_one_process_equal_the_sequential_forest():
     got = build_sharded(replicas, seeds, max_host_threads=2)
     assert got == want
     assert current_device() == before
+    # the same with every build's tail in groups of trees (each shard has 2-3 trees): the pooled node records, the ring of node
+    # tables and the groups' hand-overs of four builds at once
+    with _lib.tuning(AH_BUILD_TAIL_GROUPS=2, AH_BUILD_TAIL_MIN_MB=0, AH_ROWMAJOR=0):
+        for _rep in range(3):
+            assert build_sharded(replicas, seeds, max_host_threads=2) == want
     for r in replicas[1:]:
         r.close()
     ds.close()
