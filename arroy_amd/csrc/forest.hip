@@ -3866,7 +3866,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
                     attempt_ms[1] + attempt_ms[2] + attempt_ms[3], info.pairs ? attempt_ms[0] * 1e6 / (double)info.pairs : 0.0);
         if (timing >= 3) {
             auto ms_of = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            fprintf(stderr, "[ah]          host: after the previous wait %.2f ms, launch %.2f ms, digest of the level before %.2f ms, wait %.2f ms\n",
+            fprintf(stderr, "[ah]          host: after the previous wait %.2f ms, launch %.2f ms, under the level (ids handed over, tables digested, node lists) %.2f ms, wait %.2f ms\n",
                     ms_tail_prev, ms_of(t_level_top, t_launched), ms_of(t_launched, t_digested), ms_of(t_digested, t_waited));
         }
         forest->stats.margin_launches += 4;
