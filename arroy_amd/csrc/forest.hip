@@ -2844,7 +2844,11 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     // (room for every node of a balanced forest — leaves of split_after / 2 .. split_after items, as many split nodes — so that
     // the vector never moves: at 10M x 100 trees the 1.7 M + 1.7 M records outgrew the former 4 / 3 x max_nodes at the last big
     // level, and copying 136 MB of records held the launching thread for 38 ms with the device idle; untouched pages cost nothing)
-    recs.reserve(4 * max_nodes + n_trees + 16);
+    try {
+        recs.reserve(4 * max_nodes + n_trees + 16);
+    } catch (const std::bad_alloc &) {  // (a tiny split_after on a huge dataset: grow as needed, as before)
+        recs.reserve(4 * max_nodes / 3 + 16);
+    }
     size_t n_recs = 0;  // records in use; the vector itself is grown AHEAD of the digest (value-initialising 80 MB of fresh
                         // pages on the thread that digests the deepest level was most of that digest's 35 ms)
     LevelInfo info{};
