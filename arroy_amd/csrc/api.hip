@@ -10,6 +10,13 @@
 #include <immintrin.h>
 #include <new>
 #include <thread>
+#include <cctype>
+#include <cstdio>
+#include <mutex>
+#include <vector>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "common.h"
 
@@ -98,6 +105,93 @@ int Context::ensure_device(size_t bytes) {
     d_cap = cap;
     return AH_OK;
 }
+// ---- NUMA placement --------------------------------------------------------------------------------------------------
+// A two-socket host reaches the GPU through one of its sockets.  The 9.4 GB a 10M x 100-tree build hands back travel device ->
+// pinned bounce buffer -> the forest's blobs on a few copy threads; with the blobs first-touched on the far socket (whichever
+// cores the page-commit threads happened to get, or a recycled blob another build committed) those copies cross the socket
+// link: a build whose blobs were first touched from the far socket ran 1.273-1.285 s with 17 ms after its last launch, the same
+// build with them on the device's node 1.265-1.272 s with 13 ms, whichever socket the caller ran on (scripts/exp_numa.py,
+// profiles/r06_experiments.txt).  So the blobs prefer the device's node, and the threads that fill them run there.
+namespace {
+int read_int_file(const char *path, int fallback) {
+    FILE *f = fopen(path, "r");
+    if (!f) return fallback;
+    int v = fallback;
+    if (fscanf(f, "%d", &v) != 1) v = fallback;
+    fclose(f);
+    return v;
+}
+bool parse_cpulist(const char *path, cpu_set_t *out) {  // "0-63,128-191"
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    CPU_ZERO(out);
+    int a = 0, b = 0;
+    bool any = false;
+    while (fscanf(f, "%d", &a) == 1) {
+        b = a;
+        int c = fgetc(f);
+        if (c == '-') {
+            if (fscanf(f, "%d", &b) != 1) break;
+            c = fgetc(f);
+        }
+        for (int i = a; i <= b && i < CPU_SETSIZE; i++) {
+            CPU_SET(i, out);
+            any = true;
+        }
+        if (c != ',') break;
+    }
+    fclose(f);
+    return any;
+}
+std::mutex g_numa_mu;
+std::vector<std::pair<int, int>> g_numa_of_device;  // (device, node)
+}  // namespace
+int numa_node_of_device(int device) {
+    if (tun(TUN_NUMA) == 0) return -1;
+    {
+        std::lock_guard<std::mutex> lk(g_numa_mu);
+        for (const auto &e : g_numa_of_device)
+            if (e.first == device) return e.second;
+    }
+    int node = -1;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus - 1, device) == hipSuccess && bus[0]) {
+        for (char *c = bus; *c; c++) *c = (char)tolower((unsigned char)*c);
+        char path[160];
+        snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+        node = read_int_file(path, -1);
+    } else {
+        (void)hipGetLastError();
+    }
+    if (node >= 0) {  // (one node online: nothing to place)
+        FILE *f = fopen("/sys/devices/system/node/node1/cpulist", "r");
+        if (!f) node = -1;
+        else fclose(f);
+    }
+    std::lock_guard<std::mutex> lk(g_numa_mu);
+    g_numa_of_device.push_back({device, node});
+    return node;
+}
+bool numa_bind_thread_to_node(int node) {
+    if (node < 0) return false;
+    char path[96];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    cpu_set_t of_node, allowed, both;
+    if (!parse_cpulist(path, &of_node)) return false;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+    CPU_AND(&both, &of_node, &allowed);
+    // (a container with few or none of its CPUs on that node: leave the thread where it may run — eight copy threads squeezed onto
+    // two cores would cost more than the socket link)
+    if (CPU_COUNT(&both) < 8) return false;
+    return sched_setaffinity(0, sizeof both, &both) == 0;
+}
+void numa_prefer_node(void *p, size_t bytes, int node) {
+    if (node < 0 || node >= 1024 || !p || !bytes) return;
+    unsigned long mask[16] = {0};
+    mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+    (void)syscall(SYS_mbind, p, bytes, 1 /* MPOL_PREFERRED */, mask, (unsigned long)(8 * sizeof mask), 0u);
+}
+
 // One pinned block obtained ahead of time (ah_dataset_reserve_build's helper thread, while the records are staged): pinning the
 // ~0.4 GB a 10M x 100-tree build wants for its node tables and read-back buffer takes the driver ~120 ms, which a cold first
 // build used to spend between its entry and its first launch.  The next context of that device that has to grow takes it.

@@ -133,6 +133,7 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(MARGIN_MODE, "AH_MARGIN_MODE", 0)         /* ah_margin_mode for callers that pass AH_MARGIN_AUTO */                 \
     X(READBACK_DIRECT, "AH_READBACK_DIRECT", 0) /* 1: let the runtime stage the device -> pageable copies */             \
     X(READBACK_MB, "AH_READBACK_MB", 256)       /* pinned double buffer of a build's read-back worker, MiB (both halves) */ \
+    X(NUMA, "AH_NUMA", 1)                       /* 0: no NUMA placement: a build's host blobs are first-touched and its read-back / page-commit threads run wherever the scheduler puts them (until round 6) */ \
     X(RETRY_GATE, "AH_RETRY_GATE", 1)           /* 0: the retry attempts of a level run over every node and tile even when the attempt before left none pending (rounds 1-6a) */ \
     X(TAIL_GROUPS, "AH_BUILD_TAIL_GROUPS", 5)   /* the last big level of a build and what follows it run tree group by tree group, each group's item ids and normals travelling under the next group's kernels (0 / 1: all trees level by level to the end) */ \
     X(TAIL_MIN_MB, "AH_BUILD_TAIL_MIN_MB", 64)  /* ... when the ids still under splitting nodes are at least this many MiB */ \
@@ -227,6 +228,11 @@ inline hipError_t dev_malloc(T **p, size_t bytes, bool optional = false) {
 void dataset_born(int device);
 void dataset_gone(int device);
 size_t host_cache_trim();                    // forest.hip: the pool of destroyed forests' blobs; returns the bytes released
+// NUMA placement of a build's output path (api.hip): the host node the device hangs off (-1: unknown, one node, AH_NUMA=0), the
+// calling thread onto that node's CPUs (those of them the process may use; false: left alone), a mapping's pages preferred there
+int numa_node_of_device(int device);
+bool numa_bind_thread_to_node(int node);
+void numa_prefer_node(void *p, size_t bytes, int node);
 void pinned_spare_fill(int device, size_t bytes);  // api.hip: a pinned block obtained ahead of the context that will want it
 size_t pinned_spare_trim();                  // ... given back if nobody took it; returns its bytes
 size_t dev_cache_live_bytes(int device);     // bytes handed out and not yet freed (ah_device_cache_stats)

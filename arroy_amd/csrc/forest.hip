@@ -23,6 +23,8 @@
 #include <cstdlib>
 #include <immintrin.h>
 #include <sys/mman.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <new>
 
 #include "common.h"
@@ -1720,7 +1722,11 @@ struct HostBlob {
     bool recycled = false; // came out of the pool (HostBlobPool::take), not from a fresh mapping
     void *map = nullptr;   // the mapping p lives in (nullptr: malloc'd — small blobs)
     size_t map_len = 0;
+    int node = -1;         // host NUMA node its pages prefer (-1: none asked for)
 };
+// the host node of the device whose build is running on this thread (build_batch sets it): what fresh blobs prefer, and what
+// the pool matches recycled blobs against
+static thread_local int tl_blob_node = -1;
 class HostBlobPool {
     std::mutex mu;
     std::vector<HostBlob> idle;
@@ -1741,9 +1747,14 @@ class HostBlobPool {
             size_t best = idle.size();
             // the smallest blob that fits, and never one more than twice the size asked for: a 20 MB request must not walk off
             // with the 5 GB blob the next big build is counting on
-            for (size_t i = 0; i < idle.size(); i++)
-                if (idle[i].cap >= bytes && idle[i].cap <= 2 * bytes + kHuge && (best == idle.size() || idle[i].cap < idle[best].cap))
-                    best = i;
+            // ... of those on the asking device's host node first (a blob committed on the far socket halves the rate its copy
+            // threads reach), then of the others
+            for (int pass = 0; pass < 2 && best == idle.size(); pass++)
+                for (size_t i = 0; i < idle.size(); i++) {
+                    if (pass == 0 && tl_blob_node >= 0 && idle[i].node != tl_blob_node) continue;
+                    if (idle[i].cap >= bytes && idle[i].cap <= 2 * bytes + kHuge && (best == idle.size() || idle[i].cap < idle[best].cap))
+                        best = i;
+                }
             if (best != idle.size()) {
                 *out = idle[best];
                 out->recycled = true;
@@ -1767,6 +1778,10 @@ class HostBlobPool {
             b.p = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(m) + kHuge - 1) & ~(uintptr_t)(kHuge - 1));
             b.cap = cap;
             (void)madvise(b.p, cap, MADV_HUGEPAGE);  // a hint: 4 KiB pages where it is refused
+            // the pages prefer the host node of the device whose build asks (api.hip "NUMA placement"; tl_blob_node < 0: wherever
+            // they are first touched)
+            numa_prefer_node(b.p, cap, tl_blob_node);
+            b.node = tl_blob_node;
         }
         *out = b;
         return true;
@@ -2232,6 +2247,7 @@ struct Readback {
     bool stop = false, started = false, inline_mode = false;
     hipError_t err = hipSuccess;
     int device = 0;
+    int numa_node = -1;      // host node of the device: the worker and its copy threads run there (api.hip "NUMA placement")
     uint8_t *pin = nullptr;  // 2 x half bytes of pinned memory (owned by the build's Context)
     size_t half = 0;
 
@@ -2371,6 +2387,7 @@ struct Readback {
     void run() {
         hipStream_t cs = nullptr;
         hipEvent_t ev[2] = {nullptr, nullptr};
+        (void)numa_bind_thread_to_node(numa_node);  // (threads this one starts — the copies' spread — inherit its CPUs)
         hipError_t e = hipSetDevice(device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
@@ -2786,6 +2803,12 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     // allocated up front and its pages are touched in the background while the GPU works (first-touch faults of
     // fresh memory, not the copy, bound a read-back of several GB).
     const uint64_t desc_base = forest->descendants_len;
+    const int numa_node = numa_node_of_device(ds->device);
+    struct BlobNodeScope {  // the blobs this thread asks the pool for prefer the device's host node
+        int prev;
+        explicit BlobNodeScope(int n) : prev(tl_blob_node) { tl_blob_node = n; }
+        ~BlobNodeScope() { tl_blob_node = prev; }
+    } blob_node_scope(numa_node);
     if (!sb) {  // (a streaming build hands the ids to the sink from the pinned ring: no blob)
         AH_REQUIRE(host_blob_reserve(forest->desc_blob, (desc_base + M) * 4, desc_base * 4), AH_ERR_OUT_OF_MEMORY,
                    "host allocation of the descendants failed");
@@ -2794,6 +2817,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     struct Toucher {  // commits the pages of a fresh (still unwritten) host range in the background
         std::thread th;
         unsigned max_threads = 8;
+        int numa_node = -1;  // the pages are committed from the CPUs of the device's host node: first touch decides where they live
         // [off, off + bytes) of `blob`; what a recycled blob already has committed needs no touch
         void start(const HostBlob &blob, size_t off, size_t bytes) {
             join();
@@ -2802,8 +2826,10 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
             uint8_t *lo = blob.p + lo_off;
             const size_t len = hi_off - lo_off;
             const unsigned budget = max_threads;
+            const int node = numa_node;
             try {
-                th = std::thread([lo, len, budget] {
+                th = std::thread([lo, len, budget, node] {
+                    (void)numa_bind_thread_to_node(node);
                     // (several threads: the 2.6 GB of the deepest level's normals must be committed within that level's
                     // ~140 ms, or the level loop waits for page faults before it can hand the chunk to the read-back worker)
                     const unsigned parts = (unsigned)std::min<size_t>(budget, std::max<size_t>(1, len >> 26));
@@ -2822,6 +2848,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     } prefault, touch_normals[2];  // [level & 1]: commits the level's normals, started one level ahead
     const unsigned host_threads = host_thread_budget(opt);
     prefault.max_threads = touch_normals[0].max_threads = touch_normals[1].max_threads = host_threads;
+    prefault.numa_node = touch_normals[0].numa_node = touch_normals[1].numa_node = numa_node;
     if (!sb) prefault.start(forest->desc_blob, desc_base * 4, M * 4);
     Arena arena, shadow_arena, shadow8_arena;  // declared before the read-back worker: it is joined before the chunks it reads are freed
     arena.block_bytes = std::max<uint64_t>(32ull << 20, std::min<uint64_t>(2 * max_nodes * nstride, 16ull << 30));
@@ -2832,6 +2859,7 @@ static int build_batch(ah_dataset *ds, const ah_build_options *opt, uint32_t fir
     Readback rb;
     rb.target = sb ? &sb->target : nullptr;
     rb.copy_threads = host_threads;
+    rb.numa_node = numa_node;
     rb.start(ds->device, pin + pin_head + 2 * pin_nodes, kBounce);
 
     // ---- level 0 on the host: the roots -----------------------------------------------------------------------------
