@@ -105,6 +105,14 @@ int Context::ensure_device(size_t bytes) {
     d_cap = cap;
     return AH_OK;
 }
+hipError_t create_copy_stream(hipStream_t *out) {
+    int least = 0, greatest = 0;
+    if (tun(TUN_READBACK_PRIORITY) != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)
+        return hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest);
+    (void)hipGetLastError();
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
 // ---- NUMA placement --------------------------------------------------------------------------------------------------
 // A two-socket host reaches the GPU through one of its sockets.  The 9.4 GB a 10M x 100-tree build hands back travel device ->
 // pinned bounce buffer -> the forest's blobs on a few copy threads; with the blobs first-touched on the far socket (whichever
@@ -1853,7 +1861,7 @@ static int rerank_batch_chunk(ah_dataset *ds, Context *ctx, const float *queries
     // cores (like the staging gather) and sent right away, so the DMA of one slice overlaps the host copy of the next.
     const uint64_t n_groups = (uint64_t)std::max<long long>(1, tun(TUN_RERANK_GROUPS));
     const bool pipelined = screened && n_groups > 1 && total >= (512u << 10);
-    if (pipelined && !ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (pipelined && !ctx->copy_stream && create_copy_stream(&ctx->copy_stream) != hipSuccess) {
         (void)hipGetLastError();
         ctx->copy_stream = nullptr;
     }

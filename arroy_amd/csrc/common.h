@@ -132,6 +132,7 @@ inline int guarded(const char *what, F &&f) noexcept {
     X(DENSE_GMACS, "AH_DENSE_GMACS", 495000)    /* sustained multiply-add rate the cost model assumes, 1e9 MAC/s */       \
     X(MARGIN_MODE, "AH_MARGIN_MODE", 0)         /* ah_margin_mode for callers that pass AH_MARGIN_AUTO */                 \
     X(READBACK_DIRECT, "AH_READBACK_DIRECT", 0) /* 1: let the runtime stage the device -> pageable copies */             \
+    X(READBACK_PRIORITY, "AH_READBACK_PRIORITY", 1) /* 0: the read-back worker's copy stream has the default priority (it may then share a hardware queue with the build's compute stream once more than four streams are alive) */ \
     X(READBACK_MB, "AH_READBACK_MB", 256)       /* pinned double buffer of a build's read-back worker, MiB (both halves) */ \
     X(NUMA, "AH_NUMA", 1)                       /* 0: no NUMA placement: a build's host blobs are first-touched and its read-back / page-commit threads run wherever the scheduler puts them (until round 6) */ \
     X(RETRY_GATE, "AH_RETRY_GATE", 1)           /* 0: the retry attempts of a level run over every node and tile even when the attempt before left none pending (rounds 1-6a) */ \
@@ -230,6 +231,10 @@ void dataset_gone(int device);
 size_t host_cache_trim();                    // forest.hip: the pool of destroyed forests' blobs; returns the bytes released
 // NUMA placement of a build's output path (api.hip): the host node the device hangs off (-1: unknown, one node, AH_NUMA=0), the
 // calling thread onto that node's CPUs (those of them the process may use; false: left alone), a mapping's pages preferred there
+// A stream for copies that must run UNDER the kernels of another stream (read-back, pipelined uploads, the build's side stream):
+// created with the highest priority, because the runtime multiplexes the streams of one priority onto four hardware queues and a
+// copy stream that lands on the compute stream's queue waits for every kernel in front of it (AH_READBACK_PRIORITY=0: default).
+hipError_t create_copy_stream(hipStream_t *out);
 int numa_node_of_device(int device);
 bool numa_bind_thread_to_node(int node);
 void numa_prefer_node(void *p, size_t bytes, int node);

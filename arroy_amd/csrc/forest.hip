@@ -1977,7 +1977,7 @@ struct BatchCleanup {  // events / side stream of one batch
         AH_HIP(hipEventCreateWithFlags(&ev_level, hipEventDisableTiming));
         AH_HIP(hipEventCreateWithFlags(&ev_copy[0], hipEventDisableTiming));
         AH_HIP(hipEventCreateWithFlags(&ev_copy[1], hipEventDisableTiming));
-        AH_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        AH_HIP(create_copy_stream(&side));  // (node tables, the abort word, a group's rows -> ids: under the level's kernels)
         return AH_OK;
     }
     ~BatchCleanup() {
@@ -2389,7 +2389,13 @@ struct Readback {
         hipEvent_t ev[2] = {nullptr, nullptr};
         (void)numa_bind_thread_to_node(numa_node);  // (threads this one starts — the copies' spread — inherit its CPUs)
         hipError_t e = hipSetDevice(device);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+        // A stream of its own PRIORITY: the runtime multiplexes a process's streams onto a few hardware queues per priority
+        // (four by default), and once more than four streams are alive — a second dataset with its context is enough — this
+        // stream could land on the queue of the build's compute stream: every chunk of the read-back then waited for the
+        // level's kernel in front of it, and the ids of a group of trees arrived 0.1 s late (10M x 100 trees: 1.43 instead of
+        // 1.31 s for every build of the second dataset; scripts/exp_second_dataset.py).  High-priority streams have queues
+        // of their own.
+        if (e == hipSuccess) e = create_copy_stream(&cs);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
         for (;;) {
@@ -2437,7 +2443,7 @@ struct Readback {
         if (inline_mode) {
             hipStream_t cs = nullptr;
             hipEvent_t ev[2] = {nullptr, nullptr};
-            hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+            hipError_t e = create_copy_stream(&cs);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
             if (e == hipSuccess) e = deliver(*job, reinterpret_cast<const uint8_t *>(src), cs, ev);
