@@ -41,6 +41,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues per priority (its own switch, default 4);
+# the four-caller legs bring a stream per caller next to the datasets' own, and two callers on one queue take turns: 8 queues give
+# `rerank.callers_4` 190-203 -> 221-223 k and `search.callers_4` 552 -> 598-608 k queries/s, every one-caller figure unchanged
+# (profiles/r06_experiments.txt).  Set before anything touches the device, reported in the line (`env`); a caller's own value wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 N_ITEMS = 1_000_000
 ORACLE_TREES = (0, 99)  # trees of the 10M x 768 x 100 build the oracle also builds, whole, on the host cores (build_10m.oracle_tree)
@@ -1582,6 +1587,8 @@ def main():
             "cpu_baseline": dict(result["cpu"], build_10m=result.get("cpu_10m")) if result.get("cpu") else None,
             "build": result.get("build"),
             "build_10m": result.get("build_10m"),
+            # runtime switches this process ran under (GPU_MAX_HW_QUEUES: set at the top of this file unless the caller set it)
+            "env": {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY") if k in os.environ},
         }
         if args.virtual:
             line["config"]["virtual_devices"] = (f"{n_used} ranks / device threads, all on device 0: the N > 1 code path on one GPU — "
